@@ -1,0 +1,585 @@
+/*
+ * pss_oracle.c — CPU restatement of the PySpecSDR hot path.  TEST INFRASTRUCTURE ONLY (see pss_oracle.h).
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -mfma; contraction OFF because the reference's
+ * float64 IIR arithmetic is un-fused x86-64 baseline code, and every fused multiply-add that the
+ * reference does execute is written out explicitly with fmaf()).
+ *
+ * Parity status of each piece against tests/golden (pinned by tests/test_oracle_golden.py):
+ *   atan2f / cabsf / pairwise sums / discriminator ........ bit-exact float32
+ *   sosfilt / sosfiltfilt / AM chain ...................... bit-exact float64
+ *   65-tap FIR (OpenBLAS ddot / zdot accumulation order) ... bit-exact float64 -> NFM audio bit-exact float64
+ *   SSB ................................................... real FIR bit-exact; the reference's hilbert() FFT
+ *                                                           round trip adds ~1e-16 noise (atol 1e-14), int16 exact
+ *   spectrum dB, power dB, scanner dB ..................... tolerance (rtol 1e-9 f64 / few ulp f32)
+ */
+#include "pss_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* ------------------------------------------------------------------------------------------------
+ * VRCP14PS model.  The instruction's result depends only on the top 16 mantissa bits of the input
+ * (exhaustively verified over all 2^23 mantissas on an AVX-512 Xeon, tools/derive_rcp14.c):
+ *   v17 = (A[m>>17] - B[m>>17] * ((m>>7) & 1023)) >> 9      (17-bit significand, value v17 / 2^17)
+ *   result = v17 * 2^-17 * 2^-(e)   for x = (1 + m/2^23) * 2^e,   and exactly 2^-e when m == 0.
+ * ---------------------------------------------------------------------------------------------- */
+static const uint32_t RCP14_A[64] = {
+    67107072u, 66074112u, 65073664u, 64102400u, 63159040u, 62244608u, 61354752u, 60491264u,
+    59650560u, 58833920u, 58038272u, 57264640u, 56511488u, 55778048u, 55062784u, 54365184u,
+    53686016u, 53022976u, 52377088u, 51745536u, 51129600u, 50528000u, 49940992u, 49366272u,
+    48805376u, 48257024u, 47721728u, 47196672u, 46683904u, 46181632u, 45690368u, 45209344u,
+    44739072u, 44277504u, 43826176u, 43382784u, 42949120u, 42523904u, 42106880u, 41698048u,
+    41297920u, 40903936u, 40517888u, 40139520u, 39768320u, 39402752u, 39044608u, 38692864u,
+    38347520u, 38008064u, 37674496u, 37347840u, 37025280u, 36708608u, 36398080u, 36091648u,
+    35791360u, 35495680u, 35204352u, 34919168u, 34638080u, 34361088u, 34088192u, 33819392u};
+static const uint16_t RCP14_B[64] = {
+    1009, 977, 949, 921, 893, 869, 843, 821, 797, 777, 755, 735, 717, 699, 681, 663,
+    647, 631, 617, 601, 587, 573, 561, 547, 535, 523, 513, 501, 491, 479, 469, 459,
+    451, 441, 433, 423, 415, 407, 399, 391, 385, 377, 369, 363, 357, 349, 343, 337,
+    331, 325, 319, 315, 309, 303, 299, 293, 289, 285, 279, 275, 271, 267, 263, 259};
+
+float pss_o_rcp14f(float x)
+{
+    /* valid for normal x with a normal result (the only use: SVML atan2f main path, 2^-125 <= x < 2^123) */
+    uint32_t u = f2u(x), sign = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    if (m == 0) return u2f(sign | ((254u - e) << 23));
+    uint32_t idx = m >> 17, low = (m >> 7) & 1023u;
+    uint32_t v = (RCP14_A[idx] - (uint32_t)RCP14_B[idx] * low) >> 9; /* in [2^16, 2^17) */
+    return u2f(sign | ((253u - e) << 23) | ((v & 0xffffu) << 7));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * numpy.arctan2 for float32 under the AVX512_SKX dispatch = Intel SVML __svml_atan2f16 ("la" variant,
+ * shipped in NumPy's bundled numpy/SVML sources).  Called by np.angle at signal_processing.py:94.
+ * Main path (both |x| and |y| in [2^-125, 2^123)): reciprocal by VRCP14 + one Newton step, quotient
+ * with one correction, degree-8-in-q^2 polynomial split into two interleaved Horner chains, all in
+ * float32 FMA.  Constants are the routine's __svml_satan2_data_internal table.
+ * ---------------------------------------------------------------------------------------------- */
+float pss_o_atan2f(float y, float x)
+{
+    const float PIO2 = 0x1.921fb6p+0f, PI = 0x1.921fb6p+1f;
+    uint32_t xb = f2u(x), yb = f2u(y);
+    uint32_t axb = xb & 0x7fffffffu, ayb = yb & 0x7fffffffu;
+    uint32_t sx = xb & 0x80000000u, sy = yb & 0x80000000u;
+    float ax = u2f(axb), ay = u2f(ayb);
+    int inx = (axb >= 0x01000000u) && (axb < 0x7d000000u);
+    int iny = (ayb >= 0x01000000u) && (ayb < 0x7d000000u);
+    if (!(inx && iny)) {
+        if (x != x || y != y) return x + y;
+        if (axb == 0 || ayb == 0) { /* the routine's vector fix-up for zero operands */
+            float v = (!(ay < ax) && !(axb == 0 && ayb == 0)) ? PIO2 : 0.0f;
+            v = u2f(f2u(v) | sx);
+            if (sx) v = v + PI;
+            return u2f(f2u(v) | sy);
+        }
+        /* inf / denormal / huge operands go to the routine's scalar "rare" helper, which works in
+         * double precision; restated as correctly rounded double atan2 (not bit-pinned). */
+        return (float)atan2((double)y, (double)x);
+    }
+    int k1 = ay < ax;
+    float a = k1 ? ay : -ax;
+    float b = k1 ? ax : ay;
+    float base = k1 ? 0.0f : PIO2;
+    float r0 = pss_o_rcp14f(b);
+    float e = fmaf(-b, r0, 1.0f);
+    float r1 = fmaf(r0, e, r0);
+    float q0 = a * r1;
+    float rem = fmaf(-b, q0, a);
+    float q = fmaf(rem, r1, q0);
+    float s = q * q;
+    float s2 = s * s;
+    float pa = fmaf(s2, 0x1.64598p-9f, 0x1.578708p-5f);
+    float pb = fmaf(s2, -0x1.fe4c62p-7f, -0x1.30ec52p-4f);
+    pa = fmaf(pa, s2, 0x1.b2c8e8p-4f);
+    pb = fmaf(pb, s2, -0x1.22c3fp-3f);
+    pa = fmaf(pa, s2, 0x1.996f3ep-3f);
+    pb = fmaf(pb, s2, -0x1.555492p-2f);
+    pa = fmaf(pa, s2, 1.0f);
+    float p = fmaf(pb, s, pa);
+    float r = fmaf(p, q, base);
+    r = u2f(f2u(r) | sx);
+    if (x <= 0.0f) r = r + PI;
+    return u2f(f2u(r) | sy);
+}
+
+/* numpy.abs(complex64), AVX512F loop: scaled hypot mx*sqrt(fma(r,r,1)), r = mn/mx.
+ * Used by signal_processing.py:182 (AM envelope) and :327 (power). */
+float pss_o_cabsf(float re, float im)
+{
+    float a = fabsf(re), b = fabsf(im);
+    float mx = a > b ? a : b, mn = a > b ? b : a;
+    if (mx == 0.0f) return 0.0f;
+    float r = mn / mx;
+    return mx * sqrtf(fmaf(r, r, 1.0f));
+}
+
+/* numpy add.reduce over contiguous float32: pairwise summation, block 128, 8 accumulators
+ * (numpy/_core/src/umath/loops_utils.h.src @TYPE@_pairwise_sum).  Feeds np.mean at
+ * signal_processing.py:185 and :327. */
+float pss_o_pairwise_sum_f32(const float *a, long n)
+{
+    if (n < 8) {
+        float res = 0.0f; /* numpy starts from -0.0? it starts at 0. and adds; identical for our data */
+        for (long i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        float r[8];
+        long i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        long n2 = n / 2;
+        n2 -= n2 % 8;
+        return pss_o_pairwise_sum_f32(a, n2) + pss_o_pairwise_sum_f32(a + n2, n - n2);
+    }
+}
+
+float pss_o_log10f_ref(float x) { return (float)log10((double)x); }
+
+/* ------------------------------------------------------------------------------------------------
+ * float64 FFT (iterative radix-2, table twiddles).  np.fft.fft is pocketfft; results agree to
+ * ~1e-15 relative, the spectrum is tolerance-checked (north star: 1e-4 relative on dB).
+ * ---------------------------------------------------------------------------------------------- */
+static void fft_f64(double *re, double *im, int n)
+{
+    int lg = 0;
+    while ((1 << lg) < n) lg++;
+    for (int i = 0; i < n; i++) { /* bit reversal */
+        int j = 0;
+        for (int b = 0; b < lg; b++) j |= ((i >> b) & 1) << (lg - 1 - b);
+        if (j > i) {
+            double t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+    }
+    double *wr = (double *)malloc(sizeof(double) * (n / 2 + 1));
+    double *wi = (double *)malloc(sizeof(double) * (n / 2 + 1));
+    for (int k = 0; k < n / 2; k++) {
+        double ang = -2.0 * M_PI * (double)k / (double)n;
+        wr[k] = cos(ang);
+        wi[k] = sin(ang);
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        int half = len >> 1, step = n / len;
+        for (int i = 0; i < n; i += len)
+            for (int k = 0; k < half; k++) {
+                double cr = wr[k * step], ci = wi[k * step];
+                double xr = re[i + k + half], xi = im[i + k + half];
+                double tr = xr * cr - xi * ci, ti = xr * ci + xi * cr;
+                re[i + k + half] = re[i + k] - tr;
+                im[i + k + half] = im[i + k] - ti;
+                re[i + k] += tr;
+                im[i + k] += ti;
+            }
+    }
+    free(wr);
+    free(wi);
+}
+
+/* compute_fft — signal_processing.py:243-264:
+ *   window = np.hamming(N) (:246); samples*window -> complex128 (:247); fftshift(fft()) (:250);
+ *   10*log10(abs(fft)**2 + 1e-10) (:262). */
+void pss_o_compute_fft(const float *iq, int n, double *db)
+{
+    double *re = (double *)malloc(sizeof(double) * n), *im = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) {
+        double w = (n == 1) ? 1.0 : 0.54 - 0.46 * cos(2.0 * M_PI * (double)i / (double)(n - 1));
+        re[i] = (double)iq[2 * i] * w;
+        im[i] = (double)iq[2 * i + 1] * w;
+    }
+    fft_f64(re, im, n);
+    for (int k = 0; k < n; k++) {
+        int src = (k + n / 2) % n; /* fftshift, even n */
+        double a = hypot(re[src], im[src]);
+        db[k] = 10.0 * log10(a * a + 1e-10);
+    }
+    free(re);
+    free(im);
+}
+
+static int cmp_double(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+/* pyspecsdr.py:2278-2283: np.convolve(freq_data, ones(5)/5, 'valid'); thr = median - 10; clamp below. */
+void pss_o_postprocess(const double *db, int n, double *out)
+{
+    int m = n - 4;
+    for (int i = 0; i < m; i++) {
+        double acc = 0.0;
+        for (int k = 0; k < 5; k++) acc += db[i + k] * 0.2;
+        out[i] = acc;
+    }
+    double *tmp = (double *)malloc(sizeof(double) * m);
+    memcpy(tmp, out, sizeof(double) * m);
+    qsort(tmp, m, sizeof(double), cmp_double);
+    double med = (m & 1) ? tmp[m / 2] : 0.5 * (tmp[m / 2 - 1] + tmp[m / 2]);
+    free(tmp);
+    double thr = med - 10.0;
+    for (int i = 0; i < m; i++)
+        if (out[i] < thr) out[i] = thr;
+}
+
+/* measure_signal_power — signal_processing.py:325-328, float32: mean(abs(x)**2) then 10*log10(p + 1e-10). */
+float pss_o_power_db(const float *iq, int n)
+{
+    float *s = (float *)malloc(sizeof(float) * (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        float m = pss_o_cabsf(iq[2 * i], iq[2 * i + 1]);
+        s[i] = m * m;
+    }
+    float p = pss_o_pairwise_sum_f32(s, n) / (float)n;
+    free(s);
+    float t = p + 1e-10f;
+    return 10.0f * pss_o_log10f_ref(t);
+}
+
+/* inline scanner — pyspecsdr.py:2542-2552.  NumPy >= 2 keeps complex64 through np.fft.fft, so the
+ * reference's dB row is float32; restated in float64 and rounded (tolerance-checked). */
+int pss_o_scan_slice(const float *iq, int n, double fs, float *db, float *peak, double *bw)
+{
+    double *re = (double *)malloc(sizeof(double) * n), *im = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) { re[i] = iq[2 * i]; im[i] = iq[2 * i + 1]; }
+    fft_f64(re, im, n);
+    float pk = -INFINITY;
+    for (int k = 0; k < n; k++) {
+        int src = (k + n / 2) % n;
+        float a = (float)hypot(re[src], im[src]);
+        float p = a * a + 1e-10f;
+        db[k] = 10.0f * pss_o_log10f_ref(p);
+        if (db[k] > pk) pk = db[k];
+    }
+    int count = 0;
+    float thr = pk - 20.0f;
+    for (int k = 0; k < n; k++) count += db[k] > thr;
+    *peak = pk;
+    *bw = (double)count * (fs / (double)n);
+    free(re);
+    free(im);
+    return count;
+}
+
+/* scipy _sosfilt (Cython, _sosfilt.pyx _sosfilt_float): DF2T cascade, un-fused float64.
+ * state z[nsec][2] is updated in place; x filtered in place. */
+static void sosfilt_inplace(const double *sos, int nsec, double *x, long n, double *z)
+{
+    for (long i = 0; i < n; i++) {
+        double xc = x[i];
+        for (int s = 0; s < nsec; s++) {
+            const double *c = sos + 6 * s;
+            double xn = (c[0] * xc) + z[2 * s];
+            z[2 * s] = ((c[1] * xc) - (c[4] * xn)) + z[2 * s + 1];
+            z[2 * s + 1] = (c[2] * xc) - (c[5] * xn);
+            xc = xn;
+        }
+        x[i] = xc;
+    }
+}
+
+/* 65-tap FIR with zero initial state: scipy.signal.lfilter(taps, 1.0, x) FIR branch
+ * = np.convolve(taps, x)[:len(x)] = multiarray.correlate(x, taps[::-1], 'full') whose inner product is
+ * DOUBLE_dot -> cblas_ddot, i.e. OpenBLAS kernel/x86_64/ddot.c + ddot_microk_skylakex-2.c on the
+ * AVX-512 host that produced the goldens.  Its accumulation order, restated (all multiply-adds fused):
+ *   n1 = n & -16 elements go through 4 accumulators of 8 lanes (32 per step), folded 8->4 lanes, then
+ *   4 accumulators of 4 lanes (16 per step); s = ((a0+a1)+a2)+a3 per lane; dot = (s0+s2)+(s1+s3);
+ *   the n - n1 tail elements are added one by one with fma.
+ * xw[j]*yw[j], j = 0..n-1.  Verified bit-exact on every output (edges included) of tests/golden/nfm.npz. */
+static double ddot_skx(const double *xw, const double *yw, int n)
+{
+    int n1 = n & -16, i = 0;
+    double dot = 0.0;
+    if (n1) {
+        double a5[4][8] = {{0}}, a[4][4];
+        int n32 = n1 & ~31;
+        for (; i < n32; i += 32)
+            for (int k = 0; k < 4; k++)
+                for (int l = 0; l < 8; l++) a5[k][l] = fma(xw[i + 8 * k + l], yw[i + 8 * k + l], a5[k][l]);
+        for (int k = 0; k < 4; k++)
+            for (int l = 0; l < 4; l++) a[k][l] = a5[k][l] + a5[k][l + 4];
+        for (; i < n1; i += 16)
+            for (int k = 0; k < 4; k++)
+                for (int l = 0; l < 4; l++) a[k][l] = fma(xw[i + 4 * k + l], yw[i + 4 * k + l], a[k][l]);
+        double s[4];
+        for (int l = 0; l < 4; l++) s[l] = ((a[0][l] + a[1][l]) + a[2][l]) + a[3][l];
+        dot = (s[0] + s[2]) + (s[1] + s[3]);
+    }
+    for (; i < n; i++) dot = fma(yw[i], xw[i], dot);
+    return dot;
+}
+
+/* Real part of the complex dot product behind lfilter(taps, 1.0, complex_samples) at
+ * signal_processing.py:204/:209: CDOUBLE_dot -> cblas_zdotu = OpenBLAS kernel/x86_64/zdot.c +
+ * zdot_microk_haswell-2.c (also used on SKYLAKEX).  The taps are real, so the imag*imag lane only ever
+ * accumulates +-0 and real = sum xr*tr in this order: n & -8 elements over 4 ymm accumulators holding
+ * 2 complex each (8 complex per step, fused), c_p = (a0+a1)+(a2+a3) per slot p, dot = c0 + c1, then the
+ * tail elements one by one with fma.  Verified bit-exact against scipy on tests/golden/am_ssb.npz inputs. */
+static double zdot_re_skx(const double *xw, const double *yw, int n)
+{
+    int n1 = n & -8, i = 0;
+    double dot = 0.0;
+    if (n1) {
+        double acc[4][2] = {{0}};
+        for (; i < n1; i += 8)
+            for (int a = 0; a < 4; a++)
+                for (int p = 0; p < 2; p++) acc[a][p] = fma(xw[i + 2 * a + p], yw[i + 2 * a + p], acc[a][p]);
+        double c0 = (acc[0][0] + acc[1][0]) + (acc[2][0] + acc[3][0]);
+        double c1 = (acc[0][1] + acc[1][1]) + (acc[2][1] + acc[3][1]);
+        dot = c0 + c1;
+    }
+    for (; i < n; i++) dot = fma(xw[i], yw[i], dot);
+    return dot;
+}
+
+static inline double fir65z_at(const double *taps, const double *taps_rev, const double *x, long i, long m)
+{
+    if (m <= 65) {
+        double xr[65];
+        for (long j = 0; j <= i; j++) xr[j] = x[i - j];
+        return zdot_re_skx(taps, xr, (int)i + 1);
+    }
+    if (i >= 64) return zdot_re_skx(x + i - 64, taps_rev, 65);
+    return zdot_re_skx(x, taps_rev + 64 - i, (int)i + 1);
+}
+
+/* taps_rev[j] = taps[64 - j].  np.convolve(taps, x) swaps its operands only when len(x) > 65, so for
+ * frames of <= 65 samples the dot runs over ascending TAP index (taps[j]*x[i-j]) instead of ascending
+ * sample index; m = len(x). */
+static inline double fir65_at(const double *taps, const double *taps_rev, const double *x, long i, long m)
+{
+    if (m <= 65) {
+        double xr[65];
+        for (long j = 0; j <= i; j++) xr[j] = x[i - j];
+        return ddot_skx(taps, xr, (int)i + 1);
+    }
+    if (i >= 64) return ddot_skx(x + i - 64, taps_rev, 65);
+    return ddot_skx(x, taps_rev + 64 - i, (int)i + 1);
+}
+
+int pss_o_demod_nfm(const float *iq, int n, double fs, int q, const double *taps, const double *sos,
+                    const double *zi, double *audio, float *disc_out, double *fir_out)
+{
+    const int NSEC = 4, EDGE = 27; /* sosfiltfilt: ntaps = 2*4+1 = 9, edge = 3*9 = 27 */
+    long M = (long)n - 1;
+    if (M <= EDGE) return -1; /* ValueError: length of the input vector must be greater than padlen */
+    /* :94  np.angle(samples[1:] * np.conj(samples[:-1]))  — complex64 multiply in FMA form, operand
+     *      order first = samples[1:], second = conj(samples[:-1]); NumPy temporary elision swaps the
+     *      operands once the conj temporary reaches 262144 bytes (N-1 >= 32768) — SURVEY App. A2.1. */
+    /* :97  demod * (fs/(2*pi)) — python float is weak -> float32 scalar */
+    float kscale = (float)(fs / (2.0 * M_PI));
+    double *u = (double *)malloc(sizeof(double) * M);
+    double *d64 = (double *)malloc(sizeof(double) * M);
+    int swapped = (M * 8 >= 262144);
+    for (long i = 0; i < M; i++) {
+        float aI = iq[2 * (i + 1)], aQ = iq[2 * (i + 1) + 1];
+        float c = iq[2 * i], d = -iq[2 * i + 1];
+        float re = fmaf(aI, c, -(aQ * d));
+        float im = swapped ? fmaf(aQ, c, aI * d) : fmaf(aI, d, aQ * c);
+        float th = pss_o_atan2f(im, re);
+        float dv = th * kscale;
+        if (disc_out) disc_out[i] = dv;
+        d64[i] = (double)dv;
+    }
+    /* :105-108 firwin + lfilter */
+    double tr[65];
+    for (int j = 0; j < 65; j++) tr[j] = taps[64 - j];
+    for (long i = 0; i < M; i++) u[i] = fir65_at(taps, tr, d64, i, M);
+    if (fir_out) memcpy(fir_out, u, sizeof(double) * M);
+    /* :111-112 decimate(filtered, q) -> sosfiltfilt(cheby1 sos) then [::q]  (scipy _signaltools.py:4831, :4718) */
+    long L = M + 2 * EDGE;
+    double *ext = (double *)malloc(sizeof(double) * L);
+    for (int i = 0; i < EDGE; i++) ext[i] = 2.0 * u[0] - u[EDGE - i];               /* odd_ext, _arraytools.py:57 */
+    memcpy(ext + EDGE, u, sizeof(double) * M);
+    for (int i = 0; i < EDGE; i++) ext[EDGE + M + i] = 2.0 * u[M - 1] - u[M - 2 - i];
+    double z[8];
+    for (int i = 0; i < 2 * NSEC; i++) z[i] = zi[i] * ext[0];
+    sosfilt_inplace(sos, NSEC, ext, L, z);
+    for (long i = 0; i < L / 2; i++) { double t = ext[i]; ext[i] = ext[L - 1 - i]; ext[L - 1 - i] = t; }
+    for (int i = 0; i < 2 * NSEC; i++) z[i] = zi[i] * ext[0]; /* y_0 = last forward output */
+    sosfilt_inplace(sos, NSEC, ext, L, z);
+    for (long i = 0; i < L / 2; i++) { double t = ext[i]; ext[i] = ext[L - 1 - i]; ext[L - 1 - i] = t; }
+    int n_out = (int)((M + q - 1) / q);
+    double mx = 0.0;
+    int has_nan = 0;
+    for (int j = 0; j < n_out; j++) {
+        double v = ext[EDGE + (long)j * q];
+        audio[j] = v;
+        double av = fabs(v);
+        if (av != av) has_nan = 1;
+        if (av > mx) mx = av;
+    }
+    if (has_nan) mx = NAN; /* np.max propagates NaN */
+    /* :115 audio / np.max(np.abs(audio)) * 0.95 */
+    for (int j = 0; j < n_out; j++) audio[j] = (audio[j] / mx) * 0.95;
+    free(u);
+    free(d64);
+    free(ext);
+    return n_out;
+}
+
+/* demodulate_am — signal_processing.py:179-195 */
+void pss_o_demod_am(const float *iq, int n, const double *sos, int nsec, double *audio)
+{
+    float *e = (float *)malloc(sizeof(float) * n);
+    for (int i = 0; i < n; i++) e[i] = pss_o_cabsf(iq[2 * i], iq[2 * i + 1]);      /* :182 */
+    float mu = pss_o_pairwise_sum_f32(e, n) / (float)n;                             /* :185 np.mean (float32) */
+    for (int i = 0; i < n; i++) audio[i] = (double)(e[i] - mu);                     /* :185 float32 subtract */
+    double z[16] = {0};
+    sosfilt_inplace(sos, nsec, audio, n, z);                                        /* :191 -> :42 sosfilt */
+    double mx = 0.0;
+    int has_nan = 0;
+    for (int i = 0; i < n; i++) { double a = fabs(audio[i]); if (a != a) has_nan = 1; if (a > mx) mx = a; }
+    if (has_nan) mx = NAN;
+    for (int i = 0; i < n; i++) audio[i] = (audio[i] / mx) * 0.95;                  /* :194 */
+    free(e);
+}
+
+/* demodulate_ssb — signal_processing.py:198-217 (USB and LSB branches are the same code) */
+void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio)
+{
+    double *r = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) r[i] = (double)iq[2 * i];
+    double tr[65];
+    for (int j = 0; j < 65; j++) tr[j] = taps[64 - j];
+    for (int i = 0; i < n; i++) audio[i] = fir65z_at(taps, tr, r, i, n);                    /* :204/:209 real part */
+    double mx = 0.0;
+    int has_nan = 0;
+    for (int i = 0; i < n; i++) { double a = fabs(audio[i]); if (a != a) has_nan = 1; if (a > mx) mx = a; }
+    if (has_nan) mx = NAN;
+    for (int i = 0; i < n; i++) audio[i] = (audio[i] / mx) * 0.95;                  /* :216 */
+    free(r);
+}
+
+/* np.int16(data * 32767): C truncation toward zero; NaN -> 0 (x86 cvttsd2si 0x8000...0 then low 16 bits) */
+void pss_o_pcm16_stereo(const double *audio, int n, int16_t *pcm)
+{
+    for (int i = 0; i < n; i++) {
+        double v = audio[i] * 32767.0;
+        int16_t s = (v != v) ? 0 : (int16_t)(int32_t)v;
+        pcm[2 * i] = s;
+        pcm[2 * i + 1] = s;
+    }
+}
+
+/* adjust_gain — pyspecsdr.py:898-919.  power arrives as np.float32; AGC_TARGET_POWER - power is
+ * evaluated in float32 (python int is weak). */
+int pss_o_agc_step(float power_db, int idx, int n_gains)
+{
+    float diff = -30.0f - power_db;
+    if (fabsf(diff) < 2.0f) return idx;
+    if (diff > 0) {
+        idx += 1;
+        if (idx > n_gains - 1) idx = n_gains - 1;
+    } else {
+        idx -= 1;
+        if (idx < 0) idx = 0;
+    }
+    return idx;
+}
+
+/* np.interp(np.linspace(0, len-1, W), np.arange(len), row): linspace = start + i*step with the last
+ * point forced to stop; interp = slope*(x - xp[j]) + fp[j] (numpy compiled_base.c arr_interp). */
+static double interp_row(const double *row, int len, int W, int i)
+{
+    double stop = (double)(len - 1);
+    double x;
+    if (W == 1) x = 0.0;
+    else {
+        double step = stop / (double)(W - 1);
+        x = (i == W - 1) ? stop : (double)i * step;
+    }
+    if (x >= stop) return row[len - 1];
+    int j = (int)x;
+    double slope = (row[j + 1] - row[j]) / ((double)(j + 1) - (double)j);
+    return slope * (x - (double)j) + row[j];
+}
+
+static void ring_minmax(const double *rows, long count, double *mn, double *mx)
+{
+    double lo = INFINITY, hi = -INFINITY;
+    for (long i = 0; i < count; i++) {
+        double v = rows[i];
+        if (isfinite(v)) { if (v < lo) lo = v; if (v > hi) hi = v; }
+    }
+    *mn = lo;
+    *mx = hi;
+}
+
+/* draw_waterfall — pyspecsdr.py:1342-1406 (ring :1351-1353, min/max :1356-1358, interp :1378-1382,
+ * quantise :1386-1398; no zero-range guard).  Screen row y shows the y-th newest ring row. */
+void pss_o_waterfall_cells(const double *rows, int n_rows, int len, int disp_h, int disp_w,
+                           int8_t *glyph, int8_t *colour)
+{
+    double mn, mx;
+    ring_minmax(rows, (long)n_rows * len, &mn, &mx);
+    memset(glyph, -1, (size_t)disp_h * disp_w);
+    memset(colour, -1, (size_t)disp_h * disp_w);
+    for (int y = 0; y < n_rows && y < disp_h; y++) {
+        const double *row = rows + (long)(n_rows - 1 - y) * len;
+        for (int x = 0; x < disp_w; x++) {
+            double v = interp_row(row, len, disp_w, x);
+            if (!isfinite(v)) continue;
+            double nv = (v - mn) / (mx - mn);
+            int ci = (int)(nv * 5);
+            int g = nv > 0.75 ? 3 : nv > 0.5 ? 2 : nv > 0.25 ? 1 : 0;
+            glyph[y * disp_w + x] = (int8_t)g;
+            colour[y * disp_w + x] = (int8_t)ci;
+        }
+    }
+}
+
+/* draw_persistence — pyspecsdr.py:1512-1564 (ring :1521-1523, range guard :1528-1530,
+ * alpha/colour :1544-1545, y-cell :1555-1556).  Later traces overwrite earlier ones. */
+void pss_o_persistence_cells(const double *rows, int n_rows, int len, int disp_h, int disp_w,
+                             int8_t *colour)
+{
+    double mn, mx;
+    ring_minmax(rows, (long)n_rows * len, &mn, &mx);
+    double range = mx - mn;
+    if (range == 0) range = 1;
+    memset(colour, 0, (size_t)disp_h * disp_w);
+    for (int i = 0; i < n_rows; i++) {
+        double alpha = pow(0.7, (double)(10 - i));
+        int cp = (int)(1 + (5 * (1 - alpha)));
+        const double *row = rows + (long)i * len;
+        for (int x = 0; x < disp_w; x++) {
+            double v = interp_row(row, len, disp_w, x);
+            if (!isfinite(v)) continue;
+            double nv = (v - mn) / range;
+            int y = (int)((1 - nv) * (disp_h - 1));
+            if (y >= 0 && y < disp_h) colour[y * disp_w + x] = (int8_t)cp;
+        }
+    }
+}
+
+/* bench.py cpu_baseline leg: the BASELINE.json headline path per frame, exactly what the reference's
+ * loop does per read buffer (compute_fft + demodulate_signal(NFM) + int16), filters designed once. */
+void pss_o_batch_spectrum_nfm(const float *iq, long n_frames, int n, double fs, int q, const double *taps,
+                              const double *sos, const double *zi, float *db_out, int16_t *pcm_out,
+                              int n_threads)
+{
+    int n_out = (int)(((long)n - 1 + q - 1) / q);
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+#endif
+    for (long f = 0; f < n_frames; f++) {
+        double *db = (double *)malloc(sizeof(double) * n);
+        double *au = (double *)malloc(sizeof(double) * (n_out + 1));
+        pss_o_compute_fft(iq + 2 * f * n, n, db);
+        for (int k = 0; k < n; k++) db_out[f * n + k] = (float)db[k];
+        pss_o_demod_nfm(iq + 2 * f * n, n, fs, q, taps, sos, zi, au, 0, 0);
+        pss_o_pcm16_stereo(au, n_out, pcm_out + 2 * f * n_out);
+        free(db);
+        free(au);
+    }
+}

@@ -1,0 +1,76 @@
+/*
+ * pss_oracle.h — CPU restatement (plain C, scalar) of the PySpecSDR IQ -> spectrum + demod hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product (pyspecsdr_amd/) never links or calls it.
+ *
+ * Every function cites the reference lines it follows (paths relative to the reference tree,
+ * xqtr/PySpecSDR v1.0.6) and, where the arithmetic lives in an un-vendored third-party
+ * dependency (requirements.txt:1-2 -> numpy>=1.20, scipy>=1.7; pinned here by the golden
+ * fixtures to NumPy 2.2.6 / SciPy 1.15.3, AVX512_SKX dispatch), the library routine it restates.
+ *
+ * Parity pin: tests/test_oracle_golden.py checks every function below against
+ * tests/golden/*.npz, which tools/make_goldens.py produced by importing the reference itself.
+ * (The reference ships no tests or golden vectors of its own — SURVEY.md §4.)
+ */
+#ifndef PSS_ORACLE_H
+#define PSS_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- float32 primitives (NumPy AVX512_SKX ufunc loops) ---- */
+float pss_o_rcp14f(float x);                 /* VRCP14PS, bit-exact model (64-entry piecewise-linear table) */
+float pss_o_atan2f(float y, float x);        /* numpy.arctan2 float32 == Intel SVML __svml_atan2f16 (la)     */
+float pss_o_cabsf(float re, float im);       /* numpy.abs(complex64)                                          */
+float pss_o_pairwise_sum_f32(const float *a, long n); /* numpy add.reduce float32 (pairwise, 8 accumulators) */
+float pss_o_log10f_ref(float x);             /* float32 log10 via double (tolerance-checked, not bit-pinned) */
+
+/* ---- per-frame functions; iq = interleaved complex64 (I0,Q0,I1,Q1,...) ---- */
+
+/* compute_fft — signal_processing.py:243-264.  db[n] float64, DC-centred. */
+void pss_o_compute_fft(const float *iq, int n, double *db);
+/* caller post-process — pyspecsdr.py:2278-2283.  out[n-4]. */
+void pss_o_postprocess(const double *db, int n, double *out);
+/* measure_signal_power — signal_processing.py:325-328 (float32 throughout). */
+float pss_o_power_db(const float *iq, int n);
+/* inline scanner slice — pyspecsdr.py:2542-2552 (float32 dB). Returns number of bins in the 20 dB mask. */
+int pss_o_scan_slice(const float *iq, int n, double fs, float *db, float *peak, double *bw);
+
+/* demodulate_nfm — signal_processing.py:91-116.
+ * taps[65] = firwin(65, 15000/(fs/2)); sos[4][6] = cheby1(8,0.05,0.8/q,'sos'); zi[4][2] = sosfilt_zi(sos).
+ * audio[n_out], n_out = ceil((n-1)/q).  Returns n_out, or -1 if n-1 <= 27 (sosfiltfilt padlen ValueError).
+ * work: optional stage dumps (may be NULL): disc[n-1] float32, fir[n-1] float64. */
+int pss_o_demod_nfm(const float *iq, int n, double fs, int q, const double *taps, const double *sos,
+                    const double *zi, double *audio, float *disc_out, double *fir_out);
+/* demodulate_am — signal_processing.py:179-195 (+ bandpass_filter :34-42). sos[5][6]. audio[n]. */
+void pss_o_demod_am(const float *iq, int n, const double *sos, int nsec, double *audio);
+/* demodulate_ssb — signal_processing.py:198-217. taps[65] = firwin(65, 3000/fs). audio[n].
+ * hilbert(real(z)).real is restated as real(z) (identity up to 1e-15 round-off). */
+void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio);
+/* int16 conversion — io_manager.py:25-26 / audio_processing.py:37: np.int16(x*32767), stereo dup
+ * (mono_to_stereo signal_processing.py:83-88). pcm[2*n] = L0 R0 L1 R1 ... */
+void pss_o_pcm16_stereo(const double *audio, int n, int16_t *pcm);
+
+/* adjust_gain — pyspecsdr.py:898-919 (index part). */
+int pss_o_agc_step(float power_db, int idx, int n_gains);
+
+/* waterfall quantiser — pyspecsdr.py:1342-1406.  rows: ring contents oldest..newest, n_rows x len.
+ * glyph/colour: [disp_h][disp_w] int8, -1 = not drawn.  Row y=0 is the newest. */
+void pss_o_waterfall_cells(const double *rows, int n_rows, int len, int disp_h, int disp_w,
+                           int8_t *glyph, int8_t *colour);
+/* persistence quantiser — pyspecsdr.py:1512-1564. colour[disp_h][disp_w], 0 = empty. */
+void pss_o_persistence_cells(const double *rows, int n_rows, int len, int disp_h, int disp_w,
+                             int8_t *colour);
+
+/* ---- batched drivers used only by bench.py's cpu_baseline leg (OpenMP over frames if enabled) ---- */
+/* spectrum (float32 dB out) + NFM -> int16 stereo PCM, the BASELINE.json headline path. */
+void pss_o_batch_spectrum_nfm(const float *iq, long n_frames, int n, double fs, int q, const double *taps,
+                              const double *sos, const double *zi, float *db_out, int16_t *pcm_out,
+                              int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

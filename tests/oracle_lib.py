@@ -1,0 +1,170 @@
+"""ctypes binding of the CPU oracle (oracle/pss_oracle.c) — test infrastructure only.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never from the
+product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ODIR, "_build", "libpss_oracle.so")
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+_i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    src = [os.path.join(ODIR, f) for f in ("pss_oracle.c", "pss_oracle.h", "Makefile")]
+    if force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in src):
+        subprocess.run(["make", "-C", ODIR], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.pss_o_rcp14f.restype = C.c_float
+        L.pss_o_rcp14f.argtypes = [C.c_float]
+        L.pss_o_atan2f.restype = C.c_float
+        L.pss_o_atan2f.argtypes = [C.c_float, C.c_float]
+        L.pss_o_cabsf.restype = C.c_float
+        L.pss_o_cabsf.argtypes = [C.c_float, C.c_float]
+        L.pss_o_pairwise_sum_f32.restype = C.c_float
+        L.pss_o_pairwise_sum_f32.argtypes = [_f32p, C.c_long]
+        L.pss_o_compute_fft.argtypes = [_f32p, C.c_int, _f64p]
+        L.pss_o_postprocess.argtypes = [_f64p, C.c_int, _f64p]
+        L.pss_o_power_db.restype = C.c_float
+        L.pss_o_power_db.argtypes = [_f32p, C.c_int]
+        L.pss_o_scan_slice.restype = C.c_int
+        L.pss_o_scan_slice.argtypes = [_f32p, C.c_int, C.c_double, _f32p, C.POINTER(C.c_float),
+                                       C.POINTER(C.c_double)]
+        L.pss_o_demod_nfm.restype = C.c_int
+        L.pss_o_demod_nfm.argtypes = [_f32p, C.c_int, C.c_double, C.c_int, _f64p, _f64p, _f64p, _f64p,
+                                      C.c_void_p, C.c_void_p]
+        L.pss_o_demod_am.argtypes = [_f32p, C.c_int, _f64p, C.c_int, _f64p]
+        L.pss_o_demod_ssb.argtypes = [_f32p, C.c_int, _f64p, _f64p]
+        L.pss_o_pcm16_stereo.argtypes = [_f64p, C.c_int, _i16p]
+        L.pss_o_agc_step.restype = C.c_int
+        L.pss_o_agc_step.argtypes = [C.c_float, C.c_int, C.c_int]
+        L.pss_o_waterfall_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, C.c_int, _i8p, _i8p]
+        L.pss_o_persistence_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, C.c_int, _i8p]
+        L.pss_o_batch_spectrum_nfm.argtypes = [_f32p, C.c_long, C.c_int, C.c_double, C.c_int, _f64p, _f64p,
+                                               _f64p, _f32p, _i16p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _iq(x):
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    return x.view(np.float32)
+
+
+def atan2f(y, x):
+    L = lib()
+    y = np.asarray(y, np.float32)
+    x = np.asarray(x, np.float32)
+    return np.array([L.pss_o_atan2f(float(a), float(b)) for a, b in zip(y, x)], np.float32)
+
+
+def compute_fft(iq):
+    out = np.empty(len(iq), np.float64)
+    lib().pss_o_compute_fft(_iq(iq), len(iq), out)
+    return out
+
+
+def postprocess(db):
+    db = np.ascontiguousarray(db, np.float64)
+    out = np.empty(len(db) - 4, np.float64)
+    lib().pss_o_postprocess(db, len(db), out)
+    return out
+
+
+def power_db(iq):
+    return np.float32(lib().pss_o_power_db(_iq(iq), len(iq)))
+
+
+def scan_slice(iq, fs):
+    db = np.empty(len(iq), np.float32)
+    pk = C.c_float()
+    bw = C.c_double()
+    cnt = lib().pss_o_scan_slice(_iq(iq), len(iq), fs, db, C.byref(pk), C.byref(bw))
+    return db, np.float32(pk.value), bw.value, cnt
+
+
+def demod_nfm(iq, fs, taps, sos, zi, stages=False):
+    n = len(iq)
+    q = int(fs / 22050)
+    n_out = max((n - 1 + q - 1) // q, 0)
+    audio = np.empty(max(n_out, 1), np.float64)
+    disc = np.empty(max(n - 1, 1), np.float32)
+    fir = np.empty(max(n - 1, 1), np.float64)
+    r = lib().pss_o_demod_nfm(_iq(iq), n, fs, q, np.ascontiguousarray(taps, np.float64),
+                              np.ascontiguousarray(sos, np.float64), np.ascontiguousarray(zi, np.float64),
+                              audio, disc.ctypes.data, fir.ctypes.data)
+    if r < 0:
+        raise ValueError("The length of the input vector x must be greater than padlen, which is 27.")
+    if stages:
+        return audio[:r], disc[:n - 1], fir[:n - 1]
+    return audio[:r]
+
+
+def demod_am(iq, sos):
+    sos = np.ascontiguousarray(sos, np.float64)
+    out = np.empty(len(iq), np.float64)
+    lib().pss_o_demod_am(_iq(iq), len(iq), sos, sos.shape[0], out)
+    return out
+
+
+def demod_ssb(iq, taps):
+    out = np.empty(len(iq), np.float64)
+    lib().pss_o_demod_ssb(_iq(iq), len(iq), np.ascontiguousarray(taps, np.float64), out)
+    return out
+
+
+def pcm16_stereo(audio):
+    audio = np.ascontiguousarray(audio, np.float64)
+    out = np.empty((len(audio), 2), np.int16)
+    lib().pss_o_pcm16_stereo(audio, len(audio), out.reshape(-1))
+    return out
+
+
+def agc_step(p, idx, n):
+    return lib().pss_o_agc_step(float(np.float32(p)), idx, n)
+
+
+def waterfall_cells(rows, disp_h, disp_w):
+    rows = np.ascontiguousarray(rows, np.float64)
+    g = np.empty((disp_h, disp_w), np.int8)
+    c = np.empty((disp_h, disp_w), np.int8)
+    lib().pss_o_waterfall_cells(rows, rows.shape[0], rows.shape[1], disp_h, disp_w, g, c)
+    return g, c
+
+
+def persistence_cells(rows, disp_h, disp_w):
+    rows = np.ascontiguousarray(rows, np.float64)
+    c = np.empty((disp_h, disp_w), np.int8)
+    lib().pss_o_persistence_cells(rows, rows.shape[0], rows.shape[1], disp_h, disp_w, c)
+    return c
+
+
+def batch_spectrum_nfm(iq2d, fs, taps, sos, zi, n_threads=1):
+    iq2d = np.ascontiguousarray(iq2d, np.complex64)
+    nf, n = iq2d.shape
+    q = int(fs / 22050)
+    n_out = (n - 1 + q - 1) // q
+    db = np.empty((nf, n), np.float32)
+    pcm = np.empty((nf, n_out, 2), np.int16)
+    lib().pss_o_batch_spectrum_nfm(iq2d.view(np.float32).reshape(-1), nf, n, fs, q,
+                                   np.ascontiguousarray(taps, np.float64), np.ascontiguousarray(sos, np.float64),
+                                   np.ascontiguousarray(zi, np.float64), db.reshape(-1), pcm.reshape(-1), n_threads)
+    return db, pcm

@@ -1,0 +1,171 @@
+"""Pin the CPU oracle (oracle/pss_oracle.c) to the golden vectors captured from the reference.
+
+The reference (xqtr/PySpecSDR) has no tests or fixtures of its own; tests/golden/*.npz were produced by
+tools/make_goldens.py importing the reference's signal_processing.py / pyspecsdr.py under
+NumPy 2.2.6 + SciPy 1.15.3 (AVX512_SKX dispatch).  Bit-exact where stated, tolerance elsewhere.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def bits32(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+def test_atan2f_bit_exact(golden):
+    g = golden["atan2f"]
+    y, x, th = g["y"], g["x"], g["theta"]
+    mine = O.atan2f(y, x)
+    same = (bits32(mine) == bits32(th)) | (np.isnan(mine) & np.isnan(th))
+    assert same.all(), f"{(~same).sum()} of {len(same)} differ"
+
+
+def test_rcp14_model_properties():
+    L = O.lib()
+    # exact powers of two, monotone non-increasing, relative error < 2^-14 (the architectural bound)
+    xs = np.float32(1.0) + np.arange(0, 1 << 23, 257, dtype=np.uint32).astype(np.float32) * np.float32(2.0 ** -23)
+    r = np.array([L.pss_o_rcp14f(float(v)) for v in xs], np.float32)
+    assert L.pss_o_rcp14f(1.0) == 1.0 and L.pss_o_rcp14f(4.0) == 0.25 and L.pss_o_rcp14f(-0.5) == -2.0
+    assert np.all(np.diff(r) <= 0)
+    assert np.max(np.abs(r.astype(np.float64) * xs.astype(np.float64) - 1)) < 2.0 ** -14
+    # scale invariance in the exponent
+    for e in (-100, -7, 30, 100):
+        assert L.pss_o_rcp14f(float(np.ldexp(np.float32(1.37), e))) == float(np.ldexp(np.float32(L.pss_o_rcp14f(1.37)), -e))
+
+
+@pytest.mark.parametrize("n", [256, 1024, 2048, 4096, 8192, 16384])
+def test_compute_fft(golden, n):
+    g = golden["spectrum"]
+    for iq, ref in zip(g[f"iq_{n}"], g[f"db_{n}"]):
+        mine = O.compute_fft(iq)
+        assert np.allclose(mine, ref, rtol=1e-9, atol=1e-9)
+    if n == 1024:
+        assert np.array_equal(O.compute_fft(np.zeros(1024, np.complex64)), g["db_zero"])  # exactly -100.0
+
+
+@pytest.mark.parametrize("n", [256, 1024, 4096])
+def test_postprocess(golden, n):
+    g = golden["spectrum"]
+    for db, ref in zip(g[f"db_{n}"], g[f"post_{n}"]):
+        mine = O.postprocess(db)
+        assert mine.shape == ref.shape == (n - 4,)
+        assert np.allclose(mine, ref, rtol=1e-13, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+def test_nfm(golden, tag):
+    g = golden["nfm"]
+    fs = float(g[f"fs_{tag}"])
+    taps, sos, zi = g[f"taps_{tag}"], g[f"sos_{tag}"], g[f"zi_{tag}"]
+    for k, iq in enumerate(g[f"iq_{tag}"]):
+        audio, disc, fir = O.demod_nfm(iq, fs, taps, sos, zi, stages=True)
+        if k == 0:
+            # float32 front end (FMA complex multiply + SVML atan2 + scale) is bit-exact
+            assert np.array_equal(bits32(disc), bits32(g[f"disc_{tag}"]))
+            # FIR in OpenBLAS ddot accumulation order: bit-exact float64, edges included
+            assert np.array_equal(fir, g[f"fir_{tag}"])
+        ref = g[f"audio_{tag}"][k]
+        assert audio.shape == ref.shape
+        assert np.array_equal(audio, ref)  # float64 bit-exact
+        assert np.array_equal(O.pcm16_stereo(audio), g[f"pcm_{tag}"][k])
+
+
+def test_nfm_edges(golden):
+    g = golden["nfm"]
+    taps, sos, zi = g["taps_a"], g["sos_a"], g["zi_a"]
+    with pytest.raises(ValueError):  # N-1 <= 27 -> scipy sosfiltfilt padlen ValueError
+        O.demod_nfm(np.ones(28, np.complex64), 2.4e6, taps, sos, zi)
+    a = O.demod_nfm(np.zeros(1024, np.complex64), 2.4e6, taps, sos, zi)  # silence -> 0/0 -> NaN -> int16 0
+    assert np.isnan(a).all() and np.isnan(g["audio_silence"]).all()
+    assert np.array_equal(O.pcm16_stereo(a), g["pcm_silence"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_am_bit_exact(golden, tag):
+    g = golden["am_ssb"]
+    sos = g["am_sos"]
+    for k, iq in enumerate(g[f"am_iq_{tag}"]):
+        audio = O.demod_am(iq, sos)
+        assert np.array_equal(audio, g[f"am_audio_{tag}"][k])  # float64 bit-exact
+        assert np.array_equal(O.pcm16_stereo(audio), g[f"am_pcm_{tag}"][k])
+    L = O.lib()
+    iq0 = g[f"am_iq_{tag}"][0]
+    env = np.array([L.pss_o_cabsf(float(z.real), float(z.imag)) for z in iq0], np.float32)
+    assert np.array_equal(bits32(env), bits32(g[f"am_env_{tag}"]))
+    mu = np.float32(L.pss_o_pairwise_sum_f32(env, len(env))) / np.float32(len(env))
+    assert bits32(mu) == bits32(g[f"am_mean_{tag}"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_ssb(golden, tag):
+    g = golden["am_ssb"]
+    taps = g[f"ssb_taps_{tag}"]
+    for k, iq in enumerate(g[f"ssb_iq_{tag}"]):
+        audio = O.demod_ssb(iq, taps)
+        # real FIR is bit-exact; scipy's hilbert() FFT round trip perturbs it by ~1e-16
+        assert np.allclose(audio, g[f"ssb_audio_{tag}"][k], rtol=0, atol=2e-14)
+        assert np.array_equal(O.pcm16_stereo(audio), g[f"ssb_pcm_{tag}"][k])
+
+
+@pytest.mark.parametrize("n", [7, 100, 1024, 16384, 32768])
+def test_power(golden, n):
+    g = golden["power"]
+    iq = g[f"iq_{n}"]
+    L = O.lib()
+    a = np.array([L.pss_o_cabsf(float(z.real), float(z.imag)) for z in iq], np.float32)
+    assert bits32(np.float32(L.pss_o_pairwise_sum_f32(a, n)) / np.float32(n)) == bits32(g[f"mean_abs_{n}"])
+    s = a * a
+    assert bits32(np.float32(L.pss_o_pairwise_sum_f32(s, n)) / np.float32(n)) == bits32(g[f"mean_abs2_{n}"])
+    p = O.power_db(iq)
+    assert abs(float(p) - float(g[f"p_{n}"])) <= 4e-6 * max(1.0, abs(float(g[f"p_{n}"])))  # log10f: few ulp
+    if n == 1024:
+        # numpy's float32 log10 loop returns -100.00001 for 1e-10f (not correctly rounded): tolerance
+        assert abs(float(O.power_db(np.zeros(1024, np.complex64))) - float(g["p_zero"])) < 2e-5
+
+
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_scanner(golden, n):
+    g = golden["scanner"]
+    for k, iq in enumerate(g[f"iq_{n}"]):
+        db, pk, bw, cnt = O.scan_slice(iq, 2.4e6)
+        ref = g[f"db_{n}"][k]
+        assert np.all(np.abs(db - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0))
+        assert abs(pk - g[f"peak_{n}"][k]) <= 1e-4 * abs(g[f"peak_{n}"][k])
+        near = int(np.sum(np.abs(ref - (g[f"peak_{n}"][k] - 20)) < 2e-3))  # bins sitting on the mask edge
+        assert abs(cnt - int(g[f"count_{n}"][k])) <= near
+        assert abs(bw - g[f"bw_{n}"][k]) <= near * 2.4e6 / n + 1e-6
+
+
+def test_agc(golden):
+    g = golden["caller"]
+    n = int(g["agc_ngains"])
+    for start in (20, 0, n - 1):
+        idx, traj = start, []
+        for p in g["agc_powers"]:
+            idx = O.agc_step(p, idx, n)
+            traj.append(idx)
+        assert traj == list(g[f"agc_traj_{start}"])
+
+
+def test_waterfall_and_persistence(golden):
+    g = golden["caller"]
+    rows = g["rows"]
+    H, W = [int(v) for v in g["hw"]]
+    dh, dw = H - 4, W - 8
+    for i in range(len(rows)):
+        ring = rows[max(0, i + 1 - 30):i + 1]
+        gl, co = O.waterfall_cells(ring, dh, dw)
+        assert np.array_equal(gl, g["wf_glyph"][i]), i
+        assert np.array_equal(co, g["wf_colour"][i]), i
+    for i in range(len(g["ps_colour"])):
+        ring = rows[max(0, i + 1 - 10):i + 1]
+        assert np.array_equal(O.persistence_cells(ring, dh, dw), g["ps_colour"][i]), i
+
+
+def test_raw_and_unknown_modes(golden):
+    g = golden["am_ssb"]
+    # RAW goes through iq_correction first (signal_processing.py:222-225): float32 (N,), not plain real()
+    assert g["raw_out"].dtype == np.float32 and g["raw_out"].shape == (64,)
+    assert g["unknown_out"].shape == (64, 2) and not g["unknown_out"].any()

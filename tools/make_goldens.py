@@ -1,0 +1,362 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/.
+
+Runs ONLY in the build container, where the Python reference is mounted read-only at
+/root/reference.  It imports the reference's own hot-path module (signal_processing.py) and,
+with sounddevice/SoapySDR/curses stubbed, its caller (pyspecsdr.py), feeds them seeded
+synthetic IQ, and stores *data only* (inputs, outputs, designed filter coefficients) as
+compressed .npz fixtures.  No reference source text or bytecode is written anywhere.
+
+The numbers are produced by NumPy/SciPy native code (pocketfft, SVML, _sosfilt ...), so the
+fixtures are stamped with the library versions and the enabled NumPy CPU-dispatch features.
+
+    python tools/make_goldens.py            # rewrites tests/golden/*.npz
+"""
+import json
+import os
+import sys
+import types
+import warnings
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+import numpy as np
+import scipy
+import scipy.signal as ss
+
+import signal_processing as sp  # the reference hot path (signal_processing.py)
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+# --------------------------------------------------------------------------------------
+# synthetic IQ (SURVEY.md §8d shapes; plain seeded NumPy — inputs are stored in the fixture)
+# --------------------------------------------------------------------------------------
+def fm_iq(n_frames, n, fs, seed, amp=0.5, sigma=0.02, dev=5e3):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / fs
+    out = np.empty((n_frames, n), np.complex64)
+    for f in range(n_frames):
+        ph0 = 0.1 * f
+        m = (0.5 * np.sin(2 * np.pi * 400 * t + ph0) + 0.3 * np.sin(2 * np.pi * 1000 * t + 2 * ph0)
+             + 0.2 * np.sin(2 * np.pi * 2500 * t + 3 * ph0))
+        phase = 2 * np.pi * dev * np.cumsum(m) / fs + ph0
+        x = amp * np.exp(1j * phase) + sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        out[f] = x.astype(np.complex64)
+    return out
+
+
+def am_iq(n_frames, n, fs, seed, sigma=0.01):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / fs
+    out = np.empty((n_frames, n), np.complex64)
+    for f in range(n_frames):
+        m = 0.5 * np.sin(2 * np.pi * 40e3 * t + 0.3 * f) + 0.3 * np.sin(2 * np.pi * 90e3 * t + 0.1 * f)
+        x = (1 + 0.5 * m) * 0.5 * np.exp(1j * 0.3) + sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        out[f] = x.astype(np.complex64)
+    return out
+
+
+def ssb_iq(n_frames, n, fs, seed, sigma=0.01):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / fs
+    out = np.empty((n_frames, n), np.complex64)
+    for f in range(n_frames):
+        x = (0.4 * np.exp(1j * 2 * np.pi * (1500 + 37 * f) * t) + 0.2 * np.exp(1j * 2 * np.pi * 2400 * t)
+             + sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n)))
+        out[f] = x.astype(np.complex64)
+    return out
+
+
+def scan_iq(n_slices, n, fs, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    out = np.empty((n_slices, n), np.complex64)
+    for s in range(n_slices):
+        x = 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        b = int(rng.integers(-n // 2 + 8, n // 2 - 8))
+        x = x + 0.3 * np.exp(2j * np.pi * b * t / n)
+        if s % 2 == 0:  # wide FM-ish carrier: many bins within 20 dB of the peak
+            m = np.cumsum(rng.standard_normal(n)) * 0.4
+            x = x + 0.5 * np.exp(1j * m)
+        out[s] = x.astype(np.complex64)
+    return out
+
+
+def stamp():
+    from numpy._core._multiarray_umath import __cpu_features__ as feats
+    return json.dumps({
+        "numpy": np.__version__, "scipy": scipy.__version__,
+        "python": sys.version.split()[0],
+        "cpu_features": sorted(k for k, v in feats.items() if v),
+        "reference": "xqtr/PySpecSDR v1.0.6 tree (signal_processing.py, pyspecsdr.py)",
+    })
+
+
+def save(name, **arrs):
+    arrs["stamp"] = np.array(stamp())
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------------------
+def gen_atan2():
+    """np.angle on complex64 == the float32 arctan2 loop (SVML __svml_atan2f16 on AVX512_SKX)."""
+    rng = np.random.default_rng(101)
+    n = 60000
+    re = rng.standard_normal(n).astype(np.float32) * np.float32(0.3)
+    im = rng.standard_normal(n).astype(np.float32) * np.float32(0.3)
+    # wide dynamic range + axis-hugging cases
+    k = n // 4
+    re[:k] *= np.exp2(rng.integers(-60, 60, k)).astype(np.float32)
+    im[:k] *= np.exp2(rng.integers(-60, 60, k)).astype(np.float32)
+    im[k:k + 2000] *= np.float32(1e-6)
+    re[k + 2000:k + 4000] *= np.float32(1e-6)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-40, -1e-40, 3e38, -3e38,
+                        1e-38, 2.5e-38, 1e37, 2e36], np.float32)
+    sy, sx = np.meshgrid(special, special)
+    y = np.concatenate([im, sy.ravel()])
+    x = np.concatenate([re, sx.ravel()])
+    z = (x + 1j * y).astype(np.complex64)
+    # make sure inf/nan/-0 survive the complex construction
+    z.real[:] = x
+    z.imag[:] = y
+    with np.errstate(all="ignore"):
+        th = np.angle(z)
+        th2 = np.arctan2(y, x)
+    assert th.dtype == np.float32
+    assert np.array_equal(th.view(np.uint32), th2.view(np.uint32))
+    save("atan2f", y=y, x=x, theta=th, n_random=np.array(n))
+
+
+def gen_spectrum():
+    d = {}
+    for n, fs, nf, seed in [(1024, 2.4e6, 4, 11), (2048, 10e6, 2, 12), (4096, 2.4e6, 2, 13),
+                            (16384, 2.4e6, 1, 14), (256, 1.024e6, 2, 15), (8192, 1.024e6, 1, 16)]:
+        iq = fm_iq(nf, n, fs, seed)
+        if n == 4096:  # one high-dynamic-range frame: strong tone over a -100 dB floor
+            t = np.arange(n)
+            iq[1] = (0.9 * np.exp(2j * np.pi * 300.25 * t / n) + 1e-5 * iq[1]).astype(np.complex64)
+        db = np.stack([sp.compute_fft(f) for f in iq])
+        post = []
+        for row in db:
+            # caller-side post-process, exactly the three statements at pyspecsdr.py:2278-2283
+            fd = np.convolve(row, np.ones(5) / 5, mode="valid")
+            thr = np.median(fd) - 10
+            fd[fd < thr] = thr
+            post.append(fd)
+        d[f"iq_{n}"] = iq
+        d[f"db_{n}"] = db
+        d[f"post_{n}"] = np.stack(post)
+    z = np.zeros(1024, np.complex64)
+    d["db_zero"] = sp.compute_fft(z)
+    save("spectrum", **d)
+
+
+def gen_nfm():
+    d = {}
+    for tag, n, fs, nf, seed in [("a", 1024, 2.4e6, 6, 21), ("b", 2048, 10e6, 3, 22), ("c", 4096, 1.024e6, 2, 23),
+                                 ("d", 29, 2.4e6, 1, 24), ("e", 32768, 2.4e6, 1, 25), ("f", 1000, 2.4e6, 2, 26)]:
+        iq = fm_iq(nf, n, fs, seed)
+        aud = np.stack([sp.demodulate_signal(f, fs, "NFM") for f in iq])  # (nf, n_out, 2)
+        assert np.array_equal(aud[..., 0], aud[..., 1])
+        pcm = np.int16(aud * 32767)
+        q = int(fs / 22050)
+        d[f"iq_{tag}"] = iq
+        d[f"fs_{tag}"] = np.array(fs)
+        d[f"audio_{tag}"] = aud[..., 0].copy()
+        d[f"pcm_{tag}"] = pcm
+        # intermediate stages for the first frame (helps localise a mismatch)
+        x = iq[0]
+        dem = np.angle(x[1:] * np.conj(x[:-1]))
+        dem = dem * (fs / (2 * np.pi))
+        taps = ss.firwin(numtaps=65, cutoff=15000 / (fs / 2))
+        fil = ss.lfilter(taps, 1.0, dem)
+        d[f"disc_{tag}"] = dem
+        d[f"fir_{tag}"] = fil
+        d[f"taps_{tag}"] = taps
+        sos = ss.cheby1(8, 0.05, 0.8 / q, output="sos")
+        d[f"sos_{tag}"] = sos
+        d[f"zi_{tag}"] = ss.sosfilt_zi(sos)
+    # coefficient sets for the config sample rates
+    for fs in (1.024e6, 2.4e6, 10e6, 2.048e6, 250e3):
+        q = int(fs / 22050)
+        key = f"{int(fs)}"
+        d["design_taps_" + key] = ss.firwin(numtaps=65, cutoff=15000 / (fs / 2))
+        sos = ss.cheby1(8, 0.05, 0.8 / q, output="sos")
+        d["design_sos_" + key] = sos
+        d["design_zi_" + key] = ss.sosfilt_zi(sos)
+    # silence -> NaN audio -> int16 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        z = np.zeros(1024, np.complex64)
+        a = sp.demodulate_nfm(z, 2.4e6)
+        d["audio_silence"] = a[:, 0].copy()
+        d["pcm_silence"] = np.int16(a * 32767)
+    save("nfm", **d)
+
+
+def gen_am_ssb():
+    d = {}
+    for tag, n, nf, seed in [("a", 1024, 3, 31), ("b", 16384, 1, 32), ("c", 300, 2, 33)]:
+        iq = am_iq(nf, n, 2.4e6, seed)
+        aud = np.stack([sp.demodulate_signal(f, 2.4e6, "AM") for f in iq])
+        d[f"am_iq_{tag}"] = iq
+        d[f"am_audio_{tag}"] = aud[..., 0].copy()
+        d[f"am_pcm_{tag}"] = np.int16(aud * 32767)
+        d[f"am_env_{tag}"] = np.abs(iq[0])
+        d[f"am_mean_{tag}"] = np.array(np.mean(np.abs(iq[0])))
+    d["am_sos"] = ss.butter(5, [300.0 / (22050 / 2), 3000.0 / (22050 / 2)], btype="band", output="sos")
+    for tag, n, fs, nf, seed in [("a", 1024, 2.4e6, 3, 41), ("b", 16384, 2.4e6, 1, 42), ("c", 2048, 1.024e6, 1, 43)]:
+        iq = ssb_iq(nf, n, fs, seed)
+        usb = np.stack([sp.demodulate_signal(f, fs, "USB") for f in iq])
+        lsb = np.stack([sp.demodulate_signal(f, fs, "LSB") for f in iq])
+        assert np.array_equal(usb, lsb)
+        d[f"ssb_iq_{tag}"] = iq
+        d[f"ssb_fs_{tag}"] = np.array(fs)
+        d[f"ssb_audio_{tag}"] = usb[..., 0].copy()
+        d[f"ssb_pcm_{tag}"] = np.int16(usb * 32767)
+        d[f"ssb_taps_{tag}"] = ss.firwin(65, 3000 / fs, window="hamming")
+    # dispatcher edge cases
+    x = fm_iq(1, 64, 2.4e6, 44)[0]
+    d["raw_iq"] = x
+    d["raw_out"] = sp.demodulate_signal(x, 2.4e6, "RAW")
+    d["unknown_out"] = sp.demodulate_signal(x, 2.4e6, "DIGITAL")
+    save("am_ssb", **d)
+
+
+def gen_power():
+    d = {}
+    frames, pw = [], []
+    for n, seed in [(1024, 51), (16384, 52), (32768, 53), (100, 54), (7, 55)]:
+        iq = fm_iq(1, n, 2.4e6, seed, amp=0.05 * (1 + seed % 3))[0]
+        p = sp.measure_signal_power(iq)
+        assert p.dtype == np.float32
+        d[f"iq_{n}"] = iq
+        d[f"p_{n}"] = np.array(p)
+        # numpy float32 mean (pairwise tree) of |x| and of |x|^2
+        d[f"mean_abs_{n}"] = np.array(np.mean(np.abs(iq)))
+        d[f"mean_abs2_{n}"] = np.array(np.mean(np.abs(iq) ** 2))
+    d["p_zero"] = np.array(sp.measure_signal_power(np.zeros(1024, np.complex64)))
+    save("power", **d)
+
+
+def gen_scanner():
+    d = {}
+    for n, ns, seed in [(2048, 6, 61), (4096, 4, 62)]:
+        fs = 2.4e6
+        iq = scan_iq(ns, n, fs, seed)
+        dbs, peaks, bws = [], [], []
+        for s in iq:
+            # the inline scanner's five statements, pyspecsdr.py:2542-2552
+            spectrum = np.fft.fftshift(np.fft.fft(s))
+            power_db = 10 * np.log10(np.abs(spectrum) ** 2 + 1e-10)
+            peak = np.max(power_db)
+            mask = power_db > (peak - 20)
+            bw = np.sum(mask) * (fs / len(power_db))
+            dbs.append(power_db); peaks.append(peak); bws.append(bw)
+        d[f"iq_{n}"] = iq
+        d[f"db_{n}"] = np.stack(dbs)
+        d[f"peak_{n}"] = np.array(peaks)
+        d[f"bw_{n}"] = np.array(bws)
+        d[f"count_{n}"] = np.array([int(round(b / (fs / n))) for b in bws])
+        assert d[f"db_{n}"].dtype == np.float32
+    save("scanner", **d)
+
+
+def gen_caller():
+    """Caller-side state machines: AGC stepper and the waterfall / persistence quantisers."""
+    import curses
+    sd = types.ModuleType("sounddevice")
+    sd.PortAudioError = type("PortAudioError", (Exception,), {})
+    sd.OutputStream = object
+    so = types.ModuleType("SoapySDR")
+    so.SOAPY_SDR_RX = 1
+    so.SOAPY_SDR_CF32 = "CF32"
+    so.Device = object
+    sys.modules["sounddevice"] = sd
+    sys.modules["SoapySDR"] = so
+    curses.color_pair = lambda n: n << 8
+    import signal as _signal
+    old = (_signal.getsignal(_signal.SIGINT), _signal.getsignal(_signal.SIGTERM))
+    import pyspecsdr as P
+    _signal.signal(_signal.SIGINT, old[0]); _signal.signal(_signal.SIGTERM, old[1])
+
+    class Sdr:
+        valid_gains_db = list(np.arange(0, 50, 1.7))
+        gain = 0.0
+
+    d = {}
+    powers = np.array([-50, -45, -31, -29, -10, -10, -33, -28.0001, -32.0, -31.99, 5, 5, 5], np.float32)
+    for start in (20, 0, len(Sdr.valid_gains_db) - 1):
+        idx, traj = start, []
+        for p in powers:
+            idx = P.adjust_gain(Sdr, p, idx)
+            traj.append(idx)
+        d[f"agc_traj_{start}"] = np.array(traj)
+    d["agc_powers"] = powers
+    d["agc_ngains"] = np.array(len(Sdr.valid_gains_db))
+
+    class Scr:
+        def __init__(s, h, w): s.h, s.w, s.calls = h, w, []
+        def getmaxyx(s): return s.h, s.w
+        def addstr(s, *a): s.calls.append(a)
+        def refresh(s): pass
+
+    H, W = 40, 120
+    iq = fm_iq(34, 1024, 2.4e6, 71)
+    iq[5] *= 3.0
+    iq[20] *= 0.1
+    rows = []
+    for f in iq:
+        fd = sp.compute_fft(f)
+        fd = np.convolve(fd, np.ones(5) / 5, mode="valid")
+        thr = np.median(fd) - 10
+        fd[fd < thr] = thr
+        rows.append(fd)
+    rows = np.stack(rows)
+    d["rows"] = rows
+    d["hw"] = np.array([H, W])
+    # waterfall: after each push, grid[y, x] = glyph code (0 '.',1 '-',2 '=',3 '#'), colour idx; -1 = not drawn
+    P.WATERFALL_HISTORY.clear()
+    wf_glyph, wf_col = [], []
+    glyphs = {".": 0, "-": 1, "=": 2, "#": 3}
+    for r in rows:
+        scr = Scr(H, W)
+        P.draw_waterfall(scr, r, None, 100e6, 2.4e6, 0, 0, None)
+        g = -np.ones((H - 4, W - 8), np.int8); c = -np.ones((H - 4, W - 8), np.int8)
+        for call in scr.calls:
+            y, x, s, attr = call
+            if s in glyphs and x >= 9 and y >= 3 and len(s) == 1 and (attr >> 8) >= 10:
+                g[y - 3, x - 9] = glyphs[s]; c[y - 3, x - 9] = (attr >> 8) - 10
+        wf_glyph.append(g); wf_col.append(c)
+    d["wf_glyph"] = np.stack(wf_glyph)
+    d["wf_colour"] = np.stack(wf_col)
+    # persistence: list of hits (trace i, x, y, colour) in draw order -> final grid of colour (last writer wins)
+    P.PERSISTENCE_HISTORY.clear()
+    ps = []
+    for r in rows[:14]:
+        scr = Scr(H, W)
+        P.draw_persistence(scr, r, None, 100e6, 2.4e6, 0, 0, None)
+        g = np.zeros((H - 4, W - 8), np.int8)  # 0 = empty, else colour pair
+        for call in scr.calls:
+            y, x, s, attr = call
+            if s == "*":
+                g[y - 2, x - 8] = attr >> 8
+        ps.append(g)
+    d["ps_colour"] = np.stack(ps)
+    save("caller", **d)
+
+
+if __name__ == "__main__":
+    gen_atan2()
+    gen_spectrum()
+    gen_nfm()
+    gen_am_ssb()
+    gen_power()
+    gen_scanner()
+    gen_caller()
