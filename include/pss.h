@@ -1,0 +1,131 @@
+/*
+ * pss.h — C ABI of libpss.so, the MI355X (gfx950) implementation of PySpecSDR's IQ -> spectrum + demod
+ * hot path.  Plain C: pointers and sizes only, no torch / HIP types in any signature.
+ *
+ * What this replaces.  The reference (xqtr/PySpecSDR, pure Python) has no FFI; its hot path is the module
+ * namespace `from signal_processing import *` (pyspecsdr.py:98).  Each entry point below names the
+ * reference callable it replaces; pyspecsdr_amd/signal_processing.py is the ctypes binding that presents
+ * those callables with their original Python signatures (INTEGRATION.md shows the two-line patch).
+ *
+ * Conventions
+ *   - iq: interleaved complex64 (I0,Q0,I1,Q1,...) — the SoapySDR CF32 buffer of SDRDevice.read_samples
+ *     (pyspecsdr.py:1885-1891).  Batched calls take n_frames contiguous frames of n samples each.
+ *   - `d_` parameters are DEVICE pointers (hipMalloc / torch tensors' data_ptr); `h_` are host pointers.
+ *   - All functions return 0 on success or a negative pss_status; pss_last_error() gives the text.
+ *     Nothing aborts or throws.  A missing GPU is an error (PSS_E_HIP), never a CPU fallback.
+ *   - A context is bound to one device and one stream; calls on a context are stream-ordered and must
+ *     not be issued concurrently from several threads.  Batched calls are asynchronous w.r.t. the host
+ *     unless stated; call pss_sync() (or sync the stream you supplied) before reading results.
+ */
+#ifndef PSS_H
+#define PSS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pss_ctx pss_ctx;
+
+typedef enum {
+    PSS_OK = 0,
+    PSS_E_ARG = -1,      /* bad argument (size not supported, null pointer, ...) */
+    PSS_E_HIP = -2,      /* HIP runtime error / no device */
+    PSS_E_PADLEN = -3,   /* NFM: n-1 <= 27 -> the reference raises ValueError (scipy sosfiltfilt padlen)   */
+    PSS_E_CUTOFF = -4,   /* NFM/SSB: cutoff >= Nyquist -> the reference raises ValueError (scipy firwin)  */
+    PSS_E_NOMEM = -5
+} pss_status;
+
+typedef enum { PSS_MODE_NFM = 0, PSS_MODE_AM = 1, PSS_MODE_USB = 2, PSS_MODE_LSB = 3 } pss_mode;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int pss_create(int device, pss_ctx **out);
+void pss_destroy(pss_ctx *ctx);
+/* Use an existing hipStream_t (passed as void*) instead of the context's own stream; NULL = default stream. */
+int pss_set_stream(pss_ctx *ctx, void *hip_stream);
+int pss_sync(pss_ctx *ctx);
+const char *pss_last_error(pss_ctx *ctx); /* ctx may be NULL: error of the last failed pss_create */
+int pss_device_count(void);
+
+/* ---- filter design (host side, pure C++; replaces the per-call SciPy design work) -------------- */
+/* scipy.signal.firwin(numtaps, cutoff) low-pass, Hamming window, cutoff normalised to Nyquist
+ * (signal_processing.py:107 and :203/:208).  Returns PSS_E_CUTOFF unless 0 < cutoff < 1. */
+int pss_design_firwin(int numtaps, double cutoff, double *taps);
+/* scipy.signal.cheby1(order, rp_db, wn, output='sos') low-pass, order even (decimate(): order 8, rp 0.05,
+ * wn 0.8/q — signal_processing.py:112 via scipy _signaltools.py:4831).  sos[order/2][6]. */
+int pss_design_cheby1_sos(int order, double rp_db, double wn, double *sos);
+/* scipy.signal.sosfilt_zi(sos).  zi[nsec][2]. */
+int pss_design_sosfilt_zi(const double *sos, int nsec, double *zi);
+/* butter(5, [300, 3000]/(22050/2), 'band', output='sos') — the fixed AM filter (signal_processing.py:188-191,
+ * :39-41; pyspecconst.py:3,5).  sos[5][6]. */
+int pss_am_bandpass_sos(double *sos);
+
+/* Override the designed coefficients for a sample rate (e.g. with tables captured from SciPy). Optional. */
+int pss_set_nfm_filters(pss_ctx *ctx, double fs, const double *taps65, const double *sos4x6, const double *zi4x2);
+int pss_set_ssb_taps(pss_ctx *ctx, double fs, const double *taps65);
+/* Read back the coefficients the context uses for fs (designing them on first use). */
+int pss_get_nfm_filters(pss_ctx *ctx, double fs, double *taps65, double *sos4x6, double *zi4x2);
+int pss_get_ssb_taps(pss_ctx *ctx, double fs, double *taps65);
+
+/* ---- batched device entry points --------------------------------------------------------------- */
+/* compute_fft (signal_processing.py:243-264) for n_frames frames: Hamming window, n_fft-point FFT (float64
+ * butterflies), fftshift, 10*log10(|X|^2 + 1e-10).  d_db: float32 [n_frames][n_fft].
+ * n_fft: power of two, 16 <= n_fft <= 1048576. */
+int pss_spectrum_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db);
+/* Caller-side post-process (pyspecsdr.py:2278-2283): 5-tap moving average ('valid') then clamp below
+ * median-10.  d_post: float32 [n_frames][n_fft-4]. */
+int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post);
+/* Inline scanner slice (pyspecsdr.py:2542-2552): unwindowed FFT, dB, peak, 20-dB-down bin count,
+ * bandwidth = count * fs / n_fft.  d_db float32 [n][n_fft] (may be NULL), d_peak float32 [n],
+ * d_bw float64 [n], d_count int32 [n] (may be NULL). */
+int pss_scan(pss_ctx *ctx, const float *d_iq, long n_slices, int n_fft, double fs, float *d_db, float *d_peak,
+             double *d_bw, int32_t *d_count);
+/* measure_signal_power (signal_processing.py:325-328): float32 [n_frames]. */
+int pss_power_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_power);
+/* adjust_gain (pyspecsdr.py:898-919) run sequentially over a series of power readings:
+ * d_idx_out[i] = gain index after reading i, starting from start_idx. */
+int pss_agc_steps(pss_ctx *ctx, const float *d_power, long n, int start_idx, int n_gains, int32_t *d_idx_out);
+
+/* demodulate_signal (signal_processing.py:220-240) for NFM / AM / USB / LSB, every frame independently
+ * (filter state reset and peak normalisation per frame, exactly like the reference's per-buffer calls).
+ *   n_out per frame = pss_demod_out_len(mode, n, fs): NFM ceil((n-1)/int(fs/22050)), AM/SSB n.
+ *   d_pcm   int16  [n_frames][n_out][2]  — np.int16(audio*32767), L=R  (io_manager.py:25-26); may be NULL
+ *   d_audio double [n_frames][n_out]     — the mono float64 audio before stereo duplication; may be NULL */
+int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, int16_t *d_pcm,
+              double *d_audio);
+int pss_demod_out_len(int mode, int n, double fs);
+
+/* Headline fused call: spectrum + NFM demod of the same frames (BASELINE.json metric). */
+int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db,
+                     int16_t *d_pcm);
+
+/* Waterfall / persistence quantisers over a ring of post-processed rows (pyspecsdr.py:1342-1406,
+ * :1512-1564).  d_rows float32 [n_rows][len], oldest first (n_rows <= 30 / <= 10).
+ * d_glyph/d_colour int8 [disp_h][disp_w] (-1 = not drawn; persistence: 0 = empty). */
+int pss_waterfall_cells(pss_ctx *ctx, const float *d_rows, int n_rows, int len, int disp_h, int disp_w,
+                        int8_t *d_glyph, int8_t *d_colour);
+int pss_persistence_cells(pss_ctx *ctx, const float *d_rows, int n_rows, int len, int disp_h, int disp_w,
+                          int8_t *d_colour);
+/* Same quantisers over float64 rows (the reference's rows are float64; used to check cell-exact parity). */
+int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int len, int disp_h, int disp_w,
+                            int8_t *d_glyph, int8_t *d_colour);
+int pss_persistence_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int len, int disp_h, int disp_w,
+                              int8_t *d_colour);
+
+/* ---- host-buffer convenience (single frame, synchronous; what the drop-in Python module calls) --- */
+int pss_h_compute_fft(pss_ctx *ctx, const float *h_iq, int n, double *h_db);
+int pss_h_demodulate(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,
+                     int16_t *h_pcm);
+int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float *h_power);
+
+/* Kernel-only time of the most recent batched call on this context, measured with HIP events on the
+ * context's stream (ms); negative if timing is disabled.  pss_enable_timing(ctx, 1) turns it on. */
+int pss_enable_timing(pss_ctx *ctx, int on);
+float pss_last_kernel_ms(pss_ctx *ctx);
+/* Per-kernel durations, "name=ms;name=ms;...", one entry per kernel launch since timing was enabled or since the
+ * previous pss_kernel_times() call (HIP events around each launch on the context's stream). */
+int pss_kernel_times(pss_ctx *ctx, char *buf, int buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

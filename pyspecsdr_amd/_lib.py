@@ -1,0 +1,71 @@
+"""ctypes loader for libpss.so — the C ABI declared in include/pss.h.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, creating an Engine raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpss.so")
+
+PSS_OK, PSS_E_ARG, PSS_E_HIP, PSS_E_PADLEN, PSS_E_CUTOFF, PSS_E_NOMEM = 0, -1, -2, -3, -4, -5
+MODE_NFM, MODE_AM, MODE_USB, MODE_LSB = 0, 1, 2, 3
+
+_p = C.c_void_p
+_SIGS = {
+    "pss_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
+    "pss_destroy": (None, [_p]),
+    "pss_set_stream": (C.c_int, [_p, _p]),
+    "pss_sync": (C.c_int, [_p]),
+    "pss_last_error": (C.c_char_p, [_p]),
+    "pss_device_count": (C.c_int, []),
+    "pss_design_firwin": (C.c_int, [C.c_int, C.c_double, _p]),
+    "pss_design_cheby1_sos": (C.c_int, [C.c_int, C.c_double, C.c_double, _p]),
+    "pss_design_sosfilt_zi": (C.c_int, [_p, C.c_int, _p]),
+    "pss_am_bandpass_sos": (C.c_int, [_p]),
+    "pss_set_nfm_filters": (C.c_int, [_p, C.c_double, _p, _p, _p]),
+    "pss_set_ssb_taps": (C.c_int, [_p, C.c_double, _p]),
+    "pss_get_nfm_filters": (C.c_int, [_p, C.c_double, _p, _p, _p]),
+    "pss_get_ssb_taps": (C.c_int, [_p, C.c_double, _p]),
+    "pss_spectrum_db": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
+    "pss_spectrum_post": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
+    "pss_scan": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p]),
+    "pss_power_db": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
+    "pss_agc_steps": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_int, _p]),
+    "pss_demod": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
+    "pss_demod_out_len": (C.c_int, [C.c_int, C.c_int, C.c_double]),
+    "pss_spectrum_nfm": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
+    "pss_waterfall_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "pss_persistence_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "pss_waterfall_cells_f64": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "pss_persistence_cells_f64": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "pss_h_compute_fft": (C.c_int, [_p, _p, C.c_int, _p]),
+    "pss_h_demodulate": (C.c_int, [_p, C.c_int, _p, C.c_int, C.c_double, _p, _p]),
+    "pss_h_measure_power": (C.c_int, [_p, _p, C.c_int, _p]),
+    "pss_enable_timing": (C.c_int, [_p, C.c_int]),
+    "pss_last_kernel_ms": (C.c_float, [_p]),
+    "pss_kernel_times": (C.c_int, [_p, C.c_char_p, C.c_int]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """Load libpss.so (built by pyspecsdr_amd.build).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m pyspecsdr_amd.build` (hipcc, gfx950). "
+                "pyspecsdr_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI and this table ever drift apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

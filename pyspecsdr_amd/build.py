@@ -1,0 +1,68 @@
+"""Build libpss.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+    python -m pyspecsdr_amd.build        # or: from pyspecsdr_amd.build import build; build()
+
+hipcc cross-compiles gfx950 without a GPU present.  The library lands at pyspecsdr_amd/libpss.so (git-ignored,
+but shipped to the GPU box with the working tree).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libpss.so")
+BUILD = os.path.join(HERE, "_build")
+
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+# pss_demod.hip carries the bit-exactness contract: no implicit fused multiply-adds.
+UNITS = [
+    ("pss_fft.hip", []),
+    ("pss_demod.hip", ["-ffp-contract=off"]),
+    ("pss_api.cpp", ["-x", "hip"]),
+    ("pss_design.cpp", ["-x", "hip", "-ffp-contract=off"]),
+]
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm; this package has no CPU fallback)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(BUILD, exist_ok=True)
+    cc = hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "pss.h"))
+    headers.append(os.path.abspath(__file__))
+    objs = []
+    for src, extra in UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(BUILD, src.rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [cc] + COMMON + extra + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+    if force or _stale(OUT, objs):
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

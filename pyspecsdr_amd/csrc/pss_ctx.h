@@ -1,0 +1,61 @@
+// pss_ctx.h — the context object behind the C ABI (include/pss.h): device, stream, cached tables, scratch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <array>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pss.h"
+
+struct PssNfmFilt {
+    double taps[65];
+    double sos[24];
+    double zi[8];
+};
+
+struct PssPairwisePlan {  // numpy pairwise-sum tree for one frame length (see pss_demod.hip)
+    int n_leaves = 0, n_nodes = 0, n_levels = 0;
+    int *d_leaf_off = nullptr, *d_leaf_len = nullptr, *d_node_l = nullptr, *d_node_r = nullptr, *d_level_start = nullptr;
+};
+
+struct pss_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    std::map<int, double2 *> tw;       // exp(-2 pi i k / N), k < N
+    std::map<int, double *> win;       // np.hamming(N)
+    std::map<double, PssNfmFilt> nfm;  // per sample rate
+    std::map<double, std::array<double, 65>> ssb;
+    std::map<int, PssPairwisePlan> plans;
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    bool timing = false;
+    int tdepth = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = -1.0f;
+    // per-kernel timing of the most recent outermost call (timing mode only)
+    struct KRec { const char *name; hipEvent_t e0, e1; };
+    std::vector<KRec> krecs;   // event pool (grown on demand, reused)
+    int kused = 0;
+};
+
+int pss_fail(pss_ctx *ctx, int code, const std::string &msg);
+int pss_hip_check(pss_ctx *ctx, hipError_t e, const char *what);
+int pss_ensure_scratch(pss_ctx *ctx, size_t bytes);
+void pss_time_begin(pss_ctx *ctx);
+void pss_time_end(pss_ctx *ctx);
+// bracket ONE kernel launch with events on the context's stream (no-ops unless timing is enabled)
+void pss_kernel_begin(pss_ctx *ctx, const char *name);
+void pss_kernel_end(pss_ctx *ctx);
+
+#define PSS_HIP(ctx, call)                                         \
+    do {                                                           \
+        int _r = pss_hip_check((ctx), (call), #call);              \
+        if (_r) return _r;                                         \
+    } while (0)
+
+// implemented in pss_fft.hip
+int pss_fft_tables(pss_ctx *ctx, int n, const double2 **tw, const double **win);

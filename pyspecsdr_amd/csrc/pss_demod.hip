@@ -1,0 +1,692 @@
+// pss_demod.hip — demodulation kernels for gfx950 (NFM / AM / SSB), AGC power, int16 PCM.
+//
+// Reference lines replaced: signal_processing.py:91-116 (demodulate_nfm), :179-195 (demodulate_am),
+// :198-217 (demodulate_ssb), :325-328 (measure_signal_power), :83-88 (mono_to_stereo),
+// io_manager.py:25-26 (int16 conversion), pyspecsdr.py:898-919 (adjust_gain).
+//
+// Bit-exactness contract: this translation unit is compiled with -ffp-contract=off; every fused
+// multiply-add is an explicit fma that the reference's native code (NumPy AVX-512 loops, SVML, OpenBLAS
+// ddot/zdot) also executes, and the IIR recurrences use SciPy's exact un-fused association.  The IIR is a
+// serial recurrence in time, so it runs ONE LANE PER FRAME (64 frames per wavefront, data staged so that
+// every global access is a coalesced 512-byte row); everything else is sample-parallel.
+#include <hip/hip_runtime.h>
+#pragma clang fp contract(off)
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "pss_ctx.h"
+#include "pss_device.h"
+
+namespace {
+
+using namespace pss;
+
+constexpr int TPB = 256;
+constexpr int TILE = 64;   // frames per wavefront in the lane-per-frame kernels
+constexpr int EDGE = 27;   // sosfiltfilt: 3 * (2*4 + 1)
+constexpr int RING = 128;  // discriminator ring per frame (64 history + 64 new)
+constexpr int RSTR = 129;  // padded row stride (floats) -> conflict-free column reads
+
+struct NfmCoef {
+    Biquad s[4];
+    double zi[8];
+};
+struct AmCoef {
+    Biquad s[5];
+};
+
+__constant__ double c_taps_rev[65];  // taps[64 - j]
+__constant__ double c_taps[65];
+
+// ---------------------------------------------------------------------------------------------------
+// NFM front end: discriminator (float32, signal_processing.py:94,97) + 65-tap FIR (float64, :108).
+// One workgroup = one tile of 64 frames; time is walked in chunks of 64 samples.  Step A fills the LDS
+// ring [frame][time] with coalesced reads along time; step B lets lane = frame compute the FIR in the
+// reference's exact accumulation order and writes u[] TRANSPOSED ([tile][time][lane]) for the IIR kernel.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_nfm_front(const float2 *__restrict__ iq, double *__restrict__ U, int n,
+                                                   long n_frames, float kscale, int swapped)
+{
+    __shared__ float ring[TILE * RSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long tile = blockIdx.x;
+    const int M = n - 1;
+    const long L = (long)M + 2 * EDGE;
+    double *Ut = U + (size_t)tile * L * TILE;
+    for (int i0 = 0; i0 < M; i0 += 64) {
+        // step A: 64 frames x 64 samples; a wavefront reads 512 contiguous bytes of one frame
+        for (int rep = 0; rep < 16; rep++) {
+            int fl = rep * 4 + wave;
+            long f = tile * TILE + fl;
+            int i = i0 + lane;
+            float d = 0.0f;
+            if (f < n_frames && i < M) {
+                const float2 *x = iq + (size_t)f * n + i;
+                d = disc_sample(x[1], x[0], kscale, swapped != 0);
+            }
+            ring[fl * RSTR + (i & (RING - 1))] = d;
+        }
+        __syncthreads();
+        // step B: lane = frame; wave w handles times i0 + 16 w .. + 15
+        const float *row = ring + lane * RSTR;
+        for (int k = 0; k < 16; k++) {
+            int i = i0 + wave * 16 + k;
+            if (i >= M) break;
+            double u;
+            if (M <= 65) {  // np.convolve does not swap operands: dot runs over ascending tap index
+                u = ddot_skx([&](int j) { return c_taps[j]; }, [&](int j) { return (double)row[(i - j) & (RING - 1)]; }, i + 1);
+            } else if (i >= 64) {
+                const int b = i - 64;
+                u = ddot_skx([&](int j) { return (double)row[(b + j) & (RING - 1)]; }, [&](int j) { return c_taps_rev[j]; }, 65);
+            } else {
+                const int o = 64 - i;
+                u = ddot_skx([&](int j) { return (double)row[j]; }, [&](int j) { return c_taps_rev[o + j]; }, i + 1);
+            }
+            Ut[(size_t)(EDGE + i) * TILE + lane] = u;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// NFM back end: scipy.signal.decimate(u, q) = sosfiltfilt(cheby1 sos) then [::q]  (signal_processing.py:112),
+// peak normalisation (:115), stereo duplication (:116) and int16 conversion (io_manager.py:26).
+// One wavefront per tile, lane = frame.  Forward pass over the odd extension writes y_fwd to Y, the
+// backward pass reads it in reverse and keeps every q-th sample.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, double *__restrict__ Y,
+                                                  double *__restrict__ A, int n, int q, int n_out, long n_frames,
+                                                  NfmCoef c, int16_t *__restrict__ pcm, double *__restrict__ audio)
+{
+    const int lane = threadIdx.x;
+    const long tile = blockIdx.x;
+    const long f = tile * TILE + lane;
+    const int M = n - 1;
+    const long L = (long)M + 2 * EDGE;
+    const double *Ut = U + (size_t)tile * L * TILE + lane;
+    double *Yt = Y + (size_t)tile * L * TILE + lane;
+    double *At = A + (size_t)tile * n_out * TILE + lane;
+#define UAT(p) Ut[(size_t)(p) * TILE]
+#define YAT(p) Yt[(size_t)(p) * TILE]
+    const double u0 = UAT(EDGE), uL = UAT(EDGE + M - 1);
+    const double two_u0 = __dmul_rn(2.0, u0), two_uL = __dmul_rn(2.0, uL);
+    double z[8];
+    {
+        double x0 = __dsub_rn(two_u0, UAT(EDGE + EDGE));  // ext[0] = 2 u[0] - u[27]
+#pragma unroll
+        for (int i = 0; i < 8; i++) z[i] = __dmul_rn(c.zi[i], x0);
+    }
+    auto cascade = [&](double x) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) x = biquad_step(c.s[s], x, z[2 * s], z[2 * s + 1]);
+        return x;
+    };
+#pragma unroll 4
+    for (int p = 0; p < EDGE; p++) YAT(p) = cascade(__dsub_rn(two_u0, UAT(2 * EDGE - p)));
+#pragma unroll 4
+    for (long p = EDGE; p < EDGE + M; p++) YAT(p) = cascade(UAT(p));
+#pragma unroll 4
+    for (int k = 0; k < EDGE; k++) YAT(EDGE + M + k) = cascade(__dsub_rn(two_uL, UAT(EDGE + M - 2 - k)));
+    // backward pass (the reversed sequence); y_0 of sosfiltfilt = last forward output
+    {
+        double yl = YAT(L - 1);
+#pragma unroll
+        for (int i = 0; i < 8; i++) z[i] = __dmul_rn(c.zi[i], yl);
+    }
+    double mx = 0.0;
+    bool nan = false;
+    long next = EDGE + (long)(n_out - 1) * q;  // largest kept position
+    int j = n_out - 1;
+#pragma unroll 4
+    for (long p = L - 1; p >= EDGE; p--) {
+        double v = cascade(YAT(p));
+        if (p == next) {
+            At[(size_t)j * TILE] = v;
+            double av = fabs(v);
+            nan = nan || (av != av);
+            mx = av > mx ? av : mx;
+            next -= q;
+            j--;
+        }
+    }
+    if (nan) mx = __builtin_nan("");
+    if (f < n_frames) {
+        for (int k = 0; k < n_out; k++) {
+            double a = __dmul_rn(__ddiv_rn(At[(size_t)k * TILE], mx), 0.95);  // audio / max|audio| * 0.95
+            if (audio) audio[(size_t)f * n_out + k] = a;
+            if (pcm) {
+                uint16_t s = (uint16_t)pcm16(a);
+                reinterpret_cast<uint32_t *>(pcm)[(size_t)f * n_out + k] = (uint32_t)s | ((uint32_t)s << 16);
+            }
+        }
+    }
+#undef UAT
+#undef YAT
+}
+
+// ---------------------------------------------------------------------------------------------------
+// numpy float32 pairwise mean of |x| (KIND 1, AM: signal_processing.py:185) or |x|^2 (KIND 0, power: :327).
+// The reduction tree (block 128, 8 accumulators, halves rounded down to multiples of 8) is generated on
+// the host for the frame length and replayed level by level; one workgroup per frame.
+// ---------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(TPB) void k_pairwise(const float2 *__restrict__ iq, int n, long n_frames,
+                                                  const int *__restrict__ leaf_off, const int *__restrict__ leaf_len,
+                                                  int n_leaves, const int *__restrict__ node_l,
+                                                  const int *__restrict__ node_r, const int *__restrict__ level_start,
+                                                  int n_levels, float *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *val = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x;
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const float2 *x = iq + (size_t)f * n;
+        auto elem = [&](int i) {
+            float2 v = x[i];
+            float m = cabsf_np(v.x, v.y);
+            return KIND == 0 ? __fmul_rn(m, m) : m;
+        };
+        for (int l = tid; l < n_leaves; l += TPB) {
+            const int off = leaf_off[l], len = leaf_len[l];
+            float res;
+            if (len < 8) {
+                res = 0.0f;
+                for (int i = 0; i < len; i++) res = __fadd_rn(res, elem(off + i));
+            } else {
+                float r[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) r[k] = elem(off + k);
+                int i;
+                for (i = 8; i < len - (len % 8); i += 8) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) r[k] = __fadd_rn(r[k], elem(off + i + k));
+                }
+                res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                                __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+                for (; i < len; i++) res = __fadd_rn(res, elem(off + i));
+            }
+            val[l] = res;
+        }
+        __syncthreads();
+        for (int lv = 0; lv < n_levels; lv++) {
+            for (int k = level_start[lv] + tid; k < level_start[lv + 1]; k += TPB)
+                val[n_leaves + k] = __fadd_rn(val[node_l[k]], val[node_r[k]]);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            float sum = val[n_leaves + level_start[n_levels] - 1];
+            if (level_start[n_levels] == 0) sum = val[0];
+            float mean = __fdiv_rn(sum, (float)n);
+            if (KIND == 0) out[f] = 10.0f * log10f(__fadd_rn(mean, 1e-10f));  // 10*log10(power + 1e-10), float32
+            else out[f] = mean;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// AM: envelope - mean (float32) -> 5-section Butterworth band-pass, forward only, zero state (float64).
+// One wavefront per tile of 64 frames, lane = frame; 64-sample chunks staged through LDS both ways so
+// global reads (IQ) and writes (y) are coalesced rows.  Tracks max|y| per frame.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TILE) void k_am_iir(const float2 *__restrict__ iq, const float *__restrict__ mu,
+                                                 double *__restrict__ Yf, double *__restrict__ mxout, int n,
+                                                 long n_frames, AmCoef c)
+{
+    __shared__ float ebuf[TILE * 65];
+    __shared__ double ybuf[TILE * 65];
+    const int lane = threadIdx.x;
+    const long tile = blockIdx.x;
+    double z[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) z[i] = 0.0;
+    double mx = 0.0;
+    bool nan = false;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        for (int fl = 0; fl < TILE; fl++) {
+            long f = tile * TILE + fl;
+            int i = i0 + lane;
+            float cv = 0.0f;
+            if (f < n_frames && i < n) {
+                float2 v = iq[(size_t)f * n + i];
+                cv = __fsub_rn(cabsf_np(v.x, v.y), mu[f]);  // envelope - np.mean(envelope), float32
+            }
+            ebuf[fl * 65 + lane] = cv;
+        }
+        __syncthreads();
+        const int cnt = (n - i0) < 64 ? (n - i0) : 64;
+        for (int t = 0; t < cnt; t++) {
+            double x = (double)ebuf[lane * 65 + t];
+#pragma unroll
+            for (int s = 0; s < 5; s++) x = biquad_step(c.s[s], x, z[2 * s], z[2 * s + 1]);
+            double av = fabs(x);
+            nan = nan || (av != av);
+            mx = av > mx ? av : mx;
+            ybuf[lane * 65 + t] = x;
+        }
+        __syncthreads();
+        for (int fl = 0; fl < TILE; fl++) {
+            long f = tile * TILE + fl;
+            int i = i0 + lane;
+            if (f < n_frames && i < n) Yf[(size_t)f * n + i] = ybuf[fl * 65 + lane];
+        }
+        __syncthreads();
+    }
+    long f = tile * TILE + lane;
+    if (f < n_frames) mxout[f] = nan ? __builtin_nan("") : mx;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SSB: real part of the complex 65-tap FIR (signal_processing.py:204/209; zdotu accumulation order).
+// hilbert(real(z)).real == real(z) up to 1e-16 round-off, so the analytic-signal round trip is not run.
+// Sample-parallel; per-frame max|y| via atomicMax on the IEEE bit pattern (NaN sorts above +inf).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_ssb_fir(const float2 *__restrict__ iq, double *__restrict__ Yf,
+                                                 unsigned long long *__restrict__ mxbits, int n, long n_frames,
+                                                 int chunks_per_frame)
+{
+    constexpr int CH = 1024;
+    __shared__ float xr[CH + 64];
+    __shared__ unsigned long long wmax[TPB / 64];
+    const int tid = threadIdx.x;
+    const long total = n_frames * chunks_per_frame;
+    for (long w = blockIdx.x; w < total; w += gridDim.x) {
+        const long f = w / chunks_per_frame;
+        const int i0 = (int)(w % chunks_per_frame) * CH;
+        const float2 *x = iq + (size_t)f * n;
+        for (int k = tid; k < CH + 64; k += TPB) {
+            int i = i0 - 64 + k;
+            xr[k] = (i >= 0 && i < n) ? x[i].x : 0.0f;
+        }
+        __syncthreads();
+        unsigned long long m = 0;
+        for (int k = tid; k < CH; k += TPB) {
+            int i = i0 + k;
+            if (i >= n) break;
+            double y;
+            if (n <= 65) {
+                y = zdot_re_skx([&](int j) { return c_taps[j]; }, [&](int j) { return (double)xr[64 + k - j]; }, i + 1);
+            } else if (i >= 64) {
+                y = zdot_re_skx([&](int j) { return (double)xr[k + j]; }, [&](int j) { return c_taps_rev[j]; }, 65);
+            } else {
+                const int o = 64 - i;
+                y = zdot_re_skx([&](int j) { return (double)xr[64 - i0 + j]; }, [&](int j) { return c_taps_rev[o + j]; }, i + 1);
+            }
+            Yf[(size_t)f * n + i] = y;
+            unsigned long long b = (unsigned long long)__double_as_longlong(fabs(y));
+            m = b > m ? b : m;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned long long o = __shfl_xor(m, off);
+            m = o > m ? o : m;
+        }
+        if ((tid & 63) == 0) wmax[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 1; k < TPB / 64; k++) m = wmax[k] > m ? wmax[k] : m;
+            atomicMax(&mxbits[f], m);
+        }
+        __syncthreads();
+    }
+}
+
+// audio = y / max|y| * 0.95  -> float64 mono and/or int16 stereo (AM :194, SSB :216, io_manager.py:26)
+__global__ __launch_bounds__(TPB) void k_finalize(const double *__restrict__ Yf, const double *__restrict__ mx, int n,
+                                                  long n_frames, int16_t *__restrict__ pcm, double *__restrict__ audio)
+{
+    const size_t total = (size_t)n_frames * n;
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
+        long f = (long)(idx / n);
+        double a = __dmul_rn(__ddiv_rn(Yf[idx], mx[f]), 0.95);
+        if (audio) audio[idx] = a;
+        if (pcm) {
+            uint16_t s = (uint16_t)pcm16(a);
+            reinterpret_cast<uint32_t *>(pcm)[idx] = (uint32_t)s | ((uint32_t)s << 16);
+        }
+    }
+}
+
+// adjust_gain (pyspecsdr.py:898-919), sequential by nature.
+__global__ void k_agc(const float *__restrict__ power, long n, int idx, int n_gains, int *__restrict__ out)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    for (long i = 0; i < n; i++) {
+        float diff = __fsub_rn(-30.0f, power[i]);
+        if (!(fabsf(diff) < 2.0f)) {
+            if (diff > 0) { idx += 1; if (idx > n_gains - 1) idx = n_gains - 1; }
+            else { idx -= 1; if (idx < 0) idx = 0; }
+        }
+        out[i] = idx;
+    }
+}
+
+// ---- host helpers --------------------------------------------------------------------------------
+
+void plan_rec(int off, int n, std::vector<int> &lo, std::vector<int> &ll, std::vector<int> &nl, std::vector<int> &nr,
+              std::vector<int> &lev, int &slot, int &level)
+{
+    if (n <= 128) {
+        lo.push_back(off);
+        ll.push_back(n);
+        slot = (int)lo.size() - 1;  // leaf slot (internal nodes are renumbered later)
+        level = 0;
+        return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    int sl, sr, l1, l2;
+    plan_rec(off, n2, lo, ll, nl, nr, lev, sl, l1);
+    plan_rec(off + n2, n - n2, lo, ll, nl, nr, lev, sr, l2);
+    nl.push_back(sl);
+    nr.push_back(sr);
+    level = 1 + (l1 > l2 ? l1 : l2);
+    lev.push_back(level);
+    slot = -(int)nl.size();  // internal node id k encoded as -(k+1)
+}
+
+int get_plan(pss_ctx *ctx, int n, PssPairwisePlan **out)
+{
+    auto it = ctx->plans.find(n);
+    if (it == ctx->plans.end()) {
+        std::vector<int> lo, ll, nl, nr, lev;
+        int slot, level;
+        plan_rec(0, n, lo, ll, nl, nr, lev, slot, level);
+        const int nleaf = (int)lo.size(), nnode = (int)nl.size();
+        // order internal nodes by level; remap ids
+        std::vector<int> order(nnode), newid(nnode), lstart(level + 2, 0);
+        int pos = 0;
+        for (int lv = 1; lv <= level; lv++) {
+            lstart[lv - 1] = pos;
+            for (int k = 0; k < nnode; k++)
+                if (lev[k] == lv) { order[pos] = k; newid[k] = pos; pos++; }
+        }
+        lstart[level] = pos;
+        auto slot_of = [&](int s) { return s >= 0 ? s : nleaf + newid[-s - 1]; };
+        std::vector<int> L(nnode ? nnode : 1), R(nnode ? nnode : 1);
+        for (int k = 0; k < nnode; k++) { L[k] = slot_of(nl[order[k]]); R[k] = slot_of(nr[order[k]]); }
+        PssPairwisePlan p;
+        p.n_leaves = nleaf; p.n_nodes = nnode; p.n_levels = level;
+        PSS_HIP(ctx, hipMalloc(&p.d_leaf_off, sizeof(int) * nleaf));
+        PSS_HIP(ctx, hipMalloc(&p.d_leaf_len, sizeof(int) * nleaf));
+        PSS_HIP(ctx, hipMalloc(&p.d_node_l, sizeof(int) * L.size()));
+        PSS_HIP(ctx, hipMalloc(&p.d_node_r, sizeof(int) * R.size()));
+        PSS_HIP(ctx, hipMalloc(&p.d_level_start, sizeof(int) * (level + 1)));
+        PSS_HIP(ctx, hipMemcpy(p.d_leaf_off, lo.data(), sizeof(int) * nleaf, hipMemcpyHostToDevice));
+        PSS_HIP(ctx, hipMemcpy(p.d_leaf_len, ll.data(), sizeof(int) * nleaf, hipMemcpyHostToDevice));
+        PSS_HIP(ctx, hipMemcpy(p.d_node_l, L.data(), sizeof(int) * L.size(), hipMemcpyHostToDevice));
+        PSS_HIP(ctx, hipMemcpy(p.d_node_r, R.data(), sizeof(int) * R.size(), hipMemcpyHostToDevice));
+        PSS_HIP(ctx, hipMemcpy(p.d_level_start, lstart.data(), sizeof(int) * (level + 1), hipMemcpyHostToDevice));
+        ctx->plans[n] = p;
+    }
+    *out = &ctx->plans[n];
+    return PSS_OK;
+}
+
+template <int KIND>
+int launch_pairwise(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out)
+{
+    PssPairwisePlan *p;
+    int r = get_plan(ctx, n, &p);
+    if (r) return r;
+    size_t lds = sizeof(float) * (size_t)(p->n_leaves + p->n_nodes + 1);
+    if (lds > 150 * 1024) return pss_fail(ctx, PSS_E_ARG, "frame too long for the pairwise-mean kernel");
+    auto kern = k_pairwise<KIND>;
+    if (lds > 64 * 1024)
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+    long g = n_frames < 8192 ? n_frames : 8192;
+    pss_kernel_begin(ctx, "k_pairwise");
+    hipLaunchKernelGGL(kern, dim3((int)g), dim3(TPB), lds, ctx->stream, reinterpret_cast<const float2 *>(d_iq), n,
+                       n_frames, p->d_leaf_off, p->d_leaf_len, p->n_leaves, p->d_node_l, p->d_node_r, p->d_level_start,
+                       p->n_levels, d_out);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_pairwise launch");
+}
+
+int nfm_filters(pss_ctx *ctx, double fs, PssNfmFilt **out)
+{
+    auto it = ctx->nfm.find(fs);
+    if (it == ctx->nfm.end()) {
+        PssNfmFilt f;
+        int q = (int)(fs / 22050.0);
+        if (q < 1) return pss_fail(ctx, PSS_E_ARG, "sample rate below 22050 Hz: decimation factor int(fs/22050) is 0");
+        int r = pss_design_firwin(65, 15000.0 / (fs / 2.0), f.taps);
+        if (r) return pss_fail(ctx, r, "firwin: invalid cutoff frequency (15 kHz must be below fs/2)");
+        r = pss_design_cheby1_sos(8, 0.05, 0.8 / q, f.sos);
+        if (r) return pss_fail(ctx, r, "cheby1 design failed");
+        pss_design_sosfilt_zi(f.sos, 4, f.zi);
+        ctx->nfm[fs] = f;
+    }
+    *out = &ctx->nfm[fs];
+    return PSS_OK;
+}
+
+int ssb_taps(pss_ctx *ctx, double fs, double **out)
+{
+    auto it = ctx->ssb.find(fs);
+    if (it == ctx->ssb.end()) {
+        std::array<double, 65> t;
+        int r = pss_design_firwin(65, 3000.0 / fs, t.data());
+        if (r) return pss_fail(ctx, r, "firwin: invalid cutoff frequency (3000/fs must be in (0,1))");
+        ctx->ssb[fs] = t;
+    }
+    *out = ctx->ssb[fs].data();
+    return PSS_OK;
+}
+
+int upload_taps(pss_ctx *ctx, const double *taps)
+{
+    double rev[65];
+    for (int j = 0; j < 65; j++) rev[j] = taps[64 - j];
+    PSS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_taps), taps, sizeof(double) * 65, 0, hipMemcpyHostToDevice, ctx->stream));
+    PSS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_taps_rev), rev, sizeof(double) * 65, 0, hipMemcpyHostToDevice, ctx->stream));
+    return PSS_OK;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" int pss_demod_out_len(int mode, int n, double fs)
+{
+    if (n <= 0) return 0;
+    if (mode == PSS_MODE_NFM) {
+        int q = (int)(fs / 22050.0);
+        if (q < 1) return PSS_E_ARG;
+        return (n - 1 + q - 1) / q;
+    }
+    if (mode == PSS_MODE_AM || mode == PSS_MODE_USB || mode == PSS_MODE_LSB) return n;
+    return PSS_E_ARG;
+}
+
+extern "C" int pss_power_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_power)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!d_iq || !d_power || n < 1 || n_frames < 0) return pss_fail(ctx, PSS_E_ARG, "bad power arguments");
+    if (n_frames == 0) return PSS_OK;
+    pss_time_begin(ctx);
+    int r = launch_pairwise<0>(ctx, d_iq, n_frames, n, d_power);
+    pss_time_end(ctx);
+    return r;
+}
+
+extern "C" int pss_agc_steps(pss_ctx *ctx, const float *d_power, long n, int start_idx, int n_gains, int32_t *d_idx_out)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!d_power || !d_idx_out || n < 0 || n_gains < 1) return pss_fail(ctx, PSS_E_ARG, "bad agc arguments");
+    if (n == 0) return PSS_OK;
+    pss_kernel_begin(ctx, "k_agc");
+    hipLaunchKernelGGL(k_agc, dim3(1), dim3(1), 0, ctx->stream, d_power, n, start_idx, n_gains, d_idx_out);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_agc launch");
+}
+
+extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, int16_t *d_pcm,
+                         double *d_audio)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!d_iq || n_frames < 0 || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad demod arguments");
+    if (!d_pcm && !d_audio) return pss_fail(ctx, PSS_E_ARG, "both outputs are null");
+    const long tiles = (n_frames + TILE - 1) / TILE;
+    if (mode == PSS_MODE_NFM) {
+        if (n - 1 <= EDGE)
+            return pss_fail(ctx, PSS_E_PADLEN, "The length of the input vector x must be greater than padlen, which is 27.");
+        PssNfmFilt *flt;
+        int r = nfm_filters(ctx, fs, &flt);
+        if (r) return r;
+        if (n_frames == 0) return PSS_OK;
+        const int q = (int)(fs / 22050.0);
+        const int n_out = (n - 1 + q - 1) / q;
+        const long L = (long)(n - 1) + 2 * EDGE;
+        const size_t szU = align256((size_t)tiles * L * TILE * sizeof(double));
+        const size_t szA = align256((size_t)tiles * n_out * TILE * sizeof(double));
+        r = pss_ensure_scratch(ctx, 2 * szU + szA);
+        if (r) return r;
+        double *U = reinterpret_cast<double *>(ctx->scratch);
+        double *Y = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + szU);
+        double *A = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + 2 * szU);
+        r = upload_taps(ctx, flt->taps);
+        if (r) return r;
+        NfmCoef c;
+        for (int s = 0; s < 4; s++) {
+            const double *row = flt->sos + 6 * s;
+            c.s[s] = Biquad{row[0], row[1], row[2], row[4], row[5]};
+        }
+        for (int i = 0; i < 8; i++) c.zi[i] = flt->zi[i];
+        const float kscale = (float)(fs / (2.0 * M_PI));          // python float -> float32 scalar (:97)
+        const int swapped = ((long)(n - 1) * 8 >= 262144) ? 1 : 0;  // NumPy temporary elision threshold
+        pss_time_begin(ctx);
+        pss_kernel_begin(ctx, "k_nfm_front");
+        hipLaunchKernelGGL(k_nfm_front, dim3((unsigned)tiles), dim3(TPB), 0, ctx->stream,
+                           reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, kscale, swapped);
+        pss_kernel_end(ctx);
+        pss_kernel_begin(ctx, "k_nfm_iir");
+        hipLaunchKernelGGL(k_nfm_iir, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, U, Y, A, n, q, n_out, n_frames, c,
+                           d_pcm, d_audio);
+        pss_kernel_end(ctx);
+        pss_time_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "nfm launch");
+    }
+    if (mode == PSS_MODE_AM) {
+        if (n_frames == 0) return PSS_OK;
+        const size_t szY = align256((size_t)n_frames * n * sizeof(double));
+        const size_t szM = align256((size_t)n_frames * sizeof(double));
+        const size_t szMu = align256((size_t)n_frames * sizeof(float));
+        int r = pss_ensure_scratch(ctx, szY + szM + szMu);
+        if (r) return r;
+        char *base = reinterpret_cast<char *>(ctx->scratch);
+        double *Yf = reinterpret_cast<double *>(base);
+        double *mx = reinterpret_cast<double *>(base + szY);
+        float *mu = reinterpret_cast<float *>(base + szY + szM);
+        double sos[30];
+        pss_am_bandpass_sos(sos);
+        AmCoef c;
+        for (int s = 0; s < 5; s++) c.s[s] = Biquad{sos[6 * s], sos[6 * s + 1], sos[6 * s + 2], sos[6 * s + 4], sos[6 * s + 5]};
+        pss_time_begin(ctx);
+        r = launch_pairwise<1>(ctx, d_iq, n_frames, n, mu);
+        if (r) return r;
+        pss_kernel_begin(ctx, "k_am_iir");
+        hipLaunchKernelGGL(k_am_iir, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, reinterpret_cast<const float2 *>(d_iq),
+                           mu, Yf, mx, n, n_frames, c);
+        pss_kernel_end(ctx);
+        size_t total = (size_t)n_frames * n;
+        size_t g = (total + TPB - 1) / TPB;
+        if (g > 16384) g = 16384;
+        pss_kernel_begin(ctx, "k_finalize");
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)g), dim3(TPB), 0, ctx->stream, Yf, mx, n, n_frames, d_pcm, d_audio);
+        pss_kernel_end(ctx);
+        pss_time_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "am launch");
+    }
+    if (mode == PSS_MODE_USB || mode == PSS_MODE_LSB) {
+        double *taps;
+        int r = ssb_taps(ctx, fs, &taps);
+        if (r) return r;
+        if (n_frames == 0) return PSS_OK;
+        const size_t szY = align256((size_t)n_frames * n * sizeof(double));
+        const size_t szM = align256((size_t)n_frames * sizeof(double));
+        r = pss_ensure_scratch(ctx, szY + szM);
+        if (r) return r;
+        char *base = reinterpret_cast<char *>(ctx->scratch);
+        double *Yf = reinterpret_cast<double *>(base);
+        unsigned long long *mxb = reinterpret_cast<unsigned long long *>(base + szY);
+        r = upload_taps(ctx, taps);
+        if (r) return r;
+        pss_time_begin(ctx);
+        PSS_HIP(ctx, hipMemsetAsync(mxb, 0, (size_t)n_frames * sizeof(double), ctx->stream));
+        const int cpf = (n + 1023) / 1024;
+        long total = n_frames * cpf;
+        long g = total < 16384 ? total : 16384;
+        pss_kernel_begin(ctx, "k_ssb_fir");
+        hipLaunchKernelGGL(k_ssb_fir, dim3((unsigned)g), dim3(TPB), 0, ctx->stream, reinterpret_cast<const float2 *>(d_iq),
+                           Yf, mxb, n, n_frames, cpf);
+        pss_kernel_end(ctx);
+        size_t tot = (size_t)n_frames * n;
+        size_t g2 = (tot + TPB - 1) / TPB;
+        if (g2 > 16384) g2 = 16384;
+        pss_kernel_begin(ctx, "k_finalize");
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)g2), dim3(TPB), 0, ctx->stream, Yf,
+                           reinterpret_cast<const double *>(mxb), n, n_frames, d_pcm, d_audio);
+        pss_kernel_end(ctx);
+        pss_time_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "ssb launch");
+    }
+    return pss_fail(ctx, PSS_E_ARG, "unknown demodulation mode");
+}
+
+extern "C" int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db,
+                                int16_t *d_pcm)
+{
+    if (!ctx) return PSS_E_ARG;
+    pss_time_begin(ctx);  // nested begin/end pairs inside the two calls are no-ops
+    int r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+    if (!r) r = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
+    pss_time_end(ctx);
+    return r;
+}
+
+extern "C" int pss_set_nfm_filters(pss_ctx *ctx, double fs, const double *taps65, const double *sos4x6, const double *zi4x2)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!taps65 || !sos4x6 || !zi4x2) return pss_fail(ctx, PSS_E_ARG, "null coefficient table");
+    PssNfmFilt f;
+    memcpy(f.taps, taps65, sizeof(f.taps));
+    memcpy(f.sos, sos4x6, sizeof(f.sos));
+    memcpy(f.zi, zi4x2, sizeof(f.zi));
+    ctx->nfm[fs] = f;
+    return PSS_OK;
+}
+
+extern "C" int pss_set_ssb_taps(pss_ctx *ctx, double fs, const double *taps65)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!taps65) return pss_fail(ctx, PSS_E_ARG, "null coefficient table");
+    std::array<double, 65> t;
+    memcpy(t.data(), taps65, sizeof(double) * 65);
+    ctx->ssb[fs] = t;
+    return PSS_OK;
+}
+
+extern "C" int pss_get_nfm_filters(pss_ctx *ctx, double fs, double *taps65, double *sos4x6, double *zi4x2)
+{
+    if (!ctx) return PSS_E_ARG;
+    PssNfmFilt *f;
+    int r = nfm_filters(ctx, fs, &f);
+    if (r) return r;
+    if (taps65) memcpy(taps65, f->taps, sizeof(f->taps));
+    if (sos4x6) memcpy(sos4x6, f->sos, sizeof(f->sos));
+    if (zi4x2) memcpy(zi4x2, f->zi, sizeof(f->zi));
+    return PSS_OK;
+}
+
+extern "C" int pss_get_ssb_taps(pss_ctx *ctx, double fs, double *taps65)
+{
+    if (!ctx) return PSS_E_ARG;
+    double *t;
+    int r = ssb_taps(ctx, fs, &t);
+    if (r) return r;
+    if (taps65) memcpy(taps65, t, sizeof(double) * 65);
+    return PSS_OK;
+}

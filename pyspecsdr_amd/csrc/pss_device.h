@@ -1,0 +1,204 @@
+// pss_device.h — device-side float32/float64 primitives shared by the HIP kernels (gfx950).
+//
+// These are the bit-level building blocks that make the int16 audio identical to the reference's
+// NumPy/SciPy path (xqtr/PySpecSDR signal_processing.py).  Every multiply-add that the reference's
+// native code fuses is written as an explicit fma(); the translation unit is compiled with
+// -ffp-contract=off so nothing else is fused.
+#pragma once
+#include <hip/hip_runtime.h>
+#pragma clang fp contract(off)
+#include <stdint.h>
+
+namespace pss {
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// VRCP14PS bit-exact model (x86 AVX-512 reciprocal approximation): 64-segment piecewise-linear in the
+// top 16 mantissa bits.  Table derived and exhaustively verified by tools/derive_rcp14.c.
+__constant__ uint32_t RCP14_A[64] = {
+    67107072u, 66074112u, 65073664u, 64102400u, 63159040u, 62244608u, 61354752u, 60491264u,
+    59650560u, 58833920u, 58038272u, 57264640u, 56511488u, 55778048u, 55062784u, 54365184u,
+    53686016u, 53022976u, 52377088u, 51745536u, 51129600u, 50528000u, 49940992u, 49366272u,
+    48805376u, 48257024u, 47721728u, 47196672u, 46683904u, 46181632u, 45690368u, 45209344u,
+    44739072u, 44277504u, 43826176u, 43382784u, 42949120u, 42523904u, 42106880u, 41698048u,
+    41297920u, 40903936u, 40517888u, 40139520u, 39768320u, 39402752u, 39044608u, 38692864u,
+    38347520u, 38008064u, 37674496u, 37347840u, 37025280u, 36708608u, 36398080u, 36091648u,
+    35791360u, 35495680u, 35204352u, 34919168u, 34638080u, 34361088u, 34088192u, 33819392u};
+__constant__ uint16_t RCP14_B[64] = {
+    1009, 977, 949, 921, 893, 869, 843, 821, 797, 777, 755, 735, 717, 699, 681, 663,
+    647, 631, 617, 601, 587, 573, 561, 547, 535, 523, 513, 501, 491, 479, 469, 459,
+    451, 441, 433, 423, 415, 407, 399, 391, 385, 377, 369, 363, 357, 349, 343, 337,
+    331, 325, 319, 315, 309, 303, 299, 293, 289, 285, 279, 275, 271, 267, 263, 259};
+
+__device__ __forceinline__ float rcp14f(float x)
+{
+    uint32_t u = f2u(x), sign = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    uint32_t idx = m >> 17, low = (m >> 7) & 1023u;
+    uint32_t v = (RCP14_A[idx] - (uint32_t)RCP14_B[idx] * low) >> 9;
+    uint32_t r = sign | ((253u - e) << 23) | ((v & 0xffffu) << 7);
+    uint32_t r0 = sign | ((254u - e) << 23);
+    return u2f(m == 0 ? r0 : r);
+}
+
+// numpy.arctan2(float32) under NumPy's AVX512_SKX dispatch == Intel SVML __svml_atan2f16 (np.angle at
+// signal_processing.py:94).  Main path for 2^-125 <= |x|,|y| < 2^123; zero operands follow the routine's
+// vector fix-up; NaN/inf/denormal/huge operands use IEEE special values / a double-precision fallback.
+__device__ __forceinline__ float atan2f_svml(float y, float x)
+{
+    const float PIO2 = 0x1.921fb6p+0f, PI = 0x1.921fb6p+1f;
+    uint32_t xb = f2u(x), yb = f2u(y);
+    uint32_t axb = xb & 0x7fffffffu, ayb = yb & 0x7fffffffu;
+    uint32_t sx = xb & 0x80000000u, sy = yb & 0x80000000u;
+    float ax = u2f(axb), ay = u2f(ayb);
+    bool inr = (axb >= 0x01000000u) && (axb < 0x7d000000u) && (ayb >= 0x01000000u) && (ayb < 0x7d000000u);
+    if (__builtin_expect(!inr, 0)) {
+        if (x != x || y != y) return x + y;
+        if (axb == 0 || ayb == 0) {
+            float v = (!(ay < ax) && !(axb == 0 && ayb == 0)) ? PIO2 : 0.0f;
+            v = u2f(f2u(v) | sx);
+            if (sx) v = v + PI;
+            return u2f(f2u(v) | sy);
+        }
+        return (float)atan2((double)y, (double)x);
+    }
+    bool k1 = ay < ax;
+    float a = k1 ? ay : -ax;
+    float b = k1 ? ax : ay;
+    float base = k1 ? 0.0f : PIO2;
+    float r0 = rcp14f(b);
+    float e = __fmaf_rn(-b, r0, 1.0f);
+    float r1 = __fmaf_rn(r0, e, r0);
+    float q0 = __fmul_rn(a, r1);
+    float rem = __fmaf_rn(-b, q0, a);
+    float q = __fmaf_rn(rem, r1, q0);
+    float s = __fmul_rn(q, q);
+    float s2 = __fmul_rn(s, s);
+    float pa = __fmaf_rn(s2, 0x1.64598p-9f, 0x1.578708p-5f);
+    float pb = __fmaf_rn(s2, -0x1.fe4c62p-7f, -0x1.30ec52p-4f);
+    pa = __fmaf_rn(pa, s2, 0x1.b2c8e8p-4f);
+    pb = __fmaf_rn(pb, s2, -0x1.22c3fp-3f);
+    pa = __fmaf_rn(pa, s2, 0x1.996f3ep-3f);
+    pb = __fmaf_rn(pb, s2, -0x1.555492p-2f);
+    pa = __fmaf_rn(pa, s2, 1.0f);
+    float p = __fmaf_rn(pb, s, pa);
+    float r = __fmaf_rn(p, q, base);
+    r = u2f(f2u(r) | sx);
+    if (x <= 0.0f) r = __fadd_rn(r, PI);
+    return u2f(f2u(r) | sy);
+}
+
+// numpy.abs(complex64), AVX512F loop: mx * sqrt(fma(r, r, 1)), r = mn / mx (IEEE div and sqrt).
+__device__ __forceinline__ float cabsf_np(float re, float im)
+{
+    float a = fabsf(re), b = fabsf(im);
+    float mx = a > b ? a : b, mn = a > b ? b : a;
+    if (mx == 0.0f) return 0.0f;
+    float r = __fdiv_rn(mn, mx);
+    return __fmul_rn(mx, __fsqrt_rn(__fmaf_rn(r, r, 1.0f)));
+}
+
+// FM discriminator sample: float32(angle(a * conj(b))) * float32(fs/2pi)   (signal_processing.py:94,97)
+// a = samples[i+1], b = samples[i].  NumPy's complex64 multiply is the FMA form; `swapped` selects the
+// operand order NumPy's temporary elision produces for frames with N-1 >= 32768.
+__device__ __forceinline__ float disc_sample(float2 a, float2 b, float kscale, bool swapped)
+{
+    float c = b.x, d = -b.y;
+    float re = __fmaf_rn(a.x, c, -__fmul_rn(a.y, d));
+    float im = swapped ? __fmaf_rn(a.y, c, __fmul_rn(a.x, d)) : __fmaf_rn(a.x, d, __fmul_rn(a.y, c));
+    return __fmul_rn(atan2f_svml(im, re), kscale);
+}
+
+// Inner product in the accumulation order of OpenBLAS ddot (kernel/x86_64/ddot_microk_skylakex-2.c),
+// which is what np.convolve -> cblas_ddot executes inside scipy.signal.lfilter's FIR branch
+// (signal_processing.py:108).  X(j), Y(j): accessors for j = 0..n-1.
+template <class FX, class FY>
+__device__ __forceinline__ double ddot_skx(FX X, FY Y, int n)
+{
+    int n1 = n & -16, i = 0;
+    double dot = 0.0;
+    if (n1) {
+        double a[4][4];
+        int n32 = n1 & ~31;
+        if (n32) {
+            double a5[4][8];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int l = 0; l < 8; l++) a5[k][l] = __fma_rn(X(8 * k + l), Y(8 * k + l), 0.0);
+            for (i = 32; i < n32; i += 32) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int l = 0; l < 8; l++) a5[k][l] = __fma_rn(X(i + 8 * k + l), Y(i + 8 * k + l), a5[k][l]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int l = 0; l < 4; l++) a[k][l] = __dadd_rn(a5[k][l], a5[k][l + 4]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int l = 0; l < 4; l++) a[k][l] = 0.0;
+        }
+        for (; i < n1; i += 16) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int l = 0; l < 4; l++) a[k][l] = __fma_rn(X(i + 4 * k + l), Y(i + 4 * k + l), a[k][l]);
+        }
+        double s[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) s[l] = __dadd_rn(__dadd_rn(__dadd_rn(a[0][l], a[1][l]), a[2][l]), a[3][l]);
+        dot = __dadd_rn(__dadd_rn(s[0], s[2]), __dadd_rn(s[1], s[3]));
+    }
+    for (; i < n; i++) dot = __fma_rn(Y(i), X(i), dot);
+    return dot;
+}
+
+// Real part of OpenBLAS zdotu (zdot_microk_haswell-2.c) with a real second operand — the complex FIR at
+// signal_processing.py:204/:209.
+template <class FX, class FY>
+__device__ __forceinline__ double zdot_re_skx(FX X, FY Y, int n)
+{
+    int n1 = n & -8, i = 0;
+    double dot = 0.0;
+    if (n1) {
+        double acc[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) acc[a][p] = __fma_rn(X(2 * a + p), Y(2 * a + p), 0.0);
+        for (i = 8; i < n1; i += 8) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) acc[a][p] = __fma_rn(X(i + 2 * a + p), Y(i + 2 * a + p), acc[a][p]);
+        }
+        double c0 = __dadd_rn(__dadd_rn(acc[0][0], acc[1][0]), __dadd_rn(acc[2][0], acc[3][0]));
+        double c1 = __dadd_rn(__dadd_rn(acc[0][1], acc[1][1]), __dadd_rn(acc[2][1], acc[3][1]));
+        dot = __dadd_rn(c0, c1);
+    }
+    for (; i < n; i++) dot = __fma_rn(X(i), Y(i), dot);
+    return dot;
+}
+
+// One DF2T biquad step exactly as scipy's _sosfilt (un-fused float64, this association).
+struct Biquad { double b0, b1, b2, a1, a2; };
+__device__ __forceinline__ double biquad_step(const Biquad &c, double x, double &z0, double &z1)
+{
+    double xn = __dadd_rn(__dmul_rn(c.b0, x), z0);
+    z0 = __dadd_rn(__dsub_rn(__dmul_rn(c.b1, x), __dmul_rn(c.a1, xn)), z1);
+    z1 = __dsub_rn(__dmul_rn(c.b2, x), __dmul_rn(c.a2, xn));
+    return xn;
+}
+
+// np.int16(v * 32767): truncation toward zero, NaN -> 0 (io_manager.py:26, audio_processing.py:37)
+__device__ __forceinline__ int16_t pcm16(double a)
+{
+    double v = __dmul_rn(a, 32767.0);
+    return (v != v) ? (int16_t)0 : (int16_t)(int)v;
+}
+
+}  // namespace pss

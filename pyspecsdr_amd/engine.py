@@ -1,0 +1,163 @@
+"""Engine: one libpss context (one GPU, one stream) with the batched device-pointer entry points.
+
+Device buffers are passed as raw addresses: anything with .data_ptr() (torch tensors), an int, or None.
+PyTorch is only plumbing here (device memory / streams / torch.distributed); the library itself is
+plain HIP behind a C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class PssError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libpss error {code}: {msg}")
+        self.code = code
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return int(x)
+
+
+class Engine:
+    def __init__(self, device=0, stream=None):
+        self.lib = L.load()
+        h = C.c_void_p()
+        r = self.lib.pss_create(int(device), C.byref(h))
+        if r != 0:
+            raise PssError(r, self.lib.pss_last_error(None).decode())
+        self.h = h
+        self.device = device
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pss_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, r):
+        if r != 0:
+            msg = self.lib.pss_last_error(self.h).decode()
+            if r in (L.PSS_E_PADLEN, L.PSS_E_CUTOFF):
+                raise ValueError(msg)  # the exception type the reference's SciPy calls raise
+            raise PssError(r, msg)
+
+    # -- plumbing
+    def set_stream(self, stream):
+        self._ck(self.lib.pss_set_stream(self.h, _ptr(getattr(stream, "cuda_stream", stream))))
+
+    def sync(self):
+        self._ck(self.lib.pss_sync(self.h))
+
+    def enable_timing(self, on=True):
+        self._ck(self.lib.pss_enable_timing(self.h, int(on)))
+
+    def last_kernel_ms(self):
+        return float(self.lib.pss_last_kernel_ms(self.h))
+
+    def kernel_times(self):
+        """{kernel name: [ms per launch, ...]} for every launch since timing was enabled / last read
+        (HIP events on the engine's stream)."""
+        buf = C.create_string_buffer(1 << 20)
+        self._ck(self.lib.pss_kernel_times(self.h, buf, 1 << 20))
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if item:
+                k, v = item.split("=")
+                out.setdefault(k, []).append(float(v))
+        return out
+
+    # -- filters
+    def nfm_filters(self, fs):
+        taps, sos, zi = np.empty(65), np.empty((4, 6)), np.empty((4, 2))
+        self._ck(self.lib.pss_get_nfm_filters(self.h, float(fs), _ptr(taps), _ptr(sos), _ptr(zi)))
+        return taps, sos, zi
+
+    def set_nfm_filters(self, fs, taps, sos, zi):
+        taps = np.ascontiguousarray(taps, np.float64)
+        sos = np.ascontiguousarray(sos, np.float64)
+        zi = np.ascontiguousarray(zi, np.float64)
+        assert taps.shape == (65,) and sos.shape == (4, 6) and zi.shape == (4, 2)
+        self._ck(self.lib.pss_set_nfm_filters(self.h, float(fs), _ptr(taps), _ptr(sos), _ptr(zi)))
+
+    def ssb_taps(self, fs):
+        taps = np.empty(65)
+        self._ck(self.lib.pss_get_ssb_taps(self.h, float(fs), _ptr(taps)))
+        return taps
+
+    def set_ssb_taps(self, fs, taps):
+        taps = np.ascontiguousarray(taps, np.float64)
+        assert taps.shape == (65,)
+        self._ck(self.lib.pss_set_ssb_taps(self.h, float(fs), _ptr(taps)))
+
+    # -- batched device entry points (asynchronous on the engine's stream)
+    def spectrum_db(self, d_iq, n_frames, n_fft, d_db):
+        self._ck(self.lib.pss_spectrum_db(self.h, _ptr(d_iq), n_frames, n_fft, _ptr(d_db)))
+
+    def spectrum_post(self, d_db, n_frames, n_fft, d_post):
+        self._ck(self.lib.pss_spectrum_post(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_post)))
+
+    def scan(self, d_iq, n_slices, n_fft, fs, d_db, d_peak, d_bw, d_count):
+        self._ck(self.lib.pss_scan(self.h, _ptr(d_iq), n_slices, n_fft, float(fs), _ptr(d_db), _ptr(d_peak),
+                                   _ptr(d_bw), _ptr(d_count)))
+
+    def power_db(self, d_iq, n_frames, n, d_power):
+        self._ck(self.lib.pss_power_db(self.h, _ptr(d_iq), n_frames, n, _ptr(d_power)))
+
+    def agc_steps(self, d_power, n, start_idx, n_gains, d_idx):
+        self._ck(self.lib.pss_agc_steps(self.h, _ptr(d_power), n, start_idx, n_gains, _ptr(d_idx)))
+
+    def demod(self, mode, d_iq, n_frames, n, fs, d_pcm=None, d_audio=None):
+        self._ck(self.lib.pss_demod(self.h, mode, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_pcm), _ptr(d_audio)))
+
+    def demod_out_len(self, mode, n, fs):
+        return int(self.lib.pss_demod_out_len(mode, n, float(fs)))
+
+    def spectrum_nfm(self, d_iq, n_frames, n, fs, d_db, d_pcm):
+        self._ck(self.lib.pss_spectrum_nfm(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_pcm)))
+
+    def waterfall_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_glyph, d_colour, f64=False):
+        fn = self.lib.pss_waterfall_cells_f64 if f64 else self.lib.pss_waterfall_cells
+        self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour)))
+
+    def persistence_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_colour, f64=False):
+        fn = self.lib.pss_persistence_cells_f64 if f64 else self.lib.pss_persistence_cells
+        self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_colour)))
+
+    # -- host convenience (single frame, synchronous)
+    def h_compute_fft(self, iq):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        out = np.empty(len(iq), np.float64)
+        self._ck(self.lib.pss_h_compute_fft(self.h, _ptr(iq), len(iq), _ptr(out)))
+        return out
+
+    def h_demodulate(self, mode, iq, fs):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        n_out = self.demod_out_len(mode, len(iq), fs)
+        if n_out < 0:
+            raise ValueError("sample rate below 22050 Hz or unknown mode")
+        audio = np.empty((n_out, 2), np.float64)
+        pcm = np.empty((n_out, 2), np.int16)
+        self._ck(self.lib.pss_h_demodulate(self.h, mode, _ptr(iq), len(iq), float(fs), _ptr(audio), _ptr(pcm)))
+        return audio, pcm
+
+    def h_measure_power(self, iq):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        out = np.empty(1, np.float32)
+        self._ck(self.lib.pss_h_measure_power(self.h, _ptr(iq), len(iq), _ptr(out)))
+        return out[0]

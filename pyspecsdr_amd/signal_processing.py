@@ -1,0 +1,94 @@
+"""Drop-in for the reference's hot-path module `signal_processing.py` (xqtr/PySpecSDR), backed by libpss.so.
+
+Same callables, positional arguments, defaults, return dtypes/shapes and error behaviour as the functions
+the reference's main loop imports with `from signal_processing import *` (pyspecsdr.py:98):
+
+    compute_fft(samples)                                   signal_processing.py:243-264  -> float64 (N,), writable
+    demodulate_signal(samples, sample_rate, mode='NFM')    :220-240
+    demodulate_nfm(samples, sample_rate, target_rate=...)  :91-116   -> float64 (n_out, 2)
+    demodulate_am(samples)                                 :179-195  -> float64 (N, 2)
+    demodulate_ssb(samples, sample_rate, lower=True)       :198-217  -> float64 (N, 2)
+    measure_signal_power(samples)                          :325-328  -> np.float32
+    mono_to_stereo(mono_audio)                             :83-88
+
+Every call runs on the GPU through the C ABI; there is no NumPy/SciPy compute path here.  WFM / RAW (which
+go through iq_correction, :222-225) and classify_signal (broken in the reference) are not
+part of the accelerated path and raise NotImplementedError.
+"""
+import numpy as np
+
+from . import _lib as L
+from .engine import Engine
+
+DEFAULT_SAMPLE_RATE = 22050  # pyspecconst.py:3
+BUTTER_ORDER = 5             # pyspecconst.py:5
+
+_engine = None
+
+
+def get_engine(device=0):
+    global _engine
+    if _engine is None:
+        _engine = Engine(device)
+    return _engine
+
+
+def _samples(samples):
+    s = np.asarray(samples)
+    if s.ndim != 1:
+        raise ValueError("samples must be a 1-D complex array")
+    return np.ascontiguousarray(s, dtype=np.complex64)
+
+
+def mono_to_stereo(mono_audio):
+    stereo_audio = np.zeros((len(mono_audio), 2))
+    stereo_audio[:, 0] = mono_audio
+    stereo_audio[:, 1] = mono_audio
+    return stereo_audio
+
+
+def compute_fft(samples):
+    return get_engine().h_compute_fft(_samples(samples))
+
+
+def demodulate_nfm(samples, sample_rate, target_rate=DEFAULT_SAMPLE_RATE):
+    if target_rate != DEFAULT_SAMPLE_RATE:
+        raise NotImplementedError("only the reference's fixed target_rate=22050 is accelerated")
+    audio, _ = get_engine().h_demodulate(L.MODE_NFM, _samples(samples), sample_rate)
+    return audio
+
+
+def demodulate_am(samples):
+    audio, _ = get_engine().h_demodulate(L.MODE_AM, _samples(samples), float(DEFAULT_SAMPLE_RATE))
+    return audio
+
+
+def demodulate_ssb(samples, sample_rate, lower=True):
+    audio, _ = get_engine().h_demodulate(L.MODE_LSB if lower else L.MODE_USB, _samples(samples), sample_rate)
+    return audio
+
+
+def demodulate_signal(samples, sample_rate, mode='NFM'):
+    if mode == 'NFM':
+        return demodulate_nfm(samples, sample_rate)
+    elif mode == 'AM':
+        return demodulate_am(samples)
+    elif mode == 'USB':
+        return demodulate_ssb(samples, sample_rate, lower=False)
+    elif mode == 'LSB':
+        return demodulate_ssb(samples, sample_rate, lower=True)
+    elif mode in ('WFM', 'RAW'):
+        raise NotImplementedError(f"mode {mode!r} (iq_correction path) is outside the accelerated hot path")
+    return np.zeros((len(samples), 2))  # unknown mode -> silence of shape (n, 2), as the reference
+
+
+def demodulate_pcm(samples, sample_rate, mode='NFM'):
+    """int16 (n_out, 2) exactly as io_manager.write_to_pipe would produce from demodulate_signal()'s output."""
+    m = {'NFM': L.MODE_NFM, 'AM': L.MODE_AM, 'USB': L.MODE_USB, 'LSB': L.MODE_LSB}[mode]
+    fs = float(DEFAULT_SAMPLE_RATE) if mode == 'AM' else sample_rate
+    _, pcm = get_engine().h_demodulate(m, _samples(samples), fs)
+    return pcm
+
+
+def measure_signal_power(samples):
+    return get_engine().h_measure_power(_samples(samples))
