@@ -62,6 +62,14 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -m pyspecsdr_amd.build` (hipcc, gfx950). "
                 "pyspecsdr_amd has no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as
+        # /opt/rocm's).  If torch is going to be used in this process (device buffers, torch.distributed) it
+        # must be loaded FIRST so that libpss.so binds to that copy; two runtimes in one process cannot both
+        # open the GPU.  Without torch installed, libpss.so simply uses /opt/rocm's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)  # AttributeError if the ABI and this table ever drift apart

@@ -20,7 +20,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 # pss_demod.hip carries the bit-exactness contract: no implicit fused multiply-adds.
 UNITS = [
     ("pss_fft.hip", []),
-    ("pss_demod.hip", ["-ffp-contract=off"]),
+    ("pss_demod.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("pss_api.cpp", ["-x", "hip"]),
     ("pss_design.cpp", ["-x", "hip", "-ffp-contract=off"]),
 ]

@@ -77,7 +77,9 @@ extern "C" int pss_create(int device, pss_ctx **out)
     *out = nullptr;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) return pss_fail(nullptr, PSS_E_HIP, "no HIP device available (libpss has no CPU fallback)");
+    if (e != hipSuccess || n <= 0)
+        return pss_fail(nullptr, PSS_E_HIP, std::string("no HIP device available (libpss has no CPU fallback): ") +
+                                                (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
     if (device < 0 || device >= n) return pss_fail(nullptr, PSS_E_ARG, "device index out of range");
     e = hipSetDevice(device);
     if (e != hipSuccess) return pss_fail(nullptr, PSS_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));

@@ -89,13 +89,15 @@ __device__ __forceinline__ float atan2f_svml(float y, float x)
 }
 
 // numpy.abs(complex64), AVX512F loop: mx * sqrt(fma(r, r, 1)), r = mn / mx (IEEE div and sqrt).
+// NB: sqrtf()/operator/ are correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt, set in build.py);
+// __fsqrt_rn() is NOT (it lowers to the native approximate v_sqrt_f32).
 __device__ __forceinline__ float cabsf_np(float re, float im)
 {
     float a = fabsf(re), b = fabsf(im);
     float mx = a > b ? a : b, mn = a > b ? b : a;
     if (mx == 0.0f) return 0.0f;
     float r = __fdiv_rn(mn, mx);
-    return __fmul_rn(mx, __fsqrt_rn(__fmaf_rn(r, r, 1.0f)));
+    return __fmul_rn(mx, sqrtf(__fmaf_rn(r, r, 1.0f)));
 }
 
 // FM discriminator sample: float32(angle(a * conj(b))) * float32(fs/2pi)   (signal_processing.py:94,97)
