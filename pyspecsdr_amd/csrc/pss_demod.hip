@@ -26,8 +26,6 @@ using namespace pss;
 constexpr int TPB = 256;
 constexpr int TILE = 64;   // frames per wavefront in the lane-per-frame kernels
 constexpr int EDGE = 27;   // sosfiltfilt: 3 * (2*4 + 1)
-constexpr int RING = 128;  // discriminator ring per frame (64 history + 64 new)
-constexpr int RSTR = 129;  // padded row stride (floats) -> conflict-free column reads
 
 struct NfmCoef {
     Biquad s[4];
@@ -42,49 +40,110 @@ __constant__ double c_taps[65];
 
 // ---------------------------------------------------------------------------------------------------
 // NFM front end: discriminator (float32, signal_processing.py:94,97) + 65-tap FIR (float64, :108).
-// One workgroup = one tile of 64 frames; time is walked in chunks of 64 samples.  Step A fills the LDS
-// ring [frame][time] with coalesced reads along time; step B lets lane = frame compute the FIR in the
-// reference's exact accumulation order and writes u[] TRANSPOSED ([tile][time][lane]) for the IIR kernel.
+// One workgroup = one tile of 64 frames; time is walked in chunks of 64 samples.
+//   step A  4 waves x 16 frames: a wavefront reads 512 contiguous bytes of one frame, computes the
+//           discriminator and stores float64 d[] into the LDS window [frame][64 history | 64 new].
+//   step B  lane = frame: each wave computes 16 consecutive FIR outputs (two batches of 8) for its 64 frames
+//           in the exact OpenBLAS-ddot accumulation tree.  The taps are wave-uniform, so they are fed as
+//           SGPR operands — 16 at a time (accumulator group k of the ddot kernel: taps 8k..8k+7 and
+//           32+8k..32+8k+7), which keeps them inside the 102-SGPR budget.  x comes from LDS at compile-time
+//           offsets; u[] is written TRANSPOSED ([tile][time][lane]) for the lane-per-frame IIR kernel.
+//   step C  the "new" half becomes the history of the next chunk.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_nfm_front(const float2 *__restrict__ iq, double *__restrict__ U, int n,
-                                                   long n_frames, float kscale, int swapped)
+constexpr int WSTR = 129;  // window row stride in doubles: 2*129 mod 64 = 2 -> ds_read_b64 conflict-free per 32 lanes
+constexpr size_t FRONT_LDS = (size_t)TILE * WSTR * sizeof(double) + 72 * sizeof(double);
+constexpr int FB = 8;      // FIR outputs per batch
+
+// FB consecutive full-window outputs: output o uses x[o .. o+64] (time ascending), y = taps reversed.
+// Tree (pss_device.h ddot_skx, n = 65): a5[k][l] = fma(x[32+8k+l],y[32+8k+l], fma(x[8k+l],y[8k+l],0));
+// a[k][l] = a5[k][l] + a5[k][l+4]; s[l] = ((a[0][l]+a[1][l])+a[2][l])+a[3][l]; dot = (s0+s2)+(s1+s3); + tap 64.
+__device__ __forceinline__ void fir65_batch(const double *__restrict__ x, const double *__restrict__ yrev, double (&out)[FB])
 {
-    __shared__ float ring[TILE * RSTR];
+    double s[FB][4];
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        double ya[8], yb[8];  // wave-uniform: scalar loads, SGPR operands
+#pragma unroll
+        for (int l = 0; l < 8; l++) { ya[l] = yrev[8 * k + l]; yb[l] = yrev[32 + 8 * k + l]; }
+        const double *xk = x + 8 * k;
+#pragma unroll
+        for (int o = 0; o < FB; o++) {
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                double lo = __fma_rn(xk[o + 32 + l], yb[l], __fma_rn(xk[o + l], ya[l], 0.0));
+                double hi = __fma_rn(xk[o + 36 + l], yb[l + 4], __fma_rn(xk[o + l + 4], ya[l + 4], 0.0));
+                double a = __dadd_rn(lo, hi);
+                s[o][l] = (k == 0) ? a : __dadd_rn(s[o][l], a);
+            }
+        }
+    }
+    const double y64 = yrev[64];
+#pragma unroll
+    for (int o = 0; o < FB; o++) {
+        double dot = __dadd_rn(__dadd_rn(s[o][0], s[o][2]), __dadd_rn(s[o][1], s[o][3]));
+        out[o] = __fma_rn(y64, x[o + 64], dot);
+    }
+}
+
+__global__ __launch_bounds__(TPB, 2) void k_nfm_front(const float2 *__restrict__ iq, double *__restrict__ U, int n,
+                                                      long n_frames, float kscale, int swapped)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *win = reinterpret_cast<double *>(smem);               // [TILE][WSTR]: cols 0..63 history, 64..127 new
+    double *ltaps = win + (size_t)TILE * WSTR;                    // taps[0..64] for the (rare) edge paths
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long tile = blockIdx.x;
     const int M = n - 1;
     const long L = (long)M + 2 * EDGE;
     double *Ut = U + (size_t)tile * L * TILE;
+    if (tid < 65) ltaps[tid] = c_taps[tid];
+    double *row = win + (size_t)lane * WSTR;
     for (int i0 = 0; i0 < M; i0 += 64) {
-        // step A: 64 frames x 64 samples; a wavefront reads 512 contiguous bytes of one frame
+        // step A
+#pragma unroll 8
         for (int rep = 0; rep < 16; rep++) {
-            int fl = rep * 4 + wave;
-            long f = tile * TILE + fl;
-            int i = i0 + lane;
+            const int fl = rep * 4 + wave;
+            const long f = tile * TILE + fl;
+            const int i = i0 + lane;
             float d = 0.0f;
             if (f < n_frames && i < M) {
                 const float2 *x = iq + (size_t)f * n + i;
                 d = disc_sample(x[1], x[0], kscale, swapped != 0);
             }
-            ring[fl * RSTR + (i & (RING - 1))] = d;
+            win[(size_t)fl * WSTR + 64 + lane] = (double)d;
         }
         __syncthreads();
-        // step B: lane = frame; wave w handles times i0 + 16 w .. + 15
-        const float *row = ring + lane * RSTR;
-        for (int k = 0; k < 16; k++) {
-            int i = i0 + wave * 16 + k;
-            if (i >= M) break;
-            double u;
-            if (M <= 65) {  // np.convolve does not swap operands: dot runs over ascending tap index
-                u = ddot_skx([&](int j) { return c_taps[j]; }, [&](int j) { return (double)row[(i - j) & (RING - 1)]; }, i + 1);
-            } else if (i >= 64) {
-                const int b = i - 64;
-                u = ddot_skx([&](int j) { return (double)row[(b + j) & (RING - 1)]; }, [&](int j) { return c_taps_rev[j]; }, 65);
-            } else {
-                const int o = 64 - i;
-                u = ddot_skx([&](int j) { return (double)row[j]; }, [&](int j) { return c_taps_rev[o + j]; }, i + 1);
+        // step B
+        if (M > 65 && i0 >= 64) {
+            const int i_base = i0 + wave * 16;
+#pragma unroll 1
+            for (int b = 0; b < 16; b += FB) {
+                double out[FB];
+                fir65_batch(row + wave * 16 + b, c_taps_rev, out);  // window of output k' starts at column k'
+#pragma unroll
+                for (int o = 0; o < FB; o++)
+                    if (i_base + b + o < M) Ut[(size_t)(EDGE + i_base + b + o) * TILE + lane] = out[o];
             }
-            Ut[(size_t)(EDGE + i) * TILE + lane] = u;
+        } else {
+            for (int kk = 0; kk < 16; kk++) {
+                const int i = i0 + wave * 16 + kk;
+                if (i >= M) break;
+                const int c = 64 + (i - i0);  // column of time i
+                double u;
+                if (M <= 65) {  // np.convolve does not swap operands: the dot runs over ascending TAP index
+                    u = ddot_skx([&](int j) { return ltaps[j]; }, [&](int j) { return row[c - j]; }, i + 1);
+                } else {        // left edge: x[0..i] against taps[i..0]
+                    u = ddot_skx([&](int j) { return row[c - i + j]; }, [&](int j) { return ltaps[i - j]; }, i + 1);
+                }
+                Ut[(size_t)(EDGE + i) * TILE + lane] = u;
+            }
+        }
+        __syncthreads();
+        // step C
+#pragma unroll 4
+        for (int rep = 0; rep < 16; rep++) {
+            const int fl = rep * 4 + wave;
+            win[(size_t)fl * WSTR + lane] = win[(size_t)fl * WSTR + 64 + lane];
         }
         __syncthreads();
     }
@@ -93,10 +152,60 @@ __global__ __launch_bounds__(TPB) void k_nfm_front(const float2 *__restrict__ iq
 // ---------------------------------------------------------------------------------------------------
 // NFM back end: scipy.signal.decimate(u, q) = sosfiltfilt(cheby1 sos) then [::q]  (signal_processing.py:112),
 // peak normalisation (:115), stereo duplication (:116) and int16 conversion (io_manager.py:26).
-// One wavefront per tile, lane = frame.  Forward pass over the odd extension writes y_fwd to Y, the
-// backward pass reads it in reverse and keeps every q-th sample.
+// One wavefront per tile, lane = frame (the recurrence is serial in time; 64 frames advance in lock step).
+//  * The four biquad sections run as a SKEWED pipeline: at step t section s works on sample t-s, so the four
+//    section updates of a step are independent (4-way ILP for the ~9-cycle float64 latency) while every
+//    section still sees exactly the reference's operation sequence.
+//  * Inputs stream through a 2 x 32-deep register prefetch so ~32 coalesced 512-byte row loads are always
+//    in flight (there is only one wavefront per SIMD to hide HBM latency with).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, double *__restrict__ Y,
+constexpr int IIR_CH = 32;
+
+template <class Load, class Out>
+__device__ __forceinline__ void iir4_pass(const NfmCoef &c, double (&z)[8], long T, Load load, Out out)
+{
+    auto sec = [&](int s, double x) { return biquad_step(c.s[s], x, z[2 * s], z[2 * s + 1]); };
+    double p0, p1, p2;
+    // fill the pipeline (T > 27 always)
+    p0 = sec(0, load(0));
+    { double t1 = sec(1, p0); p0 = sec(0, load(1)); p1 = t1; }
+    { double t2 = sec(2, p1); double t1 = sec(1, p0); p0 = sec(0, load(2)); p2 = t2; p1 = t1; }
+    auto step = [&](double x) {
+        double o = sec(3, p2);
+        p2 = sec(2, p1);
+        p1 = sec(1, p0);
+        p0 = sec(0, x);
+        return o;
+    };
+    double b0[IIR_CH], b1[IIR_CH];
+    auto loadc = [&](double (&b)[IIR_CH], long r) {
+#pragma unroll
+        for (int t = 0; t < IIR_CH; t++) b[t] = load(r + t);
+    };
+    auto runc = [&](double (&b)[IIR_CH], long r) {
+#pragma unroll
+        for (int t = 0; t < IIR_CH; t++) out(r + t - 3, step(b[t]));
+    };
+    const long nfull = (T - 3) / IIR_CH;
+    long r = 3;
+    if (nfull > 0) loadc(b0, r);
+    for (long ch = 0; ch < nfull; ch += 2) {
+        if (ch + 1 < nfull) loadc(b1, r + IIR_CH);
+        runc(b0, r);
+        if (ch + 1 < nfull) {
+            if (ch + 2 < nfull) loadc(b0, r + 2 * IIR_CH);
+            runc(b1, r + IIR_CH);
+        }
+        r += 2 * IIR_CH;
+    }
+    for (r = 3 + nfull * IIR_CH; r < T; r++) out(r - 3, step(load(r)));
+    // drain
+    out(T - 3, sec(3, p2)); p2 = sec(2, p1); p1 = sec(1, p0);
+    out(T - 2, sec(3, p2)); p2 = sec(2, p1);
+    out(T - 1, sec(3, p2));
+}
+
+__global__ __launch_bounds__(TILE) void k_nfm_iir(double *__restrict__ U, double *__restrict__ Y,
                                                   double *__restrict__ A, int n, int q, int n_out, long n_frames,
                                                   NfmCoef c, int16_t *__restrict__ pcm, double *__restrict__ audio)
 {
@@ -105,52 +214,59 @@ __global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, 
     const long f = tile * TILE + lane;
     const int M = n - 1;
     const long L = (long)M + 2 * EDGE;
-    const double *Ut = U + (size_t)tile * L * TILE + lane;
+    double *Ut = U + (size_t)tile * L * TILE + lane;
     double *Yt = Y + (size_t)tile * L * TILE + lane;
     double *At = A + (size_t)tile * n_out * TILE + lane;
 #define UAT(p) Ut[(size_t)(p) * TILE]
 #define YAT(p) Yt[(size_t)(p) * TILE]
-    const double u0 = UAT(EDGE), uL = UAT(EDGE + M - 1);
-    const double two_u0 = __dmul_rn(2.0, u0), two_uL = __dmul_rn(2.0, uL);
-    double z[8];
+    // odd extension (scipy _arraytools.odd_ext): ext[p] = 2u[0] - u[27-p], ext[27+M+k] = 2u[M-1] - u[M-2-k]
     {
-        double x0 = __dsub_rn(two_u0, UAT(EDGE + EDGE));  // ext[0] = 2 u[0] - u[27]
+        const double two_u0 = __dmul_rn(2.0, UAT(EDGE)), two_uL = __dmul_rn(2.0, UAT(EDGE + M - 1));
+        double h[EDGE], t[EDGE];
+#pragma unroll
+        for (int p = 0; p < EDGE; p++) {
+            h[p] = __dsub_rn(two_u0, UAT(2 * EDGE - p));
+            t[p] = __dsub_rn(two_uL, UAT(EDGE + M - 2 - p));
+        }
+#pragma unroll
+        for (int p = 0; p < EDGE; p++) {
+            UAT(p) = h[p];
+            UAT(EDGE + M + p) = t[p];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    double z[8];
+    // ---- forward pass: z = zi * ext[0]
+    {
+        const double x0 = UAT(0);
 #pragma unroll
         for (int i = 0; i < 8; i++) z[i] = __dmul_rn(c.zi[i], x0);
     }
-    auto cascade = [&](double x) {
+    double ylast = 0.0;
+    iir4_pass(c, z, L, [&](long r) { return UAT(r); },
+              [&](long r, double v) { YAT(r) = v; ylast = v; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    // ---- backward pass over the reversed sequence (input r = position L-1-r); z = zi * y_fwd[L-1].
+    // Positions p < 27 are trimmed by sosfiltfilt, so only T = L - 27 inputs are run.
 #pragma unroll
-        for (int s = 0; s < 4; s++) x = biquad_step(c.s[s], x, z[2 * s], z[2 * s + 1]);
-        return x;
-    };
-#pragma unroll 4
-    for (int p = 0; p < EDGE; p++) YAT(p) = cascade(__dsub_rn(two_u0, UAT(2 * EDGE - p)));
-#pragma unroll 4
-    for (long p = EDGE; p < EDGE + M; p++) YAT(p) = cascade(UAT(p));
-#pragma unroll 4
-    for (int k = 0; k < EDGE; k++) YAT(EDGE + M + k) = cascade(__dsub_rn(two_uL, UAT(EDGE + M - 2 - k)));
-    // backward pass (the reversed sequence); y_0 of sosfiltfilt = last forward output
-    {
-        double yl = YAT(L - 1);
-#pragma unroll
-        for (int i = 0; i < 8; i++) z[i] = __dmul_rn(c.zi[i], yl);
-    }
+    for (int i = 0; i < 8; i++) z[i] = __dmul_rn(c.zi[i], ylast);
     double mx = 0.0;
     bool nan = false;
-    long next = EDGE + (long)(n_out - 1) * q;  // largest kept position
+    long next = EDGE + (long)(n_out - 1) * q;  // largest kept position (p = 27 + j q)
     int j = n_out - 1;
-#pragma unroll 4
-    for (long p = L - 1; p >= EDGE; p--) {
-        double v = cascade(YAT(p));
-        if (p == next) {
-            At[(size_t)j * TILE] = v;
-            double av = fabs(v);
-            nan = nan || (av != av);
-            mx = av > mx ? av : mx;
-            next -= q;
-            j--;
-        }
-    }
+    iir4_pass(c, z, L - EDGE, [&](long r) { return YAT(L - 1 - r); },
+              [&](long r, double v) {
+                  if (L - 1 - r == next) {
+                      At[(size_t)j * TILE] = v;
+                      double av = fabs(v);
+                      nan = nan || (av != av);
+                      mx = av > mx ? av : mx;
+                      next -= q;
+                      j--;
+                  }
+              });
     if (nan) mx = __builtin_nan("");
     if (f < n_frames) {
         for (int k = 0; k < n_out; k++) {
@@ -557,9 +673,11 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         for (int i = 0; i < 8; i++) c.zi[i] = flt->zi[i];
         const float kscale = (float)(fs / (2.0 * M_PI));          // python float -> float32 scalar (:97)
         const int swapped = ((long)(n - 1) * 8 >= 262144) ? 1 : 0;  // NumPy temporary elision threshold
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_nfm_front),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS));
         pss_time_begin(ctx);
         pss_kernel_begin(ctx, "k_nfm_front");
-        hipLaunchKernelGGL(k_nfm_front, dim3((unsigned)tiles), dim3(TPB), 0, ctx->stream,
+        hipLaunchKernelGGL(k_nfm_front, dim3((unsigned)tiles), dim3(TPB), FRONT_LDS, ctx->stream,
                            reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, kscale, swapped);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_nfm_iir");

@@ -41,6 +41,25 @@ __device__ __forceinline__ float rcp14f(float x)
     return u2f(m == 0 ? r0 : r);
 }
 
+// Operands outside [2^-125, 2^123) (zeros, NaN, inf, denormals, huge): kept out of line so the float64 libm
+// fallback does not bloat the hot kernels' register allocation.
+__device__ __noinline__ float atan2f_svml_rare(float y, float x)
+{
+    const float PIO2 = 0x1.921fb6p+0f, PI = 0x1.921fb6p+1f;
+    uint32_t xb = f2u(x), yb = f2u(y);
+    uint32_t axb = xb & 0x7fffffffu, ayb = yb & 0x7fffffffu;
+    uint32_t sx = xb & 0x80000000u, sy = yb & 0x80000000u;
+    float ax = u2f(axb), ay = u2f(ayb);
+    if (x != x || y != y) return x + y;
+    if (axb == 0 || ayb == 0) {  // the routine's vector fix-up for zero operands
+        float v = (!(ay < ax) && !(axb == 0 && ayb == 0)) ? PIO2 : 0.0f;
+        v = u2f(f2u(v) | sx);
+        if (sx) v = v + PI;
+        return u2f(f2u(v) | sy);
+    }
+    return (float)atan2((double)y, (double)x);  // SVML's scalar "rare" helper works in double; not bit-pinned
+}
+
 // numpy.arctan2(float32) under NumPy's AVX512_SKX dispatch == Intel SVML __svml_atan2f16 (np.angle at
 // signal_processing.py:94).  Main path for 2^-125 <= |x|,|y| < 2^123; zero operands follow the routine's
 // vector fix-up; NaN/inf/denormal/huge operands use IEEE special values / a double-precision fallback.
@@ -52,16 +71,7 @@ __device__ __forceinline__ float atan2f_svml(float y, float x)
     uint32_t sx = xb & 0x80000000u, sy = yb & 0x80000000u;
     float ax = u2f(axb), ay = u2f(ayb);
     bool inr = (axb >= 0x01000000u) && (axb < 0x7d000000u) && (ayb >= 0x01000000u) && (ayb < 0x7d000000u);
-    if (__builtin_expect(!inr, 0)) {
-        if (x != x || y != y) return x + y;
-        if (axb == 0 || ayb == 0) {
-            float v = (!(ay < ax) && !(axb == 0 && ayb == 0)) ? PIO2 : 0.0f;
-            v = u2f(f2u(v) | sx);
-            if (sx) v = v + PI;
-            return u2f(f2u(v) | sy);
-        }
-        return (float)atan2((double)y, (double)x);
-    }
+    if (__builtin_expect(!inr, 0)) return atan2f_svml_rare(y, x);
     bool k1 = ay < ax;
     float a = k1 ? ay : -ax;
     float b = k1 ? ax : ay;
