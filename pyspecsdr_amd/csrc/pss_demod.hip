@@ -40,38 +40,45 @@ __constant__ double c_taps[65];
 
 // ---------------------------------------------------------------------------------------------------
 // NFM front end: discriminator (float32, signal_processing.py:94,97) + 65-tap FIR (float64, :108).
-// One workgroup = one tile of 64 frames; time is walked in chunks of 64 samples.
-//   step A  4 waves x 16 frames: a wavefront reads 512 contiguous bytes of one frame, computes the
-//           discriminator and stores float64 d[] into the LDS window [frame][64 history | 64 new].
-//   step B  lane = frame: each wave computes 16 consecutive FIR outputs (two batches of 8) for its 64 frames
-//           in the exact OpenBLAS-ddot accumulation tree.  The taps are wave-uniform, so they are fed as
-//           SGPR operands — 16 at a time (accumulator group k of the ddot kernel: taps 8k..8k+7 and
-//           32+8k..32+8k+7), which keeps them inside the 102-SGPR budget.  x comes from LDS at compile-time
-//           offsets; u[] is written TRANSPOSED ([tile][time][lane]) for the lane-per-frame IIR kernel.
-//   step C  the "new" half becomes the history of the next chunk.
+// Sample-parallel.  One work item = 1024 consecutive FIR outputs of one frame, done by a 128-thread
+// workgroup (small LDS footprint -> many resident workgroups hide the HBM latency of the IQ read):
+//   1. threads read IQ coalesced along time, compute the discriminator and store float64 d[] into LDS
+//      (64 samples of history + 1024 new; index padded p + p/8 so that per-thread windows at a stride of
+//      8 samples are bank-conflict free for ds_read_b64);
+//   2. each thread computes 8 CONSECUTIVE outputs (their windows overlap, so a tap group's x values are
+//      loaded once for all 8) in the exact OpenBLAS-ddot accumulation tree; the taps are wave-uniform SGPR
+//      operands, fed 16 at a time (accumulator group k of the ddot kernel);
+//   3. u[] goes out in natural [frame][time] layout at offset 27, and the workgroup that owns a frame's
+//      first / last samples also writes scipy's odd extension (27 samples each side) around it.
 // ---------------------------------------------------------------------------------------------------
-constexpr int WSTR = 129;  // window row stride in doubles: 2*129 mod 64 = 2 -> ds_read_b64 conflict-free per 32 lanes
-constexpr size_t FRONT_LDS = (size_t)TILE * WSTR * sizeof(double) + 72 * sizeof(double);
-constexpr int FB = 8;      // FIR outputs per batch
+constexpr int FIR_T = 128;                    // threads per workgroup
+constexpr int FB = 8;                         // consecutive outputs per thread
+constexpr int FIR_CH = FIR_T * FB;            // outputs per work item
+constexpr int FIR_XS = (FIR_CH + 64) * 9 / 8 + 8;
 
-// FB consecutive full-window outputs: output o uses x[o .. o+64] (time ascending), y = taps reversed.
+__device__ __forceinline__ int xpad(int p) { return p + (p >> 3); }
+
+// FB consecutive full-window outputs: output o uses x(o .. o+64) (time ascending), yrev[j] = taps[64-j].
 // Tree (pss_device.h ddot_skx, n = 65): a5[k][l] = fma(x[32+8k+l],y[32+8k+l], fma(x[8k+l],y[8k+l],0));
 // a[k][l] = a5[k][l] + a5[k][l+4]; s[l] = ((a[0][l]+a[1][l])+a[2][l])+a[3][l]; dot = (s0+s2)+(s1+s3); + tap 64.
-__device__ __forceinline__ void fir65_batch(const double *__restrict__ x, const double *__restrict__ yrev, double (&out)[FB])
+// xb points at the thread's window start inside the padded LDS array: x(c) = xb[c + c/8].
+__device__ __forceinline__ void fir65_batch(const double *__restrict__ xb, const double *__restrict__ yrev, double (&out)[FB])
 {
+    auto x = [&](int c) { return xb[c + (c >> 3)]; };
     double s[FB][4];
 #pragma unroll 1
     for (int k = 0; k < 4; k++) {
         double ya[8], yb[8];  // wave-uniform: scalar loads, SGPR operands
 #pragma unroll
         for (int l = 0; l < 8; l++) { ya[l] = yrev[8 * k + l]; yb[l] = yrev[32 + 8 * k + l]; }
-        const double *xk = x + 8 * k;
+        const double *xk = xb + 9 * k;  // x(8k + c) = xk[c + c/8]
+        auto xx = [&](int c) { return xk[c + (c >> 3)]; };
 #pragma unroll
         for (int o = 0; o < FB; o++) {
 #pragma unroll
             for (int l = 0; l < 4; l++) {
-                double lo = __fma_rn(xk[o + 32 + l], yb[l], __fma_rn(xk[o + l], ya[l], 0.0));
-                double hi = __fma_rn(xk[o + 36 + l], yb[l + 4], __fma_rn(xk[o + l + 4], ya[l + 4], 0.0));
+                double lo = __fma_rn(xx(o + 32 + l), yb[l], __fma_rn(xx(o + l), ya[l], 0.0));
+                double hi = __fma_rn(xx(o + 36 + l), yb[l + 4], __fma_rn(xx(o + l + 4), ya[l + 4], 0.0));
                 double a = __dadd_rn(lo, hi);
                 s[o][l] = (k == 0) ? a : __dadd_rn(s[o][l], a);
             }
@@ -81,88 +88,107 @@ __device__ __forceinline__ void fir65_batch(const double *__restrict__ x, const 
 #pragma unroll
     for (int o = 0; o < FB; o++) {
         double dot = __dadd_rn(__dadd_rn(s[o][0], s[o][2]), __dadd_rn(s[o][1], s[o][3]));
-        out[o] = __fma_rn(y64, x[o + 64], dot);
+        out[o] = __fma_rn(y64, x(o + 64), dot);
     }
 }
 
-__global__ __launch_bounds__(TPB, 2) void k_nfm_front(const float2 *__restrict__ iq, double *__restrict__ U, int n,
-                                                      long n_frames, float kscale, int swapped)
+__global__ __launch_bounds__(FIR_T) void k_nfm_front(const float2 *__restrict__ iq, double *__restrict__ U, int n,
+                                                     long n_frames, int cpf, long Lp, float kscale, int swapped)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    double *win = reinterpret_cast<double *>(smem);               // [TILE][WSTR]: cols 0..63 history, 64..127 new
-    double *ltaps = win + (size_t)TILE * WSTR;                    // taps[0..64] for the (rare) edge paths
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long tile = blockIdx.x;
+    __shared__ double xs[FIR_XS];
+    __shared__ double edge[EDGE + 1];  // u[M-28..M-1] of the frame, for the right odd extension
+    const int tid = threadIdx.x;
     const int M = n - 1;
-    const long L = (long)M + 2 * EDGE;
-    double *Ut = U + (size_t)tile * L * TILE;
-    if (tid < 65) ltaps[tid] = c_taps[tid];
-    double *row = win + (size_t)lane * WSTR;
-    for (int i0 = 0; i0 < M; i0 += 64) {
-        // step A
-#pragma unroll 8
-        for (int rep = 0; rep < 16; rep++) {
-            const int fl = rep * 4 + wave;
-            const long f = tile * TILE + fl;
-            const int i = i0 + lane;
+    const long items = n_frames * cpf;
+    for (long item = blockIdx.x; item < items; item += gridDim.x) {
+        const long f = item / cpf;
+        const int i0 = (int)(item % cpf) * FIR_CH;
+        const float2 *x = iq + (size_t)f * n;
+        double *Uf = U + (size_t)f * Lp;
+        __syncthreads();
+        for (int k = tid; k < FIR_CH + 64; k += FIR_T) {
+            const int t = i0 - 64 + k;
             float d = 0.0f;
-            if (f < n_frames && i < M) {
-                const float2 *x = iq + (size_t)f * n + i;
-                d = disc_sample(x[1], x[0], kscale, swapped != 0);
-            }
-            win[(size_t)fl * WSTR + 64 + lane] = (double)d;
+            if (t >= 0 && t < M) d = disc_sample(x[t + 1], x[t], kscale, swapped != 0);
+            xs[xpad(k)] = (double)d;
         }
         __syncthreads();
-        // step B
-        if (M > 65 && i0 >= 64) {
-            const int i_base = i0 + wave * 16;
-#pragma unroll 1
-            for (int b = 0; b < 16; b += FB) {
-                double out[FB];
-                fir65_batch(row + wave * 16 + b, c_taps_rev, out);  // window of output k' starts at column k'
+        const int o0 = FB * tid, ibase = i0 + o0;  // first local / global output index of this thread
+        auto put = [&](int i, double v) {
+            Uf[EDGE + i] = v;
+            if (i >= M - 1 - EDGE) edge[i - (M - 1 - EDGE)] = v;
+        };
+        if (ibase >= 64 && ibase < M) {  // outputs 0..63 (shorter windows) come from k_nfm_edge
+            double out[FB];
+            fir65_batch(xs + 9 * tid, c_taps_rev, out);  // xpad(8 tid + c) = 9 tid + c + c/8
 #pragma unroll
-                for (int o = 0; o < FB; o++)
-                    if (i_base + b + o < M) Ut[(size_t)(EDGE + i_base + b + o) * TILE + lane] = out[o];
-            }
-        } else {
-            for (int kk = 0; kk < 16; kk++) {
-                const int i = i0 + wave * 16 + kk;
-                if (i >= M) break;
-                const int c = 64 + (i - i0);  // column of time i
-                double u;
-                if (M <= 65) {  // np.convolve does not swap operands: the dot runs over ascending TAP index
-                    u = ddot_skx([&](int j) { return ltaps[j]; }, [&](int j) { return row[c - j]; }, i + 1);
-                } else {        // left edge: x[0..i] against taps[i..0]
-                    u = ddot_skx([&](int j) { return row[c - i + j]; }, [&](int j) { return ltaps[i - j]; }, i + 1);
-                }
-                Ut[(size_t)(EDGE + i) * TILE + lane] = u;
-            }
+            for (int o = 0; o < FB; o++)
+                if (ibase + o < M) put(ibase + o, out[o]);
         }
         __syncthreads();
-        // step C
-#pragma unroll 4
-        for (int rep = 0; rep < 16; rep++) {
-            const int fl = rep * 4 + wave;
-            win[(size_t)fl * WSTR + lane] = win[(size_t)fl * WSTR + 64 + lane];
-        }
-        __syncthreads();
+        // right odd extension (scipy _arraytools.odd_ext): ext[27+M+k] = 2u[M-1] - u[M-2-k]; only when the last
+        // 28 outputs of the frame all have full windows (M - 28 >= 64) and live in this work item
+        if (M - 1 - EDGE >= 64 && i0 + FIR_CH >= M && i0 <= M - 1 - EDGE && tid < EDGE)
+            Uf[EDGE + M + tid] = __dsub_rn(__dmul_rn(2.0, edge[EDGE]), edge[EDGE - 1 - tid]);
+    }
+}
+
+// Left edge of the FIR and the odd extension around it: outputs i < 64 have windows shorter than 65 samples, so
+// every output has its own ddot shape — one output per lane, fully predicated (pss_device.h ddot_skx_lane).
+// One 128-thread workgroup per frame.  Also covers whole frames of <= 92 samples, where np.convolve's operand
+// order (M <= 65) or the right extension (M - 28 < 64) need the edge outputs too.
+__global__ __launch_bounds__(128) void k_nfm_edge(const float2 *__restrict__ iq, double *__restrict__ U, int n,
+                                                  long n_frames, long Lp, float kscale, int swapped)
+{
+    __shared__ double d[128];
+    __shared__ double ltaps[72];
+    __shared__ double u[128];
+    const int tid = threadIdx.x;
+    const int M = n - 1;
+    const long f = blockIdx.x;
+    const float2 *x = iq + (size_t)f * n;
+    double *Uf = U + (size_t)f * Lp;
+    const int ne = M < 92 ? M : 64;  // outputs computed here
+    if (tid < 65) ltaps[tid] = c_taps[tid];
+    d[tid] = (tid < M && tid < 92) ? (double)disc_sample(x[tid + 1], x[tid], kscale, swapped != 0) : 0.0;
+    __syncthreads();
+    if (tid < ne) {
+        const int i = tid;
+        double v;
+        if (M <= 65)  // np.convolve does not swap its operands: the dot runs over ascending TAP index
+            v = ddot_skx_lane([&](int j) { return ltaps[j]; }, [&](int j) { return d[i - j]; }, i + 1);
+        else if (i < 64)  // x[0..i] against taps[i..0]
+            v = ddot_skx_lane([&](int j) { return d[j]; }, [&](int j) { return ltaps[i - j]; }, i + 1);
+        else              // full window (only reached for 66 <= M < 92)
+            v = ddot_skx_lane([&](int j) { return d[i - 64 + j]; }, [&](int j) { return ltaps[64 - j]; }, 65);
+        u[i] = v;
+        Uf[EDGE + i] = v;
+    }
+    __syncthreads();
+    // odd extension (scipy _arraytools.odd_ext): ext[p] = 2u[0] - u[27-p], ext[27+M+k] = 2u[M-1] - u[M-2-k]
+    if (tid < EDGE) Uf[tid] = __dsub_rn(__dmul_rn(2.0, u[0]), u[EDGE - tid]);
+    if (M < 92 && tid >= 32 && tid < 32 + EDGE) {
+        const int k = tid - 32;
+        Uf[EDGE + M + k] = __dsub_rn(__dmul_rn(2.0, u[M - 1]), u[M - 2 - k]);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // NFM back end: scipy.signal.decimate(u, q) = sosfiltfilt(cheby1 sos) then [::q]  (signal_processing.py:112),
 // peak normalisation (:115), stereo duplication (:116) and int16 conversion (io_manager.py:26).
-// One wavefront per tile, lane = frame (the recurrence is serial in time; 64 frames advance in lock step).
+// One wavefront per tile of 64 frames, lane = frame (the recurrence is serial in time; 64 frames advance in
+// lock step).
 //  * The four biquad sections run as a SKEWED pipeline: at step t section s works on sample t-s, so the four
 //    section updates of a step are independent (4-way ILP for the ~9-cycle float64 latency) while every
 //    section still sees exactly the reference's operation sequence.
-//  * Inputs stream through a 2 x 32-deep register prefetch so ~32 coalesced 512-byte row loads are always
-//    in flight (there is only one wavefront per SIMD to hide HBM latency with).
+//  * Inputs stream through a 2 x 32-deep register prefetch.  The forward pass reads u in natural
+//    [frame][time] layout — each lane walks its own row with 16-byte loads — and writes y_fwd TRANSPOSED
+//    ([tile][time][lane], 512-byte rows); the backward pass reads that back in reverse.
 // ---------------------------------------------------------------------------------------------------
 constexpr int IIR_CH = 32;
 
-template <class Load, class Out>
-__device__ __forceinline__ void iir4_pass(const NfmCoef &c, double (&z)[8], long T, Load load, Out out)
+template <class Load, class LoadChunk, class Out>
+__device__ __forceinline__ void iir4_pass(const NfmCoef &c, double (&z)[8], long T, Load load, LoadChunk loadc, Out out)
 {
     auto sec = [&](int s, double x) { return biquad_step(c.s[s], x, z[2 * s], z[2 * s + 1]); };
     double p0, p1, p2;
@@ -177,17 +203,14 @@ __device__ __forceinline__ void iir4_pass(const NfmCoef &c, double (&z)[8], long
         p0 = sec(0, x);
         return o;
     };
+    out(0, step(load(3)));  // one single step so that the chunked part starts at an even input index
     double b0[IIR_CH], b1[IIR_CH];
-    auto loadc = [&](double (&b)[IIR_CH], long r) {
-#pragma unroll
-        for (int t = 0; t < IIR_CH; t++) b[t] = load(r + t);
-    };
     auto runc = [&](double (&b)[IIR_CH], long r) {
 #pragma unroll
         for (int t = 0; t < IIR_CH; t++) out(r + t - 3, step(b[t]));
     };
-    const long nfull = (T - 3) / IIR_CH;
-    long r = 3;
+    const long nfull = (T - 4) / IIR_CH;
+    long r = 4;
     if (nfull > 0) loadc(b0, r);
     for (long ch = 0; ch < nfull; ch += 2) {
         if (ch + 1 < nfull) loadc(b1, r + IIR_CH);
@@ -198,53 +221,42 @@ __device__ __forceinline__ void iir4_pass(const NfmCoef &c, double (&z)[8], long
         }
         r += 2 * IIR_CH;
     }
-    for (r = 3 + nfull * IIR_CH; r < T; r++) out(r - 3, step(load(r)));
+    for (r = 4 + nfull * IIR_CH; r < T; r++) out(r - 3, step(load(r)));
     // drain
     out(T - 3, sec(3, p2)); p2 = sec(2, p1); p1 = sec(1, p0);
     out(T - 2, sec(3, p2)); p2 = sec(2, p1);
     out(T - 1, sec(3, p2));
 }
 
-__global__ __launch_bounds__(TILE) void k_nfm_iir(double *__restrict__ U, double *__restrict__ Y,
+__global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, double *__restrict__ Y,
                                                   double *__restrict__ A, int n, int q, int n_out, long n_frames,
-                                                  NfmCoef c, int16_t *__restrict__ pcm, double *__restrict__ audio)
+                                                  long Lp, NfmCoef c, int16_t *__restrict__ pcm,
+                                                  double *__restrict__ audio)
 {
     const int lane = threadIdx.x;
     const long tile = blockIdx.x;
     const long f = tile * TILE + lane;
+    const long fr = f < n_frames ? f : n_frames - 1;  // masked lanes replay the last frame (results dropped)
     const int M = n - 1;
     const long L = (long)M + 2 * EDGE;
-    double *Ut = U + (size_t)tile * L * TILE + lane;
+    const double *Uf = U + (size_t)fr * Lp;  // 16-byte aligned: Lp is even
     double *Yt = Y + (size_t)tile * L * TILE + lane;
     double *At = A + (size_t)tile * n_out * TILE + lane;
-#define UAT(p) Ut[(size_t)(p) * TILE]
 #define YAT(p) Yt[(size_t)(p) * TILE]
-    // odd extension (scipy _arraytools.odd_ext): ext[p] = 2u[0] - u[27-p], ext[27+M+k] = 2u[M-1] - u[M-2-k]
-    {
-        const double two_u0 = __dmul_rn(2.0, UAT(EDGE)), two_uL = __dmul_rn(2.0, UAT(EDGE + M - 1));
-        double h[EDGE], t[EDGE];
-#pragma unroll
-        for (int p = 0; p < EDGE; p++) {
-            h[p] = __dsub_rn(two_u0, UAT(2 * EDGE - p));
-            t[p] = __dsub_rn(two_uL, UAT(EDGE + M - 2 - p));
-        }
-#pragma unroll
-        for (int p = 0; p < EDGE; p++) {
-            UAT(p) = h[p];
-            UAT(EDGE + M + p) = t[p];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
     double z[8];
-    // ---- forward pass: z = zi * ext[0]
+    // ---- forward pass over the odd-extended u: z = zi * ext[0]
     {
-        const double x0 = UAT(0);
+        const double x0 = Uf[0];
 #pragma unroll
         for (int i = 0; i < 8; i++) z[i] = __dmul_rn(c.zi[i], x0);
     }
     double ylast = 0.0;
-    iir4_pass(c, z, L, [&](long r) { return UAT(r); },
+    iir4_pass(c, z, L, [&](long r) { return Uf[r]; },
+              [&](double (&b)[IIR_CH], long r) {  // r is even: 16-byte loads
+                  const double2 *p = reinterpret_cast<const double2 *>(Uf + r);
+#pragma unroll
+                  for (int t = 0; t < IIR_CH / 2; t++) { double2 v = p[t]; b[2 * t] = v.x; b[2 * t + 1] = v.y; }
+              },
               [&](long r, double v) { YAT(r) = v; ylast = v; });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
@@ -257,6 +269,10 @@ __global__ __launch_bounds__(TILE) void k_nfm_iir(double *__restrict__ U, double
     long next = EDGE + (long)(n_out - 1) * q;  // largest kept position (p = 27 + j q)
     int j = n_out - 1;
     iir4_pass(c, z, L - EDGE, [&](long r) { return YAT(L - 1 - r); },
+              [&](double (&b)[IIR_CH], long r) {
+#pragma unroll
+                  for (int t = 0; t < IIR_CH; t++) b[t] = YAT(L - 1 - (r + t));
+              },
               [&](long r, double v) {
                   if (L - 1 - r == next) {
                       At[(size_t)j * TILE] = v;
@@ -278,7 +294,6 @@ __global__ __launch_bounds__(TILE) void k_nfm_iir(double *__restrict__ U, double
             }
         }
     }
-#undef UAT
 #undef YAT
 }
 
@@ -656,13 +671,15 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const int q = (int)(fs / 22050.0);
         const int n_out = (n - 1 + q - 1) / q;
         const long L = (long)(n - 1) + 2 * EDGE;
-        const size_t szU = align256((size_t)tiles * L * TILE * sizeof(double));
+        const long Lp = (L + 1) & ~1L;  // even row stride -> 16-byte aligned rows of u
+        const size_t szU = align256((size_t)n_frames * Lp * sizeof(double));
+        const size_t szY = align256((size_t)tiles * L * TILE * sizeof(double));
         const size_t szA = align256((size_t)tiles * n_out * TILE * sizeof(double));
-        r = pss_ensure_scratch(ctx, 2 * szU + szA);
+        r = pss_ensure_scratch(ctx, szU + szY + szA);
         if (r) return r;
         double *U = reinterpret_cast<double *>(ctx->scratch);
         double *Y = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + szU);
-        double *A = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + 2 * szU);
+        double *A = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + szU + szY);
         r = upload_taps(ctx, flt->taps);
         if (r) return r;
         NfmCoef c;
@@ -673,16 +690,21 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         for (int i = 0; i < 8; i++) c.zi[i] = flt->zi[i];
         const float kscale = (float)(fs / (2.0 * M_PI));          // python float -> float32 scalar (:97)
         const int swapped = ((long)(n - 1) * 8 >= 262144) ? 1 : 0;  // NumPy temporary elision threshold
-        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_nfm_front),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)FRONT_LDS));
+        const int cpf = (n - 1 + FIR_CH - 1) / FIR_CH;
+        const long items = n_frames * cpf;
+        const long g1 = items < 256L * 64 ? items : 256L * 64;
         pss_time_begin(ctx);
         pss_kernel_begin(ctx, "k_nfm_front");
-        hipLaunchKernelGGL(k_nfm_front, dim3((unsigned)tiles), dim3(TPB), FRONT_LDS, ctx->stream,
-                           reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, kscale, swapped);
+        hipLaunchKernelGGL(k_nfm_front, dim3((unsigned)g1), dim3(FIR_T), 0, ctx->stream,
+                           reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, cpf, Lp, kscale, swapped);
+        pss_kernel_end(ctx);
+        pss_kernel_begin(ctx, "k_nfm_edge");
+        hipLaunchKernelGGL(k_nfm_edge, dim3((unsigned)n_frames), dim3(128), 0, ctx->stream,
+                           reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, Lp, kscale, swapped);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_nfm_iir");
-        hipLaunchKernelGGL(k_nfm_iir, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, U, Y, A, n, q, n_out, n_frames, c,
-                           d_pcm, d_audio);
+        hipLaunchKernelGGL(k_nfm_iir, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, U, Y, A, n, q, n_out, n_frames, Lp,
+                           c, d_pcm, d_audio);
         pss_kernel_end(ctx);
         pss_time_end(ctx);
         return pss_hip_check(ctx, hipGetLastError(), "nfm launch");

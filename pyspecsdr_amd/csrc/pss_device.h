@@ -169,6 +169,49 @@ __device__ __forceinline__ double ddot_skx(FX X, FY Y, int n)
     return dot;
 }
 
+// The same inner product with a PER-LANE length n <= 65, fully predicated (no divergent loops): used for the
+// left-edge outputs of the FIR (window shorter than 65) where every lane of a wavefront has a different n.
+// Phases of the ddot kernel for n <= 65: up to two 32-element steps on 4x8 accumulators (n >= 32, n >= 64),
+// fold 8->4, at most one 16-element step on 4x4 accumulators, horizontal sum, up to 15 tail fmas.
+template <class FX, class FY>
+__device__ __forceinline__ double ddot_skx_lane(FX X, FY Y, int n)
+{
+    const int n1 = n & -16, n32 = n1 & ~31;
+    const bool has32 = n32 >= 32, has64 = n32 >= 64, has16 = (n1 - n32) == 16;
+    double a[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            double lo = 0.0, hi = 0.0;
+            {
+                const int j = has32 ? 8 * k + l : 0;  // clamp the index when the phase is inactive
+                double tlo = __fma_rn(X(j), Y(j), 0.0), thi = __fma_rn(X(j + (has32 ? 4 : 0)), Y(j + (has32 ? 4 : 0)), 0.0);
+                const int j2 = has64 ? 32 + 8 * k + l : 0;
+                double ulo = __fma_rn(X(j2), Y(j2), tlo), uhi = __fma_rn(X(j2 + (has64 ? 4 : 0)), Y(j2 + (has64 ? 4 : 0)), thi);
+                lo = has64 ? ulo : tlo;
+                hi = has64 ? uhi : thi;
+            }
+            double folded = __dadd_rn(lo, hi);
+            a[k][l] = has32 ? folded : 0.0;
+            const int j3 = has16 ? n32 + 4 * k + l : 0;
+            double v = __fma_rn(X(j3), Y(j3), a[k][l]);
+            a[k][l] = has16 ? v : a[k][l];
+        }
+    double s[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) s[l] = __dadd_rn(__dadd_rn(__dadd_rn(a[0][l], a[1][l]), a[2][l]), a[3][l]);
+    double dot = __dadd_rn(__dadd_rn(s[0], s[2]), __dadd_rn(s[1], s[3]));
+    if (n1 == 0) dot = 0.0;
+#pragma unroll
+    for (int t = 0; t < 15; t++) {
+        const int j = (n1 + t < n) ? n1 + t : 0;
+        double v = __fma_rn(Y(j), X(j), dot);
+        dot = (n1 + t < n) ? v : dot;
+    }
+    return dot;
+}
+
 // Real part of OpenBLAS zdotu (zdot_microk_haswell-2.c) with a real second operand — the complex FIR at
 // signal_processing.py:204/:209.
 template <class FX, class FY>

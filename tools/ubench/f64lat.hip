@@ -50,7 +50,9 @@ void run(const char *name, int waves_per_simd)
 int main()
 {
     run<0, 1>("fma_f64", 1); run<0, 2>("fma_f64", 1); run<0, 4>("fma_f64", 1); run<0, 8>("fma_f64", 1);
-    run<0, 1>("fma_f64", 2); run<0, 4>("fma_f64", 2);
+    run<0, 1>("fma_f64", 2); run<0, 4>("fma_f64", 2); run<0, 4>("fma_f64", 3); run<0, 4>("fma_f64", 4);
+    run<0, 1>("fma_f64", 4); run<0, 2>("fma_f64", 4);
+    run<1, 4>("add_f64", 2); run<1, 4>("add_f64", 4); run<2, 4>("mul_f64", 2); run<2, 4>("mul_f64", 4);
     run<1, 1>("add_f64", 1); run<1, 4>("add_f64", 1); run<1, 8>("add_f64", 1);
     run<2, 1>("mul_f64", 1); run<2, 4>("mul_f64", 1); run<2, 8>("mul_f64", 1);
     run<3, 1>("cvt_rt", 1); run<3, 8>("cvt_rt", 1);
