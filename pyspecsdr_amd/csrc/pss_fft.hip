@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "pss_ctx.h"
+#include "pss_fft_r16.h"
 
 namespace {
 
@@ -315,6 +316,31 @@ int grid_for(long n_frames, int per_cu)
     return (int)(g < cap ? g : cap);
 }
 
+template <int LOG_R3, bool SCAN>
+int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, const double2 *tw, const double *win,
+               float *d_peak, double *d_bw, int32_t *d_count, double bin_hz)
+{
+    using C = pss_r16::Cfg<LOG_R3>;
+    auto kern = pss_r16::k_spectrum_r16<LOG_R3, SCAN>;
+    const size_t lds = C::LDS;
+    if (lds > 64 * 1024)
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long groups = (n_frames + C::FPW - 1) / C::FPW;
+    int per_cu = (int)((160 * 1024) / (lds + 256));
+    if (per_cu > 2) per_cu = 2;  // ~200 VGPRs: two 256-thread workgroups per CU
+    if (per_cu < 1) per_cu = 1;
+    const long cap = 256L * per_cu * 2;
+    const int grid = (int)(groups < cap ? groups : cap);
+    pss_time_begin(ctx);
+    pss_kernel_begin(ctx, "k_spectrum");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, reinterpret_cast<const float2 *>(d_iq), d_db, tw,
+                       win, n_frames, d_peak, d_bw, d_count, bin_hz);
+    pss_kernel_end(ctx);
+    pss_time_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_r16 launch");
+}
+
 template <bool SCAN>
 int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db, float *d_peak, double *d_bw,
                     int32_t *d_count, double bin_hz)
@@ -328,6 +354,15 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     const double *win;
     int r = pss_fft_tables(ctx, n_fft, &tw, &win);
     if (r) return r;
+    // register-resident radix-16 kernel for the sizes that fit one workgroup (256 <= N <= 4096)
+    switch (n_fft) {
+    case 256: return launch_r16<0, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
+    case 512: return launch_r16<1, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
+    case 1024: return launch_r16<2, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
+    case 2048: return launch_r16<3, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
+    case 4096: return launch_r16<4, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
+    default: break;
+    }
     int logn = ilog2(n_fft);
     int logNsub = logn < LOG_NSUB_MAX ? logn : LOG_NSUB_MAX;
     int R = n_fft >> logNsub;
@@ -343,7 +378,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     if (per_cu < 1) per_cu = 1;
     int grid = grid_for(n_frames, per_cu);
     pss_time_begin(ctx);
-    pss_kernel_begin(ctx, "k_spectrum");
+    pss_kernel_begin(ctx, "k_spectrum_generic");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, ctx->stream, reinterpret_cast<const float2 *>(d_iq), d_db, tw,
                        win, n_fft, logNsub, R, n_frames, staged, d_peak, d_bw, d_count, bin_hz);
     pss_kernel_end(ctx);

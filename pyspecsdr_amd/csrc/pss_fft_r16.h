@@ -1,0 +1,212 @@
+// pss_fft_r16.h — register-resident radix-16 FFT kernel for the spectrum path (N = 256 * R3, R3 in {1,2,4,8,16}).
+//
+// Decomposition N = 16 (n2) x 16 (m2) x R3 (m1), T = N/16 threads per frame, 16 points per thread:
+//   stage 1  thread n1 loads x[n1 + T*n2] (n2 = 0..15; each n2 is one coalesced row), applies the Hamming window,
+//            runs a 16-point DFT over n2 in registers and multiplies by W_N^(n1*k2).
+//   exchange 1 through LDS (E1[k2][n1], rows padded by 4 so the strided ds_read_b128 below is conflict-free)
+//   stage 2  thread (k2, m1) gathers y[n1 = m1 + R3*m2][k2], runs a 16-point DFT over m2, multiplies by W_T^(m1*j2).
+//   exchange 2 through LDS (E2[m1][bf], bf = 16*j2 + k2, planes padded by 2)
+//   stage 3  thread rho takes 16/R3 radix-R3 butterflies bf = rho + T*c, whose outputs are bins
+//            k = 256*j1 + bf — so for fixed (j1, c) the T threads of a frame hold T CONSECUTIVE bins and the
+//            dB row is written with coalesced stores directly from registers (no staging, no digit reversal).
+// All butterflies are float64 (see pss_fft.hip for why); the stage-1 twiddles and the window are per-thread
+// constants and stay in registers while the workgroup loops over frames.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pss_r16 {
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+
+constexpr int brev(int i, int bits)
+{
+    int r = 0;
+    for (int b = 0; b < bits; b++) r |= ((i >> b) & 1) << (bits - 1 - b);
+    return r;
+}
+constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
+
+// multiply by W_len^j = exp(-2 pi i j / len) for compile-time (j, len), len <= 16
+template <int J, int LEN>
+__device__ __forceinline__ double2 twc(double2 a)
+{
+    constexpr int j16 = (J * (16 / LEN)) & 15;  // as a 16th root index
+    constexpr double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178, H = 0.70710678118654752440;
+    if constexpr (j16 == 0) return a;
+    else if constexpr (j16 == 4) return make_double2(a.y, -a.x);
+    else if constexpr (j16 == 8) return make_double2(-a.x, -a.y);
+    else if constexpr (j16 == 12) return make_double2(-a.y, a.x);
+    else if constexpr (j16 == 2) return make_double2((a.x + a.y) * H, (a.y - a.x) * H);
+    else if constexpr (j16 == 6) return make_double2((a.y - a.x) * H, -(a.x + a.y) * H);
+    else if constexpr (j16 == 1) return cmul(a, make_double2(C1, -S1));
+    else if constexpr (j16 == 3) return cmul(a, make_double2(S1, -C1));
+    else if constexpr (j16 == 5) return cmul(a, make_double2(-S1, -C1));
+    else if constexpr (j16 == 7) return cmul(a, make_double2(-C1, -S1));
+    else return a;  // j >= len/2 never occurs in a DIF butterfly
+}
+
+// In-register DIF FFT of R points (R = 2,4,8,16); result X[k] is left at v[brev(k)].
+template <int R, int LEN = R, int BASE = 0>
+struct Dif {
+    template <int J>
+    static __device__ __forceinline__ void bf(double2 (&v)[R])
+    {
+        if constexpr (J < LEN / 2) {
+            double2 a = v[BASE + J], b = v[BASE + J + LEN / 2];
+            v[BASE + J] = cadd(a, b);
+            v[BASE + J + LEN / 2] = twc<J, LEN>(csub(a, b));
+            bf<J + 1>(v);
+        }
+    }
+    static __device__ __forceinline__ void run(double2 (&v)[R])
+    {
+        if constexpr (LEN >= 2) {
+            bf<0>(v);
+            Dif<R, LEN / 2, BASE>::run(v);
+            Dif<R, LEN / 2, BASE + LEN / 2>::run(v);
+        }
+    }
+};
+
+template <int R>
+__device__ __forceinline__ void fft_reg(double2 (&v)[R])
+{
+    if constexpr (R > 1) Dif<R>::run(v);
+}
+
+__device__ __forceinline__ float db_of(double pw)
+{
+    // 10*log10(pw) in float32 with a log1p branch around pw = 1 (keeps the RELATIVE error ~1e-6 where dB -> 0)
+    double d = pw - 1.0;
+    if (fabs(d) < 0.25) return 4.342944819032518f * log1pf((float)d);
+    return 3.0102999566398120f * __log2f((float)pw);
+}
+
+template <int LOG_R3>
+struct Cfg {
+    static constexpr int R3 = 1 << LOG_R3;
+    static constexpr int T = 16 * R3;          // threads per frame
+    static constexpr int N = 16 * T;           // FFT length
+    static constexpr int FPW = 256 / T;        // frames per 256-thread workgroup
+    static constexpr int E1_STRIDE = T + 4;    // complex elements per k2 row
+    static constexpr int E2_STRIDE = 256 + 2;  // complex elements per m1 plane
+    static constexpr int EX = (16 * E1_STRIDE > R3 * E2_STRIDE) ? 16 * E1_STRIDE : R3 * E2_STRIDE;  // per frame
+    static constexpr size_t LDS = (size_t)FPW * EX * sizeof(double2) + (size_t)R3 * 16 * sizeof(double2);
+};
+
+template <int LOG_R3, bool SCAN>
+__global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__ iq, float *__restrict__ db,
+                                                      const double2 *__restrict__ tw, const double *__restrict__ win,
+                                                      long n_frames, float *__restrict__ peak, double *__restrict__ bw,
+                                                      int *__restrict__ count, double bin_hz)
+{
+    using C = Cfg<LOG_R3>;
+    constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = C::FPW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *ex_all = reinterpret_cast<double2 *>(smem);
+    double2 *tw2 = ex_all + (size_t)FPW * C::EX;  // W_T^(m1*j2), [m1][j2]
+    __shared__ float red_f[4];
+    __shared__ int red_i[4];
+    const int tid = threadIdx.x;
+    const int fl = tid / T;   // frame slot inside the workgroup
+    const int t = tid % T;    // thread inside the frame: n1 in stage 1, (k2, m1) in stage 2, rho in stage 3
+    double2 *ex = ex_all + (size_t)fl * C::EX;
+    const int k2s = t / R3, m1s = t % R3;  // stage-2 role
+    // per-thread constants
+    double2 tw1[16];
+    double w[16];
+#pragma unroll
+    for (int k2 = 1; k2 < 16; k2++) tw1[k2] = tw[(size_t)t * k2];  // W_N^(n1*k2), n1*k2 < N
+#pragma unroll
+    for (int n2 = 0; n2 < 16; n2++) w[n2] = SCAN ? 1.0 : win[t + T * n2];
+    if (tid < R3 * 16) {
+        const int m1 = tid / 16, j2 = tid % 16;
+        tw2[tid] = tw[(size_t)(m1 * j2) * 16];  // W_T^(m1 j2) = W_N^(16 m1 j2)
+    }
+    __syncthreads();
+    const long groups = (n_frames + FPW - 1) / FPW;
+    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+        const long f = g * FPW + fl;
+        const bool valid = f < n_frames;
+        const float2 *x = iq + (size_t)(valid ? f : 0) * N;
+        double2 v[16];
+        // ---- stage 1
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++) {
+            float2 s = x[t + T * n2];
+            v[n2] = make_double2((double)s.x * w[n2], (double)s.y * w[n2]);
+        }
+        fft_reg<16>(v);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2++) {
+            double2 y = v[brev(k2, 4)];
+            if (k2) y = cmul(y, tw1[k2]);
+            ex[k2 * C::E1_STRIDE + t] = y;
+        }
+        __syncthreads();
+        // ---- stage 2
+#pragma unroll
+        for (int m2 = 0; m2 < 16; m2++) v[m2] = ex[k2s * C::E1_STRIDE + m1s + R3 * m2];
+        __syncthreads();
+        fft_reg<16>(v);
+#pragma unroll
+        for (int j2 = 0; j2 < 16; j2++) {
+            double2 z = v[brev(j2, 4)];
+            if (R3 > 1) z = cmul(z, tw2[m1s * 16 + j2]);
+            ex[m1s * C::E2_STRIDE + 16 * j2 + k2s] = z;
+        }
+        __syncthreads();
+        // ---- stage 3 + dB epilogue: butterflies bf = t + T*c, outputs k = 256*j1 + bf
+        float *out = (db && valid) ? db + (size_t)f * N : nullptr;
+        float lmax = -INFINITY;
+        float dbv[16];
+#pragma unroll
+        for (int c = 0; c < 16 / R3; c++) {
+            double2 b[R3];
+#pragma unroll
+            for (int m1 = 0; m1 < R3; m1++) b[m1] = ex[m1 * C::E2_STRIDE + t + T * c];
+            fft_reg<R3>(b);
+#pragma unroll
+            for (int j1 = 0; j1 < R3; j1++) {
+                double2 X = b[brev(j1, LOG_R3)];
+                float d = db_of(X.x * X.x + X.y * X.y + 1e-10);
+                const int k = 256 * j1 + t + T * c;
+                if (out) out[(k + N / 2) & (N - 1)] = d;  // fftshift
+                dbv[c * R3 + j1] = d;
+                lmax = fmaxf(lmax, d);
+            }
+        }
+        if (SCAN) {
+            // per-frame peak and 20-dB-down bin count (pyspecsdr.py:2546-2552); T threads own one frame
+            float m = lmax;
+            for (int off = (T < 64 ? T : 64) / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            if (T > 64) {
+                if ((tid & 63) == 0) red_f[tid >> 6] = m;
+                __syncthreads();
+                m = red_f[(fl * T) >> 6];
+                for (int wv = 1; wv < T / 64; wv++) m = fmaxf(m, red_f[((fl * T) >> 6) + wv]);
+            }
+            const float thr = m - 20.0f;
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) cnt += dbv[i] > thr;
+            for (int off = (T < 64 ? T : 64) / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+            if (T > 64) {
+                if ((tid & 63) == 0) red_i[tid >> 6] = cnt;
+                __syncthreads();
+                cnt = 0;
+                for (int wv = 0; wv < T / 64; wv++) cnt += red_i[((fl * T) >> 6) + wv];
+            }
+            if (valid && t == 0) {
+                peak[f] = m;
+                if (bw) bw[f] = (double)cnt * bin_hz;
+                if (count) count[f] = cnt;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace pss_r16
