@@ -1,0 +1,93 @@
+"""CPU-side checks: the C ABI library loads and exports every symbol include/pss.h declares; the host-side
+filter designer against SciPy's coefficients (golden); error behaviour without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from pyspecsdr_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "pss.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pss_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/pss.h but not exported by libpss.so"
+    assert set(L.exported_symbols()) == set(names), "ctypes table and header drifted apart"
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback():
+    lib = L.load()
+    if lib.pss_device_count() > 0:
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert lib.pss_create(0, C.byref(h)) == L.PSS_E_HIP
+    assert b"no HIP device" in lib.pss_last_error(None)
+    from pyspecsdr_amd.engine import Engine, PssError
+    with pytest.raises(PssError):
+        Engine(0)
+
+
+def test_out_len_and_arg_checks():
+    lib = L.load()
+    assert lib.pss_demod_out_len(L.MODE_NFM, 1024, 2.4e6) == 10       # ceil(1023/108)
+    assert lib.pss_demod_out_len(L.MODE_NFM, 2048, 10e6) == 5         # q = 453
+    assert lib.pss_demod_out_len(L.MODE_NFM, 29, 2.4e6) == 1
+    assert lib.pss_demod_out_len(L.MODE_AM, 16384, 2.4e6) == 16384
+    assert lib.pss_demod_out_len(L.MODE_USB, 300, 1e6) == 300
+    assert lib.pss_demod_out_len(L.MODE_NFM, 1024, 20000.0) < 0       # int(fs/22050) == 0
+    assert lib.pss_demod_out_len(7, 1024, 2.4e6) < 0
+    taps = np.empty(65)
+    assert lib.pss_design_firwin(65, 1.2, taps.ctypes.data) == L.PSS_E_CUTOFF   # scipy firwin ValueError
+    assert lib.pss_design_firwin(65, 0.0, taps.ctypes.data) == L.PSS_E_CUTOFF
+
+
+def ulps(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.max(np.abs(a - b) / np.maximum(np.spacing(np.abs(b)), 1e-300))
+
+
+@pytest.mark.parametrize("fs", [1.024e6, 2.4e6, 10e6, 2.048e6, 250e3])
+def test_designer_matches_scipy(golden, fs):
+    g = golden["nfm"]
+    lib = L.load()
+    key, q = str(int(fs)), int(fs / 22050)
+    taps, sos, zi = np.empty(65), np.empty((4, 6)), np.empty((4, 2))
+    assert lib.pss_design_firwin(65, 15000 / (fs / 2), taps.ctypes.data) == 0
+    assert lib.pss_design_cheby1_sos(8, 0.05, 0.8 / q, sos.ctypes.data) == 0
+    assert lib.pss_design_sosfilt_zi(sos.ctypes.data, 4, zi.ctypes.data) == 0
+    # SciPy evaluates sin/cos/sinh through NumPy's SIMD loops: agreement to a few ulp, not bit-for-bit
+    assert ulps(taps, g["design_taps_" + key]) <= 16
+    assert ulps(sos, g["design_sos_" + key]) <= 16
+    assert np.allclose(zi, g["design_zi_" + key], rtol=1e-9)          # zi is ill-conditioned in 1 + a1 + a2
+    # given SciPy's own sos, sosfilt_zi is reproduced exactly (LAPACK dgesv arithmetic restated)
+    rs = np.ascontiguousarray(g["design_sos_" + key])
+    zi2 = np.empty((4, 2))
+    lib.pss_design_sosfilt_zi(rs.ctypes.data, 4, zi2.ctypes.data)
+    assert np.array_equal(zi2, g["design_zi_" + key])
+
+
+def test_am_table_is_scipy_butter(golden):
+    sos = np.empty((5, 6))
+    L.load().pss_am_bandpass_sos(sos.ctypes.data)
+    assert np.array_equal(sos, golden["am_ssb"]["am_sos"])
+
+
+def test_ssb_taps_design(golden):
+    g = golden["am_ssb"]
+    taps = np.empty(65)
+    for tag in "abc":
+        fs = float(g[f"ssb_fs_{tag}"])
+        assert L.load().pss_design_firwin(65, 3000 / fs, taps.ctypes.data) == 0
+        assert ulps(taps, g[f"ssb_taps_{tag}"]) <= 16
