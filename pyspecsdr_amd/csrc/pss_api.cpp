@@ -1,6 +1,7 @@
 // pss_api.cpp — context management and the host-buffer convenience calls of the C ABI (include/pss.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -85,6 +86,7 @@ extern "C" int pss_create(int device, pss_ctx **out)
     if (e != hipSuccess) return pss_fail(nullptr, PSS_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
     pss_ctx *ctx = new pss_ctx();
     ctx->device = device;
+    { const char *e = getenv("PSS_NO_FUSED"); ctx->no_fused = e && e[0] == '1'; }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return pss_fail(nullptr, PSS_E_HIP, "hipStreamCreate failed"); }
     ctx->own_stream = true;

@@ -32,6 +32,7 @@ struct pss_ctx {
     std::map<int, PssPairwisePlan> plans;
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    bool no_fused = false;  // PSS_NO_FUSED=1: use the three-kernel NFM path (A/B and fallback testing)
     bool timing = false;
     int tdepth = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "pss_ctx.h"
@@ -187,47 +188,73 @@ __global__ __launch_bounds__(128) void k_nfm_edge(const float2 *__restrict__ iq,
 // ---------------------------------------------------------------------------------------------------
 constexpr int IIR_CH = 32;
 
-template <class Load, class LoadChunk, class Out>
+template <bool B121, int CH, class Load, class LoadChunk, class Out>
 __device__ __forceinline__ void iir4_pass(const NfmCoef &c, double (&z)[8], long T, Load load, LoadChunk loadc, Out out)
 {
-    auto sec = [&](int s, double x) { return biquad_step(c.s[s], x, z[2 * s], z[2 * s + 1]); };
+    auto sec = [&](int s, double x) {
+        return (B121 && s > 0) ? biquad_step_121(c.s[s], x, z[2 * s], z[2 * s + 1])
+                               : biquad_step(c.s[s], x, z[2 * s], z[2 * s + 1]);
+    };
     double p0, p1, p2;
     // fill the pipeline (T > 27 always)
     p0 = sec(0, load(0));
     { double t1 = sec(1, p0); p0 = sec(0, load(1)); p1 = t1; }
     { double t2 = sec(2, p1); double t1 = sec(1, p0); p0 = sec(0, load(2)); p2 = t2; p1 = t1; }
+    // One steady-state step: sections 0..3 work on samples t, t-1, t-2, t-3.  The four updates are independent;
+    // they are written stage by stage (with scheduling barriers) so that dependent float64 ops are never
+    // back to back — each section still performs exactly biquad_step()'s operations in its own order.
     auto step = [&](double x) {
-        double o = sec(3, p2);
-        p2 = sec(2, p1);
-        p1 = sec(1, p0);
-        p0 = sec(0, x);
-        return o;
+        const double xs[4] = {x, p0, p1, p2};
+        double m[4], xn[4], t[4], u[4], v[4], w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // numerator products (exact no-ops for a [1,2,1] section)
+            const bool one = B121 && k > 0;
+            m[k] = one ? xs[k] : __dmul_rn(c.s[k].b0, xs[k]);
+            v[k] = one ? __dadd_rn(xs[k], xs[k]) : __dmul_rn(c.s[k].b1, xs[k]);
+            w[k] = one ? xs[k] : __dmul_rn(c.s[k].b2, xs[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) xn[k] = __dadd_rn(m[k], z[2 * k]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { t[k] = __dmul_rn(c.s[k].a1, xn[k]); u[k] = __dmul_rn(c.s[k].a2, xn[k]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = __dsub_rn(v[k], t[k]); w[k] = __dsub_rn(w[k], u[k]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { z[2 * k] = __dadd_rn(v[k], z[2 * k + 1]); z[2 * k + 1] = w[k]; }
+        __builtin_amdgcn_sched_barrier(0);
+        p0 = xn[0]; p1 = xn[1]; p2 = xn[2];
+        return xn[3];
     };
     out(0, step(load(3)));  // one single step so that the chunked part starts at an even input index
-    double b0[IIR_CH], b1[IIR_CH];
-    auto runc = [&](double (&b)[IIR_CH], long r) {
+    double b0[CH], b1[CH];
+    auto runc = [&](double (&b)[CH], long r) {
 #pragma unroll
-        for (int t = 0; t < IIR_CH; t++) out(r + t - 3, step(b[t]));
+        for (int t = 0; t < CH; t++) out(r + t - 3, step(b[t]));
     };
-    const long nfull = (T - 4) / IIR_CH;
+    const long nfull = (T - 4) / CH;
     long r = 4;
     if (nfull > 0) loadc(b0, r);
     for (long ch = 0; ch < nfull; ch += 2) {
-        if (ch + 1 < nfull) loadc(b1, r + IIR_CH);
+        if (ch + 1 < nfull) loadc(b1, r + CH);
         runc(b0, r);
         if (ch + 1 < nfull) {
-            if (ch + 2 < nfull) loadc(b0, r + 2 * IIR_CH);
-            runc(b1, r + IIR_CH);
+            if (ch + 2 < nfull) loadc(b0, r + 2 * CH);
+            runc(b1, r + CH);
         }
-        r += 2 * IIR_CH;
+        r += 2 * CH;
     }
-    for (r = 4 + nfull * IIR_CH; r < T; r++) out(r - 3, step(load(r)));
+    for (r = 4 + nfull * CH; r < T; r++) out(r - 3, step(load(r)));
     // drain
     out(T - 3, sec(3, p2)); p2 = sec(2, p1); p1 = sec(1, p0);
     out(T - 2, sec(3, p2)); p2 = sec(2, p1);
     out(T - 1, sec(3, p2));
 }
 
+template <bool B121>
 __global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, double *__restrict__ Y,
                                                   double *__restrict__ A, int n, int q, int n_out, long n_frames,
                                                   long Lp, NfmCoef c, int16_t *__restrict__ pcm,
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, 
         for (int i = 0; i < 8; i++) z[i] = __dmul_rn(c.zi[i], x0);
     }
     double ylast = 0.0;
-    iir4_pass(c, z, L, [&](long r) { return Uf[r]; },
+    iir4_pass<B121, IIR_CH>(c, z, L, [&](long r) { return Uf[r]; },
               [&](double (&b)[IIR_CH], long r) {  // r is even: 16-byte loads
                   const double2 *p = reinterpret_cast<const double2 *>(Uf + r);
 #pragma unroll
@@ -268,7 +295,7 @@ __global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, 
     bool nan = false;
     long next = EDGE + (long)(n_out - 1) * q;  // largest kept position (p = 27 + j q)
     int j = n_out - 1;
-    iir4_pass(c, z, L - EDGE, [&](long r) { return YAT(L - 1 - r); },
+    iir4_pass<B121, IIR_CH>(c, z, L - EDGE, [&](long r) { return YAT(L - 1 - r); },
               [&](double (&b)[IIR_CH], long r) {
 #pragma unroll
                   for (int t = 0; t < IIR_CH; t++) b[t] = YAT(L - 1 - (r + t));
@@ -296,6 +323,10 @@ __global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, 
     }
 #undef YAT
 }
+
+}  // namespace
+#include "pss_nfm_fused.h"
+namespace {
 
 // ---------------------------------------------------------------------------------------------------
 // numpy float32 pairwise mean of |x| (KIND 1, AM: signal_processing.py:185) or |x|^2 (KIND 0, power: :327).
@@ -690,6 +721,42 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         for (int i = 0; i < 8; i++) c.zi[i] = flt->zi[i];
         const float kscale = (float)(fs / (2.0 * M_PI));          // python float -> float32 scalar (:97)
         const int swapped = ((long)(n - 1) * 8 >= 262144) ? 1 : 0;  // NumPy temporary elision threshold
+        bool b121 = true;  // sections 1..3 with numerator exactly [1, 2, 1] (always so for cheby1 low-pass SOS)
+        for (int s = 1; s < 4; s++)
+            b121 = b121 && flt->sos[6 * s] == 1.0 && flt->sos[6 * s + 1] == 2.0 && flt->sos[6 * s + 2] == 1.0;
+        if (n - 1 >= 128 && !ctx->no_fused) {
+            // fused path: u[] stays on chip; small L2-resident scratch for the irregular head / tail of u
+            const size_t szH = align256((size_t)tiles * fused::HEAD * TILE * sizeof(double));
+            const size_t szT = align256((size_t)tiles * (EDGE + 1) * TILE * sizeof(double));
+            r = pss_ensure_scratch(ctx, szY + szA + szH + szT);
+            if (r) return r;
+            char *base = reinterpret_cast<char *>(ctx->scratch);
+            double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);
+            double *Uh = reinterpret_cast<double *>(base + szY + szA), *Ut = reinterpret_cast<double *>(base + szY + szA + szH);
+            pss_time_begin(ctx);
+            pss_kernel_begin(ctx, "k_nfm_head");
+            hipLaunchKernelGGL(fused::k_nfm_head, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<const float2 *>(d_iq), Uh, n, n_frames, kscale, swapped);
+            pss_kernel_end(ctx);
+            pss_kernel_begin(ctx, "k_nfm_fwd");
+            if (b121)
+                hipLaunchKernelGGL(fused::k_nfm_fwd<true>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, ctx->stream,
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped);
+            else
+                hipLaunchKernelGGL(fused::k_nfm_fwd<false>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, ctx->stream,
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped);
+            pss_kernel_end(ctx);
+            pss_kernel_begin(ctx, "k_nfm_bwd");
+            if (b121)
+                hipLaunchKernelGGL(fused::k_nfm_bwd<true>, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, Yf, Af, n, q,
+                                   n_out, n_frames, c, d_pcm, d_audio);
+            else
+                hipLaunchKernelGGL(fused::k_nfm_bwd<false>, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, Yf, Af, n, q,
+                                   n_out, n_frames, c, d_pcm, d_audio);
+            pss_kernel_end(ctx);
+            pss_time_end(ctx);
+            return pss_hip_check(ctx, hipGetLastError(), "nfm fused launch");
+        }
         const int cpf = (n - 1 + FIR_CH - 1) / FIR_CH;
         const long items = n_frames * cpf;
         const long g1 = items < 256L * 64 ? items : 256L * 64;
@@ -703,8 +770,12 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
                            reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, Lp, kscale, swapped);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_nfm_iir");
-        hipLaunchKernelGGL(k_nfm_iir, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, U, Y, A, n, q, n_out, n_frames, Lp,
-                           c, d_pcm, d_audio);
+        if (b121)
+            hipLaunchKernelGGL(k_nfm_iir<true>, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, U, Y, A, n, q, n_out,
+                               n_frames, Lp, c, d_pcm, d_audio);
+        else
+            hipLaunchKernelGGL(k_nfm_iir<false>, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, U, Y, A, n, q, n_out,
+                               n_frames, Lp, c, d_pcm, d_audio);
         pss_kernel_end(ctx);
         pss_time_end(ctx);
         return pss_hip_check(ctx, hipGetLastError(), "nfm launch");

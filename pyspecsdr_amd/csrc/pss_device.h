@@ -249,6 +249,16 @@ __device__ __forceinline__ double biquad_step(const Biquad &c, double x, double 
     return xn;
 }
 
+// The same step for a section whose numerator is exactly [1, 2, 1] (every section but the first of SciPy's
+// cheby1 / butter low-pass SOS): 1.0*x == x and 2.0*x == x+x exactly, so dropping the multiplies is bit-identical.
+__device__ __forceinline__ double biquad_step_121(const Biquad &c, double x, double &z0, double &z1)
+{
+    double xn = __dadd_rn(x, z0);
+    z0 = __dadd_rn(__dsub_rn(__dadd_rn(x, x), __dmul_rn(c.a1, xn)), z1);
+    z1 = __dsub_rn(x, __dmul_rn(c.a2, xn));
+    return xn;
+}
+
 // np.int16(v * 32767): truncation toward zero, NaN -> 0 (io_manager.py:26, audio_processing.py:37)
 __device__ __forceinline__ int16_t pcm16(double a)
 {

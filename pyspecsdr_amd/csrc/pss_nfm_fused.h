@@ -1,0 +1,326 @@
+// pss_nfm_fused.h — fused NFM kernel: discriminator + FIR + zero-phase Chebyshev decimator + normalise + int16
+// for one tile of 64 frames per 256-thread workgroup (included by pss_demod.hip; same -ffp-contract=off rules).
+//
+// Why fused: with separate kernels the FIR output u[] (8.6 KB/frame float64) is written and read back, which —
+// together with the forward-IIR output y[] that the backward pass needs — made the demodulator traffic-bound.
+// Here u[] never leaves the chip:
+//   wave 0      IIR wave, lane = frame (the recurrence is serial in time): consumes u chunk by chunk from LDS,
+//               runs the 4-section skewed pipeline, streams y_fwd to HBM (transposed, 512-byte rows), then runs
+//               the backward pass alone and emits the decimated, normalised int16 / float64 audio.
+//   waves 1..3  FIR workers: thread (frame f, third j) produces 8 consecutive FIR outputs per chunk of 24 in the
+//               exact OpenBLAS-ddot tree (taps as SGPR operands, 16 at a time), from a float32 discriminator
+//               window in LDS (96 columns = 4 rotating blocks of 24, so nothing is ever shifted), and computes the
+//               discriminator of the NEXT chunk's 8 samples from IQ prefetched before the FIR.
+// Per chunk: two workgroup barriers.  LDS: window 64 x 97 x 4 B + one u chunk 64 x 24 x 8 B = 37 KB -> 4 workgroups
+// (= all 4 tiles of a CU at BASELINE cfg 2) resident per CU, 4 waves per SIMD.
+// The first 64 FIR outputs (windows shorter than 65 taps) and SciPy's odd extension are irregular: the prologue
+// computes u[0..63] with the predicated per-lane ddot and parks them in a small global scratch (L2-resident), the
+// workers park the last 28 outputs likewise, and the IIR wave builds the extension from those.
+#pragma once
+
+namespace fused {
+
+using namespace pss;
+
+constexpr int FC = 24;         // time steps per chunk
+constexpr int NB = 4;          // window blocks
+constexpr int WCOLS = NB * FC; // 96 window columns: logical column l <-> time 24 c - 8 + l at chunk c
+constexpr int WSTR = 97;       // float row stride (odd: conflict-free for lane = frame at a fixed column)
+constexpr int HEAD = 64;       // outputs produced by the prologue
+constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double);
+
+struct Iir4 {
+    // skewed 4-section pipeline, see iir4_pass in pss_demod.hip
+    double z[8];
+    double p0, p1, p2;
+};
+
+template <bool B121>
+__device__ __forceinline__ double sec_step(const NfmCoef &c, Iir4 &st, int s, double x)
+{
+    return (B121 && s > 0) ? biquad_step_121(c.s[s], x, st.z[2 * s], st.z[2 * s + 1])
+                           : biquad_step(c.s[s], x, st.z[2 * s], st.z[2 * s + 1]);
+}
+
+template <bool B121>
+__device__ __forceinline__ double pipe_step(const NfmCoef &c, Iir4 &st, double x)
+{
+    const double xs[4] = {x, st.p0, st.p1, st.p2};
+    double m[4], xn[4], t[4], u[4], v[4], w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool one = B121 && k > 0;
+        m[k] = one ? xs[k] : __dmul_rn(c.s[k].b0, xs[k]);
+        v[k] = one ? __dadd_rn(xs[k], xs[k]) : __dmul_rn(c.s[k].b1, xs[k]);
+        w[k] = one ? xs[k] : __dmul_rn(c.s[k].b2, xs[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) xn[k] = __dadd_rn(m[k], st.z[2 * k]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { t[k] = __dmul_rn(c.s[k].a1, xn[k]); u[k] = __dmul_rn(c.s[k].a2, xn[k]); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = __dsub_rn(v[k], t[k]); w[k] = __dsub_rn(w[k], u[k]); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { st.z[2 * k] = __dadd_rn(v[k], st.z[2 * k + 1]); st.z[2 * k + 1] = w[k]; }
+    st.p0 = xn[0]; st.p1 = xn[1]; st.p2 = xn[2];
+    return xn[3];
+}
+
+// FBH consecutive full-window FIR outputs (outputs 4H .. 4H+3 of the thread's 8) for worker third J.  Window column
+// of x(c') (c' = 0..71 relative to the thread's first output) is l = 8 + 8 J + c'; blk[b] points at this frame's
+// row inside logical block b.  Four outputs at a time keeps the accumulators at 16 doubles (the kernel must fit
+// the 128-VGPR budget of 4 waves/SIMD).
+constexpr int FBH = 4;
+template <int J, int H>
+__device__ __forceinline__ void fir_batch(const float *const (&blk)[NB], const double *__restrict__ yrev, double (&out)[8])
+{
+    auto x = [&](int cc) {
+        const int l = 8 + 8 * J + FBH * H + cc;
+        return (double)blk[l / FC][l % FC];
+    };
+    double s[FBH][4];
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        double ya[8], yb[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) { ya[l] = yrev[8 * k + l]; yb[l] = yrev[32 + 8 * k + l]; }
+        // k is a run-time loop index (keeps only 16 taps live in SGPRs): the column arithmetic must stay
+        // compile-time, so the four k cases are spelled out
+        auto phase = [&](auto KC) {
+            constexpr int K = decltype(KC)::value;
+#pragma unroll
+            for (int o = 0; o < FBH; o++) {
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    double lo = __fma_rn(x(8 * K + o + 32 + l), yb[l], __fma_rn(x(8 * K + o + l), ya[l], 0.0));
+                    double hi = __fma_rn(x(8 * K + o + 36 + l), yb[l + 4], __fma_rn(x(8 * K + o + l + 4), ya[l + 4], 0.0));
+                    double a = __dadd_rn(lo, hi);
+                    s[o][l] = (K == 0) ? a : __dadd_rn(s[o][l], a);
+                }
+            }
+        };
+        if (k == 0) phase(std::integral_constant<int, 0>{});
+        else if (k == 1) phase(std::integral_constant<int, 1>{});
+        else if (k == 2) phase(std::integral_constant<int, 2>{});
+        else phase(std::integral_constant<int, 3>{});
+    }
+    const double y64 = yrev[64];
+#pragma unroll
+    for (int o = 0; o < FBH; o++) {
+        double dot = __dadd_rn(__dadd_rn(s[o][0], s[o][2]), __dadd_rn(s[o][1], s[o][3]));
+        out[FBH * H + o] = __fma_rn(y64, x(o + 64), dot);
+    }
+}
+
+// First 64 FIR outputs of every frame (windows shorter than 65 samples; one output per lane, predicated ddot),
+// parked TRANSPOSED in Uh[tile][i][lane] for the IIR wave of k_nfm_fwd.  One wavefront per frame-quarter:
+// workgroup = 256 threads = 4 frames.
+__global__ __launch_bounds__(256) void k_nfm_head(const float2 *__restrict__ iq, double *__restrict__ Uh, int n,
+                                                  long n_frames, float kscale, int swapped)
+{
+    __shared__ double d[4][64];
+    __shared__ double ltaps[72];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long f = (long)blockIdx.x * 4 + wave;
+    const int M = n - 1;
+    if (tid < 65) ltaps[tid] = c_taps[tid];
+    if (f < n_frames) {
+        const float2 *x = iq + (size_t)f * n;
+        d[wave][lane] = (lane < M) ? (double)disc_sample(x[lane + 1], x[lane], kscale, swapped != 0) : 0.0;
+    }
+    __syncthreads();
+    if (f < n_frames) {
+        const int i = lane;
+        const double *dw = d[wave];
+        double v = ddot_skx_lane([&](int j) { return dw[j]; }, [&](int j) { return ltaps[i - j]; }, i + 1);
+        Uh[((size_t)(f / TILE) * HEAD + i) * TILE + (f % TILE)] = v;
+    }
+}
+
+template <bool B121>
+__global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
+                                                    const double *__restrict__ Uh, double *__restrict__ Utl, int n,
+                                                    long n_frames, NfmCoef c, float kscale, int swapped)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
+    double *ubuf = reinterpret_cast<double *>(smem + (size_t)TILE * WSTR * sizeof(float));  // [FC][TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long tile = blockIdx.x;
+    const int M = n - 1;                      // FIR outputs per frame (M >= 128 guaranteed by the caller)
+    const long L = (long)M + 2 * EDGE;
+    const int NC = (M - HEAD + FC - 1) / FC;  // worker chunks
+    const long f = tile * TILE + lane;
+    const long fr = f < n_frames ? f : n_frames - 1;  // masked lanes replay the last frame (results dropped)
+    const float2 *xq = iq + (size_t)fr * n;
+    double *Yt = Y + (size_t)tile * L * TILE + lane;
+    const double *Uht = Uh + (size_t)tile * HEAD * TILE + lane;
+    double *Utt = Utl + (size_t)tile * (EDGE + 1) * TILE + lane;
+#define YAT(p) Yt[(size_t)(p) * TILE]
+    // ---- prologue: discriminator of times 0..87 into logical columns 8..95 (physical = logical at chunk 0)
+    for (int idx = tid; idx < TILE * WCOLS; idx += 256) {
+        const int fl = idx / WCOLS, l = idx % WCOLS, t = l - 8;
+        const long ff = tile * TILE + fl;
+        const float2 *x = iq + (size_t)(ff < n_frames ? ff : n_frames - 1) * n;
+        float d = 0.0f;
+        if (t >= 0 && t < M) d = disc_sample(x[t + 1], x[t], kscale, swapped != 0);
+        win[fl * WSTR + l] = d;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // =============================== IIR wave ===============================
+        Iir4 st;
+        long p = 0;  // stream position of the next input; outputs lag by 3
+        auto emit = [&](double v) { YAT(p - 3) = v; };
+        // odd extension head + u[0..63] from the prologue (scipy odd_ext: ext[p] = 2u[0] - u[27-p])
+        const double u0 = Uht[0];
+        const double two_u0 = __dmul_rn(2.0, u0);
+        auto head = [&](int pp) { return pp < EDGE ? __dsub_rn(two_u0, Uht[(size_t)(EDGE - pp) * TILE]) : Uht[(size_t)(pp - EDGE) * TILE]; };
+        {
+            const double x0 = head(0);
+#pragma unroll
+            for (int i = 0; i < 8; i++) st.z[i] = __dmul_rn(c.zi[i], x0);
+            st.p0 = sec_step<B121>(c, st, 0, x0);
+            { double t1 = sec_step<B121>(c, st, 1, st.p0); st.p0 = sec_step<B121>(c, st, 0, head(1)); st.p1 = t1; }
+            { double t2 = sec_step<B121>(c, st, 2, st.p1); double t1 = sec_step<B121>(c, st, 1, st.p0);
+              st.p0 = sec_step<B121>(c, st, 0, head(2)); st.p2 = t2; st.p1 = t1; }
+            p = 3;
+        }
+#pragma unroll 4
+        for (int pp = 3; pp < EDGE + HEAD; pp++) { double v = pipe_step<B121>(c, st, head(pp)); emit(v); p++; }
+        // chunks from the workers
+        double reg[FC];
+        for (int ch = 0; ch <= NC; ch++) {
+            if (ch >= 1) {
+                const int cnt = (M - HEAD - (ch - 1) * FC) < FC ? (M - HEAD - (ch - 1) * FC) : FC;
+                if (cnt == FC) {
+#pragma unroll
+                    for (int t = 0; t < FC; t++) { double v = pipe_step<B121>(c, st, reg[t]); emit(v); p++; }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < FC; t++)
+                        if (t < cnt) { double v = pipe_step<B121>(c, st, reg[t]); emit(v); p++; }
+                }
+            }
+            __syncthreads();  // A: workers finished FIR(ch) -> ubuf
+            if (ch < NC) {
+#pragma unroll
+                for (int t = 0; t < FC; t++) reg[t] = ubuf[t * TILE + lane];
+            }
+            __syncthreads();  // B
+        }
+        // odd extension tail: ext[27+M+k] = 2u[M-1] - u[M-2-k]; Utt[r] = u[M-28+r]
+        {
+            const double two_uL = __dmul_rn(2.0, Utt[(size_t)EDGE * TILE]);
+#pragma unroll 3
+            for (int k = 0; k < EDGE; k++) {
+                double v = pipe_step<B121>(c, st, __dsub_rn(two_uL, Utt[(size_t)(EDGE - 1 - k) * TILE]));
+                emit(v); p++;
+            }
+        }
+        // drain
+        { double v = sec_step<B121>(c, st, 3, st.p2); emit(v); p++; st.p2 = sec_step<B121>(c, st, 2, st.p1); st.p1 = sec_step<B121>(c, st, 1, st.p0); }
+        { double v = sec_step<B121>(c, st, 3, st.p2); emit(v); p++; st.p2 = sec_step<B121>(c, st, 2, st.p1); }
+        { double v = sec_step<B121>(c, st, 3, st.p2); emit(v); p++; }
+    } else {
+        // =============================== FIR workers ===============================
+        const int J = wave - 1;  // third of the chunk handled by this wave (wave-uniform)
+        float *row = win + lane * WSTR;
+        int rot = 0;  // physical block of logical block 0
+        for (int ch = 0; ch <= NC; ch++) {
+            if (ch < NC) {
+                const int ibase = HEAD + ch * FC + 8 * J;  // first output index of this thread's batch
+                // prefetch the IQ of the next chunk's 8 samples (9 complex) before the FIR
+                const int tn = HEAD + (ch + 1) * FC + 8 * J;  // = time of the next chunk's first new sample for this thread
+                float2 pre[9];
+#pragma unroll
+                for (int e = 0; e < 9; e++) pre[e] = (tn + e < n) ? xq[tn + e] : make_float2(0.0f, 0.0f);
+                const float *blk[NB];
+#pragma unroll
+                for (int b = 0; b < NB; b++) blk[b] = row + ((b + rot) & (NB - 1)) * FC;
+                double out[8];
+                if (J == 0) { fir_batch<0, 0>(blk, c_taps_rev, out); fir_batch<0, 1>(blk, c_taps_rev, out); }
+                else if (J == 1) { fir_batch<1, 0>(blk, c_taps_rev, out); fir_batch<1, 1>(blk, c_taps_rev, out); }
+                else { fir_batch<2, 0>(blk, c_taps_rev, out); fir_batch<2, 1>(blk, c_taps_rev, out); }
+#pragma unroll
+                for (int o = 0; o < 8; o++) {
+                    const int i = ibase + o;
+                    ubuf[(8 * J + o) * TILE + lane] = out[o];
+                    if (i < M && i >= M - 1 - EDGE) Utt[(size_t)(i - (M - 1 - EDGE)) * TILE] = out[o];
+                }
+                // discriminator of the next chunk's samples (kept in registers until the window block is free)
+                float dn[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) dn[e] = (tn + e < M) ? disc_sample(pre[e + 1], pre[e], kscale, swapped != 0) : 0.0f;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();  // A
+                // the oldest block (logical 0) becomes the newest (logical 3 of the next chunk)
+                float *nb = row + rot * FC + 8 * J;
+#pragma unroll
+                for (int e = 0; e < 8; e++) nb[e] = dn[e];
+                rot = (rot + 1) & (NB - 1);
+                __syncthreads();  // B
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();  // A
+                __syncthreads();  // B
+            }
+        }
+    }
+#undef YAT
+}
+
+
+// Backward pass of sosfiltfilt over y_fwd (read in reverse from Y[tile][p][lane]), decimation [::q], peak
+// normalisation, stereo int16 / float64 audio.  One wavefront per tile, lane = frame.
+template <bool B121>
+__global__ __launch_bounds__(TILE) void k_nfm_bwd(const double *__restrict__ Y, double *__restrict__ A, int n, int q,
+                                                  int n_out, long n_frames, NfmCoef c, int16_t *__restrict__ pcm,
+                                                  double *__restrict__ audio)
+{
+    const int lane = threadIdx.x;
+    const long tile = blockIdx.x;
+    const long f = tile * TILE + lane;
+    const int M = n - 1;
+    const long L = (long)M + 2 * EDGE;
+    const double *Yt = Y + (size_t)tile * L * TILE + lane;
+    double *At = A + (size_t)tile * n_out * TILE + lane;
+#define YAT(p) Yt[(size_t)(p) * TILE]
+    const double ylast = YAT(L - 1);
+    double z[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = __dmul_rn(c.zi[i], ylast);
+    double mx = 0.0;
+    bool nan = false;
+    long next = EDGE + (long)(n_out - 1) * q;  // largest kept position (p = 27 + j q)
+    int j = n_out - 1;
+    iir4_pass<B121, IIR_CH>(c, z, L - EDGE, [&](long r) { return YAT(L - 1 - r); },
+                            [&](double (&b)[IIR_CH], long r) {
+#pragma unroll
+                                for (int t = 0; t < IIR_CH; t++) b[t] = YAT(L - 1 - (r + t));
+                            },
+                            [&](long r, double v) {
+                                if (L - 1 - r == next) {
+                                    At[(size_t)j * TILE] = v;
+                                    double av = fabs(v);
+                                    nan = nan || (av != av);
+                                    mx = av > mx ? av : mx;
+                                    next -= q;
+                                    j--;
+                                }
+                            });
+    if (nan) mx = __builtin_nan("");
+    if (f < n_frames) {
+        for (int k = 0; k < n_out; k++) {
+            double a = __dmul_rn(__ddiv_rn(At[(size_t)k * TILE], mx), 0.95);  // audio / max|audio| * 0.95
+            if (audio) audio[(size_t)f * n_out + k] = a;
+            if (pcm) {
+                uint16_t s = (uint16_t)pcm16(a);
+                reinterpret_cast<uint32_t *>(pcm)[(size_t)f * n_out + k] = (uint32_t)s | ((uint32_t)s << 16);
+            }
+        }
+    }
+#undef YAT
+}
+
+}  // namespace fused
