@@ -13,6 +13,7 @@
 #pragma clang fp contract(off)
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -733,6 +734,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             char *base = reinterpret_cast<char *>(ctx->scratch);
             double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);
             double *Uh = reinterpret_cast<double *>(base + szY + szA), *Ut = reinterpret_cast<double *>(base + szY + szA + szH);
+            const int abl = getenv("PSS_ABLATE") ? atoi(getenv("PSS_ABLATE")) : 0;  // dev-only timing ablation
             pss_time_begin(ctx);
             pss_kernel_begin(ctx, "k_nfm_head");
             hipLaunchKernelGGL(fused::k_nfm_head, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, ctx->stream,
@@ -741,10 +743,10 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             pss_kernel_begin(ctx, "k_nfm_fwd");
             if (b121)
                 hipLaunchKernelGGL(fused::k_nfm_fwd<true>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, ctx->stream,
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped);
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, abl);
             else
                 hipLaunchKernelGGL(fused::k_nfm_fwd<false>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, ctx->stream,
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped);
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, abl);
             pss_kernel_end(ctx);
             pss_kernel_begin(ctx, "k_nfm_bwd");
             if (b121)

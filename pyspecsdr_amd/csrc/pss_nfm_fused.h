@@ -29,6 +29,14 @@ constexpr int WSTR = 97;       // float row stride (odd: conflict-free for lane 
 constexpr int HEAD = 64;       // outputs produced by the prologue
 constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double);
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence that also waits for every
+// outstanding GLOBAL store of the wave (vmcnt(0)); the IIR wave has 24 y_fwd row stores in flight per chunk, and
+// draining them twice per chunk serialised the whole pipeline on the store round trip.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct Iir4 {
     // skewed 4-section pipeline, see iir4_pass in pss_demod.hip
     double z[8];
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(256) void k_nfm_head(const float2 *__restrict__ iq,
 template <bool B121>
 __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
                                                     const double *__restrict__ Uh, double *__restrict__ Utl, int n,
-                                                    long n_frames, NfmCoef c, float kscale, int swapped)
+                                                    long n_frames, NfmCoef c, float kscale, int swapped, int abl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
@@ -195,19 +203,22 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
                 const int cnt = (M - HEAD - (ch - 1) * FC) < FC ? (M - HEAD - (ch - 1) * FC) : FC;
                 if (cnt == FC) {
 #pragma unroll
-                    for (int t = 0; t < FC; t++) { double v = pipe_step<B121>(c, st, reg[t]); emit(v); p++; }
+                    for (int t = 0; t < FC; t++) { double v = (abl & 4) ? reg[t] : pipe_step<B121>(c, st, reg[t]); emit(v); p++; }
                 } else {
 #pragma unroll
                     for (int t = 0; t < FC; t++)
                         if (t < cnt) { double v = pipe_step<B121>(c, st, reg[t]); emit(v); p++; }
                 }
             }
-            __syncthreads();  // A: workers finished FIR(ch) -> ubuf
             if (ch < NC) {
+                lds_barrier();  // A: workers finished FIR(ch) -> ubuf
 #pragma unroll
                 for (int t = 0; t < FC; t++) reg[t] = ubuf[t * TILE + lane];
+                lds_barrier();  // B
+            } else {
+                __syncthreads();  // final A/B: full fences, the workers' global Utt rows must be visible
+                __syncthreads();
             }
-            __syncthreads();  // B
         }
         // odd extension tail: ext[27+M+k] = 2u[M-1] - u[M-2-k]; Utt[r] = u[M-28+r]
         {
@@ -230,36 +241,46 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
         for (int ch = 0; ch <= NC; ch++) {
             if (ch < NC) {
                 const int ibase = HEAD + ch * FC + 8 * J;  // first output index of this thread's batch
-                // prefetch the IQ of the next chunk's 8 samples (9 complex) before the FIR
-                const int tn = HEAD + (ch + 1) * FC + 8 * J;  // = time of the next chunk's first new sample for this thread
-                float2 pre[9];
-#pragma unroll
-                for (int e = 0; e < 9; e++) pre[e] = (tn + e < n) ? xq[tn + e] : make_float2(0.0f, 0.0f);
+                const int tn = HEAD + (ch + 1) * FC + 8 * J;  // time of this thread's first new sample of the next chunk
                 const float *blk[NB];
 #pragma unroll
                 for (int b = 0; b < NB; b++) blk[b] = row + ((b + rot) & (NB - 1)) * FC;
-                double out[8];
-                if (J == 0) { fir_batch<0, 0>(blk, c_taps_rev, out); fir_batch<0, 1>(blk, c_taps_rev, out); }
-                else if (J == 1) { fir_batch<1, 0>(blk, c_taps_rev, out); fir_batch<1, 1>(blk, c_taps_rev, out); }
-                else { fir_batch<2, 0>(blk, c_taps_rev, out); fir_batch<2, 1>(blk, c_taps_rev, out); }
+                auto put = [&](const double (&out)[8], int h) {
 #pragma unroll
-                for (int o = 0; o < 8; o++) {
-                    const int i = ibase + o;
-                    ubuf[(8 * J + o) * TILE + lane] = out[o];
-                    if (i < M && i >= M - 1 - EDGE) Utt[(size_t)(i - (M - 1 - EDGE)) * TILE] = out[o];
+                    for (int o = FBH * h; o < FBH * h + FBH; o++) {
+                        const int i = ibase + o;
+                        ubuf[(8 * J + o) * TILE + lane] = out[o];
+                        if (i < M && i >= M - 1 - EDGE) Utt[(size_t)(i - (M - 1 - EDGE)) * TILE] = out[o];
+                    }
+                };
+                {
+                    double out[8];
+                    if (abl & 2) {
+#pragma unroll
+                        for (int o = 0; o < 8; o++) out[o] = (double)blk[1][o];
+                        put(out, 0); put(out, 1);
+                    } else if (J == 0) { fir_batch<0, 0>(blk, c_taps_rev, out); put(out, 0); fir_batch<0, 1>(blk, c_taps_rev, out); put(out, 1); }
+                    else if (J == 1) { fir_batch<1, 0>(blk, c_taps_rev, out); put(out, 0); fir_batch<1, 1>(blk, c_taps_rev, out); put(out, 1); }
+                    else { fir_batch<2, 0>(blk, c_taps_rev, out); put(out, 0); fir_batch<2, 1>(blk, c_taps_rev, out); put(out, 1); }
                 }
-                // discriminator of the next chunk's samples (kept in registers until the window block is free)
+                // discriminator of the next chunk's 8 samples (9 complex); kept in registers until the window block
+                // is free.  The loads are issued after the FIR so they do not occupy registers across it — the other
+                // three waves of the SIMD cover their latency.
                 float dn[8];
+                {
+                    float2 pre[9];
 #pragma unroll
-                for (int e = 0; e < 8; e++) dn[e] = (tn + e < M) ? disc_sample(pre[e + 1], pre[e], kscale, swapped != 0) : 0.0f;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __syncthreads();  // A
+                    for (int e = 0; e < 9; e++) pre[e] = (tn + e < n) ? xq[tn + e] : make_float2(0.0f, 0.0f);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) dn[e] = (abl & 1) ? pre[e].x : ((tn + e < M) ? disc_sample(pre[e + 1], pre[e], kscale, swapped != 0) : 0.0f);
+                }
+                lds_barrier();  // A
                 // the oldest block (logical 0) becomes the newest (logical 3 of the next chunk)
                 float *nb = row + rot * FC + 8 * J;
 #pragma unroll
                 for (int e = 0; e < 8; e++) nb[e] = dn[e];
                 rot = (rot + 1) & (NB - 1);
-                __syncthreads();  // B
+                lds_barrier();  // B
             } else {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __syncthreads();  // A
