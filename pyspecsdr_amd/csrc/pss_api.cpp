@@ -52,12 +52,12 @@ void pss_kernel_begin(pss_ctx *ctx, const char *name)
         ctx->krecs.push_back(r);
     }
     ctx->krecs[ctx->kused].name = name;
-    hipEventRecord(ctx->krecs[ctx->kused].e0, ctx->stream);
+    hipEventRecord(ctx->krecs[ctx->kused].e0, PSS_STREAM(ctx));
 }
 void pss_kernel_end(pss_ctx *ctx)
 {
     if (!ctx->timing) return;
-    hipEventRecord(ctx->krecs[ctx->kused].e1, ctx->stream);
+    hipEventRecord(ctx->krecs[ctx->kused].e1, PSS_STREAM(ctx));
     ctx->kused++;
 }
 void pss_time_end(pss_ctx *ctx)
@@ -92,6 +92,9 @@ extern "C" int pss_create(int device, pss_ctx **out)
     ctx->own_stream = true;
     hipEventCreate(&ctx->ev0);
     hipEventCreate(&ctx->ev1);
+    hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     *out = ctx;
     return PSS_OK;
 }
@@ -110,6 +113,10 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     if (ctx->scratch) hipFree(ctx->scratch);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
+    hipStreamSynchronize(ctx->stream2);
+    hipStreamDestroy(ctx->stream2);
+    hipEventDestroy(ctx->ev_fork);
+    hipEventDestroy(ctx->ev_join);
     for (auto &k : ctx->krecs) { hipEventDestroy(k.e0); hipEventDestroy(k.e1); }
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;

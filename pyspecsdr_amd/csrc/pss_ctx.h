@@ -24,6 +24,10 @@ struct pss_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream2 = nullptr;  // side stream: the spectrum kernel of pss_spectrum_nfm runs beside the demodulator
+    hipStream_t cur = nullptr;      // stream the next launches go to (nullptr = `stream`)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fork_after_fwd = false;
     std::string err;
     std::map<int, double2 *> tw;       // exp(-2 pi i k / N), k < N
     std::map<int, double *> win;       // np.hamming(N)
@@ -51,6 +55,8 @@ void pss_time_end(pss_ctx *ctx);
 // bracket ONE kernel launch with events on the context's stream (no-ops unless timing is enabled)
 void pss_kernel_begin(pss_ctx *ctx, const char *name);
 void pss_kernel_end(pss_ctx *ctx);
+
+#define PSS_STREAM(ctx) ((ctx)->cur ? (ctx)->cur : (ctx)->stream)
 
 #define PSS_HIP(ctx, call)                                         \
     do {                                                           \

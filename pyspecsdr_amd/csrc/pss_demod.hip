@@ -601,7 +601,7 @@ int launch_pairwise(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float
                                          (int)lds));
     long g = n_frames < 8192 ? n_frames : 8192;
     pss_kernel_begin(ctx, "k_pairwise");
-    hipLaunchKernelGGL(kern, dim3((int)g), dim3(TPB), lds, ctx->stream, reinterpret_cast<const float2 *>(d_iq), n,
+    hipLaunchKernelGGL(kern, dim3((int)g), dim3(TPB), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n,
                        n_frames, p->d_leaf_off, p->d_leaf_len, p->n_leaves, p->d_node_l, p->d_node_r, p->d_level_start,
                        p->n_levels, d_out);
     pss_kernel_end(ctx);
@@ -643,8 +643,8 @@ int upload_taps(pss_ctx *ctx, const double *taps)
 {
     double rev[65];
     for (int j = 0; j < 65; j++) rev[j] = taps[64 - j];
-    PSS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_taps), taps, sizeof(double) * 65, 0, hipMemcpyHostToDevice, ctx->stream));
-    PSS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_taps_rev), rev, sizeof(double) * 65, 0, hipMemcpyHostToDevice, ctx->stream));
+    PSS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_taps), taps, sizeof(double) * 65, 0, hipMemcpyHostToDevice, PSS_STREAM(ctx)));
+    PSS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_taps_rev), rev, sizeof(double) * 65, 0, hipMemcpyHostToDevice, PSS_STREAM(ctx)));
     return PSS_OK;
 }
 
@@ -681,7 +681,7 @@ extern "C" int pss_agc_steps(pss_ctx *ctx, const float *d_power, long n, int sta
     if (!d_power || !d_idx_out || n < 0 || n_gains < 1) return pss_fail(ctx, PSS_E_ARG, "bad agc arguments");
     if (n == 0) return PSS_OK;
     pss_kernel_begin(ctx, "k_agc");
-    hipLaunchKernelGGL(k_agc, dim3(1), dim3(1), 0, ctx->stream, d_power, n, start_idx, n_gains, d_idx_out);
+    hipLaunchKernelGGL(k_agc, dim3(1), dim3(1), 0, PSS_STREAM(ctx), d_power, n, start_idx, n_gains, d_idx_out);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_agc launch");
 }
@@ -737,23 +737,24 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             const int abl = getenv("PSS_ABLATE") ? atoi(getenv("PSS_ABLATE")) : 0;  // dev-only timing ablation
             pss_time_begin(ctx);
             pss_kernel_begin(ctx, "k_nfm_head");
-            hipLaunchKernelGGL(fused::k_nfm_head, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(fused::k_nfm_head, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, PSS_STREAM(ctx),
                                reinterpret_cast<const float2 *>(d_iq), Uh, n, n_frames, kscale, swapped);
             pss_kernel_end(ctx);
             pss_kernel_begin(ctx, "k_nfm_fwd");
             if (b121)
-                hipLaunchKernelGGL(fused::k_nfm_fwd<true>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, ctx->stream,
+                hipLaunchKernelGGL(fused::k_nfm_fwd<true>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, PSS_STREAM(ctx),
                                    reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, abl);
             else
-                hipLaunchKernelGGL(fused::k_nfm_fwd<false>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, ctx->stream,
+                hipLaunchKernelGGL(fused::k_nfm_fwd<false>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, PSS_STREAM(ctx),
                                    reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, abl);
             pss_kernel_end(ctx);
+            if (ctx->fork_after_fwd) hipEventRecord(ctx->ev_fork, ctx->stream);  // pss_spectrum_nfm overlaps the rest
             pss_kernel_begin(ctx, "k_nfm_bwd");
             if (b121)
-                hipLaunchKernelGGL(fused::k_nfm_bwd<true>, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, Yf, Af, n, q,
+                hipLaunchKernelGGL(fused::k_nfm_bwd<true>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af, n, q,
                                    n_out, n_frames, c, d_pcm, d_audio);
             else
-                hipLaunchKernelGGL(fused::k_nfm_bwd<false>, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, Yf, Af, n, q,
+                hipLaunchKernelGGL(fused::k_nfm_bwd<false>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af, n, q,
                                    n_out, n_frames, c, d_pcm, d_audio);
             pss_kernel_end(ctx);
             pss_time_end(ctx);
@@ -764,19 +765,19 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const long g1 = items < 256L * 64 ? items : 256L * 64;
         pss_time_begin(ctx);
         pss_kernel_begin(ctx, "k_nfm_front");
-        hipLaunchKernelGGL(k_nfm_front, dim3((unsigned)g1), dim3(FIR_T), 0, ctx->stream,
+        hipLaunchKernelGGL(k_nfm_front, dim3((unsigned)g1), dim3(FIR_T), 0, PSS_STREAM(ctx),
                            reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, cpf, Lp, kscale, swapped);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_nfm_edge");
-        hipLaunchKernelGGL(k_nfm_edge, dim3((unsigned)n_frames), dim3(128), 0, ctx->stream,
+        hipLaunchKernelGGL(k_nfm_edge, dim3((unsigned)n_frames), dim3(128), 0, PSS_STREAM(ctx),
                            reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, Lp, kscale, swapped);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_nfm_iir");
         if (b121)
-            hipLaunchKernelGGL(k_nfm_iir<true>, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, U, Y, A, n, q, n_out,
+            hipLaunchKernelGGL(k_nfm_iir<true>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), U, Y, A, n, q, n_out,
                                n_frames, Lp, c, d_pcm, d_audio);
         else
-            hipLaunchKernelGGL(k_nfm_iir<false>, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, U, Y, A, n, q, n_out,
+            hipLaunchKernelGGL(k_nfm_iir<false>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), U, Y, A, n, q, n_out,
                                n_frames, Lp, c, d_pcm, d_audio);
         pss_kernel_end(ctx);
         pss_time_end(ctx);
@@ -801,14 +802,14 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         r = launch_pairwise<1>(ctx, d_iq, n_frames, n, mu);
         if (r) return r;
         pss_kernel_begin(ctx, "k_am_iir");
-        hipLaunchKernelGGL(k_am_iir, dim3((unsigned)tiles), dim3(TILE), 0, ctx->stream, reinterpret_cast<const float2 *>(d_iq),
+        hipLaunchKernelGGL(k_am_iir, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq),
                            mu, Yf, mx, n, n_frames, c);
         pss_kernel_end(ctx);
         size_t total = (size_t)n_frames * n;
         size_t g = (total + TPB - 1) / TPB;
         if (g > 16384) g = 16384;
         pss_kernel_begin(ctx, "k_finalize");
-        hipLaunchKernelGGL(k_finalize, dim3((unsigned)g), dim3(TPB), 0, ctx->stream, Yf, mx, n, n_frames, d_pcm, d_audio);
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)g), dim3(TPB), 0, PSS_STREAM(ctx), Yf, mx, n, n_frames, d_pcm, d_audio);
         pss_kernel_end(ctx);
         pss_time_end(ctx);
         return pss_hip_check(ctx, hipGetLastError(), "am launch");
@@ -828,19 +829,19 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         r = upload_taps(ctx, taps);
         if (r) return r;
         pss_time_begin(ctx);
-        PSS_HIP(ctx, hipMemsetAsync(mxb, 0, (size_t)n_frames * sizeof(double), ctx->stream));
+        PSS_HIP(ctx, hipMemsetAsync(mxb, 0, (size_t)n_frames * sizeof(double), PSS_STREAM(ctx)));
         const int cpf = (n + 1023) / 1024;
         long total = n_frames * cpf;
         long g = total < 16384 ? total : 16384;
         pss_kernel_begin(ctx, "k_ssb_fir");
-        hipLaunchKernelGGL(k_ssb_fir, dim3((unsigned)g), dim3(TPB), 0, ctx->stream, reinterpret_cast<const float2 *>(d_iq),
+        hipLaunchKernelGGL(k_ssb_fir, dim3((unsigned)g), dim3(TPB), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq),
                            Yf, mxb, n, n_frames, cpf);
         pss_kernel_end(ctx);
         size_t tot = (size_t)n_frames * n;
         size_t g2 = (tot + TPB - 1) / TPB;
         if (g2 > 16384) g2 = 16384;
         pss_kernel_begin(ctx, "k_finalize");
-        hipLaunchKernelGGL(k_finalize, dim3((unsigned)g2), dim3(TPB), 0, ctx->stream, Yf,
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned)g2), dim3(TPB), 0, PSS_STREAM(ctx), Yf,
                            reinterpret_cast<const double *>(mxb), n, n_frames, d_pcm, d_audio);
         pss_kernel_end(ctx);
         pss_time_end(ctx);
@@ -853,11 +854,28 @@ extern "C" int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, 
                                 int16_t *d_pcm)
 {
     if (!ctx) return PSS_E_ARG;
+    // The spectrum kernel (VALU/HBM heavy, high occupancy) and the demodulator chain (one wavefront per SIMD in its
+    // serial stages) use the machine in complementary ways: run them on two streams, fork/join with events.
     pss_time_begin(ctx);  // nested begin/end pairs inside the two calls are no-ops
-    int r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
-    if (!r) r = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
+    // The backward IIR pass runs one wavefront per SIMD and is latency-bound; the spectrum kernel is launched on a
+    // side stream right behind the forward kernel so that the two share the machine (fork/join with events).
+    const bool fused = (n - 1 >= 128) && !ctx->no_fused;
+    ctx->fork_after_fwd = fused;
+    int r2 = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
+    ctx->fork_after_fwd = false;
+    int r;
+    if (fused && !r2) {
+        hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+        ctx->cur = ctx->stream2;
+        r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+        ctx->cur = nullptr;
+        hipEventRecord(ctx->ev_join, ctx->stream2);
+        hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+    } else {
+        r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+    }
     pss_time_end(ctx);
-    return r;
+    return r ? r : r2;
 }
 
 extern "C" int pss_set_nfm_filters(pss_ctx *ctx, double fs, const double *taps65, const double *sos4x6, const double *zi4x2)

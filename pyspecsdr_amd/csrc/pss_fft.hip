@@ -334,7 +334,7 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     const int grid = (int)(groups < cap ? groups : cap);
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_spectrum");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, reinterpret_cast<const float2 *>(d_iq), d_db, tw,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db, tw,
                        win, n_frames, d_peak, d_bw, d_count, bin_hz);
     pss_kernel_end(ctx);
     pss_time_end(ctx);
@@ -379,7 +379,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     int grid = grid_for(n_frames, per_cu);
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_spectrum_generic");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, ctx->stream, reinterpret_cast<const float2 *>(d_iq), d_db, tw,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db, tw,
                        win, n_fft, logNsub, R, n_frames, staged, d_peak, d_bw, d_count, bin_hz);
     pss_kernel_end(ctx);
     pss_time_end(ctx);
@@ -445,7 +445,7 @@ extern "C" int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames,
     if (per_cu > 8) per_cu = 8;
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_post");
-    hipLaunchKernelGGL(k_post, dim3(grid_for(n_frames, per_cu)), dim3(TPB), lds, ctx->stream, d_db, d_post, n_fft, P,
+    hipLaunchKernelGGL(k_post, dim3(grid_for(n_frames, per_cu)), dim3(TPB), lds, PSS_STREAM(ctx), d_db, d_post, n_fft, P,
                        n_frames);
     pss_kernel_end(ctx);
     pss_time_end(ctx);
@@ -459,7 +459,7 @@ extern "C" int pss_waterfall_cells(pss_ctx *ctx, const float *d_rows, int n_rows
     if (!d_rows || !d_glyph || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad waterfall arguments");
     pss_kernel_begin(ctx, "k_cells");
-    hipLaunchKernelGGL((k_cells<float, 0>), dim3(1), dim3(TPB), 0, ctx->stream, d_rows, n_rows, len, disp_h, disp_w,
+    hipLaunchKernelGGL((k_cells<float, 0>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
                        d_glyph, d_colour);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
@@ -472,7 +472,7 @@ extern "C" int pss_persistence_cells(pss_ctx *ctx, const float *d_rows, int n_ro
     if (!d_rows || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad persistence arguments");
     pss_kernel_begin(ctx, "k_cells");
-    hipLaunchKernelGGL((k_cells<float, 1>), dim3(1), dim3(TPB), 0, ctx->stream, d_rows, n_rows, len, disp_h, disp_w,
+    hipLaunchKernelGGL((k_cells<float, 1>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
                        (int8_t *)nullptr, d_colour);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
@@ -487,7 +487,7 @@ extern "C" int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n
     if (!d_rows || !d_glyph || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad waterfall arguments");
     pss_kernel_begin(ctx, "k_cells");
-    hipLaunchKernelGGL((k_cells<double, 0>), dim3(1), dim3(TPB), 0, ctx->stream, d_rows, n_rows, len, disp_h, disp_w,
+    hipLaunchKernelGGL((k_cells<double, 0>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
                        d_glyph, d_colour);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
@@ -500,7 +500,7 @@ extern "C" int pss_persistence_cells_f64(pss_ctx *ctx, const double *d_rows, int
     if (!d_rows || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad persistence arguments");
     pss_kernel_begin(ctx, "k_cells");
-    hipLaunchKernelGGL((k_cells<double, 1>), dim3(1), dim3(TPB), 0, ctx->stream, d_rows, n_rows, len, disp_h, disp_w,
+    hipLaunchKernelGGL((k_cells<double, 1>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
                        (int8_t *)nullptr, d_colour);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");

@@ -120,6 +120,17 @@ __device__ __forceinline__ void fir_batch(const float *const (&blk)[NB], const d
     }
 }
 
+template <int J, class Put>
+__device__ __forceinline__ void for_halves(const float *const (&blk)[NB], double (&out)[8], Put put)
+{
+    fir_batch<J, 0>(blk, c_taps_rev, out);
+    put(out, 0);
+    if constexpr (FBH == 4) {
+        fir_batch<J, 1>(blk, c_taps_rev, out);
+        put(out, 1);
+    }
+}
+
 // First 64 FIR outputs of every frame (windows shorter than 65 samples; one output per lane, predicated ddot),
 // parked TRANSPOSED in Uh[tile][i][lane] for the IIR wave of k_nfm_fwd.  One wavefront per frame-quarter:
 // workgroup = 256 threads = 4 frames.
@@ -258,10 +269,10 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
                     if (abl & 2) {
 #pragma unroll
                         for (int o = 0; o < 8; o++) out[o] = (double)blk[1][o];
-                        put(out, 0); put(out, 1);
-                    } else if (J == 0) { fir_batch<0, 0>(blk, c_taps_rev, out); put(out, 0); fir_batch<0, 1>(blk, c_taps_rev, out); put(out, 1); }
-                    else if (J == 1) { fir_batch<1, 0>(blk, c_taps_rev, out); put(out, 0); fir_batch<1, 1>(blk, c_taps_rev, out); put(out, 1); }
-                    else { fir_batch<2, 0>(blk, c_taps_rev, out); put(out, 0); fir_batch<2, 1>(blk, c_taps_rev, out); put(out, 1); }
+                        for (int h = 0; h < 8 / FBH; h++) put(out, h);
+                    } else if (J == 0) { for_halves<0>(blk, out, put); }
+                    else if (J == 1) { for_halves<1>(blk, out, put); }
+                    else { for_halves<2>(blk, out, put); }
                 }
                 // discriminator of the next chunk's 8 samples (9 complex); kept in registers until the window block
                 // is free.  The loads are issued after the FIR so they do not occupy registers across it — the other

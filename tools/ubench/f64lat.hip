@@ -20,6 +20,8 @@ __global__ void k(double *out, double a, double b, int iters, unsigned long long
                 if (MODE == 1) v[c] = v[c] + a;
                 if (MODE == 2) v[c] = v[c] * b;
                 if (MODE == 3) v[c] = (double)(float)v[c];   // cvt f64->f32->f64
+                if (MODE == 4) { float t = __fmaf_rn((float)v[c], 0.999f, 1.0f); asm volatile("" : "+v"(t)); v[c] = t; }
+                if (MODE == 5) { float t = (float)v[c]; asm volatile("" : "+v"(t)); v[c] = (double)t; }
             }
         }
     }
@@ -29,6 +31,47 @@ __global__ void k(double *out, double a, double b, int iters, unsigned long long
     for (int c = 0; c < CHAINS; c++) s += v[c];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
+template <int MODE, int CHAINS>
+__global__ void kf(float *out, float a, float b, int iters, unsigned long long *cyc)
+{
+    float v[CHAINS]; double d[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; c++) { v[c] = a + threadIdx.x * 1e-6f + c; d[c] = 0.0; }
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int c = 0; c < CHAINS; c++) {
+                if (MODE == 0) v[c] = __fmaf_rn(v[c], b, a);
+                if (MODE == 1) v[c] = v[c] + a;
+                if (MODE == 2) { d[c] = (double)v[c]; asm volatile("" : "+v"(d[c])); v[c] += 1.0f; }
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+#pragma unroll
+    for (int c = 0; c < CHAINS; c++) s += v[c] + (float)d[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+template <int MODE, int CHAINS>
+void runf(const char *name, int waves_per_simd)
+{
+    float *out; unsigned long long *cyc, h;
+    hipMalloc(&out, 8 * 1024 * 1024); hipMalloc(&cyc, 8);
+    int iters = 2000;
+    int threads = 64 * 4 * waves_per_simd;
+    hipLaunchKernelGGL((kf<MODE, CHAINS>), dim3(1), dim3(threads), 0, 0, out, 1.000001f, 0.999999f, iters, cyc);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL((kf<MODE, CHAINS>), dim3(1), dim3(threads), 0, 0, out, 1.000001f, 0.999999f, iters, cyc);
+    hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+    double per = (double)h / (iters * 8.0 * CHAINS);
+    printf("%-12s chains=%d : %.2f clk per loop element (s_memtime units)\n", name, CHAINS, per);
+    hipFree(out); hipFree(cyc);
 }
 
 template <int MODE, int CHAINS>
@@ -56,5 +99,8 @@ int main()
     run<1, 1>("add_f64", 1); run<1, 4>("add_f64", 1); run<1, 8>("add_f64", 1);
     run<2, 1>("mul_f64", 1); run<2, 4>("mul_f64", 1); run<2, 8>("mul_f64", 1);
     run<3, 1>("cvt_rt", 1); run<3, 8>("cvt_rt", 1);
+    run<5, 1>("cvt_rt_noopt", 1); run<5, 8>("cvt_rt_noopt", 1);
+    run<4, 8>("cvt+fmaf+cvt", 1);
+    runf<0, 1>("fma_f32", 1); runf<0, 8>("fma_f32", 1); runf<1, 8>("add_f32", 1); runf<2, 8>("cvt_f64_f32", 1);
     return 0;
 }
