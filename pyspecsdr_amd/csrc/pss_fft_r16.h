@@ -78,10 +78,17 @@ __device__ __forceinline__ void fft_reg(double2 (&v)[R])
 
 __device__ __forceinline__ float db_of(double pw)
 {
-    // 10*log10(pw) in float32 with a log1p branch around pw = 1 (keeps the RELATIVE error ~1e-6 where dB -> 0)
-    double d = pw - 1.0;
-    if (fabs(d) < 0.25) return 4.342944819032518f * log1pf((float)d);
-    return 3.0102999566398120f * __log2f((float)pw);
+    // 10*log10(pw), pw = |X|^2 + 1e-10 held in float64, evaluated branch-free in float32:
+    //   far from 1 : hardware log2 of the float32-rounded value (relative error of the dB value ~1e-7);
+    //   near 1     : ln(1+d) = 2 atanh(d/(2+d)) as an odd series (|s| < 0.143: truncation 3e-10), which keeps the
+    //                RELATIVE error of the dB value ~1e-7 even where dB -> 0 and float32(pw) has lost d.
+    // (ocml log1pf was correct too, but a wavefront executes its ~115 instructions whenever any lane needs it.)
+    const float t = (float)(pw - 1.0);
+    const float far = 3.0102999566398120f * __log2f((float)pw);
+    const float s = t * __builtin_amdgcn_rcpf(2.0f + t);
+    const float s2 = s * s;
+    const float p = s * (2.0f + s2 * (0.66666667f + s2 * (0.4f + s2 * (0.28571429f + s2 * 0.22222222f))));
+    return fabsf(t) < 0.25f ? 4.342944819032518f * p : far;
 }
 
 template <int LOG_R3>
