@@ -36,9 +36,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # algorithmic bytes per frame: what each kernel must move if nothing is re-read or spilled
 ALGO_BYTES = {
     "k_spectrum": N_FFT * 8 + N_FFT * 4,            # IQ in + float32 dB out
-    "k_nfm_front": N_FFT * 8,                       # IQ in (u[] is an internal hand-off, not algorithmic)
-    "k_nfm_iir": 40,                                # 10 x 2 x int16 out
-    "k_nfm": N_FFT * 8 + 40,                        # fused NFM (IQ in, PCM out)
+    "k_nfm_fwd": N_FFT * 8,                         # IQ in (y_fwd is an internal hand-off, not algorithmic)
+    "k_nfm_bwd": 40,                                # 10 x 2 x int16 out
+    "k_nfm_front": N_FFT * 8, "k_nfm_edge": 0, "k_nfm_iir": 40,   # three-kernel fallback path (PSS_NO_FUSED=1)
     "path": N_FFT * 8 + N_FFT * 4 + 40,             # 12 328 B/frame, IQ read once
 }
 

@@ -736,10 +736,6 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             double *Uh = reinterpret_cast<double *>(base + szY + szA), *Ut = reinterpret_cast<double *>(base + szY + szA + szH);
             const int abl = getenv("PSS_ABLATE") ? atoi(getenv("PSS_ABLATE")) : 0;  // dev-only timing ablation
             pss_time_begin(ctx);
-            pss_kernel_begin(ctx, "k_nfm_head");
-            hipLaunchKernelGGL(fused::k_nfm_head, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, PSS_STREAM(ctx),
-                               reinterpret_cast<const float2 *>(d_iq), Uh, n, n_frames, kscale, swapped);
-            pss_kernel_end(ctx);
             pss_kernel_begin(ctx, "k_nfm_fwd");
             if (b121)
                 hipLaunchKernelGGL(fused::k_nfm_fwd<true>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, PSS_STREAM(ctx),

@@ -212,6 +212,42 @@ __device__ __forceinline__ double ddot_skx_lane(FX X, FY Y, int n)
     return dot;
 }
 
+// The same inner product for a WAVE-UNIFORM length n <= 65 with few live registers (loops stay rolled): used by
+// the fused NFM kernel's IIR wave for the 64 left-edge FIR outputs, where lane = frame and all lanes share n.
+template <class FX, class FY>
+__device__ __forceinline__ double ddot_skx_uniform(FX X, FY Y, int n)
+{
+    const int n1 = n & -16, n32 = n1 & ~31;
+    double dot = 0.0;
+    if (n1) {
+        double s[4];
+#pragma unroll 1
+        for (int l = 0; l < 4; l++) {
+            double sl = 0.0;
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                double a = 0.0;
+                if (n32) {
+                    double lo = 0.0, hi = 0.0;
+#pragma unroll 1
+                    for (int i = 0; i < n32; i += 32) {
+                        lo = __fma_rn(X(i + 8 * k + l), Y(i + 8 * k + l), lo);
+                        hi = __fma_rn(X(i + 8 * k + l + 4), Y(i + 8 * k + l + 4), hi);
+                    }
+                    a = __dadd_rn(lo, hi);
+                }
+                if (n1 > n32) a = __fma_rn(X(n32 + 4 * k + l), Y(n32 + 4 * k + l), a);
+                sl = (k == 0) ? a : __dadd_rn(sl, a);
+            }
+            s[l] = sl;
+        }
+        dot = __dadd_rn(__dadd_rn(s[0], s[2]), __dadd_rn(s[1], s[3]));
+    }
+#pragma unroll 1
+    for (int i = n1; i < n; i++) dot = __fma_rn(Y(i), X(i), dot);
+    return dot;
+}
+
 // Real part of OpenBLAS zdotu (zdot_microk_haswell-2.c) with a real second operand — the complex FIR at
 // signal_processing.py:204/:209.
 template <class FX, class FY>

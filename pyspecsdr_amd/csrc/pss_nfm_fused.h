@@ -27,7 +27,7 @@ constexpr int NB = 4;          // window blocks
 constexpr int WCOLS = NB * FC; // 96 window columns: logical column l <-> time 24 c - 8 + l at chunk c
 constexpr int WSTR = 97;       // float row stride (odd: conflict-free for lane = frame at a fixed column)
 constexpr int HEAD = 64;       // outputs produced by the prologue
-constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double);
+constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double) + 72 * sizeof(double);
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence that also waits for every
 // outstanding GLOBAL store of the wave (vmcnt(0)); the IIR wave has 24 y_fwd row stores in flight per chunk, and
@@ -158,12 +158,13 @@ __global__ __launch_bounds__(256) void k_nfm_head(const float2 *__restrict__ iq,
 
 template <bool B121>
 __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
-                                                    const double *__restrict__ Uh, double *__restrict__ Utl, int n,
+                                                    double *__restrict__ Uh, double *__restrict__ Utl, int n,
                                                     long n_frames, NfmCoef c, float kscale, int swapped, int abl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
     double *ubuf = reinterpret_cast<double *>(smem + (size_t)TILE * WSTR * sizeof(float));  // [FC][TILE]
+    double *ltaps = ubuf + (size_t)TILE * FC;                                        // taps[0..64] (left-edge dots)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long tile = blockIdx.x;
     const int M = n - 1;                      // FIR outputs per frame (M >= 128 guaranteed by the caller)
@@ -173,9 +174,10 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
     const long fr = f < n_frames ? f : n_frames - 1;  // masked lanes replay the last frame (results dropped)
     const float2 *xq = iq + (size_t)fr * n;
     double *Yt = Y + (size_t)tile * L * TILE + lane;
-    const double *Uht = Uh + (size_t)tile * HEAD * TILE + lane;
+    double *Uht = Uh + (size_t)tile * HEAD * TILE + lane;
     double *Utt = Utl + (size_t)tile * (EDGE + 1) * TILE + lane;
 #define YAT(p) Yt[(size_t)(p) * TILE]
+    if (tid < 65) ltaps[tid] = c_taps[tid];
     // ---- prologue: discriminator of times 0..87 into logical columns 8..95 (physical = logical at chunk 0)
     for (int idx = tid; idx < TILE * WCOLS; idx += 256) {
         const int fl = idx / WCOLS, l = idx % WCOLS, t = l - 8;
@@ -185,6 +187,20 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
         if (t >= 0 && t < M) d = disc_sample(x[t + 1], x[t], kscale, swapped != 0);
         win[fl * WSTR + l] = d;
     }
+    __syncthreads();
+    // The first 64 FIR outputs have windows shorter than 65 samples, i.e. each its own ddot shape.  With lane = frame
+    // the length is wave-uniform: the four waves take 16 outputs each (interleaved, so the dot lengths balance) and
+    // park them in Uh (L2) for the IIR wave.
+    {
+        const float *row0 = win + lane * WSTR + 8;  // time t of this lane's frame at row0[t] (chunk-0 layout)
+#pragma unroll 1
+        for (int e = 0; e < HEAD / 4; e++) {
+            const int i = 4 * e + wave;
+            Uht[(size_t)i * TILE] = ddot_skx_uniform([&](int j) { return (double)row0[j]; },
+                                                     [&](int j) { return ltaps[i - j]; }, i + 1);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (wave == 0) {
         // =============================== IIR wave ===============================
