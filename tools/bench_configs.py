@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Time the library on the other BASELINE.json configs (device-resident inputs, HIP-event kernel times).
+
+    python tools/bench_configs.py [cfg3] [cfg4] [cfg5] [big]
+"""
+import json
+import sys
+import os
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from pyspecsdr_amd import _lib as L
+from pyspecsdr_amd.engine import Engine
+
+dev = torch.device("cuda", 0)
+eng = Engine(0)
+
+
+def rand_iq(nf, n, scale=0.3):
+    g = torch.Generator(device=dev).manual_seed(7)
+    return (torch.randn((nf, n, 2), generator=g, device=dev, dtype=torch.float32) * scale + 0.2).contiguous()
+
+
+def timed(name, fn, reps=5):
+    fn(); eng.sync(); torch.cuda.synchronize()
+    eng.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    eng.sync(); torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    kt = {k: round(sum(v) / len(v), 4) for k, v in eng.kernel_times().items()}
+    eng.enable_timing(False)
+    return {"call": name, "wall_ms": round(wall * 1e3, 4), "kernel_ms": kt}
+
+
+def cfg3():
+    nf, n, fs = 8192, 16384, 2.4e6
+    iq = rand_iq(nf, n)
+    db = torch.empty((nf, n), dtype=torch.float32, device=dev)
+    pcm = torch.empty((nf, n, 2), dtype=torch.int16, device=dev)
+    pw = torch.empty((nf,), dtype=torch.float32, device=dev)
+    out = [timed("spectrum_db 16384", lambda: eng.spectrum_db(iq, nf, n, db)),
+           timed("demod AM", lambda: eng.demod(L.MODE_AM, iq, nf, n, fs, pcm, None)),
+           timed("demod USB", lambda: eng.demod(L.MODE_USB, iq, nf, n, fs, pcm, None)),
+           timed("power_db", lambda: eng.power_db(iq, nf, n, pw))]
+    tot = sum(o["wall_ms"] for o in out)
+    return {"config": "cfg3 8192 x 16384 AM+SSB+power+spectrum", "calls": out, "samples_per_s": nf * n / (tot * 1e-3)}
+
+
+def cfg4():
+    ns, n, fs = 8192, 4096, 2.4e6
+    iq = rand_iq(ns, n)
+    db = torch.empty((ns, n), dtype=torch.float32, device=dev)
+    pk = torch.empty((ns,), dtype=torch.float32, device=dev)
+    bw = torch.empty((ns,), dtype=torch.float64, device=dev)
+    cnt = torch.empty((ns,), dtype=torch.int32, device=dev)
+    o = timed("scan 4096", lambda: eng.scan(iq, ns, n, fs, db, pk, bw, cnt), reps=20)
+    ms = list(o["kernel_ms"].values())[0]
+    return {"config": "cfg4 8192 slices x 4096 scanner", "calls": [o], "samples_per_s": ns * n / (o["wall_ms"] * 1e-3),
+            "hbm_GBs": ns * (n * 8 + n * 4 + 16) / (ms * 1e-3) / 1e9}
+
+
+def cfg5():
+    nf, n, fs = 48828, 2048, 10e6
+    iq = rand_iq(nf, n)
+    db = torch.empty((nf, n), dtype=torch.float32, device=dev)
+    post = torch.empty((nf, n - 4), dtype=torch.float32, device=dev)
+    n_out = eng.demod_out_len(L.MODE_NFM, n, fs)
+    pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
+    out = [timed("spectrum_nfm 2048 @10MS/s", lambda: eng.spectrum_nfm(iq, nf, n, fs, db, pcm)),
+           timed("spectrum_post 2048", lambda: eng.spectrum_post(db, nf, n, post))]
+    return {"config": "cfg5 48828 x 2048 @10 MS/s (device-resident)", "calls": out,
+            "samples_per_s": nf * n / (out[0]["wall_ms"] * 1e-3)}
+
+
+def big():
+    out = []
+    for n, nf in ((32768, 2048), (65536, 256), (1 << 20, 8)):
+        iq = rand_iq(nf, n)
+        db = torch.empty((nf, n), dtype=torch.float32, device=dev)
+        out.append(timed(f"spectrum_db {n} x{nf}", lambda: eng.spectrum_db(iq, nf, n, db), reps=2))
+    n, nf, fs = 32768, 4096, 2.4e6
+    iq = rand_iq(nf, n)
+    n_out = eng.demod_out_len(L.MODE_NFM, n, fs)
+    pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
+    out.append(timed("demod NFM 32768 x4096", lambda: eng.demod(L.MODE_NFM, iq, nf, n, fs, pcm, None), reps=2))
+    return {"config": "reference-default buffer sizes", "calls": out}
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5"]
+    for w in which:
+        print(json.dumps(globals()[w]()), flush=True)
