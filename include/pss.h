@@ -45,6 +45,9 @@ int pss_set_stream(pss_ctx *ctx, void *hip_stream);
 int pss_sync(pss_ctx *ctx);
 const char *pss_last_error(pss_ctx *ctx); /* ctx may be NULL: error of the last failed pss_create */
 int pss_device_count(void);
+/* Tuning / testing switches.  "nfm_fused" (default 1): 0 selects the three-kernel NFM path (front, edge, iir) that
+ * also serves frames shorter than 129 samples; both paths produce identical bits.  Returns PSS_E_ARG for unknown keys. */
+int pss_set_option(pss_ctx *ctx, const char *key, int value);
 
 /* ---- filter design (host side, pure C++; replaces the per-call SciPy design work) -------------- */
 /* scipy.signal.firwin(numtaps, cutoff) low-pass, Hamming window, cutoff normalised to Nyquist

@@ -19,6 +19,7 @@ _SIGS = {
     "pss_sync": (C.c_int, [_p]),
     "pss_last_error": (C.c_char_p, [_p]),
     "pss_device_count": (C.c_int, []),
+    "pss_set_option": (C.c_int, [_p, C.c_char_p, C.c_int]),
     "pss_design_firwin": (C.c_int, [C.c_int, C.c_double, _p]),
     "pss_design_cheby1_sos": (C.c_int, [C.c_int, C.c_double, C.c_double, _p]),
     "pss_design_sosfilt_zi": (C.c_int, [_p, C.c_int, _p]),

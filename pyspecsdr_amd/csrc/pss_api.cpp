@@ -132,6 +132,13 @@ extern "C" int pss_set_stream(pss_ctx *ctx, void *hip_stream)
     return PSS_OK;
 }
 
+extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
+{
+    if (!ctx || !key) return PSS_E_ARG;
+    if (!strcmp(key, "nfm_fused")) { ctx->no_fused = (value == 0); return PSS_OK; }
+    return pss_fail(ctx, PSS_E_ARG, std::string("unknown option: ") + key);
+}
+
 extern "C" int pss_sync(pss_ctx *ctx)
 {
     if (!ctx) return PSS_E_ARG;

@@ -734,15 +734,14 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             char *base = reinterpret_cast<char *>(ctx->scratch);
             double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);
             double *Uh = reinterpret_cast<double *>(base + szY + szA), *Ut = reinterpret_cast<double *>(base + szY + szA + szH);
-            const int abl = getenv("PSS_ABLATE") ? atoi(getenv("PSS_ABLATE")) : 0;  // dev-only timing ablation
             pss_time_begin(ctx);
             pss_kernel_begin(ctx, "k_nfm_fwd");
             if (b121)
                 hipLaunchKernelGGL(fused::k_nfm_fwd<true>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, abl);
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped);
             else
                 hipLaunchKernelGGL(fused::k_nfm_fwd<false>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, abl);
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped);
             pss_kernel_end(ctx);
             if (ctx->fork_after_fwd) hipEventRecord(ctx->ev_fork, ctx->stream);  // pss_spectrum_nfm overlaps the rest
             pss_kernel_begin(ctx, "k_nfm_bwd");

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_nfm_head(const float2 *__restrict__ iq,
 template <bool B121>
 __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
                                                     double *__restrict__ Uh, double *__restrict__ Utl, int n,
-                                                    long n_frames, NfmCoef c, float kscale, int swapped, int abl)
+                                                    long n_frames, NfmCoef c, float kscale, int swapped)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
                 const int cnt = (M - HEAD - (ch - 1) * FC) < FC ? (M - HEAD - (ch - 1) * FC) : FC;
                 if (cnt == FC) {
 #pragma unroll
-                    for (int t = 0; t < FC; t++) { double v = (abl & 4) ? reg[t] : pipe_step<B121>(c, st, reg[t]); emit(v); p++; }
+                    for (int t = 0; t < FC; t++) { double v = pipe_step<B121>(c, st, reg[t]); emit(v); p++; }
                 } else {
 #pragma unroll
                     for (int t = 0; t < FC; t++)
@@ -282,11 +282,7 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
                 };
                 {
                     double out[8];
-                    if (abl & 2) {
-#pragma unroll
-                        for (int o = 0; o < 8; o++) out[o] = (double)blk[1][o];
-                        for (int h = 0; h < 8 / FBH; h++) put(out, h);
-                    } else if (J == 0) { for_halves<0>(blk, out, put); }
+                    if (J == 0) { for_halves<0>(blk, out, put); }
                     else if (J == 1) { for_halves<1>(blk, out, put); }
                     else { for_halves<2>(blk, out, put); }
                 }
@@ -299,7 +295,7 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
 #pragma unroll
                     for (int e = 0; e < 9; e++) pre[e] = (tn + e < n) ? xq[tn + e] : make_float2(0.0f, 0.0f);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) dn[e] = (abl & 1) ? pre[e].x : ((tn + e < M) ? disc_sample(pre[e + 1], pre[e], kscale, swapped != 0) : 0.0f);
+                    for (int e = 0; e < 8; e++) dn[e] = (tn + e < M) ? disc_sample(pre[e + 1], pre[e], kscale, swapped != 0) : 0.0f;
                 }
                 lds_barrier();  // A
                 // the oldest block (logical 0) becomes the newest (logical 3 of the next chunk)

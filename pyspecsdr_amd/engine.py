@@ -61,6 +61,9 @@ class Engine:
     def set_stream(self, stream):
         self._ck(self.lib.pss_set_stream(self.h, _ptr(getattr(stream, "cuda_stream", stream))))
 
+    def set_option(self, key, value):
+        self._ck(self.lib.pss_set_option(self.h, key.encode(), int(value)))
+
     def sync(self):
         self._ck(self.lib.pss_sync(self.h))
 

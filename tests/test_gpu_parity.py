@@ -99,6 +99,25 @@ def test_nfm_designed_filters_pcm_exact(golden):
     e2.close()
 
 
+def test_nfm_fused_and_three_kernel_paths_agree(golden):
+    # the fused forward kernel and the front/edge/iir fallback must produce identical bits
+    rng = np.random.default_rng(79)
+    e = G.engine()
+    for nf, n, fs in ((70, 1024, 2.4e6), (5, 2048, 10e6), (3, 300, 1.024e6), (2, 129, 2.4e6), (2, 4097, 2.4e6)):
+        iq = (0.4 * np.exp(2j * np.pi * np.cumsum(rng.standard_normal((nf, n)) * 0.05, axis=1)) +
+              0.05 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
+        pcm1, a1 = G.demod(L.MODE_NFM, iq, fs)
+        e.set_option("nfm_fused", 0)
+        try:
+            pcm2, a2 = G.demod(L.MODE_NFM, iq, fs)
+        finally:
+            e.set_option("nfm_fused", 1)
+        assert np.array_equal(pcm1, pcm2) and np.array_equal(a1, a2), (nf, n, fs)
+        taps, sos, zi = e.nfm_filters(fs)
+        for k in range(min(nf, 3)):
+            assert np.array_equal(a1[k], O.demod_nfm(iq[k], fs, taps, sos, zi)), (n, k)
+
+
 def test_nfm_edges(golden):
     g = golden["nfm"]
     e = G.engine()
