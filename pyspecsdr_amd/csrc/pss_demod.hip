@@ -391,53 +391,90 @@ __global__ __launch_bounds__(TPB) void k_pairwise(const float2 *__restrict__ iq,
 
 // ---------------------------------------------------------------------------------------------------
 // AM: envelope - mean (float32) -> 5-section Butterworth band-pass, forward only, zero state (float64).
-// One wavefront per tile of 64 frames, lane = frame; 64-sample chunks staged through LDS both ways so
-// global reads (IQ) and writes (y) are coalesced rows.  Tracks max|y| per frame.
+// One wavefront per tile of 64 frames, lane = frame (the recurrence is serial in time).  The five sections run
+// as a skewed pipeline (section s works on sample t-s: five independent dependency chains per step); because the
+// filter starts from a zero state, the pipeline is filled and drained by simply feeding zeros (a biquad with zero
+// state maps 0 to 0 exactly), so every step is the same straight-line code.  Each lane walks its own IQ row with
+// 16-byte loads (two samples) through a 2 x 16-deep register prefetch and writes y[] back to its own row.
 // ---------------------------------------------------------------------------------------------------
+constexpr int AM_NS = 5;
+constexpr int AM_CH = 16;
+
 __global__ __launch_bounds__(TILE) void k_am_iir(const float2 *__restrict__ iq, const float *__restrict__ mu,
                                                  double *__restrict__ Yf, double *__restrict__ mxout, int n,
                                                  long n_frames, AmCoef c)
 {
-    __shared__ float ebuf[TILE * 65];
-    __shared__ double ybuf[TILE * 65];
     const int lane = threadIdx.x;
-    const long tile = blockIdx.x;
-    double z[10];
+    const long f = (long)blockIdx.x * TILE + lane;
+    const long fr = f < n_frames ? f : n_frames - 1;  // masked lanes replay the last frame (results dropped)
+    const float2 *x = iq + (size_t)fr * n;
+    double *y = Yf + (size_t)fr * n;
+    const float m = mu[fr];
+    double z[2 * AM_NS], p[AM_NS - 1];
 #pragma unroll
-    for (int i = 0; i < 10; i++) z[i] = 0.0;
+    for (int i = 0; i < 2 * AM_NS; i++) z[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < AM_NS - 1; i++) p[i] = 0.0;
+    auto step = [&](double xin) {
+        double xs[AM_NS], b0x[AM_NS], v[AM_NS], w[AM_NS], xn[AM_NS], t[AM_NS], u[AM_NS];
+        xs[0] = xin;
+#pragma unroll
+        for (int k = 1; k < AM_NS; k++) xs[k] = p[k - 1];
+#pragma unroll
+        for (int k = 0; k < AM_NS; k++) {
+            b0x[k] = __dmul_rn(c.s[k].b0, xs[k]);
+            v[k] = __dmul_rn(c.s[k].b1, xs[k]);
+            w[k] = __dmul_rn(c.s[k].b2, xs[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < AM_NS; k++) xn[k] = __dadd_rn(b0x[k], z[2 * k]);
+#pragma unroll
+        for (int k = 0; k < AM_NS; k++) { t[k] = __dmul_rn(c.s[k].a1, xn[k]); u[k] = __dmul_rn(c.s[k].a2, xn[k]); }
+#pragma unroll
+        for (int k = 0; k < AM_NS; k++) { v[k] = __dsub_rn(v[k], t[k]); w[k] = __dsub_rn(w[k], u[k]); }
+#pragma unroll
+        for (int k = 0; k < AM_NS; k++) { z[2 * k] = __dadd_rn(v[k], z[2 * k + 1]); z[2 * k + 1] = w[k]; }
+#pragma unroll
+        for (int k = 0; k < AM_NS - 1; k++) p[k] = xn[k];
+        return xn[AM_NS - 1];
+    };
+    auto envelope = [&](float2 s) { return (double)__fsub_rn(cabsf_np(s.x, s.y), m); };  // float32 subtract (:185)
     double mx = 0.0;
     bool nan = false;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        for (int fl = 0; fl < TILE; fl++) {
-            long f = tile * TILE + fl;
-            int i = i0 + lane;
-            float cv = 0.0f;
-            if (f < n_frames && i < n) {
-                float2 v = iq[(size_t)f * n + i];
-                cv = __fsub_rn(cabsf_np(v.x, v.y), mu[f]);  // envelope - np.mean(envelope), float32
-            }
-            ebuf[fl * 65 + lane] = cv;
-        }
-        __syncthreads();
-        const int cnt = (n - i0) < 64 ? (n - i0) : 64;
-        for (int t = 0; t < cnt; t++) {
-            double x = (double)ebuf[lane * 65 + t];
-#pragma unroll
-            for (int s = 0; s < 5; s++) x = biquad_step(c.s[s], x, z[2 * s], z[2 * s + 1]);
-            double av = fabs(x);
+    auto keep = [&](long t, double v) {  // output of step t belongs to sample t - (AM_NS - 1)
+        const long i = t - (AM_NS - 1);
+        if (i >= 0) {
+            y[i] = v;
+            double av = fabs(v);
             nan = nan || (av != av);
             mx = av > mx ? av : mx;
-            ybuf[lane * 65 + t] = x;
         }
-        __syncthreads();
-        for (int fl = 0; fl < TILE; fl++) {
-            long f = tile * TILE + fl;
-            int i = i0 + lane;
-            if (f < n_frames && i < n) Yf[(size_t)f * n + i] = ybuf[fl * 65 + lane];
+    };
+    const long T = (long)n + AM_NS - 1;            // steps incl. drain
+    const bool aligned = ((size_t)fr * n) % 2 == 0;  // 16-byte loads need an even sample offset
+    const long nfull = aligned ? n / AM_CH : 0;
+    float2 b0[AM_CH], b1[AM_CH];
+    auto loadc = [&](float2 (&b)[AM_CH], long r) {
+        const float4 *q = reinterpret_cast<const float4 *>(x + r);
+#pragma unroll
+        for (int k = 0; k < AM_CH / 2; k++) { float4 v4 = q[k]; b[2 * k] = make_float2(v4.x, v4.y); b[2 * k + 1] = make_float2(v4.z, v4.w); }
+    };
+    auto runc = [&](float2 (&b)[AM_CH], long r) {
+#pragma unroll
+        for (int k = 0; k < AM_CH; k++) keep(r + k, step(envelope(b[k])));
+    };
+    long r = 0;
+    if (nfull > 0) loadc(b0, 0);
+    for (long ch = 0; ch < nfull; ch += 2) {
+        if (ch + 1 < nfull) loadc(b1, r + AM_CH);
+        runc(b0, r);
+        if (ch + 1 < nfull) {
+            if (ch + 2 < nfull) loadc(b0, r + 2 * AM_CH);
+            runc(b1, r + AM_CH);
         }
-        __syncthreads();
+        r += 2 * AM_CH;
     }
-    long f = tile * TILE + lane;
+    for (r = nfull * AM_CH; r < T; r++) keep(r, step(r < n ? envelope(x[r]) : 0.0));
     if (f < n_frames) mxout[f] = nan ? __builtin_nan("") : mx;
 }
 
