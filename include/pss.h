@@ -120,6 +120,18 @@ int pss_h_demodulate(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs
                      int16_t *h_pcm);
 int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float *h_power);
 
+/* ---- streamed capture (BASELINE.json configs[4]) -------------------------------------------------- */
+/* Pinned host memory for the streaming call (plain malloc'ed memory works too, but cannot overlap with compute). */
+void *pss_host_alloc(size_t bytes);
+void pss_host_free(void *p);
+/* Cut a long HOST capture into n_frames frames of n samples and push it through spectrum + NFM demod in chunks of
+ * chunk_frames: chunk k+1 is uploaded (hipMemcpyAsync, copy stream) while chunk k computes and chunk k-1's results
+ * download — three streams, two device buffer sets.  h_db float32 [n_frames][n] (may be NULL), h_pcm int16
+ * [n_frames][n_out][2].  Synchronous: returns when everything has landed in host memory.  Results are identical to
+ * the device-resident pss_spectrum_nfm on the same frames. */
+int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
+                              float *h_db, int16_t *h_pcm);
+
 /* Kernel-only time of the most recent batched call on this context, measured with HIP events on the
  * context's stream (ms); negative if timing is disabled.  pss_enable_timing(ctx, 1) turns it on. */
 int pss_enable_timing(pss_ctx *ctx, int on);

@@ -250,3 +250,86 @@ extern "C" int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float
     PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PSS_OK;
 }
+
+// ---- streamed capture --------------------------------------------------------------------------------
+extern "C" void *pss_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void pss_host_free(void *p)
+{
+    if (p) hipHostFree(p);
+}
+
+extern "C" int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
+                                         float *h_db, int16_t *h_pcm)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!h_iq || !h_pcm || n_frames < 0 || n < 1 || chunk_frames < 1) return pss_fail(ctx, PSS_E_ARG, "bad stream arguments");
+    const int n_out = pss_demod_out_len(PSS_MODE_NFM, n, fs);
+    if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "sample rate below 22050 Hz");
+    if (n_frames == 0) return PSS_OK;
+    if (chunk_frames > n_frames) chunk_frames = n_frames;
+    const size_t iq_b = (size_t)chunk_frames * n * 2 * sizeof(float), db_b = (size_t)chunk_frames * n * sizeof(float),
+                 pcm_b = (size_t)chunk_frames * n_out * 2 * sizeof(int16_t);
+    hipStream_t s_up = nullptr, s_dn = nullptr;
+    hipEvent_t up_done[2] = {nullptr, nullptr}, cmp_done[2] = {nullptr, nullptr}, dn_done[2] = {nullptr, nullptr};
+    void *d_iq[2] = {nullptr, nullptr}, *d_db[2] = {nullptr, nullptr}, *d_pcm[2] = {nullptr, nullptr};
+    int rc = PSS_OK;
+    auto cleanup = [&]() {
+        hipStreamSynchronize(ctx->stream);
+        if (s_up) { hipStreamSynchronize(s_up); hipStreamDestroy(s_up); }
+        if (s_dn) { hipStreamSynchronize(s_dn); hipStreamDestroy(s_dn); }
+        for (int i = 0; i < 2; i++) {
+            if (up_done[i]) hipEventDestroy(up_done[i]);
+            if (cmp_done[i]) hipEventDestroy(cmp_done[i]);
+            if (dn_done[i]) hipEventDestroy(dn_done[i]);
+            if (d_iq[i]) hipFree(d_iq[i]);
+            if (d_db[i]) hipFree(d_db[i]);
+            if (d_pcm[i]) hipFree(d_pcm[i]);
+        }
+    };
+#define STREAM_HIP(call)                                          \
+    do {                                                          \
+        rc = pss_hip_check(ctx, (call), #call);                   \
+        if (rc) { cleanup(); return rc; }                         \
+    } while (0)
+    STREAM_HIP(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+    STREAM_HIP(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        STREAM_HIP(hipEventCreateWithFlags(&up_done[i], hipEventDisableTiming));
+        STREAM_HIP(hipEventCreateWithFlags(&cmp_done[i], hipEventDisableTiming));
+        STREAM_HIP(hipEventCreateWithFlags(&dn_done[i], hipEventDisableTiming));
+        STREAM_HIP(hipMalloc(&d_iq[i], iq_b));
+        STREAM_HIP(hipMalloc(&d_db[i], db_b));
+        STREAM_HIP(hipMalloc(&d_pcm[i], pcm_b));
+    }
+    const long n_chunks = (n_frames + chunk_frames - 1) / chunk_frames;
+    for (long k = 0; k < n_chunks; k++) {
+        const int b = (int)(k & 1);
+        const long f0 = k * chunk_frames;
+        const long cnt = (n_frames - f0) < chunk_frames ? (n_frames - f0) : chunk_frames;
+        // the buffer set is free once chunk k-2's download has finished
+        if (k >= 2) STREAM_HIP(hipStreamWaitEvent(s_up, dn_done[b], 0));
+        STREAM_HIP(hipMemcpyAsync(d_iq[b], h_iq + (size_t)f0 * n * 2, (size_t)cnt * n * 2 * sizeof(float),
+                                  hipMemcpyHostToDevice, s_up));
+        STREAM_HIP(hipEventRecord(up_done[b], s_up));
+        STREAM_HIP(hipStreamWaitEvent(ctx->stream, up_done[b], 0));
+        if (k >= 2) STREAM_HIP(hipStreamWaitEvent(ctx->stream, dn_done[b], 0));
+        rc = pss_spectrum_nfm(ctx, (const float *)d_iq[b], cnt, n, fs, (float *)d_db[b], (int16_t *)d_pcm[b]);
+        if (rc) { cleanup(); return rc; }
+        STREAM_HIP(hipEventRecord(cmp_done[b], ctx->stream));
+        STREAM_HIP(hipStreamWaitEvent(s_dn, cmp_done[b], 0));
+        if (h_db)
+            STREAM_HIP(hipMemcpyAsync(h_db + (size_t)f0 * n, d_db[b], (size_t)cnt * n * sizeof(float), hipMemcpyDeviceToHost, s_dn));
+        STREAM_HIP(hipMemcpyAsync(h_pcm + (size_t)f0 * n_out * 2, d_pcm[b], (size_t)cnt * n_out * 2 * sizeof(int16_t),
+                                  hipMemcpyDeviceToHost, s_dn));
+        STREAM_HIP(hipEventRecord(dn_done[b], s_dn));
+    }
+#undef STREAM_HIP
+    cleanup();
+    return PSS_OK;
+}

@@ -142,6 +142,36 @@ class Engine:
         fn = self.lib.pss_persistence_cells_f64 if f64 else self.lib.pss_persistence_cells
         self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_colour)))
 
+    # -- streamed capture from host memory (chunked, double-buffered H2D / compute / D2H)
+    def pinned_empty(self, shape, dtype):
+        """numpy array backed by pinned host memory (hipHostMalloc); keep a reference to it while in use."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = self.lib.pss_host_alloc(nbytes)
+        if not p:
+            raise MemoryError("hipHostMalloc failed")
+        buf = (C.c_char * nbytes).from_address(p)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def pinned_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            self.lib.pss_host_free(p)
+
+    def stream_spectrum_nfm(self, h_iq, fs, chunk_frames, h_db=None, h_pcm=None):
+        """h_iq: complex64 [n_frames, n] host array (pinned for overlap).  Returns (h_db or None, h_pcm)."""
+        assert h_iq.dtype == np.complex64 and h_iq.ndim == 2 and h_iq.flags.c_contiguous
+        nf, n = h_iq.shape
+        n_out = self.demod_out_len(L.MODE_NFM, n, fs)
+        if h_pcm is None:
+            h_pcm = np.empty((nf, n_out, 2), np.int16)
+        self._ck(self.lib.pss_h_stream_spectrum_nfm(self.h, _ptr(h_iq), nf, n, float(fs), int(chunk_frames),
+                                                     _ptr(h_db), _ptr(h_pcm)))
+        return h_db, h_pcm
+
     # -- host convenience (single frame, synchronous)
     def h_compute_fft(self, iq):
         iq = np.ascontiguousarray(iq, np.complex64)

@@ -289,6 +289,29 @@ def test_dropin_module_matches_reference_signatures(golden):
         sp.demodulate_nfm(x[:28], 2.4e6)
 
 
+def test_streamed_capture_equals_resident_batch():
+    # BASELINE.json configs[4] shape in miniature: a host capture cut into 2048-pt frames @10 MS/s, streamed in
+    # ragged chunks (pinned buffers, double-buffered) must equal the device-resident batched call bit for bit
+    e = G.engine()
+    rng = np.random.default_rng(80)
+    nf, n, fs = 333, 2048, 10e6
+    h_iq = e.pinned_empty((nf, n), np.complex64)
+    h_iq[:] = (0.4 * np.exp(2j * np.pi * np.cumsum(rng.standard_normal((nf, n)) * 0.03, axis=1)) +
+               0.05 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
+    h_db = e.pinned_empty((nf, n), np.float32)
+    n_out = e.demod_out_len(L.MODE_NFM, n, fs)
+    h_pcm = e.pinned_empty((nf, n_out, 2), np.int16)
+    e.stream_spectrum_nfm(h_iq, fs, 100, h_db, h_pcm)       # 100 + 100 + 100 + 33 frames
+    d_db, d_pcm = G.empty((nf, n), torch.float32), G.empty((nf, n_out, 2), torch.int16)
+    e.spectrum_nfm(G.dev(np.array(h_iq)), nf, n, fs, d_db, d_pcm)
+    e.sync()
+    assert np.array_equal(h_db, G.host(d_db)) and np.array_equal(h_pcm, G.host(d_pcm))
+    _, pcm2 = e.stream_spectrum_nfm(np.array(h_iq), fs, 1000)  # pageable memory, single chunk, no dB rows
+    assert np.array_equal(pcm2, h_pcm)
+    for a in (h_iq, h_db, h_pcm):
+        e.pinned_free(a)
+
+
 def test_full_size_headline_properties():
     """BASELINE.json cfg 2 size (65 536 x 1024): size-independent properties of the fused headline call."""
     e = G.engine()
