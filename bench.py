@@ -43,6 +43,17 @@ ALGO_BYTES = {
 }
 
 
+def traffic_of(kernel, n_frames):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC profile (profiles/hbm_traffic_r01.json: separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 2x fetch correction), scaled to this run's frame count; None if absent.
+    PMC counters cannot be collected from inside this process, so the number is the profiled one, not a live one."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_r01.json")))[kernel]["traffic_bytes"]
+        return t * n_frames / 65536.0
+    except Exception:
+        return None
+
+
 def synth_fm_iq(n_frames, n, fs, device, seed):
     """FM-modulated carrier + noise, SURVEY §8(d): three audio tones, 5 kHz deviation, A=0.5, sigma=0.02."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -158,7 +169,7 @@ def main():
             ms = ktimes[dom]
             achieved = ALGO_BYTES.get(dom, ALGO_BYTES["path"]) * nf / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_of(dom, nf),
                     "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
                     "path_achieved": ALGO_BYTES["path"] * nf / (elapsed / args.steps) / 1e9}
             if spec_alone:

@@ -114,6 +114,17 @@ int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int 
 int pss_persistence_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int len, int disp_h, int disp_w,
                               int8_t *d_colour);
 
+/* Stateful accumulators: a device ring of the last max_rows post-processed rows, the counterpart of the reference's
+ * WATERFALL_HISTORY (30 rows, pyspecsdr.py:130-131,1351-1353) and PERSISTENCE_HISTORY (10 rows, :151-152,1521-1523).
+ * push = history.append(row) + pop(0) when full; the two quantisers then work on the ring in place. */
+typedef struct pss_ring pss_ring;
+int pss_ring_create(pss_ctx *ctx, int max_rows, int len, pss_ring **out);
+void pss_ring_destroy(pss_ring *ring);
+int pss_ring_push(pss_ring *ring, const float *d_row);
+int pss_ring_count(pss_ring *ring);
+int pss_ring_waterfall(pss_ring *ring, int disp_h, int disp_w, int8_t *d_glyph, int8_t *d_colour);
+int pss_ring_persistence(pss_ring *ring, int disp_h, int disp_w, int8_t *d_colour);
+
 /* ---- host-buffer convenience (single frame, synchronous; what the drop-in Python module calls) --- */
 int pss_h_compute_fft(pss_ctx *ctx, const float *h_iq, int n, double *h_db);
 int pss_h_demodulate(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,

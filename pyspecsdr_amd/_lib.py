@@ -40,6 +40,12 @@ _SIGS = {
     "pss_persistence_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "pss_waterfall_cells_f64": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "pss_persistence_cells_f64": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "pss_ring_create": (C.c_int, [_p, C.c_int, C.c_int, C.POINTER(_p)]),
+    "pss_ring_destroy": (None, [_p]),
+    "pss_ring_push": (C.c_int, [_p, _p]),
+    "pss_ring_count": (C.c_int, [_p]),
+    "pss_ring_waterfall": (C.c_int, [_p, C.c_int, C.c_int, _p, _p]),
+    "pss_ring_persistence": (C.c_int, [_p, C.c_int, C.c_int, _p]),
     "pss_h_compute_fft": (C.c_int, [_p, _p, C.c_int, _p]),
     "pss_h_demodulate": (C.c_int, [_p, C.c_int, _p, C.c_int, C.c_double, _p, _p]),
     "pss_h_measure_power": (C.c_int, [_p, _p, C.c_int, _p]),

@@ -258,14 +258,19 @@ __device__ __forceinline__ double interp_row(const T *row, int len, int W, int i
 // MODE 0: waterfall (pyspecsdr.py:1342-1406)   MODE 1: persistence (pyspecsdr.py:1512-1564)
 template <class T, int MODE>
 __global__ __launch_bounds__(TPB) void k_cells(const T *__restrict__ rows, int n_rows, int len, int disp_h, int disp_w,
-                                               int8_t *__restrict__ glyph, int8_t *__restrict__ colour)
+                                               int8_t *__restrict__ glyph, int8_t *__restrict__ colour, int start, int cap)
 {
+    // rows live in a ring of `cap` rows; logical row i (0 = oldest) is physical row (start + i) mod cap
     __shared__ double red_lo[TPB / 64], red_hi[TPB / 64];
     const int tid = threadIdx.x;
+    auto rowp = [&](int i) { return rows + (size_t)((start + i) % cap) * len; };
     double lo = INFINITY, hi = -INFINITY;
-    for (long i = tid; i < (long)n_rows * len; i += TPB) {
-        double v = (double)rows[i];
-        if (isfinite(v)) { lo = fmin(lo, v); hi = fmax(hi, v); }
+    for (int r = 0; r < n_rows; r++) {
+        const T *rp = rowp(r);
+        for (int i = tid; i < len; i += TPB) {
+            double v = (double)rp[i];
+            if (isfinite(v)) { lo = fmin(lo, v); hi = fmax(hi, v); }
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         lo = fmin(lo, __shfl_xor(lo, off));
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(TPB) void k_cells(const T *__restrict__ rows, int n
             int y = c / disp_w, x = c - y * disp_w;
             int8_t g = -1, ci = -1;
             if (y < n_rows) {
-                double v = interp_row(rows + (size_t)(n_rows - 1 - y) * len, len, disp_w, x);
+                double v = interp_row(rowp(n_rows - 1 - y), len, disp_w, x);
                 if (isfinite(v)) {
                     double nv = (v - lo) / (hi - lo);  // no zero-range guard in the reference
                     ci = (int8_t)(int)(nv * 5);
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(TPB) void k_cells(const T *__restrict__ rows, int n
             for (int i = 0; i < n_rows; i++) {
                 double alpha = pow(0.7, (double)(10 - i));
                 int cp = (int)(1 + (5 * (1 - alpha)));
-                double v = interp_row(rows + (size_t)i * len, len, disp_w, x);
+                double v = interp_row(rowp(i), len, disp_w, x);
                 if (!isfinite(v)) continue;
                 double nv = (v - lo) / range;
                 int y = (int)((1 - nv) * (disp_h - 1));
@@ -468,7 +473,7 @@ extern "C" int pss_waterfall_cells(pss_ctx *ctx, const float *d_rows, int n_rows
         return pss_fail(ctx, PSS_E_ARG, "bad waterfall arguments");
     pss_kernel_begin(ctx, "k_cells");
     hipLaunchKernelGGL((k_cells<float, 0>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
-                       d_glyph, d_colour);
+                       d_glyph, d_colour, 0, n_rows);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
 }
@@ -481,7 +486,7 @@ extern "C" int pss_persistence_cells(pss_ctx *ctx, const float *d_rows, int n_ro
         return pss_fail(ctx, PSS_E_ARG, "bad persistence arguments");
     pss_kernel_begin(ctx, "k_cells");
     hipLaunchKernelGGL((k_cells<float, 1>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
-                       (int8_t *)nullptr, d_colour);
+                       (int8_t *)nullptr, d_colour, 0, n_rows);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
 }
@@ -496,7 +501,7 @@ extern "C" int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n
         return pss_fail(ctx, PSS_E_ARG, "bad waterfall arguments");
     pss_kernel_begin(ctx, "k_cells");
     hipLaunchKernelGGL((k_cells<double, 0>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
-                       d_glyph, d_colour);
+                       d_glyph, d_colour, 0, n_rows);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
 }
@@ -509,7 +514,63 @@ extern "C" int pss_persistence_cells_f64(pss_ctx *ctx, const double *d_rows, int
         return pss_fail(ctx, PSS_E_ARG, "bad persistence arguments");
     pss_kernel_begin(ctx, "k_cells");
     hipLaunchKernelGGL((k_cells<double, 1>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
-                       (int8_t *)nullptr, d_colour);
+                       (int8_t *)nullptr, d_colour, 0, n_rows);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
+}
+
+// ---- stateful display accumulators: the reference keeps WATERFALL_HISTORY (last 30 rows, pyspecsdr.py:130-131,
+// :1351-1353) and PERSISTENCE_HISTORY (last 10 rows, :151-152, :1521-1523) as Python lists; here a device ring.
+struct pss_ring {
+    pss_ctx *ctx;
+    float *d_rows;
+    int cap, len, count, head;  // head = physical index of the oldest row
+};
+
+extern "C" int pss_ring_create(pss_ctx *ctx, int max_rows, int len, pss_ring **out)
+{
+    if (!ctx || !out) return PSS_E_ARG;
+    *out = nullptr;
+    if (max_rows < 1 || len < 2) return pss_fail(ctx, PSS_E_ARG, "bad ring arguments");
+    pss_ring *r = new pss_ring{ctx, nullptr, max_rows, len, 0, 0};
+    hipError_t e = hipMalloc(&r->d_rows, sizeof(float) * (size_t)max_rows * len);
+    if (e != hipSuccess) { delete r; return pss_fail(ctx, PSS_E_NOMEM, "ring hipMalloc failed"); }
+    *out = r;
+    return PSS_OK;
+}
+
+extern "C" void pss_ring_destroy(pss_ring *r)
+{
+    if (!r) return;
+    hipStreamSynchronize(PSS_STREAM(r->ctx));
+    hipFree(r->d_rows);
+    delete r;
+}
+
+extern "C" int pss_ring_count(pss_ring *r) { return r ? r->count : PSS_E_ARG; }
+
+extern "C" int pss_ring_push(pss_ring *r, const float *d_row)
+{
+    if (!r || !d_row) return PSS_E_ARG;
+    int slot;
+    if (r->count < r->cap) slot = (r->head + r->count++) % r->cap;
+    else { slot = r->head; r->head = (r->head + 1) % r->cap; }  // history.pop(0)
+    return pss_hip_check(r->ctx, hipMemcpyAsync(r->d_rows + (size_t)slot * r->len, d_row, sizeof(float) * r->len,
+                                                hipMemcpyDeviceToDevice, PSS_STREAM(r->ctx)), "ring push");
+}
+
+extern "C" int pss_ring_waterfall(pss_ring *r, int disp_h, int disp_w, int8_t *d_glyph, int8_t *d_colour)
+{
+    if (!r || !d_glyph || !d_colour || disp_h < 1 || disp_w < 1 || r->count < 1) return PSS_E_ARG;
+    hipLaunchKernelGGL((k_cells<float, 0>), dim3(1), dim3(TPB), 0, PSS_STREAM(r->ctx), r->d_rows, r->count, r->len, disp_h,
+                       disp_w, d_glyph, d_colour, r->head, r->cap);
+    return pss_hip_check(r->ctx, hipGetLastError(), "k_cells launch");
+}
+
+extern "C" int pss_ring_persistence(pss_ring *r, int disp_h, int disp_w, int8_t *d_colour)
+{
+    if (!r || !d_colour || disp_h < 1 || disp_w < 1 || r->count < 1) return PSS_E_ARG;
+    hipLaunchKernelGGL((k_cells<float, 1>), dim3(1), dim3(TPB), 0, PSS_STREAM(r->ctx), r->d_rows, r->count, r->len, disp_h,
+                       disp_w, (int8_t *)nullptr, d_colour, r->head, r->cap);
+    return pss_hip_check(r->ctx, hipGetLastError(), "k_cells launch");
 }

@@ -142,6 +142,24 @@ class Engine:
         fn = self.lib.pss_persistence_cells_f64 if f64 else self.lib.pss_persistence_cells
         self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_colour)))
 
+    # -- stateful display accumulators (device ring of the last rows)
+    def ring_create(self, max_rows, length):
+        h = C.c_void_p()
+        self._ck(self.lib.pss_ring_create(self.h, max_rows, length, C.byref(h)))
+        return h
+
+    def ring_destroy(self, ring):
+        self.lib.pss_ring_destroy(ring)
+
+    def ring_push(self, ring, d_row):
+        self._ck(self.lib.pss_ring_push(ring, _ptr(d_row)))
+
+    def ring_waterfall(self, ring, disp_h, disp_w, d_glyph, d_colour):
+        self._ck(self.lib.pss_ring_waterfall(ring, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour)))
+
+    def ring_persistence(self, ring, disp_h, disp_w, d_colour):
+        self._ck(self.lib.pss_ring_persistence(ring, disp_h, disp_w, _ptr(d_colour)))
+
     # -- streamed capture from host memory (chunked, double-buffered H2D / compute / D2H)
     def pinned_empty(self, shape, dtype):
         """numpy array backed by pinned host memory (hipHostMalloc); keep a reference to it while in use."""

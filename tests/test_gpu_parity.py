@@ -267,6 +267,31 @@ def test_waterfall_and_persistence_cells(golden):
     assert np.mean(G.host(d_g) != g["wf_glyph"][29]) < 1e-3
 
 
+def test_ring_accumulators_follow_the_reference_history(golden):
+    # push the caller's rows one by one into 30- and 10-deep device rings; after every push the cells must equal the
+    # stateless quantiser on the same window (which test_waterfall_and_persistence_cells pins to the reference)
+    g = golden["caller"]
+    e = G.engine()
+    rows = g["rows"].astype(np.float32)
+    H, W = [int(v) for v in g["hw"]]
+    dh, dw = H - 4, W - 8
+    wf, ps = e.ring_create(30, rows.shape[1]), e.ring_create(10, rows.shape[1])
+    d_rows = G.dev(rows)
+    for i in range(len(rows)):
+        e.ring_push(wf, d_rows[i]); e.ring_push(ps, d_rows[i])
+        if i in (0, 4, 9, 10, 11, 29, 30, 33):
+            a_g, a_c, b_c = (G.empty((dh, dw), torch.int8) for _ in range(3))
+            e.ring_waterfall(wf, dh, dw, a_g, a_c)
+            e.ring_persistence(ps, dh, dw, b_c)
+            w0, p0 = max(0, i + 1 - 30), max(0, i + 1 - 10)
+            r_g, r_c, q_c = (G.empty((dh, dw), torch.int8) for _ in range(3))
+            e.waterfall_cells(d_rows[w0:i + 1].contiguous(), i + 1 - w0, rows.shape[1], dh, dw, r_g, r_c)
+            e.persistence_cells(d_rows[p0:i + 1].contiguous(), i + 1 - p0, rows.shape[1], dh, dw, q_c)
+            e.sync()
+            assert torch.equal(a_g, r_g) and torch.equal(a_c, r_c) and torch.equal(b_c, q_c), i
+    e.ring_destroy(wf); e.ring_destroy(ps)
+
+
 def test_dropin_module_matches_reference_signatures(golden):
     import pyspecsdr_amd.signal_processing as sp
     g = golden["nfm"]
