@@ -376,6 +376,28 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     case 4096: return launch_r16<4, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
     default: break;
     }
+    if (!SCAN && n_fft >= 8192 && n_fft <= 65536) {
+        // N = R * 4096: radix-R pre-pass + register-resident 4096-point transforms, one workgroup per frame
+        using C = pss_r16::Cfg<4>;
+        const long cap = 512;  // workgroups (each owns N complex float64 of L2-resident scratch)
+        const int grid = (int)(n_frames < cap ? n_frames : cap);
+        r = pss_ensure_scratch(ctx, (size_t)grid * n_fft * sizeof(double2));
+        if (r) return r;
+        double2 *scr = reinterpret_cast<double2 *>(ctx->scratch);
+        void (*kern)(const float2 *, float *, const double2 *, const double *, long, double2 *) =
+            n_fft == 8192 ? pss_r16::k_spectrum_r16_big<1, true>
+            : n_fft == 16384 ? pss_r16::k_spectrum_r16_big<2, true>
+            : n_fft == 32768 ? pss_r16::k_spectrum_r16_big<3, true> : pss_r16::k_spectrum_r16_big<4, true>;
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)C::LDS));
+        pss_time_begin(ctx);
+        pss_kernel_begin(ctx, "k_spectrum");
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db,
+                           tw, win, n_frames, scr);
+        pss_kernel_end(ctx);
+        pss_time_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_r16_big launch");
+    }
     int logn = ilog2(n_fft);
     int logNsub = logn < LOG_NSUB_MAX ? logn : LOG_NSUB_MAX;
     int R = n_fft >> logNsub;

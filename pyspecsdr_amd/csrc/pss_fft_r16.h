@@ -103,6 +103,47 @@ struct Cfg {
     static constexpr size_t LDS = (size_t)FPW * EX * sizeof(double2) + (size_t)R3 * 16 * sizeof(double2);
 };
 
+// Stages 1b..3 for one frame whose 16 (windowed) stage-1 inputs are already in v[]: 16-point DFT, twiddle, exchange,
+// 16-point DFT, twiddle, exchange, radix-R3 butterflies.  emit(i, kp, X) is called for the thread's 16 results, kp being
+// the frequency index inside this N = 256*R3 transform.  Contains three workgroup barriers; the caller adds the one
+// that separates consecutive frames.
+template <int LOG_R3, class Emit>
+__device__ __forceinline__ void r16_core(double2 (&v)[16], double2 *ex, const double2 (&tw1)[16], const double2 *tw2,
+                                         int t, Emit emit)
+{
+    using C = Cfg<LOG_R3>;
+    constexpr int R3 = C::R3, T = C::T;
+    const int k2s = t / R3, m1s = t % R3;  // stage-2 role
+    fft_reg<16>(v);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) {
+        double2 y = v[brev(k2, 4)];
+        if (k2) y = cmul(y, tw1[k2]);
+        ex[k2 * C::E1_STRIDE + t] = y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m2 = 0; m2 < 16; m2++) v[m2] = ex[k2s * C::E1_STRIDE + m1s + R3 * m2];
+    __syncthreads();
+    fft_reg<16>(v);
+#pragma unroll
+    for (int j2 = 0; j2 < 16; j2++) {
+        double2 z = v[brev(j2, 4)];
+        if (R3 > 1) z = cmul(z, tw2[m1s * 16 + j2]);
+        ex[m1s * C::E2_STRIDE + 16 * j2 + k2s] = z;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16 / R3; c++) {
+        double2 b[R3];
+#pragma unroll
+        for (int m1 = 0; m1 < R3; m1++) b[m1] = ex[m1 * C::E2_STRIDE + t + T * c];
+        fft_reg<R3>(b);
+#pragma unroll
+        for (int j1 = 0; j1 < R3; j1++) emit(c * R3 + j1, 256 * j1 + t + T * c, b[brev(j1, LOG_R3)]);
+    }
+}
+
 template <int LOG_R3, bool SCAN>
 __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__ iq, float *__restrict__ db,
                                                       const double2 *__restrict__ tw, const double *__restrict__ win,
@@ -120,10 +161,10 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
     const int fl = tid / T;   // frame slot inside the workgroup
     const int t = tid % T;    // thread inside the frame: n1 in stage 1, (k2, m1) in stage 2, rho in stage 3
     double2 *ex = ex_all + (size_t)fl * C::EX;
-    const int k2s = t / R3, m1s = t % R3;  // stage-2 role
     // per-thread constants
     double2 tw1[16];
     double w[16];
+    tw1[0] = make_double2(1.0, 0.0);
 #pragma unroll
     for (int k2 = 1; k2 < 16; k2++) tw1[k2] = tw[(size_t)t * k2];  // W_N^(n1*k2), n1*k2 < N
 #pragma unroll
@@ -139,52 +180,20 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
         const bool valid = f < n_frames;
         const float2 *x = iq + (size_t)(valid ? f : 0) * N;
         double2 v[16];
-        // ---- stage 1
 #pragma unroll
         for (int n2 = 0; n2 < 16; n2++) {
             float2 s = x[t + T * n2];
             v[n2] = make_double2((double)s.x * w[n2], (double)s.y * w[n2]);
         }
-        fft_reg<16>(v);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; k2++) {
-            double2 y = v[brev(k2, 4)];
-            if (k2) y = cmul(y, tw1[k2]);
-            ex[k2 * C::E1_STRIDE + t] = y;
-        }
-        __syncthreads();
-        // ---- stage 2
-#pragma unroll
-        for (int m2 = 0; m2 < 16; m2++) v[m2] = ex[k2s * C::E1_STRIDE + m1s + R3 * m2];
-        __syncthreads();
-        fft_reg<16>(v);
-#pragma unroll
-        for (int j2 = 0; j2 < 16; j2++) {
-            double2 z = v[brev(j2, 4)];
-            if (R3 > 1) z = cmul(z, tw2[m1s * 16 + j2]);
-            ex[m1s * C::E2_STRIDE + 16 * j2 + k2s] = z;
-        }
-        __syncthreads();
-        // ---- stage 3 + dB epilogue: butterflies bf = t + T*c, outputs k = 256*j1 + bf
         float *out = (db && valid) ? db + (size_t)f * N : nullptr;
         float lmax = -INFINITY;
         float dbv[16];
-#pragma unroll
-        for (int c = 0; c < 16 / R3; c++) {
-            double2 b[R3];
-#pragma unroll
-            for (int m1 = 0; m1 < R3; m1++) b[m1] = ex[m1 * C::E2_STRIDE + t + T * c];
-            fft_reg<R3>(b);
-#pragma unroll
-            for (int j1 = 0; j1 < R3; j1++) {
-                double2 X = b[brev(j1, LOG_R3)];
-                float d = db_of(X.x * X.x + X.y * X.y + 1e-10);
-                const int k = 256 * j1 + t + T * c;
-                if (out) out[(k + N / 2) & (N - 1)] = d;  // fftshift
-                dbv[c * R3 + j1] = d;
-                lmax = fmaxf(lmax, d);
-            }
-        }
+        r16_core<LOG_R3>(v, ex, tw1, tw2, t, [&](int i, int k, double2 X) {
+            float d = db_of(X.x * X.x + X.y * X.y + 1e-10);
+            if (out) out[(k + N / 2) & (N - 1)] = d;  // fftshift; T consecutive bins per store instruction
+            dbv[i] = d;
+            lmax = fmaxf(lmax, d);
+        });
         if (SCAN) {
             // per-frame peak and 20-dB-down bin count (pyspecsdr.py:2546-2552); T threads own one frame
             float m = lmax;
@@ -213,6 +222,66 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
             }
         }
         __syncthreads();
+    }
+}
+
+// N = R * 4096, R in {2,4,8,16}: a radix-R decimation-in-frequency pre-pass, then R register-resident 4096-point
+// transforms (r16_core<4>) one after the other:
+//   X[R k' + r] = FFT_4096( y_r )[k'],  y_r[n] = W_N^(n r) * sum_q x[n + 4096 q] w[n + 4096 q] W_R^(q r).
+// One 256-thread workgroup per frame.  The pre-pass reads the frame once (each thread: 16 R-point register DFTs) and
+// parks y_r[] in a per-workgroup scratch (N complex float64, L2-resident); bins of one sub-transform land R apart, so
+// a dB row is completed by R interleaved store passes that L2 merges.
+template <int LOG_R, bool WINDOW>
+__global__ __launch_bounds__(256) void k_spectrum_r16_big(const float2 *__restrict__ iq, float *__restrict__ db,
+                                                          const double2 *__restrict__ tw, const double *__restrict__ win,
+                                                          long n_frames, double2 *__restrict__ scratch)
+{
+    using C = Cfg<4>;
+    constexpr int T = C::T, NS = C::N, R = 1 << LOG_R, N = R * NS;  // 256 threads, 4096-point sub-transforms
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *ex = reinterpret_cast<double2 *>(smem);
+    double2 *tw2 = ex + C::EX;
+    const int t = threadIdx.x;
+    double2 *scr = scratch + (size_t)blockIdx.x * N;
+    double2 tw1[16];
+    tw1[0] = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; k2++) tw1[k2] = tw[(size_t)t * k2 * R];  // W_4096^(n1 k2) = W_N^(R n1 k2)
+    tw2[t] = tw[(size_t)((t / 16) * (t % 16)) * 16 * R];                // W_256^(m1 j2) = W_N^(16 R m1 j2)
+    __syncthreads();
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const float2 *x = iq + (size_t)f * N;
+        float *out = db + (size_t)f * N;
+        // pre-pass
+#pragma unroll 4
+        for (int j = 0; j < 16; j++) {
+            const int n = t + T * j;
+            double2 a[R];
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                float2 s = x[n + NS * q];
+                const double wv = WINDOW ? win[n + NS * q] : 1.0;
+                a[q] = make_double2((double)s.x * wv, (double)s.y * wv);
+            }
+            fft_reg<R>(a);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                double2 y = a[brev(r, LOG_R)];
+                if (r) y = cmul(y, tw[(size_t)n * r]);  // W_N^(n r), n r < N
+                scr[(size_t)r * NS + n] = y;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < R; r++) {
+            double2 v[16];
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) v[n2] = scr[(size_t)r * NS + t + T * n2];
+            r16_core<4>(v, ex, tw1, tw2, t, [&](int, int kp, double2 X) {
+                const int k = R * kp + r;
+                out[(k + N / 2) & (N - 1)] = db_of(X.x * X.x + X.y * X.y + 1e-10);
+            });
+            __syncthreads();
+        }
     }
 }
 
