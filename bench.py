@@ -121,8 +121,18 @@ def main():
     n_out = eng.demod_out_len(0, n, FS)
     d_pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
 
+    # waterfall state after the batch (configs[1] names it): the caller's smoothing + median clamp
+    # (pyspecsdr.py:2278-2283) on the newest WATERFALL_MAX_LINES = 30 rows and the 36 x 112 cell quantiser
+    # (pyspecsdr.py:1342-1406) — a display only ever shows the last 30 rows of a batch.
+    WF = min(30, nf)
+    d_post = torch.empty((WF, n - 4), dtype=torch.float32, device=dev)
+    d_glyph = torch.empty((36, 112), dtype=torch.int8, device=dev)
+    d_col = torch.empty((36, 112), dtype=torch.int8, device=dev)
+
     def step():
         eng.spectrum_nfm(iq, nf, n, FS, d_db, d_pcm)
+        eng.spectrum_post(d_db[nf - WF:], WF, n, d_post)
+        eng.waterfall_cells(d_post, WF, n - 4, 36, 112, d_glyph, d_col)
 
     def fence():
         eng.sync()
@@ -184,7 +194,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 front end / f64 FFT+FIR+IIR / int16 PCM", "data": "synthetic",
             "config": {"workload": f"{nf} frames x {n}-pt complex64 @2.4 MS/s per GPU: compute_fft dB spectrum + "
-                                   f"NFM demod -> int16 stereo (BASELINE.json configs[1])",
+                                   f"NFM demod -> int16 stereo + waterfall cells of the newest 30 rows (BASELINE.json configs[1])",
                        "frames_per_gpu": nf, "n_fft": n, "sample_rate": FS, "parallelism": f"frames sharded x{world}"},
             "roofline": roof,
         }

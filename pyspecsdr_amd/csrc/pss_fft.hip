@@ -26,6 +26,7 @@ namespace {
 constexpr int TPB = 256;
 constexpr int LOG_NSUB_MAX = 12;  // 4096 points * 16 B = 64 KiB of LDS
 constexpr int STAGE_MAX_N = 16384;
+constexpr int PT = 1024;  // k_post threads per row
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b)
 {
@@ -196,15 +197,15 @@ __global__ __launch_bounds__(TPB) void k_spectrum(const float2 *__restrict__ iq,
 
 // pyspecsdr.py:2278-2283 — 5-tap moving average ('valid'), then everything below median-10 is raised to it.
 // One workgroup per frame; the median comes from a bitonic sort of the smoothed row in LDS.
-__global__ __launch_bounds__(TPB) void k_post(const float *__restrict__ db, float *__restrict__ post, int N, int P,
+__global__ __launch_bounds__(PT) void k_post(const float *__restrict__ db, float *__restrict__ post, int N, int P,
                                               long n_frames)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *srt = reinterpret_cast<float *>(smem);
-    const int tid = threadIdx.x, m = N - 4;
+    const int tid = threadIdx.x, m = N - 4, nthr = blockDim.x;
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const float *row = db + (size_t)f * N;
-        for (int i = tid; i < P; i += TPB) {
+        for (int i = tid; i < P; i += nthr) {
             float v = INFINITY;
             if (i < m) {
                 double acc = 0.0;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(TPB) void k_post(const float *__restrict__ db, floa
         __syncthreads();
         for (int k = 2; k <= P; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < P; i += TPB) {
+                for (int i = tid; i < P; i += nthr) {
                     int ixj = i ^ j;
                     if (ixj > i) {
                         float a = srt[i], b = srt[ixj];
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(TPB) void k_post(const float *__restrict__ db, floa
         double thr = med - 10.0;
         __syncthreads();
         float *o = post + (size_t)f * m;
-        for (int i = tid; i < m; i += TPB) {
+        for (int i = tid; i < m; i += nthr) {
             double acc = 0.0;
             for (int k = 0; k < 5; k++) acc += (double)row[i + k] * 0.2;
             o[i] = (float)(acc < thr ? thr : acc);
@@ -257,20 +258,21 @@ __device__ __forceinline__ double interp_row(const T *row, int len, int W, int i
 
 // MODE 0: waterfall (pyspecsdr.py:1342-1406)   MODE 1: persistence (pyspecsdr.py:1512-1564)
 template <class T, int MODE>
-__global__ __launch_bounds__(TPB) void k_cells(const T *__restrict__ rows, int n_rows, int len, int disp_h, int disp_w,
+__global__ __launch_bounds__(1024) void k_cells(const T *__restrict__ rows, int n_rows, int len, int disp_h, int disp_w,
                                                int8_t *__restrict__ glyph, int8_t *__restrict__ colour, int start, int cap)
 {
     // rows live in a ring of `cap` rows; logical row i (0 = oldest) is physical row (start + i) mod cap
-    __shared__ double red_lo[TPB / 64], red_hi[TPB / 64];
+    constexpr int CT = 1024;  // threads: the min/max scan over the ring is latency-bound, so go wide and unroll
+    __shared__ double red_lo[CT / 64], red_hi[CT / 64];
     const int tid = threadIdx.x;
     auto rowp = [&](int i) { return rows + (size_t)((start + i) % cap) * len; };
     double lo = INFINITY, hi = -INFINITY;
-    for (int r = 0; r < n_rows; r++) {
-        const T *rp = rowp(r);
-        for (int i = tid; i < len; i += TPB) {
-            double v = (double)rp[i];
-            if (isfinite(v)) { lo = fmin(lo, v); hi = fmax(hi, v); }
-        }
+    const int total = n_rows * len;
+#pragma unroll 8
+    for (int e = tid; e < total; e += CT) {
+        const int r = e / len, i = e - r * len;
+        double v = (double)rowp(r)[i];
+        if (isfinite(v)) { lo = fmin(lo, v); hi = fmax(hi, v); }
     }
     for (int off = 32; off > 0; off >>= 1) {
         lo = fmin(lo, __shfl_xor(lo, off));
@@ -278,11 +280,12 @@ __global__ __launch_bounds__(TPB) void k_cells(const T *__restrict__ rows, int n
     }
     if ((tid & 63) == 0) { red_lo[tid >> 6] = lo; red_hi[tid >> 6] = hi; }
     __syncthreads();
-    lo = fmin(fmin(red_lo[0], red_lo[1]), fmin(red_lo[2], red_lo[3]));
-    hi = fmax(fmax(red_hi[0], red_hi[1]), fmax(red_hi[2], red_hi[3]));
+    lo = red_lo[0]; hi = red_hi[0];
+#pragma unroll
+    for (int k = 1; k < CT / 64; k++) { lo = fmin(lo, red_lo[k]); hi = fmax(hi, red_hi[k]); }
     const int cells = disp_h * disp_w;
     if (MODE == 0) {
-        for (int c = tid; c < cells; c += TPB) {
+        for (int c = tid; c < cells; c += CT) {
             int y = c / disp_w, x = c - y * disp_w;
             int8_t g = -1, ci = -1;
             if (y < n_rows) {
@@ -299,10 +302,10 @@ __global__ __launch_bounds__(TPB) void k_cells(const T *__restrict__ rows, int n
     } else {
         double range = hi - lo;
         if (range == 0) range = 1;
-        for (int c = tid; c < cells; c += TPB) colour[c] = 0;
+        for (int c = tid; c < cells; c += CT) colour[c] = 0;
         __syncthreads();
         // traces are drawn oldest first and later ones overwrite: a column is owned by one thread
-        for (int x = tid; x < disp_w; x += TPB)
+        for (int x = tid; x < disp_w; x += CT)
             for (int i = 0; i < n_rows; i++) {
                 double alpha = pow(0.7, (double)(10 - i));
                 int cp = (int)(1 + (5 * (1 - alpha)));
@@ -480,7 +483,9 @@ extern "C" int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames,
     if (per_cu > 8) per_cu = 8;
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_post");
-    hipLaunchKernelGGL(k_post, dim3(grid_for(n_frames, per_cu)), dim3(TPB), lds, PSS_STREAM(ctx), d_db, d_post, n_fft, P,
+    // few rows (a display's last 30): latency matters -> 1024 threads per row; big batches: 256 (more rows in flight)
+    const int pthreads = n_frames < 1024 ? PT : TPB;
+    hipLaunchKernelGGL(k_post, dim3(grid_for(n_frames, per_cu)), dim3(pthreads), lds, PSS_STREAM(ctx), d_db, d_post, n_fft, P,
                        n_frames);
     pss_kernel_end(ctx);
     pss_time_end(ctx);
@@ -494,7 +499,7 @@ extern "C" int pss_waterfall_cells(pss_ctx *ctx, const float *d_rows, int n_rows
     if (!d_rows || !d_glyph || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad waterfall arguments");
     pss_kernel_begin(ctx, "k_cells");
-    hipLaunchKernelGGL((k_cells<float, 0>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
+    hipLaunchKernelGGL((k_cells<float, 0>), dim3(1), dim3(1024), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
                        d_glyph, d_colour, 0, n_rows);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
@@ -507,7 +512,7 @@ extern "C" int pss_persistence_cells(pss_ctx *ctx, const float *d_rows, int n_ro
     if (!d_rows || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad persistence arguments");
     pss_kernel_begin(ctx, "k_cells");
-    hipLaunchKernelGGL((k_cells<float, 1>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
+    hipLaunchKernelGGL((k_cells<float, 1>), dim3(1), dim3(1024), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
                        (int8_t *)nullptr, d_colour, 0, n_rows);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
@@ -522,7 +527,7 @@ extern "C" int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n
     if (!d_rows || !d_glyph || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad waterfall arguments");
     pss_kernel_begin(ctx, "k_cells");
-    hipLaunchKernelGGL((k_cells<double, 0>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
+    hipLaunchKernelGGL((k_cells<double, 0>), dim3(1), dim3(1024), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
                        d_glyph, d_colour, 0, n_rows);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
@@ -535,7 +540,7 @@ extern "C" int pss_persistence_cells_f64(pss_ctx *ctx, const double *d_rows, int
     if (!d_rows || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad persistence arguments");
     pss_kernel_begin(ctx, "k_cells");
-    hipLaunchKernelGGL((k_cells<double, 1>), dim3(1), dim3(TPB), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
+    hipLaunchKernelGGL((k_cells<double, 1>), dim3(1), dim3(1024), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w,
                        (int8_t *)nullptr, d_colour, 0, n_rows);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
@@ -584,7 +589,7 @@ extern "C" int pss_ring_push(pss_ring *r, const float *d_row)
 extern "C" int pss_ring_waterfall(pss_ring *r, int disp_h, int disp_w, int8_t *d_glyph, int8_t *d_colour)
 {
     if (!r || !d_glyph || !d_colour || disp_h < 1 || disp_w < 1 || r->count < 1) return PSS_E_ARG;
-    hipLaunchKernelGGL((k_cells<float, 0>), dim3(1), dim3(TPB), 0, PSS_STREAM(r->ctx), r->d_rows, r->count, r->len, disp_h,
+    hipLaunchKernelGGL((k_cells<float, 0>), dim3(1), dim3(1024), 0, PSS_STREAM(r->ctx), r->d_rows, r->count, r->len, disp_h,
                        disp_w, d_glyph, d_colour, r->head, r->cap);
     return pss_hip_check(r->ctx, hipGetLastError(), "k_cells launch");
 }
@@ -592,7 +597,7 @@ extern "C" int pss_ring_waterfall(pss_ring *r, int disp_h, int disp_w, int8_t *d
 extern "C" int pss_ring_persistence(pss_ring *r, int disp_h, int disp_w, int8_t *d_colour)
 {
     if (!r || !d_colour || disp_h < 1 || disp_w < 1 || r->count < 1) return PSS_E_ARG;
-    hipLaunchKernelGGL((k_cells<float, 1>), dim3(1), dim3(TPB), 0, PSS_STREAM(r->ctx), r->d_rows, r->count, r->len, disp_h,
+    hipLaunchKernelGGL((k_cells<float, 1>), dim3(1), dim3(1024), 0, PSS_STREAM(r->ctx), r->d_rows, r->count, r->len, disp_h,
                        disp_w, (int8_t *)nullptr, d_colour, r->head, r->cap);
     return pss_hip_check(r->ctx, hipGetLastError(), "k_cells launch");
 }
