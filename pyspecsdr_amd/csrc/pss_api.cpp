@@ -23,19 +23,26 @@ int pss_hip_check(pss_ctx *ctx, hipError_t e, const char *what)
     return pss_fail(ctx, PSS_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+int pss_ensure_buffer(pss_ctx *ctx, void **buf, size_t *cap, size_t bytes, const char *what)
+{
+    if (bytes <= *cap) return PSS_OK;
+    if (*buf) {
+        // the old buffer may still be in use by work queued on either stream
+        hipStreamSynchronize(ctx->stream);
+        if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
+        hipFree(*buf);
+        *buf = nullptr;
+        *cap = 0;
+    }
+    hipError_t e = hipMalloc(buf, bytes);
+    if (e != hipSuccess) return pss_fail(ctx, PSS_E_NOMEM, std::string(what) + " hipMalloc: " + hipGetErrorString(e));
+    *cap = bytes;
+    return PSS_OK;
+}
+
 int pss_ensure_scratch(pss_ctx *ctx, size_t bytes)
 {
-    if (bytes <= ctx->scratch_bytes) return PSS_OK;
-    if (ctx->scratch) {
-        hipStreamSynchronize(ctx->stream);
-        hipFree(ctx->scratch);
-        ctx->scratch = nullptr;
-        ctx->scratch_bytes = 0;
-    }
-    hipError_t e = hipMalloc(&ctx->scratch, bytes);
-    if (e != hipSuccess) return pss_fail(ctx, PSS_E_NOMEM, std::string("scratch hipMalloc: ") + hipGetErrorString(e));
-    ctx->scratch_bytes = bytes;
-    return PSS_OK;
+    return pss_ensure_buffer(ctx, &ctx->scratch, &ctx->scratch_bytes, bytes, "scratch");
 }
 
 void pss_time_begin(pss_ctx *ctx)
@@ -111,6 +118,8 @@ extern "C" void pss_destroy(pss_ctx *ctx)
         hipFree(kv.second.d_node_r); hipFree(kv.second.d_level_start);
     }
     if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->scratch_fft) hipFree(ctx->scratch_fft);
+    if (ctx->stage) hipFree(ctx->stage);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
     hipStreamSynchronize(ctx->stream2);
@@ -187,26 +196,25 @@ extern "C" int pss_kernel_times(pss_ctx *ctx, char *buf, int buf_len)
 }
 
 // ---- host-buffer convenience: one frame, synchronous ------------------------------------------------
+// Device staging comes from one grow-only buffer owned by the context (no hipMalloc per call: this is the path the
+// drop-in module takes on every loop iteration of the host application).
 namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    int alloc(pss_ctx *ctx, size_t bytes) { return pss_hip_check(ctx, hipMalloc(&p, bytes ? bytes : 1), "hipMalloc"); }
-};
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
 extern "C" int pss_h_compute_fft(pss_ctx *ctx, const float *h_iq, int n, double *h_db)
 {
     if (!ctx) return PSS_E_ARG;
     if (!h_iq || !h_db || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
-    DevBuf iq, db;
-    int r;
-    if ((r = iq.alloc(ctx, sizeof(float) * 2 * n)) || (r = db.alloc(ctx, sizeof(float) * n))) return r;
-    PSS_HIP(ctx, hipMemcpyAsync(iq.p, h_iq, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
-    r = pss_spectrum_db(ctx, (const float *)iq.p, 1, n, (float *)db.p);
+    const size_t o_db = up256(sizeof(float) * 2 * n);
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_db + up256(sizeof(float) * n), "staging");
+    if (r) return r;
+    char *base = reinterpret_cast<char *>(ctx->stage);
+    PSS_HIP(ctx, hipMemcpyAsync(base, h_iq, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
+    r = pss_spectrum_db(ctx, reinterpret_cast<const float *>(base), 1, n, reinterpret_cast<float *>(base + o_db));
     if (r) return r;
     std::vector<float> tmp(n);
-    PSS_HIP(ctx, hipMemcpyAsync(tmp.data(), db.p, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    PSS_HIP(ctx, hipMemcpyAsync(tmp.data(), base + o_db, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
     PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n; i++) h_db[i] = (double)tmp[i];
     return PSS_OK;
@@ -219,17 +227,17 @@ extern "C" int pss_h_demodulate(pss_ctx *ctx, int mode, const float *h_iq, int n
     if (!h_iq || n < 1 || (!h_audio_stereo && !h_pcm)) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
     int n_out = pss_demod_out_len(mode, n, fs);
     if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "unknown mode or sample rate below 22050 Hz");
-    DevBuf iq, pcm, au;
-    int r;
-    if ((r = iq.alloc(ctx, sizeof(float) * 2 * n)) || (r = pcm.alloc(ctx, sizeof(int16_t) * 2 * n_out)) ||
-        (r = au.alloc(ctx, sizeof(double) * n_out)))
-        return r;
-    PSS_HIP(ctx, hipMemcpyAsync(iq.p, h_iq, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
-    r = pss_demod(ctx, mode, (const float *)iq.p, 1, n, fs, (int16_t *)pcm.p, (double *)au.p);
+    const size_t o_pcm = up256(sizeof(float) * 2 * n), o_au = o_pcm + up256(sizeof(int16_t) * 2 * n_out);
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_au + up256(sizeof(double) * n_out), "staging");
+    if (r) return r;
+    char *base = reinterpret_cast<char *>(ctx->stage);
+    PSS_HIP(ctx, hipMemcpyAsync(base, h_iq, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
+    r = pss_demod(ctx, mode, reinterpret_cast<const float *>(base), 1, n, fs, reinterpret_cast<int16_t *>(base + o_pcm),
+                  reinterpret_cast<double *>(base + o_au));
     if (r) return r;
     std::vector<double> mono(n_out);
-    PSS_HIP(ctx, hipMemcpyAsync(mono.data(), au.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->stream));
-    if (h_pcm) PSS_HIP(ctx, hipMemcpyAsync(h_pcm, pcm.p, sizeof(int16_t) * 2 * n_out, hipMemcpyDeviceToHost, ctx->stream));
+    PSS_HIP(ctx, hipMemcpyAsync(mono.data(), base + o_au, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_pcm) PSS_HIP(ctx, hipMemcpyAsync(h_pcm, base + o_pcm, sizeof(int16_t) * 2 * n_out, hipMemcpyDeviceToHost, ctx->stream));
     PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h_audio_stereo)
         for (int i = 0; i < n_out; i++) h_audio_stereo[2 * i] = h_audio_stereo[2 * i + 1] = mono[i];  // mono_to_stereo
@@ -240,13 +248,14 @@ extern "C" int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float
 {
     if (!ctx) return PSS_E_ARG;
     if (!h_iq || !h_power || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
-    DevBuf iq, p;
-    int r;
-    if ((r = iq.alloc(ctx, sizeof(float) * 2 * n)) || (r = p.alloc(ctx, sizeof(float)))) return r;
-    PSS_HIP(ctx, hipMemcpyAsync(iq.p, h_iq, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
-    r = pss_power_db(ctx, (const float *)iq.p, 1, n, (float *)p.p);
+    const size_t o_p = up256(sizeof(float) * 2 * n);
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_p + 256, "staging");
     if (r) return r;
-    PSS_HIP(ctx, hipMemcpyAsync(h_power, p.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    char *base = reinterpret_cast<char *>(ctx->stage);
+    PSS_HIP(ctx, hipMemcpyAsync(base, h_iq, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
+    r = pss_power_db(ctx, reinterpret_cast<const float *>(base), 1, n, reinterpret_cast<float *>(base + o_p));
+    if (r) return r;
+    PSS_HIP(ctx, hipMemcpyAsync(h_power, base + o_p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PSS_OK;
 }

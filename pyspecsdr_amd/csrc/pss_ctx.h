@@ -34,8 +34,12 @@ struct pss_ctx {
     std::map<double, PssNfmFilt> nfm;  // per sample rate
     std::map<double, std::array<double, 65>> ssb;
     std::map<int, PssPairwisePlan> plans;
-    void *scratch = nullptr;
+    void *scratch = nullptr;       // demodulator scratch (main stream)
     size_t scratch_bytes = 0;
+    void *scratch_fft = nullptr;   // spectrum scratch: separate, the spectrum kernel may run on the side stream
+    size_t scratch_fft_bytes = 0;
+    void *stage = nullptr;         // device staging of the host-buffer convenience calls (grow-only)
+    size_t stage_bytes = 0;
     bool no_fused = false;  // PSS_NO_FUSED=1: use the three-kernel NFM path (A/B and fallback testing)
     bool timing = false;
     int tdepth = 0;
@@ -50,6 +54,7 @@ struct pss_ctx {
 int pss_fail(pss_ctx *ctx, int code, const std::string &msg);
 int pss_hip_check(pss_ctx *ctx, hipError_t e, const char *what);
 int pss_ensure_scratch(pss_ctx *ctx, size_t bytes);
+int pss_ensure_buffer(pss_ctx *ctx, void **buf, size_t *cap, size_t bytes, const char *what);
 void pss_time_begin(pss_ctx *ctx);
 void pss_time_end(pss_ctx *ctx);
 // bracket ONE kernel launch with events on the context's stream (no-ops unless timing is enabled)

@@ -37,8 +37,12 @@ struct AmCoef {
     Biquad s[5];
 };
 
-__constant__ double c_taps_rev[65];  // taps[64 - j]
-__constant__ double c_taps[65];
+// The 65 FIR taps travel as a by-value kernel argument (kernarg segment: wave-uniform scalar loads), not a
+// __constant__ symbol: two contexts on one device may run different sample rates concurrently.
+struct TapsArg {
+    double fwd[65];  // taps[j]
+    double rev[65];  // taps[64 - j]
+};
 
 // ---------------------------------------------------------------------------------------------------
 // NFM front end: discriminator (float32, signal_processing.py:94,97) + 65-tap FIR (float64, :108).
@@ -95,7 +99,7 @@ __device__ __forceinline__ void fir65_batch(const double *__restrict__ xb, const
 }
 
 __global__ __launch_bounds__(FIR_T) void k_nfm_front(const float2 *__restrict__ iq, double *__restrict__ U, int n,
-                                                     long n_frames, int cpf, long Lp, float kscale, int swapped)
+                                                     long n_frames, int cpf, long Lp, float kscale, int swapped, TapsArg taps)
 {
     __shared__ double xs[FIR_XS];
     __shared__ double edge[EDGE + 1];  // u[M-28..M-1] of the frame, for the right odd extension
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(FIR_T) void k_nfm_front(const float2 *__restrict__ 
         };
         if (ibase >= 64 && ibase < M) {  // outputs 0..63 (shorter windows) come from k_nfm_edge
             double out[FB];
-            fir65_batch(xs + 9 * tid, c_taps_rev, out);  // xpad(8 tid + c) = 9 tid + c + c/8
+            fir65_batch(xs + 9 * tid, taps.rev, out);  // xpad(8 tid + c) = 9 tid + c + c/8
 #pragma unroll
             for (int o = 0; o < FB; o++)
                 if (ibase + o < M) put(ibase + o, out[o]);
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(FIR_T) void k_nfm_front(const float2 *__restrict__ 
 // One 128-thread workgroup per frame.  Also covers whole frames of <= 92 samples, where np.convolve's operand
 // order (M <= 65) or the right extension (M - 28 < 64) need the edge outputs too.
 __global__ __launch_bounds__(128) void k_nfm_edge(const float2 *__restrict__ iq, double *__restrict__ U, int n,
-                                                  long n_frames, long Lp, float kscale, int swapped)
+                                                  long n_frames, long Lp, float kscale, int swapped, TapsArg taps)
 {
     __shared__ double d[128];
     __shared__ double ltaps[72];
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(128) void k_nfm_edge(const float2 *__restrict__ iq,
     const float2 *x = iq + (size_t)f * n;
     double *Uf = U + (size_t)f * Lp;
     const int ne = M < 92 ? M : 64;  // outputs computed here
-    if (tid < 65) ltaps[tid] = c_taps[tid];
+    if (tid < 65) ltaps[tid] = taps.fwd[tid];
     d[tid] = (tid < M && tid < 92) ? (double)disc_sample(x[tid + 1], x[tid], kscale, swapped != 0) : 0.0;
     __syncthreads();
     if (tid < ne) {
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(TILE) void k_am_iir(const float2 *__restrict__ iq, 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_ssb_fir(const float2 *__restrict__ iq, double *__restrict__ Yf,
                                                  unsigned long long *__restrict__ mxbits, int n, long n_frames,
-                                                 int chunks_per_frame)
+                                                 int chunks_per_frame, TapsArg taps)
 {
     constexpr int CH = 1024;
     __shared__ float xr[CH + 64];
@@ -507,12 +511,12 @@ __global__ __launch_bounds__(TPB) void k_ssb_fir(const float2 *__restrict__ iq, 
             if (i >= n) break;
             double y;
             if (n <= 65) {
-                y = zdot_re_skx([&](int j) { return c_taps[j]; }, [&](int j) { return (double)xr[64 + k - j]; }, i + 1);
+                y = zdot_re_skx([&](int j) { return taps.fwd[j]; }, [&](int j) { return (double)xr[64 + k - j]; }, i + 1);
             } else if (i >= 64) {
-                y = zdot_re_skx([&](int j) { return (double)xr[k + j]; }, [&](int j) { return c_taps_rev[j]; }, 65);
+                y = zdot_re_skx([&](int j) { return (double)xr[k + j]; }, [&](int j) { return taps.rev[j]; }, 65);
             } else {
                 const int o = 64 - i;
-                y = zdot_re_skx([&](int j) { return (double)xr[64 - i0 + j]; }, [&](int j) { return c_taps_rev[o + j]; }, i + 1);
+                y = zdot_re_skx([&](int j) { return (double)xr[64 - i0 + j]; }, [&](int j) { return taps.rev[o + j]; }, i + 1);
             }
             Yf[(size_t)f * n + i] = y;
             unsigned long long b = (unsigned long long)__double_as_longlong(fabs(y));
@@ -676,13 +680,11 @@ int ssb_taps(pss_ctx *ctx, double fs, double **out)
     return PSS_OK;
 }
 
-int upload_taps(pss_ctx *ctx, const double *taps)
+TapsArg make_taps(const double *taps)
 {
-    double rev[65];
-    for (int j = 0; j < 65; j++) rev[j] = taps[64 - j];
-    PSS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_taps), taps, sizeof(double) * 65, 0, hipMemcpyHostToDevice, PSS_STREAM(ctx)));
-    PSS_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_taps_rev), rev, sizeof(double) * 65, 0, hipMemcpyHostToDevice, PSS_STREAM(ctx)));
-    return PSS_OK;
+    TapsArg t;
+    for (int j = 0; j < 65; j++) { t.fwd[j] = taps[j]; t.rev[j] = taps[64 - j]; }
+    return t;
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -749,8 +751,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         double *U = reinterpret_cast<double *>(ctx->scratch);
         double *Y = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + szU);
         double *A = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + szU + szY);
-        r = upload_taps(ctx, flt->taps);
-        if (r) return r;
+        const TapsArg targ = make_taps(flt->taps);
         NfmCoef c;
         for (int s = 0; s < 4; s++) {
             const double *row = flt->sos + 6 * s;
@@ -775,10 +776,10 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             pss_kernel_begin(ctx, "k_nfm_fwd");
             if (b121)
                 hipLaunchKernelGGL(fused::k_nfm_fwd<true>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped);
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
             else
                 hipLaunchKernelGGL(fused::k_nfm_fwd<false>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped);
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
             pss_kernel_end(ctx);
             if (ctx->fork_after_fwd) hipEventRecord(ctx->ev_fork, ctx->stream);  // pss_spectrum_nfm overlaps the rest
             pss_kernel_begin(ctx, "k_nfm_bwd");
@@ -798,11 +799,11 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         pss_time_begin(ctx);
         pss_kernel_begin(ctx, "k_nfm_front");
         hipLaunchKernelGGL(k_nfm_front, dim3((unsigned)g1), dim3(FIR_T), 0, PSS_STREAM(ctx),
-                           reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, cpf, Lp, kscale, swapped);
+                           reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, cpf, Lp, kscale, swapped, targ);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_nfm_edge");
         hipLaunchKernelGGL(k_nfm_edge, dim3((unsigned)n_frames), dim3(128), 0, PSS_STREAM(ctx),
-                           reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, Lp, kscale, swapped);
+                           reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, Lp, kscale, swapped, targ);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_nfm_iir");
         if (b121)
@@ -858,8 +859,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         char *base = reinterpret_cast<char *>(ctx->scratch);
         double *Yf = reinterpret_cast<double *>(base);
         unsigned long long *mxb = reinterpret_cast<unsigned long long *>(base + szY);
-        r = upload_taps(ctx, taps);
-        if (r) return r;
+        const TapsArg targ = make_taps(taps);
         pss_time_begin(ctx);
         PSS_HIP(ctx, hipMemsetAsync(mxb, 0, (size_t)n_frames * sizeof(double), PSS_STREAM(ctx)));
         const int cpf = (n + 1023) / 1024;
@@ -867,7 +867,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         long g = total < 16384 ? total : 16384;
         pss_kernel_begin(ctx, "k_ssb_fir");
         hipLaunchKernelGGL(k_ssb_fir, dim3((unsigned)g), dim3(TPB), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq),
-                           Yf, mxb, n, n_frames, cpf);
+                           Yf, mxb, n, n_frames, cpf, targ);
         pss_kernel_end(ctx);
         size_t tot = (size_t)n_frames * n;
         size_t g2 = (tot + TPB - 1) / TPB;

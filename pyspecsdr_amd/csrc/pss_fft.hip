@@ -384,9 +384,10 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
         using C = pss_r16::Cfg<4>;
         const long cap = 512;  // workgroups (each owns N complex float64 of L2-resident scratch)
         const int grid = (int)(n_frames < cap ? n_frames : cap);
-        r = pss_ensure_scratch(ctx, (size_t)grid * n_fft * sizeof(double2));
+        r = pss_ensure_buffer(ctx, &ctx->scratch_fft, &ctx->scratch_fft_bytes, (size_t)grid * n_fft * sizeof(double2),
+                              "spectrum scratch");
         if (r) return r;
-        double2 *scr = reinterpret_cast<double2 *>(ctx->scratch);
+        double2 *scr = reinterpret_cast<double2 *>(ctx->scratch_fft);
         void (*kern)(const float2 *, float *, const double2 *, const double *, long, double2 *) =
             n_fft == 8192 ? pss_r16::k_spectrum_r16_big<1, true>
             : n_fft == 16384 ? pss_r16::k_spectrum_r16_big<2, true>

@@ -121,45 +121,20 @@ __device__ __forceinline__ void fir_batch(const float *const (&blk)[NB], const d
 }
 
 template <int J, class Put>
-__device__ __forceinline__ void for_halves(const float *const (&blk)[NB], double (&out)[8], Put put)
+__device__ __forceinline__ void for_halves(const float *const (&blk)[NB], const double *__restrict__ yrev, double (&out)[8], Put put)
 {
-    fir_batch<J, 0>(blk, c_taps_rev, out);
+    fir_batch<J, 0>(blk, yrev, out);
     put(out, 0);
     if constexpr (FBH == 4) {
-        fir_batch<J, 1>(blk, c_taps_rev, out);
+        fir_batch<J, 1>(blk, yrev, out);
         put(out, 1);
-    }
-}
-
-// First 64 FIR outputs of every frame (windows shorter than 65 samples; one output per lane, predicated ddot),
-// parked TRANSPOSED in Uh[tile][i][lane] for the IIR wave of k_nfm_fwd.  One wavefront per frame-quarter:
-// workgroup = 256 threads = 4 frames.
-__global__ __launch_bounds__(256) void k_nfm_head(const float2 *__restrict__ iq, double *__restrict__ Uh, int n,
-                                                  long n_frames, float kscale, int swapped)
-{
-    __shared__ double d[4][64];
-    __shared__ double ltaps[72];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long f = (long)blockIdx.x * 4 + wave;
-    const int M = n - 1;
-    if (tid < 65) ltaps[tid] = c_taps[tid];
-    if (f < n_frames) {
-        const float2 *x = iq + (size_t)f * n;
-        d[wave][lane] = (lane < M) ? (double)disc_sample(x[lane + 1], x[lane], kscale, swapped != 0) : 0.0;
-    }
-    __syncthreads();
-    if (f < n_frames) {
-        const int i = lane;
-        const double *dw = d[wave];
-        double v = ddot_skx_lane([&](int j) { return dw[j]; }, [&](int j) { return ltaps[i - j]; }, i + 1);
-        Uh[((size_t)(f / TILE) * HEAD + i) * TILE + (f % TILE)] = v;
     }
 }
 
 template <bool B121>
 __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
                                                     double *__restrict__ Uh, double *__restrict__ Utl, int n,
-                                                    long n_frames, NfmCoef c, float kscale, int swapped)
+                                                    long n_frames, NfmCoef c, float kscale, int swapped, TapsArg taps)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
@@ -177,7 +152,7 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
     double *Uht = Uh + (size_t)tile * HEAD * TILE + lane;
     double *Utt = Utl + (size_t)tile * (EDGE + 1) * TILE + lane;
 #define YAT(p) Yt[(size_t)(p) * TILE]
-    if (tid < 65) ltaps[tid] = c_taps[tid];
+    if (tid < 65) ltaps[tid] = taps.fwd[tid];
     // ---- prologue: discriminator of times 0..87 into logical columns 8..95 (physical = logical at chunk 0)
     for (int idx = tid; idx < TILE * WCOLS; idx += 256) {
         const int fl = idx / WCOLS, l = idx % WCOLS, t = l - 8;
@@ -282,9 +257,9 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
                 };
                 {
                     double out[8];
-                    if (J == 0) { for_halves<0>(blk, out, put); }
-                    else if (J == 1) { for_halves<1>(blk, out, put); }
-                    else { for_halves<2>(blk, out, put); }
+                    if (J == 0) { for_halves<0>(blk, taps.rev, out, put); }
+                    else if (J == 1) { for_halves<1>(blk, taps.rev, out, put); }
+                    else { for_halves<2>(blk, taps.rev, out, put); }
                 }
                 // discriminator of the next chunk's 8 samples (9 complex); kept in registers until the window block
                 // is free.  The loads are issued after the FIR so they do not occupy registers across it — the other

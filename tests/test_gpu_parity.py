@@ -314,6 +314,29 @@ def test_dropin_module_matches_reference_signatures(golden):
         sp.demodulate_nfm(x[:28], 2.4e6)
 
 
+def test_spectrum_nfm_large_frames_two_streams():
+    # N >= 8192: the spectrum kernel uses its own scratch while the demodulator's backward pass runs beside it
+    e = G.engine()
+    rng = np.random.default_rng(81)
+    nf, n, fs = 130, 8192, 2.4e6
+    iq = (0.4 * np.exp(2j * np.pi * np.cumsum(rng.standard_normal((nf, n)) * 0.03, axis=1)) +
+          0.05 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
+    d_iq = G.dev(iq)
+    n_out = e.demod_out_len(L.MODE_NFM, n, fs)
+    d_db, d_pcm = G.empty((nf, n), torch.float32), G.empty((nf, n_out, 2), torch.int16)
+    for _ in range(3):
+        e.spectrum_nfm(d_iq, nf, n, fs, d_db, d_pcm)
+    e.sync()
+    d_db2, d_pcm2 = G.empty((nf, n), torch.float32), G.empty((nf, n_out, 2), torch.int16)
+    e.spectrum_db(d_iq, nf, n, d_db2); e.sync()
+    e.demod(L.MODE_NFM, d_iq, nf, n, fs, d_pcm2, None); e.sync()
+    assert torch.equal(d_db, d_db2) and torch.equal(d_pcm, d_pcm2)
+    taps, sos, zi = e.nfm_filters(fs)
+    assert np.array_equal(G.host(d_pcm[7]), O.pcm16_stereo(O.demod_nfm(iq[7], fs, taps, sos, zi)))
+    ref = O.compute_fft(iq[7])
+    assert np.all(np.abs(G.host(d_db[7]) - ref) <= 1e-4 * np.maximum(np.abs(ref), 1e-2))
+
+
 def test_streamed_capture_equals_resident_batch():
     # BASELINE.json configs[4] shape in miniature: a host capture cut into 2048-pt frames @10 MS/s, streamed in
     # ragged chunks (pinned buffers, double-buffered) must equal the device-resident batched call bit for bit
