@@ -65,7 +65,7 @@ constexpr int FIR_XS = (FIR_CH + 64) * 9 / 8 + 8;
 __device__ __forceinline__ int xpad(int p) { return p + (p >> 3); }
 
 // FB consecutive full-window outputs: output o uses x(o .. o+64) (time ascending), yrev[j] = taps[64-j].
-// Tree (pss_device.h ddot_skx, n = 65): a5[k][l] = fma(x[32+8k+l],y[32+8k+l], fma(x[8k+l],y[8k+l],0));
+// Tree (pss_device.h, ddot tree for n = 65): a5[k][l] = fma(x[32+8k+l],y[32+8k+l], fma(x[8k+l],y[8k+l],0));
 // a[k][l] = a5[k][l] + a5[k][l+4]; s[l] = ((a[0][l]+a[1][l])+a[2][l])+a[3][l]; dot = (s0+s2)+(s1+s3); + tap 64.
 // xb points at the thread's window start inside the padded LDS array: x(c) = xb[c + c/8].
 __device__ __forceinline__ void fir65_batch(const double *__restrict__ xb, const double *__restrict__ yrev, double (&out)[FB])
@@ -483,57 +483,126 @@ __global__ __launch_bounds__(TILE) void k_am_iir(const float2 *__restrict__ iq, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// SSB: real part of the complex 65-tap FIR (signal_processing.py:204/209; zdotu accumulation order).
+// SSB: real part of the complex 65-tap FIR (signal_processing.py:204/209; OpenBLAS zdotu accumulation order).
 // hilbert(real(z)).real == real(z) up to 1e-16 round-off, so the analytic-signal round trip is not run.
-// Sample-parallel; per-frame max|y| via atomicMax on the IEEE bit pattern (NaN sorts above +inf).
+// Sample-parallel: a workgroup takes 1024 outputs of one frame, each thread four consecutive ones (four
+// independent fma chains per accumulator); taps are SGPR operands, 32 at a time (one real/imag slot p of the zdot
+// kernel per pass); x is staged in LDS as float64.  Outputs with windows shorter than 65 samples (i < 64, or whole
+// frames of <= 65 samples) take the predicated per-lane tree.  Per-frame max|y| via atomicMax on the IEEE bit
+// pattern (NaN sorts above +inf).
 // ---------------------------------------------------------------------------------------------------
+constexpr int SSB_CH = 1024, SSB_FB = 4;
+constexpr int SSB_XS = (SSB_CH + 64) * 5 / 4 + 8;
+
+__device__ __forceinline__ int xpad4(int p) { return p + (p >> 2); }  // lane stride 5 doubles: conflict-free ds_read_b64
+
+__device__ __forceinline__ void ssb_track_max(unsigned long long m, unsigned long long *wmax, unsigned long long *mxbits_f)
+{
+    const int tid = threadIdx.x;
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    if ((tid & 63) == 0) wmax[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); k++) m = wmax[k] > m ? wmax[k] : m;
+        atomicMax(mxbits_f, m);
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(TPB) void k_ssb_fir(const float2 *__restrict__ iq, double *__restrict__ Yf,
                                                  unsigned long long *__restrict__ mxbits, int n, long n_frames,
                                                  int chunks_per_frame, TapsArg taps)
 {
-    constexpr int CH = 1024;
-    __shared__ float xr[CH + 64];
+    __shared__ double xr[SSB_XS];  // xr[xpad4(k)] = real(x[i0 - 64 + k])
     __shared__ unsigned long long wmax[TPB / 64];
     const int tid = threadIdx.x;
     const long total = n_frames * chunks_per_frame;
     for (long w = blockIdx.x; w < total; w += gridDim.x) {
         const long f = w / chunks_per_frame;
-        const int i0 = (int)(w % chunks_per_frame) * CH;
+        const int i0 = (int)(w % chunks_per_frame) * SSB_CH;
         const float2 *x = iq + (size_t)f * n;
-        for (int k = tid; k < CH + 64; k += TPB) {
+        for (int k = tid; k < SSB_CH + 64; k += TPB) {
             int i = i0 - 64 + k;
-            xr[k] = (i >= 0 && i < n) ? x[i].x : 0.0f;
+            xr[xpad4(k)] = (i >= 0 && i < n) ? (double)x[i].x : 0.0;
         }
         __syncthreads();
         unsigned long long m = 0;
-        for (int k = tid; k < CH; k += TPB) {
-            int i = i0 + k;
-            if (i >= n) break;
-            double y;
-            if (n <= 65) {
-                y = zdot_re_skx([&](int j) { return taps.fwd[j]; }, [&](int j) { return (double)xr[64 + k - j]; }, i + 1);
-            } else if (i >= 64) {
-                y = zdot_re_skx([&](int j) { return (double)xr[k + j]; }, [&](int j) { return taps.rev[j]; }, 65);
-            } else {
-                const int o = 64 - i;
-                y = zdot_re_skx([&](int j) { return (double)xr[64 - i0 + j]; }, [&](int j) { return taps.rev[o + j]; }, i + 1);
+        const int ibase = i0 + SSB_FB * tid;
+        if (n > 65 && ibase >= 64 && ibase < n) {
+            // four consecutive full windows: output o uses x(4 tid + o + j), j = 0..64; xpad4(4 tid + c) = 5 tid + c + c/4.
+            // The accumulators (a, p) of the zdot kernel (element j = 8 it + 2a + p) are taken two a's at a time (run-time
+            // h: a = 2h, 2h+1 -> 32 taps live in SGPRs); 4h elements further along the row is 5h doubles in the padded array.
+            const double *xb = xr + 5 * tid;
+            double cp[2][SSB_FB];  // c_p = (acc[0][p] + acc[1][p]) + (acc[2][p] + acc[3][p]), built up over h
+#pragma unroll 1
+            for (int h = 0; h < 2; h++) {
+                const double *xh = xb + 5 * h;
+                auto xw = [&](int cc) { return xh[cc + (cc >> 2)]; };
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    double acc[2][SSB_FB];
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; a2++) {
+                        double y[8];
+#pragma unroll
+                        for (int it = 0; it < 8; it++) y[it] = taps.rev[8 * it + 4 * h + 2 * a2 + p];
+#pragma unroll
+                        for (int o = 0; o < SSB_FB; o++) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int it = 0; it < 8; it++) v = __fma_rn(xw(o + 8 * it + 2 * a2 + p), y[it], v);
+                            acc[a2][o] = v;
+                        }
+                    }
+#pragma unroll
+                    for (int o = 0; o < SSB_FB; o++) {
+                        const double pair = __dadd_rn(acc[0][o], acc[1][o]);
+                        cp[p][o] = (h == 0) ? pair : __dadd_rn(cp[p][o], pair);
+                    }
+                }
             }
-            Yf[(size_t)f * n + i] = y;
-            unsigned long long b = (unsigned long long)__double_as_longlong(fabs(y));
-            m = b > m ? b : m;
+            const double y64 = taps.rev[64];
+#pragma unroll
+            for (int o = 0; o < SSB_FB; o++)
+                if (ibase + o < n) {
+                    double y = __fma_rn(xb[(o + 64) + ((o + 64) >> 2)], y64, __dadd_rn(cp[0][o], cp[1][o]));
+                    Yf[(size_t)f * n + ibase + o] = y;
+                    unsigned long long bb = (unsigned long long)__double_as_longlong(fabs(y));
+                    m = bb > m ? bb : m;
+                }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            unsigned long long o = __shfl_xor(m, off);
-            m = o > m ? o : m;
-        }
-        if ((tid & 63) == 0) wmax[tid >> 6] = m;
-        __syncthreads();
-        if (tid == 0) {
-            for (int k = 1; k < TPB / 64; k++) m = wmax[k] > m ? wmax[k] : m;
-            atomicMax(&mxbits[f], m);
-        }
-        __syncthreads();
+        ssb_track_max(m, wmax, &mxbits[f]);
     }
+}
+
+// Outputs whose window is shorter than 65 samples — i < 64, or every output of a frame of <= 65 samples (where
+// np.convolve keeps the taps as its first operand) — one output per lane with the predicated zdot tree.
+__global__ __launch_bounds__(128) void k_ssb_edge(const float2 *__restrict__ iq, double *__restrict__ Yf,
+                                                  unsigned long long *__restrict__ mxbits, int n, long n_frames,
+                                                  TapsArg taps)
+{
+    __shared__ double xr[128];
+    __shared__ double ltaps[72];
+    __shared__ unsigned long long wmax[2];
+    const int tid = threadIdx.x;
+    const long f = blockIdx.x;
+    const float2 *x = iq + (size_t)f * n;
+    if (tid < 65) ltaps[tid] = taps.fwd[tid];
+    xr[tid] = tid < n ? (double)x[tid].x : 0.0;
+    __syncthreads();
+    unsigned long long m = 0;
+    const int ne = n <= 65 ? n : 64;
+    if (tid < ne) {
+        const int i = tid;
+        double y = n <= 65 ? zdot_re_skx_lane([&](int j) { return ltaps[j]; }, [&](int j) { return xr[i - j]; }, i + 1)
+                           : zdot_re_skx_lane([&](int j) { return xr[j]; }, [&](int j) { return ltaps[i - j]; }, i + 1);
+        Yf[(size_t)f * n + i] = y;
+        m = (unsigned long long)__double_as_longlong(fabs(y));
+    }
+    ssb_track_max(m, wmax, &mxbits[f]);
 }
 
 // audio = y / max|y| * 0.95  -> float64 mono and/or int16 stereo (AM :194, SSB :216, io_manager.py:26)
@@ -868,6 +937,10 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         pss_kernel_begin(ctx, "k_ssb_fir");
         hipLaunchKernelGGL(k_ssb_fir, dim3((unsigned)g), dim3(TPB), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq),
                            Yf, mxb, n, n_frames, cpf, targ);
+        pss_kernel_end(ctx);
+        pss_kernel_begin(ctx, "k_ssb_edge");
+        hipLaunchKernelGGL(k_ssb_edge, dim3((unsigned)n_frames), dim3(128), 0, PSS_STREAM(ctx),
+                           reinterpret_cast<const float2 *>(d_iq), Yf, mxb, n, n_frames, targ);
         pss_kernel_end(ctx);
         size_t tot = (size_t)n_frames * n;
         size_t g2 = (tot + TPB - 1) / TPB;

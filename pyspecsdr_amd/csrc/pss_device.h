@@ -121,55 +121,16 @@ __device__ __forceinline__ float disc_sample(float2 a, float2 b, float kscale, b
     return __fmul_rn(atan2f_svml(im, re), kscale);
 }
 
-// Inner product in the accumulation order of OpenBLAS ddot (kernel/x86_64/ddot_microk_skylakex-2.c),
-// which is what np.convolve -> cblas_ddot executes inside scipy.signal.lfilter's FIR branch
-// (signal_processing.py:108).  X(j), Y(j): accessors for j = 0..n-1.
-template <class FX, class FY>
-__device__ __forceinline__ double ddot_skx(FX X, FY Y, int n)
-{
-    int n1 = n & -16, i = 0;
-    double dot = 0.0;
-    if (n1) {
-        double a[4][4];
-        int n32 = n1 & ~31;
-        if (n32) {
-            double a5[4][8];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int l = 0; l < 8; l++) a5[k][l] = __fma_rn(X(8 * k + l), Y(8 * k + l), 0.0);
-            for (i = 32; i < n32; i += 32) {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-#pragma unroll
-                    for (int l = 0; l < 8; l++) a5[k][l] = __fma_rn(X(i + 8 * k + l), Y(i + 8 * k + l), a5[k][l]);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int l = 0; l < 4; l++) a[k][l] = __dadd_rn(a5[k][l], a5[k][l + 4]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int l = 0; l < 4; l++) a[k][l] = 0.0;
-        }
-        for (; i < n1; i += 16) {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int l = 0; l < 4; l++) a[k][l] = __fma_rn(X(i + 4 * k + l), Y(i + 4 * k + l), a[k][l]);
-        }
-        double s[4];
-#pragma unroll
-        for (int l = 0; l < 4; l++) s[l] = __dadd_rn(__dadd_rn(__dadd_rn(a[0][l], a[1][l]), a[2][l]), a[3][l]);
-        dot = __dadd_rn(__dadd_rn(s[0], s[2]), __dadd_rn(s[1], s[3]));
-    }
-    for (; i < n; i++) dot = __fma_rn(Y(i), X(i), dot);
-    return dot;
-}
+// Inner product in the accumulation order of OpenBLAS ddot (kernel/x86_64/ddot.c + ddot_microk_skylakex-2.c), which is
+// what np.convolve -> cblas_ddot executes inside scipy.signal.lfilter's FIR branch (signal_processing.py:108):
+//   n1 = n & -16 elements go through 4 accumulators of 8 lanes (32 per step, fused multiply-add from +0.0), folded
+//   8 -> 4 lanes, then 4 accumulators of 4 lanes (16 per step); s[l] = ((a0[l]+a1[l])+a2[l])+a3[l];
+//   dot = (s0+s2)+(s1+s3); the n - n1 tail elements are added one by one with fma(y, x, dot).
+// Three renderings of this tree live here and in the kernels: ddot_skx_lane (per-lane length, predicated),
+// ddot_skx_uniform (wave-uniform length, rolled loops) and fir65_batch / fir_batch (n = 65, several consecutive
+// outputs at once, taps as SGPR operands).  X(j), Y(j): accessors for j = 0..n-1.
 
-// The same inner product with a PER-LANE length n <= 65, fully predicated (no divergent loops): used for the
+// ddot tree with a PER-LANE length n <= 65, fully predicated (no divergent loops): used for the
 // left-edge outputs of the FIR (window shorter than 65) where every lane of a wavefront has a different n.
 // Phases of the ddot kernel for n <= 65: up to two 32-element steps on 4x8 accumulators (n >= 32, n >= 64),
 // fold 8->4, at most one 16-element step on 4x4 accumulators, horizontal sum, up to 15 tail fmas.
@@ -212,7 +173,7 @@ __device__ __forceinline__ double ddot_skx_lane(FX X, FY Y, int n)
     return dot;
 }
 
-// The same inner product for a WAVE-UNIFORM length n <= 65 with few live registers (loops stay rolled): used by
+// ddot tree for a WAVE-UNIFORM length n <= 65 with few live registers (loops stay rolled): used by
 // the fused NFM kernel's IIR wave for the 64 left-edge FIR outputs, where lane = frame and all lanes share n.
 template <class FX, class FY>
 __device__ __forceinline__ double ddot_skx_uniform(FX X, FY Y, int n)
@@ -272,6 +233,41 @@ __device__ __forceinline__ double zdot_re_skx(FX X, FY Y, int n)
         dot = __dadd_rn(c0, c1);
     }
     for (; i < n; i++) dot = __fma_rn(X(i), Y(i), dot);
+    return dot;
+}
+
+// zdot tree (real part, real second operand) with a PER-LANE length n <= 65, fully predicated: up to eight 8-element
+// steps on 4x2 accumulators, c_p = (a0p+a1p)+(a2p+a3p), dot = c0+c1, up to 7 tail fmas (one when n = 65).
+template <class FX, class FY>
+__device__ __forceinline__ double zdot_re_skx_lane(FX X, FY Y, int n)
+{
+    const int n1 = n & -8;
+    double acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) acc[a][p] = 0.0;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const bool on = 8 * it < n1;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int j = on ? 8 * it + 2 * a + p : 0;
+                double v = __fma_rn(X(j), Y(j), acc[a][p]);
+                acc[a][p] = on ? v : acc[a][p];
+            }
+    }
+    double c0 = __dadd_rn(__dadd_rn(acc[0][0], acc[1][0]), __dadd_rn(acc[2][0], acc[3][0]));
+    double c1 = __dadd_rn(__dadd_rn(acc[0][1], acc[1][1]), __dadd_rn(acc[2][1], acc[3][1]));
+    double dot = n1 ? __dadd_rn(c0, c1) : 0.0;
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const int j = (n1 + t < n) ? n1 + t : 0;
+        double v = __fma_rn(X(j), Y(j), dot);
+        dot = (n1 + t < n) ? v : dot;
+    }
     return dot;
 }
 
