@@ -483,6 +483,118 @@ __global__ __launch_bounds__(TILE) void k_am_iir(const float2 *__restrict__ iq, 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// AM band-pass for SMALL batches: with lane = frame (k_am_iir) a batch of F frames keeps only F/64 wavefronts busy
+// (BASELINE cfg 3: 8192 frames = 128 waves on a 1024-SIMD part).  Here the five sections of one frame sit in five
+// adjacent lanes and the recurrence runs as a systolic array: at step t lane (g, s) works on sample t-s and hands its
+// output to lane (g, s+1) with one DPP row shift.  A wavefront carries 12 frames (4 DPP rows x 3 frames x 5 lanes,
+// lane 15 of every row idle) -> 5.3x more wavefronts, each step a 5-deep dependent chain instead of 45 instructions.
+// Every section still executes exactly biquad_step()'s operations on exactly its own sample sequence (zero initial
+// state, filled and drained with zeros), so the output bits are those of k_am_iir.
+// ---------------------------------------------------------------------------------------------------
+constexpr int SYS_G = 12, SYS_T = 64;
+
+__device__ __forceinline__ double dpp_row_shr1(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true);  // row_shr:1, out-of-row lanes read 0
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void k_am_sys(const float2 *__restrict__ iq, const float *__restrict__ mu,
+                                               double *__restrict__ Yf, double *__restrict__ mxout, int n,
+                                               long n_frames, AmCoef c)
+{
+    __shared__ double ebuf[SYS_G][SYS_T + 1];
+    __shared__ double ybuf[SYS_G][SYS_T + 1];
+    const int lane = threadIdx.x, row = lane >> 4, r = lane & 15;
+    const int g3 = r / 5, s = r - 5 * g3;           // r = 15 -> g3 = 3 (idle lane)
+    const bool active = r < 15;
+    const int g = active ? row * 3 + g3 : 0;
+    const long f0 = (long)blockIdx.x * SYS_G;
+    const long f = f0 + g;
+    Biquad cs = c.s[0];
+#pragma unroll
+    for (int k = 1; k < AM_NS; k++)
+        if (s == k) cs = c.s[k];
+    double z0 = 0.0, z1 = 0.0, xprev = 0.0, mx = 0.0;
+    bool nan = false;
+    const long T = (long)n + AM_NS - 1;
+    const bool last = active && s == AM_NS - 1;
+    float2 pre[SYS_G];  // IQ of the next chunk (SYS_G frame rows, one sample per lane), loaded while the current one runs
+    auto prefetch = [&](long c0) {
+#pragma unroll
+        for (int gg = 0; gg < SYS_G; gg++) {
+            const long ff = f0 + gg;
+            const long i = c0 + lane;
+            pre[gg] = (ff < n_frames && i < n) ? iq[(size_t)ff * n + i] : make_float2(0.0f, 0.0f);
+        }
+    };
+    prefetch(0);
+    for (long c0 = 0; c0 < T; c0 += SYS_T) {
+        // envelope - mean of SYS_G frames x SYS_T samples
+#pragma unroll
+        for (int gg = 0; gg < SYS_G; gg++) {
+            const long ff = f0 + gg;
+            double e = 0.0;
+            if (ff < n_frames && c0 + lane < n)
+                e = (double)__fsub_rn(cabsf_np(pre[gg].x, pre[gg].y), mu[ff]);  // float32 subtract (signal_processing.py:185)
+            ebuf[gg][lane] = e;
+        }
+        if (c0 + SYS_T < T) prefetch(c0 + SYS_T);
+        __syncthreads();
+        const int cnt = (T - c0) < SYS_T ? (int)(T - c0) : SYS_T;
+        auto one = [&](int t, double e, bool checked) {
+            const double from_prev = dpp_row_shr1(xprev);
+            const double x = (s == 0) ? e : from_prev;
+            const double xn = __dadd_rn(__dmul_rn(cs.b0, x), z0);
+            z0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, x), __dmul_rn(cs.a1, xn)), z1);
+            z1 = __dsub_rn(__dmul_rn(cs.b2, x), __dmul_rn(cs.a2, xn));
+            xprev = xn;
+            bool keep = last;
+            if (checked) {
+                const long i = c0 + t - (AM_NS - 1);  // sample index of the last section's output
+                keep = keep && i >= 0 && i < n;
+            }
+            if (keep) {
+                ybuf[g][t] = xn;
+                const double av = fabs(xn);
+                nan = nan || (av != av);
+                mx = av > mx ? av : mx;
+            }
+        };
+        if (cnt == SYS_T) {
+            // straight-line groups of 8 steps: the eight LDS reads of a group are issued together, ahead of the chain;
+            // interior chunks (every output index valid) skip the index checks
+            const bool interior = c0 >= AM_NS - 1 && c0 + SYS_T <= n;
+            for (int t0 = 0; t0 < SYS_T; t0 += 8) {
+                double e8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) e8[k] = ebuf[g][t0 + k];
+                if (interior) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) one(t0 + k, e8[k], false);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) one(t0 + k, e8[k], true);
+                }
+            }
+        } else {
+            for (int t = 0; t < cnt; t++) one(t, ebuf[g][t], true);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int gg = 0; gg < SYS_G; gg++) {
+            const long ff = f0 + gg;
+            const long i = c0 + lane - (AM_NS - 1);
+            if (ff < n_frames && lane < cnt && i >= 0 && i < n) Yf[(size_t)ff * n + i] = ybuf[gg][lane];
+        }
+        __syncthreads();
+    }
+    if (active && s == AM_NS - 1 && f < n_frames) mxout[f] = nan ? __builtin_nan("") : mx;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // SSB: real part of the complex 65-tap FIR (signal_processing.py:204/209; OpenBLAS zdotu accumulation order).
 // hilbert(real(z)).real == real(z) up to 1e-16 round-off, so the analytic-signal round trip is not run.
 // Sample-parallel: a workgroup takes 1024 outputs of one frame, each thread four consecutive ones (four
@@ -904,8 +1016,12 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         r = launch_pairwise<1>(ctx, d_iq, n_frames, n, mu);
         if (r) return r;
         pss_kernel_begin(ctx, "k_am_iir");
-        hipLaunchKernelGGL(k_am_iir, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq),
-                           mu, Yf, mx, n, n_frames, c);
+        if (n_frames < 32768)  // few frames: spread the sections over lanes (5.3x more wavefronts)
+            hipLaunchKernelGGL(k_am_sys, dim3((unsigned)((n_frames + SYS_G - 1) / SYS_G)), dim3(64), 0, PSS_STREAM(ctx),
+                               reinterpret_cast<const float2 *>(d_iq), mu, Yf, mx, n, n_frames, c);
+        else
+            hipLaunchKernelGGL(k_am_iir, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx),
+                               reinterpret_cast<const float2 *>(d_iq), mu, Yf, mx, n, n_frames, c);
         pss_kernel_end(ctx);
         size_t total = (size_t)n_frames * n;
         size_t g = (total + TPB - 1) / TPB;
