@@ -117,13 +117,14 @@ float pss_o_cabsf(float re, float im)
     return mx * sqrtf(fmaf(r, r, 1.0f));
 }
 
-/* numpy add.reduce over contiguous float32: pairwise summation, block 128, 8 accumulators
- * (numpy/_core/src/umath/loops_utils.h.src @TYPE@_pairwise_sum).  Feeds np.mean at
- * signal_processing.py:185 and :327. */
-float pss_o_pairwise_sum_f32(const float *a, long n)
+/* numpy add.reduce over float32 (np.mean at signal_processing.py:185 and :327):
+ *  - the ufunc machinery hands the inner loop at most 8192 elements at a time (its buffer size) and adds the chunk
+ *    results up sequentially: sum = ((S(c0) + S(c1)) + S(c2)) + ...   (probed: tools/probe notes in DESIGN.md §2);
+ *  - inside a chunk: pairwise summation, block 128, 8 accumulators (numpy loops_utils.h.src @TYPE@_pairwise_sum). */
+static float pairwise_chunk_f32(const float *a, long n)
 {
     if (n < 8) {
-        float res = 0.0f; /* numpy starts from -0.0? it starts at 0. and adds; identical for our data */
+        float res = 0.0f;
         for (long i = 0; i < n; i++) res += a[i];
         return res;
     } else if (n <= 128) {
@@ -138,8 +139,17 @@ float pss_o_pairwise_sum_f32(const float *a, long n)
     } else {
         long n2 = n / 2;
         n2 -= n2 % 8;
-        return pss_o_pairwise_sum_f32(a, n2) + pss_o_pairwise_sum_f32(a + n2, n - n2);
+        return pairwise_chunk_f32(a, n2) + pairwise_chunk_f32(a + n2, n - n2);
     }
+}
+
+float pss_o_pairwise_sum_f32(const float *a, long n)
+{
+    const long B = 8192;
+    if (n <= B) return pairwise_chunk_f32(a, n);
+    float acc = pairwise_chunk_f32(a, B);
+    for (long st = B; st < n; st += B) acc += pairwise_chunk_f32(a + st, (n - st) < B ? (n - st) : B);
+    return acc;
 }
 
 float pss_o_log10f_ref(float x) { return (float)log10((double)x); }

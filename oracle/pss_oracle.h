@@ -24,7 +24,7 @@ extern "C" {
 float pss_o_rcp14f(float x);                 /* VRCP14PS, bit-exact model (64-entry piecewise-linear table) */
 float pss_o_atan2f(float y, float x);        /* numpy.arctan2 float32 == Intel SVML __svml_atan2f16 (la)     */
 float pss_o_cabsf(float re, float im);       /* numpy.abs(complex64)                                          */
-float pss_o_pairwise_sum_f32(const float *a, long n); /* numpy add.reduce float32 (pairwise, 8 accumulators) */
+float pss_o_pairwise_sum_f32(const float *a, long n); /* numpy add.reduce float32 (8192-element chunks, pairwise inside) */
 float pss_o_log10f_ref(float x);             /* float32 log10 via double (tolerance-checked, not bit-pinned) */
 
 /* ---- per-frame functions; iq = interleaved complex64 (I0,Q0,I1,Q1,...) ---- */

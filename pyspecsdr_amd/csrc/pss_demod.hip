@@ -335,8 +335,9 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------------
 // numpy float32 pairwise mean of |x| (KIND 1, AM: signal_processing.py:185) or |x|^2 (KIND 0, power: :327).
-// The reduction tree (block 128, 8 accumulators, halves rounded down to multiples of 8) is generated on
-// the host for the frame length and replayed level by level; one workgroup per frame.
+// The reduction tree (8192-element chunks added sequentially; inside a chunk: block 128, 8 accumulators, halves
+// rounded down to multiples of 8) is generated on the host for the frame length and replayed level by level; one
+// workgroup per frame.
 // ---------------------------------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(TPB) void k_pairwise(const float2 *__restrict__ iq, int n, long n_frames,
@@ -777,7 +778,21 @@ int get_plan(pss_ctx *ctx, int n, PssPairwisePlan **out)
     if (it == ctx->plans.end()) {
         std::vector<int> lo, ll, nl, nr, lev;
         int slot, level;
-        plan_rec(0, n, lo, ll, nl, nr, lev, slot, level);
+        // numpy hands its inner loop at most 8192 elements (the ufunc buffer size) and adds the chunk sums sequentially:
+        // sum = ((S(c0) + S(c1)) + S(c2)) + ...; inside a chunk the pairwise tree of plan_rec
+        {
+            const int B = 8192;
+            plan_rec(0, n < B ? n : B, lo, ll, nl, nr, lev, slot, level);
+            for (int st = B; st < n; st += B) {
+                int s2, l2;
+                plan_rec(st, (n - st) < B ? (n - st) : B, lo, ll, nl, nr, lev, s2, l2);
+                nl.push_back(slot);
+                nr.push_back(s2);
+                level = 1 + (level > l2 ? level : l2);
+                lev.push_back(level);
+                slot = -(int)nl.size();
+            }
+        }
         const int nleaf = (int)lo.size(), nnode = (int)nl.size();
         // order internal nodes by level; remap ids
         std::vector<int> order(nnode), newid(nnode), lstart(level + 2, 0);

@@ -151,7 +151,7 @@ def test_nfm_vs_oracle_random():
         assert np.array_equal(pcm[k], O.pcm16_stereo(a)), k
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_am_vs_golden_bit_exact(golden, tag):
     g = golden["am_ssb"]
     pcm, audio = G.demod(L.MODE_AM, g[f"am_iq_{tag}"], 2.4e6)
@@ -194,7 +194,7 @@ def test_am_ssb_ragged_vs_oracle():
         assert np.array_equal(pcm[k], O.pcm16_stereo(a)), k
 
 
-@pytest.mark.parametrize("n", [7, 100, 1024, 16384, 32768])
+@pytest.mark.parametrize("n", [7, 100, 1024, 16384, 20000, 32768, 40001])
 def test_power(golden, n):
     g = golden["power"]
     e = G.engine()

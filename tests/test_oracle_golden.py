@@ -82,7 +82,7 @@ def test_nfm_edges(golden):
     assert np.array_equal(O.pcm16_stereo(a), g["pcm_silence"])
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_am_bit_exact(golden, tag):
     g = golden["am_ssb"]
     sos = g["am_sos"]
@@ -109,7 +109,7 @@ def test_ssb(golden, tag):
         assert np.array_equal(O.pcm16_stereo(audio), g[f"ssb_pcm_{tag}"][k])
 
 
-@pytest.mark.parametrize("n", [7, 100, 1024, 16384, 32768])
+@pytest.mark.parametrize("n", [7, 100, 1024, 16384, 20000, 32768, 40001])
 def test_power(golden, n):
     g = golden["power"]
     iq = g[f"iq_{n}"]

@@ -202,7 +202,7 @@ def gen_nfm():
 
 def gen_am_ssb():
     d = {}
-    for tag, n, nf, seed in [("a", 1024, 3, 31), ("b", 16384, 1, 32), ("c", 300, 2, 33)]:
+    for tag, n, nf, seed in [("a", 1024, 3, 31), ("b", 16384, 1, 32), ("c", 300, 2, 33), ("d", 20000, 1, 34)]:
         iq = am_iq(nf, n, 2.4e6, seed)
         aud = np.stack([sp.demodulate_signal(f, 2.4e6, "AM") for f in iq])
         d[f"am_iq_{tag}"] = iq
@@ -232,7 +232,7 @@ def gen_am_ssb():
 def gen_power():
     d = {}
     frames, pw = [], []
-    for n, seed in [(1024, 51), (16384, 52), (32768, 53), (100, 54), (7, 55)]:
+    for n, seed in [(1024, 51), (16384, 52), (32768, 53), (100, 54), (7, 55), (20000, 56), (40001, 57)]:
         iq = fm_iq(1, n, 2.4e6, seed, amp=0.05 * (1 + seed % 3))[0]
         p = sp.measure_signal_power(iq)
         assert p.dtype == np.float32
