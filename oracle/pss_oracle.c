@@ -154,6 +154,90 @@ float pss_o_pairwise_sum_f32(const float *a, long n)
 
 float pss_o_log10f_ref(float x) { return (float)log10((double)x); }
 
+/* numpy add.reduce on complex64 (CFLOAT_pairwise_sum, loops_utils.h.src): the interleaved float array is summed
+ * with 8 accumulators (4 complex lanes), block 128 FLOATS, fold (r0+r2)+(r4+r6) / (r1+r3)+(r5+r7); the ufunc
+ * buffer hands over 8192 COMPLEX elements at a time and chunk sums are added sequentially. a = interleaved, n floats. */
+static void cpairwise_chunk_f32(const float *a, long n, float *rr, float *ri)
+{
+    if (n < 8) {
+        *rr = 0.0f; *ri = 0.0f;
+        for (long i = 0; i < n; i += 2) { *rr += a[i]; *ri += a[i + 1]; }
+    } else if (n <= 128) {
+        float r[8];
+        long i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        *rr = (r[0] + r[2]) + (r[4] + r[6]);
+        *ri = (r[1] + r[3]) + (r[5] + r[7]);
+        for (; i < n; i += 2) { *rr += a[i]; *ri += a[i + 1]; }
+    } else {
+        long n2 = n / 2;
+        n2 -= n2 % 8;
+        float ar, ai, br, bi;
+        cpairwise_chunk_f32(a, n2, &ar, &ai);
+        cpairwise_chunk_f32(a + n2, n - n2, &br, &bi);
+        *rr = ar + br; *ri = ai + bi;
+    }
+}
+static void csum_f32(const float *x, long n, float *rr, float *ri) /* n complex elements */
+{
+    const long B = 8192;
+    cpairwise_chunk_f32(x, 2 * (n < B ? n : B), rr, ri);
+    for (long st = B; st < n; st += B) {
+        float cr, ci;
+        cpairwise_chunk_f32(x + 2 * st, 2 * ((n - st) < B ? (n - st) : B), &cr, &ci);
+        *rr += cr; *ri += ci;
+    }
+}
+/* np.var(complex64 array) -> float32 (numpy _methods._var): mean = add.reduce / n (true_divide), x = arr - mean,
+ * x = (x * conj(x)).real  [AVX512F complex multiply: re = fma(xr, xr, xi*xi)], ret = add.reduce(x) / n. */
+static float var_c64(const float *z, long n, float *tmp)
+{
+    float sr, si;
+    csum_f32(z, n, &sr, &si);
+    const float mr = sr / (float)n, mi = si / (float)n;
+    for (long i = 0; i < n; i++) {
+        const float dr = z[2 * i] - mr, di = z[2 * i + 1] - mi;
+        tmp[i] = fmaf(dr, dr, di * di);
+    }
+    return pss_o_pairwise_sum_f32(tmp, n) / (float)n;
+}
+
+/* iq_correction — signal_processing.py:46-80, complex64 in, complex64 out, every step in float32 as NumPy 2.2
+ * evaluates it (NEP 50: the Python scalars 2, 1, 1j are weak; complex64 / float32-scalar multiplies by the
+ * reciprocal; complex64 * float32-scalar is a plain per-component multiply). */
+void pss_o_iq_correction(const float *iq, int n, float *out)
+{
+    float *c = (float *)malloc(sizeof(float) * 2 * (size_t)n), *t = (float *)malloc(sizeof(float) * (size_t)n);
+    float sr, si;
+    csum_f32(iq, n, &sr, &si);                                   /* :48 np.mean(samples) */
+    const float mr = sr / (float)n, mi = si / (float)n;
+    for (int i = 0; i < n; i++) { c[2 * i] = iq[2 * i] - mr; c[2 * i + 1] = iq[2 * i + 1] - mi; }
+    const float input_power = var_c64(c, n, t);                  /* :49 */
+    for (int i = 0; i < n; i++) t[i] = iq[2 * i + 1] * iq[2 * i + 1];
+    const float qa = sqrtf(2.0f * (pss_o_pairwise_sum_f32(t, n) / (float)n));   /* :52 */
+    const float scl = 1.0f / qa;                                 /* :55 samples / q_amplitude */
+    for (int i = 0; i < n; i++) { const float is = iq[2 * i] * scl; t[i] = is * is; }
+    const float alpha = sqrtf(2.0f * (pss_o_pairwise_sum_f32(t, n) / (float)n)); /* :60 */
+    for (int i = 0; i < n; i++) t[i] = (iq[2 * i] * scl) * (iq[2 * i + 1] * scl);
+    const float sinphi = (2.0f / alpha) * (pss_o_pairwise_sum_f32(t, n) / (float)n); /* :61 */
+    const float cosphi = sqrtf(1.0f - sinphi * sinphi);          /* :64 */
+    const float ia = 1.0f / alpha, qa2 = -sinphi / alpha, sc = 1.0f / cosphi;
+    for (int i = 0; i < n; i++) {                                /* :67-71 */
+        const float is = iq[2 * i] * scl, qs = iq[2 * i + 1] * scl;
+        const float i_new = ia * is, q_new = qa2 * is + qs;
+        /* i_new + 1j*q_new: (0+1j)*(q+0j) = (fma(0,q,-(1*0)), fma(0,0,1*q)); adding (i_new + 0j) normalises -0 */
+        const float jr = fmaf(0.0f, q_new, -0.0f), ji = fmaf(0.0f, 0.0f, q_new);
+        c[2 * i] = (i_new + jr) * sc;
+        c[2 * i + 1] = (0.0f + ji) * sc;
+    }
+    const float v2 = var_c64(c, n, t);                           /* :80 */
+    const float g = sqrtf(input_power / v2);
+    for (int i = 0; i < 2 * n; i++) out[i] = c[i] * g;
+    free(c); free(t);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * float64 FFT (iterative radix-2, table twiddles).  np.fft.fft is pocketfft; results agree to
  * ~1e-15 relative, the spectrum is tolerance-checked (north star: 1e-4 relative on dB).

@@ -38,6 +38,10 @@ float pss_o_power_db(const float *iq, int n);
 /* inline scanner slice — pyspecsdr.py:2542-2552 (float32 dB). Returns number of bins in the 20 dB mask. */
 int pss_o_scan_slice(const float *iq, int n, double fs, float *db, float *peak, double *bw);
 
+/* iq_correction — signal_processing.py:46-80 (DC removal, IQ amplitude/phase balance, power restore), float32
+ * throughout.  out[2n] interleaved complex64.  demodulate_signal(..., 'RAW') (:222-238) = real part of this. */
+void pss_o_iq_correction(const float *iq, int n, float *out);
+
 /* demodulate_nfm — signal_processing.py:91-116.
  * taps[65] = firwin(65, 15000/(fs/2)); sos[4][6] = cheby1(8,0.05,0.8/q,'sos'); zi[4][2] = sosfilt_zi(sos).
  * audio[n_out], n_out = ceil((n-1)/q).  Returns n_out, or -1 if n-1 <= 27 (sosfiltfilt padlen ValueError).

@@ -43,6 +43,7 @@ def lib():
         L.pss_o_pairwise_sum_f32.argtypes = [_f32p, C.c_long]
         L.pss_o_compute_fft.argtypes = [_f32p, C.c_int, _f64p]
         L.pss_o_postprocess.argtypes = [_f64p, C.c_int, _f64p]
+        L.pss_o_iq_correction.argtypes = [_f32p, C.c_int, _f32p]
         L.pss_o_power_db.restype = C.c_float
         L.pss_o_power_db.argtypes = [_f32p, C.c_int]
         L.pss_o_scan_slice.restype = C.c_int
@@ -86,6 +87,12 @@ def postprocess(db):
     db = np.ascontiguousarray(db, np.float64)
     out = np.empty(len(db) - 4, np.float64)
     lib().pss_o_postprocess(db, len(db), out)
+    return out
+
+
+def iq_correction(iq):
+    out = np.empty(len(iq), np.complex64)
+    lib().pss_o_iq_correction(_iq(iq), len(iq), out.view(np.float32))
     return out
 
 

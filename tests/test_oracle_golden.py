@@ -169,3 +169,15 @@ def test_raw_and_unknown_modes(golden):
     # RAW goes through iq_correction first (signal_processing.py:222-225): float32 (N,), not plain real()
     assert g["raw_out"].dtype == np.float32 and g["raw_out"].shape == (64,)
     assert g["unknown_out"].shape == (64, 2) and not g["unknown_out"].any()
+
+
+def test_iq_correction_bit_exact(golden):
+    """signal_processing.py:46-80 — every float32 bit of the corrected frame, incl. frames longer than numpy's
+    8192-element reduce buffer, odd lengths and 8-bit style samples with exact zeros."""
+    g = golden["iqcorr"]
+    for n in [int(v) for v in g["sizes"]] + ["u8"]:
+        got = O.iq_correction(g[f"iq_{n}"])
+        want = g[f"corr_{n}"]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), n
+        if n != "u8":
+            assert np.array_equal(got.real.view(np.uint32), g[f"raw_{n}"].view(np.uint32)), n

@@ -229,6 +229,34 @@ def gen_am_ssb():
     save("am_ssb", **d)
 
 
+def gen_iqcorr():
+    """iq_correction (signal_processing.py:46-80) + demodulate_signal(..., 'RAW') on frames of assorted lengths."""
+    d = {}
+    rng = np.random.default_rng(71)
+    sizes = [64, 1000, 1024, 4096, 10000, 16384, 32768, 40001]
+    for n in sizes:
+        # unbalanced IQ: DC offset, gain mismatch, phase skew — what the routine is meant to repair
+        i = rng.standard_normal(n) * 0.3 + 0.05
+        q = 0.8 * (rng.standard_normal(n) * 0.3 + 0.2 * i) - 0.02
+        x = (i + 1j * q).astype(np.complex64)
+        d[f"iq_{n}"] = x
+        d[f"corr_{n}"] = sp.iq_correction(x)
+        d[f"raw_{n}"] = sp.demodulate_signal(x, 2.4e6, "RAW")
+        assert d[f"corr_{n}"].dtype == np.complex64 and d[f"raw_{n}"].dtype == np.float32
+    # rtl-sdr style 8-bit samples (pyrtlsdr: (u8 - 127.5)/127.5), a tone plus noise, with exact zeros spliced in
+    n = 2048
+    u = rng.integers(0, 256, size=(n, 2)).astype(np.float64)
+    x = ((u[:, 0] - 127.5) / 127.5 + 1j * (u[:, 1] - 127.5) / 127.5).astype(np.complex64)
+    x[5] = 0
+    x[17] = complex(0.0, 0.25)
+    x[33] = complex(-0.5, 0.0)
+    x[40] = complex(-0.0, -0.0)
+    d["iq_u8"] = x
+    d["corr_u8"] = sp.iq_correction(x)
+    d["sizes"] = np.array(sizes)
+    save("iqcorr", **d)
+
+
 def gen_power():
     d = {}
     frames, pw = [], []
@@ -358,5 +386,6 @@ if __name__ == "__main__":
     gen_nfm()
     gen_am_ssb()
     gen_power()
+    gen_iqcorr()
     gen_scanner()
     gen_caller()
