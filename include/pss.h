@@ -82,6 +82,11 @@ int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft,
  * d_bw float64 [n], d_count int32 [n] (may be NULL). */
 int pss_scan(pss_ctx *ctx, const float *d_iq, long n_slices, int n_fft, double fs, float *d_db, float *d_peak,
              double *d_bw, int32_t *d_count);
+/* iq_correction — signal_processing.py:46-80, per frame: DC removal, IQ amplitude/phase balance, power restore; float32
+ * throughout, bit-identical to the reference on NumPy 2.2.  d_out_iq: complex64 [n_frames][n] (nullable);
+ * d_raw: float32 [n_frames][n] = real part = demodulate_signal(..., 'RAW') (signal_processing.py:222-238) (nullable). */
+int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out_iq, float *d_raw);
+
 /* measure_signal_power (signal_processing.py:325-328): float32 [n_frames]. */
 int pss_power_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_power);
 /* adjust_gain (pyspecsdr.py:898-919) run sequentially over a series of power readings:
@@ -130,6 +135,8 @@ int pss_h_compute_fft(pss_ctx *ctx, const float *h_iq, int n, double *h_db);
 int pss_h_demodulate(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,
                      int16_t *h_pcm);
 int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float *h_power);
+/* iq_correction(samples) / demodulate_signal(samples, fs, 'RAW') on one host frame; either output may be NULL. */
+int pss_h_iq_correction(pss_ctx *ctx, const float *h_iq, int n, float *h_out_iq, float *h_raw);
 
 /* ---- streamed capture (BASELINE.json configs[4]) -------------------------------------------------- */
 /* Pinned host memory for the streaming call (plain malloc'ed memory works too, but cannot overlap with compute). */

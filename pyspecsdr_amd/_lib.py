@@ -32,6 +32,7 @@ _SIGS = {
     "pss_spectrum_post": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
     "pss_scan": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p]),
     "pss_power_db": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
+    "pss_iq_correction": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p]),
     "pss_agc_steps": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_int, _p]),
     "pss_demod": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
     "pss_demod_out_len": (C.c_int, [C.c_int, C.c_int, C.c_double]),
@@ -49,6 +50,7 @@ _SIGS = {
     "pss_h_compute_fft": (C.c_int, [_p, _p, C.c_int, _p]),
     "pss_h_demodulate": (C.c_int, [_p, C.c_int, _p, C.c_int, C.c_double, _p, _p]),
     "pss_h_measure_power": (C.c_int, [_p, _p, C.c_int, _p]),
+    "pss_h_iq_correction": (C.c_int, [_p, _p, C.c_int, _p, _p]),
     "pss_host_alloc": (_p, [C.c_size_t]),
     "pss_host_free": (None, [_p]),
     "pss_h_stream_spectrum_nfm": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, C.c_long, _p, _p]),

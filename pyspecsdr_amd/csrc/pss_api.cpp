@@ -260,6 +260,25 @@ extern "C" int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float
     return PSS_OK;
 }
 
+extern "C" int pss_h_iq_correction(pss_ctx *ctx, const float *h_iq, int n, float *h_out_iq, float *h_raw)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!h_iq || (!h_out_iq && !h_raw) || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
+    const size_t o_c = up256(sizeof(float) * 2 * n), o_r = o_c + up256(sizeof(float) * 2 * n);
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_r + up256(sizeof(float) * n), "staging");
+    if (r) return r;
+    char *base = reinterpret_cast<char *>(ctx->stage);
+    PSS_HIP(ctx, hipMemcpyAsync(base, h_iq, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
+    r = pss_iq_correction(ctx, reinterpret_cast<const float *>(base), 1, n,
+                          h_out_iq ? reinterpret_cast<float *>(base + o_c) : nullptr,
+                          h_raw ? reinterpret_cast<float *>(base + o_r) : nullptr);
+    if (r) return r;
+    if (h_out_iq) PSS_HIP(ctx, hipMemcpyAsync(h_out_iq, base + o_c, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_raw) PSS_HIP(ctx, hipMemcpyAsync(h_raw, base + o_r, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSS_OK;
+}
+
 // ---- streamed capture --------------------------------------------------------------------------------
 extern "C" void *pss_host_alloc(size_t bytes)
 {

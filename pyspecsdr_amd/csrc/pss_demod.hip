@@ -734,6 +734,155 @@ __global__ __launch_bounds__(TPB) void k_finalize(const double *__restrict__ Yf,
     }
 }
 
+// ---- iq_correction (signal_processing.py:46-80) ------------------------------------------------------------------
+// One workgroup per frame.  The routine is a chain of eight float32 reductions whose results feed the next
+// elementwise step; each reduction walks numpy's own summation tree (PssPairwisePlan) so every intermediate scalar
+// has numpy's bits.  The frame (8 KB at n=1024) is re-read from L1/L2 per pass; intermediates are recomputed.
+struct PlanDev {
+    const int *leaf_off, *leaf_len, *node_l, *node_r, *level_start;
+    int n_leaves, n_levels;
+};
+#define IQC_TPB 256
+template <class F>
+__device__ __forceinline__ float wg_rsum(const PlanDev &p, float *val, F elem)
+{
+    const int tid = threadIdx.x;
+    for (int l = tid; l < p.n_leaves; l += IQC_TPB) {
+        const int off = p.leaf_off[l], len = p.leaf_len[l];
+        float res;
+        if (len < 8) {
+            res = 0.0f;
+            for (int i = 0; i < len; i++) res = __fadd_rn(res, elem(off + i));
+        } else {
+            float r[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) r[k] = elem(off + k);
+            int i;
+            for (i = 8; i < len - (len % 8); i += 8) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) r[k] = __fadd_rn(r[k], elem(off + i + k));
+            }
+            res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                            __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+            for (; i < len; i++) res = __fadd_rn(res, elem(off + i));
+        }
+        val[l] = res;
+    }
+    __syncthreads();
+    for (int lv = 0; lv < p.n_levels; lv++) {
+        for (int k = p.level_start[lv] + tid; k < p.level_start[lv + 1]; k += IQC_TPB)
+            val[p.n_leaves + k] = __fadd_rn(val[p.node_l[k]], val[p.node_r[k]]);
+        __syncthreads();
+    }
+    const int nn = p.level_start[p.n_levels];
+    const float sum = nn ? val[p.n_leaves + nn - 1] : val[0];
+    __syncthreads();
+    return sum;
+}
+// complex64 reduce: elem(ci) -> float2 of complex element ci; leaves are float ranges of the interleaved array
+template <class F>
+__device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *val, F elem)
+{
+    const int tid = threadIdx.x;
+    for (int l = tid; l < p.n_leaves; l += IQC_TPB) {
+        const int off = p.leaf_off[l] >> 1, len = p.leaf_len[l];  // off in complex elements, len in floats
+        float rr, ri;
+        if (len < 8) {
+            rr = 0.0f; ri = 0.0f;
+            for (int i = 0; i < len; i += 2) { float2 v = elem(off + (i >> 1)); rr = __fadd_rn(rr, v.x); ri = __fadd_rn(ri, v.y); }
+        } else {
+            float2 r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = elem(off + k);
+            int i;
+            for (i = 8; i < len - (len % 8); i += 8) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float2 v = elem(off + (i >> 1) + k);
+                    r[k].x = __fadd_rn(r[k].x, v.x);
+                    r[k].y = __fadd_rn(r[k].y, v.y);
+                }
+            }
+            rr = __fadd_rn(__fadd_rn(r[0].x, r[1].x), __fadd_rn(r[2].x, r[3].x));
+            ri = __fadd_rn(__fadd_rn(r[0].y, r[1].y), __fadd_rn(r[2].y, r[3].y));
+            for (; i < len; i += 2) { float2 v = elem(off + (i >> 1)); rr = __fadd_rn(rr, v.x); ri = __fadd_rn(ri, v.y); }
+        }
+        val[l] = make_float2(rr, ri);
+    }
+    __syncthreads();
+    for (int lv = 0; lv < p.n_levels; lv++) {
+        for (int k = p.level_start[lv] + tid; k < p.level_start[lv + 1]; k += IQC_TPB) {
+            const float2 a = val[p.node_l[k]], b = val[p.node_r[k]];
+            val[p.n_leaves + k] = make_float2(__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y));
+        }
+        __syncthreads();
+    }
+    const int nn = p.level_start[p.n_levels];
+    const float2 sum = nn ? val[p.n_leaves + nn - 1] : val[0];
+    __syncthreads();
+    return sum;
+}
+
+__global__ __launch_bounds__(IQC_TPB) void k_iqcorr(const float2 *__restrict__ iq, int n, long n_frames, PlanDev rp,
+                                                    PlanDev cp, float2 *__restrict__ out, float *__restrict__ raw)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *rval = reinterpret_cast<float *>(smem);
+    float2 *cval = reinterpret_cast<float2 *>(smem);
+    const float fn = (float)n;
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const float2 *x = iq + (size_t)f * n;
+        // :48 centered = samples - mean(samples)
+        float2 s = wg_csum(cp, cval, [&](int i) { return x[i]; });
+        const float mr = __fdiv_rn(s.x, fn), mi = __fdiv_rn(s.y, fn);
+        // :49 input_power = var(centered): mean again, |.|^2 with the FMA form of numpy's complex multiply, mean
+        s = wg_csum(cp, cval, [&](int i) { float2 v = x[i]; return make_float2(__fsub_rn(v.x, mr), __fsub_rn(v.y, mi)); });
+        const float m2r = __fdiv_rn(s.x, fn), m2i = __fdiv_rn(s.y, fn);
+        const float input_power = __fdiv_rn(wg_rsum(rp, rval, [&](int i) {
+            float2 v = x[i];
+            const float dr = __fsub_rn(__fsub_rn(v.x, mr), m2r), di = __fsub_rn(__fsub_rn(v.y, mi), m2i);
+            return __fmaf_rn(dr, dr, __fmul_rn(di, di));
+        }), fn);
+        // :52 q_amplitude
+        const float qa = sqrtf(__fmul_rn(2.0f, __fdiv_rn(wg_rsum(rp, rval, [&](int i) { float q = x[i].y; return __fmul_rn(q, q); }), fn)));
+        const float scl = __fdiv_rn(1.0f, qa);  // :55 complex64 / float32 scalar multiplies by the reciprocal
+        // :60-61 alpha, sin(phi)
+        const float alpha = sqrtf(__fmul_rn(2.0f, __fdiv_rn(wg_rsum(rp, rval, [&](int i) {
+            const float is = __fmul_rn(x[i].x, scl);
+            return __fmul_rn(is, is);
+        }), fn)));
+        const float sinphi = __fmul_rn(__fdiv_rn(2.0f, alpha), __fdiv_rn(wg_rsum(rp, rval, [&](int i) {
+            float2 v = x[i];
+            return __fmul_rn(__fmul_rn(v.x, scl), __fmul_rn(v.y, scl));
+        }), fn));
+        const float cosphi = sqrtf(__fsub_rn(1.0f, __fmul_rn(sinphi, sinphi)));  // :64
+        const float ia = __fdiv_rn(1.0f, alpha), qa2 = __fdiv_rn(-sinphi, alpha), sc = __fdiv_rn(1.0f, cosphi);
+        auto corrected = [&](int i) {  // :67-71 (the 1j*q_new complex multiply only touches the sign of zeros)
+            float2 v = x[i];
+            const float is = __fmul_rn(v.x, scl), qs = __fmul_rn(v.y, scl);
+            const float i_new = __fmul_rn(ia, is), q_new = __fadd_rn(__fmul_rn(qa2, is), qs);
+            const float jr = __fmaf_rn(0.0f, q_new, -0.0f), ji = __fmaf_rn(0.0f, 0.0f, q_new);
+            return make_float2(__fmul_rn(__fadd_rn(i_new, jr), sc), __fmul_rn(__fadd_rn(0.0f, ji), sc));
+        };
+        // :80 var(corrected), rescale to the input power
+        s = wg_csum(cp, cval, corrected);
+        const float m3r = __fdiv_rn(s.x, fn), m3i = __fdiv_rn(s.y, fn);
+        const float v2 = __fdiv_rn(wg_rsum(rp, rval, [&](int i) {
+            float2 c = corrected(i);
+            const float dr = __fsub_rn(c.x, m3r), di = __fsub_rn(c.y, m3i);
+            return __fmaf_rn(dr, dr, __fmul_rn(di, di));
+        }), fn);
+        const float g = sqrtf(__fdiv_rn(input_power, v2));
+        for (int i = threadIdx.x; i < n; i += IQC_TPB) {
+            float2 c = corrected(i);
+            c.x = __fmul_rn(c.x, g);
+            c.y = __fmul_rn(c.y, g);
+            if (out) out[(size_t)f * n + i] = c;
+            if (raw) raw[(size_t)f * n + i] = c.x;  // demodulate_signal(..., 'RAW'): np.real(samples) (:238)
+        }
+    }
+}
+
 // adjust_gain (pyspecsdr.py:898-919), sequential by nature.
 __global__ void k_agc(const float *__restrict__ power, long n, int idx, int n_gains, int *__restrict__ out)
 {
@@ -772,16 +921,20 @@ void plan_rec(int off, int n, std::vector<int> &lo, std::vector<int> &ll, std::v
     slot = -(int)nl.size();  // internal node id k encoded as -(k+1)
 }
 
-int get_plan(pss_ctx *ctx, int n, PssPairwisePlan **out)
+// cplx: the tree numpy walks for a complex64 reduce — same recursion over the 2n interleaved FLOATS, chunks of 8192
+// complex elements; leaf offsets/lengths are then in floats (always even).  Stored under key -n.
+int get_plan(pss_ctx *ctx, int n_elems, PssPairwisePlan **out, bool cplx = false)
 {
-    auto it = ctx->plans.find(n);
+    const int key = cplx ? -n_elems : n_elems;
+    const int n = cplx ? 2 * n_elems : n_elems;
+    auto it = ctx->plans.find(key);
     if (it == ctx->plans.end()) {
         std::vector<int> lo, ll, nl, nr, lev;
         int slot, level;
         // numpy hands its inner loop at most 8192 elements (the ufunc buffer size) and adds the chunk sums sequentially:
         // sum = ((S(c0) + S(c1)) + S(c2)) + ...; inside a chunk the pairwise tree of plan_rec
         {
-            const int B = 8192;
+            const int B = cplx ? 16384 : 8192;
             plan_rec(0, n < B ? n : B, lo, ll, nl, nr, lev, slot, level);
             for (int st = B; st < n; st += B) {
                 int s2, l2;
@@ -818,9 +971,9 @@ int get_plan(pss_ctx *ctx, int n, PssPairwisePlan **out)
         PSS_HIP(ctx, hipMemcpy(p.d_node_l, L.data(), sizeof(int) * L.size(), hipMemcpyHostToDevice));
         PSS_HIP(ctx, hipMemcpy(p.d_node_r, R.data(), sizeof(int) * R.size(), hipMemcpyHostToDevice));
         PSS_HIP(ctx, hipMemcpy(p.d_level_start, lstart.data(), sizeof(int) * (level + 1), hipMemcpyHostToDevice));
-        ctx->plans[n] = p;
+        ctx->plans[key] = p;
     }
-    *out = &ctx->plans[n];
+    *out = &ctx->plans[key];
     return PSS_OK;
 }
 
@@ -897,6 +1050,33 @@ extern "C" int pss_demod_out_len(int mode, int n, double fs)
     }
     if (mode == PSS_MODE_AM || mode == PSS_MODE_USB || mode == PSS_MODE_LSB) return n;
     return PSS_E_ARG;
+}
+
+extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out_iq, float *d_raw)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!d_iq || n_frames < 0 || n <= 0 || (!d_out_iq && !d_raw)) return pss_fail(ctx, PSS_E_ARG, "pss_iq_correction: bad argument");
+    if (n_frames == 0) return PSS_OK;
+    PssPairwisePlan *rp, *cp;
+    int r = get_plan(ctx, n, &rp);
+    if (r) return r;
+    r = get_plan(ctx, n, &cp, true);
+    if (r) return r;
+    size_t l1 = sizeof(float) * (size_t)(rp->n_leaves + rp->n_nodes + 1);
+    size_t l2 = sizeof(float2) * (size_t)(cp->n_leaves + cp->n_nodes + 1);
+    size_t lds = l1 > l2 ? l1 : l2;
+    if (lds > 150 * 1024) return pss_fail(ctx, PSS_E_ARG, "frame too long for the iq_correction kernel");
+    if (lds > 64 * 1024)
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_iqcorr), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+    PlanDev a{rp->d_leaf_off, rp->d_leaf_len, rp->d_node_l, rp->d_node_r, rp->d_level_start, rp->n_leaves, rp->n_levels};
+    PlanDev b{cp->d_leaf_off, cp->d_leaf_len, cp->d_node_l, cp->d_node_r, cp->d_level_start, cp->n_leaves, cp->n_levels};
+    long g = n_frames < 16384 ? n_frames : 16384;
+    pss_kernel_begin(ctx, "k_iqcorr");
+    hipLaunchKernelGGL(k_iqcorr, dim3((int)g), dim3(IQC_TPB), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n,
+                       n_frames, a, b, reinterpret_cast<float2 *>(d_out_iq), d_raw);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_iqcorr launch");
 }
 
 extern "C" int pss_power_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_power)

@@ -122,6 +122,9 @@ class Engine:
     def power_db(self, d_iq, n_frames, n, d_power):
         self._ck(self.lib.pss_power_db(self.h, _ptr(d_iq), n_frames, n, _ptr(d_power)))
 
+    def iq_correction(self, d_iq, n_frames, n, d_out_iq=None, d_raw=None):
+        self._ck(self.lib.pss_iq_correction(self.h, _ptr(d_iq), n_frames, n, _ptr(d_out_iq), _ptr(d_raw)))
+
     def agc_steps(self, d_power, n, start_idx, n_gains, d_idx):
         self._ck(self.lib.pss_agc_steps(self.h, _ptr(d_power), n, start_idx, n_gains, _ptr(d_idx)))
 
@@ -206,6 +209,18 @@ class Engine:
         pcm = np.empty((n_out, 2), np.int16)
         self._ck(self.lib.pss_h_demodulate(self.h, mode, _ptr(iq), len(iq), float(fs), _ptr(audio), _ptr(pcm)))
         return audio, pcm
+
+    def h_iq_correction(self, iq):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        out = np.empty(len(iq), np.complex64)
+        self._ck(self.lib.pss_h_iq_correction(self.h, _ptr(iq), len(iq), _ptr(out), None))
+        return out
+
+    def h_raw(self, iq):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        raw = np.empty(len(iq), np.float32)
+        self._ck(self.lib.pss_h_iq_correction(self.h, _ptr(iq), len(iq), None, _ptr(raw)))
+        return raw
 
     def h_measure_power(self, iq):
         iq = np.ascontiguousarray(iq, np.complex64)

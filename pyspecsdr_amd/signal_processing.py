@@ -11,9 +11,11 @@ the reference's main loop imports with `from signal_processing import *` (pyspec
     measure_signal_power(samples)                          :325-328  -> np.float32
     mono_to_stereo(mono_audio)                             :83-88
 
-Every call runs on the GPU through the C ABI; there is no NumPy/SciPy compute path here.  WFM / RAW (which
-go through iq_correction, :222-225) and classify_signal (broken in the reference) are not
-part of the accelerated path and raise NotImplementedError.
+    iq_correction(samples)                                 :46-80    -> complex64 (N,)  ('RAW' mode = its real part)
+
+Every call runs on the GPU through the C ABI; there is no NumPy/SciPy compute path here.  WFM (:119-176) and
+classify_signal (broken in the reference) are not part of the accelerated path and raise
+NotImplementedError.
 """
 import numpy as np
 
@@ -47,6 +49,11 @@ def mono_to_stereo(mono_audio):
     return stereo_audio
 
 
+def iq_correction(samples):
+    """signal_processing.py:46-80 -> complex64 (N,)."""
+    return get_engine().h_iq_correction(_samples(samples))
+
+
 def compute_fft(samples):
     return get_engine().h_compute_fft(_samples(samples))
 
@@ -77,8 +84,11 @@ def demodulate_signal(samples, sample_rate, mode='NFM'):
         return demodulate_ssb(samples, sample_rate, lower=False)
     elif mode == 'LSB':
         return demodulate_ssb(samples, sample_rate, lower=True)
-    elif mode in ('WFM', 'RAW'):
-        raise NotImplementedError(f"mode {mode!r} (iq_correction path) is outside the accelerated hot path")
+    elif mode == 'RAW':
+        # :222-225 + :238 — every non-voice mode is IQ-corrected first; RAW then returns the I samples (float32)
+        return get_engine().h_raw(_samples(samples))
+    elif mode == 'WFM':
+        raise NotImplementedError("mode 'WFM' (stereo/RDS chain, signal_processing.py:119-176) is not accelerated yet")
     return np.zeros((len(samples), 2))  # unknown mode -> silence of shape (n, 2), as the reference
 
 

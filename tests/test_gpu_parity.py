@@ -207,6 +207,43 @@ def test_power(golden, n):
     assert abs(p - float(O.power_db(iq))) <= 4e-6 * max(1.0, abs(p))
 
 
+def test_iq_correction_and_raw_bit_exact(golden):
+    """signal_processing.py:46-80 and the RAW mode of demodulate_signal (:222-238): every float32 bit."""
+    g = golden["iqcorr"]
+    e = G.engine()
+    for n in [int(v) for v in g["sizes"]] + ["u8"]:
+        iq, want = g[f"iq_{n}"], g[f"corr_{n}"]
+        m = len(iq)
+        d_out, d_raw = G.empty((m, 2), torch.float32), G.empty((m,), torch.float32)
+        e.iq_correction(G.dev(iq), 1, m, d_out, d_raw)
+        e.sync()
+        got = G.host(d_out).reshape(-1).view(np.complex64)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), n
+        assert np.array_equal(G.host(d_raw).view(np.uint32), want.real.copy().view(np.uint32)), n
+    import pyspecsdr_amd.signal_processing as sp
+    raw = sp.demodulate_signal(g["iq_1000"], 2.4e6, "RAW")
+    assert raw.dtype == np.float32 and np.array_equal(raw.view(np.uint32), g["raw_1000"].view(np.uint32))
+    c = sp.iq_correction(g["iq_4096"])
+    assert c.dtype == np.complex64 and np.array_equal(c.view(np.uint32), g["corr_4096"].view(np.uint32))
+
+
+def test_iq_correction_batch_vs_oracle():
+    rng = np.random.default_rng(808)
+    e = G.engine()
+    for nf, n in [(300, 1024), (5, 9000), (40000, 256), (3, 77)]:
+        iq = ((rng.standard_normal((nf, n)) * 0.3 + 0.04) + 1j * (rng.standard_normal((nf, n)) * 0.2 - 0.03)).astype(np.complex64)
+        d_out = G.empty((nf, n, 2), torch.float32)
+        e.iq_correction(G.dev(iq), nf, n, d_out, None)
+        e.sync()
+        got = G.host(d_out).reshape(nf, -1).view(np.complex64)
+        for f in list(range(min(nf, 40))) + [nf - 1]:
+            assert np.array_equal(got[f].view(np.uint32), O.iq_correction(iq[f]).view(np.uint32)), (nf, n, f)
+        # property at batch size: the output power equals the (DC-removed) input power, and the I/Q imbalance is gone
+        c = got.astype(np.complex128)
+        assert np.allclose(np.var(c, axis=1), np.var(iq.astype(np.complex128), axis=1), rtol=2e-5)
+        assert np.all(np.abs(np.mean(c.real * c.imag, axis=1)) < 1e-6 * n ** 0.5 + 2e-7)
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()
