@@ -537,6 +537,110 @@ void pss_o_demod_am(const float *iq, int n, const double *sos, int nsec, double 
     free(e);
 }
 
+/* scipy.signal.lfilter(b=[b0], a=[1, a1], x) — _sigtools._linear_filter (lfilter.c.in, double loop), b zero-padded
+ * to [b0, 0], zero initial state:  y = z + b0*x;  z = x*0 - y*a1  (un-fused).  In place. */
+static void lfilter_1pole(double b0, double a1, double *x, long n)
+{
+    double z = 0.0;
+    for (long i = 0; i < n; i++) {
+        const double xi = x[i], y = z + b0 * xi;
+        z = (xi * 0.0) - (y * a1);
+        x[i] = y;
+    }
+}
+
+/* scipy.signal.decimate(u, q, zero_phase=True) (_signaltools.py: cheby1(8, 0.05, 0.8/q) -> sosfiltfilt -> [::q]).
+ * Same restatement as inside pss_o_demod_nfm.  out[ceil(M/q)]. */
+static int decimate_zero_phase(const double *u, long M, int q, const double *sos, const double *zi, double *out)
+{
+    const int NSEC = 4, EDGE = 27;
+    long L = M + 2 * EDGE;
+    double *ext = (double *)malloc(sizeof(double) * L);
+    for (int i = 0; i < EDGE; i++) ext[i] = 2.0 * u[0] - u[EDGE - i];
+    memcpy(ext + EDGE, u, sizeof(double) * M);
+    for (int i = 0; i < EDGE; i++) ext[EDGE + M + i] = 2.0 * u[M - 1] - u[M - 2 - i];
+    double z[8];
+    for (int i = 0; i < 2 * NSEC; i++) z[i] = zi[i] * ext[0];
+    sosfilt_inplace(sos, NSEC, ext, L, z);
+    for (long i = 0; i < L / 2; i++) { double t = ext[i]; ext[i] = ext[L - 1 - i]; ext[L - 1 - i] = t; }
+    for (int i = 0; i < 2 * NSEC; i++) z[i] = zi[i] * ext[0];
+    sosfilt_inplace(sos, NSEC, ext, L, z);
+    for (long i = 0; i < L / 2; i++) { double t = ext[i]; ext[i] = ext[L - 1 - i]; ext[L - 1 - i] = t; }
+    int n_out = (int)((M + q - 1) / q);
+    for (int j = 0; j < n_out; j++) out[j] = ext[EDGE + (long)j * q];
+    free(ext);
+    return n_out;
+}
+
+static double max_abs_np(const double *a, long n) /* np.max(np.abs(a)): NaN propagates */
+{
+    double mx = 0.0;
+    int has_nan = 0;
+    for (long i = 0; i < n; i++) { double v = fabs(a[i]); if (v != v) has_nan = 1; if (v > mx) mx = v; }
+    return has_nan ? NAN : mx;
+}
+
+/* demodulate_wfm — signal_processing.py:119-176 (the RDS hooks at :165-174 call undefined names and are swallowed by
+ * the try/except).  The "pilot" the reference extracts is sin(unwrap(angle(REAL signal))): the angle
+ * of a real float64 is 0 or pi, unwrap leaves that sequence untouched (every jump is exactly +-pi, ph_correct = 0),
+ * so pilot[i] is 0.0 or sin(pi) = 0x1.1a62633145c07p-53 and the L-R branch only perturbs the last bits of L and R.
+ * It is restated in full all the same, so that those last bits match. */
+int pss_o_demod_wfm(const float *iq, int n, int q, const double *lp_sos, const double *pilot_sos,
+                    const double *lmr_sos, double alpha, const double *dec_sos, const double *dec_zi, double *left,
+                    double *right)
+{
+    const double SIN_PI = 0x1.1a62633145c07p-53; /* np.sin(np.pi) */
+    long M = (long)n - 1;
+    if (M < 1) return -1;                  /* np.max of an empty array: ValueError */
+    if (q > 1 && M <= 27) return -1;       /* sosfiltfilt padlen ValueError */
+    double *d = (double *)malloc(sizeof(double) * M), *lpr = (double *)malloc(sizeof(double) * M);
+    double *pil = (double *)malloc(sizeof(double) * M), *lmr = (double *)malloc(sizeof(double) * M);
+    int swapped = (M * 8 >= 262144);       /* as in pss_o_demod_nfm (:122 is the same expression as :94) */
+    for (long i = 0; i < M; i++) {
+        float aI = iq[2 * (i + 1)], aQ = iq[2 * (i + 1) + 1];
+        float c = iq[2 * i], dd = -iq[2 * i + 1];
+        float re = fmaf(aI, c, -(aQ * dd));
+        float im = swapped ? fmaf(aQ, c, aI * dd) : fmaf(aI, dd, aQ * c);
+        d[i] = (double)pss_o_atan2f(im, re);                     /* :122, float32 -> float64 inside sosfilt */
+    }
+    double z[16];
+    memcpy(lpr, d, sizeof(double) * M); memset(z, 0, sizeof z);
+    sosfilt_inplace(lp_sos, 3, lpr, M, z);                       /* :126 */
+    memcpy(pil, d, sizeof(double) * M); memset(z, 0, sizeof z);
+    sosfilt_inplace(pilot_sos, 5, pil, M, z);                    /* :129 */
+    lfilter_1pole(1.0, -0.99, pil, M);                           /* :130 lfilter([1], [1, -0.99], pilot) */
+    memcpy(lmr, d, sizeof(double) * M); memset(z, 0, sizeof z);
+    sosfilt_inplace(lmr_sos, 5, lmr, M, z);                      /* :133 */
+    for (long i = 0; i < M; i++) {
+        const double y = pil[i];
+        const double p = (y != y) ? NAN : ((y < 0.0 || (y == 0.0 && signbit(y))) ? SIN_PI : 0.0);
+        lmr[i] = lmr[i] * (2.0 * p);                             /* :134 */
+    }
+    memset(z, 0, sizeof z);
+    sosfilt_inplace(lp_sos, 3, lmr, M, z);                       /* :137 */
+    for (long i = 0; i < M; i++) {                               /* :140-141 */
+        const double a = lpr[i], b = lmr[i];
+        lpr[i] = (a + b) / 2.0;
+        lmr[i] = (a - b) / 2.0;
+    }
+    lfilter_1pole(1.0 - alpha, -alpha, lpr, M);                  /* :144-149 de-emphasis */
+    lfilter_1pole(1.0 - alpha, -alpha, lmr, M);
+    int n_out;
+    if (q > 1) {                                                 /* :152-155 */
+        n_out = decimate_zero_phase(lpr, M, q, dec_sos, dec_zi, left);
+        decimate_zero_phase(lmr, M, q, dec_sos, dec_zi, right);
+    } else {
+        n_out = (int)M;
+        memcpy(left, lpr, sizeof(double) * M);
+        memcpy(right, lmr, sizeof(double) * M);
+    }
+    const double ml = max_abs_np(left, n_out), mr = max_abs_np(right, n_out);
+    const double mx = (mr > ml) ? mr : ml;                       /* :158 python max(a, b): b only if b > a */
+    for (int j = 0; j < n_out; j++) { left[j] /= mx; right[j] /= mx; }
+    free(d); free(lpr); free(pil); free(lmr);
+    return n_out;
+}
+
 /* demodulate_ssb — signal_processing.py:198-217 (USB and LSB branches are the same code) */
 void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio)
 {

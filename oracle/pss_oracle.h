@@ -53,6 +53,13 @@ void pss_o_demod_am(const float *iq, int n, const double *sos, int nsec, double 
 /* demodulate_ssb — signal_processing.py:198-217. taps[65] = firwin(65, 3000/fs). audio[n].
  * hilbert(real(z)).real is restated as real(z) (identity up to 1e-15 round-off). */
 void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio);
+/* demodulate_wfm — signal_processing.py:119-176 (called on iq_correction()'s output, :222-228).
+ * lp_sos[3][6] = butter(5, 15000/(fs/2), 'low'); pilot_sos[5][6] = butter(5, [18800, 19200]/(fs/2), 'band');
+ * lmr_sos[5][6] = butter(5, [23000, 53000]/(fs/2), 'band'); alpha = exp(-1/(75e-6 fs)); dec_sos/dec_zi as for NFM;
+ * q = int(fs/22050).  left/right[n_out].  Returns n_out, or -1 where the reference raises ValueError. */
+int pss_o_demod_wfm(const float *iq, int n, int q, const double *lp_sos, const double *pilot_sos,
+                    const double *lmr_sos, double alpha, const double *dec_sos, const double *dec_zi, double *left,
+                    double *right);
 /* int16 conversion — io_manager.py:25-26 / audio_processing.py:37: np.int16(x*32767), stereo dup
  * (mono_to_stereo signal_processing.py:83-88). pcm[2*n] = L0 R0 L1 R1 ... */
 void pss_o_pcm16_stereo(const double *audio, int n, int16_t *pcm);

@@ -44,6 +44,7 @@ def lib():
         L.pss_o_compute_fft.argtypes = [_f32p, C.c_int, _f64p]
         L.pss_o_postprocess.argtypes = [_f64p, C.c_int, _f64p]
         L.pss_o_iq_correction.argtypes = [_f32p, C.c_int, _f32p]
+        L.pss_o_demod_wfm.argtypes = [_f32p, C.c_int, C.c_int, _f64p, _f64p, _f64p, C.c_double, _f64p, _f64p, _f64p, _f64p]
         L.pss_o_power_db.restype = C.c_float
         L.pss_o_power_db.argtypes = [_f32p, C.c_int]
         L.pss_o_scan_slice.restype = C.c_int
@@ -94,6 +95,20 @@ def iq_correction(iq):
     out = np.empty(len(iq), np.complex64)
     lib().pss_o_iq_correction(_iq(iq), len(iq), out.view(np.float32))
     return out
+
+
+def demod_wfm(iq, fs, filt):
+    """filt: dict with lp_sos, pilot_sos, lmr_sos, alpha, dec_sos, dec_zi.  Returns (n_out, 2) float64 or None (ValueError)."""
+    n = len(iq)
+    q = int(fs / 22050)
+    cap = max(n, 1)
+    left, right = np.empty(cap), np.empty(cap)
+    c = lambda a: np.ascontiguousarray(a, np.float64)
+    r = lib().pss_o_demod_wfm(_iq(iq), n, q, c(filt["lp_sos"]), c(filt["pilot_sos"]), c(filt["lmr_sos"]),
+                              float(filt["alpha"]), c(filt["dec_sos"]), c(filt["dec_zi"]), left, right)
+    if r < 0:
+        return None
+    return np.stack([left[:r], right[:r]], axis=1)
 
 
 def power_db(iq):

@@ -181,3 +181,24 @@ def test_iq_correction_bit_exact(golden):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), n
         if n != "u8":
             assert np.array_equal(got.real.view(np.uint32), g[f"raw_{n}"].view(np.uint32)), n
+
+
+def wfm_filters(g, fs):
+    key = str(int(fs))
+    return {k: g[f"{k}_{key}"] for k in ("lp_sos", "pilot_sos", "lmr_sos", "alpha", "dec_sos", "dec_zi")}
+
+
+def test_wfm_bit_exact(golden):
+    """demodulate_signal(..., 'WFM') = iq_correction + demodulate_wfm (signal_processing.py:119-176): float64 audio
+    bit for bit (both channels — they differ in the last bits at low sample rates), hence int16 too."""
+    g = golden["wfm"]
+    assert float(g["sin_pi"]) == float.fromhex("0x1.1a62633145c07p-53")
+    for tag in g["tags"]:
+        fs = float(g[f"fs_{tag}"])
+        filt = wfm_filters(g, fs)
+        for f, iq in enumerate(g[f"iq_{tag}"]):
+            a = O.demod_wfm(O.iq_correction(iq), fs, filt)
+            want = g[f"audio_{tag}"][f]
+            assert a.shape == want.shape, tag
+            assert np.array_equal(a.view(np.uint64), want.view(np.uint64)), (tag, f, np.abs(a - want).max())
+            assert np.array_equal(np.int16(a * 32767), g[f"pcm_{tag}"][f])

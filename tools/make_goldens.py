@@ -257,6 +257,54 @@ def gen_iqcorr():
     save("iqcorr", **d)
 
 
+def wfm_iq(n_frames, n, fs, seed, sigma=0.01):
+    """Stereo-multiplexed broadcast FM: L+R, 19 kHz pilot, (L-R) on 38 kHz, 75 kHz deviation, mild IQ imbalance."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / fs
+    out = np.empty((n_frames, n), np.complex64)
+    for f in range(n_frames):
+        l = np.sin(2 * np.pi * (1000 + 50 * f) * t)
+        r = np.sin(2 * np.pi * 3000 * t + 0.3)
+        mpx = 0.45 * (l + r) + 0.1 * np.sin(2 * np.pi * 19000 * t) + 0.45 * (l - r) * np.sin(2 * np.pi * 38000 * t)
+        ph = 2 * np.pi * 75000 * np.cumsum(mpx) / fs + rng.uniform(0, 6.28)
+        x = 0.5 * np.exp(1j * ph) + sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        x = x.real * 1.05 + 0.01 + 1j * (x.imag * 0.97 + 0.03 * x.real - 0.02)
+        out[f] = x.astype(np.complex64)
+    return out
+
+
+def gen_wfm():
+    """demodulate_signal(..., 'WFM') = iq_correction (:46-80) + demodulate_wfm (:119-176), plus its filter sets."""
+    d = {}
+    tags = []
+    for tag, n, fs, nf, seed in [("a", 1024, 2.4e6, 4, 81), ("b", 16384, 2.4e6, 1, 82), ("c", 4096, 1.024e6, 2, 83),
+                                 ("d", 8192, 250e3, 1, 84), ("e", 2048, 2.048e6, 2, 85), ("f", 29, 2.4e6, 1, 86),
+                                 ("g", 40000, 2.4e6, 1, 87)]:
+        iq = wfm_iq(nf, n, fs, seed)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            aud = np.stack([sp.demodulate_signal(f, fs, "WFM") for f in iq])  # (nf, n_out, 2)
+        assert aud.dtype == np.float64
+        d[f"iq_{tag}"] = iq
+        d[f"fs_{tag}"] = np.array(fs)
+        d[f"audio_{tag}"] = aud
+        d[f"pcm_{tag}"] = np.int16(aud * 32767)
+        tags.append(tag)
+    d["tags"] = np.array(tags)
+    for fs in (1.024e6, 2.4e6, 2.048e6, 250e3, 10e6):
+        key = f"{int(fs)}"
+        q = int(fs / 22050)
+        d["lp_sos_" + key] = ss.butter(5, 15000 / (fs / 2), btype="low", output="sos")
+        d["pilot_sos_" + key] = ss.butter(5, [18800 / (fs / 2), 19200 / (fs / 2)], btype="band", output="sos")
+        d["lmr_sos_" + key] = ss.butter(5, [23000 / (fs / 2), 53000 / (fs / 2)], btype="band", output="sos")
+        d["alpha_" + key] = np.array(np.exp(-1 / (75e-6 * fs)))
+        sos = ss.cheby1(8, 0.05, 0.8 / q, output="sos")
+        d["dec_sos_" + key] = sos
+        d["dec_zi_" + key] = ss.sosfilt_zi(sos)
+    d["sin_pi"] = np.array(np.sin(np.pi))
+    save("wfm", **d)
+
+
 def gen_power():
     d = {}
     frames, pw = [], []
@@ -387,5 +435,6 @@ if __name__ == "__main__":
     gen_am_ssb()
     gen_power()
     gen_iqcorr()
+    gen_wfm()
     gen_scanner()
     gen_caller()
