@@ -35,7 +35,7 @@ typedef enum {
     PSS_E_NOMEM = -5
 } pss_status;
 
-typedef enum { PSS_MODE_NFM = 0, PSS_MODE_AM = 1, PSS_MODE_USB = 2, PSS_MODE_LSB = 3 } pss_mode;
+typedef enum { PSS_MODE_NFM = 0, PSS_MODE_AM = 1, PSS_MODE_USB = 2, PSS_MODE_LSB = 3, PSS_MODE_WFM = 4 } pss_mode;
 
 /* ---- context ------------------------------------------------------------------------------------ */
 int pss_create(int device, pss_ctx **out);
@@ -56,6 +56,10 @@ int pss_design_firwin(int numtaps, double cutoff, double *taps);
 /* scipy.signal.cheby1(order, rp_db, wn, output='sos') low-pass, order even (decimate(): order 8, rp 0.05,
  * wn 0.8/q — signal_processing.py:112 via scipy _signaltools.py:4831).  sos[order/2][6]. */
 int pss_design_cheby1_sos(int order, double rp_db, double wn, double *sos);
+/* scipy.signal.butter(order, Wn, output='sos'): low-pass with cutoff wn_high when wn_low <= 0 (as bandpass_filter does,
+ * signal_processing.py:37-39), else band-pass [wn_low, wn_high] (:41).  sos[ceil(order/2)][6] (low) / sos[order][6] (band);
+ * *nsec (nullable) receives the row count.  PSS_E_CUTOFF where SciPy raises ValueError (Wn outside 0 < Wn < 1). */
+int pss_design_butter_sos(int order, double wn_low, double wn_high, double *sos, int *nsec);
 /* scipy.signal.sosfilt_zi(sos).  zi[nsec][2]. */
 int pss_design_sosfilt_zi(const double *sos, int nsec, double *zi);
 /* butter(5, [300, 3000]/(22050/2), 'band', output='sos') — the fixed AM filter (signal_processing.py:188-191,
@@ -102,6 +106,20 @@ int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, d
               double *d_audio);
 int pss_demod_out_len(int mode, int n, double fs);
 
+/* PSS_MODE_WFM = demodulate_wfm (signal_processing.py:119-176): discriminator, L+R / pilot / L-R Butterworth branches,
+ * 75 us de-emphasis, zero-phase decimation, joint peak normalisation.  n_out = ceil((n-1)/int(fs/22050)); here
+ *   d_audio double [n_frames][n_out][2] holds np.column_stack((left, right)) and d_pcm its int16 image.
+ * pss_demod() runs the demodulator on the samples as given; pss_demod_signal() is the reference's dispatcher
+ * demodulate_signal (:220-240): identical for NFM/AM/USB/LSB, and for WFM it applies iq_correction first (:222-225). */
+int pss_demod_signal(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, int16_t *d_pcm,
+                     double *d_audio);
+/* WFM filter set of one sample rate: lp = butter(5, 15000/(fs/2)) [3][6], pilot = butter(5, [18800,19200]/(fs/2), 'band')
+ * [5][6], lmr = butter(5, [23000,53000]/(fs/2), 'band') [5][6], alpha = exp(-1/(75e-6 fs)).  Designed on first use
+ * (pss_design_butter_sos, a few ulp from SciPy); set_ lets a caller inject SciPy's own tables. */
+int pss_set_wfm_filters(pss_ctx *ctx, double fs, const double *lp3x6, const double *pilot5x6, const double *lmr5x6,
+                        double alpha);
+int pss_get_wfm_filters(pss_ctx *ctx, double fs, double *lp3x6, double *pilot5x6, double *lmr5x6, double *alpha);
+
 /* Headline fused call: spectrum + NFM demod of the same frames (BASELINE.json metric). */
 int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db,
                      int16_t *d_pcm);
@@ -134,6 +152,9 @@ int pss_ring_persistence(pss_ring *ring, int disp_h, int disp_w, int8_t *d_colou
 int pss_h_compute_fft(pss_ctx *ctx, const float *h_iq, int n, double *h_db);
 int pss_h_demodulate(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,
                      int16_t *h_pcm);
+/* demodulate_signal(samples, fs, mode) on one host frame (dispatcher semantics: WFM is IQ-corrected first). */
+int pss_h_demodulate_signal(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,
+                            int16_t *h_pcm);
 int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float *h_power);
 /* iq_correction(samples) / demodulate_signal(samples, fs, 'RAW') on one host frame; either output may be NULL. */
 int pss_h_iq_correction(pss_ctx *ctx, const float *h_iq, int n, float *h_out_iq, float *h_raw);

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpss.so")
 
 PSS_OK, PSS_E_ARG, PSS_E_HIP, PSS_E_PADLEN, PSS_E_CUTOFF, PSS_E_NOMEM = 0, -1, -2, -3, -4, -5
-MODE_NFM, MODE_AM, MODE_USB, MODE_LSB = 0, 1, 2, 3
+MODE_NFM, MODE_AM, MODE_USB, MODE_LSB, MODE_WFM = 0, 1, 2, 3, 4
 
 _p = C.c_void_p
 _SIGS = {
@@ -23,6 +23,7 @@ _SIGS = {
     "pss_design_firwin": (C.c_int, [C.c_int, C.c_double, _p]),
     "pss_design_cheby1_sos": (C.c_int, [C.c_int, C.c_double, C.c_double, _p]),
     "pss_design_sosfilt_zi": (C.c_int, [_p, C.c_int, _p]),
+    "pss_design_butter_sos": (C.c_int, [C.c_int, C.c_double, C.c_double, _p, _p]),
     "pss_am_bandpass_sos": (C.c_int, [_p]),
     "pss_set_nfm_filters": (C.c_int, [_p, C.c_double, _p, _p, _p]),
     "pss_set_ssb_taps": (C.c_int, [_p, C.c_double, _p]),
@@ -35,6 +36,9 @@ _SIGS = {
     "pss_iq_correction": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p]),
     "pss_agc_steps": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_int, _p]),
     "pss_demod": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
+    "pss_demod_signal": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
+    "pss_set_wfm_filters": (C.c_int, [_p, C.c_double, _p, _p, _p, C.c_double]),
+    "pss_get_wfm_filters": (C.c_int, [_p, C.c_double, _p, _p, _p, _p]),
     "pss_demod_out_len": (C.c_int, [C.c_int, C.c_int, C.c_double]),
     "pss_spectrum_nfm": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
     "pss_waterfall_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
@@ -49,6 +53,7 @@ _SIGS = {
     "pss_ring_persistence": (C.c_int, [_p, C.c_int, C.c_int, _p]),
     "pss_h_compute_fft": (C.c_int, [_p, _p, C.c_int, _p]),
     "pss_h_demodulate": (C.c_int, [_p, C.c_int, _p, C.c_int, C.c_double, _p, _p]),
+    "pss_h_demodulate_signal": (C.c_int, [_p, C.c_int, _p, C.c_int, C.c_double, _p, _p]),
     "pss_h_measure_power": (C.c_int, [_p, _p, C.c_int, _p]),
     "pss_h_iq_correction": (C.c_int, [_p, _p, C.c_int, _p, _p]),
     "pss_host_alloc": (_p, [C.c_size_t]),

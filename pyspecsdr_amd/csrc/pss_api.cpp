@@ -119,6 +119,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     }
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->scratch_fft) hipFree(ctx->scratch_fft);
+    if (ctx->scratch_iqc) hipFree(ctx->scratch_iqc);
     if (ctx->stage) hipFree(ctx->stage);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
@@ -220,28 +221,45 @@ extern "C" int pss_h_compute_fft(pss_ctx *ctx, const float *h_iq, int n, double 
     return PSS_OK;
 }
 
-extern "C" int pss_h_demodulate(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,
-                                int16_t *h_pcm)
+static int h_demod_impl(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,
+                        int16_t *h_pcm, bool dispatcher)
 {
     if (!ctx) return PSS_E_ARG;
     if (!h_iq || n < 1 || (!h_audio_stereo && !h_pcm)) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
     int n_out = pss_demod_out_len(mode, n, fs);
     if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "unknown mode or sample rate below 22050 Hz");
+    const bool stereo = mode == PSS_MODE_WFM;
     const size_t o_pcm = up256(sizeof(float) * 2 * n), o_au = o_pcm + up256(sizeof(int16_t) * 2 * n_out);
-    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_au + up256(sizeof(double) * n_out), "staging");
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_au + up256(sizeof(double) * 2 * n_out), "staging");
     if (r) return r;
     char *base = reinterpret_cast<char *>(ctx->stage);
     PSS_HIP(ctx, hipMemcpyAsync(base, h_iq, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
-    r = pss_demod(ctx, mode, reinterpret_cast<const float *>(base), 1, n, fs, reinterpret_cast<int16_t *>(base + o_pcm),
-                  reinterpret_cast<double *>(base + o_au));
+    r = (dispatcher ? pss_demod_signal : pss_demod)(ctx, mode, reinterpret_cast<const float *>(base), 1, n, fs,
+                                                    reinterpret_cast<int16_t *>(base + o_pcm),
+                                                    reinterpret_cast<double *>(base + o_au));
     if (r) return r;
-    std::vector<double> mono(n_out);
-    PSS_HIP(ctx, hipMemcpyAsync(mono.data(), base + o_au, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> au((size_t)n_out * (stereo ? 2 : 1));
+    PSS_HIP(ctx, hipMemcpyAsync(au.data(), base + o_au, sizeof(double) * au.size(), hipMemcpyDeviceToHost, ctx->stream));
     if (h_pcm) PSS_HIP(ctx, hipMemcpyAsync(h_pcm, base + o_pcm, sizeof(int16_t) * 2 * n_out, hipMemcpyDeviceToHost, ctx->stream));
     PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (h_audio_stereo)
-        for (int i = 0; i < n_out; i++) h_audio_stereo[2 * i] = h_audio_stereo[2 * i + 1] = mono[i];  // mono_to_stereo
+    if (h_audio_stereo) {
+        if (stereo) memcpy(h_audio_stereo, au.data(), sizeof(double) * au.size());  // np.column_stack((left, right))
+        else
+            for (int i = 0; i < n_out; i++) h_audio_stereo[2 * i] = h_audio_stereo[2 * i + 1] = au[i];  // mono_to_stereo
+    }
     return PSS_OK;
+}
+
+extern "C" int pss_h_demodulate(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,
+                                int16_t *h_pcm)
+{
+    return h_demod_impl(ctx, mode, h_iq, n, fs, h_audio_stereo, h_pcm, false);
+}
+
+extern "C" int pss_h_demodulate_signal(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs,
+                                       double *h_audio_stereo, int16_t *h_pcm)
+{
+    return h_demod_impl(ctx, mode, h_iq, n, fs, h_audio_stereo, h_pcm, true);
 }
 
 extern "C" int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float *h_power)

@@ -15,6 +15,11 @@ struct PssNfmFilt {
     double zi[8];
 };
 
+struct PssWfmFilt {
+    double lp[18], pilot[30], lmr[30];  // butter(5) SOS rows: low-pass 15 kHz, pilot band-pass, L-R band-pass
+    double alpha;                       // de-emphasis pole exp(-1/(75e-6 fs))
+};
+
 struct PssPairwisePlan {  // numpy pairwise-sum tree for one frame length (see pss_demod.hip)
     int n_leaves = 0, n_nodes = 0, n_levels = 0;
     int *d_leaf_off = nullptr, *d_leaf_len = nullptr, *d_node_l = nullptr, *d_node_r = nullptr, *d_level_start = nullptr;
@@ -33,9 +38,12 @@ struct pss_ctx {
     std::map<int, double *> win;       // np.hamming(N)
     std::map<double, PssNfmFilt> nfm;  // per sample rate
     std::map<double, std::array<double, 65>> ssb;
+    std::map<double, PssWfmFilt> wfm;
     std::map<int, PssPairwisePlan> plans;
     void *scratch = nullptr;       // demodulator scratch (main stream)
     size_t scratch_bytes = 0;
+    void *scratch_iqc = nullptr;   // IQ-corrected frames for the WFM dispatcher path
+    size_t scratch_iqc_bytes = 0;
     void *scratch_fft = nullptr;   // spectrum scratch: separate, the spectrum kernel may run on the side stream
     size_t scratch_fft_bytes = 0;
     void *stage = nullptr;         // device staging of the host-buffer convenience calls (grow-only)

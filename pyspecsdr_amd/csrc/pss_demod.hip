@@ -36,6 +36,10 @@ struct NfmCoef {
 struct AmCoef {
     Biquad s[5];
 };
+struct WfmCoef {
+    Biquad lp[3], pil[5], lmr[5];  // butter(5) low-pass 15 kHz, band-pass 19 kHz +- 200 Hz, band-pass 23..53 kHz
+    double b0d, a1d;               // de-emphasis lfilter([1 - alpha], [1, -alpha])
+};
 
 // The 65 FIR taps travel as a by-value kernel argument (kernarg segment: wave-uniform scalar loads), not a
 // __constant__ symbol: two contexts on one device may run different sample rates concurrently.
@@ -259,7 +263,7 @@ __device__ __forceinline__ void iir4_pass(const NfmCoef &c, double (&z)[8], long
     out(T - 1, sec(3, p2));
 }
 
-template <bool B121>
+template <bool B121, bool WFM = false>
 __global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, double *__restrict__ Y,
                                                   double *__restrict__ A, int n, int q, int n_out, long n_frames,
                                                   long Lp, NfmCoef c, int16_t *__restrict__ pcm,
@@ -316,6 +320,10 @@ __global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, 
                   }
               });
     if (nan) mx = __builtin_nan("");
+    if (WFM) {  // rows are (frame, channel) pairs: k_wfm_finalize normalises both channels by their joint peak
+        if (f < n_frames) audio[f] = mx;
+        return;
+    }
     if (f < n_frames) {
         for (int k = 0; k < n_out; k++) {
             double a = __dmul_rn(__ddiv_rn(At[(size_t)k * TILE], mx), 0.95);  // audio / max|audio| * 0.95
@@ -883,6 +891,89 @@ __global__ __launch_bounds__(IQC_TPB) void k_iqcorr(const float2 *__restrict__ i
     }
 }
 
+// ---- demodulate_wfm (signal_processing.py:119-176) ----------------------------------------------------------------
+// Everything up to the decimator is causal and serial in time, so one lane owns one frame and walks it once:
+// discriminator -> {LP15k, BP pilot -> 1-pole -> sign, BP 23..53k} -> x(2*pilot) -> LP15k -> L/R matrix -> de-emphasis.
+// The reference's pilot = sin(unwrap(angle(real signal))) is 0.0 or sin(pi) (see oracle/pss_oracle.c), restated as such.
+// The two de-emphasised channels land in U as rows 2f (left) and 2f+1 (right), odd-extended by 27 samples each side,
+// which is the layout k_nfm_iir (zero-phase cheby1 decimator) consumes.
+__device__ __forceinline__ double lfilter1(double b0, double a1, double x, double &z)
+{
+    const double y = __dadd_rn(z, __dmul_rn(b0, x));
+    z = __dsub_rn(__dmul_rn(x, 0.0), __dmul_rn(y, a1));
+    return y;
+}
+__global__ __launch_bounds__(TILE) void k_wfm_front(const float2 *__restrict__ iq, double *U, int n, long n_frames,
+                                                    long Lp, int swapped, WfmCoef c)
+{
+    const int lane = threadIdx.x;
+    const long f = (long)blockIdx.x * TILE + lane;
+    const bool live = f < n_frames;
+    const long fr = live ? f : n_frames - 1;
+    const int M = n - 1;
+    const float2 *x = iq + (size_t)fr * n;
+    double *UL = U + (size_t)(2 * fr) * Lp, *UR = UL + Lp;
+    double zlp[6] = {0, 0, 0, 0, 0, 0}, zl2[6] = {0, 0, 0, 0, 0, 0};
+    double zpi[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, zlm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double zp1 = 0.0, zdl = 0.0, zdr = 0.0;
+    const double SIN_PI = 0x1.1a62633145c07p-53;  // np.sin(np.pi)
+    float2 prev = x[0];
+    for (int i = 0; i < M; i++) {
+        const float2 cur = x[i + 1];
+        const double d = (double)disc_sample(cur, prev, 1.0f, swapped != 0);  // :122 (x1.0f is exact)
+        prev = cur;
+        double a = d, p = d, m = d;
+#pragma unroll
+        for (int s2 = 0; s2 < 3; s2++) a = biquad_step(c.lp[s2], a, zlp[2 * s2], zlp[2 * s2 + 1]);     // :126
+#pragma unroll
+        for (int s2 = 0; s2 < 5; s2++) p = biquad_step(c.pil[s2], p, zpi[2 * s2], zpi[2 * s2 + 1]);    // :129
+#pragma unroll
+        for (int s2 = 0; s2 < 5; s2++) m = biquad_step(c.lmr[s2], m, zlm[2 * s2], zlm[2 * s2 + 1]);    // :133
+        const double y = lfilter1(1.0, -0.99, p, zp1);                                                 // :130
+        const double pil = (y != y) ? y : ((y < 0.0 || (y == 0.0 && __builtin_signbit(y))) ? SIN_PI : 0.0);
+        m = __dmul_rn(m, __dmul_rn(2.0, pil));                                                         // :134
+#pragma unroll
+        for (int s2 = 0; s2 < 3; s2++) m = biquad_step(c.lp[s2], m, zl2[2 * s2], zl2[2 * s2 + 1]);     // :137
+        const double l = __dmul_rn(__dadd_rn(a, m), 0.5), r = __dmul_rn(__dsub_rn(a, m), 0.5);         // :140-141 (/2 exact)
+        const double yl = lfilter1(c.b0d, c.a1d, l, zdl), yr = lfilter1(c.b0d, c.a1d, r, zdr);         // :148-149
+        if (live) { UL[EDGE + i] = yl; UR[EDGE + i] = yr; }
+    }
+    if (!live) return;
+    // odd extension (scipy _arraytools.odd_ext) of both rows, from this lane's own stores
+    __threadfence_block();
+    for (int ch = 0; ch < 2; ch++) {
+        double *u = (ch ? UR : UL) + EDGE;
+        const double u0 = u[0], ul = u[M - 1];
+        for (int k = 0; k < EDGE; k++) {
+            u[k - EDGE] = __dsub_rn(__dmul_rn(2.0, u0), u[EDGE - k]);
+            u[M + k] = __dsub_rn(__dmul_rn(2.0, ul), u[M - 2 - k]);
+        }
+    }
+}
+
+// :157-163 — joint peak normalisation of the two decimated channels, column_stack, and the int16 conversion.
+// A: k_nfm_iir's transposed decimated rows ([tile][k][lane], row g = 2f + channel); mxrow[g] = max|row g| (NaN kept).
+__global__ __launch_bounds__(TPB) void k_wfm_finalize(const double *__restrict__ A, const double *__restrict__ mxrow,
+                                                      int n_out, long n_frames, int16_t *__restrict__ pcm,
+                                                      double *__restrict__ audio)
+{
+    const size_t total = (size_t)n_frames * n_out;
+    for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
+        const long f = (long)(idx / n_out);
+        const int k = (int)(idx - (size_t)f * n_out);
+        const long g = 2 * f;
+        const double ml = mxrow[g], mr = mxrow[g + 1];
+        const double mx = (mr > ml) ? mr : ml;  // python max(a, b): b only if b > a
+        const double *At = A + (size_t)(g / TILE) * n_out * TILE + (size_t)k * TILE + (g % TILE);
+        const double l = __ddiv_rn(At[0], mx), r = __ddiv_rn(At[1], mx);
+        if (audio) { audio[2 * idx] = l; audio[2 * idx + 1] = r; }
+        if (pcm) {
+            const uint16_t a = (uint16_t)pcm16(l), b = (uint16_t)pcm16(r);
+            reinterpret_cast<uint32_t *>(pcm)[idx] = (uint32_t)a | ((uint32_t)b << 16);
+        }
+    }
+}
+
 // adjust_gain (pyspecsdr.py:898-919), sequential by nature.
 __global__ void k_agc(const float *__restrict__ power, long n, int idx, int n_gains, int *__restrict__ out)
 {
@@ -1016,6 +1107,24 @@ int nfm_filters(pss_ctx *ctx, double fs, PssNfmFilt **out)
     return PSS_OK;
 }
 
+int wfm_filters(pss_ctx *ctx, double fs, PssWfmFilt **out)
+{
+    auto it = ctx->wfm.find(fs);
+    if (it == ctx->wfm.end()) {
+        PssWfmFilt f;
+        const double nyq = fs / 2.0;
+        int r = pss_design_butter_sos(5, 0.0, 15000.0 / nyq, f.lp, nullptr);
+        if (!r) r = pss_design_butter_sos(5, (19000.0 - 200.0) / nyq, (19000.0 + 200.0) / nyq, f.pilot, nullptr);
+        if (!r) r = pss_design_butter_sos(5, (38000.0 - 15000.0) / nyq, (38000.0 + 15000.0) / nyq, f.lmr, nullptr);
+        // scipy: "Digital filter critical frequencies must be 0 < Wn < 1" (53 kHz must be below fs/2)
+        if (r) return pss_fail(ctx, r, "butter: digital filter critical frequencies must be 0 < Wn < 1 (WFM needs fs > 106 kHz)");
+        f.alpha = exp(-1.0 / (75e-6 * fs));
+        ctx->wfm[fs] = f;
+    }
+    *out = &ctx->wfm[fs];
+    return PSS_OK;
+}
+
 int ssb_taps(pss_ctx *ctx, double fs, double **out)
 {
     auto it = ctx->ssb.find(fs);
@@ -1043,7 +1152,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" int pss_demod_out_len(int mode, int n, double fs)
 {
     if (n <= 0) return 0;
-    if (mode == PSS_MODE_NFM) {
+    if (mode == PSS_MODE_NFM || mode == PSS_MODE_WFM) {
         int q = (int)(fs / 22050.0);
         if (q < 1) return PSS_E_ARG;
         return (n - 1 + q - 1) / q;
@@ -1263,7 +1372,115 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         pss_time_end(ctx);
         return pss_hip_check(ctx, hipGetLastError(), "ssb launch");
     }
+    if (mode == PSS_MODE_WFM) {
+        const int q = (int)(fs / 22050.0);
+        if (q < 2) return pss_fail(ctx, PSS_E_ARG, "WFM: sample rates below 44.1 kHz (no decimation stage) are not supported");
+        if (n - 1 <= EDGE)
+            return pss_fail(ctx, PSS_E_PADLEN, "The length of the input vector x must be greater than padlen, which is 27.");
+        PssWfmFilt *wf;
+        int r = wfm_filters(ctx, fs, &wf);
+        if (r) return r;
+        PssNfmFilt *flt;  // the decimator (cheby1 + zi) is the NFM one
+        r = nfm_filters(ctx, fs, &flt);
+        if (r) return r;
+        if (n_frames == 0) return PSS_OK;
+        const long rows = 2 * n_frames, tiles2 = (rows + TILE - 1) / TILE;
+        const int n_out = (n - 1 + q - 1) / q;
+        const long L = (long)(n - 1) + 2 * EDGE;
+        const long Lp = (L + 1) & ~1L;
+        const size_t szU = align256((size_t)rows * Lp * sizeof(double));
+        const size_t szY = align256((size_t)tiles2 * L * TILE * sizeof(double));
+        const size_t szA = align256((size_t)tiles2 * n_out * TILE * sizeof(double));
+        const size_t szM = align256((size_t)rows * sizeof(double));
+        r = pss_ensure_scratch(ctx, szU + szY + szA + szM);
+        if (r) return r;
+        char *base = reinterpret_cast<char *>(ctx->scratch);
+        double *U = reinterpret_cast<double *>(base), *Y = reinterpret_cast<double *>(base + szU);
+        double *A = reinterpret_cast<double *>(base + szU + szY), *MX = reinterpret_cast<double *>(base + szU + szY + szA);
+        WfmCoef wc;
+        auto fill = [](Biquad *dst, const double *sos, int ns) {
+            for (int s2 = 0; s2 < ns; s2++) dst[s2] = Biquad{sos[6 * s2], sos[6 * s2 + 1], sos[6 * s2 + 2], sos[6 * s2 + 4], sos[6 * s2 + 5]};
+        };
+        fill(wc.lp, wf->lp, 3); fill(wc.pil, wf->pilot, 5); fill(wc.lmr, wf->lmr, 5);
+        wc.b0d = 1.0 - wf->alpha;
+        wc.a1d = -wf->alpha;
+        NfmCoef c;
+        fill(c.s, flt->sos, 4);
+        for (int i = 0; i < 8; i++) c.zi[i] = flt->zi[i];
+        bool b121 = true;
+        for (int s2 = 1; s2 < 4; s2++)
+            b121 = b121 && flt->sos[6 * s2] == 1.0 && flt->sos[6 * s2 + 1] == 2.0 && flt->sos[6 * s2 + 2] == 1.0;
+        const int swapped = ((long)(n - 1) * 8 >= 262144) ? 1 : 0;
+        pss_time_begin(ctx);
+        pss_kernel_begin(ctx, "k_wfm_front");
+        hipLaunchKernelGGL(k_wfm_front, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx),
+                           reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, Lp, swapped, wc);
+        pss_kernel_end(ctx);
+        pss_kernel_begin(ctx, "k_nfm_iir");
+        if (b121)
+            hipLaunchKernelGGL((k_nfm_iir<true, true>), dim3((unsigned)tiles2), dim3(TILE), 0, PSS_STREAM(ctx), U, Y, A, n, q,
+                               n_out, rows, Lp, c, nullptr, MX);
+        else
+            hipLaunchKernelGGL((k_nfm_iir<false, true>), dim3((unsigned)tiles2), dim3(TILE), 0, PSS_STREAM(ctx), U, Y, A, n, q,
+                               n_out, rows, Lp, c, nullptr, MX);
+        pss_kernel_end(ctx);
+        size_t tot = (size_t)n_frames * n_out;
+        size_t g2 = (tot + TPB - 1) / TPB;
+        if (g2 > 16384) g2 = 16384;
+        pss_kernel_begin(ctx, "k_wfm_finalize");
+        hipLaunchKernelGGL(k_wfm_finalize, dim3((unsigned)g2), dim3(TPB), 0, PSS_STREAM(ctx), A, MX, n_out, n_frames, d_pcm,
+                           d_audio);
+        pss_kernel_end(ctx);
+        pss_time_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "wfm launch");
+    }
     return pss_fail(ctx, PSS_E_ARG, "unknown demodulation mode");
+}
+
+// demodulate_signal (signal_processing.py:220-240): the voice modes go straight to their demodulator, every other mode
+// is IQ-corrected first (:222-225).
+extern "C" int pss_demod_signal(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, int16_t *d_pcm,
+                                double *d_audio)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (mode != PSS_MODE_WFM) return pss_demod(ctx, mode, d_iq, n_frames, n, fs, d_pcm, d_audio);
+    if (!d_iq || n_frames < 0 || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad demod arguments");
+    if (n_frames == 0) return pss_demod(ctx, mode, d_iq, n_frames, n, fs, d_pcm, d_audio);
+    int r = pss_ensure_buffer(ctx, &ctx->scratch_iqc, &ctx->scratch_iqc_bytes, (size_t)n_frames * n * sizeof(float2),
+                              "iq_correction scratch");
+    if (r) return r;
+    pss_time_begin(ctx);
+    r = pss_iq_correction(ctx, d_iq, n_frames, n, reinterpret_cast<float *>(ctx->scratch_iqc), nullptr);
+    if (!r) r = pss_demod(ctx, mode, reinterpret_cast<const float *>(ctx->scratch_iqc), n_frames, n, fs, d_pcm, d_audio);
+    pss_time_end(ctx);
+    return r;
+}
+
+extern "C" int pss_set_wfm_filters(pss_ctx *ctx, double fs, const double *lp3x6, const double *pilot5x6, const double *lmr5x6,
+                                   double alpha)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!lp3x6 || !pilot5x6 || !lmr5x6) return pss_fail(ctx, PSS_E_ARG, "null coefficient table");
+    PssWfmFilt f;
+    memcpy(f.lp, lp3x6, sizeof(f.lp));
+    memcpy(f.pilot, pilot5x6, sizeof(f.pilot));
+    memcpy(f.lmr, lmr5x6, sizeof(f.lmr));
+    f.alpha = alpha;
+    ctx->wfm[fs] = f;
+    return PSS_OK;
+}
+
+extern "C" int pss_get_wfm_filters(pss_ctx *ctx, double fs, double *lp3x6, double *pilot5x6, double *lmr5x6, double *alpha)
+{
+    if (!ctx) return PSS_E_ARG;
+    PssWfmFilt *f;
+    int r = wfm_filters(ctx, fs, &f);
+    if (r) return r;
+    if (lp3x6) memcpy(lp3x6, f->lp, sizeof(f->lp));
+    if (pilot5x6) memcpy(pilot5x6, f->pilot, sizeof(f->pilot));
+    if (lmr5x6) memcpy(lmr5x6, f->lmr, sizeof(f->lmr));
+    if (alpha) *alpha = f->alpha;
+    return PSS_OK;
 }
 
 extern "C" int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db,

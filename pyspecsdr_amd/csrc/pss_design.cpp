@@ -97,6 +97,158 @@ extern "C" int pss_design_cheby1_sos(int order, double rp_db, double wn, double 
     return PSS_OK;
 }
 
+// scipy.signal.butter(N, Wn, btype='low'|'band', output='sos') (_filter_design.py: iirfilter -> buttap ->
+// lp2lp_zpk | lp2bp_zpk -> bilinear_zpk -> zpk2sos(pairing='nearest')).  wn_low <= 0 selects the low-pass with cutoff
+// wn_high (what the reference's bandpass_filter does, signal_processing.py:37-39).  sos: ceil(N/2) rows (low) or N rows
+// (band); *nsec receives the row count.
+namespace {
+inline bool is_real(const cplx &v) { return v.imag() == 0.0; }
+// zpk2sos's inner pairing loop on the "cplxreal" lists (one member per conjugate pair, imag > 0, then the reals)
+int zpk2sos_nearest(std::vector<cplx> z, std::vector<cplx> p, double k, double *sos, int nsec)
+{
+    auto nearest_idx = [](const std::vector<cplx> &fro, cplx to, int which) {  // which: 0 real, 1 complex, 2 any
+        int best = -1;
+        double bd = 0;
+        for (size_t j = 0; j < fro.size(); j++) {
+            if (which == 0 && !is_real(fro[j])) continue;
+            if (which == 1 && is_real(fro[j])) continue;
+            double d = std::abs(fro[j] - to);
+            if (best < 0 || d < bd) { best = (int)j; bd = d; }
+        }
+        return best;
+    };
+    auto count_real = [](const std::vector<cplx> &v) { int c = 0; for (auto &x : v) c += is_real(x); return c; };
+    auto put = [&](int si, const cplx *zz, int nz, cplx p1, cplx p2) {
+        double *row = sos + 6 * si;
+        // zpk2tf -> np.poly: [1, -(r1 + r2), r1 r2]
+        if (nz == 2) {
+            row[0] = 1.0; row[1] = -(zz[0] + zz[1]).real(); row[2] = (zz[0] * zz[1]).real();
+        } else { row[0] = 1.0; row[1] = -zz[0].real(); row[2] = 0.0; }
+        row[3] = 1.0; row[4] = -(p1 + p2).real(); row[5] = (p1 * p2).real();
+    };
+    for (int si = nsec - 1; si >= 0; si--) {
+        int pi = 0;
+        double best = 1e300;
+        for (size_t j = 0; j < p.size(); j++) {
+            double d = std::fabs(1.0 - std::abs(p[j]));
+            if (d < best) { best = d; pi = (int)j; }
+        }
+        cplx p1 = p[pi];
+        p.erase(p.begin() + pi);
+        if (is_real(p1) && count_real(p) == 0) {  // first-order section
+            int zi = nearest_idx(z, p1, 2);
+            if (zi < 0) return PSS_E_ARG;
+            cplx z1 = z[zi];
+            z.erase(z.begin() + zi);
+            cplx zz[2] = {z1, cplx(0, 0)};
+            put(si, zz, 2, p1, cplx(0, 0));
+        } else if (!is_real(p1) && count_real(z) == 1) {
+            int zi = nearest_idx(z, p1, 1);
+            if (zi < 0) return PSS_E_ARG;
+            cplx z1 = z[zi];
+            z.erase(z.begin() + zi);
+            cplx zz[2] = {z1, std::conj(z1)};
+            put(si, zz, 2, p1, std::conj(p1));
+        } else {
+            cplx p2;
+            if (is_real(p1)) {
+                int pj = -1;
+                double bd = 0;
+                for (size_t j = 0; j < p.size(); j++) {
+                    if (!is_real(p[j])) continue;
+                    double d = std::fabs(std::abs(p[j]) - 1.0);
+                    if (pj < 0 || d < bd) { pj = (int)j; bd = d; }
+                }
+                if (pj < 0) return PSS_E_ARG;
+                p2 = p[pj];
+                p.erase(p.begin() + pj);
+            } else p2 = std::conj(p1);
+            if (z.empty()) return PSS_E_ARG;
+            int zi = nearest_idx(z, p1, 2);
+            cplx z1 = z[zi];
+            z.erase(z.begin() + zi);
+            if (!is_real(z1)) {
+                cplx zz[2] = {z1, std::conj(z1)};
+                put(si, zz, 2, p1, p2);
+            } else if (!z.empty()) {
+                int zj = nearest_idx(z, p1, 0);
+                if (zj < 0) return PSS_E_ARG;
+                cplx z2 = z[zj];
+                z.erase(z.begin() + zj);
+                cplx zz[2] = {z1, z2};
+                put(si, zz, 2, p1, p2);
+            } else {
+                cplx zz[1] = {z1};
+                put(si, zz, 1, p1, p2);
+            }
+        }
+    }
+    sos[0] *= k; sos[1] *= k; sos[2] *= k;
+    return PSS_OK;
+}
+}  // namespace
+
+extern "C" int pss_design_butter_sos(int order, double wn_low, double wn_high, double *sos, int *nsec_out)
+{
+    const int N = order;
+    if (N < 1 || N > 16 || !sos) return PSS_E_ARG;
+    const bool band = wn_low > 0.0;
+    if (!(wn_high > 0.0 && wn_high < 1.0) || (band && !(wn_low < wn_high))) return PSS_E_CUTOFF;  // scipy ValueError
+    // buttap
+    std::vector<cplx> p(N), z;
+    for (int i = 0; i < N; i++) {
+        double m = (double)(-N + 1 + 2 * i);
+        p[i] = -std::exp(cplx(0.0, M_PI * m / (2.0 * N)));
+    }
+    double k = 1.0;
+    const double fs = 2.0, fs2 = 2.0 * fs;
+    int degree = N;
+    if (!band) {
+        double warped = 2.0 * fs * std::tan(M_PI * wn_high / fs);
+        for (auto &v : p) v *= warped;
+        k *= std::pow(warped, (double)degree);
+    } else {
+        double w0 = 2.0 * fs * std::tan(M_PI * wn_low / fs), w1 = 2.0 * fs * std::tan(M_PI * wn_high / fs);
+        double bw = w1 - w0, wo = std::sqrt(w0 * w1);
+        std::vector<cplx> pb(2 * N);
+        for (int i = 0; i < N; i++) {
+            cplx pl = p[i] * (bw / 2.0);
+            cplx r = std::sqrt(pl * pl - wo * wo);
+            pb[i] = pl + r;
+            pb[N + i] = pl - r;
+        }
+        p = pb;
+        z.assign(degree, cplx(0, 0));
+        k *= std::pow(bw, (double)degree);
+    }
+    // bilinear_zpk
+    cplx num(1, 0), den(1, 0);
+    for (auto &v : z) { num *= (fs2 - v); v = (fs2 + v) / (fs2 - v); }
+    for (auto &v : p) { den *= (fs2 - v); v = (fs2 + v) / (fs2 - v); }
+    const int deg2 = (int)p.size() - (int)z.size();
+    for (int i = 0; i < deg2; i++) z.push_back(cplx(-1.0, 0.0));
+    k *= (num / den).real();
+    // zpk2sos front matter: equalise lengths, make the count even, reduce to one member per conjugate pair + reals
+    if (p.size() % 2 == 1) { p.push_back(cplx(0, 0)); z.push_back(cplx(0, 0)); }
+    const int nsec = (int)p.size() / 2;
+    auto cplxreal = [](const std::vector<cplx> &v) {
+        std::vector<cplx> c, r;
+        for (auto &x : v) {
+            if (std::fabs(x.imag()) <= 100 * 2.220446049250313e-16 * std::abs(x)) r.push_back(cplx(x.real(), 0.0));
+            else if (x.imag() > 0) c.push_back(x);
+        }
+        std::sort(r.begin(), r.end(), [](const cplx &a, const cplx &b) { return a.real() < b.real(); });
+        std::sort(c.begin(), c.end(), [](const cplx &a, const cplx &b) {
+            return a.real() != b.real() ? a.real() < b.real() : std::fabs(a.imag()) < std::fabs(b.imag()); });
+        c.insert(c.end(), r.begin(), r.end());
+        return c;
+    };
+    int r = zpk2sos_nearest(cplxreal(z), cplxreal(p), k, sos, nsec);
+    if (r) return r;
+    if (nsec_out) *nsec_out = nsec;
+    return PSS_OK;
+}
+
 extern "C" int pss_design_sosfilt_zi(const double *sos, int nsec, double *zi)
 {
     if (!sos || !zi || nsec < 1) return PSS_E_ARG;

@@ -131,6 +131,23 @@ class Engine:
     def demod(self, mode, d_iq, n_frames, n, fs, d_pcm=None, d_audio=None):
         self._ck(self.lib.pss_demod(self.h, mode, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_pcm), _ptr(d_audio)))
 
+    def demod_signal(self, mode, d_iq, n_frames, n, fs, d_pcm=None, d_audio=None):
+        """Dispatcher semantics (demodulate_signal): WFM frames are IQ-corrected first."""
+        self._ck(self.lib.pss_demod_signal(self.h, mode, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_pcm), _ptr(d_audio)))
+
+    def wfm_filters(self, fs):
+        lp, pil, lmr = np.empty((3, 6)), np.empty((5, 6)), np.empty((5, 6))
+        import ctypes as C
+        a = C.c_double()
+        self._ck(self.lib.pss_get_wfm_filters(self.h, float(fs), _ptr(lp), _ptr(pil), _ptr(lmr), C.addressof(a)))
+        return lp, pil, lmr, a.value
+
+    def set_wfm_filters(self, fs, lp, pilot, lmr, alpha):
+        c = lambda x: np.ascontiguousarray(x, np.float64)
+        lp, pilot, lmr = c(lp), c(pilot), c(lmr)
+        assert lp.shape == (3, 6) and pilot.shape == (5, 6) and lmr.shape == (5, 6)
+        self._ck(self.lib.pss_set_wfm_filters(self.h, float(fs), _ptr(lp), _ptr(pilot), _ptr(lmr), float(alpha)))
+
     def demod_out_len(self, mode, n, fs):
         return int(self.lib.pss_demod_out_len(mode, n, float(fs)))
 
@@ -208,6 +225,16 @@ class Engine:
         audio = np.empty((n_out, 2), np.float64)
         pcm = np.empty((n_out, 2), np.int16)
         self._ck(self.lib.pss_h_demodulate(self.h, mode, _ptr(iq), len(iq), float(fs), _ptr(audio), _ptr(pcm)))
+        return audio, pcm
+
+    def h_demodulate_signal(self, mode, iq, fs):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        n_out = self.demod_out_len(mode, len(iq), fs)
+        if n_out < 0:
+            raise ValueError("sample rate below 22050 Hz or unknown mode")
+        audio = np.empty((n_out, 2), np.float64)
+        pcm = np.empty((n_out, 2), np.int16)
+        self._ck(self.lib.pss_h_demodulate_signal(self.h, mode, _ptr(iq), len(iq), float(fs), _ptr(audio), _ptr(pcm)))
         return audio, pcm
 
     def h_iq_correction(self, iq):

@@ -6,6 +6,7 @@ the reference's main loop imports with `from signal_processing import *` (pyspec
     compute_fft(samples)                                   signal_processing.py:243-264  -> float64 (N,), writable
     demodulate_signal(samples, sample_rate, mode='NFM')    :220-240
     demodulate_nfm(samples, sample_rate, target_rate=...)  :91-116   -> float64 (n_out, 2)
+    demodulate_wfm(samples, sample_rate, target_rate=...)  :119-176  -> float64 (n_out, 2), left/right
     demodulate_am(samples)                                 :179-195  -> float64 (N, 2)
     demodulate_ssb(samples, sample_rate, lower=True)       :198-217  -> float64 (N, 2)
     measure_signal_power(samples)                          :325-328  -> np.float32
@@ -13,9 +14,8 @@ the reference's main loop imports with `from signal_processing import *` (pyspec
 
     iq_correction(samples)                                 :46-80    -> complex64 (N,)  ('RAW' mode = its real part)
 
-Every call runs on the GPU through the C ABI; there is no NumPy/SciPy compute path here.  WFM (:119-176) and
-classify_signal (broken in the reference) are not part of the accelerated path and raise
-NotImplementedError.
+Every call runs on the GPU through the C ABI; there is no NumPy/SciPy compute path here.  classify_signal (broken in
+the reference) is not part of the accelerated path.
 """
 import numpy as np
 
@@ -33,6 +33,43 @@ def get_engine(device=0):
     if _engine is None:
         _engine = Engine(device)
     return _engine
+
+
+# ---- coefficient tables --------------------------------------------------------------------------------------------
+# The reference designs its filters with SciPy on every call; libpss.so designs them natively once per sample rate
+# (pss_design_*), which lands within a few ulp of SciPy (NumPy evaluates tan/asinh through SVML, glibc differs in the
+# last bit).  A host that runs the reference has SciPy by definition, so this shim asks THAT SciPy for the tables once
+# per sample rate and injects them (pss_set_*_filters): the GPU path then reproduces the reference's float64 bits
+# whatever SciPy version the host carries.  Only the coefficient design happens here — never sample data.
+USE_SCIPY_DESIGNS = True
+_designed = set()
+
+
+def _inject_designs(kind, fs):
+    key = (kind, float(fs))
+    if not USE_SCIPY_DESIGNS or key in _designed:
+        return
+    try:
+        import scipy.signal as ss
+    except ImportError:
+        _designed.add(key)
+        return
+    e = get_engine()
+    fs = float(fs)
+    q = int(fs / DEFAULT_SAMPLE_RATE)
+    if kind == 'wfm':
+        nyq = fs / 2
+        lp = ss.butter(BUTTER_ORDER, 15000 / nyq, btype='low', output='sos')                     # :126 -> :39
+        pil = ss.butter(BUTTER_ORDER, [18800 / nyq, 19200 / nyq], btype='band', output='sos')    # :129 -> :41
+        lmr = ss.butter(BUTTER_ORDER, [23000 / nyq, 53000 / nyq], btype='band', output='sos')    # :133
+        e.set_wfm_filters(fs, lp, pil, lmr, float(np.exp(-1 / (75e-6 * fs))))                    # :145
+    if kind in ('nfm', 'wfm') and q > 1:
+        taps = ss.firwin(numtaps=65, cutoff=15000 / (fs / 2))                 # :107 (ValueError as in the reference)
+        sos = ss.cheby1(8, 0.05, 0.8 / q, output='sos')                       # decimate(), scipy _signaltools.py
+        e.set_nfm_filters(fs, taps, sos, ss.sosfilt_zi(sos))
+    if kind == 'ssb':
+        e.set_ssb_taps(fs, ss.firwin(65, 3000 / fs, window='hamming'))                           # :203/:208
+    _designed.add(key)
 
 
 def _samples(samples):
@@ -61,7 +98,18 @@ def compute_fft(samples):
 def demodulate_nfm(samples, sample_rate, target_rate=DEFAULT_SAMPLE_RATE):
     if target_rate != DEFAULT_SAMPLE_RATE:
         raise NotImplementedError("only the reference's fixed target_rate=22050 is accelerated")
+    _inject_designs('nfm', sample_rate)
     audio, _ = get_engine().h_demodulate(L.MODE_NFM, _samples(samples), sample_rate)
+    return audio
+
+
+def demodulate_wfm(samples, sample_rate, target_rate=DEFAULT_SAMPLE_RATE):
+    """signal_processing.py:119-176 -> float64 (n_out, 2) = column_stack((left, right)).  (The reference's RDS hooks at
+    :165-174 call undefined names inside a try/except and never produce anything; nothing to mirror.)"""
+    if target_rate != DEFAULT_SAMPLE_RATE:
+        raise NotImplementedError("only the reference's fixed target_rate=22050 is accelerated")
+    _inject_designs('wfm', sample_rate)
+    audio, _ = get_engine().h_demodulate(L.MODE_WFM, _samples(samples), sample_rate)
     return audio
 
 
@@ -71,6 +119,7 @@ def demodulate_am(samples):
 
 
 def demodulate_ssb(samples, sample_rate, lower=True):
+    _inject_designs('ssb', sample_rate)
     audio, _ = get_engine().h_demodulate(L.MODE_LSB if lower else L.MODE_USB, _samples(samples), sample_rate)
     return audio
 
@@ -88,15 +137,19 @@ def demodulate_signal(samples, sample_rate, mode='NFM'):
         # :222-225 + :238 — every non-voice mode is IQ-corrected first; RAW then returns the I samples (float32)
         return get_engine().h_raw(_samples(samples))
     elif mode == 'WFM':
-        raise NotImplementedError("mode 'WFM' (stereo/RDS chain, signal_processing.py:119-176) is not accelerated yet")
+        _inject_designs('wfm', sample_rate)
+        audio, _ = get_engine().h_demodulate_signal(L.MODE_WFM, _samples(samples), sample_rate)  # :222-228
+        return audio
     return np.zeros((len(samples), 2))  # unknown mode -> silence of shape (n, 2), as the reference
 
 
 def demodulate_pcm(samples, sample_rate, mode='NFM'):
     """int16 (n_out, 2) exactly as io_manager.write_to_pipe would produce from demodulate_signal()'s output."""
-    m = {'NFM': L.MODE_NFM, 'AM': L.MODE_AM, 'USB': L.MODE_USB, 'LSB': L.MODE_LSB}[mode]
+    m = {'NFM': L.MODE_NFM, 'AM': L.MODE_AM, 'USB': L.MODE_USB, 'LSB': L.MODE_LSB, 'WFM': L.MODE_WFM}[mode]
     fs = float(DEFAULT_SAMPLE_RATE) if mode == 'AM' else sample_rate
-    _, pcm = get_engine().h_demodulate(m, _samples(samples), fs)
+    if mode != 'AM':
+        _inject_designs({'NFM': 'nfm', 'WFM': 'wfm'}.get(mode, 'ssb'), fs)
+    _, pcm = get_engine().h_demodulate_signal(m, _samples(samples), fs)
     return pcm
 
 
