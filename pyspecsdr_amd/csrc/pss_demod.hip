@@ -750,35 +750,39 @@ struct PlanDev {
     const int *leaf_off, *leaf_len, *node_l, *node_r, *level_start;
     int n_leaves, n_levels;
 };
-#define IQC_TPB 256
+// A leaf of numpy's tree is <= 128 elements summed into 8 running accumulators; those 8 partial sums are independent,
+// so a lane owns one (leaf, accumulator) pair — at n = 1024 that is exactly one wavefront per frame — and one lane per
+// leaf then folds the 8 partials and the < 8 tail elements in numpy's order.  part: 8 floats per leaf.
 template <class F>
-__device__ __forceinline__ float wg_rsum(const PlanDev &p, float *val, F elem)
+__device__ __forceinline__ float wg_rsum(const PlanDev &p, float *part, float *val, F elem)
 {
-    const int tid = threadIdx.x;
-    for (int l = tid; l < p.n_leaves; l += IQC_TPB) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int slot = tid; slot < p.n_leaves * 8; slot += T) {
+        const int l = slot >> 3, k = slot & 7, off = p.leaf_off[l], len = p.leaf_len[l];
+        if (len >= 8) {
+            float r = elem(off + k);
+            for (int i = 8; i < len - (len % 8); i += 8) r = __fadd_rn(r, elem(off + i + k));
+            part[slot] = r;
+        }
+    }
+    __syncthreads();
+    for (int l = tid; l < p.n_leaves; l += T) {
         const int off = p.leaf_off[l], len = p.leaf_len[l];
         float res;
         if (len < 8) {
             res = 0.0f;
             for (int i = 0; i < len; i++) res = __fadd_rn(res, elem(off + i));
         } else {
-            float r[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) r[k] = elem(off + k);
-            int i;
-            for (i = 8; i < len - (len % 8); i += 8) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) r[k] = __fadd_rn(r[k], elem(off + i + k));
-            }
+            const float *r = part + 8 * l;
             res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
                             __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
-            for (; i < len; i++) res = __fadd_rn(res, elem(off + i));
+            for (int i = len - (len % 8); i < len; i++) res = __fadd_rn(res, elem(off + i));
         }
         val[l] = res;
     }
     __syncthreads();
     for (int lv = 0; lv < p.n_levels; lv++) {
-        for (int k = p.level_start[lv] + tid; k < p.level_start[lv + 1]; k += IQC_TPB)
+        for (int k = p.level_start[lv] + tid; k < p.level_start[lv + 1]; k += T)
             val[p.n_leaves + k] = __fadd_rn(val[p.node_l[k]], val[p.node_r[k]]);
         __syncthreads();
     }
@@ -787,39 +791,42 @@ __device__ __forceinline__ float wg_rsum(const PlanDev &p, float *val, F elem)
     __syncthreads();
     return sum;
 }
-// complex64 reduce: elem(ci) -> float2 of complex element ci; leaves are float ranges of the interleaved array
+// complex64 reduce: elem(ci) -> float2 of complex element ci; leaves are float ranges of the interleaved array, the 8
+// float accumulators are 4 complex ones: a lane owns one (leaf, complex accumulator) pair.  part: 4 float2 per leaf.
 template <class F>
-__device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *val, F elem)
+__device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *part, float2 *val, F elem)
 {
-    const int tid = threadIdx.x;
-    for (int l = tid; l < p.n_leaves; l += IQC_TPB) {
-        const int off = p.leaf_off[l] >> 1, len = p.leaf_len[l];  // off in complex elements, len in floats
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int slot = tid; slot < p.n_leaves * 4; slot += T) {
+        const int l = slot >> 2, k = slot & 3, off = p.leaf_off[l] >> 1, len = p.leaf_len[l];  // off: complex, len: floats
+        if (len >= 8) {
+            float2 r = elem(off + k);
+            for (int i = 8; i < len - (len % 8); i += 8) {
+                const float2 v = elem(off + (i >> 1) + k);
+                r.x = __fadd_rn(r.x, v.x);
+                r.y = __fadd_rn(r.y, v.y);
+            }
+            part[slot] = r;
+        }
+    }
+    __syncthreads();
+    for (int l = tid; l < p.n_leaves; l += T) {
+        const int off = p.leaf_off[l] >> 1, len = p.leaf_len[l];
         float rr, ri;
         if (len < 8) {
             rr = 0.0f; ri = 0.0f;
-            for (int i = 0; i < len; i += 2) { float2 v = elem(off + (i >> 1)); rr = __fadd_rn(rr, v.x); ri = __fadd_rn(ri, v.y); }
+            for (int i = 0; i < len; i += 2) { const float2 v = elem(off + (i >> 1)); rr = __fadd_rn(rr, v.x); ri = __fadd_rn(ri, v.y); }
         } else {
-            float2 r[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = elem(off + k);
-            int i;
-            for (i = 8; i < len - (len % 8); i += 8) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    float2 v = elem(off + (i >> 1) + k);
-                    r[k].x = __fadd_rn(r[k].x, v.x);
-                    r[k].y = __fadd_rn(r[k].y, v.y);
-                }
-            }
+            const float2 *r = part + 4 * l;
             rr = __fadd_rn(__fadd_rn(r[0].x, r[1].x), __fadd_rn(r[2].x, r[3].x));
             ri = __fadd_rn(__fadd_rn(r[0].y, r[1].y), __fadd_rn(r[2].y, r[3].y));
-            for (; i < len; i += 2) { float2 v = elem(off + (i >> 1)); rr = __fadd_rn(rr, v.x); ri = __fadd_rn(ri, v.y); }
+            for (int i = len - (len % 8); i < len; i += 2) { const float2 v = elem(off + (i >> 1)); rr = __fadd_rn(rr, v.x); ri = __fadd_rn(ri, v.y); }
         }
         val[l] = make_float2(rr, ri);
     }
     __syncthreads();
     for (int lv = 0; lv < p.n_levels; lv++) {
-        for (int k = p.level_start[lv] + tid; k < p.level_start[lv + 1]; k += IQC_TPB) {
+        for (int k = p.level_start[lv] + tid; k < p.level_start[lv + 1]; k += T) {
             const float2 a = val[p.node_l[k]], b = val[p.node_r[k]];
             val[p.n_leaves + k] = make_float2(__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y));
         }
@@ -831,63 +838,74 @@ __device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *val, F elem)
     return sum;
 }
 
-__global__ __launch_bounds__(IQC_TPB) void k_iqcorr(const float2 *__restrict__ iq, int n, long n_frames, PlanDev rp,
-                                                    PlanDev cp, float2 *__restrict__ out, float *__restrict__ raw)
+// STAGED: the frame is copied to LDS once and every pass reads it from there (frames up to 16384 samples).
+// LDS: [frame: n float2 if STAGED][part: part_slots float2][val: val_slots float2]
+template <bool STAGED>
+__global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, int n, long n_frames, PlanDev rp, PlanDev cp,
+                                                int part_slots, float2 *__restrict__ out, float *__restrict__ raw)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    float *rval = reinterpret_cast<float *>(smem);
-    float2 *cval = reinterpret_cast<float2 *>(smem);
+    float2 *xs = reinterpret_cast<float2 *>(smem);
+    float2 *cpart = xs + (STAGED ? n : 0), *cval = cpart + part_slots;
+    float *rpart = reinterpret_cast<float *>(cpart), *rval = reinterpret_cast<float *>(cval);
     const float fn = (float)n;
+    const int T = blockDim.x;
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
-        const float2 *x = iq + (size_t)f * n;
+        const float2 *xg = iq + (size_t)f * n;
+        if (STAGED) {
+            for (int i = threadIdx.x; i < n; i += T) xs[i] = xg[i];
+            __syncthreads();
+        }
+        auto X = [&](int i) { return STAGED ? xs[i] : xg[i]; };
         // :48 centered = samples - mean(samples)
-        float2 s = wg_csum(cp, cval, [&](int i) { return x[i]; });
+        float2 s = wg_csum(cp, cpart, cval, X);
         const float mr = __fdiv_rn(s.x, fn), mi = __fdiv_rn(s.y, fn);
         // :49 input_power = var(centered): mean again, |.|^2 with the FMA form of numpy's complex multiply, mean
-        s = wg_csum(cp, cval, [&](int i) { float2 v = x[i]; return make_float2(__fsub_rn(v.x, mr), __fsub_rn(v.y, mi)); });
+        s = wg_csum(cp, cpart, cval, [&](int i) { float2 v = X(i); return make_float2(__fsub_rn(v.x, mr), __fsub_rn(v.y, mi)); });
         const float m2r = __fdiv_rn(s.x, fn), m2i = __fdiv_rn(s.y, fn);
-        const float input_power = __fdiv_rn(wg_rsum(rp, rval, [&](int i) {
-            float2 v = x[i];
+        const float input_power = __fdiv_rn(wg_rsum(rp, rpart, rval, [&](int i) {
+            float2 v = X(i);
             const float dr = __fsub_rn(__fsub_rn(v.x, mr), m2r), di = __fsub_rn(__fsub_rn(v.y, mi), m2i);
             return __fmaf_rn(dr, dr, __fmul_rn(di, di));
         }), fn);
         // :52 q_amplitude
-        const float qa = sqrtf(__fmul_rn(2.0f, __fdiv_rn(wg_rsum(rp, rval, [&](int i) { float q = x[i].y; return __fmul_rn(q, q); }), fn)));
+        const float qa = sqrtf(__fmul_rn(2.0f, __fdiv_rn(wg_rsum(rp, rpart, rval, [&](int i) { float q = X(i).y; return __fmul_rn(q, q); }), fn)));
         const float scl = __fdiv_rn(1.0f, qa);  // :55 complex64 / float32 scalar multiplies by the reciprocal
         // :60-61 alpha, sin(phi)
-        const float alpha = sqrtf(__fmul_rn(2.0f, __fdiv_rn(wg_rsum(rp, rval, [&](int i) {
-            const float is = __fmul_rn(x[i].x, scl);
+        const float alpha = sqrtf(__fmul_rn(2.0f, __fdiv_rn(wg_rsum(rp, rpart, rval, [&](int i) {
+            const float is = __fmul_rn(X(i).x, scl);
             return __fmul_rn(is, is);
         }), fn)));
-        const float sinphi = __fmul_rn(__fdiv_rn(2.0f, alpha), __fdiv_rn(wg_rsum(rp, rval, [&](int i) {
-            float2 v = x[i];
+        const float sinphi = __fmul_rn(__fdiv_rn(2.0f, alpha), __fdiv_rn(wg_rsum(rp, rpart, rval, [&](int i) {
+            float2 v = X(i);
             return __fmul_rn(__fmul_rn(v.x, scl), __fmul_rn(v.y, scl));
         }), fn));
         const float cosphi = sqrtf(__fsub_rn(1.0f, __fmul_rn(sinphi, sinphi)));  // :64
         const float ia = __fdiv_rn(1.0f, alpha), qa2 = __fdiv_rn(-sinphi, alpha), sc = __fdiv_rn(1.0f, cosphi);
         auto corrected = [&](int i) {  // :67-71 (the 1j*q_new complex multiply only touches the sign of zeros)
-            float2 v = x[i];
+            float2 v = X(i);
             const float is = __fmul_rn(v.x, scl), qs = __fmul_rn(v.y, scl);
             const float i_new = __fmul_rn(ia, is), q_new = __fadd_rn(__fmul_rn(qa2, is), qs);
             const float jr = __fmaf_rn(0.0f, q_new, -0.0f), ji = __fmaf_rn(0.0f, 0.0f, q_new);
             return make_float2(__fmul_rn(__fadd_rn(i_new, jr), sc), __fmul_rn(__fadd_rn(0.0f, ji), sc));
         };
         // :80 var(corrected), rescale to the input power
-        s = wg_csum(cp, cval, corrected);
+        s = wg_csum(cp, cpart, cval, corrected);
         const float m3r = __fdiv_rn(s.x, fn), m3i = __fdiv_rn(s.y, fn);
-        const float v2 = __fdiv_rn(wg_rsum(rp, rval, [&](int i) {
+        const float v2 = __fdiv_rn(wg_rsum(rp, rpart, rval, [&](int i) {
             float2 c = corrected(i);
             const float dr = __fsub_rn(c.x, m3r), di = __fsub_rn(c.y, m3i);
             return __fmaf_rn(dr, dr, __fmul_rn(di, di));
         }), fn);
         const float g = sqrtf(__fdiv_rn(input_power, v2));
-        for (int i = threadIdx.x; i < n; i += IQC_TPB) {
+        for (int i = threadIdx.x; i < n; i += T) {
             float2 c = corrected(i);
             c.x = __fmul_rn(c.x, g);
             c.y = __fmul_rn(c.y, g);
             if (out) out[(size_t)f * n + i] = c;
             if (raw) raw[(size_t)f * n + i] = c.x;  // demodulate_signal(..., 'RAW'): np.real(samples) (:238)
         }
+        __syncthreads();  // xs is overwritten by the next frame
     }
 }
 
@@ -1171,20 +1189,27 @@ extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames,
     if (r) return r;
     r = get_plan(ctx, n, &cp, true);
     if (r) return r;
-    size_t l1 = sizeof(float) * (size_t)(rp->n_leaves + rp->n_nodes + 1);
-    size_t l2 = sizeof(float2) * (size_t)(cp->n_leaves + cp->n_nodes + 1);
-    size_t lds = l1 > l2 ? l1 : l2;
+    // LDS: partial sums (8 floats | 4 float2 per leaf) + tree values, optionally the frame itself
+    size_t part_slots = (size_t)(rp->n_leaves * 4 > cp->n_leaves * 4 ? rp->n_leaves * 4 : cp->n_leaves * 4);  // in float2
+    size_t val_slots = (size_t)(rp->n_leaves + rp->n_nodes > cp->n_leaves + cp->n_nodes ? rp->n_leaves + rp->n_nodes
+                                                                                          : cp->n_leaves + cp->n_nodes) + 1;
+    const bool staged = n <= 16384 && (part_slots + val_slots + (size_t)n) * sizeof(float2) <= 150 * 1024;
+    size_t lds = (part_slots + val_slots + (staged ? (size_t)n : 0)) * sizeof(float2);
     if (lds > 150 * 1024) return pss_fail(ctx, PSS_E_ARG, "frame too long for the iq_correction kernel");
+    auto kern = staged ? k_iqcorr<true> : k_iqcorr<false>;
     if (lds > 64 * 1024)
-        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_iqcorr), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds));
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PlanDev a{rp->d_leaf_off, rp->d_leaf_len, rp->d_node_l, rp->d_node_r, rp->d_level_start, rp->n_leaves, rp->n_levels};
     PlanDev b{cp->d_leaf_off, cp->d_leaf_len, cp->d_node_l, cp->d_node_r, cp->d_level_start, cp->n_leaves, cp->n_levels};
-    long g = n_frames < 16384 ? n_frames : 16384;
+    const int lanes = rp->n_leaves * 8 > cp->n_leaves * 4 ? rp->n_leaves * 8 : cp->n_leaves * 4;
+    const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);  // one lane per (leaf, accumulator) pair
+    long g = n_frames < 65536 ? n_frames : 65536;
+    pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_iqcorr");
-    hipLaunchKernelGGL(k_iqcorr, dim3((int)g), dim3(IQC_TPB), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n,
-                       n_frames, a, b, reinterpret_cast<float2 *>(d_out_iq), d_raw);
+    hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, a, b,
+                       (int)part_slots, reinterpret_cast<float2 *>(d_out_iq), d_raw);
     pss_kernel_end(ctx);
+    pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_iqcorr launch");
 }
 

@@ -78,6 +78,29 @@ def test_designer_matches_scipy(golden, fs):
     assert np.array_equal(zi2, g["design_zi_" + key])
 
 
+@pytest.mark.parametrize("fs", [1.024e6, 2.4e6, 10e6, 2.048e6, 250e3])
+def test_butter_designer_matches_scipy(golden, fs):
+    """pss_design_butter_sos vs scipy.signal.butter(5, ..., output='sos') for the three WFM filters (:126-133): same
+    section order / zero pairing, coefficients within a few ulp."""
+    import ctypes as C
+    g = golden["wfm"]
+    lib = L.load()
+    key, nyq = str(int(fs)), fs / 2
+    for name, lo, hi, ns in (("lp_sos", 0.0, 15000.0, 3), ("pilot_sos", 18800.0, 19200.0, 5), ("lmr_sos", 23000.0, 53000.0, 5)):
+        sos, n = np.zeros((ns, 6)), C.c_int()
+        assert lib.pss_design_butter_sos(5, lo / nyq, hi / nyq, sos.ctypes.data, C.addressof(n)) == 0
+        ref = g[f"{name}_{key}"]
+        assert n.value == ns == ref.shape[0]
+        exact = (ref == 0) | (np.abs(ref) == 1) | (np.abs(ref) == 2)       # structural entries (zeros at +-1, 0)
+        assert np.array_equal(sos[exact], ref[exact])
+        assert ulps(sos, ref) <= 16
+    sos = np.zeros((5, 6))
+    assert lib.pss_design_butter_sos(5, 300 / 11025, 3000 / 11025, sos.ctypes.data, None) == 0
+    assert ulps(sos, golden["am_ssb"]["am_sos"]) <= 16
+    assert lib.pss_design_butter_sos(5, 0.0, 1.06, sos.ctypes.data, None) == L.PSS_E_CUTOFF   # scipy: 0 < Wn < 1
+    assert lib.pss_design_butter_sos(5, 0.5, 0.4, sos.ctypes.data, None) == L.PSS_E_CUTOFF
+
+
 def test_am_table_is_scipy_butter(golden):
     sos = np.empty((5, 6))
     L.load().pss_am_bandpass_sos(sos.ctypes.data)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the library on the other BASELINE.json configs (device-resident inputs, HIP-event kernel times).
 
-    python tools/bench_configs.py [cfg3] [cfg4] [cfg5] [big]
+    python tools/bench_configs.py [cfg3] [cfg4] [cfg5] [cfg5stream] [big] [wfm]
 """
 import json
 import sys
@@ -111,6 +111,19 @@ def big():
     pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
     out.append(timed("demod NFM 32768 x4096", lambda: eng.demod(L.MODE_NFM, iq, nf, n, fs, pcm, None), reps=2))
     return {"config": "reference-default buffer sizes", "calls": out}
+
+
+def wfm():
+    """The reference's default mode (pyspecsdr.py --demod WFM): iq_correction + demodulate_wfm, cfg2-sized batch."""
+    nf, n, fs = 65536, 1024, 2.4e6
+    iq = rand_iq(nf, n)
+    n_out = eng.demod_out_len(L.MODE_WFM, n, fs)
+    pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
+    corr = torch.empty((nf, n, 2), dtype=torch.float32, device=dev)
+    out = [timed("iq_correction 1024", lambda: eng.iq_correction(iq, nf, n, corr, None)),
+           timed("demod_signal WFM", lambda: eng.demod_signal(L.MODE_WFM, iq, nf, n, fs, pcm, None), reps=3)]
+    return {"config": "WFM 65536 x 1024 @2.4 MS/s (device-resident)", "calls": out,
+            "samples_per_s": nf * n / (out[1]["wall_ms"] * 1e-3)}
 
 
 if __name__ == "__main__":
