@@ -48,6 +48,7 @@ struct pss_ctx {
     size_t scratch_fft_bytes = 0;
     void *stage = nullptr;         // device staging of the host-buffer convenience calls (grow-only)
     size_t stage_bytes = 0;
+    bool no_wfm_fused = false;  // option "wfm_fused" = 0: k_wfm_front + k_nfm_iir path (A/B testing)
     bool no_fused = false;  // PSS_NO_FUSED=1: use the three-kernel NFM path (A/B and fallback testing)
     bool timing = false;
     int tdepth = 0;

@@ -921,6 +921,44 @@ __device__ __forceinline__ double lfilter1(double b0, double a1, double x, doubl
     z = __dsub_rn(__dmul_rn(x, 0.0), __dmul_rn(y, a1));
     return y;
 }
+// Numerator shapes of SciPy's Butterworth SOS rows (zpk2sos 'nearest' pairing puts the zeros at +-1 / 0 the same way
+// at every sample rate): multiplications by 1, 2, -1, -2 are exact and are dropped; a zero coefficient keeps its
+// multiply (0*x carries the sign of x into a -0.0).  NUM_GEN is sosfilt's step verbatim.
+enum { NUM_GEN = 0, NUM_121 = 1, NUM_10M1 = 2, NUM_1M21 = 3, NUM_110 = 4 };
+template <int K>
+__device__ __forceinline__ double biquad_num(const Biquad &c, double x, double &z0, double &z1)
+{
+    if (K == NUM_GEN) return biquad_step(c, x, z0, z1);
+    const double xn = __dadd_rn(x, z0);                                     // b0 = 1
+    const double t = __dmul_rn(c.a1, xn), u = __dmul_rn(c.a2, xn);
+    double v, w;
+    if (K == NUM_121) { v = __dadd_rn(x, x); w = x; }
+    else if (K == NUM_1M21) { v = -__dadd_rn(x, x); w = x; }
+    else if (K == NUM_10M1) { v = __dmul_rn(c.b1, x); w = -x; }
+    else { v = x; w = __dmul_rn(c.b2, x); }                                 // NUM_110
+    z0 = __dadd_rn(__dsub_rn(v, t), z1);
+    z1 = __dsub_rn(w, u);
+    return xn;
+}
+template <bool SPEC>
+__device__ __forceinline__ double wfm_lp(const Biquad *c, double x, double *z)
+{
+    x = biquad_num<NUM_GEN>(c[0], x, z[0], z[1]);
+    x = biquad_num<SPEC ? NUM_121 : NUM_GEN>(c[1], x, z[2], z[3]);
+    return biquad_num<SPEC ? NUM_110 : NUM_GEN>(c[2], x, z[4], z[5]);
+}
+template <bool SPEC>
+__device__ __forceinline__ double wfm_bp(const Biquad *c, double x, double *z)
+{
+    x = biquad_num<NUM_GEN>(c[0], x, z[0], z[1]);
+    x = biquad_num<SPEC ? NUM_121 : NUM_GEN>(c[1], x, z[2], z[3]);
+    x = biquad_num<SPEC ? NUM_10M1 : NUM_GEN>(c[2], x, z[4], z[5]);
+    x = biquad_num<SPEC ? NUM_1M21 : NUM_GEN>(c[3], x, z[6], z[7]);
+    return biquad_num<SPEC ? NUM_1M21 : NUM_GEN>(c[4], x, z[8], z[9]);
+}
+
+constexpr int WFM_CH = 8;   // input samples prefetched per chunk (each lane walks its own row)
+template <bool SPEC>
 __global__ __launch_bounds__(TILE) void k_wfm_front(const float2 *__restrict__ iq, double *U, int n, long n_frames,
                                                     long Lp, int swapped, WfmCoef c)
 {
@@ -936,26 +974,42 @@ __global__ __launch_bounds__(TILE) void k_wfm_front(const float2 *__restrict__ i
     double zp1 = 0.0, zdl = 0.0, zdr = 0.0;
     const double SIN_PI = 0x1.1a62633145c07p-53;  // np.sin(np.pi)
     float2 prev = x[0];
-    for (int i = 0; i < M; i++) {
-        const float2 cur = x[i + 1];
+    auto step = [&](int i, float2 cur) {
         const double d = (double)disc_sample(cur, prev, 1.0f, swapped != 0);  // :122 (x1.0f is exact)
         prev = cur;
-        double a = d, p = d, m = d;
-#pragma unroll
-        for (int s2 = 0; s2 < 3; s2++) a = biquad_step(c.lp[s2], a, zlp[2 * s2], zlp[2 * s2 + 1]);     // :126
-#pragma unroll
-        for (int s2 = 0; s2 < 5; s2++) p = biquad_step(c.pil[s2], p, zpi[2 * s2], zpi[2 * s2 + 1]);    // :129
-#pragma unroll
-        for (int s2 = 0; s2 < 5; s2++) m = biquad_step(c.lmr[s2], m, zlm[2 * s2], zlm[2 * s2 + 1]);    // :133
+        const double a = wfm_lp<SPEC>(c.lp, d, zlp);                                                   // :126
+        const double p = wfm_bp<SPEC>(c.pil, d, zpi);                                                  // :129
+        double m = wfm_bp<SPEC>(c.lmr, d, zlm);                                                        // :133
         const double y = lfilter1(1.0, -0.99, p, zp1);                                                 // :130
         const double pil = (y != y) ? y : ((y < 0.0 || (y == 0.0 && __builtin_signbit(y))) ? SIN_PI : 0.0);
         m = __dmul_rn(m, __dmul_rn(2.0, pil));                                                         // :134
-#pragma unroll
-        for (int s2 = 0; s2 < 3; s2++) m = biquad_step(c.lp[s2], m, zl2[2 * s2], zl2[2 * s2 + 1]);     // :137
+        m = wfm_lp<SPEC>(c.lp, m, zl2);                                                                // :137
         const double l = __dmul_rn(__dadd_rn(a, m), 0.5), r = __dmul_rn(__dsub_rn(a, m), 0.5);         // :140-141 (/2 exact)
         const double yl = lfilter1(c.b0d, c.a1d, l, zdl), yr = lfilter1(c.b0d, c.a1d, r, zdr);         // :148-149
         if (live) { UL[EDGE + i] = yl; UR[EDGE + i] = yr; }
+    };
+    // x[1 + i], i = 0..M-1, in chunks of WFM_CH with the next chunk's loads in flight (x + 1 is 8-byte aligned only)
+    float2 b0[WFM_CH], b1[WFM_CH];
+    auto loadc = [&](float2 (&b)[WFM_CH], int i0) {
+#pragma unroll
+        for (int t = 0; t < WFM_CH; t++) b[t] = x[1 + i0 + t];
+    };
+    const int nfull = M / WFM_CH;
+    int i = 0;
+    if (nfull > 0) loadc(b0, 0);
+    for (int ch = 0; ch < nfull; ch += 2) {
+        if (ch + 1 < nfull) loadc(b1, i + WFM_CH);
+#pragma unroll
+        for (int t = 0; t < WFM_CH; t++) step(i + t, b0[t]);
+        i += WFM_CH;
+        if (ch + 1 < nfull) {
+            if (ch + 2 < nfull) loadc(b0, i + WFM_CH);
+#pragma unroll
+            for (int t = 0; t < WFM_CH; t++) step(i + t, b1[t]);
+            i += WFM_CH;
+        }
     }
+    for (; i < M; i++) step(i, x[i + 1]);
     if (!live) return;
     // odd extension (scipy _arraytools.odd_ext) of both rows, from this lane's own stores
     __threadfence_block();
@@ -971,19 +1025,21 @@ __global__ __launch_bounds__(TILE) void k_wfm_front(const float2 *__restrict__ i
 
 // :157-163 — joint peak normalisation of the two decimated channels, column_stack, and the int16 conversion.
 // A: k_nfm_iir's transposed decimated rows ([tile][k][lane], row g = 2f + channel); mxrow[g] = max|row g| (NaN kept).
+// planar: rows are [2*tile + channel][lane] (fused forward kernel) instead of 2f + channel (k_wfm_front).
 __global__ __launch_bounds__(TPB) void k_wfm_finalize(const double *__restrict__ A, const double *__restrict__ mxrow,
-                                                      int n_out, long n_frames, int16_t *__restrict__ pcm,
+                                                      int n_out, long n_frames, int planar, int16_t *__restrict__ pcm,
                                                       double *__restrict__ audio)
 {
     const size_t total = (size_t)n_frames * n_out;
     for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
         const long f = (long)(idx / n_out);
         const int k = (int)(idx - (size_t)f * n_out);
-        const long g = 2 * f;
-        const double ml = mxrow[g], mr = mxrow[g + 1];
+        const long gl = planar ? (f / TILE) * 2 * TILE + (f % TILE) : 2 * f, gr = planar ? gl + TILE : gl + 1;
+        const double ml = mxrow[gl], mr = mxrow[gr];
         const double mx = (mr > ml) ? mr : ml;  // python max(a, b): b only if b > a
-        const double *At = A + (size_t)(g / TILE) * n_out * TILE + (size_t)k * TILE + (g % TILE);
-        const double l = __ddiv_rn(At[0], mx), r = __ddiv_rn(At[1], mx);
+        const double vl = A[(size_t)(gl / TILE) * n_out * TILE + (size_t)k * TILE + (gl % TILE)];
+        const double vr = A[(size_t)(gr / TILE) * n_out * TILE + (size_t)k * TILE + (gr % TILE)];
+        const double l = __ddiv_rn(vl, mx), r = __ddiv_rn(vr, mx);
         if (audio) { audio[2 * idx] = l; audio[2 * idx + 1] = r; }
         if (pcm) {
             const uint16_t a = (uint16_t)pcm16(l), b = (uint16_t)pcm16(r);
@@ -991,6 +1047,10 @@ __global__ __launch_bounds__(TPB) void k_wfm_finalize(const double *__restrict__
         }
     }
 }
+
+}  // namespace
+#include "pss_wfm_fused.h"
+namespace {
 
 // adjust_gain (pyspecsdr.py:898-919), sequential by nature.
 __global__ void k_agc(const float *__restrict__ power, long n, int idx, int n_gains, int *__restrict__ out)
@@ -1414,10 +1474,11 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const long L = (long)(n - 1) + 2 * EDGE;
         const long Lp = (L + 1) & ~1L;
         const size_t szU = align256((size_t)rows * Lp * sizeof(double));
-        const size_t szY = align256((size_t)tiles2 * L * TILE * sizeof(double));
-        const size_t szA = align256((size_t)tiles2 * n_out * TILE * sizeof(double));
-        const size_t szM = align256((size_t)rows * sizeof(double));
-        r = pss_ensure_scratch(ctx, szU + szY + szA + szM);
+        const long T2 = 2 * tiles;  // the fused path keeps the channels of a tile in two separate row blocks (T2 >= tiles2)
+        const size_t szY = align256((size_t)T2 * L * TILE * sizeof(double));
+        const size_t szA = align256((size_t)T2 * n_out * TILE * sizeof(double));
+        const size_t szM = align256((size_t)T2 * TILE * sizeof(double));
+        r = pss_ensure_scratch(ctx, (ctx->no_wfm_fused ? szU : 0) + szY + szA + szM);
         if (r) return r;
         char *base = reinterpret_cast<char *>(ctx->scratch);
         double *U = reinterpret_cast<double *>(base), *Y = reinterpret_cast<double *>(base + szU);
@@ -1436,9 +1497,42 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         for (int s2 = 1; s2 < 4; s2++)
             b121 = b121 && flt->sos[6 * s2] == 1.0 && flt->sos[6 * s2 + 1] == 2.0 && flt->sos[6 * s2 + 2] == 1.0;
         const int swapped = ((long)(n - 1) * 8 >= 262144) ? 1 : 0;
+        // SciPy's zero pairing gives every Butterworth SOS the same numerator shapes; anything else takes the generic steps
+        auto is_num = [](const double *row, double b0, double b1, double b2) { return row[0] == b0 && row[1] == b1 && row[2] == b2; };
+        bool spec = is_num(wf->lp + 6, 1, 2, 1) && is_num(wf->lp + 12, 1, 1, 0);
+        for (const double *bp : {wf->pilot, wf->lmr})
+            spec = spec && is_num(bp + 6, 1, 2, 1) && is_num(bp + 12, 1, 0, -1) && is_num(bp + 18, 1, -2, 1) && is_num(bp + 24, 1, -2, 1);
         pss_time_begin(ctx);
+        if (!ctx->no_wfm_fused) {
+            // fused path: forward decimator pass inside the front kernel, y_fwd planar-transposed, u[] never stored
+            double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);
+            double *MXf = reinterpret_cast<double *>(base + szY + szA);
+            auto kf = spec ? (b121 ? wfmf::k_wfm_fwd<true, true> : wfmf::k_wfm_fwd<true, false>)
+                           : (b121 ? wfmf::k_wfm_fwd<false, true> : wfmf::k_wfm_fwd<false, false>);
+            pss_kernel_begin(ctx, "k_wfm_fwd");
+            hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(TILE), wfmf::LDS_BYTES, PSS_STREAM(ctx),
+                               reinterpret_cast<const float2 *>(d_iq), Yf, n, n_frames, swapped, wc, c);
+            pss_kernel_end(ctx);
+            pss_kernel_begin(ctx, "k_nfm_bwd");
+            if (b121)
+                hipLaunchKernelGGL((fused::k_nfm_bwd<true, true>), dim3((unsigned)(2 * tiles)), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af,
+                                   n, q, n_out, 2 * tiles * TILE, c, nullptr, MXf);
+            else
+                hipLaunchKernelGGL((fused::k_nfm_bwd<false, true>), dim3((unsigned)(2 * tiles)), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af,
+                                   n, q, n_out, 2 * tiles * TILE, c, nullptr, MXf);
+            pss_kernel_end(ctx);
+            size_t tot = (size_t)n_frames * n_out;
+            size_t g2 = (tot + TPB - 1) / TPB;
+            if (g2 > 16384) g2 = 16384;
+            pss_kernel_begin(ctx, "k_wfm_finalize");
+            hipLaunchKernelGGL(k_wfm_finalize, dim3((unsigned)g2), dim3(TPB), 0, PSS_STREAM(ctx), Af, MXf, n_out, n_frames, 1, d_pcm,
+                               d_audio);
+            pss_kernel_end(ctx);
+            pss_time_end(ctx);
+            return pss_hip_check(ctx, hipGetLastError(), "wfm fused launch");
+        }
         pss_kernel_begin(ctx, "k_wfm_front");
-        hipLaunchKernelGGL(k_wfm_front, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx),
+        hipLaunchKernelGGL(spec ? k_wfm_front<true> : k_wfm_front<false>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx),
                            reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, Lp, swapped, wc);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_nfm_iir");
@@ -1453,7 +1547,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         size_t g2 = (tot + TPB - 1) / TPB;
         if (g2 > 16384) g2 = 16384;
         pss_kernel_begin(ctx, "k_wfm_finalize");
-        hipLaunchKernelGGL(k_wfm_finalize, dim3((unsigned)g2), dim3(TPB), 0, PSS_STREAM(ctx), A, MX, n_out, n_frames, d_pcm,
+        hipLaunchKernelGGL(k_wfm_finalize, dim3((unsigned)g2), dim3(TPB), 0, PSS_STREAM(ctx), A, MX, n_out, n_frames, 0, d_pcm,
                            d_audio);
         pss_kernel_end(ctx);
         pss_time_end(ctx);

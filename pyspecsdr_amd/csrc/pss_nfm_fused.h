@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
 
 // Backward pass of sosfiltfilt over y_fwd (read in reverse from Y[tile][p][lane]), decimation [::q], peak
 // normalisation, stereo int16 / float64 audio.  One wavefront per tile, lane = frame.
-template <bool B121>
+template <bool B121, bool WFM = false>
 __global__ __launch_bounds__(TILE) void k_nfm_bwd(const double *__restrict__ Y, double *__restrict__ A, int n, int q,
                                                   int n_out, long n_frames, NfmCoef c, int16_t *__restrict__ pcm,
                                                   double *__restrict__ audio)
@@ -329,6 +329,10 @@ __global__ __launch_bounds__(TILE) void k_nfm_bwd(const double *__restrict__ Y, 
                                 }
                             });
     if (nan) mx = __builtin_nan("");
+    if (WFM) {  // rows are (tile, channel, frame-in-tile): k_wfm_finalize normalises the two channels jointly
+        audio[f] = mx;
+        return;
+    }
     if (f < n_frames) {
         for (int k = 0; k < n_out; k++) {
             double a = __dmul_rn(__ddiv_rn(At[(size_t)k * TILE], mx), 0.95);  // audio / max|audio| * 0.95

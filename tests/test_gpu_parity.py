@@ -326,6 +326,22 @@ def test_wfm_batch_vs_oracle():
         assert np.all(np.abs(audio).max(axis=(1, 2)) == 1.0)
 
 
+def test_wfm_fused_and_unfused_paths_agree():
+    # the fused forward kernel (k_wfm_fwd + k_nfm_bwd) and the k_wfm_front + k_nfm_iir path must produce identical bits
+    rng = np.random.default_rng(99)
+    e = G.engine()
+    for nf, n, fs in ((70, 1024, 2.4e6), (3, 29, 2.4e6), (5, 30, 250e3), (2, 45, 1.024e6), (65, 61, 2.4e6), (2, 4097, 2.048e6)):
+        ph = np.cumsum(rng.standard_normal((nf, n)) * 0.2, axis=1)
+        iq = (0.5 * np.exp(1j * ph) + 0.03 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
+        pcm1, a1 = _wfm(e, iq, fs, dispatcher=False)
+        e.set_option("wfm_fused", 0)
+        try:
+            pcm2, a2 = _wfm(e, iq, fs, dispatcher=False)
+        finally:
+            e.set_option("wfm_fused", 1)
+        assert np.array_equal(a1.view(np.uint64), a2.view(np.uint64)) and np.array_equal(pcm1, pcm2), (nf, n, fs)
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()
