@@ -152,6 +152,13 @@ int pss_ring_persistence(pss_ring *ring, int disp_h, int disp_w, int8_t *d_colou
 int pss_h_compute_fft(pss_ctx *ctx, const float *h_iq, int n, double *h_db);
 int pss_h_demodulate(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,
                      int16_t *h_pcm);
+/* scipy.signal.sosfilt(sos, x) with zero initial state on n_rows independent float64 rows of n samples (one lane per row);
+ * sos: HOST pointer, nsec <= 8 rows of 6.  The building block behind bandpass_filter (signal_processing.py:34-42). */
+int pss_sosfilt(pss_ctx *ctx, const double *d_x, long n_rows, int n, const double *sos, int nsec, double *d_y);
+/* bandpass_filter(data, lowcut, highcut, sample_rate) (signal_processing.py:34-42; used by decoders.py:100-101) on one
+ * host row: lowcut <= 0 -> butter(5) low-pass at highcut, else band-pass.  sos/nsec: caller's table, or NULL to design it. */
+int pss_h_bandpass_filter(pss_ctx *ctx, const double *h_x, int n, double lowcut, double highcut, double fs,
+                          const double *sos, int nsec, double *h_y);
 /* demodulate_signal(samples, fs, mode) on one host frame (dispatcher semantics: WFM is IQ-corrected first). */
 int pss_h_demodulate_signal(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,
                             int16_t *h_pcm);

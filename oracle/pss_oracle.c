@@ -380,6 +380,14 @@ static void sosfilt_inplace(const double *sos, int nsec, double *x, long n, doub
     }
 }
 
+/* bandpass_filter — signal_processing.py:34-42 given its SOS table: sosfilt(sos, data), zero initial state. */
+void pss_o_sosfilt(const double *sos, int nsec, const double *x, long n, double *y)
+{
+    double z[32] = {0};
+    memcpy(y, x, sizeof(double) * n);
+    sosfilt_inplace(sos, nsec, y, n, z);
+}
+
 /* 65-tap FIR with zero initial state: scipy.signal.lfilter(taps, 1.0, x) FIR branch
  * = np.convolve(taps, x)[:len(x)] = multiarray.correlate(x, taps[::-1], 'full') whose inner product is
  * DOUBLE_dot -> cblas_ddot, i.e. OpenBLAS kernel/x86_64/ddot.c + ddot_microk_skylakex-2.c on the

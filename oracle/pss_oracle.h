@@ -60,6 +60,8 @@ void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio);
 int pss_o_demod_wfm(const float *iq, int n, int q, const double *lp_sos, const double *pilot_sos,
                     const double *lmr_sos, double alpha, const double *dec_sos, const double *dec_zi, double *left,
                     double *right);
+/* bandpass_filter — signal_processing.py:34-42 with the SOS table given (butter(5) low-/band-pass): sosfilt, zero state. */
+void pss_o_sosfilt(const double *sos, int nsec, const double *x, long n, double *y);
 /* int16 conversion — io_manager.py:25-26 / audio_processing.py:37: np.int16(x*32767), stereo dup
  * (mono_to_stereo signal_processing.py:83-88). pcm[2*n] = L0 R0 L1 R1 ... */
 void pss_o_pcm16_stereo(const double *audio, int n, int16_t *pcm);

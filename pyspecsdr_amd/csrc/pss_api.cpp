@@ -298,6 +298,32 @@ extern "C" int pss_h_iq_correction(pss_ctx *ctx, const float *h_iq, int n, float
     return PSS_OK;
 }
 
+// bandpass_filter(data, lowcut, highcut, sample_rate) (signal_processing.py:34-42) on one host row of float64 samples.
+// sos: caller-supplied table (nsec rows) or NULL to design butter(5, ...) natively.
+extern "C" int pss_h_bandpass_filter(pss_ctx *ctx, const double *h_x, int n, double lowcut, double highcut, double fs,
+                                     const double *sos, int nsec, double *h_y)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!h_x || !h_y || n < 0) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
+    double tbl[48];
+    if (!sos) {
+        int r = pss_design_butter_sos(5, lowcut <= 0 ? 0.0 : lowcut / (fs / 2.0), highcut / (fs / 2.0), tbl, &nsec);
+        if (r) return pss_fail(ctx, r, "butter: digital filter critical frequencies must be 0 < Wn < 1");
+        sos = tbl;
+    }
+    if (n == 0) return PSS_OK;
+    const size_t o_y = up256(sizeof(double) * n);
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, 2 * o_y, "staging");
+    if (r) return r;
+    char *base = reinterpret_cast<char *>(ctx->stage);
+    PSS_HIP(ctx, hipMemcpyAsync(base, h_x, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    r = pss_sosfilt(ctx, reinterpret_cast<const double *>(base), 1, n, sos, nsec, reinterpret_cast<double *>(base + o_y));
+    if (r) return r;
+    PSS_HIP(ctx, hipMemcpyAsync(h_y, base + o_y, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSS_OK;
+}
+
 // ---- streamed capture --------------------------------------------------------------------------------
 extern "C" void *pss_host_alloc(size_t bytes)
 {

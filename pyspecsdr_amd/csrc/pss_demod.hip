@@ -1052,6 +1052,28 @@ __global__ __launch_bounds__(TPB) void k_wfm_finalize(const double *__restrict__
 #include "pss_wfm_fused.h"
 namespace {
 
+// bandpass_filter (signal_processing.py:34-42) on real float64 rows: scipy.signal.sosfilt, zero initial state, one lane per
+// row (the recurrence is serial in time).  Used by the reference's decoders (decoders.py:100-101) on single audio buffers —
+// a batch of rows is where a GPU makes sense; a single row runs on one lane and is there for interface completeness.
+struct SosArg { Biquad s[8]; int nsec; };
+__global__ __launch_bounds__(TILE) void k_sosfilt(const double *__restrict__ x, double *__restrict__ y, int n, long n_rows, SosArg c)
+{
+    const long r = (long)blockIdx.x * TILE + threadIdx.x;
+    if (r >= n_rows) return;
+    const double *xr = x + (size_t)r * n;
+    double *yr = y + (size_t)r * n;
+    double z[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.0;
+    for (int i = 0; i < n; i++) {
+        double v = xr[i];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; s2++)
+            if (s2 < c.nsec) v = biquad_step(c.s[s2], v, z[2 * s2], z[2 * s2 + 1]);
+        yr[i] = v;
+    }
+}
+
 // adjust_gain (pyspecsdr.py:898-919), sequential by nature.
 __global__ void k_agc(const float *__restrict__ power, long n, int idx, int n_gains, int *__restrict__ out)
 {
@@ -1573,6 +1595,25 @@ extern "C" int pss_demod_signal(pss_ctx *ctx, int mode, const float *d_iq, long 
     if (!r) r = pss_demod(ctx, mode, reinterpret_cast<const float *>(ctx->scratch_iqc), n_frames, n, fs, d_pcm, d_audio);
     pss_time_end(ctx);
     return r;
+}
+
+extern "C" int pss_sosfilt(pss_ctx *ctx, const double *d_x, long n_rows, int n, const double *sos, int nsec, double *d_y)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!d_x || !d_y || !sos || n_rows < 0 || n < 0 || nsec < 1 || nsec > 8) return pss_fail(ctx, PSS_E_ARG, "pss_sosfilt: bad argument");
+    if (n_rows == 0 || n == 0) return PSS_OK;
+    SosArg a;
+    a.nsec = nsec;
+    for (int s2 = 0; s2 < 8; s2++) {
+        const double *row = sos + 6 * (s2 < nsec ? s2 : 0);
+        a.s[s2] = Biquad{row[0], row[1], row[2], row[4], row[5]};
+    }
+    pss_time_begin(ctx);
+    pss_kernel_begin(ctx, "k_sosfilt");
+    hipLaunchKernelGGL(k_sosfilt, dim3((unsigned)((n_rows + TILE - 1) / TILE)), dim3(TILE), 0, PSS_STREAM(ctx), d_x, d_y, n, n_rows, a);
+    pss_kernel_end(ctx);
+    pss_time_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_sosfilt launch");
 }
 
 extern "C" int pss_set_wfm_filters(pss_ctx *ctx, double fs, const double *lp3x6, const double *pilot5x6, const double *lmr5x6,

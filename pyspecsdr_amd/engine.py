@@ -249,6 +249,19 @@ class Engine:
         self._ck(self.lib.pss_h_iq_correction(self.h, _ptr(iq), len(iq), None, _ptr(raw)))
         return raw
 
+    def sosfilt(self, d_x, n_rows, n, sos, d_y):
+        sos = np.ascontiguousarray(sos, np.float64)
+        self._ck(self.lib.pss_sosfilt(self.h, _ptr(d_x), n_rows, n, _ptr(sos), sos.shape[0], _ptr(d_y)))
+
+    def h_bandpass_filter(self, data, lowcut, highcut, fs, sos=None):
+        x = np.ascontiguousarray(data, np.float64)
+        y = np.empty_like(x)
+        if sos is not None:
+            sos = np.ascontiguousarray(sos, np.float64)
+        self._ck(self.lib.pss_h_bandpass_filter(self.h, _ptr(x), len(x), float(lowcut), float(highcut), float(fs),
+                                                _ptr(sos), 0 if sos is None else sos.shape[0], _ptr(y)))
+        return y
+
     def h_measure_power(self, iq):
         iq = np.ascontiguousarray(iq, np.complex64)
         out = np.empty(1, np.float32)

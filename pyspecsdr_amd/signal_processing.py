@@ -13,9 +13,10 @@ the reference's main loop imports with `from signal_processing import *` (pyspec
     mono_to_stereo(mono_audio)                             :83-88
 
     iq_correction(samples)                                 :46-80    -> complex64 (N,)  ('RAW' mode = its real part)
+    bandpass_filter(data, lowcut, highcut, sample_rate)    :34-42    -> float64 (N,)   (decoders.py:100-101)
+    classify_signal(samples, sample_rate, bandwidth)       :296-322  -> NameError, as in the reference (App. C2)
 
-Every call runs on the GPU through the C ABI; there is no NumPy/SciPy compute path here.  classify_signal (broken in
-the reference) is not part of the accelerated path.
+Every call runs on the GPU through the C ABI; there is no NumPy/SciPy compute path here.
 """
 import numpy as np
 
@@ -84,6 +85,29 @@ def mono_to_stereo(mono_audio):
     stereo_audio[:, 0] = mono_audio
     stereo_audio[:, 1] = mono_audio
     return stereo_audio
+
+
+def bandpass_filter(data, lowcut, highcut, sample_rate):
+    """signal_processing.py:34-42 (imported by decoders.py:3): butter(5) low-/band-pass SOS + sosfilt -> float64 (N,)."""
+    d = np.asarray(data)
+    if d.ndim != 1 or np.iscomplexobj(d):
+        raise NotImplementedError("bandpass_filter: only 1-D real input is accelerated")
+    sos = None
+    if USE_SCIPY_DESIGNS:
+        try:
+            import scipy.signal as ss
+            nyq = sample_rate / 2
+            sos = (ss.butter(BUTTER_ORDER, highcut / nyq, btype='low', output='sos') if lowcut <= 0 else
+                   ss.butter(BUTTER_ORDER, [lowcut / nyq, highcut / nyq], btype='band', output='sos'))
+        except ImportError:
+            pass
+    return get_engine().h_bandpass_filter(d, lowcut, highcut, sample_rate, sos)
+
+
+def classify_signal(samples, sample_rate, bandwidth):
+    """signal_processing.py:296-322 calls `welch`, which the module never imports: in the reference this
+    function raises NameError on every call (swallowed by the scanner's try/except, pyspecsdr.py:2571).  Same here."""
+    raise NameError("name 'welch' is not defined")
 
 
 def iq_correction(samples):

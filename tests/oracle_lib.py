@@ -45,6 +45,7 @@ def lib():
         L.pss_o_postprocess.argtypes = [_f64p, C.c_int, _f64p]
         L.pss_o_iq_correction.argtypes = [_f32p, C.c_int, _f32p]
         L.pss_o_demod_wfm.argtypes = [_f32p, C.c_int, C.c_int, _f64p, _f64p, _f64p, C.c_double, _f64p, _f64p, _f64p, _f64p]
+        L.pss_o_sosfilt.argtypes = [_f64p, C.c_int, _f64p, C.c_long, _f64p]
         L.pss_o_power_db.restype = C.c_float
         L.pss_o_power_db.argtypes = [_f32p, C.c_int]
         L.pss_o_scan_slice.restype = C.c_int
@@ -109,6 +110,14 @@ def demod_wfm(iq, fs, filt):
     if r < 0:
         return None
     return np.stack([left[:r], right[:r]], axis=1)
+
+
+def sosfilt(sos, x):
+    sos = np.ascontiguousarray(sos, np.float64)
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty_like(x)
+    lib().pss_o_sosfilt(sos, sos.shape[0], x, len(x), y)
+    return y
 
 
 def power_db(iq):

@@ -342,6 +342,28 @@ def test_wfm_fused_and_unfused_paths_agree():
         assert np.array_equal(a1.view(np.uint64), a2.view(np.uint64)) and np.array_equal(pcm1, pcm2), (nf, n, fs)
 
 
+def test_bandpass_filter_and_sosfilt_rows(golden):
+    """bandpass_filter (signal_processing.py:34-42) through the shim, and the batched sosfilt entry behind it."""
+    import pyspecsdr_amd.signal_processing as sp
+    g = golden["bandpass"]
+    for tag in g["tags"]:
+        lo, hi, fs = g[f"args_{tag}"]
+        y = sp.bandpass_filter(g[f"x_{tag}"], lo, hi, fs)
+        assert y.dtype == np.float64 and np.array_equal(y.view(np.uint64), g[f"y_{tag}"].view(np.uint64)), tag
+    with pytest.raises(NameError):
+        sp.classify_signal(np.zeros(2048, np.complex64), 2.4e6, 1e4)   # the reference's own behaviour (App. C2)
+    rng = np.random.default_rng(17)
+    e = G.engine()
+    x = rng.standard_normal((200, 777))
+    sos = g["sos_afsk1200"]
+    d_y = G.empty(x.shape, torch.float64)
+    e.sosfilt(G.dev(x), x.shape[0], x.shape[1], sos, d_y)
+    e.sync()
+    y = G.host(d_y)
+    for r in (0, 63, 64, 199):
+        assert np.array_equal(y[r], O.sosfilt(sos, x[r]))
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()

@@ -202,3 +202,10 @@ def test_wfm_bit_exact(golden):
             assert a.shape == want.shape, tag
             assert np.array_equal(a.view(np.uint64), want.view(np.uint64)), (tag, f, np.abs(a - want).max())
             assert np.array_equal(np.int16(a * 32767), g[f"pcm_{tag}"][f])
+
+
+def test_bandpass_filter_bit_exact(golden):
+    g = golden["bandpass"]
+    for tag in g["tags"]:
+        y = O.sosfilt(g[f"sos_{tag}"], g[f"x_{tag}"])
+        assert np.array_equal(y.view(np.uint64), g[f"y_{tag}"].view(np.uint64)), tag

@@ -305,6 +305,27 @@ def gen_wfm():
     save("wfm", **d)
 
 
+def gen_bandpass():
+    """bandpass_filter (signal_processing.py:34-42) the way decoders.py:100-101 and the demodulators call it."""
+    d = {}
+    rng = np.random.default_rng(91)
+    cases = [("afsk1200", 4000, 1100, 1300, 22050.0, np.float64), ("afsk2200", 4000, 2100, 2300, 22050.0, np.float64),
+             ("low", 3000, 0, 15000, 2.4e6, np.float32), ("voice", 5000, 300, 3000, 22050.0, np.float32),
+             ("short", 3, 300, 3000, 22050.0, np.float64)]
+    for tag, n, lo, hi, fs, dt in cases:
+        t = np.arange(n) / fs
+        x = (np.sin(2 * np.pi * 1200 * t) + 0.5 * np.sin(2 * np.pi * 2200 * t) + 0.1 * rng.standard_normal(n)).astype(dt)
+        y = sp.bandpass_filter(x, lo, hi, fs)
+        assert y.dtype == np.float64
+        d[f"x_{tag}"], d[f"y_{tag}"] = x, y
+        d[f"args_{tag}"] = np.array([lo, hi, fs])
+        nyq = fs / 2
+        d[f"sos_{tag}"] = (ss.butter(5, hi / nyq, btype="low", output="sos") if lo <= 0 else
+                           ss.butter(5, [lo / nyq, hi / nyq], btype="band", output="sos"))
+    d["tags"] = np.array([c[0] for c in cases])
+    save("bandpass", **d)
+
+
 def gen_power():
     d = {}
     frames, pw = [], []
@@ -436,5 +457,6 @@ if __name__ == "__main__":
     gen_power()
     gen_iqcorr()
     gen_wfm()
+    gen_bandpass()
     gen_scanner()
     gen_caller()
