@@ -347,60 +347,7 @@ namespace {
 // rounded down to multiples of 8) is generated on the host for the frame length and replayed level by level; one
 // workgroup per frame.
 // ---------------------------------------------------------------------------------------------------
-template <int KIND>
-__global__ __launch_bounds__(TPB) void k_pairwise(const float2 *__restrict__ iq, int n, long n_frames,
-                                                  const int *__restrict__ leaf_off, const int *__restrict__ leaf_len,
-                                                  int n_leaves, const int *__restrict__ node_l,
-                                                  const int *__restrict__ node_r, const int *__restrict__ level_start,
-                                                  int n_levels, float *__restrict__ out)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    float *val = reinterpret_cast<float *>(smem);
-    const int tid = threadIdx.x;
-    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
-        const float2 *x = iq + (size_t)f * n;
-        auto elem = [&](int i) {
-            float2 v = x[i];
-            float m = cabsf_np(v.x, v.y);
-            return KIND == 0 ? __fmul_rn(m, m) : m;
-        };
-        for (int l = tid; l < n_leaves; l += TPB) {
-            const int off = leaf_off[l], len = leaf_len[l];
-            float res;
-            if (len < 8) {
-                res = 0.0f;
-                for (int i = 0; i < len; i++) res = __fadd_rn(res, elem(off + i));
-            } else {
-                float r[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) r[k] = elem(off + k);
-                int i;
-                for (i = 8; i < len - (len % 8); i += 8) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) r[k] = __fadd_rn(r[k], elem(off + i + k));
-                }
-                res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
-                                __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
-                for (; i < len; i++) res = __fadd_rn(res, elem(off + i));
-            }
-            val[l] = res;
-        }
-        __syncthreads();
-        for (int lv = 0; lv < n_levels; lv++) {
-            for (int k = level_start[lv] + tid; k < level_start[lv + 1]; k += TPB)
-                val[n_leaves + k] = __fadd_rn(val[node_l[k]], val[node_r[k]]);
-            __syncthreads();
-        }
-        if (tid == 0) {
-            float sum = val[n_leaves + level_start[n_levels] - 1];
-            if (level_start[n_levels] == 0) sum = val[0];
-            float mean = __fdiv_rn(sum, (float)n);
-            if (KIND == 0) out[f] = 10.0f * log10f(__fadd_rn(mean, 1e-10f));  // 10*log10(power + 1e-10), float32
-            else out[f] = mean;
-        }
-        __syncthreads();
-    }
-}
+// (k_pairwise itself follows the shared reduction helpers further down)
 
 // ---------------------------------------------------------------------------------------------------
 // AM: envelope - mean (float32) -> 5-section Butterworth band-pass, forward only, zero state (float64).
@@ -838,6 +785,40 @@ __device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *part, float2
     return sum;
 }
 
+// np.mean float32 of |x| (KIND 1, AM: signal_processing.py:185) or |x|^2 (KIND 0, power: :327), one workgroup per frame.
+// STAGED: every thread computes the elements of its coalesced share once into LDS (4 B each) and the tree is summed from
+// there; otherwise the (leaf, accumulator) lanes read global memory directly.
+// LDS: [e: n floats if STAGED][part: 8 floats per leaf][val]
+template <int KIND, bool STAGED>
+__global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq, int n, long n_frames, PlanDev rp,
+                                                  float *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *e = reinterpret_cast<float *>(smem);
+    float *part = e + (STAGED ? n : 0), *val = part + 8 * rp.n_leaves;
+    const int T = blockDim.x;
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const float2 *x = iq + (size_t)f * n;
+        auto elem = [&](int i) {
+            const float2 v = x[i];
+            const float m = cabsf_np(v.x, v.y);
+            return KIND == 0 ? __fmul_rn(m, m) : m;
+        };
+        float sum;
+        if (STAGED) {
+            for (int i = threadIdx.x; i < n; i += T) e[i] = elem(i);
+            __syncthreads();
+            sum = wg_rsum(rp, part, val, [&](int i) { return e[i]; });
+        } else {
+            sum = wg_rsum(rp, part, val, elem);
+        }
+        if (threadIdx.x == 0) {
+            const float mean = __fdiv_rn(sum, (float)n);
+            out[f] = KIND == 0 ? 10.0f * log10f(__fadd_rn(mean, 1e-10f)) : mean;  // 10*log10(power + 1e-10), float32
+        }
+    }
+}
+
 // STAGED: the frame is copied to LDS once and every pass reads it from there (frames up to 16384 samples).
 // LDS: [frame: n float2 if STAGED][part: part_slots float2][val: val_slots float2]
 template <bool STAGED>
@@ -1174,17 +1155,21 @@ int launch_pairwise(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float
     PssPairwisePlan *p;
     int r = get_plan(ctx, n, &p);
     if (r) return r;
-    size_t lds = sizeof(float) * (size_t)(p->n_leaves + p->n_nodes + 1);
+    const size_t tree = sizeof(float) * (size_t)(8 * p->n_leaves + p->n_leaves + p->n_nodes + 1);
+    const bool staged = tree + sizeof(float) * (size_t)n <= 64 * 1024;  // 2+ workgroups per CU
+    const size_t lds = tree + (staged ? sizeof(float) * (size_t)n : 0);
     if (lds > 150 * 1024) return pss_fail(ctx, PSS_E_ARG, "frame too long for the pairwise-mean kernel");
-    auto kern = k_pairwise<KIND>;
+    auto kern = staged ? k_pairwise<KIND, true> : k_pairwise<KIND, false>;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
-    long g = n_frames < 8192 ? n_frames : 8192;
+    PlanDev a{p->d_leaf_off, p->d_leaf_len, p->d_node_l, p->d_node_r, p->d_level_start, p->n_leaves, p->n_levels};
+    const int lanes = staged ? n : 8 * p->n_leaves;
+    const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);
+    long g = n_frames < 65536 ? n_frames : 65536;
     pss_kernel_begin(ctx, "k_pairwise");
-    hipLaunchKernelGGL(kern, dim3((int)g), dim3(TPB), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n,
-                       n_frames, p->d_leaf_off, p->d_leaf_len, p->n_leaves, p->d_node_l, p->d_node_r, p->d_level_start,
-                       p->n_levels, d_out);
+    hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, a,
+                       d_out);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_pairwise launch");
 }
