@@ -360,14 +360,14 @@ namespace {
 constexpr int AM_NS = 5;
 constexpr int AM_CH = 16;
 
-__global__ __launch_bounds__(TILE) void k_am_iir(const float2 *__restrict__ iq, const float *__restrict__ mu,
+__global__ __launch_bounds__(TILE) void k_am_iir(const float *__restrict__ env, const float *__restrict__ mu,
                                                  double *__restrict__ Yf, double *__restrict__ mxout, int n,
                                                  long n_frames, AmCoef c)
 {
     const int lane = threadIdx.x;
     const long f = (long)blockIdx.x * TILE + lane;
     const long fr = f < n_frames ? f : n_frames - 1;  // masked lanes replay the last frame (results dropped)
-    const float2 *x = iq + (size_t)fr * n;
+    const float *x = env + (size_t)fr * n;            // |samples| (float32), written by k_pairwise<1>
     double *y = Yf + (size_t)fr * n;
     const float m = mu[fr];
     double z[2 * AM_NS], p[AM_NS - 1];
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(TILE) void k_am_iir(const float2 *__restrict__ iq, 
         for (int k = 0; k < AM_NS - 1; k++) p[k] = xn[k];
         return xn[AM_NS - 1];
     };
-    auto envelope = [&](float2 s) { return (double)__fsub_rn(cabsf_np(s.x, s.y), m); };  // float32 subtract (:185)
+    auto envelope = [&](float a) { return (double)__fsub_rn(a, m); };  // float32 subtract (:185)
     double mx = 0.0;
     bool nan = false;
     auto keep = [&](long t, double v) {  // output of step t belongs to sample t - (AM_NS - 1)
@@ -411,15 +411,15 @@ __global__ __launch_bounds__(TILE) void k_am_iir(const float2 *__restrict__ iq, 
         }
     };
     const long T = (long)n + AM_NS - 1;            // steps incl. drain
-    const bool aligned = ((size_t)fr * n) % 2 == 0;  // 16-byte loads need an even sample offset
+    const bool aligned = ((size_t)fr * n) % 4 == 0;  // 16-byte loads need a sample offset that is a multiple of 4
     const long nfull = aligned ? n / AM_CH : 0;
-    float2 b0[AM_CH], b1[AM_CH];
-    auto loadc = [&](float2 (&b)[AM_CH], long r) {
+    float b0[AM_CH], b1[AM_CH];
+    auto loadc = [&](float (&b)[AM_CH], long r) {
         const float4 *q = reinterpret_cast<const float4 *>(x + r);
 #pragma unroll
-        for (int k = 0; k < AM_CH / 2; k++) { float4 v4 = q[k]; b[2 * k] = make_float2(v4.x, v4.y); b[2 * k + 1] = make_float2(v4.z, v4.w); }
+        for (int k = 0; k < AM_CH / 4; k++) { float4 v4 = q[k]; b[4 * k] = v4.x; b[4 * k + 1] = v4.y; b[4 * k + 2] = v4.z; b[4 * k + 3] = v4.w; }
     };
-    auto runc = [&](float2 (&b)[AM_CH], long r) {
+    auto runc = [&](float (&b)[AM_CH], long r) {
 #pragma unroll
         for (int k = 0; k < AM_CH; k++) keep(r + k, step(envelope(b[k])));
     };
@@ -457,97 +457,112 @@ __device__ __forceinline__ double dpp_row_shr1(double v)
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(64) void k_am_sys(const float2 *__restrict__ iq, const float *__restrict__ mu,
+__global__ __launch_bounds__(64) void k_am_sys(const float *__restrict__ env, const float *__restrict__ mu,
                                                double *__restrict__ Yf, double *__restrict__ mxout, int n,
                                                long n_frames, AmCoef c)
 {
     __shared__ double ebuf[SYS_G][SYS_T + 1];
-    __shared__ double ybuf[SYS_G][SYS_T + 1];
+    __shared__ double ybuf[SYS_G + 1][SYS_T + 1];  // row SYS_G: dump row for the lanes that are not a last section
     const int lane = threadIdx.x, row = lane >> 4, r = lane & 15;
     const int g3 = r / 5, s = r - 5 * g3;           // r = 15 -> g3 = 3 (idle lane)
     const bool active = r < 15;
     const int g = active ? row * 3 + g3 : 0;
     const long f0 = (long)blockIdx.x * SYS_G;
-    const long f = f0 + g;
     Biquad cs = c.s[0];
 #pragma unroll
     for (int k = 1; k < AM_NS; k++)
         if (s == k) cs = c.s[k];
-    double z0 = 0.0, z1 = 0.0, xprev = 0.0, mx = 0.0;
-    bool nan = false;
+    double z0 = 0.0, z1 = 0.0, xprev = 0.0;
     const long T = (long)n + AM_NS - 1;
     const bool last = active && s == AM_NS - 1;
-    float2 pre[SYS_G];  // IQ of the next chunk (SYS_G frame rows, one sample per lane), loaded while the current one runs
+    double *yrow = ybuf[last ? g : SYS_G];          // every lane stores every step, no branch in the chain
+    // peak tracking happens where the outputs are written back (lane = time there): mxl[gg] = max over this lane's samples
+    double mxl[SYS_G];
+    bool nanl = false;
+#pragma unroll
+    for (int gg = 0; gg < SYS_G; gg++) mxl[gg] = 0.0;
+    float pre[SYS_G];  // |x| of the next chunk (SYS_G frame rows, one sample per lane), loaded while the current one runs
+    float mus[SYS_G];
+#pragma unroll
+    for (int gg = 0; gg < SYS_G; gg++) mus[gg] = (f0 + gg < n_frames) ? mu[f0 + gg] : 0.0f;
     auto prefetch = [&](long c0) {
 #pragma unroll
         for (int gg = 0; gg < SYS_G; gg++) {
             const long ff = f0 + gg;
             const long i = c0 + lane;
-            pre[gg] = (ff < n_frames && i < n) ? iq[(size_t)ff * n + i] : make_float2(0.0f, 0.0f);
+            pre[gg] = (ff < n_frames && i < n) ? env[(size_t)ff * n + i] : 0.0f;
+        }
+    };
+    unsigned nanmask = 0;  // bit gg: a NaN was seen in frame gg by this lane
+    // write back the chunk that started at step c0: step t carries the last section's output for sample c0 + t - 4
+    auto writeback = [&](long c0) {
+        const int cnt = (T - c0) < SYS_T ? (int)(T - c0) : SYS_T;
+#pragma unroll
+        for (int gg = 0; gg < SYS_G; gg++) {
+            const long ff = f0 + gg;
+            const long i = c0 + lane - (AM_NS - 1);
+            if (ff < n_frames && lane < cnt && i >= 0 && i < n) {
+                const double v = ybuf[gg][lane];
+                Yf[(size_t)ff * n + i] = v;
+                const double av = fabs(v);
+                if (av != av) nanmask |= 1u << gg;
+                mxl[gg] = av > mxl[gg] ? av : mxl[gg];
+            }
         }
     };
     prefetch(0);
     for (long c0 = 0; c0 < T; c0 += SYS_T) {
-        // envelope - mean of SYS_G frames x SYS_T samples
+        // envelope - mean of SYS_G frames x SYS_T samples; then the previous chunk's outputs go out, so that their stores
+        // are a whole chain old when the next wait on the prefetched loads (an in-order vmcnt) comes around
 #pragma unroll
         for (int gg = 0; gg < SYS_G; gg++) {
             const long ff = f0 + gg;
             double e = 0.0;
-            if (ff < n_frames && c0 + lane < n)
-                e = (double)__fsub_rn(cabsf_np(pre[gg].x, pre[gg].y), mu[ff]);  // float32 subtract (signal_processing.py:185)
+            if (ff < n_frames && c0 + lane < n) e = (double)__fsub_rn(pre[gg], mus[gg]);  // float32 subtract (:185)
             ebuf[gg][lane] = e;
         }
+        if (c0 > 0) writeback(c0 - SYS_T);
         if (c0 + SYS_T < T) prefetch(c0 + SYS_T);
-        __syncthreads();
+        fused::lds_barrier();
         const int cnt = (T - c0) < SYS_T ? (int)(T - c0) : SYS_T;
-        auto one = [&](int t, double e, bool checked) {
+        auto one = [&](int t, double e) {
             const double from_prev = dpp_row_shr1(xprev);
             const double x = (s == 0) ? e : from_prev;
             const double xn = __dadd_rn(__dmul_rn(cs.b0, x), z0);
             z0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, x), __dmul_rn(cs.a1, xn)), z1);
             z1 = __dsub_rn(__dmul_rn(cs.b2, x), __dmul_rn(cs.a2, xn));
             xprev = xn;
-            bool keep = last;
-            if (checked) {
-                const long i = c0 + t - (AM_NS - 1);  // sample index of the last section's output
-                keep = keep && i >= 0 && i < n;
-            }
-            if (keep) {
-                ybuf[g][t] = xn;
-                const double av = fabs(xn);
-                nan = nan || (av != av);
-                mx = av > mx ? av : mx;
-            }
+            yrow[t] = xn;
         };
         if (cnt == SYS_T) {
-            // straight-line groups of 8 steps: the eight LDS reads of a group are issued together, ahead of the chain;
-            // interior chunks (every output index valid) skip the index checks
-            const bool interior = c0 >= AM_NS - 1 && c0 + SYS_T <= n;
+            // straight-line groups of 8 steps: the eight LDS reads of a group are issued together, ahead of the chain
             for (int t0 = 0; t0 < SYS_T; t0 += 8) {
                 double e8[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) e8[k] = ebuf[g][t0 + k];
-                if (interior) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) one(t0 + k, e8[k], false);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) one(t0 + k, e8[k], true);
-                }
+                for (int k = 0; k < 8; k++) one(t0 + k, e8[k]);
             }
         } else {
-            for (int t = 0; t < cnt; t++) one(t, ebuf[g][t], true);
+            for (int t = 0; t < cnt; t++) one(t, ebuf[g][t]);
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int gg = 0; gg < SYS_G; gg++) {
-            const long ff = f0 + gg;
-            const long i = c0 + lane - (AM_NS - 1);
-            if (ff < n_frames && lane < cnt && i >= 0 && i < n) Yf[(size_t)ff * n + i] = ybuf[gg][lane];
-        }
-        __syncthreads();
+        fused::lds_barrier();
     }
-    if (active && s == AM_NS - 1 && f < n_frames) mxout[f] = nan ? __builtin_nan("") : mx;
+    writeback(((T - 1) / SYS_T) * SYS_T);
+    // per-frame peak: max over the 64 lanes (np.max propagates NaN)
+#pragma unroll
+    for (int gg = 0; gg < SYS_G; gg++) {
+        double m = mxl[gg];
+        int nn = (nanmask >> gg) & 1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(m, off);
+            m = o > m ? o : m;
+            nn |= __shfl_xor(nn, off);
+        }
+        if (lane == 0 && f0 + gg < n_frames) mxout[f0 + gg] = nn ? __builtin_nan("") : m;
+    }
+    (void)nanl;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -785,33 +800,23 @@ __device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *part, float2
     return sum;
 }
 
-// np.mean float32 of |x| (KIND 1, AM: signal_processing.py:185) or |x|^2 (KIND 0, power: :327), one workgroup per frame.
-// STAGED: every thread computes the elements of its coalesced share once into LDS (4 B each) and the tree is summed from
-// there; otherwise the (leaf, accumulator) lanes read global memory directly.
-// LDS: [e: n floats if STAGED][part: 8 floats per leaf][val]
-template <int KIND, bool STAGED>
+// np.mean float32 of |x| (KIND 1, AM: signal_processing.py:185) or |x|^2 (KIND 0, power: :327), one workgroup per frame;
+// the (leaf, accumulator) lanes read global memory directly (every element is used exactly once; staging the frame in
+// LDS first measured 2-3x slower: fewer resident workgroups, one more barrier).  LDS: [part: 8 floats per leaf][val]
+template <int KIND>
 __global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq, int n, long n_frames, PlanDev rp,
-                                                  float *__restrict__ out)
+                                                  float *__restrict__ out, float *__restrict__ env)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    float *e = reinterpret_cast<float *>(smem);
-    float *part = e + (STAGED ? n : 0), *val = part + 8 * rp.n_leaves;
-    const int T = blockDim.x;
+    float *part = reinterpret_cast<float *>(smem), *val = part + 8 * rp.n_leaves;
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const float2 *x = iq + (size_t)f * n;
-        auto elem = [&](int i) {
+        const float sum = wg_rsum(rp, part, val, [&](int i) {
             const float2 v = x[i];
             const float m = cabsf_np(v.x, v.y);
+            if (KIND == 1 && env) env[(size_t)f * n + i] = m;  // the AM envelope (:182), reused by the band-pass kernel
             return KIND == 0 ? __fmul_rn(m, m) : m;
-        };
-        float sum;
-        if (STAGED) {
-            for (int i = threadIdx.x; i < n; i += T) e[i] = elem(i);
-            __syncthreads();
-            sum = wg_rsum(rp, part, val, [&](int i) { return e[i]; });
-        } else {
-            sum = wg_rsum(rp, part, val, elem);
-        }
+        });
         if (threadIdx.x == 0) {
             const float mean = __fdiv_rn(sum, (float)n);
             out[f] = KIND == 0 ? 10.0f * log10f(__fadd_rn(mean, 1e-10f)) : mean;  // 10*log10(power + 1e-10), float32
@@ -819,7 +824,7 @@ __global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq,
     }
 }
 
-// STAGED: the frame is copied to LDS once and every pass reads it from there (frames up to 16384 samples).
+// STAGED: the frame is copied to LDS once and every pass reads it from there (frames up to 8192 samples).
 // LDS: [frame: n float2 if STAGED][part: part_slots float2][val: val_slots float2]
 template <bool STAGED>
 __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, int n, long n_frames, PlanDev rp, PlanDev cp,
@@ -1150,26 +1155,24 @@ int get_plan(pss_ctx *ctx, int n_elems, PssPairwisePlan **out, bool cplx = false
 }
 
 template <int KIND>
-int launch_pairwise(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out)
+int launch_pairwise(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out, float *d_env = nullptr)
 {
     PssPairwisePlan *p;
     int r = get_plan(ctx, n, &p);
     if (r) return r;
-    const size_t tree = sizeof(float) * (size_t)(8 * p->n_leaves + p->n_leaves + p->n_nodes + 1);
-    const bool staged = tree + sizeof(float) * (size_t)n <= 64 * 1024;  // 2+ workgroups per CU
-    const size_t lds = tree + (staged ? sizeof(float) * (size_t)n : 0);
+    const size_t lds = sizeof(float) * (size_t)(8 * p->n_leaves + p->n_leaves + p->n_nodes + 1);
     if (lds > 150 * 1024) return pss_fail(ctx, PSS_E_ARG, "frame too long for the pairwise-mean kernel");
-    auto kern = staged ? k_pairwise<KIND, true> : k_pairwise<KIND, false>;
+    auto kern = k_pairwise<KIND>;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
     PlanDev a{p->d_leaf_off, p->d_leaf_len, p->d_node_l, p->d_node_r, p->d_level_start, p->n_leaves, p->n_levels};
-    const int lanes = staged ? n : 8 * p->n_leaves;
+    const int lanes = 8 * p->n_leaves;  // one lane per (leaf, accumulator) pair
     const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);
     long g = n_frames < 65536 ? n_frames : 65536;
     pss_kernel_begin(ctx, "k_pairwise");
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, a,
-                       d_out);
+                       d_out, d_env);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_pairwise launch");
 }
@@ -1260,7 +1263,8 @@ extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames,
     size_t part_slots = (size_t)(rp->n_leaves * 4 > cp->n_leaves * 4 ? rp->n_leaves * 4 : cp->n_leaves * 4);  // in float2
     size_t val_slots = (size_t)(rp->n_leaves + rp->n_nodes > cp->n_leaves + cp->n_nodes ? rp->n_leaves + rp->n_nodes
                                                                                           : cp->n_leaves + cp->n_nodes) + 1;
-    const bool staged = n <= 16384 && (part_slots + val_slots + (size_t)n) * sizeof(float2) <= 150 * 1024;
+    // staging pays while >= 2 workgroups fit a CU (measured: 0.59 vs 0.91 ms at 65536 x 1024, but 2.6 vs 1.8 ms at 8192 x 16384)
+    const bool staged = n <= 8192;
     size_t lds = (part_slots + val_slots + (staged ? (size_t)n : 0)) * sizeof(float2);
     if (lds > 150 * 1024) return pss_fail(ctx, PSS_E_ARG, "frame too long for the iq_correction kernel");
     auto kern = staged ? k_iqcorr<true> : k_iqcorr<false>;
@@ -1398,26 +1402,27 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const size_t szY = align256((size_t)n_frames * n * sizeof(double));
         const size_t szM = align256((size_t)n_frames * sizeof(double));
         const size_t szMu = align256((size_t)n_frames * sizeof(float));
-        int r = pss_ensure_scratch(ctx, szY + szM + szMu);
+        const size_t szE = align256((size_t)n_frames * n * sizeof(float));
+        int r = pss_ensure_scratch(ctx, szY + szM + szMu + szE);
         if (r) return r;
         char *base = reinterpret_cast<char *>(ctx->scratch);
         double *Yf = reinterpret_cast<double *>(base);
         double *mx = reinterpret_cast<double *>(base + szY);
         float *mu = reinterpret_cast<float *>(base + szY + szM);
+        float *env = reinterpret_cast<float *>(base + szY + szM + szMu);  // |samples| float32, written once by the mean pass
         double sos[30];
         pss_am_bandpass_sos(sos);
         AmCoef c;
         for (int s = 0; s < 5; s++) c.s[s] = Biquad{sos[6 * s], sos[6 * s + 1], sos[6 * s + 2], sos[6 * s + 4], sos[6 * s + 5]};
         pss_time_begin(ctx);
-        r = launch_pairwise<1>(ctx, d_iq, n_frames, n, mu);
+        r = launch_pairwise<1>(ctx, d_iq, n_frames, n, mu, env);
         if (r) return r;
         pss_kernel_begin(ctx, "k_am_iir");
         if (n_frames < 32768)  // few frames: spread the sections over lanes (5.3x more wavefronts)
-            hipLaunchKernelGGL(k_am_sys, dim3((unsigned)((n_frames + SYS_G - 1) / SYS_G)), dim3(64), 0, PSS_STREAM(ctx),
-                               reinterpret_cast<const float2 *>(d_iq), mu, Yf, mx, n, n_frames, c);
+            hipLaunchKernelGGL(k_am_sys, dim3((unsigned)((n_frames + SYS_G - 1) / SYS_G)), dim3(64), 0, PSS_STREAM(ctx), env, mu, Yf,
+                               mx, n, n_frames, c);
         else
-            hipLaunchKernelGGL(k_am_iir, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx),
-                               reinterpret_cast<const float2 *>(d_iq), mu, Yf, mx, n, n_frames, c);
+            hipLaunchKernelGGL(k_am_iir, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), env, mu, Yf, mx, n, n_frames, c);
         pss_kernel_end(ctx);
         size_t total = (size_t)n_frames * n;
         size_t g = (total + TPB - 1) / TPB;
