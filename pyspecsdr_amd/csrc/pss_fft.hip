@@ -402,6 +402,40 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
         pss_time_end(ctx);
         return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_r16_big launch");
     }
+    if (!SCAN && n_fft >= (1 << 17)) {
+        // N = 256 * NS: 256-point column transforms into a float64 scratch, then NS-point row transforms + dB
+        const int NS = n_fft >> 8;
+        r = pss_ensure_buffer(ctx, &ctx->scratch_fft, &ctx->scratch_fft_bytes, (size_t)n_frames * n_fft * sizeof(double2),
+                              "spectrum scratch");
+        if (r) return r;
+        double2 *Y = reinterpret_cast<double2 *>(ctx->scratch_fft);
+        using C0 = pss_r16::Cfg<0>;
+        const size_t lds1 = (size_t)16 * (C0::EX + 1) * sizeof(double2);
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pss_r16::k_huge_p1),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        const long total1 = n_frames * (NS / 16);
+        pss_time_begin(ctx);
+        pss_kernel_begin(ctx, "k_spectrum_p1");
+        hipLaunchKernelGGL(pss_r16::k_huge_p1, dim3((unsigned)(total1 < 8192 ? total1 : 8192)), dim3(256), lds1, PSS_STREAM(ctx),
+                           reinterpret_cast<const float2 *>(d_iq), tw, win, Y, NS, n_frames);
+        pss_kernel_end(ctx);
+        const long rows = n_frames * 256;
+        auto launch2 = [&](auto kern, size_t lds2, int fpw) {
+            if (lds2 > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            const long groups = rows / fpw;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(groups < 8192 ? groups : 8192)), dim3(256), lds2, PSS_STREAM(ctx), Y, d_db, tw, rows);
+        };
+        pss_kernel_begin(ctx, "k_spectrum");
+        switch (NS) {
+        case 512: launch2(pss_r16::k_huge_p2<1>, pss_r16::Cfg<1>::LDS, pss_r16::Cfg<1>::FPW); break;
+        case 1024: launch2(pss_r16::k_huge_p2<2>, pss_r16::Cfg<2>::LDS, pss_r16::Cfg<2>::FPW); break;
+        case 2048: launch2(pss_r16::k_huge_p2<3>, pss_r16::Cfg<3>::LDS, pss_r16::Cfg<3>::FPW); break;
+        default: launch2(pss_r16::k_huge_p2<4>, pss_r16::Cfg<4>::LDS, pss_r16::Cfg<4>::FPW); break;
+        }
+        pss_kernel_end(ctx);
+        pss_time_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "k_huge launch");
+    }
     int logn = ilog2(n_fft);
     int logNsub = logn < LOG_NSUB_MAX ? logn : LOG_NSUB_MAX;
     int R = n_fft >> logNsub;

@@ -285,4 +285,87 @@ __global__ __launch_bounds__(256) void k_spectrum_r16_big(const float2 *__restri
     }
 }
 
+// N = 256 * NS, NS in {512, 1024, 2048, 4096} (N = 131072 ... 1048576, the reference's largest read buffers,
+// pyspecsdr.py:2236 with SAMPLES = 9..12): two kernels around a float64 scratch Y[frame][r][n]:
+//   pass 1  for every column n < NS: 256-point transform over q of x[n + NS q] w[n + NS q], times W_N^(n r)  -> Y[r][n]
+//   pass 2  for every r < 256: NS-point transform of the contiguous row Y[r][.]  -> bin 256 k' + r, dB, fftshift.
+// Pass 1 maps 16 adjacent columns to adjacent LANES (thread = 16 * t + column), so loads are 128-byte and stores
+// 256-byte contiguous although each transform walks the frame with stride NS; the per-transform LDS regions are offset
+// by one element so that the 16 columns hit different banks.
+__global__ __launch_bounds__(256) void k_huge_p1(const float2 *__restrict__ iq, const double2 *__restrict__ tw,
+                                                 const double *__restrict__ win, double2 *__restrict__ Y, int NS, long n_frames)
+{
+    using C = Cfg<0>;  // 256-point transforms, 16 threads each
+    constexpr int EXP = C::EX + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *ex_all = reinterpret_cast<double2 *>(smem);
+    const int tid = threadIdx.x, fl = tid & 15, t = tid >> 4;
+    const size_t N = (size_t)256 * NS;
+    const int cpf = NS / 16;  // column groups per frame
+    double2 tw1[16];
+    tw1[0] = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; k2++) tw1[k2] = tw[(size_t)(t * k2) * NS];  // W_256^(t k2) = W_N^(NS t k2)
+    double2 *ex = ex_all + (size_t)fl * EXP;
+    const long total = n_frames * cpf;
+    for (long g = blockIdx.x; g < total; g += gridDim.x) {
+        const long f = g / cpf;
+        const int col = (int)(g - f * cpf) * 16 + fl;
+        const float2 *x = iq + (size_t)f * N;
+        double2 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const size_t idx = (size_t)col + (size_t)NS * (t + 16 * j);
+            const float2 sv = x[idx];
+            const double wv = win[idx];
+            v[j] = make_double2((double)sv.x * wv, (double)sv.y * wv);
+        }
+        double2 *Yf = Y + (size_t)f * N;
+        r16_core<0>(v, ex, tw1, nullptr, t, [&](int, int r, double2 X) {
+            if (r) X = cmul(X, tw[(size_t)col * r]);  // W_N^(n r), n r < N
+            Yf[(size_t)r * NS + col] = X;
+        });
+        __syncthreads();
+    }
+}
+
+template <int LOG_R3>
+__global__ __launch_bounds__(256) void k_huge_p2(const double2 *__restrict__ Y, float *__restrict__ db,
+                                                 const double2 *__restrict__ tw, long n_rows)
+{
+    using C = Cfg<LOG_R3>;
+    constexpr int R3 = C::R3, T = C::T, NS = C::N, FPW = C::FPW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *ex_all = reinterpret_cast<double2 *>(smem);
+    double2 *tw2 = ex_all + (size_t)FPW * C::EX;
+    const int tid = threadIdx.x, fl = tid / T, t = tid % T;
+    double2 *ex = ex_all + (size_t)fl * C::EX;
+    const size_t N = (size_t)256 * NS;
+    double2 tw1[16];
+    tw1[0] = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; k2++) tw1[k2] = tw[(size_t)(t * k2) * 256];  // W_NS^(t k2) = W_N^(256 t k2)
+    if (tid < R3 * 16) {
+        const int m1 = tid / 16, j2 = tid % 16;
+        tw2[tid] = tw[(size_t)(m1 * j2) * 16 * 256];
+    }
+    __syncthreads();
+    const long groups = (n_rows + FPW - 1) / FPW;  // n_rows = n_frames * 256, a multiple of FPW
+    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+        const long row = g * FPW + fl;             // row = f * 256 + r
+        const long f = row >> 8;
+        const int r = (int)(row & 255);
+        const double2 *y = Y + (size_t)row * NS;
+        double2 v[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++) v[n2] = y[t + T * n2];
+        float *out = db + (size_t)f * N;
+        r16_core<LOG_R3>(v, ex, tw1, tw2, t, [&](int, int kp, double2 X) {
+            const size_t k = (size_t)256 * kp + r;
+            out[(k + N / 2) & (N - 1)] = db_of(X.x * X.x + X.y * X.y + 1e-10);
+        });
+        __syncthreads();
+    }
+}
+
 }  // namespace pss_r16

@@ -47,6 +47,20 @@ def test_spectrum_zero_and_large(golden):
         assert np.all(np.abs(db - ref) <= 1e-4 * np.maximum(np.abs(ref), 1e-2))
 
 
+@pytest.mark.parametrize("n", [131072, 262144, 524288, 1048576])
+def test_spectrum_huge_frames(n):
+    """The reference's largest read buffers (pyspecsdr.py:2236, SAMPLES = 9..12 -> 2^17..2^20 samples): two-pass
+    256 x NS transform through a float64 scratch."""
+    rng = np.random.default_rng(n)
+    t = np.arange(n)
+    iq = (0.3 * np.exp(2j * np.pi * 0.0371 * t) + 0.05 * (rng.standard_normal((3, n)) + 1j * rng.standard_normal((3, n)))).astype(np.complex64)
+    db = G.spectrum(iq)
+    for f in (0, 2):
+        ref = O.compute_fft(iq[f])
+        assert np.all(np.abs(db[f] - ref) <= 1e-4 * np.maximum(np.abs(ref), 1e-2)), f
+        assert np.max(np.abs(db[f] - ref)) < 1e-4
+
+
 def test_spectrum_linearity_property():
     # Parseval at full batch width: sum |X|^2 = N * sum |w x|^2 for every frame (size-independent check)
     rng = np.random.default_rng(6)
