@@ -33,6 +33,7 @@ struct pss_ctx {
     hipStream_t cur = nullptr;      // stream the next launches go to (nullptr = `stream`)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fork_after_fwd = false;
+    bool did_fork = false;  // set by pss_demod when it recorded ev_fork (fused NFM path only)
     std::string err;
     std::map<int, double2 *> tw;       // exp(-2 pi i k / N), k < N
     std::map<int, double *> win;       // np.hamming(N)
@@ -49,6 +50,8 @@ struct pss_ctx {
     void *stage = nullptr;         // device staging of the host-buffer convenience calls (grow-only)
     size_t stage_bytes = 0;
     bool no_wfm_fused = false;  // option "wfm_fused" = 0: k_wfm_front + k_nfm_iir path (A/B testing)
+    long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover 8192..16384)
+    bool no_small_batch = false;  // option "small_batch" = 0: never take the systolic small-batch NFM path (A/B testing)
     bool no_fused = false;  // PSS_NO_FUSED=1: use the three-kernel NFM path (A/B and fallback testing)
     bool timing = false;
     int tdepth = 0;

@@ -475,7 +475,8 @@ __global__ __launch_bounds__(64) void k_am_sys(const float *__restrict__ env, co
     double z0 = 0.0, z1 = 0.0, xprev = 0.0;
     const long T = (long)n + AM_NS - 1;
     const bool last = active && s == AM_NS - 1;
-    double *yrow = ybuf[last ? g : SYS_G];          // every lane stores every step, no branch in the chain
+    double *const yp = ybuf[last ? g : SYS_G];  // every lane stores every step, no branch in the chain (a shared dump
+                                                // row measured faster than private dump slots)
     // peak tracking happens where the outputs are written back (lane = time there): mxl[gg] = max over this lane's samples
     double mxl[SYS_G];
     bool nanl = false;
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(64) void k_am_sys(const float *__restrict__ env, co
             z0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, x), __dmul_rn(cs.a1, xn)), z1);
             z1 = __dsub_rn(__dmul_rn(cs.b2, x), __dmul_rn(cs.a2, xn));
             xprev = xn;
-            yrow[t] = xn;
+            yp[t] = xn;
         };
         if (cnt == SYS_T) {
             // straight-line groups of 8 steps: the eight LDS reads of a group are issued together, ahead of the chain
@@ -686,6 +687,119 @@ __global__ __launch_bounds__(128) void k_ssb_edge(const float2 *__restrict__ iq,
         m = (unsigned long long)__double_as_longlong(fabs(y));
     }
     ssb_track_max(m, wmax, &mxbits[f]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Zero-phase decimator for SMALL batches (a handful of long frames: the reference's interactive loop hands over one
+// 32768-sample buffer at a time).  With lane = frame a batch of F frames keeps F/64 wavefronts busy and a single frame
+// runs 4 sections x ~9 float64 instructions per sample on one lane of one wavefront.  Here the four cheby1 sections of
+// one frame sit in four adjacent lanes (systolic array, one DPP row shift per step, as k_am_sys): 16 frames per
+// wavefront, each step a single biquad deep.  One launch filters in one direction:
+//   forward  : in = u with SciPy's odd extension around it (k_nfm_front / k_nfm_edge), state zi * in[0], all L outputs kept;
+//   backward : in = y_fwd read back to front, state zi * y_fwd[L-1], only the positions 27 + j q survive ([::q] after the
+//              27-sample trim), written to A[row][j] together with the row's peak.
+// The initial state is non-zero, so section s must not see anything before its first sample: the first four steps update
+// the state under a predicate (t >= s), every later step is unconditional; what the array computes after the last sample
+// has left a section is never read.
+// ---------------------------------------------------------------------------------------------------
+constexpr int IS_G = 16, IS_T = 64;
+__global__ __launch_bounds__(64) void k_iir4_sys(const double *__restrict__ in, long in_stride, int backward, long L, long T,
+                                                 NfmCoef c, double *__restrict__ out, long out_stride, int q, int n_out,
+                                                 double *__restrict__ mxout, long n_rows)
+{
+    __shared__ double ebuf[IS_G][IS_T + 1];
+    __shared__ double ybuf[IS_G + 1][IS_T + 1];  // row IS_G: dump row for the lanes that are not a last section
+    const int lane = threadIdx.x, g = lane >> 2, s = lane & 3;  // 16 frames x 4 sections; DPP rows hold 4 frames each
+    double *const yp = ybuf[s == 3 ? g : IS_G];
+    const long f0 = (long)blockIdx.x * IS_G;
+    const long fg = (f0 + g < n_rows) ? f0 + g : n_rows - 1;
+    const Biquad cs = c.s[s];
+    const double x0 = in[(size_t)fg * in_stride + (backward ? L - 1 : 0)];
+    double z0 = __dmul_rn(c.zi[2 * s], x0), z1 = __dmul_rn(c.zi[2 * s + 1], x0), xprev = 0.0;
+    double mxl[IS_G];
+    unsigned nanmask = 0;
+#pragma unroll
+    for (int gg = 0; gg < IS_G; gg++) mxl[gg] = 0.0;
+    double pre[IS_G];
+    auto prefetch = [&](long c0) {
+#pragma unroll
+        for (int gg = 0; gg < IS_G; gg++) {
+            const long ff = f0 + gg, r = c0 + lane;
+            pre[gg] = (ff < n_rows && r < T) ? in[(size_t)ff * in_stride + (backward ? L - 1 - r : r)] : 0.0;
+        }
+    };
+    const long TT = T + 3;  // steps incl. drain of the 4-deep pipeline
+    auto writeback = [&](long c0) {  // step c0 + t carries the last section's output for input index c0 + t - 3
+#pragma unroll
+        for (int gg = 0; gg < IS_G; gg++) {
+            const long ff = f0 + gg, r = c0 + lane - 3;
+            if (ff < n_rows && r >= 0 && r < T) {
+                const double v = ybuf[gg][lane];
+                if (!backward) out[(size_t)ff * out_stride + r] = v;
+                else {
+                    const long p = L - 1 - r - EDGE;  // position after the 27-sample trim (0 <= p < M survive it)
+                    if (p >= 0 && p < L - 2 * EDGE && p % q == 0) {
+                        out[(size_t)ff * out_stride + p / q] = v;
+                        const double av = fabs(v);
+                        if (av != av) nanmask |= 1u << gg;
+                        mxl[gg] = av > mxl[gg] ? av : mxl[gg];
+                    }
+                }
+            }
+        }
+    };
+    prefetch(0);
+    for (long c0 = 0; c0 < TT; c0 += IS_T) {
+#pragma unroll
+        for (int gg = 0; gg < IS_G; gg++) ebuf[gg][lane] = pre[gg];
+        if (c0 > 0) writeback(c0 - IS_T);
+        if (c0 + IS_T < TT) prefetch(c0 + IS_T);
+        fused::lds_barrier();
+        const int cnt = (TT - c0) < IS_T ? (int)(TT - c0) : IS_T;
+        auto one = [&](int t, double e, bool gated) {
+            const double from_prev = dpp_row_shr1(xprev);
+            const double x = (s == 0) ? e : from_prev;
+            const double xn = __dadd_rn(__dmul_rn(cs.b0, x), z0);
+            const double n0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, x), __dmul_rn(cs.a1, xn)), z1);
+            const double n1 = __dsub_rn(__dmul_rn(cs.b2, x), __dmul_rn(cs.a2, xn));
+            if (gated) {
+                const bool on = c0 + t >= s;
+                z0 = on ? n0 : z0;
+                z1 = on ? n1 : z1;
+            } else { z0 = n0; z1 = n1; }
+            xprev = xn;
+            yp[t] = xn;
+        };
+        for (int t0 = 0; t0 < cnt; t0 += 8) {
+            const int m = (cnt - t0) < 8 ? (cnt - t0) : 8;
+            double e8[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) e8[k] = (k < m) ? ebuf[g][t0 + k] : 0.0;
+            if (c0 == 0 && t0 == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < m) one(t0 + k, e8[k], true);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < m) one(t0 + k, e8[k], false);
+            }
+        }
+        fused::lds_barrier();
+    }
+    writeback(((TT - 1) / IS_T) * IS_T);
+    if (backward) {
+#pragma unroll
+        for (int gg = 0; gg < IS_G; gg++) {
+            double m = mxl[gg];
+            int nn = (nanmask >> gg) & 1;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_xor(m, off);
+                m = o > m ? o : m;
+                nn |= __shfl_xor(nn, off);
+            }
+            if (lane == 0 && f0 + gg < n_rows) mxout[f0 + gg] = nn ? __builtin_nan("") : m;
+        }
+    }
 }
 
 // audio = y / max|y| * 0.95  -> float64 mono and/or int16 stereo (AM :194, SSB :216, io_manager.py:26)
@@ -1344,7 +1458,10 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         bool b121 = true;  // sections 1..3 with numerator exactly [1, 2, 1] (always so for cheby1 low-pass SOS)
         for (int s = 1; s < 4; s++)
             b121 = b121 && flt->sos[6 * s] == 1.0 && flt->sos[6 * s + 1] == 2.0 && flt->sos[6 * s + 2] == 1.0;
-        if (n - 1 >= 128 && !ctx->no_fused) {
+        // a handful of long frames (the interactive loop: one 32768-sample buffer per call) cannot fill lane-per-frame
+        // wavefronts: below this many frames the decimator runs as a 4-lane systolic array per frame instead
+        const bool small_batch = !ctx->no_small_batch && n_frames <= ctx->small_batch_max;
+        if (n - 1 >= 128 && !ctx->no_fused && !small_batch) {
             // fused path: u[] stays on chip; small L2-resident scratch for the irregular head / tail of u
             const size_t szH = align256((size_t)tiles * fused::HEAD * TILE * sizeof(double));
             const size_t szT = align256((size_t)tiles * (EDGE + 1) * TILE * sizeof(double));
@@ -1362,7 +1479,10 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
                 hipLaunchKernelGGL(fused::k_nfm_fwd<false>, dim3((unsigned)tiles), dim3(256), fused::LDS_BYTES, PSS_STREAM(ctx),
                                    reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
             pss_kernel_end(ctx);
-            if (ctx->fork_after_fwd) hipEventRecord(ctx->ev_fork, ctx->stream);  // pss_spectrum_nfm overlaps the rest
+            if (ctx->fork_after_fwd) {  // pss_spectrum_nfm overlaps the rest
+                hipEventRecord(ctx->ev_fork, ctx->stream);
+                ctx->did_fork = true;
+            }
             pss_kernel_begin(ctx, "k_nfm_bwd");
             if (b121)
                 hipLaunchKernelGGL(fused::k_nfm_bwd<true>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af, n, q,
@@ -1377,6 +1497,13 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const int cpf = (n - 1 + FIR_CH - 1) / FIR_CH;
         const long items = n_frames * cpf;
         const long g1 = items < 256L * 64 ? items : 256L * 64;
+        if (small_batch) {
+            const size_t szY2 = align256((size_t)n_frames * L * sizeof(double));
+            const size_t szA2 = align256((size_t)n_frames * n_out * sizeof(double));
+            r = pss_ensure_scratch(ctx, szU + szY2 + szA2 + align256((size_t)n_frames * sizeof(double)));
+            if (r) return r;
+            U = reinterpret_cast<double *>(ctx->scratch);
+        }
         pss_time_begin(ctx);
         pss_kernel_begin(ctx, "k_nfm_front");
         hipLaunchKernelGGL(k_nfm_front, dim3((unsigned)g1), dim3(FIR_T), 0, PSS_STREAM(ctx),
@@ -1386,6 +1513,30 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         hipLaunchKernelGGL(k_nfm_edge, dim3((unsigned)n_frames), dim3(128), 0, PSS_STREAM(ctx),
                            reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, Lp, kscale, swapped, targ);
         pss_kernel_end(ctx);
+        if (small_batch) {
+            // few frames: the four sections of a frame on four lanes (16 frames per wavefront), one launch per direction
+            char *b2 = reinterpret_cast<char *>(ctx->scratch);
+            const size_t szY2 = align256((size_t)n_frames * L * sizeof(double));
+            const size_t szA2 = align256((size_t)n_frames * n_out * sizeof(double));
+            double *Y2 = reinterpret_cast<double *>(b2 + szU), *A2 = reinterpret_cast<double *>(b2 + szU + szY2);
+            double *MX = reinterpret_cast<double *>(b2 + szU + szY2 + szA2);
+            const unsigned gs = (unsigned)((n_frames + IS_G - 1) / IS_G);
+            pss_kernel_begin(ctx, "k_iir4_sys");
+            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(64), 0, PSS_STREAM(ctx), U, Lp, 0, L, L, c, Y2, L, q, n_out, nullptr, n_frames);
+            pss_kernel_end(ctx);
+            pss_kernel_begin(ctx, "k_iir4_sys");
+            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(64), 0, PSS_STREAM(ctx), Y2, L, 1, L, L - EDGE, c, A2, (long)n_out, q, n_out, MX,
+                               n_frames);
+            pss_kernel_end(ctx);
+            size_t tot = (size_t)n_frames * n_out;
+            size_t g2 = (tot + TPB - 1) / TPB;
+            if (g2 > 16384) g2 = 16384;
+            pss_kernel_begin(ctx, "k_finalize");
+            hipLaunchKernelGGL(k_finalize, dim3((unsigned)g2), dim3(TPB), 0, PSS_STREAM(ctx), A2, MX, n_out, n_frames, d_pcm, d_audio);
+            pss_kernel_end(ctx);
+            pss_time_end(ctx);
+            return pss_hip_check(ctx, hipGetLastError(), "nfm small-batch launch");
+        }
         pss_kernel_begin(ctx, "k_nfm_iir");
         if (b121)
             hipLaunchKernelGGL(k_nfm_iir<true>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), U, Y, A, n, q, n_out,
@@ -1642,12 +1793,12 @@ extern "C" int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, 
     pss_time_begin(ctx);  // nested begin/end pairs inside the two calls are no-ops
     // The backward IIR pass runs one wavefront per SIMD and is latency-bound; the spectrum kernel is launched on a
     // side stream right behind the forward kernel so that the two share the machine (fork/join with events).
-    const bool fused = (n - 1 >= 128) && !ctx->no_fused;
-    ctx->fork_after_fwd = fused;
+    ctx->fork_after_fwd = true;  // honoured only by the fused large-batch path, which then sets did_fork
+    ctx->did_fork = false;
     int r2 = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
     ctx->fork_after_fwd = false;
     int r;
-    if (fused && !r2) {
+    if (ctx->did_fork && !r2) {
         hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
         ctx->cur = ctx->stream2;
         r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);

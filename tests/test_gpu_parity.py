@@ -92,9 +92,14 @@ def test_nfm_vs_golden_bit_exact(golden, tag):
     fs = float(g[f"fs_{tag}"])
     e = G.engine()
     e.set_nfm_filters(fs, g[f"taps_{tag}"], g[f"sos_{tag}"], g[f"zi_{tag}"])  # SciPy's own coefficients
-    pcm, audio = G.demod(L.MODE_NFM, g[f"iq_{tag}"], fs)
-    assert np.array_equal(pcm, g[f"pcm_{tag}"])            # int16 bit-exact
-    assert np.array_equal(audio, g[f"audio_{tag}"])        # float64 bit-exact
+    for small_batch in (1, 0):   # systolic small-batch path (default for <= 8192 frames) and the fused large-batch kernels
+        e.set_option("small_batch", small_batch)
+        try:
+            pcm, audio = G.demod(L.MODE_NFM, g[f"iq_{tag}"], fs)
+        finally:
+            e.set_option("small_batch", 1)
+        assert np.array_equal(pcm, g[f"pcm_{tag}"])            # int16 bit-exact
+        assert np.array_equal(audio, g[f"audio_{tag}"])        # float64 bit-exact
 
 
 def test_nfm_designed_filters_pcm_exact(golden):
@@ -120,13 +125,17 @@ def test_nfm_fused_and_three_kernel_paths_agree(golden):
     for nf, n, fs in ((70, 1024, 2.4e6), (5, 2048, 10e6), (3, 300, 1.024e6), (2, 129, 2.4e6), (2, 4097, 2.4e6)):
         iq = (0.4 * np.exp(2j * np.pi * np.cumsum(rng.standard_normal((nf, n)) * 0.05, axis=1)) +
               0.05 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
-        pcm1, a1 = G.demod(L.MODE_NFM, iq, fs)
-        e.set_option("nfm_fused", 0)
+        pcm0, a0 = G.demod(L.MODE_NFM, iq, fs)               # small-batch systolic decimator
+        e.set_option("small_batch", 0)
         try:
-            pcm2, a2 = G.demod(L.MODE_NFM, iq, fs)
+            pcm1, a1 = G.demod(L.MODE_NFM, iq, fs)           # fused forward kernel + backward kernel
+            e.set_option("nfm_fused", 0)
+            pcm2, a2 = G.demod(L.MODE_NFM, iq, fs)           # front / edge / lane-per-frame IIR
         finally:
             e.set_option("nfm_fused", 1)
+            e.set_option("small_batch", 1)
         assert np.array_equal(pcm1, pcm2) and np.array_equal(a1, a2), (nf, n, fs)
+        assert np.array_equal(pcm0, pcm1) and np.array_equal(a0, a1), (nf, n, fs)
         taps, sos, zi = e.nfm_filters(fs)
         for k in range(min(nf, 3)):
             assert np.array_equal(a1[k], O.demod_nfm(iq[k], fs, taps, sos, zi)), (n, k)
@@ -144,10 +153,15 @@ def test_nfm_edges(golden):
     assert np.isnan(audio).all() and np.array_equal(pcm[0], g["pcm_silence"])
     # ragged batch: 70 frames = one full tile + 6 (masked lanes), every frame must equal its single-frame result
     iq = np.tile(g["iq_a"], (12, 1))[:70]
-    pcm, audio = G.demod(L.MODE_NFM, iq, 2.4e6)
-    for k in range(70):
-        assert np.array_equal(pcm[k], g["pcm_a"][k % 6])
-        assert np.array_equal(audio[k], g["audio_a"][k % 6])
+    for small_batch in (1, 0):
+        e.set_option("small_batch", small_batch)
+        try:
+            pcm, audio = G.demod(L.MODE_NFM, iq, 2.4e6)
+        finally:
+            e.set_option("small_batch", 1)
+        for k in range(70):
+            assert np.array_equal(pcm[k], g["pcm_a"][k % 6])
+            assert np.array_equal(audio[k], g["audio_a"][k % 6])
 
 
 def test_nfm_vs_oracle_random():
