@@ -394,7 +394,14 @@ extern "C" int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n
         STREAM_HIP(hipEventRecord(up_done[b], s_up));
         STREAM_HIP(hipStreamWaitEvent(ctx->stream, up_done[b], 0));
         if (k >= 2) STREAM_HIP(hipStreamWaitEvent(ctx->stream, dn_done[b], 0));
-        rc = pss_spectrum_nfm(ctx, (const float *)d_iq[b], cnt, n, fs, (float *)d_db[b], (int16_t *)d_pcm[b]);
+        {
+            // chunks of a stream are throughput work: keep them on the fused large-batch kernels, which also overlap the
+            // spectrum kernel with the backward pass (the small-batch path measured 1.5x slower here)
+            const bool keep = ctx->no_small_batch;
+            ctx->no_small_batch = true;
+            rc = pss_spectrum_nfm(ctx, (const float *)d_iq[b], cnt, n, fs, (float *)d_db[b], (int16_t *)d_pcm[b]);
+            ctx->no_small_batch = keep;
+        }
         if (rc) { cleanup(); return rc; }
         STREAM_HIP(hipEventRecord(cmp_done[b], ctx->stream));
         STREAM_HIP(hipStreamWaitEvent(s_dn, cmp_done[b], 0));
