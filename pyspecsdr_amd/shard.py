@@ -55,6 +55,36 @@ def gather_rows(local, n_items, dst=None, group=None):
     return torch.cat([bufs[r][:counts[r]] for r in range(world)], dim=0)
 
 
+def halo_from_left(local, halo, group=None):
+    """Rows a rank needs from its LEFT neighbour so that the ring accumulators (waterfall: last 30 post-processed rows,
+    persistence: last 10 — pyspecsdr.py:130-132,151-154) of its first frames see the frames just before its block.
+
+    local : tensor [count_r, ...], this rank's block of rows in frame order.
+    Returns a tensor [h, ...] (h <= halo): the last h rows that precede this block in global order; rank 0 gets an empty
+    tensor.  One point-to-point message per neighbour pair (xGMI: a direct peer link, no collective).  A neighbour whose
+    own block is shorter than `halo` forwards what it received, so short blocks still deliver a full halo.
+    """
+    tail = tuple(local.shape[1:])
+    empty = torch.empty((0,) + tail, dtype=local.dtype, device=local.device)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or halo <= 0:
+        return empty
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    got = empty
+    if rank > 0:
+        n = torch.zeros(1, dtype=torch.int64, device=local.device)
+        dist.recv(n, src=rank - 1, group=group)
+        got = torch.empty((int(n.item()),) + tail, dtype=local.dtype, device=local.device)
+        if got.shape[0]:
+            dist.recv(got, src=rank - 1, group=group)
+    if rank < world - 1:
+        rows = torch.cat([got, local], dim=0)[-halo:].contiguous()   # my last rows, topped up with what I was handed
+        n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=local.device)
+        dist.send(n, dst=rank + 1, group=group)
+        if rows.shape[0]:
+            dist.send(rows, dst=rank + 1, group=group)
+    return got
+
+
 def sharded_scan(scan_fn, n_slices, n_fft, gather_db=False, dst=0, group=None):
     """Scanner sweep over n_slices centre frequencies, sharded over the ranks.
 

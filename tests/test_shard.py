@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pyspecsdr_amd.shard import gather_rows, shard_counts, shard_range, sharded_scan
+from pyspecsdr_amd.shard import gather_rows, halo_from_left, shard_counts, shard_range, sharded_scan
 
 import oracle_lib as O
 
@@ -84,3 +84,42 @@ def test_sharded_scan_equals_single_rank(world):
     for s in range(n_slices):          # byte-for-byte what one rank computes alone
         d, p, b, c = O.scan_slice(iq[s], 2.4e6)
         assert np.array_equal(db[s], d) and pk[s] == p and bw[s] == b and cnt[s] == c
+
+
+def _halo_worker(rank, world, port, n_rows, halo, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "caller.npz"))
+        rows = np.tile(g["rows"], (3, 1))[:n_rows]               # post-processed dB rows in frame order
+        start, count = shard_range(n_rows, rank, world)
+        mine = torch.from_numpy(rows[start:start + count].copy())
+        left = halo_from_left(mine, halo)
+        assert left.shape[0] == min(halo, start)
+        assert np.array_equal(left.numpy(), rows[start - left.shape[0]:start])
+        # the ring a display would hold after this rank's LAST frame, built from halo + own rows, quantised by the oracle
+        ring = torch.cat([left, mine], dim=0)[-30:].numpy()
+        H, W = [int(v) for v in g["hw"]]
+        gl, co = O.waterfall_cells(ring, H - 4, W - 8)
+        last = start + count - 1
+        want_ring = rows[max(0, last + 1 - 30):last + 1]
+        gl2, co2 = O.waterfall_cells(want_ring, H - 4, W - 8)
+        assert np.array_equal(gl, gl2) and np.array_equal(co, co2)
+        q.put(rank)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_rows", [(2, 40), (3, 40), (3, 8)])
+def test_halo_exchange_feeds_ring_accumulators(world, n_rows):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, n_rows, 29, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    done = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    assert done == list(range(world)) and all(p.exitcode == 0 for p in procs)
