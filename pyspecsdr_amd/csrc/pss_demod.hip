@@ -737,9 +737,10 @@ __global__ __launch_bounds__(64) void k_iir4_sys(const double *__restrict__ in, 
                 const double v = ybuf[gg][lane];
                 if (!backward) out[(size_t)ff * out_stride + r] = v;
                 else {
-                    const long p = L - 1 - r - EDGE;  // position after the 27-sample trim (0 <= p < M survive it)
-                    if (p >= 0 && p < L - 2 * EDGE && p % q == 0) {
-                        out[(size_t)ff * out_stride + p / q] = v;
+                    const int p = (int)(L - 1 - r - EDGE);  // position after the 27-sample trim (0 <= p < M survive it)
+                    const unsigned j = (unsigned)p / (unsigned)q;
+                    if (p >= 0 && p < (int)(L - 2 * EDGE) && j * (unsigned)q == (unsigned)p) {
+                        out[(size_t)ff * out_stride + j] = v;
                         const double av = fabs(v);
                         if (av != av) nanmask |= 1u << gg;
                         mxl[gg] = av > mxl[gg] ? av : mxl[gg];
@@ -770,17 +771,16 @@ __global__ __launch_bounds__(64) void k_iir4_sys(const double *__restrict__ in, 
             xprev = xn;
             yp[t] = xn;
         };
-        for (int t0 = 0; t0 < cnt; t0 += 8) {
-            const int m = (cnt - t0) < 8 ? (cnt - t0) : 8;
-            double e8[8];
+        if (c0 == 0 || cnt < IS_T) {  // first chunk (gated start) and the last, partial one: step by step
+            for (int t = 0; t < cnt; t++) one(t, ebuf[g][t], c0 == 0 && t < 4);
+        } else {
+            // straight-line groups of 8 steps: the eight LDS reads of a group are issued together, ahead of the chain
+            for (int t0 = 0; t0 < IS_T; t0 += 8) {
+                double e8[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) e8[k] = (k < m) ? ebuf[g][t0 + k] : 0.0;
-            if (c0 == 0 && t0 == 0) {
+                for (int k = 0; k < 8; k++) e8[k] = ebuf[g][t0 + k];
 #pragma unroll
-                for (int k = 0; k < 8; k++) if (k < m) one(t0 + k, e8[k], true);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; k++) if (k < m) one(t0 + k, e8[k], false);
+                for (int k = 0; k < 8; k++) one(t0 + k, e8[k], false);
             }
         }
         fused::lds_barrier();
