@@ -1125,7 +1125,8 @@ __global__ __launch_bounds__(TILE) void k_wfm_front(const float2 *__restrict__ i
 
 // :157-163 — joint peak normalisation of the two decimated channels, column_stack, and the int16 conversion.
 // A: k_nfm_iir's transposed decimated rows ([tile][k][lane], row g = 2f + channel); mxrow[g] = max|row g| (NaN kept).
-// planar: rows are [2*tile + channel][lane] (fused forward kernel) instead of 2f + channel (k_wfm_front).
+// planar 1: rows are [2*tile + channel][lane] (fused forward kernel) instead of 2f + channel (k_wfm_front);
+// planar 2: A is row-major [2f + channel][k] (small-batch decimator).
 __global__ __launch_bounds__(TPB) void k_wfm_finalize(const double *__restrict__ A, const double *__restrict__ mxrow,
                                                       int n_out, long n_frames, int planar, int16_t *__restrict__ pcm,
                                                       double *__restrict__ audio)
@@ -1134,16 +1135,148 @@ __global__ __launch_bounds__(TPB) void k_wfm_finalize(const double *__restrict__
     for (size_t idx = (size_t)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (size_t)gridDim.x * TPB) {
         const long f = (long)(idx / n_out);
         const int k = (int)(idx - (size_t)f * n_out);
-        const long gl = planar ? (f / TILE) * 2 * TILE + (f % TILE) : 2 * f, gr = planar ? gl + TILE : gl + 1;
+        const long gl = planar == 1 ? (f / TILE) * 2 * TILE + (f % TILE) : 2 * f, gr = planar == 1 ? gl + TILE : gl + 1;
         const double ml = mxrow[gl], mr = mxrow[gr];
         const double mx = (mr > ml) ? mr : ml;  // python max(a, b): b only if b > a
-        const double vl = A[(size_t)(gl / TILE) * n_out * TILE + (size_t)k * TILE + (gl % TILE)];
-        const double vr = A[(size_t)(gr / TILE) * n_out * TILE + (size_t)k * TILE + (gr % TILE)];
+        const double vl = planar == 2 ? A[(size_t)gl * n_out + k] : A[(size_t)(gl / TILE) * n_out * TILE + (size_t)k * TILE + (gl % TILE)];
+        const double vr = planar == 2 ? A[(size_t)gr * n_out + k] : A[(size_t)(gr / TILE) * n_out * TILE + (size_t)k * TILE + (gr % TILE)];
         const double l = __ddiv_rn(vl, mx), r = __ddiv_rn(vr, mx);
         if (audio) { audio[2 * idx] = l; audio[2 * idx + 1] = r; }
         if (pcm) {
             const uint16_t a = (uint16_t)pcm16(l), b = (uint16_t)pcm16(r);
             reinterpret_cast<uint32_t *>(pcm)[idx] = (uint32_t)a | ((uint32_t)b << 16);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// WFM for SMALL batches (the interactive loop: one frame per call).  k_wfm_fwd steps ~200 float64 instructions per sample
+// on ONE lane per frame; here every filter section is its own lane (systolic array, one frame per 16-lane DPP row, four
+// frames per wavefront) and the chain runs as two cascaded passes with float64 rows in memory between them:
+//   pass 1  d -> LP15k (3 lanes) -> a ; d -> BP pilot (5) -> 1-pole -> y -> pilot value p ; d -> BP 23..53k (5) -> m
+//   pass 2  m * (2 p) -> LP15k (3) -> (a +- .)/2 -> de-emphasis, once per channel (two 4-lane groups) -> u_l, u_r,
+//           written with SciPy's odd extension around them in the layout the small-batch decimator (k_iir4_sys) reads.
+// Every lane executes sosfilt's step on its own section; a 1-pole stage is that step with b1 = +0.0 and its second state
+// pinned to -0.0 (v + -0.0 == v bit for bit), which is lfilter's  y = z + b0 x ; z = x*0 - y*a1.  All stages start from a
+// zero state, so filling and draining the pipeline with zeros is exact.
+// ---------------------------------------------------------------------------------------------------
+struct CascLane {
+    Biquad c;
+    int head;      // 1: takes the staged input instead of its left neighbour's output
+    int onepole;   // 1: 1-pole stage (second state pinned to -0.0)
+    int mix;       // +1 / -1: input = (a +- left neighbour) * 0.5 (the L/R matrix), 0: plain
+    int out_slot;  // >= 0: this lane's output is row out_slot of the write-back buffer
+};
+struct CascArg { CascLane lane[16]; };
+constexpr int CS_T = 64;
+
+template <int MODE>  // 1: discriminator -> a, p, m      2: m, p, a -> u_l, u_r (+ odd extension)
+__global__ __launch_bounds__(64) void k_wfm_casc(const float2 *__restrict__ iq, double *__restrict__ Aa, double *__restrict__ Pp,
+                                                 double *__restrict__ Mm, double *U, int n, long n_frames, long Lp, int swapped,
+                                                 CascArg arg)
+{
+    constexpr int NIN = 2, NOUT = 3;
+    __shared__ double ebuf[4][NIN][CS_T + 1];
+    __shared__ double ybuf[4][NOUT + 1][CS_T + 1];  // row NOUT: dump row
+    const int lane = threadIdx.x, row = lane >> 4, r = lane & 15;
+    const CascLane me = arg.lane[r];
+    const long f0 = (long)blockIdx.x * 4;
+    const int M = n - 1;
+    const int DA = (MODE == 1) ? 2 : 3, DB = (MODE == 1) ? 5 : 3, DC = 4;  // pipeline delay of each output row
+    const long TT = (long)M + 5;  // steps incl. drain of the deepest cascade
+    double z0 = 0.0, z1 = me.onepole ? -0.0 : 0.0, xprev = 0.0;
+    double *const yp = ybuf[row][me.out_slot >= 0 ? me.out_slot : NOUT];
+    const double SIN_PI = 0x1.1a62633145c07p-53;  // np.sin(np.pi)
+    double pre[4][NIN];
+    auto prefetch = [&](long c0) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const long f = f0 + g, i = c0 + lane;
+            pre[g][0] = 0.0; pre[g][1] = 0.0;
+            if (f < n_frames) {
+                if (MODE == 1) {
+                    if (i < M) {
+                        const float2 *x = iq + (size_t)f * n;
+                        pre[g][0] = (double)disc_sample(x[i + 1], x[i], 1.0f, swapped != 0);  // :122
+                    }
+                } else {
+                    if (i < M) pre[g][0] = __dmul_rn(Mm[(size_t)f * M + i], __dmul_rn(2.0, Pp[(size_t)f * M + i]));  // :134
+                    if (i - 3 >= 0 && i - 3 < M) pre[g][1] = Aa[(size_t)f * M + i - 3];  // a[], aligned with the mixing lanes
+                }
+            }
+        }
+    };
+    auto writeback = [&](long c0) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const long f = f0 + g;
+            if (f >= n_frames) continue;
+            const long ia = c0 + lane - DA, ib = c0 + lane - DB, ic = c0 + lane - DC;
+            if (MODE == 1) {
+                if (ia >= 0 && ia < M) Aa[(size_t)f * M + ia] = ybuf[g][0][lane];
+                if (ib >= 0 && ib < M) {
+                    const double y = ybuf[g][1][lane];  // :130 np.sin(np.unwrap(np.angle(real))) = 0 or sin(pi)
+                    Pp[(size_t)f * M + ib] = (y != y) ? y : ((y < 0.0 || (y == 0.0 && __builtin_signbit(y))) ? SIN_PI : 0.0);
+                }
+                if (ic >= 0 && ic < M) Mm[(size_t)f * M + ic] = ybuf[g][2][lane];
+            } else {
+                if (ia >= 0 && ia < M) U[(size_t)(2 * f) * Lp + EDGE + ia] = ybuf[g][0][lane];
+                if (ib >= 0 && ib < M) U[(size_t)(2 * f + 1) * Lp + EDGE + ib] = ybuf[g][1][lane];
+            }
+        }
+    };
+    prefetch(0);
+    for (long c0 = 0; c0 < TT; c0 += CS_T) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) { ebuf[g][0][lane] = pre[g][0]; ebuf[g][1][lane] = pre[g][1]; }
+        if (c0 > 0) writeback(c0 - CS_T);
+        if (c0 + CS_T < TT) prefetch(c0 + CS_T);
+        fused::lds_barrier();
+        const int cnt = (TT - c0) < CS_T ? (int)(TT - c0) : CS_T;
+        auto one = [&](int t, double e, double a) {
+            const double from_prev = dpp_row_shr1(xprev);
+            double x = me.head ? e : from_prev;
+            if (MODE == 2) {
+                const double mixed = __dmul_rn(me.mix > 0 ? __dadd_rn(a, from_prev) : __dsub_rn(a, from_prev), 0.5);  // :140-141
+                x = me.mix ? mixed : x;
+            }
+            const double xn = __dadd_rn(__dmul_rn(me.c.b0, x), z0);
+            z0 = __dadd_rn(__dsub_rn(__dmul_rn(me.c.b1, x), __dmul_rn(me.c.a1, xn)), z1);
+            const double n1 = __dsub_rn(__dmul_rn(me.c.b2, x), __dmul_rn(me.c.a2, xn));
+            z1 = me.onepole ? -0.0 : n1;
+            xprev = xn;
+            yp[t] = xn;
+        };
+        if (cnt == CS_T) {
+            for (int t0 = 0; t0 < CS_T; t0 += 8) {
+                double e8[8], a8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { e8[k] = ebuf[row][0][t0 + k]; a8[k] = (MODE == 2) ? ebuf[row][1][t0 + k] : 0.0; }
+#pragma unroll
+                for (int k = 0; k < 8; k++) one(t0 + k, e8[k], a8[k]);
+            }
+        } else {
+            for (int t = 0; t < cnt; t++) one(t, ebuf[row][0][t], (MODE == 2) ? ebuf[row][1][t] : 0.0);
+        }
+        fused::lds_barrier();
+    }
+    writeback(((TT - 1) / CS_T) * CS_T);
+    if (MODE == 2) {
+        // odd extension (scipy _arraytools.odd_ext) of both channel rows from this wavefront's own stores
+        __threadfence();
+        fused::lds_barrier();
+        for (int g = 0; g < 4; g++) {
+            const long f = f0 + g;
+            if (f >= n_frames) continue;
+            for (int ch = 0; ch < 2; ch++) {
+                double *u = U + (size_t)(2 * f + ch) * Lp + EDGE;
+                if (lane < EDGE) {
+                    const double u0 = __builtin_nontemporal_load(u), ul = __builtin_nontemporal_load(u + M - 1);
+                    const double a = __builtin_nontemporal_load(u + EDGE - lane), b = __builtin_nontemporal_load(u + M - 2 - lane);
+                    u[lane - EDGE] = __dsub_rn(__dmul_rn(2.0, u0), a);
+                    u[M + lane] = __dsub_rn(__dmul_rn(2.0, ul), b);
+                }
+            }
         }
     }
 }
@@ -1666,6 +1799,54 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         for (const double *bp : {wf->pilot, wf->lmr})
             spec = spec && is_num(bp + 6, 1, 2, 1) && is_num(bp + 12, 1, 0, -1) && is_num(bp + 18, 1, -2, 1) && is_num(bp + 24, 1, -2, 1);
         pss_time_begin(ctx);
+        if (!ctx->no_small_batch && n_frames <= ctx->wfm_small_batch_max) {
+            // a handful of frames: one lane per filter SECTION instead of one lane per frame (k_wfm_casc, k_iir4_sys)
+            const int M = n - 1;
+            const size_t szR = align256((size_t)n_frames * M * sizeof(double));
+            const size_t szY2 = align256((size_t)rows * L * sizeof(double));
+            const size_t szA2 = align256((size_t)rows * n_out * sizeof(double));
+            r = pss_ensure_scratch(ctx, 3 * szR + szU + szY2 + szA2 + align256((size_t)rows * sizeof(double)));
+            if (r) return r;
+            char *b2 = reinterpret_cast<char *>(ctx->scratch);
+            double *Aa = reinterpret_cast<double *>(b2), *Pp = reinterpret_cast<double *>(b2 + szR), *Mm = reinterpret_cast<double *>(b2 + 2 * szR);
+            double *U2 = reinterpret_cast<double *>(b2 + 3 * szR), *Y2 = reinterpret_cast<double *>(b2 + 3 * szR + szU);
+            double *A2 = reinterpret_cast<double *>(b2 + 3 * szR + szU + szY2), *MX2 = reinterpret_cast<double *>(b2 + 3 * szR + szU + szY2 + szA2);
+            CascArg a1, a2;
+            const Biquad idle{0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int i = 0; i < 16; i++) a1.lane[i] = a2.lane[i] = CascLane{idle, 1, 0, 0, -1};
+            for (int i = 0; i < 3; i++) a1.lane[i] = CascLane{wc.lp[i], i == 0, 0, 0, i == 2 ? 0 : -1};             // a
+            for (int i = 0; i < 5; i++) a1.lane[3 + i] = CascLane{wc.pil[i], i == 0, 0, 0, -1};                       // pilot band-pass
+            a1.lane[8] = CascLane{Biquad{1.0, 0.0, 0.0, -0.99, 0.0}, 0, 1, 0, 1};                                     // lfilter([1],[1,-0.99]) -> y
+            for (int i = 0; i < 5; i++) a1.lane[9 + i] = CascLane{wc.lmr[i], i == 0, 0, 0, i == 4 ? 2 : -1};          // m
+            for (int ch = 0; ch < 2; ch++) {
+                for (int i = 0; i < 3; i++) a2.lane[4 * ch + i] = CascLane{wc.lp[i], i == 0, 0, 0, -1};               // :137
+                a2.lane[4 * ch + 3] = CascLane{Biquad{wc.b0d, 0.0, 0.0, wc.a1d, 0.0}, 0, 1, ch ? -1 : 1, ch};         // matrix + de-emphasis
+            }
+            const unsigned gc = (unsigned)((n_frames + 3) / 4);
+            pss_kernel_begin(ctx, "k_wfm_casc");
+            hipLaunchKernelGGL(k_wfm_casc<1>, dim3(gc), dim3(64), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Aa, Pp, Mm,
+                               U2, n, n_frames, Lp, swapped, a1);
+            pss_kernel_end(ctx);
+            pss_kernel_begin(ctx, "k_wfm_casc");
+            hipLaunchKernelGGL(k_wfm_casc<2>, dim3(gc), dim3(64), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Aa, Pp, Mm,
+                               U2, n, n_frames, Lp, swapped, a2);
+            pss_kernel_end(ctx);
+            const unsigned gs = (unsigned)((rows + IS_G - 1) / IS_G);
+            pss_kernel_begin(ctx, "k_iir4_sys");
+            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(64), 0, PSS_STREAM(ctx), U2, Lp, 0, L, L, c, Y2, L, q, n_out, nullptr, rows);
+            pss_kernel_end(ctx);
+            pss_kernel_begin(ctx, "k_iir4_sys");
+            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(64), 0, PSS_STREAM(ctx), Y2, L, 1, L, L - EDGE, c, A2, (long)n_out, q, n_out, MX2, rows);
+            pss_kernel_end(ctx);
+            size_t tot = (size_t)n_frames * n_out;
+            size_t g2 = (tot + TPB - 1) / TPB;
+            if (g2 > 16384) g2 = 16384;
+            pss_kernel_begin(ctx, "k_wfm_finalize");
+            hipLaunchKernelGGL(k_wfm_finalize, dim3((unsigned)g2), dim3(TPB), 0, PSS_STREAM(ctx), A2, MX2, n_out, n_frames, 2, d_pcm, d_audio);
+            pss_kernel_end(ctx);
+            pss_time_end(ctx);
+            return pss_hip_check(ctx, hipGetLastError(), "wfm small-batch launch");
+        }
         if (!ctx->no_wfm_fused) {
             // fused path: forward decimator pass inside the front kernel, y_fwd planar-transposed, u[] never stored
             double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);

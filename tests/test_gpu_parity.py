@@ -297,11 +297,16 @@ def test_wfm_vs_golden_bit_exact(golden, tag):
     e.set_wfm_filters(fs, f["lp_sos"], f["pilot_sos"], f["lmr_sos"], float(f["alpha"]))
     taps, _, _ = e.nfm_filters(fs)
     e.set_nfm_filters(fs, taps, f["dec_sos"], f["dec_zi"])
-    pcm, audio = _wfm(e, g[f"iq_{tag}"], fs)
     want = g[f"audio_{tag}"]
-    assert audio.shape == want.shape
-    assert np.array_equal(audio.view(np.uint64), want.view(np.uint64)), np.abs(audio - want).max()
-    assert np.array_equal(pcm, g[f"pcm_{tag}"])
+    for small_batch in (1, 0):   # systolic small-batch kernels (default for a few frames) and the fused large-batch kernels
+        e.set_option("small_batch", small_batch)
+        try:
+            pcm, audio = _wfm(e, g[f"iq_{tag}"], fs)
+        finally:
+            e.set_option("small_batch", 1)
+        assert audio.shape == want.shape
+        assert np.array_equal(audio.view(np.uint64), want.view(np.uint64)), (small_batch, np.abs(audio - want).max())
+        assert np.array_equal(pcm, g[f"pcm_{tag}"])
 
 
 def test_wfm_designed_filters_and_shim(golden):
@@ -361,13 +366,17 @@ def test_wfm_fused_and_unfused_paths_agree():
     for nf, n, fs in ((70, 1024, 2.4e6), (3, 29, 2.4e6), (5, 30, 250e3), (2, 45, 1.024e6), (65, 61, 2.4e6), (2, 4097, 2.048e6)):
         ph = np.cumsum(rng.standard_normal((nf, n)) * 0.2, axis=1)
         iq = (0.5 * np.exp(1j * ph) + 0.03 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
-        pcm1, a1 = _wfm(e, iq, fs, dispatcher=False)
-        e.set_option("wfm_fused", 0)
+        pcm0, a0 = _wfm(e, iq, fs, dispatcher=False)        # small-batch: one lane per filter section
+        e.set_option("small_batch", 0)
         try:
-            pcm2, a2 = _wfm(e, iq, fs, dispatcher=False)
+            pcm1, a1 = _wfm(e, iq, fs, dispatcher=False)    # fused forward kernel + backward kernel
+            e.set_option("wfm_fused", 0)
+            pcm2, a2 = _wfm(e, iq, fs, dispatcher=False)    # k_wfm_front + lane-per-frame decimator
         finally:
             e.set_option("wfm_fused", 1)
+            e.set_option("small_batch", 1)
         assert np.array_equal(a1.view(np.uint64), a2.view(np.uint64)) and np.array_equal(pcm1, pcm2), (nf, n, fs)
+        assert np.array_equal(a0.view(np.uint64), a1.view(np.uint64)) and np.array_equal(pcm0, pcm1), (nf, n, fs)
 
 
 def test_bandpass_filter_and_sosfilt_rows(golden):
