@@ -39,6 +39,7 @@ def main():
             ("measure_signal_power", lambda: sp.measure_signal_power(x), lambda: O.power_db(x)),
             ("demodulate_signal NFM", lambda: sp.demodulate_signal(x, fs, "NFM"), lambda: O.demod_nfm(x, fs, taps, sos, zi)),
             ("demodulate_signal AM", lambda: sp.demodulate_signal(x, fs, "AM"), lambda: O.demod_am(x, am)),
+            ("demodulate_signal USB", lambda: sp.demodulate_signal(x, fs, "USB"), lambda: O.demod_ssb(x, e.ssb_taps(fs))),
             ("demodulate_signal WFM", lambda: sp.demodulate_signal(x, fs, "WFM"), None),
             ("demodulate_signal RAW", lambda: sp.demodulate_signal(x, fs, "RAW"), lambda: O.iq_correction(x)),
         ]
