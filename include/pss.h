@@ -162,6 +162,10 @@ int pss_h_bandpass_filter(pss_ctx *ctx, const double *h_x, int n, double lowcut,
 /* demodulate_signal(samples, fs, mode) on one host frame (dispatcher semantics: WFM is IQ-corrected first). */
 int pss_h_demodulate_signal(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,
                             int16_t *h_pcm);
+/* demodulate_signal over n_frames read buffers held in host memory (e.g. an IQ recording, pyspecsdr.py:814-824, cut into
+ * the reference's read size): h_pcm int16 [n_frames][n_out][2], chunk_frames frames per round trip. */
+int pss_h_demodulate_batch(pss_ctx *ctx, int mode, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
+                           int16_t *h_pcm);
 int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float *h_power);
 /* iq_correction(samples) / demodulate_signal(samples, fs, 'RAW') on one host frame; either output may be NULL. */
 int pss_h_iq_correction(pss_ctx *ctx, const float *h_iq, int n, float *h_out_iq, float *h_raw);

@@ -54,6 +54,7 @@ _SIGS = {
     "pss_h_compute_fft": (C.c_int, [_p, _p, C.c_int, _p]),
     "pss_h_demodulate": (C.c_int, [_p, C.c_int, _p, C.c_int, C.c_double, _p, _p]),
     "pss_h_demodulate_signal": (C.c_int, [_p, C.c_int, _p, C.c_int, C.c_double, _p, _p]),
+    "pss_h_demodulate_batch": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, C.c_long, _p]),
     "pss_h_measure_power": (C.c_int, [_p, _p, C.c_int, _p]),
     "pss_sosfilt": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, C.c_int, _p]),
     "pss_h_bandpass_filter": (C.c_int, [_p, _p, C.c_int, C.c_double, C.c_double, C.c_double, _p, C.c_int, _p]),

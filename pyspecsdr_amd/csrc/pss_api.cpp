@@ -266,6 +266,37 @@ extern "C" int pss_h_demodulate_signal(pss_ctx *ctx, int mode, const float *h_iq
     return h_demod_impl(ctx, mode, h_iq, n, fs, h_audio_stereo, h_pcm, true);
 }
 
+// demodulate_signal over a batch of frames in HOST memory (a recording cut into read buffers, pyspecsdr.py:814-824 /
+// :2236): chunks of frames go up, through pss_demod_signal, and the int16 PCM comes back — the byte stream
+// audio_processing.write_audio_samples / io_manager.write_to_pipe would have produced buffer by buffer.
+extern "C" int pss_h_demodulate_batch(pss_ctx *ctx, int mode, const float *h_iq, long n_frames, int n, double fs,
+                                      long chunk_frames, int16_t *h_pcm)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!h_iq || !h_pcm || n_frames < 0 || n < 1 || chunk_frames < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
+    const int n_out = pss_demod_out_len(mode, n, fs);
+    if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "unknown mode or sample rate below 22050 Hz");
+    if (chunk_frames > n_frames) chunk_frames = n_frames;
+    if (n_frames == 0) return PSS_OK;
+    const size_t iq_b = up256((size_t)chunk_frames * n * 2 * sizeof(float));
+    const size_t pcm_b = up256((size_t)chunk_frames * n_out * 2 * sizeof(int16_t));
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, iq_b + pcm_b, "staging");
+    if (r) return r;
+    char *base = reinterpret_cast<char *>(ctx->stage);
+    for (long f0 = 0; f0 < n_frames; f0 += chunk_frames) {
+        const long cnt = (n_frames - f0) < chunk_frames ? (n_frames - f0) : chunk_frames;
+        PSS_HIP(ctx, hipMemcpyAsync(base, h_iq + (size_t)f0 * n * 2, (size_t)cnt * n * 2 * sizeof(float), hipMemcpyHostToDevice,
+                                    ctx->stream));
+        r = pss_demod_signal(ctx, mode, reinterpret_cast<const float *>(base), cnt, n, fs, reinterpret_cast<int16_t *>(base + iq_b),
+                             nullptr);
+        if (r) return r;
+        PSS_HIP(ctx, hipMemcpyAsync(h_pcm + (size_t)f0 * n_out * 2, base + iq_b, (size_t)cnt * n_out * 2 * sizeof(int16_t),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PSS_OK;
+}
+
 extern "C" int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float *h_power)
 {
     if (!ctx) return PSS_E_ARG;

@@ -237,6 +237,17 @@ class Engine:
         self._ck(self.lib.pss_h_demodulate_signal(self.h, mode, _ptr(iq), len(iq), float(fs), _ptr(audio), _ptr(pcm)))
         return audio, pcm
 
+    def h_demodulate_batch(self, mode, frames, fs, chunk_frames=4096):
+        """frames: complex64 [n_frames][n] in host memory -> int16 PCM [n_frames][n_out][2] (dispatcher semantics)."""
+        frames = np.ascontiguousarray(frames, np.complex64)
+        nf, n = frames.shape
+        n_out = self.demod_out_len(mode, n, fs)
+        if n_out < 0:
+            raise ValueError("sample rate below 22050 Hz or unknown mode")
+        pcm = np.empty((nf, n_out, 2), np.int16)
+        self._ck(self.lib.pss_h_demodulate_batch(self.h, mode, _ptr(frames), nf, n, float(fs), int(chunk_frames), _ptr(pcm)))
+        return pcm
+
     def h_iq_correction(self, iq):
         iq = np.ascontiguousarray(iq, np.complex64)
         out = np.empty(len(iq), np.complex64)

@@ -401,6 +401,26 @@ def test_bandpass_filter_and_sosfilt_rows(golden):
         assert np.array_equal(y[r], O.sosfilt(sos, x[r]))
 
 
+def test_recording_to_wav_roundtrip(tmp_path, golden):
+    """Formats either side of the path: an np.save'd IQ recording (pyspecsdr.py:814-824) cut into read
+    buffers, demodulated on the GPU, written as the WAV file audio_processing.py:25-43 would produce."""
+    import wave
+    from pyspecsdr_amd import formats
+    g = golden["nfm"]
+    frames = g["iq_a"]                                   # 6 buffers of 1024 samples
+    rec = np.concatenate([frames.reshape(-1), frames[0][:100]])   # plus an incomplete tail buffer
+    npy, wav = str(tmp_path / "rec.npy"), str(tmp_path / "rec.wav")
+    np.save(npy, rec)
+    pcm = formats.recording_to_wav(npy, wav, 2.4e6, "NFM", frame_len=1024)
+    assert np.array_equal(pcm, g["pcm_a"])
+    with wave.open(wav, "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (2, 2, 22050)
+        assert w.readframes(w.getnframes()) == g["pcm_a"].tobytes() == formats.pipe_bytes(pcm)
+    wf = golden["wfm"]
+    pcm = formats.demodulate_recording(wf["iq_a"].reshape(-1), 2.4e6, "WFM", frame_len=1024, chunk_frames=3)
+    assert np.array_equal(pcm, wf["pcm_a"])
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()
