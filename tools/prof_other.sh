@@ -1,0 +1,14 @@
+#!/bin/bash
+# Kernel-trace stats + HBM counters of the widened rows (WFM dispatcher path, cfg 3 AM/SSB/power/16k spectrum) on the GPU box.
+#   bash tools/prof_other.sh r01
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/prof_other_$TAG
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p "$OUT"
+CMD="python tools/bench_configs.py wfm cfg3"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt -- $CMD > "$OUT/kt.log" 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT" -o write -- $CMD > "$OUT/write.log" 2>&1
+python tools/prof_digest.py "$OUT" "$TAG" | sed "s#python bench.py --steps 10 --warmup 2 --no-cpu-baseline#$CMD#"
+grep '^{"config"' "$OUT/kt.log" >> "$OUT/summary_$TAG.txt"
