@@ -123,38 +123,38 @@ __global__ __launch_bounds__(TILE) void k_wfm_fwd(const float2 *__restrict__ iq,
         for (int k = 0; k <= EDGE; k++) feed(RG(k, 0), RG(k, 1));
     };
 
-    // ---- input staging: lane -> (frame lane/16 + 4 j, sample lane%16), j = 0..15
+    // ---- input staging: lane -> (frame lane/16 + 4 j, sample lane%16), j = 0..15.  Chunks are ALIGNED groups of 16 samples
+    // x[16 c .. 16 c + 15] (one 128-byte line per frame and chunk; the off-by-one window x[1 + 16 c ...] straddled two lines
+    // and doubled the HBM fetch, rocprofv3 FETCH_SIZE).  Element e = 0 only seeds `prev`; element e >= 1 is step i = e - 1.
     const int ls = lane & 15, lf = lane >> 4;
-    auto gload = [&](float2 (&b)[CH], int i0) {  // samples x[1 + i0 + ls] of 16 x 4 frames
+    auto gload = [&](float2 (&b)[CH], int e0) {
 #pragma unroll
         for (int j = 0; j < CH; j++) {
             long fr = f0 + lf + 4 * j;
             fr = fr < n_frames ? fr : n_frames - 1;
-            const int t = 1 + i0 + ls;
-            b[j] = t < n ? iq[(size_t)fr * n + t] : make_float2(0.0f, 0.0f);
+            const int e = e0 + ls;
+            b[j] = e < n ? iq[(size_t)fr * n + e] : make_float2(0.0f, 0.0f);
         }
     };
     auto spill = [&](const float2 (&b)[CH]) {
 #pragma unroll
         for (int j = 0; j < CH; j++) xs[ls * XSTR + lf + 4 * j] = b[j];
     };
-    long frl = f0 + lane;
-    frl = frl < n_frames ? frl : n_frames - 1;
-    float2 prev = iq[(size_t)frl * n];
+    float2 prev = make_float2(0.0f, 0.0f);
     float2 nb[CH];
     gload(nb, 0);
-    for (int i0 = 0; i0 < M; i0 += CH) {
+    for (int e0 = 0; e0 < n; e0 += CH) {
         spill(nb);
-        if (i0 + CH < M) gload(nb, i0 + CH);
+        if (e0 + CH < n) gload(nb, e0 + CH);
         fused::lds_barrier();  // the transposed chunk is in LDS (LDS-only wait: the Y row stores stay in flight)
-        const int cnt = (M - i0) < CH ? (M - i0) : CH;
+        const int cnt = (n - e0) < CH ? (n - e0) : CH;
         for (int t4 = 0; t4 < cnt; t4 += 4) {
-            if (i0 + t4 == EDGE + 1) prime();  // steps 0..27 are in the ring (28 is a multiple of 4)
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int t = t4 + u, i = i0 + t;
+                const int t = t4 + u, i = e0 + t - 1;
                 if (t < cnt) {
                     const float2 cur = xs[t * XSTR + lane];
+                    if (i < 0) { prev = cur; continue; }
                     const double d = (double)disc_sample(cur, prev, 1.0f, swapped != 0);  // :122 (x1.0f is exact)
                     prev = cur;
                     const double a = lp3(d, zlp);                                                              // :126
@@ -169,12 +169,12 @@ __global__ __launch_bounds__(TILE) void k_wfm_fwd(const float2 *__restrict__ iq,
                     RG(i, 0) = yl;
                     RG(i, 1) = yr;
                     if (i > EDGE) feed(yl, yr);
+                    else if (i == EDGE) prime();  // steps 0..27 are in the ring
                 }
             }
         }
         fused::lds_barrier();  // all lanes are done with xs before the next chunk overwrites it
     }
-    if (M == EDGE + 1) prime();  // shortest legal frame: the loop never reached step 28
     // right extension: 2 u[M-1] - u[M-2-k], k = 0..26
     {
         const double lN = RG(M - 1, 0), rN = RG(M - 1, 1);
