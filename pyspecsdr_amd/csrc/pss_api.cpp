@@ -115,7 +115,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     for (auto &kv : ctx->win) hipFree(kv.second);
     for (auto &kv : ctx->plans) {
         hipFree(kv.second.d_leaf_off); hipFree(kv.second.d_leaf_len); hipFree(kv.second.d_node_l);
-        hipFree(kv.second.d_node_r); hipFree(kv.second.d_level_start);
+        hipFree(kv.second.d_node_r); hipFree(kv.second.d_level_start); hipFree(kv.second.d_roots);
     }
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->scratch_fft) hipFree(ctx->scratch_fft);

@@ -21,8 +21,9 @@ struct PssWfmFilt {
 };
 
 struct PssPairwisePlan {  // numpy pairwise-sum tree for one frame length (see pss_demod.hip)
-    int n_leaves = 0, n_nodes = 0, n_levels = 0;
+    int n_leaves = 0, n_nodes = 0, n_levels = 0, n_roots = 0;
     int *d_leaf_off = nullptr, *d_leaf_len = nullptr, *d_node_l = nullptr, *d_node_r = nullptr, *d_level_start = nullptr;
+    int *d_roots = nullptr;
 };
 
 struct pss_ctx {

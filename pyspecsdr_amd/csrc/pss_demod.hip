@@ -823,14 +823,22 @@ __global__ __launch_bounds__(TPB) void k_finalize(const double *__restrict__ Yf,
 // elementwise step; each reduction walks numpy's own summation tree (PssPairwisePlan) so every intermediate scalar
 // has numpy's bits.  The frame (8 KB at n=1024) is re-read from L1/L2 per pass; intermediates are recomputed.
 struct PlanDev {
-    const int *leaf_off, *leaf_len, *node_l, *node_r, *level_start;
-    int n_leaves, n_levels;
+    const int *leaf_off, *leaf_len, *node_l, *node_r, *level_start, *roots;
+    int n_leaves, n_levels, n_roots;
+};
+// A frame is reduced in GROUPS of up to RED_K ufunc chunks (8192 elements each): numpy adds the chunk sums sequentially,
+// sum = ((S0 + S1) + S2) + ..., so a group's plan is a forest (one pairwise tree per chunk) whose roots are added in
+// order onto the running sum.  Frames up to RED_K chunks are one (tail) group; longer ones loop over full groups first —
+// the LDS footprint no longer grows with the frame (1 Mi-sample read buffers, pyspecsdr.py:2236 with SAMPLES = 12).
+struct RedPlan {
+    PlanDev full, tail;
+    int n_full, glen;  // full groups of glen elements each, then the tail group (tail.n_leaves may be 0)
 };
 // A leaf of numpy's tree is <= 128 elements summed into 8 running accumulators; those 8 partial sums are independent,
 // so a lane owns one (leaf, accumulator) pair — at n = 1024 that is exactly one wavefront per frame — and one lane per
 // leaf then folds the 8 partials and the < 8 tail elements in numpy's order.  part: 8 floats per leaf.
 template <class F>
-__device__ __forceinline__ float wg_rsum(const PlanDev &p, float *part, float *val, F elem)
+__device__ __forceinline__ float wg_rsum(const PlanDev &p, float *part, float *val, F elem, float carry, bool have)
 {
     const int tid = threadIdx.x, T = blockDim.x;
     for (int slot = tid; slot < p.n_leaves * 8; slot += T) {
@@ -862,15 +870,21 @@ __device__ __forceinline__ float wg_rsum(const PlanDev &p, float *part, float *v
             val[p.n_leaves + k] = __fadd_rn(val[p.node_l[k]], val[p.node_r[k]]);
         __syncthreads();
     }
-    const int nn = p.level_start[p.n_levels];
-    const float sum = nn ? val[p.n_leaves + nn - 1] : val[0];
+    const int res = p.n_leaves + p.level_start[p.n_levels];  // free slot behind the nodes
+    if (tid == 0) {
+        float acc = have ? __fadd_rn(carry, val[p.roots[0]]) : val[p.roots[0]];
+        for (int k = 1; k < p.n_roots; k++) acc = __fadd_rn(acc, val[p.roots[k]]);
+        val[res] = acc;
+    }
+    __syncthreads();
+    const float sum = val[res];
     __syncthreads();
     return sum;
 }
 // complex64 reduce: elem(ci) -> float2 of complex element ci; leaves are float ranges of the interleaved array, the 8
 // float accumulators are 4 complex ones: a lane owns one (leaf, complex accumulator) pair.  part: 4 float2 per leaf.
 template <class F>
-__device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *part, float2 *val, F elem)
+__device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *part, float2 *val, F elem, float2 carry, bool have)
 {
     const int tid = threadIdx.x, T = blockDim.x;
     for (int slot = tid; slot < p.n_leaves * 4; slot += T) {
@@ -908,24 +922,67 @@ __device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *part, float2
         }
         __syncthreads();
     }
-    const int nn = p.level_start[p.n_levels];
-    const float2 sum = nn ? val[p.n_leaves + nn - 1] : val[0];
+    const int res = p.n_leaves + p.level_start[p.n_levels];
+    if (tid == 0) {
+        float2 acc = val[p.roots[0]];
+        if (have) acc = make_float2(__fadd_rn(carry.x, acc.x), __fadd_rn(carry.y, acc.y));
+        for (int k = 1; k < p.n_roots; k++) {
+            const float2 v = val[p.roots[k]];
+            acc = make_float2(__fadd_rn(acc.x, v.x), __fadd_rn(acc.y, v.y));
+        }
+        val[res] = acc;
+    }
+    __syncthreads();
+    const float2 sum = val[res];
     __syncthreads();
     return sum;
+}
+// whole-frame reductions: loop over the groups, elem(i) indexed from the start of the frame
+template <class F>
+__device__ __forceinline__ float frame_rsum(const RedPlan &rp, float *part, float *val, F elem)
+{
+    float acc = 0.0f;
+    bool have = false;
+    for (int g = 0; g < rp.n_full; g++) {
+        const int base = g * rp.glen;
+        acc = wg_rsum(rp.full, part, val, [&](int i) { return elem(base + i); }, acc, have);
+        have = true;
+    }
+    if (rp.tail.n_leaves) {
+        const int base = rp.n_full * rp.glen;
+        acc = wg_rsum(rp.tail, part, val, [&](int i) { return elem(base + i); }, acc, have);
+    }
+    return acc;
+}
+template <class F>
+__device__ __forceinline__ float2 frame_csum(const RedPlan &rp, float2 *part, float2 *val, F elem)
+{
+    float2 acc = make_float2(0.0f, 0.0f);
+    bool have = false;
+    for (int g = 0; g < rp.n_full; g++) {
+        const int base = g * rp.glen;
+        acc = wg_csum(rp.full, part, val, [&](int i) { return elem(base + i); }, acc, have);
+        have = true;
+    }
+    if (rp.tail.n_leaves) {
+        const int base = rp.n_full * rp.glen;
+        acc = wg_csum(rp.tail, part, val, [&](int i) { return elem(base + i); }, acc, have);
+    }
+    return acc;
 }
 
 // np.mean float32 of |x| (KIND 1, AM: signal_processing.py:185) or |x|^2 (KIND 0, power: :327), one workgroup per frame;
 // the (leaf, accumulator) lanes read global memory directly (every element is used exactly once; staging the frame in
 // LDS first measured 2-3x slower: fewer resident workgroups, one more barrier).  LDS: [part: 8 floats per leaf][val]
 template <int KIND>
-__global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq, int n, long n_frames, PlanDev rp,
-                                                  float *__restrict__ out, float *__restrict__ env)
+__global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq, int n, long n_frames, RedPlan rp,
+                                                  int part_slots, float *__restrict__ out, float *__restrict__ env)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    float *part = reinterpret_cast<float *>(smem), *val = part + 8 * rp.n_leaves;
+    float *part = reinterpret_cast<float *>(smem), *val = part + part_slots;
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const float2 *x = iq + (size_t)f * n;
-        const float sum = wg_rsum(rp, part, val, [&](int i) {
+        const float sum = frame_rsum(rp, part, val, [&](int i) {
             const float2 v = x[i];
             const float m = cabsf_np(v.x, v.y);
             if (KIND == 1 && env) env[(size_t)f * n + i] = m;  // the AM envelope (:182), reused by the band-pass kernel
@@ -941,7 +998,7 @@ __global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq,
 // STAGED: the frame is copied to LDS once and every pass reads it from there (frames up to 8192 samples).
 // LDS: [frame: n float2 if STAGED][part: part_slots float2][val: val_slots float2]
 template <bool STAGED>
-__global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, int n, long n_frames, PlanDev rp, PlanDev cp,
+__global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, int n, long n_frames, RedPlan rp, RedPlan cp,
                                                 int part_slots, float2 *__restrict__ out, float *__restrict__ raw)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -958,25 +1015,25 @@ __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, i
         }
         auto X = [&](int i) { return STAGED ? xs[i] : xg[i]; };
         // :48 centered = samples - mean(samples)
-        float2 s = wg_csum(cp, cpart, cval, X);
+        float2 s = frame_csum(cp, cpart, cval, X);
         const float mr = __fdiv_rn(s.x, fn), mi = __fdiv_rn(s.y, fn);
         // :49 input_power = var(centered): mean again, |.|^2 with the FMA form of numpy's complex multiply, mean
-        s = wg_csum(cp, cpart, cval, [&](int i) { float2 v = X(i); return make_float2(__fsub_rn(v.x, mr), __fsub_rn(v.y, mi)); });
+        s = frame_csum(cp, cpart, cval, [&](int i) { float2 v = X(i); return make_float2(__fsub_rn(v.x, mr), __fsub_rn(v.y, mi)); });
         const float m2r = __fdiv_rn(s.x, fn), m2i = __fdiv_rn(s.y, fn);
-        const float input_power = __fdiv_rn(wg_rsum(rp, rpart, rval, [&](int i) {
+        const float input_power = __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) {
             float2 v = X(i);
             const float dr = __fsub_rn(__fsub_rn(v.x, mr), m2r), di = __fsub_rn(__fsub_rn(v.y, mi), m2i);
             return __fmaf_rn(dr, dr, __fmul_rn(di, di));
         }), fn);
         // :52 q_amplitude
-        const float qa = sqrtf(__fmul_rn(2.0f, __fdiv_rn(wg_rsum(rp, rpart, rval, [&](int i) { float q = X(i).y; return __fmul_rn(q, q); }), fn)));
+        const float qa = sqrtf(__fmul_rn(2.0f, __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) { float q = X(i).y; return __fmul_rn(q, q); }), fn)));
         const float scl = __fdiv_rn(1.0f, qa);  // :55 complex64 / float32 scalar multiplies by the reciprocal
         // :60-61 alpha, sin(phi)
-        const float alpha = sqrtf(__fmul_rn(2.0f, __fdiv_rn(wg_rsum(rp, rpart, rval, [&](int i) {
+        const float alpha = sqrtf(__fmul_rn(2.0f, __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) {
             const float is = __fmul_rn(X(i).x, scl);
             return __fmul_rn(is, is);
         }), fn)));
-        const float sinphi = __fmul_rn(__fdiv_rn(2.0f, alpha), __fdiv_rn(wg_rsum(rp, rpart, rval, [&](int i) {
+        const float sinphi = __fmul_rn(__fdiv_rn(2.0f, alpha), __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) {
             float2 v = X(i);
             return __fmul_rn(__fmul_rn(v.x, scl), __fmul_rn(v.y, scl));
         }), fn));
@@ -990,9 +1047,9 @@ __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, i
             return make_float2(__fmul_rn(__fadd_rn(i_new, jr), sc), __fmul_rn(__fadd_rn(0.0f, ji), sc));
         };
         // :80 var(corrected), rescale to the input power
-        s = wg_csum(cp, cpart, cval, corrected);
+        s = frame_csum(cp, cpart, cval, corrected);
         const float m3r = __fdiv_rn(s.x, fn), m3i = __fdiv_rn(s.y, fn);
-        const float v2 = __fdiv_rn(wg_rsum(rp, rpart, rval, [&](int i) {
+        const float v2 = __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) {
             float2 c = corrected(i);
             const float dr = __fsub_rn(c.x, m3r), di = __fsub_rn(c.y, m3i);
             return __fmaf_rn(dr, dr, __fmul_rn(di, di));
@@ -1345,34 +1402,29 @@ void plan_rec(int off, int n, std::vector<int> &lo, std::vector<int> &ll, std::v
     slot = -(int)nl.size();  // internal node id k encoded as -(k+1)
 }
 
-// cplx: the tree numpy walks for a complex64 reduce — same recursion over the 2n interleaved FLOATS, chunks of 8192
-// complex elements; leaf offsets/lengths are then in floats (always even).  Stored under key -n.
-int get_plan(pss_ctx *ctx, int n_elems, PssPairwisePlan **out, bool cplx = false)
+// Plan of ONE GROUP of `len` elements (at most RED_K ufunc chunks): a forest, one pairwise tree per 8192-element chunk,
+// plus the list of roots in chunk order (numpy adds the chunk sums sequentially).
+// cplx: the tree numpy walks for a complex64 reduce — same recursion over the 2 len interleaved FLOATS, chunks of 8192
+// complex elements; leaf offsets/lengths are then in floats (always even).  Stored under key -len.
+constexpr int RED_K = 8;
+int get_plan(pss_ctx *ctx, int len, PssPairwisePlan **out, bool cplx = false)
 {
-    const int key = cplx ? -n_elems : n_elems;
-    const int n = cplx ? 2 * n_elems : n_elems;
+    const int key = cplx ? -len : len;
+    const int n = cplx ? 2 * len : len;
     auto it = ctx->plans.find(key);
     if (it == ctx->plans.end()) {
-        std::vector<int> lo, ll, nl, nr, lev;
-        int slot, level;
-        // numpy hands its inner loop at most 8192 elements (the ufunc buffer size) and adds the chunk sums sequentially:
-        // sum = ((S(c0) + S(c1)) + S(c2)) + ...; inside a chunk the pairwise tree of plan_rec
-        {
-            const int B = cplx ? 16384 : 8192;
-            plan_rec(0, n < B ? n : B, lo, ll, nl, nr, lev, slot, level);
-            for (int st = B; st < n; st += B) {
-                int s2, l2;
-                plan_rec(st, (n - st) < B ? (n - st) : B, lo, ll, nl, nr, lev, s2, l2);
-                nl.push_back(slot);
-                nr.push_back(s2);
-                level = 1 + (level > l2 ? level : l2);
-                lev.push_back(level);
-                slot = -(int)nl.size();
-            }
+        std::vector<int> lo, ll, nl, nr, lev, roots;
+        int level = 0;
+        const int B = cplx ? 16384 : 8192;
+        for (int st = 0; st < n; st += B) {
+            int s2, l2;
+            plan_rec(st, (n - st) < B ? (n - st) : B, lo, ll, nl, nr, lev, s2, l2);
+            roots.push_back(s2);
+            level = level > l2 ? level : l2;
         }
         const int nleaf = (int)lo.size(), nnode = (int)nl.size();
         // order internal nodes by level; remap ids
-        std::vector<int> order(nnode), newid(nnode), lstart(level + 2, 0);
+        std::vector<int> order(nnode ? nnode : 1), newid(nnode ? nnode : 1), lstart(level + 2, 0);
         int pos = 0;
         for (int lv = 1; lv <= level; lv++) {
             lstart[lv - 1] = pos;
@@ -1380,46 +1432,79 @@ int get_plan(pss_ctx *ctx, int n_elems, PssPairwisePlan **out, bool cplx = false
                 if (lev[k] == lv) { order[pos] = k; newid[k] = pos; pos++; }
         }
         lstart[level] = pos;
-        auto slot_of = [&](int s) { return s >= 0 ? s : nleaf + newid[-s - 1]; };
+        auto slot_of = [&](int sl) { return sl >= 0 ? sl : nleaf + newid[-sl - 1]; };
         std::vector<int> L(nnode ? nnode : 1), R(nnode ? nnode : 1);
         for (int k = 0; k < nnode; k++) { L[k] = slot_of(nl[order[k]]); R[k] = slot_of(nr[order[k]]); }
+        for (auto &rt : roots) rt = slot_of(rt);
         PssPairwisePlan p;
-        p.n_leaves = nleaf; p.n_nodes = nnode; p.n_levels = level;
+        p.n_leaves = nleaf; p.n_nodes = nnode; p.n_levels = level; p.n_roots = (int)roots.size();
         PSS_HIP(ctx, hipMalloc(&p.d_leaf_off, sizeof(int) * nleaf));
         PSS_HIP(ctx, hipMalloc(&p.d_leaf_len, sizeof(int) * nleaf));
         PSS_HIP(ctx, hipMalloc(&p.d_node_l, sizeof(int) * L.size()));
         PSS_HIP(ctx, hipMalloc(&p.d_node_r, sizeof(int) * R.size()));
         PSS_HIP(ctx, hipMalloc(&p.d_level_start, sizeof(int) * (level + 1)));
+        PSS_HIP(ctx, hipMalloc(&p.d_roots, sizeof(int) * roots.size()));
         PSS_HIP(ctx, hipMemcpy(p.d_leaf_off, lo.data(), sizeof(int) * nleaf, hipMemcpyHostToDevice));
         PSS_HIP(ctx, hipMemcpy(p.d_leaf_len, ll.data(), sizeof(int) * nleaf, hipMemcpyHostToDevice));
         PSS_HIP(ctx, hipMemcpy(p.d_node_l, L.data(), sizeof(int) * L.size(), hipMemcpyHostToDevice));
         PSS_HIP(ctx, hipMemcpy(p.d_node_r, R.data(), sizeof(int) * R.size(), hipMemcpyHostToDevice));
         PSS_HIP(ctx, hipMemcpy(p.d_level_start, lstart.data(), sizeof(int) * (level + 1), hipMemcpyHostToDevice));
+        PSS_HIP(ctx, hipMemcpy(p.d_roots, roots.data(), sizeof(int) * roots.size(), hipMemcpyHostToDevice));
         ctx->plans[key] = p;
     }
     *out = &ctx->plans[key];
     return PSS_OK;
 }
 
+PlanDev plan_dev(const PssPairwisePlan *p)
+{
+    if (!p) return PlanDev{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    return PlanDev{p->d_leaf_off, p->d_leaf_len, p->d_node_l, p->d_node_r, p->d_level_start, p->d_roots, p->n_leaves, p->n_levels,
+                   p->n_roots};
+}
+
+// Group decomposition of a frame of n elements; slots = the largest (leaves, leaves + nodes + 1) over its group plans.
+int get_red_plan(pss_ctx *ctx, int n, bool cplx, RedPlan *rp, int *max_leaves, int *max_vals)
+{
+    const int glen = RED_K * 8192;
+    PssPairwisePlan *full = nullptr, *tail = nullptr;
+    const int n_full = n > glen ? n / glen : 0, rem = n - n_full * glen;
+    int r;
+    if (n_full && (r = get_plan(ctx, glen, &full, cplx))) return r;
+    if (rem && (r = get_plan(ctx, rem, &tail, cplx))) return r;
+    rp->full = plan_dev(full);
+    rp->tail = plan_dev(tail);
+    rp->n_full = n_full;
+    rp->glen = glen;
+    *max_leaves = 0; *max_vals = 0;
+    for (const PssPairwisePlan *p : {full, tail})
+        if (p) {
+            *max_leaves = p->n_leaves > *max_leaves ? p->n_leaves : *max_leaves;
+            const int v = p->n_leaves + p->n_nodes + 1;
+            *max_vals = v > *max_vals ? v : *max_vals;
+        }
+    return PSS_OK;
+}
+
 template <int KIND>
 int launch_pairwise(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out, float *d_env = nullptr)
 {
-    PssPairwisePlan *p;
-    int r = get_plan(ctx, n, &p);
+    RedPlan rp;
+    int leaves, vals;
+    int r = get_red_plan(ctx, n, false, &rp, &leaves, &vals);
     if (r) return r;
-    const size_t lds = sizeof(float) * (size_t)(8 * p->n_leaves + p->n_leaves + p->n_nodes + 1);
-    if (lds > 150 * 1024) return pss_fail(ctx, PSS_E_ARG, "frame too long for the pairwise-mean kernel");
+    const int part_slots = 8 * leaves;
+    const size_t lds = sizeof(float) * (size_t)(part_slots + vals);
     auto kern = k_pairwise<KIND>;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
-    PlanDev a{p->d_leaf_off, p->d_leaf_len, p->d_node_l, p->d_node_r, p->d_level_start, p->n_leaves, p->n_levels};
-    const int lanes = 8 * p->n_leaves;  // one lane per (leaf, accumulator) pair
+    const int lanes = 8 * leaves;  // one lane per (leaf, accumulator) pair
     const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);
     long g = n_frames < 65536 ? n_frames : 65536;
     pss_kernel_begin(ctx, "k_pairwise");
-    hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, a,
-                       d_out, d_env);
+    hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, rp,
+                       part_slots, d_out, d_env);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_pairwise launch");
 }
@@ -1501,25 +1586,23 @@ extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames,
     if (!ctx) return PSS_E_ARG;
     if (!d_iq || n_frames < 0 || n <= 0 || (!d_out_iq && !d_raw)) return pss_fail(ctx, PSS_E_ARG, "pss_iq_correction: bad argument");
     if (n_frames == 0) return PSS_OK;
-    PssPairwisePlan *rp, *cp;
-    int r = get_plan(ctx, n, &rp);
+    RedPlan rp, cp;
+    int rl, rv, cl, cv;
+    int r = get_red_plan(ctx, n, false, &rp, &rl, &rv);
     if (r) return r;
-    r = get_plan(ctx, n, &cp, true);
+    r = get_red_plan(ctx, n, true, &cp, &cl, &cv);
     if (r) return r;
     // LDS: partial sums (8 floats | 4 float2 per leaf) + tree values, optionally the frame itself
-    size_t part_slots = (size_t)(rp->n_leaves * 4 > cp->n_leaves * 4 ? rp->n_leaves * 4 : cp->n_leaves * 4);  // in float2
-    size_t val_slots = (size_t)(rp->n_leaves + rp->n_nodes > cp->n_leaves + cp->n_nodes ? rp->n_leaves + rp->n_nodes
-                                                                                          : cp->n_leaves + cp->n_nodes) + 1;
+    size_t part_slots = (size_t)(rl * 4 > cl * 4 ? rl * 4 : cl * 4);  // in float2
+    size_t val_slots = (size_t)(rv > cv ? rv : cv);
     // staging pays while >= 2 workgroups fit a CU (measured: 0.59 vs 0.91 ms at 65536 x 1024, but 2.6 vs 1.8 ms at 8192 x 16384)
     const bool staged = n <= 8192;
     size_t lds = (part_slots + val_slots + (staged ? (size_t)n : 0)) * sizeof(float2);
-    if (lds > 150 * 1024) return pss_fail(ctx, PSS_E_ARG, "frame too long for the iq_correction kernel");
     auto kern = staged ? k_iqcorr<true> : k_iqcorr<false>;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PlanDev a{rp->d_leaf_off, rp->d_leaf_len, rp->d_node_l, rp->d_node_r, rp->d_level_start, rp->n_leaves, rp->n_levels};
-    PlanDev b{cp->d_leaf_off, cp->d_leaf_len, cp->d_node_l, cp->d_node_r, cp->d_level_start, cp->n_leaves, cp->n_levels};
-    const int lanes = rp->n_leaves * 8 > cp->n_leaves * 4 ? rp->n_leaves * 8 : cp->n_leaves * 4;
+    const RedPlan &a = rp, &b = cp;
+    const int lanes = rl * 8 > cl * 4 ? rl * 8 : cl * 4;
     const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);  // one lane per (leaf, accumulator) pair
     long g = n_frames < 65536 ? n_frames : 65536;
     pss_time_begin(ctx);

@@ -421,6 +421,28 @@ def test_recording_to_wav_roundtrip(tmp_path, golden):
     assert np.array_equal(pcm, wf["pcm_a"])
 
 
+@pytest.mark.parametrize("n", [65536, 70001, 131072, 1 << 20])
+def test_long_frames_grouped_reductions(n):
+    """Frames longer than one reduction group (8 ufunc chunks = 65536 samples), up to the reference's largest read
+    buffer (pyspecsdr.py:2236, SAMPLES = 12): power, IQ correction and the AM mean against the oracle, bit for bit."""
+    rng = np.random.default_rng(n)
+    iq = ((rng.standard_normal((2, n)) * 0.3 + 0.05) + 1j * (rng.standard_normal((2, n)) * 0.25 - 0.02)).astype(np.complex64)
+    e = G.engine()
+    d_p = G.empty((2,), torch.float32)
+    e.power_db(G.dev(iq), 2, n, d_p)
+    d_out = G.empty((2, n, 2), torch.float32)
+    e.iq_correction(G.dev(iq), 2, n, d_out, None)
+    e.sync()
+    p = G.host(d_p)
+    got = G.host(d_out).reshape(2, -1).view(np.complex64)
+    for f in range(2):
+        assert abs(float(p[f]) - float(O.power_db(iq[f]))) <= 4e-6 * max(1.0, abs(float(p[f])))
+        assert np.array_equal(got[f].view(np.uint32), O.iq_correction(iq[f]).view(np.uint32)), (n, f)
+    sos = np.empty((5, 6)); e.lib.pss_am_bandpass_sos(sos.ctypes.data)
+    pcm, audio = G.demod(L.MODE_AM, iq[:1], 2.4e6)
+    assert np.array_equal(audio[0], O.demod_am(iq[0], sos))
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()
