@@ -240,6 +240,84 @@ __global__ __launch_bounds__(PT) void k_post(const float *__restrict__ db, float
     }
 }
 
+// The same for rows that do not fit an LDS sort (N > 32768, up to the reference's 2^20-sample buffers): the two middle
+// order statistics come from a most-significant-digit-first radix SELECT over the order-preserving integer image of the
+// float32 smoothed values (4 passes of 8 bits per rank, 256-bin LDS histogram).  dB rows cluster in a few top-digit bins,
+// so lanes that hit the same bin are combined with a ballot before the LDS atomic.
+__device__ __forceinline__ unsigned f2ord(float v)
+{
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+
+__global__ __launch_bounds__(1024) void k_post_select(const float *__restrict__ db, float *__restrict__ post, int N, long n_frames)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_k;
+    const int tid = threadIdx.x, m = N - 4, nthr = blockDim.x;
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const float *row = db + (size_t)f * N;
+        auto smooth = [&](int i) {
+            double acc = 0.0;
+            for (int k = 0; k < 5; k++) acc += (double)row[i + k] * 0.2;
+            return acc;
+        };
+        auto select = [&](unsigned k) {  // k-th smallest (0-based) of float32(smooth(i)), as its ordered-integer image
+            unsigned prefix = 0, mask = 0;
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                for (int b = tid; b < 256; b += nthr) hist[b] = 0;
+                __syncthreads();
+                for (int i0 = 0; i0 < m; i0 += nthr) {
+                    const int i = i0 + tid;
+                    bool live = i < m;
+                    unsigned bin = 0;
+                    if (live) {
+                        const unsigned o = f2ord((float)smooth(i));
+                        live = (o & mask) == prefix;
+                        bin = (o >> shift) & 255u;
+                    }
+                    // combine equal bins of this wavefront: one atomic per distinct bin
+                    unsigned long long todo = __ballot(live);
+                    while (todo) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const unsigned b0 = __shfl(bin, leader);
+                        const unsigned long long same = __ballot(live && bin == b0) & todo;
+                        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+                        todo &= ~same;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned cum = 0, b = 0;
+                    for (; b < 256; b++) {
+                        if (cum + hist[b] > k) break;
+                        cum += hist[b];
+                    }
+                    sel_prefix = prefix | (b << shift);
+                    sel_k = k - cum;
+                }
+                __syncthreads();
+                prefix = sel_prefix;
+                k = sel_k;
+                mask |= 255u << shift;
+                __syncthreads();
+            }
+            return prefix;
+        };
+        double med;
+        if (m & 1) med = (double)ord2f(select((unsigned)(m >> 1)));
+        else med = 0.5 * ((double)ord2f(select((unsigned)(m >> 1) - 1)) + (double)ord2f(select((unsigned)(m >> 1))));
+        const double thr = med - 10.0;
+        float *o = post + (size_t)f * m;
+        for (int i = tid; i < m; i += nthr) {
+            const double acc = smooth(i);
+            o[i] = (float)(acc < thr ? thr : acc);
+        }
+        __syncthreads();
+    }
+}
+
 // np.interp(np.linspace(0, len-1, W), np.arange(len), row)[i]
 template <class T>
 __device__ __forceinline__ double interp_row(const T *row, int len, int W, int i)
@@ -506,8 +584,18 @@ extern "C" int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames,
 {
     if (!ctx) return PSS_E_ARG;
     if (!d_db || !d_post || n_frames < 0) return pss_fail(ctx, PSS_E_ARG, "null pointer");
-    if (n_fft < 8 || n_fft > 32768) return pss_fail(ctx, PSS_E_ARG, "post-process supports 8 <= n_fft <= 32768");
+    if (n_fft < 8 || n_fft > (1 << 20)) return pss_fail(ctx, PSS_E_ARG, "post-process supports 8 <= n_fft <= 1048576");
     if (n_frames == 0) return PSS_OK;
+    if (n_fft > ctx->post_sort_max) {  // rows too long for the LDS sort: radix select of the two middle order statistics
+        pss_time_begin(ctx);
+        pss_kernel_begin(ctx, "k_post");
+        const int thr = n_fft <= 2048 ? 256 : 1024;
+        hipLaunchKernelGGL(k_post_select, dim3((unsigned)(n_frames < 8192 ? n_frames : 8192)), dim3(thr), 0, PSS_STREAM(ctx), d_db,
+                           d_post, n_fft, n_frames);
+        pss_kernel_end(ctx);
+        pss_time_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "k_post_select launch");
+    }
     int P = 1;
     while (P < n_fft - 4) P <<= 1;
     size_t lds = (size_t)P * sizeof(float);

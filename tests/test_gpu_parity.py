@@ -86,6 +86,26 @@ def test_post_process(golden, n):
     assert np.all(np.abs(post - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0))
 
 
+@pytest.mark.parametrize("n", [8192, 16384, 32768, 65536, 1 << 20])
+def test_post_process_long_rows(n):
+    """pyspecsdr.py:2278-2283 on full read buffers (N = 32768 is the reference's default; up to 2^20): LDS sort up to
+    8192, radix select above — against the NumPy formula on the float32 dB rows."""
+    rng = np.random.default_rng(n)
+    db = (rng.standard_normal((2, n)) * 6.0 - 35.0).astype(np.float32)
+    db[0, 1000:1100] += 40.0                                  # a signal hump well above the noise floor
+    db[1, :] = np.round(db[1, :])                             # heavy ties
+    e = G.engine()
+    d_post = G.empty((2, n - 4), torch.float32)
+    e.spectrum_post(G.dev(db), 2, n, d_post)
+    e.sync()
+    post = G.host(d_post)
+    for f in range(2):
+        sm = np.convolve(db[f].astype(np.float64), np.ones(5) / 5, mode="valid")
+        thr = np.median(sm) - 10
+        ref = np.where(sm < thr, thr, sm)
+        assert np.all(np.abs(post[f] - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0)), (n, f, np.abs(post[f] - ref).max())
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
 def test_nfm_vs_golden_bit_exact(golden, tag):
     g = golden["nfm"]
