@@ -54,6 +54,15 @@ def traffic_of(kernel, n_frames):
         return None
 
 
+def valu_busy_of(kernel):
+    """VALU busy fraction of `kernel` from the committed SQ-counter profile (profiles/r01f_sq_counters_bench.txt, digested
+    into profiles/hbm_traffic_r01.json); None if absent.  Says how close an issue-bound kernel is to ITS roof."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_r01.json")))[kernel].get("valu_busy_frac")
+    except Exception:
+        return None
+
+
 def synth_fm_iq(n_frames, n, fs, device, seed):
     """FM-modulated carrier + noise, SURVEY §8(d): three audio tones, 5 kHz deviation, A=0.5, sigma=0.02."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -179,7 +188,7 @@ def main():
             ms = ktimes[dom]
             achieved = ALGO_BYTES.get(dom, ALGO_BYTES["path"]) * nf / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_of(dom, nf),
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_of(dom, nf), "valu_busy_frac": valu_busy_of(dom),
                     "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
                     "path_achieved": ALGO_BYTES["path"] * nf / (elapsed / args.steps) / 1e9}
             if spec_alone:
