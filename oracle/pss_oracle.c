@@ -767,6 +767,59 @@ void pss_o_persistence_cells(const double *rows, int n_rows, int len, int disp_h
     }
 }
 
+/* draw_spectrogram — pyspecsdr.py:398-498: noise floor = 20th percentile (np.percentile, method 'linear': virtual index
+ * (n-1)*0.2, numpy _lerp), display range :424-427, clip + x**0.7 :442-445, np.interp to the display width :448-452, bar
+ * height int(value*H) :457-458, glyph / colour by strength and position in the bar :471-490.  glyph: 0 '.', 1 '-', 2 '=',
+ * 3 '#', 4 ' '; colour = curses pair number (1 = cleared cell); -1 where nothing was drawn (non-finite column). */
+void pss_o_spectrogram_cells(const double *row, int len, int disp_h, int disp_w, int8_t *glyph, int8_t *colour,
+                             double *disp_min, double *disp_max)
+{
+    double *fin = (double *)malloc(sizeof(double) * len), *pw = (double *)malloc(sizeof(double) * len);
+    int nf = 0;
+    for (int i = 0; i < len; i++)
+        if (isfinite(row[i])) fin[nf++] = row[i];
+    memset(glyph, -1, (size_t)disp_h * disp_w);
+    memset(colour, -1, (size_t)disp_h * disp_w);
+    if (nf == 0) { free(fin); free(pw); return; }
+    qsort(fin, nf, sizeof(double), cmp_double);
+    const double max_db = fin[nf - 1];
+    const double vi = (double)(nf - 1) * 0.2;
+    long lo = (long)floor(vi), hi = lo + 1;
+    if (vi >= (double)(nf - 1)) { lo = nf - 1; hi = nf - 1; }
+    if (hi > nf - 1) hi = nf - 1;
+    const double g = vi - floor(vi), a = fin[lo], b = fin[hi], dba = b - a;
+    double noise = a + dba * g;
+    if (g >= 0.5) noise = b - dba * (1 - g);
+    const double range = max_db - noise;
+    const double dmin = noise - (range * 0.1), dmax = max_db + (range * 0.05);
+    if (disp_min) *disp_min = dmin;
+    if (disp_max) *disp_max = dmax;
+    for (int i = 0; i < len; i++) {
+        double v = (row[i] - dmin) / (dmax - dmin);
+        v = v < 0 ? 0 : (v > 1 ? 1 : v);                       /* np.clip(., 0, 1) (NaN stays NaN) */
+        pw[i] = pow(v, 0.7);
+    }
+    for (int x = 0; x < disp_w; x++) {
+        const double value = interp_row(pw, len, disp_w, x);
+        if (!isfinite(value)) continue;
+        int height = (int)(value * disp_h);
+        if (height > disp_h) height = disp_h;
+        for (int y = 0; y < disp_h; y++) { glyph[y * disp_w + x] = 4; colour[y * disp_w + x] = 1; }
+        for (int y = disp_h - height; y < disp_h; y++) {
+            const double rel = height > 0 ? (double)(y - (disp_h - height)) / (double)height : 0.0;
+            int gch, col;
+            if (value > 0.8) { gch = rel > 0.5 ? 3 : 2; col = 14; }
+            else if (value > 0.4) { gch = rel > 0.5 ? 2 : 1; col = 13; }
+            else if (value > 0.2) { gch = rel > 0.5 ? 1 : 0; col = 12; }
+            else if (rel > 0.7) { gch = 0; col = 11; }
+            else { gch = 4; col = 10; }
+            glyph[y * disp_w + x] = (int8_t)gch;
+            colour[y * disp_w + x] = (int8_t)col;
+        }
+    }
+    free(fin); free(pw);
+}
+
 /* bench.py cpu_baseline leg: the BASELINE.json headline path per frame, exactly what the reference's
  * loop does per read buffer (compute_fft + demodulate_signal(NFM) + int16), filters designed once. */
 void pss_o_batch_spectrum_nfm(const float *iq, long n_frames, int n, double fs, int q, const double *taps,

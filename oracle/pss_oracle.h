@@ -77,6 +77,12 @@ void pss_o_waterfall_cells(const double *rows, int n_rows, int len, int disp_h, 
 void pss_o_persistence_cells(const double *rows, int n_rows, int len, int disp_h, int disp_w,
                              int8_t *colour);
 
+/* spectrum display quantiser — draw_spectrogram, pyspecsdr.py:398-498.  row[len] = one post-processed dB row.
+ * glyph/colour [disp_h][disp_w]: glyph 0 '.', 1 '-', 2 '=', 3 '#', 4 ' '; colour = curses pair (1 = cleared); -1 = not drawn.
+ * disp_min/disp_max (nullable): the dB range of the scale labels (:424-427). */
+void pss_o_spectrogram_cells(const double *row, int len, int disp_h, int disp_w, int8_t *glyph, int8_t *colour,
+                             double *disp_min, double *disp_max);
+
 /* ---- batched drivers used only by bench.py's cpu_baseline leg (OpenMP over frames if enabled) ---- */
 /* spectrum (float32 dB out) + NFM -> int16 stereo PCM, the BASELINE.json headline path. */
 void pss_o_batch_spectrum_nfm(const float *iq, long n_frames, int n, double fs, int q, const double *taps,

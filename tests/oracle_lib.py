@@ -46,6 +46,7 @@ def lib():
         L.pss_o_iq_correction.argtypes = [_f32p, C.c_int, _f32p]
         L.pss_o_demod_wfm.argtypes = [_f32p, C.c_int, C.c_int, _f64p, _f64p, _f64p, C.c_double, _f64p, _f64p, _f64p, _f64p]
         L.pss_o_sosfilt.argtypes = [_f64p, C.c_int, _f64p, C.c_long, _f64p]
+        L.pss_o_spectrogram_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, _i8p, _i8p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.pss_o_power_db.restype = C.c_float
         L.pss_o_power_db.argtypes = [_f32p, C.c_int]
         L.pss_o_scan_slice.restype = C.c_int
@@ -118,6 +119,14 @@ def sosfilt(sos, x):
     y = np.empty_like(x)
     lib().pss_o_sosfilt(sos, sos.shape[0], x, len(x), y)
     return y
+
+
+def spectrogram_cells(row, disp_h, disp_w):
+    row = np.ascontiguousarray(row, np.float64)
+    gl, co = np.empty((disp_h, disp_w), np.int8), np.empty((disp_h, disp_w), np.int8)
+    dmin, dmax = C.c_double(), C.c_double()
+    lib().pss_o_spectrogram_cells(row, len(row), disp_h, disp_w, gl, co, C.byref(dmin), C.byref(dmax))
+    return gl, co, dmin.value, dmax.value
 
 
 def power_db(iq):

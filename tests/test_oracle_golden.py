@@ -209,3 +209,14 @@ def test_bandpass_filter_bit_exact(golden):
     for tag in g["tags"]:
         y = O.sosfilt(g[f"sos_{tag}"], g[f"x_{tag}"])
         assert np.array_equal(y.view(np.uint64), g[f"y_{tag}"].view(np.uint64)), tag
+
+
+def test_spectrogram_cells(golden):
+    """draw_spectrogram (pyspecsdr.py:398-498): the final glyph / colour grid, incl. a full 32768-sample read buffer."""
+    g = golden["caller"]
+    for tag in g["sg_tags"]:
+        hh, ww = [int(v) for v in g[f"sg_hw_{tag}"]]
+        gl, co, dmin, dmax = O.spectrogram_cells(g[f"sg_row_{tag}"], hh - 4, ww - 7)
+        assert np.array_equal(gl, g[f"sg_glyph_{tag}"]), tag
+        assert np.array_equal(co, g[f"sg_colour_{tag}"]), tag
+        assert dmin < dmax

@@ -446,6 +446,31 @@ def gen_caller():
                 g[y - 2, x - 8] = attr >> 8
         ps.append(g)
     d["ps_colour"] = np.stack(ps)
+    # spectrum display (draw_spectrogram, pyspecsdr.py:398-498): final cell grid, glyph code (0 '.',1 '-',2 '=',3 '#',
+    # 4 ' '), colour pair; -1 = cell never written.  Short rows and one full default read buffer (32768 samples).
+    glyphs5 = {".": 0, "-": 1, "=": 2, "#": 3, " ": 4}
+    big = fm_iq(1, 32768, 2.4e6, 72)[0]
+    fd = sp.compute_fft(big)
+    fd = np.convolve(fd, np.ones(5) / 5, mode="valid")
+    thr = np.median(fd) - 10
+    fd[fd < thr] = thr
+    cases = [("r0", rows[0], 40, 120), ("r5", rows[5], 40, 120), ("r20", rows[20], 30, 87), ("big", fd, 50, 200)]
+    for tag, r, hh, ww in cases:
+        scr = Scr(hh, ww)
+        P.draw_spectrogram(scr, r.copy(), None, 100e6, 2.4e6, 0, 0, None)
+        dh, dw = hh - 4, ww - 7
+        g = -np.ones((dh, dw), np.int8); c = -np.ones((dh, dw), np.int8)
+        for call in scr.calls:
+            if len(call) != 4:
+                continue
+            y, x, st, attr = call
+            if len(st) == 1 and st in glyphs5 and x >= 7 and 2 <= y < 2 + dh and x - 7 < dw:
+                g[y - 2, x - 7] = glyphs5[st]; c[y - 2, x - 7] = (attr >> 8) & 0xFF
+        d[f"sg_row_{tag}"] = r
+        d[f"sg_hw_{tag}"] = np.array([hh, ww])
+        d[f"sg_glyph_{tag}"] = g
+        d[f"sg_colour_{tag}"] = c
+    d["sg_tags"] = np.array([c_[0] for c_ in cases])
     save("caller", **d)
 
 
