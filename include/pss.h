@@ -131,6 +131,16 @@ int pss_waterfall_cells(pss_ctx *ctx, const float *d_rows, int n_rows, int len, 
                         int8_t *d_glyph, int8_t *d_colour);
 int pss_persistence_cells(pss_ctx *ctx, const float *d_rows, int n_rows, int len, int disp_h, int disp_w,
                           int8_t *d_colour);
+/* Spectrum display quantiser — draw_spectrogram (pyspecsdr.py:398-498), one independent post-processed dB row per display:
+ * 20th-percentile noise floor, display range, clip + x**0.7, resample to disp_w columns, bar height and the glyph / colour
+ * of every cell.  d_rows [n_rows][len]; d_glyph / d_colour int8 [n_rows][disp_h][disp_w]: glyph 0 '.', 1 '-', 2 '=',
+ * 3 '#', 4 ' '; colour = curses pair number (1 = cleared cell); -1 where the column was not drawn (non-finite value).
+ * d_range (nullable) double [n_rows][2] = (display_min, display_max), the dB range of the scale labels (:424-436). */
+int pss_spectrogram_cells(pss_ctx *ctx, const float *d_rows, long n_rows, int len, int disp_h, int disp_w, int8_t *d_glyph,
+                          int8_t *d_colour, double *d_range);
+int pss_spectrogram_cells_f64(pss_ctx *ctx, const double *d_rows, long n_rows, int len, int disp_h, int disp_w,
+                              int8_t *d_glyph, int8_t *d_colour, double *d_range);
+
 /* Same quantisers over float64 rows (the reference's rows are float64; used to check cell-exact parity). */
 int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int len, int disp_h, int disp_w,
                             int8_t *d_glyph, int8_t *d_colour);

@@ -334,6 +334,150 @@ __device__ __forceinline__ double interp_row(const T *row, int len, int W, int i
     return slope * (x - (double)j) + (double)row[j];
 }
 
+// draw_spectrogram (pyspecsdr.py:398-498) for one post-processed dB row per workgroup: noise floor = np.percentile(., 20)
+// (method 'linear': the order statistics floor((n-1)*0.2) and the next one, found by an MSD radix select over the
+// order-preserving 64-bit image of the values, then numpy's _lerp), display range (:424-427), clip + x**0.7 (:442-445),
+// np.interp to the display width (:448-452), bar height int(value*H) and the glyph / colour of every cell (:455-490).
+// glyph: 0 '.', 1 '-', 2 '=', 3 '#', 4 ' '; colour: curses pair (1 = cleared cell); -1: column not drawn (non-finite).
+__device__ __forceinline__ unsigned long long d2ord(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord2d(unsigned long long o)
+{
+    return __longlong_as_double((long long)((o >> 63) ? (o & 0x7fffffffffffffffull) : ~o));
+}
+
+template <class T>
+__global__ __launch_bounds__(1024) void k_spectrogram(const T *__restrict__ rows, long n_rows, int len, int disp_h, int disp_w,
+                                                      int8_t *__restrict__ glyph, int8_t *__restrict__ colour,
+                                                      double *__restrict__ range_out)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long sel_prefix;
+    __shared__ unsigned sel_k;
+    __shared__ double red[16];
+    __shared__ unsigned redn[16];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (long f = blockIdx.x; f < n_rows; f += gridDim.x) {
+        const T *row = rows + (size_t)f * len;
+        int8_t *gl = glyph + (size_t)f * disp_h * disp_w, *co = colour + (size_t)f * disp_h * disp_w;
+        // max and count of the finite values
+        double mx = -INFINITY;
+        unsigned cnt = 0;
+        for (int i = tid; i < len; i += nthr) {
+            const double v = (double)row[i];
+            if (isfinite(v)) { mx = v > mx ? v : mx; cnt++; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(mx, off);
+            mx = o > mx ? o : mx;
+            cnt += __shfl_xor(cnt, off);
+        }
+        if ((tid & 63) == 0) { red[tid >> 6] = mx; redn[tid >> 6] = cnt; }
+        __syncthreads();
+        mx = red[0]; cnt = redn[0];
+        for (int w = 1; w < nthr / 64; w++) { mx = red[w] > mx ? red[w] : mx; cnt += redn[w]; }
+        __syncthreads();
+        for (int i = tid; i < disp_h * disp_w; i += nthr) { gl[i] = -1; co[i] = -1; }
+        if (cnt == 0) { __syncthreads(); continue; }
+        auto select = [&](unsigned k) {  // k-th smallest finite value (0-based)
+            unsigned long long prefix = 0, mask = 0;
+            for (int shift = 56; shift >= 0; shift -= 8) {
+                for (int b = tid; b < 256; b += nthr) hist[b] = 0;
+                __syncthreads();
+                for (int i0 = 0; i0 < len; i0 += nthr) {
+                    const int i = i0 + tid;
+                    bool live = false;
+                    unsigned bin = 0;
+                    if (i < len) {
+                        const double v = (double)row[i];
+                        const unsigned long long o = d2ord(v);
+                        live = isfinite(v) && (o & mask) == prefix;
+                        bin = (unsigned)(o >> shift) & 255u;
+                    }
+                    unsigned long long todo = __ballot(live);
+                    while (todo) {  // one LDS atomic per distinct bin of the wavefront
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const unsigned b0 = __shfl(bin, leader);
+                        const unsigned long long same = __ballot(live && bin == b0) & todo;
+                        if ((tid & 63) == leader) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+                        todo &= ~same;
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned cum = 0, b = 0;
+                    for (; b < 256; b++) {
+                        if (cum + hist[b] > k) break;
+                        cum += hist[b];
+                    }
+                    sel_prefix = prefix | ((unsigned long long)b << shift);
+                    sel_k = k - cum;
+                }
+                __syncthreads();
+                prefix = sel_prefix;
+                k = sel_k;
+                mask |= 255ull << shift;
+                __syncthreads();
+            }
+            return ord2d(prefix);
+        };
+        // np.percentile(fin, 20), method 'linear'
+        const double vi = (double)(cnt - 1) * 0.2;
+        unsigned lo = (unsigned)floor(vi), hi = lo + 1;
+        if (vi >= (double)(cnt - 1)) { lo = cnt - 1; hi = cnt - 1; }
+        if (hi > cnt - 1) hi = cnt - 1;
+        const double g = vi - floor(vi), a = select(lo), b = (hi == lo) ? a : select(hi), dba = b - a;
+        double noise = a + dba * g;
+        if (g >= 0.5) noise = b - dba * (1 - g);
+        const double range = mx - noise;
+        const double dmin = noise - (range * 0.1), dmax = mx + (range * 0.05);
+        if (range_out && tid == 0) { range_out[2 * f] = dmin; range_out[2 * f + 1] = dmax; }
+        auto shaped = [&](int j) {
+            double v = ((double)row[j] - dmin) / (dmax - dmin);
+            v = v < 0 ? 0 : (v > 1 ? 1 : v);
+            return pow(v, 0.7);
+        };
+        for (int x = tid; x < disp_w; x += nthr) {
+            // np.interp(np.linspace(0, len-1, W), np.arange(len), shaped)[x]
+            const double stop = (double)(len - 1);
+            double xp;
+            if (disp_w == 1) xp = 0.0;
+            else {
+                const double step = stop / (double)(disp_w - 1);
+                xp = (x == disp_w - 1) ? stop : (double)x * step;
+            }
+            double value;
+            if (xp >= stop) value = shaped(len - 1);
+            else {
+                const int j = (int)xp;
+                const double p0 = shaped(j), p1 = shaped(j + 1);
+                const double slope = (p1 - p0) / ((double)(j + 1) - (double)j);
+                value = slope * (xp - (double)j) + p0;
+            }
+            if (!isfinite(value)) continue;
+            int height = (int)(value * disp_h);
+            if (height > disp_h) height = disp_h;
+            for (int y = 0; y < disp_h; y++) {
+                int gch = 4, col = 1;
+                if (y >= disp_h - height) {
+                    const double rel = height > 0 ? (double)(y - (disp_h - height)) / (double)height : 0.0;
+                    if (value > 0.8) { gch = rel > 0.5 ? 3 : 2; col = 14; }
+                    else if (value > 0.4) { gch = rel > 0.5 ? 2 : 1; col = 13; }
+                    else if (value > 0.2) { gch = rel > 0.5 ? 1 : 0; col = 12; }
+                    else if (rel > 0.7) { gch = 0; col = 11; }
+                    else { gch = 4; col = 10; }
+                }
+                gl[y * disp_w + x] = (int8_t)gch;
+                co[y * disp_w + x] = (int8_t)col;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // MODE 0: waterfall (pyspecsdr.py:1342-1406)   MODE 1: persistence (pyspecsdr.py:1512-1564)
 template <class T, int MODE>
 __global__ __launch_bounds__(1024) void k_cells(const T *__restrict__ rows, int n_rows, int len, int disp_h, int disp_w,
@@ -643,6 +787,33 @@ extern "C" int pss_persistence_cells(pss_ctx *ctx, const float *d_rows, int n_ro
 
 // float64-row variants: the quantisers are integer-valued functions of float64 data in the reference, so the
 // parity tests drive them with the reference's own float64 rows.
+template <class T>
+static int launch_spectrogram(pss_ctx *ctx, const T *d_rows, long n_rows, int len, int disp_h, int disp_w, int8_t *d_glyph,
+                              int8_t *d_colour, double *d_range)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!d_rows || !d_glyph || !d_colour || n_rows < 0 || len < 2 || disp_h < 1 || disp_w < 1)
+        return pss_fail(ctx, PSS_E_ARG, "bad spectrogram arguments");
+    if (n_rows == 0) return PSS_OK;
+    pss_kernel_begin(ctx, "k_spectrogram");
+    hipLaunchKernelGGL(k_spectrogram<T>, dim3((unsigned)(n_rows < 4096 ? n_rows : 4096)), dim3(len <= 4096 ? 256 : 1024), 0,
+                       PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w, d_glyph, d_colour, d_range);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_spectrogram launch");
+}
+
+extern "C" int pss_spectrogram_cells(pss_ctx *ctx, const float *d_rows, long n_rows, int len, int disp_h, int disp_w,
+                                     int8_t *d_glyph, int8_t *d_colour, double *d_range)
+{
+    return launch_spectrogram<float>(ctx, d_rows, n_rows, len, disp_h, disp_w, d_glyph, d_colour, d_range);
+}
+
+extern "C" int pss_spectrogram_cells_f64(pss_ctx *ctx, const double *d_rows, long n_rows, int len, int disp_h, int disp_w,
+                                         int8_t *d_glyph, int8_t *d_colour, double *d_range)
+{
+    return launch_spectrogram<double>(ctx, d_rows, n_rows, len, disp_h, disp_w, d_glyph, d_colour, d_range);
+}
+
 extern "C" int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int len, int disp_h, int disp_w,
                                        int8_t *d_glyph, int8_t *d_colour)
 {

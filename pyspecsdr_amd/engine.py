@@ -158,6 +158,10 @@ class Engine:
         fn = self.lib.pss_waterfall_cells_f64 if f64 else self.lib.pss_waterfall_cells
         self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour)))
 
+    def spectrogram_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_glyph, d_colour, d_range=None, f64=False):
+        fn = self.lib.pss_spectrogram_cells_f64 if f64 else self.lib.pss_spectrogram_cells
+        self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_range)))
+
     def persistence_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_colour, f64=False):
         fn = self.lib.pss_persistence_cells_f64 if f64 else self.lib.pss_persistence_cells
         self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_colour)))

@@ -463,6 +463,36 @@ def test_long_frames_grouped_reductions(n):
     assert np.array_equal(audio[0], O.demod_am(iq[0], sos))
 
 
+def test_spectrogram_cells(golden):
+    """draw_spectrogram (pyspecsdr.py:398-498): float64 rows against the reference's own cell grids (incl. a full
+    32768-sample buffer), float32 rows in a batch against the oracle."""
+    g = golden["caller"]
+    e = G.engine()
+    for tag in g["sg_tags"]:
+        hh, ww = [int(v) for v in g[f"sg_hw_{tag}"]]
+        row = g[f"sg_row_{tag}"]
+        dh, dw = hh - 4, ww - 7
+        d_gl, d_co = G.empty((dh, dw), torch.int8), G.empty((dh, dw), torch.int8)
+        d_rg = G.empty((1, 2), torch.float64)
+        e.spectrogram_cells(G.dev(row), 1, len(row), dh, dw, d_gl, d_co, d_rg, f64=True)
+        e.sync()
+        assert np.array_equal(G.host(d_gl), g[f"sg_glyph_{tag}"]), tag
+        assert np.array_equal(G.host(d_co), g[f"sg_colour_{tag}"]), tag
+        _, _, dmin, dmax = O.spectrogram_cells(row, dh, dw)
+        assert np.allclose(G.host(d_rg)[0], [dmin, dmax], rtol=1e-14, atol=0)
+    rng = np.random.default_rng(12)
+    rows = (rng.standard_normal((37, 2044)) * 5 - 40).astype(np.float32)
+    rows[:, 700:760] += 35
+    rows[3, 10] = np.nan                                        # excluded from the statistics; its columns stay undrawn
+    d_gl, d_co = G.empty((37, 30, 100), torch.int8), G.empty((37, 30, 100), torch.int8)
+    e.spectrogram_cells(G.dev(rows), 37, 2044, 30, 100, d_gl, d_co, None)
+    e.sync()
+    gl, co = G.host(d_gl), G.host(d_co)
+    for f in (0, 3, 36):
+        ogl, oco, _, _ = O.spectrogram_cells(rows[f].astype(np.float64), 30, 100)
+        assert np.array_equal(gl[f], ogl) and np.array_equal(co[f], oco), f
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()
