@@ -45,8 +45,12 @@ int pss_set_stream(pss_ctx *ctx, void *hip_stream);
 int pss_sync(pss_ctx *ctx);
 const char *pss_last_error(pss_ctx *ctx); /* ctx may be NULL: error of the last failed pss_create */
 int pss_device_count(void);
-/* Tuning / testing switches.  "nfm_fused" (default 1): 0 selects the three-kernel NFM path (front, edge, iir) that
- * also serves frames shorter than 129 samples; both paths produce identical bits.  Returns PSS_E_ARG for unknown keys. */
+/* Tuning / testing switches; every alternative path produces identical bits.  Returns PSS_E_ARG for unknown keys.
+ *   "nfm_fused" (1)            0: lane-per-frame three-kernel NFM path (front, edge, iir) instead of the fused kernels
+ *   "wfm_fused" (1)            0: k_wfm_front + lane-per-frame decimator instead of the fused WFM forward kernel
+ *   "small_batch" (1)          0: never take the latency-oriented small-batch kernels (one lane per filter section)
+ *   "small_batch_max" (16384)  largest NFM frame count that takes them;  "wfm_small_batch_max" (8192) likewise for WFM
+ *   "post_sort_max" (8192)     longest dB row post-processed with the LDS sort (longer rows: radix select) */
 int pss_set_option(pss_ctx *ctx, const char *key, int value);
 
 /* ---- filter design (host side, pure C++; replaces the per-call SciPy design work) -------------- */
