@@ -559,14 +559,17 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
                float *d_peak, double *d_bw, int32_t *d_count, double bin_hz)
 {
     using C = pss_r16::Cfg<LOG_R3>;
-    auto kern = pss_r16::k_spectrum_r16<LOG_R3, SCAN>;
-    const size_t lds = C::LDS;
+    // component-wise LDS exchanges (half the LDS, twice the barriers) pay only at N = 256, where the plain kernel fits a
+    // single 80 KB workgroup per CU: 0.29 -> 0.20 ms for 262144 frames; at 512...2048 they measured 20 % slower
+    const bool split = ctx->fft_split >= 0 ? ctx->fft_split != 0 : LOG_R3 == 0;
+    auto kern = split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, false>;
+    const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2) : C::LDS;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long groups = (n_frames + C::FPW - 1) / C::FPW;
     int per_cu = (int)((160 * 1024) / (lds + 256));
-    if (per_cu > 2) per_cu = 2;  // ~200 VGPRs: two 256-thread workgroups per CU
+    if (per_cu > (split ? 4 : 2)) per_cu = split ? 4 : 2;  // 124 VGPRs: at most four 256-thread workgroups per CU
     if (per_cu < 1) per_cu = 1;
     const long cap = 256L * per_cu * 2;
     const int grid = (int)(groups < cap ? groups : cap);

@@ -144,7 +144,68 @@ __device__ __forceinline__ void r16_core(double2 (&v)[16], double2 *ex, const do
     }
 }
 
-template <int LOG_R3, bool SCAN>
+// The same transform with the two LDS exchanges done one COMPONENT at a time (real parts, then imaginary parts): the
+// exchange buffer shrinks to EX doubles per frame, which doubles the workgroups a CU can hold (the kernel is LDS-capacity
+// bound at 2 workgroups per CU otherwise) at the price of twice the barriers.  Same arithmetic, same results.
+template <int LOG_R3, class Emit>
+__device__ __forceinline__ void r16_core_split(double2 (&v)[16], double *ex, const double2 (&tw1)[16], const double2 *tw2,
+                                               int t, Emit emit)
+{
+    using C = Cfg<LOG_R3>;
+    constexpr int R3 = C::R3, T = C::T;
+    const int k2s = t / R3, m1s = t % R3;  // stage-2 role
+    fft_reg<16>(v);
+    double2 y[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) {
+        y[k2] = v[brev(k2, 4)];
+        if (k2) y[k2] = cmul(y[k2], tw1[k2]);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) ex[k2 * C::E1_STRIDE + t] = y[k2].x;
+    __syncthreads();
+#pragma unroll
+    for (int m2 = 0; m2 < 16; m2++) v[m2].x = ex[k2s * C::E1_STRIDE + m1s + R3 * m2];
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) ex[k2 * C::E1_STRIDE + t] = y[k2].y;
+    __syncthreads();
+#pragma unroll
+    for (int m2 = 0; m2 < 16; m2++) v[m2].y = ex[k2s * C::E1_STRIDE + m1s + R3 * m2];
+    __syncthreads();
+    fft_reg<16>(v);
+#pragma unroll
+    for (int j2 = 0; j2 < 16; j2++) {
+        y[j2] = v[brev(j2, 4)];
+        if (R3 > 1) y[j2] = cmul(y[j2], tw2[m1s * 16 + j2]);
+    }
+#pragma unroll
+    for (int j2 = 0; j2 < 16; j2++) ex[m1s * C::E2_STRIDE + 16 * j2 + k2s] = y[j2].x;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16 / R3; c++)
+#pragma unroll
+        for (int m1 = 0; m1 < R3; m1++) v[c * R3 + m1].x = ex[m1 * C::E2_STRIDE + t + T * c];
+    __syncthreads();
+#pragma unroll
+    for (int j2 = 0; j2 < 16; j2++) ex[m1s * C::E2_STRIDE + 16 * j2 + k2s] = y[j2].y;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16 / R3; c++)
+#pragma unroll
+        for (int m1 = 0; m1 < R3; m1++) v[c * R3 + m1].y = ex[m1 * C::E2_STRIDE + t + T * c];
+#pragma unroll
+    for (int c = 0; c < 16 / R3; c++) {
+        double2 b[R3];
+#pragma unroll
+        for (int m1 = 0; m1 < R3; m1++) b[m1] = v[c * R3 + m1];
+        fft_reg<R3>(b);
+#pragma unroll
+        for (int j1 = 0; j1 < R3; j1++) emit(c * R3 + j1, 256 * j1 + t + T * c, b[brev(j1, LOG_R3)]);
+    }
+}
+
+template <int LOG_R3, bool SCAN, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__ iq, float *__restrict__ db,
                                                       const double2 *__restrict__ tw, const double *__restrict__ win,
                                                       long n_frames, float *__restrict__ peak, double *__restrict__ bw,
@@ -154,7 +215,8 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
     constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = C::FPW;
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *ex_all = reinterpret_cast<double2 *>(smem);
-    double2 *tw2 = ex_all + (size_t)FPW * C::EX;  // W_T^(m1*j2), [m1][j2]
+    double2 *tw2 = SPLIT ? reinterpret_cast<double2 *>(smem + (size_t)FPW * C::EX * sizeof(double))
+                         : ex_all + (size_t)FPW * C::EX;  // W_T^(m1*j2), [m1][j2]
     __shared__ float red_f[4];
     __shared__ int red_i[4];
     const int tid = threadIdx.x;
@@ -188,12 +250,14 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
         float *out = (db && valid) ? db + (size_t)f * N : nullptr;
         float lmax = -INFINITY;
         float dbv[16];
-        r16_core<LOG_R3>(v, ex, tw1, tw2, t, [&](int i, int k, double2 X) {
+        auto emit = [&](int i, int k, double2 X) {
             float d = db_of(X.x * X.x + X.y * X.y + 1e-10);
             if (out) out[(k + N / 2) & (N - 1)] = d;  // fftshift; T consecutive bins per store instruction
             dbv[i] = d;
             lmax = fmaxf(lmax, d);
-        });
+        };
+        if (SPLIT) r16_core_split<LOG_R3>(v, reinterpret_cast<double *>(smem) + (size_t)fl * C::EX, tw1, tw2, t, emit);
+        else r16_core<LOG_R3>(v, ex, tw1, tw2, t, emit);
         if (SCAN) {
             // per-frame peak and 20-dB-down bin count (pyspecsdr.py:2546-2552); T threads own one frame
             float m = lmax;

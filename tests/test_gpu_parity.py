@@ -36,6 +36,22 @@ def test_spectrum_vs_golden(golden, n):
     assert np.max(np.abs(db - ref)) < 2e-5  # in practice: float32 rounding of the output only
 
 
+def test_spectrum_split_exchange_is_bit_identical():
+    # the component-wise LDS exchange variant of the register FFT (automatic at N = 256) must not change a bit
+    rng = np.random.default_rng(44)
+    e = G.engine()
+    for n in (256, 1024, 4096):
+        iq = (rng.standard_normal((40, n)) + 1j * rng.standard_normal((40, n))).astype(np.complex64)
+        res = []
+        for sp in (0, 1):
+            e.set_option("fft_split", sp)
+            try:
+                res.append(G.spectrum(iq))
+            finally:
+                e.set_option("fft_split", -1)
+        assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32)), n
+
+
 def test_spectrum_zero_and_large(golden):
     z = np.zeros((3, 1024), np.complex64)
     assert np.all(np.abs(G.spectrum(z) + 100.0) <= 1e-4 * 100.0)   # reference: exactly -100.0
