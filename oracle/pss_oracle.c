@@ -743,6 +743,55 @@ void pss_o_waterfall_cells(const double *rows, int n_rows, int len, int disp_h, 
     }
 }
 
+/* draw_gradient_waterfall — pyspecsdr.py:1640-1716: the same ring, min/max and resampling as draw_waterfall, a zero-range
+ * guard (:1657-1659), character index int(norm*8) into ' ._-=+*#@' (:1686-1691) and colour index int(norm*5) (:1694). */
+void pss_o_gradient_cells(const double *rows, int n_rows, int len, int disp_h, int disp_w, int8_t *glyph, int8_t *colour)
+{
+    double mn, mx;
+    ring_minmax(rows, (long)n_rows * len, &mn, &mx);
+    double range = mx - mn;
+    if (range == 0) range = 1;
+    memset(glyph, -1, (size_t)disp_h * disp_w);
+    memset(colour, -1, (size_t)disp_h * disp_w);
+    for (int y = 0; y < n_rows && y < disp_h; y++) {
+        const double *row = rows + (long)(n_rows - 1 - y) * len;
+        for (int x = 0; x < disp_w; x++) {
+            double v = interp_row(row, len, disp_w, x);
+            if (!isfinite(v)) continue;
+            double nv = (v - mn) / range;
+            glyph[y * disp_w + x] = (int8_t)(int)(nv * 8);
+            colour[y * disp_w + x] = (int8_t)(int)(nv * 5);
+        }
+    }
+}
+
+/* draw_surface_plot — pyspecsdr.py:1567-1616: row min/max with a zero-range guard (:1575-1580), resampling to
+ * max_w - 8 columns (:1583-1587), magnitude int(value*20) (:1593), then '#' cells marching up-left at 45 degrees
+ * (:1595-1596) on the WHOLE screen grid [max_h][max_w], colour pair 1 + y % 5 (:1601); later (x, y) overwrite. 0 = empty. */
+void pss_o_surface_cells(const double *row, int len, int max_h, int max_w, int8_t *colour)
+{
+    const double COS45 = 0x1.6a09e667f3bcdp-1, SIN45 = 0x1.6a09e667f3bccp-1; /* np.cos / np.sin(np.radians(45)) */
+    double mn, mx;
+    ring_minmax(row, len, &mn, &mx);
+    double range = mx - mn;
+    if (range == 0) range = 1;
+    const int disp_w = max_w - 8;
+    memset(colour, 0, (size_t)max_h * max_w);
+    double *nrm = (double *)malloc(sizeof(double) * len);
+    for (int i = 0; i < len; i++) nrm[i] = (row[i] - mn) / range;
+    for (int x = 0; x < disp_w; x++) {
+        const double value = interp_row(nrm, len, disp_w, x);
+        if (!isfinite(value)) continue;
+        const int mag = (int)(value * 20);
+        for (int y = 0; y < mag; y++) {
+            const int sx = (int)((double)x - (double)y * COS45) + 8;
+            const int sy = (int)((double)(max_h - 2) - (double)y * SIN45);
+            if (sx >= 0 && sx < max_w && sy >= 2 && sy < max_h - 1) colour[sy * max_w + sx] = (int8_t)(1 + y % 5);
+        }
+    }
+    free(nrm);
+}
+
 /* draw_persistence — pyspecsdr.py:1512-1564 (ring :1521-1523, range guard :1528-1530,
  * alpha/colour :1544-1545, y-cell :1555-1556).  Later traces overwrite earlier ones. */
 void pss_o_persistence_cells(const double *rows, int n_rows, int len, int disp_h, int disp_w,

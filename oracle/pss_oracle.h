@@ -77,6 +77,10 @@ void pss_o_waterfall_cells(const double *rows, int n_rows, int len, int disp_h, 
 void pss_o_persistence_cells(const double *rows, int n_rows, int len, int disp_h, int disp_w,
                              int8_t *colour);
 
+/* gradient waterfall — pyspecsdr.py:1640-1716: glyph = index into ' ._-=+*#@' (0..8), colour 0..5, -1 = not drawn. */
+void pss_o_gradient_cells(const double *rows, int n_rows, int len, int disp_h, int disp_w, int8_t *glyph, int8_t *colour);
+/* surface plot — pyspecsdr.py:1567-1616: colour[max_h][max_w] over the whole screen, 0 = empty, else pair 1..5 ('#'). */
+void pss_o_surface_cells(const double *row, int len, int max_h, int max_w, int8_t *colour);
 /* spectrum display quantiser — draw_spectrogram, pyspecsdr.py:398-498.  row[len] = one post-processed dB row.
  * glyph/colour [disp_h][disp_w]: glyph 0 '.', 1 '-', 2 '=', 3 '#', 4 ' '; colour = curses pair (1 = cleared); -1 = not drawn.
  * disp_min/disp_max (nullable): the dB range of the scale labels (:424-427). */

@@ -47,6 +47,8 @@ def lib():
         L.pss_o_demod_wfm.argtypes = [_f32p, C.c_int, C.c_int, _f64p, _f64p, _f64p, C.c_double, _f64p, _f64p, _f64p, _f64p]
         L.pss_o_sosfilt.argtypes = [_f64p, C.c_int, _f64p, C.c_long, _f64p]
         L.pss_o_spectrogram_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, _i8p, _i8p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.pss_o_gradient_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, C.c_int, _i8p, _i8p]
+        L.pss_o_surface_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, _i8p]
         L.pss_o_power_db.restype = C.c_float
         L.pss_o_power_db.argtypes = [_f32p, C.c_int]
         L.pss_o_scan_slice.restype = C.c_int
@@ -127,6 +129,20 @@ def spectrogram_cells(row, disp_h, disp_w):
     dmin, dmax = C.c_double(), C.c_double()
     lib().pss_o_spectrogram_cells(row, len(row), disp_h, disp_w, gl, co, C.byref(dmin), C.byref(dmax))
     return gl, co, dmin.value, dmax.value
+
+
+def gradient_cells(rows, disp_h, disp_w):
+    rows = np.ascontiguousarray(rows, np.float64)
+    gl, co = np.empty((disp_h, disp_w), np.int8), np.empty((disp_h, disp_w), np.int8)
+    lib().pss_o_gradient_cells(rows, rows.shape[0], rows.shape[1], disp_h, disp_w, gl, co)
+    return gl, co
+
+
+def surface_cells(row, max_h, max_w):
+    row = np.ascontiguousarray(row, np.float64)
+    co = np.empty((max_h, max_w), np.int8)
+    lib().pss_o_surface_cells(row, len(row), max_h, max_w, co)
+    return co
 
 
 def power_db(iq):

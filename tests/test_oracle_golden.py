@@ -220,3 +220,16 @@ def test_spectrogram_cells(golden):
         assert np.array_equal(gl, g[f"sg_glyph_{tag}"]), tag
         assert np.array_equal(co, g[f"sg_colour_{tag}"]), tag
         assert dmin < dmax
+
+
+def test_gradient_waterfall_and_surface_cells(golden):
+    g = golden["caller"]
+    rows = g["rows"]
+    H, W = [int(v) for v in g["hw"]]
+    for i in range(len(g["gw_glyph"])):
+        ring = rows[max(0, i + 1 - 30):i + 1]
+        gl, co = O.gradient_cells(ring, H - 4, W - 10)
+        assert np.array_equal(gl, g["gw_glyph"][i]) and np.array_equal(co, g["gw_colour"][i]), i
+    assert [float(v).hex() for v in g["sf_cos_sin"]] == ["0x1.6a09e667f3bcdp-1", "0x1.6a09e667f3bccp-1"]
+    for i, (row, hh, ww) in enumerate(((rows[0], 40, 120), (rows[5], 40, 120), (g["sg_row_big"], 50, 200))):
+        assert np.array_equal(O.surface_cells(row, hh, ww), g[f"sf_colour_{i}"]), i

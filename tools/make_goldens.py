@@ -471,6 +471,36 @@ def gen_caller():
         d[f"sg_glyph_{tag}"] = g
         d[f"sg_colour_{tag}"] = c
     d["sg_tags"] = np.array([c_[0] for c_ in cases])
+    # gradient waterfall (draw_gradient_waterfall, pyspecsdr.py:1640-1716): 9 intensity characters ' ._-=+*#@' (code =
+    # index), colour index 0..5; same ring as the plain waterfall.  -1 = not drawn.
+    P.WATERFALL_HISTORY.clear()
+    chars9 = ' ._-=+*#@'
+    gw_g, gw_c = [], []
+    for r in rows[:33]:
+        scr = Scr(H, W)
+        P.draw_gradient_waterfall(scr, r, None, 100e6, 2.4e6, 0, 0, None)
+        g = -np.ones((H - 4, W - 10), np.int8); c = -np.ones((H - 4, W - 10), np.int8)
+        for call in scr.calls:
+            y, x, st, attr = call
+            if len(st) == 1 and st in chars9 and 9 <= x < 9 + (W - 10) and 2 <= y < 2 + (H - 4) and (attr >> 8) >= 10:
+                g[y - 2, x - 9] = chars9.index(st); c[y - 2, x - 9] = (attr >> 8) - 10
+        gw_g.append(g); gw_c.append(c)
+    d["gw_glyph"] = np.stack(gw_g)
+    d["gw_colour"] = np.stack(gw_c)
+    P.WATERFALL_HISTORY.clear()
+    # surface plot (draw_surface_plot, pyspecsdr.py:1567-1616): '#' cells on the whole screen, colour pair 1..5; 0 = empty
+    sf = []
+    for r, hh, ww in ((rows[0], 40, 120), (rows[5], 40, 120), (fd, 50, 200)):
+        scr = Scr(hh, ww)
+        P.draw_surface_plot(scr, r.copy(), None, 100e6, 2.4e6, 0, 0, None)
+        g = np.zeros((hh, ww), np.int8)
+        for call in scr.calls:
+            y, x, st, attr = call
+            if st == "#":
+                g[y, x] = attr >> 8
+        sf.append(g)
+    d["sf_colour_0"], d["sf_colour_1"], d["sf_colour_2"] = sf
+    d["sf_cos_sin"] = np.array([np.cos(np.radians(P.SURFACE_ANGLE)), np.sin(np.radians(P.SURFACE_ANGLE))])
     save("caller", **d)
 
 
