@@ -146,6 +146,17 @@ int pss_spectrogram_cells(pss_ctx *ctx, const float *d_rows, long n_rows, int le
 int pss_spectrogram_cells_f64(pss_ctx *ctx, const double *d_rows, long n_rows, int len, int disp_h, int disp_w,
                               int8_t *d_glyph, int8_t *d_colour, double *d_range);
 
+/* Gradient waterfall — draw_gradient_waterfall (pyspecsdr.py:1640-1716) over the same ring of rows: glyph = index into
+ * ' ._-=+*#@' (0..8), colour index 0..5, -1 = not drawn.  d_glyph / d_colour int8 [disp_h][disp_w], disp_w = max_width - 10. */
+int pss_gradient_cells(pss_ctx *ctx, const float *d_rows, int n_rows, int len, int disp_h, int disp_w, int8_t *d_glyph,
+                       int8_t *d_colour);
+int pss_gradient_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int len, int disp_h, int disp_w, int8_t *d_glyph,
+                           int8_t *d_colour);
+/* Surface plot — draw_surface_plot (pyspecsdr.py:1567-1616) of one row on the whole screen: d_colour int8 [max_h][max_w],
+ * 0 = empty, else the curses pair 1..5 of the '#' drawn there. */
+int pss_surface_cells(pss_ctx *ctx, const float *d_row, int len, int max_h, int max_w, int8_t *d_colour);
+int pss_surface_cells_f64(pss_ctx *ctx, const double *d_row, int len, int max_h, int max_w, int8_t *d_colour);
+
 /* Same quantisers over float64 rows (the reference's rows are float64; used to check cell-exact parity). */
 int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int len, int disp_h, int disp_w,
                             int8_t *d_glyph, int8_t *d_colour);

@@ -479,6 +479,8 @@ __global__ __launch_bounds__(1024) void k_spectrogram(const T *__restrict__ rows
 }
 
 // MODE 0: waterfall (pyspecsdr.py:1342-1406)   MODE 1: persistence (pyspecsdr.py:1512-1564)
+// MODE 2: gradient waterfall (pyspecsdr.py:1640-1716): zero-range guard, glyph = int(norm*8) into ' ._-=+*#@', colour int(norm*5)
+// MODE 3: surface plot (pyspecsdr.py:1567-1616) of ONE row on the whole screen grid [disp_h][disp_w] = [max_h][max_w]
 template <class T, int MODE>
 __global__ __launch_bounds__(1024) void k_cells(const T *__restrict__ rows, int n_rows, int len, int disp_h, int disp_w,
                                                int8_t *__restrict__ glyph, int8_t *__restrict__ colour, int start, int cap)
@@ -506,21 +508,62 @@ __global__ __launch_bounds__(1024) void k_cells(const T *__restrict__ rows, int 
 #pragma unroll
     for (int k = 1; k < CT / 64; k++) { lo = fmin(lo, red_lo[k]); hi = fmax(hi, red_hi[k]); }
     const int cells = disp_h * disp_w;
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {
+        double range2 = hi - lo;
+        if (MODE == 2 && range2 == 0) range2 = 1;  // the plain waterfall has no zero-range guard
         for (int c = tid; c < cells; c += CT) {
             int y = c / disp_w, x = c - y * disp_w;
             int8_t g = -1, ci = -1;
             if (y < n_rows) {
                 double v = interp_row(rowp(n_rows - 1 - y), len, disp_w, x);
                 if (isfinite(v)) {
-                    double nv = (v - lo) / (hi - lo);  // no zero-range guard in the reference
+                    double nv = (v - lo) / range2;
                     ci = (int8_t)(int)(nv * 5);
-                    g = nv > 0.75 ? 3 : nv > 0.5 ? 2 : nv > 0.25 ? 1 : 0;
+                    if (MODE == 0) g = nv > 0.75 ? 3 : nv > 0.5 ? 2 : nv > 0.25 ? 1 : 0;
+                    else g = (int8_t)(int)(nv * 8);
                 }
             }
             glyph[c] = g;
             colour[c] = ci;
         }
+    } else if (MODE == 3) {
+        // '#' cells march up-left at 45 degrees from every column; later (x, y) overwrite earlier ones, so each cell keeps
+        // the LARGEST (x, y) key that hits it (atomicMax on an int grid in global memory, then decoded to the colour pair)
+        const double COS45 = 0x1.6a09e667f3bcdp-1, SIN45 = 0x1.6a09e667f3bccp-1;  // np.cos / np.sin(np.radians(45))
+        double range = hi - lo;
+        if (range == 0) range = 1;
+        int *keys = reinterpret_cast<int *>(glyph);  // scratch: [disp_h][disp_w] ints supplied by the host wrapper
+        for (int c = tid; c < cells; c += CT) keys[c] = -1;
+        __syncthreads();
+        const int w = disp_w - 8;
+        const T *row = rowp(0);
+        for (int x = tid; x < w; x += CT) {
+            // np.interp over the NORMALISED row: normalisation is affine and applied per sample before interpolating
+            const double stop = (double)(len - 1);
+            double xp;
+            if (w == 1) xp = 0.0;
+            else {
+                const double step = stop / (double)(w - 1);
+                xp = (x == w - 1) ? stop : (double)x * step;
+            }
+            double value;
+            if (xp >= stop) value = ((double)row[len - 1] - lo) / range;
+            else {
+                const int j = (int)xp;
+                const double p0 = ((double)row[j] - lo) / range, p1 = ((double)row[j + 1] - lo) / range;
+                const double slope = (p1 - p0) / ((double)(j + 1) - (double)j);
+                value = slope * (xp - (double)j) + p0;
+            }
+            if (!isfinite(value)) continue;
+            const int mag = (int)(value * 20);
+            for (int y = 0; y < mag; y++) {
+                const int sx = (int)((double)x - (double)y * COS45) + 8;
+                const int sy = (int)((double)(disp_h - 2) - (double)y * SIN45);
+                if (sx >= 0 && sx < disp_w && sy >= 2 && sy < disp_h - 1) atomicMax(&keys[sy * disp_w + sx], x * 32 + y);
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < cells; c += CT) colour[c] = keys[c] < 0 ? 0 : (int8_t)(1 + (keys[c] & 31) % 5);
     } else {
         double range = hi - lo;
         if (range == 0) range = 1;
@@ -815,6 +858,53 @@ extern "C" int pss_spectrogram_cells_f64(pss_ctx *ctx, const double *d_rows, lon
                                          int8_t *d_glyph, int8_t *d_colour, double *d_range)
 {
     return launch_spectrogram<double>(ctx, d_rows, n_rows, len, disp_h, disp_w, d_glyph, d_colour, d_range);
+}
+
+template <class T>
+static int launch_gradient(pss_ctx *ctx, const T *d_rows, int n_rows, int len, int disp_h, int disp_w, int8_t *d_glyph,
+                           int8_t *d_colour)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!d_rows || !d_glyph || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
+        return pss_fail(ctx, PSS_E_ARG, "bad waterfall arguments");
+    pss_kernel_begin(ctx, "k_cells");
+    hipLaunchKernelGGL((k_cells<T, 2>), dim3(1), dim3(1024), 0, PSS_STREAM(ctx), d_rows, n_rows, len, disp_h, disp_w, d_glyph,
+                       d_colour, 0, n_rows);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
+}
+extern "C" int pss_gradient_cells(pss_ctx *ctx, const float *d_rows, int n_rows, int len, int disp_h, int disp_w,
+                                  int8_t *d_glyph, int8_t *d_colour)
+{
+    return launch_gradient<float>(ctx, d_rows, n_rows, len, disp_h, disp_w, d_glyph, d_colour);
+}
+extern "C" int pss_gradient_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int len, int disp_h, int disp_w,
+                                      int8_t *d_glyph, int8_t *d_colour)
+{
+    return launch_gradient<double>(ctx, d_rows, n_rows, len, disp_h, disp_w, d_glyph, d_colour);
+}
+
+template <class T>
+static int launch_surface(pss_ctx *ctx, const T *d_row, int len, int max_h, int max_w, int8_t *d_colour)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!d_row || !d_colour || len < 2 || max_h < 4 || max_w < 10) return pss_fail(ctx, PSS_E_ARG, "bad surface arguments");
+    // one int key per screen cell, parked in the FFT scratch (the display path does not run beside a big-N spectrum)
+    int r = pss_ensure_buffer(ctx, &ctx->scratch_fft, &ctx->scratch_fft_bytes, (size_t)max_h * max_w * sizeof(int), "surface keys");
+    if (r) return r;
+    pss_kernel_begin(ctx, "k_cells");
+    hipLaunchKernelGGL((k_cells<T, 3>), dim3(1), dim3(1024), 0, PSS_STREAM(ctx), d_row, 1, len, max_h, max_w,
+                       reinterpret_cast<int8_t *>(ctx->scratch_fft), d_colour, 0, 1);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_cells launch");
+}
+extern "C" int pss_surface_cells(pss_ctx *ctx, const float *d_row, int len, int max_h, int max_w, int8_t *d_colour)
+{
+    return launch_surface<float>(ctx, d_row, len, max_h, max_w, d_colour);
+}
+extern "C" int pss_surface_cells_f64(pss_ctx *ctx, const double *d_row, int len, int max_h, int max_w, int8_t *d_colour)
+{
+    return launch_surface<double>(ctx, d_row, len, max_h, max_w, d_colour);
 }
 
 extern "C" int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int len, int disp_h, int disp_w,

@@ -162,6 +162,14 @@ class Engine:
         fn = self.lib.pss_spectrogram_cells_f64 if f64 else self.lib.pss_spectrogram_cells
         self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_range)))
 
+    def gradient_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_glyph, d_colour, f64=False):
+        fn = self.lib.pss_gradient_cells_f64 if f64 else self.lib.pss_gradient_cells
+        self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour)))
+
+    def surface_cells(self, d_row, length, max_h, max_w, d_colour, f64=False):
+        fn = self.lib.pss_surface_cells_f64 if f64 else self.lib.pss_surface_cells
+        self._ck(fn(self.h, _ptr(d_row), length, max_h, max_w, _ptr(d_colour)))
+
     def persistence_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_colour, f64=False):
         fn = self.lib.pss_persistence_cells_f64 if f64 else self.lib.pss_persistence_cells
         self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_colour)))

@@ -509,6 +509,30 @@ def test_spectrogram_cells(golden):
         assert np.array_equal(gl[f], ogl) and np.array_equal(co[f], oco), f
 
 
+def test_gradient_waterfall_and_surface_cells(golden):
+    """draw_gradient_waterfall (pyspecsdr.py:1640-1716) and draw_surface_plot (:1567-1616) against the reference's grids."""
+    g = golden["caller"]
+    rows = g["rows"]
+    H, W = [int(v) for v in g["hw"]]
+    e = G.engine()
+    d_gl, d_co = G.empty((H - 4, W - 10), torch.int8), G.empty((H - 4, W - 10), torch.int8)
+    for i in (0, 7, 29, 32):
+        ring = np.ascontiguousarray(rows[max(0, i + 1 - 30):i + 1])
+        e.gradient_cells(G.dev(ring), ring.shape[0], ring.shape[1], H - 4, W - 10, d_gl, d_co, f64=True)
+        e.sync()
+        assert np.array_equal(G.host(d_gl), g["gw_glyph"][i]) and np.array_equal(G.host(d_co), g["gw_colour"][i]), i
+    for i, (row, hh, ww) in enumerate(((rows[0], 40, 120), (rows[5], 40, 120), (g["sg_row_big"], 50, 200))):
+        d_c = G.empty((hh, ww), torch.int8)
+        e.surface_cells(G.dev(np.ascontiguousarray(row)), len(row), hh, ww, d_c, f64=True)
+        e.sync()
+        assert np.array_equal(G.host(d_c), g[f"sf_colour_{i}"]), i
+    r32 = rows[3].astype(np.float32)
+    d_c = G.empty((40, 120), torch.int8)
+    e.surface_cells(G.dev(r32), len(r32), 40, 120, d_c)
+    e.sync()
+    assert np.array_equal(G.host(d_c), O.surface_cells(r32.astype(np.float64), 40, 120))
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()
