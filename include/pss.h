@@ -157,6 +157,10 @@ int pss_gradient_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int l
 int pss_surface_cells(pss_ctx *ctx, const float *d_row, int len, int max_h, int max_w, int8_t *d_colour);
 int pss_surface_cells_f64(pss_ctx *ctx, const double *d_row, int len, int max_h, int max_w, int8_t *d_colour);
 
+/* Constellation display — draw_vector_display (pyspecsdr.py:1718-1752): d_grid int8 [max_h][max_w], 1 where the '.' of
+ * one of the n IQ samples lands (float32 arithmetic as in the reference). */
+int pss_vector_cells(pss_ctx *ctx, const float *d_iq, int n, int max_h, int max_w, int8_t *d_grid);
+
 /* Same quantisers over float64 rows (the reference's rows are float64; used to check cell-exact parity). */
 int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int len, int disp_h, int disp_w,
                             int8_t *d_glyph, int8_t *d_colour);

@@ -792,6 +792,20 @@ void pss_o_surface_cells(const double *row, int len, int max_h, int max_w, int8_
     free(nrm);
 }
 
+/* draw_vector_display — pyspecsdr.py:1718-1752: x = int(center_x + i*scale), y = int(center_y - q*scale) in float32 (the
+ * samples are np.float32 scalars, the Python ints are weak), '.' where the dot lands on the screen.  grid[max_h][max_w]. */
+void pss_o_vector_cells(const float *iq, int n, int max_h, int max_w, int8_t *grid)
+{
+    const int cx = max_w / 2, cy = max_h / 2, scale = (max_w < max_h ? max_w : max_h) / 4;
+    memset(grid, 0, (size_t)max_h * max_w);
+    for (int k = 0; k < n; k++) {
+        const float fx = (float)cx + iq[2 * k] * (float)scale, fy = (float)cy - iq[2 * k + 1] * (float)scale;
+        if (!isfinite(fx) || !isfinite(fy)) continue; /* the reference raises here; nothing is drawn */
+        const int x = (int)fx, y = (int)fy;
+        if (x >= 0 && x < max_w && y >= 0 && y < max_h) grid[y * max_w + x] = 1;
+    }
+}
+
 /* draw_persistence — pyspecsdr.py:1512-1564 (ring :1521-1523, range guard :1528-1530,
  * alpha/colour :1544-1545, y-cell :1555-1556).  Later traces overwrite earlier ones. */
 void pss_o_persistence_cells(const double *rows, int n_rows, int len, int disp_h, int disp_w,

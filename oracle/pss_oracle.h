@@ -81,6 +81,8 @@ void pss_o_persistence_cells(const double *rows, int n_rows, int len, int disp_h
 void pss_o_gradient_cells(const double *rows, int n_rows, int len, int disp_h, int disp_w, int8_t *glyph, int8_t *colour);
 /* surface plot — pyspecsdr.py:1567-1616: colour[max_h][max_w] over the whole screen, 0 = empty, else pair 1..5 ('#'). */
 void pss_o_surface_cells(const double *row, int len, int max_h, int max_w, int8_t *colour);
+/* constellation display — pyspecsdr.py:1718-1752: grid[max_h][max_w] = 1 where a sample's dot lands. */
+void pss_o_vector_cells(const float *iq, int n, int max_h, int max_w, int8_t *grid);
 /* spectrum display quantiser — draw_spectrogram, pyspecsdr.py:398-498.  row[len] = one post-processed dB row.
  * glyph/colour [disp_h][disp_w]: glyph 0 '.', 1 '-', 2 '=', 3 '#', 4 ' '; colour = curses pair (1 = cleared); -1 = not drawn.
  * disp_min/disp_max (nullable): the dB range of the scale labels (:424-427). */

@@ -49,6 +49,7 @@ _SIGS = {
     "pss_gradient_cells_f64": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "pss_surface_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "pss_surface_cells_f64": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p]),
+    "pss_vector_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "pss_waterfall_cells_f64": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "pss_persistence_cells_f64": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "pss_ring_create": (C.c_int, [_p, C.c_int, C.c_int, C.POINTER(_p)]),

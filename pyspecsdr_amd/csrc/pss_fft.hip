@@ -860,6 +860,33 @@ extern "C" int pss_spectrogram_cells_f64(pss_ctx *ctx, const double *d_rows, lon
     return launch_spectrogram<double>(ctx, d_rows, n_rows, len, disp_h, disp_w, d_glyph, d_colour, d_range);
 }
 
+// draw_vector_display (pyspecsdr.py:1718-1752): every IQ sample drops a '.' at (int(cx + i*scale), int(cy - q*scale)),
+// float32 arithmetic as NumPy evaluates it.  grid[max_h][max_w] = 1 where a dot lands (cleared by the launcher).
+__global__ __launch_bounds__(256) void k_vector(const float2 *__restrict__ iq, int n, int max_h, int max_w, int8_t *__restrict__ grid)
+{
+    const int cx = max_w / 2, cy = max_h / 2, scale = (max_w < max_h ? max_w : max_h) / 4;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const float2 v = iq[k];
+        const float fx = __fadd_rn((float)cx, __fmul_rn(v.x, (float)scale)), fy = __fsub_rn((float)cy, __fmul_rn(v.y, (float)scale));
+        if (!isfinite(fx) || !isfinite(fy)) continue;
+        const int x = (int)fx, y = (int)fy;
+        if (x >= 0 && x < max_w && y >= 0 && y < max_h) grid[y * max_w + x] = 1;
+    }
+}
+
+extern "C" int pss_vector_cells(pss_ctx *ctx, const float *d_iq, int n, int max_h, int max_w, int8_t *d_grid)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!d_iq || !d_grid || n < 0 || max_h < 1 || max_w < 1) return pss_fail(ctx, PSS_E_ARG, "bad vector-display arguments");
+    PSS_HIP(ctx, hipMemsetAsync(d_grid, 0, (size_t)max_h * max_w, PSS_STREAM(ctx)));
+    if (n == 0) return PSS_OK;
+    pss_kernel_begin(ctx, "k_vector");
+    hipLaunchKernelGGL(k_vector, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, PSS_STREAM(ctx),
+                       reinterpret_cast<const float2 *>(d_iq), n, max_h, max_w, d_grid);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_vector launch");
+}
+
 template <class T>
 static int launch_gradient(pss_ctx *ctx, const T *d_rows, int n_rows, int len, int disp_h, int disp_w, int8_t *d_glyph,
                            int8_t *d_colour)

@@ -170,6 +170,9 @@ class Engine:
         fn = self.lib.pss_surface_cells_f64 if f64 else self.lib.pss_surface_cells
         self._ck(fn(self.h, _ptr(d_row), length, max_h, max_w, _ptr(d_colour)))
 
+    def vector_cells(self, d_iq, n, max_h, max_w, d_grid):
+        self._ck(self.lib.pss_vector_cells(self.h, _ptr(d_iq), n, max_h, max_w, _ptr(d_grid)))
+
     def persistence_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_colour, f64=False):
         fn = self.lib.pss_persistence_cells_f64 if f64 else self.lib.pss_persistence_cells
         self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_colour)))

@@ -49,6 +49,7 @@ def lib():
         L.pss_o_spectrogram_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, _i8p, _i8p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.pss_o_gradient_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, C.c_int, _i8p, _i8p]
         L.pss_o_surface_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, _i8p]
+        L.pss_o_vector_cells.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _i8p]
         L.pss_o_power_db.restype = C.c_float
         L.pss_o_power_db.argtypes = [_f32p, C.c_int]
         L.pss_o_scan_slice.restype = C.c_int
@@ -143,6 +144,12 @@ def surface_cells(row, max_h, max_w):
     co = np.empty((max_h, max_w), np.int8)
     lib().pss_o_surface_cells(row, len(row), max_h, max_w, co)
     return co
+
+
+def vector_cells(iq, max_h, max_w):
+    g = np.empty((max_h, max_w), np.int8)
+    lib().pss_o_vector_cells(_iq(iq), len(iq), max_h, max_w, g)
+    return g
 
 
 def power_db(iq):

@@ -533,6 +533,16 @@ def test_gradient_waterfall_and_surface_cells(golden):
     assert np.array_equal(G.host(d_c), O.surface_cells(r32.astype(np.float64), 40, 120))
 
 
+def test_vector_display_cells(golden):
+    g = golden["caller"]
+    e = G.engine()
+    for tag, hh, ww in (("a", 40, 120), ("b", 25, 81)):
+        d_g = G.empty((hh, ww), torch.int8)
+        e.vector_cells(G.dev(g["vec_iq"]), len(g["vec_iq"]), hh, ww, d_g)
+        e.sync()
+        assert np.array_equal(G.host(d_g), g[f"vec_grid_{tag}"]), tag
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()

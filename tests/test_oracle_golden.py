@@ -233,3 +233,9 @@ def test_gradient_waterfall_and_surface_cells(golden):
     assert [float(v).hex() for v in g["sf_cos_sin"]] == ["0x1.6a09e667f3bcdp-1", "0x1.6a09e667f3bccp-1"]
     for i, (row, hh, ww) in enumerate(((rows[0], 40, 120), (rows[5], 40, 120), (g["sg_row_big"], 50, 200))):
         assert np.array_equal(O.surface_cells(row, hh, ww), g[f"sf_colour_{i}"]), i
+
+
+def test_vector_display_cells(golden):
+    g = golden["caller"]
+    for tag, hh, ww in (("a", 40, 120), ("b", 25, 81)):
+        assert np.array_equal(O.vector_cells(g["vec_iq"], hh, ww), g[f"vec_grid_{tag}"]), tag

@@ -501,6 +501,19 @@ def gen_caller():
         sf.append(g)
     d["sf_colour_0"], d["sf_colour_1"], d["sf_colour_2"] = sf
     d["sf_cos_sin"] = np.array([np.cos(np.radians(P.SURFACE_ANGLE)), np.sin(np.radians(P.SURFACE_ANGLE))])
+    # vector (constellation) display (draw_vector_display, pyspecsdr.py:1718-1752): 1 where a sample's '.' lands
+    vs = (iq[3][:600] * np.float32(2.5)).astype(np.complex64)
+    vs[7] = complex(-1.999, 1.999)
+    vs[8] = complex(0.0, -0.0)
+    d["vec_iq"] = vs
+    for tag, hh, ww in (("a", 40, 120), ("b", 25, 81)):
+        scr = Scr(hh, ww)
+        P.draw_vector_display(scr, vs, 100e6, 2.4e6, 0, 0, None)
+        g = np.zeros((hh, ww), np.int8)
+        for call in scr.calls:
+            if len(call) == 4 and call[2] == ".":
+                g[call[0], call[1]] = 1
+        d[f"vec_grid_{tag}"] = g
     save("caller", **d)
 
 
