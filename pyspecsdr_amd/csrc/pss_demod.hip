@@ -1584,7 +1584,7 @@ extern "C" int pss_demod_out_len(int mode, int n, double fs)
 extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out_iq, float *d_raw)
 {
     if (!ctx) return PSS_E_ARG;
-    if (!d_iq || n_frames < 0 || n <= 0 || (!d_out_iq && !d_raw)) return pss_fail(ctx, PSS_E_ARG, "pss_iq_correction: bad argument");
+    if (n_frames < 0 || n <= 0 || (n_frames > 0 && (!d_iq || (!d_out_iq && !d_raw)))) return pss_fail(ctx, PSS_E_ARG, "pss_iq_correction: bad argument");
     if (n_frames == 0) return PSS_OK;
     RedPlan rp, cp;
     int rl, rv, cl, cv;
@@ -1617,7 +1617,7 @@ extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames,
 extern "C" int pss_power_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_power)
 {
     if (!ctx) return PSS_E_ARG;
-    if (!d_iq || !d_power || n < 1 || n_frames < 0) return pss_fail(ctx, PSS_E_ARG, "bad power arguments");
+    if (n < 1 || n_frames < 0 || (n_frames > 0 && (!d_iq || !d_power))) return pss_fail(ctx, PSS_E_ARG, "bad power arguments");
     if (n_frames == 0) return PSS_OK;
     pss_time_begin(ctx);
     int r = launch_pairwise<0>(ctx, d_iq, n_frames, n, d_power);
@@ -1640,8 +1640,8 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
                          double *d_audio)
 {
     if (!ctx) return PSS_E_ARG;
-    if (!d_iq || n_frames < 0 || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad demod arguments");
-    if (!d_pcm && !d_audio) return pss_fail(ctx, PSS_E_ARG, "both outputs are null");
+    if (n_frames < 0 || n < 1 || (n_frames > 0 && !d_iq)) return pss_fail(ctx, PSS_E_ARG, "bad demod arguments");
+    if (n_frames > 0 && !d_pcm && !d_audio) return pss_fail(ctx, PSS_E_ARG, "both outputs are null");
     const long tiles = (n_frames + TILE - 1) / TILE;
     if (mode == PSS_MODE_NFM) {
         if (n - 1 <= EDGE)
@@ -1990,7 +1990,7 @@ extern "C" int pss_demod_signal(pss_ctx *ctx, int mode, const float *d_iq, long 
 {
     if (!ctx) return PSS_E_ARG;
     if (mode != PSS_MODE_WFM) return pss_demod(ctx, mode, d_iq, n_frames, n, fs, d_pcm, d_audio);
-    if (!d_iq || n_frames < 0 || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad demod arguments");
+    if (n_frames < 0 || n < 1 || (n_frames > 0 && !d_iq)) return pss_fail(ctx, PSS_E_ARG, "bad demod arguments");
     if (n_frames == 0) return pss_demod(ctx, mode, d_iq, n_frames, n, fs, d_pcm, d_audio);
     int r = pss_ensure_buffer(ctx, &ctx->scratch_iqc, &ctx->scratch_iqc_bytes, (size_t)n_frames * n * sizeof(float2),
                               "iq_correction scratch");

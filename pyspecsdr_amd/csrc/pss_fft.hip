@@ -630,7 +630,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
                     int32_t *d_count, double bin_hz)
 {
     if (!ctx) return PSS_E_ARG;
-    if (!d_iq || n_frames < 0) return pss_fail(ctx, PSS_E_ARG, "null iq / negative n_frames");
+    if (n_frames < 0 || (n_frames > 0 && !d_iq)) return pss_fail(ctx, PSS_E_ARG, "null iq / negative n_frames");
     if (n_fft < 16 || n_fft > (1 << 20) || (n_fft & (n_fft - 1)))
         return pss_fail(ctx, PSS_E_ARG, "n_fft must be a power of two in [16, 1048576]");
     if (n_frames == 0) return PSS_OK;
@@ -759,7 +759,7 @@ int pss_fft_tables(pss_ctx *ctx, int n, const double2 **tw, const double **win)
 
 extern "C" int pss_spectrum_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db)
 {
-    if (ctx && !d_db) return pss_fail(ctx, PSS_E_ARG, "d_db is null");
+    if (ctx && !d_db && n_frames > 0) return pss_fail(ctx, PSS_E_ARG, "d_db is null");
     return launch_spectrum<false>(ctx, d_iq, n_frames, n_fft, d_db, nullptr, nullptr, nullptr, 0.0);
 }
 
@@ -773,7 +773,7 @@ extern "C" int pss_scan(pss_ctx *ctx, const float *d_iq, long n_slices, int n_ff
 extern "C" int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post)
 {
     if (!ctx) return PSS_E_ARG;
-    if (!d_db || !d_post || n_frames < 0) return pss_fail(ctx, PSS_E_ARG, "null pointer");
+    if (n_frames < 0 || (n_frames > 0 && (!d_db || !d_post))) return pss_fail(ctx, PSS_E_ARG, "null pointer");
     if (n_fft < 8 || n_fft > (1 << 20)) return pss_fail(ctx, PSS_E_ARG, "post-process supports 8 <= n_fft <= 1048576");
     if (n_frames == 0) return PSS_OK;
     if (n_fft > ctx->post_sort_max) {  // rows too long for the LDS sort: radix select of the two middle order statistics

@@ -543,6 +543,43 @@ def test_vector_display_cells(golden):
         assert np.array_equal(G.host(d_g), g[f"vec_grid_{tag}"]), tag
 
 
+def test_empty_batches_and_non_finite_samples(golden):
+    """Edge cases: zero frames through every batched entry point; NaN / Inf samples behave as in the reference's
+    arithmetic (they poison the frame they are in — and only that frame)."""
+    e = G.engine()
+    z = G.empty((0, 1024, 2), torch.float32)
+    e.spectrum_db(z, 0, 1024, G.empty((0, 1024), torch.float32))
+    e.power_db(z, 0, 1024, G.empty((0,), torch.float32))
+    e.iq_correction(z, 0, 1024, G.empty((0, 1024, 2), torch.float32), None)
+    for mode in (L.MODE_NFM, L.MODE_AM, L.MODE_USB, L.MODE_WFM):
+        e.demod_signal(mode, z, 0, 1024, 2.4e6, G.empty((0, 10, 2), torch.int16), None)
+    e.spectrum_nfm(z, 0, 1024, 2.4e6, G.empty((0, 1024), torch.float32), G.empty((0, 10, 2), torch.int16))
+    e.sync()
+    rng = np.random.default_rng(31)
+    iq = (0.4 * np.exp(2j * np.pi * np.cumsum(rng.standard_normal((5, 1024)) * 0.05, axis=1))).astype(np.complex64)
+    iq[1, 500] = complex(np.nan, 0.1)
+    iq[3, 17] = complex(np.inf, -0.2)
+    taps, sos, zi = e.nfm_filters(2.4e6)
+    with np.errstate(all="ignore"):
+        pcm, audio = G.demod(L.MODE_NFM, iq, 2.4e6)
+        for f in range(5):
+            ref = O.demod_nfm(iq[f], 2.4e6, taps, sos, zi)
+            assert np.array_equal(audio[f], ref, equal_nan=True), f
+            assert np.array_equal(pcm[f, :, 0], np.int16(np.nan_to_num(ref * 32767, nan=0.0))), f
+        assert np.isnan(audio[1]).all() and np.isfinite(audio[[0, 2, 4]]).all()   # (an Inf sample only bends the angle)
+        am = np.empty((5, 6)); e.lib.pss_am_bandpass_sos(am.ctypes.data)
+        pcm, audio = G.demod(L.MODE_AM, iq, 2.4e6)
+        for f in range(5):
+            assert np.array_equal(audio[f], O.demod_am(iq[f], am), equal_nan=True), f
+        d_p = G.empty((5,), torch.float32)
+        e.power_db(G.dev(iq), 5, 1024, d_p)
+        e.sync()
+        p = G.host(d_p)
+        assert np.isnan(p[1]) and np.isinf(p[3]) and np.isfinite(p[[0, 2, 4]]).all()
+        db = G.spectrum(iq)
+        assert np.isnan(db[1]).all() and np.isfinite(db[[0, 2, 4]]).all()
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()
