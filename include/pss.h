@@ -185,6 +185,13 @@ int pss_h_demodulate(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs
 /* scipy.signal.sosfilt(sos, x) with zero initial state on n_rows independent float64 rows of n samples (one lane per row);
  * sos: HOST pointer, nsec <= 8 rows of 6.  The building block behind bandpass_filter (signal_processing.py:34-42). */
 int pss_sosfilt(pss_ctx *ctx, const double *d_x, long n_rows, int n, const double *sos, int nsec, double *d_y);
+/* decode_afsk (decoders.py:94-112) for n_rows independent float64 audio rows of n samples: the two Bell-202 band-passes,
+ * the energy of each band per bit period of int(fs/1200) samples, bit = e2200 > e1200.  d_bits uint8 [n_rows][n_bits],
+ * n_bits = pss_afsk_n_bits(n, fs) = len(range(0, n - window, window)).  sos1200 / sos2200: HOST tables of nsec rows
+ * (butter(5, [1100,1300] / [2100,2300] Hz, 'band')), or NULL to design them. */
+int pss_afsk_n_bits(int n, double fs);
+int pss_afsk_bits(pss_ctx *ctx, const double *d_audio, long n_rows, int n, double fs, const double *sos1200,
+                  const double *sos2200, int nsec, uint8_t *d_bits);
 /* bandpass_filter(data, lowcut, highcut, sample_rate) (signal_processing.py:34-42; used by decoders.py:100-101) on one
  * host row: lowcut <= 0 -> butter(5) low-pass at highcut, else band-pass.  sos/nsec: caller's table, or NULL to design it. */
 int pss_h_bandpass_filter(pss_ctx *ctx, const double *h_x, int n, double lowcut, double highcut, double fs,

@@ -388,6 +388,54 @@ void pss_o_sosfilt(const double *sos, int nsec, const double *x, long n, double 
     sosfilt_inplace(sos, nsec, y, n, z);
 }
 
+/* numpy add.reduce float64 over n <= 8192 elements of a[i]^2 (DOUBLE_pairwise_sum, same tree as the float32 one). */
+static double pairwise_sq_f64(const double *a, long n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (long i = 0; i < n; i++) res += a[i] * a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        long i;
+        for (int j = 0; j < 8; j++) r[j] = a[j] * a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j] * a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i] * a[i];
+        return res;
+    } else {
+        long n2 = n / 2;
+        n2 -= n2 % 8;
+        return pairwise_sq_f64(a, n2) + pairwise_sq_f64(a + n2, n - n2);
+    }
+}
+
+/* decode_afsk — decoders.py:94-112: two butter(5) band-passes (1100-1300 Hz, 2100-2300 Hz; bandpass_filter,
+ * signal_processing.py:34-42), energy of each band over every bit period of int(fs/1200) samples (np.sum of the squares,
+ * float64 pairwise), bit = e2200 > e1200.  Returns the number of bits = len(range(0, n - window, window)). */
+int pss_o_afsk_bits(const double *x, int n, double fs, const double *sos1200, const double *sos2200, int nsec, uint8_t *bits)
+{
+    const int w = (int)(fs / 1200.0);
+    if (w < 1 || n - w <= 0) return 0;
+    double *f1 = (double *)malloc(sizeof(double) * n), *f2 = (double *)malloc(sizeof(double) * n);
+    pss_o_sosfilt(sos1200, nsec, x, n, f1);
+    pss_o_sosfilt(sos2200, nsec, x, n, f2);
+    int nb = 0;
+    for (int i = 0; i < n - w; i += w) {
+        double e1 = 0.0, e2 = 0.0;
+        for (int st = 0; st < w; st += 8192) {  /* windows longer than the ufunc buffer: chunk sums added in order */
+            const int len = (w - st) < 8192 ? (w - st) : 8192;
+            const double c1 = pairwise_sq_f64(f1 + i + st, len), c2 = pairwise_sq_f64(f2 + i + st, len);
+            e1 = st ? e1 + c1 : c1;
+            e2 = st ? e2 + c2 : c2;
+        }
+        bits[nb++] = e2 > e1;
+    }
+    free(f1); free(f2);
+    return nb;
+}
+
 /* 65-tap FIR with zero initial state: scipy.signal.lfilter(taps, 1.0, x) FIR branch
  * = np.convolve(taps, x)[:len(x)] = multiarray.correlate(x, taps[::-1], 'full') whose inner product is
  * DOUBLE_dot -> cblas_ddot, i.e. OpenBLAS kernel/x86_64/ddot.c + ddot_microk_skylakex-2.c on the

@@ -62,6 +62,9 @@ int pss_o_demod_wfm(const float *iq, int n, int q, const double *lp_sos, const d
                     double *right);
 /* bandpass_filter — signal_processing.py:34-42 with the SOS table given (butter(5) low-/band-pass): sosfilt, zero state. */
 void pss_o_sosfilt(const double *sos, int nsec, const double *x, long n, double *y);
+/* decode_afsk — decoders.py:94-112 given the two band-pass SOS tables: bits[k] = energy(2200 Hz band) > energy(1200 Hz band)
+ * over bit period k of int(fs/1200) samples.  Returns the number of bits. */
+int pss_o_afsk_bits(const double *x, int n, double fs, const double *sos1200, const double *sos2200, int nsec, uint8_t *bits);
 /* int16 conversion — io_manager.py:25-26 / audio_processing.py:37: np.int16(x*32767), stereo dup
  * (mono_to_stereo signal_processing.py:83-88). pcm[2*n] = L0 R0 L1 R1 ... */
 void pss_o_pcm16_stereo(const double *audio, int n, int16_t *pcm);

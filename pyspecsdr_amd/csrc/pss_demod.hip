@@ -1364,6 +1364,52 @@ __global__ __launch_bounds__(TILE) void k_sosfilt(const double *__restrict__ x, 
     }
 }
 
+// decode_afsk (decoders.py:94-112) after the two band-pass rows exist: energy of each band over every bit period (np.sum of
+// the squares: float64 pairwise tree, 8192-element chunks added in order) and the comparison.  One thread per (row, bit).
+__device__ double pairwise_sq_f64(const double *a, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; i++) res = __dadd_rn(res, __dmul_rn(a[i], a[i]));
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = __dmul_rn(a[j], a[j]);
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = __dadd_rn(r[j], __dmul_rn(a[i + j], a[i + j]));
+        }
+        double res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                               __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+        for (; i < n; i++) res = __dadd_rn(res, __dmul_rn(a[i], a[i]));
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return __dadd_rn(pairwise_sq_f64(a, n2), pairwise_sq_f64(a + n2, n - n2));
+}
+__global__ __launch_bounds__(256) void k_afsk_bits(const double *__restrict__ f1, const double *__restrict__ f2, int n, int w,
+                                                   int n_bits, long n_rows, uint8_t *__restrict__ bits)
+{
+    const long total = n_rows * n_bits;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / n_bits;
+        const int b = (int)(idx - r * n_bits);
+        const double *a1 = f1 + (size_t)r * n + (size_t)b * w, *a2 = f2 + (size_t)r * n + (size_t)b * w;
+        double e1 = 0.0, e2 = 0.0;
+        for (int st = 0; st < w; st += 8192) {
+            const int len = (w - st) < 8192 ? (w - st) : 8192;
+            const double c1 = pairwise_sq_f64(a1 + st, len), c2 = pairwise_sq_f64(a2 + st, len);
+            e1 = st ? __dadd_rn(e1, c1) : c1;
+            e2 = st ? __dadd_rn(e2, c2) : c2;
+        }
+        bits[idx] = e2 > e1;
+    }
+}
+
 // adjust_gain (pyspecsdr.py:898-919), sequential by nature.
 __global__ void k_agc(const float *__restrict__ power, long n, int idx, int n_gains, int *__restrict__ out)
 {
@@ -2019,6 +2065,46 @@ extern "C" int pss_sosfilt(pss_ctx *ctx, const double *d_x, long n_rows, int n, 
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_sosfilt launch");
+}
+
+extern "C" int pss_afsk_n_bits(int n, double fs)
+{
+    const int w = (int)(fs / 1200.0);
+    if (w < 1 || n - w <= 0) return 0;
+    return (n - w + w - 1) / w;  // len(range(0, n - w, w))
+}
+
+extern "C" int pss_afsk_bits(pss_ctx *ctx, const double *d_audio, long n_rows, int n, double fs, const double *sos1200,
+                             const double *sos2200, int nsec, uint8_t *d_bits)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (n_rows < 0 || n < 0 || !(fs >= 1200.0)) return pss_fail(ctx, PSS_E_ARG, "pss_afsk_bits: bad argument");
+    double t1[48], t2[48];
+    if (!sos1200 || !sos2200) {  // design butter(5) band-passes as bandpass_filter does (signal_processing.py:41)
+        const double nyq = fs / 2.0;
+        int r = pss_design_butter_sos(5, 1100.0 / nyq, 1300.0 / nyq, t1, &nsec);
+        if (!r) r = pss_design_butter_sos(5, 2100.0 / nyq, 2300.0 / nyq, t2, &nsec);
+        if (r) return pss_fail(ctx, r, "butter: digital filter critical frequencies must be 0 < Wn < 1");
+        sos1200 = t1; sos2200 = t2;
+    }
+    const int n_bits = pss_afsk_n_bits(n, fs);
+    if (n_rows == 0 || n_bits == 0) return PSS_OK;
+    if (!d_audio || !d_bits) return pss_fail(ctx, PSS_E_ARG, "pss_afsk_bits: null buffer");
+    const size_t szF = align256((size_t)n_rows * n * sizeof(double));
+    int r = pss_ensure_scratch(ctx, 2 * szF);
+    if (r) return r;
+    double *f1 = reinterpret_cast<double *>(ctx->scratch), *f2 = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + szF);
+    pss_time_begin(ctx);
+    r = pss_sosfilt(ctx, d_audio, n_rows, n, sos1200, nsec, f1);
+    if (!r) r = pss_sosfilt(ctx, d_audio, n_rows, n, sos2200, nsec, f2);
+    if (r) { pss_time_end(ctx); return r; }
+    const long total = n_rows * n_bits;
+    pss_kernel_begin(ctx, "k_afsk_bits");
+    hipLaunchKernelGGL(k_afsk_bits, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0,
+                       PSS_STREAM(ctx), f1, f2, n, (int)(fs / 1200.0), n_bits, n_rows, d_bits);
+    pss_kernel_end(ctx);
+    pss_time_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_afsk_bits launch");
 }
 
 extern "C" int pss_set_wfm_filters(pss_ctx *ctx, double fs, const double *lp3x6, const double *pilot5x6, const double *lmr5x6,

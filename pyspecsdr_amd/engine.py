@@ -279,6 +279,15 @@ class Engine:
         sos = np.ascontiguousarray(sos, np.float64)
         self._ck(self.lib.pss_sosfilt(self.h, _ptr(d_x), n_rows, n, _ptr(sos), sos.shape[0], _ptr(d_y)))
 
+    def afsk_bits(self, d_audio, n_rows, n, fs, d_bits, sos1200=None, sos2200=None):
+        c = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)
+        s1, s2 = c(sos1200), c(sos2200)
+        self._ck(self.lib.pss_afsk_bits(self.h, _ptr(d_audio), n_rows, n, float(fs), _ptr(s1), _ptr(s2),
+                                        5 if s1 is None else s1.shape[0], _ptr(d_bits)))
+
+    def afsk_n_bits(self, n, fs):
+        return self.lib.pss_afsk_n_bits(int(n), float(fs))
+
     def h_bandpass_filter(self, data, lowcut, highcut, fs, sos=None):
         x = np.ascontiguousarray(data, np.float64)
         y = np.empty_like(x)

@@ -50,6 +50,7 @@ def lib():
         L.pss_o_gradient_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, C.c_int, _i8p, _i8p]
         L.pss_o_surface_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, _i8p]
         L.pss_o_vector_cells.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _i8p]
+        L.pss_o_afsk_bits.argtypes = [_f64p, C.c_int, C.c_double, _f64p, _f64p, C.c_int, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")]
         L.pss_o_power_db.restype = C.c_float
         L.pss_o_power_db.argtypes = [_f32p, C.c_int]
         L.pss_o_scan_slice.restype = C.c_int
@@ -150,6 +151,14 @@ def vector_cells(iq, max_h, max_w):
     g = np.empty((max_h, max_w), np.int8)
     lib().pss_o_vector_cells(_iq(iq), len(iq), max_h, max_w, g)
     return g
+
+
+def afsk_bits(x, fs, sos1200, sos2200):
+    x = np.ascontiguousarray(x, np.float64)
+    bits = np.empty(max(len(x), 1), np.uint8)
+    c = lambda a: np.ascontiguousarray(a, np.float64)
+    nb = lib().pss_o_afsk_bits(x, len(x), fs, c(sos1200), c(sos2200), 5, bits)
+    return bits[:nb].copy()
 
 
 def power_db(iq):

@@ -580,6 +580,31 @@ def test_empty_batches_and_non_finite_samples(golden):
         assert np.isnan(db[1]).all() and np.isfinite(db[[0, 2, 4]]).all()
 
 
+def test_afsk_bits(golden):
+    """decode_afsk (decoders.py:94-112): the reference's bit lists, and a batch of rows against the oracle."""
+    g = golden["afsk"]
+    e = G.engine()
+    for tag in g["tags"]:
+        x, fs = g[f"x_{tag}"], float(g[f"fs_{tag}"])
+        nb = e.afsk_n_bits(len(x), fs)
+        assert nb == len(g[f"bits_{tag}"])
+        if nb == 0:
+            continue
+        d_bits = G.empty((1, nb), torch.uint8)
+        e.afsk_bits(G.dev(x), 1, len(x), fs, d_bits, g[f"sos1200_{tag}"], g[f"sos2200_{tag}"])
+        e.sync()
+        assert np.array_equal(G.host(d_bits)[0], g[f"bits_{tag}"]), tag
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((70, 5000))
+    nb = e.afsk_n_bits(5000, 22050.0)
+    d_bits = G.empty((70, nb), torch.uint8)
+    e.afsk_bits(G.dev(x), 70, 5000, 22050.0, d_bits, g["sos1200_a"], g["sos2200_a"])
+    e.sync()
+    bits = G.host(d_bits)
+    for r in (0, 63, 64, 69):
+        assert np.array_equal(bits[r], O.afsk_bits(x[r], 22050.0, g["sos1200_a"], g["sos2200_a"])), r
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()

@@ -239,3 +239,12 @@ def test_vector_display_cells(golden):
     g = golden["caller"]
     for tag, hh, ww in (("a", 40, 120), ("b", 25, 81)):
         assert np.array_equal(O.vector_cells(g["vec_iq"], hh, ww), g[f"vec_grid_{tag}"]), tag
+
+
+def test_afsk_bits(golden):
+    """decode_afsk (decoders.py:94-112): the bit list, incl. bit periods longer than one pairwise block and a buffer
+    shorter than a bit period (no bits)."""
+    g = golden["afsk"]
+    for tag in g["tags"]:
+        bits = O.afsk_bits(g[f"x_{tag}"], float(g[f"fs_{tag}"]), g[f"sos1200_{tag}"], g[f"sos2200_{tag}"])
+        assert np.array_equal(bits, g[f"bits_{tag}"]), tag

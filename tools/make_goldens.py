@@ -326,6 +326,29 @@ def gen_bandpass():
     save("bandpass", **d)
 
 
+def gen_afsk():
+    """decode_afsk (decoders.py:94-112): Bell-202 tone energies per bit period -> bit list, on AFSK-like audio."""
+    import decoders
+    d = {}
+    rng = np.random.default_rng(101)
+    cases = [("a", 6000, 22050.0), ("b", 9000, 48000.0), ("c", 30000, 250000.0), ("d", 17, 22050.0)]
+    for tag, n, fs in cases:
+        t = np.arange(n) / fs
+        w = int(fs / 1200)
+        sym = rng.integers(0, 2, size=n // w + 1)[np.arange(n) // w]
+        x = np.where(sym == 1, np.sin(2 * np.pi * 2200 * t), np.sin(2 * np.pi * 1200 * t)) + 0.2 * rng.standard_normal(n)
+        x = x / np.max(np.abs(x))                              # decode_aprs normalises first (decoders.py:126)
+        bits = decoders.decode_afsk(x, fs)
+        d[f"x_{tag}"] = x
+        d[f"fs_{tag}"] = np.array(fs)
+        d[f"bits_{tag}"] = np.array(bits, np.uint8)
+        nyq = fs / 2
+        d[f"sos1200_{tag}"] = ss.butter(5, [1100 / nyq, 1300 / nyq], btype="band", output="sos")
+        d[f"sos2200_{tag}"] = ss.butter(5, [2100 / nyq, 2300 / nyq], btype="band", output="sos")
+    d["tags"] = np.array([c[0] for c in cases])
+    save("afsk", **d)
+
+
 def gen_power():
     d = {}
     frames, pw = [], []
@@ -526,5 +549,6 @@ if __name__ == "__main__":
     gen_iqcorr()
     gen_wfm()
     gen_bandpass()
+    gen_afsk()
     gen_scanner()
     gen_caller()
