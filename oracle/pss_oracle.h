@@ -10,7 +10,7 @@
  * fixtures to NumPy 2.2.6 / SciPy 1.15.3, AVX512_SKX dispatch), the library routine it restates.
  *
  * Parity pin: tests/test_oracle_golden.py checks every function below against
- * tests/golden/*.npz, which tools/make_goldens.py produced by importing the reference itself.
+ * tests/golden/ (npz files), which tools/make_goldens.py produced by importing the reference itself.
  * (The reference ships no tests or golden vectors of its own — SURVEY.md §4.)
  */
 #ifndef PSS_ORACLE_H
