@@ -49,7 +49,7 @@ int pss_device_count(void);
  *   "nfm_fused" (1)            0: lane-per-frame three-kernel NFM path (front, edge, iir) instead of the fused kernels
  *   "wfm_fused" (1)            0: k_wfm_front + lane-per-frame decimator instead of the fused WFM forward kernel
  *   "small_batch" (1)          0: never take the latency-oriented small-batch kernels (one lane per filter section)
- *   "small_batch_max" (16384)  largest NFM frame count that takes them;  "wfm_small_batch_max" (8192) likewise for WFM
+ *   "small_batch_max" (8192)   largest NFM frame count that takes them;  "wfm_small_batch_max" (8192) likewise for WFM
  *   "post_sort_max" (8192)     longest dB row post-processed with the LDS sort (longer rows: radix select)
  *   "fft_split" (-1 = auto)    1 / 0: force / forbid the component-wise LDS exchanges of the register FFT (auto: N = 256) */
 int pss_set_option(pss_ctx *ctx, const char *key, int value);

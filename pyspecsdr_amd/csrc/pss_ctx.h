@@ -51,7 +51,7 @@ struct pss_ctx {
     void *stage = nullptr;         // device staging of the host-buffer convenience calls (grow-only)
     size_t stage_bytes = 0;
     bool no_wfm_fused = false;  // option "wfm_fused" = 0: k_wfm_front + k_nfm_iir path (A/B testing)
-    long small_batch_max = 16384;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~16384)
+    long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~12000)
     long wfm_small_batch_max = 8192;  // option "wfm_small_batch_max" (measured crossover with the fused kernels ~12000 frames)
     int post_sort_max = 8192;  // option "post_sort_max": longest row that takes the LDS bitonic sort, else radix select (measured crossover 8192..16384)
     int fft_split = -1;  // option "fft_split": component-wise LDS exchanges in k_spectrum_r16; -1 = automatic (N = 256 only)

@@ -707,33 +707,36 @@ __global__ __launch_bounds__(64) void k_iir4_sys(const double *__restrict__ in, 
                                                  NfmCoef c, double *__restrict__ out, long out_stride, int q, int n_out,
                                                  double *__restrict__ mxout, long n_rows)
 {
-    __shared__ double ebuf[IS_G][IS_T + 1];
-    __shared__ double ybuf[IS_G + 1][IS_T + 1];  // row IS_G: dump row for the lanes that are not a last section
-    const int lane = threadIdx.x, g = lane >> 2, s = lane & 3;  // 16 frames x 4 sections; DPP rows hold 4 frames each
-    double *const yp = ybuf[s == 3 ? g : IS_G];
+    // Block-systolic: at macro-step m lane (frame g, section s) filters the whole 64-sample block m - s of its frame and
+    // leaves it in LDS for lane (g, s + 1), which filters it one macro-step later.  Inside a block a lane's only
+    // dependent chain is its own state (xn -> a1*xn -> ... -> z0 -> next xn); nothing crosses lanes sample by sample.
+    __shared__ double ebuf[IS_G][IS_T + 1];             // staged input block of section 0
+    __shared__ double xbuf[2][IS_G][3][IS_T + 1];       // block handed from section s to s + 1, double-buffered
+    __shared__ double ybuf[IS_G][IS_T + 1];             // block leaving section 3
+    const int lane = threadIdx.x, g = lane >> 2, s = lane & 3;  // 16 frames x 4 sections
     const long f0 = (long)blockIdx.x * IS_G;
     const long fg = (f0 + g < n_rows) ? f0 + g : n_rows - 1;
     const Biquad cs = c.s[s];
     const double x0 = in[(size_t)fg * in_stride + (backward ? L - 1 : 0)];
-    double z0 = __dmul_rn(c.zi[2 * s], x0), z1 = __dmul_rn(c.zi[2 * s + 1], x0), xprev = 0.0;
+    double z0 = __dmul_rn(c.zi[2 * s], x0), z1 = __dmul_rn(c.zi[2 * s + 1], x0);
     double mxl[IS_G];
     unsigned nanmask = 0;
 #pragma unroll
     for (int gg = 0; gg < IS_G; gg++) mxl[gg] = 0.0;
     double pre[IS_G];
-    auto prefetch = [&](long c0) {
+    const long nblk = (T + IS_T - 1) / IS_T;
+    auto prefetch = [&](long blk) {
 #pragma unroll
         for (int gg = 0; gg < IS_G; gg++) {
-            const long ff = f0 + gg, r = c0 + lane;
+            const long ff = f0 + gg, r = blk * IS_T + lane;
             pre[gg] = (ff < n_rows && r < T) ? in[(size_t)ff * in_stride + (backward ? L - 1 - r : r)] : 0.0;
         }
     };
-    const long TT = T + 3;  // steps incl. drain of the 4-deep pipeline
-    auto writeback = [&](long c0) {  // step c0 + t carries the last section's output for input index c0 + t - 3
+    auto writeback = [&](long blk) {  // ybuf holds block blk of every frame, lane = sample inside the block
 #pragma unroll
         for (int gg = 0; gg < IS_G; gg++) {
-            const long ff = f0 + gg, r = c0 + lane - 3;
-            if (ff < n_rows && r >= 0 && r < T) {
+            const long ff = f0 + gg, r = blk * IS_T + lane;
+            if (ff < n_rows && r < T) {
                 const double v = ybuf[gg][lane];
                 if (!backward) out[(size_t)ff * out_stride + r] = v;
                 else {
@@ -749,55 +752,55 @@ __global__ __launch_bounds__(64) void k_iir4_sys(const double *__restrict__ in, 
             }
         }
     };
+    auto step = [&](double x) {
+        const double xn = __dadd_rn(__dmul_rn(cs.b0, x), z0);
+        z0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, x), __dmul_rn(cs.a1, xn)), z1);
+        z1 = __dsub_rn(__dmul_rn(cs.b2, x), __dmul_rn(cs.a2, xn));
+        return xn;
+    };
     prefetch(0);
-    for (long c0 = 0; c0 < TT; c0 += IS_T) {
+    for (long m = 0; m < nblk + 3; m++) {
+        if (m < nblk) {
 #pragma unroll
-        for (int gg = 0; gg < IS_G; gg++) ebuf[gg][lane] = pre[gg];
-        if (c0 > 0) writeback(c0 - IS_T);
-        if (c0 + IS_T < TT) prefetch(c0 + IS_T);
+            for (int gg = 0; gg < IS_G; gg++) ebuf[gg][lane] = pre[gg];
+        }
+        if (m >= 4) writeback(m - 4);          // section 3 finished block m - 4 in the previous macro-step
+        if (m + 1 < nblk) prefetch(m + 1);
         fused::lds_barrier();
-        const int cnt = (TT - c0) < IS_T ? (int)(TT - c0) : IS_T;
-        auto one = [&](int t, double e, bool gated) {
-            const double from_prev = dpp_row_shr1(xprev);
-            const double x = (s == 0) ? e : from_prev;
-            const double xn = __dadd_rn(__dmul_rn(cs.b0, x), z0);
-            const double n0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, x), __dmul_rn(cs.a1, xn)), z1);
-            const double n1 = __dsub_rn(__dmul_rn(cs.b2, x), __dmul_rn(cs.a2, xn));
-            if (gated) {
-                const bool on = c0 + t >= s;
-                z0 = on ? n0 : z0;
-                z1 = on ? n1 : z1;
-            } else { z0 = n0; z1 = n1; }
-            xprev = xn;
-            yp[t] = xn;
-        };
-        if (c0 == 0 || cnt < IS_T) {  // first chunk (gated start) and the last, partial one: step by step
-            for (int t = 0; t < cnt; t++) one(t, ebuf[g][t], c0 == 0 && t < 4);
-        } else {
-            // straight-line groups of 8 steps: the eight LDS reads of a group are issued together, ahead of the chain
-            for (int t0 = 0; t0 < IS_T; t0 += 8) {
-                double e8[8];
+        const long blk = m - s;
+        if (blk >= 0 && blk < nblk) {
+            const double *src = s == 0 ? ebuf[g] : xbuf[(m - 1) & 1][g][s - 1];
+            double *dst = s == 3 ? ybuf[g] : xbuf[m & 1][g][s];
+            const int cnt = (T - blk * IS_T) < IS_T ? (int)(T - blk * IS_T) : IS_T;
+            if (cnt == IS_T) {
+                for (int t0 = 0; t0 < IS_T; t0 += 8) {
+                    double e8[8], y8[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) e8[k] = ebuf[g][t0 + k];
+                    for (int k = 0; k < 8; k++) e8[k] = src[t0 + k];
 #pragma unroll
-                for (int k = 0; k < 8; k++) one(t0 + k, e8[k], false);
+                    for (int k = 0; k < 8; k++) y8[k] = step(e8[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dst[t0 + k] = y8[k];
+                }
+            } else {
+                for (int t = 0; t < cnt; t++) dst[t] = step(src[t]);
             }
         }
         fused::lds_barrier();
     }
-    writeback(((TT - 1) / IS_T) * IS_T);
+    writeback(nblk - 1);
     if (backward) {
 #pragma unroll
         for (int gg = 0; gg < IS_G; gg++) {
-            double m = mxl[gg];
+            double mm = mxl[gg];
             int nn = (nanmask >> gg) & 1;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
-                const double o = __shfl_xor(m, off);
-                m = o > m ? o : m;
+                const double o = __shfl_xor(mm, off);
+                mm = o > mm ? o : mm;
                 nn |= __shfl_xor(nn, off);
             }
-            if (lane == 0 && f0 + gg < n_rows) mxout[f0 + gg] = nn ? __builtin_nan("") : m;
+            if (lane == 0 && f0 + gg < n_rows) mxout[f0 + gg] = nn ? __builtin_nan("") : mm;
         }
     }
 }

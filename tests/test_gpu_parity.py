@@ -128,7 +128,7 @@ def test_nfm_vs_golden_bit_exact(golden, tag):
     fs = float(g[f"fs_{tag}"])
     e = G.engine()
     e.set_nfm_filters(fs, g[f"taps_{tag}"], g[f"sos_{tag}"], g[f"zi_{tag}"])  # SciPy's own coefficients
-    for small_batch in (1, 0):   # systolic small-batch path (default for <= 16384 frames) and the fused large-batch kernels
+    for small_batch in (1, 0):   # systolic small-batch path (default for <= 8192 frames) and the fused large-batch kernels
         e.set_option("small_batch", small_batch)
         try:
             pcm, audio = G.demod(L.MODE_NFM, g[f"iq_{tag}"], fs)
