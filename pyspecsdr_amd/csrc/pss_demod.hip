@@ -441,9 +441,9 @@ __global__ __launch_bounds__(TILE) void k_am_iir(const float *__restrict__ env, 
 // ---------------------------------------------------------------------------------------------------
 // AM band-pass for SMALL batches: with lane = frame (k_am_iir) a batch of F frames keeps only F/64 wavefronts busy
 // (BASELINE cfg 3: 8192 frames = 128 waves on a 1024-SIMD part).  Here the five sections of one frame sit in five
-// adjacent lanes and the recurrence runs as a systolic array: at step t lane (g, s) works on sample t-s and hands its
-// output to lane (g, s+1) with one DPP row shift.  A wavefront carries 12 frames (4 DPP rows x 3 frames x 5 lanes,
-// lane 15 of every row idle) -> 5.3x more wavefronts, each step a 5-deep dependent chain instead of 45 instructions.
+// adjacent lanes and the recurrence runs as a block-systolic array: lane (g, s) filters 64-sample blocks and hands each
+// to lane (g, s+1) through LDS.  A wavefront carries 12 frames (60 lanes) -> 5.3x more wavefronts than lane = frame,
+// each step one section's state update instead of 45 instructions.
 // Every section still executes exactly biquad_step()'s operations on exactly its own sample sequence (zero initial
 // state, filled and drained with zeros), so the output bits are those of k_am_iir.
 // ---------------------------------------------------------------------------------------------------
@@ -461,48 +461,42 @@ __global__ __launch_bounds__(64) void k_am_sys(const float *__restrict__ env, co
                                                double *__restrict__ Yf, double *__restrict__ mxout, int n,
                                                long n_frames, AmCoef c)
 {
-    __shared__ double ebuf[SYS_G][SYS_T + 1];
-    __shared__ double ybuf[SYS_G + 1][SYS_T + 1];  // row SYS_G: dump row for the lanes that are not a last section
-    const int lane = threadIdx.x, row = lane >> 4, r = lane & 15;
-    const int g3 = r / 5, s = r - 5 * g3;           // r = 15 -> g3 = 3 (idle lane)
-    const bool active = r < 15;
-    const int g = active ? row * 3 + g3 : 0;
+    // Block-systolic (see k_iir4_sys): at macro-step m lane (frame g, section s) filters the whole 64-sample block m - s
+    // and leaves it in LDS, in place, for lane (g, s + 1).  12 frames x 5 sections per wavefront (4 lanes idle).
+    __shared__ double ebuf[SYS_G][SYS_T + 1];                  // envelope - mean, the input block of section 0
+    __shared__ double xbuf[SYS_G][AM_NS - 1][SYS_T + 1];       // block handed from section s to s + 1 (in place)
+    __shared__ double ybuf[SYS_G][SYS_T + 1];                  // block leaving the last section
+    const int lane = threadIdx.x;
+    const int g = lane / AM_NS, s = lane - AM_NS * g;          // lanes 60..63: g = 12 -> idle
+    const bool lane_on = g < SYS_G;
     const long f0 = (long)blockIdx.x * SYS_G;
     Biquad cs = c.s[0];
 #pragma unroll
     for (int k = 1; k < AM_NS; k++)
         if (s == k) cs = c.s[k];
-    double z0 = 0.0, z1 = 0.0, xprev = 0.0;
-    const long T = (long)n + AM_NS - 1;
-    const bool last = active && s == AM_NS - 1;
-    double *const yp = ybuf[last ? g : SYS_G];  // every lane stores every step, no branch in the chain (a shared dump
-                                                // row measured faster than private dump slots)
+    double z0 = 0.0, z1 = 0.0;
     // peak tracking happens where the outputs are written back (lane = time there): mxl[gg] = max over this lane's samples
     double mxl[SYS_G];
-    bool nanl = false;
 #pragma unroll
     for (int gg = 0; gg < SYS_G; gg++) mxl[gg] = 0.0;
-    float pre[SYS_G];  // |x| of the next chunk (SYS_G frame rows, one sample per lane), loaded while the current one runs
+    float pre[SYS_G];  // |x| of the next block (SYS_G frame rows, one sample per lane), loaded while the current one runs
     float mus[SYS_G];
 #pragma unroll
     for (int gg = 0; gg < SYS_G; gg++) mus[gg] = (f0 + gg < n_frames) ? mu[f0 + gg] : 0.0f;
-    auto prefetch = [&](long c0) {
+    const long nblk = ((long)n + SYS_T - 1) / SYS_T;
+    auto prefetch = [&](long blk) {
 #pragma unroll
         for (int gg = 0; gg < SYS_G; gg++) {
-            const long ff = f0 + gg;
-            const long i = c0 + lane;
+            const long ff = f0 + gg, i = blk * SYS_T + lane;
             pre[gg] = (ff < n_frames && i < n) ? env[(size_t)ff * n + i] : 0.0f;
         }
     };
     unsigned nanmask = 0;  // bit gg: a NaN was seen in frame gg by this lane
-    // write back the chunk that started at step c0: step t carries the last section's output for sample c0 + t - 4
-    auto writeback = [&](long c0) {
-        const int cnt = (T - c0) < SYS_T ? (int)(T - c0) : SYS_T;
+    auto writeback = [&](long blk) {  // ybuf holds block blk of every frame, lane = sample inside the block
 #pragma unroll
         for (int gg = 0; gg < SYS_G; gg++) {
-            const long ff = f0 + gg;
-            const long i = c0 + lane - (AM_NS - 1);
-            if (ff < n_frames && lane < cnt && i >= 0 && i < n) {
+            const long ff = f0 + gg, i = blk * SYS_T + lane;
+            if (ff < n_frames && i < n) {
                 const double v = ybuf[gg][lane];
                 Yf[(size_t)ff * n + i] = v;
                 const double av = fabs(v);
@@ -511,59 +505,68 @@ __global__ __launch_bounds__(64) void k_am_sys(const float *__restrict__ env, co
             }
         }
     };
+    auto step = [&](double x) {
+        const double xn = __dadd_rn(__dmul_rn(cs.b0, x), z0);
+        z0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, x), __dmul_rn(cs.a1, xn)), z1);
+        z1 = __dsub_rn(__dmul_rn(cs.b2, x), __dmul_rn(cs.a2, xn));
+        return xn;
+    };
     prefetch(0);
-    for (long c0 = 0; c0 < T; c0 += SYS_T) {
-        // envelope - mean of SYS_G frames x SYS_T samples; then the previous chunk's outputs go out, so that their stores
-        // are a whole chain old when the next wait on the prefetched loads (an in-order vmcnt) comes around
+    for (long m = 0; m < nblk + AM_NS - 1; m++) {
+        if (m < nblk) {
 #pragma unroll
-        for (int gg = 0; gg < SYS_G; gg++) {
-            const long ff = f0 + gg;
-            double e = 0.0;
-            if (ff < n_frames && c0 + lane < n) e = (double)__fsub_rn(pre[gg], mus[gg]);  // float32 subtract (:185)
-            ebuf[gg][lane] = e;
+            for (int gg = 0; gg < SYS_G; gg++) {
+                const long ff = f0 + gg;
+                double e = 0.0;
+                if (ff < n_frames && m * SYS_T + lane < n) e = (double)__fsub_rn(pre[gg], mus[gg]);  // float32 subtract (:185)
+                ebuf[gg][lane] = e;
+            }
         }
-        if (c0 > 0) writeback(c0 - SYS_T);
-        if (c0 + SYS_T < T) prefetch(c0 + SYS_T);
+        if (m >= AM_NS) writeback(m - AM_NS);   // the last section finished block m - 5 in the previous macro-step
+        if (m + 1 < nblk) prefetch(m + 1);
         fused::lds_barrier();
-        const int cnt = (T - c0) < SYS_T ? (int)(T - c0) : SYS_T;
-        auto one = [&](int t, double e) {
-            const double from_prev = dpp_row_shr1(xprev);
-            const double x = (s == 0) ? e : from_prev;
-            const double xn = __dadd_rn(__dmul_rn(cs.b0, x), z0);
-            z0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, x), __dmul_rn(cs.a1, xn)), z1);
-            z1 = __dsub_rn(__dmul_rn(cs.b2, x), __dmul_rn(cs.a2, xn));
-            xprev = xn;
-            yp[t] = xn;
-        };
-        if (cnt == SYS_T) {
-            // straight-line groups of 8 steps: the eight LDS reads of a group are issued together, ahead of the chain
-            for (int t0 = 0; t0 < SYS_T; t0 += 8) {
-                double e8[8];
+        const long blk = m - s;
+        const bool active = lane_on && blk >= 0 && blk < nblk;
+        const int gi = lane_on ? g : 0;
+        const double *src = s == 0 ? ebuf[gi] : xbuf[gi][s > 0 ? s - 1 : 0];
+        double *dst = s == AM_NS - 1 ? ybuf[gi] : xbuf[gi][s < AM_NS - 1 ? s : 0];
+        const int cnt = !active ? 0 : ((n - blk * SYS_T) < SYS_T ? (int)(n - blk * SYS_T) : SYS_T);
+        if (__all(!active || cnt == SYS_T)) {  // one code path per macro-step for the whole wavefront (in-place hand-off)
+            if (active) {
+                for (int t0 = 0; t0 < SYS_T; t0 += 8) {
+                    double e8[8], y8[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) e8[k] = ebuf[g][t0 + k];
+                    for (int k = 0; k < 8; k++) e8[k] = src[t0 + k];
 #pragma unroll
-                for (int k = 0; k < 8; k++) one(t0 + k, e8[k]);
+                    for (int k = 0; k < 8; k++) y8[k] = step(e8[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dst[t0 + k] = y8[k];
+                }
             }
         } else {
-            for (int t = 0; t < cnt; t++) one(t, ebuf[g][t]);
+            for (int t = 0; t < SYS_T; t++) {
+                if (t < cnt) {
+                    const double e = src[t];
+                    dst[t] = step(e);
+                }
+            }
         }
         fused::lds_barrier();
     }
-    writeback(((T - 1) / SYS_T) * SYS_T);
+    writeback(nblk - 1);
     // per-frame peak: max over the 64 lanes (np.max propagates NaN)
 #pragma unroll
     for (int gg = 0; gg < SYS_G; gg++) {
-        double m = mxl[gg];
+        double mm = mxl[gg];
         int nn = (nanmask >> gg) & 1;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const double o = __shfl_xor(m, off);
-            m = o > m ? o : m;
+            const double o = __shfl_xor(mm, off);
+            mm = o > mm ? o : mm;
             nn |= __shfl_xor(nn, off);
         }
-        if (lane == 0 && f0 + gg < n_frames) mxout[f0 + gg] = nn ? __builtin_nan("") : m;
+        if (lane == 0 && f0 + gg < n_frames) mxout[f0 + gg] = nn ? __builtin_nan("") : mm;
     }
-    (void)nanl;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -711,7 +714,10 @@ __global__ __launch_bounds__(64) void k_iir4_sys(const double *__restrict__ in, 
     // leaves it in LDS for lane (g, s + 1), which filters it one macro-step later.  Inside a block a lane's only
     // dependent chain is its own state (xn -> a1*xn -> ... -> z0 -> next xn); nothing crosses lanes sample by sample.
     __shared__ double ebuf[IS_G][IS_T + 1];             // staged input block of section 0
-    __shared__ double xbuf[2][IS_G][3][IS_T + 1];       // block handed from section s to s + 1, double-buffered
+    // block handed from section s to s + 1, IN PLACE: within a group of 8 steps every lane first reads its 8 inputs, then
+    // writes its 8 outputs, and a wavefront's LDS operations execute in program order — so lane s overwrites positions
+    // t0..t0+7 of its row only after lane s + 1 has read them (the previous block), and never touches t0 + 8... early
+    __shared__ double xbuf[IS_G][3][IS_T + 1];
     __shared__ double ybuf[IS_G][IS_T + 1];             // block leaving section 3
     const int lane = threadIdx.x, g = lane >> 2, s = lane & 3;  // 16 frames x 4 sections
     const long f0 = (long)blockIdx.x * IS_G;
@@ -768,11 +774,13 @@ __global__ __launch_bounds__(64) void k_iir4_sys(const double *__restrict__ in, 
         if (m + 1 < nblk) prefetch(m + 1);
         fused::lds_barrier();
         const long blk = m - s;
-        if (blk >= 0 && blk < nblk) {
-            const double *src = s == 0 ? ebuf[g] : xbuf[(m - 1) & 1][g][s - 1];
-            double *dst = s == 3 ? ybuf[g] : xbuf[m & 1][g][s];
-            const int cnt = (T - blk * IS_T) < IS_T ? (int)(T - blk * IS_T) : IS_T;
-            if (cnt == IS_T) {
+        const bool active = blk >= 0 && blk < nblk;
+        const double *src = s == 0 ? ebuf[g] : xbuf[g][s > 0 ? s - 1 : 0];
+        double *dst = s == 3 ? ybuf[g] : xbuf[g][s];
+        const int cnt = !active ? 0 : ((T - blk * IS_T) < IS_T ? (int)(T - blk * IS_T) : IS_T);
+        // all lanes must walk the block in lockstep for the in-place hand-off: one code path per macro-step, chosen wave-wide
+        if (__all(!active || cnt == IS_T)) {
+            if (active) {
                 for (int t0 = 0; t0 < IS_T; t0 += 8) {
                     double e8[8], y8[8];
 #pragma unroll
@@ -782,8 +790,13 @@ __global__ __launch_bounds__(64) void k_iir4_sys(const double *__restrict__ in, 
 #pragma unroll
                     for (int k = 0; k < 8; k++) dst[t0 + k] = y8[k];
                 }
-            } else {
-                for (int t = 0; t < cnt; t++) dst[t] = step(src[t]);
+            }
+        } else {
+            for (int t = 0; t < IS_T; t++) {  // a partial block somewhere: masked steps, read-then-write per position
+                if (t < cnt) {
+                    const double e = src[t];
+                    dst[t] = step(e);
+                }
             }
         }
         fused::lds_barrier();
