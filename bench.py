@@ -55,7 +55,7 @@ def traffic_of(kernel, n_frames):
 
 
 def valu_busy_of(kernel):
-    """VALU busy fraction of `kernel` from the committed SQ-counter profile (profiles/r01f_sq_counters_bench.txt, digested
+    """VALU busy fraction of `kernel` from the committed SQ-counter profile (profiles/r01g_sq_counters_bench.txt, digested
     into profiles/hbm_traffic_r01.json); None if absent.  Says how close an issue-bound kernel is to ITS roof."""
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_r01.json")))[kernel].get("valu_busy_frac")
