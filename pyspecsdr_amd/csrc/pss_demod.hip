@@ -840,8 +840,27 @@ __global__ __launch_bounds__(TPB) void k_finalize(const double *__restrict__ Yf,
 // has numpy's bits.  The frame (8 KB at n=1024) is re-read from L1/L2 per pass; intermediates are recomputed.
 struct PlanDev {
     const int *leaf_off, *leaf_len, *node_l, *node_r, *level_start, *roots;
-    int n_leaves, n_levels, n_roots;
+    int n_leaves, n_levels, n_roots, n_nodes;
 };
+// The plan tables are walked with DEPENDENT loads several times per reduction (offsets -> elements, one round per tree
+// level): read from global memory that was ~8 us per pass and dominated k_iqcorr (8 passes per frame).  Every workgroup
+// copies the tables it needs into LDS once and works from there.
+__device__ __forceinline__ int plan_ints(const PlanDev &p)
+{
+    return p.n_leaves ? 2 * p.n_leaves + 2 * p.n_nodes + (p.n_levels + 1) + p.n_roots : 0;
+}
+__device__ __forceinline__ void plan_to_lds(PlanDev &p, int *&cur)
+{
+    if (!p.n_leaves) return;
+    const int tid = threadIdx.x, T = blockDim.x;
+    int *lo = cur, *ll = lo + p.n_leaves, *nl = ll + p.n_leaves, *nr = nl + p.n_nodes, *ls = nr + p.n_nodes, *rt = ls + p.n_levels + 1;
+    for (int i = tid; i < p.n_leaves; i += T) { lo[i] = p.leaf_off[i]; ll[i] = p.leaf_len[i]; }
+    for (int i = tid; i < p.n_nodes; i += T) { nl[i] = p.node_l[i]; nr[i] = p.node_r[i]; }
+    for (int i = tid; i <= p.n_levels; i += T) ls[i] = p.level_start[i];
+    for (int i = tid; i < p.n_roots; i += T) rt[i] = p.roots[i];
+    p.leaf_off = lo; p.leaf_len = ll; p.node_l = nl; p.node_r = nr; p.level_start = ls; p.roots = rt;
+    cur = rt + p.n_roots;
+}
 // A frame is reduced in GROUPS of up to RED_K ufunc chunks (8192 elements each): numpy adds the chunk sums sequentially,
 // sum = ((S0 + S1) + S2) + ..., so a group's plan is a forest (one pairwise tree per chunk) whose roots are added in
 // order onto the running sum.  Frames up to RED_K chunks are one (tail) group; longer ones loop over full groups first —
@@ -992,10 +1011,16 @@ __device__ __forceinline__ float2 frame_csum(const RedPlan &rp, float2 *part, fl
 // LDS first measured 2-3x slower: fewer resident workgroups, one more barrier).  LDS: [part: 8 floats per leaf][val]
 template <int KIND>
 __global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq, int n, long n_frames, RedPlan rp,
-                                                  int part_slots, float *__restrict__ out, float *__restrict__ env)
+                                                  int part_slots, int val_slots, float *__restrict__ out, float *__restrict__ env)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *part = reinterpret_cast<float *>(smem), *val = part + part_slots;
+    {
+        int *cur = reinterpret_cast<int *>(val + val_slots);
+        plan_to_lds(rp.full, cur);
+        plan_to_lds(rp.tail, cur);
+        __syncthreads();
+    }
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const float2 *x = iq + (size_t)f * n;
         const float sum = frame_rsum(rp, part, val, [&](int i) {
@@ -1015,12 +1040,20 @@ __global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq,
 // LDS: [frame: n float2 if STAGED][part: part_slots float2][val: val_slots float2]
 template <bool STAGED>
 __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, int n, long n_frames, RedPlan rp, RedPlan cp,
-                                                int part_slots, float2 *__restrict__ out, float *__restrict__ raw)
+                                                int part_slots, int val_slots, float2 *__restrict__ out, float *__restrict__ raw)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *xs = reinterpret_cast<float2 *>(smem);
     float2 *cpart = xs + (STAGED ? n : 0), *cval = cpart + part_slots;
     float *rpart = reinterpret_cast<float *>(cpart), *rval = reinterpret_cast<float *>(cval);
+    {
+        int *cur = reinterpret_cast<int *>(cval + val_slots);
+        plan_to_lds(rp.full, cur);
+        plan_to_lds(rp.tail, cur);
+        plan_to_lds(cp.full, cur);
+        plan_to_lds(cp.tail, cur);
+        __syncthreads();
+    }
     const float fn = (float)n;
     const int T = blockDim.x;
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
@@ -1520,12 +1553,20 @@ int get_plan(pss_ctx *ctx, int len, PssPairwisePlan **out, bool cplx = false)
 
 PlanDev plan_dev(const PssPairwisePlan *p)
 {
-    if (!p) return PlanDev{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    if (!p) return PlanDev{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     return PlanDev{p->d_leaf_off, p->d_leaf_len, p->d_node_l, p->d_node_r, p->d_level_start, p->d_roots, p->n_leaves, p->n_levels,
-                   p->n_roots};
+                   p->n_roots, p->n_nodes};
 }
 
 // Group decomposition of a frame of n elements; slots = the largest (leaves, leaves + nodes + 1) over its group plans.
+size_t plan_lds_bytes(const RedPlan &rp)
+{
+    size_t ints = 0;
+    for (const PlanDev *p : {&rp.full, &rp.tail})
+        if (p->n_leaves) ints += (size_t)2 * p->n_leaves + 2 * p->n_nodes + (p->n_levels + 1) + p->n_roots;
+    return ints * sizeof(int);
+}
+
 int get_red_plan(pss_ctx *ctx, int n, bool cplx, RedPlan *rp, int *max_leaves, int *max_vals)
 {
     const int glen = RED_K * 8192;
@@ -1556,17 +1597,17 @@ int launch_pairwise(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float
     int r = get_red_plan(ctx, n, false, &rp, &leaves, &vals);
     if (r) return r;
     const int part_slots = 8 * leaves;
-    const size_t lds = sizeof(float) * (size_t)(part_slots + vals);
+    const size_t lds = sizeof(float) * (size_t)(part_slots + vals) + plan_lds_bytes(rp);
     auto kern = k_pairwise<KIND>;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
     const int lanes = 8 * leaves;  // one lane per (leaf, accumulator) pair
     const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);
-    long g = n_frames < 65536 ? n_frames : 65536;
+    long g = n_frames < 8192 ? n_frames : 8192;  // several frames per workgroup: the plan tables are copied to LDS once
     pss_kernel_begin(ctx, "k_pairwise");
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, rp,
-                       part_slots, d_out, d_env);
+                       part_slots, vals, d_out, d_env);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_pairwise launch");
 }
@@ -1659,18 +1700,18 @@ extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames,
     size_t val_slots = (size_t)(rv > cv ? rv : cv);
     // staging pays while >= 2 workgroups fit a CU (measured: 0.59 vs 0.91 ms at 65536 x 1024, but 2.6 vs 1.8 ms at 8192 x 16384)
     const bool staged = n <= 8192;
-    size_t lds = (part_slots + val_slots + (staged ? (size_t)n : 0)) * sizeof(float2);
+    size_t lds = (part_slots + val_slots + (staged ? (size_t)n : 0)) * sizeof(float2) + plan_lds_bytes(rp) + plan_lds_bytes(cp);
     auto kern = staged ? k_iqcorr<true> : k_iqcorr<false>;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const RedPlan &a = rp, &b = cp;
     const int lanes = rl * 8 > cl * 4 ? rl * 8 : cl * 4;
     const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);  // one lane per (leaf, accumulator) pair
-    long g = n_frames < 65536 ? n_frames : 65536;
+    long g = n_frames < 8192 ? n_frames : 8192;  // several frames per workgroup: the plan tables are copied to LDS once
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_iqcorr");
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, a, b,
-                       (int)part_slots, reinterpret_cast<float2 *>(d_out_iq), d_raw);
+                       (int)part_slots, (int)val_slots, reinterpret_cast<float2 *>(d_out_iq), d_raw);
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_iqcorr launch");
