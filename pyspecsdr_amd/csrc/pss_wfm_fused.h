@@ -11,8 +11,8 @@
 //  * SciPy's odd extension needs u[1..27] before the first filter step and u[M-28..M-2] after the last: the last 28
 //    outputs of both channels live in an LDS ring ([slot][channel][lane], conflict-free), the decimator is primed
 //    from it at step 27 and flushed from it after the last step;
-//  * all filter coefficients are moved to VGPRs once (one wave per SIMD: 512 VGPRs to spend), which keeps the ~100
-//    64-bit constants out of the SGPR file (102 SGPRs) and its spill traffic.
+//  * ~50 filter coefficients are live in the loop: the Butterworth sets stay scalar operands, the decimator set is
+//    pinned in VGPRs (all-scalar spilled the 102-entry SGPR file, all-vector pushed filter state into AGPRs).
 #pragma once
 
 namespace wfmf {
@@ -69,14 +69,17 @@ __global__ __launch_bounds__(TILE) void k_wfm_fwd(const float2 *__restrict__ iq,
     const long L = (long)M + 2 * EDGE;
     double *YL = Y + (size_t)(2 * tile) * L * TILE + lane, *YR = YL + (size_t)L * TILE;
 
+    // ~50 coefficients are live in the loop: the three Butterworth sets (40 doubles) stay scalar (SGPR operands), the
+    // decimator set is pinned in VGPRs — all in SGPRs spilled the scalar file, all in VGPRs pushed state into AGPRs
     BqV lp[3], pil[5], lmr[5], dec[4];
+    auto as_is = [](const Biquad &c) { return BqV{c.b0, c.b1, c.b2, c.a1, c.a2}; };
 #pragma unroll
-    for (int s = 0; s < 3; s++) lp[s] = to_v(wc.lp[s]);
+    for (int s = 0; s < 3; s++) lp[s] = as_is(wc.lp[s]);
 #pragma unroll
-    for (int s = 0; s < 5; s++) { pil[s] = to_v(wc.pil[s]); lmr[s] = to_v(wc.lmr[s]); }
+    for (int s = 0; s < 5; s++) { pil[s] = as_is(wc.pil[s]); lmr[s] = as_is(wc.lmr[s]); }
 #pragma unroll
     for (int s = 0; s < 4; s++) dec[s] = to_v(dc.s[s]);
-    const double b0d = vreg(wc.b0d), a1d = vreg(wc.a1d);
+    const double b0d = wc.b0d, a1d = wc.a1d;
 
     double zlp[6] = {0, 0, 0, 0, 0, 0}, zl2[6] = {0, 0, 0, 0, 0, 0};
     double zpi[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, zlm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
