@@ -114,3 +114,25 @@ def test_ssb_taps_design(golden):
         fs = float(g[f"ssb_fs_{tag}"])
         assert L.load().pss_design_firwin(65, 3000 / fs, taps.ctypes.data) == 0
         assert ulps(taps, g[f"ssb_taps_{tag}"]) <= 16
+
+
+def test_formats_host_side(tmp_path):
+    """The byte formats either side of the path (no GPU involved): np.save'd IQ recordings cut into read buffers
+    (pyspecsdr.py:814-824, :2236), WAV header fields of audio_processing.py:25-43, FIFO bytes of io_manager.py:23-27."""
+    import wave
+    from pyspecsdr_amd import formats
+    rec = (np.arange(2500) + 1j * np.arange(2500)[::-1]).astype(np.complex64)
+    p = str(tmp_path / "rec.npy")
+    np.save(p, rec)
+    s = formats.load_iq_recording(p)
+    assert s.dtype == np.complex64 and np.array_equal(s, rec)
+    fr = formats.cut_frames(s, 1024)
+    assert fr.shape == (2, 1024) and np.array_equal(fr[1], rec[1024:2048])        # incomplete tail buffer dropped
+    with pytest.raises(ValueError):
+        np.save(p, np.zeros((3, 4), np.float32)); formats.load_iq_recording(p)
+    pcm = (np.arange(40, dtype=np.int16) - 20).reshape(10, 2)
+    w = str(tmp_path / "a.wav")
+    formats.write_wav(w, pcm)
+    with wave.open(w, "rb") as f:
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (2, 2, 22050, 10)
+        assert f.readframes(10) == pcm.tobytes() == formats.pipe_bytes(pcm)
