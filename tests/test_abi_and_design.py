@@ -130,7 +130,7 @@ def test_formats_host_side(tmp_path):
     assert fr.shape == (2, 1024) and np.array_equal(fr[1], rec[1024:2048])        # incomplete tail buffer dropped
     with pytest.raises(ValueError):
         np.save(p, np.zeros((3, 4), np.float32)); formats.load_iq_recording(p)
-    pcm = (np.arange(40, dtype=np.int16) - 20).reshape(10, 2)
+    pcm = (np.arange(20, dtype=np.int16) - 10).reshape(10, 2)
     w = str(tmp_path / "a.wav")
     formats.write_wav(w, pcm)
     with wave.open(w, "rb") as f:
