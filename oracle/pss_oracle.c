@@ -190,8 +190,10 @@ static void csum_f32(const float *x, long n, float *rr, float *ri) /* n complex 
         *rr += cr; *ri += ci;
     }
 }
-/* np.var(complex64 array) -> float32 (numpy _methods._var): mean = add.reduce / n (true_divide), x = arr - mean,
- * x = (x * conj(x)).real  [AVX512F complex multiply: re = fma(xr, xr, xi*xi)], ret = add.reduce(x) / n. */
+/* np.var(complex64 array) -> float32 (numpy _methods._var): mean = add.reduce / n (true_divide), x = arr - mean, then the
+ * fast path for built-in complex types: view as float pairs, square every float, add the two squares (three separately
+ * rounded float32 operations, no fused multiply-add), ret = add.reduce(.) / n.  (Found by fuzzing against the reference:
+ * fma(xr, xr, xi*xi) — the complex-multiply form — agrees on ~92 % of frames only.) */
 static float var_c64(const float *z, long n, float *tmp)
 {
     float sr, si;
@@ -199,7 +201,7 @@ static float var_c64(const float *z, long n, float *tmp)
     const float mr = sr / (float)n, mi = si / (float)n;
     for (long i = 0; i < n; i++) {
         const float dr = z[2 * i] - mr, di = z[2 * i + 1] - mi;
-        tmp[i] = fmaf(dr, dr, di * di);
+        tmp[i] = (dr * dr) + (di * di);
     }
     return pss_o_pairwise_sum_f32(tmp, n) / (float)n;
 }

@@ -1066,13 +1066,13 @@ __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, i
         // :48 centered = samples - mean(samples)
         float2 s = frame_csum(cp, cpart, cval, X);
         const float mr = __fdiv_rn(s.x, fn), mi = __fdiv_rn(s.y, fn);
-        // :49 input_power = var(centered): mean again, |.|^2 with the FMA form of numpy's complex multiply, mean
+        // :49 input_power = var(centered): mean again, re^2 + im^2 as three separately rounded float32 operations, mean
         s = frame_csum(cp, cpart, cval, [&](int i) { float2 v = X(i); return make_float2(__fsub_rn(v.x, mr), __fsub_rn(v.y, mi)); });
         const float m2r = __fdiv_rn(s.x, fn), m2i = __fdiv_rn(s.y, fn);
         const float input_power = __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) {
             float2 v = X(i);
             const float dr = __fsub_rn(__fsub_rn(v.x, mr), m2r), di = __fsub_rn(__fsub_rn(v.y, mi), m2i);
-            return __fmaf_rn(dr, dr, __fmul_rn(di, di));
+            return __fadd_rn(__fmul_rn(dr, dr), __fmul_rn(di, di));  // np.var fast path: squares, then add (no fma)
         }), fn);
         // :52 q_amplitude
         const float qa = sqrtf(__fmul_rn(2.0f, __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) { float q = X(i).y; return __fmul_rn(q, q); }), fn)));
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, i
         const float v2 = __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) {
             float2 c = corrected(i);
             const float dr = __fsub_rn(c.x, m3r), di = __fsub_rn(c.y, m3i);
-            return __fmaf_rn(dr, dr, __fmul_rn(di, di));
+            return __fadd_rn(__fmul_rn(dr, dr), __fmul_rn(di, di));  // np.var fast path: squares, then add (no fma)
         }), fn);
         const float g = sqrtf(__fdiv_rn(input_power, v2));
         for (int i = threadIdx.x; i < n; i += T) {

@@ -284,6 +284,12 @@ def test_iq_correction_and_raw_bit_exact(golden):
         got = G.host(d_out).reshape(-1).view(np.complex64)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), n
         assert np.array_equal(G.host(d_raw).view(np.uint32), want.real.copy().view(np.uint32)), n
+    fz = g["iq_fuzz"]
+    d_out = G.empty(fz.shape + (2,), torch.float32)
+    e.iq_correction(G.dev(fz), fz.shape[0], fz.shape[1], d_out, None)
+    e.sync()
+    got = G.host(d_out).reshape(fz.shape[0], -1).view(np.complex64)
+    assert np.array_equal(got.view(np.uint32), g["corr_fuzz"].view(np.uint32))
     import pyspecsdr_amd.signal_processing as sp
     raw = sp.demodulate_signal(g["iq_1000"], 2.4e6, "RAW")
     assert raw.dtype == np.float32 and np.array_equal(raw.view(np.uint32), g["raw_1000"].view(np.uint32))

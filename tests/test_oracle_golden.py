@@ -181,6 +181,8 @@ def test_iq_correction_bit_exact(golden):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), n
         if n != "u8":
             assert np.array_equal(got.real.view(np.uint32), g[f"raw_{n}"].view(np.uint32)), n
+    for k, f in enumerate(g["iq_fuzz"]):
+        assert np.array_equal(O.iq_correction(f).view(np.uint32), g["corr_fuzz"][k].view(np.uint32)), k
 
 
 def wfm_filters(g, fs):

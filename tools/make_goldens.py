@@ -253,6 +253,25 @@ def gen_iqcorr():
     x[40] = complex(-0.0, -0.0)
     d["iq_u8"] = x
     d["corr_u8"] = sp.iq_correction(x)
+    # a batch of assorted random frames (fuzzing against the reference showed that single cases hide 1-ulp differences in
+    # np.var's |x|^2: ~8 % of frames are sensitive to its exact form)
+    fz = []
+    for k in range(48):
+        m = 257
+        kind = k % 4
+        if kind == 0:
+            v = rng.uniform(0.05, 2.0) * np.exp(1j * np.cumsum(rng.standard_normal(m) * rng.uniform(0.01, 0.5)))
+        elif kind == 1:
+            v = rng.standard_normal(m) + 1j * rng.standard_normal(m)
+        elif kind == 2:
+            u = rng.integers(0, 256, size=(m, 2))
+            v = ((u[:, 0] - 127.5) / 127.5) + 1j * ((u[:, 1] - 127.5) / 127.5)
+        else:
+            v = 0.3 * np.exp(2j * np.pi * rng.uniform(-0.4, 0.4) * np.arange(m)) + 0.01 * (rng.standard_normal(m) + 1j * rng.standard_normal(m))
+        fz.append(v.astype(np.complex64))
+    fz = np.stack(fz)
+    d["iq_fuzz"] = fz
+    d["corr_fuzz"] = np.stack([sp.iq_correction(f) for f in fz])
     d["sizes"] = np.array(sizes)
     save("iqcorr", **d)
 
