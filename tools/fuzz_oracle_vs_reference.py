@@ -22,8 +22,8 @@ def rnd_iq(n):
     return x.astype(np.complex64)
 bad=0; cnt={'nfm':0,'am':0,'wfm':0,'iqc':0,'pow':0}
 rates=[2.4e6,1.024e6,2.048e6,250e3,3.2e6,10e6]
-for it in range(240):
-    n=int(rng.choice([29,30,64,100,257,1000,1024,2048,4097,8192,16384,20000,33000]))
+for it in range(int(os.environ.get("FUZZ_N", "240"))):
+    n=int(rng.choice(eval(os.environ.get("FUZZ_SIZES", "[29,30,64,100,257,1000,1024,2048,4097,8192,16384,20000,33000]"))))
     fs=float(rng.choice(rates)); x=rnd_iq(n); q=int(fs/22050)
     # NFM
     taps=ss.firwin(65,15000/(fs/2)); sos=ss.cheby1(8,0.05,0.8/q,output='sos'); zi=ss.sosfilt_zi(sos)
