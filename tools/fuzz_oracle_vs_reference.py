@@ -7,7 +7,7 @@ import sys, warnings; sys.path.insert(0,'/root/reference'); import os; sys.path.
 import numpy as np, signal_processing as sp, scipy.signal as ss
 import oracle_lib as O
 warnings.simplefilter('ignore')
-rng=np.random.default_rng(2026)
+rng=np.random.default_rng(int(os.environ.get("FUZZ_SEED", "2026")))
 def rnd_iq(n):
     kind=rng.integers(0,4)
     if kind==0:
