@@ -611,6 +611,37 @@ def test_afsk_bits(golden):
         assert np.array_equal(bits[r], O.afsk_bits(x[r], 22050.0, g["sos1200_a"], g["sos2200_a"])), r
 
 
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/pss_example.c: the library used from C alone (no Python / torch in the process) gives what the shim gives."""
+    import math, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pss_example")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "pss_example.c"),
+                    "-L" + os.path.join(root, "pyspecsdr_amd"), "-lpss", "-lm", "-o", exe], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, "pyspecsdr_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe, "1024", "2400000"], check=True, capture_output=True, text=True, env=env, timeout=120).stdout.split("\n")
+    head = out[0].split()
+    n, fs = 1024, 2.4e6
+    ph = 0.0
+    iq = np.empty(n, np.complex64)
+    for i in range(n):
+        ph += 2.0 * math.pi * 5e3 * math.sin(2.0 * math.pi * 1000.0 * i / fs) / fs
+        iq[i] = np.float32(0.5 * math.cos(ph)) + 1j * np.float32(0.5 * math.sin(ph))
+    import pyspecsdr_amd.signal_processing as sp
+    db = sp.compute_fft(iq)
+    assert int(head[3]) == 10 and int(head[7]) == int(np.argmax(db))
+    assert abs(float(head[9]) - float(db.max())) < 1e-5 and abs(float(head[5]) - float(sp.measure_signal_power(iq))) < 1e-5
+    sp.USE_SCIPY_DESIGNS, keep = False, sp.USE_SCIPY_DESIGNS     # the C program uses the library's native designers
+    try:
+        from pyspecsdr_amd.engine import Engine
+        e2 = Engine(0)
+        _, pcm = e2.h_demodulate(L.MODE_NFM, iq, fs)
+        e2.close()
+    finally:
+        sp.USE_SCIPY_DESIGNS = keep
+    assert [int(v) for v in out[1].split()[1:]] == [int(v) for v in pcm[:, 0]]
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()
