@@ -27,6 +27,9 @@ constexpr int NB = 4;          // window blocks
 constexpr int WCOLS = NB * FC; // 96 window columns: logical column l <-> time 24 c - 8 + l at chunk c
 constexpr int WSTR = 97;       // float row stride (odd: conflict-free for lane = frame at a fixed column)
 constexpr int HEAD = 64;       // outputs produced by the prologue
+constexpr int NFW = 3;         // FIR worker waves (4 x 6 outputs in 5-wave workgroups measured slower: 0.89 vs 0.67 ms)
+constexpr int OPT = FC / NFW;  // FIR outputs per worker thread and chunk
+constexpr int WG = 64 * (1 + NFW);
 constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double) + 72 * sizeof(double);
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence that also waits for every
@@ -79,11 +82,12 @@ __device__ __forceinline__ double pipe_step(const NfmCoef &c, Iir4 &st, double x
 // row inside logical block b.  Four outputs at a time keeps the accumulators at 16 doubles (the kernel must fit
 // the 128-VGPR budget of 4 waves/SIMD).
 constexpr int FBH = 4;
+static_assert(FC % NFW == 0 && OPT % FBH == 0 && OPT <= 8, "chunk / worker split");
 template <int J, int H>
-__device__ __forceinline__ void fir_batch(const float *const (&blk)[NB], const double *__restrict__ yrev, double (&out)[8])
+__device__ __forceinline__ void fir_batch(const float *const (&blk)[NB], const double *__restrict__ yrev, double (&out)[OPT])
 {
     auto x = [&](int cc) {
-        const int l = 8 + 8 * J + FBH * H + cc;
+        const int l = 8 + OPT * J + FBH * H + cc;
         return (double)blk[l / FC][l % FC];
     };
     double s[FBH][4];
@@ -120,19 +124,16 @@ __device__ __forceinline__ void fir_batch(const float *const (&blk)[NB], const d
     }
 }
 
-template <int J, class Put>
-__device__ __forceinline__ void for_halves(const float *const (&blk)[NB], const double *__restrict__ yrev, double (&out)[8], Put put)
+template <int J, int H = 0, class Put>
+__device__ __forceinline__ void for_halves(const float *const (&blk)[NB], const double *__restrict__ yrev, double (&out)[OPT], Put put)
 {
-    fir_batch<J, 0>(blk, yrev, out);
-    put(out, 0);
-    if constexpr (FBH == 4) {
-        fir_batch<J, 1>(blk, yrev, out);
-        put(out, 1);
-    }
+    fir_batch<J, H>(blk, yrev, out);
+    put(out, H);
+    if constexpr ((H + 1) * FBH < OPT) for_halves<J, H + 1>(blk, yrev, out, put);
 }
 
 template <bool B121>
-__global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
+__global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
                                                     double *__restrict__ Uh, double *__restrict__ Utl, int n,
                                                     long n_frames, NfmCoef c, float kscale, int swapped, TapsArg taps)
 {
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
 #define YAT(p) Yt[(size_t)(p) * TILE]
     if (tid < 65) ltaps[tid] = taps.fwd[tid];
     // ---- prologue: discriminator of times 0..87 into logical columns 8..95 (physical = logical at chunk 0)
-    for (int idx = tid; idx < TILE * WCOLS; idx += 256) {
+    for (int idx = tid; idx < TILE * WCOLS; idx += WG) {
         const int fl = idx / WCOLS, l = idx % WCOLS, t = l - 8;
         const long ff = tile * TILE + fl;
         const float2 *x = iq + (size_t)(ff < n_frames ? ff : n_frames - 1) * n;
@@ -169,8 +170,7 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
     {
         const float *row0 = win + lane * WSTR + 8;  // time t of this lane's frame at row0[t] (chunk-0 layout)
 #pragma unroll 1
-        for (int e = 0; e < HEAD / 4; e++) {
-            const int i = 4 * e + wave;
+        for (int i = wave; i < HEAD; i += 1 + NFW) {
             Uht[(size_t)i * TILE] = ddot_skx_uniform([&](int j) { return (double)row0[j]; },
                                                      [&](int j) { return ltaps[i - j]; }, i + 1);
         }
@@ -242,41 +242,42 @@ __global__ __launch_bounds__(256, 4) void k_nfm_fwd(const float2 *__restrict__ i
         int rot = 0;  // physical block of logical block 0
         for (int ch = 0; ch <= NC; ch++) {
             if (ch < NC) {
-                const int ibase = HEAD + ch * FC + 8 * J;  // first output index of this thread's batch
-                const int tn = HEAD + (ch + 1) * FC + 8 * J;  // time of this thread's first new sample of the next chunk
+                const int ibase = HEAD + ch * FC + OPT * J;  // first output index of this thread's batch
+                const int tn = HEAD + (ch + 1) * FC + OPT * J;  // time of this thread's first new sample of the next chunk
                 const float *blk[NB];
 #pragma unroll
                 for (int b = 0; b < NB; b++) blk[b] = row + ((b + rot) & (NB - 1)) * FC;
-                auto put = [&](const double (&out)[8], int h) {
+                auto put = [&](const double (&out)[OPT], int h) {
 #pragma unroll
                     for (int o = FBH * h; o < FBH * h + FBH; o++) {
                         const int i = ibase + o;
-                        ubuf[(8 * J + o) * TILE + lane] = out[o];
+                        ubuf[(OPT * J + o) * TILE + lane] = out[o];
                         if (i < M && i >= M - 1 - EDGE) Utt[(size_t)(i - (M - 1 - EDGE)) * TILE] = out[o];
                     }
                 };
                 {
-                    double out[8];
+                    double out[OPT];
                     if (J == 0) { for_halves<0>(blk, taps.rev, out, put); }
                     else if (J == 1) { for_halves<1>(blk, taps.rev, out, put); }
-                    else { for_halves<2>(blk, taps.rev, out, put); }
+                    else if (J == 2 || NFW == 3) { for_halves<2>(blk, taps.rev, out, put); }
+                    else { for_halves<NFW - 1>(blk, taps.rev, out, put); }
                 }
                 // discriminator of the next chunk's 8 samples (9 complex); kept in registers until the window block
                 // is free.  The loads are issued after the FIR so they do not occupy registers across it — the other
                 // three waves of the SIMD cover their latency.
-                float dn[8];
+                float dn[OPT];
                 {
-                    float2 pre[9];
+                    float2 pre[OPT + 1];
 #pragma unroll
-                    for (int e = 0; e < 9; e++) pre[e] = (tn + e < n) ? xq[tn + e] : make_float2(0.0f, 0.0f);
+                    for (int e = 0; e <= OPT; e++) pre[e] = (tn + e < n) ? xq[tn + e] : make_float2(0.0f, 0.0f);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) dn[e] = (tn + e < M) ? disc_sample(pre[e + 1], pre[e], kscale, swapped != 0) : 0.0f;
+                    for (int e = 0; e < OPT; e++) dn[e] = (tn + e < M) ? disc_sample(pre[e + 1], pre[e], kscale, swapped != 0) : 0.0f;
                 }
                 lds_barrier();  // A
                 // the oldest block (logical 0) becomes the newest (logical 3 of the next chunk)
-                float *nb = row + rot * FC + 8 * J;
+                float *nb = row + rot * FC + OPT * J;
 #pragma unroll
-                for (int e = 0; e < 8; e++) nb[e] = dn[e];
+                for (int e = 0; e < OPT; e++) nb[e] = dn[e];
                 rot = (rot + 1) & (NB - 1);
                 lds_barrier();  // B
             } else {
