@@ -226,6 +226,10 @@ float pss_last_kernel_ms(pss_ctx *ctx);
 /* Per-kernel durations, "name=ms;name=ms;...", one entry per kernel launch since timing was enabled or since the
  * previous pss_kernel_times() call (HIP events around each launch on the context's stream). */
 int pss_kernel_times(pss_ctx *ctx, char *buf, int buf_len);
+/* Restrict the per-kernel events to launches of ONE kernel (the name pss_kernel_times reports, e.g. "k_nfm_fwd") and
+ * drop the per-call events: every event is a barrier packet in the queue (~4 us), which a throughput measurement over
+ * many launches should not pay for kernels it is not reporting.  NULL or "" = every kernel (the default). */
+int pss_timing_filter(pss_ctx *ctx, const char *kernel);
 
 #ifdef __cplusplus
 }

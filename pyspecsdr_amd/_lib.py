@@ -74,6 +74,7 @@ _SIGS = {
     "pss_enable_timing": (C.c_int, [_p, C.c_int]),
     "pss_last_kernel_ms": (C.c_float, [_p]),
     "pss_kernel_times": (C.c_int, [_p, C.c_char_p, C.c_int]),
+    "pss_timing_filter": (C.c_int, [_p, C.c_char_p]),
 }
 
 _lib = None

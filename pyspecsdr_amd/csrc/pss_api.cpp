@@ -47,11 +47,13 @@ int pss_ensure_scratch(pss_ctx *ctx, size_t bytes)
 
 void pss_time_begin(pss_ctx *ctx)
 {
-    if (ctx->timing && ctx->tdepth++ == 0) hipEventRecord(ctx->ev0, ctx->stream);
+    if (ctx->timing && ctx->tdepth++ == 0 && ctx->tfilter.empty()) hipEventRecord(ctx->ev0, ctx->stream);
 }
 void pss_kernel_begin(pss_ctx *ctx, const char *name)
 {
     if (!ctx->timing) return;
+    ctx->kskip = !ctx->tfilter.empty() && ctx->tfilter != name;
+    if (ctx->kskip) return;
     if (ctx->kused == (int)ctx->krecs.size()) {
         pss_ctx::KRec r{name, nullptr, nullptr};
         hipEventCreate(&r.e0);
@@ -63,13 +65,16 @@ void pss_kernel_begin(pss_ctx *ctx, const char *name)
 }
 void pss_kernel_end(pss_ctx *ctx)
 {
-    if (!ctx->timing) return;
+    if (!ctx->timing || ctx->kskip) return;
     hipEventRecord(ctx->krecs[ctx->kused].e1, PSS_STREAM(ctx));
     ctx->kused++;
 }
 void pss_time_end(pss_ctx *ctx)
 {
-    if (ctx->timing && --ctx->tdepth == 0) { hipEventRecord(ctx->ev1, ctx->stream); ctx->last_ms = 0.0f; }
+    if (ctx->timing && --ctx->tdepth == 0) {
+        if (ctx->tfilter.empty()) hipEventRecord(ctx->ev1, ctx->stream);
+        ctx->last_ms = 0.0f;
+    }
 }
 
 extern "C" int pss_device_count(void)
@@ -173,9 +178,18 @@ extern "C" int pss_enable_timing(pss_ctx *ctx, int on)
     return PSS_OK;
 }
 
+extern "C" int pss_timing_filter(pss_ctx *ctx, const char *kernel)
+{
+    if (!ctx) return PSS_E_ARG;
+    ctx->tfilter = kernel ? kernel : "";
+    ctx->kused = 0;
+    ctx->last_ms = -1.0f;
+    return PSS_OK;
+}
+
 extern "C" float pss_last_kernel_ms(pss_ctx *ctx)
 {
-    if (!ctx || !ctx->timing || ctx->last_ms < 0.0f) return -1.0f;
+    if (!ctx || !ctx->timing || ctx->last_ms < 0.0f || !ctx->tfilter.empty()) return -1.0f;
     if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
     float ms = -1.0f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
@@ -188,7 +202,8 @@ extern "C" int pss_kernel_times(pss_ctx *ctx, char *buf, int buf_len)
     if (!ctx || !buf || buf_len < 1) return PSS_E_ARG;
     std::string out;
     if (ctx->timing && ctx->last_ms >= 0.0f) {
-        hipEventSynchronize(ctx->ev1);
+        if (ctx->tfilter.empty()) hipEventSynchronize(ctx->ev1);
+        else hipStreamSynchronize(ctx->stream);
         for (int i = 0; i < ctx->kused; i++) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, ctx->krecs[i].e0, ctx->krecs[i].e1) != hipSuccess) continue;

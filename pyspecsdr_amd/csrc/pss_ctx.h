@@ -58,6 +58,8 @@ struct pss_ctx {
     bool no_small_batch = false;  // option "small_batch" = 0: never take the systolic small-batch NFM path (A/B testing)
     bool no_fused = false;  // PSS_NO_FUSED=1: use the three-kernel NFM path (A/B and fallback testing)
     bool timing = false;
+    std::string tfilter;  // pss_timing_filter: only launches of this kernel get events (and no per-call events); empty = all
+    bool kskip = false;
     int tdepth = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = -1.0f;

@@ -70,6 +70,10 @@ class Engine:
     def enable_timing(self, on=True):
         self._ck(self.lib.pss_enable_timing(self.h, int(on)))
 
+    def timing_filter(self, kernel=None):
+        """Only launches of `kernel` are bracketed with events (None = every kernel)."""
+        self._ck(self.lib.pss_timing_filter(self.h, kernel.encode() if kernel else None))
+
     def last_kernel_ms(self):
         return float(self.lib.pss_last_kernel_ms(self.h))
 

@@ -611,6 +611,40 @@ def test_afsk_bits(golden):
         assert np.array_equal(bits[r], O.afsk_bits(x[r], 22050.0, g["sos1200_a"], g["sos2200_a"])), r
 
 
+def test_kernel_timing_and_filter():
+    """pss_kernel_times lists every launch; pss_timing_filter keeps one kernel's events only; results do not change."""
+    eng = G.engine()
+    nf, n, fs = 128, 1024, 2.4e6
+    rng = np.random.default_rng(5)
+    iq = torch.from_numpy((rng.standard_normal((nf, n, 2)) * 0.3).astype(np.float32)).cuda()
+    db = torch.empty((nf, n), dtype=torch.float32, device="cuda")
+    pcm = torch.empty((nf, eng.demod_out_len(L.MODE_NFM, n, fs), 2), dtype=torch.int16, device="cuda")
+    eng.set_option("small_batch", 0)
+    try:
+        eng.spectrum_nfm(iq, nf, n, fs, db, pcm); eng.sync()
+        want = (db.clone(), pcm.clone())
+        eng.enable_timing(True)
+        eng.spectrum_nfm(iq, nf, n, fs, db, pcm); eng.sync()
+        every = eng.kernel_times()
+        assert {"k_nfm_fwd", "k_nfm_bwd", "k_spectrum"} <= set(every) and all(v[0] > 0 for v in every.values())
+        assert eng.last_kernel_ms() > 0
+        eng.timing_filter("k_nfm_fwd")
+        for _ in range(3):
+            eng.spectrum_nfm(iq, nf, n, fs, db, pcm)
+        eng.sync()
+        only = eng.kernel_times()
+        assert list(only) == ["k_nfm_fwd"] and len(only["k_nfm_fwd"]) == 3 and min(only["k_nfm_fwd"]) > 0
+        assert eng.last_kernel_ms() < 0
+        eng.timing_filter(None)
+        eng.spectrum_nfm(iq, nf, n, fs, db, pcm); eng.sync()
+        assert set(eng.kernel_times()) == set(every)
+        assert torch.equal(db, want[0]) and torch.equal(pcm, want[1])
+    finally:
+        eng.timing_filter(None)
+        eng.enable_timing(False)
+        eng.set_option("small_batch", 1)
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """examples/pss_example.c: the library used from C alone (no Python / torch in the process) gives what the shim gives."""
     import math, os, subprocess
