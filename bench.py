@@ -171,7 +171,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     live = eng.kernel_times().get(dom, [])
-    assert len(live) == args.steps, (dom, len(live))
+    assert len(live) >= args.steps and len(live) % args.steps == 0, (dom, len(live))   # some kernels launch twice a step
     ktimes[dom] = sum(live) / len(live)   # mean launch duration over the K timed steps
     eng.timing_filter(None)
     # outside the timed region: the spectrum kernel alone (inside a step it overlaps the backward IIR pass on a side
