@@ -85,6 +85,12 @@ void pss_o_gradient_cells(const double *rows, int n_rows, int len, int disp_h, i
 /* surface plot — pyspecsdr.py:1567-1616: colour[max_h][max_w] over the whole screen, 0 = empty, else pair 1..5 ('#'). */
 void pss_o_surface_cells(const double *row, int len, int max_h, int max_w, int8_t *colour);
 /* constellation display — pyspecsdr.py:1718-1752: grid[max_h][max_w] = 1 where a sample's dot lands. */
+/* classify_signal (signal_processing.py:296-322 with welch bound to scipy.signal.welch); labels as in the reference */
+enum { PSS_O_CLS_UNKNOWN = 0, PSS_O_CLS_FM_BROADCAST = 1, PSS_O_CLS_NARROW_FM = 2, PSS_O_CLS_AM_BROADCAST = 3, PSS_O_CLS_SSB = 4,
+       PSS_O_CLS_DIGITAL = 5 };
+float pss_o_modulation_index(const float *iq, long n);
+void pss_o_hann1024_f32(float *w);
+int pss_o_classify(const float *iq, long n, double fs, double *bw_out, float *mi_out, float *flat_out, float *psd_out);
 void pss_o_vector_cells(const float *iq, int n, int max_h, int max_w, int8_t *grid);
 /* spectrum display quantiser — draw_spectrogram, pyspecsdr.py:398-498.  row[len] = one post-processed dB row.
  * glyph/colour [disp_h][disp_w]: glyph 0 '.', 1 '-', 2 '=', 3 '#', 4 ' '; colour = curses pair (1 = cleared); -1 = not drawn.

@@ -51,6 +51,9 @@ def lib():
         L.pss_o_surface_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, _i8p]
         L.pss_o_vector_cells.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _i8p]
         L.pss_o_afsk_bits.argtypes = [_f64p, C.c_int, C.c_double, _f64p, _f64p, C.c_int, np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")]
+        L.pss_o_classify.restype = C.c_int
+        L.pss_o_classify.argtypes = [_f32p, C.c_long, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float), _f32p]
+        L.pss_o_hann1024_f32.argtypes = [_f32p]
         L.pss_o_power_db.restype = C.c_float
         L.pss_o_power_db.argtypes = [_f32p, C.c_int]
         L.pss_o_scan_slice.restype = C.c_int
@@ -159,6 +162,25 @@ def afsk_bits(x, fs, sos1200, sos2200):
     c = lambda a: np.ascontiguousarray(a, np.float64)
     nb = lib().pss_o_afsk_bits(x, len(x), fs, c(sos1200), c(sos2200), 5, bits)
     return bits[:nb].copy()
+
+
+CLASS_LABELS = ("UNKNOWN", "FM_BROADCAST", "NARROW_FM", "AM_BROADCAST", "SSB", "DIGITAL")
+
+
+def classify(iq, fs):
+    """-> (label, signal_bw float64, modulation_index float32, spectral_flatness float32, psd float32[1024])."""
+    bw, mi, fl = C.c_double(), C.c_float(), C.c_float()
+    psd = np.empty(1024, np.float32)
+    lab = lib().pss_o_classify(_iq(iq), len(iq), fs, C.byref(bw), C.byref(mi), C.byref(fl), psd)
+    if lab < 0:
+        raise ValueError("classify: fewer than 1024 samples")
+    return CLASS_LABELS[lab], bw.value, np.float32(mi.value), np.float32(fl.value), psd
+
+
+def hann1024():
+    w = np.empty(1024, np.float32)
+    lib().pss_o_hann1024_f32(w)
+    return w
 
 
 def power_db(iq):

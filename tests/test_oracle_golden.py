@@ -250,3 +250,23 @@ def test_afsk_bits(golden):
     for tag in g["tags"]:
         bits = O.afsk_bits(g[f"x_{tag}"], float(g[f"fs_{tag}"]), g[f"sos1200_{tag}"], g[f"sos2200_{tag}"])
         assert np.array_equal(bits, g[f"bits_{tag}"]), tag
+
+
+def test_classify_signal(golden):
+    """classify_signal with `welch` bound: label and bandwidth equal, modulation index bit-exact (float32,
+    restated operation by operation), Welch PSD / flatness within the reference's own float32-FFT noise."""
+    g = golden["classify"]
+    fs = float(g["fs"])
+    assert np.array_equal(O.hann1024(), g["win"])
+    for tag in g["tags"]:
+        lab, bw, mi, fl, psd = O.classify(g[f"iq_{tag}"], fs)
+        assert lab == str(g[f"label_{tag}"]), tag
+        assert bw == float(g[f"bw_{tag}"]), tag
+        rmi = g[f"mi_{tag}"]
+        assert mi.tobytes() == rmi.tobytes() or (np.isnan(mi) and np.isnan(rmi)), (tag, mi, rmi)
+        ref = g[f"psd_{tag}"]
+        assert np.all(np.abs(psd - ref) <= 1e-4 * (ref + 1e-10)), tag          # 1e-4 relative above the 1e-10 floor the features add
+        rfl = float(g[f"flat_{tag}"])
+        assert float(fl) == rfl or abs(float(fl) - rfl) <= 1e-5 * abs(rfl) or (np.isnan(fl) and np.isnan(rfl)), (tag, fl, rfl)
+    with pytest.raises(ValueError):
+        O.classify(np.zeros(1000, np.complex64), fs)

@@ -368,6 +368,51 @@ def gen_afsk():
     save("afsk", **d)
 
 
+def gen_classify():
+    """classify_signal (signal_processing.py:296-322) with its missing import supplied: the module calls `welch` without
+    importing it (NameError on every call in the reference); binding scipy.signal.welch into the module's namespace is the
+    one-line fix SURVEY §8(f) #3 names.  Stored: inputs, the Welch PSD, the three features and the label."""
+    sp.welch = ss.welch
+    fs = 2.4e6
+    rng = np.random.default_rng(202)
+
+    def sig(n, dev, ftone, noise, off=0.0, amp=0.5):
+        t = np.arange(n) / fs
+        ph = 2 * np.pi * dev * np.cumsum(np.sin(2 * np.pi * ftone * t)) / fs + 2 * np.pi * off * t
+        return (amp * np.exp(1j * ph) + noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+
+    d, tags = {}, []
+    for n in (1024, 1500, 2048, 4096, 10000):
+        t = np.arange(n) / fs
+        cases = [("fm75k", sig(n, 75e3, 1e3, 0.01)), ("nfm5k", sig(n, 5e3, 1e3, 0.01)), ("noise", sig(n, 0, 1, 0.1, amp=0)),
+                 ("tone300k", sig(n, 0, 1, 0.001, off=300e3)), ("fmoff", sig(n, 75e3, 5e3, 0.02, off=-450e3)),
+                 ("am", ((1 + 0.5 * np.sin(2 * np.pi * 1e3 * t)) * 0.5 * np.exp(0.3j)).astype(np.complex64) + sig(n, 0, 1, 0.005, amp=0)),
+                 ("wide", sig(n, 400e3, 20e3, 0.01))]
+        for name, x in cases:
+            tags.append(f"{name}_{n}")
+            d[f"iq_{name}_{n}"] = x
+    # a long scanner dwell (pyspecsdr.py:1026: SCAN_DWELL_TIME * fs samples): the float32 cumsum inside np.unwrap grows large
+    tags.append("tone300k_60000"); d["iq_tone300k_60000"] = sig(60000, 0, 1, 0.001, off=300e3)
+    tags.append("silence_2048"); d["iq_silence_2048"] = np.zeros(2048, np.complex64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag in tags:
+            x = d[f"iq_{tag}"]
+            freqs, psd = sp.welch(x, fs=fs, nperseg=1024)
+            assert psd.dtype == np.float32 and freqs.dtype == np.float64
+            d[f"psd_{tag}"] = psd
+            d[f"bw_{tag}"] = np.array(float(sp.estimate_bandwidth(psd, freqs)))
+            d[f"mi_{tag}"] = np.array(sp.estimate_modulation_index(x))
+            d[f"flat_{tag}"] = np.array(np.exp(np.mean(np.log(psd + 1e-10))) / np.mean(psd))
+            d[f"label_{tag}"] = np.array(sp.classify_signal(x, fs, 0.0))
+            assert d[f"mi_{tag}"].dtype == np.float32 and d[f"flat_{tag}"].dtype == np.float32
+    d["win"] = ss.get_window("hann", 1024).astype(np.complex64).real.copy()
+    d["fs"] = np.array(fs)
+    d["tags"] = np.array(tags)
+    del sp.welch
+    save("classify", **d)
+
+
 def gen_power():
     d = {}
     frames, pw = [], []
@@ -569,5 +614,6 @@ if __name__ == "__main__":
     gen_wfm()
     gen_bandpass()
     gen_afsk()
+    gen_classify()
     gen_scanner()
     gen_caller()
