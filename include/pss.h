@@ -161,6 +161,22 @@ int pss_surface_cells_f64(pss_ctx *ctx, const double *d_row, int len, int max_h,
  * one of the n IQ samples lands (float32 arithmetic as in the reference). */
 int pss_vector_cells(pss_ctx *ctx, const float *d_iq, int n, int max_h, int max_w, int8_t *d_grid);
 
+/* classify_signal (signal_processing.py:296-322; helpers estimate_bandwidth :267-280, estimate_modulation_index :283-293) for
+ * a batch of scanner reads, as the function runs once its missing `welch` import is supplied (in the reference it raises
+ * NameError on every call: SURVEY App. C2, §8(f) #3).  d_iq: interleaved complex64 [n_frames][n], n >= 1024 (Welch segments
+ * of 1024 samples every 512; shorter reads would need a non-power-of-two FFT and return PSS_E_ARG).  Outputs (each may be
+ * NULL): d_label int32 [n_frames] (PSS_CLASS_*), d_bw float64 (the "bandwidth" of estimate_bandwidth: last minus first bin
+ * above max - 20 dB in FFT order, in Hz), d_mi float32 (modulation index, bit-exact with NumPy's float32 evaluation),
+ * d_flat float32 (spectral flatness), d_psd float32 [n_frames][1024] (Welch PSD, FFT order).  The segment FFT runs in
+ * float64 (the reference's is single precision): PSD and flatness agree to the reference's own float32 FFT noise. */
+enum { PSS_CLASS_UNKNOWN = 0, PSS_CLASS_FM_BROADCAST = 1, PSS_CLASS_NARROW_FM = 2, PSS_CLASS_AM_BROADCAST = 3, PSS_CLASS_SSB = 4,
+       PSS_CLASS_DIGITAL = 5 };
+int pss_classify(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, int32_t *d_label, double *d_bw, float *d_mi,
+                 float *d_flat, float *d_psd);
+const char *pss_class_name(int label);
+/* One read buffer in host memory (what pyspecsdr.py:1061 / :2560 hand over), synchronous. */
+int pss_h_classify_signal(pss_ctx *ctx, const float *h_iq, int n, double fs, int *label, double *bw, float *mi, float *flat);
+
 /* Same quantisers over float64 rows (the reference's rows are float64; used to check cell-exact parity). */
 int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n_rows, int len, int disp_h, int disp_w,
                             int8_t *d_glyph, int8_t *d_colour);

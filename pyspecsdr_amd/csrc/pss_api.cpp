@@ -125,6 +125,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->scratch_fft) hipFree(ctx->scratch_fft);
     if (ctx->scratch_iqc) hipFree(ctx->scratch_iqc);
+    if (ctx->d_hann) hipFree(ctx->d_hann);
     if (ctx->stage) hipFree(ctx->stage);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
@@ -327,6 +328,33 @@ extern "C" int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float
     if (r) return r;
     PSS_HIP(ctx, hipMemcpyAsync(h_power, base + o_p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSS_OK;
+}
+
+extern "C" int pss_h_classify_signal(pss_ctx *ctx, const float *h_iq, int n, double fs, int *label, double *bw, float *mi, float *flat)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!h_iq || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
+    const size_t o_out = up256(sizeof(float) * 2 * n);
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_out + 256, "staging");
+    if (r) return r;
+    char *base = reinterpret_cast<char *>(ctx->stage);
+    PSS_HIP(ctx, hipMemcpyAsync(base, h_iq, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
+    // results: [bw f64][label i32][mi f32][flat f32]
+    double *d_bw = reinterpret_cast<double *>(base + o_out);
+    int32_t *d_lab = reinterpret_cast<int32_t *>(base + o_out + 8);
+    float *d_mi = reinterpret_cast<float *>(base + o_out + 12), *d_fl = reinterpret_cast<float *>(base + o_out + 16);
+    r = pss_classify(ctx, reinterpret_cast<const float *>(base), 1, n, fs, d_lab, d_bw, d_mi, d_fl, nullptr);
+    if (r) return r;
+    unsigned char res[24];
+    PSS_HIP(ctx, hipMemcpyAsync(res, base + o_out, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+    PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bw) memcpy(bw, res, 8);
+    int32_t lab;
+    memcpy(&lab, res + 8, 4);
+    if (label) *label = lab;
+    if (mi) memcpy(mi, res + 12, 4);
+    if (flat) memcpy(flat, res + 16, 4);
     return PSS_OK;
 }
 

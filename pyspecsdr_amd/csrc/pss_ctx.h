@@ -45,6 +45,8 @@ struct pss_ctx {
     void *scratch = nullptr;       // demodulator scratch (main stream)
     size_t scratch_bytes = 0;
     void *scratch_iqc = nullptr;   // IQ-corrected frames for the WFM dispatcher path
+    float *d_hann = nullptr;       // pss_classify: scipy's periodic Hann window (1024, float32) and sum(win * win)
+    float hann_sum = 0.0f;
     size_t scratch_iqc_bytes = 0;
     void *scratch_fft = nullptr;   // spectrum scratch: separate, the spectrum kernel may run on the side stream
     size_t scratch_fft_bytes = 0;

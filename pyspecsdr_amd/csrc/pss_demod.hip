@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <functional>
 #include <vector>
 
 #include "pss_ctx.h"
@@ -1440,6 +1441,234 @@ __device__ double pairwise_sq_f64(const double *a, int n)
     n2 -= n2 % 8;
     return __dadd_rn(pairwise_sq_f64(a, n2), pairwise_sq_f64(a + n2, n - n2));
 }
+// ---- classify_signal (signal_processing.py:296-322 with `welch` bound to scipy.signal.welch) ----------
+// Two kernels, one workgroup per frame.
+// k_cls_modidx: estimate_modulation_index (:283-293), float32 exactly as NumPy evaluates it: np.abs / np.angle (SVML
+//   atan2f model), np.unwrap's float32 arithmetic — its cumsum is a SEQUENTIAL float32 sum, so one lane walks it, chunk
+//   by chunk through LDS — np.diff, and both np.var's on NumPy's own summation trees (frame_rsum).  The unwrapped phase
+//   goes through a global scratch (float32 [frame][n]).
+// k_cls_welch: Welch PSD (SciPy _spectral_helper: periodic Hann, 1024-sample segments every 512, per-segment mean
+//   removed, two-sided, density scaling, mean over segments) with the segment FFT in float64 (the reference's is
+//   pocketfft float32: its noise, ~1e-7 of the peak bin, is the tolerance of this row), then estimate_bandwidth
+//   (:267-280, bins in FFT order), spectral flatness (:304) and the decision tree (:307-322).
+constexpr int CLS_NP = 1024, CLS_STEP = 512, CLS_CH = 2048;
+
+__device__ __forceinline__ float np_modf32(float a, float b)  // npy_remainderf
+{
+    float m = fmodf(a, b);
+    if (m != 0.0f) { if ((b < 0.0f) != (m < 0.0f)) m = __fadd_rn(m, b); }
+    else m = copysignf(0.0f, b);
+    return m;
+}
+
+// LDS: [part: 8 * leaves floats][val][pbuf: CLS_CH + 1][cbuf: CLS_CH][carry][plans]
+__global__ __launch_bounds__(256) void k_cls_modidx(const float2 *__restrict__ iq, int n, long n_frames, RedPlan rn, RedPlan rm,
+                                                    int part_slots, int val_slots, float *__restrict__ up_all,
+                                                    float *__restrict__ mi_out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *part = reinterpret_cast<float *>(smem), *val = part + part_slots;
+    float *pbuf = val + val_slots, *cbuf = pbuf + CLS_CH + 4, *carry = cbuf + CLS_CH;  // cbuf 16-byte aligned (val_slots % 4 == 0)
+    {
+        int *cur = reinterpret_cast<int *>(carry + 1);
+        plan_to_lds(rn.full, cur);
+        plan_to_lds(rn.tail, cur);
+        plan_to_lds(rm.full, cur);
+        plan_to_lds(rm.tail, cur);
+        __syncthreads();
+    }
+    const int tid = threadIdx.x, T = blockDim.x;
+    const float PI32 = (float)M_PI, TWOPI32 = (float)(2.0 * M_PI), NPI32 = (float)(-M_PI);
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const float2 *x = iq + (size_t)f * n;
+        float *up = up_all + (size_t)f * n;
+        const float fn = (float)n, fm = (float)(n - 1);
+        // :286, :290  np.var(np.abs(samples))
+        auto A = [&](int i) { const float2 v = x[i]; return cabsf_np(v.x, v.y); };
+        const float amean = __fdiv_rn(frame_rsum(rn, part, val, A), fn);
+        const float amp_var = __fdiv_rn(frame_rsum(rn, part, val, [&](int i) { const float d = __fsub_rn(A(i), amean); return __fmul_rn(d, d); }), fn);
+        // :287  np.unwrap(np.angle(samples)) -> up[]
+        if (tid == 0) *carry = 0.0f;
+        for (int base = 0; base < n - 1; base += CLS_CH) {
+            const int cnt = (n - 1 - base) < CLS_CH ? (n - 1 - base) : CLS_CH;
+            for (int j = tid; j <= cnt; j += T) { const float2 v = x[base + j]; pbuf[j] = atan2f_svml(v.y, v.x); }
+            __syncthreads();
+            for (int j = tid; j < cnt; j += T) {
+                const float dd = __fsub_rn(pbuf[j + 1], pbuf[j]);
+                float ddmod = __fadd_rn(np_modf32(__fsub_rn(dd, NPI32), TWOPI32), NPI32);
+                if (ddmod == NPI32 && dd > 0.0f) ddmod = PI32;
+                float corr = __fsub_rn(ddmod, dd);
+                if (fabsf(dd) < PI32) corr = 0.0f;
+                cbuf[j] = corr;
+            }
+            __syncthreads();
+            if (tid == 0) {  // ph_correct.cumsum(): sequential float32
+                float cs = *carry;
+                int j = 0;
+                for (; j + 8 <= cnt; j += 8) {  // wide LDS accesses: the chain is then bound by the 8 dependent adds, not by LDS latency
+                    float4 a = *reinterpret_cast<const float4 *>(cbuf + j), b = *reinterpret_cast<const float4 *>(cbuf + j + 4);
+                    a.x = cs = __fadd_rn(cs, a.x); a.y = cs = __fadd_rn(cs, a.y); a.z = cs = __fadd_rn(cs, a.z); a.w = cs = __fadd_rn(cs, a.w);
+                    b.x = cs = __fadd_rn(cs, b.x); b.y = cs = __fadd_rn(cs, b.y); b.z = cs = __fadd_rn(cs, b.z); b.w = cs = __fadd_rn(cs, b.w);
+                    *reinterpret_cast<float4 *>(cbuf + j) = a;
+                    *reinterpret_cast<float4 *>(cbuf + j + 4) = b;
+                }
+                for (; j < cnt; j++) { cs = __fadd_rn(cs, cbuf[j]); cbuf[j] = cs; }
+                *carry = cs;
+                if (base == 0) up[0] = pbuf[0];
+            }
+            __syncthreads();
+            for (int j = tid; j < cnt; j += T) up[base + j + 1] = __fadd_rn(pbuf[j + 1], cbuf[j]);
+            __syncthreads();
+        }
+        if (n == 1 && tid == 0) { const float2 v = x[0]; up[0] = atan2f_svml(v.y, v.x); }
+        __threadfence_block();
+        __syncthreads();
+        // :291  np.var(np.diff(phase_env))
+        float mi = NAN;  // np.var of an empty array
+        if (n > 1) {
+            auto D = [&](int i) { return __fsub_rn(up[i + 1], up[i]); };
+            const float dmean = __fdiv_rn(frame_rsum(rm, part, val, D), fm);
+            const float phase_var = __fdiv_rn(frame_rsum(rm, part, val, [&](int i) { const float d = __fsub_rn(D(i), dmean); return __fmul_rn(d, d); }), fm);
+            mi = __fdiv_rn(phase_var, __fadd_rn(amp_var, (float)1e-10));  // :293
+        }
+        if (tid == 0) mi_out[f] = mi;
+        __syncthreads();
+    }
+}
+
+// LDS: [buf: 1024 double2][tw: 512 double2][cpart][cval][plan]; psd (float) and the reduction slots alias buf afterwards
+__global__ __launch_bounds__(256) void k_cls_welch(const float2 *__restrict__ iq, int n, long n_frames, double fs, RedPlan cp,
+                                                   int part_slots, int val_slots, const float *__restrict__ win, float scale,
+                                                   const float *__restrict__ mi_in, int32_t *__restrict__ label,
+                                                   double *__restrict__ bw_out, float *__restrict__ flat_out,
+                                                   float *__restrict__ psd_out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *buf = reinterpret_cast<double2 *>(smem), *tw = buf + CLS_NP;
+    float2 *cpart = reinterpret_cast<float2 *>(tw + CLS_NP / 2), *cval = cpart + part_slots;
+    {
+        int *cur = reinterpret_cast<int *>(cval + val_slots);
+        plan_to_lds(cp.full, cur);
+        plan_to_lds(cp.tail, cur);
+    }
+    const int tid = threadIdx.x;
+    for (int k = tid; k < CLS_NP / 2; k += 256) {
+        double sn, cs;
+        sincospi(-2.0 * (double)k / (double)CLS_NP, &sn, &cs);
+        tw[k] = make_double2(cs, sn);
+    }
+    float w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = win[tid + 256 * j];
+    __syncthreads();
+    const long nseg = (n - CLS_NP) / CLS_STEP + 1;
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const float2 *x = iq + (size_t)f * n;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};  // positions tid + 256 j of the bit-reversed spectrum
+        for (long sg = 0; sg < nseg; sg++) {
+            const float2 *xs = x + sg * CLS_STEP;
+            const float2 m = frame_csum(cp, cpart, cval, [&](int i) { return xs[i]; });  // detrend: data - mean(data), complex64
+            const float mr = __fdiv_rn(m.x, (float)CLS_NP), mim = __fdiv_rn(m.y, (float)CLS_NP);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float2 v = xs[tid + 256 * j];
+                buf[tid + 256 * j] = make_double2((double)__fmul_rn(w[j], __fsub_rn(v.x, mr)), (double)__fmul_rn(w[j], __fsub_rn(v.y, mim)));
+            }
+            __syncthreads();
+            // radix-2 decimation in frequency, natural order in, bit-reversed order out
+            for (int st = 9; st >= 0; st--) {
+                const int half = 1 << st;
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int b = tid + 256 * r, grp = b >> st, pos = b & (half - 1);
+                    const int i0 = (grp << (st + 1)) + pos, i1 = i0 + half;
+                    const double2 a = buf[i0], c = buf[i1], t = tw[pos << (9 - st)];
+                    const double dr = a.x - c.x, di = a.y - c.y;
+                    buf[i0] = make_double2(a.x + c.x, a.y + c.y);
+                    buf[i1] = make_double2(dr * t.x - di * t.y, dr * t.y + di * t.x);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const double2 v = buf[tid + 256 * j]; acc[j] += v.x * v.x + v.y * v.y; }
+            __syncthreads();
+        }
+        float *psd = reinterpret_cast<float *>(buf);                    // [1024], FFT order
+        float *dbv = psd + CLS_NP;                                       // [1024]
+        double *red = reinterpret_cast<double *>(dbv + CLS_NP);          // [4][4] wave partials
+        int *redi = reinterpret_cast<int *>(red + 16);                   // [2][4]
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int bin = (int)(__brev((unsigned)(tid + 256 * j)) >> 22);
+            psd[bin] = (float)(acc[j] / (double)nseg * (double)scale);
+        }
+        __syncthreads();
+        // estimate_bandwidth (:267-280): 10 log10(psd + 1e-10), bins above max - 20 dB, first / last in FFT order
+        float mx = -INFINITY;
+        bool nanv = false;
+        double slog = 0.0, spsd = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = tid + 256 * j;
+            const float v = __fadd_rn(psd[k], (float)1e-10);
+            const float d = __fmul_rn(10.0f, (float)log10((double)v));
+            dbv[k] = d;
+            nanv = nanv || (d != d);
+            mx = d > mx ? d : mx;
+            slog += (double)(float)log((double)v);                       // :304 np.log(psd + 1e-10), float32
+            spsd += (double)psd[k];
+            if (psd_out) psd_out[(size_t)f * CLS_NP + k] = psd[k];
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(mx, off);
+            mx = o > mx ? o : mx;
+            nanv = nanv || __shfl_xor((int)nanv, off);
+            slog += __shfl_xor(slog, off);
+            spsd += __shfl_xor(spsd, off);
+        }
+        if ((tid & 63) == 0) { red[tid >> 6] = (double)mx; red[4 + (tid >> 6)] = nanv ? 1.0 : 0.0; red[8 + (tid >> 6)] = slog; red[12 + (tid >> 6)] = spsd; }
+        __syncthreads();
+        mx = (float)fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        nanv = (red[4] + red[5] + red[6] + red[7]) != 0.0;
+        slog = (red[8] + red[9]) + (red[10] + red[11]);
+        spsd = (red[12] + red[13]) + (red[14] + red[15]);
+        const float thr = nanv ? NAN : __fadd_rn(mx, -20.0f);            // np.max propagates NaN: then nothing compares above it
+        int first = CLS_NP, last = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = tid + 256 * j;
+            if (dbv[k] > thr) { first = k < first ? k : first; last = k > last ? k : last; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const int a = __shfl_xor(first, off), b = __shfl_xor(last, off);
+            first = a < first ? a : first;
+            last = b > last ? b : last;
+        }
+        if ((tid & 63) == 0) { redi[tid >> 6] = first; redi[4 + (tid >> 6)] = last; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 0; k < 4; k++) { first = redi[k] < first ? redi[k] : first; last = redi[4 + k] > last ? redi[4 + k] : last; }
+            double bw = 0.0;
+            if (last >= 0) {
+                const double val = 1.0 / ((double)CLS_NP * (1.0 / fs));  // np.fft.fftfreq(n, d) = integers * (1 / (n d))
+                bw = (double)(last < CLS_NP / 2 ? last : last - CLS_NP) * val - (double)(first < CLS_NP / 2 ? first : first - CLS_NP) * val;
+            }
+            const float gm = (float)exp((double)(float)(slog / (double)CLS_NP));
+            const float flat = __fdiv_rn(gm, (float)(spsd / (double)CLS_NP));
+            const float mi = mi_in[f];
+            int lab = PSS_CLASS_UNKNOWN;                                  // :307-322; np.float32 vs Python float compares in float32
+            if (bw > 150e3) lab = mi > 0.8f ? PSS_CLASS_FM_BROADCAST : PSS_CLASS_UNKNOWN;
+            else if (8e3 <= bw && bw <= 16e3) lab = mi < 0.3f ? PSS_CLASS_NARROW_FM : PSS_CLASS_UNKNOWN;
+            else if (2e3 <= bw && bw <= 3e3) lab = flat < 0.2f ? PSS_CLASS_SSB : PSS_CLASS_UNKNOWN;   // (:314 AM_BROADCAST is unreachable)
+            else if (flat > 0.7f) lab = PSS_CLASS_DIGITAL;
+            if (label) label[f] = lab;
+            if (bw_out) bw_out[f] = bw;
+            if (flat_out) flat_out[f] = flat;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_afsk_bits(const double *__restrict__ f1, const double *__restrict__ f2, int n, int w,
                                                    int n_bits, long n_rows, uint8_t *__restrict__ bits)
 {
@@ -2129,6 +2358,82 @@ extern "C" int pss_afsk_n_bits(int n, double fs)
     const int w = (int)(fs / 1200.0);
     if (w < 1 || n - w <= 0) return 0;
     return (n - w + w - 1) / w;  // len(range(0, n - w, w))
+}
+
+extern "C" const char *pss_class_name(int label)
+{
+    static const char *names[] = {"UNKNOWN", "FM_BROADCAST", "NARROW_FM", "AM_BROADCAST", "SSB", "DIGITAL"};
+    return (label >= 0 && label < 6) ? names[label] : "UNKNOWN";
+}
+
+extern "C" int pss_classify(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, int32_t *d_label, double *d_bw,
+                            float *d_mi, float *d_flat, float *d_psd)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (n_frames < 0 || !(fs > 0.0)) return pss_fail(ctx, PSS_E_ARG, "pss_classify: bad argument");
+    if (n < CLS_NP)
+        return pss_fail(ctx, PSS_E_ARG, "pss_classify: fewer than 1024 samples (welch would fall back to nperseg = n, a non-power-of-two FFT)");
+    if (n_frames == 0) return PSS_OK;
+    if (!d_iq) return pss_fail(ctx, PSS_E_ARG, "pss_classify: null input");
+    // Hann window as scipy.signal.get_window('hann', 1024) builds it (general_cosine over np.linspace(-pi, pi, 1025)), cast to
+    // float32; scale = 1 / (fs * sum(win * win)) in complex64 arithmetic with zero imaginary parts
+    if (!ctx->d_hann) {
+        std::vector<float> w(CLS_NP);
+        const double start = -M_PI, step = (M_PI - (-M_PI)) / 1024.0;
+        for (int i = 0; i < CLS_NP; i++) w[i] = (float)(0.5 + 0.5 * cos((double)i * step + start));
+        // (win * win).sum(): complex64 pairwise sum — 2048 floats, below the 8-float unroll threshold nothing special: replay numpy's
+        // tree on the host (blocks of 128 floats, 8 accumulators striding the interleaved array; imaginary lanes are all zero)
+        std::vector<float> z(2 * CLS_NP, 0.0f);
+        for (int i = 0; i < CLS_NP; i++) z[2 * i] = w[i] * w[i];
+        std::function<float(const float *, int)> pw = [&](const float *a, int nn) -> float {  // real part of numpy's pairwise complex sum
+            if (nn <= 128) {
+                float r[8];
+                for (int k = 0; k < 8; k++) r[k] = a[k];
+                int i;
+                for (i = 8; i < nn - (nn % 8); i += 8)
+                    for (int k = 0; k < 8; k++) r[k] += a[i + k];
+                float res = ((r[0] + r[2]) + (r[4] + r[6]));
+                for (; i < nn; i += 2) res += a[i];
+                return res;
+            }
+            int n2 = nn / 2;
+            n2 -= n2 % 8;
+            return pw(a, n2) + pw(a + n2, nn - n2);
+        };
+        ctx->hann_sum = pw(z.data(), 2 * CLS_NP);
+        PSS_HIP(ctx, hipMalloc(&ctx->d_hann, sizeof(float) * CLS_NP));
+        PSS_HIP(ctx, hipMemcpy(ctx->d_hann, w.data(), sizeof(float) * CLS_NP, hipMemcpyHostToDevice));
+    }
+    const float scale = 1.0f / ((float)fs * ctx->hann_sum);
+    RedPlan rn, rm, cp;
+    int l1, v1, l2, v2, lc, vc;
+    int r = get_red_plan(ctx, n, false, &rn, &l1, &v1);
+    if (!r) r = get_red_plan(ctx, n - 1, false, &rm, &l2, &v2);
+    if (!r) r = get_red_plan(ctx, CLS_NP, true, &cp, &lc, &vc);
+    if (r) return r;
+    const size_t szUp = align256((size_t)n_frames * n * sizeof(float)), szMi = align256((size_t)n_frames * sizeof(float));
+    r = pss_ensure_scratch(ctx, szUp + szMi);
+    if (r) return r;
+    float *up = reinterpret_cast<float *>(ctx->scratch);
+    float *mi = d_mi ? d_mi : reinterpret_cast<float *>(reinterpret_cast<char *>(ctx->scratch) + szUp);
+    const int part1 = 8 * (l1 > l2 ? l1 : l2), val1 = ((v1 > v2 ? v1 : v2) + 3) & ~3;
+    const size_t lds1 = sizeof(float) * ((size_t)part1 + val1 + (CLS_CH + 4) + CLS_CH + 1) + plan_lds_bytes(rn) + plan_lds_bytes(rm);
+    if (lds1 > 64 * 1024)
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cls_modidx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    const int partc = 4 * lc;
+    const size_t lds2 = sizeof(double2) * (CLS_NP + CLS_NP / 2) + sizeof(float2) * ((size_t)partc + vc) + plan_lds_bytes(cp);
+    const long g = n_frames < 16384 ? n_frames : 16384;
+    pss_time_begin(ctx);
+    pss_kernel_begin(ctx, "k_cls_modidx");
+    hipLaunchKernelGGL(k_cls_modidx, dim3((unsigned)g), dim3(256), lds1, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n,
+                       n_frames, rn, rm, part1, val1, up, mi);
+    pss_kernel_end(ctx);
+    pss_kernel_begin(ctx, "k_cls_welch");
+    hipLaunchKernelGGL(k_cls_welch, dim3((unsigned)g), dim3(256), lds2, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n,
+                       n_frames, fs, cp, partc, vc, ctx->d_hann, scale, mi, d_label, d_bw, d_flat, d_psd);
+    pss_kernel_end(ctx);
+    pss_time_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "classify launch");
 }
 
 extern "C" int pss_afsk_bits(pss_ctx *ctx, const double *d_audio, long n_rows, int n, double fs, const double *sos1200,

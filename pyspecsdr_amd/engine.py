@@ -177,6 +177,14 @@ class Engine:
     def vector_cells(self, d_iq, n, max_h, max_w, d_grid):
         self._ck(self.lib.pss_vector_cells(self.h, _ptr(d_iq), n, max_h, max_w, _ptr(d_grid)))
 
+    def classify(self, d_iq, n_frames, n, fs, d_label=None, d_bw=None, d_mi=None, d_flat=None, d_psd=None):
+        """classify_signal for a batch (pss_classify): any of label int32 / bw float64 / mi float32 / flat float32 / psd float32 [.,1024]."""
+        self._ck(self.lib.pss_classify(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_label), _ptr(d_bw), _ptr(d_mi),
+                                       _ptr(d_flat), _ptr(d_psd)))
+
+    def class_name(self, label):
+        return self.lib.pss_class_name(int(label)).decode()
+
     def persistence_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_colour, f64=False):
         fn = self.lib.pss_persistence_cells_f64 if f64 else self.lib.pss_persistence_cells
         self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_colour)))
@@ -272,6 +280,13 @@ class Engine:
         out = np.empty(len(iq), np.complex64)
         self._ck(self.lib.pss_h_iq_correction(self.h, _ptr(iq), len(iq), _ptr(out), None))
         return out
+
+    def h_classify_signal(self, iq, fs):
+        """-> (label str, signal_bw float, modulation_index np.float32, spectral_flatness np.float32) for one read buffer."""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        lab, bw, mi, fl = C.c_int(), C.c_double(), C.c_float(), C.c_float()
+        self._ck(self.lib.pss_h_classify_signal(self.h, _ptr(iq), len(iq), float(fs), C.byref(lab), C.byref(bw), C.byref(mi), C.byref(fl)))
+        return self.class_name(lab.value), bw.value, np.float32(mi.value), np.float32(fl.value)
 
     def h_raw(self, iq):
         iq = np.ascontiguousarray(iq, np.complex64)

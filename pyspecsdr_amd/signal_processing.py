@@ -14,7 +14,8 @@ the reference's main loop imports with `from signal_processing import *` (pyspec
 
     iq_correction(samples)                                 :46-80    -> complex64 (N,)  ('RAW' mode = its real part)
     bandpass_filter(data, lowcut, highcut, sample_rate)    :34-42    -> float64 (N,)   (decoders.py:100-101)
-    classify_signal(samples, sample_rate, bandwidth)       :296-322  -> NameError, as in the reference (App. C2)
+    classify_signal(samples, sample_rate, bandwidth)       :296-322  -> label str (the reference raises NameError: see the function)
+    estimate_modulation_index(samples)                     :283-293  -> np.float32
 
 Every call runs on the GPU through the C ABI; there is no NumPy/SciPy compute path here.
 """
@@ -104,10 +105,36 @@ def bandpass_filter(data, lowcut, highcut, sample_rate):
     return get_engine().h_bandpass_filter(d, lowcut, highcut, sample_rate, sos)
 
 
+# signal_processing.py:296-322 calls `welch`, which the module never imports: in the reference the function
+# raises NameError on every call (swallowed by the scanner's try/except, pyspecsdr.py:2571).  By default this module runs
+# the function as it is written, i.e. as it behaves once `from scipy.signal import welch` is added; set
+# CLASSIFY_RAISES_NAMEERROR = True to get the reference's present behaviour instead.
+CLASSIFY_RAISES_NAMEERROR = False
+
+
+def classify_signal_features(samples, sample_rate):
+    """-> (label, signal_bw, modulation_index, spectral_flatness): the label of classify_signal and the three numbers it
+    is decided on (estimate_bandwidth :267-280, estimate_modulation_index :283-293, flatness :304)."""
+    x = _samples(samples)
+    if len(x) < 1024:
+        raise ValueError("classify_signal: fewer than 1024 samples (Welch segments of 1024 samples are not shortened here)")
+    return get_engine().h_classify_signal(x, sample_rate)
+
+
 def classify_signal(samples, sample_rate, bandwidth):
-    """signal_processing.py:296-322 calls `welch`, which the module never imports: in the reference this
-    function raises NameError on every call (swallowed by the scanner's try/except, pyspecsdr.py:2571).  Same here."""
-    raise NameError("name 'welch' is not defined")
+    """signal_processing.py:296-322 -> 'FM_BROADCAST' | 'NARROW_FM' | 'AM_BROADCAST' | 'SSB' | 'DIGITAL' | 'UNKNOWN'
+    (`bandwidth` is unused, as in the reference)."""
+    if CLASSIFY_RAISES_NAMEERROR:
+        raise NameError("name 'welch' is not defined")
+    return classify_signal_features(samples, sample_rate)[0]
+
+
+def estimate_modulation_index(samples):
+    """signal_processing.py:283-293 -> np.float32, bit-exact with NumPy's float32 evaluation."""
+    x = _samples(samples)
+    if len(x) < 1024:
+        raise ValueError("estimate_modulation_index: fewer than 1024 samples")
+    return get_engine().h_classify_signal(x, 1.0)[2]
 
 
 def iq_correction(samples):

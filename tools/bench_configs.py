@@ -126,6 +126,19 @@ def wfm():
             "samples_per_s": nf * n / (out[1]["wall_ms"] * 1e-3)}
 
 
+def classify():
+    """classify_signal over a scanner sweep: cfg-4-sized slices (8192 x 4096) and the reference's own dwell (64 x 240 000)."""
+    out = []
+    for nf, n in ((8192, 4096), (64, 240000)):
+        iq = rand_iq(nf, n)
+        lab = torch.empty((nf,), dtype=torch.int32, device=dev)
+        bw = torch.empty((nf,), dtype=torch.float64, device=dev)
+        mi = torch.empty((nf,), dtype=torch.float32, device=dev)
+        fl = torch.empty((nf,), dtype=torch.float32, device=dev)
+        out.append(timed(f"classify {n} x{nf}", lambda: eng.classify(iq, nf, n, 2.4e6, lab, bw, mi, fl, None), reps=3))
+    return {"config": "classify_signal (Welch PSD + modulation index + flatness + label)", "calls": out}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5"]
     for w in which:
