@@ -636,7 +636,7 @@ def test_classify_signal(golden):
         e.classify(G.dev(iq.view(np.float32).reshape(1, n, 2)), 1, n, fs, d_label=d_lab, d_psd=d_psd)
         e.sync()
         psd, ref = d_psd.cpu().numpy()[0], g[f"psd_{tag}"]
-        assert np.all(np.abs(psd - ref) <= 1e-4 * (ref + 1e-10)), tag
+        assert np.all(np.abs(psd - ref) <= 1e-5 * (ref + 1e-10) + 1e-6 * np.sqrt(ref * np.max(ref))), tag   # float32-FFT noise of the reference: ~1e-7 sqrt(p P_peak)
         olab, obw, omi, ofl, opsd = O.classify(iq, fs)
         assert e.class_name(int(d_lab.cpu()[0])) == olab == lab and obw == bw, tag
         assert omi.tobytes() == mi.tobytes() or (np.isnan(omi) and np.isnan(mi)), tag

@@ -265,7 +265,7 @@ def test_classify_signal(golden):
         rmi = g[f"mi_{tag}"]
         assert mi.tobytes() == rmi.tobytes() or (np.isnan(mi) and np.isnan(rmi)), (tag, mi, rmi)
         ref = g[f"psd_{tag}"]
-        assert np.all(np.abs(psd - ref) <= 1e-4 * (ref + 1e-10)), tag          # 1e-4 relative above the 1e-10 floor the features add
+        assert np.all(np.abs(psd - ref) <= 1e-5 * (ref + 1e-10) + 1e-6 * np.sqrt(ref * np.max(ref))), tag   # float32-FFT noise of the reference: ~1e-7 sqrt(p P_peak)
         rfl = float(g[f"flat_{tag}"])
         assert float(fl) == rfl or abs(float(fl) - rfl) <= 1e-5 * abs(rfl) or (np.isnan(fl) and np.isnan(rfl)), (tag, fl, rfl)
     with pytest.raises(ValueError):

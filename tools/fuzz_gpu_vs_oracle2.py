@@ -56,4 +56,21 @@ for it in range(cases):
         b = G.host(d_b)
         for r in (0, nrw - 1):
             if not np.array_equal(b[r], O.afsk_bits(a[r], fs, s1, s2)): bad += 1; print("AFSK", nrw, n, fs, r)
+    # classify_signal: a few reads of a random length (>= 1024), every output against the oracle
+    n = int(rng.choice([1024, 1025, 1536, 2048, 3001, 4096, 9000, 20000])); nf = int(rng.integers(1, 9)); fs = float(rng.choice([2.4e6, 1.024e6, 250e3]))
+    t = np.arange(n) / fs
+    iq = np.empty((nf, n), np.complex64)
+    for f in range(nf):
+        k = int(rng.integers(0, 4)); off = rng.uniform(-0.45, 0.45) * fs; nz = 10.0 ** rng.uniform(-4, -0.7)
+        ph = 2 * np.pi * (0.0, 3e3, 6e4, 2e5)[k] * np.cumsum(np.sin(2 * np.pi * rng.uniform(200, 9e3) * t)) / fs + 2 * np.pi * off * t
+        iq[f] = ((0.0 if k == 0 and f % 2 else 0.5) * np.exp(1j * ph) + nz * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    d_lab, d_bw = G.empty((nf,), torch.int32), G.empty((nf,), torch.float64)
+    d_mi, d_fl, d_psd = G.empty((nf,), torch.float32), G.empty((nf,), torch.float32), G.empty((nf, 1024), torch.float32)
+    e.classify(G.dev(iq.view(np.float32).reshape(nf, n, 2)), nf, n, fs, d_lab, d_bw, d_mi, d_fl, d_psd); e.sync()
+    lab, bw, mi, fl, psd = (G.host(a) for a in (d_lab, d_bw, d_mi, d_fl, d_psd))
+    for f in range(nf):
+        ol, ob, om, of, op = O.classify(iq[f], fs)
+        if not (O.CLASS_LABELS[lab[f]] == ol and bw[f] == ob and mi[f].tobytes() == om.tobytes()
+                and abs(float(fl[f]) - float(of)) <= 1e-5 * abs(float(of)) and np.all(np.abs(psd[f] - op) <= 1e-6 * (op + 1e-10))):
+            bad += 1; print("CLASSIFY", nf, n, fs, f, (O.CLASS_LABELS[lab[f]], ol), (bw[f], ob), (mi[f], om), (fl[f], of))
 print("cases", cases, "bad", bad)
