@@ -161,6 +161,17 @@ int pss_surface_cells_f64(pss_ctx *ctx, const double *d_row, int len, int max_h,
  * one of the n IQ samples lands (float32 arithmetic as in the reference). */
 int pss_vector_cells(pss_ctx *ctx, const float *d_iq, int n, int max_h, int max_w, int8_t *d_grid);
 
+/* decode_morse, front half (decoders.py:149-165): envelope = |x| / max|x| in float32, 20 log10(envelope + 1e-10) > threshold,
+ * and the indices of the rising / falling transitions of that mask (np.diff + np.where), i.e. the arrays rise_times /
+ * fall_times the timing logic of decode_morse (:167 ff., host side: pyspecsdr_amd/decoders.py) starts from.
+ * d_iq: interleaved complex64 [n_frames][n]; d_rise / d_fall: int32 [n_frames][cap], in increasing order; d_counts: int32
+ * [n_frames][2] = the TRUE numbers of rises and falls (entries beyond cap are dropped).  threshold_db must be -20.0, the
+ * value the reference calls it with (pyspecsdr.py:573): the comparison is pinned to NumPy's float32 log10 at that point. */
+int pss_morse_edges(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double threshold_db, int cap, int32_t *d_rise,
+                    int32_t *d_fall, int32_t *d_counts);
+int pss_h_morse_edges(pss_ctx *ctx, const float *h_iq, int n, double threshold_db, int cap, int32_t *h_rise, int32_t *h_fall,
+                      int *n_rise, int *n_fall);
+
 /* classify_signal (signal_processing.py:296-322; helpers estimate_bandwidth :267-280, estimate_modulation_index :283-293) for
  * a batch of scanner reads, as the function runs once its missing `welch` import is supplied (in the reference it raises
  * NameError on every call: SURVEY App. C2, §8(f) #3).  d_iq: interleaved complex64 [n_frames][n], n >= 1024 (Welch segments

@@ -431,6 +431,40 @@ int pss_o_classify(const float *iq, long n, double fs, double *bw_out, float *mi
     return PSS_O_CLS_UNKNOWN;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * decode_morse, front half — decoders.py:149-165 (called with the default threshold = -20 dB, pyspecsdr.py:573):
+ *   envelope = np.abs(samples); envelope /= np.max(envelope); envelope_db = 20*np.log10(envelope + 1e-10)   (float32)
+ *   signals = envelope_db > threshold; transitions = np.diff(signals.astype(int)); rise/fall = where(== +1 / -1)
+ * NumPy's float32 log10 under AVX512_SKX dispatch is SVML's __svml_log10f16.  Only the comparison matters: probing
+ * the reference environment around 0.1 (+-2000 ulp, monotone there) shows 20*log10(v) > -20 exactly for
+ * v >= 0x3dcccccf (SVML returns -1.0 for 0x3dccccce, where a correctly rounded log10f gives -0.99999994).
+ * Returns the number of transitions written is min(count, cap); *n_rise / *n_fall are the true counts.
+ * ---------------------------------------------------------------------------------------------- */
+void pss_o_morse_edges(const float *iq, long n, int32_t *rise, int32_t *fall, long cap, long *n_rise, long *n_fall)
+{
+    const float CUT = u2f(0x3dcccccfu);
+    float mx = -INFINITY;
+    int has_nan = 0;
+    for (long i = 0; i < n; i++) {
+        float e = pss_o_cabsf(iq[2 * i], iq[2 * i + 1]);
+        if (e != e) has_nan = 1;
+        if (e > mx) mx = e;
+    }
+    if (has_nan) mx = NAN;
+    long nr = 0, nf = 0;
+    int prev = 0;
+    for (long i = 0; i < n; i++) {
+        float v = pss_o_cabsf(iq[2 * i], iq[2 * i + 1]) / mx + (float)1e-10;
+        int sgn = v >= CUT; /* false for NaN */
+        if (i > 0) {
+            if (!prev && sgn) { if (nr < cap) rise[nr] = (int32_t)(i - 1); nr++; }
+            if (prev && !sgn) { if (nf < cap) fall[nf] = (int32_t)(i - 1); nf++; }
+        }
+        prev = sgn;
+    }
+    *n_rise = nr; *n_fall = nf;
+}
+
 static int cmp_double(const void *a, const void *b)
 {
     double x = *(const double *)a, y = *(const double *)b;

@@ -331,6 +331,31 @@ extern "C" int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float
     return PSS_OK;
 }
 
+extern "C" int pss_h_morse_edges(pss_ctx *ctx, const float *h_iq, int n, double threshold_db, int cap, int32_t *h_rise,
+                                 int32_t *h_fall, int *n_rise, int *n_fall)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (!h_iq || n < 1 || cap < 0 || (cap > 0 && (!h_rise || !h_fall))) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
+    const size_t o_r = up256(sizeof(float) * 2 * n), o_f = o_r + up256(sizeof(int32_t) * (size_t)cap), o_c = o_f + up256(sizeof(int32_t) * (size_t)cap);
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_c + 256, "staging");
+    if (r) return r;
+    char *base = reinterpret_cast<char *>(ctx->stage);
+    PSS_HIP(ctx, hipMemcpyAsync(base, h_iq, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
+    r = pss_morse_edges(ctx, reinterpret_cast<const float *>(base), 1, n, threshold_db, cap, reinterpret_cast<int32_t *>(base + o_r),
+                        reinterpret_cast<int32_t *>(base + o_f), reinterpret_cast<int32_t *>(base + o_c));
+    if (r) return r;
+    int32_t cnt[2];
+    PSS_HIP(ctx, hipMemcpyAsync(cnt, base + o_c, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int kr = cnt[0] < cap ? cnt[0] : cap, kf = cnt[1] < cap ? cnt[1] : cap;
+    if (kr) PSS_HIP(ctx, hipMemcpyAsync(h_rise, base + o_r, sizeof(int32_t) * kr, hipMemcpyDeviceToHost, ctx->stream));
+    if (kf) PSS_HIP(ctx, hipMemcpyAsync(h_fall, base + o_f, sizeof(int32_t) * kf, hipMemcpyDeviceToHost, ctx->stream));
+    PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_rise) *n_rise = cnt[0];
+    if (n_fall) *n_fall = cnt[1];
+    return PSS_OK;
+}
+
 extern "C" int pss_h_classify_signal(pss_ctx *ctx, const float *h_iq, int n, double fs, int *label, double *bw, float *mi, float *flat)
 {
     if (!ctx) return PSS_E_ARG;

@@ -1669,6 +1669,80 @@ __global__ __launch_bounds__(256) void k_cls_welch(const float2 *__restrict__ iq
     }
 }
 
+// ---- decode_morse, front half (decoders.py:149-165; called with threshold = -20 dB, pyspecsdr.py:573) ---------------------
+// envelope = |x| / max|x| (float32); "20 log10(envelope + 1e-10) > -20" holds exactly for envelope + 1e-10 >= 0x3dcccccf under
+// NumPy's SVML log10f (probed in the reference environment, see oracle/pss_oracle.c); the rise / fall indices of
+// np.diff(signals) are compacted IN ORDER: each wavefront owns a contiguous quarter of the frame, counts its transitions
+// (ballot + popcount), the four totals are scanned, then a second sweep writes them.  One workgroup per frame.
+__global__ __launch_bounds__(256) void k_morse_edges(const float2 *__restrict__ iq, int n, long n_frames, int cap,
+                                                     int32_t *__restrict__ rise, int32_t *__restrict__ fall,
+                                                     int32_t *__restrict__ counts)
+{
+    __shared__ float red[4];
+    __shared__ int rnan[4], cr[4], cf[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float CUT = __uint_as_float(0x3dcccccfu);
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const float2 *x = iq + (size_t)f * n;
+        float mx = -INFINITY;
+        int nanv = 0;
+        for (int i = tid; i < n; i += 256) {
+            const float2 v = x[i];
+            const float e = cabsf_np(v.x, v.y);
+            nanv |= (e != e);
+            mx = e > mx ? e : mx;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(mx, off);
+            mx = o > mx ? o : mx;
+            nanv |= __shfl_xor(nanv, off);
+        }
+        if (lane == 0) { red[wave] = mx; rnan[wave] = nanv; }
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (rnan[0] | rnan[1] | rnan[2] | rnan[3]) mx = NAN;  // np.max propagates NaN: then nothing is above the threshold
+        auto sig = [&](int i) {
+            const float2 v = x[i];
+            return __fadd_rn(__fdiv_rn(cabsf_np(v.x, v.y), mx), (float)1e-10) >= CUT;
+        };
+        const int nt = n - 1;                                   // transitions i = 0 .. n-2 (between samples i and i+1)
+        const int seg = ((nt + 3) / 4 + 63) & ~63;              // per wavefront, a multiple of 64
+        const int lo = wave * seg, hi = (lo + seg) < nt ? (lo + seg) : nt;
+        int32_t *rf = rise + (size_t)f * cap, *ff = fall + (size_t)f * cap;
+        int nr = 0, nf = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            int br = 0, bf = 0;
+            if (pass == 1) {
+                for (int w = 0; w < wave; w++) { br += cr[w]; bf += cf[w]; }
+            }
+            nr = 0; nf = 0;
+            for (int b = lo; b < hi; b += 64) {
+                const int i = b + lane;
+                bool r = false, d = false;
+                if (i < hi) {
+                    const bool s0 = sig(i), s1 = sig(i + 1);
+                    r = !s0 && s1;
+                    d = s0 && !s1;
+                }
+                const unsigned long long mr = __ballot(r), mf = __ballot(d);
+                if (pass == 1) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (r) { const int o = br + nr + __popcll(mr & below); if (o < cap) rf[o] = i; }
+                    if (d) { const int o = bf + nf + __popcll(mf & below); if (o < cap) ff[o] = i; }
+                }
+                nr += __popcll(mr);
+                nf += __popcll(mf);
+            }
+            if (pass == 0) {
+                if (lane == 0) { cr[wave] = nr; cf[wave] = nf; }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) { counts[2 * f] = cr[0] + cr[1] + cr[2] + cr[3]; counts[2 * f + 1] = cf[0] + cf[1] + cf[2] + cf[3]; }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_afsk_bits(const double *__restrict__ f1, const double *__restrict__ f2, int n, int w,
                                                    int n_bits, long n_rows, uint8_t *__restrict__ bits)
 {
@@ -2358,6 +2432,24 @@ extern "C" int pss_afsk_n_bits(int n, double fs)
     const int w = (int)(fs / 1200.0);
     if (w < 1 || n - w <= 0) return 0;
     return (n - w + w - 1) / w;  // len(range(0, n - w, w))
+}
+
+extern "C" int pss_morse_edges(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double threshold_db, int cap,
+                               int32_t *d_rise, int32_t *d_fall, int32_t *d_counts)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (n_frames < 0 || n < 1 || cap < 0) return pss_fail(ctx, PSS_E_ARG, "pss_morse_edges: bad argument");
+    if (threshold_db != -20.0)
+        return pss_fail(ctx, PSS_E_ARG, "pss_morse_edges: only the reference's threshold of -20 dB is pinned (the comparison replays "
+                                        "NumPy's float32 log10 at that one point)");
+    if (n_frames == 0) return PSS_OK;
+    if (!d_iq || !d_counts || (cap > 0 && (!d_rise || !d_fall))) return pss_fail(ctx, PSS_E_ARG, "pss_morse_edges: null buffer");
+    const long g = n_frames < 16384 ? n_frames : 16384;
+    pss_kernel_begin(ctx, "k_morse_edges");
+    hipLaunchKernelGGL(k_morse_edges, dim3((unsigned)g), dim3(256), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n,
+                       n_frames, cap, d_rise, d_fall, d_counts);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_morse_edges launch");
 }
 
 extern "C" const char *pss_class_name(int label)

@@ -177,6 +177,10 @@ class Engine:
     def vector_cells(self, d_iq, n, max_h, max_w, d_grid):
         self._ck(self.lib.pss_vector_cells(self.h, _ptr(d_iq), n, max_h, max_w, _ptr(d_grid)))
 
+    def morse_edges(self, d_iq, n_frames, n, cap, d_rise, d_fall, d_counts, threshold_db=-20.0):
+        self._ck(self.lib.pss_morse_edges(self.h, _ptr(d_iq), n_frames, n, float(threshold_db), cap, _ptr(d_rise), _ptr(d_fall),
+                                          _ptr(d_counts)))
+
     def classify(self, d_iq, n_frames, n, fs, d_label=None, d_bw=None, d_mi=None, d_flat=None, d_psd=None):
         """classify_signal for a batch (pss_classify): any of label int32 / bw float64 / mi float32 / flat float32 / psd float32 [.,1024]."""
         self._ck(self.lib.pss_classify(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_label), _ptr(d_bw), _ptr(d_mi),
@@ -281,6 +285,16 @@ class Engine:
         self._ck(self.lib.pss_h_iq_correction(self.h, _ptr(iq), len(iq), _ptr(out), None))
         return out
 
+    def h_morse_edges(self, iq, threshold_db=-20.0):
+        """-> (rise_times, fall_times) int32 arrays of decode_morse (decoders.py:159-161) for one buffer."""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        cap = max(len(iq) // 2 + 1, 1)
+        rise, fall = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        nr, nf = C.c_int(), C.c_int()
+        self._ck(self.lib.pss_h_morse_edges(self.h, _ptr(iq), len(iq), float(threshold_db), cap, _ptr(rise), _ptr(fall),
+                                            C.byref(nr), C.byref(nf)))
+        return rise[:nr.value].copy(), fall[:nf.value].copy()
+
     def h_classify_signal(self, iq, fs):
         """-> (label str, signal_bw float, modulation_index np.float32, spectral_flatness np.float32) for one read buffer."""
         iq = np.ascontiguousarray(iq, np.complex64)
@@ -303,6 +317,20 @@ class Engine:
         s1, s2 = c(sos1200), c(sos2200)
         self._ck(self.lib.pss_afsk_bits(self.h, _ptr(d_audio), n_rows, n, float(fs), _ptr(s1), _ptr(s2),
                                         5 if s1 is None else s1.shape[0], _ptr(d_bits)))
+
+    def h_afsk_bits(self, x, fs, sos1200=None, sos2200=None):
+        """decode_afsk's bit list for one host buffer of real audio (float64) -> uint8 array."""
+        import torch
+        x = np.ascontiguousarray(x, np.float64)
+        nb = self.afsk_n_bits(len(x), fs)
+        if nb <= 0:
+            return np.zeros(0, np.uint8)
+        d_x = torch.from_numpy(x).cuda()
+        d_b = torch.empty(nb, dtype=torch.uint8, device=d_x.device)
+        torch.cuda.synchronize()
+        self.afsk_bits(d_x, 1, len(x), fs, d_b, sos1200, sos2200)
+        self.sync()
+        return d_b.cpu().numpy()
 
     def afsk_n_bits(self, n, fs):
         return self.lib.pss_afsk_n_bits(int(n), float(fs))

@@ -54,6 +54,9 @@ def lib():
         L.pss_o_classify.restype = C.c_int
         L.pss_o_classify.argtypes = [_f32p, C.c_long, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float), _f32p]
         L.pss_o_hann1024_f32.argtypes = [_f32p]
+        _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+        L.pss_o_morse_edges.restype = None
+        L.pss_o_morse_edges.argtypes = [_f32p, C.c_long, _i32p, _i32p, C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_long)]
         L.pss_o_power_db.restype = C.c_float
         L.pss_o_power_db.argtypes = [_f32p, C.c_int]
         L.pss_o_scan_slice.restype = C.c_int
@@ -181,6 +184,15 @@ def hann1024():
     w = np.empty(1024, np.float32)
     lib().pss_o_hann1024_f32(w)
     return w
+
+
+def morse_edges(iq):
+    """-> (rise_times, fall_times) int32 arrays of decode_morse (decoders.py:159-161), threshold -20 dB."""
+    n = len(iq)
+    rise, fall = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.int32)
+    nr, nf = C.c_long(), C.c_long()
+    lib().pss_o_morse_edges(_iq(iq), n, rise, fall, n, C.byref(nr), C.byref(nf))
+    return rise[:nr.value].copy(), fall[:nf.value].copy()
 
 
 def power_db(iq):

@@ -6,6 +6,8 @@ plus size-independent properties at larger batch sizes.
 Bars: int16 PCM bit-exact; float64 audio bit-exact for NFM/AM (SSB: 2e-14, the reference's Hilbert FFT
 round trip); float32 dB within 1e-4 RELATIVE of the reference's float64 value.
 """
+import json
+
 import numpy as np
 import pytest
 
@@ -670,6 +672,42 @@ def test_classify_batch_vs_oracle():
             assert mi[f].tobytes() == omi.tobytes(), (n, f, mi[f], omi)
             assert abs(float(fl[f]) - float(ofl)) <= 1e-5 * abs(float(ofl)), (n, f)
             assert np.all(np.abs(psd[f] - opsd) <= 1e-6 * (opsd + 1e-10)), (n, f)
+
+
+def test_decoders_dropin(golden):
+    """pyspecsdr_amd.decoders against the reference's decoders.py outputs: decode_morse text + timing (kmeans seeded as in the
+    fixture script), its rise / fall indices, decode_aprs packets; batched pss_morse_edges against the oracle."""
+    import pyspecsdr_amd.decoders as D
+    g = golden["decoders"]
+    e = G.engine()
+    for tag in g["mtags"]:
+        x, fs = g[f"m_iq_{tag}"], float(g[f"m_fs_{tag}"])
+        rise, fall = e.h_morse_edges(x)
+        assert np.array_equal(rise, g[f"m_rise_{tag}"]) and np.array_equal(fall, g[f"m_fall_{tag}"]), tag
+        np.random.seed(1234)
+        text, timing = D.decode_morse(x, fs)
+        assert text == str(g[f"m_text_{tag}"]), tag
+        assert [float(timing[k]) for k in ("dot", "dash", "gap")] == list(g[f"m_timing_{tag}"]), tag
+    for tag in g["atags"]:
+        x, fs = g[f"a_x_{tag}"], float(g[f"a_fs_{tag}"])
+        assert D.decode_aprs(x, fs) == json.loads(str(g[f"a_packets_{tag}"])), tag
+    from pyspecsdr_amd.engine import PssError
+    with pytest.raises(PssError):
+        e.h_morse_edges(g["m_iq_one"], threshold_db=-15.0)       # only the reference's -20 dB is pinned
+    rng = np.random.default_rng(9)
+    for nf, n in ((33, 5000), (7, 2), (4, 70001), (300, 777)):
+        key = np.repeat(rng.integers(0, 2, (nf, n // 40 + 1)), 40, axis=1)[:, :n] * rng.uniform(0.05, 1.0, (nf, 1))
+        iq = (key * np.exp(0.2j * np.arange(n)) + 10.0 ** rng.uniform(-4, -1, (nf, 1)) * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
+        iq[nf // 2] = 0
+        cap = n // 2 + 1
+        d_r, d_f, d_c = G.empty((nf, cap), torch.int32), G.empty((nf, cap), torch.int32), G.empty((nf, 2), torch.int32)
+        e.morse_edges(G.dev(iq.view(np.float32).reshape(nf, n, 2)), nf, n, cap, d_r, d_f, d_c)
+        e.sync()
+        r, f, c = G.host(d_r), G.host(d_f), G.host(d_c)
+        for k in range(nf):
+            orr, off = O.morse_edges(iq[k])
+            assert c[k, 0] == len(orr) and c[k, 1] == len(off), (n, k)
+            assert np.array_equal(r[k, :len(orr)], orr) and np.array_equal(f[k, :len(off)], off), (n, k)
 
 
 def test_kernel_timing_and_filter():

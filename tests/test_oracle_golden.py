@@ -270,3 +270,25 @@ def test_classify_signal(golden):
         assert float(fl) == rfl or abs(float(fl) - rfl) <= 1e-5 * abs(rfl) or (np.isnan(fl) and np.isnan(rfl)), (tag, fl, rfl)
     with pytest.raises(ValueError):
         O.classify(np.zeros(1000, np.complex64), fs)
+
+
+def test_morse_edges_and_ax25_bookkeeping(golden):
+    """decode_morse's mask / transition indices (decoders.py:149-161, threshold -20 dB: NumPy's SVML log10f pinned at the one point
+    that matters) and the host-side AX.25 bookkeeping of the drop-in decoders module (decoders.py:6-91) on the goldens."""
+    g = golden["decoders"]
+    for tag in g["mtags"]:
+        rise, fall = O.morse_edges(g[f"m_iq_{tag}"])
+        assert np.array_equal(rise, g[f"m_rise_{tag}"]) and np.array_equal(fall, g[f"m_fall_{tag}"]), tag
+    # values one ulp either side of the cut-off: 0x3dccccce is still "off" under SVML (a correctly rounded log10f says "on")
+    vals = (np.arange(-40, 41, dtype=np.int64) + 0x3DCCCCCD).astype(np.uint32).view(np.float32)
+    x = np.zeros(2 * len(vals) + 1, np.complex64); x[0] = 1.0; x[1::2] = vals
+    rise, fall = O.morse_edges(x)
+    on = vals.view(np.uint32) >= 0x3DCCCCCF
+    assert np.array_equal(rise, 2 * np.nonzero(on)[0]) and len(fall) == on.sum() + 1
+    import pyspecsdr_amd.decoders as D
+    off = np.concatenate([[0], np.cumsum(g["ax_len"])])
+    import json
+    for k, want in enumerate(json.loads(str(g["ax_out"]))):
+        bits = [int(b) for b in g["ax_bits"][off[k]:off[k + 1]]]
+        got = D.decode_ax25_frame(bits)
+        assert ("<None>" if got is None else got) == str(want), k

@@ -413,6 +413,85 @@ def gen_classify():
     save("classify", **d)
 
 
+def gen_decoders():
+    """decoders.py end to end: decode_morse (text + timing; np.random seeded because scipy's kmeans draws its initial centroids from
+    the global state) and decode_aprs (AFSK audio -> packet list).  rise_ / fall_ are NOT reference outputs (decode_morse keeps
+    them local): they are the same NumPy expressions (decoders.py:149-161) evaluated here, stored to pin the edge kernel."""
+    import decoders
+    d, mtags, atags = {}, [], []
+    rng = np.random.default_rng(303)
+    code = {v: k for k, v in __import__("pyspecconst").MORSE_CODE.items() if len(v) == 1}
+
+    def cw(text, fs, unit, n, noise, lead=3, amp=0.6, soft=0):
+        key = [0] * lead
+        for wi, word in enumerate(text.split(" ")):
+            if wi: key += [0] * 4                      # 7 units between words (3 already follow the last letter)
+            for ch in word:
+                for sym in code[ch]:
+                    key += [1] * (1 if sym == "." else 3) + [0]
+                key += [0] * 2
+        k = np.repeat(np.array(key, float), unit)[:n]
+        k = np.concatenate([k, np.zeros(n - len(k))])
+        if soft: k = np.convolve(k, np.ones(soft) / soft, mode="same")
+        t = np.arange(n)
+        return (amp * k * np.exp(2j * np.pi * 700.0 / fs * t) + noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+
+    cases = [("sos", cw("SOS", 24000.0, 1100, 32768, 0.002), 24000.0),
+             ("cq", cw("CQ DE K", 48000.0, 900, 60000, 0.01, soft=40), 48000.0),
+             ("noisy", cw("TEST", 24000.0, 700, 30000, 0.04, soft=25), 24000.0),
+             ("one", cw("E", 24000.0, 1000, 5000, 0.001), 24000.0),
+             ("keydown", cw("AN", 24000.0, 800, 20000, 0.002, lead=0), 24000.0),
+             ("silence", np.zeros(4096, np.complex64), 24000.0),
+             ("noise", (0.1 * (rng.standard_normal(8000) + 1j * rng.standard_normal(8000))).astype(np.complex64), 24000.0)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, x, fs in cases:
+            np.random.seed(1234)
+            text, timing = decoders.decode_morse(x, fs)
+            env = np.abs(x); env = env / np.max(env); sig = 20 * np.log10(env + 1e-10) > -20
+            tr = np.diff(sig.astype(int))
+            mtags.append(tag)
+            d[f"m_iq_{tag}"] = x; d[f"m_fs_{tag}"] = np.array(fs); d[f"m_text_{tag}"] = np.array(text)
+            d[f"m_timing_{tag}"] = np.array([float(timing["dot"]), float(timing["dash"]), float(timing["gap"])])
+            d[f"m_rise_{tag}"] = np.where(tr == 1)[0].astype(np.int32); d[f"m_fall_{tag}"] = np.where(tr == -1)[0].astype(np.int32)
+
+    def ax25_bits(dest, src, info, pre):
+        by = [(ord(c) << 1) for c in dest.ljust(6)] + [0x60] + [(ord(c) << 1) for c in src.ljust(6)] + [0x61, 0x03, 0xF0] + [ord(c) for c in info]
+        bits = [(b >> j) & 1 for b in by for j in range(8)]
+        st, ones = [], 0
+        for b in bits:
+            st.append(b); ones = ones + 1 if b else 0
+            if ones == 5: st.append(0); ones = 0
+        flag = [0, 1, 1, 1, 1, 1, 1, 0]
+        return [0] * pre + flag + st + flag + [0] * 9
+
+    for tag, fs, delay, cplx in (("a", 22050.0, 9, False), ("b", 48000.0, 30, False), ("c", 9600.0, 7, True), ("d", 22050.0, 0, False)):
+        bits = ax25_bits("APRS", "N0CALL", "HELLO " + tag, 5)
+        w = int(fs / 1200)
+        sym = np.repeat(bits, w)
+        n = len(sym) + 12 * w
+        f = np.where(np.concatenate([np.zeros(delay), sym, np.zeros(n - len(sym) - delay)])[:n] > 0, 2200.0, 1200.0)
+        x = 0.8 * np.sin(2 * np.pi * np.cumsum(f) / fs) + 0.01 * rng.standard_normal(n)
+        if cplx: x = x + 0.3j * rng.standard_normal(n)
+        out = decoders.decode_aprs(x, fs)
+        atags.append(tag)
+        d[f"a_x_{tag}"] = x; d[f"a_fs_{tag}"] = np.array(fs)
+        d[f"a_packets_{tag}"] = np.array(json.dumps(out))          # JSON text: NumPy's str dtype drops trailing NULs
+        nyq = fs / 2
+        d[f"a_sos1200_{tag}"] = ss.butter(5, [1100 / nyq, 1300 / nyq], btype="band", output="sos")
+        d[f"a_sos2200_{tag}"] = ss.butter(5, [2100 / nyq, 2300 / nyq], btype="band", output="sos")
+    # the bookkeeping either side: random and planted bit streams through decode_ax25_frame
+    streams, outs = [], []
+    for it in range(40):
+        bits = [int(b) for b in rng.integers(0, 2, int(rng.integers(0, 300)))]
+        if it % 2 == 0: bits = bits[:7] + ax25_bits("DST" + str(it), "SRC" + str(it), "msg %d" % it, 0) + bits[7:15]
+        streams.append(np.array(bits, np.uint8)); r = decoders.decode_ax25_frame(bits); outs.append("<None>" if r is None else r)
+    d["ax_len"] = np.array([len(b) for b in streams]); d["ax_bits"] = np.concatenate(streams) if streams else np.zeros(0, np.uint8)
+    d["ax_out"] = np.array(json.dumps(outs))
+    d["mtags"] = np.array(mtags); d["atags"] = np.array(atags)
+    save("decoders", **d)
+
+
 def gen_power():
     d = {}
     frames, pw = [], []
@@ -615,5 +694,6 @@ if __name__ == "__main__":
     gen_bandpass()
     gen_afsk()
     gen_classify()
+    gen_decoders()
     gen_scanner()
     gen_caller()
