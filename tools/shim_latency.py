@@ -42,9 +42,15 @@ def main():
             ("demodulate_signal USB", lambda: sp.demodulate_signal(x, fs, "USB"), lambda: O.demod_ssb(x, e.ssb_taps(fs))),
             ("demodulate_signal WFM", lambda: sp.demodulate_signal(x, fs, "WFM"), None),
             ("demodulate_signal RAW", lambda: sp.demodulate_signal(x, fs, "RAW"), lambda: O.iq_correction(x)),
+            ("classify_signal", lambda: sp.classify_signal(x, fs, 0.0), lambda: O.classify(x, fs)),
+            ("decode_morse (edges)", lambda: e.h_morse_edges(x), lambda: O.morse_edges(x)),
         ]
         for name, g, c in rows:
-            tg = timeit(g, reps)
+            try:
+                tg = timeit(g, reps)
+            except Exception as ex:                      # e.g. compute_fft on a buffer that is not a power of two
+                print(f"n={n:6d}  {name:24s} not applicable ({type(ex).__name__})", flush=True)
+                continue
             tc = timeit(c, reps) if c else float("nan")
             print(f"n={n:6d}  {name:24s} GPU shim {tg:8.3f} ms   C oracle (1 core, filters given) {tc:8.3f} ms", flush=True)
 
