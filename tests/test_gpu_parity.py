@@ -652,7 +652,7 @@ def test_classify_batch_vs_oracle():
     rng = np.random.default_rng(77)
     e = G.engine()
     fs = 2.4e6
-    for nf, n in ((37, 4096), (5, 2048), (3, 70001)):
+    for nf, n in ((37, 4096), (5, 2048), (3, 70001), (2, 1 << 20)):   # up to the reference's largest read buffer
         t = np.arange(n) / fs
         iq = np.empty((nf, n), np.complex64)
         for f in range(nf):
