@@ -81,16 +81,23 @@ int pss_get_ssb_taps(pss_ctx *ctx, double fs, double *taps65);
 /* ---- batched device entry points --------------------------------------------------------------- */
 /* compute_fft (signal_processing.py:243-264) for n_frames frames: Hamming window, n_fft-point FFT (float64
  * butterflies), fftshift, 10*log10(|X|^2 + 1e-10).  d_db: float32 [n_frames][n_fft].
- * n_fft: power of two, 16 <= n_fft <= 1048576. */
+ * n_fft: a power of two in [16, 1048576] (register / LDS radix-16 kernels), or any other length in [2, 524288]
+ * (Bluestein's algorithm over the two-pass 2^17..2^20-point transform: NumPy's fft takes any length too). */
 int pss_spectrum_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db);
 /* Caller-side post-process (pyspecsdr.py:2278-2283): 5-tap moving average ('valid') then clamp below
  * median-10.  d_post: float32 [n_frames][n_fft-4]. */
 int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post);
 /* Inline scanner slice (pyspecsdr.py:2542-2552): unwindowed FFT, dB, peak, 20-dB-down bin count,
  * bandwidth = count * fs / n_fft.  d_db float32 [n][n_fft] (may be NULL), d_peak float32 [n],
- * d_bw float64 [n], d_count int32 [n] (may be NULL). */
+ * d_bw float64 [n], d_count int32 [n] (may be NULL).  n_fft: power of two in [16, 16384] (one kernel), or any other
+ * length in [2, 524288] (Bluestein + a reduction kernel). */
 int pss_scan(pss_ctx *ctx, const float *d_iq, long n_slices, int n_fft, double fs, float *d_db, float *d_peak,
              double *d_bw, int32_t *d_count);
+/* The sweep driver's per-read arithmetic (scan_frequencies, pyspecsdr.py:1049-1057): unwindowed fft of a read of
+ * n = int(0.1 * fs) samples (240 000 at 2.4 MS/s: not a power of two), dB, max_power, bins above the ABSOLUTE threshold,
+ * bandwidth = count * fs / n.  Buffers as for pss_scan (d_db, d_peak, d_bw, d_count may each be NULL). */
+int pss_scan_threshold(pss_ctx *ctx, const float *d_iq, long n_slices, int n, double fs, double threshold_db, float *d_db,
+                       float *d_peak, double *d_bw, int32_t *d_count);
 /* iq_correction — signal_processing.py:46-80, per frame: DC removal, IQ amplitude/phase balance, power restore; float32
  * throughout, bit-identical to the reference on NumPy 2.2.  d_out_iq: complex64 [n_frames][n] (nullable);
  * d_raw: float32 [n_frames][n] = real part = demodulate_signal(..., 'RAW') (signal_processing.py:222-238) (nullable). */

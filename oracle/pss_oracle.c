@@ -280,6 +280,41 @@ static void fft_f64(double *re, double *im, int n)
     free(wi);
 }
 
+/* Any length: powers of two go to fft_f64; other lengths (np.fft.fft takes any n; the sweep driver reads int(0.1 fs)
+ * samples, pyspecsdr.py:1026) use Bluestein's chirp-z identity over a power-of-two circular convolution. */
+static void fft_any_f64(double *re, double *im, int n)
+{
+    if (n <= 1) return;
+    if (!(n & (n - 1))) { fft_f64(re, im, n); return; }
+    int M = 1;
+    while (M < 2 * n - 1) M <<= 1;
+    double *ar = (double *)calloc(M, sizeof(double)), *ai = (double *)calloc(M, sizeof(double));
+    double *br = (double *)calloc(M, sizeof(double)), *bi = (double *)calloc(M, sizeof(double));
+    double *cr = (double *)malloc(sizeof(double) * n), *ci = (double *)malloc(sizeof(double) * n);
+    for (int k = 0; k < n; k++) {
+        long long q = ((long long)k * k) % (2LL * n);
+        double ang = -M_PI * (double)q / (double)n;
+        cr[k] = cos(ang); ci[k] = sin(ang);
+        ar[k] = re[k] * cr[k] - im[k] * ci[k];
+        ai[k] = re[k] * ci[k] + im[k] * cr[k];
+        br[k] = cr[k]; bi[k] = -ci[k];
+        if (k) { br[M - k] = br[k]; bi[M - k] = bi[k]; }
+    }
+    fft_f64(ar, ai, M);
+    fft_f64(br, bi, M);
+    for (int k = 0; k < M; k++) { /* conj(A B), so that a forward transform inverts */
+        double pr = ar[k] * br[k] - ai[k] * bi[k], pi = ar[k] * bi[k] + ai[k] * br[k];
+        ar[k] = pr; ai[k] = -pi;
+    }
+    fft_f64(ar, ai, M);
+    for (int k = 0; k < n; k++) {
+        double zr = ar[k] / (double)M, zi = -ai[k] / (double)M;
+        re[k] = zr * cr[k] - zi * ci[k];
+        im[k] = zr * ci[k] + zi * cr[k];
+    }
+    free(ar); free(ai); free(br); free(bi); free(cr); free(ci);
+}
+
 /* compute_fft — signal_processing.py:243-264:
  *   window = np.hamming(N) (:246); samples*window -> complex128 (:247); fftshift(fft()) (:250);
  *   10*log10(abs(fft)**2 + 1e-10) (:262). */
@@ -291,9 +326,9 @@ void pss_o_compute_fft(const float *iq, int n, double *db)
         re[i] = (double)iq[2 * i] * w;
         im[i] = (double)iq[2 * i + 1] * w;
     }
-    fft_f64(re, im, n);
+    fft_any_f64(re, im, n);
     for (int k = 0; k < n; k++) {
-        int src = (k + n / 2) % n; /* fftshift, even n */
+        int src = (k + (n + 1) / 2) % n; /* np.fft.fftshift: out[(k + n // 2) % n] = X[k] */
         double a = hypot(re[src], im[src]);
         db[k] = 10.0 * log10(a * a + 1e-10);
     }
@@ -510,10 +545,10 @@ int pss_o_scan_slice(const float *iq, int n, double fs, float *db, float *peak, 
 {
     double *re = (double *)malloc(sizeof(double) * n), *im = (double *)malloc(sizeof(double) * n);
     for (int i = 0; i < n; i++) { re[i] = iq[2 * i]; im[i] = iq[2 * i + 1]; }
-    fft_f64(re, im, n);
+    fft_any_f64(re, im, n);
     float pk = -INFINITY;
     for (int k = 0; k < n; k++) {
-        int src = (k + n / 2) % n;
+        int src = (k + (n + 1) / 2) % n;
         float a = (float)hypot(re[src], im[src]);
         float p = a * a + 1e-10f;
         db[k] = 10.0f * pss_o_log10f_ref(p);
@@ -526,6 +561,17 @@ int pss_o_scan_slice(const float *iq, int n, double fs, float *db, float *peak, 
     *bw = (double)count * (fs / (double)n);
     free(re);
     free(im);
+    return count;
+}
+
+/* scan_frequencies' per-read arithmetic — pyspecsdr.py:1049-1057: the same unwindowed spectrum, max_power, and the bins above an
+ * ABSOLUTE threshold: bandwidth = np.sum(power_db > threshold) * (sample_rate / len(power_db)). */
+int pss_o_scan_threshold(const float *iq, int n, double fs, double threshold_db, float *db, float *peak, double *bw)
+{
+    pss_o_scan_slice(iq, n, fs, db, peak, bw);
+    int count = 0;
+    for (int k = 0; k < n; k++) count += db[k] > (float)threshold_db;
+    *bw = (double)count * (fs / (double)n);
     return count;
 }
 

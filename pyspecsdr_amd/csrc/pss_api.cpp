@@ -118,6 +118,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->tw) hipFree(kv.second);
     for (auto &kv : ctx->win) hipFree(kv.second);
+    for (auto &kv : ctx->bs) { hipFree(kv.second.d_chirp); hipFree(kv.second.d_B); hipFree(kv.second.d_win); }
     for (auto &kv : ctx->plans) {
         hipFree(kv.second.d_leaf_off); hipFree(kv.second.d_leaf_len); hipFree(kv.second.d_node_l);
         hipFree(kv.second.d_node_r); hipFree(kv.second.d_level_start); hipFree(kv.second.d_roots);
@@ -126,6 +127,8 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     if (ctx->scratch_fft) hipFree(ctx->scratch_fft);
     if (ctx->scratch_iqc) hipFree(ctx->scratch_iqc);
     if (ctx->d_hann) hipFree(ctx->d_hann);
+    if (ctx->scratch_scan) hipFree(ctx->scratch_scan);
+    if (ctx->scratch_pk) hipFree(ctx->scratch_pk);
     if (ctx->stage) hipFree(ctx->stage);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);

@@ -38,6 +38,8 @@ struct pss_ctx {
     std::string err;
     std::map<int, double2 *> tw;       // exp(-2 pi i k / N), k < N
     std::map<int, double *> win;       // np.hamming(N)
+    struct Bluestein { double2 *d_chirp; double2 *d_B; double *d_win; int M; };
+    std::map<int, Bluestein> bs;       // per frame length that is not a power of two (pss_fft.hip)
     std::map<double, PssNfmFilt> nfm;  // per sample rate
     std::map<double, std::array<double, 65>> ssb;
     std::map<double, PssWfmFilt> wfm;
@@ -45,6 +47,10 @@ struct pss_ctx {
     void *scratch = nullptr;       // demodulator scratch (main stream)
     size_t scratch_bytes = 0;
     void *scratch_iqc = nullptr;   // IQ-corrected frames for the WFM dispatcher path
+    void *scratch_scan = nullptr;  // scanner dB rows when the caller asks only for the per-slice numbers
+    size_t scratch_scan_bytes = 0;
+    void *scratch_pk = nullptr;
+    size_t scratch_pk_bytes = 0;
     float *d_hann = nullptr;       // pss_classify: scipy's periodic Hann window (1024, float32) and sum(win * win)
     float hann_sum = 0.0f;
     size_t scratch_iqc_bytes = 0;

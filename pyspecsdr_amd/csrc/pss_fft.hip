@@ -757,17 +757,260 @@ int pss_fft_tables(pss_ctx *ctx, int n, const double2 **tw, const double **win)
     return PSS_OK;
 }
 
+// ---- frame lengths that are not a power of two: Bluestein's algorithm on the N = 256 * NS transform ------------------------
+// compute_fft and the scanner's fft accept any length in the reference (NumPy's pocketfft); its reads are powers of two
+// except the sweep driver's, int(0.1 * sample_rate) samples (pyspecsdr.py:1026, 240 000 at 2.4 MS/s).  With the chirp
+// c[k] = exp(-i pi k^2 / n):  X[k] = c[k] * sum_j (x[j] c[j]) conj(c)[k - j], a circular convolution of length
+// M = 2^m >= 2 n - 1 (M >= 2^17, the smallest size the two-pass transform handles; n <= 2^19):
+//   A = FFT_M(x c, zero-padded);  B = FFT_M(conj(c) wrapped) (once per n);  conv = IFFT_M(A B) = conj(FFT_M(conj(A B))) / M.
+// Four launches per batch chunk; the spectrum epilogue (chirp, |.|^2, dB, fftshift by n // 2) sits in the last store functor.
+namespace {
+
+struct BsLoadX {
+    const float2 *iq; const double2 *chirp; const double *win; int n;
+    __device__ double2 operator()(long f, size_t idx) const
+    {
+        if (idx >= (size_t)n) return make_double2(0.0, 0.0);
+        const float2 s = iq[(size_t)f * n + idx];
+        const double w = win ? win[idx] : 1.0;
+        return pss_r16::cmul(make_double2((double)s.x * w, (double)s.y * w), chirp[idx]);
+    }
+};
+struct BsLoadArr {
+    const double2 *a;
+    __device__ double2 operator()(long, size_t idx) const { return a[idx]; }
+};
+struct BsLoadConv {
+    const double2 *A, *B; size_t M;
+    __device__ double2 operator()(long f, size_t idx) const
+    {
+        const double2 p = pss_r16::cmul(A[(size_t)f * M + idx], B[idx]);
+        return make_double2(p.x, -p.y);
+    }
+};
+struct BsStoreC {
+    double2 *A; size_t M;
+    __device__ void operator()(long f, size_t k, double2 X) const { A[(size_t)f * M + k] = X; }
+};
+struct BsStoreDb {
+    float *db; const double2 *chirp; int n, shift; double inv_m;
+    __device__ void operator()(long f, size_t k, double2 X) const
+    {
+        if (k >= (size_t)n) return;
+        const double2 z = pss_r16::cmul(make_double2(X.x * inv_m, -X.y * inv_m), chirp[k]);
+        int o = (int)k + shift;                      // np.fft.fftshift: out[(k + n // 2) % n] = X[k]
+        if (o >= n) o -= n;
+        db[(size_t)f * n + o] = pss_r16::db_of(z.x * z.x + z.y * z.y + 1e-10);
+    }
+};
+
+template <class Load>
+int bs_pass1(pss_ctx *ctx, Load load, const double2 *tw, double2 *Y, int NS, long n_frames)
+{
+    using C0 = pss_r16::Cfg<0>;
+    const size_t lds1 = (size_t)16 * (C0::EX + 1) * sizeof(double2);
+    auto kern = pss_r16::k_huge_p1_g<Load>;
+    PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    const long total1 = n_frames * (NS / 16);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(total1 < 8192 ? total1 : 8192)), dim3(256), lds1, PSS_STREAM(ctx), load, tw, Y, NS, n_frames);
+    return PSS_OK;
+}
+template <class Store>
+int bs_pass2(pss_ctx *ctx, const double2 *Y, Store store, const double2 *tw, int NS, long n_frames)
+{
+    const long rows = n_frames * 256;
+    auto go = [&](auto kern, size_t lds2, int fpw) -> int {
+        if (lds2 > 64 * 1024)
+            PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        const long groups = rows / fpw;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(groups < 8192 ? groups : 8192)), dim3(256), lds2, PSS_STREAM(ctx), Y, store, tw, rows);
+        return PSS_OK;
+    };
+    switch (NS) {
+    case 512: return go(pss_r16::k_huge_p2_g<1, Store>, pss_r16::Cfg<1>::LDS, pss_r16::Cfg<1>::FPW);
+    case 1024: return go(pss_r16::k_huge_p2_g<2, Store>, pss_r16::Cfg<2>::LDS, pss_r16::Cfg<2>::FPW);
+    case 2048: return go(pss_r16::k_huge_p2_g<3, Store>, pss_r16::Cfg<3>::LDS, pss_r16::Cfg<3>::FPW);
+    default: return go(pss_r16::k_huge_p2_g<4, Store>, pss_r16::Cfg<4>::LDS, pss_r16::Cfg<4>::FPW);
+    }
+}
+
+int bs_plan(pss_ctx *ctx, int n, pss_ctx::Bluestein **out)
+{
+    auto it = ctx->bs.find(n);
+    if (it == ctx->bs.end()) {
+        int M = 1 << 17;
+        while (M < 2 * n - 1) M <<= 1;
+        std::vector<double2> c(n), b((size_t)M, make_double2(0.0, 0.0));
+        std::vector<double> w(n);
+        for (int k = 0; k < n; k++) {
+            const long long q = ((long long)k * k) % (2LL * n);          // k^2 mod 2n keeps the angle small: exp(-i pi q / n)
+            const double ang = -M_PI * (double)q / (double)n;
+            c[k] = make_double2(std::cos(ang), std::sin(ang));
+            b[k] = make_double2(c[k].x, -c[k].y);
+            if (k) b[(size_t)M - k] = b[k];
+            w[k] = (n == 1) ? 1.0 : 0.54 - 0.46 * std::cos(2.0 * M_PI * (double)k / (double)(n - 1));   // np.hamming(n)
+        }
+        pss_ctx::Bluestein p{nullptr, nullptr, nullptr, M};
+        double2 *d_b = nullptr;
+        PSS_HIP(ctx, hipMalloc(&p.d_chirp, sizeof(double2) * n));
+        PSS_HIP(ctx, hipMalloc(&p.d_B, sizeof(double2) * (size_t)M));
+        PSS_HIP(ctx, hipMalloc(&p.d_win, sizeof(double) * n));
+        PSS_HIP(ctx, hipMalloc(&d_b, sizeof(double2) * (size_t)M));
+        PSS_HIP(ctx, hipMemcpy(p.d_chirp, c.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+        PSS_HIP(ctx, hipMemcpy(p.d_win, w.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        PSS_HIP(ctx, hipMemcpy(d_b, b.data(), sizeof(double2) * (size_t)M, hipMemcpyHostToDevice));
+        const double2 *tw;
+        const double *wm;
+        int r = pss_fft_tables(ctx, M, &tw, &wm);
+        if (!r) r = pss_ensure_buffer(ctx, &ctx->scratch_fft, &ctx->scratch_fft_bytes, (size_t)M * sizeof(double2), "spectrum scratch");
+        if (!r) r = bs_pass1(ctx, BsLoadArr{d_b}, tw, reinterpret_cast<double2 *>(ctx->scratch_fft), M >> 8, 1);
+        if (!r) r = bs_pass2(ctx, reinterpret_cast<const double2 *>(ctx->scratch_fft), BsStoreC{p.d_B, (size_t)M}, tw, M >> 8, 1);
+        hipStreamSynchronize(PSS_STREAM(ctx));
+        hipFree(d_b);
+        if (r) return r;
+        ctx->bs[n] = p;
+    }
+    *out = &ctx->bs[n];
+    return PSS_OK;
+}
+
+// dB rows (float32 [n_frames][n], DC-centred) of frames of any length 2 <= n <= 2^19; window: np.hamming (compute_fft) or none (scanner)
+int bluestein_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n, bool window, float *d_db)
+{
+    if (n < 2 || n > (1 << 19)) return pss_fail(ctx, PSS_E_ARG, "frame lengths that are not a power of two must lie in [2, 524288]");
+    pss_ctx::Bluestein *p;
+    int r = bs_plan(ctx, n, &p);
+    if (r) return r;
+    const size_t M = (size_t)p->M;
+    const double2 *tw;
+    const double *wm;
+    r = pss_fft_tables(ctx, p->M, &tw, &wm);
+    if (r) return r;
+    long chunk = (long)(((size_t)1 << 30) / (M * sizeof(double2)));   // <= 1 GiB per scratch half
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_frames) chunk = n_frames;
+    r = pss_ensure_buffer(ctx, &ctx->scratch_fft, &ctx->scratch_fft_bytes, 2 * (size_t)chunk * M * sizeof(double2), "spectrum scratch");
+    if (r) return r;
+    double2 *Y = reinterpret_cast<double2 *>(ctx->scratch_fft), *A = Y + (size_t)chunk * M;
+    const int NS = p->M >> 8;
+    pss_time_begin(ctx);
+    for (long f0 = 0; f0 < n_frames && !r; f0 += chunk) {
+        const long nf = (n_frames - f0) < chunk ? (n_frames - f0) : chunk;
+        const float2 *x = reinterpret_cast<const float2 *>(d_iq) + (size_t)f0 * n;
+        pss_kernel_begin(ctx, "k_bluestein_p1");
+        r = bs_pass1(ctx, BsLoadX{x, p->d_chirp, window ? p->d_win : nullptr, n}, tw, Y, NS, nf);
+        pss_kernel_end(ctx);
+        pss_kernel_begin(ctx, "k_bluestein_p2");
+        if (!r) r = bs_pass2(ctx, Y, BsStoreC{A, M}, tw, NS, nf);
+        pss_kernel_end(ctx);
+        pss_kernel_begin(ctx, "k_bluestein_p1");
+        if (!r) r = bs_pass1(ctx, BsLoadConv{A, p->d_B, M}, tw, Y, NS, nf);
+        pss_kernel_end(ctx);
+        pss_kernel_begin(ctx, "k_bluestein_p2");
+        if (!r) r = bs_pass2(ctx, Y, BsStoreDb{d_db + (size_t)f0 * n, p->d_chirp, n, n / 2, 1.0 / (double)M}, tw, NS, nf);
+        pss_kernel_end(ctx);
+    }
+    pss_time_end(ctx);
+    if (r) return r;
+    return pss_hip_check(ctx, hipGetLastError(), "bluestein launch");
+}
+
+// per-row peak and number of bins above (mode 0) peak - 20 dB, pyspecsdr.py:2546-2552, or (mode 1) an absolute threshold,
+// the sweep driver's pyspecsdr.py:1051-1057
+__global__ __launch_bounds__(256) void k_scan_reduce(const float *__restrict__ db, int n, long n_rows, int mode, float threshold,
+                                                     double bin_hz, float *__restrict__ peak, double *__restrict__ bw,
+                                                     int32_t *__restrict__ count)
+{
+    __shared__ float redf[4];
+    __shared__ int redi[4];
+    const int tid = threadIdx.x;
+    for (long f = blockIdx.x; f < n_rows; f += gridDim.x) {
+        const float *row = db + (size_t)f * n;
+        float m = -INFINITY;
+        for (int i = tid; i < n; i += 256) m = fmaxf(m, row[i]);
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if ((tid & 63) == 0) redf[tid >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+        const float thr = mode == 0 ? m - 20.0f : threshold;
+        int c = 0;
+        for (int i = tid; i < n; i += 256) c += row[i] > thr;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        if ((tid & 63) == 0) redi[tid >> 6] = c;
+        __syncthreads();
+        if (tid == 0) {
+            c = redi[0] + redi[1] + redi[2] + redi[3];
+            if (peak) peak[f] = m;
+            if (bw) bw[f] = (double)c * bin_hz;
+            if (count) count[f] = c;
+        }
+        __syncthreads();
+    }
+}
+
+int scan_reduce(pss_ctx *ctx, const float *d_db, int n, long n_rows, int mode, float threshold, double bin_hz, float *d_peak,
+                double *d_bw, int32_t *d_count)
+{
+    pss_kernel_begin(ctx, "k_scan_reduce");
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)(n_rows < 16384 ? n_rows : 16384)), dim3(256), 0, PSS_STREAM(ctx), d_db, n, n_rows,
+                       mode, threshold, bin_hz, d_peak, d_bw, d_count);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_scan_reduce launch");
+}
+
+bool is_pow2(int n) { return n > 0 && !(n & (n - 1)); }
+
+}  // namespace
+
 extern "C" int pss_spectrum_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db)
 {
     if (ctx && !d_db && n_frames > 0) return pss_fail(ctx, PSS_E_ARG, "d_db is null");
+    if (ctx && n_frames > 0 && d_iq && n_fft >= 2 && !(is_pow2(n_fft) && n_fft >= 16)) return bluestein_db(ctx, d_iq, n_frames, n_fft, true, d_db);
     return launch_spectrum<false>(ctx, d_iq, n_frames, n_fft, d_db, nullptr, nullptr, nullptr, 0.0);
+}
+
+// dB rows of the scanner's unwindowed fft into d_db or, when the caller wants only the per-slice numbers, into scratch
+static int scan_rows(pss_ctx *ctx, const float *d_iq, long n_slices, int n, float *d_db, const float **rows)
+{
+    if (!d_db) {
+        int r = pss_ensure_buffer(ctx, &ctx->scratch_scan, &ctx->scratch_scan_bytes, (size_t)n_slices * n * sizeof(float), "scan rows");
+        if (r) return r;
+        d_db = reinterpret_cast<float *>(ctx->scratch_scan);
+    }
+    *rows = d_db;
+    if (is_pow2(n) && n >= 16 && n <= 16384) {
+        float *pk = nullptr;   // launch_spectrum<true> wants a peak buffer: use the tail of the same scratch? simpler: a tiny one
+        int r = pss_ensure_buffer(ctx, &ctx->scratch_pk, &ctx->scratch_pk_bytes, (size_t)n_slices * sizeof(float), "scan peaks");
+        if (r) return r;
+        pk = reinterpret_cast<float *>(ctx->scratch_pk);
+        return launch_spectrum<true>(ctx, d_iq, n_slices, n, d_db, pk, nullptr, nullptr, 0.0);
+    }
+    return bluestein_db(ctx, d_iq, n_slices, n, false, d_db);
 }
 
 extern "C" int pss_scan(pss_ctx *ctx, const float *d_iq, long n_slices, int n_fft, double fs, float *d_db, float *d_peak,
                         double *d_bw, int32_t *d_count)
 {
     if (ctx && !d_peak) return pss_fail(ctx, PSS_E_ARG, "d_peak is null");
+    if (ctx && n_slices > 0 && d_iq && n_fft >= 2 && !(is_pow2(n_fft) && n_fft >= 16 && n_fft <= 16384)) {
+        const float *rows;
+        int r = scan_rows(ctx, d_iq, n_slices, n_fft, d_db, &rows);
+        if (r) return r;
+        return scan_reduce(ctx, rows, n_fft, n_slices, 0, 0.0f, fs / (double)n_fft, d_peak, d_bw, d_count);
+    }
     return launch_spectrum<true>(ctx, d_iq, n_slices, n_fft, d_db, d_peak, d_bw, d_count, fs / (double)n_fft);
+}
+
+extern "C" int pss_scan_threshold(pss_ctx *ctx, const float *d_iq, long n_slices, int n, double fs, double threshold_db, float *d_db,
+                                  float *d_peak, double *d_bw, int32_t *d_count)
+{
+    if (!ctx) return PSS_E_ARG;
+    if (n_slices < 0 || n < 2 || (n_slices > 0 && !d_iq)) return pss_fail(ctx, PSS_E_ARG, "pss_scan_threshold: bad argument");
+    if (n_slices == 0) return PSS_OK;
+    const float *rows;
+    int r = scan_rows(ctx, d_iq, n_slices, n, d_db, &rows);
+    if (r) return r;
+    return scan_reduce(ctx, rows, n, n_slices, 1, (float)threshold_db, fs / (double)n, d_peak, d_bw, d_count);
 }
 
 extern "C" int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post)

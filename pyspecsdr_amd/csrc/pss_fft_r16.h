@@ -432,4 +432,73 @@ __global__ __launch_bounds__(256) void k_huge_p2(const double2 *__restrict__ Y, 
     }
 }
 
+// ---- the same two-pass N = 256 * NS float64 transform around caller-supplied load / store functors -----------------
+// (Bluestein's algorithm for frame lengths that are not a power of two: pss_fft.hip).  load(f, idx) -> element idx of
+// frame f's length-N input; store(f, k, X) receives bin k.
+template <class Load>
+__global__ __launch_bounds__(256) void k_huge_p1_g(Load load, const double2 *__restrict__ tw, double2 *__restrict__ Y, int NS,
+                                                   long n_frames)
+{
+    using C = Cfg<0>;
+    constexpr int EXP = C::EX + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *ex_all = reinterpret_cast<double2 *>(smem);
+    const int tid = threadIdx.x, fl = tid & 15, t = tid >> 4;
+    const size_t N = (size_t)256 * NS;
+    const int cpf = NS / 16;
+    double2 tw1[16];
+    tw1[0] = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; k2++) tw1[k2] = tw[(size_t)(t * k2) * NS];
+    double2 *ex = ex_all + (size_t)fl * EXP;
+    const long total = n_frames * cpf;
+    for (long g = blockIdx.x; g < total; g += gridDim.x) {
+        const long f = g / cpf;
+        const int col = (int)(g - f * cpf) * 16 + fl;
+        double2 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = load(f, (size_t)col + (size_t)NS * (t + 16 * j));
+        double2 *Yf = Y + (size_t)f * N;
+        r16_core<0>(v, ex, tw1, nullptr, t, [&](int, int r, double2 X) {
+            if (r) X = cmul(X, tw[(size_t)col * r]);
+            Yf[(size_t)r * NS + col] = X;
+        });
+        __syncthreads();
+    }
+}
+
+template <int LOG_R3, class Store>
+__global__ __launch_bounds__(256) void k_huge_p2_g(const double2 *__restrict__ Y, Store store, const double2 *__restrict__ tw,
+                                                   long n_rows)
+{
+    using C = Cfg<LOG_R3>;
+    constexpr int R3 = C::R3, T = C::T, NS = C::N, FPW = C::FPW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *ex_all = reinterpret_cast<double2 *>(smem);
+    double2 *tw2 = ex_all + (size_t)FPW * C::EX;
+    const int tid = threadIdx.x, fl = tid / T, t = tid % T;
+    double2 *ex = ex_all + (size_t)fl * C::EX;
+    double2 tw1[16];
+    tw1[0] = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; k2++) tw1[k2] = tw[(size_t)(t * k2) * 256];
+    if (tid < R3 * 16) {
+        const int m1 = tid / 16, j2 = tid % 16;
+        tw2[tid] = tw[(size_t)(m1 * j2) * 16 * 256];
+    }
+    __syncthreads();
+    const long groups = (n_rows + FPW - 1) / FPW;
+    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+        const long row = g * FPW + fl;
+        const long f = row >> 8;
+        const int r = (int)(row & 255);
+        const double2 *y = Y + (size_t)row * NS;
+        double2 v[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++) v[n2] = y[t + T * n2];
+        r16_core<LOG_R3>(v, ex, tw1, tw2, t, [&](int, int kp, double2 X) { store(f, (size_t)256 * kp + r, X); });
+        __syncthreads();
+    }
+}
+
 }  // namespace pss_r16

@@ -123,6 +123,11 @@ class Engine:
         self._ck(self.lib.pss_scan(self.h, _ptr(d_iq), n_slices, n_fft, float(fs), _ptr(d_db), _ptr(d_peak),
                                    _ptr(d_bw), _ptr(d_count)))
 
+    def scan_threshold(self, d_iq, n_slices, n, fs, threshold_db, d_db=None, d_peak=None, d_bw=None, d_count=None):
+        """The sweep driver's per-read numbers (pyspecsdr.py:1049-1057): max power, bins above an absolute threshold, bandwidth."""
+        self._ck(self.lib.pss_scan_threshold(self.h, _ptr(d_iq), n_slices, n, float(fs), float(threshold_db), _ptr(d_db), _ptr(d_peak),
+                                             _ptr(d_bw), _ptr(d_count)))
+
     def power_db(self, d_iq, n_frames, n, d_power):
         self._ck(self.lib.pss_power_db(self.h, _ptr(d_iq), n_frames, n, _ptr(d_power)))
 

@@ -59,6 +59,8 @@ def lib():
         L.pss_o_morse_edges.argtypes = [_f32p, C.c_long, _i32p, _i32p, C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_long)]
         L.pss_o_power_db.restype = C.c_float
         L.pss_o_power_db.argtypes = [_f32p, C.c_int]
+        L.pss_o_scan_threshold.restype = C.c_int
+        L.pss_o_scan_threshold.argtypes = [_f32p, C.c_int, C.c_double, C.c_double, _f32p, C.POINTER(C.c_float), C.POINTER(C.c_double)]
         L.pss_o_scan_slice.restype = C.c_int
         L.pss_o_scan_slice.argtypes = [_f32p, C.c_int, C.c_double, _f32p, C.POINTER(C.c_float),
                                        C.POINTER(C.c_double)]
@@ -197,6 +199,14 @@ def morse_edges(iq):
 
 def power_db(iq):
     return np.float32(lib().pss_o_power_db(_iq(iq), len(iq)))
+
+
+def scan_threshold(iq, fs, threshold_db):
+    """-> (db float32[n], max_power float32, bandwidth float64, count) of pyspecsdr.py:1049-1057."""
+    db = np.empty(len(iq), np.float32)
+    pk, bw = C.c_float(), C.c_double()
+    cnt = lib().pss_o_scan_threshold(_iq(iq), len(iq), fs, threshold_db, db, C.byref(pk), C.byref(bw))
+    return db, np.float32(pk.value), bw.value, cnt
 
 
 def scan_slice(iq, fs):

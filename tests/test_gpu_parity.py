@@ -808,6 +808,60 @@ def test_scanner(golden, n):
         assert pk[k] == db[k].max() and cnt[k] == int(np.sum(db[k] > pk[k] - np.float32(20)))  # self-consistent
 
 
+def test_lengths_that_are_not_a_power_of_two(golden):
+    """Bluestein path: compute_fft (shim and batched entry), pss_scan and the sweep driver's pss_scan_threshold on lengths
+    that are not a power of two, against the reference's goldens and against the oracle on random batches."""
+    import pyspecsdr_amd.signal_processing as sp
+    e = G.engine()
+    g = golden["spectrum"]
+    for n in g["np2_sizes"]:
+        iq, ref = g[f"iq_np2_{n}"], g[f"db_np2_{n}"]
+        db = G.spectrum(iq)
+        big = np.abs(ref) > 1e-2
+        assert np.all(rel_err(db, ref)[big] <= 1e-4) and np.all(np.abs(db - ref)[~big] <= 1e-6), n
+        one = sp.compute_fft(iq[0])
+        assert one.dtype == np.float64 and one.flags.writeable and np.array_equal(one.astype(np.float32), db[0])
+    g = golden["scanner"]
+    for n in g["sw_sizes"]:
+        fs, thr = (float(v) for v in g[f"sw_args_{n}"])
+        iq = g[f"sw_iq_{n}"]
+        ns = iq.shape[0]
+        d_db, d_pk = G.empty((ns, n), torch.float32), G.empty((ns,), torch.float32)
+        d_bw, d_cnt = G.empty((ns,), torch.float64), G.empty((ns,), torch.int32)
+        e.scan_threshold(G.dev(iq), ns, n, fs, thr, d_db, d_pk, d_bw, d_cnt)
+        e.sync()
+        db, pk, bw, cnt = G.host(d_db), G.host(d_pk), G.host(d_bw), G.host(d_cnt)
+        ref = g[f"sw_db_{n}"]
+        assert np.all(np.abs(db - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0)), n
+        for k in range(ns):
+            assert abs(pk[k] - g[f"sw_peak_{n}"][k]) <= 1e-4 * abs(g[f"sw_peak_{n}"][k])
+            near = int(np.sum(np.abs(ref[k] - np.float32(thr)) < 2e-3))
+            assert abs(int(cnt[k]) - int(g[f"sw_count_{n}"][k])) <= near
+            assert bw[k] == cnt[k] * (fs / n) and pk[k] == db[k].max() and cnt[k] == int(np.sum(db[k] > np.float32(thr)))
+        # the per-read numbers alone (no dB rows handed back) are the same numbers
+        d_pk2, d_cnt2 = G.empty((ns,), torch.float32), G.empty((ns,), torch.int32)
+        e.scan_threshold(G.dev(iq), ns, n, fs, thr, None, d_pk2, None, d_cnt2)
+        e.sync()
+        assert np.array_equal(G.host(d_pk2), pk) and np.array_equal(G.host(d_cnt2), cnt)
+    rng = np.random.default_rng(23)
+    for nf, n in ((5, 240000), (9, 1000), (3, 65537), (2, 524288), (4, 3)):
+        iq = (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n))).astype(np.complex64) * 0.2
+        iq[:, : n // 2] += (0.4 * np.exp(2j * np.pi * 0.123 * np.arange(n // 2))).astype(np.complex64)
+        db = G.spectrum(iq)
+        d_db, d_pk = G.empty((nf, n), torch.float32), G.empty((nf,), torch.float32)
+        d_bw, d_cnt = G.empty((nf,), torch.float64), G.empty((nf,), torch.int32)
+        e.scan(G.dev(iq), nf, n, 2.4e6, d_db, d_pk, d_bw, d_cnt)
+        e.sync()
+        sdb, pk, cnt = G.host(d_db), G.host(d_pk), G.host(d_cnt)
+        for k in (0, nf - 1):
+            o = O.compute_fft(iq[k])
+            assert np.all(np.abs(db[k] - o) <= 1e-4 * np.maximum(np.abs(o), 1e-2)), (n, k)
+            odb, opk, obw, ocnt = O.scan_slice(iq[k], 2.4e6)
+            assert np.all(np.abs(sdb[k] - odb) <= 1e-4 * np.maximum(np.abs(odb), 1.0)), (n, k)
+            near = int(np.sum(np.abs(odb - (opk - 20)) < 2e-3))
+            assert abs(float(pk[k]) - float(opk)) <= 1e-4 * abs(float(opk)) and abs(int(cnt[k]) - ocnt) <= near, (n, k)
+
+
 def test_waterfall_and_persistence_cells(golden):
     g = golden["caller"]
     e = G.engine()

@@ -292,3 +292,24 @@ def test_morse_edges_and_ax25_bookkeeping(golden):
         bits = [int(b) for b in g["ax_bits"][off[k]:off[k + 1]]]
         got = D.decode_ax25_frame(bits)
         assert ("<None>" if got is None else got) == str(want), k
+
+
+def test_lengths_that_are_not_a_power_of_two(golden):
+    """compute_fft and the sweep driver's per-read arithmetic (pyspecsdr.py:1049-1057) on frame lengths NumPy's fft accepts and
+    a radix-2 transform does not (1000, 3001, 24 000 = int(0.1 * 240 kS/s), 17): Bluestein in the oracle."""
+    g = golden["spectrum"]
+    for n in g["np2_sizes"]:
+        for iq, ref in zip(g[f"iq_np2_{n}"], g[f"db_np2_{n}"]):
+            db = O.compute_fft(iq)
+            assert np.all(np.abs(db - ref) <= 1e-9 * np.maximum(np.abs(ref), 1.0)), n
+    g = golden["scanner"]
+    for n in g["sw_sizes"]:
+        fs, thr = g[f"sw_args_{n}"]
+        for k, iq in enumerate(g[f"sw_iq_{n}"]):
+            db, pk, bw, cnt = O.scan_threshold(iq, float(fs), float(thr))
+            ref = g[f"sw_db_{n}"][k]
+            assert np.all(np.abs(db - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0)), n
+            assert abs(pk - g[f"sw_peak_{n}"][k]) <= 1e-4 * abs(g[f"sw_peak_{n}"][k])
+            near = int(np.sum(np.abs(ref - np.float32(thr)) < 2e-3))      # bins sitting on the threshold
+            assert abs(cnt - int(g[f"sw_count_{n}"][k])) <= near
+            assert abs(bw - g[f"sw_bw_{n}"][k]) <= near * fs / n + 1e-6

@@ -139,6 +139,21 @@ def classify():
     return {"config": "classify_signal (Welch PSD + modulation index + flatness + label)", "calls": out}
 
 
+def sweep():
+    """The sweep driver's reads (pyspecsdr.py:1022-1093): 0.1 s dwells of 240 000 samples — not a power of two, i.e. the Bluestein
+    path — spectrum rows + max power + bins above a threshold, and classify_signal on the same reads."""
+    nf, n = 64, 240000
+    iq = rand_iq(nf, n)
+    db = torch.empty((nf, n), dtype=torch.float32, device=dev)
+    pk = torch.empty((nf,), dtype=torch.float32, device=dev)
+    bw = torch.empty((nf,), dtype=torch.float64, device=dev)
+    cnt = torch.empty((nf,), dtype=torch.int32, device=dev)
+    out = [timed(f"scan_threshold {n} x{nf}", lambda: eng.scan_threshold(iq, nf, n, 2.4e6, -10.0, db, pk, bw, cnt), reps=3),
+           timed(f"spectrum_db (Hamming) {n} x{nf}", lambda: eng.spectrum_db(iq, nf, n, db), reps=3)]
+    return {"config": "sweep driver reads, 64 x 240000 (Bluestein, M = 2^19)", "calls": out,
+            "samples_per_s": nf * n / (out[0]["wall_ms"] * 1e-3)}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5"]
     for w in which:

@@ -154,6 +154,12 @@ def gen_spectrum():
         d[f"post_{n}"] = np.stack(post)
     z = np.zeros(1024, np.complex64)
     d["db_zero"] = sp.compute_fft(z)
+    # lengths that are not a power of two (np.fft.fft takes any length; the sweep driver reads int(0.1 * fs) samples)
+    for n, seed in [(1000, 17), (3001, 18), (24000, 19), (17, 20)]:
+        iq = fm_iq(1, n, 2.4e6, seed)
+        d[f"iq_np2_{n}"] = iq
+        d[f"db_np2_{n}"] = np.stack([sp.compute_fft(f) for f in iq])
+    d["np2_sizes"] = np.array([1000, 3001, 24000, 17])
     save("spectrum", **d)
 
 
@@ -528,6 +534,22 @@ def gen_scanner():
         d[f"bw_{n}"] = np.array(bws)
         d[f"count_{n}"] = np.array([int(round(b / (fs / n))) for b in bws])
         assert d[f"db_{n}"].dtype == np.float32
+    # the sweep driver's per-read statements, pyspecsdr.py:1049-1057 (scan_frequencies): a read of int(SCAN_DWELL_TIME * fs)
+    # samples (not a power of two) against an absolute threshold
+    for n, fs, thr, seed in [(24000, 240e3, -10.0, 63), (5000, 50e3, 5.0, 64), (2048, 2.4e6, 0.0, 65)]:
+        iq = scan_iq(3, n, fs, seed)
+        dbs, peaks, bws, cnts = [], [], [], []
+        for s_ in iq:
+            spectrum = np.fft.fftshift(np.fft.fft(s_))
+            power_db = 10 * np.log10(np.abs(spectrum) ** 2 + 1e-10)
+            max_power = np.max(power_db)
+            mask = power_db > thr
+            bandwidth = np.sum(mask) * (fs / len(power_db))
+            dbs.append(power_db); peaks.append(max_power); bws.append(bandwidth); cnts.append(int(np.sum(mask)))
+        d[f"sw_iq_{n}"] = iq; d[f"sw_db_{n}"] = np.stack(dbs); d[f"sw_peak_{n}"] = np.array(peaks)
+        d[f"sw_bw_{n}"] = np.array(bws); d[f"sw_count_{n}"] = np.array(cnts); d[f"sw_args_{n}"] = np.array([fs, thr])
+        assert d[f"sw_db_{n}"].dtype == np.float32
+    d["sw_sizes"] = np.array([24000, 5000, 2048])
     save("scanner", **d)
 
 
