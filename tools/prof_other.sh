@@ -3,10 +3,10 @@
 #   bash tools/prof_other.sh r01
 set -u
 TAG=${1:-r01}
-OUT=gpurun_out/prof_other_$TAG
+OUT=gpurun_out/prof_other_${TAG}${3:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-CMD="python tools/bench_configs.py wfm cfg3"
+CMD=${2:-"python tools/bench_configs.py wfm cfg3"}   # bash tools/prof_other.sh r01h "python tools/bench_configs.py classify sweep"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt -- $CMD > "$OUT/kt.log" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT" -o write -- $CMD > "$OUT/write.log" 2>&1
