@@ -979,11 +979,10 @@ static int scan_rows(pss_ctx *ctx, const float *d_iq, long n_slices, int n, floa
     }
     *rows = d_db;
     if (is_pow2(n) && n >= 16 && n <= 16384) {
-        float *pk = nullptr;   // launch_spectrum<true> wants a peak buffer: use the tail of the same scratch? simpler: a tiny one
+        // the one-kernel scanner path also produces its peak-relative numbers; they land in a throw-away buffer here
         int r = pss_ensure_buffer(ctx, &ctx->scratch_pk, &ctx->scratch_pk_bytes, (size_t)n_slices * sizeof(float), "scan peaks");
         if (r) return r;
-        pk = reinterpret_cast<float *>(ctx->scratch_pk);
-        return launch_spectrum<true>(ctx, d_iq, n_slices, n, d_db, pk, nullptr, nullptr, 0.0);
+        return launch_spectrum<true>(ctx, d_iq, n_slices, n, d_db, reinterpret_cast<float *>(ctx->scratch_pk), nullptr, nullptr, 0.0);
     }
     return bluestein_db(ctx, d_iq, n_slices, n, false, d_db);
 }
