@@ -1,0 +1,37 @@
+"""Run the reference application UNMODIFIED on top of libpss.so:
+
+    python -m pyspecsdr_amd.run /path/to/PySpecSDR/pyspecsdr.py [its own arguments]
+
+The reference reaches its hot path through two module names — `from signal_processing import *` (pyspecsdr.py:98) and
+`import decoders` (pyspecsdr.py:100; decoders.py:3 imports `bandpass_filter` from `signal_processing` again).  `install()`
+registers the drop-in modules under exactly those names in `sys.modules` before the script starts, so every such import
+resolves to the GPU-backed implementation and no file of the reference is edited.
+"""
+import os
+import runpy
+import sys
+
+
+def install():
+    """Make `signal_processing` and `decoders` resolve to the drop-in modules for the rest of this process."""
+    from . import decoders, signal_processing
+    sys.modules["signal_processing"] = signal_processing
+    sys.modules["decoders"] = decoders
+    return signal_processing, decoders
+
+
+def main(argv=None):
+    argv = list(sys.argv if argv is None else argv)
+    if len(argv) < 2:
+        print(__doc__)
+        return 2
+    script = os.path.abspath(argv[1])
+    install()
+    sys.argv = [script] + argv[2:]
+    sys.path.insert(0, os.path.dirname(script))          # what `python script.py` would put first
+    runpy.run_path(script, run_name="__main__")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

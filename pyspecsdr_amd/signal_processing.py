@@ -24,6 +24,11 @@ import numpy as np
 from . import _lib as L
 from .engine import Engine
 
+# what `from signal_processing import *` hands to the caller (pyspecsdr.py:98): the reference's public callables
+__all__ = ["bandpass_filter", "iq_correction", "mono_to_stereo", "demodulate_nfm", "demodulate_wfm", "demodulate_am",
+           "demodulate_ssb", "demodulate_signal", "compute_fft", "estimate_modulation_index", "classify_signal",
+           "measure_signal_power", "DEFAULT_SAMPLE_RATE", "BUTTER_ORDER"]
+
 DEFAULT_SAMPLE_RATE = 22050  # pyspecconst.py:3
 BUTTER_ORDER = 5             # pyspecconst.py:5
 

@@ -136,3 +136,21 @@ def test_formats_host_side(tmp_path):
     with wave.open(w, "rb") as f:
         assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (2, 2, 22050, 10)
         assert f.readframes(10) == pcm.tobytes() == formats.pipe_bytes(pcm)
+
+
+def test_zero_edit_dropin_resolves_the_reference_module_names(tmp_path):
+    """pyspecsdr_amd.run.install(): `from signal_processing import *` / `import decoders` (pyspecsdr.py:98,100; decoders.py:3)
+    resolve to the drop-in modules, with the reference's public names and nothing else leaking through the star import."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    app = tmp_path / "app.py"
+    app.write_text("from signal_processing import *\nimport decoders\nimport signal_processing as m\n"
+                   "assert m.__name__ == 'pyspecsdr_amd.signal_processing' and decoders.__name__ == 'pyspecsdr_amd.decoders'\n"
+                   "for f in (compute_fft, demodulate_signal, measure_signal_power, classify_signal, bandpass_filter, iq_correction,\n"
+                   "          decoders.decode_aprs, decoders.decode_morse, decoders.decode_afsk, decoders.decode_ax25_frame):\n"
+                   "    assert callable(f)\n"
+                   "assert 'get_engine' not in globals() and 'Engine' not in globals() and 'L' not in globals()\n"
+                   "import sys; print('ARGS', sys.argv[1:])\n")
+    out = subprocess.run([sys.executable, "-m", "pyspecsdr_amd.run", str(app), "--demod", "WFM"], cwd=root, check=True,
+                         capture_output=True, text=True, timeout=300).stdout
+    assert "ARGS ['--demod', 'WFM']" in out
