@@ -107,7 +107,23 @@ struct Cfg {
 // 16-point DFT, twiddle, exchange, radix-R3 butterflies.  emit(i, kp, X) is called for the thread's 16 results, kp being
 // the frequency index inside this N = 256*R3 transform.  Contains three workgroup barriers; the caller adds the one
 // that separates consecutive frames.
-template <int LOG_R3, class Emit>
+// Synchronisation between an LDS exchange's writes and reads.  WAVE_LOCAL: the T <= 64 threads of a frame are lanes of ONE
+// wavefront (k_spectrum_r16 at N <= 1024: tid = frame * T + t); a wavefront's LDS instructions execute in order, so only
+// the compiler has to be kept from reordering them — no s_barrier, and the frames of a workgroup no longer wait for
+// each other three times per transform.
+template <bool WAVE_LOCAL>
+__device__ __forceinline__ void frame_sync()
+{
+    if constexpr (WAVE_LOCAL) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int LOG_R3, bool WAVE_LOCAL = false, class Emit>
 __device__ __forceinline__ void r16_core(double2 (&v)[16], double2 *ex, const double2 (&tw1)[16], const double2 *tw2,
                                          int t, Emit emit)
 {
@@ -121,10 +137,10 @@ __device__ __forceinline__ void r16_core(double2 (&v)[16], double2 *ex, const do
         if (k2) y = cmul(y, tw1[k2]);
         ex[k2 * C::E1_STRIDE + t] = y;
     }
-    __syncthreads();
+    frame_sync<WAVE_LOCAL>();
 #pragma unroll
     for (int m2 = 0; m2 < 16; m2++) v[m2] = ex[k2s * C::E1_STRIDE + m1s + R3 * m2];
-    __syncthreads();
+    frame_sync<WAVE_LOCAL>();
     fft_reg<16>(v);
 #pragma unroll
     for (int j2 = 0; j2 < 16; j2++) {
@@ -132,7 +148,7 @@ __device__ __forceinline__ void r16_core(double2 (&v)[16], double2 *ex, const do
         if (R3 > 1) z = cmul(z, tw2[m1s * 16 + j2]);
         ex[m1s * C::E2_STRIDE + 16 * j2 + k2s] = z;
     }
-    __syncthreads();
+    frame_sync<WAVE_LOCAL>();
 #pragma unroll
     for (int c = 0; c < 16 / R3; c++) {
         double2 b[R3];
@@ -147,7 +163,7 @@ __device__ __forceinline__ void r16_core(double2 (&v)[16], double2 *ex, const do
 // The same transform with the two LDS exchanges done one COMPONENT at a time (real parts, then imaginary parts): the
 // exchange buffer shrinks to EX doubles per frame, which doubles the workgroups a CU can hold (the kernel is LDS-capacity
 // bound at 2 workgroups per CU otherwise) at the price of twice the barriers.  Same arithmetic, same results.
-template <int LOG_R3, class Emit>
+template <int LOG_R3, bool WAVE_LOCAL = false, class Emit>
 __device__ __forceinline__ void r16_core_split(double2 (&v)[16], double *ex, const double2 (&tw1)[16], const double2 *tw2,
                                                int t, Emit emit)
 {
@@ -163,16 +179,16 @@ __device__ __forceinline__ void r16_core_split(double2 (&v)[16], double *ex, con
     }
 #pragma unroll
     for (int k2 = 0; k2 < 16; k2++) ex[k2 * C::E1_STRIDE + t] = y[k2].x;
-    __syncthreads();
+    frame_sync<WAVE_LOCAL>();
 #pragma unroll
     for (int m2 = 0; m2 < 16; m2++) v[m2].x = ex[k2s * C::E1_STRIDE + m1s + R3 * m2];
-    __syncthreads();
+    frame_sync<WAVE_LOCAL>();
 #pragma unroll
     for (int k2 = 0; k2 < 16; k2++) ex[k2 * C::E1_STRIDE + t] = y[k2].y;
-    __syncthreads();
+    frame_sync<WAVE_LOCAL>();
 #pragma unroll
     for (int m2 = 0; m2 < 16; m2++) v[m2].y = ex[k2s * C::E1_STRIDE + m1s + R3 * m2];
-    __syncthreads();
+    frame_sync<WAVE_LOCAL>();
     fft_reg<16>(v);
 #pragma unroll
     for (int j2 = 0; j2 < 16; j2++) {
@@ -181,15 +197,15 @@ __device__ __forceinline__ void r16_core_split(double2 (&v)[16], double *ex, con
     }
 #pragma unroll
     for (int j2 = 0; j2 < 16; j2++) ex[m1s * C::E2_STRIDE + 16 * j2 + k2s] = y[j2].x;
-    __syncthreads();
+    frame_sync<WAVE_LOCAL>();
 #pragma unroll
     for (int c = 0; c < 16 / R3; c++)
 #pragma unroll
         for (int m1 = 0; m1 < R3; m1++) v[c * R3 + m1].x = ex[m1 * C::E2_STRIDE + t + T * c];
-    __syncthreads();
+    frame_sync<WAVE_LOCAL>();
 #pragma unroll
     for (int j2 = 0; j2 < 16; j2++) ex[m1s * C::E2_STRIDE + 16 * j2 + k2s] = y[j2].y;
-    __syncthreads();
+    frame_sync<WAVE_LOCAL>();
 #pragma unroll
     for (int c = 0; c < 16 / R3; c++)
 #pragma unroll
@@ -256,8 +272,9 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
             dbv[i] = d;
             lmax = fmaxf(lmax, d);
         };
-        if (SPLIT) r16_core_split<LOG_R3>(v, reinterpret_cast<double *>(smem) + (size_t)fl * C::EX, tw1, tw2, t, emit);
-        else r16_core<LOG_R3>(v, ex, tw1, tw2, t, emit);
+        constexpr bool WL = T <= 64;  // a frame's threads are lanes of one wavefront: no workgroup barriers in the transform
+        if (SPLIT) r16_core_split<LOG_R3, WL>(v, reinterpret_cast<double *>(smem) + (size_t)fl * C::EX, tw1, tw2, t, emit);
+        else r16_core<LOG_R3, WL>(v, ex, tw1, tw2, t, emit);
         if (SCAN) {
             // per-frame peak and 20-dB-down bin count (pyspecsdr.py:2546-2552); T threads own one frame
             float m = lmax;
@@ -285,7 +302,7 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
                 if (count) count[f] = cnt;
             }
         }
-        __syncthreads();
+        frame_sync<T <= 64 && !SCAN>();  // the next frame overwrites this frame's exchange buffer (SCAN's reductions use barriers)
     }
 }
 
