@@ -51,7 +51,9 @@ int pss_device_count(void);
  *   "small_batch" (1)          0: never take the latency-oriented small-batch kernels (one lane per filter section)
  *   "small_batch_max" (8192)   largest NFM frame count that takes them;  "wfm_small_batch_max" (8192) likewise for WFM
  *   "post_sort_max" (8192)     longest dB row post-processed with the LDS sort (longer rows: radix select)
- *   "fft_split" (-1 = auto)    1 / 0: force / forbid the component-wise LDS exchanges of the register FFT (auto: N = 256) */
+ *   "fft_split" (-1 = auto)    1 / 0: force / forbid the component-wise LDS exchanges of the register FFT (auto: N = 256)
+ *   "fft_prefetch" (-1 = auto) 1 / 0: force / forbid requesting the next frame's samples before transforming the current one
+ *                              (auto: N = 1024 and 2048) */
 int pss_set_option(pss_ctx *ctx, const char *key, int value);
 
 /* ---- filter design (host side, pure C++; replaces the per-call SciPy design work) -------------- */

@@ -62,6 +62,7 @@ struct pss_ctx {
     long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~12000)
     long wfm_small_batch_max = 8192;  // option "wfm_small_batch_max" (measured crossover with the fused kernels ~12000 frames)
     int post_sort_max = 8192;  // option "post_sort_max": longest row that takes the LDS bitonic sort, else radix select (measured crossover 8192..16384)
+    int fft_prefetch = -1;  // option "fft_prefetch": request the next frame's samples before transforming the current one; -1 = automatic
     int fft_split = -1;  // option "fft_split": component-wise LDS exchanges in k_spectrum_r16; -1 = automatic (N = 256 only)
     bool no_small_batch = false;  // option "small_batch" = 0: never take the systolic small-batch NFM path (A/B testing)
     bool no_fused = false;  // PSS_NO_FUSED=1: use the three-kernel NFM path (A/B and fallback testing)

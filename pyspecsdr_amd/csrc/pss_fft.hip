@@ -605,7 +605,11 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     // component-wise LDS exchanges (half the LDS, twice the barriers) pay only at N = 256, where the plain kernel fits a
     // single 80 KB workgroup per CU: 0.29 -> 0.20 ms for 262144 frames; at 512...2048 they measured 20 % slower
     const bool split = ctx->fft_split >= 0 ? ctx->fft_split != 0 : LOG_R3 == 0;
-    auto kern = split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, false>;
+    // next-frame prefetch (option "fft_prefetch", -1 = automatic), A/B in one process: N = 1024: 0.198 -> 0.185 ms (65536 frames),
+    // 2048: 0.234 -> 0.226 ms; 512: no change; 4096: 0.27 -> 0.35 ms (274 VGPRs: one wavefront per SIMD); 256: the split kernel wins
+    const bool prefetch = !split && (ctx->fft_prefetch >= 0 ? ctx->fft_prefetch != 0 : (LOG_R3 == 2 || LOG_R3 == 3));
+    auto kern = split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true, false>
+                : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, true> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, false>;
     const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2) : C::LDS;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

@@ -221,7 +221,7 @@ __device__ __forceinline__ void r16_core_split(double2 (&v)[16], double *ex, con
     }
 }
 
-template <int LOG_R3, bool SCAN, bool SPLIT = false>
+template <int LOG_R3, bool SCAN, bool SPLIT = false, bool PREFETCH = false>
 __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__ iq, float *__restrict__ db,
                                                       const double2 *__restrict__ tw, const double *__restrict__ win,
                                                       long n_frames, float *__restrict__ peak, double *__restrict__ bw,
@@ -253,16 +253,24 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
     }
     __syncthreads();
     const long groups = (n_frames + FPW - 1) / FPW;
+    // PREFETCH: the next frame's samples are requested before this frame is transformed and converted when it comes up.
+    // Costs ~100 VGPRs (the unsplit kernel is LDS-bound at two wavefronts per SIMD, where 256 are available).
+    float2 nx[16];
+    auto fetch = [&](long g) {
+        const long f = g * FPW + fl;
+        const float2 *x = iq + (size_t)(f < n_frames ? f : 0) * N;
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++) nx[n2] = x[t + T * n2];
+    };
+    if (PREFETCH && (long)blockIdx.x < groups) fetch(blockIdx.x);
     for (long g = blockIdx.x; g < groups; g += gridDim.x) {
         const long f = g * FPW + fl;
         const bool valid = f < n_frames;
-        const float2 *x = iq + (size_t)(valid ? f : 0) * N;
         double2 v[16];
+        if constexpr (!PREFETCH) fetch(g);
 #pragma unroll
-        for (int n2 = 0; n2 < 16; n2++) {
-            float2 s = x[t + T * n2];
-            v[n2] = make_double2((double)s.x * w[n2], (double)s.y * w[n2]);
-        }
+        for (int n2 = 0; n2 < 16; n2++) v[n2] = make_double2((double)nx[n2].x * w[n2], (double)nx[n2].y * w[n2]);
+        if (PREFETCH && g + gridDim.x < groups) fetch(g + gridDim.x);
         float *out = (db && valid) ? db + (size_t)f * N : nullptr;
         float lmax = -INFINITY;
         float dbv[16];

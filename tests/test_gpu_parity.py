@@ -39,19 +39,23 @@ def test_spectrum_vs_golden(golden, n):
 
 
 def test_spectrum_split_exchange_is_bit_identical():
-    # the component-wise LDS exchange variant of the register FFT (automatic at N = 256) must not change a bit
+    # the component-wise LDS exchange variant of the register FFT (automatic at N = 256) and the next-frame prefetch
+    # (automatic at N = 1024, 2048) must not change a bit; 5000 frames make every workgroup loop over several frames
     rng = np.random.default_rng(44)
     e = G.engine()
     for n in (256, 1024, 4096):
-        iq = (rng.standard_normal((40, n)) + 1j * rng.standard_normal((40, n))).astype(np.complex64)
+        iq = (rng.standard_normal((5000, n)) + 1j * rng.standard_normal((5000, n))).astype(np.complex64)
         res = []
-        for sp in (0, 1):
+        for sp, pf in ((0, 0), (1, 0), (0, 1)):
             e.set_option("fft_split", sp)
+            e.set_option("fft_prefetch", pf)
             try:
                 res.append(G.spectrum(iq))
             finally:
                 e.set_option("fft_split", -1)
+                e.set_option("fft_prefetch", -1)
         assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32)), n
+        assert np.array_equal(res[0].view(np.uint32), res[2].view(np.uint32)), n
 
 
 def test_spectrum_zero_and_large(golden):
