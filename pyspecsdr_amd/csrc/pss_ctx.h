@@ -22,6 +22,7 @@ struct PssWfmFilt {
 
 struct PssPairwisePlan {  // numpy pairwise-sum tree for one frame length (see pss_demod.hip)
     int n_leaves = 0, n_nodes = 0, n_levels = 0, n_roots = 0;
+    int wave_tree = 0;  // 64 (leaf, accumulator) pairs and a perfectly balanced tree over equal leaves: one wavefront can fold it with xor shuffles
     int *d_leaf_off = nullptr, *d_leaf_len = nullptr, *d_node_l = nullptr, *d_node_r = nullptr, *d_level_start = nullptr;
     int *d_roots = nullptr;
 };

@@ -842,6 +842,7 @@ __global__ __launch_bounds__(TPB) void k_finalize(const double *__restrict__ Yf,
 struct PlanDev {
     const int *leaf_off, *leaf_len, *node_l, *node_r, *level_start, *roots;
     int n_leaves, n_levels, n_roots, n_nodes;
+    int wave_tree;  // see PssPairwisePlan::wave_tree
 };
 // The plan tables are walked with DEPENDENT loads several times per reduction (offsets -> elements, one round per tree
 // level): read from global memory that was ~8 us per pass and dominated k_iqcorr (8 passes per frame).  Every workgroup
@@ -873,15 +874,34 @@ struct RedPlan {
 // A leaf of numpy's tree is <= 128 elements summed into 8 running accumulators; those 8 partial sums are independent,
 // so a lane owns one (leaf, accumulator) pair — at n = 1024 that is exactly one wavefront per frame — and one lane per
 // leaf then folds the 8 partials and the < 8 tail elements in numpy's order.  part: 8 floats per leaf.
-template <class F>
+template <bool WT = false, class F>
 __device__ __forceinline__ float wg_rsum(const PlanDev &p, float *part, float *val, F elem, float carry, bool have)
 {
     const int tid = threadIdx.x, T = blockDim.x;
+    if constexpr (WT) {  // the host guarantees: p.wave_tree, a 64-thread workgroup, a single group (no carry)
+        // n = 1024: 8 leaves x 8 accumulators = the 64 lanes of the one wavefront of this workgroup, and numpy's tree is
+        // perfectly balanced — ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) inside a leaf, adjacent halves above it.  IEEE addition is
+        // commutative, so an xor-butterfly computes exactly those sums (in every lane): no LDS, no barriers.
+        const int l = tid >> 3, k = tid & 7, off = l * 128;
+        float r = elem(off + k);
+#pragma unroll
+        for (int i = 8; i < 128; i += 8) r = __fadd_rn(r, elem(off + i + k));
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) r = __fadd_rn(r, __shfl_xor(r, m));
+        return r;
+    }
     for (int slot = tid; slot < p.n_leaves * 8; slot += T) {
         const int l = slot >> 3, k = slot & 7, off = p.leaf_off[l], len = p.leaf_len[l];
         if (len >= 8) {
+            // the additions are a dependent chain in numpy's order; the operands are not: fetch four ahead of the chain
             float r = elem(off + k);
-            for (int i = 8; i < len - (len % 8); i += 8) r = __fadd_rn(r, elem(off + i + k));
+            const int end = len - (len % 8);
+            int i = 8;
+            for (; i + 24 < end; i += 32) {
+                const float a = elem(off + i + k), b = elem(off + i + 8 + k), c = elem(off + i + 16 + k), d = elem(off + i + 24 + k);
+                r = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(r, a), b), c), d);
+            }
+            for (; i < end; i += 8) r = __fadd_rn(r, elem(off + i + k));
             part[slot] = r;
         }
     }
@@ -919,15 +939,40 @@ __device__ __forceinline__ float wg_rsum(const PlanDev &p, float *part, float *v
 }
 // complex64 reduce: elem(ci) -> float2 of complex element ci; leaves are float ranges of the interleaved array, the 8
 // float accumulators are 4 complex ones: a lane owns one (leaf, complex accumulator) pair.  part: 4 float2 per leaf.
-template <class F>
+template <bool WT = false, class F>
 __device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *part, float2 *val, F elem, float2 carry, bool have)
 {
     const int tid = threadIdx.x, T = blockDim.x;
+    if constexpr (WT) {
+        // 1024 complex = 2048 floats: 16 leaves x 4 complex accumulators = 64 lanes; same butterfly as wg_rsum
+        const int l = tid >> 2, k = tid & 3, off = l * 64;  // complex offset of the leaf
+        float2 r = elem(off + k);
+#pragma unroll
+        for (int i = 4; i < 64; i += 4) {
+            const float2 v = elem(off + i + k);
+            r.x = __fadd_rn(r.x, v.x);
+            r.y = __fadd_rn(r.y, v.y);
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            r.x = __fadd_rn(r.x, __shfl_xor(r.x, m));
+            r.y = __fadd_rn(r.y, __shfl_xor(r.y, m));
+        }
+        return r;
+    }
     for (int slot = tid; slot < p.n_leaves * 4; slot += T) {
         const int l = slot >> 2, k = slot & 3, off = p.leaf_off[l] >> 1, len = p.leaf_len[l];  // off: complex, len: floats
         if (len >= 8) {
             float2 r = elem(off + k);
-            for (int i = 8; i < len - (len % 8); i += 8) {
+            const int end = len - (len % 8);
+            int i = 8;
+            for (; i + 24 < end; i += 32) {  // operands fetched four ahead of the dependent additions
+                const float2 a = elem(off + (i >> 1) + k), b = elem(off + ((i + 8) >> 1) + k), c = elem(off + ((i + 16) >> 1) + k),
+                             d = elem(off + ((i + 24) >> 1) + k);
+                r.x = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(r.x, a.x), b.x), c.x), d.x);
+                r.y = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(r.y, a.y), b.y), c.y), d.y);
+            }
+            for (; i < end; i += 8) {
                 const float2 v = elem(off + (i >> 1) + k);
                 r.x = __fadd_rn(r.x, v.x);
                 r.y = __fadd_rn(r.y, v.y);
@@ -974,9 +1019,10 @@ __device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *part, float2
     return sum;
 }
 // whole-frame reductions: loop over the groups, elem(i) indexed from the start of the frame
-template <class F>
+template <bool WT = false, class F>
 __device__ __forceinline__ float frame_rsum(const RedPlan &rp, float *part, float *val, F elem)
 {
+    if constexpr (WT) return wg_rsum<true>(rp.tail, part, val, elem, 0.0f, false);
     float acc = 0.0f;
     bool have = false;
     for (int g = 0; g < rp.n_full; g++) {
@@ -990,9 +1036,10 @@ __device__ __forceinline__ float frame_rsum(const RedPlan &rp, float *part, floa
     }
     return acc;
 }
-template <class F>
+template <bool WT = false, class F>
 __device__ __forceinline__ float2 frame_csum(const RedPlan &rp, float2 *part, float2 *val, F elem)
 {
+    if constexpr (WT) return wg_csum<true>(rp.tail, part, val, elem, make_float2(0.0f, 0.0f), false);
     float2 acc = make_float2(0.0f, 0.0f);
     bool have = false;
     for (int g = 0; g < rp.n_full; g++) {
@@ -1010,7 +1057,7 @@ __device__ __forceinline__ float2 frame_csum(const RedPlan &rp, float2 *part, fl
 // np.mean float32 of |x| (KIND 1, AM: signal_processing.py:185) or |x|^2 (KIND 0, power: :327), one workgroup per frame;
 // the (leaf, accumulator) lanes read global memory directly (every element is used exactly once; staging the frame in
 // LDS first measured 2-3x slower: fewer resident workgroups, one more barrier).  LDS: [part: 8 floats per leaf][val]
-template <int KIND>
+template <int KIND, bool WT = false>
 __global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq, int n, long n_frames, RedPlan rp,
                                                   int part_slots, int val_slots, float *__restrict__ out, float *__restrict__ env)
 {
@@ -1024,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq,
     }
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const float2 *x = iq + (size_t)f * n;
-        const float sum = frame_rsum(rp, part, val, [&](int i) {
+        const float sum = frame_rsum<WT>(rp, part, val, [&](int i) {
             const float2 v = x[i];
             const float m = cabsf_np(v.x, v.y);
             if (KIND == 1 && env) env[(size_t)f * n + i] = m;  // the AM envelope (:182), reused by the band-pass kernel
@@ -1039,7 +1086,7 @@ __global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq,
 
 // STAGED: the frame is copied to LDS once and every pass reads it from there (frames up to 8192 samples).
 // LDS: [frame: n float2 if STAGED][part: part_slots float2][val: val_slots float2]
-template <bool STAGED>
+template <bool STAGED, bool WT = false>
 __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, int n, long n_frames, RedPlan rp, RedPlan cp,
                                                 int part_slots, int val_slots, float2 *__restrict__ out, float *__restrict__ raw)
 {
@@ -1065,25 +1112,25 @@ __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, i
         }
         auto X = [&](int i) { return STAGED ? xs[i] : xg[i]; };
         // :48 centered = samples - mean(samples)
-        float2 s = frame_csum(cp, cpart, cval, X);
+        float2 s = frame_csum<WT>(cp, cpart, cval, X);
         const float mr = __fdiv_rn(s.x, fn), mi = __fdiv_rn(s.y, fn);
         // :49 input_power = var(centered): mean again, re^2 + im^2 as three separately rounded float32 operations, mean
-        s = frame_csum(cp, cpart, cval, [&](int i) { float2 v = X(i); return make_float2(__fsub_rn(v.x, mr), __fsub_rn(v.y, mi)); });
+        s = frame_csum<WT>(cp, cpart, cval, [&](int i) { float2 v = X(i); return make_float2(__fsub_rn(v.x, mr), __fsub_rn(v.y, mi)); });
         const float m2r = __fdiv_rn(s.x, fn), m2i = __fdiv_rn(s.y, fn);
-        const float input_power = __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) {
+        const float input_power = __fdiv_rn(frame_rsum<WT>(rp, rpart, rval, [&](int i) {
             float2 v = X(i);
             const float dr = __fsub_rn(__fsub_rn(v.x, mr), m2r), di = __fsub_rn(__fsub_rn(v.y, mi), m2i);
             return __fadd_rn(__fmul_rn(dr, dr), __fmul_rn(di, di));  // np.var fast path: squares, then add (no fma)
         }), fn);
         // :52 q_amplitude
-        const float qa = sqrtf(__fmul_rn(2.0f, __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) { float q = X(i).y; return __fmul_rn(q, q); }), fn)));
+        const float qa = sqrtf(__fmul_rn(2.0f, __fdiv_rn(frame_rsum<WT>(rp, rpart, rval, [&](int i) { float q = X(i).y; return __fmul_rn(q, q); }), fn)));
         const float scl = __fdiv_rn(1.0f, qa);  // :55 complex64 / float32 scalar multiplies by the reciprocal
         // :60-61 alpha, sin(phi)
-        const float alpha = sqrtf(__fmul_rn(2.0f, __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) {
+        const float alpha = sqrtf(__fmul_rn(2.0f, __fdiv_rn(frame_rsum<WT>(rp, rpart, rval, [&](int i) {
             const float is = __fmul_rn(X(i).x, scl);
             return __fmul_rn(is, is);
         }), fn)));
-        const float sinphi = __fmul_rn(__fdiv_rn(2.0f, alpha), __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) {
+        const float sinphi = __fmul_rn(__fdiv_rn(2.0f, alpha), __fdiv_rn(frame_rsum<WT>(rp, rpart, rval, [&](int i) {
             float2 v = X(i);
             return __fmul_rn(__fmul_rn(v.x, scl), __fmul_rn(v.y, scl));
         }), fn));
@@ -1097,9 +1144,9 @@ __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, i
             return make_float2(__fmul_rn(__fadd_rn(i_new, jr), sc), __fmul_rn(__fadd_rn(0.0f, ji), sc));
         };
         // :80 var(corrected), rescale to the input power
-        s = frame_csum(cp, cpart, cval, corrected);
+        s = frame_csum<WT>(cp, cpart, cval, corrected);
         const float m3r = __fdiv_rn(s.x, fn), m3i = __fdiv_rn(s.y, fn);
-        const float v2 = __fdiv_rn(frame_rsum(rp, rpart, rval, [&](int i) {
+        const float v2 = __fdiv_rn(frame_rsum<WT>(rp, rpart, rval, [&](int i) {
             float2 c = corrected(i);
             const float dr = __fsub_rn(c.x, m3r), di = __fsub_rn(c.y, m3i);
             return __fadd_rn(__fmul_rn(dr, dr), __fmul_rn(di, di));  // np.var fast path: squares, then add (no fma)
@@ -1836,6 +1883,22 @@ int get_plan(pss_ctx *ctx, int len, PssPairwisePlan **out, bool cplx = false)
         for (auto &rt : roots) rt = slot_of(rt);
         PssPairwisePlan p;
         p.n_leaves = nleaf; p.n_nodes = nnode; p.n_levels = level; p.n_roots = (int)roots.size();
+        {   // one wavefront can fold the tree with shuffles if 64 (leaf, accumulator) pairs cover equal 128-float leaves in order
+            // and every node joins two adjacent, equally sized halves (true for 1024 floats and for 1024 complex)
+            bool ok = roots.size() == 1 && nleaf * (cplx ? 4 : 8) == 64;
+            for (int l = 0; ok && l < nleaf; l++) ok = ll[l] == 128 && lo[l] == 128 * l;
+            std::function<int(int, int &)> span = [&](int slot, int &first) -> int {  // leaves under slot, -1 if not perfect
+                if (slot < nleaf) { first = slot; return 1; }
+                int fl, fr;
+                const int a = span(L[slot - nleaf], fl), b = span(R[slot - nleaf], fr);
+                if (a < 0 || b < 0 || a != b || fr != fl + a) return -1;
+                first = fl;
+                return a + b;
+            };
+            int first = 0;
+            if (ok) ok = span(roots[0], first) == nleaf && first == 0;
+            p.wave_tree = ok ? 1 : 0;
+        }
         PSS_HIP(ctx, hipMalloc(&p.d_leaf_off, sizeof(int) * nleaf));
         PSS_HIP(ctx, hipMalloc(&p.d_leaf_len, sizeof(int) * nleaf));
         PSS_HIP(ctx, hipMalloc(&p.d_node_l, sizeof(int) * L.size()));
@@ -1856,9 +1919,9 @@ int get_plan(pss_ctx *ctx, int len, PssPairwisePlan **out, bool cplx = false)
 
 PlanDev plan_dev(const PssPairwisePlan *p)
 {
-    if (!p) return PlanDev{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    if (!p) return PlanDev{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
     return PlanDev{p->d_leaf_off, p->d_leaf_len, p->d_node_l, p->d_node_r, p->d_level_start, p->d_roots, p->n_leaves, p->n_levels,
-                   p->n_roots, p->n_nodes};
+                   p->n_roots, p->n_nodes, p->wave_tree};
 }
 
 // Group decomposition of a frame of n elements; slots = the largest (leaves, leaves + nodes + 1) over its group plans.
@@ -1901,12 +1964,13 @@ int launch_pairwise(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float
     if (r) return r;
     const int part_slots = 8 * leaves;
     const size_t lds = sizeof(float) * (size_t)(part_slots + vals) + plan_lds_bytes(rp);
-    auto kern = k_pairwise<KIND>;
+    const int lanes = 8 * leaves;  // one lane per (leaf, accumulator) pair
+    const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);
+    const bool wt = T == 64 && !rp.n_full && rp.tail.wave_tree;  // n = 1024: the whole tree folds inside one wavefront
+    auto kern = wt ? k_pairwise<KIND, true> : k_pairwise<KIND, false>;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
-    const int lanes = 8 * leaves;  // one lane per (leaf, accumulator) pair
-    const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);
     long g = n_frames < 8192 ? n_frames : 8192;  // several frames per workgroup: the plan tables are copied to LDS once
     pss_kernel_begin(ctx, "k_pairwise");
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, rp,
@@ -2004,12 +2068,13 @@ extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames,
     // staging pays while >= 2 workgroups fit a CU (measured: 0.59 vs 0.91 ms at 65536 x 1024, but 2.6 vs 1.8 ms at 8192 x 16384)
     const bool staged = n <= 8192;
     size_t lds = (part_slots + val_slots + (staged ? (size_t)n : 0)) * sizeof(float2) + plan_lds_bytes(rp) + plan_lds_bytes(cp);
-    auto kern = staged ? k_iqcorr<true> : k_iqcorr<false>;
+    const int lanes = rl * 8 > cl * 4 ? rl * 8 : cl * 4;
+    const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);  // one lane per (leaf, accumulator) pair
+    const bool wt = T == 64 && staged && !rp.n_full && !cp.n_full && rp.tail.wave_tree && cp.tail.wave_tree;  // n = 1024
+    auto kern = wt ? k_iqcorr<true, true> : (staged ? k_iqcorr<true, false> : k_iqcorr<false, false>);
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const RedPlan &a = rp, &b = cp;
-    const int lanes = rl * 8 > cl * 4 ? rl * 8 : cl * 4;
-    const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);  // one lane per (leaf, accumulator) pair
     long g = n_frames < 8192 ? n_frames : 8192;  // several frames per workgroup: the plan tables are copied to LDS once
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_iqcorr");
