@@ -882,7 +882,8 @@ __device__ __forceinline__ float wg_rsum(const PlanDev &p, float *part, float *v
         // n = 1024: 8 leaves x 8 accumulators = the 64 lanes of the one wavefront of this workgroup, and numpy's tree is
         // perfectly balanced — ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) inside a leaf, adjacent halves above it.  IEEE addition is
         // commutative, so an xor-butterfly computes exactly those sums (in every lane): no LDS, no barriers.
-        const int l = tid >> 3, k = tid & 7, off = l * 128;
+        const int lane = tid & 63;  // (in a wider workgroup every wavefront computes the same sums redundantly)
+        const int l = lane >> 3, k = lane & 7, off = l * 128;
         float r = elem(off + k);
 #pragma unroll
         for (int i = 8; i < 128; i += 8) r = __fadd_rn(r, elem(off + i + k));
@@ -945,7 +946,8 @@ __device__ __forceinline__ float2 wg_csum(const PlanDev &p, float2 *part, float2
     const int tid = threadIdx.x, T = blockDim.x;
     if constexpr (WT) {
         // 1024 complex = 2048 floats: 16 leaves x 4 complex accumulators = 64 lanes; same butterfly as wg_rsum
-        const int l = tid >> 2, k = tid & 3, off = l * 64;  // complex offset of the leaf
+        const int lane = tid & 63;
+        const int l = lane >> 2, k = lane & 3, off = l * 64;  // complex offset of the leaf
         float2 r = elem(off + k);
 #pragma unroll
         for (int i = 4; i < 64; i += 4) {
@@ -1609,12 +1611,16 @@ __global__ __launch_bounds__(256) void k_cls_welch(const float2 *__restrict__ iq
     for (int j = 0; j < 4; j++) w[j] = win[tid + 256 * j];
     __syncthreads();
     const long nseg = (n - CLS_NP) / CLS_STEP + 1;
+    const bool wave_tree = cp.tail.wave_tree && !cp.n_full;
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const float2 *x = iq + (size_t)f * n;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};  // positions tid + 256 j of the bit-reversed spectrum
         for (long sg = 0; sg < nseg; sg++) {
             const float2 *xs = x + sg * CLS_STEP;
-            const float2 m = frame_csum(cp, cpart, cval, [&](int i) { return xs[i]; });  // detrend: data - mean(data), complex64
+            // detrend: data - mean(data), complex64.  1024 complex = NumPy's perfectly balanced tree: each wavefront folds it with
+            // shuffles on its own (redundantly, no barrier); the general LDS walk remains for plans that are not (never here)
+            const float2 m = wave_tree ? wg_csum<true>(cp.tail, cpart, cval, [&](int i) { return xs[i]; }, make_float2(0.0f, 0.0f), false)
+                                       : frame_csum(cp, cpart, cval, [&](int i) { return xs[i]; });
             const float mr = __fdiv_rn(m.x, (float)CLS_NP), mim = __fdiv_rn(m.y, (float)CLS_NP);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
