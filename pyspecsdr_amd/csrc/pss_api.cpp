@@ -94,19 +94,35 @@ extern "C" int pss_create(int device, pss_ctx **out)
         return pss_fail(nullptr, PSS_E_HIP, std::string("no HIP device available (libpss has no CPU fallback): ") +
                                                 (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
     if (device < 0 || device >= n) return pss_fail(nullptr, PSS_E_ARG, "device index out of range");
+    int prev = -1;
+    hipGetDevice(&prev);
     e = hipSetDevice(device);
     if (e != hipSuccess) return pss_fail(nullptr, PSS_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    struct Restore {  // the caller's current device is left as it was
+        int prev, dev;
+        ~Restore() { if (prev >= 0 && prev != dev) hipSetDevice(prev); }
+    } restore{prev, device};
     pss_ctx *ctx = new pss_ctx();
     ctx->device = device;
     { const char *e = getenv("PSS_NO_FUSED"); ctx->no_fused = e && e[0] == '1'; }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete ctx; return pss_fail(nullptr, PSS_E_HIP, "hipStreamCreate failed"); }
-    ctx->own_stream = true;
-    hipEventCreate(&ctx->ev0);
-    hipEventCreate(&ctx->ev1);
-    hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
-    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
-    hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) ctx->own_stream = true;
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        const std::string msg = std::string("context stream / event creation: ") + hipGetErrorString(e);
+        if (ctx->ev0) hipEventDestroy(ctx->ev0);
+        if (ctx->ev1) hipEventDestroy(ctx->ev1);
+        if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+        if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+        if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+        if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return pss_fail(nullptr, PSS_E_HIP, msg);
+    }
     *out = ctx;
     return PSS_OK;
 }
@@ -114,7 +130,7 @@ extern "C" int pss_create(int device, pss_ctx **out)
 extern "C" void pss_destroy(pss_ctx *ctx)
 {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
+    PssDevGuard guard(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->tw) hipFree(kv.second);
     for (auto &kv : ctx->win) hipFree(kv.second);
@@ -144,6 +160,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
 extern "C" int pss_set_stream(pss_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -168,6 +185,7 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
 extern "C" int pss_sync(pss_ctx *ctx)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     return pss_hip_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
 
@@ -176,6 +194,7 @@ extern "C" const char *pss_last_error(pss_ctx *ctx) { return ctx ? ctx->err.c_st
 extern "C" int pss_enable_timing(pss_ctx *ctx, int on)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     ctx->timing = on != 0;
     ctx->tdepth = 0;
     ctx->kused = 0;
@@ -186,6 +205,7 @@ extern "C" int pss_enable_timing(pss_ctx *ctx, int on)
 extern "C" int pss_timing_filter(pss_ctx *ctx, const char *kernel)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     ctx->tfilter = kernel ? kernel : "";
     ctx->kused = 0;
     ctx->last_ms = -1.0f;
@@ -195,6 +215,7 @@ extern "C" int pss_timing_filter(pss_ctx *ctx, const char *kernel)
 extern "C" float pss_last_kernel_ms(pss_ctx *ctx)
 {
     if (!ctx || !ctx->timing || ctx->last_ms < 0.0f || !ctx->tfilter.empty()) return -1.0f;
+    PSS_GUARD(ctx);
     if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
     float ms = -1.0f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
@@ -205,6 +226,7 @@ extern "C" int pss_kernel_times(pss_ctx *ctx, char *buf, int buf_len)
 {
     // "name=ms;name=ms;..." for every kernel launched since timing was enabled / since the previous read
     if (!ctx || !buf || buf_len < 1) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     std::string out;
     if (ctx->timing && ctx->last_ms >= 0.0f) {
         if (ctx->tfilter.empty()) hipEventSynchronize(ctx->ev1);
@@ -232,6 +254,7 @@ size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" int pss_h_compute_fft(pss_ctx *ctx, const float *h_iq, int n, double *h_db)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!h_iq || !h_db || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
     const size_t o_db = up256(sizeof(float) * 2 * n);
     int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_db + up256(sizeof(float) * n), "staging");
@@ -295,6 +318,7 @@ extern "C" int pss_h_demodulate_batch(pss_ctx *ctx, int mode, const float *h_iq,
                                       long chunk_frames, int16_t *h_pcm)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!h_iq || !h_pcm || n_frames < 0 || n < 1 || chunk_frames < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
     const int n_out = pss_demod_out_len(mode, n, fs);
     if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "unknown mode or sample rate below 22050 Hz");
@@ -322,6 +346,7 @@ extern "C" int pss_h_demodulate_batch(pss_ctx *ctx, int mode, const float *h_iq,
 extern "C" int pss_h_measure_power(pss_ctx *ctx, const float *h_iq, int n, float *h_power)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!h_iq || !h_power || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
     const size_t o_p = up256(sizeof(float) * 2 * n);
     int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_p + 256, "staging");
@@ -339,6 +364,7 @@ extern "C" int pss_h_morse_edges(pss_ctx *ctx, const float *h_iq, int n, double 
                                  int32_t *h_fall, int *n_rise, int *n_fall)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!h_iq || n < 1 || cap < 0 || (cap > 0 && (!h_rise || !h_fall))) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
     const size_t o_r = up256(sizeof(float) * 2 * n), o_f = o_r + up256(sizeof(int32_t) * (size_t)cap), o_c = o_f + up256(sizeof(int32_t) * (size_t)cap);
     int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_c + 256, "staging");
@@ -363,6 +389,7 @@ extern "C" int pss_h_morse_edges(pss_ctx *ctx, const float *h_iq, int n, double 
 extern "C" int pss_h_classify_signal(pss_ctx *ctx, const float *h_iq, int n, double fs, int *label, double *bw, float *mi, float *flat)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!h_iq || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
     const size_t o_out = up256(sizeof(float) * 2 * n);
     int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_out + 256, "staging");
@@ -390,6 +417,7 @@ extern "C" int pss_h_classify_signal(pss_ctx *ctx, const float *h_iq, int n, dou
 extern "C" int pss_h_iq_correction(pss_ctx *ctx, const float *h_iq, int n, float *h_out_iq, float *h_raw)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!h_iq || (!h_out_iq && !h_raw) || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
     const size_t o_c = up256(sizeof(float) * 2 * n), o_r = o_c + up256(sizeof(float) * 2 * n);
     int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_r + up256(sizeof(float) * n), "staging");
@@ -412,6 +440,7 @@ extern "C" int pss_h_bandpass_filter(pss_ctx *ctx, const double *h_x, int n, dou
                                      const double *sos, int nsec, double *h_y)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!h_x || !h_y || n < 0) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
     double tbl[48];
     if (!sos) {
@@ -436,7 +465,7 @@ extern "C" int pss_h_bandpass_filter(pss_ctx *ctx, const double *h_x, int n, dou
 extern "C" void *pss_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;  // pinned for every device
     return p;
 }
 
@@ -449,6 +478,7 @@ extern "C" int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n
                                          float *h_db, int16_t *h_pcm)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!h_iq || !h_pcm || n_frames < 0 || n < 1 || chunk_frames < 1) return pss_fail(ctx, PSS_E_ARG, "bad stream arguments");
     const int n_out = pss_demod_out_len(PSS_MODE_NFM, n, fs);
     if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "sample rate below 22050 Hz");
@@ -503,10 +533,8 @@ extern "C" int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n
         {
             // chunks of a stream are throughput work: keep them on the fused large-batch kernels, which also overlap the
             // spectrum kernel with the backward pass (the small-batch path measured 1.5x slower here)
-            const bool keep = ctx->no_small_batch;
-            ctx->no_small_batch = true;
+            PssFlagScope keep(ctx->no_small_batch, true);
             rc = pss_spectrum_nfm(ctx, (const float *)d_iq[b], cnt, n, fs, (float *)d_db[b], (int16_t *)d_pcm[b]);
-            ctx->no_small_batch = keep;
         }
         if (rc) { cleanup(); return rc; }
         STREAM_HIP(hipEventRecord(cmp_done[b], ctx->stream));

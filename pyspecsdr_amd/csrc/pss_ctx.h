@@ -79,6 +79,37 @@ struct pss_ctx {
     int kused = 0;
 };
 
+// Every entry point works on ITS context's device, whatever the calling thread's current device is, and leaves the
+// caller's current device as it found it (HIP's current device is per thread and defaults to 0).
+struct PssDevGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit PssDevGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~PssDevGuard()
+    {
+        if (switched) hipSetDevice(prev);
+    }
+    PssDevGuard(const PssDevGuard &) = delete;
+    PssDevGuard &operator=(const PssDevGuard &) = delete;
+};
+#define PSS_GUARD(ctx) PssDevGuard _pss_dev_guard((ctx)->device)
+
+// Temporarily override a context switch (restored on scope exit, also on early returns)
+template <class T>
+struct PssScoped {
+    T &ref;
+    T keep;
+    PssScoped(T &r, T v) : ref(r), keep(r) { r = v; }
+    ~PssScoped() { ref = keep; }
+    PssScoped(const PssScoped &) = delete;
+    PssScoped &operator=(const PssScoped &) = delete;
+};
+using PssFlagScope = PssScoped<bool>;
+using PssStreamScope = PssScoped<hipStream_t>;
+
 int pss_fail(pss_ctx *ctx, int code, const std::string &msg);
 int pss_hip_check(pss_ctx *ctx, hipError_t e, const char *what);
 int pss_ensure_scratch(pss_ctx *ctx, size_t bytes);

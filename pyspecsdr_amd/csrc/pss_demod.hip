@@ -2060,6 +2060,7 @@ extern "C" int pss_demod_out_len(int mode, int n, double fs)
 extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out_iq, float *d_raw)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (n_frames < 0 || n <= 0 || (n_frames > 0 && (!d_iq || (!d_out_iq && !d_raw)))) return pss_fail(ctx, PSS_E_ARG, "pss_iq_correction: bad argument");
     if (n_frames == 0) return PSS_OK;
     RedPlan rp, cp;
@@ -2094,6 +2095,7 @@ extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames,
 extern "C" int pss_power_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_power)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (n < 1 || n_frames < 0 || (n_frames > 0 && (!d_iq || !d_power))) return pss_fail(ctx, PSS_E_ARG, "bad power arguments");
     if (n_frames == 0) return PSS_OK;
     pss_time_begin(ctx);
@@ -2105,6 +2107,7 @@ extern "C" int pss_power_db(pss_ctx *ctx, const float *d_iq, long n_frames, int 
 extern "C" int pss_agc_steps(pss_ctx *ctx, const float *d_power, long n, int start_idx, int n_gains, int32_t *d_idx_out)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!d_power || !d_idx_out || n < 0 || n_gains < 1) return pss_fail(ctx, PSS_E_ARG, "bad agc arguments");
     if (n == 0) return PSS_OK;
     pss_kernel_begin(ctx, "k_agc");
@@ -2117,6 +2120,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
                          double *d_audio)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (n_frames < 0 || n < 1 || (n_frames > 0 && !d_iq)) return pss_fail(ctx, PSS_E_ARG, "bad demod arguments");
     if (n_frames > 0 && !d_pcm && !d_audio) return pss_fail(ctx, PSS_E_ARG, "both outputs are null");
     const long tiles = (n_frames + TILE - 1) / TILE;
@@ -2134,11 +2138,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const size_t szU = align256((size_t)n_frames * Lp * sizeof(double));
         const size_t szY = align256((size_t)tiles * L * TILE * sizeof(double));
         const size_t szA = align256((size_t)tiles * n_out * TILE * sizeof(double));
-        r = pss_ensure_scratch(ctx, szU + szY + szA);
-        if (r) return r;
-        double *U = reinterpret_cast<double *>(ctx->scratch);
-        double *Y = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + szU);
-        double *A = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + szU + szY);
+        double *U = nullptr, *Y = nullptr, *A = nullptr;  // three-kernel path only; each path sizes the (grow-only) scratch itself
         const TapsArg targ = make_taps(flt->taps);
         NfmCoef c;
         for (int s = 0; s < 4; s++) {
@@ -2173,7 +2173,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
                                    reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
             pss_kernel_end(ctx);
             if (ctx->fork_after_fwd) {  // pss_spectrum_nfm overlaps the rest
-                hipEventRecord(ctx->ev_fork, ctx->stream);
+                PSS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
                 ctx->did_fork = true;
             }
             pss_kernel_begin(ctx, "k_nfm_bwd");
@@ -2190,6 +2190,13 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const int cpf = (n - 1 + FIR_CH - 1) / FIR_CH;
         const long items = n_frames * cpf;
         const long g1 = items < 256L * 64 ? items : 256L * 64;
+        if (!small_batch) {
+            r = pss_ensure_scratch(ctx, szU + szY + szA);
+            if (r) return r;
+            U = reinterpret_cast<double *>(ctx->scratch);
+            Y = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + szU);
+            A = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + szU + szY);
+        }
         if (small_batch) {
             const size_t szY2 = align256((size_t)n_frames * L * sizeof(double));
             const size_t szA2 = align256((size_t)n_frames * n_out * sizeof(double));
@@ -2466,6 +2473,7 @@ extern "C" int pss_demod_signal(pss_ctx *ctx, int mode, const float *d_iq, long 
                                 double *d_audio)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (mode != PSS_MODE_WFM) return pss_demod(ctx, mode, d_iq, n_frames, n, fs, d_pcm, d_audio);
     if (n_frames < 0 || n < 1 || (n_frames > 0 && !d_iq)) return pss_fail(ctx, PSS_E_ARG, "bad demod arguments");
     if (n_frames == 0) return pss_demod(ctx, mode, d_iq, n_frames, n, fs, d_pcm, d_audio);
@@ -2482,6 +2490,7 @@ extern "C" int pss_demod_signal(pss_ctx *ctx, int mode, const float *d_iq, long 
 extern "C" int pss_sosfilt(pss_ctx *ctx, const double *d_x, long n_rows, int n, const double *sos, int nsec, double *d_y)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!d_x || !d_y || !sos || n_rows < 0 || n < 0 || nsec < 1 || nsec > 8) return pss_fail(ctx, PSS_E_ARG, "pss_sosfilt: bad argument");
     if (n_rows == 0 || n == 0) return PSS_OK;
     SosArg a;
@@ -2509,6 +2518,7 @@ extern "C" int pss_morse_edges(pss_ctx *ctx, const float *d_iq, long n_frames, i
                                int32_t *d_rise, int32_t *d_fall, int32_t *d_counts)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (n_frames < 0 || n < 1 || cap < 0) return pss_fail(ctx, PSS_E_ARG, "pss_morse_edges: bad argument");
     if (threshold_db != -20.0)
         return pss_fail(ctx, PSS_E_ARG, "pss_morse_edges: only the reference's threshold of -20 dB is pinned (the comparison replays "
@@ -2533,6 +2543,7 @@ extern "C" int pss_classify(pss_ctx *ctx, const float *d_iq, long n_frames, int 
                             float *d_mi, float *d_flat, float *d_psd)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (n_frames < 0 || !(fs > 0.0)) return pss_fail(ctx, PSS_E_ARG, "pss_classify: bad argument");
     if (n < CLS_NP)
         return pss_fail(ctx, PSS_E_ARG, "pss_classify: fewer than 1024 samples (welch would fall back to nperseg = n, a non-power-of-two FFT)");
@@ -2603,6 +2614,7 @@ extern "C" int pss_afsk_bits(pss_ctx *ctx, const double *d_audio, long n_rows, i
                              const double *sos2200, int nsec, uint8_t *d_bits)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (n_rows < 0 || n < 0 || !(fs >= 1200.0)) return pss_fail(ctx, PSS_E_ARG, "pss_afsk_bits: bad argument");
     double t1[48], t2[48];
     if (!sos1200 || !sos2200) {  // design butter(5) band-passes as bandpass_filter does (signal_processing.py:41)
@@ -2636,6 +2648,7 @@ extern "C" int pss_set_wfm_filters(pss_ctx *ctx, double fs, const double *lp3x6,
                                    double alpha)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!lp3x6 || !pilot5x6 || !lmr5x6) return pss_fail(ctx, PSS_E_ARG, "null coefficient table");
     PssWfmFilt f;
     memcpy(f.lp, lp3x6, sizeof(f.lp));
@@ -2649,6 +2662,7 @@ extern "C" int pss_set_wfm_filters(pss_ctx *ctx, double fs, const double *lp3x6,
 extern "C" int pss_get_wfm_filters(pss_ctx *ctx, double fs, double *lp3x6, double *pilot5x6, double *lmr5x6, double *alpha)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     PssWfmFilt *f;
     int r = wfm_filters(ctx, fs, &f);
     if (r) return r;
@@ -2663,33 +2677,40 @@ extern "C" int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, 
                                 int16_t *d_pcm)
 {
     if (!ctx) return PSS_E_ARG;
-    // The spectrum kernel (VALU/HBM heavy, high occupancy) and the demodulator chain (one wavefront per SIMD in its
-    // serial stages) use the machine in complementary ways: run them on two streams, fork/join with events.
+    PSS_GUARD(ctx);
+    // The backward IIR pass runs one wavefront per SIMD and is latency-bound; the spectrum kernel (HBM-bound, high
+    // occupancy) is launched on a side stream right behind the forward kernel so that the two share the machine
+    // (fork / join with events).  Only the fused large-batch NFM path honours fork_after_fwd, and reports it in did_fork.
     pss_time_begin(ctx);  // nested begin/end pairs inside the two calls are no-ops
-    // The backward IIR pass runs one wavefront per SIMD and is latency-bound; the spectrum kernel is launched on a
-    // side stream right behind the forward kernel so that the two share the machine (fork/join with events).
-    ctx->fork_after_fwd = true;  // honoured only by the fused large-batch path, which then sets did_fork
-    ctx->did_fork = false;
-    int r2 = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
-    ctx->fork_after_fwd = false;
+    int r2;
+    {
+        PssFlagScope fork(ctx->fork_after_fwd, true);
+        ctx->did_fork = false;
+        r2 = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
+    }
     int r;
-    if (ctx->did_fork && !r2) {
-        hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
-        ctx->cur = ctx->stream2;
-        r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
-        ctx->cur = nullptr;
-        hipEventRecord(ctx->ev_join, ctx->stream2);
-        hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+    if (ctx->did_fork) {
+        ctx->did_fork = false;
+        r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
+        if (!r && !r2) {
+            PssStreamScope side(ctx->cur, ctx->stream2);
+            r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+        }
+        // the join is attempted whatever happened above: the main stream must never run ahead of the side stream
+        int rj = pss_hip_check(ctx, hipEventRecord(ctx->ev_join, ctx->stream2), "hipEventRecord(join)");
+        if (!rj) rj = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)");
+        if (!r) r = rj;
     } else {
-        r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+        r = r2 ? r2 : pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
     }
     pss_time_end(ctx);
-    return r ? r : r2;
+    return r2 ? r2 : r;
 }
 
 extern "C" int pss_set_nfm_filters(pss_ctx *ctx, double fs, const double *taps65, const double *sos4x6, const double *zi4x2)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!taps65 || !sos4x6 || !zi4x2) return pss_fail(ctx, PSS_E_ARG, "null coefficient table");
     PssNfmFilt f;
     memcpy(f.taps, taps65, sizeof(f.taps));
@@ -2702,6 +2723,7 @@ extern "C" int pss_set_nfm_filters(pss_ctx *ctx, double fs, const double *taps65
 extern "C" int pss_set_ssb_taps(pss_ctx *ctx, double fs, const double *taps65)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!taps65) return pss_fail(ctx, PSS_E_ARG, "null coefficient table");
     std::array<double, 65> t;
     memcpy(t.data(), taps65, sizeof(double) * 65);
@@ -2712,6 +2734,7 @@ extern "C" int pss_set_ssb_taps(pss_ctx *ctx, double fs, const double *taps65)
 extern "C" int pss_get_nfm_filters(pss_ctx *ctx, double fs, double *taps65, double *sos4x6, double *zi4x2)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     PssNfmFilt *f;
     int r = nfm_filters(ctx, fs, &f);
     if (r) return r;
@@ -2724,6 +2747,7 @@ extern "C" int pss_get_nfm_filters(pss_ctx *ctx, double fs, double *taps65, doub
 extern "C" int pss_get_ssb_taps(pss_ctx *ctx, double fs, double *taps65)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     double *t;
     int r = ssb_taps(ctx, fs, &t);
     if (r) return r;

@@ -634,6 +634,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
                     int32_t *d_count, double bin_hz)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (n_frames < 0 || (n_frames > 0 && !d_iq)) return pss_fail(ctx, PSS_E_ARG, "null iq / negative n_frames");
     if (n_fft < 16 || n_fft > (1 << 20) || (n_fft & (n_fft - 1)))
         return pss_fail(ctx, PSS_E_ARG, "n_fft must be a power of two in [16, 1048576]");
@@ -968,8 +969,10 @@ bool is_pow2(int n) { return n > 0 && !(n & (n - 1)); }
 
 extern "C" int pss_spectrum_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db)
 {
-    if (ctx && !d_db && n_frames > 0) return pss_fail(ctx, PSS_E_ARG, "d_db is null");
-    if (ctx && n_frames > 0 && d_iq && n_fft >= 2 && !(is_pow2(n_fft) && n_fft >= 16)) return bluestein_db(ctx, d_iq, n_frames, n_fft, true, d_db);
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (!d_db && n_frames > 0) return pss_fail(ctx, PSS_E_ARG, "d_db is null");
+    if (n_frames > 0 && d_iq && n_fft >= 2 && !(is_pow2(n_fft) && n_fft >= 16)) return bluestein_db(ctx, d_iq, n_frames, n_fft, true, d_db);
     return launch_spectrum<false>(ctx, d_iq, n_frames, n_fft, d_db, nullptr, nullptr, nullptr, 0.0);
 }
 
@@ -994,8 +997,10 @@ static int scan_rows(pss_ctx *ctx, const float *d_iq, long n_slices, int n, floa
 extern "C" int pss_scan(pss_ctx *ctx, const float *d_iq, long n_slices, int n_fft, double fs, float *d_db, float *d_peak,
                         double *d_bw, int32_t *d_count)
 {
-    if (ctx && !d_peak) return pss_fail(ctx, PSS_E_ARG, "d_peak is null");
-    if (ctx && n_slices > 0 && d_iq && n_fft >= 2 && !(is_pow2(n_fft) && n_fft >= 16 && n_fft <= 16384)) {
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (!d_peak) return pss_fail(ctx, PSS_E_ARG, "d_peak is null");
+    if (n_slices > 0 && d_iq && n_fft >= 2 && !(is_pow2(n_fft) && n_fft >= 16 && n_fft <= 16384)) {
         const float *rows;
         int r = scan_rows(ctx, d_iq, n_slices, n_fft, d_db, &rows);
         if (r) return r;
@@ -1008,6 +1013,7 @@ extern "C" int pss_scan_threshold(pss_ctx *ctx, const float *d_iq, long n_slices
                                   float *d_peak, double *d_bw, int32_t *d_count)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (n_slices < 0 || n < 2 || (n_slices > 0 && !d_iq)) return pss_fail(ctx, PSS_E_ARG, "pss_scan_threshold: bad argument");
     if (n_slices == 0) return PSS_OK;
     const float *rows;
@@ -1019,6 +1025,7 @@ extern "C" int pss_scan_threshold(pss_ctx *ctx, const float *d_iq, long n_slices
 extern "C" int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (n_frames < 0 || (n_frames > 0 && (!d_db || !d_post))) return pss_fail(ctx, PSS_E_ARG, "null pointer");
     if (n_fft < 8 || n_fft > (1 << 20)) return pss_fail(ctx, PSS_E_ARG, "post-process supports 8 <= n_fft <= 1048576");
     if (n_frames == 0) return PSS_OK;
@@ -1055,6 +1062,7 @@ extern "C" int pss_waterfall_cells(pss_ctx *ctx, const float *d_rows, int n_rows
                                    int8_t *d_glyph, int8_t *d_colour)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!d_rows || !d_glyph || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad waterfall arguments");
     pss_kernel_begin(ctx, "k_cells");
@@ -1068,6 +1076,7 @@ extern "C" int pss_persistence_cells(pss_ctx *ctx, const float *d_rows, int n_ro
                                      int8_t *d_colour)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!d_rows || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad persistence arguments");
     pss_kernel_begin(ctx, "k_cells");
@@ -1084,6 +1093,7 @@ static int launch_spectrogram(pss_ctx *ctx, const T *d_rows, long n_rows, int le
                               int8_t *d_colour, double *d_range)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!d_rows || !d_glyph || !d_colour || n_rows < 0 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad spectrogram arguments");
     if (n_rows == 0) return PSS_OK;
@@ -1123,6 +1133,7 @@ __global__ __launch_bounds__(256) void k_vector(const float2 *__restrict__ iq, i
 extern "C" int pss_vector_cells(pss_ctx *ctx, const float *d_iq, int n, int max_h, int max_w, int8_t *d_grid)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!d_iq || !d_grid || n < 0 || max_h < 1 || max_w < 1) return pss_fail(ctx, PSS_E_ARG, "bad vector-display arguments");
     PSS_HIP(ctx, hipMemsetAsync(d_grid, 0, (size_t)max_h * max_w, PSS_STREAM(ctx)));
     if (n == 0) return PSS_OK;
@@ -1138,6 +1149,7 @@ static int launch_gradient(pss_ctx *ctx, const T *d_rows, int n_rows, int len, i
                            int8_t *d_colour)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!d_rows || !d_glyph || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad waterfall arguments");
     pss_kernel_begin(ctx, "k_cells");
@@ -1161,6 +1173,7 @@ template <class T>
 static int launch_surface(pss_ctx *ctx, const T *d_row, int len, int max_h, int max_w, int8_t *d_colour)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!d_row || !d_colour || len < 2 || max_h < 4 || max_w < 10) return pss_fail(ctx, PSS_E_ARG, "bad surface arguments");
     // one int key per screen cell, parked in the FFT scratch (the display path does not run beside a big-N spectrum)
     int r = pss_ensure_buffer(ctx, &ctx->scratch_fft, &ctx->scratch_fft_bytes, (size_t)max_h * max_w * sizeof(int), "surface keys");
@@ -1184,6 +1197,7 @@ extern "C" int pss_waterfall_cells_f64(pss_ctx *ctx, const double *d_rows, int n
                                        int8_t *d_glyph, int8_t *d_colour)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!d_rows || !d_glyph || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad waterfall arguments");
     pss_kernel_begin(ctx, "k_cells");
@@ -1197,6 +1211,7 @@ extern "C" int pss_persistence_cells_f64(pss_ctx *ctx, const double *d_rows, int
                                          int8_t *d_colour)
 {
     if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     if (!d_rows || !d_colour || n_rows < 1 || len < 2 || disp_h < 1 || disp_w < 1)
         return pss_fail(ctx, PSS_E_ARG, "bad persistence arguments");
     pss_kernel_begin(ctx, "k_cells");
@@ -1217,6 +1232,7 @@ struct pss_ring {
 extern "C" int pss_ring_create(pss_ctx *ctx, int max_rows, int len, pss_ring **out)
 {
     if (!ctx || !out) return PSS_E_ARG;
+    PSS_GUARD(ctx);
     *out = nullptr;
     if (max_rows < 1 || len < 2) return pss_fail(ctx, PSS_E_ARG, "bad ring arguments");
     pss_ring *r = new pss_ring{ctx, nullptr, max_rows, len, 0, 0};
@@ -1229,6 +1245,7 @@ extern "C" int pss_ring_create(pss_ctx *ctx, int max_rows, int len, pss_ring **o
 extern "C" void pss_ring_destroy(pss_ring *r)
 {
     if (!r) return;
+    PSS_GUARD(r->ctx);
     hipStreamSynchronize(PSS_STREAM(r->ctx));
     hipFree(r->d_rows);
     delete r;
@@ -1239,6 +1256,7 @@ extern "C" int pss_ring_count(pss_ring *r) { return r ? r->count : PSS_E_ARG; }
 extern "C" int pss_ring_push(pss_ring *r, const float *d_row)
 {
     if (!r || !d_row) return PSS_E_ARG;
+    PSS_GUARD(r->ctx);
     int slot;
     if (r->count < r->cap) slot = (r->head + r->count++) % r->cap;
     else { slot = r->head; r->head = (r->head + 1) % r->cap; }  // history.pop(0)
@@ -1249,6 +1267,7 @@ extern "C" int pss_ring_push(pss_ring *r, const float *d_row)
 extern "C" int pss_ring_waterfall(pss_ring *r, int disp_h, int disp_w, int8_t *d_glyph, int8_t *d_colour)
 {
     if (!r || !d_glyph || !d_colour || disp_h < 1 || disp_w < 1 || r->count < 1) return PSS_E_ARG;
+    PSS_GUARD(r->ctx);
     hipLaunchKernelGGL((k_cells<float, 0>), dim3(1), dim3(1024), 0, PSS_STREAM(r->ctx), r->d_rows, r->count, r->len, disp_h,
                        disp_w, d_glyph, d_colour, r->head, r->cap);
     return pss_hip_check(r->ctx, hipGetLastError(), "k_cells launch");
@@ -1257,6 +1276,7 @@ extern "C" int pss_ring_waterfall(pss_ring *r, int disp_h, int disp_w, int8_t *d
 extern "C" int pss_ring_persistence(pss_ring *r, int disp_h, int disp_w, int8_t *d_colour)
 {
     if (!r || !d_colour || disp_h < 1 || disp_w < 1 || r->count < 1) return PSS_E_ARG;
+    PSS_GUARD(r->ctx);
     hipLaunchKernelGGL((k_cells<float, 1>), dim3(1), dim3(1024), 0, PSS_STREAM(r->ctx), r->d_rows, r->count, r->len, disp_h,
                        disp_w, (int8_t *)nullptr, d_colour, r->head, r->cap);
     return pss_hip_check(r->ctx, hipGetLastError(), "k_cells launch");
