@@ -4,19 +4,28 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-One "step" = one pass of the hot path (compute_fft spectrum + NFM demod -> int16) over one batch of
-synthetic FM-modulated IQ already resident in HBM: BASELINE.json configs[1] = 65 536 frames x 1024 points
-@ 2.4 MS/s per GPU.  Frames are independent, so N GPUs each process their own 65 536-frame batch with no
-data-path collective (weak scaling); the timed region is bracketed by barrier + device synchronize and
-the max over ranks is reported.  value = complex64 IQ samples per second over all ranks.
+One "step" = one pass of the hot path over one batch of synthetic FM-modulated IQ already resident in HBM
+(BASELINE.json configs[1] = 65 536 frames x 1024 points @ 2.4 MS/s per GPU), for EVERY frame of the batch:
+    compute_fft dB spectrum (signal_processing.py:243-264)            -> float32 [frames][1024]
+    the caller's smoothing + median clamp (pyspecsdr.py:2278-2283)     -> float32 [frames][1020]
+    the waterfall accumulator's newest display line (:1342-1406)       -> int8 glyph + colour [frames][112]
+    demodulate_nfm -> int16 stereo (signal_processing.py:91-116)       -> int16 [frames][10][2]
+Frames are independent, so N GPUs each process their own batch (weak scaling).  The one exchange step of the path
+(BASELINE.json north_star: "a trivial RCCL gather over xGMI") is INSIDE the timed region when N > 1: after every step
+each rank's display lines + PCM (one packed buffer, 17 MB) are gathered to rank 0 over RCCL, on a side stream,
+overlapped with the next step's compute (two output buffer sets).  --exchange db gathers the float32 dB rows instead
+(256 MiB per rank and step: link-bound, reported separately as exchange_db by default).
+value = complex64 IQ samples per second over all ranks, max-over-ranks time, barrier + synchronize on both sides.
 
 Extra objects on the JSON line:
   roofline     — the dominant kernel of the step: its algorithmic bytes / its mean launch duration (HIP events
-                 on the library's stream, measured inside the timed region) against the 8 TB/s HBM peak.
+                 on the library's stream, measured inside the timed region) against the 8 TB/s HBM peak; plus the float64
+                 issue roof of that kernel when it is the NFM forward kernel, and every HBM-bound kernel's own fraction.
   cpu_baseline — the CPU oracle (oracle/pss_oracle.c, a port of the reference's NumPy/SciPy path with the
                  filters designed once) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,36 +40,53 @@ import torch
 N_FRAMES = 65536
 N_FFT = 1024
 FS = 2.4e6
+DISP_W = 112          # max_width 120 - 8 (pyspecsdr.py:1347)
+WF_WINDOW = 30        # WATERFALL_MAX_LINES (pyspecsdr.py:131)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+F64_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9  # float64 VALU: 16 lanes / clk / SIMD x 1024 SIMDs x 2.4 GHz = 39.3e12 (= 78.6 TFLOP/s FMA)
 
-# algorithmic bytes per frame (DESIGN.md §Kernels): what each kernel must move if nothing is re-read or spilled
+# algorithmic bytes per frame (DESIGN.md §4): what each kernel must move if nothing is re-read or spilled
 ALGO_BYTES = {
     "k_spectrum": N_FFT * 8 + N_FFT * 4,            # IQ in + float32 dB out
     "k_nfm_fwd": N_FFT * 8,                         # IQ in (y_fwd is an internal hand-off, not algorithmic)
     "k_nfm_bwd": 40,                                # 10 x 2 x int16 out
+    "k_post": N_FFT * 4 + (N_FFT - 4) * 4 + 8,      # dB row in, post-processed row + its extremes out
+    "k_disp_rows": (N_FFT - 4) * 4 + 2 * DISP_W,    # post-processed row in, glyph + colour line out
+    "k_slide_extremes": 8 + 16,
     "k_nfm_front": N_FFT * 8, "k_nfm_edge": 0, "k_nfm_iir": 40,   # three-kernel fallback path (PSS_NO_FUSED=1)
-    "path": N_FFT * 8 + N_FFT * 4 + 40,             # 12 328 B/frame, IQ read once
+    # 12 328 B/frame (IQ read once, dB row, PCM) + the materialised waterfall line (glyph and colour)
+    "path": N_FFT * 8 + N_FFT * 4 + 40 + 2 * DISP_W,
 }
+HBM_BOUND = ("k_spectrum", "k_post", "k_disp_rows")
+# float64 VALU operations per input sample and lane of k_nfm_fwd, fixed by the reference's accumulation order (DESIGN.md §4;
+# measured with SQ_INSTS_VALU_{FMA,ADD,MUL}_F64: profiles/r02_valu_instruction_mix.txt): 63 fma + 51 add + 12 mul
+NFM_FWD_F64_OPS_PER_SAMPLE = 126
 
 
-def traffic_of(kernel, n_frames):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC profile (profiles/hbm_traffic_r01.json: separate
-    --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 2x fetch correction), scaled to this run's frame count; None if absent.
+def source_hash():
+    """sha256 over the kernel sources: profiles are only quoted next to the binary they were taken from."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pyspecsdr_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled(kernel, n_frames):
+    """(traffic bytes per launch, VALU-busy fraction) of `kernel` from the committed rocprofv3 PMC digest
+    (profiles/hbm_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 2x fetch correction), scaled to this
+    run's frame count — and only if the digest was taken from THIS source tree (its src_hash matches); else (None, None).
     PMC counters cannot be collected from inside this process, so the number is the profiled one, not a live one."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_r01.json")))[kernel]["traffic_bytes"]
-        return t * n_frames / 65536.0
-    except Exception:
-        return None
-
-
-def valu_busy_of(kernel):
-    """VALU busy fraction of `kernel` from the committed SQ-counter profile (profiles/r01g_sq_counters_bench.txt, digested
-    into profiles/hbm_traffic_r01.json); None if absent.  Says how close an issue-bound kernel is to ITS roof."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_r01.json")))[kernel].get("valu_busy_frac")
-    except Exception:
-        return None
+        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        if t.get("src_hash") != source_hash():
+            return None, None, f"profiles/hbm_traffic.json is from source {t.get('src_hash')}, this tree is {source_hash()}"
+        k = t["kernels"][kernel]
+        return k["traffic_bytes"] * n_frames / float(t["n_frames"]), k.get("valu_busy_frac"), t.get("profile")
+    except Exception as ex:  # noqa: BLE001
+        return None, None, f"no digest ({type(ex).__name__})"
 
 
 def synth_fm_iq(n_frames, n, fs, device, seed):
@@ -78,23 +104,32 @@ def synth_fm_iq(n_frames, n, fs, device, seed):
     return iq.contiguous()
 
 
-def cpu_baseline(iq_host, fs, taps, sos, zi, budget_s=12.0):
+def cpu_baseline(iq_host, fs, taps, sos, zi, min_wall_s=1.0, max_wall_s=25.0):
+    """The oracle's port of the same step (spectrum + post-process + waterfall line + NFM + int16), OpenMP over frames, on
+    the whole batch, repeated until every thread has had >= min_wall_s of work (the all-core number is not a 6 ms burst)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     cores = os.cpu_count() or 1
-    n = iq_host.shape[1]
-    # calibrate on one thread, then size the all-core sample for ~budget_s of wall time
+    nf, n = iq_host.shape
+    buf = O.HeadlineBuffers(nf, n, fs, DISP_W)
     t0 = time.perf_counter()
-    O.batch_spectrum_nfm(iq_host[:256], fs, taps, sos, zi, 1)
-    t1 = time.perf_counter() - t0
-    per_frame_1t = t1 / 256
-    nf = int(min(iq_host.shape[0], max(512, budget_s / per_frame_1t * cores * 0.7)))
-    t0 = time.perf_counter()
-    O.batch_spectrum_nfm(iq_host[:nf], fs, taps, sos, zi, cores)
-    tall = time.perf_counter() - t0
+    O.batch_headline(iq_host[:512], fs, taps, sos, zi, buf, 1)
+    per_frame_1t = (time.perf_counter() - t0) / 512
+    # one pass ~ 2 s of wall time on this host (the whole batch on a 256-thread box, fewer frames on a small one)
+    nf = int(min(nf, max(cores * 64, 2.0 / per_frame_1t * cores)))
+    iq_host = iq_host[:nf]
+    O.batch_headline(iq_host, fs, taps, sos, zi, buf, cores)        # warm-up: thread pool, page faults of the outputs
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        O.batch_headline(iq_host, fs, taps, sos, zi, buf, cores)
+        reps += 1
+        wall = time.perf_counter() - t0
+        if wall >= min_wall_s and (wall >= max_wall_s or reps >= 3):
+            break
     return {
-        "value": nf * n / tall, "unit": "IQ samples/s", "cores": cores, "kind": "port",
-        "sample": f"{nf} frames x {n} pts (spectrum + NFM + int16, filters designed once), OpenMP over frames",
+        "value": reps * nf * n / wall, "unit": "IQ samples/s", "cores": cores, "kind": "port",
+        "sample": f"{nf} frames x {n} pts x {reps} passes in {wall:.2f} s wall (spectrum + post-process + waterfall line + NFM + "
+                  f"int16, filters designed once), OpenMP over frames, {wall:.2f} s busy per thread",
         "single_thread_value": n / per_frame_1t,
     }
 
@@ -105,6 +140,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=N_FRAMES, help="frames per GPU per step (default: BASELINE cfg 2)")
+    ap.add_argument("--exchange", choices=["display", "db", "none"], default="display",
+                    help="what is gathered to rank 0 inside the timed region when N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -112,36 +149,62 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PSS_BENCH_DIST") == "1":   # PSS_BENCH_DIST=1: exercise the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from pyspecsdr_amd.engine import Engine
     eng = Engine(local_rank)
+    comp = torch.cuda.ExternalStream(eng.stream_handle(), device=dev)   # the library's stream, for event ordering
     nf, n = args.frames, N_FFT
     iq = synth_fm_iq(nf, n, FS, dev, seed=20260928 + 2 + rank)
-    d_db = torch.empty((nf, n), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)            # the IQ batch is produced on torch's stream, consumed on the library's
     n_out = eng.demod_out_len(0, n, FS)
-    d_pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
+    m = n - 4
+    d_post = torch.empty((nf, m), dtype=torch.float32, device=dev)
+    d_lo = torch.empty((nf,), dtype=torch.float32, device=dev)
+    d_hi = torch.empty((nf,), dtype=torch.float32, device=dev)
+    # two output sets: step k+1 computes into one while step k's is in flight to rank 0.  A set is ONE packed buffer
+    # [glyph | colour | pcm] (one message per rank and step) + the dB rows.
+    o_col, o_pcm, set_bytes = nf * DISP_W, 2 * nf * DISP_W, 2 * nf * DISP_W + nf * n_out * 4
+    packed = [torch.empty((set_bytes,), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_db = [torch.empty((nf, n), dtype=torch.float32, device=dev) for _ in range(2 if (dist and args.exchange == "db") else 1)]
+    exch = args.exchange if dist is not None else "none"
+    comm = torch.cuda.Stream(device=dev) if exch != "none" else None
+    recv = None
+    if exch != "none" and rank == 0:
+        per = set_bytes if exch == "display" else nf * n * 4
+        recv = torch.empty((world, per), dtype=torch.uint8, device=dev)
+    sent = [None, None]     # event: set b's gather has finished (the set may be overwritten)
 
-    # waterfall state after the batch (configs[1] names it): the caller's smoothing + median clamp
-    # (pyspecsdr.py:2278-2283) on the newest WATERFALL_MAX_LINES = 30 rows and the 36 x 112 cell quantiser
-    # (pyspecsdr.py:1342-1406) — a display only ever shows the last 30 rows of a batch.
-    WF = min(30, nf)
-    d_post = torch.empty((WF, n - 4), dtype=torch.float32, device=dev)
-    d_glyph = torch.empty((36, 112), dtype=torch.int8, device=dev)
-    d_col = torch.empty((36, 112), dtype=torch.int8, device=dev)
+    def compute(b):
+        db = d_db[b % len(d_db)]
+        base = packed[b].data_ptr()
+        eng.spectrum_nfm(iq, nf, n, FS, db, base + o_pcm)
+        eng.spectrum_post_extremes(db, nf, n, d_post, d_lo, d_hi)
+        eng.waterfall_rows(d_post, nf, m, d_lo, d_hi, DISP_W, base, base + o_col, window=WF_WINDOW)
 
-    def step():
-        eng.spectrum_nfm(iq, nf, n, FS, d_db, d_pcm)
-        eng.spectrum_post(d_db[nf - WF:], WF, n, d_post)
-        eng.waterfall_cells(d_post, WF, n - 4, 36, 112, d_glyph, d_col)
+    def exchange(b):
+        src = packed[b] if exch == "display" else d_db[b % len(d_db)].view(torch.uint8).view(-1)
+        comm.wait_stream(comp)
+        with torch.cuda.stream(comm):
+            dist.gather(src, list(recv.unbind(0)) if rank == 0 else None, dst=0)
+            sent[b] = comm.record_event()
+
+    def step(k):
+        b = k & 1
+        if exch != "none" and sent[b] is not None:
+            comp.wait_event(sent[b])
+        compute(b)
+        if exch != "none":
+            exchange(b)
 
     def fence():
         eng.sync()
@@ -150,41 +213,77 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
     # untimed survey pass: every launch bracketed by HIP events on the library's stream -> which kernel dominates, and the
-    # table of mean launch durations.  An event is a barrier packet in the queue (~4 us each, 16 per step with every
-    # kernel and call bracketed = 6 % of a step), so the timed region below keeps only the dominant kernel's pair.
+    # table of mean launch durations.  An event is a barrier packet in the queue (~4 us each), so the timed region below
+    # keeps only the dominant kernel's pair.
     eng.enable_timing(True)
-    for _ in range(max(3, min(args.steps, 10))):
-        step()
+    for k in range(max(3, min(args.steps, 10))):
+        compute(k & 1)
     fence()
     ktimes = {k: sum(v) / len(v) for k, v in eng.kernel_times().items()}
     dom = max(ktimes, key=ktimes.get)
     eng.timing_filter(dom)
     fence()
-    # timed region: exactly K steps, barrier + synchronize on both sides
+    # timed region: exactly K steps (compute + exchange), barrier + synchronize on both sides
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()   # the dominant kernel's launches are bracketed by HIP events; read back after the fence
+    for k in range(args.steps):
+        step(k)   # the dominant kernel's launches are bracketed by HIP events; read back after the fence
     fence()
     elapsed = time.perf_counter() - t0
     live = eng.kernel_times().get(dom, [])
     assert len(live) >= args.steps and len(live) % args.steps == 0, (dom, len(live))   # some kernels launch twice a step
     ktimes[dom] = sum(live) / len(live)   # mean launch duration over the K timed steps
     eng.timing_filter(None)
-    # outside the timed region: the spectrum kernel alone (inside a step it overlaps the backward IIR pass on a side
-    # stream, which stretches its own duration) — this is the HBM-bound kernel of the path
+    eng.enable_timing(False)
+
+    # ---- outside the timed region -------------------------------------------------------------------------------------
+    def timed(fn, reps=5):
+        fn(); fence()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        fence()
+        return (time.perf_counter() - t) / reps * 1e3
+
+    side = {}
+    # each HBM-bound kernel alone (inside a step the spectrum kernel shares the machine with the backward IIR pass)
+    eng.enable_timing(True)
     for _ in range(2):
-        eng.spectrum_db(iq, nf, n, d_db)
-    eng.sync()
-    eng.kernel_times()
+        eng.spectrum_db(iq, nf, n, d_db[0])
+    eng.sync(); eng.kernel_times()
     for _ in range(5):
-        eng.spectrum_db(iq, nf, n, d_db)
+        eng.spectrum_db(iq, nf, n, d_db[0])
     eng.sync()
     spec_alone = eng.kernel_times().get("k_spectrum", [])
     eng.enable_timing(False)
+    # round-1 reading of "waterfall": post-process + cell grid of the newest 30 rows only (a display's last state)
+    WF = min(30, nf)
+    d_g30 = torch.empty((36, DISP_W), dtype=torch.int8, device=dev)
+    d_c30 = torch.empty((36, DISP_W), dtype=torch.int8, device=dev)
+
+    def step30():
+        eng.spectrum_nfm(iq, nf, n, FS, d_db[0], packed[0].data_ptr() + o_pcm)
+        eng.spectrum_post(d_db[0][nf - WF:], WF, n, d_post)
+        eng.waterfall_cells(d_post, WF, m, 36, DISP_W, d_g30, d_c30)
+    side["ms_per_step_newest_30_rows_only"] = timed(step30)
+    if exch != "none":
+        # compute alone, and the exchange alone (both variants), so that overlap can be read off
+        side["compute_ms"] = timed(lambda: compute(0))
+        comm_db = torch.cuda.Stream(device=dev)
+
+        def xfer(src, per):
+            buf = torch.empty((world, per), dtype=torch.uint8, device=dev) if rank == 0 else None
+            def go():
+                with torch.cuda.stream(comm_db):
+                    dist.gather(src, list(buf.unbind(0)) if rank == 0 else None, dst=0)
+            return timed(go, 3)
+        side["exchange_display_ms"] = xfer(packed[0], set_bytes)
+        side["exchange_display_bytes_per_rank"] = set_bytes
+        side["exchange_db_ms"] = xfer(d_db[0].view(torch.uint8).view(-1), nf * n * 4)
+        side["exchange_db_bytes_per_rank"] = nf * n * 4
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -194,19 +293,31 @@ def main():
     value = total_samples / elapsed
 
     if rank == 0:
-        roof = None
-        if dom:
-            ms = ktimes[dom]
-            achieved = ALGO_BYTES.get(dom, ALGO_BYTES["path"]) * nf / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_of(dom, nf), "valu_busy_frac": valu_busy_of(dom),
-                    "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
-                    "kernel_ms_note": f"{dom}: HIP events inside the timed region; the others: untimed survey pass before it",
-                    "path_achieved": ALGO_BYTES["path"] * nf / (elapsed / args.steps) / 1e9}
-            if spec_alone:
-                sms = sum(spec_alone) / len(spec_alone)
-                sa = ALGO_BYTES["k_spectrum"] * nf / (sms * 1e-3) / 1e9
-                roof["spectrum_kernel_standalone"] = {"ms": round(sms, 4), "achieved": sa, "frac": sa / HBM_PEAK_GBS}
+        ms = ktimes[dom]
+        achieved = ALGO_BYTES.get(dom, ALGO_BYTES["path"]) * nf / (ms * 1e-3) / 1e9
+        traffic, valu_busy, prof_note = profiled(dom, nf)
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy, "profile": prof_note,
+                "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
+                "kernel_ms_note": f"{dom}: HIP events inside the timed region; the others: untimed survey pass before it",
+                "path_achieved": ALGO_BYTES["path"] * nf / (elapsed / args.steps) / 1e9,
+                "path_frac": ALGO_BYTES["path"] * nf / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
+        if dom == "k_nfm_fwd":
+            ops = NFM_FWD_F64_OPS_PER_SAMPLE * float(nf) * n / (ms * 1e-3)
+            roof["f64_issue"] = {"achieved": ops, "peak": F64_PEAK_LANEOPS, "unit": "float64 lane-ops/s", "frac": ops / F64_PEAK_LANEOPS,
+                                 "ops_per_sample": NFM_FWD_F64_OPS_PER_SAMPLE,
+                                 "note": "the kernel's binding roof: 63 fma + 51 add + 12 mul float64 per sample are fixed by the "
+                                         "reference's accumulation order; peak = 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz"}
+        hb = {}
+        for k in HBM_BOUND:
+            if k in ktimes:
+                a = ALGO_BYTES[k] * nf / (ktimes[k] * 1e-3) / 1e9
+                hb[k] = {"ms": round(ktimes[k], 4), "achieved": a, "frac": a / HBM_PEAK_GBS}
+        if spec_alone:
+            sms = sum(spec_alone) / len(spec_alone)
+            sa = ALGO_BYTES["k_spectrum"] * nf / (sms * 1e-3) / 1e9
+            hb["k_spectrum_standalone"] = {"ms": round(sms, 4), "achieved": sa, "frac": sa / HBM_PEAK_GBS}
+        roof["hbm_bound_kernels"] = hb
         out = {
             "metric": "IQ MSamples/sec end-to-end (FFT+dB+FM demod)",
             "value": value / 1e6, "unit": "MSamples/s",
@@ -214,14 +325,21 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 front end / f64 FFT+FIR+IIR / int16 PCM", "data": "synthetic",
-            "config": {"workload": f"{nf} frames x {n}-pt complex64 @2.4 MS/s per GPU: compute_fft dB spectrum + "
-                                   f"NFM demod -> int16 stereo + waterfall cells of the newest 30 rows (BASELINE.json configs[1])",
-                       "frames_per_gpu": nf, "n_fft": n, "sample_rate": FS, "parallelism": f"frames sharded x{world}"},
+            "config": {"workload": f"{nf} frames x {n}-pt complex64 @2.4 MS/s per GPU, every frame: compute_fft dB spectrum + "
+                                   f"post-process (smoothing, median clamp) + waterfall display line + NFM demod -> int16 stereo "
+                                   f"(BASELINE.json configs[1])",
+                       "frames_per_gpu": nf, "n_fft": n, "sample_rate": FS, "parallelism": f"frames sharded x{world}",
+                       "exchange": {"display": "RCCL gather to rank 0 of every rank's waterfall lines + PCM (one packed buffer per step), "
+                                               "overlapped with the next step, inside the timed region",
+                                    "db": "RCCL gather to rank 0 of every rank's float32 dB rows, inside the timed region",
+                                    "none": "none (one rank)"}[exch]},
             "roofline": roof,
+            "src_hash": source_hash(),
         }
+        out.update(side)
         if world == 1 and not args.no_cpu_baseline:
             taps, sos, zi = eng.nfm_filters(FS)
-            out["cpu_baseline"] = cpu_baseline(iq[:16384].cpu().numpy().view(np.complex64).reshape(-1, n), FS, taps, sos, zi)
+            out["cpu_baseline"] = cpu_baseline(iq.cpu().numpy().view(np.complex64).reshape(-1, n), FS, taps, sos, zi)
             out["cpu_baseline"]["value"] /= 1e6
             out["cpu_baseline"]["single_thread_value"] /= 1e6
             out["cpu_baseline"]["unit"] = "MSamples/s"

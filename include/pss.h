@@ -42,6 +42,9 @@ int pss_create(int device, pss_ctx **out);
 void pss_destroy(pss_ctx *ctx);
 /* Use an existing hipStream_t (passed as void*) instead of the context's own stream; NULL = default stream. */
 int pss_set_stream(pss_ctx *ctx, void *hip_stream);
+/* The hipStream_t (as void*) the context's work is queued on: lets a caller order its own streams / events against it
+ * (e.g. torch.cuda.ExternalStream(pss_get_stream(ctx)) to overlap an RCCL gather with the next batch). */
+void *pss_get_stream(pss_ctx *ctx);
 int pss_sync(pss_ctx *ctx);
 const char *pss_last_error(pss_ctx *ctx); /* ctx may be NULL: error of the last failed pss_create */
 int pss_device_count(void);
@@ -50,7 +53,9 @@ int pss_device_count(void);
  *   "wfm_fused" (1)            0: k_wfm_front + lane-per-frame decimator instead of the fused WFM forward kernel
  *   "small_batch" (1)          0: never take the latency-oriented small-batch kernels (one lane per filter section)
  *   "small_batch_max" (8192)   largest NFM frame count that takes them;  "wfm_small_batch_max" (8192) likewise for WFM
- *   "post_sort_max" (8192)     longest dB row post-processed with the LDS sort (longer rows: radix select)
+ *   "post_legacy" (0)          1: the post-process takes the LDS bitonic sort / LDS-histogram radix select kernels instead of
+ *                              the register-resident binary-search select;  "post_sort_max" (8192): longest row the legacy
+ *                              path sorts (longer rows: radix select)
  *   "fft_split" (-1 = auto)    1 / 0: force / forbid the component-wise LDS exchanges of the register FFT (auto: N = 256)
  *   "fft_prefetch" (-1 = auto) 1 / 0: force / forbid requesting the next frame's samples before transforming the current one
  *                              (auto: N = 1024 and 2048) */
@@ -89,6 +94,13 @@ int pss_spectrum_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
 /* Caller-side post-process (pyspecsdr.py:2278-2283): 5-tap moving average ('valid') then clamp below
  * median-10.  d_post: float32 [n_frames][n_fft-4]. */
 int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post);
+/* The same, and the finite minimum / maximum of every post-processed row (float32 [n_frames] each; (+inf, -inf) for a row
+ * without a finite value): what the display accumulators below normalise with. */
+int pss_spectrum_post_extremes(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_row_lo,
+                               float *d_row_hi);
+/* Finite extremes of arbitrary rows (np.min / np.max over all_data[np.isfinite(all_data)], pyspecsdr.py:1356-1358, per row). */
+int pss_row_extremes(pss_ctx *ctx, const float *d_rows, long n_rows, int len, float *d_row_lo, float *d_row_hi);
+int pss_row_extremes_f64(pss_ctx *ctx, const double *d_rows, long n_rows, int len, double *d_row_lo, double *d_row_hi);
 /* Inline scanner slice (pyspecsdr.py:2542-2552): unwindowed FFT, dB, peak, 20-dB-down bin count,
  * bandwidth = count * fs / n_fft.  d_db float32 [n][n_fft] (may be NULL), d_peak float32 [n],
  * d_bw float64 [n], d_count int32 [n] (may be NULL).  n_fft: power of two in [16, 16384] (one kernel), or any other
@@ -213,6 +225,28 @@ int pss_ring_push(pss_ring *ring, const float *d_row);
 int pss_ring_count(pss_ring *ring);
 int pss_ring_waterfall(pss_ring *ring, int disp_h, int disp_w, int8_t *d_glyph, int8_t *d_colour);
 int pss_ring_persistence(pss_ring *ring, int disp_h, int disp_w, int8_t *d_colour);
+
+/* Batched accumulators: the display line the reference would draw for EVERY frame of a batch, in one call.
+ * draw_waterfall / draw_persistence (pyspecsdr.py:1342-1406, :1512-1564) append the frame's post-processed row to a history
+ * of `window` rows (30 / 10) and normalise with the finite extremes of that history; for frame i of a batch that is the
+ * sliding-window minimum / maximum of the per-row extremes over rows i-window+1 .. i.
+ *   d_post            [n_frames][len]        the batch's post-processed rows
+ *   d_row_lo/d_row_hi [n_halo + n_frames]    per-row finite extremes (pss_spectrum_post_extremes / pss_row_extremes); the
+ *                                            first n_halo entries belong to the rows that PRECEDE the batch (the previous
+ *                                            batch's tail, or the left neighbour's when frames are sharded over GPUs:
+ *                                            8 bytes per row cross the link instead of the rows) — 0 for a fresh history
+ *   waterfall:   d_glyph / d_colour int8 [n_frames][disp_w] = line y = 0 (the newest row) of the reference's grid at frame i
+ *                (glyph 0 '.', 1 '-', 2 '=', 3 '#'; colour 0..5; -1 where the value is not finite)
+ *   persistence: d_y int8 [n_frames][disp_w] = row index int((1 - norm) * (disp_h - 1)) of the newest trace's '*' in every
+ *                column (-1: not drawn); disp_h <= 127. */
+int pss_waterfall_rows(pss_ctx *ctx, const float *d_post, long n_frames, int len, const float *d_row_lo, const float *d_row_hi,
+                       int n_halo, int window, int disp_w, int8_t *d_glyph, int8_t *d_colour);
+int pss_waterfall_rows_f64(pss_ctx *ctx, const double *d_post, long n_frames, int len, const double *d_row_lo,
+                           const double *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph, int8_t *d_colour);
+int pss_persistence_rows(pss_ctx *ctx, const float *d_post, long n_frames, int len, const float *d_row_lo, const float *d_row_hi,
+                         int n_halo, int window, int disp_h, int disp_w, int8_t *d_y);
+int pss_persistence_rows_f64(pss_ctx *ctx, const double *d_post, long n_frames, int len, const double *d_row_lo,
+                             const double *d_row_hi, int n_halo, int window, int disp_h, int disp_w, int8_t *d_y);
 
 /* ---- host-buffer convenience (single frame, synchronous; what the drop-in Python module calls) --- */
 int pss_h_compute_fft(pss_ctx *ctx, const float *h_iq, int n, double *h_db);

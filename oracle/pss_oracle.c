@@ -1165,3 +1165,100 @@ void pss_o_batch_spectrum_nfm(const float *iq, long n_frames, int n, double fs, 
         free(au);
     }
 }
+
+/* The full BASELINE cfg-2 step per frame: compute_fft (float32 dB out), the caller's smoothing + median clamp
+ * (pyspecsdr.py:2278-2283; float32 rows out, finite extremes per row), NFM -> int16 stereo.  post_out / lo_out / hi_out may be
+ * NULL (then this is pss_o_batch_spectrum_nfm). */
+void pss_o_batch_spectrum_post_nfm(const float *iq, long n_frames, int n, double fs, int q, const double *taps,
+                                   const double *sos, const double *zi, float *db_out, float *post_out, float *lo_out,
+                                   float *hi_out, int16_t *pcm_out, int n_threads)
+{
+    int n_out = (int)(((long)n - 1 + q - 1) / q);
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+#endif
+    for (long f = 0; f < n_frames; f++) {
+        double *db = (double *)malloc(sizeof(double) * n);
+        double *po = (double *)malloc(sizeof(double) * n);
+        double *au = (double *)malloc(sizeof(double) * (n_out + 1));
+        pss_o_compute_fft(iq + 2 * f * n, n, db);
+        for (int k = 0; k < n; k++) db_out[f * n + k] = (float)db[k];
+        if (post_out) {
+            pss_o_postprocess(db, n, po);
+            float lo = INFINITY, hi = -INFINITY;
+            for (int k = 0; k < n - 4; k++) {
+                const float v = (float)po[k];
+                post_out[f * (n - 4) + k] = v;
+                if (isfinite(v)) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+            }
+            if (lo_out) lo_out[f] = lo;
+            if (hi_out) hi_out[f] = hi;
+        }
+        pss_o_demod_nfm(iq + 2 * f * n, n, fs, q, taps, sos, zi, au, 0, 0);
+        pss_o_pcm16_stereo(au, n_out, pcm_out + 2 * f * n_out);
+        free(db);
+        free(po);
+        free(au);
+    }
+}
+
+/* Batched waterfall accumulator: for every frame the newest display line (y = 0) of draw_waterfall (pyspecsdr.py:1342-1406)
+ * with the history of the last `window` rows — min / max over the finite values of rows i-window+1 .. i (:1356-1358),
+ * np.interp to disp_w (:1379-1383), glyph / colour (:1386-1398).  rows float32 [n_frames][len]; glyph / colour int8
+ * [n_frames][disp_w], -1 where the value is not finite. */
+void pss_o_waterfall_rows(const float *rows, long n_frames, int len, int window, int disp_w, int8_t *glyph, int8_t *colour,
+                          int n_threads)
+{
+    double *rlo = (double *)malloc(sizeof(double) * (n_frames > 0 ? n_frames : 1));
+    double *rhi = (double *)malloc(sizeof(double) * (n_frames > 0 ? n_frames : 1));
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+#endif
+    for (long f = 0; f < n_frames; f++) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int k = 0; k < len; k++) {
+            const double v = (double)rows[f * len + k];
+            if (isfinite(v)) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        }
+        rlo[f] = lo;
+        rhi[f] = hi;
+    }
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+#endif
+    for (long f = 0; f < n_frames; f++) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (long p = f - (window - 1) < 0 ? 0 : f - (window - 1); p <= f; p++) {
+            lo = rlo[p] < lo ? rlo[p] : lo;
+            hi = rhi[p] > hi ? rhi[p] : hi;
+        }
+        const float *row = rows + f * len;
+        const double stop = (double)(len - 1);
+        for (int x = 0; x < disp_w; x++) {
+            double xp, v;
+            if (disp_w == 1) xp = 0.0;
+            else {
+                const double step = stop / (double)(disp_w - 1);
+                xp = (x == disp_w - 1) ? stop : (double)x * step;
+            }
+            if (xp >= stop) v = (double)row[len - 1];
+            else {
+                const int j = (int)xp;
+                const double slope = ((double)row[j + 1] - (double)row[j]) / ((double)(j + 1) - (double)j);
+                v = slope * (xp - (double)j) + (double)row[j];
+            }
+            int8_t g = -1, ci = -1;
+            if (isfinite(v)) {
+                const double nv = (v - lo) / (hi - lo);
+                ci = (int8_t)(int)(nv * 5);
+                g = nv > 0.75 ? 3 : nv > 0.5 ? 2 : nv > 0.25 ? 1 : 0;
+            }
+            glyph[f * disp_w + x] = g;
+            colour[f * disp_w + x] = ci;
+        }
+    }
+    free(rlo);
+    free(rhi);
+}

@@ -106,6 +106,13 @@ void pss_o_spectrogram_cells(const double *row, int len, int disp_h, int disp_w,
 void pss_o_batch_spectrum_nfm(const float *iq, long n_frames, int n, double fs, int q, const double *taps,
                               const double *sos, const double *zi, float *db_out, int16_t *pcm_out,
                               int n_threads);
+/* the same + the caller's post-process (float32 rows, per-row finite extremes); post_out / lo_out / hi_out nullable. */
+void pss_o_batch_spectrum_post_nfm(const float *iq, long n_frames, int n, double fs, int q, const double *taps,
+                                   const double *sos, const double *zi, float *db_out, float *post_out, float *lo_out,
+                                   float *hi_out, int16_t *pcm_out, int n_threads);
+/* batched waterfall accumulator: newest display line per frame, history of `window` rows (pyspecsdr.py:1342-1406). */
+void pss_o_waterfall_rows(const float *rows, long n_frames, int len, int window, int disp_w, int8_t *glyph, int8_t *colour,
+                          int n_threads);
 
 #ifdef __cplusplus
 }

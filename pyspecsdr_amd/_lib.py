@@ -16,6 +16,7 @@ _SIGS = {
     "pss_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
     "pss_destroy": (None, [_p]),
     "pss_set_stream": (C.c_int, [_p, _p]),
+    "pss_get_stream": (_p, [_p]),
     "pss_sync": (C.c_int, [_p]),
     "pss_last_error": (C.c_char_p, [_p]),
     "pss_device_count": (C.c_int, []),
@@ -31,6 +32,13 @@ _SIGS = {
     "pss_get_ssb_taps": (C.c_int, [_p, C.c_double, _p]),
     "pss_spectrum_db": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
     "pss_spectrum_post": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
+    "pss_spectrum_post_extremes": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, _p]),
+    "pss_row_extremes": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p]),
+    "pss_row_extremes_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p]),
+    "pss_waterfall_rows": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "pss_waterfall_rows_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "pss_persistence_rows": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "pss_persistence_rows_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "pss_scan": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p]),
     "pss_scan_threshold": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, C.c_double, _p, _p, _p, _p]),
     "pss_power_db": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),

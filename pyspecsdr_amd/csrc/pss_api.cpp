@@ -145,6 +145,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     if (ctx->d_hann) hipFree(ctx->d_hann);
     if (ctx->scratch_scan) hipFree(ctx->scratch_scan);
     if (ctx->scratch_pk) hipFree(ctx->scratch_pk);
+    if (ctx->scratch_win) hipFree(ctx->scratch_win);
     if (ctx->stage) hipFree(ctx->stage);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);
@@ -168,6 +169,8 @@ extern "C" int pss_set_stream(pss_ctx *ctx, void *hip_stream)
     return PSS_OK;
 }
 
+extern "C" void *pss_get_stream(pss_ctx *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream) : nullptr; }
+
 extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
 {
     if (!ctx || !key) return PSS_E_ARG;
@@ -178,6 +181,7 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "fft_split")) { ctx->fft_split = value; return PSS_OK; }
     if (!strcmp(key, "fft_prefetch")) { ctx->fft_prefetch = value; return PSS_OK; }
     if (!strcmp(key, "post_sort_max")) { ctx->post_sort_max = value; return PSS_OK; }
+    if (!strcmp(key, "post_legacy")) { ctx->post_legacy = value != 0; return PSS_OK; }
     if (!strcmp(key, "wfm_small_batch_max")) { ctx->wfm_small_batch_max = value; return PSS_OK; }
     return pss_fail(ctx, PSS_E_ARG, std::string("unknown option: ") + key);
 }

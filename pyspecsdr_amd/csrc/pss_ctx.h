@@ -52,6 +52,8 @@ struct pss_ctx {
     size_t scratch_scan_bytes = 0;
     void *scratch_pk = nullptr;
     size_t scratch_pk_bytes = 0;
+    void *scratch_win = nullptr;   // sliding-window extremes of the batched display accumulators
+    size_t scratch_win_bytes = 0;
     float *d_hann = nullptr;       // pss_classify: scipy's periodic Hann window (1024, float32) and sum(win * win)
     float hann_sum = 0.0f;
     size_t scratch_iqc_bytes = 0;
@@ -62,6 +64,7 @@ struct pss_ctx {
     bool no_wfm_fused = false;  // option "wfm_fused" = 0: k_wfm_front + k_nfm_iir path (A/B testing)
     long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~12000)
     long wfm_small_batch_max = 8192;  // option "wfm_small_batch_max" (measured crossover with the fused kernels ~12000 frames)
+    bool post_legacy = false;  // option "post_legacy": LDS bitonic sort / LDS-histogram radix select instead of the register select
     int post_sort_max = 8192;  // option "post_sort_max": longest row that takes the LDS bitonic sort, else radix select (measured crossover 8192..16384)
     int fft_prefetch = -1;  // option "fft_prefetch": request the next frame's samples before transforming the current one; -1 = automatic
     int fft_split = -1;  // option "fft_split": component-wise LDS exchanges in k_spectrum_r16; -1 = automatic (N = 256 only)

@@ -20,6 +20,7 @@
 
 #include "pss_ctx.h"
 #include "pss_fft_r16.h"
+#include "pss_post.h"
 
 namespace {
 
@@ -1022,40 +1023,177 @@ extern "C" int pss_scan_threshold(pss_ctx *ctx, const float *d_iq, long n_slices
     return scan_reduce(ctx, rows, n, n_slices, 1, (float)threshold_db, fs / (double)n, d_peak, d_bw, d_count);
 }
 
-extern "C" int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post)
+namespace {
+
+template <int EPL, int W>
+int launch_post_sel(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_lo, float *d_hi)
 {
-    if (!ctx) return PSS_E_ARG;
-    PSS_GUARD(ctx);
+    constexpr int T = 64 * W, RPW = W == 1 ? 4 : 1;
+    const size_t lds = (size_t)RPW * (T + 1) * pss_post::PostCfg<EPL>::S * sizeof(float);
+    auto kern = n_fft == T * EPL ? pss_post::k_post_sel<EPL, W, true> : pss_post::k_post_sel<EPL, W, false>;
+    if (lds > 64 * 1024)
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long groups = (n_frames + RPW - 1) / RPW;
+    const long cap = 256L * (W == 1 ? 6 : (W <= 4 ? 4 : 1));
+    pss_kernel_begin(ctx, "k_post");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(W == 1 ? 256 : 64 * W), lds, PSS_STREAM(ctx), d_db,
+                       d_post, n_fft, n_frames, d_lo, d_hi);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_post_sel launch");
+}
+
+// smoothing + median clamp of n_frames rows; d_lo / d_hi (both or neither) receive the finite extremes of every clamped row
+int spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_lo, float *d_hi)
+{
     if (n_frames < 0 || (n_frames > 0 && (!d_db || !d_post))) return pss_fail(ctx, PSS_E_ARG, "null pointer");
+    if ((d_lo == nullptr) != (d_hi == nullptr)) return pss_fail(ctx, PSS_E_ARG, "row extremes: pass both arrays or neither");
     if (n_fft < 8 || n_fft > (1 << 20)) return pss_fail(ctx, PSS_E_ARG, "post-process supports 8 <= n_fft <= 1048576");
     if (n_frames == 0) return PSS_OK;
-    if (n_fft > ctx->post_sort_max) {  // rows too long for the LDS sort: radix select of the two middle order statistics
-        pss_time_begin(ctx);
+    const int m = n_fft - 4;
+    int r = PSS_OK;
+    pss_time_begin(ctx);
+    if (!ctx->post_legacy && m <= 32768 && (n_fft & 3) == 0) {
+        // register-resident binary-search select: one wavefront per row up to 2048 points, 4 / 16 wavefronts above
+        if (m <= 256) r = launch_post_sel<4, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
+        else if (m <= 512) r = launch_post_sel<8, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
+        else if (m <= 1024) r = launch_post_sel<16, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
+        else if (m <= 2048) r = launch_post_sel<32, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
+        else if (m <= 4096) r = launch_post_sel<16, 4>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
+        else if (m <= 8192) r = launch_post_sel<32, 4>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
+        else if (m <= 16384) r = launch_post_sel<16, 16>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
+        else r = launch_post_sel<32, 16>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
+    } else if (n_fft > ctx->post_sort_max) {
+        // rows too long for registers / the LDS sort: MSD radix select with an LDS histogram
         pss_kernel_begin(ctx, "k_post");
         const int thr = n_fft <= 2048 ? 256 : 1024;
         hipLaunchKernelGGL(k_post_select, dim3((unsigned)(n_frames < 8192 ? n_frames : 8192)), dim3(thr), 0, PSS_STREAM(ctx), d_db,
                            d_post, n_fft, n_frames);
         pss_kernel_end(ctx);
-        pss_time_end(ctx);
-        return pss_hip_check(ctx, hipGetLastError(), "k_post_select launch");
+        r = pss_hip_check(ctx, hipGetLastError(), "k_post_select launch");
+    } else {
+        // option "post_legacy": bitonic sort of the smoothed row in LDS (kept as an A/B reference)
+        int P = 1;
+        while (P < n_fft - 4) P <<= 1;
+        const size_t lds = (size_t)P * sizeof(float);
+        if (lds > 64 * 1024)
+            PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_post), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds));
+        int per_cu = (int)((160 * 1024) / (lds + 64));
+        if (per_cu > 8) per_cu = 8;
+        pss_kernel_begin(ctx, "k_post");
+        const int pthreads = n_frames < 1024 ? PT : TPB;
+        hipLaunchKernelGGL(k_post, dim3(grid_for(n_frames, per_cu)), dim3(pthreads), lds, PSS_STREAM(ctx), d_db, d_post, n_fft, P,
+                           n_frames);
+        pss_kernel_end(ctx);
+        r = pss_hip_check(ctx, hipGetLastError(), "k_post launch");
     }
-    int P = 1;
-    while (P < n_fft - 4) P <<= 1;
-    size_t lds = (size_t)P * sizeof(float);
-    if (lds > 64 * 1024)
-        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_post), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds));
-    int per_cu = (int)((160 * 1024) / (lds + 64));
-    if (per_cu > 8) per_cu = 8;
+    if (!r && d_lo && (ctx->post_legacy || m > 32768 || (n_fft & 3) != 0)) {
+        pss_kernel_begin(ctx, "k_row_extremes");
+        hipLaunchKernelGGL(pss_post::k_row_extremes<float>, dim3((unsigned)((n_frames + 3) / 4 < 8192 ? (n_frames + 3) / 4 : 8192)),
+                           dim3(256), 0, PSS_STREAM(ctx), d_post, n_frames, m, d_lo, d_hi);
+        pss_kernel_end(ctx);
+        r = pss_hip_check(ctx, hipGetLastError(), "k_row_extremes launch");
+    }
+    pss_time_end(ctx);
+    return r;
+}
+
+template <class T>
+int row_extremes(pss_ctx *ctx, const T *d_rows, long n_rows, int len, T *d_lo, T *d_hi)
+{
+    if (n_rows < 0 || len < 1 || (n_rows > 0 && (!d_rows || !d_lo || !d_hi))) return pss_fail(ctx, PSS_E_ARG, "bad row-extremes arguments");
+    if (n_rows == 0) return PSS_OK;
+    pss_kernel_begin(ctx, "k_row_extremes");
+    hipLaunchKernelGGL(pss_post::k_row_extremes<T>, dim3((unsigned)((n_rows + 3) / 4 < 8192 ? (n_rows + 3) / 4 : 8192)), dim3(256), 0,
+                       PSS_STREAM(ctx), d_rows, n_rows, len, d_lo, d_hi);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_row_extremes launch");
+}
+
+// MODE 0: waterfall line (glyph, colour); MODE 1: persistence trace (y).  d_lo / d_hi: [n_halo + n_frames] row extremes.
+template <class T, int MODE>
+int display_rows(pss_ctx *ctx, const T *d_post, long n_frames, int len, const T *d_lo, const T *d_hi, int n_halo, int window,
+                 int disp_h, int disp_w, int8_t *d_a, int8_t *d_b)
+{
+    if (n_frames < 0 || len < 2 || disp_w < 1 || disp_h < 1 || disp_h > 127 || window < 1 || n_halo < 0 ||
+        (n_frames > 0 && (!d_post || !d_lo || !d_hi || !d_a || (MODE == 0 && !d_b))))
+        return pss_fail(ctx, PSS_E_ARG, "bad display-rows arguments");
+    if (n_frames == 0) return PSS_OK;
+    int r = pss_ensure_buffer(ctx, &ctx->scratch_win, &ctx->scratch_win_bytes, (size_t)n_frames * 2 * sizeof(double), "window extremes");
+    if (r) return r;
+    double *wlo = reinterpret_cast<double *>(ctx->scratch_win), *whi = wlo + n_frames;
     pss_time_begin(ctx);
-    pss_kernel_begin(ctx, "k_post");
-    // few rows (a display's last 30): latency matters -> 1024 threads per row; big batches: 256 (more rows in flight)
-    const int pthreads = n_frames < 1024 ? PT : TPB;
-    hipLaunchKernelGGL(k_post, dim3(grid_for(n_frames, per_cu)), dim3(pthreads), lds, PSS_STREAM(ctx), d_db, d_post, n_fft, P,
-                       n_frames);
+    pss_kernel_begin(ctx, "k_slide_extremes");
+    hipLaunchKernelGGL(pss_post::k_slide_extremes<T>, dim3((unsigned)((n_frames + 255) / 256 < 4096 ? (n_frames + 255) / 256 : 4096)),
+                       dim3(256), 0, PSS_STREAM(ctx), d_lo, d_hi, n_frames, n_halo, window, wlo, whi);
+    pss_kernel_end(ctx);
+    const long cells = n_frames * disp_w;
+    pss_kernel_begin(ctx, "k_disp_rows");
+    hipLaunchKernelGGL((pss_post::k_disp_rows<T, MODE>), dim3((unsigned)((cells + 255) / 256 < 16384 ? (cells + 255) / 256 : 16384)),
+                       dim3(256), 0, PSS_STREAM(ctx), d_post, wlo, whi, n_frames, len, disp_w, disp_h, d_a, d_b);
     pss_kernel_end(ctx);
     pss_time_end(ctx);
-    return pss_hip_check(ctx, hipGetLastError(), "k_post launch");
+    return pss_hip_check(ctx, hipGetLastError(), "k_disp_rows launch");
+}
+
+}  // namespace
+
+extern "C" int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    return spectrum_post(ctx, d_db, n_frames, n_fft, d_post, nullptr, nullptr);
+}
+
+extern "C" int pss_spectrum_post_extremes(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_row_lo,
+                                          float *d_row_hi)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames > 0 && (!d_row_lo || !d_row_hi)) return pss_fail(ctx, PSS_E_ARG, "null row-extremes array");
+    return spectrum_post(ctx, d_db, n_frames, n_fft, d_post, d_row_lo, d_row_hi);
+}
+
+extern "C" int pss_row_extremes(pss_ctx *ctx, const float *d_rows, long n_rows, int len, float *d_row_lo, float *d_row_hi)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    return row_extremes<float>(ctx, d_rows, n_rows, len, d_row_lo, d_row_hi);
+}
+extern "C" int pss_row_extremes_f64(pss_ctx *ctx, const double *d_rows, long n_rows, int len, double *d_row_lo, double *d_row_hi)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    return row_extremes<double>(ctx, d_rows, n_rows, len, d_row_lo, d_row_hi);
+}
+
+extern "C" int pss_waterfall_rows(pss_ctx *ctx, const float *d_post, long n_frames, int len, const float *d_row_lo,
+                                  const float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph, int8_t *d_colour)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    return display_rows<float, 0>(ctx, d_post, n_frames, len, d_row_lo, d_row_hi, n_halo, window, 1, disp_w, d_glyph, d_colour);
+}
+extern "C" int pss_waterfall_rows_f64(pss_ctx *ctx, const double *d_post, long n_frames, int len, const double *d_row_lo,
+                                      const double *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph, int8_t *d_colour)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    return display_rows<double, 0>(ctx, d_post, n_frames, len, d_row_lo, d_row_hi, n_halo, window, 1, disp_w, d_glyph, d_colour);
+}
+extern "C" int pss_persistence_rows(pss_ctx *ctx, const float *d_post, long n_frames, int len, const float *d_row_lo,
+                                    const float *d_row_hi, int n_halo, int window, int disp_h, int disp_w, int8_t *d_y)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    return display_rows<float, 1>(ctx, d_post, n_frames, len, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_y, nullptr);
+}
+extern "C" int pss_persistence_rows_f64(pss_ctx *ctx, const double *d_post, long n_frames, int len, const double *d_row_lo,
+                                        const double *d_row_hi, int n_halo, int window, int disp_h, int disp_w, int8_t *d_y)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    return display_rows<double, 1>(ctx, d_post, n_frames, len, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_y, nullptr);
 }
 
 extern "C" int pss_waterfall_cells(pss_ctx *ctx, const float *d_rows, int n_rows, int len, int disp_h, int disp_w,

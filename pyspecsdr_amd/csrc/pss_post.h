@@ -1,0 +1,377 @@
+// pss_post.h — the caller's spectrum post-process (pyspecsdr.py:2278-2283) and the batched display accumulators
+// (pyspecsdr.py:1342-1406 waterfall, :1512-1564 persistence) for whole batches of dB rows.  Included by pss_fft.hip.
+//
+// k_post_sel<EPL, W>: 5-tap moving average ('valid', float64 products and sums as np.convolve forms them), the median of
+// the smoothed row, clamp below median - 10.  A row is owned by W wavefronts (W = 1: four independent rows per
+// 256-thread workgroup and not a single workgroup barrier); thread t of T = 64 W keeps
+// the smoothed row in registers — EPL CONSECUTIVE elements, transposed through LDS on the way in and out, so that global
+// accesses are 16 bytes per lane and contiguous per wavefront and each sample is converted to float64 once.  The median is a
+// bit-by-bit binary search over the order-preserving integer image of the float32 values, below the common prefix of the
+// row's extremes and until a single candidate is left (about a dozen steps for a dB row): per step every register slot is
+// compared with the trial value, the per-lane counts are summed over the wavefront on the DPP crossbar — no LDS, no sort.
+// (The previous kernel bitonic-sorted the row in LDS: 55 barrier stages to find two order statistics.)
+// Optionally the finite minimum / maximum of each clamped row is written out: the display accumulators normalise with the
+// extremes of the last 30 (10) rows, which then costs 8 bytes per row to look up instead of a pass over 30 rows.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pss_post {
+
+// order-preserving integer image of a float32 (unsigned compare = float compare; -0 < +0; NaNs at the two ends), branch-free
+__device__ __forceinline__ unsigned f2ord(float v)
+{
+    const unsigned u = __float_as_uint(v);
+    return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float(o ^ ((unsigned)((int)~o >> 31) | 0x80000000u)); }
+constexpr unsigned ORD_NEG_INF = 0x007fffffu, ORD_POS_INF = 0xff800000u;  // images of -inf / +inf: finite values lie strictly between
+
+// ---- wavefront reductions on the DPP crossbar (no LDS, no SALU chains) ---------------------------------------------------
+// quad_perm / row_half_mirror / row_mirror leave every lane of a 16-lane row with its row's result; the four row results are
+// then read with v_readlane and combined on the scalar unit.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+struct OpAdd { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return a + b; } };
+struct OpMin { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return a < b ? a : b; } };
+struct OpMax { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return a > b ? a : b; } };
+
+template <class Op>
+__device__ __forceinline__ unsigned wave_reduce(unsigned v)
+{
+    v = Op::f(v, dpp_u32<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = Op::f(v, dpp_u32<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = Op::f(v, dpp_u32<0x141>(v));   // row_half_mirror
+    v = Op::f(v, dpp_u32<0x140>(v));   // row_mirror
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return Op::f(Op::f(a, b), Op::f(c, d));
+}
+
+// the same over the W wavefronts of a row (W = 1: nothing more to do); `red` is double-buffered: one barrier per reduction
+template <class Op, int W>
+__device__ __forceinline__ unsigned row_reduce(unsigned v, unsigned *red, int wave, int lane, int &phase)
+{
+    v = wave_reduce<Op>(v);
+    if constexpr (W == 1) return v;
+    unsigned *slot = red + (phase & 1) * W;
+    phase++;
+    if (lane == 0) slot[wave] = v;
+    __syncthreads();
+    unsigned s = slot[0];
+#pragma unroll
+    for (int w = 1; w < W; w++) s = Op::f(s, slot[w]);
+    return s;
+}
+
+// number of keys of the row below `trial`.  The per-lane count is accumulated on the vector unit (v_cmp + v_addc per
+// element) and reduced once: counting each register slot with ballot + s_bcnt1 + s_add instead put 2 scalar instructions
+// per element on the CU's single scalar unit and made the kernel scalar-issue bound (measured: 0.23 ms at 65536 x 1024).
+template <int EPL, int W>
+__device__ __forceinline__ unsigned count_below(const unsigned (&key)[EPL], unsigned trial, unsigned *red, int wave, int lane,
+                                                int &phase)
+{
+    unsigned c = 0;
+#pragma unroll
+    for (int r = 0; r < EPL; r++) c += key[r] < trial ? 1u : 0u;
+    return row_reduce<OpAdd, W>(c, red, wave, lane, phase);
+}
+
+// k-th smallest (0-based) of the row's n_valid keys (padding slots hold 0xffffffff): binary search on the key bits below
+// the common prefix of the row's minimum and maximum (returned in mn / mx); stops as soon as one candidate is left.
+// PAD_FROM: first register slot that may hold padding (EPL: none anywhere).
+template <int EPL, int W, int PAD_FROM>
+__device__ __forceinline__ unsigned select_kth(const unsigned (&key)[EPL], unsigned k, unsigned n_valid, unsigned &mn, unsigned &mx,
+                                               unsigned *red, int wave, int lane, int &phase)
+{
+    unsigned a = 0xffffffffu, b0 = 0u, b2 = 0u;
+#pragma unroll
+    for (int r = 0; r < EPL; r++) {
+        a = key[r] < a ? key[r] : a;                          // padding = 0xffffffff never lowers the minimum
+        if (r < PAD_FROM) b0 = key[r] > b0 ? key[r] : b0;     // never padding: taken as it is
+        else { const unsigned kp = key[r] + 1u; b2 = kp > b2 ? kp : b2; }  // padding wraps to 0, the neutral element
+    }
+    if (PAD_FROM < EPL) { b2 = b2 ? b2 - 1u : 0u; b0 = b2 > b0 ? b2 : b0; }
+    mn = row_reduce<OpMin, W>(a, red, wave, lane, phase);
+    mx = row_reduce<OpMax, W>(b0, red, wave, lane, phase);
+    if (mn == mx) return mn;
+    int b = 31 - __builtin_clz(mn ^ mx);                      // highest bit in which two keys of the row differ
+    unsigned lo = mn & ~((2u << b) - 1u);                     // all keys lie in [lo, lo + 2^(b+1))
+    unsigned n_lo = 0, n_hi = n_valid;                        // #keys < lo, #keys < lo + 2^(b+1)
+#pragma unroll 1
+    for (; b >= 0; b--) {
+        const unsigned trial = lo | (1u << b);
+        const unsigned c = count_below<EPL, W>(key, trial, red, wave, lane, phase);
+        if (c <= k) { lo = trial; n_lo = c; } else n_hi = c;
+        if (n_hi - n_lo == 1) {
+            // one key left in [lo, lo + 2^b): it is the answer
+            unsigned cand = 0xffffffffu;
+            const unsigned span = 1u << b;
+#pragma unroll
+            for (int r = 0; r < EPL; r++) cand = (key[r] - lo < span) ? key[r] : cand;
+            return row_reduce<OpMin, W>(cand, red, wave, lane, phase);
+        }
+    }
+    return lo;
+}
+
+// LDS row stride (floats) of a thread's EPL consecutive elements: EPL + 4 (or + 8), chosen = 4 mod 8 so that the 16 lanes
+// a ds_read_b128 / ds_write_b128 services together start 16 bytes apart modulo the 64 banks (conflict-free)
+template <int EPL>
+struct PostCfg {
+    static constexpr int S = ((EPL + 4) % 8 == 4) ? EPL + 4 : EPL + 8;
+};
+
+template <bool WAVE_LOCAL>
+__device__ __forceinline__ void row_sync()
+{
+    if constexpr (WAVE_LOCAL) {  // the row's threads are the lanes of one wavefront, whose LDS instructions execute in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// Requires N % 4 == 0 (16-byte aligned rows) and N - 4 <= 64 * W * EPL.  FULL: N == 64 * W * EPL exactly (the power-of-two
+// read buffers), where the only padding is the last thread's last four slots.
+template <int EPL, int W, bool FULL>
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_post_sel(const float *__restrict__ db, float *__restrict__ post, int N,
+                                                                     long n_frames, float *__restrict__ row_lo,
+                                                                     float *__restrict__ row_hi)
+{
+    constexpr int T = 64 * W;                    // threads per row
+    constexpr int RPW = W == 1 ? 4 : 1;          // rows per workgroup
+    constexpr int S = PostCfg<EPL>::S, Q = EPL / 4;
+    constexpr int PAD_FROM = FULL ? EPL - 4 : 0;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ unsigned red[2 * (W > 1 ? W : 1)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = W == 1 ? lane : tid;           // thread inside the row
+    float *buf = reinterpret_cast<float *>(smem) + (W == 1 ? wave : 0) * (T + 1) * S;
+    const int m = N - 4, n4 = N >> 2, m4 = m >> 2;
+    const int nv = m - t * EPL;                  // this thread's slots r < nv hold elements of the smoothed row
+    int phase = 0;
+    // LDS slot of the 4-element chunk c = j * T + t (the unit of the coalesced global accesses)
+    int slot[Q];
+#pragma unroll
+    for (int j = 0; j < Q; j++) {
+        const int e0 = 4 * (j * T + t);
+        slot[j] = (e0 / EPL) * S + (e0 % EPL);
+    }
+    const long groups = (n_frames + RPW - 1) / RPW;
+    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+        const long f = g * RPW + (W == 1 ? wave : 0);
+        if (W == 1 && f >= n_frames) continue;   // whole wavefront (rows are wavefront-private when W = 1)
+        const float4 *row4 = reinterpret_cast<const float4 *>(db + (size_t)f * N);
+        float4 q[Q];
+#pragma unroll
+        for (int j = 0; j < Q; j++) {
+            const int c = j * T + t;
+            q[j] = row4[(FULL || c < n4) ? c : 0];   // chunks past the row re-read chunk 0 (their elements are never used)
+        }
+#pragma unroll
+        for (int j = 0; j < Q; j++) *reinterpret_cast<float4 *>(buf + slot[j]) = q[j];
+        // rows of more than T * EPL points (N - 4 <= T * EPL < N): the last thread's window reaches into one more chunk
+        if (!FULL && t == 0 && T * Q < n4) *reinterpret_cast<float4 *>(buf + T * S) = row4[T * Q];
+        row_sync<W == 1>();
+        // EPL consecutive elements + the next thread's first four (the 5-tap window of the last four outputs)
+        unsigned key[EPL];
+        {
+            float x[EPL + 4];
+#pragma unroll
+            for (int i = 0; i < Q + 1; i++) {
+                const float4 v = *reinterpret_cast<const float4 *>(buf + (i < Q ? t * S + 4 * i : (t + 1) * S));
+                x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+            }
+            // np.convolve(fd, ones(5)/5, 'valid') in float64 (pyspecsdr.py:2279); the row is kept as the order-preserving
+            // integer image of its float32 value (4 bytes per element instead of 12)
+            double xd[EPL + 4];
+#pragma unroll
+            for (int i = 0; i < EPL + 4; i++) xd[i] = (double)x[i];
+#pragma unroll
+            for (int r = 0; r < EPL; r++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) acc += xd[r + k] * 0.2;
+                key[r] = f2ord((float)acc);
+                // padding sorts above everything
+                if (FULL) { if (r >= PAD_FROM) key[r] = t == T - 1 ? 0xffffffffu : key[r]; }
+                else key[r] = r < nv ? key[r] : 0xffffffffu;
+            }
+        }
+        // np.median: the middle order statistic, or the mean of the two middle ones
+        const unsigned k1 = (unsigned)((m - 1) >> 1);
+        unsigned mn, mx;
+        const unsigned v1 = select_kth<EPL, W, PAD_FROM>(key, k1, (unsigned)m, mn, mx, red, wave, lane, phase);
+        double med = (double)ord2f(v1);
+        if (!(m & 1)) {
+            // rank k1 + 1: v1 again if it is repeated often enough, else the smallest key above it
+            unsigned v2 = v1;
+            if (v1 != 0xffffffffu && count_below<EPL, W>(key, v1 + 1u, red, wave, lane, phase) <= k1 + 1u) {
+                unsigned c = 0xffffffffu;
+#pragma unroll
+                for (int r = 0; r < EPL; r++) c = (key[r] > v1 && key[r] < c) ? key[r] : c;
+                v2 = row_reduce<OpMin, W>(c, red, wave, lane, phase);
+            }
+            med = 0.5 * (med + (double)ord2f(v2));
+        }
+        // fd[fd < thr] = thr (:2282-2283).  float32(max(s, thr)) = max(float32(s), float32(thr)) (rounding is monotonic), and
+        // the maximum of two floats is the maximum of their ordered images
+        const unsigned thr = f2ord((float)(med - 10.0));
+        row_sync<W == 1>();                      // every thread has read its input window
+#pragma unroll
+        for (int i = 0; i < Q; i++) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned kk = key[4 * i + k];
+                o[k] = ord2f(kk > thr ? kk : thr);
+            }
+            *reinterpret_cast<float4 *>(buf + t * S + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        row_sync<W == 1>();
+        float4 *out4 = reinterpret_cast<float4 *>(post + (size_t)f * m);
+#pragma unroll
+        for (int j = 0; j < Q; j++) {
+            const int c = j * T + t;
+            if (c < m4) out4[c] = *reinterpret_cast<const float4 *>(buf + slot[j]);
+        }
+        if (row_lo) {
+            // finite extremes of the clamped row, as the accumulators' np.isfinite masks see them.  A row whose smoothed
+            // values are all finite (any real dB row): min / max commute with the clamp.
+            unsigned a, b;
+            if (mn > ORD_NEG_INF && mx < ORD_POS_INF) {
+                a = mn > thr ? mn : thr;
+                b = mx > thr ? mx : thr;
+            } else {
+                a = 0xffffffffu; b = 0u;
+#pragma unroll
+                for (int r = 0; r < EPL; r++) {
+                    const unsigned kk = key[r] > thr ? key[r] : thr;
+                    const bool fin = key[r] != 0xffffffffu && kk > ORD_NEG_INF && kk < ORD_POS_INF;
+                    a = (fin && kk < a) ? kk : a;
+                    b = (fin && kk > b) ? kk : b;
+                }
+                a = row_reduce<OpMin, W>(a, red, wave, lane, phase);
+                b = row_reduce<OpMax, W>(b, red, wave, lane, phase);
+                if (a > b) { a = f2ord(INFINITY); b = f2ord(-INFINITY); }  // no finite value: the neutral pair
+            }
+            if (t == 0) { row_lo[f] = ord2f(a); row_hi[f] = ord2f(b); }
+        }
+        row_sync<W == 1>();                      // the next row overwrites the staging buffer
+    }
+}
+
+// ---- batched display accumulators -----------------------------------------------------------------------------------
+// The reference keeps the last 30 (waterfall, pyspecsdr.py:130-131,1351-1353) / 10 (persistence, :151-152,1521-1523)
+// post-processed rows and, for every new frame, normalises with the finite minimum / maximum over that history
+// (:1356-1358, :1525-1530).  For a batch of frames that is a sliding-window extreme over per-row extremes:
+// win_lo[i] = min(row_lo[i - window + 1 .. i]); rows before the batch are supplied as a halo of n_halo (lo, hi) pairs in
+// front of the arrays (from the previous batch, or from the left neighbour when the batch is sharded over GPUs: 8 bytes
+// per row instead of the rows themselves).
+
+// finite minimum / maximum of every row (np.min / np.max over all_data[np.isfinite(all_data)], one row's share);
+// a row without a finite value yields (+inf, -inf), the neutral pair.  One wavefront per row.
+template <class T>
+__global__ __launch_bounds__(256) void k_row_extremes(const T *__restrict__ rows, long n_rows, int len, T *__restrict__ row_lo,
+                                                      T *__restrict__ row_hi)
+{
+    const int lane = threadIdx.x & 63;
+    const long wpb = blockDim.x >> 6;
+    for (long f = (long)blockIdx.x * wpb + (threadIdx.x >> 6); f < n_rows; f += (long)gridDim.x * wpb) {
+        const T *row = rows + (size_t)f * len;
+        T lo = (T)INFINITY, hi = (T)-INFINITY;
+        for (int i = lane; i < len; i += 64) {
+            const T v = row[i];
+            if (isfinite(v)) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const T a = __shfl_xor(lo, off), b = __shfl_xor(hi, off);
+            lo = a < lo ? a : lo;
+            hi = b > hi ? b : hi;
+        }
+        if (lane == 0) { row_lo[f] = lo; row_hi[f] = hi; }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_slide_extremes(const T *__restrict__ row_lo, const T *__restrict__ row_hi, long n_frames,
+                                                        int n_halo, int window, double *__restrict__ win_lo,
+                                                        double *__restrict__ win_hi)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_frames; i += (long)gridDim.x * blockDim.x) {
+        const long p = i + n_halo;               // position in the halo-prefixed arrays
+        long first = p - (window - 1);
+        if (first < 0) first = 0;
+        double lo = INFINITY, hi = -INFINITY;
+        for (long q = first; q <= p; q++) {
+            const double a = (double)row_lo[q], b = (double)row_hi[q];
+            lo = a < lo ? a : lo;
+            hi = b > hi ? b : hi;
+        }
+        win_lo[i] = lo;
+        win_hi[i] = hi;
+    }
+}
+
+// np.interp(np.linspace(0, len-1, W), np.arange(len), row)[x] in float64 (pyspecsdr.py:1379-1383 / :1550-1554)
+template <class T>
+__device__ __forceinline__ double interp_at(const T *row, int len, int W, int x)
+{
+    const double stop = (double)(len - 1);
+    double xp;
+    if (W == 1) xp = 0.0;
+    else {
+        const double step = stop / (double)(W - 1);
+        xp = (x == W - 1) ? stop : (double)x * step;
+    }
+    if (xp >= stop) return (double)row[len - 1];
+    const int j = (int)xp;
+    const double slope = ((double)row[j + 1] - (double)row[j]) / ((double)(j + 1) - (double)j);
+    return slope * (xp - (double)j) + (double)row[j];
+}
+
+// One display line per frame: the NEWEST row of the history as the reference draws it at frame i (waterfall line y = 0).
+//   MODE 0  waterfall (pyspecsdr.py:1386-1403): glyph 0 '.', 1 '-', 2 '=', 3 '#'; colour int(norm * 5); -1: not finite.
+//           No zero-range guard (:1389), as in the reference.
+//   MODE 1  persistence (:1556-1563): y = int((1 - norm) * (disp_h - 1)) of the newest trace, -1 if not drawn (not finite or
+//           outside the grid); range 0 -> 1 (:1528-1530).
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void k_disp_rows(const T *__restrict__ post, const double *__restrict__ win_lo,
+                                                   const double *__restrict__ win_hi, long n_frames, int len, int disp_w,
+                                                   int disp_h, int8_t *__restrict__ out_a, int8_t *__restrict__ out_b)
+{
+    const long total = n_frames * disp_w;
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
+        const long f = c / disp_w;
+        const int x = (int)(c - f * disp_w);
+        const double lo = win_lo[f], hi = win_hi[f];
+        const double v = interp_at(post + (size_t)f * len, len, disp_w, x);
+        if (MODE == 0) {
+            int8_t g = -1, ci = -1;
+            if (isfinite(v)) {
+                const double nv = (v - lo) / (hi - lo);
+                ci = (int8_t)(int)(nv * 5);
+                g = nv > 0.75 ? 3 : nv > 0.5 ? 2 : nv > 0.25 ? 1 : 0;
+            }
+            out_a[c] = g;
+            out_b[c] = ci;
+        } else {
+            int8_t y8 = -1;
+            if (isfinite(v)) {
+                double range = hi - lo;
+                if (range == 0) range = 1;
+                const int y = (int)((1 - (v - lo) / range) * (disp_h - 1));
+                if (y >= 0 && y < disp_h) y8 = (int8_t)y;
+            }
+            out_a[c] = y8;
+        }
+    }
+}
+
+}  // namespace pss_post

@@ -61,6 +61,10 @@ class Engine:
     def set_stream(self, stream):
         self._ck(self.lib.pss_set_stream(self.h, _ptr(getattr(stream, "cuda_stream", stream))))
 
+    def stream_handle(self):
+        """The hipStream_t this engine queues its work on, as an integer (e.g. for torch.cuda.ExternalStream)."""
+        return int(self.lib.pss_get_stream(self.h) or 0)
+
     def set_option(self, key, value):
         self._ck(self.lib.pss_set_option(self.h, key.encode(), int(value)))
 
@@ -118,6 +122,29 @@ class Engine:
 
     def spectrum_post(self, d_db, n_frames, n_fft, d_post):
         self._ck(self.lib.pss_spectrum_post(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_post)))
+
+    def spectrum_post_extremes(self, d_db, n_frames, n_fft, d_post, d_row_lo, d_row_hi):
+        """Post-process + the finite min / max of every post-processed row (inputs of waterfall_rows / persistence_rows)."""
+        self._ck(self.lib.pss_spectrum_post_extremes(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_post), _ptr(d_row_lo),
+                                                     _ptr(d_row_hi)))
+
+    def row_extremes(self, d_rows, n_rows, length, d_row_lo, d_row_hi, f64=False):
+        fn = self.lib.pss_row_extremes_f64 if f64 else self.lib.pss_row_extremes
+        self._ck(fn(self.h, _ptr(d_rows), n_rows, length, _ptr(d_row_lo), _ptr(d_row_hi)))
+
+    def waterfall_rows(self, d_post, n_frames, length, d_row_lo, d_row_hi, disp_w, d_glyph, d_colour, n_halo=0, window=30,
+                       f64=False):
+        """Batched waterfall accumulator: the newest display line of every frame (history of `window` rows)."""
+        fn = self.lib.pss_waterfall_rows_f64 if f64 else self.lib.pss_waterfall_rows
+        self._ck(fn(self.h, _ptr(d_post), n_frames, length, _ptr(d_row_lo), _ptr(d_row_hi), n_halo, window, disp_w,
+                    _ptr(d_glyph), _ptr(d_colour)))
+
+    def persistence_rows(self, d_post, n_frames, length, d_row_lo, d_row_hi, disp_h, disp_w, d_y, n_halo=0, window=10,
+                         f64=False):
+        """Batched persistence accumulator: the newest trace's row index per column for every frame."""
+        fn = self.lib.pss_persistence_rows_f64 if f64 else self.lib.pss_persistence_rows
+        self._ck(fn(self.h, _ptr(d_post), n_frames, length, _ptr(d_row_lo), _ptr(d_row_hi), n_halo, window, disp_h, disp_w,
+                    _ptr(d_y)))
 
     def scan(self, d_iq, n_slices, n_fft, fs, d_db, d_peak, d_bw, d_count):
         self._ck(self.lib.pss_scan(self.h, _ptr(d_iq), n_slices, n_fft, float(fs), _ptr(d_db), _ptr(d_peak),

@@ -76,6 +76,9 @@ def lib():
         L.pss_o_persistence_cells.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, C.c_int, _i8p]
         L.pss_o_batch_spectrum_nfm.argtypes = [_f32p, C.c_long, C.c_int, C.c_double, C.c_int, _f64p, _f64p,
                                                _f64p, _f32p, _i16p, C.c_int]
+        L.pss_o_batch_spectrum_post_nfm.argtypes = [_f32p, C.c_long, C.c_int, C.c_double, C.c_int, _f64p, _f64p, _f64p, _f32p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, _i16p, C.c_int]
+        L.pss_o_waterfall_rows.argtypes = [_f32p, C.c_long, C.c_int, C.c_int, C.c_int, _i8p, _i8p, C.c_int]
         _lib = L
     return _lib
 
@@ -284,3 +287,33 @@ def batch_spectrum_nfm(iq2d, fs, taps, sos, zi, n_threads=1):
                                    np.ascontiguousarray(taps, np.float64), np.ascontiguousarray(sos, np.float64),
                                    np.ascontiguousarray(zi, np.float64), db.reshape(-1), pcm.reshape(-1), n_threads)
     return db, pcm
+
+
+class HeadlineBuffers:
+    """Preallocated outputs of the full BASELINE cfg-2 step on the CPU (bench.py's cpu_baseline leg re-runs the step
+    several times; allocating 0.5 GB of outputs per call would be timed as well)."""
+
+    def __init__(self, nf, n, fs, disp_w=112):
+        self.q = int(fs / 22050)
+        self.n_out = (n - 1 + self.q - 1) // self.q
+        self.db = np.empty((nf, n), np.float32)
+        self.post = np.empty((nf, n - 4), np.float32)
+        self.lo = np.empty(nf, np.float32)
+        self.hi = np.empty(nf, np.float32)
+        self.pcm = np.empty((nf, self.n_out, 2), np.int16)
+        self.glyph = np.empty((nf, disp_w), np.int8)
+        self.colour = np.empty((nf, disp_w), np.int8)
+
+
+def batch_headline(iq2d, fs, taps, sos, zi, buf, n_threads=1, window=30):
+    """compute_fft + post-process + waterfall line + NFM -> int16 for every frame (what one bench.py step does on the GPU)."""
+    iq2d = np.ascontiguousarray(iq2d, np.complex64)
+    nf, n = iq2d.shape
+    L = lib()
+    L.pss_o_batch_spectrum_post_nfm(iq2d.view(np.float32).reshape(-1), nf, n, fs, buf.q, np.ascontiguousarray(taps, np.float64),
+                                    np.ascontiguousarray(sos, np.float64), np.ascontiguousarray(zi, np.float64),
+                                    buf.db[:nf].reshape(-1), buf.post[:nf].ctypes.data, buf.lo[:nf].ctypes.data,
+                                    buf.hi[:nf].ctypes.data, buf.pcm[:nf].reshape(-1), n_threads)
+    L.pss_o_waterfall_rows(buf.post[:nf].reshape(-1), nf, n - 4, window, buf.glyph.shape[1], buf.glyph[:nf].reshape(-1),
+                           buf.colour[:nf].reshape(-1), n_threads)
+    return buf

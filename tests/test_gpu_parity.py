@@ -128,6 +128,106 @@ def test_post_process_long_rows(n):
         assert np.all(np.abs(post[f] - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0)), (n, f, np.abs(post[f] - ref).max())
 
 
+@pytest.mark.parametrize("n", [8, 12, 256, 512, 1000, 1024, 2048, 4096, 8192, 16384, 20000, 32768, 32772])
+def test_post_process_select_kernel_equals_sort_kernel(n):
+    """The register-resident binary-search select (default) and the LDS sort / radix-select kernels (option post_legacy)
+    must produce the same bits: same float32 smoothed values, same two middle order statistics, same clamp."""
+    rng = np.random.default_rng(n)
+    nf = 37 if n <= 4096 else 5
+    db = (rng.standard_normal((nf, n)) * 6.0 - 35.0).astype(np.float32)
+    db[0, : n // 2] = np.round(db[0, : n // 2])           # heavy ties around the median
+    db[1] = -42.5                                          # a constant row
+    if n >= 256:
+        db[2, 100:140] += 50.0
+    e = G.engine()
+    d_db = G.dev(db)
+    res = []
+    for legacy in (0, 1):
+        e.set_option("post_legacy", legacy)
+        try:
+            d_post = G.empty((nf, n - 4), torch.float32)
+            d_post.fill_(float("nan"))
+            e.spectrum_post(d_db, nf, n, d_post)
+            e.sync()
+            res.append(G.host(d_post))
+        finally:
+            e.set_option("post_legacy", 0)
+    assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32)), n
+    for f in (0, 1, nf - 1):
+        sm = np.convolve(db[f].astype(np.float64), np.ones(5) / 5, mode="valid")
+        thr = np.median(sm) - 10
+        ref = np.where(sm < thr, thr, sm)
+        assert np.all(np.abs(res[0][f] - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0)), (n, f)
+
+
+def test_post_process_row_extremes():
+    rng = np.random.default_rng(77)
+    e = G.engine()
+    for n in (1024, 2048, 4096, 16384, 1002):
+        nf = 50
+        db = (rng.standard_normal((nf, n)) * 5.0 - 60.0).astype(np.float32)
+        db[3, 10:20] = np.inf                              # non-finite values are not extremes (np.isfinite mask)
+        d_post, d_lo, d_hi = G.empty((nf, n - 4), torch.float32), G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
+        e.spectrum_post_extremes(G.dev(db), nf, n, d_post, d_lo, d_hi)
+        e.sync()
+        post, lo, hi = G.host(d_post), G.host(d_lo), G.host(d_hi)
+        for f in range(nf):
+            fin = post[f][np.isfinite(post[f])]
+            assert lo[f] == fin.min() and hi[f] == fin.max(), (n, f)
+        d_lo2, d_hi2 = G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
+        e.row_extremes(d_post, nf, n - 4, d_lo2, d_hi2)
+        e.sync()
+        assert np.array_equal(G.host(d_lo2), lo) and np.array_equal(G.host(d_hi2), hi)
+
+
+def test_batched_accumulators_vs_reference_histories(golden):
+    """pss_waterfall_rows / pss_persistence_rows: one display line per frame for a whole batch, against the grids the
+    reference drew frame by frame (tests/golden/caller.npz: draw_waterfall / draw_persistence with a fake stdscr)."""
+    g = golden["caller"]
+    e = G.engine()
+    rows = np.ascontiguousarray(g["rows"])                 # float64 [34][1020], the caller's post-processed rows
+    nf, ln = rows.shape
+    H, W = [int(v) for v in g["hw"]]
+    dh, dw = H - 4, W - 8
+    d_rows = G.dev(rows)
+    d_lo, d_hi = G.empty((nf,), torch.float64), G.empty((nf,), torch.float64)
+    e.row_extremes(d_rows, nf, ln, d_lo, d_hi, f64=True)
+    d_g, d_c = G.empty((nf, dw), torch.int8), G.empty((nf, dw), torch.int8)
+    e.waterfall_rows(d_rows, nf, ln, d_lo, d_hi, dw, d_g, d_c, window=30, f64=True)
+    e.sync()
+    gl, co = G.host(d_g), G.host(d_c)
+    for i in range(nf):                                    # line y = 0 of the reference's grid at frame i is the newest row
+        assert np.array_equal(gl[i], g["wf_glyph"][i][0]) and np.array_equal(co[i], g["wf_colour"][i][0]), i
+    # persistence: the newest trace's '*' row per column; the reference grid holds that trace's colour there
+    nps = g["ps_colour"].shape[0]
+    d_y = G.empty((nps, dw), torch.int8)
+    e.persistence_rows(d_rows, nps, ln, d_lo, d_hi, dh, dw, d_y, window=10, f64=True)
+    e.sync()
+    ys = G.host(d_y)
+    for i in range(nps):
+        n_hist = min(i + 1, 10)
+        cp_new = int(1 + 5 * (1 - 0.7 ** (10 - (n_hist - 1))))
+        win = rows[max(0, i + 1 - 10):i + 1]
+        lo, hi = win.min(), win.max()
+        rs = np.interp(np.linspace(0, ln - 1, dw), np.arange(ln), rows[i])
+        want = ((1 - (rs - lo) / ((hi - lo) or 1.0)) * (dh - 1)).astype(int)
+        assert np.array_equal(ys[i], want), i
+        assert np.all(g["ps_colour"][i][ys[i], np.arange(dw)] == cp_new), i
+    # a history that continues across a block boundary: extremes of the preceding rows as a halo
+    cut = 13
+    d_g2, d_c2 = G.empty((nf - cut, dw), torch.int8), G.empty((nf - cut, dw), torch.int8)
+    e.waterfall_rows(d_rows[cut:], nf - cut, ln, d_lo, d_hi, dw, d_g2, d_c2, n_halo=cut, window=30, f64=True)
+    e.sync()
+    assert np.array_equal(G.host(d_g2), gl[cut:]) and np.array_equal(G.host(d_c2), co[cut:])
+    # float32 rows (what the GPU pipeline produces itself): cells differ only where a value sits on a quantisation edge
+    r32 = G.dev(rows.astype(np.float32))
+    l32, h32 = G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
+    e.row_extremes(r32, nf, ln, l32, h32)
+    e.waterfall_rows(r32, nf, ln, l32, h32, dw, d_g, d_c, window=30)
+    e.sync()
+    assert np.mean(G.host(d_g) != gl) < 2e-3 and np.mean(G.host(d_c) != co) < 2e-3
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
 def test_nfm_vs_golden_bit_exact(golden, tag):
     g = golden["nfm"]
