@@ -1,0 +1,100 @@
+"""GPU-side multi-rank drivers: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI), each rank an
+Engine on its own device, the exchange step overlapped with the next batch's compute.
+
+ShardedScanner — BASELINE.json configs[3]: the scanner sweep (pyspecsdr.py:2514-2590: every centre frequency is an
+independent slice) split into contiguous blocks of slices per rank; Engine.scan writes its results straight into the
+rank's packed message (shard.ShardBuffer), ONE gather per sweep moves it to the root on a side stream while the next
+sweep computes into the other buffer set.
+
+The library itself knows nothing about torch or RCCL (plain C ABI); this module is the host-side glue, in the
+reference's own language.
+"""
+import torch
+import torch.distributed as dist
+
+from .shard import gather_packed, scan_buffer, shard_counts, shard_range, unpack_gathered
+
+
+def _world_rank(group=None):
+    if not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+class ShardedScanner:
+    """Sweep of n_slices scanner slices of n_fft points, sharded over the ranks of `group`.
+
+    gather_db=True moves every rank's float32 dB rows (n_fft * 4 bytes per slice) + (peak, bandwidth, count) to rank
+    `dst`; gather_db=False only the 16 bytes per slice of (peak, bandwidth, count) — the dB rows stay sharded on the
+    ranks that computed them (`local_db(handle)`).
+    """
+
+    def __init__(self, engine, n_slices, n_fft, fs, gather_db=True, dst=0, group=None, device=None):
+        self.eng, self.n_slices, self.n_fft, self.fs = engine, int(n_slices), int(n_fft), float(fs)
+        self.gather_db, self.dst, self.group = gather_db, dst, group
+        self.world, self.rank = _world_rank(group)
+        self.device = torch.device("cuda", engine.device) if device is None else torch.device(device)
+        self.start, self.count = shard_range(self.n_slices, self.rank, self.world)
+        self.counts = shard_counts(self.n_slices, self.world)
+        # two buffer sets: sweep k+1 computes into one while sweep k's is in flight
+        self.bufs = [scan_buffer(self.n_slices, self.n_fft, gather_db, self.device, group) for _ in range(2)]
+        self.db_local = None if gather_db else [torch.empty((max(self.counts), self.n_fft), dtype=torch.float32, device=self.device)
+                                                for _ in range(2)]
+        # gloo (tests on a box with fewer GPUs than ranks) cannot gather device tensors: stage through the host
+        # an initialised process group means "exchange", also with a single rank (exercises the RCCL path on one GPU)
+        self.exchange = dist.is_initialized()
+        self.host_stage = self.exchange and dist.get_backend(group) == "gloo"
+        self.comp = torch.cuda.ExternalStream(engine.stream_handle(), device=self.device)
+        self.comm = torch.cuda.Stream(device=self.device)
+        self.recv = [None, None]
+        if self.rank == dst and self.exchange:
+            dev = "cpu" if self.host_stage else self.device
+            self.recv = [torch.empty((self.world, self.bufs[0].nbytes), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.sent = [None, None]     # event on the comm stream: set b's message has left (the set may be rewritten)
+        self.k = 0
+
+    def sweep(self, d_iq_local):
+        """Queue one sweep over this rank's block (d_iq_local: interleaved complex64 [count][n_fft] on this rank's GPU)
+        and its gather.  Asynchronous; returns a handle for result()."""
+        b = self.k & 1
+        self.k += 1
+        buf = self.bufs[b]
+        if self.sent[b] is not None:
+            self.comp.wait_event(self.sent[b])
+        db = buf.view("db") if self.gather_db else self.db_local[b]
+        if self.count:
+            self.eng.scan(d_iq_local, self.count, self.n_fft, self.fs, db, buf.view("peak"), buf.view("bw"), buf.view("cnt"))
+        if self.exchange:
+            self.comm.wait_stream(self.comp)
+            with torch.cuda.stream(self.comm):
+                if self.host_stage:
+                    h = buf.raw.cpu()            # synchronous on the comm stream
+                    dist.gather(h, list(self.recv[b].unbind(0)) if self.rank == self.dst else None, dst=self.dst, group=self.group)
+                else:
+                    dist.gather(buf.raw, list(self.recv[b].unbind(0)) if self.rank == self.dst else None, dst=self.dst,
+                                group=self.group)
+                self.sent[b] = self.comm.record_event()
+        return b
+
+    def wait(self, handle):
+        """Block the host until sweep `handle` (compute + gather) has finished."""
+        self.eng.sync()
+        if self.sent[handle] is not None:
+            self.sent[handle].synchronize()
+
+    def result(self, handle):
+        """(db or None, peak, bw, cnt) of the whole sweep in slice order on rank dst; None on the other ranks."""
+        self.wait(handle)
+        buf = self.bufs[handle]
+        if not self.exchange:
+            res = gather_packed(buf, self.n_slices, dst=self.dst, group=self.group)
+        elif self.rank != self.dst:
+            return None
+        else:
+            res = unpack_gathered(buf, self.recv[handle], self.counts)
+        return res.get("db"), res["peak"], res["bw"], res["cnt"]
+
+    def local_db(self, handle):
+        """This rank's dB rows [count][n_fft] of sweep `handle` (valid until the set is reused two sweeps later)."""
+        db = self.bufs[handle].view("db") if self.gather_db else self.db_local[handle]
+        return db[:self.count]

@@ -2,12 +2,17 @@
 
 Frames share nothing (every read buffer is demodulated and transformed on its own —
 signal_processing.py:91-116, pyspecsdr.py:2523-2578), so the path shards by contiguous blocks of the frame
-index with NO data-path collective.  The only exchange step is the optional gather of results to one
-rank — per-slice (peak, bandwidth) pairs, or the float32 dB rows of a scanner sweep (BASELINE.json configs[3]).
-On ROCm the "nccl" backend is RCCL; the xGMI mesh gives every pair of GPUs its own link, so a flat
-all_gather / gather (each peer sends its block directly) is the right collective — no ring staging.
-The same code runs on CPU tensors with the gloo backend (tests/test_shard.py).
+index with NO data-path collective.  The only exchange step is the gather of results to one rank — per-slice
+(peak, bandwidth, count) and, optionally, the float32 dB rows of a scanner sweep (BASELINE.json configs[3]) — and, for
+the display accumulators, a halo of the rows that precede a rank's block.
+
+One sweep = ONE collective: every rank's results live in one packed buffer (`ShardBuffer`: a section per field, each
+section sized for the largest block, so the kernels write their outputs in place and nothing is copied or padded
+afterwards) and `gather_packed` moves it with a single gather / all_gather.  On ROCm the "nccl" backend is RCCL; a
+gather is grouped point-to-point sends, which on the xGMI mesh go over each peer's own link to the root — no ring
+staging.  The same code runs on CPU tensors with the gloo backend (tests/test_shard.py).
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -23,83 +28,172 @@ def shard_counts(n_items, world):
     return [shard_range(n_items, r, world)[1] for r in range(world)]
 
 
+def _world_rank(group=None):
+    if not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+class ShardBuffer:
+    """One rank's results of a sharded pass, as ONE contiguous byte buffer with a section per field.
+
+    fields: [(name, per-item shape tuple, torch dtype), ...].  Section f holds `capacity` items (the largest block of
+    any rank), 256-byte aligned; `view(name)` is the typed [capacity, *shape] tensor over it — hand its data_ptr() to
+    the engine and the kernel writes straight into the message.
+    """
+
+    def __init__(self, fields, capacity, device):
+        self.fields = [(n, tuple(s), d) for n, s, d in fields]
+        self.capacity = int(capacity)
+        self.offsets, off = {}, 0
+        for name, shape, dtype in self.fields:
+            self.offsets[name] = off
+            nbytes = self.capacity * int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+            off += (nbytes + 255) & ~255
+        self.nbytes = max(off, 256)
+        self.raw = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+
+    def view(self, name, raw=None):
+        raw = self.raw if raw is None else raw
+        for n, shape, dtype in self.fields:
+            if n == name:
+                cnt = self.capacity * int(np.prod(shape, dtype=np.int64))
+                es = torch.empty((), dtype=dtype).element_size()
+                o = self.offsets[n]
+                return raw[o:o + cnt * es].view(dtype).view((self.capacity,) + shape)
+        raise KeyError(name)
+
+
+def gather_packed(buf, n_items, dst=0, group=None, out=None):
+    """ONE collective for everything a rank produced: gather (dst = rank) or all_gather (dst = None) of `buf.raw`.
+
+    Returns on the receiving rank(s) a dict name -> [n_items, *shape] tensor in item order (blocks of shard_range(),
+    the per-rank padding dropped); None on the others.  `out`: optional preallocated [world, buf.nbytes] uint8 tensor
+    on the receiving rank (reused across sweeps).  With one rank nothing is communicated.
+    """
+    world, rank = _world_rank(group)
+    counts = shard_counts(n_items, world)
+    if world == 1:
+        return {n: buf.view(n)[:counts[0]] for n, _, _ in buf.fields}
+    if dst is None:
+        if out is None:
+            out = torch.empty((world, buf.nbytes), dtype=torch.uint8, device=buf.raw.device)
+        dist.all_gather_into_tensor(out.view(-1), buf.raw, group=group)
+    else:
+        if rank == dst and out is None:
+            out = torch.empty((world, buf.nbytes), dtype=torch.uint8, device=buf.raw.device)
+        dist.gather(buf.raw, list(out.unbind(0)) if rank == dst else None, dst=dst, group=group)
+        if rank != dst:
+            return None
+    return unpack_gathered(buf, out, counts)
+
+
+def unpack_gathered(buf, out, counts):
+    """Typed item-order tensors over a gathered [world, buf.nbytes] byte matrix (per-rank padding dropped)."""
+    res = {}
+    for name, _, _ in buf.fields:
+        res[name] = torch.cat([buf.view(name, out[r])[:counts[r]] for r in range(len(counts))], dim=0)
+    return res
+
+
 def gather_rows(local, n_items, dst=None, group=None):
-    """Collect per-item result rows from every rank.
+    """Collect per-item result rows of ONE field from every rank (kept for single-field callers).
 
     local : tensor [count_r, ...] holding this rank's block (count_r = shard_range(...)[1]).
     dst   : None -> all_gather (every rank gets the full [n_items, ...] tensor);
             int  -> gather to that rank only (others get None).
-    Blocks are padded to the largest block so one fixed-size collective moves everything.
     """
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    world, rank = _world_rank(group)
+    if world == 1:
         return local
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = shard_counts(n_items, world)
     assert local.shape[0] == counts[rank], (local.shape, counts, rank)
-    mx = max(counts)
-    tail = tuple(local.shape[1:])
-    padded = local
-    if counts[rank] < mx:
-        padded = torch.zeros((mx,) + tail, dtype=local.dtype, device=local.device)
-        padded[:counts[rank]] = local
-    padded = padded.contiguous()
-    if dst is None:
-        buf = torch.empty((world * mx,) + tail, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(buf, padded, group=group)
-        parts = [buf[r * mx:r * mx + counts[r]] for r in range(world)]
-        return torch.cat(parts, dim=0)
-    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, bufs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return torch.cat([bufs[r][:counts[r]] for r in range(world)], dim=0)
+    buf = ShardBuffer([("x", tuple(local.shape[1:]), local.dtype)], max(counts), local.device)
+    buf.view("x")[:counts[rank]] = local
+    res = gather_packed(buf, n_items, dst=dst, group=group)
+    return None if res is None else res["x"]
 
 
 def halo_from_left(local, halo, group=None):
-    """Rows a rank needs from its LEFT neighbour so that the ring accumulators (waterfall: last 30 post-processed rows,
-    persistence: last 10 — pyspecsdr.py:130-132,151-154) of its first frames see the frames just before its block.
+    """Rows a rank needs from its LEFT neighbours so that the display accumulators (waterfall: history of 30 post-processed
+    rows, persistence: 10 — pyspecsdr.py:130-132,151-154) of its first frames see the frames just before its block.
+    `local` may be the rows themselves or, with the batched accumulators (pss_waterfall_rows), just their (lo, hi)
+    extremes — 8 bytes per row.
 
-    local : tensor [count_r, ...], this rank's block of rows in frame order.
-    Returns a tensor [h, ...] (h <= halo): the last h rows that precede this block in global order; rank 0 gets an empty
-    tensor.  One point-to-point message per neighbour pair (xGMI: a direct peer link, no collective).  A neighbour whose
-    own block is shorter than `halo` forwards what it received, so short blocks still deliver a full halo.
+    local : tensor [count_r, ...], this rank's block in frame order.
+    Returns a tensor [h, ...] (h = min(halo, rows before this block)): the rows that precede this block in global order.
+    Every rank works out from the block sizes which of its rows which rank needs (a block shorter than `halo` means the
+    halo spans several left neighbours) and all messages are posted at once (batch_isend_irecv): no rank waits for a
+    neighbour's receive before it can send, as a recv -> forward chain would.
     """
     tail = tuple(local.shape[1:])
     empty = torch.empty((0,) + tail, dtype=local.dtype, device=local.device)
-    if not dist.is_initialized() or dist.get_world_size(group) == 1 or halo <= 0:
+    world, rank = _world_rank(group)
+    if world == 1 or halo <= 0:
         return empty
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    got = empty
-    if rank > 0:
-        n = torch.zeros(1, dtype=torch.int64, device=local.device)
-        dist.recv(n, src=rank - 1, group=group)
-        got = torch.empty((int(n.item()),) + tail, dtype=local.dtype, device=local.device)
-        if got.shape[0]:
-            dist.recv(got, src=rank - 1, group=group)
-    if rank < world - 1:
-        rows = torch.cat([got, local], dim=0)[-halo:].contiguous()   # my last rows, topped up with what I was handed
-        n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=local.device)
-        dist.send(n, dst=rank + 1, group=group)
-        if rows.shape[0]:
-            dist.send(rows, dst=rank + 1, group=group)
-    return got
+    cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    allc = torch.empty(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(allc, cnt, group=group)
+    counts = [int(c) for c in allc.tolist()]
+    starts = [sum(counts[:r]) for r in range(world)]
+
+    def need(r):   # global rows rank r wants: [lo, hi)
+        return max(0, starts[r] - halo), starts[r]
+
+    ops, pieces = [], []
+    lo, hi = need(rank)
+    for s in range(rank):                          # what I receive, left to right
+        a, b = max(lo, starts[s]), min(hi, starts[s] + counts[s])
+        if b > a:
+            t = torch.empty((b - a,) + tail, dtype=local.dtype, device=local.device)
+            pieces.append(t)
+            ops.append(dist.P2POp(dist.irecv, t, s, group))
+    keep = []
+    for r in range(rank + 1, world):               # what the ranks to my right need from me
+        a, b = need(r)
+        a, b = max(a, starts[rank]), min(b, starts[rank] + counts[rank])
+        if b > a:
+            t = local[a - starts[rank]:b - starts[rank]].contiguous()
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, r, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return torch.cat(pieces, dim=0) if pieces else empty
 
 
-def sharded_scan(scan_fn, n_slices, n_fft, gather_db=False, dst=0, group=None):
-    """Scanner sweep over n_slices centre frequencies, sharded over the ranks.
+SCAN_FIELDS = (("peak", (), torch.float32), ("bw", (), torch.float64), ("cnt", (), torch.int32))
 
-    scan_fn(start, count) -> (db [count, n_fft] float32 or None, peak [count] float32, bw [count] float64,
-                              cnt [count] int32) for this rank's block (e.g. Engine.scan on the local GPU).
-    Returns on rank dst: (db or None, peak, bw, cnt) for all slices in sweep order; None elsewhere.
+
+def scan_buffer(n_slices, n_fft, gather_db, device, group=None):
+    """The packed result buffer of one rank's share of a scanner sweep (sections: [db rows,] peak, bandwidth, count)."""
+    world, _ = _world_rank(group)
+    fields = ([("db", (n_fft,), torch.float32)] if gather_db else []) + list(SCAN_FIELDS)
+    return ShardBuffer(fields, max(shard_counts(n_slices, world)), device)
+
+
+def sharded_scan(scan_fn, n_slices, n_fft, gather_db=False, dst=0, group=None, device="cpu", buf=None, out=None):
+    """Scanner sweep over n_slices centre frequencies (pyspecsdr.py:2514-2590), sharded over the ranks, one collective.
+
+    scan_fn(start, count, views) handles this rank's block: `views` maps "db" (only with gather_db), "peak", "bw",
+    "cnt" to the [capacity, ...] sections of the packed buffer; the function either fills views[name][:count] in place
+    (Engine.scan writing through data_ptr()) and returns None, or returns (db or None, peak, bw, cnt) tensors, which
+    are then copied in.  Returns on rank dst: (db or None, peak, bw, cnt) for all slices in sweep order; None elsewhere.
     """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world, rank = _world_rank(group)
     start, count = shard_range(n_slices, rank, world)
-    db, peak, bw, cnt = scan_fn(start, count)
-    out_db = gather_rows(db, n_slices, dst=dst, group=group) if (gather_db and db is not None) else None
-    out_peak = gather_rows(peak, n_slices, dst=dst, group=group)
-    out_bw = gather_rows(bw, n_slices, dst=dst, group=group)
-    out_cnt = gather_rows(cnt, n_slices, dst=dst, group=group)
-    if rank != dst and world > 1:
+    if buf is None:
+        buf = scan_buffer(n_slices, n_fft, gather_db, device, group)
+    views = {n: buf.view(n) for n, _, _ in buf.fields}
+    ret = scan_fn(start, count, views)
+    if ret is not None:
+        db, peak, bw, cnt = ret
+        if gather_db and db is not None:
+            views["db"][:count] = db
+        views["peak"][:count] = peak
+        views["bw"][:count] = bw
+        views["cnt"][:count] = cnt
+    res = gather_packed(buf, n_slices, dst=dst, group=group, out=out)
+    if res is None:
         return None
-    return out_db, out_peak, out_bw, out_cnt
+    return res.get("db"), res["peak"], res["bw"], res["cnt"]

@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pyspecsdr_amd.shard import gather_rows, halo_from_left, shard_counts, shard_range, sharded_scan
+from pyspecsdr_amd.shard import (ShardBuffer, gather_packed, gather_rows, halo_from_left, shard_counts, shard_range,
+                                 sharded_scan)
 
 import oracle_lib as O
 
@@ -42,7 +43,7 @@ def _worker(rank, world, port, n_slices, n_fft, q):
         g = np.load(os.path.join(os.path.dirname(__file__), "golden", "scanner.npz"))
         iq = np.tile(g[f"iq_{n_fft}"], (4, 1))[:n_slices]   # the same sweep on every rank; each takes its block
 
-        def scan_fn(start, count):  # stand-in for Engine.scan on the local GPU: the CPU oracle
+        def scan_fn(start, count, views):  # stand-in for Engine.scan on the local GPU: the CPU oracle, returning tensors
             db, pk, bw, cnt = [], [], [], []
             for s in range(start, start + count):
                 d, p, b, c = O.scan_slice(iq[s], 2.4e6)
@@ -57,6 +58,17 @@ def _worker(rank, world, port, n_slices, n_fft, q):
         mine = torch.arange(start, start + count, dtype=torch.float32).unsqueeze(1).repeat(1, 3)
         full = gather_rows(mine, n_slices)
         assert torch.equal(full[:, 0], torch.arange(n_slices, dtype=torch.float32))
+        # several fields, written in place into the packed buffer, one collective
+        buf = ShardBuffer([("a", (5,), torch.float32), ("b", (), torch.float64), ("c", (2,), torch.int8)], max(shard_counts(n_slices, world)), "cpu")
+        idx = torch.arange(start, start + count)
+        buf.view("a")[:count] = idx.float().unsqueeze(1) + torch.arange(5).float() / 8
+        buf.view("b")[:count] = idx.double() * 1.5
+        buf.view("c")[:count] = torch.stack([idx % 7, idx % 5], dim=1).to(torch.int8)
+        got = gather_packed(buf, n_slices, dst=None)
+        alli = torch.arange(n_slices)
+        assert torch.equal(got["a"], alli.float().unsqueeze(1) + torch.arange(5).float() / 8)
+        assert torch.equal(got["b"], alli.double() * 1.5)
+        assert torch.equal(got["c"], torch.stack([alli % 7, alli % 5], dim=1).to(torch.int8))
         if rank == 0:
             db, pk, bw, cnt = res
             q.put((db.numpy(), pk.numpy(), bw.numpy(), cnt.numpy()))

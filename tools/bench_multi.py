@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Multi-rank benchmark of the sharded configs (BASELINE.json configs[3] / configs[4] halves that need > 1 GPU).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        tools/bench_multi.py --config cfg4 [--steps K]
+    (N = 1 works too: PSS_BENCH_DIST=1 python tools/bench_multi.py --config cfg4 initialises RCCL with one rank.)
+
+cfg4: scanner sweep of 8192 centre-frequency slices x 4096-pt FFT (pyspecsdr.py:2514-2590), slices sharded over the
+ranks (strong scaling: the sweep is fixed), results gathered to rank 0 over RCCL.  Reported separately, as SURVEY §7.2 #5
+asks: compute alone, the gather alone (full float32 dB rows: 16 KiB per slice; and the 16 B per slice of peak /
+bandwidth / count), and back-to-back sweeps with the gather of sweep k overlapping the compute of sweep k+1.
+One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=["cfg4"], default="cfg4")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--slices", type=int, default=8192)
+    ap.add_argument("--n-fft", type=int, default=4096)
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or os.environ.get("PSS_BENCH_DIST") == "1"
+    if use_dist:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pyspecsdr_amd.engine import Engine
+    from pyspecsdr_amd.multi import ShardedScanner
+    eng = Engine(local_rank)
+    fs, n = 2.4e6, args.n_fft
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def maxr(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    res = {"config": args.config, "n_gpus": world, "slices": args.slices, "n_fft": n, "steps": args.steps}
+    for gather_db in (True, False):
+        sc = ShardedScanner(eng, args.slices, n, fs, gather_db=gather_db, dst=0)
+        g = torch.Generator(device=dev).manual_seed(4 + rank)
+        iq = 0.01 * torch.randn((max(sc.count, 1), n, 2), generator=g, device=dev)
+        t = torch.arange(n, device=dev, dtype=torch.float32)
+        car = torch.arange(sc.count, device=dev) % 8 == 0                  # 1 slice in 8 carries a carrier
+        ph = 2 * torch.pi * (0.05 + 0.4 * torch.rand(sc.count, generator=g, device=dev)).unsqueeze(1) * t
+        iq[:sc.count, :, 0] += car.unsqueeze(1) * 0.3 * torch.cos(ph)
+        iq[:sc.count, :, 1] += car.unsqueeze(1) * 0.3 * torch.sin(ph)
+        torch.cuda.synchronize(dev)
+        tag = "db" if gather_db else "peaks"
+        for _ in range(args.warmup):
+            sc.sweep(iq)
+        fence()
+        # (1) back-to-back sweeps, gather inside the timed region and overlapped with the next sweep's compute
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sc.sweep(iq)
+        fence()
+        el = maxr(time.perf_counter() - t0)
+        res[f"sweep_ms_gather_{tag}"] = el / args.steps * 1e3
+        res[f"samples_per_s_gather_{tag}"] = args.slices * n * args.steps / el
+        res[f"message_bytes_per_rank_{tag}"] = sc.bufs[0].nbytes
+        # (2) the gather alone (the message of the last sweep, no compute)
+        if use_dist:
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                with torch.cuda.stream(sc.comm):
+                    dist.gather(sc.bufs[0].raw, list(sc.recv[0].unbind(0)) if rank == 0 else None, dst=0)
+            fence()
+            res[f"gather_alone_ms_{tag}"] = maxr(time.perf_counter() - t0) / args.steps * 1e3
+        if gather_db:
+            # (3) compute alone: this rank's block, no exchange
+            db = sc.bufs[0].view("db")
+            for _ in range(args.warmup):
+                eng.scan(iq, sc.count, n, fs, db, sc.bufs[0].view("peak"), sc.bufs[0].view("bw"), sc.bufs[0].view("cnt"))
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.scan(iq, sc.count, n, fs, db, sc.bufs[0].view("peak"), sc.bufs[0].view("bw"), sc.bufs[0].view("cnt"))
+            fence()
+            res["compute_alone_ms"] = maxr(time.perf_counter() - t0) / args.steps * 1e3
+            res["slices_per_rank"] = sc.count
+        del sc
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
