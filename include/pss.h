@@ -184,7 +184,7 @@ int pss_vector_cells(pss_ctx *ctx, const float *d_iq, int n, int max_h, int max_
 
 /* decode_morse, front half (decoders.py:149-165): envelope = |x| / max|x| in float32, 20 log10(envelope + 1e-10) > threshold,
  * and the indices of the rising / falling transitions of that mask (np.diff + np.where), i.e. the arrays rise_times /
- * fall_times the timing logic of decode_morse (:167 ff., host side: pyspecsdr_amd/decoders.py) starts from.
+ * fall_times the timing logic of decode_morse (:167 ff., stays in the reference's own decoders.py) starts from.
  * d_iq: interleaved complex64 [n_frames][n]; d_rise / d_fall: int32 [n_frames][cap], in increasing order; d_counts: int32
  * [n_frames][2] = the TRUE numbers of rises and falls (entries beyond cap are dropped).  threshold_db must be -20.0, the
  * value the reference calls it with (pyspecsdr.py:573): the comparison is pinned to NumPy's float32 log10 at that point. */
@@ -262,6 +262,12 @@ int pss_sosfilt(pss_ctx *ctx, const double *d_x, long n_rows, int n, const doubl
 int pss_afsk_n_bits(int n, double fs);
 int pss_afsk_bits(pss_ctx *ctx, const double *d_audio, long n_rows, int n, double fs, const double *sos1200,
                   const double *sos2200, int nsec, uint8_t *d_bits);
+/* samples / np.max(np.abs(samples)) on n_rows float64 rows (decode_aprs's normalisation, decoders.py:126). */
+int pss_row_normalise(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_y);
+/* decode_afsk on one HOST buffer of real float64 audio; normalise != 0 divides by max|x| on the device first, which makes
+ * the result the bit stream decode_aprs (decoders.py:115-133) hands to its AX.25 framing.  h_bits uint8 [pss_afsk_n_bits]. */
+int pss_h_afsk_bits(pss_ctx *ctx, const double *h_audio, int n, double fs, int normalise, const double *sos1200,
+                    const double *sos2200, int nsec, uint8_t *h_bits);
 /* bandpass_filter(data, lowcut, highcut, sample_rate) (signal_processing.py:34-42; used by decoders.py:100-101) on one
  * host row: lowcut <= 0 -> butter(5) low-pass at highcut, else band-pass.  sos/nsec: caller's table, or NULL to design it. */
 int pss_h_bandpass_filter(pss_ctx *ctx, const double *h_x, int n, double lowcut, double highcut, double fs,

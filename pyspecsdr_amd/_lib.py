@@ -81,6 +81,8 @@ _SIGS = {
     "pss_sosfilt": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, C.c_int, _p]),
     "pss_afsk_n_bits": (C.c_int, [C.c_int, C.c_double]),
     "pss_afsk_bits": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, C.c_int, _p]),
+    "pss_row_normalise": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
+    "pss_h_afsk_bits": (C.c_int, [_p, _p, C.c_int, C.c_double, C.c_int, _p, _p, C.c_int, _p]),
     "pss_h_bandpass_filter": (C.c_int, [_p, _p, C.c_int, C.c_double, C.c_double, C.c_double, _p, C.c_int, _p]),
     "pss_h_iq_correction": (C.c_int, [_p, _p, C.c_int, _p, _p]),
     "pss_host_alloc": (_p, [C.c_size_t]),

@@ -1815,6 +1815,36 @@ __global__ __launch_bounds__(256) void k_afsk_bits(const double *__restrict__ f1
     }
 }
 
+// samples / np.max(np.abs(samples)) on float64 rows (decode_aprs, decoders.py:126): one workgroup per row; max|x| is exact
+// whatever the order, the quotient is IEEE division.  A row of zeros gives 0/0 = NaN, as NumPy does.
+__global__ __launch_bounds__(256) void k_row_normalise(const double *__restrict__ x, double *__restrict__ y, int n, long n_rows)
+{
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    for (long r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const double *a = x + (size_t)r * n;
+        double m = 0.0;
+        bool nan = false;
+        for (int i = tid; i < n; i += 256) {
+            const double v = fabs(a[i]);
+            nan = nan || v != v;
+            m = v > m ? v : m;
+        }
+        if (nan) m = __builtin_nan("");                      // np.max propagates NaN
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(m, off);
+            m = (o != o || o > m) ? o : m;
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        m = red[0];
+        for (int w = 1; w < 4; w++) m = (red[w] != red[w] || red[w] > m) ? red[w] : m;
+        double *o = y + (size_t)r * n;
+        for (int i = tid; i < n; i += 256) o[i] = __ddiv_rn(a[i], m);
+    }
+}
+
 // adjust_gain (pyspecsdr.py:898-919), sequential by nature.
 __global__ void k_agc(const float *__restrict__ power, long n, int idx, int n_gains, int *__restrict__ out)
 {
@@ -2642,6 +2672,46 @@ extern "C" int pss_afsk_bits(pss_ctx *ctx, const double *d_audio, long n_rows, i
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_afsk_bits launch");
+}
+
+extern "C" int pss_row_normalise(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_y)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_rows < 0 || n < 0 || (n_rows > 0 && n > 0 && (!d_x || !d_y))) return pss_fail(ctx, PSS_E_ARG, "pss_row_normalise: bad argument");
+    if (n_rows == 0 || n == 0) return PSS_OK;
+    pss_kernel_begin(ctx, "k_row_normalise");
+    hipLaunchKernelGGL(k_row_normalise, dim3((unsigned)(n_rows < 8192 ? n_rows : 8192)), dim3(256), 0, PSS_STREAM(ctx), d_x, d_y, n, n_rows);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_row_normalise launch");
+}
+
+// decode_afsk on one HOST buffer of real float64 audio, optionally normalised first the way decode_aprs does
+// (decoders.py:126): upload, [normalise,] two band-passes, per-bit energy compare, download — no torch involved.
+extern "C" int pss_h_afsk_bits(pss_ctx *ctx, const double *h_audio, int n, double fs, int normalise, const double *sos1200,
+                               const double *sos2200, int nsec, uint8_t *h_bits)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n < 0 || !(fs >= 1200.0) || (n > 0 && !h_audio)) return pss_fail(ctx, PSS_E_ARG, "pss_h_afsk_bits: bad argument");
+    const int n_bits = pss_afsk_n_bits(n, fs);
+    if (n_bits <= 0) return PSS_OK;
+    if (!h_bits) return pss_fail(ctx, PSS_E_ARG, "pss_h_afsk_bits: null bit buffer");
+    const size_t o_n = align256(sizeof(double) * (size_t)n), o_b = 2 * o_n;
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_b + align256((size_t)n_bits), "staging");
+    if (r) return r;
+    char *base = reinterpret_cast<char *>(ctx->stage);
+    double *d_x = reinterpret_cast<double *>(base), *d_nrm = reinterpret_cast<double *>(base + o_n);
+    PSS_HIP(ctx, hipMemcpyAsync(d_x, h_audio, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    if (normalise) {
+        r = pss_row_normalise(ctx, d_x, 1, n, d_nrm);
+        if (r) return r;
+    }
+    r = pss_afsk_bits(ctx, normalise ? d_nrm : d_x, 1, n, fs, sos1200, sos2200, nsec, reinterpret_cast<uint8_t *>(base + o_b));
+    if (r) return r;
+    PSS_HIP(ctx, hipMemcpyAsync(h_bits, base + o_b, (size_t)n_bits, hipMemcpyDeviceToHost, ctx->stream));
+    PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSS_OK;
 }
 
 extern "C" int pss_set_wfm_filters(pss_ctx *ctx, double fs, const double *lp3x6, const double *pilot5x6, const double *lmr5x6,

@@ -350,19 +350,22 @@ class Engine:
         self._ck(self.lib.pss_afsk_bits(self.h, _ptr(d_audio), n_rows, n, float(fs), _ptr(s1), _ptr(s2),
                                         5 if s1 is None else s1.shape[0], _ptr(d_bits)))
 
-    def h_afsk_bits(self, x, fs, sos1200=None, sos2200=None):
-        """decode_afsk's bit list for one host buffer of real audio (float64) -> uint8 array."""
-        import torch
+    def h_afsk_bits(self, x, fs, sos1200=None, sos2200=None, normalise=False):
+        """decode_afsk's bit list for one host buffer of real audio (float64) -> uint8 array; normalise=True divides by
+        max|x| on the device first (what decode_aprs does before it calls decode_afsk, decoders.py:126)."""
         x = np.ascontiguousarray(x, np.float64)
         nb = self.afsk_n_bits(len(x), fs)
         if nb <= 0:
             return np.zeros(0, np.uint8)
-        d_x = torch.from_numpy(x).cuda()
-        d_b = torch.empty(nb, dtype=torch.uint8, device=d_x.device)
-        torch.cuda.synchronize()
-        self.afsk_bits(d_x, 1, len(x), fs, d_b, sos1200, sos2200)
-        self.sync()
-        return d_b.cpu().numpy()
+        bits = np.empty(nb, np.uint8)
+        s1 = None if sos1200 is None else np.ascontiguousarray(sos1200, np.float64)
+        s2 = None if sos2200 is None else np.ascontiguousarray(sos2200, np.float64)
+        self._ck(self.lib.pss_h_afsk_bits(self.h, _ptr(x), len(x), float(fs), int(bool(normalise)), _ptr(s1), _ptr(s2),
+                                          0 if s1 is None else s1.shape[0], _ptr(bits)))
+        return bits
+
+    def row_normalise(self, d_x, n_rows, n, d_y):
+        self._ck(self.lib.pss_row_normalise(self.h, _ptr(d_x), n_rows, n, _ptr(d_y)))
 
     def afsk_n_bits(self, n, fs):
         return self.lib.pss_afsk_n_bits(int(n), float(fs))

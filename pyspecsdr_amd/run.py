@@ -2,10 +2,11 @@
 
     python -m pyspecsdr_amd.run /path/to/PySpecSDR/pyspecsdr.py [its own arguments]
 
-The reference reaches its hot path through two module names — `from signal_processing import *` (pyspecsdr.py:98) and
-`import decoders` (pyspecsdr.py:100; decoders.py:3 imports `bandpass_filter` from `signal_processing` again).  `install()`
-registers the drop-in modules under exactly those names in `sys.modules` before the script starts, so every such import
-resolves to the GPU-backed implementation and no file of the reference is edited.
+The reference reaches its hot path through ONE module name — `from signal_processing import *` (pyspecsdr.py:98; its
+decoders.py:3 imports `bandpass_filter` from `signal_processing` again).  `install()` registers the drop-in module under
+exactly that name in `sys.modules` before the script starts, so every such import resolves to the GPU-backed
+implementation and no file of the reference is edited.  The reference's own decoders.py is left alone: its bookkeeping
+runs as it is, on top of the GPU band-pass.
 """
 import os
 import runpy
@@ -13,11 +14,10 @@ import sys
 
 
 def install():
-    """Make `signal_processing` and `decoders` resolve to the drop-in modules for the rest of this process."""
-    from . import decoders, signal_processing
+    """Make `signal_processing` resolve to the drop-in module for the rest of this process."""
+    from . import signal_processing
     sys.modules["signal_processing"] = signal_processing
-    sys.modules["decoders"] = decoders
-    return signal_processing, decoders
+    return signal_processing
 
 
 def main(argv=None):

@@ -139,15 +139,17 @@ def test_formats_host_side(tmp_path):
 
 
 def test_zero_edit_dropin_resolves_the_reference_module_names(tmp_path):
-    """pyspecsdr_amd.run.install(): `from signal_processing import *` / `import decoders` (pyspecsdr.py:98,100; decoders.py:3)
-    resolve to the drop-in modules, with the reference's public names and nothing else leaking through the star import."""
+    """pyspecsdr_amd.run.install(): `from signal_processing import *` (pyspecsdr.py:98; decoders.py:3) resolves to the drop-in
+    module, with the reference's public names and nothing else leaking through the star import; `decoders` is NOT replaced
+    (the reference's own module keeps its bookkeeping and picks up the GPU band-pass through its import)."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     app = tmp_path / "app.py"
-    app.write_text("from signal_processing import *\nimport decoders\nimport signal_processing as m\n"
-                   "assert m.__name__ == 'pyspecsdr_amd.signal_processing' and decoders.__name__ == 'pyspecsdr_amd.decoders'\n"
-                   "for f in (compute_fft, demodulate_signal, measure_signal_power, classify_signal, bandpass_filter, iq_correction,\n"
-                   "          decoders.decode_aprs, decoders.decode_morse, decoders.decode_afsk, decoders.decode_ax25_frame):\n"
+    (tmp_path / "decoders.py").write_text("from signal_processing import bandpass_filter\nWHO = bandpass_filter.__module__\n")
+    app.write_text("from signal_processing import *\nimport sys, decoders\nimport signal_processing as m\n"
+                   "assert m.__name__ == 'pyspecsdr_amd.signal_processing'\n"
+                   "assert decoders.__name__ == 'decoders' and decoders.WHO == 'pyspecsdr_amd.signal_processing'\n"
+                   "for f in (compute_fft, demodulate_signal, measure_signal_power, classify_signal, bandpass_filter, iq_correction):\n"
                    "    assert callable(f)\n"
                    "assert 'get_engine' not in globals() and 'Engine' not in globals() and 'L' not in globals()\n"
                    "import sys; print('ARGS', sys.argv[1:])\n")

@@ -272,9 +272,9 @@ def test_classify_signal(golden):
         O.classify(np.zeros(1000, np.complex64), fs)
 
 
-def test_morse_edges_and_ax25_bookkeeping(golden):
+def test_morse_edges(golden):
     """decode_morse's mask / transition indices (decoders.py:149-161, threshold -20 dB: NumPy's SVML log10f pinned at the one point
-    that matters) and the host-side AX.25 bookkeeping of the drop-in decoders module (decoders.py:6-91) on the goldens."""
+    that matters) on the goldens."""
     g = golden["decoders"]
     for tag in g["mtags"]:
         rise, fall = O.morse_edges(g[f"m_iq_{tag}"])
@@ -285,13 +285,6 @@ def test_morse_edges_and_ax25_bookkeeping(golden):
     rise, fall = O.morse_edges(x)
     on = vals.view(np.uint32) >= 0x3DCCCCCF
     assert np.array_equal(rise, 2 * np.nonzero(on)[0]) and len(fall) == on.sum() + 1
-    import pyspecsdr_amd.decoders as D
-    off = np.concatenate([[0], np.cumsum(g["ax_len"])])
-    import json
-    for k, want in enumerate(json.loads(str(g["ax_out"]))):
-        bits = [int(b) for b in g["ax_bits"][off[k]:off[k + 1]]]
-        got = D.decode_ax25_frame(bits)
-        assert ("<None>" if got is None else got) == str(want), k
 
 
 def test_lengths_that_are_not_a_power_of_two(golden):

@@ -483,6 +483,8 @@ def gen_decoders():
         atags.append(tag)
         d[f"a_x_{tag}"] = x; d[f"a_fs_{tag}"] = np.array(fs)
         d[f"a_packets_{tag}"] = np.array(json.dumps(out))          # JSON text: NumPy's str dtype drops trailing NULs
+        xr = np.real(x) if np.iscomplexobj(x) else x               # the bit stream decode_aprs hands to its framing code:
+        d[f"a_bits_{tag}"] = np.array(decoders.decode_afsk(xr / np.max(np.abs(xr)), fs), np.uint8)   # decoders.py:122-129
         nyq = fs / 2
         d[f"a_sos1200_{tag}"] = ss.butter(5, [1100 / nyq, 1300 / nyq], btype="band", output="sos")
         d[f"a_sos2200_{tag}"] = ss.butter(5, [2100 / nyq, 2300 / nyq], btype="band", output="sos")
@@ -706,16 +708,9 @@ def gen_caller():
 
 
 if __name__ == "__main__":
-    gen_atan2()
-    gen_spectrum()
-    gen_nfm()
-    gen_am_ssb()
-    gen_power()
-    gen_iqcorr()
-    gen_wfm()
-    gen_bandpass()
-    gen_afsk()
-    gen_classify()
-    gen_decoders()
-    gen_scanner()
-    gen_caller()
+    gens = [gen_atan2, gen_spectrum, gen_nfm, gen_am_ssb, gen_power, gen_iqcorr, gen_wfm, gen_bandpass, gen_afsk, gen_classify,
+            gen_decoders, gen_scanner, gen_caller]
+    want = sys.argv[1:]                      # e.g. `python tools/make_goldens.py decoders` regenerates one fixture
+    for g in gens:
+        if not want or g.__name__[4:] in want:
+            g()
