@@ -57,6 +57,7 @@ int pss_device_count(void);
  *                              the register-resident binary-search select;  "post_sort_max" (8192): longest row the legacy
  *                              path sorts (longer rows: radix select)
  *   "fft_split" (-1 = auto)    1 / 0: force / forbid the component-wise LDS exchanges of the register FFT (auto: N = 256)
+ *   "fft_big_scratch" (0)      1: N = 8192 / 16384 on the scratch-based pre-pass kernel instead of the four-stage register kernel
  *   "fft_prefetch" (-1 = auto) 1 / 0: force / forbid requesting the next frame's samples before transforming the current one
  *                              (auto: N = 1024 and 2048) */
 int pss_set_option(pss_ctx *ctx, const char *key, int value);

@@ -179,6 +179,7 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "small_batch")) { ctx->no_small_batch = (value == 0); return PSS_OK; }
     if (!strcmp(key, "small_batch_max")) { ctx->small_batch_max = value; return PSS_OK; }
     if (!strcmp(key, "fft_split")) { ctx->fft_split = value; return PSS_OK; }
+    if (!strcmp(key, "fft_big_scratch")) { ctx->fft_big_scratch = value != 0; return PSS_OK; }
     if (!strcmp(key, "fft_prefetch")) { ctx->fft_prefetch = value; return PSS_OK; }
     if (!strcmp(key, "post_sort_max")) { ctx->post_sort_max = value; return PSS_OK; }
     if (!strcmp(key, "post_legacy")) { ctx->post_legacy = value != 0; return PSS_OK; }

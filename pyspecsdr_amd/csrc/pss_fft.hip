@@ -20,6 +20,7 @@
 
 #include "pss_ctx.h"
 #include "pss_fft_r16.h"
+#include "pss_fft_xl.h"
 #include "pss_post.h"
 
 namespace {
@@ -652,6 +653,22 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     case 2048: return launch_r16<3, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
     case 4096: return launch_r16<4, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
     default: break;
+    }
+    if (!SCAN && (n_fft == 8192 || n_fft == 16384) && !ctx->fft_big_scratch) {
+        // N = 16 x 16 x 16 x R4 in registers + LDS: the frame is read once, the dB row written once
+        auto go = [&](auto kern, size_t lds, int threads, int per_cu) -> int {
+            PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const long cap = 256L * per_cu;
+            pss_time_begin(ctx);
+            pss_kernel_begin(ctx, "k_spectrum");
+            hipLaunchKernelGGL(kern, dim3((unsigned)(n_frames < cap ? n_frames : cap)), dim3(threads), lds, PSS_STREAM(ctx),
+                               reinterpret_cast<const float2 *>(d_iq), d_db, tw, win, n_frames);
+            pss_kernel_end(ctx);
+            pss_time_end(ctx);
+            return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_xl launch");
+        };
+        if (n_fft == 8192) return go(pss_xl::k_spectrum_xl<1, true>, pss_xl::CfgX<1>::LDS, 512, 2);
+        return go(pss_xl::k_spectrum_xl<2, true>, pss_xl::CfgX<2>::LDS, 1024, 1);
     }
     if (!SCAN && n_fft >= 8192 && n_fft <= 65536) {
         // N = R * 4096: radix-R pre-pass + register-resident 4096-point transforms, one workgroup per frame

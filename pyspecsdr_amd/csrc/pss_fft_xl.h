@@ -1,0 +1,209 @@
+// pss_fft_xl.h — register-resident FOUR-stage FFT for N = 8192 and 16384 (N = 16 x 16 x 16 x R4, R4 = 2 / 4): one workgroup
+// of T = N / 16 threads per frame, 16 points per thread, nothing but the frame itself and its result ever touches HBM
+// (12 algorithmic bytes per sample for a spectrum).  The previous big-N kernel parked the radix-R pre-pass in a float64
+// scratch (16 B / sample written and read back) and completed every dB row by R interleaved 4-byte store passes:
+// 44 B / sample moved and 4.7 x the algorithmic traffic at N = 16384.
+//
+// Decimation in frequency, three radix-16 stages and one radix-R4 stage (a, b, c = the sample index inside the
+// sub-sequence of stage 1, 2, 3; T2 = T / 16 = 16 R4):
+//   stage 1  thread t = a             x[a + T q], q < 16           16-point DFT over q,  times W_N^(a r)     -> y_r[a]
+//   stage 2  thread (r, b)            y_r[b + T2 q2]               16-point DFT over q2, times W_T^(b r2)    -> z_{r r2}[b]
+//   stage 3  thread (r, r2, c)        z_{r r2}[c + R4 q3]          16-point DFT over q3, times W_T2^(c r3)   -> u_{r r2 r3}[c]
+//   stage 4  thread rho, j < 16/R4    u_g[0 .. R4-1], g = rho + T j = r + 16 r2 + 256 r3     radix-R4        -> X[4096 k + g]
+// For fixed (j, k) the T threads of the frame hold T CONSECUTIVE bins, so rows leave in full lines straight from registers.
+// The three exchanges go through LDS one COMPONENT at a time (real parts, then imaginary parts): N doubles (+ padding)
+// = 140 KB at N = 16384, which is what lets the whole frame stay on the CU.  Layouts are padded so that every
+// ds_read_b64 / ds_write_b64 of a 32-lane group touches 32 different bank pairs (derivations at each exchange).
+// Twiddles: one table load per stage and thread (W^t), the 15 powers by repeated multiplication (relative error ~1e-15,
+// far below the 1e-4 contract) — 45 per-thread table loads per frame would be 5 x the frame's own bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pss_fft_r16.h"
+
+namespace pss_xl {
+
+using pss_r16::brev;
+using pss_r16::cmul;
+using pss_r16::fft_reg;
+
+template <int LOG_R4>
+struct CfgX {
+    static constexpr int R4 = 1 << LOG_R4;
+    static constexpr int T = 256 * R4;              // threads per frame
+    static constexpr int N = 16 * T;
+    static constexpr int T2 = 16 * R4;              // T / 16
+    static constexpr int E2 = T2 + R4;              // row stride of exchange 2 (doubles): groups of R4 lanes land R4 apart mod 32
+    static constexpr int P3 = 16 * 272 + 32 / R4;   // plane stride of exchange 3 (doubles): 17-double rows, planes 32/R4 apart mod 32
+    static constexpr int EXD = (R4 * P3 > 256 * E2) ? R4 * P3 : 256 * E2;   // doubles (>= 16 T for exchange 1)
+    static constexpr size_t LDS = (size_t)EXD * sizeof(double);
+};
+
+// v[brev(r)] (the in-register DFT leaves X[r] there) *= w^r, r = 1..15, in place; the powers come from two interleaved
+// product chains (odd / even exponents) so that only a few complex temporaries are live — the kernel runs 16 wavefronts
+// per CU and must fit 128 VGPRs with its 16 complex float64 points.
+__device__ __forceinline__ void twiddle_powers(double2 (&v)[16], double2 w)
+{
+    const double2 w2 = cmul(w, w);
+    double2 po = w, pe = w2;               // w^(2j+1), w^(2j+2)
+    v[brev(1, 4)] = cmul(v[brev(1, 4)], po);
+    v[brev(2, 4)] = cmul(v[brev(2, 4)], pe);
+#pragma unroll
+    for (int j = 1; j < 7; j++) {
+        po = cmul(po, w2);
+        pe = cmul(pe, w2);
+        v[brev(2 * j + 1, 4)] = cmul(v[brev(2 * j + 1, 4)], po);
+        v[brev(2 * j + 2, 4)] = cmul(v[brev(2 * j + 2, 4)], pe);
+    }
+    po = cmul(po, w2);
+    v[brev(15, 4)] = cmul(v[brev(15, 4)], po);
+}
+
+// Buffer addressing: resource descriptor (scalar base + size) + ONE per-lane byte offset + a scalar offset per access.  With
+// plain pointers the compiler materialises a 64-bit per-lane address for every row of the frame, hoists the 48 of them out
+// of the persistent frame loop and spills them (measured: 180 VGPRs of spills in a 128-VGPR kernel).
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float2 buf_load_f2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void buf_store_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff, float x)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
+}
+
+// keeps the compiler from hoisting the next block's loads (and their registers) above this point
+__device__ __forceinline__ void sched_fence() { asm volatile("" ::: "memory"); }
+
+// One component-wise exchange: every thread writes its 16 values (real parts, then imaginary parts) and gathers 16 others.
+// wr(i) / rd(i) return the LDS location of the i-th value written / read as (base pointer, COMPILE-TIME element offset), so
+// that every access is one VGPR base + an immediate offset (the DS offset field holds 65535 bytes; bases are shared by as
+// many accesses as that reach allows).  Four workgroup barriers.
+template <class Wr, class Rd>
+__device__ __forceinline__ void exchange(double2 (&v)[16], Wr wr, Rd rd)
+{
+    double im[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { *wr(i) = v[brev(i, 4)].x; im[i] = v[brev(i, 4)].y; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i].x = *rd(i);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) *wr(i) = im[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i].y = *rd(i);
+    __syncthreads();
+}
+
+// One frame whose 16 stage-1 inputs x[t + T q] (windowed, as complex float64) are in v[].  w1 = W_N^t, w2 = W_T^(t % T2),
+// w3 = W_T2^(t % R4) (per-thread constants).  emit(i, j, k, X) receives the thread's 16 results: X = bin 4096 k + T j + t.
+// Twelve workgroup barriers; the last exchange ends with one after its reads, so the caller adds none between frames.
+template <int LOG_R4, class Emit>
+__device__ __forceinline__ void xl_core(double2 (&v)[16], double *ex, double2 w1, double2 w2, double2 w3, int t, Emit emit)
+{
+    using C = CfgX<LOG_R4>;
+    constexpr int R4 = C::R4, T = C::T, T2 = C::T2, E2 = C::E2, P3 = C::P3;
+    const int r_s = t / T2, b_s = t % T2;   // stage-2 role (r, b)
+    const int g3 = t / R4, c_s = t % R4;    // stage-3 role (g = 16 r + r2, c)
+    // ---- stage 1
+    fft_reg<16>(v);
+    twiddle_powers(v, w1);
+    // exchange 1: L1[r][a] (row stride T).  Writes: a wavefront stores 64 consecutive doubles of one row.  Reads: thread
+    // (r, b) takes L1[r][b + T2 q2]: 32 lanes = 32 consecutive doubles (R4 = 2: one row; R4 = 4: half a row).
+    {
+        double *w_lo = ex + t, *w_hi = ex + 8 * T + t;      // rows 0..7 / 8..15 (8 T doubles = 64 KiB at N = 16384)
+        double *rb = ex + r_s * T + b_s;
+        exchange(v, [&](int r) { return (r < 8 ? w_lo : w_hi) + (r & 7) * T; }, [&](int q) { return rb + T2 * q; });
+    }
+    // ---- stage 2
+    fft_reg<16>(v);
+    twiddle_powers(v, w2);
+    // exchange 2: L2[r][r2][b] (row stride E2 = T2 + R4).  Writes: lanes of one r store consecutive b.  Reads: thread (g, c)
+    // takes L2[g][c + R4 q3]: a 32-lane group is 32 / R4 rows x R4 doubles, rows E2 = R4 (mod 32) apart -> 32 distinct
+    // bank pairs.
+    {
+        double *wb = ex + (r_s * 16) * E2 + b_s, *rb = ex + g3 * E2 + c_s;
+        exchange(v, [&](int r2) { return wb + r2 * E2; }, [&](int q) { return rb + R4 * q; });
+    }
+    // ---- stage 3
+    fft_reg<16>(v);
+    twiddle_powers(v, w3);
+    // exchange 3: L3[c][r3][r2][r] with 17-double (r2) rows, 272-double r3 blocks and planes P3 apart.  Writes: a 32-lane
+    // group is 32 / R4 values of r2 x R4 planes at fixed r: offsets 17 r2 + (32 / R4) c (mod 32) are all different.
+    // Reads: thread rho takes g = rho + T j in bin order (r fastest): 32 lanes = two rows of 16 consecutive doubles, 17 apart
+    // (one shared bank pair in 32: a single extra LDS cycle).  Value i = j R4 + k is u_g[k]; g = t + T j only moves r3
+    // (T = 256 R4), i.e. a compile-time offset of 272 R4 j.
+    {
+        double *wb = ex + c_s * P3 + 17 * (g3 & 15) + (g3 >> 4);
+        double *rb0 = ex + 272 * (t >> 8) + 17 * ((t >> 4) & 15) + (t & 15);
+        double *rb1 = rb0 + (R4 > 2 ? 2 * P3 : 0);          // planes 2, 3 (beyond the offset field's reach from rb0)
+        exchange(v, [&](int r3) { return wb + 272 * r3; },
+                 [&](int i) { return ((i % R4) < 2 ? rb0 : rb1) + ((i % R4) & 1) * P3 + 272 * R4 * (i / R4); });
+    }
+    // ---- stage 4: radix-R4 butterflies over c; bin = 4096 k + g
+#pragma unroll
+    for (int j = 0; j < 16 / R4; j++) {
+        double2 b[R4];
+#pragma unroll
+        for (int k = 0; k < R4; k++) b[k] = v[j * R4 + k];
+        fft_reg<R4>(b);
+#pragma unroll
+        for (int k = 0; k < R4; k++) emit(j * R4 + k, j, k, b[brev(k, LOG_R4)]);
+    }
+}
+
+// compute_fft (signal_processing.py:243-264) for frames of N = 4096 * R4 points: Hamming window (np.hamming, float64 table),
+// transform, fftshift, 10 log10(|X|^2 + 1e-10) as float32.  WINDOW = false: an unwindowed transform.
+template <int LOG_R4, bool WINDOW>
+__global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *__restrict__ iq, float *__restrict__ db,
+                                                                  const double2 *__restrict__ tw, const double *__restrict__ win,
+                                                                  long n_frames)
+{
+    using C = CfgX<LOG_R4>;
+    constexpr int T = C::T, N = C::N, T2 = C::T2, R4 = C::R4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *ex = reinterpret_cast<double *>(smem);
+    const int t = threadIdx.x;
+    const double2 w1 = tw[t];                                  // W_N^t
+    const double2 w2 = tw[(size_t)(t % T2) * 16];              // W_T^b = W_N^(16 b)
+    const double2 w3 = tw[(size_t)(t % R4) * 256];             // W_T2^c = W_N^(256 c)
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(win, N * 8);
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(iq + (size_t)f * N, N * 8), ro = make_rsrc(db + (size_t)f * N, N * 4);
+        // the 45 twiddle powers are loop-invariant and the compiler would compute them once, park them in scratch memory
+        // (180 VGPRs) and reload them every frame; recomputing them from the three bases is cheaper than that traffic
+        double2 u1 = w1, u2 = w2, u3 = w3;
+        asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
+        double2 v[16];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {              // two batches of eight: 16 sample + 16 window loads in flight would not fit
+            float2 s[8];
+            double wv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) s[q] = buf_load_f2(rx, t * 8, T * (8 * h + q) * 8);
+#pragma unroll
+            for (int q = 0; q < 8; q++) wv[q] = WINDOW ? buf_load_f64(rw, t * 8, T * (8 * h + q) * 8) : 1.0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[8 * h + q] = make_double2((double)s[q].x * wv[q], (double)s[q].y * wv[q]);
+            sched_fence();
+        }
+        xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int, int j, int k, double2 X) {
+            // fftshift; bin 4096 k + T j + t: T consecutive bins per store instruction
+            buf_store_f32(ro, t * 4, ((4096 * k + T * j + N / 2) & (N - 1)) * 4, pss_r16::db_of(X.x * X.x + X.y * X.y + 1e-10));
+        });
+    }
+}
+
+}  // namespace pss_xl
