@@ -296,6 +296,17 @@ void pss_host_free(void *p);
 int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
                               float *h_db, int16_t *h_pcm);
 
+/* The same capture, returning what the application consumes per frame instead of the dB rows: the display accumulator's
+ * newest line (mode 0 waterfall: h_line_a = glyph, h_line_b = colour; mode 1 persistence: h_line_a = row index of the newest
+ * trace, h_line_b unused) with a history of `window` rows, and the int16 PCM.  int8 [n_frames][disp_w] each.  Post-process
+ * and accumulators run on the device chunk by chunk; the history crosses chunk boundaries.  h_halo_lo / h_halo_hi (n_halo
+ * floats each, nullable): extremes of the rows preceding this capture (pss_waterfall_rows).  h_db (nullable) also returns
+ * the dB rows; h_row_lo / h_row_hi (nullable, n_frames floats) return the per-row extremes (the halo for whatever follows).
+ * Results are identical to the device-resident calls on the same frames. */
+int pss_h_stream_display_nfm(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames, int mode,
+                             int window, int disp_h, int disp_w, const float *h_halo_lo, const float *h_halo_hi, int n_halo,
+                             int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm, float *h_db, float *h_row_lo, float *h_row_hi);
+
 /* Kernel-only time of the most recent batched call on this context, measured with HIP events on the
  * context's stream (ms); negative if timing is disabled.  pss_enable_timing(ctx, 1) turns it on. */
 int pss_enable_timing(pss_ctx *ctx, int on);

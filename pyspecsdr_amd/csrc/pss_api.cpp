@@ -554,3 +554,117 @@ extern "C" int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n
     cleanup();
     return PSS_OK;
 }
+
+// BASELINE.json configs[4] as the host sees it: a long capture streamed through the GPU, and what comes back per frame is
+// what the application consumes — the display accumulator's line (waterfall: glyph + colour, persistence: the newest trace's
+// row indices) and the int16 PCM — not the dB rows (8 KB per frame of PCIe traffic nobody reads; still available: h_db).
+// Per chunk: upload (copy stream) | spectrum + NFM, post-process + row extremes, display lines (compute stream) | download
+// (copy stream), two buffer sets.  The row extremes of the whole capture stay in one device array, so a frame's history
+// window reaches back across chunk boundaries; h_halo_lo / h_halo_hi (n_halo values each, may be NULL) are the extremes of
+// the rows that precede this capture (previous capture, or the left neighbour's tail when the capture is sharded).
+extern "C" int pss_h_stream_display_nfm(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
+                                        int mode, int window, int disp_h, int disp_w, const float *h_halo_lo,
+                                        const float *h_halo_hi, int n_halo, int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm,
+                                        float *h_db, float *h_row_lo, float *h_row_hi)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (!h_iq || !h_pcm || !h_line_a || n_frames < 0 || n < 8 || chunk_frames < 1 || window < 1 || disp_w < 1 || disp_h < 1 ||
+        disp_h > 127 || n_halo < 0 || (mode != 0 && mode != 1) || (mode == 0 && !h_line_b) || (n_halo > 0 && (!h_halo_lo || !h_halo_hi)))
+        return pss_fail(ctx, PSS_E_ARG, "bad stream-display arguments");
+    const int n_out = pss_demod_out_len(PSS_MODE_NFM, n, fs);
+    if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "sample rate below 22050 Hz");
+    if (n_frames == 0) return PSS_OK;
+    if (chunk_frames > n_frames) chunk_frames = n_frames;
+    const int m = n - 4;
+    const size_t iq_b = (size_t)chunk_frames * n * 2 * sizeof(float), db_b = (size_t)chunk_frames * n * sizeof(float),
+                 post_b = (size_t)chunk_frames * m * sizeof(float), pcm_b = (size_t)chunk_frames * n_out * 2 * sizeof(int16_t),
+                 line_b = (size_t)chunk_frames * disp_w;
+    hipStream_t s_up = nullptr, s_dn = nullptr;
+    hipEvent_t up_done[2] = {nullptr, nullptr}, cmp_done[2] = {nullptr, nullptr}, dn_done[2] = {nullptr, nullptr};
+    void *d_iq[2] = {nullptr, nullptr}, *d_db[2] = {nullptr, nullptr}, *d_pcm[2] = {nullptr, nullptr}, *d_la[2] = {nullptr, nullptr},
+         *d_lb[2] = {nullptr, nullptr};
+    void *d_post = nullptr, *d_ext = nullptr;   // post rows of the chunk in flight; [lo | hi] x (n_halo + n_frames)
+    int rc = PSS_OK;
+    auto cleanup = [&]() {
+        hipStreamSynchronize(ctx->stream);
+        if (s_up) { hipStreamSynchronize(s_up); hipStreamDestroy(s_up); }
+        if (s_dn) { hipStreamSynchronize(s_dn); hipStreamDestroy(s_dn); }
+        for (int i = 0; i < 2; i++) {
+            if (up_done[i]) hipEventDestroy(up_done[i]);
+            if (cmp_done[i]) hipEventDestroy(cmp_done[i]);
+            if (dn_done[i]) hipEventDestroy(dn_done[i]);
+            if (d_iq[i]) hipFree(d_iq[i]);
+            if (d_db[i]) hipFree(d_db[i]);
+            if (d_pcm[i]) hipFree(d_pcm[i]);
+            if (d_la[i]) hipFree(d_la[i]);
+            if (d_lb[i]) hipFree(d_lb[i]);
+        }
+        if (d_post) hipFree(d_post);
+        if (d_ext) hipFree(d_ext);
+    };
+#define STREAM_HIP(call)                                          \
+    do {                                                          \
+        rc = pss_hip_check(ctx, (call), #call);                   \
+        if (rc) { cleanup(); return rc; }                         \
+    } while (0)
+    STREAM_HIP(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+    STREAM_HIP(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        STREAM_HIP(hipEventCreateWithFlags(&up_done[i], hipEventDisableTiming));
+        STREAM_HIP(hipEventCreateWithFlags(&cmp_done[i], hipEventDisableTiming));
+        STREAM_HIP(hipEventCreateWithFlags(&dn_done[i], hipEventDisableTiming));
+        STREAM_HIP(hipMalloc(&d_iq[i], iq_b));
+        STREAM_HIP(hipMalloc(&d_db[i], db_b));
+        STREAM_HIP(hipMalloc(&d_pcm[i], pcm_b));
+        STREAM_HIP(hipMalloc(&d_la[i], line_b));
+        if (mode == 0) STREAM_HIP(hipMalloc(&d_lb[i], line_b));
+    }
+    STREAM_HIP(hipMalloc(&d_post, post_b));
+    const size_t n_ext = (size_t)n_halo + (size_t)n_frames;
+    STREAM_HIP(hipMalloc(&d_ext, 2 * n_ext * sizeof(float)));
+    float *d_lo = reinterpret_cast<float *>(d_ext), *d_hi = d_lo + n_ext;
+    if (n_halo) {
+        STREAM_HIP(hipMemcpyAsync(d_lo, h_halo_lo, sizeof(float) * n_halo, hipMemcpyHostToDevice, ctx->stream));
+        STREAM_HIP(hipMemcpyAsync(d_hi, h_halo_hi, sizeof(float) * n_halo, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const long n_chunks = (n_frames + chunk_frames - 1) / chunk_frames;
+    for (long k = 0; k < n_chunks; k++) {
+        const int b = (int)(k & 1);
+        const long f0 = k * chunk_frames;
+        const long cnt = (n_frames - f0) < chunk_frames ? (n_frames - f0) : chunk_frames;
+        if (k >= 2) STREAM_HIP(hipStreamWaitEvent(s_up, dn_done[b], 0));   // the buffer set is free once chunk k-2 has been downloaded
+        STREAM_HIP(hipMemcpyAsync(d_iq[b], h_iq + (size_t)f0 * n * 2, (size_t)cnt * n * 2 * sizeof(float), hipMemcpyHostToDevice, s_up));
+        STREAM_HIP(hipEventRecord(up_done[b], s_up));
+        STREAM_HIP(hipStreamWaitEvent(ctx->stream, up_done[b], 0));
+        if (k >= 2) STREAM_HIP(hipStreamWaitEvent(ctx->stream, dn_done[b], 0));
+        {
+            PssFlagScope keep(ctx->no_small_batch, true);   // chunks of a stream are throughput work: fused large-batch kernels
+            rc = pss_spectrum_nfm(ctx, (const float *)d_iq[b], cnt, n, fs, (float *)d_db[b], (int16_t *)d_pcm[b]);
+        }
+        // rows f0 .. f0+cnt-1 of the capture sit at positions n_halo + f0 .. of the extremes arrays; their history reaches
+        // back over everything before them (previous chunks and the caller's halo)
+        if (!rc) rc = pss_spectrum_post_extremes(ctx, (const float *)d_db[b], cnt, n, (float *)d_post, d_lo + n_halo + f0, d_hi + n_halo + f0);
+        const long before = (long)n_halo + f0;
+        const int halo_k = (int)(before < (long)(window - 1) ? before : (long)(window - 1));
+        const float *lo_k = d_lo + n_halo + f0 - halo_k, *hi_k = d_hi + n_halo + f0 - halo_k;
+        if (!rc) {
+            if (mode == 0) rc = pss_waterfall_rows(ctx, (const float *)d_post, cnt, m, lo_k, hi_k, halo_k, window, disp_w, (int8_t *)d_la[b], (int8_t *)d_lb[b]);
+            else rc = pss_persistence_rows(ctx, (const float *)d_post, cnt, m, lo_k, hi_k, halo_k, window, disp_h, disp_w, (int8_t *)d_la[b]);
+        }
+        if (rc) { cleanup(); return rc; }
+        STREAM_HIP(hipEventRecord(cmp_done[b], ctx->stream));
+        STREAM_HIP(hipStreamWaitEvent(s_dn, cmp_done[b], 0));
+        if (h_db) STREAM_HIP(hipMemcpyAsync(h_db + (size_t)f0 * n, d_db[b], (size_t)cnt * n * sizeof(float), hipMemcpyDeviceToHost, s_dn));
+        STREAM_HIP(hipMemcpyAsync(h_line_a + (size_t)f0 * disp_w, d_la[b], (size_t)cnt * disp_w, hipMemcpyDeviceToHost, s_dn));
+        if (mode == 0) STREAM_HIP(hipMemcpyAsync(h_line_b + (size_t)f0 * disp_w, d_lb[b], (size_t)cnt * disp_w, hipMemcpyDeviceToHost, s_dn));
+        STREAM_HIP(hipMemcpyAsync(h_pcm + (size_t)f0 * n_out * 2, d_pcm[b], (size_t)cnt * n_out * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, s_dn));
+        STREAM_HIP(hipEventRecord(dn_done[b], s_dn));
+    }
+    STREAM_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_row_lo) STREAM_HIP(hipMemcpy(h_row_lo, d_lo + n_halo, sizeof(float) * n_frames, hipMemcpyDeviceToHost));
+    if (h_row_hi) STREAM_HIP(hipMemcpy(h_row_hi, d_hi + n_halo, sizeof(float) * n_frames, hipMemcpyDeviceToHost));
+#undef STREAM_HIP
+    cleanup();
+    return PSS_OK;
+}

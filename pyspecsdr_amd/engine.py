@@ -262,6 +262,31 @@ class Engine:
         if p:
             self.lib.pss_host_free(p)
 
+    def stream_display_nfm(self, h_iq, fs, chunk_frames, mode="waterfall", window=None, disp_h=36, disp_w=112, halo=None,
+                           want_db=False):
+        """Stream a host capture (complex64 [n_frames, n], pinned for overlap) and get back, per frame, the display
+        accumulator's newest line and the int16 PCM (BASELINE configs[4]).  mode "waterfall": lines = (glyph, colour),
+        history 30; "persistence": lines = (y,), history 10.  halo: (lo, hi) float32 arrays of the rows preceding the
+        capture.  Returns dict(lines=..., pcm=..., row_lo=..., row_hi=..., db=... or None)."""
+        assert h_iq.dtype == np.complex64 and h_iq.ndim == 2 and h_iq.flags.c_contiguous
+        nf, n = h_iq.shape
+        m = 0 if mode == "waterfall" else 1
+        window = (30 if m == 0 else 10) if window is None else int(window)
+        n_out = self.demod_out_len(L.MODE_NFM, n, fs)
+        la = np.empty((nf, disp_w), np.int8)
+        lb = np.empty((nf, disp_w), np.int8) if m == 0 else None
+        pcm = np.empty((nf, n_out, 2), np.int16)
+        db = np.empty((nf, n), np.float32) if want_db else None
+        lo, hi = np.empty(nf, np.float32), np.empty(nf, np.float32)
+        hl = hh = None
+        n_halo = 0
+        if halo is not None and len(halo[0]):
+            hl, hh = np.ascontiguousarray(halo[0], np.float32), np.ascontiguousarray(halo[1], np.float32)
+            n_halo = len(hl)
+        self._ck(self.lib.pss_h_stream_display_nfm(self.h, _ptr(h_iq), nf, n, float(fs), int(chunk_frames), m, window, disp_h, disp_w,
+                                                   _ptr(hl), _ptr(hh), n_halo, _ptr(la), _ptr(lb), _ptr(pcm), _ptr(db), _ptr(lo), _ptr(hi)))
+        return {"lines": (la, lb) if m == 0 else (la,), "pcm": pcm, "row_lo": lo, "row_hi": hi, "db": db}
+
     def stream_spectrum_nfm(self, h_iq, fs, chunk_frames, h_db=None, h_pcm=None):
         """h_iq: complex64 [n_frames, n] host array (pinned for overlap).  Returns (h_db or None, h_pcm)."""
         assert h_iq.dtype == np.complex64 and h_iq.ndim == 2 and h_iq.flags.c_contiguous

@@ -8,11 +8,20 @@ sweep computes into the other buffer set.
 
 The library itself knows nothing about torch or RCCL (plain C ABI); this module is the host-side glue, in the
 reference's own language.
+
+sharded_stream_display — BASELINE.json configs[4]: a long capture cut into frames, contiguous blocks of frames per rank,
+every rank streaming ITS block from its own pinned host memory over its own PCIe link (Engine.stream_display_nfm: copy /
+compute / copy streams, two buffer sets) and returning the display lines + PCM of its frames.  The display history of a
+block's first frames reaches into the left neighbour's block: the per-row extremes (8 bytes per row) are exchanged after
+the pass and the first window-1 frames of every block are redone with that halo (a 29-frame fix-up instead of making
+every rank wait for its neighbour's last chunk).
 """
 import torch
 import torch.distributed as dist
 
-from .shard import gather_packed, scan_buffer, shard_counts, shard_range, unpack_gathered
+import numpy as np
+
+from .shard import ShardBuffer, gather_packed, halo_from_left, scan_buffer, shard_counts, shard_range, unpack_gathered
 
 
 def _world_rank(group=None):
@@ -98,3 +107,64 @@ class ShardedScanner:
         """This rank's dB rows [count][n_fft] of sweep `handle` (valid until the set is reused two sweeps later)."""
         db = self.bufs[handle].view("db") if self.gather_db else self.db_local[handle]
         return db[:self.count]
+
+
+def sharded_stream_display(engine, h_iq_local, fs, chunk_frames, mode="waterfall", window=None, disp_h=36, disp_w=112, group=None,
+                           gather_dst=None):
+    """Every rank streams its block of a capture (h_iq_local: complex64 [count_r][n], pinned) and ends up with the display
+    lines + PCM of its frames, exactly as one rank streaming the whole capture would produce them.
+
+    gather_dst=None: results stay on the ranks (each writes its part of the FIFO / screen log); an int gathers
+    (lines..., pcm) to that rank over the process group (one packed message per rank) and returns them in frame order
+    there, None elsewhere.  Returns (lines tuple, pcm) of this rank's block otherwise.
+    """
+    world, rank = _world_rank(group)
+    window = (30 if mode == "waterfall" else 10) if window is None else int(window)
+    res = engine.stream_display_nfm(h_iq_local, fs, chunk_frames, mode=mode, window=window, disp_h=disp_h, disp_w=disp_w)
+    lines, pcm = res["lines"], res["pcm"]
+    if world > 1:
+        # extremes of the rows preceding this block: 8 bytes per row from the left neighbour(s), all messages posted at once
+        dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", engine.device)
+        ext = torch.from_numpy(np.stack([res["row_lo"], res["row_hi"]], axis=1)).to(dev)
+        halo = halo_from_left(ext, window - 1, group=group).cpu().numpy()
+        fix = min(window - 1, h_iq_local.shape[0])
+        if len(halo) and fix:
+            # only the first window-1 frames of the block see the halo; redo them with it (their history is complete now)
+            r2 = engine.stream_display_nfm(np.ascontiguousarray(h_iq_local[:fix]), fs, fix, mode=mode, window=window, disp_h=disp_h,
+                                           disp_w=disp_w, halo=(halo[:, 0], halo[:, 1]))
+            for dst_a, src_a in zip(lines, r2["lines"]):
+                dst_a[:fix] = src_a
+    if gather_dst is None or world == 1:
+        return lines, pcm
+    # one packed message per rank: [lines... | pcm]
+    dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", engine.device)
+    counts = shard_counts_from(torch.tensor([h_iq_local.shape[0]], dtype=torch.int64), group)
+    fields = [(f"l{i}", (disp_w,), torch.int8) for i in range(len(lines))] + [("pcm", tuple(pcm.shape[1:]), torch.int16)]
+    buf = ShardBuffer(fields, max(counts), dev)
+    for i, a in enumerate(lines):
+        buf.view(f"l{i}")[:a.shape[0]] = torch.from_numpy(a).to(dev)
+    buf.view("pcm")[:pcm.shape[0]] = torch.from_numpy(pcm).to(dev)
+    got = _gather_uneven(buf, counts, gather_dst, group)
+    if got is None:
+        return None
+    return tuple(got[f"l{i}"].cpu().numpy() for i in range(len(lines))), got["pcm"].cpu().numpy()
+
+
+def shard_counts_from(count_tensor, group=None):
+    """All ranks' block sizes (blocks need not come from shard_range: a capture is cut where the caller cut it)."""
+    world, _ = _world_rank(group)
+    if world == 1:
+        return [int(count_tensor.item())]
+    dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    allc = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allc, count_tensor.to(dev), group=group)
+    return [int(c) for c in allc.tolist()]
+
+
+def _gather_uneven(buf, counts, dst, group):
+    world, rank = _world_rank(group)
+    out = torch.empty((world, buf.nbytes), dtype=torch.uint8, device=buf.raw.device) if rank == dst else None
+    dist.gather(buf.raw, list(out.unbind(0)) if rank == dst else None, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return unpack_gathered(buf, out, counts)

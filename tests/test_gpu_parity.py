@@ -1096,6 +1096,61 @@ def test_streamed_capture_equals_resident_batch():
         e.pinned_free(a)
 
 
+def test_streamed_display_equals_resident_pipeline():
+    """pss_h_stream_display_nfm (BASELINE configs[4]: pinned host capture in, display lines + PCM out, chunked, three
+    streams) against the device-resident calls on the same frames; the display history crosses chunk boundaries, and a
+    capture continued with a halo of row extremes equals the tail of the uninterrupted one."""
+    e = G.engine()
+    nf, n, fs = 1500, 2048, 10e6
+    rng = np.random.default_rng(21)
+    t = np.arange(n) / fs
+    iq = (0.4 * np.exp(2j * np.pi * (2e5 * t[None, :] + rng.random((nf, 1)))) * (1 + 0.5 * rng.random((nf, 1)))
+          + 0.03 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
+    iq[700:760] *= 30.0                                     # a burst: the window extremes change across chunk boundaries
+    h_iq = e.pinned_empty((nf, n), np.complex64)
+    h_iq[:] = iq
+    n_out = e.demod_out_len(0, n, fs)
+    d_iq = G.dev(iq)
+    d_db, d_pcm = G.empty((nf, n), torch.float32), G.empty((nf, n_out, 2), torch.int16)
+    d_post, d_lo, d_hi = G.empty((nf, n - 4), torch.float32), G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
+    e.set_option("small_batch", 0)
+    try:
+        e.spectrum_nfm(d_iq, nf, n, fs, d_db, d_pcm)
+    finally:
+        e.set_option("small_batch", 1)
+    e.spectrum_post_extremes(d_db, nf, n, d_post, d_lo, d_hi)
+    for mode, window in (("waterfall", 30), ("persistence", 10)):
+        if mode == "waterfall":
+            a, b = G.empty((nf, 112), torch.int8), G.empty((nf, 112), torch.int8)
+            e.waterfall_rows(d_post, nf, n - 4, d_lo, d_hi, 112, a, b, window=window)
+            e.sync()
+            want = (G.host(a), G.host(b))
+        else:
+            a = G.empty((nf, 112), torch.int8)
+            e.persistence_rows(d_post, nf, n - 4, d_lo, d_hi, 36, 112, a, window=window)
+            e.sync()
+            want = (G.host(a),)
+        for chunk in (256, 7, 1500):
+            if chunk == 7 and mode == "persistence":
+                continue
+            got = e.stream_display_nfm(h_iq, fs, chunk, mode=mode, want_db=(chunk == 256))
+            assert all(np.array_equal(x, y) for x, y in zip(got["lines"], want)), \
+                (mode, chunk, [(int((x != y).sum()), np.nonzero((x != y).any(axis=1))[0][:8].tolist()) for x, y in zip(got["lines"], want)])
+            assert np.array_equal(got["pcm"], G.host(d_pcm)), (mode, chunk)
+            assert np.array_equal(got["row_lo"], G.host(d_lo)) and np.array_equal(got["row_hi"], G.host(d_hi))
+            if chunk == 256:
+                assert np.array_equal(got["db"].view(np.uint32), G.host(d_db).view(np.uint32))
+        # continuation: frames 900.. with the extremes of the window-1 rows before them as halo
+        cut = 900
+        h2 = e.pinned_empty((nf - cut, n), np.complex64)
+        h2[:] = iq[cut:]
+        lo, hi = G.host(d_lo), G.host(d_hi)
+        got = e.stream_display_nfm(h2, fs, 200, mode=mode, halo=(lo[cut - (window - 1):cut], hi[cut - (window - 1):cut]))
+        assert all(np.array_equal(x, y[cut:]) for x, y in zip(got["lines"], want)), mode
+        e.pinned_free(h2)
+    e.pinned_free(h_iq)
+
+
 def test_full_size_headline_properties():
     """BASELINE.json cfg 2 size (65 536 x 1024): size-independent properties of the fused headline call."""
     e = G.engine()

@@ -124,3 +124,69 @@ def test_sharded_scanner_equals_single_rank(world, gather_db):
         assert np.array_equal(pk.view(np.uint32), wpk.view(np.uint32)) and np.array_equal(bw, wbw) and np.array_equal(cnt, wcnt), k
     for r, (start, rows) in local.items():
         assert np.array_equal(rows.view(np.uint32), want[-1][0][start:start + rows.shape[0]].view(np.uint32)), r
+
+
+def _stream_iq(n_frames, n):
+    rng = np.random.default_rng(77)
+    t = np.arange(n) / 10e6
+    iq = (0.4 * np.exp(2j * np.pi * (3e5 * t[None, :] + rng.random((n_frames, 1)))) * (1 + rng.random((n_frames, 1)))
+          + 0.03 * (rng.standard_normal((n_frames, n)) + 1j * rng.standard_normal((n_frames, n)))).astype(np.complex64)
+    iq[n_frames // 2 - 5:n_frames // 2 + 5] *= 20.0        # a burst across the block boundary of two ranks
+    return iq
+
+
+def _stream_worker(rank, world, port, backend, n_frames, n, fs, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyspecsdr_amd.engine import Engine
+        from pyspecsdr_amd.multi import sharded_stream_display
+        from pyspecsdr_amd.shard import shard_range
+        e = Engine(dev)
+        start, count = shard_range(n_frames, rank, world)
+        h = e.pinned_empty((count, n), np.complex64)       # every rank its own pinned buffer / PCIe link
+        h[:] = _stream_iq(n_frames, n)[start:start + count]
+        res = sharded_stream_display(e, h, fs, 64, mode=mode, gather_dst=0)
+        if rank == 0:
+            q.put(res)
+        e.pinned_free(h)
+        e.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "waterfall"), (3, "persistence")])
+def test_sharded_stream_equals_single_rank(world, mode):
+    """BASELINE configs[4] on N ranks: each rank streams its block of the capture from its own pinned memory; display
+    lines (history continued across the block boundaries through the halo of row extremes) and PCM gathered to rank 0 must
+    equal one rank streaming the whole capture."""
+    from pyspecsdr_amd.engine import Engine
+    ngpu = torch.cuda.device_count()
+    backend = "nccl" if ngpu >= world else "gloo"
+    n_frames, n, fs = 301, 2048, 10e6
+    e = Engine(0)
+    h = e.pinned_empty((n_frames, n), np.complex64)
+    h[:] = _stream_iq(n_frames, n)
+    want = e.stream_display_nfm(h, fs, 64, mode=mode)
+    e.pinned_free(h)
+    e.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, backend, n_frames, n, fs, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    lines, pcm = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert len(lines) == len(want["lines"]) and all(np.array_equal(a, b) for a, b in zip(lines, want["lines"]))
+    assert np.array_equal(pcm, want["pcm"])
