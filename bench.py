@@ -187,9 +187,7 @@ def main():
     def compute(b):
         db = d_db[b % len(d_db)]
         base = packed[b].data_ptr()
-        eng.spectrum_nfm(iq, nf, n, FS, db, base + o_pcm)
-        eng.spectrum_post_extremes(db, nf, n, d_post, d_lo, d_hi)
-        eng.waterfall_rows(d_post, nf, m, d_lo, d_hi, DISP_W, base, base + o_col, window=WF_WINDOW)
+        eng.frame_pipeline_nfm(iq, nf, n, FS, db, d_post, d_lo, d_hi, DISP_W, base, base + o_col, base + o_pcm, window=WF_WINDOW)
 
     def exchange(b):
         src = packed[b] if exch == "display" else d_db[b % len(d_db)].view(torch.uint8).view(-1)

@@ -151,6 +151,15 @@ int pss_get_wfm_filters(pss_ctx *ctx, double fs, double *lp3x6, double *pilot5x6
 int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db,
                      int16_t *d_pcm);
 
+/* One iteration of the reference's main loop (pyspecsdr.py:2262-2283 and the waterfall draw) for a batch of read buffers:
+ * NFM demod -> d_pcm; compute_fft -> d_db [n_frames][n]; post-process -> d_post [n_frames][n-4] and the row extremes
+ * (d_row_lo / d_row_hi: [n_halo + n_frames], the first n_halo entries supplied by the caller as for pss_waterfall_rows);
+ * waterfall line per frame -> d_glyph / d_colour [n_frames][disp_w].  The same results as the separate calls; the display
+ * chain runs beside the demodulator's backward pass. */
+int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
+                           float *d_row_lo, float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
+                           int8_t *d_colour, int16_t *d_pcm);
+
 /* Waterfall / persistence quantisers over a ring of post-processed rows (pyspecsdr.py:1342-1406,
  * :1512-1564).  d_rows float32 [n_rows][len], oldest first (n_rows <= 30 / <= 10).
  * d_glyph/d_colour int8 [disp_h][disp_w] (-1 = not drawn; persistence: 0 = empty). */

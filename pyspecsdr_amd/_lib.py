@@ -50,6 +50,7 @@ _SIGS = {
     "pss_get_wfm_filters": (C.c_int, [_p, C.c_double, _p, _p, _p, _p]),
     "pss_demod_out_len": (C.c_int, [C.c_int, C.c_int, C.c_double]),
     "pss_spectrum_nfm": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
+    "pss_frame_pipeline_nfm": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "pss_waterfall_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "pss_persistence_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "pss_spectrogram_cells": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_int, C.c_int, _p, _p, _p]),

@@ -2777,6 +2777,49 @@ extern "C" int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, 
     return r2 ? r2 : r;
 }
 
+// One iteration of the reference's main loop for a whole batch of read buffers (pyspecsdr.py:2262-2283 + the display call):
+// demodulate_signal(samples, fs, 'NFM') -> int16; compute_fft -> dB row; smoothing + median clamp; waterfall accumulator
+// line.  The demodulator's backward pass is latency-bound (one wavefront per SIMD), the whole display chain is HBM-bound:
+// behind the forward kernel the two run side by side on two streams (fork / join with events).
+extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
+                                      float *d_row_lo, float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
+                                      int8_t *d_colour, int16_t *d_pcm)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames > 0 && (!d_db || !d_post || !d_row_lo || !d_row_hi || !d_glyph || !d_colour || !d_pcm))
+        return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_nfm: null buffer");
+    pss_time_begin(ctx);
+    int r2;
+    {
+        PssFlagScope fork(ctx->fork_after_fwd, true);
+        ctx->did_fork = false;
+        r2 = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
+    }
+    auto display_chain = [&]() -> int {
+        int r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+        if (!r) r = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+        if (!r) r = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+        return r;
+    };
+    int r = PSS_OK;
+    if (ctx->did_fork) {
+        ctx->did_fork = false;
+        r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
+        if (!r && !r2) {
+            PssStreamScope side(ctx->cur, ctx->stream2);
+            r = display_chain();
+        }
+        int rj = pss_hip_check(ctx, hipEventRecord(ctx->ev_join, ctx->stream2), "hipEventRecord(join)");
+        if (!rj) rj = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)");
+        if (!r) r = rj;
+    } else if (!r2) {
+        r = display_chain();
+    }
+    pss_time_end(ctx);
+    return r2 ? r2 : r;
+}
+
 extern "C" int pss_set_nfm_filters(pss_ctx *ctx, double fs, const double *taps65, const double *sos4x6, const double *zi4x2)
 {
     if (!ctx) return PSS_E_ARG;

@@ -190,6 +190,13 @@ class Engine:
     def spectrum_nfm(self, d_iq, n_frames, n, fs, d_db, d_pcm):
         self._ck(self.lib.pss_spectrum_nfm(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_pcm)))
 
+    def frame_pipeline_nfm(self, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, disp_w, d_glyph, d_colour, d_pcm,
+                           n_halo=0, window=30):
+        """One main-loop iteration for a batch of read buffers: NFM -> int16, dB row, post-processed row (+ extremes),
+        waterfall line (pyspecsdr.py:2262-2283 + draw_waterfall)."""
+        self._ck(self.lib.pss_frame_pipeline_nfm(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
+                                                 _ptr(d_row_hi), n_halo, window, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_pcm)))
+
     def waterfall_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_glyph, d_colour, f64=False):
         fn = self.lib.pss_waterfall_cells_f64 if f64 else self.lib.pss_waterfall_cells
         self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour)))

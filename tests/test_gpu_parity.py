@@ -1151,6 +1151,29 @@ def test_streamed_display_equals_resident_pipeline():
     e.pinned_free(h_iq)
 
 
+def test_frame_pipeline_equals_separate_calls():
+    """pss_frame_pipeline_nfm (what bench.py times: one main-loop iteration per frame of the batch, display chain beside the
+    demodulator's backward pass) against the separate entry points, byte for byte."""
+    e = G.engine()
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    for nf, n, fs in ((9000, 1024, 2.4e6), (300, 2048, 10e6)):
+        iq = torch.randn((nf, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3
+        torch.cuda.synchronize()
+        n_out = e.demod_out_len(0, n, fs)
+        def bufs():
+            return dict(db=G.empty((nf, n), torch.float32), post=G.empty((nf, n - 4), torch.float32), lo=G.empty((nf,), torch.float32),
+                        hi=G.empty((nf,), torch.float32), g=G.empty((nf, 112), torch.int8), c=G.empty((nf, 112), torch.int8),
+                        pcm=G.empty((nf, n_out, 2), torch.int16))
+        a, b = bufs(), bufs()
+        e.frame_pipeline_nfm(iq, nf, n, fs, a["db"], a["post"], a["lo"], a["hi"], 112, a["g"], a["c"], a["pcm"])
+        e.spectrum_nfm(iq, nf, n, fs, b["db"], b["pcm"])
+        e.spectrum_post_extremes(b["db"], nf, n, b["post"], b["lo"], b["hi"])
+        e.waterfall_rows(b["post"], nf, n - 4, b["lo"], b["hi"], 112, b["g"], b["c"])
+        e.sync()
+        for k in a:
+            assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k)
+
+
 def test_full_size_headline_properties():
     """BASELINE.json cfg 2 size (65 536 x 1024): size-independent properties of the fused headline call."""
     e = G.engine()

@@ -5,6 +5,8 @@
         tools/bench_multi.py --config cfg4 [--steps K]
     (N = 1 works too: PSS_BENCH_DIST=1 python tools/bench_multi.py --config cfg4 initialises RCCL with one rank.)
 
+cfg5: 10 s @ 10 MS/s capture in 2048-pt frames, every rank streams its block from its own pinned host memory through
+spectrum + post-process + display accumulator + NFM and gets display lines + int16 PCM back (PCIe-inclusive rate).
 cfg4: scanner sweep of 8192 centre-frequency slices x 4096-pt FFT (pyspecsdr.py:2514-2590), slices sharded over the
 ranks (strong scaling: the sweep is fixed), results gathered to rank 0 over RCCL.  Reported separately, as SURVEY §7.2 #5
 asks: compute alone, the gather alone (full float32 dB rows: 16 KiB per slice; and the 16 B per slice of peak /
@@ -24,9 +26,47 @@ import torch
 import torch.distributed as dist
 
 
+def cfg5(args, eng, dev, world, rank, use_dist, fence, maxr):
+    """10 s @ 10 MS/s capture cut into 2048-pt frames (48 828 frames), contiguous blocks per rank, every rank streaming its
+    block from its own pinned host memory: persistence display lines (history 10) + FM -> int16 PCM back to the host.
+    PCIe-bound by construction (16 KB in, ~150 B out per frame); the halo exchange is 8 bytes per row."""
+    import numpy as np
+    from pyspecsdr_amd.multi import sharded_stream_display
+    from pyspecsdr_amd.shard import shard_range
+    fs, n = 10e6, 2048
+    n_frames = int(args.seconds * fs) // n
+    start, count = shard_range(n_frames, rank, world)
+    h = eng.pinned_empty((count, n), np.complex64)
+    rng = np.random.default_rng(5 + rank)
+    base = (0.4 * np.exp(2j * np.pi * np.cumsum(rng.standard_normal((64, n)) * 0.03, axis=1))
+            + 0.03 * (rng.standard_normal((64, n)) + 1j * rng.standard_normal((64, n)))).astype(np.complex64)
+    for f0 in range(0, count, 64):
+        h[f0:f0 + 64] = base[:min(64, count - f0)]
+    res = {"config": "cfg5", "n_gpus": world, "frames": n_frames, "frames_per_rank": count, "n_fft": n, "chunk_frames": 4096}
+    for mode in ("persistence", "waterfall"):
+        sharded_stream_display(eng, h, fs, 4096, mode=mode)            # warm-up (buffers, plans)
+        fence()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            sharded_stream_display(eng, h, fs, 4096, mode=mode)
+        fence()
+        el = maxr(time.perf_counter() - t0) / reps
+        res[f"{mode}_s_per_capture"] = el
+        res[f"{mode}_samples_per_s"] = n_frames * n / el
+        res[f"{mode}_h2d_GBps_per_rank"] = count * n * 8 / el / 1e9
+    eng.pinned_free(h)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", choices=["cfg4"], default="cfg4")
+    ap.add_argument("--config", choices=["cfg4", "cfg5"], default="cfg4")
+    ap.add_argument("--seconds", type=float, default=10.0, help="cfg5: length of the capture at 10 MS/s")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--slices", type=int, default=8192)
@@ -62,6 +102,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    if args.config == "cfg5":
+        return cfg5(args, eng, dev, world, rank, use_dist, fence, maxr)
     res = {"config": args.config, "n_gpus": world, "slices": args.slices, "n_fft": n, "steps": args.steps}
     for gather_db in (True, False):
         sc = ShardedScanner(eng, args.slices, n, fs, gather_db=gather_db, dst=0)
