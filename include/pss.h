@@ -53,6 +53,8 @@ int pss_device_count(void);
  *   "wfm_fused" (1)            0: k_wfm_front + lane-per-frame decimator instead of the fused WFM forward kernel
  *   "small_batch" (1)          0: never take the latency-oriented small-batch kernels (one lane per filter section)
  *   "small_batch_max" (8192)   largest NFM frame count that takes them;  "wfm_small_batch_max" (8192) likewise for WFM
+ *   "ssb_hilbert" (1)          0: demodulate_ssb skips the reference's hilbert() FFT round trip (the identity on the real part it
+ *                              keeps, up to ~1e-16); 1: executed for power-of-two frames of 256..16384 samples
  *   "post_legacy" (0)          1: the post-process takes the LDS bitonic sort / LDS-histogram radix select kernels instead of
  *                              the register-resident binary-search select;  "post_sort_max" (8192): longest row the legacy
  *                              path sorts (longer rows: radix select)
@@ -117,6 +119,11 @@ int pss_scan_threshold(pss_ctx *ctx, const float *d_iq, long n_slices, int n, do
  * throughout, bit-identical to the reference on NumPy 2.2.  d_out_iq: complex64 [n_frames][n] (nullable);
  * d_raw: float32 [n_frames][n] = real part = demodulate_signal(..., 'RAW') (signal_processing.py:222-238) (nullable). */
 int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out_iq, float *d_raw);
+
+/* scipy.signal.hilbert along n_rows float64 rows of n samples (the analytic signal demodulate_ssb builds,
+ * signal_processing.py:205, :210): fft, one-sided mask, ifft in one kernel.  n: a power of two in [256, 16384] (PSS_E_ARG
+ * otherwise).  d_analytic: complex128 [n_rows][n] (interleaved re, im). */
+int pss_hilbert(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_analytic);
 
 /* measure_signal_power (signal_processing.py:325-328): float32 [n_frames]. */
 int pss_power_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_power);

@@ -41,6 +41,7 @@ _SIGS = {
     "pss_persistence_rows_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "pss_scan": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p]),
     "pss_scan_threshold": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, C.c_double, _p, _p, _p, _p]),
+    "pss_hilbert": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
     "pss_power_db": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
     "pss_iq_correction": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p]),
     "pss_agc_steps": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_int, _p]),

@@ -64,6 +64,7 @@ struct pss_ctx {
     bool no_wfm_fused = false;  // option "wfm_fused" = 0: k_wfm_front + k_nfm_iir path (A/B testing)
     long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~12000)
     long wfm_small_batch_max = 8192;  // option "wfm_small_batch_max" (measured crossover with the fused kernels ~12000 frames)
+    bool ssb_hilbert = true;   // option "ssb_hilbert": run the reference's hilbert() round trip inside demodulate_ssb where a register transform exists for the frame length
     bool post_legacy = false;  // option "post_legacy": LDS bitonic sort / LDS-histogram radix select instead of the register select
     int post_sort_max = 8192;  // option "post_sort_max": longest row that takes the LDS bitonic sort, else radix select (measured crossover 8192..16384)
     bool fft_big_scratch = false;  // option "fft_big_scratch": N = 8192 / 16384 on the scratch-based radix-R pre-pass kernel (A/B reference)
@@ -133,4 +134,6 @@ void pss_kernel_end(pss_ctx *ctx);
     } while (0)
 
 // implemented in pss_fft.hip
+bool pss_hilbert_supported(int n);
+int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits);
 int pss_fft_tables(pss_ctx *ctx, int n, const double2 **tw, const double **win);

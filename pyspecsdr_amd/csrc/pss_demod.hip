@@ -2340,6 +2340,15 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         hipLaunchKernelGGL(k_ssb_edge, dim3((unsigned)n_frames), dim3(128), 0, PSS_STREAM(ctx),
                            reinterpret_cast<const float2 *>(d_iq), Yf, mxb, n, n_frames, targ);
         pss_kernel_end(ctx);
+        // hilbert(np.real(analytical)) and np.real of it again (signal_processing.py:205-213): the FFT round trip of the
+        // reference, executed where a register transform exists for the frame length; numerically the identity on the
+        // real part up to the transforms' rounding (~1e-16), so skipping it (option "ssb_hilbert" = 0, and every other
+        // frame length) changes no int16 sample
+        if (ctx->ssb_hilbert && pss_hilbert_supported(n)) {
+            PSS_HIP(ctx, hipMemsetAsync(mxb, 0, (size_t)n_frames * sizeof(double), PSS_STREAM(ctx)));
+            r = pss_hilbert_rows(ctx, Yf, n_frames, n, Yf, 1, mxb);
+            if (r) { pss_time_end(ctx); return r; }
+        }
         size_t tot = (size_t)n_frames * n;
         size_t g2 = (tot + TPB - 1) / TPB;
         if (g2 > 16384) g2 = 16384;

@@ -22,6 +22,7 @@
 #include "pss_fft_r16.h"
 #include "pss_fft_xl.h"
 #include "pss_post.h"
+#include "pss_hilbert.h"
 
 namespace {
 
@@ -984,6 +985,64 @@ int scan_reduce(pss_ctx *ctx, const float *d_db, int n, long n_rows, int mode, f
 bool is_pow2(int n) { return n > 0 && !(n & (n - 1)); }
 
 }  // namespace
+
+// scipy.signal.hilbert on n_rows float64 rows of n samples, n a power of two in [256, 16384] (the register transforms).
+// out_mode 0: complex128 analytic signal to d_out; 1: real part to d_out (may be d_x itself) and, if d_maxbits is given,
+// the row's max |real| as a double's bit pattern (atomicMax onto d_maxbits[row]; the caller clears it).
+bool pss_hilbert_supported(int n) { return n >= 256 && n <= 16384 && !(n & (n - 1)); }
+
+int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits)
+{
+    if (!pss_hilbert_supported(n)) return pss_fail(ctx, PSS_E_ARG, "pss_hilbert: the row length must be a power of two in [256, 16384]");
+    if (n_rows == 0) return PSS_OK;
+    const double2 *tw;
+    const double *win;
+    int r = pss_fft_tables(ctx, n, &tw, &win);
+    if (r) return r;
+    auto go = [&](auto kern, size_t lds, int threads, long groups, long cap) -> int {
+        if (lds > 64 * 1024)
+            PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        pss_kernel_begin(ctx, "k_hilbert");
+        hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(threads), lds, PSS_STREAM(ctx), d_x, d_out, tw, n_rows,
+                           d_maxbits);
+        pss_kernel_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "k_hilbert launch");
+    };
+#define HIL_R16(L)                                                                                                           \
+    {                                                                                                                        \
+        using C = pss_r16::Cfg<L>;                                                                                           \
+        const long groups = (n_rows + C::FPW - 1) / C::FPW;                                                                  \
+        int per_cu = (int)((160 * 1024) / (C::LDS + 256));                                                                   \
+        if (per_cu > 2) per_cu = 2;                                                                                          \
+        return out_mode == 0 ? go(pss_hil::k_hilbert_r16<L, 0>, C::LDS, 256, groups, 256L * per_cu * 2)                      \
+                             : go(pss_hil::k_hilbert_r16<L, 1>, C::LDS, 256, groups, 256L * per_cu * 2);                     \
+    }
+    switch (n) {
+    case 256: HIL_R16(0)
+    case 512: HIL_R16(1)
+    case 1024: HIL_R16(2)
+    case 2048: HIL_R16(3)
+    case 4096: HIL_R16(4)
+    case 8192:
+        return out_mode == 0 ? go(pss_hil::k_hilbert_xl<1, 0>, pss_xl::CfgX<1>::LDS, 512, n_rows, 512)
+                             : go(pss_hil::k_hilbert_xl<1, 1>, pss_xl::CfgX<1>::LDS, 512, n_rows, 512);
+    default:
+        return out_mode == 0 ? go(pss_hil::k_hilbert_xl<2, 0>, pss_xl::CfgX<2>::LDS, 1024, n_rows, 256)
+                             : go(pss_hil::k_hilbert_xl<2, 1>, pss_xl::CfgX<2>::LDS, 1024, n_rows, 256);
+    }
+#undef HIL_R16
+}
+
+extern "C" int pss_hilbert(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_analytic)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_rows < 0 || (n_rows > 0 && (!d_x || !d_analytic))) return pss_fail(ctx, PSS_E_ARG, "pss_hilbert: bad argument");
+    pss_time_begin(ctx);
+    const int r = pss_hilbert_rows(ctx, d_x, n_rows, n, d_analytic, 0, nullptr);
+    pss_time_end(ctx);
+    return r;
+}
 
 extern "C" int pss_spectrum_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db)
 {

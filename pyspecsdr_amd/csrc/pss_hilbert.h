@@ -1,0 +1,138 @@
+// pss_hilbert.h — scipy.signal.hilbert along rows (analytic signal): X = fft(x); X *= h (h[0] = h[N/2] = 1, h[1..N/2-1] = 2,
+// h[N/2+1..] = 0); ifft(X) (scipy/signal/_signaltools.py:2318 ff.), which demodulate_ssb applies to the real part of its
+// FIR output (signal_processing.py:205, :210).  Included by pss_fft.hip.
+//
+// Both transforms of a row run back to back in ONE kernel, the row never leaving the CU in between: the register FFTs
+// (pss_fft_r16.h: N = 256..4096, pss_fft_xl.h: N = 8192, 16384) take their input as x[t + T q] (thread t, q < 16) and
+// deliver bin t + T q' to the same thread — the forward transform's output IS the next transform's input layout, so
+// the one-sided mask is a per-register constant (h depends on q' only, except for bins 0 and N/2 in thread 0) and the
+// inverse transform is the same code on the conjugate (ifft(Z) = conj(fft(conj(Z))) / N).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pss_fft_r16.h"
+#include "pss_fft_xl.h"
+
+namespace pss_hil {
+
+// h[t + T q] applied to the bin a thread holds in slot q, then the conjugate (input of the second forward transform)
+__device__ __forceinline__ double2 mask_conj(double2 X, int q, int t)
+{
+    const double f = q == 0 ? (t == 0 ? 1.0 : 2.0) : (q < 8 ? 2.0 : (q == 8 ? (t == 0 ? 1.0 : 0.0) : 0.0));
+    return make_double2(X.x * f, -(X.y * f));
+}
+
+// |re| maximum of a frame as the bit pattern of a non-negative double (orders like the value), into mx[f]
+__device__ __forceinline__ void track_max(double m, unsigned long long *mx)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(m, off);
+        m = (o != o || o > m) ? o : m;           // NaN propagates, as np.max does
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(mx, (unsigned long long)__double_as_longlong(m));
+}
+
+// N = 256 * R3 (R3 = 1..16).  OUT: 0 = complex128 analytic signal to `out`, 1 = real part only (in place allowed) + frame peak
+template <int LOG_R3, int OUT>
+__global__ __launch_bounds__(256) void k_hilbert_r16(const double *x, double *out, const double2 *__restrict__ tw,
+                                                     long n_rows, unsigned long long *__restrict__ mxbits)
+{
+    using C = pss_r16::Cfg<LOG_R3>;
+    constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = C::FPW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *ex_all = reinterpret_cast<double2 *>(smem);
+    double2 *tw2 = ex_all + (size_t)FPW * C::EX;
+    const int tid = threadIdx.x, fl = tid / T, t = tid % T;
+    double2 *ex = ex_all + (size_t)fl * C::EX;
+    double2 tw1[16];
+    tw1[0] = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; k2++) tw1[k2] = tw[(size_t)t * k2];
+    if (tid < R3 * 16) tw2[tid] = tw[(size_t)((tid / 16) * (tid % 16)) * 16];
+    __syncthreads();
+    constexpr bool WL = T <= 64;
+    constexpr double INV_N = 1.0 / (double)N;
+    const long groups = (n_rows + FPW - 1) / FPW;
+    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+        const long f = g * FPW + fl;
+        const bool valid = f < n_rows;
+        const double *row = x + (size_t)(valid ? f : 0) * N;
+        double2 v[16], y[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = make_double2(row[t + T * q], 0.0);
+        // bin k = 256 j1 + t + T c sits in slot (k - t) / T = c + (16 / R3) j1 of the next transform's input
+        pss_r16::r16_core<LOG_R3, WL>(v, ex, tw1, tw2, t, [&](int i, int, double2 X) { y[(i / R3) + (16 / R3) * (i % R3)] = X; });
+        pss_r16::frame_sync<WL>();
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = mask_conj(y[q], q, t);
+        double m = 0.0;
+        pss_r16::r16_core<LOG_R3, WL>(v, ex, tw1, tw2, t, [&](int i, int, double2 W) {
+            const int q = (i / R3) + (16 / R3) * (i % R3);
+            const double re = W.x * INV_N, im = -(W.y * INV_N);      // conj(fft(conj(Z))) / N
+            if (valid) {
+                if (OUT == 0) reinterpret_cast<double2 *>(out)[(size_t)f * N + t + T * q] = make_double2(re, im);
+                else out[(size_t)f * N + t + T * q] = re;
+            }
+            const double a = fabs(re);
+            m = (a != a || a > m) ? a : m;
+        });
+        if (OUT == 1 && mxbits) {
+            // the T threads of a frame: T >= 64 whole wavefronts, T < 64 a slice of one (reduce over the slice only)
+            if (T >= 64) { if (valid) track_max(m, &mxbits[f]); }
+            else {
+                for (int off = T / 2; off > 0; off >>= 1) { const double o = __shfl_xor(m, off); m = (o != o || o > m) ? o : m; }
+                if (valid && t == 0) atomicMax(&mxbits[f], (unsigned long long)__double_as_longlong(m));
+            }
+        }
+        pss_r16::frame_sync<WL>();
+    }
+}
+
+// N = 4096 * R4 (R4 = 2, 4): one workgroup of T = N / 16 threads per frame
+template <int LOG_R4, int OUT>
+__global__ __launch_bounds__(256 << LOG_R4, 4) void k_hilbert_xl(const double *x, double *out,
+                                                                 const double2 *__restrict__ tw, long n_rows,
+                                                                 unsigned long long *__restrict__ mxbits)
+{
+    using C = pss_xl::CfgX<LOG_R4>;
+    constexpr int T = C::T, N = C::N, T2 = C::T2, R4 = C::R4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *ex = reinterpret_cast<double *>(smem);
+    const int t = threadIdx.x;
+    const double2 w1 = tw[t], w2 = tw[(size_t)(t % T2) * 16], w3 = tw[(size_t)(t % R4) * 256];
+    constexpr double INV_N = 1.0 / (double)N;
+    for (long f = blockIdx.x; f < n_rows; f += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t rx = pss_xl::make_rsrc(x + (size_t)f * N, N * 8);
+        const __amdgpu_buffer_rsrc_t ro = pss_xl::make_rsrc(out + (size_t)f * N * (OUT == 0 ? 2 : 1), N * (OUT == 0 ? 16 : 8));
+        double2 u1 = w1, u2 = w2, u3 = w3;
+        asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
+        double2 v[16], y[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = make_double2(pss_xl::buf_load_f64(rx, t * 8, T * q * 8), 0.0);
+        // bin 4096 k + T j + t sits in slot j + (16 / R4) k
+        pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int, int j, int k, double2 X) { y[j + (16 / R4) * k] = X; });
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = mask_conj(y[q], q, t);
+        asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
+        double m = 0.0;
+        pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int, int j, int k, double2 W) {
+            const int q = j + (16 / R4) * k;
+            const double re = W.x * INV_N, im = -(W.y * INV_N);
+            if (OUT == 0) {
+                const unsigned lo = (unsigned)__double2loint(re), hi = (unsigned)__double2hiint(re);
+                const unsigned li = (unsigned)__double2loint(im), hj = (unsigned)__double2hiint(im);
+                typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+                v4u_t pk = {lo, hi, li, hj};
+                __builtin_amdgcn_raw_buffer_store_b128(pk, ro, t * 16, T * q * 16, 0);
+            } else {
+                pss_xl::v2u_t pk = {(unsigned)__double2loint(re), (unsigned)__double2hiint(re)};
+                __builtin_amdgcn_raw_buffer_store_b64(pk, ro, t * 8, T * q * 8, 0);
+            }
+            const double a = fabs(re);
+            m = (a != a || a > m) ? a : m;
+        });
+        if (OUT == 1 && mxbits) track_max(m, &mxbits[f]);
+    }
+}
+
+}  // namespace pss_hil

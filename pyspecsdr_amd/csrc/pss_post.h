@@ -79,12 +79,13 @@ __device__ __forceinline__ unsigned count_below(const unsigned (&key)[EPL], unsi
     return row_reduce<OpAdd, W>(c, red, wave, lane, phase);
 }
 
-// k-th smallest (0-based) of the row's n_valid keys (padding slots hold 0xffffffff): binary search on the key bits below
-// the common prefix of the row's minimum and maximum (returned in mn / mx); stops as soon as one candidate is left.
+// k-th smallest (0-based) of the row's n_valid keys (padding slots hold 0xffffffff) and, in `next`, the (k+1)-th: binary
+// search on the key bits below the common prefix of the row's minimum and maximum (returned in mn / mx); stops as soon as
+// one candidate is left in the bracket, and that last pass also finds the smallest key above the bracket (= rank k + 1).
 // PAD_FROM: first register slot that may hold padding (EPL: none anywhere).
 template <int EPL, int W, int PAD_FROM>
-__device__ __forceinline__ unsigned select_kth(const unsigned (&key)[EPL], unsigned k, unsigned n_valid, unsigned &mn, unsigned &mx,
-                                               unsigned *red, int wave, int lane, int &phase)
+__device__ __forceinline__ unsigned select_kth(const unsigned (&key)[EPL], unsigned k, unsigned n_valid, unsigned &next, unsigned &mn,
+                                               unsigned &mx, unsigned *red, int wave, int lane, int &phase)
 {
     unsigned a = 0xffffffffu, b0 = 0u, b2 = 0u;
 #pragma unroll
@@ -96,7 +97,14 @@ __device__ __forceinline__ unsigned select_kth(const unsigned (&key)[EPL], unsig
     if (PAD_FROM < EPL) { b2 = b2 ? b2 - 1u : 0u; b0 = b2 > b0 ? b2 : b0; }
     mn = row_reduce<OpMin, W>(a, red, wave, lane, phase);
     mx = row_reduce<OpMax, W>(b0, red, wave, lane, phase);
-    if (mn == mx) return mn;
+    // smallest key above v among the row's keys (0xffffffff if there is none but padding)
+    auto above = [&](unsigned v) {
+        unsigned c = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < EPL; r++) c = (key[r] > v && key[r] < c) ? key[r] : c;
+        return row_reduce<OpMin, W>(c, red, wave, lane, phase);
+    };
+    if (mn == mx) { next = mn; return mn; }                   // a constant row (n_valid >= 2 wherever next is used)
     int b = 31 - __builtin_clz(mn ^ mx);                      // highest bit in which two keys of the row differ
     unsigned lo = mn & ~((2u << b) - 1u);                     // all keys lie in [lo, lo + 2^(b+1))
     unsigned n_lo = 0, n_hi = n_valid;                        // #keys < lo, #keys < lo + 2^(b+1)
@@ -106,14 +114,24 @@ __device__ __forceinline__ unsigned select_kth(const unsigned (&key)[EPL], unsig
         const unsigned c = count_below<EPL, W>(key, trial, red, wave, lane, phase);
         if (c <= k) { lo = trial; n_lo = c; } else n_hi = c;
         if (n_hi - n_lo == 1) {
-            // one key left in [lo, lo + 2^b): it is the answer
-            unsigned cand = 0xffffffffu;
+            // one key left in [lo, lo + 2^b): rank k.  Exactly k keys lie below it, so rank k + 1 is the smallest key at or
+            // above lo + 2^b: both come out of one sweep (key - lo wraps to huge values for keys below lo).
+            unsigned cand = 0xffffffffu, nx = 0xffffffffu;
             const unsigned span = 1u << b;
 #pragma unroll
-            for (int r = 0; r < EPL; r++) cand = (key[r] - lo < span) ? key[r] : cand;
-            return row_reduce<OpMin, W>(cand, red, wave, lane, phase);
+            for (int r = 0; r < EPL; r++) {
+                const unsigned d = key[r] - lo;
+                const bool in = d < span;
+                cand = in ? key[r] : cand;
+                nx = (!in && key[r] >= lo && key[r] < nx) ? key[r] : nx;
+            }
+            cand = row_reduce<OpMin, W>(cand, red, wave, lane, phase);
+            next = row_reduce<OpMin, W>(nx, red, wave, lane, phase);
+            return cand;
         }
     }
+    // every bit decided with several equal keys left: lo is repeated n_hi - n_lo times, ranks n_lo .. n_hi - 1
+    next = (k + 1u < n_hi) ? lo : above(lo);
     return lo;
 }
 
@@ -206,20 +224,9 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_post_sel(const float 
         }
         // np.median: the middle order statistic, or the mean of the two middle ones
         const unsigned k1 = (unsigned)((m - 1) >> 1);
-        unsigned mn, mx;
-        const unsigned v1 = select_kth<EPL, W, PAD_FROM>(key, k1, (unsigned)m, mn, mx, red, wave, lane, phase);
-        double med = (double)ord2f(v1);
-        if (!(m & 1)) {
-            // rank k1 + 1: v1 again if it is repeated often enough, else the smallest key above it
-            unsigned v2 = v1;
-            if (v1 != 0xffffffffu && count_below<EPL, W>(key, v1 + 1u, red, wave, lane, phase) <= k1 + 1u) {
-                unsigned c = 0xffffffffu;
-#pragma unroll
-                for (int r = 0; r < EPL; r++) c = (key[r] > v1 && key[r] < c) ? key[r] : c;
-                v2 = row_reduce<OpMin, W>(c, red, wave, lane, phase);
-            }
-            med = 0.5 * (med + (double)ord2f(v2));
-        }
+        unsigned mn, mx, v2;
+        const unsigned v1 = select_kth<EPL, W, PAD_FROM>(key, k1, (unsigned)m, v2, mn, mx, red, wave, lane, phase);
+        const double med = (m & 1) ? (double)ord2f(v1) : 0.5 * ((double)ord2f(v1) + (double)ord2f(v2));
         // fd[fd < thr] = thr (:2282-2283).  float32(max(s, thr)) = max(float32(s), float32(thr)) (rounding is monotonic), and
         // the maximum of two floats is the maximum of their ordered images
         const unsigned thr = f2ord((float)(med - 10.0));

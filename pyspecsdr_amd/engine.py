@@ -155,6 +155,10 @@ class Engine:
         self._ck(self.lib.pss_scan_threshold(self.h, _ptr(d_iq), n_slices, n, float(fs), float(threshold_db), _ptr(d_db), _ptr(d_peak),
                                              _ptr(d_bw), _ptr(d_count)))
 
+    def hilbert(self, d_x, n_rows, n, d_analytic):
+        """scipy.signal.hilbert along float64 rows -> complex128 rows (n: power of two in 256..16384)."""
+        self._ck(self.lib.pss_hilbert(self.h, _ptr(d_x), n_rows, n, _ptr(d_analytic)))
+
     def power_db(self, d_iq, n_frames, n, d_power):
         self._ck(self.lib.pss_power_db(self.h, _ptr(d_iq), n_frames, n, _ptr(d_power)))
 

@@ -336,12 +336,45 @@ def test_ssb_vs_golden(golden, tag, mode):
     fs = float(g[f"ssb_fs_{tag}"])
     e = G.engine()
     e.set_ssb_taps(fs, g[f"ssb_taps_{tag}"])
-    pcm, audio = G.demod(mode, g[f"ssb_iq_{tag}"], fs)
-    assert np.array_equal(pcm, g[f"ssb_pcm_{tag}"])
-    assert np.allclose(audio, g[f"ssb_audio_{tag}"], rtol=0, atol=2e-14)
     taps = g[f"ssb_taps_{tag}"]
+    res = {}
+    for hil in (1, 0):     # 1 (default): the reference's hilbert() FFT round trip is executed; 0: skipped (identity on the real part)
+        e.set_option("ssb_hilbert", hil)
+        try:
+            pcm, audio = G.demod(mode, g[f"ssb_iq_{tag}"], fs)
+        finally:
+            e.set_option("ssb_hilbert", 1)
+        res[hil] = audio
+        assert np.array_equal(pcm, g[f"ssb_pcm_{tag}"]), hil
+        # float64: the reference's own round trip is pocketfft, ours the register transform — both leave ~1e-16 of rounding
+        assert np.allclose(audio, g[f"ssb_audio_{tag}"], rtol=0, atol=2e-14), hil
     for k, iq in enumerate(g[f"ssb_iq_{tag}"]):
-        assert np.array_equal(audio[k], O.demod_ssb(iq, taps))   # bit-exact vs the oracle's zdot-order FIR
+        assert np.array_equal(res[0][k], O.demod_ssb(iq, taps))   # without the round trip: bit-exact vs the oracle's zdot-order FIR
+    assert np.max(np.abs(res[1] - res[0])) < 1e-14
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_hilbert_rows(n):
+    """pss_hilbert = scipy.signal.hilbert along rows (fft, one-sided mask, ifft; _signaltools.py:2318), both transforms in one
+    kernel; against the same statements in NumPy float64."""
+    rng = np.random.default_rng(n)
+    nf = 77 if n <= 4096 else 9
+    x = rng.standard_normal((nf, n)) * rng.uniform(0.01, 10.0, (nf, 1))
+    x[1] = np.cos(2 * np.pi * 37 * np.arange(n) / n)          # analytic signal of a cosine: exp(i w t)
+    e = G.engine()
+    d_out = G.empty((nf, n, 2), torch.float64)
+    e.hilbert(G.dev(x), nf, n, d_out)
+    e.sync()
+    got = G.host(d_out).view(np.complex128).reshape(nf, n)
+    X = np.fft.fft(x, axis=1)
+    h = np.zeros(n); h[0] = h[n // 2] = 1; h[1:n // 2] = 2
+    ref = np.fft.ifft(X * h, axis=1)
+    scale = np.max(np.abs(x), axis=1, keepdims=True)
+    assert np.max(np.abs(got - ref) / scale) < 1e-13
+    assert np.max(np.abs(got[1] - np.exp(2j * np.pi * 37 * np.arange(n) / n))) < 1e-12
+    assert np.max(np.abs(got.real - x) / scale) < 1e-13      # the real part is the input (what demodulate_ssb keeps)
+    with pytest.raises(Exception):
+        e.hilbert(G.dev(x[:, :100].copy()), nf, 100, d_out)
 
 
 def test_am_ssb_ragged_vs_oracle():
