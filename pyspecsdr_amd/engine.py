@@ -355,6 +355,9 @@ class Engine:
 
     def h_morse_edges(self, iq, threshold_db=-20.0):
         """-> (rise_times, fall_times) int32 arrays of decode_morse (decoders.py:159-161) for one buffer."""
+        if float(threshold_db) != -20.0:
+            raise NotImplementedError("morse edges: only the reference's threshold of -20 dB is served (the comparison is pinned to "
+                                      "NumPy's float32 log10 at exactly that point, pyspecsdr.py:573)")
         iq = np.ascontiguousarray(iq, np.complex64)
         cap = max(len(iq) // 2 + 1, 1)
         rise, fall = np.empty(cap, np.int32), np.empty(cap, np.int32)

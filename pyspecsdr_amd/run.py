@@ -1,6 +1,9 @@
 """Run the reference application UNMODIFIED on top of libpss.so:
 
-    python -m pyspecsdr_amd.run /path/to/PySpecSDR/pyspecsdr.py [its own arguments]
+    python -m pyspecsdr_amd.run [--fix-classify] /path/to/PySpecSDR/pyspecsdr.py [its own arguments]
+
+--fix-classify: classify_signal runs (on the GPU) instead of raising the reference's NameError for its missing `welch`
+import — a deliberate deviation from the reference's present behaviour, hence opt-in.
 
 The reference reaches its hot path through ONE module name — `from signal_processing import *` (pyspecsdr.py:98; its
 decoders.py:3 imports `bandpass_filter` from `signal_processing` again).  `install()` registers the drop-in module under
@@ -22,11 +25,16 @@ def install():
 
 def main(argv=None):
     argv = list(sys.argv if argv is None else argv)
+    fix_classify = "--fix-classify" in argv[1:2]
+    if fix_classify:
+        del argv[1]
     if len(argv) < 2:
         print(__doc__)
         return 2
     script = os.path.abspath(argv[1])
-    install()
+    sp = install()
+    if fix_classify:
+        sp.CLASSIFY_RAISES_NAMEERROR = False
     sys.argv = [script] + argv[2:]
     sys.path.insert(0, os.path.dirname(script))          # what `python script.py` would put first
     runpy.run_path(script, run_name="__main__")

@@ -79,10 +79,22 @@ def _inject_designs(kind, fs):
     _designed.add(key)
 
 
+_warned_narrowing = False
+
+
 def _samples(samples):
+    """The reference's read buffer is complex64 (pyspecsdr.py:1885-1891) and the kernels replay NumPy's complex64
+    arithmetic; wider input (complex128) would make the reference compute in float64, which is NOT what happens here —
+    it is narrowed, with a one-time warning."""
+    global _warned_narrowing
     s = np.asarray(samples)
     if s.ndim != 1:
         raise ValueError("samples must be a 1-D complex array")
+    if s.dtype == np.complex128 and not _warned_narrowing:
+        import warnings
+        warnings.warn("pyspecsdr_amd.signal_processing: complex128 samples are narrowed to complex64 (the reference's SDR read "
+                      "buffer type); the reference would have computed this call in float64", RuntimeWarning, stacklevel=3)
+        _warned_narrowing = True
     return np.ascontiguousarray(s, dtype=np.complex64)
 
 
@@ -111,10 +123,11 @@ def bandpass_filter(data, lowcut, highcut, sample_rate):
 
 
 # signal_processing.py:296-322 calls `welch`, which the module never imports: in the reference the function
-# raises NameError on every call (swallowed by the scanner's try/except, pyspecsdr.py:2571).  By default this module runs
-# the function as it is written, i.e. as it behaves once `from scipy.signal import welch` is added; set
-# CLASSIFY_RAISES_NAMEERROR = True to get the reference's present behaviour instead.
-CLASSIFY_RAISES_NAMEERROR = False
+# raises NameError on every call (swallowed by the scanner's try/except, pyspecsdr.py:2571).  The drop-in default is the
+# reference's PRESENT behaviour (a drop-in must not change what the application does); set CLASSIFY_RAISES_NAMEERROR = False
+# — or start the launcher with --fix-classify — to run the function as it is written, i.e. as it behaves once
+# `from scipy.signal import welch` is added.  classify_signal_features() is always available.
+CLASSIFY_RAISES_NAMEERROR = True
 
 
 def classify_signal_features(samples, sample_rate):
