@@ -55,6 +55,7 @@ int pss_device_count(void);
  *   "small_batch_max" (8192)   largest NFM frame count that takes them;  "wfm_small_batch_max" (8192) likewise for WFM
  *   "ssb_hilbert" (1)          0: demodulate_ssb skips the reference's hilbert() FFT round trip (the identity on the real part it
  *                              keeps, up to ~1e-16); 1: executed for power-of-two frames of 256..16384 samples
+ *   "fuse_post" (0)            1: pss_spectrum_db_post takes the fused spectrum + post-process kernel for 1024-point frames
  *   "post_legacy" (0)          1: the post-process takes the LDS bitonic sort / LDS-histogram radix select kernels instead of
  *                              the register-resident binary-search select;  "post_sort_max" (8192): longest row the legacy
  *                              path sorts (longer rows: radix select)
@@ -101,6 +102,12 @@ int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft,
  * without a finite value): what the display accumulators below normalise with. */
 int pss_spectrum_post_extremes(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_row_lo,
                                float *d_row_hi);
+/* compute_fft and the post-process of the same frames in one call (d_db, d_post, and — both or neither — the row extremes);
+ * 1024-point frames run as ONE kernel: the dB row goes from the transform's registers through LDS into the post-process
+ * (option "fuse_post"; default 0: measured no faster inside a pipeline step — 0.52 ms against 0.30 + 0.19 — because the
+ * post-process then runs at the transform's two wavefronts per SIMD), other lengths as the two launches. */
+int pss_spectrum_db_post(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db, float *d_post, float *d_row_lo,
+                         float *d_row_hi);
 /* Finite extremes of arbitrary rows (np.min / np.max over all_data[np.isfinite(all_data)], pyspecsdr.py:1356-1358, per row). */
 int pss_row_extremes(pss_ctx *ctx, const float *d_rows, long n_rows, int len, float *d_row_lo, float *d_row_hi);
 int pss_row_extremes_f64(pss_ctx *ctx, const double *d_rows, long n_rows, int len, double *d_row_lo, double *d_row_hi);

@@ -33,6 +33,7 @@ _SIGS = {
     "pss_spectrum_db": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
     "pss_spectrum_post": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
     "pss_spectrum_post_extremes": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, _p]),
+    "pss_spectrum_db_post": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, _p, _p]),
     "pss_row_extremes": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p]),
     "pss_row_extremes_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p]),
     "pss_waterfall_rows": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -35,7 +36,9 @@ struct pss_ctx {
     hipStream_t cur = nullptr;      // stream the next launches go to (nullptr = `stream`)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fork_after_fwd = false;
-    bool did_fork = false;  // set by pss_demod when it recorded ev_fork (fused NFM path only)
+    bool did_fork = false;
+    bool defer_bwd = false;              // the fused NFM path launches only its forward kernel and parks the backward launch here:
+    std::function<int()> pending_bwd;    // pss_frame_pipeline_nfm places it beside the post-process  // set by pss_demod when it recorded ev_fork (fused NFM path only)
     std::string err;
     std::map<int, double2 *> tw;       // exp(-2 pi i k / N), k < N
     std::map<int, double *> win;       // np.hamming(N)
@@ -65,6 +68,7 @@ struct pss_ctx {
     long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~12000)
     long wfm_small_batch_max = 8192;  // option "wfm_small_batch_max" (measured crossover with the fused kernels ~12000 frames)
     bool ssb_hilbert = true;   // option "ssb_hilbert": run the reference's hilbert() round trip inside demodulate_ssb where a register transform exists for the frame length
+    bool fuse_post = false;    // option "fuse_post": 1024-point frames take the fused spectrum + post-process kernel in pss_spectrum_db_post
     bool post_legacy = false;  // option "post_legacy": LDS bitonic sort / LDS-histogram radix select instead of the register select
     int post_sort_max = 8192;  // option "post_sort_max": longest row that takes the LDS bitonic sort, else radix select (measured crossover 8192..16384)
     bool fft_big_scratch = false;  // option "fft_big_scratch": N = 8192 / 16384 on the scratch-based radix-R pre-pass kernel (A/B reference)

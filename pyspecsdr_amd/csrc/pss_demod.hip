@@ -2202,19 +2202,29 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
                 hipLaunchKernelGGL(fused::k_nfm_fwd<false>, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
                                    reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
             pss_kernel_end(ctx);
+            auto launch_bwd = [=]() -> int {
+                pss_kernel_begin(ctx, "k_nfm_bwd");
+                if (b121)
+                    hipLaunchKernelGGL(fused::k_nfm_bwd<true>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af, n, q,
+                                       n_out, n_frames, c, d_pcm, d_audio);
+                else
+                    hipLaunchKernelGGL(fused::k_nfm_bwd<false>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af, n, q,
+                                       n_out, n_frames, c, d_pcm, d_audio);
+                pss_kernel_end(ctx);
+                return pss_hip_check(ctx, hipGetLastError(), "k_nfm_bwd launch");
+            };
+            if (ctx->defer_bwd) {  // pss_frame_pipeline_nfm places the backward pass itself (beside the post-process)
+                ctx->pending_bwd = launch_bwd;
+                pss_time_end(ctx);
+                return pss_hip_check(ctx, hipGetLastError(), "nfm fused launch");
+            }
             if (ctx->fork_after_fwd) {  // pss_spectrum_nfm overlaps the rest
                 PSS_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
                 ctx->did_fork = true;
             }
-            pss_kernel_begin(ctx, "k_nfm_bwd");
-            if (b121)
-                hipLaunchKernelGGL(fused::k_nfm_bwd<true>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af, n, q,
-                                   n_out, n_frames, c, d_pcm, d_audio);
-            else
-                hipLaunchKernelGGL(fused::k_nfm_bwd<false>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af, n, q,
-                                   n_out, n_frames, c, d_pcm, d_audio);
-            pss_kernel_end(ctx);
+            r = launch_bwd();
             pss_time_end(ctx);
+            if (r) return r;
             return pss_hip_check(ctx, hipGetLastError(), "nfm fused launch");
         }
         const int cpf = (n - 1 + FIR_CH - 1) / FIR_CH;
@@ -2798,35 +2808,41 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
     PSS_GUARD(ctx);
     if (n_frames > 0 && (!d_db || !d_post || !d_row_lo || !d_row_hi || !d_glyph || !d_colour || !d_pcm))
         return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_nfm: null buffer");
+    // Schedule: forward kernel (VALU-bound, fills the machine) -> spectrum (HBM-bound, alone: 0.17 ms at cfg 2) ->
+    // { backward pass (latency-bound, one wavefront per SIMD)  ||  post-process (VALU-bound) -> display lines }.
+    // Running the spectrum beside the backward pass instead (round 1) made the two fight for HBM: 0.30 ms.
     pss_time_begin(ctx);
     int r2;
+    ctx->pending_bwd = nullptr;
     {
-        PssFlagScope fork(ctx->fork_after_fwd, true);
-        ctx->did_fork = false;
+        PssFlagScope defer(ctx->defer_bwd, true);
         r2 = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
     }
+    int r = r2;
+    if (!r) r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
     auto display_chain = [&]() -> int {
-        int r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
-        if (!r) r = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
-        if (!r) r = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
-        return r;
+        int q = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+        if (!q) q = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+        return q;
     };
-    int r = PSS_OK;
-    if (ctx->did_fork) {
-        ctx->did_fork = false;
-        r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
-        if (!r && !r2) {
+    if (ctx->pending_bwd) {
+        auto bwd = ctx->pending_bwd;
+        ctx->pending_bwd = nullptr;
+        if (!r) r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
+        if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
+        if (!r) {
             PssStreamScope side(ctx->cur, ctx->stream2);
             r = display_chain();
         }
+        const int rb = bwd();                      // main stream; launched whatever happened above (the PCM must be produced)
         int rj = pss_hip_check(ctx, hipEventRecord(ctx->ev_join, ctx->stream2), "hipEventRecord(join)");
         if (!rj) rj = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)");
-        if (!r) r = rj;
-    } else if (!r2) {
-        r = display_chain();
+        if (!r) r = rb ? rb : rj;
+    } else if (!r) {
+        r = display_chain();                       // the demodulator took a path without a separate backward kernel
     }
     pss_time_end(ctx);
-    return r2 ? r2 : r;
+    return r;
 }
 
 extern "C" int pss_set_nfm_filters(pss_ctx *ctx, double fs, const double *taps65, const double *sos4x6, const double *zi4x2)

@@ -22,6 +22,7 @@
 #include "pss_fft_r16.h"
 #include "pss_fft_xl.h"
 #include "pss_post.h"
+#include "pss_specpost.h"
 #include "pss_hilbert.h"
 
 namespace {
@@ -1213,6 +1214,43 @@ int display_rows(pss_ctx *ctx, const T *d_post, long n_frames, int len, const T 
 }
 
 }  // namespace
+
+// compute_fft + post-process (+ row extremes) of the same frames: one fused kernel for 1024-point frames (option "fuse_post"),
+// the two launches otherwise.  d_lo / d_hi may both be NULL.
+extern "C" int pss_spectrum_db_post(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db, float *d_post,
+                                    float *d_row_lo, float *d_row_hi)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames < 0 || (n_frames > 0 && (!d_iq || !d_db || !d_post))) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_db_post: null buffer");
+    if ((d_row_lo == nullptr) != (d_row_hi == nullptr)) return pss_fail(ctx, PSS_E_ARG, "row extremes: pass both arrays or neither");
+    if (n_frames == 0) return PSS_OK;
+    if (n_fft == 1024 && ctx->fuse_post && !ctx->post_legacy) {
+        const double2 *tw;
+        const double *win;
+        int r = pss_fft_tables(ctx, n_fft, &tw, &win);
+        if (r) return r;
+        using C = pss_r16::Cfg<2>;
+        const bool prefetch = ctx->fft_prefetch != 0;
+        auto kern = prefetch ? pss_sp::k_spectrum_post_1024<true> : pss_sp::k_spectrum_post_1024<false>;
+        if (C::LDS > 64 * 1024)
+            PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        const long groups = (n_frames + C::FPW - 1) / C::FPW;
+        int per_cu = (int)((160 * 1024) / (C::LDS + 256));
+        if (per_cu > 2) per_cu = 2;
+        const long cap = 256L * per_cu * 2;
+        pss_time_begin(ctx);
+        pss_kernel_begin(ctx, "k_spectrum_post");
+        hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(256), C::LDS, PSS_STREAM(ctx),
+                           reinterpret_cast<const float2 *>(d_iq), d_db, d_post, d_row_lo, d_row_hi, tw, win, n_frames);
+        pss_kernel_end(ctx);
+        pss_time_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_post launch");
+    }
+    int r = pss_spectrum_db(ctx, d_iq, n_frames, n_fft, d_db);
+    if (!r) r = spectrum_post(ctx, d_db, n_frames, n_fft, d_post, d_row_lo, d_row_hi);
+    return r;
+}
 
 extern "C" int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post)
 {

@@ -154,6 +154,94 @@ __device__ __forceinline__ void row_sync()
     }
 }
 
+// One row, staged in LDS in the per-thread-consecutive layout (element e at buf[(e / EPL) * S + e % EPL]) and already
+// synchronised: 5-tap smoothing, median, clamp, the clamped row out through the same staging buffer (coalesced 16-byte
+// stores to out4), the row's finite extremes.  slot[j]: LDS slot of the 4-element chunk j * T + t.  Ends with a row_sync
+// (the buffer may be overwritten afterwards).  FULL: the row has exactly T * EPL points (padding = the last thread's last
+// four slots only).
+template <int EPL, int W, bool FULL>
+__device__ __forceinline__ void post_row_staged(float *buf, const int (&slot)[EPL / 4], int t, int m, unsigned *red, int wave, int lane,
+                                                int &phase, float4 *out4, float *row_lo, float *row_hi, long f)
+{
+    constexpr int T = 64 * W, S = PostCfg<EPL>::S, Q = EPL / 4;
+    constexpr int PAD_FROM = FULL ? EPL - 4 : 0;
+    const int m4 = m >> 2;
+    const int nv = m - t * EPL;                  // this thread's slots r < nv hold elements of the smoothed row
+    // EPL consecutive elements + the next thread's first four (the 5-tap window of the last four outputs)
+    unsigned key[EPL];
+    {
+        float x[EPL + 4];
+#pragma unroll
+        for (int i = 0; i < Q + 1; i++) {
+            const float4 v = *reinterpret_cast<const float4 *>(buf + (i < Q ? t * S + 4 * i : (t + 1) * S));
+            x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+        }
+        // np.convolve(fd, ones(5)/5, 'valid') in float64 (pyspecsdr.py:2279); the row is kept as the order-preserving
+        // integer image of its float32 value (4 bytes per element instead of 12)
+        double xd[EPL + 4];
+#pragma unroll
+        for (int i = 0; i < EPL + 4; i++) xd[i] = (double)x[i];
+#pragma unroll
+        for (int r = 0; r < EPL; r++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) acc += xd[r + k] * 0.2;
+            key[r] = f2ord((float)acc);
+            // padding sorts above everything
+            if (FULL) { if (r >= PAD_FROM) key[r] = t == T - 1 ? 0xffffffffu : key[r]; }
+            else key[r] = r < nv ? key[r] : 0xffffffffu;
+        }
+    }
+    // np.median: the middle order statistic, or the mean of the two middle ones
+    const unsigned k1 = (unsigned)((m - 1) >> 1);
+    unsigned mn, mx, v2;
+    const unsigned v1 = select_kth<EPL, W, PAD_FROM>(key, k1, (unsigned)m, v2, mn, mx, red, wave, lane, phase);
+    const double med = (m & 1) ? (double)ord2f(v1) : 0.5 * ((double)ord2f(v1) + (double)ord2f(v2));
+    // fd[fd < thr] = thr (:2282-2283).  float32(max(s, thr)) = max(float32(s), float32(thr)) (rounding is monotonic), and
+    // the maximum of two floats is the maximum of their ordered images
+    const unsigned thr = f2ord((float)(med - 10.0));
+    row_sync<W == 1>();                      // every thread has read its input window
+#pragma unroll
+    for (int i = 0; i < Q; i++) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned kk = key[4 * i + k];
+            o[k] = ord2f(kk > thr ? kk : thr);
+        }
+        *reinterpret_cast<float4 *>(buf + t * S + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    row_sync<W == 1>();
+#pragma unroll
+    for (int j = 0; j < Q; j++) {
+        const int c = j * T + t;
+        if (c < m4) out4[c] = *reinterpret_cast<const float4 *>(buf + slot[j]);
+    }
+    if (row_lo) {
+        // finite extremes of the clamped row, as the accumulators' np.isfinite masks see them.  A row whose smoothed
+        // values are all finite (any real dB row): min / max commute with the clamp.
+        unsigned a, b;
+        if (mn > ORD_NEG_INF && mx < ORD_POS_INF) {
+            a = mn > thr ? mn : thr;
+            b = mx > thr ? mx : thr;
+        } else {
+            a = 0xffffffffu; b = 0u;
+#pragma unroll
+            for (int r = 0; r < EPL; r++) {
+                const unsigned kk = key[r] > thr ? key[r] : thr;
+                const bool fin = key[r] != 0xffffffffu && kk > ORD_NEG_INF && kk < ORD_POS_INF;
+                a = (fin && kk < a) ? kk : a;
+                b = (fin && kk > b) ? kk : b;
+            }
+            a = row_reduce<OpMin, W>(a, red, wave, lane, phase);
+            b = row_reduce<OpMax, W>(b, red, wave, lane, phase);
+            if (a > b) { a = f2ord(INFINITY); b = f2ord(-INFINITY); }  // no finite value: the neutral pair
+        }
+        if (t == 0) { row_lo[f] = ord2f(a); row_hi[f] = ord2f(b); }
+    }
+    row_sync<W == 1>();                      // the staging buffer may be overwritten now
+}
+
 // Requires N % 4 == 0 (16-byte aligned rows) and N - 4 <= 64 * W * EPL.  FULL: N == 64 * W * EPL exactly (the power-of-two
 // read buffers), where the only padding is the last thread's last four slots.
 template <int EPL, int W, bool FULL>
@@ -164,15 +252,13 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_post_sel(const float 
     constexpr int T = 64 * W;                    // threads per row
     constexpr int RPW = W == 1 ? 4 : 1;          // rows per workgroup
     constexpr int S = PostCfg<EPL>::S, Q = EPL / 4;
-    constexpr int PAD_FROM = FULL ? EPL - 4 : 0;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned red[2 * (W > 1 ? W : 1)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = W == 1 ? lane : tid;           // thread inside the row
     float *buf = reinterpret_cast<float *>(smem) + (W == 1 ? wave : 0) * (T + 1) * S;
-    const int m = N - 4, n4 = N >> 2, m4 = m >> 2;
-    const int nv = m - t * EPL;                  // this thread's slots r < nv hold elements of the smoothed row
+    const int m = N - 4, n4 = N >> 2;
     int phase = 0;
     // LDS slot of the 4-element chunk c = j * T + t (the unit of the coalesced global accesses)
     int slot[Q];
@@ -197,80 +283,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_post_sel(const float 
         // rows of more than T * EPL points (N - 4 <= T * EPL < N): the last thread's window reaches into one more chunk
         if (!FULL && t == 0 && T * Q < n4) *reinterpret_cast<float4 *>(buf + T * S) = row4[T * Q];
         row_sync<W == 1>();
-        // EPL consecutive elements + the next thread's first four (the 5-tap window of the last four outputs)
-        unsigned key[EPL];
-        {
-            float x[EPL + 4];
-#pragma unroll
-            for (int i = 0; i < Q + 1; i++) {
-                const float4 v = *reinterpret_cast<const float4 *>(buf + (i < Q ? t * S + 4 * i : (t + 1) * S));
-                x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
-            }
-            // np.convolve(fd, ones(5)/5, 'valid') in float64 (pyspecsdr.py:2279); the row is kept as the order-preserving
-            // integer image of its float32 value (4 bytes per element instead of 12)
-            double xd[EPL + 4];
-#pragma unroll
-            for (int i = 0; i < EPL + 4; i++) xd[i] = (double)x[i];
-#pragma unroll
-            for (int r = 0; r < EPL; r++) {
-                double acc = 0.0;
-#pragma unroll
-                for (int k = 0; k < 5; k++) acc += xd[r + k] * 0.2;
-                key[r] = f2ord((float)acc);
-                // padding sorts above everything
-                if (FULL) { if (r >= PAD_FROM) key[r] = t == T - 1 ? 0xffffffffu : key[r]; }
-                else key[r] = r < nv ? key[r] : 0xffffffffu;
-            }
-        }
-        // np.median: the middle order statistic, or the mean of the two middle ones
-        const unsigned k1 = (unsigned)((m - 1) >> 1);
-        unsigned mn, mx, v2;
-        const unsigned v1 = select_kth<EPL, W, PAD_FROM>(key, k1, (unsigned)m, v2, mn, mx, red, wave, lane, phase);
-        const double med = (m & 1) ? (double)ord2f(v1) : 0.5 * ((double)ord2f(v1) + (double)ord2f(v2));
-        // fd[fd < thr] = thr (:2282-2283).  float32(max(s, thr)) = max(float32(s), float32(thr)) (rounding is monotonic), and
-        // the maximum of two floats is the maximum of their ordered images
-        const unsigned thr = f2ord((float)(med - 10.0));
-        row_sync<W == 1>();                      // every thread has read its input window
-#pragma unroll
-        for (int i = 0; i < Q; i++) {
-            float o[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const unsigned kk = key[4 * i + k];
-                o[k] = ord2f(kk > thr ? kk : thr);
-            }
-            *reinterpret_cast<float4 *>(buf + t * S + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-        row_sync<W == 1>();
-        float4 *out4 = reinterpret_cast<float4 *>(post + (size_t)f * m);
-#pragma unroll
-        for (int j = 0; j < Q; j++) {
-            const int c = j * T + t;
-            if (c < m4) out4[c] = *reinterpret_cast<const float4 *>(buf + slot[j]);
-        }
-        if (row_lo) {
-            // finite extremes of the clamped row, as the accumulators' np.isfinite masks see them.  A row whose smoothed
-            // values are all finite (any real dB row): min / max commute with the clamp.
-            unsigned a, b;
-            if (mn > ORD_NEG_INF && mx < ORD_POS_INF) {
-                a = mn > thr ? mn : thr;
-                b = mx > thr ? mx : thr;
-            } else {
-                a = 0xffffffffu; b = 0u;
-#pragma unroll
-                for (int r = 0; r < EPL; r++) {
-                    const unsigned kk = key[r] > thr ? key[r] : thr;
-                    const bool fin = key[r] != 0xffffffffu && kk > ORD_NEG_INF && kk < ORD_POS_INF;
-                    a = (fin && kk < a) ? kk : a;
-                    b = (fin && kk > b) ? kk : b;
-                }
-                a = row_reduce<OpMin, W>(a, red, wave, lane, phase);
-                b = row_reduce<OpMax, W>(b, red, wave, lane, phase);
-                if (a > b) { a = f2ord(INFINITY); b = f2ord(-INFINITY); }  // no finite value: the neutral pair
-            }
-            if (t == 0) { row_lo[f] = ord2f(a); row_hi[f] = ord2f(b); }
-        }
-        row_sync<W == 1>();                      // the next row overwrites the staging buffer
+        post_row_staged<EPL, W, FULL>(buf, slot, t, m, red, wave, lane, phase, reinterpret_cast<float4 *>(post + (size_t)f * m), row_lo,
+                                      row_hi, f);
     }
 }
 

@@ -128,6 +128,11 @@ class Engine:
         self._ck(self.lib.pss_spectrum_post_extremes(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_post), _ptr(d_row_lo),
                                                      _ptr(d_row_hi)))
 
+    def spectrum_db_post(self, d_iq, n_frames, n_fft, d_db, d_post, d_row_lo=None, d_row_hi=None):
+        """compute_fft + post-process (+ row extremes) in one call; one fused kernel for 1024-point frames."""
+        self._ck(self.lib.pss_spectrum_db_post(self.h, _ptr(d_iq), n_frames, n_fft, _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
+                                               _ptr(d_row_hi)))
+
     def row_extremes(self, d_rows, n_rows, length, d_row_lo, d_row_hi, f64=False):
         fn = self.lib.pss_row_extremes_f64 if f64 else self.lib.pss_row_extremes
         self._ck(fn(self.h, _ptr(d_rows), n_rows, length, _ptr(d_row_lo), _ptr(d_row_hi)))

@@ -1205,6 +1205,18 @@ def test_frame_pipeline_equals_separate_calls():
         e.sync()
         for k in a:
             assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k)
+        # the fused spectrum + post-process kernel (1024-point frames) against the two separate kernels
+        c = bufs()
+        e.spectrum_db_post(iq, nf, n, c["db"], c["post"], c["lo"], c["hi"])
+        d = bufs()
+        e.set_option("fuse_post", 1)
+        try:
+            e.spectrum_db_post(iq, nf, n, d["db"], d["post"], d["lo"], d["hi"])
+        finally:
+            e.set_option("fuse_post", 0)
+        e.sync()
+        for k in ("db", "post", "lo", "hi"):
+            assert torch.equal(c[k].view(torch.uint8), d[k].view(torch.uint8)) and torch.equal(c[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k)
 
 
 def test_full_size_headline_properties():
