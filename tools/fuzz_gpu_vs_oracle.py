@@ -75,13 +75,18 @@ for it in range(cases):
         am = np.empty((5, 6)); e.lib.pss_am_bandpass_sos(am.ctypes.data)
         pcm, au = G.demod(L.MODE_AM, iq, fs)
         stp = e.ssb_taps(fs)
-        pcm2, au2 = G.demod(L.MODE_USB, iq, fs)
+        e.set_option("ssb_hilbert", 0)          # without the Hilbert round trip: bit for bit; with it (the default, power-of-two
+        pcm2, au2 = G.demod(L.MODE_USB, iq, fs)  # frames of 256..16384 samples): the same int16, float64 within the round trip's rounding
+        e.set_option("ssb_hilbert", 1)
+        pcm3, au3 = G.demod(L.MODE_USB, iq, fs)
         d_p = G.empty((nf,), torch.float32); e.power_db(G.dev(iq), nf, n, d_p)
         d_c = G.empty((nf, n, 2), torch.float32); e.iq_correction(G.dev(iq), nf, n, d_c, None); e.sync()
         p = G.host(d_p); corr = G.host(d_c).reshape(nf, -1).view(np.complex64)
         for f in pick:
             if not np.array_equal(au[f], O.demod_am(iq[f], am), equal_nan=True): bad += 1; print("AM", nf, n, f)
             if not np.array_equal(au2[f], O.demod_ssb(iq[f], stp), equal_nan=True): bad += 1; print("SSB", nf, n, f)
+            if not np.array_equal(pcm3[f], pcm2[f]): bad += 1; print("SSB-hilbert int16", nf, n, f, int((pcm3[f] != pcm2[f]).sum()))
+            if not np.allclose(au3[f], au2[f], rtol=0, atol=1e-13, equal_nan=True): bad += 1; print("SSB-hilbert f64", nf, n, f, np.nanmax(np.abs(au3[f] - au2[f])))
             ref = O.iq_correction(iq[f])   # NaN payloads / signs differ between x86 and the GPU: compare values, NaN == NaN
             if not (np.array_equal(corr[f].real, ref.real, equal_nan=True) and np.array_equal(corr[f].imag, ref.imag, equal_nan=True)
                     and np.array_equal(np.signbit(corr[f].real[np.isfinite(ref.real)]), np.signbit(ref.real[np.isfinite(ref.real)]))):
