@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Standalone launches of the HBM-bound kernels of the bench step at BASELINE cfg-2 size (and the big-N spectrum at cfg 3),
+each alone on the machine, on the dB rows / IQ the step itself would see: algorithmic bytes / mean launch time (HIP events).
+Run under rocprofv3 by tools/prof_round.sh; prints one "alone:" line per kernel."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import bench
+from pyspecsdr_amd.engine import Engine
+
+dev = torch.device("cuda", 0)
+e = Engine(0)
+nf, n = bench.N_FRAMES, bench.N_FFT
+iq = bench.synth_fm_iq(nf, n, bench.FS, dev, seed=20260930)
+torch.cuda.synchronize()
+db = torch.empty((nf, n), dtype=torch.float32, device=dev)
+post = torch.empty((nf, n - 4), dtype=torch.float32, device=dev)
+lo, hi = torch.empty(nf, dtype=torch.float32, device=dev), torch.empty(nf, dtype=torch.float32, device=dev)
+g, c = (torch.empty((nf, bench.DISP_W), dtype=torch.int8, device=dev) for _ in range(2))
+
+
+def run(name, fn, kernel, nbytes, reps=8):
+    for _ in range(2):
+        fn()
+    e.sync()
+    e.enable_timing(True)
+    for _ in range(reps):
+        fn()
+    e.sync()
+    v = e.kernel_times()[kernel]
+    e.enable_timing(False)
+    ms = sum(v) / len(v)
+    print(f"alone: {name:44s} {ms:8.4f} ms  {nbytes / ms / 1e9:6.2f} TB/s algorithmic = {nbytes / ms / 1e9 / 8.0:5.3f} of the 8 TB/s HBM peak")
+
+
+run("k_spectrum_r16 65536 x 1024 (FM IQ)", lambda: e.spectrum_db(iq, nf, n, db), "k_spectrum", nf * bench.ALGO_BYTES["k_spectrum"])
+run("k_post_sel 65536 x 1024 (the FM spectra)", lambda: e.spectrum_post_extremes(db, nf, n, post, lo, hi), "k_post", nf * bench.ALGO_BYTES["k_post"])
+run("k_disp_rows 65536 x 1020 -> 112 cells", lambda: e.waterfall_rows(post, nf, n - 4, lo, hi, bench.DISP_W, g, c), "k_disp_rows",
+    nf * bench.ALGO_BYTES["k_disp_rows"])
+del iq, db, post
+for n2, f2 in ((16384, 8192), (8192, 16384), (4096, 32768), (2048, 32768)):
+    x = torch.randn((f2, n2, 2), device=dev) * 0.1
+    d = torch.empty((f2, n2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    run(f"k_spectrum {f2} x {n2}", lambda: e.spectrum_db(x, f2, n2, d), "k_spectrum", f2 * n2 * 12)
+    del x, d

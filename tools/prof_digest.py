@@ -66,6 +66,20 @@ if os.path.exists(p):
         if n not in big_ms or g > big_ms[n][0]:
             big_ms[n] = (g, sum(v) / len(v))
 
+p = os.path.join(out, "alone_kernel_trace.csv")
+if os.path.exists(p):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        n = kname(r["Kernel_Name"])
+        if n:
+            acc[(n, int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    lines.append("== standalone launches (rocprofv3 --kernel-trace: python tools/bench_alone.py; its own lines below): kernel, grid, launches, mean ms")
+    for (n, g), v in sorted(acc.items()):
+        lines.append(f"{n:28s} grid={g:9d} launches={len(v):4d} mean={sum(v) / len(v):8.4f} ms  min={min(v):8.4f} ms")
+    lg = os.path.join(out, "alone.log")
+    if os.path.exists(lg):
+        lines += [l.rstrip() for l in open(lg) if l.startswith("alone:")]
+
 digest = {"src_hash": source_hash(), "git": git_head(), "n_frames": N_FRAMES,
           "profile": f"profiles/{tag}_summary.txt (tools/prof_round.sh {tag})", "kernels": {}}
 meta = {}

@@ -20,4 +20,6 @@ timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
     --kernel-trace --output-format csv -d "$OUT" -o sqa -- $SHORT > "$OUT/sqa.log" 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
     --kernel-trace --output-format csv -d "$OUT" -o sqb -- $SHORT > "$OUT/sqb.log" 2>&1
+# standalone launches of the HBM-bound kernels (inside a bench step they share the machine with the backward IIR pass)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o alone -- python tools/bench_alone.py > "$OUT/alone.log" 2>&1
 python tools/prof_digest.py "$OUT" "$TAG"
