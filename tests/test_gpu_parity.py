@@ -726,6 +726,57 @@ def test_empty_batches_and_non_finite_samples(golden):
         assert np.isnan(db[1]).all() and np.isfinite(db[[0, 2, 4]]).all()
 
 
+def test_round2_entry_points_edge_cases():
+    """Zero frames through the batched accumulators / pipeline / Hilbert; infinities inside a dB row (np.median and the
+    np.isfinite masks of the accumulators); argument checks."""
+    from pyspecsdr_amd.engine import PssError
+    e = G.engine()
+    z1 = G.empty((0,), torch.float32)
+    e.spectrum_post_extremes(G.empty((0, 1024), torch.float32), 0, 1024, G.empty((0, 1020), torch.float32), z1, z1)
+    e.row_extremes(G.empty((0, 1020), torch.float32), 0, 1020, z1, z1)
+    e.waterfall_rows(G.empty((0, 1020), torch.float32), 0, 1020, z1, z1, 112, G.empty((0, 112), torch.int8), G.empty((0, 112), torch.int8))
+    e.persistence_rows(G.empty((0, 1020), torch.float32), 0, 1020, z1, z1, 36, 112, G.empty((0, 112), torch.int8))
+    e.spectrum_db_post(G.empty((0, 1024, 2), torch.float32), 0, 1024, G.empty((0, 1024), torch.float32), G.empty((0, 1020), torch.float32), z1, z1)
+    e.frame_pipeline_nfm(G.empty((0, 1024, 2), torch.float32), 0, 1024, 2.4e6, G.empty((0, 1024), torch.float32),
+                         G.empty((0, 1020), torch.float32), z1, z1, 112, G.empty((0, 112), torch.int8), G.empty((0, 112), torch.int8),
+                         G.empty((0, 10, 2), torch.int16))
+    e.hilbert(G.empty((0, 1024), torch.float64), 0, 1024, G.empty((0, 1024, 2), torch.float64))
+    got = e.stream_display_nfm(np.zeros((0, 2048), np.complex64), 10e6, 16)
+    assert got["pcm"].shape[0] == 0 and got["lines"][0].shape == (0, 112)
+    e.sync()
+    with pytest.raises(PssError):
+        e.persistence_rows(G.empty((1, 1020), torch.float32), 1, 1020, G.empty((1,), torch.float32), G.empty((1,), torch.float32), 128, 112,
+                           G.empty((1, 112), torch.int8))                         # row indices are int8
+    with pytest.raises(PssError):
+        e.spectrum_post_extremes(G.empty((1, 1024), torch.float32), 1, 1024, G.empty((1, 1020), torch.float32), None, None)
+    # infinities: +inf / -inf stretches in otherwise ordinary rows (np.median is well defined; the extremes skip them)
+    rng = np.random.default_rng(8)
+    for n in (1024, 4096):
+        db = (rng.standard_normal((6, n)) * 5.0 - 50.0).astype(np.float32)
+        db[1, 100:160] = np.inf
+        db[2, 300:310] = -np.inf
+        db[3, : n // 2 + 50] = np.inf                                                  # the median itself is +inf
+        db[4, 7] = -np.inf
+        db[4, 900:960] = np.inf
+        d_post, d_lo, d_hi = G.empty((6, n - 4), torch.float32), G.empty((6,), torch.float32), G.empty((6,), torch.float32)
+        e.spectrum_post_extremes(G.dev(db), 6, n, d_post, d_lo, d_hi)
+        e.sync()
+        post, lo, hi = G.host(d_post), G.host(d_lo), G.host(d_hi)
+        with np.errstate(all="ignore"):
+            for f in range(6):
+                sm = np.convolve(db[f].astype(np.float64), np.ones(5) / 5, mode="valid")
+                sm32 = sm.astype(np.float32)
+                thr = np.float32(np.median(sm32.astype(np.float64)) - 10)
+                ref = np.where(sm32 < thr, thr, sm32)
+                ok = (post[f] == ref) | (np.abs(post[f] - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0))
+                assert ok.all(), (n, f, np.nonzero(~ok)[0][:5], post[f][~ok][:5], ref[~ok][:5])
+                fin = post[f][np.isfinite(post[f])]
+                if len(fin):
+                    assert lo[f] == fin.min() and hi[f] == fin.max(), (n, f)
+                else:
+                    assert lo[f] == np.inf and hi[f] == -np.inf, (n, f)
+
+
 def test_afsk_bits(golden):
     """decode_afsk (decoders.py:94-112): the reference's bit lists, and a batch of rows against the oracle."""
     g = golden["afsk"]
