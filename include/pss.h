@@ -48,7 +48,7 @@ void *pss_get_stream(pss_ctx *ctx);
 int pss_sync(pss_ctx *ctx);
 const char *pss_last_error(pss_ctx *ctx); /* ctx may be NULL: error of the last failed pss_create */
 int pss_device_count(void);
-/* Tuning / testing switches; every alternative path produces identical bits.  Returns PSS_E_ARG for unknown keys.
+/* Tuning / testing switches; every alternative path produces identical bits (one exception, last).  Returns PSS_E_ARG for unknown keys.
  *   "nfm_fused" (1)            0: lane-per-frame three-kernel NFM path (front, edge, iir) instead of the fused kernels
  *   "wfm_fused" (1)            0: k_wfm_front + lane-per-frame decimator instead of the fused WFM forward kernel
  *   "small_batch" (1)          0: never take the latency-oriented small-batch kernels (one lane per filter section)
@@ -62,7 +62,12 @@ int pss_device_count(void);
  *   "fft_split" (-1 = auto)    1 / 0: force / forbid the component-wise LDS exchanges of the register FFT (auto: N = 256)
  *   "fft_big_scratch" (0)      1: N = 8192 / 16384 on the scratch-based pre-pass kernel instead of the four-stage register kernel
  *   "fft_prefetch" (-1 = auto) 1 / 0: force / forbid requesting the next frame's samples before transforming the current one
- *                              (auto: N = 1024 and 2048) */
+ *                              (auto: N = 1024 and 2048)
+ * The ONE switch that changes results:
+ *   "fir_mfma" (0)             1: the NFM forward kernel runs its 65-tap FIR as a Toeplitz product on the matrix pipe
+ *                              (v_mfma_f64_16x16x4_f64): another summation order than the reference's OpenBLAS ddot, so the float64
+ *                              audio differs in the last bits (~1e-16 relative); int16 PCM differs only where a sample lies
+ *                              within ~3e-11 of an integer boundary.  Faster (the VALU keeps only discriminator + IIR). */
 int pss_set_option(pss_ctx *ctx, const char *key, int value);
 
 /* ---- filter design (host side, pure C++; replaces the per-call SciPy design work) -------------- */

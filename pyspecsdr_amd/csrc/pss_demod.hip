@@ -340,6 +340,7 @@ __global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, 
 
 }  // namespace
 #include "pss_nfm_fused.h"
+#include "pss_nfm_mfma.h"
 namespace {
 
 // ---------------------------------------------------------------------------------------------------
@@ -2195,7 +2196,16 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             double *Uh = reinterpret_cast<double *>(base + szY + szA), *Ut = reinterpret_cast<double *>(base + szY + szA + szH);
             pss_time_begin(ctx);
             pss_kernel_begin(ctx, "k_nfm_fwd");
-            if (b121)
+            if (ctx->fir_mfma) {
+                // opt-in: the FIR as a Toeplitz product on the matrix pipe (another summation order: float64 audio differs in
+                // the last bits from the reference's OpenBLAS order — see pss_nfm_mfma.h)
+                if (b121)
+                    hipLaunchKernelGGL(fusedm::k_nfm_fwd_mfma<true>, dim3((unsigned)tiles), dim3(fusedm::WG), fusedm::LDS_BYTES,
+                                       PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
+                else
+                    hipLaunchKernelGGL(fusedm::k_nfm_fwd_mfma<false>, dim3((unsigned)tiles), dim3(fusedm::WG), fusedm::LDS_BYTES,
+                                       PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
+            } else if (b121)
                 hipLaunchKernelGGL(fused::k_nfm_fwd<true>, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
                                    reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
             else

@@ -283,6 +283,30 @@ def test_nfm_fused_and_three_kernel_paths_agree(golden):
             assert np.array_equal(a1[k], O.demod_nfm(iq[k], fs, taps, sos, zi)), (n, k)
 
 
+def test_nfm_fir_mfma_variant_is_close_but_not_the_default():
+    # option "fir_mfma": the FIR as one ascending 65-term FMA chain per output on the matrix pipe (pss_nfm_mfma.h).  That
+    # is NOT OpenBLAS's summation order, so the float64 audio may differ in the last bits and the variant stays opt-in;
+    # what it must hold: audio within 1e-10 of the frame peak (the decimator's poles sit closer to the unit circle the
+    # higher the sample rate and amplify the FIR's last-bit differences: 3e-12 at 2.4 MS/s, 1.5e-11 at 10 MS/s), int16 equal except where the exact value sits within
+    # that distance of a rounding boundary (never more than one LSB, a handful per million samples)
+    rng = np.random.default_rng(83)
+    e = G.engine()
+    for nf, n, fs in ((200, 1024, 2.4e6), (70, 2048, 10e6), (65, 129, 2.4e6), (3, 4097, 1.024e6)):
+        iq = (0.4 * np.exp(2j * np.pi * np.cumsum(rng.standard_normal((nf, n)) * 0.05, axis=1)) +
+              0.05 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
+        e.set_option("small_batch", 0)
+        try:
+            pcm0, a0 = G.demod(L.MODE_NFM, iq, fs)
+            e.set_option("fir_mfma", 1)
+            pcm1, a1 = G.demod(L.MODE_NFM, iq, fs)
+        finally:
+            e.set_option("fir_mfma", 0)
+            e.set_option("small_batch", 1)
+        assert np.abs(a1 - a0).max() <= 1e-10 * 0.95, (nf, n, fs, np.abs(a1 - a0).max())
+        d = np.abs(pcm1.astype(np.int32) - pcm0.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).sum() <= max(2, d.size // 100000), (nf, n, fs, int((d != 0).sum()))
+
+
 def test_nfm_edges(golden):
     g = golden["nfm"]
     e = G.engine()
