@@ -224,8 +224,9 @@ int pss_h_morse_edges(pss_ctx *ctx, const float *h_iq, int n, double threshold_d
 
 /* classify_signal (signal_processing.py:296-322; helpers estimate_bandwidth :267-280, estimate_modulation_index :283-293) for
  * a batch of scanner reads, as the function runs once its missing `welch` import is supplied (in the reference it raises
- * NameError on every call: SURVEY App. C2, §8(f) #3).  d_iq: interleaved complex64 [n_frames][n], n >= 1024 (Welch segments
- * of 1024 samples every 512; shorter reads would need a non-power-of-two FFT and return PSS_E_ARG).  Outputs (each may be
+ * NameError on every call: SURVEY App. C2, §8(f) #3).  d_iq: interleaved complex64 [n_frames][n], n >= 1.  n >= 1024: Welch
+ * segments of 1024 samples every 512; shorter reads: ONE segment of n samples (SciPy's nperseg = n fallback: Hann window and
+ * transform of length n, n PSD bins — the first n entries of a d_psd row).  n < 1: PSS_E_ARG (welch raises).  Outputs (each may be
  * NULL): d_label int32 [n_frames] (PSS_CLASS_*), d_bw float64 (the "bandwidth" of estimate_bandwidth: last minus first bin
  * above max - 20 dB in FFT order, in Hz), d_mi float32 (modulation index, bit-exact with NumPy's float32 evaluation),
  * d_flat float32 (spectral flatness), d_psd float32 [n_frames][1024] (Welch PSD, FFT order).  The segment FFT runs in

@@ -354,8 +354,8 @@ void pss_o_compute_fft(const float *iq, int n, double *db)
  *     SVML atan2f, np.unwrap's float32 arithmetic incl. the sequential float32 cumsum, np.diff, np.var) => bit-exact.
  *   spectral flatness :304: exp(mean(log(psd + 1e-10))) / mean(psd), float32 (libm logf/expf here; NumPy uses its
  *     own SIMD log/exp: <= 1 ulp apart).
- * Returns the label (PSS_O_CLS_*), or -1 when n < 1024 (welch would shrink nperseg to n: a non-power-of-two FFT,
- * not provided).  psd_out (may be NULL): float32[1024] in FFT order.
+ * Reads shorter than 1024 samples: SciPy shrinks nperseg to n — one segment, Hann window and FFT of length n.
+ * Returns the label (PSS_O_CLS_*), or -1 when n < 1.  psd_out (may be NULL): float32[min(n, 1024)] in FFT order.
  * ---------------------------------------------------------------------------------------------- */
 static float var_f32(const float *a, long n, float *tmp) /* np.var of a float32 vector (_methods._var) */
 {
@@ -400,27 +400,32 @@ float pss_o_modulation_index(const float *iq, long n)
     return phase_var / (amp_var + (float)1e-10);                 /* :293 */
 }
 
-void pss_o_hann1024_f32(float *w) /* scipy.signal.get_window('hann', 1024) -> general_cosine, cast to float32 */
+void pss_o_hann_f32(float *w, int n) /* scipy.signal.get_window('hann', n) -> general_cosine(n + 1, [0.5, 0.5])[:-1], cast to float32 */
 {
-    const double start = -M_PI, step = (M_PI - (-M_PI)) / 1024.0;  /* np.linspace(-pi, pi, 1025) */
-    for (int i = 0; i < 1024; i++) {
+    if (n <= 1) { if (n == 1) w[0] = 1.0f; return; }             /* windows/_windows.py _len_guards: M <= 1 -> ones(M) */
+    const double start = -M_PI, step = (M_PI - (-M_PI)) / (double)n;  /* np.linspace(-pi, pi, n + 1) */
+    for (int i = 0; i < n; i++) {
         double fac = (double)i * step + start;
         w[i] = (float)(0.5 + 0.5 * cos(fac));
     }
 }
 
+void pss_o_hann1024_f32(float *w) { pss_o_hann_f32(w, 1024); }
+
 int pss_o_classify(const float *iq, long n, double fs, double *bw_out, float *mi_out, float *flat_out, float *psd_out)
 {
-    enum { NP = 1024, STEP = 512 };
-    if (n < NP) return -1;
-    const long nseg = (n - NP) / STEP + 1;
-    float w[NP], w2[2 * NP];
-    pss_o_hann1024_f32(w);
+    if (n < 1) return -1;
+    /* :299 nperseg=1024; a shorter read makes SciPy take nperseg = n (_spectral_py.py _triage_segments: "nperseg = 1024 is
+     * greater than input length ... using nperseg = n"): ONE segment, Hann window of length n, nfft = n (any length) */
+    const int NP = n < 1024 ? (int)n : 1024, STEP = NP - NP / 2;
+    const long nseg = (n - NP / 2) / STEP;                       /* = (n - 1024) / 512 + 1 for n >= 1024, 1 below */
+    float w[1024], w2[2048];
+    pss_o_hann_f32(w, NP);
     for (int i = 0; i < NP; i++) { w2[2 * i] = w[i] * w[i]; w2[2 * i + 1] = 0.0f; }
     float sr, si;
     csum_f32(w2, NP, &sr, &si);                                  /* (win*win).sum(), complex64 */
     const float scale = 1.0f / ((float)fs * sr);                 /* 1.0 / (fs * sum): complex64 scalars with zero imaginary parts */
-    double acc[NP], re[NP], im[NP];
+    double acc[1024], re[1024], im[1024];
     for (int k = 0; k < NP; k++) acc[k] = 0.0;
     for (long s = 0; s < nseg; s++) {
         const float *x = iq + 2 * s * STEP;
@@ -432,12 +437,25 @@ int pss_o_classify(const float *iq, long n, double fs, double *bw_out, float *mi
             re[i] = (double)(w[i] * dr);                         /* win * segment, complex64 with win.imag == 0 */
             im[i] = (double)(w[i] * di);
         }
-        fft_f64(re, im, NP);
+        if (NP == 1024) fft_f64(re, im, NP);
+        else {                                                   /* short read: plain DFT of length n in float64 */
+            double xr[1024], xi[1024];
+            memcpy(xr, re, sizeof(double) * NP); memcpy(xi, im, sizeof(double) * NP);
+            for (int k = 0; k < NP; k++) {
+                double ar = 0.0, ai = 0.0;
+                for (int i = 0; i < NP; i++) {
+                    const double ang = -2.0 * M_PI * (double)(((long)i * k) % NP) / (double)NP, c = cos(ang), sn = sin(ang);
+                    ar += xr[i] * c - xi[i] * sn;
+                    ai += xr[i] * sn + xi[i] * c;
+                }
+                re[k] = ar; im[k] = ai;
+            }
+        }
         for (int k = 0; k < NP; k++) acc[k] += re[k] * re[k] + im[k] * im[k];
     }
-    float psd[NP], tmp[NP];
+    float psd[1024], tmp[1024];
     for (int k = 0; k < NP; k++) psd[k] = (float)(acc[k] / (double)nseg * (double)scale);
-    if (psd_out) memcpy(psd_out, psd, sizeof psd);
+    if (psd_out) memcpy(psd_out, psd, sizeof(float) * NP);
     /* estimate_bandwidth(psd, freqs, -20) :267-280 */
     float mx = -INFINITY;
     for (int k = 0; k < NP; k++) { tmp[k] = 10.0f * log10f(psd[k] + (float)1e-10); if (tmp[k] > mx || tmp[k] != tmp[k]) mx = tmp[k]; }
@@ -447,7 +465,8 @@ int pss_o_classify(const float *iq, long n, double fs, double *bw_out, float *mi
     double bw = 0.0;
     if (first >= 0) {
         const double val = 1.0 / ((double)NP * (1.0 / fs));      /* np.fft.fftfreq(n, d): integers * (1 / (n d)) */
-        const double f0 = (double)(first < NP / 2 ? first : first - NP) * val, f1 = (double)(last < NP / 2 ? last : last - NP) * val;
+        const int npos = (NP - 1) / 2 + 1;                       /* bins 0 .. npos-1 are >= 0, the rest k - n */
+        const double f0 = (double)(first < npos ? first : first - NP) * val, f1 = (double)(last < npos ? last : last - NP) * val;
         bw = f1 - f0;
     }
     const float mi_v = pss_o_modulation_index(iq, n);

@@ -90,6 +90,7 @@ enum { PSS_O_CLS_UNKNOWN = 0, PSS_O_CLS_FM_BROADCAST = 1, PSS_O_CLS_NARROW_FM = 
        PSS_O_CLS_DIGITAL = 5 };
 float pss_o_modulation_index(const float *iq, long n);
 void pss_o_hann1024_f32(float *w);
+void pss_o_hann_f32(float *w, int n);
 int pss_o_classify(const float *iq, long n, double fs, double *bw_out, float *mi_out, float *flat_out, float *psd_out);
 /* decode_morse front half (decoders.py:149-165, threshold -20 dB): indices of the rising / falling transitions */
 void pss_o_morse_edges(const float *iq, long n, int32_t *rise, int32_t *fall, long cap, long *n_rise, long *n_fall);

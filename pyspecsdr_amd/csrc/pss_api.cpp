@@ -143,6 +143,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     if (ctx->scratch_fft) hipFree(ctx->scratch_fft);
     if (ctx->scratch_iqc) hipFree(ctx->scratch_iqc);
     if (ctx->d_hann) hipFree(ctx->d_hann);
+    if (ctx->d_hann_short) hipFree(ctx->d_hann_short);
     if (ctx->scratch_scan) hipFree(ctx->scratch_scan);
     if (ctx->scratch_pk) hipFree(ctx->scratch_pk);
     if (ctx->scratch_win) hipFree(ctx->scratch_win);

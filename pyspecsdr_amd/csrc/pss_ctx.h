@@ -59,6 +59,9 @@ struct pss_ctx {
     size_t scratch_win_bytes = 0;
     float *d_hann = nullptr;       // pss_classify: scipy's periodic Hann window (1024, float32) and sum(win * win)
     float hann_sum = 0.0f;
+    float *d_hann_short = nullptr;  // the same for reads shorter than 1024 samples (window length = read length hann_short_n)
+    float hann_short_sum = 0.0f;
+    int hann_short_n = 0;
     size_t scratch_iqc_bytes = 0;
     void *scratch_fft = nullptr;   // spectrum scratch: separate, the spectrum kernel may run on the side stream
     size_t scratch_fft_bytes = 0;

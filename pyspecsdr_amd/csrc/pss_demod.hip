@@ -1586,6 +1586,75 @@ __global__ __launch_bounds__(256) void k_cls_modidx(const float2 *__restrict__ i
     }
 }
 
+// The part of classify_signal behind the PSD (np bins in FFT order, float32, in LDS): estimate_bandwidth (:267-280), spectral
+// flatness (:304), the decision tree (:307-322).  dbv: np floats, red: 16 doubles, redi: 8 ints of LDS.  All 256 threads.
+__device__ __forceinline__ void cls_features(const float *psd, float *dbv, double *red, int *redi, int np, long f, double fs,
+                                             const float *__restrict__ mi_in, int32_t *__restrict__ label,
+                                             double *__restrict__ bw_out, float *__restrict__ flat_out,
+                                             float *__restrict__ psd_out)
+{
+    const int tid = threadIdx.x;
+    // estimate_bandwidth (:267-280): 10 log10(psd + 1e-10), bins above max - 20 dB, first / last in FFT order
+    float mx = -INFINITY;
+    bool nanv = false;
+    double slog = 0.0, spsd = 0.0;
+    for (int k = tid; k < np; k += 256) {
+        const float v = __fadd_rn(psd[k], (float)1e-10);
+        const float d = __fmul_rn(10.0f, (float)log10((double)v));
+        dbv[k] = d;
+        nanv = nanv || (d != d);
+        mx = d > mx ? d : mx;
+        slog += (double)(float)log((double)v);                       // :304 np.log(psd + 1e-10), float32
+        spsd += (double)psd[k];
+        if (psd_out) psd_out[(size_t)f * CLS_NP + k] = psd[k];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+        nanv = nanv || __shfl_xor((int)nanv, off);
+        slog += __shfl_xor(slog, off);
+        spsd += __shfl_xor(spsd, off);
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = (double)mx; red[4 + (tid >> 6)] = nanv ? 1.0 : 0.0; red[8 + (tid >> 6)] = slog; red[12 + (tid >> 6)] = spsd; }
+    __syncthreads();
+    mx = (float)fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    nanv = (red[4] + red[5] + red[6] + red[7]) != 0.0;
+    slog = (red[8] + red[9]) + (red[10] + red[11]);
+    spsd = (red[12] + red[13]) + (red[14] + red[15]);
+    const float thr = nanv ? NAN : __fadd_rn(mx, -20.0f);            // np.max propagates NaN: then nothing compares above it
+    int first = np, last = -1;
+    for (int k = tid; k < np; k += 256)
+        if (dbv[k] > thr) { first = k < first ? k : first; last = k > last ? k : last; }
+    for (int off = 32; off > 0; off >>= 1) {
+        const int a = __shfl_xor(first, off), b = __shfl_xor(last, off);
+        first = a < first ? a : first;
+        last = b > last ? b : last;
+    }
+    if ((tid & 63) == 0) { redi[tid >> 6] = first; redi[4 + (tid >> 6)] = last; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 0; k < 4; k++) { first = redi[k] < first ? redi[k] : first; last = redi[4 + k] > last ? redi[4 + k] : last; }
+        double bw = 0.0;
+        if (last >= 0) {
+            const double val = 1.0 / ((double)np * (1.0 / fs));      // np.fft.fftfreq(n, d) = integers * (1 / (n d))
+            const int npos = (np - 1) / 2 + 1;                        // bins 0 .. npos - 1 are the non-negative frequencies
+            bw = (double)(last < npos ? last : last - np) * val - (double)(first < npos ? first : first - np) * val;
+        }
+        const float gm = (float)exp((double)(float)(slog / (double)np));
+        const float flat = __fdiv_rn(gm, (float)(spsd / (double)np));
+        const float mi = mi_in[f];
+        int lab = PSS_CLASS_UNKNOWN;                                  // :307-322; np.float32 vs Python float compares in float32
+        if (bw > 150e3) lab = mi > 0.8f ? PSS_CLASS_FM_BROADCAST : PSS_CLASS_UNKNOWN;
+        else if (8e3 <= bw && bw <= 16e3) lab = mi < 0.3f ? PSS_CLASS_NARROW_FM : PSS_CLASS_UNKNOWN;
+        else if (2e3 <= bw && bw <= 3e3) lab = flat < 0.2f ? PSS_CLASS_SSB : PSS_CLASS_UNKNOWN;   // (:314 AM_BROADCAST is unreachable)
+        else if (flat > 0.7f) lab = PSS_CLASS_DIGITAL;
+        if (label) label[f] = lab;
+        if (bw_out) bw_out[f] = bw;
+        if (flat_out) flat_out[f] = flat;
+    }
+    __syncthreads();
+}
+
 // LDS: [buf: 1024 double2][tw: 512 double2][cpart][cval][plan]; psd (float) and the reduction slots alias buf afterwards
 __global__ __launch_bounds__(256) void k_cls_welch(const float2 *__restrict__ iq, int n, long n_frames, double fs, RedPlan cp,
                                                    int part_slots, int val_slots, const float *__restrict__ win, float scale,
@@ -1657,69 +1726,62 @@ __global__ __launch_bounds__(256) void k_cls_welch(const float2 *__restrict__ iq
             psd[bin] = (float)(acc[j] / (double)nseg * (double)scale);
         }
         __syncthreads();
-        // estimate_bandwidth (:267-280): 10 log10(psd + 1e-10), bins above max - 20 dB, first / last in FFT order
-        float mx = -INFINITY;
-        bool nanv = false;
-        double slog = 0.0, spsd = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = tid + 256 * j;
-            const float v = __fadd_rn(psd[k], (float)1e-10);
-            const float d = __fmul_rn(10.0f, (float)log10((double)v));
-            dbv[k] = d;
-            nanv = nanv || (d != d);
-            mx = d > mx ? d : mx;
-            slog += (double)(float)log((double)v);                       // :304 np.log(psd + 1e-10), float32
-            spsd += (double)psd[k];
-            if (psd_out) psd_out[(size_t)f * CLS_NP + k] = psd[k];
+        cls_features(psd, dbv, red, redi, CLS_NP, f, fs, mi_in, label, bw_out, flat_out, psd_out);
+    }
+}
+
+// Reads shorter than one Welch segment (n < 1024): SciPy takes nperseg = n (_spectral_py.py _triage_segments) — ONE segment,
+// a Hann window of length n, an FFT of length n (any length).  Such reads are tiny (the sweep driver never produces them: it
+// reads 0.1 s), so the transform is the plain length-n DFT in float64, one bin per thread and pass, twiddles exp(-2 pi i j / n)
+// in LDS indexed by (i k) mod n.  LDS: [xw: 1024 double2][tw: 1024 double2][psd: 1024 f][dbv: 1024 f][red][redi][cpart][cval][plan]
+__global__ __launch_bounds__(256) void k_cls_welch_short(const float2 *__restrict__ iq, int n, long n_frames, double fs, RedPlan cp,
+                                                         int part_slots, int val_slots, const float *__restrict__ win, float scale,
+                                                         const float *__restrict__ mi_in, int32_t *__restrict__ label,
+                                                         double *__restrict__ bw_out, float *__restrict__ flat_out,
+                                                         float *__restrict__ psd_out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *xw = reinterpret_cast<double2 *>(smem), *tw = xw + CLS_NP;
+    float *psd = reinterpret_cast<float *>(tw + CLS_NP), *dbv = psd + CLS_NP;
+    double *red = reinterpret_cast<double *>(dbv + CLS_NP);
+    int *redi = reinterpret_cast<int *>(red + 16);
+    float2 *cpart = reinterpret_cast<float2 *>(redi + 8), *cval = cpart + part_slots;
+    {
+        int *cur = reinterpret_cast<int *>(cval + val_slots);
+        plan_to_lds(cp.full, cur);
+        plan_to_lds(cp.tail, cur);
+    }
+    const int tid = threadIdx.x;
+    for (int j = tid; j < n; j += 256) {
+        double sn, cs;
+        sincospi(-2.0 * (double)j / (double)n, &sn, &cs);
+        tw[j] = make_double2(cs, sn);
+    }
+    __syncthreads();
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const float2 *x = iq + (size_t)f * n;
+        const float2 m = frame_csum(cp, cpart, cval, [&](int i) { return x[i]; });   // detrend: data - mean(data), complex64
+        const float mr = __fdiv_rn(m.x, (float)n), mim = __fdiv_rn(m.y, (float)n);
+        for (int i = tid; i < n; i += 256) {
+            const float2 v = x[i];
+            const float w = win[i];
+            xw[i] = make_double2((double)__fmul_rn(w, __fsub_rn(v.x, mr)), (double)__fmul_rn(w, __fsub_rn(v.y, mim)));
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const float o = __shfl_xor(mx, off);
-            mx = o > mx ? o : mx;
-            nanv = nanv || __shfl_xor((int)nanv, off);
-            slog += __shfl_xor(slog, off);
-            spsd += __shfl_xor(spsd, off);
-        }
-        if ((tid & 63) == 0) { red[tid >> 6] = (double)mx; red[4 + (tid >> 6)] = nanv ? 1.0 : 0.0; red[8 + (tid >> 6)] = slog; red[12 + (tid >> 6)] = spsd; }
         __syncthreads();
-        mx = (float)fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-        nanv = (red[4] + red[5] + red[6] + red[7]) != 0.0;
-        slog = (red[8] + red[9]) + (red[10] + red[11]);
-        spsd = (red[12] + red[13]) + (red[14] + red[15]);
-        const float thr = nanv ? NAN : __fadd_rn(mx, -20.0f);            // np.max propagates NaN: then nothing compares above it
-        int first = CLS_NP, last = -1;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = tid + 256 * j;
-            if (dbv[k] > thr) { first = k < first ? k : first; last = k > last ? k : last; }
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            const int a = __shfl_xor(first, off), b = __shfl_xor(last, off);
-            first = a < first ? a : first;
-            last = b > last ? b : last;
-        }
-        if ((tid & 63) == 0) { redi[tid >> 6] = first; redi[4 + (tid >> 6)] = last; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int k = 0; k < 4; k++) { first = redi[k] < first ? redi[k] : first; last = redi[4 + k] > last ? redi[4 + k] : last; }
-            double bw = 0.0;
-            if (last >= 0) {
-                const double val = 1.0 / ((double)CLS_NP * (1.0 / fs));  // np.fft.fftfreq(n, d) = integers * (1 / (n d))
-                bw = (double)(last < CLS_NP / 2 ? last : last - CLS_NP) * val - (double)(first < CLS_NP / 2 ? first : first - CLS_NP) * val;
+        for (int k = tid; k < n; k += 256) {
+            double ar = 0.0, ai = 0.0;
+            int idx = 0;
+            for (int i = 0; i < n; i++) {
+                const double2 a = xw[i], t = tw[idx];
+                ar += a.x * t.x - a.y * t.y;
+                ai += a.x * t.y + a.y * t.x;
+                idx += k;
+                idx = idx >= n ? idx - n : idx;
             }
-            const float gm = (float)exp((double)(float)(slog / (double)CLS_NP));
-            const float flat = __fdiv_rn(gm, (float)(spsd / (double)CLS_NP));
-            const float mi = mi_in[f];
-            int lab = PSS_CLASS_UNKNOWN;                                  // :307-322; np.float32 vs Python float compares in float32
-            if (bw > 150e3) lab = mi > 0.8f ? PSS_CLASS_FM_BROADCAST : PSS_CLASS_UNKNOWN;
-            else if (8e3 <= bw && bw <= 16e3) lab = mi < 0.3f ? PSS_CLASS_NARROW_FM : PSS_CLASS_UNKNOWN;
-            else if (2e3 <= bw && bw <= 3e3) lab = flat < 0.2f ? PSS_CLASS_SSB : PSS_CLASS_UNKNOWN;   // (:314 AM_BROADCAST is unreachable)
-            else if (flat > 0.7f) lab = PSS_CLASS_DIGITAL;
-            if (label) label[f] = lab;
-            if (bw_out) bw_out[f] = bw;
-            if (flat_out) flat_out[f] = flat;
+            psd[k] = (float)((ar * ar + ai * ai) * (double)scale);      // mean over the one segment
         }
         __syncthreads();
+        cls_features(psd, dbv, red, redi, n, f, fs, mi_in, label, bw_out, flat_out, psd_out);
     }
 }
 
@@ -2604,21 +2666,29 @@ extern "C" int pss_classify(pss_ctx *ctx, const float *d_iq, long n_frames, int 
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
     if (n_frames < 0 || !(fs > 0.0)) return pss_fail(ctx, PSS_E_ARG, "pss_classify: bad argument");
-    if (n < CLS_NP)
-        return pss_fail(ctx, PSS_E_ARG, "pss_classify: fewer than 1024 samples (welch would fall back to nperseg = n, a non-power-of-two FFT)");
+    if (n < 1) return pss_fail(ctx, PSS_E_ARG, "pss_classify: empty read (welch raises on it)");
     if (n_frames == 0) return PSS_OK;
     if (!d_iq) return pss_fail(ctx, PSS_E_ARG, "pss_classify: null input");
-    // Hann window as scipy.signal.get_window('hann', 1024) builds it (general_cosine over np.linspace(-pi, pi, 1025)), cast to
-    // float32; scale = 1 / (fs * sum(win * win)) in complex64 arithmetic with zero imaginary parts
-    if (!ctx->d_hann) {
-        std::vector<float> w(CLS_NP);
-        const double start = -M_PI, step = (M_PI - (-M_PI)) / 1024.0;
-        for (int i = 0; i < CLS_NP; i++) w[i] = (float)(0.5 + 0.5 * cos((double)i * step + start));
-        // (win * win).sum(): complex64 pairwise sum — 2048 floats, below the 8-float unroll threshold nothing special: replay numpy's
-        // tree on the host (blocks of 128 floats, 8 accumulators striding the interleaved array; imaginary lanes are all zero)
-        std::vector<float> z(2 * CLS_NP, 0.0f);
-        for (int i = 0; i < CLS_NP; i++) z[2 * i] = w[i] * w[i];
+    // Hann window as scipy.signal.get_window('hann', np) builds it (general_cosine over np.linspace(-pi, pi, np + 1); ones for
+    // np <= 1), cast to float32; scale = 1 / (fs * sum(win * win)) in complex64 arithmetic with zero imaginary parts.
+    // np = 1024, or the read length when that is shorter (one segment: SciPy's nperseg = n fallback)
+    const int np = n < CLS_NP ? n : CLS_NP;
+    float *&d_win = np == CLS_NP ? ctx->d_hann : ctx->d_hann_short;
+    float &win_sum = np == CLS_NP ? ctx->hann_sum : ctx->hann_short_sum;
+    if (!d_win || (np != CLS_NP && ctx->hann_short_n != np)) {
+        std::vector<float> w(np);
+        const double start = -M_PI, step = (M_PI - (-M_PI)) / (double)np;
+        for (int i = 0; i < np; i++) w[i] = np == 1 ? 1.0f : (float)(0.5 + 0.5 * cos((double)i * step + start));
+        // (win * win).sum(): numpy's pairwise sum over the 2 np interleaved floats of the complex64 array (imaginary lanes all
+        // zero): blocks of <= 128 floats with 8 accumulators striding the array, a plain loop below 8 floats
+        std::vector<float> z(2 * np, 0.0f);
+        for (int i = 0; i < np; i++) z[2 * i] = w[i] * w[i];
         std::function<float(const float *, int)> pw = [&](const float *a, int nn) -> float {  // real part of numpy's pairwise complex sum
+            if (nn < 8) {
+                float res = 0.0f;
+                for (int i = 0; i < nn; i += 2) res += a[i];
+                return res;
+            }
             if (nn <= 128) {
                 float r[8];
                 for (int k = 0; k < 8; k++) r[k] = a[k];
@@ -2633,16 +2703,18 @@ extern "C" int pss_classify(pss_ctx *ctx, const float *d_iq, long n_frames, int 
             n2 -= n2 % 8;
             return pw(a, n2) + pw(a + n2, nn - n2);
         };
-        ctx->hann_sum = pw(z.data(), 2 * CLS_NP);
-        PSS_HIP(ctx, hipMalloc(&ctx->d_hann, sizeof(float) * CLS_NP));
-        PSS_HIP(ctx, hipMemcpy(ctx->d_hann, w.data(), sizeof(float) * CLS_NP, hipMemcpyHostToDevice));
+        win_sum = pw(z.data(), 2 * np);
+        if (!d_win) PSS_HIP(ctx, hipMalloc(&d_win, sizeof(float) * CLS_NP));
+        PSS_HIP(ctx, hipMemcpyAsync(d_win, w.data(), sizeof(float) * np, hipMemcpyHostToDevice, PSS_STREAM(ctx)));
+        PSS_HIP(ctx, hipStreamSynchronize(PSS_STREAM(ctx)));   // w is a local; also orders the upload behind earlier launches reading the old window
+        if (np != CLS_NP) ctx->hann_short_n = np;
     }
-    const float scale = 1.0f / ((float)fs * ctx->hann_sum);
+    const float scale = 1.0f / ((float)fs * win_sum);
     RedPlan rn, rm, cp;
     int l1, v1, l2, v2, lc, vc;
     int r = get_red_plan(ctx, n, false, &rn, &l1, &v1);
     if (!r) r = get_red_plan(ctx, n - 1, false, &rm, &l2, &v2);
-    if (!r) r = get_red_plan(ctx, CLS_NP, true, &cp, &lc, &vc);
+    if (!r) r = get_red_plan(ctx, np, true, &cp, &lc, &vc);
     if (r) return r;
     const size_t szUp = align256((size_t)n_frames * n * sizeof(float)), szMi = align256((size_t)n_frames * sizeof(float));
     r = pss_ensure_scratch(ctx, szUp + szMi);
@@ -2662,8 +2734,15 @@ extern "C" int pss_classify(pss_ctx *ctx, const float *d_iq, long n_frames, int 
                        n_frames, rn, rm, part1, val1, up, mi);
     pss_kernel_end(ctx);
     pss_kernel_begin(ctx, "k_cls_welch");
-    hipLaunchKernelGGL(k_cls_welch, dim3((unsigned)g), dim3(256), lds2, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n,
-                       n_frames, fs, cp, partc, vc, ctx->d_hann, scale, mi, d_label, d_bw, d_flat, d_psd);
+    if (np == CLS_NP)
+        hipLaunchKernelGGL(k_cls_welch, dim3((unsigned)g), dim3(256), lds2, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n,
+                           n_frames, fs, cp, partc, vc, d_win, scale, mi, d_label, d_bw, d_flat, d_psd);
+    else {
+        const size_t lds3 = sizeof(double2) * 2 * CLS_NP + sizeof(float) * 2 * CLS_NP + sizeof(double) * 16 + sizeof(int) * 8 +
+                            sizeof(float2) * ((size_t)partc + vc) + plan_lds_bytes(cp);
+        hipLaunchKernelGGL(k_cls_welch_short, dim3((unsigned)g), dim3(256), lds3, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq),
+                           n, n_frames, fs, cp, partc, vc, d_win, scale, mi, d_label, d_bw, d_flat, d_psd);
+    }
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "classify launch");

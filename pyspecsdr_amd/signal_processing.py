@@ -134,8 +134,8 @@ def classify_signal_features(samples, sample_rate):
     """-> (label, signal_bw, modulation_index, spectral_flatness): the label of classify_signal and the three numbers it
     is decided on (estimate_bandwidth :267-280, estimate_modulation_index :283-293, flatness :304)."""
     x = _samples(samples)
-    if len(x) < 1024:
-        raise ValueError("classify_signal: fewer than 1024 samples (Welch segments of 1024 samples are not shortened here)")
+    if len(x) < 1:
+        raise ValueError("classify_signal: empty read (scipy.signal.welch raises on it)")
     return get_engine().h_classify_signal(x, sample_rate)
 
 
@@ -150,8 +150,8 @@ def classify_signal(samples, sample_rate, bandwidth):
 def estimate_modulation_index(samples):
     """signal_processing.py:283-293 -> np.float32, bit-exact with NumPy's float32 evaluation."""
     x = _samples(samples)
-    if len(x) < 1024:
-        raise ValueError("estimate_modulation_index: fewer than 1024 samples")
+    if len(x) < 1:
+        return np.float32("nan")              # np.var of empty arrays (NumPy warns and returns nan)
     return get_engine().h_classify_signal(x, 1.0)[2]
 
 

@@ -54,6 +54,7 @@ def lib():
         L.pss_o_classify.restype = C.c_int
         L.pss_o_classify.argtypes = [_f32p, C.c_long, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float), _f32p]
         L.pss_o_hann1024_f32.argtypes = [_f32p]
+        L.pss_o_hann_f32.argtypes = [_f32p, C.c_int]
         _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
         L.pss_o_morse_edges.restype = None
         L.pss_o_morse_edges.argtypes = [_f32p, C.c_long, _i32p, _i32p, C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_long)]
@@ -176,18 +177,24 @@ CLASS_LABELS = ("UNKNOWN", "FM_BROADCAST", "NARROW_FM", "AM_BROADCAST", "SSB", "
 
 
 def classify(iq, fs):
-    """-> (label, signal_bw float64, modulation_index float32, spectral_flatness float32, psd float32[1024])."""
+    """-> (label, signal_bw float64, modulation_index float32, spectral_flatness float32, psd float32[min(n, 1024)])."""
     bw, mi, fl = C.c_double(), C.c_float(), C.c_float()
     psd = np.empty(1024, np.float32)
     lab = lib().pss_o_classify(_iq(iq), len(iq), fs, C.byref(bw), C.byref(mi), C.byref(fl), psd)
     if lab < 0:
-        raise ValueError("classify: fewer than 1024 samples")
-    return CLASS_LABELS[lab], bw.value, np.float32(mi.value), np.float32(fl.value), psd
+        raise ValueError("classify: empty read")
+    return CLASS_LABELS[lab], bw.value, np.float32(mi.value), np.float32(fl.value), psd[:min(len(iq), 1024)].copy()
 
 
 def hann1024():
     w = np.empty(1024, np.float32)
     lib().pss_o_hann1024_f32(w)
+    return w
+
+
+def hann(n):
+    w = np.empty(n, np.float32)
+    lib().pss_o_hann_f32(w, n)
     return w
 
 

@@ -855,9 +855,49 @@ def test_classify_signal(golden):
         assert np.all(np.abs(psd - opsd) <= 1e-6 * (opsd + 1e-10)), tag
     try:
         with pytest.raises(ValueError):
-            sp.classify_signal(np.zeros(1000, np.complex64), fs, 0.0)
+            sp.classify_signal(np.zeros(0, np.complex64), fs, 0.0)
     finally:
         sp.CLASSIFY_RAISES_NAMEERROR = True
+
+
+def test_classify_signal_short_reads(golden):
+    """Reads shorter than Welch's 1024-sample segment (signal_processing.py:299; SciPy then takes ONE segment of len(x) samples):
+    same bars as test_classify_signal, n = 1023 .. 1, against the reference's goldens and the oracle; then a batch."""
+    import pyspecsdr_amd.signal_processing as sp
+    g = golden["classify_short"]
+    e = G.engine()
+    for tag in g["tags"]:
+        iq, fs = g[f"iq_{tag}"], float(g[f"fs_{tag}"])
+        n = len(iq)
+        lab, bw, mi, fl = sp.classify_signal_features(iq, fs)
+        rmi, rfl = g[f"mi_{tag}"], float(g[f"flat_{tag}"])
+        assert lab == str(g[f"label_{tag}"]), tag
+        assert bw == float(g[f"bw_{tag}"]), tag
+        assert mi.tobytes() == rmi.tobytes() or (np.isnan(mi) and np.isnan(rmi)), (tag, mi, rmi)
+        assert float(fl) == rfl or abs(float(fl) - rfl) <= 1e-5 * abs(rfl), (tag, fl, rfl)
+        d_psd, d_lab = G.empty((1, 1024), torch.float32), G.empty((1,), torch.int32)
+        e.classify(G.dev(iq.view(np.float32).reshape(1, n, 2)), 1, n, fs, d_label=d_lab, d_psd=d_psd)
+        e.sync()
+        psd, ref = d_psd.cpu().numpy()[0, :n], g[f"psd_{tag}"]
+        assert np.all(np.abs(psd - ref) <= 1e-5 * (ref + 1e-10) + 1e-6 * np.sqrt(ref * np.max(ref))), tag
+        olab, obw, omi, ofl, opsd = O.classify(iq, fs)
+        assert e.class_name(int(d_lab.cpu()[0])) == olab == lab and obw == bw, tag
+        assert np.all(np.abs(psd - opsd) <= 1e-6 * (opsd + 1e-10)), tag
+    rng = np.random.default_rng(78)
+    for nf, n, fs in ((300, 1000, 2.4e6), (41, 333, 250e3), (7, 6, 2.4e6)):
+        iq = ((rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n))) * 0.05 +
+              0.5 * np.exp(2j * np.pi * np.cumsum(rng.uniform(-0.2, 0.2, (nf, 1)) + 0.01 * rng.standard_normal((nf, n)), axis=1))).astype(np.complex64)
+        d_lab, d_bw = G.empty((nf,), torch.int32), G.empty((nf,), torch.float64)
+        d_mi, d_fl, d_psd = G.empty((nf,), torch.float32), G.empty((nf,), torch.float32), G.empty((nf, 1024), torch.float32)
+        e.classify(G.dev(iq.view(np.float32).reshape(nf, n, 2)), nf, n, fs, d_lab, d_bw, d_mi, d_fl, d_psd)
+        e.sync()
+        lab, bw, mi, fl, psd = (a.cpu().numpy() for a in (d_lab, d_bw, d_mi, d_fl, d_psd))
+        for f in range(nf):
+            olab, obw, omi, ofl, opsd = O.classify(iq[f], fs)
+            assert O.CLASS_LABELS[lab[f]] == olab and bw[f] == obw, (n, f)
+            assert mi[f].tobytes() == omi.tobytes(), (n, f, mi[f], omi)
+            assert abs(float(fl[f]) - float(ofl)) <= 1e-5 * abs(float(ofl)), (n, f)
+            assert np.all(np.abs(psd[f, :n] - opsd) <= 1e-6 * (opsd + 1e-10)), (n, f)
 
 
 def test_classify_batch_vs_oracle():

@@ -269,7 +269,27 @@ def test_classify_signal(golden):
         rfl = float(g[f"flat_{tag}"])
         assert float(fl) == rfl or abs(float(fl) - rfl) <= 1e-5 * abs(rfl) or (np.isnan(fl) and np.isnan(rfl)), (tag, fl, rfl)
     with pytest.raises(ValueError):
-        O.classify(np.zeros(1000, np.complex64), fs)
+        O.classify(np.zeros(0, np.complex64), fs)
+
+
+def test_classify_signal_short_reads(golden):
+    """Reads shorter than Welch's 1024-sample segment (signal_processing.py:299): SciPy takes nperseg = len(x) — one segment,
+    a Hann window and an FFT of that length.  Same bars as above; n = 1 (PSD exactly 0, flatness inf, index NaN) included."""
+    g = golden["classify_short"]
+    for n in (1000, 257, 8, 3, 1):
+        assert np.array_equal(O.hann(n), g[f"win_{n}"]), n
+    for tag in g["tags"]:
+        fs = float(g[f"fs_{tag}"])
+        lab, bw, mi, fl, psd = O.classify(g[f"iq_{tag}"], fs)
+        assert lab == str(g[f"label_{tag}"]), tag
+        assert bw == float(g[f"bw_{tag}"]), tag
+        rmi = g[f"mi_{tag}"]
+        assert mi.tobytes() == rmi.tobytes() or (np.isnan(mi) and np.isnan(rmi)), (tag, mi, rmi)
+        ref = g[f"psd_{tag}"]
+        assert psd.shape == ref.shape
+        assert np.all(np.abs(psd - ref) <= 1e-5 * (ref + 1e-10) + 1e-6 * np.sqrt(ref * np.max(ref))), tag
+        rfl = float(g[f"flat_{tag}"])
+        assert float(fl) == rfl or abs(float(fl) - rfl) <= 1e-5 * abs(rfl) or (np.isnan(fl) and np.isnan(rfl)), (tag, fl, rfl)
 
 
 def test_morse_edges(golden):

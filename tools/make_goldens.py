@@ -419,6 +419,44 @@ def gen_classify():
     save("classify", **d)
 
 
+def gen_classify_short():
+    """classify_signal on reads SHORTER than Welch's segment (signal_processing.py:299: nperseg=1024; SciPy then takes
+    nperseg = len(x): ONE segment, a Hann window of that length, an FFT of that — arbitrary — length).  Same stored items
+    as gen_classify; the PSD has len(x) bins."""
+    sp.welch = ss.welch
+    rng = np.random.default_rng(303)
+    d, tags = {}, []
+    for fs in (2.4e6, 250e3):
+        for n in (1023, 1000, 777, 512, 257, 100, 31, 8, 5, 3, 2, 1):
+            t = np.arange(n) / fs
+            cases = [("nfm", 5e3, 0.0, 0.01), ("fm", 75e3, 0.0, 0.01), ("tone", 0.0, 0.11 * fs, 0.002), ("noise", 0.0, 0.0, 0.2)]
+            for name, dev, off, noise in cases:
+                ph = 2 * np.pi * dev * np.cumsum(np.sin(2 * np.pi * 3e3 * t)) / fs + 2 * np.pi * off * t
+                amp = 0.0 if name == "noise" else 0.5
+                x = (amp * np.exp(1j * ph) + noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+                tag = f"{name}_{n}_{int(fs)}"
+                tags.append(tag)
+                d[f"iq_{tag}"] = x
+                d[f"fs_{tag}"] = np.array(fs)
+    tags.append("silence_600_2400000"); d["iq_silence_600_2400000"] = np.zeros(600, np.complex64); d["fs_silence_600_2400000"] = np.array(2.4e6)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag in tags:
+            x, fs = d[f"iq_{tag}"], float(d[f"fs_{tag}"])
+            freqs, psd = sp.welch(x, fs=fs, nperseg=1024)
+            assert psd.dtype == np.float32 and freqs.dtype == np.float64 and len(psd) == len(x)
+            d[f"psd_{tag}"] = psd
+            d[f"bw_{tag}"] = np.array(float(sp.estimate_bandwidth(psd, freqs)))
+            d[f"mi_{tag}"] = np.array(sp.estimate_modulation_index(x))
+            d[f"flat_{tag}"] = np.array(np.exp(np.mean(np.log(psd + 1e-10))) / np.mean(psd))
+            d[f"label_{tag}"] = np.array(sp.classify_signal(x, fs, 0.0))
+    for n in (1000, 257, 8, 3, 1):
+        d[f"win_{n}"] = ss.get_window("hann", n).astype(np.complex64).real.copy()
+    d["tags"] = np.array(tags)
+    del sp.welch
+    save("classify_short", **d)
+
+
 def gen_decoders():
     """decoders.py end to end: decode_morse (text + timing; np.random seeded because scipy's kmeans draws its initial centroids from
     the global state) and decode_aprs (AFSK audio -> packet list).  rise_ / fall_ are NOT reference outputs (decode_morse keeps
@@ -708,7 +746,7 @@ def gen_caller():
 
 
 if __name__ == "__main__":
-    gens = [gen_atan2, gen_spectrum, gen_nfm, gen_am_ssb, gen_power, gen_iqcorr, gen_wfm, gen_bandpass, gen_afsk, gen_classify,
+    gens = [gen_atan2, gen_spectrum, gen_nfm, gen_am_ssb, gen_power, gen_iqcorr, gen_wfm, gen_bandpass, gen_afsk, gen_classify, gen_classify_short,
             gen_decoders, gen_scanner, gen_caller]
     want = sys.argv[1:]                      # e.g. `python tools/make_goldens.py decoders` regenerates one fixture
     for g in gens:
