@@ -152,7 +152,42 @@ float pss_o_pairwise_sum_f32(const float *a, long n)
     return acc;
 }
 
-float pss_o_log10f_ref(float x) { return (float)log10((double)x); }
+/* np.log10 on float32 under NumPy's AVX512_SKX dispatch = Intel SVML __svml_log10f16 (inside NumPy's _multiarray_umath):
+ * m = mantissa scaled into [0.75, 1.5), k the matching exponent, r = m - 1, degree-4 polynomial in r with coefficients
+ * selected by the top four mantissa bits of m, result fma(p, r, k * log10(2)), all float32.  tools/check_log10f_model.py
+ * compares this function with np.log10 on EVERY positive finite float32: no differing bit.  Specials as the library
+ * returns them: +-0 -> -inf, negative -> NaN, +inf -> +inf, NaN -> NaN. */
+static const uint32_t L10_C0[16] = {0xbdc9ae9bu, 0xbda6fcf4u, 0xbd8bac76u, 0xbd6bca30u, 0xbd48a99bu, 0xbd2c0a9fu, 0xbd1480dbu, 0xbd00faf2u,
+                                    0xbe823aa9u, 0xbe656348u, 0xbe4afbb9u, 0xbe346895u, 0xbe20ffffu, 0xbe103a0bu, 0xbe01a91cu, 0xbde9e84eu};
+static const uint32_t L10_C1[16] = {0x3e13d888u, 0x3e10a87cu, 0x3e0b95c3u, 0x3e057f0bu, 0x3dfde038u, 0x3df080d9u, 0x3de34c1eu, 0x3dd68333u,
+                                    0x3dac6e8eu, 0x3dd54a51u, 0x3df30f40u, 0x3e04235du, 0x3e0b7033u, 0x3e102c90u, 0x3e12ebadu, 0x3e141ff8u};
+static const uint32_t L10_C2[16] = {0xbe5e5a9bu, 0xbe5e2677u, 0xbe5d83f5u, 0xbe5c6016u, 0xbe5abd0bu, 0xbe58a6fdu, 0xbe562e02u, 0xbe5362f8u,
+                                    0xbe68e27cu, 0xbe646747u, 0xbe619a73u, 0xbe5ff05au, 0xbe5f0570u, 0xbe5e92d0u, 0xbe5e662bu, 0xbe5e5c08u};
+static const uint32_t L10_C3[16] = {0x3ede5bd8u, 0x3ede5b45u, 0x3ede57d8u, 0x3ede4eb1u, 0x3ede3d37u, 0x3ede2166u, 0x3eddf9d9u, 0x3eddc5bbu,
+                                    0x3ede08edu, 0x3ede32e7u, 0x3ede4967u, 0x3ede5490u, 0x3ede597fu, 0x3ede5b50u, 0x3ede5bcau, 0x3ede5bd9u};
+float pss_o_log10f_np(float x)
+{
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    if (x != x) return x;
+    if ((b & 0x7fffffffu) == 0u) return -INFINITY;
+    if (b & 0x80000000u) return NAN;
+    if (b == 0x7f800000u) return x;
+    int e = (int)(b >> 23);
+    uint32_t man = b & 0x7fffffu;
+    if (e == 0) { int sh = 0; while (!(man & 0x800000u)) { man <<= 1; sh++; } man &= 0x7fffffu; e = 1 - sh; }
+    int k = e - 127;
+    uint32_t mb;
+    if (man >= 0x400000u) { mb = (126u << 23) | man; k += 1; } else mb = (127u << 23) | man;
+    const int idx = (int)(mb >> 19) & 15;
+    const float r = u2f(mb) - 1.0f;
+    float p = fmaf(u2f(L10_C0[idx]), r, u2f(L10_C1[idx]));
+    p = fmaf(p, r, u2f(L10_C2[idx]));
+    p = fmaf(p, r, u2f(L10_C3[idx]));
+    return fmaf(p, r, (float)k * u2f(0x3e9a209bu));
+}
+float pss_o_log10f_ref(float x) { return pss_o_log10f_np(x); }
+void pss_o_log10f_np_many(const float *x, float *y, long n) { for (long i = 0; i < n; i++) y[i] = pss_o_log10f_np(x[i]); }
 
 /* numpy add.reduce on complex64 (CFLOAT_pairwise_sum, loops_utils.h.src): the interleaved float array is summed
  * with 8 accumulators (4 complex lanes), block 128 FLOATS, fold (r0+r2)+(r4+r6) / (r1+r3)+(r5+r7); the ufunc
@@ -458,7 +493,7 @@ int pss_o_classify(const float *iq, long n, double fs, double *bw_out, float *mi
     if (psd_out) memcpy(psd_out, psd, sizeof(float) * NP);
     /* estimate_bandwidth(psd, freqs, -20) :267-280 */
     float mx = -INFINITY;
-    for (int k = 0; k < NP; k++) { tmp[k] = 10.0f * log10f(psd[k] + (float)1e-10); if (tmp[k] > mx || tmp[k] != tmp[k]) mx = tmp[k]; }
+    for (int k = 0; k < NP; k++) { tmp[k] = 10.0f * pss_o_log10f_np(psd[k] + (float)1e-10); if (tmp[k] > mx || tmp[k] != tmp[k]) mx = tmp[k]; }
     const float thr = mx + -20.0f;
     int first = -1, last = -1;
     for (int k = 0; k < NP; k++) if (tmp[k] > thr) { if (first < 0) first = k; last = k; }

@@ -25,7 +25,9 @@ float pss_o_rcp14f(float x);                 /* VRCP14PS, bit-exact model (64-en
 float pss_o_atan2f(float y, float x);        /* numpy.arctan2 float32 == Intel SVML __svml_atan2f16 (la)     */
 float pss_o_cabsf(float re, float im);       /* numpy.abs(complex64)                                          */
 float pss_o_pairwise_sum_f32(const float *a, long n); /* numpy add.reduce float32 (8192-element chunks, pairwise inside) */
-float pss_o_log10f_ref(float x);             /* float32 log10 via double (tolerance-checked, not bit-pinned) */
+float pss_o_log10f_np(float x);              /* np.log10 float32 (SVML __svml_log10f16 model, bit-pinned: tests/golden/log10f.npz) */
+void pss_o_log10f_np_many(const float *x, float *y, long n);
+float pss_o_log10f_ref(float x);             /* = pss_o_log10f_np (kept for callers) */
 
 /* ---- per-frame functions; iq = interleaved complex64 (I0,Q0,I1,Q1,...) ---- */
 

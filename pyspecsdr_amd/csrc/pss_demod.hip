@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq,
         });
         if (threadIdx.x == 0) {
             const float mean = __fdiv_rn(sum, (float)n);
-            out[f] = KIND == 0 ? 10.0f * log10f(__fadd_rn(mean, 1e-10f)) : mean;  // 10*log10(power + 1e-10), float32
+            out[f] = KIND == 0 ? __fmul_rn(10.0f, log10f_np(__fadd_rn(mean, 1e-10f))) : mean;  // 10*log10(power + 1e-10), float32 (SVML model)
         }
     }
 }
@@ -1600,7 +1600,7 @@ __device__ __forceinline__ void cls_features(const float *psd, float *dbv, doubl
     double slog = 0.0, spsd = 0.0;
     for (int k = tid; k < np; k += 256) {
         const float v = __fadd_rn(psd[k], (float)1e-10);
-        const float d = __fmul_rn(10.0f, (float)log10((double)v));
+        const float d = __fmul_rn(10.0f, log10f_np(v));               // np.log10 float32 = SVML (pss_device.h)
         dbv[k] = d;
         nanv = nanv || (d != d);
         mx = d > mx ? d : mx;

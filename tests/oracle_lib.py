@@ -54,6 +54,7 @@ def lib():
         L.pss_o_classify.restype = C.c_int
         L.pss_o_classify.argtypes = [_f32p, C.c_long, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float), _f32p]
         L.pss_o_hann1024_f32.argtypes = [_f32p]
+        L.pss_o_log10f_np_many.argtypes = [_f32p, _f32p, C.c_long]
         L.pss_o_hann_f32.argtypes = [_f32p, C.c_int]
         _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
         L.pss_o_morse_edges.restype = None
@@ -184,6 +185,14 @@ def classify(iq, fs):
     if lab < 0:
         raise ValueError("classify: empty read")
     return CLASS_LABELS[lab], bw.value, np.float32(mi.value), np.float32(fl.value), psd[:min(len(iq), 1024)].copy()
+
+
+def log10f(x):
+    """np.log10 of a float32 array as NumPy's AVX512_SKX dispatch (SVML) evaluates it."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().pss_o_log10f_np_many(x, y, x.size)
+    return y
 
 
 def hann1024():

@@ -457,6 +457,26 @@ def gen_classify_short():
     save("classify_short", **d)
 
 
+def gen_log10f():
+    """np.log10 on float32 (measure_signal_power :328, estimate_bandwidth :270, the scanner's dB rows): inputs and NumPy's
+    outputs, bit patterns.  Under the AVX512_SKX dispatch this is SVML's __svml_log10f16, not a correctly rounded log10f."""
+    rng = np.random.default_rng(404)
+    u = np.concatenate([
+        rng.integers(1, 0x7f800000, 60000, dtype=np.uint32),                        # all over the positive finite range
+        np.arange(1, 4097, dtype=np.uint32), np.arange(0x00800000 - 2048, 0x00800000 + 2048, dtype=np.uint32),   # denormals, the boundary
+        np.arange(0x3f800000 - 4096, 0x3f800000 + 4096, dtype=np.uint32),           # around 1
+        np.arange(0x3fc00000 - 2048, 0x3fc00000 + 2048, dtype=np.uint32),           # around 1.5 (the mantissa fold)
+        np.float32([1e-10, 0.1, 0.01, 10.0, 100.0, 1e10]).view(np.uint32),
+        np.float32(1e-10).view(np.uint32) + np.arange(-64, 64).astype(np.uint32),
+        np.uint32([0x7f7fffff, 0x7f800000, 0x00000000, 0x80000000, 0xbf800000, 0x7fc00000, 0xff800000])])
+    x = u.astype(np.uint32).view(np.float32)
+    with np.errstate(all="ignore"):
+        y = np.log10(x)
+        ys = np.array([np.log10(v) for v in x[:2000]])                               # scalars take the same loop
+    assert y.dtype == np.float32 and np.array_equal(ys.view(np.uint32), y[:2000].view(np.uint32))
+    save("log10f", x=x, y=y)
+
+
 def gen_decoders():
     """decoders.py end to end: decode_morse (text + timing; np.random seeded because scipy's kmeans draws its initial centroids from
     the global state) and decode_aprs (AFSK audio -> packet list).  rise_ / fall_ are NOT reference outputs (decode_morse keeps
@@ -746,7 +766,7 @@ def gen_caller():
 
 
 if __name__ == "__main__":
-    gens = [gen_atan2, gen_spectrum, gen_nfm, gen_am_ssb, gen_power, gen_iqcorr, gen_wfm, gen_bandpass, gen_afsk, gen_classify, gen_classify_short,
+    gens = [gen_atan2, gen_spectrum, gen_nfm, gen_am_ssb, gen_power, gen_iqcorr, gen_wfm, gen_bandpass, gen_afsk, gen_classify, gen_classify_short, gen_log10f,
             gen_decoders, gen_scanner, gen_caller]
     want = sys.argv[1:]                      # e.g. `python tools/make_goldens.py decoders` regenerates one fixture
     for g in gens:
