@@ -292,6 +292,12 @@ int pss_sosfilt(pss_ctx *ctx, const double *d_x, long n_rows, int n, const doubl
 int pss_afsk_n_bits(int n, double fs);
 int pss_afsk_bits(pss_ctx *ctx, const double *d_audio, long n_rows, int n, double fs, const double *sos1200,
                   const double *sos2200, int nsec, uint8_t *d_bits);
+/* The float32 primitives the path is built from, element by element, as NumPy's AVX512_SKX loops evaluate them (the
+ * reference gets them from np.angle -> np.arctan2 :97/:125, np.log10 :328/:270, np.abs :185/:286): PSS_NP_ARCTAN2
+ * out = arctan2(a, b) (SVML atan2f16 model), PSS_NP_LOG10 out = log10(a) (SVML log10f16 model; d_b unused),
+ * PSS_NP_ABS out = abs(a + i b) (npy_hypotf).  Exposed so the models can be checked bit for bit against NumPy's outputs. */
+enum { PSS_NP_ARCTAN2 = 0, PSS_NP_LOG10 = 1, PSS_NP_ABS = 2 };
+int pss_np_f32(pss_ctx *ctx, int op, const float *d_a, const float *d_b, long n, float *d_out);
 /* samples / np.max(np.abs(samples)) on n_rows float64 rows (decode_aprs's normalisation, decoders.py:126). */
 int pss_row_normalise(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_y);
 /* decode_afsk on one HOST buffer of real float64 audio; normalise != 0 divides by max|x| on the device first, which makes

@@ -188,6 +188,8 @@ float pss_o_log10f_np(float x)
 }
 float pss_o_log10f_ref(float x) { return pss_o_log10f_np(x); }
 void pss_o_log10f_np_many(const float *x, float *y, long n) { for (long i = 0; i < n; i++) y[i] = pss_o_log10f_np(x[i]); }
+void pss_o_atan2f_many(const float *y, const float *x, float *out, long n) { for (long i = 0; i < n; i++) out[i] = pss_o_atan2f(y[i], x[i]); }
+void pss_o_cabsf_many(const float *re, const float *im, float *out, long n) { for (long i = 0; i < n; i++) out[i] = pss_o_cabsf(re[i], im[i]); }
 
 /* numpy add.reduce on complex64 (CFLOAT_pairwise_sum, loops_utils.h.src): the interleaved float array is summed
  * with 8 accumulators (4 complex lanes), block 128 FLOATS, fold (r0+r2)+(r4+r6) / (r1+r3)+(r5+r7); the ufunc

@@ -27,6 +27,8 @@ float pss_o_cabsf(float re, float im);       /* numpy.abs(complex64)            
 float pss_o_pairwise_sum_f32(const float *a, long n); /* numpy add.reduce float32 (8192-element chunks, pairwise inside) */
 float pss_o_log10f_np(float x);              /* np.log10 float32 (SVML __svml_log10f16 model, bit-pinned: tests/golden/log10f.npz) */
 void pss_o_log10f_np_many(const float *x, float *y, long n);
+void pss_o_atan2f_many(const float *y, const float *x, float *out, long n);
+void pss_o_cabsf_many(const float *re, const float *im, float *out, long n);
 float pss_o_log10f_ref(float x);             /* = pss_o_log10f_np (kept for callers) */
 
 /* ---- per-frame functions; iq = interleaved complex64 (I0,Q0,I1,Q1,...) ---- */

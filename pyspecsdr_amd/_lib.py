@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(HERE, "libpss.so")
 
 PSS_OK, PSS_E_ARG, PSS_E_HIP, PSS_E_PADLEN, PSS_E_CUTOFF, PSS_E_NOMEM = 0, -1, -2, -3, -4, -5
 MODE_NFM, MODE_AM, MODE_USB, MODE_LSB, MODE_WFM = 0, 1, 2, 3, 4
+NP_ARCTAN2, NP_LOG10, NP_ABS = 0, 1, 2          # pss_np_f32 operations
 
 _p = C.c_void_p
 _SIGS = {
@@ -85,6 +86,7 @@ _SIGS = {
     "pss_afsk_n_bits": (C.c_int, [C.c_int, C.c_double]),
     "pss_afsk_bits": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, C.c_int, _p]),
     "pss_row_normalise": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
+    "pss_np_f32": (C.c_int, [_p, C.c_int, _p, _p, C.c_long, _p]),
     "pss_h_afsk_bits": (C.c_int, [_p, _p, C.c_int, C.c_double, C.c_int, _p, _p, C.c_int, _p]),
     "pss_h_bandpass_filter": (C.c_int, [_p, _p, C.c_int, C.c_double, C.c_double, C.c_double, _p, C.c_int, _p]),
     "pss_h_iq_correction": (C.c_int, [_p, _p, C.c_int, _p, _p]),

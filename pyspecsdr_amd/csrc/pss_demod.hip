@@ -2782,6 +2782,35 @@ extern "C" int pss_afsk_bits(pss_ctx *ctx, const double *d_audio, long n_rows, i
     return pss_hip_check(ctx, hipGetLastError(), "k_afsk_bits launch");
 }
 
+// The float32 building blocks on their own — np.arctan2 / np.log10 / np.abs(complex64) as NumPy's AVX512_SKX loops evaluate
+// them — so that the device models can be pinned element by element against NumPy's outputs (tests/golden/atan2f.npz,
+// log10f.npz), not only through the demodulators that use them.
+__global__ __launch_bounds__(256) void k_np_f32(int op, const float *__restrict__ a, const float *__restrict__ b, long n,
+                                                float *__restrict__ out)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float r;
+        if (op == PSS_NP_ARCTAN2) r = atan2f_svml(a[i], b[i]);
+        else if (op == PSS_NP_LOG10) r = log10f_np(a[i]);
+        else r = cabsf_np(a[i], b[i]);
+        out[i] = r;
+    }
+}
+
+extern "C" int pss_np_f32(pss_ctx *ctx, int op, const float *d_a, const float *d_b, long n, float *d_out)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (op < PSS_NP_ARCTAN2 || op > PSS_NP_ABS || n < 0) return pss_fail(ctx, PSS_E_ARG, "pss_np_f32: bad argument");
+    if (n == 0) return PSS_OK;
+    if (!d_a || !d_out || (op != PSS_NP_LOG10 && !d_b)) return pss_fail(ctx, PSS_E_ARG, "pss_np_f32: null pointer");
+    const long blocks = (n + 255) / 256;
+    pss_kernel_begin(ctx, "k_np_f32");
+    hipLaunchKernelGGL(k_np_f32, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, PSS_STREAM(ctx), op, d_a, d_b, n, d_out);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_np_f32 launch");
+}
+
 extern "C" int pss_row_normalise(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_y)
 {
     if (!ctx) return PSS_E_ARG;

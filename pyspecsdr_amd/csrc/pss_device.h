@@ -57,7 +57,7 @@ __device__ __noinline__ float atan2f_svml_rare(float y, float x)
         if (sx) v = v + PI;
         return u2f(f2u(v) | sy);
     }
-    return (float)atan2((double)y, (double)x);  // SVML's scalar "rare" helper works in double; not bit-pinned
+    return (float)atan2((double)y, (double)x);  // SVML's scalar "rare" helper works in double (pinned on random bit patterns: atan2f_bits.npz)
 }
 
 // numpy.arctan2(float32) under NumPy's AVX512_SKX dispatch == Intel SVML __svml_atan2f16 (np.angle at

@@ -408,6 +408,10 @@ class Engine:
                                           0 if s1 is None else s1.shape[0], _ptr(bits)))
         return bits
 
+    def np_f32(self, op, d_a, d_b, n, d_out):
+        """NumPy's float32 arctan2 (op 0) / log10 (1) / abs of a + ib (2), element by element (pss_np_f32)."""
+        self._ck(self.lib.pss_np_f32(self.h, int(op), _ptr(d_a), _ptr(d_b), int(n), _ptr(d_out)))
+
     def row_normalise(self, d_x, n_rows, n, d_y):
         self._ck(self.lib.pss_row_normalise(self.h, _ptr(d_x), n_rows, n, _ptr(d_y)))
 

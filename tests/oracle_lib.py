@@ -55,6 +55,8 @@ def lib():
         L.pss_o_classify.argtypes = [_f32p, C.c_long, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float), _f32p]
         L.pss_o_hann1024_f32.argtypes = [_f32p]
         L.pss_o_log10f_np_many.argtypes = [_f32p, _f32p, C.c_long]
+        L.pss_o_atan2f_many.argtypes = [_f32p, _f32p, _f32p, C.c_long]
+        L.pss_o_cabsf_many.argtypes = [_f32p, _f32p, _f32p, C.c_long]
         L.pss_o_hann_f32.argtypes = [_f32p, C.c_int]
         _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
         L.pss_o_morse_edges.restype = None
@@ -91,10 +93,20 @@ def _iq(x):
 
 
 def atan2f(y, x):
-    L = lib()
-    y = np.asarray(y, np.float32)
-    x = np.asarray(x, np.float32)
-    return np.array([L.pss_o_atan2f(float(a), float(b)) for a, b in zip(y, x)], np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(y)
+    lib().pss_o_atan2f_many(y, x, out, y.size)
+    return out
+
+
+def cabsf(re, im):
+    """np.abs(re + 1j im) on complex64, element by element."""
+    re = np.ascontiguousarray(re, np.float32)
+    im = np.ascontiguousarray(im, np.float32)
+    out = np.empty_like(re)
+    lib().pss_o_cabsf_many(re, im, out, re.size)
+    return out
 
 
 def compute_fft(iq):

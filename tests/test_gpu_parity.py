@@ -434,6 +434,36 @@ def test_power(golden, n):
     assert p.tobytes() == np.float32(O.power_db(iq)).tobytes()
 
 
+def test_numpy_float32_primitives(golden):
+    """The device models of NumPy's float32 arctan2 / log10 (SVML under AVX512_SKX) and abs(complex64), element by element
+    against NumPy's own outputs (fixtures) and, on random bit patterns, against the oracle; NaNs compared as NaNs."""
+    e = G.engine()
+
+    def run(op, a, b=None):
+        d_out = G.empty((len(a),), torch.float32)
+        e.np_f32(op, G.dev(np.ascontiguousarray(a)), None if b is None else G.dev(np.ascontiguousarray(b)), len(a), d_out)
+        e.sync()
+        return G.host(d_out)
+
+    def same(got, want):
+        nan = np.isnan(want)
+        return np.array_equal(np.isnan(got), nan) and np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32))
+
+    for name in ("atan2f", "atan2f_bits"):
+        g = golden[name]
+        assert same(run(L.NP_ARCTAN2, g["y"], g["x"]), g["theta"]), name
+    g = golden["log10f"]
+    assert same(run(L.NP_LOG10, g["x"]), g["y"])
+    rng = np.random.default_rng(92)
+    a = rng.integers(0, 2 ** 32, 1 << 20, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    b = rng.integers(0, 2 ** 32, 1 << 20, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    assert same(run(L.NP_ARCTAN2, a, b), O.atan2f(a, b))
+    assert same(run(L.NP_LOG10, a), O.log10f(a))
+    assert same(run(L.NP_ABS, a, b), O.cabsf(a, b))
+    with pytest.raises(Exception):
+        run(7, a, b)
+
+
 def test_power_bits_over_the_float_range():
     # tiny frames with magnitudes all over the float32 range (down to denormal powers, up to overflow): the float32 log10
     # model must agree with the oracle's (which is pinned to NumPy's outputs) in every bit, -inf / inf / NaN included

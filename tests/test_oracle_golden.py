@@ -20,6 +20,11 @@ def test_atan2f_bit_exact(golden):
     mine = O.atan2f(y, x)
     same = (bits32(mine) == bits32(th)) | (np.isnan(mine) & np.isnan(th))
     assert same.all(), f"{(~same).sum()} of {len(same)} differ"
+    # operands as random bit patterns (all exponents, denormals, inf, NaN): the library's special-value path
+    g = golden["atan2f_bits"]
+    mine = O.atan2f(g["y"], g["x"])
+    same = (bits32(mine) == bits32(g["theta"])) | (np.isnan(mine) & np.isnan(g["theta"]))
+    assert same.all(), f"{(~same).sum()} of {len(same)} differ"
 
 
 def test_rcp14_model_properties():

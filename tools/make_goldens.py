@@ -133,6 +133,21 @@ def gen_atan2():
     save("atan2f", y=y, x=x, theta=th, n_random=np.array(n))
 
 
+def gen_atan2f_bits():
+    """np.arctan2 float32 on operands drawn as RANDOM BIT PATTERNS (every exponent, denormals, infinities, NaNs): pins the
+    special-value path of the library routine, which gen_atan2's mostly well-scaled operands reach only through its 15 x 15 grid."""
+    rng = np.random.default_rng(505)
+    n = 20000
+    y = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    x = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    sp_ = np.float32([0.0, -0.0, np.inf, -np.inf, 1e-45, -1e-45, 1e-38, 3e38, -3e38, 1.0, -1.0, 1e-20, 1e20])
+    y = np.concatenate([y, rng.choice(sp_, 4000), rng.integers(0, 2 ** 32, 4000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    x = np.concatenate([x, rng.integers(0, 2 ** 32, 4000, dtype=np.uint64).astype(np.uint32).view(np.float32), rng.choice(sp_, 4000)])
+    with np.errstate(all="ignore"):
+        th = np.arctan2(y, x)
+    save("atan2f_bits", y=y, x=x, theta=th)
+
+
 def gen_spectrum():
     d = {}
     for n, fs, nf, seed in [(1024, 2.4e6, 4, 11), (2048, 10e6, 2, 12), (4096, 2.4e6, 2, 13),
@@ -766,7 +781,7 @@ def gen_caller():
 
 
 if __name__ == "__main__":
-    gens = [gen_atan2, gen_spectrum, gen_nfm, gen_am_ssb, gen_power, gen_iqcorr, gen_wfm, gen_bandpass, gen_afsk, gen_classify, gen_classify_short, gen_log10f,
+    gens = [gen_atan2, gen_atan2f_bits, gen_spectrum, gen_nfm, gen_am_ssb, gen_power, gen_iqcorr, gen_wfm, gen_bandpass, gen_afsk, gen_classify, gen_classify_short, gen_log10f,
             gen_decoders, gen_scanner, gen_caller]
     want = sys.argv[1:]                      # e.g. `python tools/make_goldens.py decoders` regenerates one fixture
     for g in gens:
