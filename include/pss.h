@@ -56,6 +56,8 @@ int pss_device_count(void);
  *   "ssb_hilbert" (1)          0: demodulate_ssb skips the reference's hilbert() FFT round trip (the identity on the real part it
  *                              keeps, up to ~1e-16); 1: executed for power-of-two frames of 256..16384 samples
  *   "fuse_post" (0)            1: pss_spectrum_db_post takes the fused spectrum + post-process kernel for 1024-point frames
+ *   "pipe_overlap" (1)         0: pss_frame_pipeline_nfm starts its display chain only after the NFM forward kernel (the earlier
+ *                              schedule); 1: on the side stream from the start
  *   "post_legacy" (0)          1: the post-process takes the LDS bitonic sort / LDS-histogram radix select kernels instead of
  *                              the register-resident binary-search select;  "post_sort_max" (8192): longest row the legacy
  *                              path sorts (longer rows: radix select)
@@ -67,7 +69,7 @@ int pss_device_count(void);
  *   "fir_mfma" (0)             1: the NFM forward kernel runs its 65-tap FIR as a Toeplitz product on the matrix pipe
  *                              (v_mfma_f64_16x16x4_f64): another summation order than the reference's OpenBLAS ddot, so the float64
  *                              audio differs in the last bits (~1e-16 relative); int16 PCM differs only where a sample lies
- *                              within ~3e-11 of an integer boundary.  Faster (the VALU keeps only discriminator + IIR). */
+ *                              within ~3e-11 of an integer boundary.  Faster (0.60 against 0.71 ms at cfg 2: the VALU keeps only discriminator + IIR). */
 int pss_set_option(pss_ctx *ctx, const char *key, int value);
 
 /* ---- filter design (host side, pure C++; replaces the per-call SciPy design work) -------------- */
@@ -174,7 +176,7 @@ int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, doub
  * NFM demod -> d_pcm; compute_fft -> d_db [n_frames][n]; post-process -> d_post [n_frames][n-4] and the row extremes
  * (d_row_lo / d_row_hi: [n_halo + n_frames], the first n_halo entries supplied by the caller as for pss_waterfall_rows);
  * waterfall line per frame -> d_glyph / d_colour [n_frames][disp_w].  The same results as the separate calls; the display
- * chain runs beside the demodulator's backward pass. */
+ * chain (which needs only the IQ) runs on a side stream beside the demodulator and is joined before the call returns. */
 int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
                            float *d_row_lo, float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
                            int8_t *d_colour, int16_t *d_pcm);

@@ -2926,10 +2926,33 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
     PSS_GUARD(ctx);
     if (n_frames > 0 && (!d_db || !d_post || !d_row_lo || !d_row_hi || !d_glyph || !d_colour || !d_pcm))
         return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_nfm: null buffer");
-    // Schedule: forward kernel (VALU-bound, fills the machine) -> spectrum (HBM-bound, alone: 0.17 ms at cfg 2) ->
-    // { backward pass (latency-bound, one wavefront per SIMD)  ||  post-process (VALU-bound) -> display lines }.
-    // Running the spectrum beside the backward pass instead (round 1) made the two fight for HBM: 0.30 ms.
     pss_time_begin(ctx);
+    if (ctx->pipe_overlap) {
+        // Default schedule (round 2): the display chain needs only the IQ, so it goes to the side stream at once —
+        //   main: forward kernel -> backward pass        side: spectrum -> post-process -> display lines
+        // The forward kernel fills every CU by itself (4 workgroups x 37.6 KB LDS, 4 x 124 VGPRs per SIMD), so the spectrum
+        // mostly runs in its wake; what is gained is that nothing waits for anything it does not need (1.18 -> 1.10 ms at
+        // cfg 2, every shape measured gains 3-13 %).  Measured and rejected: capping the forward kernel at 3 or 2 workgroups
+        // per CU to leave room for the chain (forward 0.64 -> 0.80 / 0.83 ms, step 1.17 / 1.35 ms), the chain enqueued
+        // first (1.27 ms), and two fully decoupled streams without a join per step (1.15 ms).
+        int r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
+        if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
+        if (r) { pss_time_end(ctx); return r; }
+        const int rn = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
+        int rd;
+        {
+            PssStreamScope side(ctx->cur, ctx->stream2);
+            rd = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+            if (!rd) rd = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+            if (!rd) rd = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+        }
+        // joined whatever happened above: the main stream must not run ahead of work already queued on the side stream
+        int rj = pss_hip_check(ctx, hipEventRecord(ctx->ev_join, ctx->stream2), "hipEventRecord(join)");
+        if (!rj) rj = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)");
+        pss_time_end(ctx);
+        return rn ? rn : (rd ? rd : rj);
+    }
+    // pipe_overlap = 0, the earlier schedule: forward kernel -> spectrum alone -> { backward pass || post-process -> display lines }
     int r2;
     ctx->pending_bwd = nullptr;
     {
