@@ -144,5 +144,6 @@ void pss_kernel_end(pss_ctx *ctx);
 
 // implemented in pss_fft.hip
 bool pss_hilbert_supported(int n);
-int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits);
+int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits,
+                     int16_t *d_pcm);
 int pss_fft_tables(pss_ctx *ctx, int n, const double2 **tw, const double **win);

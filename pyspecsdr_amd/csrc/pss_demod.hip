@@ -2427,9 +2427,11 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         // real part up to the transforms' rounding (~1e-16), so skipping it (option "ssb_hilbert" = 0, and every other
         // frame length) changes no int16 sample
         if (ctx->ssb_hilbert && pss_hilbert_supported(n)) {
-            PSS_HIP(ctx, hipMemsetAsync(mxb, 0, (size_t)n_frames * sizeof(double), PSS_STREAM(ctx)));
-            r = pss_hilbert_rows(ctx, Yf, n_frames, n, Yf, 1, mxb);
-            if (r) { pss_time_end(ctx); return r; }
+            // ... with the normalisation and the int16 conversion in the same kernel (the frame is in registers when the frame
+            // peak becomes known): no float64 round trip through HBM, no k_finalize pass
+            r = pss_hilbert_rows(ctx, Yf, n_frames, n, d_audio, 2, nullptr, d_pcm);
+            pss_time_end(ctx);
+            return r ? r : pss_hip_check(ctx, hipGetLastError(), "ssb launch");
         }
         size_t tot = (size_t)n_frames * n;
         size_t g2 = (tot + TPB - 1) / TPB;

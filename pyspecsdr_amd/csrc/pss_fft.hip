@@ -992,7 +992,8 @@ bool is_pow2(int n) { return n > 0 && !(n & (n - 1)); }
 // the row's max |real| as a double's bit pattern (atomicMax onto d_maxbits[row]; the caller clears it).
 bool pss_hilbert_supported(int n) { return n >= 256 && n <= 16384 && !(n & (n - 1)); }
 
-int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits)
+int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits,
+                     int16_t *d_pcm)
 {
     if (!pss_hilbert_supported(n)) return pss_fail(ctx, PSS_E_ARG, "pss_hilbert: the row length must be a power of two in [256, 16384]");
     if (n_rows == 0) return PSS_OK;
@@ -1005,7 +1006,7 @@ int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double
             PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         pss_kernel_begin(ctx, "k_hilbert");
         hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(threads), lds, PSS_STREAM(ctx), d_x, d_out, tw, n_rows,
-                           d_maxbits);
+                           d_maxbits, reinterpret_cast<unsigned *>(d_pcm));
         pss_kernel_end(ctx);
         return pss_hip_check(ctx, hipGetLastError(), "k_hilbert launch");
     };
@@ -1016,7 +1017,8 @@ int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double
         int per_cu = (int)((160 * 1024) / (C::LDS + 256));                                                                   \
         if (per_cu > 2) per_cu = 2;                                                                                          \
         return out_mode == 0 ? go(pss_hil::k_hilbert_r16<L, 0>, C::LDS, 256, groups, 256L * per_cu * 2)                      \
-                             : go(pss_hil::k_hilbert_r16<L, 1>, C::LDS, 256, groups, 256L * per_cu * 2);                     \
+             : out_mode == 1 ? go(pss_hil::k_hilbert_r16<L, 1>, C::LDS, 256, groups, 256L * per_cu * 2)                      \
+                             : go(pss_hil::k_hilbert_r16<L, 2>, C::LDS, 256, groups, 256L * per_cu * 2);                     \
     }
     switch (n) {
     case 256: HIL_R16(0)
@@ -1026,10 +1028,12 @@ int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double
     case 4096: HIL_R16(4)
     case 8192:
         return out_mode == 0 ? go(pss_hil::k_hilbert_xl<1, 0>, pss_xl::CfgX<1>::LDS, 512, n_rows, 512)
-                             : go(pss_hil::k_hilbert_xl<1, 1>, pss_xl::CfgX<1>::LDS, 512, n_rows, 512);
+             : out_mode == 1 ? go(pss_hil::k_hilbert_xl<1, 1>, pss_xl::CfgX<1>::LDS, 512, n_rows, 512)
+                             : go(pss_hil::k_hilbert_xl<1, 2>, pss_xl::CfgX<1>::LDS, 512, n_rows, 512);
     default:
         return out_mode == 0 ? go(pss_hil::k_hilbert_xl<2, 0>, pss_xl::CfgX<2>::LDS, 1024, n_rows, 256)
-                             : go(pss_hil::k_hilbert_xl<2, 1>, pss_xl::CfgX<2>::LDS, 1024, n_rows, 256);
+             : out_mode == 1 ? go(pss_hil::k_hilbert_xl<2, 1>, pss_xl::CfgX<2>::LDS, 1024, n_rows, 256)
+                             : go(pss_hil::k_hilbert_xl<2, 2>, pss_xl::CfgX<2>::LDS, 1024, n_rows, 256);
     }
 #undef HIL_R16
 }
@@ -1040,7 +1044,7 @@ extern "C" int pss_hilbert(pss_ctx *ctx, const double *d_x, long n_rows, int n, 
     PSS_GUARD(ctx);
     if (n_rows < 0 || (n_rows > 0 && (!d_x || !d_analytic))) return pss_fail(ctx, PSS_E_ARG, "pss_hilbert: bad argument");
     pss_time_begin(ctx);
-    const int r = pss_hilbert_rows(ctx, d_x, n_rows, n, d_analytic, 0, nullptr);
+    const int r = pss_hilbert_rows(ctx, d_x, n_rows, n, d_analytic, 0, nullptr, nullptr);
     pss_time_end(ctx);
     return r;
 }

@@ -32,11 +32,28 @@ __device__ __forceinline__ void track_max(double m, unsigned long long *mx)
     if ((threadIdx.x & 63) == 0) atomicMax(mx, (unsigned long long)__double_as_longlong(m));
 }
 
-// N = 256 * R3 (R3 = 1..16).  OUT: 0 = complex128 analytic signal to `out`, 1 = real part only (in place allowed) + frame peak
+// np.int16(v * 32767) (io_manager.py:26), as pss_device.h pcm16 (that header's __constant__ tables keep it out of this unit)
+__device__ __forceinline__ unsigned pcm_pair(double a)
+{
+    const double v = __dmul_rn(a, 32767.0);
+    const unsigned s = (unsigned)(unsigned short)((v != v) ? (short)0 : (short)(int)v);
+    return s | (s << 16);                                   // mono_to_stereo: left = right
+}
+
+// NaN-propagating maximum (np.max) of non-negative values
+__device__ __forceinline__ double nanmax(double a, double b) { return (b != b || b > a) ? b : a; }
+
+// OUT = 2 tail, shared by both kernels: samples / np.max(np.abs(samples)) * 0.95 (signal_processing.py:213-216) with the frame
+// peak mx, float64 audio (optional) and int16 stereo PCM
+__device__ __forceinline__ double normalise95(double re, double mx) { return __dmul_rn(__ddiv_rn(re, mx), 0.95); }
+
+// N = 256 * R3 (R3 = 1..16).  OUT: 0 = complex128 analytic signal to `out`, 1 = real part only (in place allowed) + frame peak,
+// 2 = demodulate_ssb's tail in the same kernel: real part / frame peak * 0.95 -> `out` (float64 audio, may be NULL) and `pcm`
 template <int LOG_R3, int OUT>
 __global__ __launch_bounds__(256) void k_hilbert_r16(const double *x, double *out, const double2 *__restrict__ tw,
-                                                     long n_rows, unsigned long long *__restrict__ mxbits)
+                                                     long n_rows, unsigned long long *__restrict__ mxbits, unsigned *__restrict__ pcm)
 {
+    __shared__ double red[2][4];             // OUT = 2: wave maxima, double-buffered by loop parity
     using C = pss_r16::Cfg<LOG_R3>;
     constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = C::FPW;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -69,19 +86,39 @@ __global__ __launch_bounds__(256) void k_hilbert_r16(const double *x, double *ou
         pss_r16::r16_core<LOG_R3, WL>(v, ex, tw1, tw2, t, [&](int i, int, double2 W) {
             const int q = (i / R3) + (16 / R3) * (i % R3);
             const double re = W.x * INV_N, im = -(W.y * INV_N);      // conj(fft(conj(Z))) / N
-            if (valid) {
+            if (OUT == 2) y[q].x = re;
+            else if (valid) {
                 if (OUT == 0) reinterpret_cast<double2 *>(out)[(size_t)f * N + t + T * q] = make_double2(re, im);
                 else out[(size_t)f * N + t + T * q] = re;
             }
-            const double a = fabs(re);
-            m = (a != a || a > m) ? a : m;
+            m = nanmax(m, fabs(re));
         });
         if (OUT == 1 && mxbits) {
             // the T threads of a frame: T >= 64 whole wavefronts, T < 64 a slice of one (reduce over the slice only)
             if (T >= 64) { if (valid) track_max(m, &mxbits[f]); }
             else {
-                for (int off = T / 2; off > 0; off >>= 1) { const double o = __shfl_xor(m, off); m = (o != o || o > m) ? o : m; }
+                for (int off = T / 2; off > 0; off >>= 1) m = nanmax(m, __shfl_xor(m, off));
                 if (valid && t == 0) atomicMax(&mxbits[f], (unsigned long long)__double_as_longlong(m));
+            }
+        }
+        if (OUT == 2) {
+            // frame peak: over the frame's T lanes — a slice of one wavefront, or T / 64 whole wavefronts through LDS
+            for (int off = (T < 64 ? T : 64) / 2; off > 0; off >>= 1) m = nanmax(m, __shfl_xor(m, off));
+            if (T > 64) {
+                const int par = (int)(((g - blockIdx.x) / gridDim.x) & 1);
+                if ((tid & 63) == 0) red[par][tid >> 6] = m;
+                __syncthreads();
+                m = red[par][fl * (T / 64)];
+#pragma unroll
+                for (int w = 1; w < T / 64; w++) m = nanmax(m, red[par][fl * (T / 64) + w]);
+            }
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const double a = normalise95(y[q].x, m);
+                    if (out) out[(size_t)f * N + t + T * q] = a;
+                    if (pcm) pcm[(size_t)f * N + t + T * q] = pcm_pair(a);
+                }
             }
         }
         pss_r16::frame_sync<WL>();
@@ -92,8 +129,9 @@ __global__ __launch_bounds__(256) void k_hilbert_r16(const double *x, double *ou
 template <int LOG_R4, int OUT>
 __global__ __launch_bounds__(256 << LOG_R4, 4) void k_hilbert_xl(const double *x, double *out,
                                                                  const double2 *__restrict__ tw, long n_rows,
-                                                                 unsigned long long *__restrict__ mxbits)
+                                                                 unsigned long long *__restrict__ mxbits, unsigned *__restrict__ pcm)
 {
+    __shared__ double red[2][16];            // OUT = 2: wave maxima, double-buffered by loop parity
     using C = pss_xl::CfgX<LOG_R4>;
     constexpr int T = C::T, N = C::N, T2 = C::T2, R4 = C::R4;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -103,7 +141,8 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_hilbert_xl(const double *x
     constexpr double INV_N = 1.0 / (double)N;
     for (long f = blockIdx.x; f < n_rows; f += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rx = pss_xl::make_rsrc(x + (size_t)f * N, N * 8);
-        const __amdgpu_buffer_rsrc_t ro = pss_xl::make_rsrc(out + (size_t)f * N * (OUT == 0 ? 2 : 1), N * (OUT == 0 ? 16 : 8));
+        const __amdgpu_buffer_rsrc_t ro = pss_xl::make_rsrc(out + (out ? (size_t)f * N * (OUT == 0 ? 2 : 1) : 0), out ? N * (OUT == 0 ? 16 : 8) : 0);
+        const __amdgpu_buffer_rsrc_t rp = pss_xl::make_rsrc(pcm + (pcm ? (size_t)f * N : 0), (OUT == 2 && pcm) ? N * 4 : 0);
         double2 u1 = w1, u2 = w2, u3 = w3;
         asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
         double2 v[16], y[16];
@@ -124,13 +163,31 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_hilbert_xl(const double *x
                 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
                 v4u_t pk = {lo, hi, li, hj};
                 __builtin_amdgcn_raw_buffer_store_b128(pk, ro, t * 16, T * q * 16, 0);
-            } else {
+            } else if (OUT == 1) {
                 pss_xl::v2u_t pk = {(unsigned)__double2loint(re), (unsigned)__double2hiint(re)};
                 __builtin_amdgcn_raw_buffer_store_b64(pk, ro, t * 8, T * q * 8, 0);
+            } else {
+                y[q].x = re;
             }
-            const double a = fabs(re);
-            m = (a != a || a > m) ? a : m;
+            m = nanmax(m, fabs(re));
         });
+        if (OUT == 2) {
+            // frame peak over the workgroup (= the frame), then demodulate_ssb's normalisation and the int16 conversion from registers
+            for (int off = 32; off > 0; off >>= 1) m = nanmax(m, __shfl_xor(m, off));
+            const int par = (int)(((f - blockIdx.x) / gridDim.x) & 1);
+            if ((t & 63) == 0) red[par][t >> 6] = m;
+            __syncthreads();
+            m = red[par][0];
+#pragma unroll
+            for (int w = 1; w < T / 64; w++) m = nanmax(m, red[par][w]);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const double a = normalise95(y[q].x, m);
+                pss_xl::v2u_t pk = {(unsigned)__double2loint(a), (unsigned)__double2hiint(a)};
+                __builtin_amdgcn_raw_buffer_store_b64(pk, ro, t * 8, T * q * 8, 0);       // out == NULL: zero-sized resource, dropped
+                __builtin_amdgcn_raw_buffer_store_b32(pcm_pair(a), rp, t * 4, T * q * 4, 0);
+            }
+        }
         if (OUT == 1 && mxbits) track_max(m, &mxbits[f]);
     }
 }
