@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--exchange", choices=["display", "db", "none"], default="display",
                     help="what is gathered to rank 0 inside the timed region when N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the untimed side measurements (standalone kernels, the 30-row reading, exchange alone): under a profiler "
+                         "every launch then belongs to a step of the default schedule")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,11 +225,7 @@ def main():
         compute(k & 1)
     fence()
     ktimes = {k: sum(v) / len(v) for k, v in eng.kernel_times().items()}
-    # The display chain runs on the library's side stream beside the demodulator (pss_frame_pipeline_nfm): its kernels' bracketed
-    # durations include the time their workgroups queue behind the forward kernel's, so the dominant kernel is chosen among
-    # the main stream's (the demodulator), which are the step's critical path.
-    main_stream = [k for k in ktimes if k.startswith("k_nfm_")] or list(ktimes)
-    dom = max(main_stream, key=ktimes.get)
+    dom = max(ktimes, key=ktimes.get)
     eng.timing_filter(dom)
     fence()
     # timed region: exactly K steps (compute + exchange), barrier + synchronize on both sides
@@ -250,50 +249,51 @@ def main():
         fence()
         return (time.perf_counter() - t) / reps * 1e3
 
-    side = {}
-    # each HBM-bound kernel alone (inside a step the spectrum kernel shares the machine with the backward IIR pass)
-    eng.enable_timing(True)
-    for _ in range(2):
-        eng.spectrum_db(iq, nf, n, d_db[0])
-    eng.sync(); eng.kernel_times()
-    for _ in range(5):
-        eng.spectrum_db(iq, nf, n, d_db[0])
-    eng.sync()
-    spec_alone = eng.kernel_times().get("k_spectrum", [])
-    for _ in range(5):      # likewise the post-process kernel (inside a step it runs beside the backward IIR pass)
-        eng.spectrum_post_extremes(d_db[0], nf, n, d_post, d_lo, d_hi)
-    eng.sync()
-    post_alone = eng.kernel_times().get("k_post", [])
-    for _ in range(5):      # and the demodulator with nothing beside it
-        eng.demod(0, iq, nf, n, FS, packed[0].data_ptr() + o_pcm, None)
-    eng.sync()
-    dom_alone = eng.kernel_times().get(dom, [])
-    eng.enable_timing(False)
-    # round-1 reading of "waterfall": post-process + cell grid of the newest 30 rows only (a display's last state)
-    WF = min(30, nf)
-    d_g30 = torch.empty((36, DISP_W), dtype=torch.int8, device=dev)
-    d_c30 = torch.empty((36, DISP_W), dtype=torch.int8, device=dev)
+    side, spec_alone, post_alone, dom_alone = {}, [], [], []
+    if not args.no_side:
+        # each HBM-bound kernel alone (inside a step the post-process runs beside the backward IIR pass)
+        eng.enable_timing(True)
+        for _ in range(2):
+            eng.spectrum_db(iq, nf, n, d_db[0])
+        eng.sync(); eng.kernel_times()
+        for _ in range(5):
+            eng.spectrum_db(iq, nf, n, d_db[0])
+        eng.sync()
+        spec_alone = eng.kernel_times().get("k_spectrum", [])
+        for _ in range(5):      # likewise the post-process kernel
+            eng.spectrum_post_extremes(d_db[0], nf, n, d_post, d_lo, d_hi)
+        eng.sync()
+        post_alone = eng.kernel_times().get("k_post", [])
+        for _ in range(5):      # and the demodulator with nothing beside it
+            eng.demod(0, iq, nf, n, FS, packed[0].data_ptr() + o_pcm, None)
+        eng.sync()
+        dom_alone = eng.kernel_times().get(dom, [])
+        eng.enable_timing(False)
+        # round-1 reading of "waterfall": post-process + cell grid of the newest 30 rows only (a display's last state)
+        WF = min(30, nf)
+        d_g30 = torch.empty((36, DISP_W), dtype=torch.int8, device=dev)
+        d_c30 = torch.empty((36, DISP_W), dtype=torch.int8, device=dev)
 
-    def step30():
-        eng.spectrum_nfm(iq, nf, n, FS, d_db[0], packed[0].data_ptr() + o_pcm)
-        eng.spectrum_post(d_db[0][nf - WF:], WF, n, d_post)
-        eng.waterfall_cells(d_post, WF, m, 36, DISP_W, d_g30, d_c30)
-    side["ms_per_step_newest_30_rows_only"] = timed(step30)
-    if exch != "none":
-        # compute alone, and the exchange alone (both variants), so that overlap can be read off
-        side["compute_ms"] = timed(lambda: compute(0))
-        comm_db = torch.cuda.Stream(device=dev)
+        def step30():
+            eng.spectrum_nfm(iq, nf, n, FS, d_db[0], packed[0].data_ptr() + o_pcm)
+            eng.spectrum_post(d_db[0][nf - WF:], WF, n, d_post)
+            eng.waterfall_cells(d_post, WF, m, 36, DISP_W, d_g30, d_c30)
+        side["ms_per_step_newest_30_rows_only"] = timed(step30)
+        if exch != "none":
+            # compute alone, and the exchange alone (both variants), so that overlap can be read off
+            side["compute_ms"] = timed(lambda: compute(0))
+            comm_db = torch.cuda.Stream(device=dev)
 
-        def xfer(src, per):
-            buf = torch.empty((world, per), dtype=torch.uint8, device=dev) if rank == 0 else None
-            def go():
-                with torch.cuda.stream(comm_db):
-                    dist.gather(src, list(buf.unbind(0)) if rank == 0 else None, dst=0)
-            return timed(go, 3)
-        side["exchange_display_ms"] = xfer(packed[0], set_bytes)
-        side["exchange_display_bytes_per_rank"] = set_bytes
-        side["exchange_db_ms"] = xfer(d_db[0].view(torch.uint8).view(-1), nf * n * 4)
-        side["exchange_db_bytes_per_rank"] = nf * n * 4
+            def xfer(src, per):
+                buf = torch.empty((world, per), dtype=torch.uint8, device=dev) if rank == 0 else None
+                def go():
+                    with torch.cuda.stream(comm_db):
+                        dist.gather(src, list(buf.unbind(0)) if rank == 0 else None, dst=0)
+                return timed(go, 3)
+            side["exchange_display_ms"] = xfer(packed[0], set_bytes)
+            side["exchange_display_bytes_per_rank"] = set_bytes
+            side["exchange_db_ms"] = xfer(d_db[0].view(torch.uint8).view(-1), nf * n * 4)
+            side["exchange_db_bytes_per_rank"] = nf * n * 4
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -316,7 +316,7 @@ def main():
             ams = sum(dom_alone) / len(dom_alone)
             aa = ALGO_BYTES.get(dom, ALGO_BYTES["path"]) * nf / (ams * 1e-3) / 1e9
             roof["standalone"] = {"ms": round(ams, 4), "achieved": aa, "frac": aa / HBM_PEAK_GBS,
-                                  "note": "the same kernel with nothing beside it (inside a step the display chain's workgroups share the CUs)"}
+                                  "note": "the same kernel in a plain demodulate call (no spectrum / display work queued around it)"}
             if dom == "k_nfm_fwd":
                 roof["standalone"]["f64_issue_frac"] = NFM_FWD_F64_OPS_PER_SAMPLE * float(nf) * n / (ams * 1e-3) / F64_PEAK_LANEOPS
         if dom == "k_nfm_fwd":

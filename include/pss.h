@@ -56,8 +56,9 @@ int pss_device_count(void);
  *   "ssb_hilbert" (1)          0: demodulate_ssb skips the reference's hilbert() FFT round trip (the identity on the real part it
  *                              keeps, up to ~1e-16); 1: executed for power-of-two frames of 256..16384 samples
  *   "fuse_post" (0)            1: pss_spectrum_db_post takes the fused spectrum + post-process kernel for 1024-point frames
- *   "pipe_overlap" (1)         0: pss_frame_pipeline_nfm starts its display chain only after the NFM forward kernel (the earlier
- *                              schedule); 1: on the side stream from the start
+ *   "pipe_overlap" (0)         schedule of pss_frame_pipeline_nfm.  0: forward kernel -> spectrum -> {backward pass || post-process ->
+ *                              lines}; 1: the whole display chain on the side stream from the start (6 % faster when the forward
+ *                              kernel reaches the dispatcher first, slower when it does not); 2: fork right after the forward kernel
  *   "post_legacy" (0)          1: the post-process takes the LDS bitonic sort / LDS-histogram radix select kernels instead of
  *                              the register-resident binary-search select;  "post_sort_max" (8192): longest row the legacy
  *                              path sorts (longer rows: radix select)
@@ -175,8 +176,8 @@ int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, doub
 /* One iteration of the reference's main loop (pyspecsdr.py:2262-2283 and the waterfall draw) for a batch of read buffers:
  * NFM demod -> d_pcm; compute_fft -> d_db [n_frames][n]; post-process -> d_post [n_frames][n-4] and the row extremes
  * (d_row_lo / d_row_hi: [n_halo + n_frames], the first n_halo entries supplied by the caller as for pss_waterfall_rows);
- * waterfall line per frame -> d_glyph / d_colour [n_frames][disp_w].  The same results as the separate calls; the display
- * chain (which needs only the IQ) runs on a side stream beside the demodulator and is joined before the call returns. */
+ * waterfall line per frame -> d_glyph / d_colour [n_frames][disp_w].  The same results as the separate calls; part of the
+ * display chain runs on a side stream beside the demodulator's backward pass and is joined before the call returns. */
 int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
                            float *d_row_lo, float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
                            int8_t *d_colour, int16_t *d_pcm);

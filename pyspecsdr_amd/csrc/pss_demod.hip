@@ -2929,14 +2929,15 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
     if (n_frames > 0 && (!d_db || !d_post || !d_row_lo || !d_row_hi || !d_glyph || !d_colour || !d_pcm))
         return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_nfm: null buffer");
     pss_time_begin(ctx);
-    if (ctx->pipe_overlap) {
-        // Default schedule (round 2): the display chain needs only the IQ, so it goes to the side stream at once —
+    if (ctx->pipe_overlap_mode == 1) {
+        // Opt-in schedule: the display chain needs only the IQ, so it goes to the side stream at once —
         //   main: forward kernel -> backward pass        side: spectrum -> post-process -> display lines
-        // The forward kernel fills every CU by itself (4 workgroups x 37.6 KB LDS, 4 x 124 VGPRs per SIMD), so the spectrum
-        // mostly runs in its wake; what is gained is that nothing waits for anything it does not need (1.18 -> 1.10 ms at
-        // cfg 2, every shape measured gains 3-13 %).  Measured and rejected: capping the forward kernel at 3 or 2 workgroups
-        // per CU to leave room for the chain (forward 0.64 -> 0.80 / 0.83 ms, step 1.17 / 1.35 ms), the chain enqueued
-        // first (1.27 ms), and two fully decoupled streams without a join per step (1.15 ms).
+        // 1.11 ms per step at cfg 2 against 1.18 ms WHEN the forward kernel's workgroups reach the dispatcher first (it then
+        // fills every CU — 4 workgroups x 37.6 KB LDS, 4 x 124 VGPRs per SIMD — and the chain runs in its wake, beside the
+        // backward pass).  When the spectrum wins that race (an event packet in front of the forward kernel is enough: bench.py's
+        // own bracketing) its persistent workgroups hold half of every CU for their whole life and the step takes 1.19-1.26 ms:
+        // not the default.  Also measured and rejected: capping the forward kernel at 3 / 2 workgroups per CU to make room
+        // (forward 0.64 -> 0.80 / 0.83 ms, step 1.17 / 1.35 ms), two fully decoupled streams with no join per step (1.15 ms).
         int r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
         if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
         if (r) { pss_time_end(ctx); return r; }
@@ -2954,7 +2955,9 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
         pss_time_end(ctx);
         return rn ? rn : (rd ? rd : rj);
     }
-    // pipe_overlap = 0, the earlier schedule: forward kernel -> spectrum alone -> { backward pass || post-process -> display lines }
+    // Default schedule: forward kernel (VALU-bound, fills the machine) -> spectrum (HBM-bound, alone: 0.17 ms at cfg 2) ->
+    // { backward pass (latency-bound, one wavefront per SIMD)  ||  post-process -> display lines }.
+    // pipe_overlap = 2 forks one kernel earlier ({ backward pass || spectrum -> post-process -> lines }: 1.19 ms against 1.18).
     int r2;
     ctx->pending_bwd = nullptr;
     {
@@ -2962,9 +2965,11 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
         r2 = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
     }
     int r = r2;
-    if (!r) r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+    const bool spectrum_beside_bwd = ctx->pipe_overlap_mode == 2 && ctx->pending_bwd;
+    if (!r && !spectrum_beside_bwd) r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
     auto display_chain = [&]() -> int {
-        int q = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+        int q = spectrum_beside_bwd ? pss_spectrum_db(ctx, d_iq, n_frames, n, d_db) : PSS_OK;
+        if (!q) q = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
         if (!q) q = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
         return q;
     };

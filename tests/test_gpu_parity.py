@@ -1351,7 +1351,7 @@ def test_streamed_display_equals_resident_pipeline():
 
 def test_frame_pipeline_equals_separate_calls():
     """pss_frame_pipeline_nfm (what bench.py times: one main-loop iteration per frame of the batch, display chain on a side
-    stream beside the demodulator) against the separate entry points, byte for byte, under both schedules."""
+    stream beside the demodulator's backward pass) against the separate entry points, byte for byte, under every schedule."""
     e = G.engine()
     gen = torch.Generator(device="cuda").manual_seed(77)
     for nf, n, fs in ((9000, 1024, 2.4e6), (300, 2048, 10e6)):
@@ -1370,15 +1370,16 @@ def test_frame_pipeline_equals_separate_calls():
         e.sync()
         for k in a:
             assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k)
-        a2 = bufs()                               # the earlier schedule (display chain after the forward kernel)
-        e.set_option("pipe_overlap", 0)
-        try:
-            e.frame_pipeline_nfm(iq, nf, n, fs, a2["db"], a2["post"], a2["lo"], a2["hi"], 112, a2["g"], a2["c"], a2["pcm"])
-        finally:
-            e.set_option("pipe_overlap", 1)
-        e.sync()
-        for k in a:
-            assert torch.equal(a2[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k)
+        for sched in (1, 2):                      # the opt-in schedules (display chain forked earlier)
+            a2 = bufs()
+            e.set_option("pipe_overlap", sched)
+            try:
+                e.frame_pipeline_nfm(iq, nf, n, fs, a2["db"], a2["post"], a2["lo"], a2["hi"], 112, a2["g"], a2["c"], a2["pcm"])
+            finally:
+                e.set_option("pipe_overlap", 0)
+            e.sync()
+            for k in a:
+                assert torch.equal(a2[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k, sched)
         # the fused spectrum + post-process kernel (1024-point frames) against the two separate kernels
         c = bufs()
         e.spectrum_db_post(iq, nf, n, c["db"], c["post"], c["lo"], c["hi"])

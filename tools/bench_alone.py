@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Standalone launches of the HBM-bound kernels of the bench step at BASELINE cfg-2 size (and the big-N spectrum at cfg 3),
+"""Standalone launches of the kernels of the bench step at BASELINE cfg-2 size (and the big-N spectrum at cfg 3),
 each alone on the machine, on the dB rows / IQ the step itself would see: algorithmic bytes / mean launch time (HIP events).
 Run under rocprofv3 by tools/prof_round.sh; prints one "alone:" line per kernel."""
 import os
@@ -41,7 +41,11 @@ run("k_spectrum_r16 65536 x 1024 (FM IQ)", lambda: e.spectrum_db(iq, nf, n, db),
 run("k_post_sel 65536 x 1024 (the FM spectra)", lambda: e.spectrum_post_extremes(db, nf, n, post, lo, hi), "k_post", nf * bench.ALGO_BYTES["k_post"])
 run("k_disp_rows 65536 x 1020 -> 112 cells", lambda: e.waterfall_rows(post, nf, n - 4, lo, hi, bench.DISP_W, g, c), "k_disp_rows",
     nf * bench.ALGO_BYTES["k_disp_rows"])
-del iq, db, post
+n_out = e.demod_out_len(0, n, bench.FS)
+pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
+run("k_nfm_fwd 65536 x 1024 (demodulator alone)", lambda: e.demod(0, iq, nf, n, bench.FS, pcm, None), "k_nfm_fwd", nf * bench.ALGO_BYTES["k_nfm_fwd"])
+run("k_nfm_bwd 65536 x 1024 (demodulator alone)", lambda: e.demod(0, iq, nf, n, bench.FS, pcm, None), "k_nfm_bwd", nf * 8616)   # y_fwd read back
+del iq, db, post, pcm
 for n2, f2 in ((16384, 8192), (8192, 16384), (4096, 32768), (2048, 32768)):
     x = torch.randn((f2, n2, 2), device=dev) * 0.1
     d = torch.empty((f2, n2), dtype=torch.float32, device=dev)

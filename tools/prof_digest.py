@@ -41,7 +41,7 @@ def git_head():
 lines = [f"== profile {tag}: source hash {source_hash()} (sha256 over pyspecsdr_amd/csrc), git {git_head()}"]
 p = os.path.join(out, "kt_kernel_stats.csv")
 if os.path.exists(p):
-    lines.append("== rocprofv3 --kernel-trace --stats : python bench.py --steps 10 --warmup 2 --no-cpu-baseline")
+    lines.append("== rocprofv3 --kernel-trace --stats : python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side")
     lines.append(f"{'kernel':28s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>7s}")
     rows = list(csv.DictReader(open(p)))
     with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
@@ -122,7 +122,7 @@ for name in ("sqa", "sqb"):
         n = kname(r["Kernel_Name"])
         if n:
             sq[(n, int(float(r["Grid_Size"])))][r["Counter_Name"]].append(float(r["Counter_Value"]))
-sq_lines = [f"== SQ counters per launch (mean over dispatches), python bench.py --steps 2 --warmup 1; source hash {source_hash()}"]
+sq_lines = [f"== SQ counters per launch (mean over dispatches), python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side; source hash {source_hash()}"]
 seen = {}
 for (n, g), d in sorted(sq.items()):
     v = {k: sum(x) / len(x) for k, x in d.items()}

@@ -11,6 +11,6 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT" -o write -- $CMD > "$OUT/write.log" 2>&1
 python tools/prof_digest.py "$OUT" "$TAG" > /dev/null
-sed -i "s#python bench.py --steps 10 --warmup 2 --no-cpu-baseline#$CMD#" "$OUT/${TAG}_summary.txt"
+sed -i "s#python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side#$CMD#" "$OUT/${TAG}_summary.txt"
 grep '^{"config"' "$OUT/kt.log" >> "$OUT/${TAG}_summary.txt"
 cat "$OUT/${TAG}_summary.txt"

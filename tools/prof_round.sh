@@ -11,8 +11,8 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline"
-SHORT="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side"
+SHORT="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt -- $CMD > "$OUT/kt.log" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT" -o write -- $CMD > "$OUT/write.log" 2>&1
@@ -20,6 +20,6 @@ timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
     --kernel-trace --output-format csv -d "$OUT" -o sqa -- $SHORT > "$OUT/sqa.log" 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
     --kernel-trace --output-format csv -d "$OUT" -o sqb -- $SHORT > "$OUT/sqb.log" 2>&1
-# standalone launches of the HBM-bound kernels (inside a bench step they share the machine with the backward IIR pass)
+# standalone launches of the step's kernels (inside a bench step the display chain and the demodulator share the machine)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o alone -- python tools/bench_alone.py > "$OUT/alone.log" 2>&1
 python tools/prof_digest.py "$OUT" "$TAG"
