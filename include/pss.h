@@ -64,6 +64,9 @@ int pss_device_count(void);
  *                              path sorts (longer rows: radix select)
  *   "fft_split" (-1 = auto)    1 / 0: force / forbid the component-wise LDS exchanges of the register FFT (auto: N = 256)
  *   "fft_big_scratch" (0)      1: N = 8192 / 16384 on the scratch-based pre-pass kernel instead of the four-stage register kernel
+ *   "fft_xl4096" (1)           0: N = 4096 (spectrum and scanner slice) on the three-stage kernel with complex LDS exchanges
+ *                              (k_spectrum_r16<4>: 240 VGPRs, two workgroups per CU) instead of the component-wise-exchange kernel
+ *                              (128 VGPRs, four workgroups per CU)
  *   "fft_prefetch" (-1 = auto) 1 / 0: force / forbid requesting the next frame's samples before transforming the current one
  *                              (auto: N = 1024 and 2048)
  * The ONE switch that changes results:

@@ -653,10 +653,14 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     case 512: return launch_r16<1, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
     case 1024: return launch_r16<2, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
     case 2048: return launch_r16<3, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
-    case 4096: return launch_r16<4, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
+    case 4096:
+        // default: the component-wise-exchange kernel below (128 VGPRs, 35 KB LDS: four workgroups per CU; 3.3 against 2.4-2.7 TB/s);
+        // "fft_xl4096" = 0 or "fft_big_scratch" = 1: the three-stage kernel with complex exchanges (two workgroups per CU)
+        if (!ctx->fft_xl4096 || ctx->fft_big_scratch) return launch_r16<4, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
+        break;
     default: break;
     }
-    if (!SCAN && (n_fft == 8192 || n_fft == 16384) && !ctx->fft_big_scratch) {
+    if (((!SCAN && (n_fft == 8192 || n_fft == 16384)) || n_fft == 4096) && !ctx->fft_big_scratch) {
         // N = 16 x 16 x 16 x R4 in registers + LDS: the frame is read once, the dB row written once
         auto go = [&](auto kern, size_t lds, int threads, int per_cu) -> int {
             PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -664,11 +668,12 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
             pss_time_begin(ctx);
             pss_kernel_begin(ctx, "k_spectrum");
             hipLaunchKernelGGL(kern, dim3((unsigned)(n_frames < cap ? n_frames : cap)), dim3(threads), lds, PSS_STREAM(ctx),
-                               reinterpret_cast<const float2 *>(d_iq), d_db, tw, win, n_frames);
+                               reinterpret_cast<const float2 *>(d_iq), d_db, tw, win, n_frames, d_peak, d_bw, d_count, bin_hz);
             pss_kernel_end(ctx);
             pss_time_end(ctx);
             return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_xl launch");
         };
+        if (n_fft == 4096) return go(pss_xl::k_spectrum_xl<0, !SCAN, SCAN>, pss_xl::CfgX<0>::LDS, 256, 4);
         if (n_fft == 8192) return go(pss_xl::k_spectrum_xl<1, true>, pss_xl::CfgX<1>::LDS, 512, 2);
         return go(pss_xl::k_spectrum_xl<2, true>, pss_xl::CfgX<2>::LDS, 1024, 1);
     }

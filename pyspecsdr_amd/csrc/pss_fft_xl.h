@@ -139,7 +139,7 @@ __device__ __forceinline__ void xl_core(double2 (&v)[16], double *ex, double2 w1
     }
     // ---- stage 3
     fft_reg<16>(v);
-    twiddle_powers(v, w3);
+    if constexpr (R4 > 1) twiddle_powers(v, w3);   // R4 = 1 (N = 4096): stage 3 is the last one, its twiddles are all 1
     // exchange 3: L3[c][r3][r2][r] with 17-double (r2) rows, 272-double r3 blocks and planes P3 apart.  Writes: a 32-lane
     // group is 32 / R4 values of r2 x R4 planes at fixed r: offsets 17 r2 + (32 / R4) c (mod 32) are all different.
     // Reads: thread rho takes g = rho + T j in bin order (r fastest): 32 lanes = two rows of 16 consecutive doubles, 17 apart
@@ -164,24 +164,30 @@ __device__ __forceinline__ void xl_core(double2 (&v)[16], double *ex, double2 w1
     }
 }
 
-// compute_fft (signal_processing.py:243-264) for frames of N = 4096 * R4 points: Hamming window (np.hamming, float64 table),
-// transform, fftshift, 10 log10(|X|^2 + 1e-10) as float32.  WINDOW = false: an unwindowed transform.
-template <int LOG_R4, bool WINDOW>
+// compute_fft (signal_processing.py:243-264) for frames of N = 4096 * R4 points (R4 = 1, 2, 4): Hamming window (np.hamming,
+// float64 table), transform, fftshift, 10 log10(|X|^2 + 1e-10) as float32.  WINDOW = false: an unwindowed transform.
+// SCAN: the inline scanner's slice (pyspecsdr.py:2542-2552) — unwindowed, plus the slice's peak and the number of bins within
+// 20 dB of it; db may then be NULL.  The dB values wait in the (then idle) exchange buffer for the peak to be known.
+template <int LOG_R4, bool WINDOW, bool SCAN = false>
 __global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *__restrict__ iq, float *__restrict__ db,
                                                                   const double2 *__restrict__ tw, const double *__restrict__ win,
-                                                                  long n_frames)
+                                                                  long n_frames, float *__restrict__ peak, double *__restrict__ bw,
+                                                                  int *__restrict__ count, double bin_hz)
 {
     using C = CfgX<LOG_R4>;
     constexpr int T = C::T, N = C::N, T2 = C::T2, R4 = C::R4;
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ float red_f[16];
+    __shared__ int red_i[16];
     double *ex = reinterpret_cast<double *>(smem);
     const int t = threadIdx.x;
     const double2 w1 = tw[t];                                  // W_N^t
     const double2 w2 = tw[(size_t)(t % T2) * 16];              // W_T^b = W_N^(16 b)
     const double2 w3 = tw[(size_t)(t % R4) * 256];             // W_T2^c = W_N^(256 c)
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(win, N * 8);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(win, WINDOW ? N * 8 : 0);
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc(iq + (size_t)f * N, N * 8), ro = make_rsrc(db + (size_t)f * N, N * 4);
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(iq + (size_t)f * N, N * 8);
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(db ? db + (size_t)f * N : nullptr, db ? N * 4 : 0);   // no rows wanted: every store dropped
         // the 45 twiddle powers are loop-invariant and the compiler would compute them once, park them in scratch memory
         // (180 VGPRs) and reload them every frame; recomputing them from the three bases is cheaper than that traffic
         double2 u1 = w1, u2 = w2, u3 = w3;
@@ -199,10 +205,38 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *
             for (int q = 0; q < 8; q++) v[8 * h + q] = make_double2((double)s[q].x * wv[q], (double)s[q].y * wv[q]);
             sched_fence();
         }
-        xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int, int j, int k, double2 X) {
+        float lmax = -INFINITY;
+        float *held = reinterpret_cast<float *>(ex);           // SCAN: this thread's 16 dB values at held[i * T + t]
+        xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int i, int j, int k, double2 X) {
             // fftshift; bin 4096 k + T j + t: T consecutive bins per store instruction
-            buf_store_f32(ro, t * 4, ((4096 * k + T * j + N / 2) & (N - 1)) * 4, pss_r16::db_of(X.x * X.x + X.y * X.y + 1e-10));
+            const float d = pss_r16::db_of(X.x * X.x + X.y * X.y + 1e-10);
+            buf_store_f32(ro, t * 4, ((4096 * k + T * j + N / 2) & (N - 1)) * 4, d);
+            if (SCAN) { held[i * T + t] = d; lmax = fmaxf(lmax, d); }
         });
+        if (SCAN) {
+            // per-frame peak and 20-dB-down bin count (pyspecsdr.py:2546-2552), as k_spectrum_r16 computes them
+            float m = lmax;
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            if ((t & 63) == 0) red_f[t >> 6] = m;
+            __syncthreads();
+            m = red_f[0];
+#pragma unroll
+            for (int wv = 1; wv < T / 64; wv++) m = fmaxf(m, red_f[wv]);
+            const float thr = m - 20.0f;
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) cnt += held[i * T + t] > thr;
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+            if ((t & 63) == 0) red_i[t >> 6] = cnt;
+            __syncthreads();                       // also: every thread has read its held[] before the next frame's exchange writes
+            if (t == 0) {
+                cnt = 0;
+                for (int wv = 0; wv < T / 64; wv++) cnt += red_i[wv];
+                peak[f] = m;
+                if (bw) bw[f] = (double)cnt * bin_hz;
+                if (count) count[f] = cnt;
+            }
+        }
     }
 }
 

@@ -36,6 +36,15 @@ def test_spectrum_vs_golden(golden, n):
     assert np.all(rel_err(db, ref)[big] <= 1e-4)
     assert np.all(np.abs(db - ref)[~big] <= 1e-6)
     assert np.max(np.abs(db - ref)) < 2e-5  # in practice: float32 rounding of the output only
+    if n == 4096:       # the three-stage kernel with complex exchanges (the default until round 2) against the same golden
+        e = G.engine()
+        e.set_option("fft_xl4096", 0)
+        try:
+            db0 = G.spectrum(iq)
+        finally:
+            e.set_option("fft_xl4096", 1)
+        assert np.all(rel_err(db0, ref)[big] <= 1e-4) and np.max(np.abs(db0 - ref)) < 2e-5
+        assert np.max(np.abs(db0 - db)) < 2e-5
 
 
 def test_spectrum_split_exchange_is_bit_identical():
@@ -46,6 +55,7 @@ def test_spectrum_split_exchange_is_bit_identical():
     for n in (256, 1024, 4096):
         iq = (rng.standard_normal((5000, n)) + 1j * rng.standard_normal((5000, n))).astype(np.complex64)
         res = []
+        e.set_option("fft_xl4096", 0)          # these switches belong to k_spectrum_r16
         for sp, pf in ((0, 0), (1, 0), (0, 1)):
             e.set_option("fft_split", sp)
             e.set_option("fft_prefetch", pf)
@@ -54,6 +64,7 @@ def test_spectrum_split_exchange_is_bit_identical():
             finally:
                 e.set_option("fft_split", -1)
                 e.set_option("fft_prefetch", -1)
+        e.set_option("fft_xl4096", 1)
         assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32)), n
         assert np.array_equal(res[0].view(np.uint32), res[2].view(np.uint32)), n
 
