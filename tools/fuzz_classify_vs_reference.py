@@ -14,7 +14,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 bad = labels = 0
 seen = {}
 for it in range(N):
-    n = int(rng.choice([1024, 1025, 1535, 1536, 2048, 3000, 4096, 8191, 16384, 33000, 70000]))
+    n = int(rng.choice([1024, 1025, 1535, 1536, 2048, 3000, 4096, 8191, 16384, 33000, 70000,
+                        1023, 1000, 640, 513, 512, 300, 129, 64, 33, 17, 9, 4, 3, 2]))   # below 1024: welch's nperseg = n fallback
     fs = float(rng.choice([2.4e6, 1.024e6, 250e3, 10e6, 48e3]))
     t = np.arange(n) / fs
     kind = int(rng.integers(0, 7))
