@@ -54,7 +54,7 @@ int pss_device_count(void);
  *   "small_batch" (1)          0: never take the latency-oriented small-batch kernels (one lane per filter section)
  *   "small_batch_max" (8192)   largest NFM frame count that takes them;  "wfm_small_batch_max" (8192) likewise for WFM
  *   "ssb_hilbert" (1)          0: demodulate_ssb skips the reference's hilbert() FFT round trip (the identity on the real part it
- *                              keeps, up to ~1e-16); 1: executed for power-of-two frames of 256..16384 samples
+ *                              keeps, up to ~1e-16); 1: executed for power-of-two frames of 256..1048576 samples
  *   "fuse_post" (0)            1: pss_spectrum_db_post takes the fused spectrum + post-process kernel for 1024-point frames
  *   "pipe_overlap" (0)         schedule of pss_frame_pipeline_nfm.  0: forward kernel -> spectrum -> {backward pass || post-process ->
  *                              lines}; 1: the whole display chain on the side stream from the start (6 % faster when the forward
@@ -139,8 +139,9 @@ int pss_scan_threshold(pss_ctx *ctx, const float *d_iq, long n_slices, int n, do
 int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out_iq, float *d_raw);
 
 /* scipy.signal.hilbert along n_rows float64 rows of n samples (the analytic signal demodulate_ssb builds,
- * signal_processing.py:205, :210): fft, one-sided mask, ifft in one kernel.  n: a power of two in [256, 16384] (PSS_E_ARG
- * otherwise).  d_analytic: complex128 [n_rows][n] (interleaved re, im). */
+ * signal_processing.py:205, :210): fft, one-sided mask, ifft.  n: a power of two in [256, 1048576] (PSS_E_ARG otherwise) — up to
+ * 16384 both transforms in one kernel; longer rows (the reference's read buffers: 32768 by default, up to 2^20) through a complex
+ * float64 spectrum in HBM.  d_analytic: complex128 [n_rows][n] (interleaved re, im). */
 int pss_hilbert(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_analytic);
 
 /* measure_signal_power (signal_processing.py:325-328): float32 [n_frames]. */

@@ -2426,12 +2426,19 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         // reference, executed where a register transform exists for the frame length; numerically the identity on the
         // real part up to the transforms' rounding (~1e-16), so skipping it (option "ssb_hilbert" = 0, and every other
         // frame length) changes no int16 sample
-        if (ctx->ssb_hilbert && pss_hilbert_supported(n)) {
+        if (ctx->ssb_hilbert && pss_hilbert_supported(n) && n <= 16384) {
             // ... with the normalisation and the int16 conversion in the same kernel (the frame is in registers when the frame
             // peak becomes known): no float64 round trip through HBM, no k_finalize pass
             r = pss_hilbert_rows(ctx, Yf, n_frames, n, d_audio, 2, nullptr, d_pcm);
             pss_time_end(ctx);
             return r ? r : pss_hip_check(ctx, hipGetLastError(), "ssb launch");
+        }
+        if (ctx->ssb_hilbert && pss_hilbert_supported(n)) {
+            // longer read buffers (the reference's default is 32768 samples): the round trip goes through a spectrum in HBM, in
+            // place on Yf, and leaves the frame peak of its real part for k_finalize
+            PSS_HIP(ctx, hipMemsetAsync(mxb, 0, (size_t)n_frames * sizeof(double), PSS_STREAM(ctx)));
+            r = pss_hilbert_rows(ctx, Yf, n_frames, n, Yf, 1, mxb, nullptr);
+            if (r) { pss_time_end(ctx); return r; }
         }
         size_t tot = (size_t)n_frames * n;
         size_t g2 = (tot + TPB - 1) / TPB;

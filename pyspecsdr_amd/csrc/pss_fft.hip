@@ -995,17 +995,117 @@ bool is_pow2(int n) { return n > 0 && !(n & (n - 1)); }
 // scipy.signal.hilbert on n_rows float64 rows of n samples, n a power of two in [256, 16384] (the register transforms).
 // out_mode 0: complex128 analytic signal to d_out; 1: real part to d_out (may be d_x itself) and, if d_maxbits is given,
 // the row's max |real| as a double's bit pattern (atomicMax onto d_maxbits[row]; the caller clears it).
-bool pss_hilbert_supported(int n) { return n >= 256 && n <= 16384 && !(n & (n - 1)); }
+// ---- scipy.signal.hilbert for rows longer than one workgroup's registers (N = 2^15 .. 2^20: the reference's read buffers are
+// (2 ** SAMPLES) * 256 samples, SAMPLES = 5 .. 12, default 7 = 32768: pyspecsdr.py:105, :2236) ----------------------------------
+// Two transforms through a complex float64 spectrum Z in HBM: forward (real input) -> Z = conj(h X) (one-sided mask and the
+// conjugate that turns the second forward transform into the inverse), forward again -> conj(.) / N.  N = 32768, 65536: the
+// radix-R pre-pass + 4096-point kernel (k_big_g); N >= 2^17: the two-pass 256 x NS transform (bs_pass1 / bs_pass2).
+namespace {
+
+struct HilLoadReal {
+    const double *x; size_t n;
+    __device__ double2 operator()(long f, size_t idx) const { return make_double2(x[(size_t)f * n + idx], 0.0); }
+};
+struct HilStoreMasked {
+    double2 *Z; size_t n;
+    __device__ void operator()(long f, size_t k, double2 X) const
+    {
+        const double h = (k == 0 || k == n / 2) ? 1.0 : (k < n / 2 ? 2.0 : 0.0);
+        Z[(size_t)f * n + k] = make_double2(X.x * h, -(X.y * h));
+    }
+};
+struct HilLoadZ {
+    const double2 *Z; size_t n;
+    __device__ double2 operator()(long f, size_t idx) const { return Z[(size_t)f * n + idx]; }
+};
+// OUT 0: complex128 analytic signal; 1: real part + the row's peak |re| (bit pattern, atomicMax; one atomic per wavefront and call:
+// every lane of the calling kernels is active here)
+template <int OUT>
+struct HilStoreOut {
+    double *out; unsigned long long *mxbits; size_t n; double inv_n;
+    __device__ void operator()(long f, size_t k, double2 W) const
+    {
+        const double re = W.x * inv_n, im = -(W.y * inv_n);
+        if (OUT == 0) reinterpret_cast<double2 *>(out)[(size_t)f * n + k] = make_double2(re, im);
+        else {
+            out[(size_t)f * n + k] = re;
+            if (mxbits) {
+                // lanes of one wavefront may belong to different rows in the two-pass kernels (16 frames' columns side by side is
+                // not how they are called here: n_frames rows are walked one after the other) — still, reduce only among equal f
+                double m = fabs(re);
+                const int fi = (int)f, f0 = __shfl(fi, 0);
+                if (__all(fi == f0)) {
+                    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(m, off); m = (o != o || o > m) ? o : m; }
+                    if ((threadIdx.x & 63) == 0) atomicMax(&mxbits[f], (unsigned long long)__double_as_longlong(m));
+                } else {
+                    atomicMax(&mxbits[f], (unsigned long long)__double_as_longlong(m));
+                }
+            }
+        }
+    }
+};
+
+template <int LOG_R, class Load, class Store>
+int big_pass(pss_ctx *ctx, Load load, Store store, const double2 *tw, long n_rows, double2 *scr, int grid)
+{
+    using C = pss_r16::Cfg<4>;
+    auto kern = pss_r16::k_big_g<LOG_R, Load, Store>;
+    PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C::LDS, PSS_STREAM(ctx), load, store, tw, n_rows, scr);
+    return pss_hip_check(ctx, hipGetLastError(), "k_big_g launch");
+}
+
+int hilbert_long(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits,
+                 const double2 *tw)
+{
+    if (out_mode != 0 && out_mode != 1) return pss_fail(ctx, PSS_E_ARG, "pss_hilbert: rows longer than 16384 samples have no fused demodulator tail");
+    const size_t N = (size_t)n;
+    const int grid = (int)(n_rows < 512 ? n_rows : 512);
+    // Z [n_rows][N] + the per-workgroup pre-pass scratch [grid][N] (N <= 65536) or the pass-1 output Y [n_rows][N] (N >= 2^17)
+    const size_t szZ = (size_t)n_rows * N * sizeof(double2), szS = (n <= 65536 ? (size_t)grid : (size_t)n_rows) * N * sizeof(double2);
+    int r = pss_ensure_buffer(ctx, &ctx->scratch_fft, &ctx->scratch_fft_bytes, szZ + szS, "hilbert spectrum");
+    if (r) return r;
+    double2 *Z = reinterpret_cast<double2 *>(ctx->scratch_fft), *S = Z + (size_t)n_rows * N;
+    const HilLoadReal lx{d_x, N};
+    const HilStoreMasked sz{Z, N};
+    const HilLoadZ lz{Z, N};
+    const double inv_n = 1.0 / (double)n;
+    pss_kernel_begin(ctx, "k_hilbert");
+    auto second = [&](auto pass) -> int {
+        return out_mode == 0 ? pass(HilStoreOut<0>{d_out, nullptr, N, inv_n}) : pass(HilStoreOut<1>{d_out, d_maxbits, N, inv_n});
+    };
+    if (n == 32768) {
+        r = big_pass<3>(ctx, lx, sz, tw, n_rows, S, grid);
+        if (!r) r = second([&](auto st) { return big_pass<3>(ctx, lz, st, tw, n_rows, S, grid); });
+    } else if (n == 65536) {
+        r = big_pass<4>(ctx, lx, sz, tw, n_rows, S, grid);
+        if (!r) r = second([&](auto st) { return big_pass<4>(ctx, lz, st, tw, n_rows, S, grid); });
+    } else {
+        const int NS = n >> 8;
+        r = bs_pass1(ctx, lx, tw, S, NS, n_rows);
+        if (!r) r = bs_pass2(ctx, S, sz, tw, NS, n_rows);
+        if (!r) r = bs_pass1(ctx, lz, tw, S, NS, n_rows);
+        if (!r) r = second([&](auto st) { return bs_pass2(ctx, S, st, tw, NS, n_rows); });
+        if (!r) r = pss_hip_check(ctx, hipGetLastError(), "hilbert two-pass launch");
+    }
+    pss_kernel_end(ctx);
+    return r;
+}
+
+}  // namespace
+
+bool pss_hilbert_supported(int n) { return n >= 256 && n <= (1 << 20) && !(n & (n - 1)); }
 
 int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits,
                      int16_t *d_pcm)
 {
-    if (!pss_hilbert_supported(n)) return pss_fail(ctx, PSS_E_ARG, "pss_hilbert: the row length must be a power of two in [256, 16384]");
+    if (!pss_hilbert_supported(n)) return pss_fail(ctx, PSS_E_ARG, "pss_hilbert: the row length must be a power of two in [256, 1048576]");
     if (n_rows == 0) return PSS_OK;
     const double2 *tw;
     const double *win;
     int r = pss_fft_tables(ctx, n, &tw, &win);
     if (r) return r;
+    if (n > 16384) return hilbert_long(ctx, d_x, n_rows, n, d_out, out_mode, d_maxbits, tw);
     auto go = [&](auto kern, size_t lds, int threads, long groups, long cap) -> int {
         if (lds > 64 * 1024)
             PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -374,6 +374,52 @@ __global__ __launch_bounds__(256) void k_spectrum_r16_big(const float2 *__restri
     }
 }
 
+// The N = R * 4096 transform (R = 8, 16: N = 32768, 65536) around caller-supplied load / store functors, complex float64
+// in and out: load(f, idx) -> element idx of frame f, store(f, k, X) receives bin k.  Same scheme as k_spectrum_r16_big
+// (radix-R pre-pass into a per-workgroup scratch, then R register-resident 4096-point transforms).
+template <int LOG_R, class Load, class Store>
+__global__ __launch_bounds__(256) void k_big_g(Load load, Store store, const double2 *__restrict__ tw, long n_frames,
+                                               double2 *__restrict__ scratch)
+{
+    using C = Cfg<4>;
+    constexpr int T = C::T, NS = C::N, R = 1 << LOG_R, N = R * NS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *ex = reinterpret_cast<double2 *>(smem);
+    double2 *tw2 = ex + C::EX;
+    const int t = threadIdx.x;
+    double2 *scr = scratch + (size_t)blockIdx.x * N;
+    double2 tw1[16];
+    tw1[0] = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; k2++) tw1[k2] = tw[(size_t)t * k2 * R];
+    tw2[t] = tw[(size_t)((t / 16) * (t % 16)) * 16 * R];
+    __syncthreads();
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+#pragma unroll 2
+        for (int j = 0; j < 16; j++) {
+            const int n = t + T * j;
+            double2 a[R];
+#pragma unroll
+            for (int q = 0; q < R; q++) a[q] = load(f, (size_t)(n + NS * q));
+            fft_reg<R>(a);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                double2 y = a[brev(r, LOG_R)];
+                if (r) y = cmul(y, tw[(size_t)n * r]);
+                scr[(size_t)r * NS + n] = y;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < R; r++) {
+            double2 v[16];
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) v[n2] = scr[(size_t)r * NS + t + T * n2];
+            r16_core<4>(v, ex, tw1, tw2, t, [&](int, int kp, double2 X) { store(f, (size_t)(R * kp + r), X); });
+            __syncthreads();
+        }
+    }
+}
+
 // N = 256 * NS, NS in {512, 1024, 2048, 4096} (N = 131072 ... 1048576, the reference's largest read buffers,
 // pyspecsdr.py:2236 with SAMPLES = 9..12): two kernels around a float64 scratch Y[frame][r][n]:
 //   pass 1  for every column n < NS: 256-point transform over q of x[n + NS q] w[n + NS q], times W_N^(n r)  -> Y[r][n]

@@ -161,7 +161,7 @@ class Engine:
                                              _ptr(d_bw), _ptr(d_count)))
 
     def hilbert(self, d_x, n_rows, n, d_analytic):
-        """scipy.signal.hilbert along float64 rows -> complex128 rows (n: power of two in 256..16384)."""
+        """scipy.signal.hilbert along float64 rows -> complex128 rows (n: power of two in 256..1048576)."""
         self._ck(self.lib.pss_hilbert(self.h, _ptr(d_x), n_rows, n, _ptr(d_analytic)))
 
     def power_db(self, d_iq, n_frames, n, d_power):

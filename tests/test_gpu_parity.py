@@ -388,12 +388,36 @@ def test_ssb_vs_golden(golden, tag, mode):
     assert np.max(np.abs(res[1] - res[0])) < 1e-14
 
 
-@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_ssb_on_the_reference_read_buffer_sizes():
+    """demodulate_ssb on the main loop's read buffers ((2 ** SAMPLES) * 256 samples, pyspecsdr.py:2236; 32768 by default): the
+    Hilbert round trip runs through a spectrum in HBM there.  int16 equal with and without it, float64 within the transforms'
+    rounding, and the path without it bit-exact against the oracle."""
+    rng = np.random.default_rng(85)
+    e = G.engine()
+    fs = 2.4e6
+    for n in (32768, 65536, 262144):
+        t = np.arange(n) / fs
+        iq = (0.4 * np.exp(2j * np.pi * 1.5e3 * t)[None, :] * (1 + 0.3 * np.sin(2 * np.pi * 300 * t))[None, :] +
+              0.05 * (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n)))).astype(np.complex64)
+        res = {}
+        for hil in (1, 0):
+            e.set_option("ssb_hilbert", hil)
+            try:
+                res[hil] = G.demod(L.MODE_USB, iq, fs)
+            finally:
+                e.set_option("ssb_hilbert", 1)
+        assert np.array_equal(res[1][0], res[0][0]), n
+        assert np.max(np.abs(res[1][1] - res[0][1])) < 1e-13, n
+        taps = e.ssb_taps(fs)
+        assert np.array_equal(res[0][1][0], O.demod_ssb(iq[0], taps)), n
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 1048576])
 def test_hilbert_rows(n):
     """pss_hilbert = scipy.signal.hilbert along rows (fft, one-sided mask, ifft; _signaltools.py:2318), both transforms in one
     kernel; against the same statements in NumPy float64."""
     rng = np.random.default_rng(n)
-    nf = 77 if n <= 4096 else 9
+    nf = 77 if n <= 4096 else (9 if n <= 65536 else 3)      # above 16384 (the reference's read buffers): spectrum through HBM
     x = rng.standard_normal((nf, n)) * rng.uniform(0.01, 10.0, (nf, 1))
     x[1] = np.cos(2 * np.pi * 37 * np.arange(n) / n)          # analytic signal of a cosine: exp(i w t)
     e = G.engine()
