@@ -84,7 +84,12 @@ def profiled(kernel, n_frames):
         if t.get("src_hash") != source_hash():
             return None, None, f"profiles/hbm_traffic.json is from source {t.get('src_hash')}, this tree is {source_hash()}"
         k = t["kernels"][kernel]
-        return k["traffic_bytes"] * n_frames / float(t["n_frames"]), k.get("valu_busy_frac"), t.get("profile")
+        busy = None
+        if kernel in ("k_nfm_fwd", "k_nfm_bwd") and k.get("waves") and n_frames == t["n_frames"]:
+            # every wavefront of these launches is resident from start to end (waves / 1024 SIMDs = 4 resp. 1 per SIMD), so the
+            # SIMD's VALU-busy fraction is the per-wave active fraction times the waves sharing it
+            busy = k["valu_active_frac_of_wave_cycles"] * k["waves"] / 1024.0
+        return k["traffic_bytes"] * n_frames / float(t["n_frames"]), busy, t.get("profile")
     except Exception as ex:  # noqa: BLE001
         return None, None, f"no digest ({type(ex).__name__})"
 
