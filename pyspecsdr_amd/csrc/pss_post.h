@@ -35,6 +35,7 @@ __device__ __forceinline__ unsigned dpp_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
 struct OpAdd { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return a + b; } };
+struct OpFAdd { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return __float_as_uint(__uint_as_float(a) + __uint_as_float(b)); } };
 struct OpMin { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return a < b ? a : b; } };
 struct OpMax { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return a > b ? a : b; } };
 
@@ -83,9 +84,14 @@ __device__ __forceinline__ unsigned count_below(const unsigned (&key)[EPL], unsi
 // search on the key bits below the common prefix of the row's minimum and maximum (returned in mn / mx); stops as soon as
 // one candidate is left in the bracket, and that last pass also finds the smallest key above the bracket (= rank k + 1).
 // PAD_FROM: first register slot that may hold padding (EPL: none anywhere).
+// `guess`: a value near which the order statistic is expected (the row's mean: most of a dB row is noise floor) or NaN.  The
+// brackets [guess - 0.5, guess + 0.5] and [guess - 2, guess + 2] are tried first — two counts tell whether rank k lies inside —
+// and the search then halves such a bracket instead of spending its first steps on the empty stretch between the noise
+// floor and the row's extremes (measured on FM / noise / weak-tone rows: 10.4-10.7 counting passes instead of 15-19).
+// A wrong guess costs four counts and changes nothing else: every result is decided by exact counts.
 template <int EPL, int W, int PAD_FROM>
 __device__ __forceinline__ unsigned select_kth(const unsigned (&key)[EPL], unsigned k, unsigned n_valid, unsigned &next, unsigned &mn,
-                                               unsigned &mx, unsigned *red, int wave, int lane, int &phase)
+                                               unsigned &mx, unsigned *red, int wave, int lane, int &phase, float guess = NAN)
 {
     unsigned a = 0xffffffffu, b0 = 0u, b2 = 0u;
 #pragma unroll
@@ -105,6 +111,42 @@ __device__ __forceinline__ unsigned select_kth(const unsigned (&key)[EPL], unsig
         return row_reduce<OpMin, W>(c, red, wave, lane, phase);
     };
     if (mn == mx) { next = mn; return mn; }                   // a constant row (n_valid >= 2 wherever next is used)
+    if (guess == guess && mx != 0xffffffffu) {
+#pragma unroll 1
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const float d = attempt ? 2.0f : 0.5f;
+            unsigned lo = f2ord(guess - d), hi = f2ord(guess + d);
+            lo = lo < mn ? mn : lo;
+            hi = hi > mx ? mx : hi;
+            if (lo > hi) continue;
+            unsigned n_lo = count_below<EPL, W>(key, lo, red, wave, lane, phase);          // #keys < lo
+            unsigned n_hi = count_below<EPL, W>(key, hi + 1u, red, wave, lane, phase);     // #keys <= hi
+            if (!(n_lo <= k && k < n_hi)) continue;
+            // rank k lies in [lo, hi]: halve the bracket until one key (or one value) is left
+#pragma unroll 1
+            while (n_hi - n_lo > 1u && lo < hi) {
+                const unsigned trial = lo + ((hi - lo + 1u) >> 1);
+                const unsigned c = count_below<EPL, W>(key, trial, red, wave, lane, phase);
+                if (c <= k) { lo = trial; n_lo = c; } else { hi = trial - 1u; n_hi = c; }
+            }
+            if (n_hi - n_lo == 1u) {
+                // the one key in [lo, hi] has rank k; exactly k + 1 keys are <= hi, so rank k + 1 is the smallest key above hi
+                unsigned cand = 0xffffffffu, nx = 0xffffffffu;
+                const unsigned span = hi - lo;
+#pragma unroll
+                for (int r = 0; r < EPL; r++) {
+                    const bool in = key[r] - lo <= span;
+                    cand = in ? key[r] : cand;
+                    nx = (key[r] > hi && key[r] < nx) ? key[r] : nx;
+                }
+                cand = row_reduce<OpMin, W>(cand, red, wave, lane, phase);
+                next = row_reduce<OpMin, W>(nx, red, wave, lane, phase);
+                return cand;
+            }
+            next = (k + 1u < n_hi) ? lo : above(lo);          // lo == hi: the value lo holds the ranks n_lo .. n_hi - 1
+            return lo;
+        }
+    }
     int b = 31 - __builtin_clz(mn ^ mx);                      // highest bit in which two keys of the row differ
     unsigned lo = mn & ~((2u << b) - 1u);                     // all keys lie in [lo, lo + 2^(b+1))
     unsigned n_lo = 0, n_hi = n_valid;                        // #keys < lo, #keys < lo + 2^(b+1)
@@ -169,6 +211,7 @@ __device__ __forceinline__ void post_row_staged(float *buf, const int (&slot)[EP
     const int nv = m - t * EPL;                  // this thread's slots r < nv hold elements of the smoothed row
     // EPL consecutive elements + the next thread's first four (the 5-tap window of the last four outputs)
     unsigned key[EPL];
+    float lsum = 0.0f;
     {
         float x[EPL + 4];
 #pragma unroll
@@ -186,16 +229,20 @@ __device__ __forceinline__ void post_row_staged(float *buf, const int (&slot)[EP
             double acc = 0.0;
 #pragma unroll
             for (int k = 0; k < 5; k++) acc += xd[r + k] * 0.2;
-            key[r] = f2ord((float)acc);
+            const float sm = (float)acc;
+            key[r] = f2ord(sm);
             // padding sorts above everything
-            if (FULL) { if (r >= PAD_FROM) key[r] = t == T - 1 ? 0xffffffffu : key[r]; }
-            else key[r] = r < nv ? key[r] : 0xffffffffu;
+            const bool pad = FULL ? (r >= PAD_FROM && t == T - 1) : r >= nv;
+            key[r] = pad ? 0xffffffffu : key[r];
+            lsum += pad ? 0.0f : sm;
         }
     }
+    // the row's mean: where the median search starts looking (select_kth; a hint only, never part of a result)
+    const float guess = __uint_as_float(row_reduce<OpFAdd, W>(__float_as_uint(lsum), red, wave, lane, phase)) / (float)m;
     // np.median: the middle order statistic, or the mean of the two middle ones
     const unsigned k1 = (unsigned)((m - 1) >> 1);
     unsigned mn, mx, v2;
-    const unsigned v1 = select_kth<EPL, W, PAD_FROM>(key, k1, (unsigned)m, v2, mn, mx, red, wave, lane, phase);
+    const unsigned v1 = select_kth<EPL, W, PAD_FROM>(key, k1, (unsigned)m, v2, mn, mx, red, wave, lane, phase, guess);
     const double med = (m & 1) ? (double)ord2f(v1) : 0.5 * ((double)ord2f(v1) + (double)ord2f(v2));
     // fd[fd < thr] = thr (:2282-2283).  float32(max(s, thr)) = max(float32(s), float32(thr)) (rounding is monotonic), and
     // the maximum of two floats is the maximum of their ordered images
