@@ -256,7 +256,7 @@ def main():
 
     side, spec_alone, post_alone, dom_alone = {}, [], [], []
     if not args.no_side:
-        # each HBM-bound kernel alone (inside a step the post-process runs beside the backward IIR pass)
+        # each HBM-bound kernel alone (inside a step the spectrum and the post-process run beside the backward IIR pass)
         eng.enable_timing(True)
         for _ in range(2):
             eng.spectrum_db(iq, nf, n, d_db[0])

@@ -56,9 +56,10 @@ int pss_device_count(void);
  *   "ssb_hilbert" (1)          0: demodulate_ssb skips the reference's hilbert() FFT round trip (the identity on the real part it
  *                              keeps, up to ~1e-16); 1: executed for power-of-two frames of 256..1048576 samples
  *   "fuse_post" (0)            1: pss_spectrum_db_post takes the fused spectrum + post-process kernel for 1024-point frames
- *   "pipe_overlap" (0)         schedule of pss_frame_pipeline_nfm.  0: forward kernel -> spectrum -> {backward pass || post-process ->
- *                              lines}; 1: the whole display chain on the side stream from the start (6 % faster when the forward
- *                              kernel reaches the dispatcher first, slower when it does not); 2: fork right after the forward kernel
+ *   "pipe_overlap" (2)         schedule of pss_frame_pipeline_nfm.  2: forward kernel -> {backward pass || spectrum -> post-process ->
+ *                              lines}; 0: forward kernel -> spectrum -> {backward pass || post-process -> lines} (2 % slower);
+ *                              1: the whole display chain on the side stream from the start (5 % faster when the forward kernel
+ *                              reaches the dispatcher first, 8 % slower when it does not)
  *   "post_legacy" (0)          1: the post-process takes the LDS bitonic sort / LDS-histogram radix select kernels instead of
  *                              the register-resident binary-search select;  "post_sort_max" (8192): longest row the legacy
  *                              path sorts (longer rows: radix select)

@@ -73,7 +73,7 @@ struct pss_ctx {
     bool ssb_hilbert = true;   // option "ssb_hilbert": run the reference's hilbert() round trip inside demodulate_ssb where a register transform exists for the frame length
     bool fir_mfma = false;
     bool fft_xl4096 = true;        // N = 4096 on the component-wise-exchange kernel (pss_fft_xl.h, R4 = 1) instead of k_spectrum_r16<4>
-    int pipe_overlap_mode = 0;     // pss_frame_pipeline_nfm schedule: 0 fwd -> spectrum -> {bwd || post -> lines}; 1 / 2: see pss.h "pipe_overlap"     // option "fir_mfma": NFM forward kernel with the FIR on the matrix pipe (NOT bit-identical float64; opt-in)
+    int pipe_overlap_mode = 2;     // pss_frame_pipeline_nfm schedule: 2 fwd -> {bwd || spectrum -> post -> lines}; 0 / 1: see pss.h "pipe_overlap"     // option "fir_mfma": NFM forward kernel with the FIR on the matrix pipe (NOT bit-identical float64; opt-in)
     bool fuse_post = false;    // option "fuse_post": 1024-point frames take the fused spectrum + post-process kernel in pss_spectrum_db_post
     bool post_legacy = false;  // option "post_legacy": LDS bitonic sort / LDS-histogram radix select instead of the register select
     int post_sort_max = 8192;  // option "post_sort_max": longest row that takes the LDS bitonic sort, else radix select (measured crossover 8192..16384)

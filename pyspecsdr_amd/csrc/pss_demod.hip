@@ -2962,9 +2962,10 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
         pss_time_end(ctx);
         return rn ? rn : (rd ? rd : rj);
     }
-    // Default schedule: forward kernel (VALU-bound, fills the machine) -> spectrum (HBM-bound, alone: 0.17 ms at cfg 2) ->
-    // { backward pass (latency-bound, one wavefront per SIMD)  ||  post-process -> display lines }.
-    // pipe_overlap = 2 forks one kernel earlier ({ backward pass || spectrum -> post-process -> lines }: 1.19 ms against 1.18).
+    // Default schedule (pipe_overlap = 2): forward kernel (VALU-bound, fills the machine) ->
+    //   { backward pass (latency-bound, one wavefront per SIMD)  ||  spectrum -> post-process -> display lines }.
+    // pipe_overlap = 0 keeps the spectrum in front of the fork (alone on the machine: 0.17 instead of 0.2 ms, but the backward
+    // pass then waits for it): 1.14-1.16 ms per step at cfg 2 against 1.12 ms.
     int r2;
     ctx->pending_bwd = nullptr;
     {

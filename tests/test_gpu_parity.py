@@ -1405,13 +1405,13 @@ def test_frame_pipeline_equals_separate_calls():
         e.sync()
         for k in a:
             assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k)
-        for sched in (1, 2):                      # the opt-in schedules (display chain forked earlier)
+        for sched in (0, 1):                      # the other schedules (fork one kernel later / at the very start)
             a2 = bufs()
             e.set_option("pipe_overlap", sched)
             try:
                 e.frame_pipeline_nfm(iq, nf, n, fs, a2["db"], a2["post"], a2["lo"], a2["hi"], 112, a2["g"], a2["c"], a2["pcm"])
             finally:
-                e.set_option("pipe_overlap", 0)
+                e.set_option("pipe_overlap", 2)
             e.sync()
             for k in a:
                 assert torch.equal(a2[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k, sched)
