@@ -5,6 +5,7 @@ PyTorch is only plumbing here (device memory / streams / torch.distributed); the
 plain HIP behind a C ABI.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -38,6 +39,10 @@ class Engine:
         self.device = device
         if stream is not None:
             self.set_stream(stream)
+        # PSS_OPTIONS="key=value,key=value": pss_set_option switches for A/B measurements without touching the caller
+        for kv in filter(None, os.environ.get("PSS_OPTIONS", "").split(",")):
+            k, _, v = kv.partition("=")
+            self.set_option(k.strip(), int(v))
 
     def close(self):
         if getattr(self, "h", None):
