@@ -65,6 +65,8 @@ int pss_device_count(void);
  *                              path sorts (longer rows: radix select)
  *   "fft_split" (-1 = auto)    1 / 0: force / forbid the component-wise LDS exchanges of the register FFT (auto: N = 256)
  *   "fft_big_scratch" (0)      1: N = 8192 / 16384 on the scratch-based pre-pass kernel instead of the four-stage register kernel
+ *   "fft_lean" (0)             1: N = 1024 / 2048 spectra on the 112-VGPR component-wise-exchange kernel (k_spectrum_lean) instead of
+ *                              k_spectrum_r16 (same results within the dB tolerance, not bit-identical: twiddle powers by product chains)
  *   "fft_xl4096" (1)           0: N = 4096 (spectrum and scanner slice) on the three-stage kernel with complex LDS exchanges
  *                              (k_spectrum_r16<4>: 240 VGPRs, two workgroups per CU) instead of the component-wise-exchange kernel
  *                              (128 VGPRs, four workgroups per CU)

@@ -72,6 +72,8 @@ struct pss_ctx {
     long wfm_small_batch_max = 8192;  // option "wfm_small_batch_max" (measured crossover with the fused kernels ~12000 frames)
     bool ssb_hilbert = true;   // option "ssb_hilbert": run the reference's hilbert() round trip inside demodulate_ssb where a register transform exists for the frame length
     bool fir_mfma = false;
+    int fft_lean = 0;              // N = 1024 / 2048 on k_spectrum_lean (112 VGPRs): 0 never (default), 1 always, -1 = only beside the NFM backward pass
+    bool spectrum_beside = false;  // set by pss_frame_pipeline_nfm around its side chain
     bool fft_xl4096 = true;        // N = 4096 on the component-wise-exchange kernel (pss_fft_xl.h, R4 = 1) instead of k_spectrum_r16<4>
     int pipe_overlap_mode = 2;     // pss_frame_pipeline_nfm schedule: 2 fwd -> {bwd || spectrum -> post -> lines}; 0 / 1: see pss.h "pipe_overlap"     // option "fir_mfma": NFM forward kernel with the FIR on the matrix pipe (NOT bit-identical float64; opt-in)
     bool fuse_post = false;    // option "fuse_post": 1024-point frames take the fused spectrum + post-process kernel in pss_spectrum_db_post

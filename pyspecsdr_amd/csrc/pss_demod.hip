@@ -2977,8 +2977,10 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
     if (!r && !spectrum_beside_bwd) r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
     auto display_chain = [&]() -> int {
         int q;
-        if (spectrum_beside_bwd)   // (option "fuse_post": spectrum and post-process of 1024-point frames in one kernel)
+        if (spectrum_beside_bwd) {  // (option "fuse_post": spectrum and post-process of 1024-point frames in one kernel)
+            PssFlagScope beside(ctx->spectrum_beside, true);
             q = pss_spectrum_db_post(ctx, d_iq, n_frames, n, d_db, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+        }
         else
             q = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
         if (!q) q = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);

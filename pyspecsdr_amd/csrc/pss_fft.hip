@@ -647,6 +647,25 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     const double *win;
     int r = pss_fft_tables(ctx, n_fft, &tw, &win);
     if (r) return r;
+    // N = 1024 / 2048 on the 112-VGPR kernel: opt-in ("fft_lean" = 1, or -1: only where the spectrum shares the machine with the NFM
+    // backward pass).  Measured: alone 0.434 against 0.412 ms at 131072 x 1024, 0.513 against 0.540 ms at 65536 x 2048; inside the
+    // bench step 0.326 against 0.303 ms — the wide kernel's slowdown beside the backward pass is not an occupancy effect
+    if (!SCAN && (n_fft == 1024 || n_fft == 2048) && (ctx->fft_lean > 0 || (ctx->fft_lean < 0 && ctx->spectrum_beside))) {
+        auto go = [&](auto kern, size_t lds, int fpw) -> int {
+            if (lds > 64 * 1024)
+                PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const long groups = (n_frames + fpw - 1) / fpw, cap = 256L * 4 * 2;
+            pss_time_begin(ctx);
+            pss_kernel_begin(ctx, "k_spectrum");
+            hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(256), lds, PSS_STREAM(ctx),
+                               reinterpret_cast<const float2 *>(d_iq), d_db, tw, win, n_frames);
+            pss_kernel_end(ctx);
+            pss_time_end(ctx);
+            return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_lean launch");
+        };
+        if (n_fft == 1024) return go(pss_xl::k_spectrum_lean<2, true>, pss_xl::CfgL<2>::LDS, pss_xl::CfgL<2>::FPW);
+        return go(pss_xl::k_spectrum_lean<3, true>, pss_xl::CfgL<3>::LDS, pss_xl::CfgL<3>::FPW);
+    }
     // register-resident radix-16 kernel for the sizes that fit one workgroup (256 <= N <= 4096)
     switch (n_fft) {
     case 256: return launch_r16<0, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);

@@ -36,6 +36,18 @@ def test_spectrum_vs_golden(golden, n):
     assert np.all(rel_err(db, ref)[big] <= 1e-4)
     assert np.all(np.abs(db - ref)[~big] <= 1e-6)
     assert np.max(np.abs(db - ref)) < 2e-5  # in practice: float32 rounding of the output only
+    if n in (1024, 2048):   # the opt-in 112-VGPR kernel ("fft_lean") against the same golden
+        e = G.engine()
+        e.set_option("fft_lean", 1)
+        try:
+            db1 = G.spectrum(iq)
+            rng = np.random.default_rng(n)
+            many = (rng.standard_normal((1031, n)) + 1j * rng.standard_normal((1031, n))).astype(np.complex64)   # ragged: 1031 frames
+            a = G.spectrum(many)
+        finally:
+            e.set_option("fft_lean", 0)
+        assert np.all(rel_err(db1, ref)[big] <= 1e-4) and np.all(np.abs(db1 - ref)[~big] <= 1e-6) and np.max(np.abs(db1 - ref)) < 2e-5
+        assert np.max(np.abs(a - G.spectrum(many))) < 2e-5
     if n == 4096:       # the three-stage kernel with complex exchanges (the default until round 2) against the same golden
         e = G.engine()
         e.set_option("fft_xl4096", 0)
