@@ -1,4 +1,4 @@
-"""Multi-process (world_size 2 and 3, gloo, CPU) tests of the frame-sharding layer used for N > 1 GPUs."""
+"""Multi-process (world_size 2, 3 and 8, gloo, CPU) tests of the frame-sharding layer used for N > 1 GPUs."""
 import os
 import socket
 
@@ -78,7 +78,7 @@ def _worker(rank, world, port, n_slices, n_fft, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_scan_equals_single_rank(world):
     n_slices, n_fft = 7, 2048          # 7 slices over 2/3 ranks: uneven blocks exercise the padding
     ctx = mp.get_context("spawn")
@@ -123,7 +123,7 @@ def _halo_worker(rank, world, port, n_rows, halo, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_rows", [(2, 40), (3, 40), (3, 8)])
+@pytest.mark.parametrize("world,n_rows", [(2, 40), (3, 40), (3, 8), (8, 100), (8, 9)])
 def test_halo_exchange_feeds_ring_accumulators(world, n_rows):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
