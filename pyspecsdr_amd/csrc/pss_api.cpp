@@ -144,6 +144,10 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     if (ctx->scratch_iqc) hipFree(ctx->scratch_iqc);
     if (ctx->d_hann) hipFree(ctx->d_hann);
     if (ctx->d_hann_short) hipFree(ctx->d_hann_short);
+    if (ctx->st_up) hipStreamDestroy(ctx->st_up);
+    if (ctx->st_dn) hipStreamDestroy(ctx->st_dn);
+    for (auto &e : ctx->st_ev) if (e) hipEventDestroy(e);
+    for (auto &b : ctx->st_buf) if (b) hipFree(b);
     if (ctx->scratch_scan) hipFree(ctx->scratch_scan);
     if (ctx->scratch_pk) hipFree(ctx->scratch_pk);
     if (ctx->scratch_win) hipFree(ctx->scratch_win);
@@ -486,6 +490,33 @@ extern "C" void pss_host_free(void *p)
     if (p) hipHostFree(p);
 }
 
+// Streaming resources of a context: created on first use, grown when a capture needs more, released by pss_destroy.
+static int stream_res(pss_ctx *ctx)
+{
+    if (!ctx->st_up) PSS_HIP(ctx, hipStreamCreateWithFlags(&ctx->st_up, hipStreamNonBlocking));
+    if (!ctx->st_dn) PSS_HIP(ctx, hipStreamCreateWithFlags(&ctx->st_dn, hipStreamNonBlocking));
+    for (auto &e : ctx->st_ev)
+        if (!e) PSS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return PSS_OK;
+}
+static int stream_buf(pss_ctx *ctx, int slot, size_t bytes, void **out)
+{
+    if (ctx->st_cap[slot] < bytes) {
+        if (ctx->st_buf[slot]) { PSS_HIP(ctx, hipFree(ctx->st_buf[slot])); ctx->st_buf[slot] = nullptr; ctx->st_cap[slot] = 0; }
+        PSS_HIP(ctx, hipMalloc(&ctx->st_buf[slot], bytes));
+        ctx->st_cap[slot] = bytes;
+    }
+    *out = ctx->st_buf[slot];
+    return PSS_OK;
+}
+// every queued copy / kernel of a capture has finished (also on the error paths: the caller's host buffers must not be in use)
+static void stream_drain(pss_ctx *ctx)
+{
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->st_up) hipStreamSynchronize(ctx->st_up);
+    if (ctx->st_dn) hipStreamSynchronize(ctx->st_dn);
+}
+
 extern "C" int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
                                          float *h_db, int16_t *h_pcm)
 {
@@ -498,38 +529,23 @@ extern "C" int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n
     if (chunk_frames > n_frames) chunk_frames = n_frames;
     const size_t iq_b = (size_t)chunk_frames * n * 2 * sizeof(float), db_b = (size_t)chunk_frames * n * sizeof(float),
                  pcm_b = (size_t)chunk_frames * n_out * 2 * sizeof(int16_t);
-    hipStream_t s_up = nullptr, s_dn = nullptr;
-    hipEvent_t up_done[2] = {nullptr, nullptr}, cmp_done[2] = {nullptr, nullptr}, dn_done[2] = {nullptr, nullptr};
-    void *d_iq[2] = {nullptr, nullptr}, *d_db[2] = {nullptr, nullptr}, *d_pcm[2] = {nullptr, nullptr};
-    int rc = PSS_OK;
-    auto cleanup = [&]() {
-        hipStreamSynchronize(ctx->stream);
-        if (s_up) { hipStreamSynchronize(s_up); hipStreamDestroy(s_up); }
-        if (s_dn) { hipStreamSynchronize(s_dn); hipStreamDestroy(s_dn); }
-        for (int i = 0; i < 2; i++) {
-            if (up_done[i]) hipEventDestroy(up_done[i]);
-            if (cmp_done[i]) hipEventDestroy(cmp_done[i]);
-            if (dn_done[i]) hipEventDestroy(dn_done[i]);
-            if (d_iq[i]) hipFree(d_iq[i]);
-            if (d_db[i]) hipFree(d_db[i]);
-            if (d_pcm[i]) hipFree(d_pcm[i]);
-        }
-    };
+    int rc = stream_res(ctx);
+    if (rc) return rc;
+    hipStream_t s_up = ctx->st_up, s_dn = ctx->st_dn;
+    hipEvent_t *up_done = ctx->st_ev, *cmp_done = ctx->st_ev + 2, *dn_done = ctx->st_ev + 4;
+    void *d_iq[2], *d_db[2], *d_pcm[2];
+    for (int i = 0; i < 2; i++) {
+        if (!rc) rc = stream_buf(ctx, 0 + i, iq_b, &d_iq[i]);
+        if (!rc) rc = stream_buf(ctx, 2 + i, db_b, &d_db[i]);
+        if (!rc) rc = stream_buf(ctx, 4 + i, pcm_b, &d_pcm[i]);
+    }
+    if (rc) return rc;
+    auto cleanup = [&]() { stream_drain(ctx); };
 #define STREAM_HIP(call)                                          \
     do {                                                          \
         rc = pss_hip_check(ctx, (call), #call);                   \
         if (rc) { cleanup(); return rc; }                         \
     } while (0)
-    STREAM_HIP(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
-    STREAM_HIP(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
-        STREAM_HIP(hipEventCreateWithFlags(&up_done[i], hipEventDisableTiming));
-        STREAM_HIP(hipEventCreateWithFlags(&cmp_done[i], hipEventDisableTiming));
-        STREAM_HIP(hipEventCreateWithFlags(&dn_done[i], hipEventDisableTiming));
-        STREAM_HIP(hipMalloc(&d_iq[i], iq_b));
-        STREAM_HIP(hipMalloc(&d_db[i], db_b));
-        STREAM_HIP(hipMalloc(&d_pcm[i], pcm_b));
-    }
     const long n_chunks = (n_frames + chunk_frames - 1) / chunk_frames;
     for (long k = 0; k < n_chunks; k++) {
         const int b = (int)(k & 1);
@@ -587,49 +603,29 @@ extern "C" int pss_h_stream_display_nfm(pss_ctx *ctx, const float *h_iq, long n_
     const size_t iq_b = (size_t)chunk_frames * n * 2 * sizeof(float), db_b = (size_t)chunk_frames * n * sizeof(float),
                  post_b = (size_t)chunk_frames * m * sizeof(float), pcm_b = (size_t)chunk_frames * n_out * 2 * sizeof(int16_t),
                  line_b = (size_t)chunk_frames * disp_w;
-    hipStream_t s_up = nullptr, s_dn = nullptr;
-    hipEvent_t up_done[2] = {nullptr, nullptr}, cmp_done[2] = {nullptr, nullptr}, dn_done[2] = {nullptr, nullptr};
-    void *d_iq[2] = {nullptr, nullptr}, *d_db[2] = {nullptr, nullptr}, *d_pcm[2] = {nullptr, nullptr}, *d_la[2] = {nullptr, nullptr},
-         *d_lb[2] = {nullptr, nullptr};
+    int rc = stream_res(ctx);
+    if (rc) return rc;
+    hipStream_t s_up = ctx->st_up, s_dn = ctx->st_dn;
+    hipEvent_t *up_done = ctx->st_ev, *cmp_done = ctx->st_ev + 2, *dn_done = ctx->st_ev + 4;
+    void *d_iq[2], *d_db[2], *d_pcm[2], *d_la[2], *d_lb[2] = {nullptr, nullptr};
     void *d_post = nullptr, *d_ext = nullptr;   // post rows of the chunk in flight; [lo | hi] x (n_halo + n_frames)
-    int rc = PSS_OK;
-    auto cleanup = [&]() {
-        hipStreamSynchronize(ctx->stream);
-        if (s_up) { hipStreamSynchronize(s_up); hipStreamDestroy(s_up); }
-        if (s_dn) { hipStreamSynchronize(s_dn); hipStreamDestroy(s_dn); }
-        for (int i = 0; i < 2; i++) {
-            if (up_done[i]) hipEventDestroy(up_done[i]);
-            if (cmp_done[i]) hipEventDestroy(cmp_done[i]);
-            if (dn_done[i]) hipEventDestroy(dn_done[i]);
-            if (d_iq[i]) hipFree(d_iq[i]);
-            if (d_db[i]) hipFree(d_db[i]);
-            if (d_pcm[i]) hipFree(d_pcm[i]);
-            if (d_la[i]) hipFree(d_la[i]);
-            if (d_lb[i]) hipFree(d_lb[i]);
-        }
-        if (d_post) hipFree(d_post);
-        if (d_ext) hipFree(d_ext);
-    };
+    const size_t n_ext = (size_t)n_halo + (size_t)n_frames;
+    for (int i = 0; i < 2; i++) {
+        if (!rc) rc = stream_buf(ctx, 0 + i, iq_b, &d_iq[i]);
+        if (!rc) rc = stream_buf(ctx, 2 + i, db_b, &d_db[i]);
+        if (!rc) rc = stream_buf(ctx, 4 + i, pcm_b, &d_pcm[i]);
+        if (!rc) rc = stream_buf(ctx, 6 + i, line_b, &d_la[i]);
+        if (!rc && mode == 0) rc = stream_buf(ctx, 8 + i, line_b, &d_lb[i]);
+    }
+    if (!rc) rc = stream_buf(ctx, 10, post_b, &d_post);
+    if (!rc) rc = stream_buf(ctx, 11, 2 * n_ext * sizeof(float), &d_ext);
+    if (rc) return rc;
+    auto cleanup = [&]() { stream_drain(ctx); };
 #define STREAM_HIP(call)                                          \
     do {                                                          \
         rc = pss_hip_check(ctx, (call), #call);                   \
         if (rc) { cleanup(); return rc; }                         \
     } while (0)
-    STREAM_HIP(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
-    STREAM_HIP(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
-        STREAM_HIP(hipEventCreateWithFlags(&up_done[i], hipEventDisableTiming));
-        STREAM_HIP(hipEventCreateWithFlags(&cmp_done[i], hipEventDisableTiming));
-        STREAM_HIP(hipEventCreateWithFlags(&dn_done[i], hipEventDisableTiming));
-        STREAM_HIP(hipMalloc(&d_iq[i], iq_b));
-        STREAM_HIP(hipMalloc(&d_db[i], db_b));
-        STREAM_HIP(hipMalloc(&d_pcm[i], pcm_b));
-        STREAM_HIP(hipMalloc(&d_la[i], line_b));
-        if (mode == 0) STREAM_HIP(hipMalloc(&d_lb[i], line_b));
-    }
-    STREAM_HIP(hipMalloc(&d_post, post_b));
-    const size_t n_ext = (size_t)n_halo + (size_t)n_frames;
-    STREAM_HIP(hipMalloc(&d_ext, 2 * n_ext * sizeof(float)));
     float *d_lo = reinterpret_cast<float *>(d_ext), *d_hi = d_lo + n_ext;
     if (n_halo) {
         STREAM_HIP(hipMemcpyAsync(d_lo, h_halo_lo, sizeof(float) * n_halo, hipMemcpyHostToDevice, ctx->stream));

@@ -59,6 +59,12 @@ struct pss_ctx {
     size_t scratch_win_bytes = 0;
     float *d_hann = nullptr;       // pss_classify: scipy's periodic Hann window (1024, float32) and sum(win * win)
     float hann_sum = 0.0f;
+    // streaming entry points (pss_h_stream_*): copy streams, events and the two device buffer sets, kept across calls
+    // (creating and freeing them per capture cost ~2 ms of a 17 ms capture)
+    hipStream_t st_up = nullptr, st_dn = nullptr;
+    hipEvent_t st_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // up_done[2], cmp_done[2], dn_done[2]
+    void *st_buf[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t st_cap[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float *d_hann_short = nullptr;  // the same for reads shorter than 1024 samples (window length = read length hann_short_n)
     float hann_short_sum = 0.0f;
     int hann_short_n = 0;

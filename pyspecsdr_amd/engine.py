@@ -284,7 +284,7 @@ class Engine:
             self.lib.pss_host_free(p)
 
     def stream_display_nfm(self, h_iq, fs, chunk_frames, mode="waterfall", window=None, disp_h=36, disp_w=112, halo=None,
-                           want_db=False):
+                           want_db=False, out=None):
         """Stream a host capture (complex64 [n_frames, n], pinned for overlap) and get back, per frame, the display
         accumulator's newest line and the int16 PCM (BASELINE configs[4]).  mode "waterfall": lines = (glyph, colour),
         history 30; "persistence": lines = (y,), history 10.  halo: (lo, hi) float32 arrays of the rows preceding the
@@ -294,11 +294,18 @@ class Engine:
         m = 0 if mode == "waterfall" else 1
         window = (30 if m == 0 else 10) if window is None else int(window)
         n_out = self.demod_out_len(L.MODE_NFM, n, fs)
-        la = np.empty((nf, disp_w), np.int8)
-        lb = np.empty((nf, disp_w), np.int8) if m == 0 else None
-        pcm = np.empty((nf, n_out, 2), np.int16)
-        db = np.empty((nf, n), np.float32) if want_db else None
-        lo, hi = np.empty(nf, np.float32), np.empty(nf, np.float32)
+        # out: a previous call's result dict to write into again (pass arrays from pinned_empty() to keep the downloads
+        # asynchronous: a copy into pageable memory is staged by the runtime and blocks the pipeline)
+        if out is not None:
+            la, lb = (out["lines"] + (None,))[:2]
+            pcm, db, lo, hi = out["pcm"], out.get("db"), out["row_lo"], out["row_hi"]
+            assert la.shape == (nf, disp_w) and pcm.shape == (nf, n_out, 2) and len(lo) == nf and len(hi) == nf
+        else:
+            la = np.empty((nf, disp_w), np.int8)
+            lb = np.empty((nf, disp_w), np.int8) if m == 0 else None
+            pcm = np.empty((nf, n_out, 2), np.int16)
+            db = np.empty((nf, n), np.float32) if want_db else None
+            lo, hi = np.empty(nf, np.float32), np.empty(nf, np.float32)
         hl = hh = None
         n_halo = 0
         if halo is not None and len(halo[0]):

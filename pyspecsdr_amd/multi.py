@@ -110,17 +110,18 @@ class ShardedScanner:
 
 
 def sharded_stream_display(engine, h_iq_local, fs, chunk_frames, mode="waterfall", window=None, disp_h=36, disp_w=112, group=None,
-                           gather_dst=None):
+                           gather_dst=None, out=None):
     """Every rank streams its block of a capture (h_iq_local: complex64 [count_r][n], pinned) and ends up with the display
     lines + PCM of its frames, exactly as one rank streaming the whole capture would produce them.
 
+    out: a result dict of Engine.stream_display_nfm to write into (arrays from Engine.pinned_empty keep the downloads asynchronous).
     gather_dst=None: results stay on the ranks (each writes its part of the FIFO / screen log); an int gathers
     (lines..., pcm) to that rank over the process group (one packed message per rank) and returns them in frame order
     there, None elsewhere.  Returns (lines tuple, pcm) of this rank's block otherwise.
     """
     world, rank = _world_rank(group)
     window = (30 if mode == "waterfall" else 10) if window is None else int(window)
-    res = engine.stream_display_nfm(h_iq_local, fs, chunk_frames, mode=mode, window=window, disp_h=disp_h, disp_w=disp_w)
+    res = engine.stream_display_nfm(h_iq_local, fs, chunk_frames, mode=mode, window=window, disp_h=disp_h, disp_w=disp_w, out=out)
     lines, pcm = res["lines"], res["pcm"]
     if world > 1:
         # extremes of the rows preceding this block: 8 bytes per row from the left neighbour(s), all messages posted at once

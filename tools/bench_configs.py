@@ -96,6 +96,17 @@ def cfg5stream():
         dt = (time.perf_counter() - t0) / reps
         res.append({"chunk_frames": chunk, "dB_rows_downloaded": with_db, "wall_ms": round(dt * 1e3, 2),
                     "samples_per_s": nf * n / dt, "h2d_GBs": nf * n * 8 / dt / 1e9})
+    # the same capture through the display pipeline: per frame a waterfall line + PCM come back (BASELINE configs[4])
+    outp = {"lines": (eng.pinned_empty((nf, 112), np.int8), eng.pinned_empty((nf, 112), np.int8)), "pcm": h_pcm,
+            "row_lo": eng.pinned_empty((nf,), np.float32), "row_hi": eng.pinned_empty((nf,), np.float32)}
+    for chunk in (4096, 8192, 16384):
+        eng.stream_display_nfm(h_iq, fs, chunk, out=outp)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.stream_display_nfm(h_iq, fs, chunk, out=outp)
+        dt = (time.perf_counter() - t0) / 3
+        res.append({"call": "stream_display_nfm", "chunk_frames": chunk, "wall_ms": round(dt * 1e3, 2), "samples_per_s": nf * n / dt,
+                    "h2d_GBs": nf * n * 8 / dt / 1e9})
     return {"config": "cfg5 streamed: 48828 x 2048 @10 MS/s from pinned host memory", "runs": res}
 
 

@@ -43,13 +43,18 @@ def cfg5(args, eng, dev, world, rank, use_dist, fence, maxr):
     for f0 in range(0, count, 64):
         h[f0:f0 + 64] = base[:min(64, count - f0)]
     res = {"config": "cfg5", "n_gpus": world, "frames": n_frames, "frames_per_rank": count, "n_fft": n, "chunk_frames": 4096}
+    n_out = eng.demod_out_len(0, n, fs)
+    pin = lambda shape, dt: eng.pinned_empty(shape, dt)      # results land in pinned host memory: the downloads stay asynchronous
+    outs = {"persistence": {"lines": (pin((count, 112), np.int8),), "pcm": pin((count, n_out, 2), np.int16),
+                            "row_lo": pin((count,), np.float32), "row_hi": pin((count,), np.float32)}}
+    outs["waterfall"] = dict(outs["persistence"], lines=(outs["persistence"]["lines"][0], pin((count, 112), np.int8)))
     for mode in ("persistence", "waterfall"):
-        sharded_stream_display(eng, h, fs, 4096, mode=mode)            # warm-up (buffers, plans)
+        sharded_stream_display(eng, h, fs, 4096, mode=mode, out=outs[mode])            # warm-up (buffers, plans)
         fence()
         t0 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            sharded_stream_display(eng, h, fs, 4096, mode=mode)
+            sharded_stream_display(eng, h, fs, 4096, mode=mode, out=outs[mode])
         fence()
         el = maxr(time.perf_counter() - t0) / reps
         res[f"{mode}_s_per_capture"] = el
