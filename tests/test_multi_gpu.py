@@ -190,3 +190,40 @@ def test_sharded_stream_equals_single_rank(world, mode):
         assert p.exitcode == 0
     assert len(lines) == len(want["lines"]) and all(np.array_equal(a, b) for a, b in zip(lines, want["lines"]))
     assert np.array_equal(pcm, want["pcm"])
+
+
+def test_two_contexts_in_one_process_interleaved():
+    """Two library contexts used alternately from one thread: every entry point runs on ITS context's device and
+    scratch, whatever the calling thread's current device is.  With two visible GPUs the second context lives on cuda:1 while
+    the thread's current device stays cuda:0; on a one-GPU box both live on cuda:0 (separate streams, scratch, tables)."""
+    from pyspecsdr_amd.engine import Engine
+    ngpu = torch.cuda.device_count()
+    dev_b = 1 if ngpu >= 2 else 0
+    torch.cuda.set_device(0)
+    a, b = Engine(0), Engine(dev_b)
+    rng = np.random.default_rng(31)
+    nf, n, fs = 300, 1024, 2.4e6
+    iq = (0.4 * np.exp(2j * np.pi * np.cumsum(rng.standard_normal((nf, n)) * 0.05, axis=1)) +
+          0.03 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
+    h = torch.from_numpy(iq.view(np.float32).reshape(nf, n, 2))
+    xa, xb = h.to("cuda:0"), h.to(f"cuda:{dev_b}")
+    torch.cuda.synchronize(0); torch.cuda.synchronize(dev_b)
+    n_out = a.demod_out_len(0, n, fs)
+    out = {}
+    for name, e, x, dev in (("a", a, xa, 0), ("b", b, xb, dev_b)):
+        d = f"cuda:{dev}"
+        out[name] = dict(db=torch.empty((nf, n), dtype=torch.float32, device=d), pcm=torch.empty((nf, n_out, 2), dtype=torch.int16, device=d),
+                         pw=torch.empty((nf,), dtype=torch.float32, device=d), post=torch.empty((nf, n - 4), dtype=torch.float32, device=d))
+    assert torch.cuda.current_device() == 0
+    for _ in range(2):                       # interleave: each call would trample the other's scratch if it were shared
+        a.spectrum_nfm(xa, nf, n, fs, out["a"]["db"], out["a"]["pcm"])
+        b.power_db(xb, nf, n, out["b"]["pw"])
+        b.spectrum_nfm(xb, nf, n, fs, out["b"]["db"], out["b"]["pcm"])
+        a.spectrum_post(out["a"]["db"], nf, n, out["a"]["post"])
+        a.power_db(xa, nf, n, out["a"]["pw"])
+        b.spectrum_post(out["b"]["db"], nf, n, out["b"]["post"])
+    a.sync(); b.sync()
+    assert torch.cuda.current_device() == 0          # the calls restored the caller's device
+    for k in out["a"]:
+        assert torch.equal(out["a"][k].cpu(), out["b"][k].cpu()), k
+    b.close(); a.close()
