@@ -65,6 +65,8 @@ int pss_device_count(void);
  *                              path sorts (longer rows: radix select)
  *   "fft_split" (-1 = auto)    1 / 0: force / forbid the component-wise LDS exchanges of the register FFT (auto: N = 256)
  *   "fft_big_scratch" (0)      1: N = 8192 / 16384 on the scratch-based pre-pass kernel instead of the four-stage register kernel
+ *   "scan_exact" (1)           0: scanner slices (pss_scan, pss_scan_threshold) get their dB values from compute_fft's float64 / hardware-log2
+ *                              evaluation (1e-4 relative; 30 % faster at 8192 x 4096) instead of NumPy's float32 chain bit for bit
  *   "fft_lean" (0)             1: N = 1024 / 2048 spectra on the 112-VGPR component-wise-exchange kernel (k_spectrum_lean) instead of
  *                              k_spectrum_r16 (same results within the dB tolerance, not bit-identical: twiddle powers by product chains)
  *   "fft_xl4096" (1)           0: N = 4096 (spectrum and scanner slice) on the three-stage kernel with complex LDS exchanges
@@ -128,7 +130,10 @@ int pss_row_extremes_f64(pss_ctx *ctx, const double *d_rows, long n_rows, int le
 /* Inline scanner slice (pyspecsdr.py:2542-2552): unwindowed FFT, dB, peak, 20-dB-down bin count,
  * bandwidth = count * fs / n_fft.  d_db float32 [n][n_fft] (may be NULL), d_peak float32 [n],
  * d_bw float64 [n], d_count int32 [n] (may be NULL).  n_fft: power of two in [16, 16384] (one kernel), or any other
- * length in [2, 524288] (Bluestein + a reduction kernel). */
+ * length in [2, 524288] (Bluestein + a reduction kernel).  The dB values are the reference's float32 values bit for bit (so are
+ * peak, count and bandwidth): np.fft.fft on complex64 is a double transform rounded to complex64 (NumPy 2.2), everything behind
+ * it float32 arithmetic that is modelled exactly; a bin can differ only if its float64 component lies within ~1e-16 relative of a
+ * float32 rounding boundary (option "scan_exact" = 0: the 1e-4-relative evaluation of pss_spectrum_db, 30 % faster). */
 int pss_scan(pss_ctx *ctx, const float *d_iq, long n_slices, int n_fft, double fs, float *d_db, float *d_peak,
              double *d_bw, int32_t *d_count);
 /* The sweep driver's per-read arithmetic (scan_frequencies, pyspecsdr.py:1049-1057): unwindowed fft of a read of

@@ -595,8 +595,12 @@ float pss_o_power_db(const float *iq, int n)
     return 10.0f * pss_o_log10f_ref(t);
 }
 
-/* inline scanner — pyspecsdr.py:2542-2552.  NumPy >= 2 keeps complex64 through np.fft.fft, so the
- * reference's dB row is float32; restated in float64 and rounded (tolerance-checked). */
+/* inline scanner — pyspecsdr.py:2542-2552.  np.fft.fft on complex64 returns complex64, but NumPy 2.2 computes it in DOUBLE
+ * and rounds the result (checked: identical bits to fft(x.astype(complex128)).astype(complex64) for n = 8 .. 240000), so the
+ * spectrum is round_f32(double transform) and everything behind it is float32: np.abs(complex64) (pss_o_cabsf), ** 2,
+ * + 1e-10 (weak scalar -> float32), np.log10 float32 (SVML, pss_o_log10f_np), * 10.  This restatement's own float64
+ * transform differs from pocketfft's by ~1e-16 relative, which the rounding to float32 hides except when a component sits
+ * within that distance of a rounding boundary (~1e-8 of the values). */
 int pss_o_scan_slice(const float *iq, int n, double fs, float *db, float *peak, double *bw)
 {
     double *re = (double *)malloc(sizeof(double) * n), *im = (double *)malloc(sizeof(double) * n);
@@ -605,9 +609,9 @@ int pss_o_scan_slice(const float *iq, int n, double fs, float *db, float *peak, 
     float pk = -INFINITY;
     for (int k = 0; k < n; k++) {
         int src = (k + (n + 1) / 2) % n;
-        float a = (float)hypot(re[src], im[src]);
+        float a = pss_o_cabsf((float)re[src], (float)im[src]);
         float p = a * a + 1e-10f;
-        db[k] = 10.0f * pss_o_log10f_ref(p);
+        db[k] = 10.0f * pss_o_log10f_np(p);
         if (db[k] > pk) pk = db[k];
     }
     int count = 0;

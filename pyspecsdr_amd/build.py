@@ -19,7 +19,7 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 # pss_demod.hip carries the bit-exactness contract: no implicit fused multiply-adds.
 UNITS = [
-    ("pss_fft.hip", []),
+    ("pss_fft.hip", ["-fhip-fp32-correctly-rounded-divide-sqrt"]),   # the scanner rows use NumPy's float32 abs (IEEE sqrt / divide)
     ("pss_demod.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("pss_api.cpp", ["-x", "hip"]),
     ("pss_design.cpp", ["-x", "hip", "-ffp-contract=off"]),

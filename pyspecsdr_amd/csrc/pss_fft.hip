@@ -122,7 +122,7 @@ __global__ __launch_bounds__(TPB) void k_spectrum(const float2 *__restrict__ iq,
                                                   const double2 *__restrict__ tw, const double *__restrict__ win,
                                                   int N, int logNsub, int R, long n_frames, int staged,
                                                   float *__restrict__ peak, double *__restrict__ bw,
-                                                  int *__restrict__ count, double bin_hz)
+                                                  int *__restrict__ count, double bin_hz, int scan_exact)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int Nsub = 1 << logNsub;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(TPB) void k_spectrum(const float2 *__restrict__ iq,
                 double pw = v.x * v.x + v.y * v.y + 1e-10;
                 int k = R * digit_reverse(p, logNsub) + r;
                 int o = (k + (N >> 1)) & (N - 1);  // fftshift
-                float d = db_of(pw);
+                float d = (SCAN && scan_exact) ? pss::scan_db_np(v.x, v.y) : db_of(pw);   // scanner slice: NumPy's complex64 spectrum + float32 chain
                 if (staged) stage[o] = d;
                 else if (out) out[o] = d;
             }
@@ -627,7 +627,7 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_spectrum");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db, tw,
-                       win, n_frames, d_peak, d_bw, d_count, bin_hz);
+                       win, n_frames, d_peak, d_bw, d_count, bin_hz, ctx->scan_exact ? 1 : 0);
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_r16 launch");
@@ -687,7 +687,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
             pss_time_begin(ctx);
             pss_kernel_begin(ctx, "k_spectrum");
             hipLaunchKernelGGL(kern, dim3((unsigned)(n_frames < cap ? n_frames : cap)), dim3(threads), lds, PSS_STREAM(ctx),
-                               reinterpret_cast<const float2 *>(d_iq), d_db, tw, win, n_frames, d_peak, d_bw, d_count, bin_hz);
+                               reinterpret_cast<const float2 *>(d_iq), d_db, tw, win, n_frames, d_peak, d_bw, d_count, bin_hz, ctx->scan_exact ? 1 : 0);
             pss_kernel_end(ctx);
             pss_time_end(ctx);
             return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_xl launch");
@@ -770,7 +770,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_spectrum_generic");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db, tw,
-                       win, n_fft, logNsub, R, n_frames, staged, d_peak, d_bw, d_count, bin_hz);
+                       win, n_fft, logNsub, R, n_frames, staged, d_peak, d_bw, d_count, bin_hz, ctx->scan_exact ? 1 : 0);
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_spectrum launch");
@@ -842,14 +842,14 @@ struct BsStoreC {
     __device__ void operator()(long f, size_t k, double2 X) const { A[(size_t)f * M + k] = X; }
 };
 struct BsStoreDb {
-    float *db; const double2 *chirp; int n, shift; double inv_m;
+    float *db; const double2 *chirp; int n, shift; double inv_m; bool np32;   // np32: the scanner's float32 chain (scan_db_np)
     __device__ void operator()(long f, size_t k, double2 X) const
     {
         if (k >= (size_t)n) return;
         const double2 z = pss_r16::cmul(make_double2(X.x * inv_m, -X.y * inv_m), chirp[k]);
         int o = (int)k + shift;                      // np.fft.fftshift: out[(k + n // 2) % n] = X[k]
         if (o >= n) o -= n;
-        db[(size_t)f * n + o] = pss_r16::db_of(z.x * z.x + z.y * z.y + 1e-10);
+        db[(size_t)f * n + o] = np32 ? pss::scan_db_np(z.x, z.y) : pss_r16::db_of(z.x * z.x + z.y * z.y + 1e-10);
     }
 };
 
@@ -956,7 +956,7 @@ int bluestein_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n, bool win
         if (!r) r = bs_pass1(ctx, BsLoadConv{A, p->d_B, M}, tw, Y, NS, nf);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_bluestein_p2");
-        if (!r) r = bs_pass2(ctx, Y, BsStoreDb{d_db + (size_t)f0 * n, p->d_chirp, n, n / 2, 1.0 / (double)M}, tw, NS, nf);
+        if (!r) r = bs_pass2(ctx, Y, BsStoreDb{d_db + (size_t)f0 * n, p->d_chirp, n, n / 2, 1.0 / (double)M, !window && ctx->scan_exact}, tw, NS, nf);
         pss_kernel_end(ctx);
     }
     pss_time_end(ctx);

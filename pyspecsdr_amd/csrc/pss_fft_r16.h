@@ -14,6 +14,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "pss_npf32.h"
+
 namespace pss_r16 {
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -225,7 +227,7 @@ template <int LOG_R3, bool SCAN, bool SPLIT = false, bool PREFETCH = false>
 __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__ iq, float *__restrict__ db,
                                                       const double2 *__restrict__ tw, const double *__restrict__ win,
                                                       long n_frames, float *__restrict__ peak, double *__restrict__ bw,
-                                                      int *__restrict__ count, double bin_hz)
+                                                      int *__restrict__ count, double bin_hz, int scan_exact)
 {
     using C = Cfg<LOG_R3>;
     constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = C::FPW;
@@ -275,7 +277,8 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
         float lmax = -INFINITY;
         float dbv[16];
         auto emit = [&](int i, int k, double2 X) {
-            float d = db_of(X.x * X.x + X.y * X.y + 1e-10);
+            // compute_fft: float64 all the way, dB rounded to float32; scanner slice: NumPy's complex64 spectrum + float32 chain
+            float d = (SCAN && scan_exact) ? pss::scan_db_np(X.x, X.y) : db_of(X.x * X.x + X.y * X.y + 1e-10);
             if (out) out[(k + N / 2) & (N - 1)] = d;  // fftshift; T consecutive bins per store instruction
             dbv[i] = d;
             lmax = fmaxf(lmax, d);

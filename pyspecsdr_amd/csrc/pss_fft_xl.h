@@ -172,7 +172,7 @@ template <int LOG_R4, bool WINDOW, bool SCAN = false>
 __global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *__restrict__ iq, float *__restrict__ db,
                                                                   const double2 *__restrict__ tw, const double *__restrict__ win,
                                                                   long n_frames, float *__restrict__ peak, double *__restrict__ bw,
-                                                                  int *__restrict__ count, double bin_hz)
+                                                                  int *__restrict__ count, double bin_hz, int scan_exact)
 {
     using C = CfgX<LOG_R4>;
     constexpr int T = C::T, N = C::N, T2 = C::T2, R4 = C::R4;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *
         float *held = reinterpret_cast<float *>(ex);           // SCAN: this thread's 16 dB values at held[i * T + t]
         xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int i, int j, int k, double2 X) {
             // fftshift; bin 4096 k + T j + t: T consecutive bins per store instruction
-            const float d = pss_r16::db_of(X.x * X.x + X.y * X.y + 1e-10);
+            const float d = (SCAN && scan_exact) ? pss::scan_db_np(X.x, X.y) : pss_r16::db_of(X.x * X.x + X.y * X.y + 1e-10);
             buf_store_f32(ro, t * 4, ((4096 * k + T * j + N / 2) & (N - 1)) * 4, d);
             if (SCAN) { held[i * T + t] = d; lmax = fmaxf(lmax, d); }
         });

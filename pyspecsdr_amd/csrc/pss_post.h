@@ -14,6 +14,11 @@
 // extremes of the last 30 (10) rows, which then costs 8 bytes per row to look up instead of a pass over 30 rows.
 #pragma once
 #include <hip/hip_runtime.h>
+// From here to the end of the including unit (pss_fft.hip: this header, the display quantisers, the Bluestein functors) float
+// expressions are evaluated as written — no fused multiply-adds the reference's NumPy statements do not contain (np.convolve's
+// products and sums, the normalisation / interpolation arithmetic of the display code).  The transform kernels are defined
+// in the headers included BEFORE this one (pss_fft_r16.h, pss_fft_xl.h) and keep the unit's default contraction.
+#pragma clang fp contract(off)
 
 namespace pss_post {
 

@@ -9,6 +9,10 @@
 #include "pss_fft_r16.h"
 #include "pss_post.h"
 
+// the spectrum half of this kernel must produce k_spectrum_r16's bits: same contraction mode as pss_fft_r16.h (the post-process
+// half lives in pss_post.h's functions, which were defined under contract(off))
+#pragma clang fp contract(fast)
+
 namespace pss_sp {
 
 template <bool PREFETCH>
@@ -87,3 +91,5 @@ __global__ __launch_bounds__(256) void k_spectrum_post_1024(const float2 *__rest
 }
 
 }  // namespace pss_sp
+
+#pragma clang fp contract(off)   // back to pss_post.h's mode for the rest of the unit

@@ -1158,13 +1158,22 @@ def test_scanner(golden, n):
     e.sync()
     db, pk, bw, cnt = G.host(d_db), G.host(d_pk), G.host(d_bw), G.host(d_cnt)
     ref = g[f"db_{n}"]
-    assert np.all(np.abs(db - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0))
+    # every bit of the reference's float32 rows: np.fft.fft(complex64) is a double transform rounded to complex64 (NumPy 2.2), the
+    # rest float32 arithmetic modelled exactly (scan_db_np) — so peak, 20-dB-down count and bandwidth are the reference's too
+    assert np.array_equal(db.view(np.uint32), ref.view(np.uint32)), int((db.view(np.uint32) != ref.view(np.uint32)).sum())
+    assert np.array_equal(pk.view(np.uint32), g[f"peak_{n}"].astype(np.float32).view(np.uint32))
+    assert np.array_equal(cnt, g[f"count_{n}"].astype(cnt.dtype)) and np.array_equal(bw, g[f"bw_{n}"])
     for k in range(ns):
-        assert abs(pk[k] - g[f"peak_{n}"][k]) <= 1e-4 * abs(g[f"peak_{n}"][k])
-        near = int(np.sum(np.abs(ref[k] - (g[f"peak_{n}"][k] - 20)) < 2e-3))
-        assert abs(int(cnt[k]) - int(g[f"count_{n}"][k])) <= near
-        assert bw[k] == cnt[k] * (2.4e6 / n)
         assert pk[k] == db[k].max() and cnt[k] == int(np.sum(db[k] > pk[k] - np.float32(20)))  # self-consistent
+    if n == 4096:   # the other N = 4096 kernel produces the same rows
+        e.set_option("fft_xl4096", 0)
+        try:
+            d_db2 = G.empty((ns, n), torch.float32)
+            e.scan(G.dev(iq), ns, n, 2.4e6, d_db2, d_pk, d_bw, d_cnt)
+            e.sync()
+        finally:
+            e.set_option("fft_xl4096", 1)
+        assert np.array_equal(G.host(d_db2).view(np.uint32), ref.view(np.uint32))
 
 
 def test_lengths_that_are_not_a_power_of_two(golden):
@@ -1191,11 +1200,10 @@ def test_lengths_that_are_not_a_power_of_two(golden):
         e.sync()
         db, pk, bw, cnt = G.host(d_db), G.host(d_pk), G.host(d_bw), G.host(d_cnt)
         ref = g[f"sw_db_{n}"]
-        assert np.all(np.abs(db - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0)), n
+        assert np.array_equal(db.view(np.uint32), ref.view(np.uint32)), (n, int((db.view(np.uint32) != ref.view(np.uint32)).sum()))
+        assert np.array_equal(pk.view(np.uint32), g[f"sw_peak_{n}"].astype(np.float32).view(np.uint32)), n
+        assert np.array_equal(cnt, g[f"sw_count_{n}"].astype(cnt.dtype)) and np.array_equal(bw, g[f"sw_bw_{n}"]), n
         for k in range(ns):
-            assert abs(pk[k] - g[f"sw_peak_{n}"][k]) <= 1e-4 * abs(g[f"sw_peak_{n}"][k])
-            near = int(np.sum(np.abs(ref[k] - np.float32(thr)) < 2e-3))
-            assert abs(int(cnt[k]) - int(g[f"sw_count_{n}"][k])) <= near
             assert bw[k] == cnt[k] * (fs / n) and pk[k] == db[k].max() and cnt[k] == int(np.sum(db[k] > np.float32(thr)))
         # the per-read numbers alone (no dB rows handed back) are the same numbers
         d_pk2, d_cnt2 = G.empty((ns,), torch.float32), G.empty((ns,), torch.int32)
