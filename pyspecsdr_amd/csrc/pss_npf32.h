@@ -78,13 +78,42 @@ __device__ __forceinline__ float cabsf_np(float re, float im)
 // spectrum = np.fft.fft(complex64) — which NumPy 2.2 computes in DOUBLE and rounds to complex64 (identical bits to
 // fft(x.astype(complex128)).astype(complex64) for every length tried) — so: round the float64 bin to float32 components, then
 // float32 all the way (npy_hypotf form of np.abs, x * x, + float32(1e-10), SVML log10, * 10).
+// the four coefficient sets side by side: one 16-byte load per evaluation in the hot scanner epilogue
+static __constant__ uint4 L10_PACK[16] = {
+    {0xbdc9ae9bu, 0x3e13d888u, 0xbe5e5a9bu, 0x3ede5bd8u}, {0xbda6fcf4u, 0x3e10a87cu, 0xbe5e2677u, 0x3ede5b45u},
+    {0xbd8bac76u, 0x3e0b95c3u, 0xbe5d83f5u, 0x3ede57d8u}, {0xbd6bca30u, 0x3e057f0bu, 0xbe5c6016u, 0x3ede4eb1u},
+    {0xbd48a99bu, 0x3dfde038u, 0xbe5abd0bu, 0x3ede3d37u}, {0xbd2c0a9fu, 0x3df080d9u, 0xbe58a6fdu, 0x3ede2166u},
+    {0xbd1480dbu, 0x3de34c1eu, 0xbe562e02u, 0x3eddf9d9u}, {0xbd00faf2u, 0x3dd68333u, 0xbe5362f8u, 0x3eddc5bbu},
+    {0xbe823aa9u, 0x3dac6e8eu, 0xbe68e27cu, 0x3ede08edu}, {0xbe656348u, 0x3dd54a51u, 0xbe646747u, 0x3ede32e7u},
+    {0xbe4afbb9u, 0x3df30f40u, 0xbe619a73u, 0x3ede4967u}, {0xbe346895u, 0x3e04235du, 0xbe5ff05au, 0x3ede5490u},
+    {0xbe20ffffu, 0x3e0b7033u, 0xbe5f0570u, 0x3ede597fu}, {0xbe103a0bu, 0x3e102c90u, 0xbe5e92d0u, 0x3ede5b50u},
+    {0xbe01a91cu, 0x3e12ebadu, 0xbe5e662bu, 0x3ede5bcau}, {0xbde9e84eu, 0x3e141ff8u, 0xbe5e5c08u, 0x3ede5bd9u}};
+
 __device__ __forceinline__ float scan_db_np(double re, double im)
 {
 #pragma clang fp contract(off)
-    const float a = cabsf_np((float)re, (float)im);
+    // np.abs(complex64): cabsf_np without its early return (a select instead: the scanner evaluates this for every bin)
+    const float ar = fabsf((float)re), ai = fabsf((float)im);
+    const float mx = ar > ai ? ar : ai, mn = ar > ai ? ai : ar;
+    const float r = mn / mx;
+    const float h = sqrtf(__fmaf_rn(r, r, 1.0f));
+    const float a = mx == 0.0f ? 0.0f : mx * h;
     const float sq = a * a;                 // separate statements under contract(off): a fused a * a + 1e-10 would differ
     const float p = sq + 1e-10f;
-    return 10.0f * log10f_np(p);
+    // log10f_np for p >= 1e-10 (never zero, negative or denormal here); +inf and NaN pass through
+    const uint32_t b = f2u(p);
+    const uint32_t man = b & 0x7fffffu;
+    const bool up = man >= 0x400000u;
+    const uint32_t mb = (up ? (126u << 23) : (127u << 23)) | man;
+    const int k = (int)(b >> 23) - 127 + (up ? 1 : 0);
+    const uint4 c = L10_PACK[(mb >> 19) & 15u];
+    const float q = u2f(mb) - 1.0f;
+    float t = __fmaf_rn(u2f(c.x), q, u2f(c.y));
+    t = __fmaf_rn(t, q, u2f(c.z));
+    t = __fmaf_rn(t, q, u2f(c.w));
+    const float kl = (float)k * u2f(0x3e9a209bu);
+    const float lg = b >= 0x7f800000u ? p : __fmaf_rn(t, q, kl);
+    return 10.0f * lg;
 }
 
 }  // namespace pss
