@@ -36,6 +36,7 @@ def rnd_iq(n):
 
 bad = 0
 cnt = dict(ssb=0, fft=0, scan=0, bp=0, afsk=0, sg=0, wf=0, gw=0, sf=0, vec=0, ps=0)
+scan_bits = scan_vals = 0
 for it in range(150):
     n = int(rng.choice([64, 300, 1024, 2048, 4096, 16384]))
     fs = float(rng.choice([2.4e6, 1.024e6, 250e3]))
@@ -57,8 +58,10 @@ for it in range(150):
         spec = np.fft.fftshift(np.fft.fft(x)); pdb = 10 * np.log10(np.abs(spec) ** 2 + 1e-10); pk = np.max(pdb)
         mask = pdb > pk - 20; bw = np.sum(mask) * (fs / len(pdb))
         db, opk, obw, ocnt = O.scan_slice(x, fs); cnt['scan'] += 1
-        if not (abs(float(opk) - float(pk)) <= 2e-5 * max(1, abs(float(pk))) and abs(ocnt - int(np.sum(mask))) <= 2):
-            bad += 1; print('SCAN mismatch', n, pk, opk, np.sum(mask), ocnt)
+        nd = int((db.view(np.uint32) != pdb.astype(np.float32).view(np.uint32)).sum())   # rows: every bit (NaNs aside)
+        scan_bits += nd; scan_vals += len(db)
+        if not (pdb.dtype == np.float32 and nd == 0 and np.float32(opk).tobytes() == np.float32(pk).tobytes() and ocnt == int(np.sum(mask)) and obw == bw):
+            bad += 1; print('SCAN mismatch', n, pk, opk, np.sum(mask), ocnt, nd)
     # bandpass_filter + decode_afsk on audio-rate rows
     afs = float(rng.choice([22050.0, 48000.0]))
     m = int(rng.integers(50, 6000)); a = rng.standard_normal(m); a = a / np.max(np.abs(a))
@@ -132,3 +135,4 @@ for it in range(150):
     og = O.vector_cells(vs, H, W); cnt['vec'] += 1
     if not np.array_equal(g, og): bad += 1; print('VECTOR mismatch', H, W, int(np.sum(g != og)))
 print('cases', cnt, 'bad', bad)
+print('scanner rows: %d of %d float32 dB values differ' % (scan_bits, scan_vals))
