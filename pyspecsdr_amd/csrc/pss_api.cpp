@@ -192,6 +192,7 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "fft_xl4096")) { ctx->fft_xl4096 = value != 0; return PSS_OK; }
     if (!strcmp(key, "fft_lean")) { ctx->fft_lean = value; return PSS_OK; }
     if (!strcmp(key, "scan_exact")) { ctx->scan_exact = value != 0; return PSS_OK; }
+    if (!strcmp(key, "db_exact")) { ctx->db_exact = value != 0; return PSS_OK; }
     if (!strcmp(key, "pipe_overlap")) { ctx->pipe_overlap_mode = value; return PSS_OK; }
     if (!strcmp(key, "fuse_post")) { ctx->fuse_post = value != 0; return PSS_OK; }
     if (!strcmp(key, "post_legacy")) { ctx->post_legacy = value != 0; return PSS_OK; }

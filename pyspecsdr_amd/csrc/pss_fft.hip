@@ -28,6 +28,9 @@
 namespace {
 
 constexpr int TPB = 256;
+
+// wave-uniform switches of the spectrum kernels (pss_fft_r16.h FLAG_*)
+inline int spec_flags(const pss_ctx *ctx) { return (ctx->scan_exact ? pss_r16::FLAG_SCAN_EXACT : 0) | (ctx->db_exact ? pss_r16::FLAG_DB_EXACT : 0); }
 constexpr int LOG_NSUB_MAX = 12;  // 4096 points * 16 B = 64 KiB of LDS
 constexpr int STAGE_MAX_N = 16384;
 constexpr int PT = 1024;  // k_post threads per row
@@ -100,29 +103,14 @@ __device__ __forceinline__ int digit_reverse(int p, int logn)
     return k;
 }
 
-// 10*log10(pw), pw = |X|^2 + 1e-10 held in float64.  float32 log with a log1p branch around pw = 1 so
-// the RELATIVE error of the dB value stays ~1e-6 even where dB -> 0.
-__device__ __forceinline__ float db_of(double pw)
-{
-    // 10*log10(pw), pw = |X|^2 + 1e-10 held in float64, evaluated branch-free in float32:
-    //   far from 1 : hardware log2 of the float32-rounded value (relative error of the dB value ~1e-7);
-    //   near 1     : ln(1+d) = 2 atanh(d/(2+d)) as an odd series (|s| < 0.143: truncation 3e-10), which keeps the
-    //                RELATIVE error of the dB value ~1e-7 even where dB -> 0 and float32(pw) has lost d.
-    // (ocml log1pf was correct too, but a wavefront executes its ~115 instructions whenever any lane needs it.)
-    const float t = (float)(pw - 1.0);
-    const float far = 3.0102999566398120f * __log2f((float)pw);
-    const float s = t * __builtin_amdgcn_rcpf(2.0f + t);
-    const float s2 = s * s;
-    const float p = s * (2.0f + s2 * (0.66666667f + s2 * (0.4f + s2 * (0.28571429f + s2 * 0.22222222f))));
-    return fabsf(t) < 0.25f ? 4.342944819032518f * p : far;
-}
+using pss_r16::db_of;   // 10 log10(pw) to float64 accuracy, rounded once to float32 (pss_fft_r16.h)
 
-template <bool SCAN>
+template <bool SCAN, bool EXACT = false>
 __global__ __launch_bounds__(TPB) void k_spectrum(const float2 *__restrict__ iq, float *__restrict__ db,
                                                   const double2 *__restrict__ tw, const double *__restrict__ win,
                                                   int N, int logNsub, int R, long n_frames, int staged,
                                                   float *__restrict__ peak, double *__restrict__ bw,
-                                                  int *__restrict__ count, double bin_hz, int scan_exact)
+                                                  int *__restrict__ count, double bin_hz, int flags)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int Nsub = 1 << logNsub;
@@ -162,7 +150,9 @@ __global__ __launch_bounds__(TPB) void k_spectrum(const float2 *__restrict__ iq,
                 double pw = v.x * v.x + v.y * v.y + 1e-10;
                 int k = R * digit_reverse(p, logNsub) + r;
                 int o = (k + (N >> 1)) & (N - 1);  // fftshift
-                float d = (SCAN && scan_exact) ? pss::scan_db_np(v.x, v.y) : db_of(pw);   // scanner slice: NumPy's complex64 spectrum + float32 chain
+                float d;
+                if constexpr (SCAN) d = (flags & pss_r16::FLAG_SCAN_EXACT) ? pss::scan_db_np(v.x, v.y) : pss_r16::db_of_fast(pw);
+                else d = EXACT ? pss_r16::db_of_exact(pw) : pss_r16::db_of_fast(pw);   // scanner slice: NumPy's complex64 spectrum + float32 chain
                 if (staged) stage[o] = d;
                 else if (out) out[o] = d;
             }
@@ -612,7 +602,11 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     // next-frame prefetch (option "fft_prefetch", -1 = automatic), A/B in one process: N = 1024: 0.198 -> 0.185 ms (65536 frames),
     // 2048: 0.234 -> 0.226 ms; 512: no change; 4096: 0.27 -> 0.35 ms (274 VGPRs: one wavefront per SIMD); 256: the split kernel wins
     const bool prefetch = !split && (ctx->fft_prefetch >= 0 ? ctx->fft_prefetch != 0 : (LOG_R3 == 2 || LOG_R3 == 3));
-    auto kern = split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true, false>
+    // "db_exact" (compute_fft rows only): its own instantiations — split at N = 256, plain otherwise (the float64 evaluation and the
+    // prefetch registers do not fit together)
+    const bool exact = !SCAN && ctx->db_exact;
+    auto kern = exact ? (split ? pss_r16::k_spectrum_r16<LOG_R3, false, true, false, true> : pss_r16::k_spectrum_r16<LOG_R3, false, false, false, true>)
+                : split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true, false>
                 : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, true> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, false>;
     const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2) : C::LDS;
     if (lds > 64 * 1024)
@@ -627,7 +621,7 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_spectrum");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db, tw,
-                       win, n_frames, d_peak, d_bw, d_count, bin_hz, ctx->scan_exact ? 1 : 0);
+                       win, n_frames, d_peak, d_bw, d_count, bin_hz, spec_flags(ctx));
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_r16 launch");
@@ -650,7 +644,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     // N = 1024 / 2048 on the 112-VGPR kernel: opt-in ("fft_lean" = 1, or -1: only where the spectrum shares the machine with the NFM
     // backward pass).  Measured: alone 0.434 against 0.412 ms at 131072 x 1024, 0.513 against 0.540 ms at 65536 x 2048; inside the
     // bench step 0.326 against 0.303 ms — the wide kernel's slowdown beside the backward pass is not an occupancy effect
-    if (!SCAN && (n_fft == 1024 || n_fft == 2048) && (ctx->fft_lean > 0 || (ctx->fft_lean < 0 && ctx->spectrum_beside))) {
+    if (!SCAN && !ctx->db_exact && (n_fft == 1024 || n_fft == 2048) && (ctx->fft_lean > 0 || (ctx->fft_lean < 0 && ctx->spectrum_beside))) {
         auto go = [&](auto kern, size_t lds, int fpw) -> int {
             if (lds > 64 * 1024)
                 PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -658,7 +652,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
             pss_time_begin(ctx);
             pss_kernel_begin(ctx, "k_spectrum");
             hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(256), lds, PSS_STREAM(ctx),
-                               reinterpret_cast<const float2 *>(d_iq), d_db, tw, win, n_frames);
+                               reinterpret_cast<const float2 *>(d_iq), d_db, tw, win, n_frames, spec_flags(ctx));
             pss_kernel_end(ctx);
             pss_time_end(ctx);
             return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_lean launch");
@@ -687,11 +681,16 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
             pss_time_begin(ctx);
             pss_kernel_begin(ctx, "k_spectrum");
             hipLaunchKernelGGL(kern, dim3((unsigned)(n_frames < cap ? n_frames : cap)), dim3(threads), lds, PSS_STREAM(ctx),
-                               reinterpret_cast<const float2 *>(d_iq), d_db, tw, win, n_frames, d_peak, d_bw, d_count, bin_hz, ctx->scan_exact ? 1 : 0);
+                               reinterpret_cast<const float2 *>(d_iq), d_db, tw, win, n_frames, d_peak, d_bw, d_count, bin_hz, spec_flags(ctx));
             pss_kernel_end(ctx);
             pss_time_end(ctx);
             return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_xl launch");
         };
+        if (!SCAN && ctx->db_exact) {
+            if (n_fft == 4096) return go(pss_xl::k_spectrum_xl<0, true, false, true>, pss_xl::CfgX<0>::LDS, 256, 4);
+            if (n_fft == 8192) return go(pss_xl::k_spectrum_xl<1, true, false, true>, pss_xl::CfgX<1>::LDS, 512, 2);
+            return go(pss_xl::k_spectrum_xl<2, true, false, true>, pss_xl::CfgX<2>::LDS, 1024, 1);
+        }
         if (n_fft == 4096) return go(pss_xl::k_spectrum_xl<0, !SCAN, SCAN>, pss_xl::CfgX<0>::LDS, 256, 4);
         if (n_fft == 8192) return go(pss_xl::k_spectrum_xl<1, true>, pss_xl::CfgX<1>::LDS, 512, 2);
         return go(pss_xl::k_spectrum_xl<2, true>, pss_xl::CfgX<2>::LDS, 1024, 1);
@@ -705,7 +704,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
                               "spectrum scratch");
         if (r) return r;
         double2 *scr = reinterpret_cast<double2 *>(ctx->scratch_fft);
-        void (*kern)(const float2 *, float *, const double2 *, const double *, long, double2 *) =
+        void (*kern)(const float2 *, float *, const double2 *, const double *, long, double2 *, int) =
             n_fft == 8192 ? pss_r16::k_spectrum_r16_big<1, true>
             : n_fft == 16384 ? pss_r16::k_spectrum_r16_big<2, true>
             : n_fft == 32768 ? pss_r16::k_spectrum_r16_big<3, true> : pss_r16::k_spectrum_r16_big<4, true>;
@@ -714,7 +713,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
         pss_time_begin(ctx);
         pss_kernel_begin(ctx, "k_spectrum");
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db,
-                           tw, win, n_frames, scr);
+                           tw, win, n_frames, scr, spec_flags(ctx));
         pss_kernel_end(ctx);
         pss_time_end(ctx);
         return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_r16_big launch");
@@ -740,7 +739,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
         auto launch2 = [&](auto kern, size_t lds2, int fpw) {
             if (lds2 > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             const long groups = rows / fpw;
-            hipLaunchKernelGGL(kern, dim3((unsigned)(groups < 8192 ? groups : 8192)), dim3(256), lds2, PSS_STREAM(ctx), Y, d_db, tw, rows);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(groups < 8192 ? groups : 8192)), dim3(256), lds2, PSS_STREAM(ctx), Y, d_db, tw, rows, spec_flags(ctx));
         };
         pss_kernel_begin(ctx, "k_spectrum");
         switch (NS) {
@@ -759,7 +758,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     int staged = n_fft <= STAGE_MAX_N;
     if (SCAN && !staged) return pss_fail(ctx, PSS_E_ARG, "scanner slices support n_fft <= 16384");
     size_t lds = ((size_t)1 << logNsub) * sizeof(double2) + (staged ? (size_t)n_fft * sizeof(float) : 0);
-    auto kern = k_spectrum<SCAN>;
+    auto kern = (!SCAN && ctx->db_exact) ? k_spectrum<false, true> : k_spectrum<SCAN>;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -770,7 +769,7 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_spectrum_generic");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db, tw,
-                       win, n_fft, logNsub, R, n_frames, staged, d_peak, d_bw, d_count, bin_hz, ctx->scan_exact ? 1 : 0);
+                       win, n_fft, logNsub, R, n_frames, staged, d_peak, d_bw, d_count, bin_hz, spec_flags(ctx));
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_spectrum launch");
@@ -842,14 +841,14 @@ struct BsStoreC {
     __device__ void operator()(long f, size_t k, double2 X) const { A[(size_t)f * M + k] = X; }
 };
 struct BsStoreDb {
-    float *db; const double2 *chirp; int n, shift; double inv_m; bool np32;   // np32: the scanner's float32 chain (scan_db_np)
+    float *db; const double2 *chirp; int n, shift; double inv_m; bool np32; int flags;   // np32: the scanner's float32 chain (scan_db_np)
     __device__ void operator()(long f, size_t k, double2 X) const
     {
         if (k >= (size_t)n) return;
         const double2 z = pss_r16::cmul(make_double2(X.x * inv_m, -X.y * inv_m), chirp[k]);
         int o = (int)k + shift;                      // np.fft.fftshift: out[(k + n // 2) % n] = X[k]
         if (o >= n) o -= n;
-        db[(size_t)f * n + o] = np32 ? pss::scan_db_np(z.x, z.y) : pss_r16::db_of(z.x * z.x + z.y * z.y + 1e-10);
+        db[(size_t)f * n + o] = np32 ? pss::scan_db_np(z.x, z.y) : pss_r16::db_of(z.x * z.x + z.y * z.y + 1e-10, flags);
     }
 };
 
@@ -956,7 +955,7 @@ int bluestein_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n, bool win
         if (!r) r = bs_pass1(ctx, BsLoadConv{A, p->d_B, M}, tw, Y, NS, nf);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_bluestein_p2");
-        if (!r) r = bs_pass2(ctx, Y, BsStoreDb{d_db + (size_t)f0 * n, p->d_chirp, n, n / 2, 1.0 / (double)M, !window && ctx->scan_exact}, tw, NS, nf);
+        if (!r) r = bs_pass2(ctx, Y, BsStoreDb{d_db + (size_t)f0 * n, p->d_chirp, n, n / 2, 1.0 / (double)M, !window && ctx->scan_exact, spec_flags(ctx)}, tw, NS, nf);
         pss_kernel_end(ctx);
     }
     pss_time_end(ctx);
@@ -1353,7 +1352,7 @@ extern "C" int pss_spectrum_db_post(pss_ctx *ctx, const float *d_iq, long n_fram
     if (n_frames < 0 || (n_frames > 0 && (!d_iq || !d_db || !d_post))) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_db_post: null buffer");
     if ((d_row_lo == nullptr) != (d_row_hi == nullptr)) return pss_fail(ctx, PSS_E_ARG, "row extremes: pass both arrays or neither");
     if (n_frames == 0) return PSS_OK;
-    if (n_fft == 1024 && ctx->fuse_post && !ctx->post_legacy) {
+    if (n_fft == 1024 && ctx->fuse_post && !ctx->post_legacy && !ctx->db_exact) {
         const double2 *tw;
         const double *win;
         int r = pss_fft_tables(ctx, n_fft, &tw, &win);
@@ -1370,7 +1369,7 @@ extern "C" int pss_spectrum_db_post(pss_ctx *ctx, const float *d_iq, long n_fram
         pss_time_begin(ctx);
         pss_kernel_begin(ctx, "k_spectrum_post");
         hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(256), C::LDS, PSS_STREAM(ctx),
-                           reinterpret_cast<const float2 *>(d_iq), d_db, d_post, d_row_lo, d_row_hi, tw, win, n_frames);
+                           reinterpret_cast<const float2 *>(d_iq), d_db, d_post, d_row_lo, d_row_hi, tw, win, n_frames, spec_flags(ctx));
         pss_kernel_end(ctx);
         pss_time_end(ctx);
         return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_post launch");

@@ -78,19 +78,151 @@ __device__ __forceinline__ void fft_reg(double2 (&v)[R])
     if constexpr (R > 1) Dif<R>::run(v);
 }
 
-__device__ __forceinline__ float db_of(double pw)
+// 10 log10(pw), pw = |X|^2 + 1e-10 (>= 1e-10, float64), evaluated to float64 accuracy and rounded ONCE to float32.
+// compute_fft's own result is float64 (np.abs / ** 2 / np.log10 on a complex128 transform, signal_processing.py:250-262); a
+// float64-accurate evaluation rounded to float32 equals the float32 rounding of the reference's value except where that value
+// lies within the two evaluations' ~1e-15 of a float32 rounding boundary (~1e-8 of the bins) — the previous float32 evaluation
+// (hardware log2) was 1-2 float32 ulp off on most bins, at about the same instruction count.
+//   pw = 2^e z, z folded into [0.75, 1.5);  c = 0.75 + i / 128 the nearest of 97 centres (z = 1 is one: relative accuracy is
+//   kept where dB -> 0);  r = z / c - 1 (|r| <= 0.0053) with 1 / c from the table;  log10 pw = e log10 2 + log10 c + ln(1 + r) / ln 10.
+// DB_TAB[i] = {double(1 / c_i), -log10 of THAT double} (tools/make_db_table.py: extended precision), so the table's rounding cancels.
+static __constant__ double2 DB_TAB[97] = {
+    {0x1.5555555555555p+0, -0x1.ffbfc2bbc7802p-4},
+    {0x1.51d07eae2f815p+0, -0x1.ed50a4a26eafbp-4},
+    {0x1.4e5e0a72f0539p+0, -0x1.db11ed766abf2p-4},
+    {0x1.4afd6a052bf5bp+0, -0x1.c902a19e65114p-4},
+    {0x1.47ae147ae147bp+0, -0x1.b721cd17157e3p-4},
+    {0x1.446f86562d9fbp+0, -0x1.a56e8325f5c87p-4},
+    {0x1.4141414141414p+0, -0x1.93e7de0fc3e7fp-4},
+    {0x1.3e22cbce4a902p+0, -0x1.828cfed29a212p-4},
+    {0x1.3b13b13b13b14p+0, -0x1.715d0ce367afdp-4},
+    {0x1.3813813813814p+0, -0x1.605735ee985f4p-4},
+    {0x1.3521cfb2b78c1p+0, -0x1.4f7aad9bbcbaep-4},
+    {0x1.323e34a2b10bfp+0, -0x1.3ec6ad5407866p-4},
+    {0x1.2f684bda12f68p+0, -0x1.2e3a740b7800dp-4},
+    {0x1.2c9fb4d812ca0p+0, -0x1.1dd5460c8b170p-4},
+    {0x1.29e4129e4129ep+0, -0x1.0d966cc6500f8p-4},
+    {0x1.27350b8812735p+0, -0x1.fafa6d397efdbp-5},
+    {0x1.2492492492492p+0, -0x1.db11ed766abf1p-5},
+    {0x1.21fb78121fb78p+0, -0x1.bb7209d1e24e4p-5},
+    {0x1.1f7047dc11f70p+0, -0x1.9c197abf00dd3p-5},
+    {0x1.1cf06ada2811dp+0, -0x1.7d070145f4fd8p-5},
+    {0x1.1a7b9611a7b96p+0, -0x1.5e3966b7e9294p-5},
+    {0x1.1811811811812p+0, -0x1.3faf7c6630614p-5},
+    {0x1.15b1e5f75270dp+0, -0x1.21681b5c8c213p-5},
+    {0x1.135c81135c811p+0, -0x1.0362241e638eap-5},
+    {0x1.1111111111111p+0, -0x1.cb38fccd8bfdap-6},
+    {0x1.0ecf56be69c90p+0, -0x1.902c31d62a847p-6},
+    {0x1.0c9714fbcda3bp+0, -0x1.559bd2406c3c1p-6},
+    {0x1.0a6810a6810a7p+0, -0x1.1b85d6044e9bbp-6},
+    {0x1.0842108421084p+0, -0x1.c3d0837784c3ap-7},
+    {0x1.0624dd2f1a9fcp+0, -0x1.51824c7587eb5p-7},
+    {0x1.0410410410410p+0, -0x1.c03a80ae5e038p-8},
+    {0x1.0204081020408p+0, -0x1.be76bd77b4fb5p-9},
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.fc07f01fc07f0p-1, 0x1.bafd47221ed34p-9},
+    {0x1.f81f81f81f820p-1, 0x1.b9476a4fcd0f3p-8},
+    {0x1.f44659e4a4271p-1, 0x1.49b085144368ep-7},
+    {0x1.f07c1f07c1f08p-1, 0x1.b5e908eb13789p-7},
+    {0x1.ecc07b301ecc0p-1, 0x1.10a83a8446c7fp-6},
+    {0x1.e9131abf0b767p-1, 0x1.45f4f5acb8be3p-6},
+    {0x1.e573ac901e574p-1, 0x1.7adc3df3b1ff3p-6},
+    {0x1.e1e1e1e1e1e1ep-1, 0x1.af5f92b00e611p-6},
+    {0x1.de5d6e3f8868ap-1, 0x1.e3806acbd0593p-6},
+    {0x1.dae6076b981dbp-1, 0x1.0ba01a816ffffp-5},
+    {0x1.d77b654b82c34p-1, 0x1.25502c0fc3148p-5},
+    {0x1.d41d41d41d41dp-1, 0x1.3ed1199a5e427p-5},
+    {0x1.d0cb58f6ec074p-1, 0x1.58238eeb353dcp-5},
+    {0x1.cd85689039b0bp-1, 0x1.71483427d2a97p-5},
+    {0x1.ca4b3055ee191p-1, 0x1.8a3fadeb847f4p-5},
+    {0x1.c71c71c71c71cp-1, 0x1.a30a9d609efedp-5},
+    {0x1.c3f8f01c3f8f0p-1, 0x1.bba9a058dfd85p-5},
+    {0x1.c0e070381c0e0p-1, 0x1.d41d5164facb7p-5},
+    {0x1.bdd2b899406f7p-1, 0x1.ec6647eb5880bp-5},
+    {0x1.bacf914c1bad0p-1, 0x1.02428c1f08014p-4},
+    {0x1.b7d6c3dda338bp-1, 0x1.0e3d29d81165fp-4},
+    {0x1.b4e81b4e81b4fp-1, 0x1.1a23445501814p-4},
+    {0x1.b2036406c80d9p-1, 0x1.25f5215eb594ap-4},
+    {0x1.af286bca1af28p-1, 0x1.31b3055c4711ap-4},
+    {0x1.ac5701ac5701bp-1, 0x1.3d5d335c53178p-4},
+    {0x1.a98ef606a63bep-1, 0x1.48f3ed1df48f9p-4},
+    {0x1.a6d01a6d01a6dp-1, 0x1.5477731973e85p-4},
+    {0x1.a41a41a41a41ap-1, 0x1.5fe80488af4fep-4},
+    {0x1.a16d3f97a4b02p-1, 0x1.6b45df6f3e2c8p-4},
+    {0x1.9ec8e951033d9p-1, 0x1.769140a2526fdp-4},
+    {0x1.9c2d14ee4a102p-1, 0x1.81ca63d05a448p-4},
+    {0x1.999999999999ap-1, 0x1.8cf183886480bp-4},
+    {0x1.970e4f80cb872p-1, 0x1.9806d9414a20cp-4},
+    {0x1.948b0fcd6e9e0p-1, 0x1.a30a9d609efebp-4},
+    {0x1.920fb49d0e229p-1, 0x1.adfd07416be06p-4},
+    {0x1.8f9c18f9c18fap-1, 0x1.b8de4d3ab3d97p-4},
+    {0x1.8d3018d3018d3p-1, 0x1.c3aea4a5c6effp-4},
+    {0x1.8acb90f6bf3aap-1, 0x1.ce6e41e463da3p-4},
+    {0x1.886e5f0abb04ap-1, 0x1.d91d5866aa99ap-4},
+    {0x1.8618618618618p-1, 0x1.e3bc1ab0e1a00p-4},
+    {0x1.83c977ab2beddp-1, 0x1.ee4aba610f205p-4},
+    {0x1.8181818181818p-1, 0x1.f8c9683468191p-4},
+    {0x1.7f405fd017f40p-1, 0x1.019c2a064b487p-3},
+    {0x1.7d05f417d05f4p-1, 0x1.06cbd67a6c3b7p-3},
+    {0x1.7ad2208e0ecc3p-1, 0x1.0bf3d0937c41dp-3},
+    {0x1.78a4c8178a4c8p-1, 0x1.11142f0811357p-3},
+    {0x1.767dce434a9b1p-1, 0x1.162d082ac9d10p-3},
+    {0x1.745d1745d1746p-1, 0x1.1b3e71ec94f7ap-3},
+    {0x1.724287f46debcp-1, 0x1.204881dee8777p-3},
+    {0x1.702e05c0b8170p-1, 0x1.254b4d35e7d3dp-3},
+    {0x1.6e1f76b4337c7p-1, 0x1.2a46e8ca7ba29p-3},
+    {0x1.6c16c16c16c17p-1, 0x1.2f3b691c5a000p-3},
+    {0x1.6a13cd1537290p-1, 0x1.3428e2540096ep-3},
+    {0x1.6816816816817p-1, 0x1.390f6844a0b82p-3},
+    {0x1.661ec6a5122f9p-1, 0x1.3def0e6dfdf85p-3},
+    {0x1.642c8590b2164p-1, 0x1.42c7e7fe3fc02p-3},
+    {0x1.623fa77016240p-1, 0x1.479a07d3b6410p-3},
+    {0x1.6058160581606p-1, 0x1.4c65807e93337p-3},
+    {0x1.5e75bb8d015e7p-1, 0x1.512a644296c3ep-3},
+    {0x1.5c9882b931057p-1, 0x1.55e8c518b10f9p-3},
+    {0x1.5ac056b015ac0p-1, 0x1.5aa0b4b0988fap-3},
+    {0x1.58ed2308158edp-1, 0x1.5f52447255c93p-3},
+    {0x1.571ed3c506b3ap-1, 0x1.63fd857fc49bap-3},
+    {0x1.5555555555555p-1, 0x1.68a288b60b7fdp-3}};
+
+__device__ __forceinline__ float db_of_exact(double pw, const double2 *tab = DB_TAB)
 {
-    // 10*log10(pw), pw = |X|^2 + 1e-10 held in float64, evaluated branch-free in float32:
-    //   far from 1 : hardware log2 of the float32-rounded value (relative error of the dB value ~1e-7);
-    //   near 1     : ln(1+d) = 2 atanh(d/(2+d)) as an odd series (|s| < 0.143: truncation 3e-10), which keeps the
-    //                RELATIVE error of the dB value ~1e-7 even where dB -> 0 and float32(pw) has lost d.
-    // (ocml log1pf was correct too, but a wavefront executes its ~115 instructions whenever any lane needs it.)
+    const unsigned hi = (unsigned)__double2hiint(pw), lo = (unsigned)__double2loint(pw);
+    const bool up = (hi & 0xfffffu) >= 0x80000u;                         // mantissa >= 1.5: halve
+    const int e = (int)(hi >> 20) - 1023 + (up ? 1 : 0);                 // pw > 0: no sign bit to mask
+    const double z = __hiloint2double((int)((hi & 0xfffffu) | (up ? 0x3fe00000u : 0x3ff00000u)), (int)lo);
+    const int i = (int)fma(z, 128.0, -95.5);                             // round((z - 0.75) * 128), 0 .. 96
+    const double2 tc = tab[i];
+    const double r = fma(z, tc.x, -1.0);
+    double p = fma(r, -0x1.5555555555555p-3, 0x1.999999999999ap-3);      // -1/6, 1/5
+    p = fma(p, r, -0.25);
+    p = fma(p, r, 0x1.5555555555555p-2);                                 // 1/3
+    p = fma(p, r, -0.5);
+    p = fma(p, r, 1.0);
+    double res = fma(p * r, 0x1.bcb7b1526e50ep-2, tc.y);                 // ln(1 + r) / ln 10 + log10 c
+    res = fma((double)e, 0x1.34413509f79ffp-2, res);                     // + e log10 2
+    const float out = (float)(10.0 * res);
+    return hi >= 0x7ff00000u ? (float)pw : out;                          // +inf, NaN
+}
+
+// The same quantity evaluated in float32 (hardware log2; an atanh series near pw = 1 keeps the RELATIVE error ~1e-7 where dB -> 0):
+// within 1-2 float32 ulp of the value above — far inside the 1e-4 relative contract of compute_fft's rows — at about half the
+// issue slots.  This is the default; option "db_exact" selects db_of_exact (spectrum kernel 0.17 -> 0.21 ms at cfg 2).
+__device__ __forceinline__ float db_of_fast(double pw)
+{
     const float t = (float)(pw - 1.0);
     const float far = 3.0102999566398120f * __log2f((float)pw);
     const float s = t * __builtin_amdgcn_rcpf(2.0f + t);
     const float s2 = s * s;
     const float p = s * (2.0f + s2 * (0.66666667f + s2 * (0.4f + s2 * (0.28571429f + s2 * 0.22222222f))));
     return fabsf(t) < 0.25f ? 4.342944819032518f * p : far;
+}
+
+// flags of the spectrum kernels (wave-uniform): bit 0 = scanner rows by NumPy's float32 chain, bit 1 = db_of_exact
+constexpr int FLAG_SCAN_EXACT = 1, FLAG_DB_EXACT = 2;
+__device__ __forceinline__ float db_of(double pw, int flags = 0, const double2 *tab = DB_TAB)
+{
+    return (flags & FLAG_DB_EXACT) ? db_of_exact(pw, tab) : db_of_fast(pw);
 }
 
 template <int LOG_R3>
@@ -223,11 +355,13 @@ __device__ __forceinline__ void r16_core_split(double2 (&v)[16], double *ex, con
     }
 }
 
-template <int LOG_R3, bool SCAN, bool SPLIT = false, bool PREFETCH = false>
+// EXACT: dB rows by db_of_exact (compile-time: the float64 evaluation next to the float32 one in ONE kernel costs both of them
+// registers — measured 0.41 -> 0.45 ms for the default path at 131072 x 1024)
+template <int LOG_R3, bool SCAN, bool SPLIT = false, bool PREFETCH = false, bool EXACT = false>
 __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__ iq, float *__restrict__ db,
                                                       const double2 *__restrict__ tw, const double *__restrict__ win,
                                                       long n_frames, float *__restrict__ peak, double *__restrict__ bw,
-                                                      int *__restrict__ count, double bin_hz, int scan_exact)
+                                                      int *__restrict__ count, double bin_hz, int flags)
 {
     using C = Cfg<LOG_R3>;
     constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = C::FPW;
@@ -278,7 +412,9 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
         float dbv[16];
         auto emit = [&](int i, int k, double2 X) {
             // compute_fft: float64 all the way, dB rounded to float32; scanner slice: NumPy's complex64 spectrum + float32 chain
-            float d = (SCAN && scan_exact) ? pss::scan_db_np(X.x, X.y) : db_of(X.x * X.x + X.y * X.y + 1e-10);
+            float d;
+            if constexpr (SCAN) d = (flags & FLAG_SCAN_EXACT) ? pss::scan_db_np(X.x, X.y) : db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
+            else d = EXACT ? db_of_exact(X.x * X.x + X.y * X.y + 1e-10) : db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
             if (out) out[(k + N / 2) & (N - 1)] = d;  // fftshift; T consecutive bins per store instruction
             dbv[i] = d;
             lmax = fmaxf(lmax, d);
@@ -326,7 +462,7 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
 template <int LOG_R, bool WINDOW>
 __global__ __launch_bounds__(256) void k_spectrum_r16_big(const float2 *__restrict__ iq, float *__restrict__ db,
                                                           const double2 *__restrict__ tw, const double *__restrict__ win,
-                                                          long n_frames, double2 *__restrict__ scratch)
+                                                          long n_frames, double2 *__restrict__ scratch, int flags)
 {
     using C = Cfg<4>;
     constexpr int T = C::T, NS = C::N, R = 1 << LOG_R, N = R * NS;  // 256 threads, 4096-point sub-transforms
@@ -370,7 +506,7 @@ __global__ __launch_bounds__(256) void k_spectrum_r16_big(const float2 *__restri
             for (int n2 = 0; n2 < 16; n2++) v[n2] = scr[(size_t)r * NS + t + T * n2];
             r16_core<4>(v, ex, tw1, tw2, t, [&](int, int kp, double2 X) {
                 const int k = R * kp + r;
-                out[(k + N / 2) & (N - 1)] = db_of(X.x * X.x + X.y * X.y + 1e-10);
+                out[(k + N / 2) & (N - 1)] = db_of(X.x * X.x + X.y * X.y + 1e-10, flags);
             });
             __syncthreads();
         }
@@ -469,7 +605,7 @@ __global__ __launch_bounds__(256) void k_huge_p1(const float2 *__restrict__ iq, 
 
 template <int LOG_R3>
 __global__ __launch_bounds__(256) void k_huge_p2(const double2 *__restrict__ Y, float *__restrict__ db,
-                                                 const double2 *__restrict__ tw, long n_rows)
+                                                 const double2 *__restrict__ tw, long n_rows, int flags)
 {
     using C = Cfg<LOG_R3>;
     constexpr int R3 = C::R3, T = C::T, NS = C::N, FPW = C::FPW;
@@ -500,7 +636,7 @@ __global__ __launch_bounds__(256) void k_huge_p2(const double2 *__restrict__ Y, 
         float *out = db + (size_t)f * N;
         r16_core<LOG_R3>(v, ex, tw1, tw2, t, [&](int, int kp, double2 X) {
             const size_t k = (size_t)256 * kp + r;
-            out[(k + N / 2) & (N - 1)] = db_of(X.x * X.x + X.y * X.y + 1e-10);
+            out[(k + N / 2) & (N - 1)] = db_of(X.x * X.x + X.y * X.y + 1e-10, flags);
         });
         __syncthreads();
     }

@@ -168,11 +168,11 @@ __device__ __forceinline__ void xl_core(double2 (&v)[16], double *ex, double2 w1
 // float64 table), transform, fftshift, 10 log10(|X|^2 + 1e-10) as float32.  WINDOW = false: an unwindowed transform.
 // SCAN: the inline scanner's slice (pyspecsdr.py:2542-2552) — unwindowed, plus the slice's peak and the number of bins within
 // 20 dB of it; db may then be NULL.  The dB values wait in the (then idle) exchange buffer for the peak to be known.
-template <int LOG_R4, bool WINDOW, bool SCAN = false>
+template <int LOG_R4, bool WINDOW, bool SCAN = false, bool EXACT = false>
 __global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *__restrict__ iq, float *__restrict__ db,
                                                                   const double2 *__restrict__ tw, const double *__restrict__ win,
                                                                   long n_frames, float *__restrict__ peak, double *__restrict__ bw,
-                                                                  int *__restrict__ count, double bin_hz, int scan_exact)
+                                                                  int *__restrict__ count, double bin_hz, int flags)
 {
     using C = CfgX<LOG_R4>;
     constexpr int T = C::T, N = C::N, T2 = C::T2, R4 = C::R4;
@@ -209,7 +209,9 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *
         float *held = reinterpret_cast<float *>(ex);           // SCAN: this thread's 16 dB values at held[i * T + t]
         xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int i, int j, int k, double2 X) {
             // fftshift; bin 4096 k + T j + t: T consecutive bins per store instruction
-            const float d = (SCAN && scan_exact) ? pss::scan_db_np(X.x, X.y) : pss_r16::db_of(X.x * X.x + X.y * X.y + 1e-10);
+            float d;
+            if constexpr (SCAN) d = (flags & pss_r16::FLAG_SCAN_EXACT) ? pss::scan_db_np(X.x, X.y) : pss_r16::db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
+            else d = EXACT ? pss_r16::db_of_exact(X.x * X.x + X.y * X.y + 1e-10) : pss_r16::db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
             buf_store_f32(ro, t * 4, ((4096 * k + T * j + N / 2) & (N - 1)) * 4, d);
             if (SCAN) { held[i * T + t] = d; lmax = fmaxf(lmax, d); }
         });
@@ -279,7 +281,7 @@ __device__ __forceinline__ void exchange_l(double2 (&v)[16], Wr wr, Rd rd)
 template <int LOG_R3, bool WINDOW>
 __global__ __launch_bounds__(256, 4) void k_spectrum_lean(const float2 *__restrict__ iq, float *__restrict__ db,
                                                           const double2 *__restrict__ tw, const double *__restrict__ win,
-                                                          long n_frames)
+                                                          long n_frames, int flags)
 {
     using C = CfgL<LOG_R3>;
     constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = C::FPW, E1 = C::E1, E2 = C::E2;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256, 4) void k_spectrum_lean(const float2 *__restri
 #pragma unroll
             for (int j1 = 0; j1 < R3; j1++) {
                 const double2 X = b[brev(j1, LOG_R3)];
-                buf_store_f32(ro, t * 4, ((256 * j1 + T * c + N / 2) & (N - 1)) * 4, pss_r16::db_of(X.x * X.x + X.y * X.y + 1e-10));
+                buf_store_f32(ro, t * 4, ((256 * j1 + T * c + N / 2) & (N - 1)) * 4, pss_r16::db_of_fast(X.x * X.x + X.y * X.y + 1e-10));
             }
         }
     }

@@ -19,7 +19,7 @@ template <bool PREFETCH>
 __global__ __launch_bounds__(256) void k_spectrum_post_1024(const float2 *__restrict__ iq, float *__restrict__ db,
                                                             float *__restrict__ post, float *__restrict__ row_lo,
                                                             float *__restrict__ row_hi, const double2 *__restrict__ tw,
-                                                            const double *__restrict__ win, long n_frames)
+                                                            const double *__restrict__ win, long n_frames, int flags)
 {
     constexpr int LOG_R3 = 2;
     using C = pss_r16::Cfg<LOG_R3>;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_spectrum_post_1024(const float2 *__rest
         float *out = valid ? db + (size_t)f * N : nullptr;
         float dbv[16];
         pss_r16::r16_core<LOG_R3, true>(v, ex, tw1, tw2, t, [&](int i, int k, double2 X) {
-            const float d = pss_r16::db_of(X.x * X.x + X.y * X.y + 1e-10);
+            const float d = pss_r16::db_of_fast(X.x * X.x + X.y * X.y + 1e-10);   // ("db_exact" takes the two separate kernels)
             if (out) out[(k + N / 2) & (N - 1)] = d;  // fftshift; 64 consecutive bins per store instruction
             dbv[i] = d;
         });

@@ -59,6 +59,28 @@ def test_spectrum_vs_golden(golden, n):
         assert np.max(np.abs(db0 - db)) < 2e-5
 
 
+def test_spectrum_db_exact_is_the_float32_rounding_of_the_reference_rows(golden):
+    """Option "db_exact": the dB rows are evaluated to float64 accuracy and rounded once, so the float32 row IS the float32
+    rounding of the reference's float64 row — every golden value of every kernel family (register FFT 256 .. 4096, four-stage
+    8192 / 16384, Bluestein lengths); the default float32 evaluation is 1-2 ulp from that (and inside the 1e-4 contract)."""
+    g = golden["spectrum"]
+    e = G.engine()
+    sizes = [256, 1024, 2048, 4096, 8192, 16384] + [f"np2_{n}" for n in g["np2_sizes"]]
+    for tag in sizes:
+        iq, ref = g[f"iq_{tag}"], g[f"db_{tag}"]
+        iq, ref = (iq[None], ref[None]) if iq.ndim == 1 else (iq, ref)
+        want = ref.astype(np.float32)
+        e.set_option("db_exact", 1)
+        try:
+            got = G.spectrum(iq)
+        finally:
+            e.set_option("db_exact", 0)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tag, int((got.view(np.uint32) != want.view(np.uint32)).sum()))
+        fast = G.spectrum(iq)
+        ulp = np.abs(fast.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 64 and np.all(np.abs(fast - want) <= 1e-6 * np.maximum(np.abs(want), 1.0)), (tag, int(ulp.max()))
+
+
 def test_spectrum_split_exchange_is_bit_identical():
     # the component-wise LDS exchange variant of the register FFT (automatic at N = 256) and the next-frame prefetch
     # (automatic at N = 1024, 2048) must not change a bit; 5000 frames make every workgroup loop over several frames
