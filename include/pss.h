@@ -136,8 +136,8 @@ int pss_row_extremes_f64(pss_ctx *ctx, const double *d_rows, long n_rows, int le
  * d_bw float64 [n], d_count int32 [n] (may be NULL).  n_fft: power of two in [16, 16384] (one kernel), or any other
  * length in [2, 524288] (Bluestein + a reduction kernel).  The dB values are the reference's float32 values bit for bit (so are
  * peak, count and bandwidth): np.fft.fft on complex64 is a double transform rounded to complex64 (NumPy 2.2), everything behind
- * it float32 arithmetic that is modelled exactly; a bin can differ only if its float64 component lies within ~1e-16 relative of a
- * float32 rounding boundary (option "scan_exact" = 0: the 1e-4-relative evaluation of pss_spectrum_db, 30 % faster). */
+ * it float32 arithmetic that is modelled exactly; a bin can differ only if a float64 component lies within the transform's ~1e-16 * max|X|
+ * of a float32 rounding boundary (weak bins beside a strong carrier: ~1e-6 of the bins) (option "scan_exact" = 0: the 1e-4-relative evaluation of pss_spectrum_db, 30 % faster). */
 int pss_scan(pss_ctx *ctx, const float *d_iq, long n_slices, int n_fft, double fs, float *d_db, float *d_peak,
              double *d_bw, int32_t *d_count);
 /* The sweep driver's per-read arithmetic (scan_frequencies, pyspecsdr.py:1049-1057): unwindowed fft of a read of
