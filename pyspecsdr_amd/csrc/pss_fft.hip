@@ -602,10 +602,10 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     // next-frame prefetch (option "fft_prefetch", -1 = automatic), A/B in one process: N = 1024: 0.198 -> 0.185 ms (65536 frames),
     // 2048: 0.234 -> 0.226 ms; 512: no change; 4096: 0.27 -> 0.35 ms (274 VGPRs: one wavefront per SIMD); 256: the split kernel wins
     const bool prefetch = !split && (ctx->fft_prefetch >= 0 ? ctx->fft_prefetch != 0 : (LOG_R3 == 2 || LOG_R3 == 3));
-    // "db_exact" (compute_fft rows only): its own instantiations — split at N = 256, plain otherwise (the float64 evaluation and the
-    // prefetch registers do not fit together)
+    // "db_exact" (compute_fft rows only): its own instantiations of the same three variants (244 VGPRs with the prefetch: no spill)
     const bool exact = !SCAN && ctx->db_exact;
-    auto kern = exact ? (split ? pss_r16::k_spectrum_r16<LOG_R3, false, true, false, true> : pss_r16::k_spectrum_r16<LOG_R3, false, false, false, true>)
+    auto kern = exact ? (split ? pss_r16::k_spectrum_r16<LOG_R3, false, true, false, true>
+                         : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, false, false, true, true> : pss_r16::k_spectrum_r16<LOG_R3, false, false, false, true>)
                 : split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true, false>
                 : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, true> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, false>;
     const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2) : C::LDS;
