@@ -65,11 +65,12 @@ int pss_device_count(void);
  *                              path sorts (longer rows: radix select)
  *   "fft_split" (-1 = auto)    1 / 0: force / forbid the component-wise LDS exchanges of the register FFT (auto: N = 256)
  *   "fft_big_scratch" (0)      1: N = 8192 / 16384 on the scratch-based pre-pass kernel instead of the four-stage register kernel
- *   "db_exact" (1)             compute_fft's dB rows (pss_spectrum_db and everything built on it) are evaluated to float64 accuracy and
- *                              rounded once: the float32 row IS the float32 rounding of the reference's float64 row (all 69 490 golden
- *                              values; a bin can differ by one ulp within ~1e-15 of a rounding boundary: measured 5 of 8.4 million bins).  0: float32 evaluation of the
- *                              logarithm, 1-2 ulp from that (the contract is 1e-4 relative), spectrum kernel 0.17 instead of 0.20 ms at
- *                              cfg 2 (bench step 3 % shorter); "fuse_post" and "fft_lean" exist for this evaluation only
+ *   "db_exact" (0)             1: compute_fft's dB rows (pss_spectrum_db and everything built on it) are evaluated to float64 accuracy and
+ *                              rounded once: the float32 row then IS the float32 rounding of the reference's float64 row (all 69 490
+ *                              golden values; measured on FM frames: 5 of 8.4 million bins off by one ulp, where the value lies within
+ *                              ~1e-15 of a rounding boundary).  0 (default): float32 evaluation of the logarithm, 1-2 ulp from that
+ *                              (the contract is 1e-4 relative); the exact evaluation costs the spectrum kernels 15-25 % (0.17 -> 0.20 ms
+ *                              at cfg 2, 0.75 -> 0.91 ms at 8192 x 16384) and the bench step 3 %; "fuse_post" / "fft_lean" need 0
  *   "scan_exact" (1)           0: scanner slices (pss_scan, pss_scan_threshold) get their dB values from compute_fft's float64 / hardware-log2
  *                              evaluation (1e-4 relative; 30 % faster at 8192 x 4096) instead of NumPy's float32 chain bit for bit
  *   "fft_lean" (0)             1: N = 1024 / 2048 spectra on the 112-VGPR component-wise-exchange kernel (k_spectrum_lean) instead of

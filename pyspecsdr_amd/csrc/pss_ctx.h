@@ -78,7 +78,7 @@ struct pss_ctx {
     long wfm_small_batch_max = 8192;  // option "wfm_small_batch_max" (measured crossover with the fused kernels ~12000 frames)
     bool ssb_hilbert = true;   // option "ssb_hilbert": run the reference's hilbert() round trip inside demodulate_ssb where a register transform exists for the frame length
     bool fir_mfma = false;
-    bool db_exact = true;          // compute_fft's dB rows evaluated to float64 accuracy and rounded once (= float32 of the reference's float64 rows); false: float32 evaluation, 1-2 ulp off, 15-20 % faster kernel
+    bool db_exact = false;         // true: compute_fft's dB rows evaluated to float64 accuracy and rounded once (= float32 of the reference's float64 rows); false: float32 evaluation, 1-2 ulp off, 15-25 % faster kernels
     bool scan_exact = true;        // scanner slices: NumPy's float32 chain bit for bit (scan_db_np); false: the float64 / hardware-log2 dB of compute_fft
     int fft_lean = 0;              // N = 1024 / 2048 on k_spectrum_lean (112 VGPRs): 0 never (default), 1 always, -1 = only beside the NFM backward pass
     bool spectrum_beside = false;  // set by pss_frame_pipeline_nfm around its side chain

@@ -207,7 +207,7 @@ __device__ __forceinline__ float db_of_exact(double pw, const double2 *tab = DB_
 
 // The same quantity evaluated in float32 (hardware log2; an atanh series near pw = 1 keeps the RELATIVE error ~1e-7 where dB -> 0):
 // within 1-2 float32 ulp of the value above — far inside the 1e-4 relative contract of compute_fft's rows — at about half the
-// issue slots.  Option "db_exact" = 0 selects it (spectrum kernel 0.20 -> 0.17 ms at cfg 2, bench step - 3 %); the default is db_of_exact.
+// issue slots.  This is the default; option "db_exact" = 1 selects db_of_exact (spectrum kernel 0.17 -> 0.20 ms at cfg 2, bench step + 3 %).
 __device__ __forceinline__ float db_of_fast(double pw)
 {
     const float t = (float)(pw - 1.0);

@@ -39,7 +39,6 @@ def test_spectrum_vs_golden(golden, n):
     if n in (1024, 2048):   # the opt-in 112-VGPR kernel ("fft_lean") against the same golden
         e = G.engine()
         e.set_option("fft_lean", 1)
-        e.set_option("db_exact", 0)          # the narrow kernel exists for the float32 dB evaluation only
         try:
             db1 = G.spectrum(iq)
             rng = np.random.default_rng(n)
@@ -47,7 +46,6 @@ def test_spectrum_vs_golden(golden, n):
             a = G.spectrum(many)
         finally:
             e.set_option("fft_lean", 0)
-            e.set_option("db_exact", 1)
         assert np.all(rel_err(db1, ref)[big] <= 1e-4) and np.all(np.abs(db1 - ref)[~big] <= 1e-6) and np.max(np.abs(db1 - ref)) < 2e-5
         assert np.max(np.abs(a - G.spectrum(many))) < 2e-5
     if n == 4096:       # the three-stage kernel with complex exchanges (the default until round 2) against the same golden
@@ -61,10 +59,10 @@ def test_spectrum_vs_golden(golden, n):
         assert np.max(np.abs(db0 - db)) < 2e-5
 
 
-def test_spectrum_rows_are_the_float32_rounding_of_the_reference_rows(golden):
-    """compute_fft's dB rows are evaluated to float64 accuracy and rounded once (default, option "db_exact"): the float32 row IS the
-    float32 rounding of the reference's float64 row — every golden value of every kernel family (register FFT 256 .. 4096,
-    four-stage 8192 / 16384, Bluestein lengths).  "db_exact" = 0 is the float32 evaluation: 1-2 ulp from that, inside the 1e-4 contract."""
+def test_spectrum_db_exact_is_the_float32_rounding_of_the_reference_rows(golden):
+    """Option "db_exact": compute_fft's dB rows evaluated to float64 accuracy and rounded once — the float32 row then IS the float32
+    rounding of the reference's float64 row, every golden value of every kernel family (register FFT 256 .. 4096, four-stage
+    8192 / 16384, Bluestein lengths).  The default float32 evaluation is 1-2 ulp from that, inside the 1e-4 contract."""
     g = golden["spectrum"]
     e = G.engine()
     sizes = [256, 1024, 2048, 4096, 8192, 16384] + [f"np2_{n}" for n in g["np2_sizes"]]
@@ -72,13 +70,13 @@ def test_spectrum_rows_are_the_float32_rounding_of_the_reference_rows(golden):
         iq, ref = g[f"iq_{tag}"], g[f"db_{tag}"]
         iq, ref = (iq[None], ref[None]) if iq.ndim == 1 else (iq, ref)
         want = ref.astype(np.float32)
-        got = G.spectrum(iq)
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tag, int((got.view(np.uint32) != want.view(np.uint32)).sum()))
-        e.set_option("db_exact", 0)
+        e.set_option("db_exact", 1)
         try:
-            fast = G.spectrum(iq)
+            got = G.spectrum(iq)
         finally:
-            e.set_option("db_exact", 1)
+            e.set_option("db_exact", 0)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tag, int((got.view(np.uint32) != want.view(np.uint32)).sum()))
+        fast = G.spectrum(iq)
         ulp = np.abs(fast.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
         assert ulp.max() <= 64 and np.all(np.abs(fast - want) <= 1e-6 * np.maximum(np.abs(want), 1.0)), (tag, int(ulp.max()))
 
@@ -1488,24 +1486,17 @@ def test_frame_pipeline_equals_separate_calls():
             for k in a:
                 assert torch.equal(a2[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k, sched)
         # the fused spectrum + post-process kernel (1024-point frames) against the two separate kernels
-        # (it exists for the float32 dB evaluation, "db_exact" = 0)
-        c, d = bufs(), bufs()
-        e.set_option("db_exact", 0)
+        c = bufs()
+        e.spectrum_db_post(iq, nf, n, c["db"], c["post"], c["lo"], c["hi"])
+        d = bufs()
+        e.set_option("fuse_post", 1)
         try:
-            e.spectrum_db_post(iq, nf, n, c["db"], c["post"], c["lo"], c["hi"])
-            e.set_option("fuse_post", 1)
             e.spectrum_db_post(iq, nf, n, d["db"], d["post"], d["lo"], d["hi"])
         finally:
             e.set_option("fuse_post", 0)
-            e.set_option("db_exact", 1)
         e.sync()
         for k in ("db", "post", "lo", "hi"):
-            assert torch.equal(c[k].view(torch.uint8), d[k].view(torch.uint8)), (nf, k)
-        c = bufs()                                # and the unfused entry under the default evaluation equals the separate calls
-        e.spectrum_db_post(iq, nf, n, c["db"], c["post"], c["lo"], c["hi"])
-        e.sync()
-        for k in ("db", "post", "lo", "hi"):
-            assert torch.equal(c[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k)
+            assert torch.equal(c[k].view(torch.uint8), d[k].view(torch.uint8)) and torch.equal(c[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k)
 
 
 def test_full_size_headline_properties():
