@@ -140,6 +140,10 @@ def cpu_baseline(iq_host, fs, taps, sos, zi, min_wall_s=1.0, max_wall_s=25.0):
 
 
 def main():
+    # stdout carries ONE line: the result.  Everything else this process or its libraries print there (RCCL's version banner is a
+    # C-level printf that libc flushes at exit, i.e. AFTER a Python print) is sent to stderr by pointing fd 1 at fd 2 for the run.
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -369,10 +373,12 @@ def main():
             out["cpu_baseline"]["value"] /= 1e6
             out["cpu_baseline"]["single_thread_value"] /= 1e6
             out["cpu_baseline"]["unit"] = "MSamples/s"
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
