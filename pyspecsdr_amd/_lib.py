@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpss.so")
+# PSS_LIBRARY: load another build of the same ABI (kernel experiments: tools/build_variant.py)
+LIB_PATH = os.environ.get("PSS_LIBRARY") or os.path.join(HERE, "libpss.so")
 
 PSS_OK, PSS_E_ARG, PSS_E_HIP, PSS_E_PADLEN, PSS_E_CUTOFF, PSS_E_NOMEM = 0, -1, -2, -3, -4, -5
 MODE_NFM, MODE_AM, MODE_USB, MODE_LSB, MODE_WFM = 0, 1, 2, 3, 4

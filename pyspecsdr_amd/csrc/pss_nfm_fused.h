@@ -30,7 +30,8 @@ constexpr int HEAD = 64;       // outputs produced by the prologue
 constexpr int NFW = 3;         // FIR worker waves (4 x 6 outputs in 5-wave workgroups measured slower: 0.89 vs 0.67 ms)
 constexpr int OPT = FC / NFW;  // FIR outputs per worker thread and chunk
 constexpr int WG = 64 * (1 + NFW);
-constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double) + 72 * sizeof(double);
+constexpr int HTAPS = 80;     // LDS copy of the reversed taps for the left-edge outputs: 65 taps + 15 zero slots (clamp-free tail loads)
+constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double) + HTAPS * sizeof(double);
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence that also waits for every
 // outstanding GLOBAL store of the wave (vmcnt(0)); the IIR wave has 24 y_fwd row stores in flight per chunk, and
@@ -124,6 +125,59 @@ __device__ __forceinline__ void fir_batch(const float *const (&blk)[NB], const d
     }
 }
 
+// The ddot tree (pss_device.h) for a WAVE-UNIFORM length n = 1..64: the left-edge FIR outputs, lane = frame.  x[j] is the
+// lane's window row (float32 discriminator at time j), y[j] the tap that meets it (LDS, same address in every lane).
+// One straight-line body per shape of the tree — S32 32-element steps (n >= 32; two only for n = 64) and an optional
+// 16-element step — so that the LDS loads of a whole phase are in flight together; the n - n1 <= 15 tail elements are
+// loaded ahead of their dependent FMA chain.  (The rolled ddot_skx_uniform this replaces paid one exposed LDS round trip
+// per element: 0.045 ms of the kernel's 0.69.)
+template <int S32, bool H16>
+__device__ __forceinline__ double ddot_head_body(const float *__restrict__ x, const double *__restrict__ y)
+{
+    double s[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        double a[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double v = 0.0;
+            if (S32 >= 1) {
+                double lo = __fma_rn((double)x[8 * k + l], y[8 * k + l], 0.0);
+                double hi = __fma_rn((double)x[8 * k + l + 4], y[8 * k + l + 4], 0.0);
+                if (S32 == 2) {
+                    lo = __fma_rn((double)x[32 + 8 * k + l], y[32 + 8 * k + l], lo);
+                    hi = __fma_rn((double)x[32 + 8 * k + l + 4], y[32 + 8 * k + l + 4], hi);
+                }
+                v = __dadd_rn(lo, hi);
+            }
+            if (H16) v = __fma_rn((double)x[32 * S32 + 4 * k + l], y[32 * S32 + 4 * k + l], v);
+            a[k] = v;
+        }
+        s[l] = __dadd_rn(__dadd_rn(__dadd_rn(a[0], a[1]), a[2]), a[3]);
+    }
+    return __dadd_rn(__dadd_rn(s[0], s[2]), __dadd_rn(s[1], s[3]));
+}
+
+__device__ __forceinline__ double ddot_head(const float *__restrict__ x, const double *__restrict__ y, int n)
+{
+    const int n1 = n & -16;
+    double dot = 0.0;
+    if (n1 == 16) dot = ddot_head_body<0, true>(x, y);
+    else if (n1 == 32) dot = ddot_head_body<1, false>(x, y);
+    else if (n1 == 48) dot = ddot_head_body<1, true>(x, y);
+    else if (n1 == 64) dot = ddot_head_body<2, false>(x, y);
+    // tail operands: all loads ahead of the chain (y has 15 zero slots behind the taps, x is a window row: in bounds)
+    float xt[15];
+    double yt[15];
+#pragma unroll
+    for (int t = 0; t < 15; t++) { xt[t] = x[n1 + t]; yt[t] = y[n1 + t]; }
+    const int cnt = n - n1;
+#pragma unroll
+    for (int t = 0; t < 15; t++)
+        if (t < cnt) dot = __fma_rn(yt[t], (double)xt[t], dot);
+    return dot;
+}
+
 template <int J, int H = 0, class Put>
 __device__ __forceinline__ void for_halves(const float *const (&blk)[NB], const double *__restrict__ yrev, double (&out)[OPT], Put put)
 {
@@ -140,7 +194,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
     double *ubuf = reinterpret_cast<double *>(smem + (size_t)TILE * WSTR * sizeof(float));  // [FC][TILE]
-    double *ltaps = ubuf + (size_t)TILE * FC;                                        // taps[0..64] (left-edge dots)
+    double *ltaps = ubuf + (size_t)TILE * FC;                                        // reversed taps (left-edge dots)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long tile = blockIdx.x;
     const int M = n - 1;                      // FIR outputs per frame (M >= 128 guaranteed by the caller)
@@ -153,7 +207,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
     double *Uht = Uh + (size_t)tile * HEAD * TILE + lane;
     double *Utt = Utl + (size_t)tile * (EDGE + 1) * TILE + lane;
 #define YAT(p) Yt[(size_t)(p) * TILE]
-    if (tid < 65) ltaps[tid] = taps.fwd[tid];
+    if (tid < HTAPS) ltaps[tid] = tid < 65 ? taps.rev[tid] : 0.0;  // ltaps[m] = taps[64 - m]: output i pairs x[j] with ltaps[64 - i + j]
     // ---- prologue: discriminator of times 0..87 into logical columns 8..95 (physical = logical at chunk 0)
     for (int idx = tid; idx < TILE * WCOLS; idx += WG) {
         const int fl = idx / WCOLS, l = idx % WCOLS, t = l - 8;
@@ -171,8 +225,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
         const float *row0 = win + lane * WSTR + 8;  // time t of this lane's frame at row0[t] (chunk-0 layout)
 #pragma unroll 1
         for (int i = wave; i < HEAD; i += 1 + NFW) {
-            Uht[(size_t)i * TILE] = ddot_skx_uniform([&](int j) { return (double)row0[j]; },
-                                                     [&](int j) { return ltaps[i - j]; }, i + 1);
+            Uht[(size_t)i * TILE] = ddot_head(row0, ltaps + (64 - i), i + 1);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
