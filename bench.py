@@ -94,6 +94,35 @@ def profiled(kernel, n_frames):
         return None, None, f"no digest ({type(ex).__name__})"
 
 
+def step_valu(kernels, n_frames, ms_per_step):
+    """VALU-issue view of the WHOLE step from the committed counter digest (same source-hash rule as profiled()): every VALU
+    instruction of a wavefront occupies its SIMD for 4 clocks (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU in every kernel here, float64
+    included), so sum(instructions) x 4 clk / 1024 SIMDs is the time the step needs if nothing but VALU issue limited it.  The clock
+    is the one k_nfm_fwd ran at in the counter pass (its wavefronts live from launch to end: SQ_WAVE_CYCLES / SQ_WAVES = the
+    kernel's length in 4-clock units)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        if t.get("src_hash") != source_hash() or n_frames != t["n_frames"]:
+            return None
+        ks = t["kernels"]
+        f = ks["k_nfm_fwd"]
+        quad_rate = f["wave_cycles"] / f["waves"] / (f["sq_pass_ms"] * 1e-3)       # 4-clock units per second
+        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel"}
+        per = {}
+        for k in kernels:
+            d = ks.get(names.get(k, k))
+            if d and d.get("valu_insts"):
+                per[k] = d["valu_insts"]
+        total = sum(per.values())
+        issue_ms = total / 1024.0 / quad_rate * 1e3
+        return {"valu_insts_per_step": total, "by_kernel": per, "clock_ghz": 4e-9 * quad_rate, "issue_ms": issue_ms,
+                "frac": issue_ms / ms_per_step,
+                "note": "sum of VALU wave-instructions of the step's kernels x 4 clk / 1024 SIMDs at the clock k_nfm_fwd ran at, "
+                        "over the measured step: how close the step is to pure VALU issue"}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def synth_fm_iq(n_frames, n, fs, device, seed):
     """FM-modulated carrier + noise, SURVEY §8(d): three audio tones, 5 kHz deviation, A=0.5, sigma=0.02."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -334,6 +363,9 @@ def main():
                                  "ops_per_sample": NFM_FWD_F64_OPS_PER_SAMPLE,
                                  "note": "the kernel's binding roof: 63 fma + 51 add + 12 mul float64 per sample are fixed by the "
                                          "reference's accumulation order; peak = 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz"}
+        sv = step_valu(list(ktimes), nf, elapsed / args.steps * 1e3)
+        if sv:
+            roof["step_valu"] = sv
         hb = {}
         for k in HBM_BOUND:
             if k in ktimes:

@@ -2267,12 +2267,12 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
                 else
                     hipLaunchKernelGGL(fusedm::k_nfm_fwd_mfma<false>, dim3((unsigned)tiles), dim3(fusedm::WG), fusedm::LDS_BYTES,
                                        PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
-            } else if (b121)
-                hipLaunchKernelGGL(fused::k_nfm_fwd<true>, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
-            else
-                hipLaunchKernelGGL(fused::k_nfm_fwd<false>, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
+            } else {
+                auto kf = b121 ? (swapped ? fused::k_nfm_fwd<true, true> : fused::k_nfm_fwd<true, false>)
+                               : (swapped ? fused::k_nfm_fwd<false, true> : fused::k_nfm_fwd<false, false>);
+                hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, targ);
+            }
             pss_kernel_end(ctx);
             auto launch_bwd = [=]() -> int {
                 pss_kernel_begin(ctx, "k_nfm_bwd");

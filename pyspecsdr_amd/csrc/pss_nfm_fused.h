@@ -92,30 +92,34 @@ __device__ __forceinline__ void fir_batch(const float *const (&blk)[NB], const d
         return (double)blk[l / FC][l % FC];
     };
     double s[FBH][4];
-#pragma unroll 1
-    for (int k = 0; k < 4; k++) {
+    // Four phases of 16 taps; k is a run-time loop index (keeps only 16 taps live in SGPRs, and converted window values
+    // from one phase out of the next), but the column arithmetic must stay compile-time, so the cases are spelled out.
+    // Phase 0 (which STARTS the sums) runs ahead of the loop: with all four cases in the loop the accumulators were copied
+    // (16 v_mov_b64 per pass) where the starting case and the accumulating cases join.
+    auto phase = [&](auto KC, int k) {
+        constexpr int K = decltype(KC)::value;
         double ya[8], yb[8];
 #pragma unroll
         for (int l = 0; l < 8; l++) { ya[l] = yrev[8 * k + l]; yb[l] = yrev[32 + 8 * k + l]; }
-        // k is a run-time loop index (keeps only 16 taps live in SGPRs): the column arithmetic must stay
-        // compile-time, so the four k cases are spelled out
-        auto phase = [&](auto KC) {
-            constexpr int K = decltype(KC)::value;
 #pragma unroll
-            for (int o = 0; o < FBH; o++) {
+        for (int o = 0; o < FBH; o++) {
 #pragma unroll
-                for (int l = 0; l < 4; l++) {
-                    double lo = __fma_rn(x(8 * K + o + 32 + l), yb[l], __fma_rn(x(8 * K + o + l), ya[l], 0.0));
-                    double hi = __fma_rn(x(8 * K + o + 36 + l), yb[l + 4], __fma_rn(x(8 * K + o + l + 4), ya[l + 4], 0.0));
-                    double a = __dadd_rn(lo, hi);
-                    s[o][l] = (K == 0) ? a : __dadd_rn(s[o][l], a);
-                }
+            for (int l = 0; l < 4; l++) {
+                double lo = __fma_rn(x(8 * K + o + 32 + l), yb[l], __fma_rn(x(8 * K + o + l), ya[l], 0.0));
+                double hi = __fma_rn(x(8 * K + o + 36 + l), yb[l + 4], __fma_rn(x(8 * K + o + l + 4), ya[l + 4], 0.0));
+                double a = __dadd_rn(lo, hi);
+                s[o][l] = (K == 0) ? a : __dadd_rn(s[o][l], a);
             }
-        };
-        if (k == 0) phase(std::integral_constant<int, 0>{});
-        else if (k == 1) phase(std::integral_constant<int, 1>{});
-        else if (k == 2) phase(std::integral_constant<int, 2>{});
-        else phase(std::integral_constant<int, 3>{});
+        }
+    };
+    int k0 = 0;
+    asm volatile("" : "+s"(k0));  // opaque zero: constant tap indices would be hoisted out of the chunk loop and held in SGPRs for good
+    phase(std::integral_constant<int, 0>{}, k0);
+#pragma unroll 1
+    for (int k = 1; k < 4; k++) {
+        if (k == 1) phase(std::integral_constant<int, 1>{}, k);
+        else if (k == 2) phase(std::integral_constant<int, 2>{}, k);
+        else phase(std::integral_constant<int, 3>{}, k);
     }
     const double y64 = yrev[64];
 #pragma unroll
@@ -186,16 +190,19 @@ __device__ __forceinline__ void for_halves(const float *const (&blk)[NB], const 
     if constexpr ((H + 1) * FBH < OPT) for_halves<J, H + 1>(blk, yrev, out, put);
 }
 
-template <bool B121>
+// SWAPPED: operand order of the discriminator's complex product for frames of 32 769 samples and more (disc_sample); a template
+// parameter because as a run-time flag both orders were evaluated and selected per sample.
+template <bool B121, bool SWAPPED = false>
 __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
                                                     double *__restrict__ Uh, double *__restrict__ Utl, int n,
-                                                    long n_frames, NfmCoef c, float kscale, int swapped, TapsArg taps)
+                                                    long n_frames, NfmCoef c, float kscale, TapsArg taps)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
     double *ubuf = reinterpret_cast<double *>(smem + (size_t)TILE * WSTR * sizeof(float));  // [FC][TILE]
     double *ltaps = ubuf + (size_t)TILE * FC;                                        // reversed taps (left-edge dots)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: everything indexed by the role / chunk stays scalar
     const long tile = blockIdx.x;
     const int M = n - 1;                      // FIR outputs per frame (M >= 128 guaranteed by the caller)
     const long L = (long)M + 2 * EDGE;
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
         const long ff = tile * TILE + fl;
         const float2 *x = iq + (size_t)(ff < n_frames ? ff : n_frames - 1) * n;
         float d = 0.0f;
-        if (t >= 0 && t < M) d = disc_sample(x[t + 1], x[t], kscale, swapped != 0);
+        if (t >= 0 && t < M) d = disc_sample(x[t + 1], x[t], kscale, SWAPPED);
         win[fl * WSTR + l] = d;
     }
     __syncthreads();
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
 #pragma unroll
                     for (int e = 0; e <= OPT; e++) pre[e] = (tn + e < n) ? xq[tn + e] : make_float2(0.0f, 0.0f);
 #pragma unroll
-                    for (int e = 0; e < OPT; e++) dn[e] = (tn + e < M) ? disc_sample(pre[e + 1], pre[e], kscale, swapped != 0) : 0.0f;
+                    for (int e = 0; e < OPT; e++) dn[e] = (tn + e < M) ? disc_sample(pre[e + 1], pre[e], kscale, SWAPPED) : 0.0f;
                 }
                 lds_barrier();  // A
                 // the oldest block (logical 0) becomes the newest (logical 3 of the next chunk)

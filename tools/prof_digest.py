@@ -112,6 +112,18 @@ for n, t in traffic.items():
                             "traffic_bytes": 2 * f + w, **meta.get(n, {})}
     if n in big_ms:
         digest["kernels"][n]["rocprof_ms"] = big_ms[n][1]
+# duration of the large launches inside the SQ counter pass itself (counters serialise dispatches: not the bench's timing)
+sq_ms = {}
+p = os.path.join(out, "sqa_kernel_trace.csv")
+if os.path.exists(p):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        n = kname(r["Kernel_Name"])
+        if n:
+            acc[(n, int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    for (n, g), v in acc.items():
+        if n not in sq_ms or g > sq_ms[n][0]:
+            sq_ms[n] = (g, sum(v) / len(v))
 # SQ counters: totals per kernel over its large launches
 sq = collections.defaultdict(lambda: collections.defaultdict(list))
 for name in ("sqa", "sqb"):
@@ -138,6 +150,10 @@ for (n, g), d in sorted(sq.items()):
             digest["kernels"][n]["valu_active_frac_of_wave_cycles"] = v.get("SQ_ACTIVE_INST_VALU", 0) / wc
             digest["kernels"][n]["valu_insts"] = v.get("SQ_INSTS_VALU")
             digest["kernels"][n]["waves"] = waves
+            digest["kernels"][n]["wave_cycles"] = wc                                   # SQ counts in units of 4 clocks
+            digest["kernels"][n]["valu_active_cycles"] = v.get("SQ_ACTIVE_INST_VALU", 0)
+            if n in sq_ms:
+                digest["kernels"][n]["sq_pass_ms"] = sq_ms[n][1]
         if n in digest["kernels"]:
             for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_CVT"):
                 if k in v:

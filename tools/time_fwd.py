@@ -22,7 +22,7 @@ for rnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
         e.demod(0, iq, nf, n, bench.FS, pcm, None)
     e.sync()
     e.enable_timing(True)
-    for _ in range(10):
+    for _ in range(30):
         e.demod(0, iq, nf, n, bench.FS, pcm, None)
     e.sync()
     kt = e.kernel_times()
