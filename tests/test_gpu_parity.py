@@ -273,7 +273,7 @@ def test_batched_accumulators_vs_reference_histories(golden):
     assert np.mean(G.host(d_g) != gl) < 2e-3 and np.mean(G.host(d_c) != co) < 2e-3
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f", "g"])
 def test_nfm_vs_golden_bit_exact(golden, tag):
     g = golden["nfm"]
     fs = float(g[f"fs_{tag}"])

@@ -59,7 +59,7 @@ def test_postprocess(golden, n):
         assert np.allclose(mine, ref, rtol=1e-13, atol=1e-12)
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f", "g"])
 def test_nfm(golden, tag):
     g = golden["nfm"]
     fs = float(g[f"fs_{tag}"])

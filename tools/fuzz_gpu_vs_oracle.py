@@ -52,7 +52,7 @@ bad = 0
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 for it in range(cases):
     nf = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 130, 300]))
-    n = int(rng.choice([29, 64, 129, 257, 1000, 1024, 2049, 4096, 9000]))
+    n = int(rng.choice([29, 64, 129, 257, 1000, 1024, 2049, 4096, 9000, 33000]))
     fs = float(rng.choice([2.4e6, 1.024e6, 2.048e6, 250e3, 10e6]))
     iq = rnd_iq(nf, n)
     pick = sorted(set([0, nf - 1, int(rng.integers(0, nf))]))

@@ -181,7 +181,8 @@ def gen_spectrum():
 def gen_nfm():
     d = {}
     for tag, n, fs, nf, seed in [("a", 1024, 2.4e6, 6, 21), ("b", 2048, 10e6, 3, 22), ("c", 4096, 1.024e6, 2, 23),
-                                 ("d", 29, 2.4e6, 1, 24), ("e", 32768, 2.4e6, 1, 25), ("f", 1000, 2.4e6, 2, 26)]:
+                                 ("d", 29, 2.4e6, 1, 24), ("e", 32768, 2.4e6, 1, 25), ("f", 1000, 2.4e6, 2, 26),
+                                 ("g", 40000, 2.4e6, 2, 27)]:   # g: past NumPy's 256 KiB temporary-elision threshold (N - 1 >= 32768)
         iq = fm_iq(nf, n, fs, seed)
         aud = np.stack([sp.demodulate_signal(f, fs, "NFM") for f in iq])  # (nf, n_out, 2)
         assert np.array_equal(aud[..., 0], aud[..., 1])
