@@ -15,26 +15,31 @@ namespace pss {
 
 // VRCP14PS bit-exact model (x86 AVX-512 reciprocal approximation): 64-segment piecewise-linear in the
 // top 16 mantissa bits.  Table derived and exhaustively verified by tools/derive_rcp14.c.
-__constant__ uint32_t RCP14_A[64] = {
-    67107072u, 66074112u, 65073664u, 64102400u, 63159040u, 62244608u, 61354752u, 60491264u,
-    59650560u, 58833920u, 58038272u, 57264640u, 56511488u, 55778048u, 55062784u, 54365184u,
-    53686016u, 53022976u, 52377088u, 51745536u, 51129600u, 50528000u, 49940992u, 49366272u,
-    48805376u, 48257024u, 47721728u, 47196672u, 46683904u, 46181632u, 45690368u, 45209344u,
-    44739072u, 44277504u, 43826176u, 43382784u, 42949120u, 42523904u, 42106880u, 41698048u,
-    41297920u, 40903936u, 40517888u, 40139520u, 39768320u, 39402752u, 39044608u, 38692864u,
-    38347520u, 38008064u, 37674496u, 37347840u, 37025280u, 36708608u, 36398080u, 36091648u,
-    35791360u, 35495680u, 35204352u, 34919168u, 34638080u, 34361088u, 34088192u, 33819392u};
-__constant__ uint16_t RCP14_B[64] = {
-    1009, 977, 949, 921, 893, 869, 843, 821, 797, 777, 755, 735, 717, 699, 681, 663,
-    647, 631, 617, 601, 587, 573, 561, 547, 535, 523, 513, 501, 491, 479, 469, 459,
-    451, 441, 433, 423, 415, 407, 399, 391, 385, 377, 369, 363, 357, 349, 343, 337,
-    331, 325, 319, 315, 309, 303, 299, 293, 289, 285, 279, 275, 271, 267, 263, 259};
+// {intercept, slope} per segment, one 8-byte load per lookup
+__constant__ uint2 RCP14_AB[64] = {
+    {67107072u, 1009u}, {66074112u, 977u}, {65073664u, 949u}, {64102400u, 921u},
+    {63159040u, 893u}, {62244608u, 869u}, {61354752u, 843u}, {60491264u, 821u},
+    {59650560u, 797u}, {58833920u, 777u}, {58038272u, 755u}, {57264640u, 735u},
+    {56511488u, 717u}, {55778048u, 699u}, {55062784u, 681u}, {54365184u, 663u},
+    {53686016u, 647u}, {53022976u, 631u}, {52377088u, 617u}, {51745536u, 601u},
+    {51129600u, 587u}, {50528000u, 573u}, {49940992u, 561u}, {49366272u, 547u},
+    {48805376u, 535u}, {48257024u, 523u}, {47721728u, 513u}, {47196672u, 501u},
+    {46683904u, 491u}, {46181632u, 479u}, {45690368u, 469u}, {45209344u, 459u},
+    {44739072u, 451u}, {44277504u, 441u}, {43826176u, 433u}, {43382784u, 423u},
+    {42949120u, 415u}, {42523904u, 407u}, {42106880u, 399u}, {41698048u, 391u},
+    {41297920u, 385u}, {40903936u, 377u}, {40517888u, 369u}, {40139520u, 363u},
+    {39768320u, 357u}, {39402752u, 349u}, {39044608u, 343u}, {38692864u, 337u},
+    {38347520u, 331u}, {38008064u, 325u}, {37674496u, 319u}, {37347840u, 315u},
+    {37025280u, 309u}, {36708608u, 303u}, {36398080u, 299u}, {36091648u, 293u},
+    {35791360u, 289u}, {35495680u, 285u}, {35204352u, 279u}, {34919168u, 275u},
+    {34638080u, 271u}, {34361088u, 267u}, {34088192u, 263u}, {33819392u, 259u}};
 
 __device__ __forceinline__ float rcp14f(float x)
 {
     uint32_t u = f2u(x), sign = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
     uint32_t idx = m >> 17, low = (m >> 7) & 1023u;
-    uint32_t v = (RCP14_A[idx] - (uint32_t)RCP14_B[idx] * low) >> 9;
+    const uint2 ab = RCP14_AB[idx];
+    uint32_t v = (ab.x - ab.y * low) >> 9;
     uint32_t r = sign | ((253u - e) << 23) | ((v & 0xffffu) << 7);
     uint32_t r0 = sign | ((254u - e) << 23);
     return u2f(m == 0 ? r0 : r);
@@ -69,11 +74,13 @@ __device__ __forceinline__ float atan2f_svml(float y, float x)
     uint32_t axb = xb & 0x7fffffffu, ayb = yb & 0x7fffffffu;
     uint32_t sx = xb & 0x80000000u, sy = yb & 0x80000000u;
     float ax = u2f(axb), ay = u2f(ayb);
-    bool inr = (axb >= 0x01000000u) && (axb < 0x7d000000u) && (ayb >= 0x01000000u) && (ayb < 0x7d000000u);
-    if (__builtin_expect(!inr, 0)) return atan2f_svml_rare(y, x);
+    // main path: 2^-125 <= min(|x|, |y|) and max(|x|, |y|) < 2^123, tested on the ordered pair the routine needs anyway (two
+    // float compares; NaN operands fail them, zeros and denormals the first, inf and huge values the second)
     bool k1 = ay < ax;
     float a = k1 ? ay : -ax;
     float b = k1 ? ax : ay;
+    bool inr = (fabsf(a) >= 0x1p-125f) && (b < 0x1p123f);
+    if (__builtin_expect(!inr, 0)) return atan2f_svml_rare(y, x);
     float base = k1 ? 0.0f : PIO2;
     float r0 = rcp14f(b);
     float e = __fmaf_rn(-b, r0, 1.0f);

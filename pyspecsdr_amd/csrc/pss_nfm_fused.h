@@ -328,10 +328,11 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
                 float dn[OPT];
                 {
                     float2 pre[OPT + 1];
+                    const int left = M - tn;  // discriminator samples of this batch inside the frame (one scalar per chunk: the bounds n / M themselves live in spilled SGPRs)
 #pragma unroll
-                    for (int e = 0; e <= OPT; e++) pre[e] = (tn + e < n) ? xq[tn + e] : make_float2(0.0f, 0.0f);
+                    for (int e = 0; e <= OPT; e++) pre[e] = (e <= left) ? xq[tn + e] : make_float2(0.0f, 0.0f);
 #pragma unroll
-                    for (int e = 0; e < OPT; e++) dn[e] = (tn + e < M) ? disc_sample(pre[e + 1], pre[e], kscale, SWAPPED) : 0.0f;
+                    for (int e = 0; e < OPT; e++) dn[e] = (e < left) ? disc_sample(pre[e + 1], pre[e], kscale, SWAPPED) : 0.0f;
                 }
                 lds_barrier();  // A
                 // the oldest block (logical 0) becomes the newest (logical 3 of the next chunk)
