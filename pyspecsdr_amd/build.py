@@ -46,8 +46,8 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "pss.h"))
     headers.append(os.path.abspath(__file__))
-    objs = []
-    for src, extra in UNITS:
+    objs, running = [], []
+    for src, extra in UNITS:   # the translation units compile side by side (the two .hip files take ~30 s each)
         s = os.path.join(CSRC, src)
         o = os.path.join(BUILD, src.rsplit(".", 1)[0] + ".o")
         objs.append(o)
@@ -55,7 +55,10 @@ def build(force=False, verbose=False):
             cmd = [cc] + COMMON + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
+            running.append((cmd, subprocess.Popen(cmd)))
+    for cmd, proc in running:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
     if force or _stale(OUT, objs):
         cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs
         if verbose:
