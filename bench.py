@@ -85,40 +85,48 @@ def profiled(kernel, n_frames):
             return None, None, f"profiles/hbm_traffic.json is from source {t.get('src_hash')}, this tree is {source_hash()}"
         k = t["kernels"][kernel]
         busy = None
-        if kernel in ("k_nfm_fwd", "k_nfm_bwd") and k.get("waves") and n_frames == t["n_frames"]:
-            # every wavefront of these launches is resident from start to end (waves / 1024 SIMDs = 4 resp. 1 per SIMD), so the
-            # SIMD's VALU-busy fraction is the per-wave active fraction times the waves sharing it
-            busy = k["valu_active_frac_of_wave_cycles"] * k["waves"] / 1024.0
+        if k.get("valu_insts") and k.get("rocprof_ms") and n_frames == t["n_frames"]:
+            # pure VALU issue time of the launch (class-weighted, see valu_issue_ms) over its profiled duration
+            busy = valu_issue_ms(k) / k["rocprof_ms"]
         return k["traffic_bytes"] * n_frames / float(t["n_frames"]), busy, t.get("profile")
     except Exception as ex:  # noqa: BLE001
         return None, None, f"no digest ({type(ex).__name__})"
 
 
+# Machine-wide VALU issue rates measured with tools/ubench/valu_rate.hip on this part (>= 2 wavefronts per SIMD, hipEvent timing):
+# float64 add / mul / fma and conversions to float64 37 T lane-ops/s (16 lanes per clock and SIMD at ~2.3 GHz: 4 clocks per
+# wavefront-instruction), float32 / integer instructions 61 T lane-ops/s (32 lanes per clock: 2 clocks per wavefront-instruction).
+VALU_RATE_F64 = 37.0e12 / 64     # wavefront-instructions per second, whole chip
+VALU_RATE_B32 = 61.0e12 / 64
+
+
+def valu_issue_ms(d):
+    """Pure VALU issue time of one launch from its counter digest entry: float64-class and 32-bit-class instruction counts over the
+    measured machine-wide rates of each class."""
+    f64 = sum(d.get(k, 0.0) or 0.0 for k in ("sq_insts_valu_add_f64", "sq_insts_valu_mul_f64", "sq_insts_valu_fma_f64", "sq_insts_valu_cvt"))
+    b32 = max(d["valu_insts"] - f64, 0.0)
+    return (f64 / VALU_RATE_F64 + b32 / VALU_RATE_B32) * 1e3
+
+
 def step_valu(kernels, n_frames, ms_per_step):
-    """VALU-issue view of the WHOLE step from the committed counter digest (same source-hash rule as profiled()): every VALU
-    instruction of a wavefront occupies its SIMD for 4 clocks (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU in every kernel here, float64
-    included), so sum(instructions) x 4 clk / 1024 SIMDs is the time the step needs if nothing but VALU issue limited it.  The clock
-    is the one k_nfm_fwd ran at in the counter pass (its wavefronts live from launch to end: SQ_WAVE_CYCLES / SQ_WAVES = the
-    kernel's length in 4-clock units)."""
+    """VALU-issue view of the WHOLE step from the committed counter digest (same source-hash rule as profiled()): per kernel, the
+    float64-class and 32-bit-class instruction counts over the measured issue rates (above) = the time the kernel would take if nothing
+    but VALU issue limited it; their sum over the measured step."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
         if t.get("src_hash") != source_hash() or n_frames != t["n_frames"]:
             return None
         ks = t["kernels"]
-        f = ks["k_nfm_fwd"]
-        quad_rate = f["wave_cycles"] / f["waves"] / (f["sq_pass_ms"] * 1e-3)       # 4-clock units per second
         names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel"}
         per = {}
         for k in kernels:
             d = ks.get(names.get(k, k))
             if d and d.get("valu_insts"):
-                per[k] = d["valu_insts"]
-        total = sum(per.values())
-        issue_ms = total / 1024.0 / quad_rate * 1e3
-        return {"valu_insts_per_step": total, "by_kernel": per, "clock_ghz": 4e-9 * quad_rate, "issue_ms": issue_ms,
-                "frac": issue_ms / ms_per_step,
-                "note": "sum of VALU wave-instructions of the step's kernels x 4 clk / 1024 SIMDs at the clock k_nfm_fwd ran at, "
-                        "over the measured step: how close the step is to pure VALU issue"}
+                per[k] = round(valu_issue_ms(d), 4)
+        issue_ms = sum(per.values())
+        return {"issue_ms": issue_ms, "by_kernel_ms": per, "frac": issue_ms / ms_per_step,
+                "note": "VALU wave-instructions of the step's kernels by class (float64 + conversions: 4 clk, 32-bit: 2 clk per "
+                        "wavefront-instruction; rates measured by tools/ubench/valu_rate.hip) = pure issue time, over the measured step"}
     except Exception:  # noqa: BLE001
         return None
 

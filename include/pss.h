@@ -56,6 +56,11 @@ int pss_device_count(void);
  *   "ssb_hilbert" (1)          0: demodulate_ssb skips the reference's hilbert() FFT round trip (the identity on the real part it
  *                              keeps, up to ~1e-16); 1: executed for power-of-two frames of 256..1048576 samples
  *   "fuse_post" (0)            1: pss_spectrum_db_post takes the fused spectrum + post-process kernel for 1024-point frames
+ *   "disc_rows" (0)            1: the NFM discriminator as a pass of its own (float32 rows) that the forward kernel then reads in
+ *                              16-byte pieces instead of fetching the IQ at one line per lane (forward kernel 0.62 -> 0.45 ms at cfg 2, the
+ *                              pass itself 0.23 ms: a measurement aid).  "disc_spectrum" (0) 1: pss_frame_pipeline_nfm lets the 1024-point
+ *                              spectrum kernel write those rows and runs spectrum -> forward -> {backward || post-process -> lines}
+ *                              (1.11 against 1.09 ms per step at cfg 2: not the default).  Same results bit for bit.
  *   "pipe_overlap" (2)         schedule of pss_frame_pipeline_nfm.  2: forward kernel -> {backward pass || spectrum -> post-process ->
  *                              lines}; 0: forward kernel -> spectrum -> {backward pass || post-process -> lines} (2 % slower);
  *                              1: the whole display chain on the side stream from the start (5 % faster when the forward kernel

@@ -140,6 +140,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
         hipFree(kv.second.d_node_r); hipFree(kv.second.d_level_start); hipFree(kv.second.d_roots);
     }
     if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->disc_buf) hipFree(ctx->disc_buf);
     if (ctx->scratch_fft) hipFree(ctx->scratch_fft);
     if (ctx->scratch_iqc) hipFree(ctx->scratch_iqc);
     if (ctx->d_hann) hipFree(ctx->d_hann);
@@ -188,6 +189,8 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "fft_prefetch")) { ctx->fft_prefetch = value; return PSS_OK; }
     if (!strcmp(key, "post_sort_max")) { ctx->post_sort_max = value; return PSS_OK; }
     if (!strcmp(key, "ssb_hilbert")) { ctx->ssb_hilbert = value != 0; return PSS_OK; }
+    if (!strcmp(key, "disc_rows")) { ctx->disc_rows = value != 0; return PSS_OK; }
+    if (!strcmp(key, "disc_spectrum")) { ctx->disc_spectrum = (int)value; return PSS_OK; }
     if (!strcmp(key, "fir_mfma")) { ctx->fir_mfma = value != 0; return PSS_OK; }
     if (!strcmp(key, "fft_xl4096")) { ctx->fft_xl4096 = value != 0; return PSS_OK; }
     if (!strcmp(key, "fft_lean")) { ctx->fft_lean = value; return PSS_OK; }

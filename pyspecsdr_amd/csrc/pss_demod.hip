@@ -339,6 +339,25 @@ __global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, 
 }
 
 }  // namespace
+// floats per discriminator row: the frame's n - 1 values, zero-filled up to the end: the workers fetch one chunk (24 values) past the
+// last one they use, i.e. up to index n + 45
+static inline int pss_disc_ld(int n) { return (n + 48 + 3) & ~3; }
+
+// Discriminator rows for k_nfm_fwd<..., DISC_IN> when no spectrum kernel produces them: d[f][t] = disc_sample(x[t + 1], x[t]) for
+// t < n - 1, zeros up to the row's end (ld floats per frame).  One thread per element, coalesced both ways.
+template <bool SWAPPED>
+__global__ __launch_bounds__(256) void k_disc_rows(const float2 *__restrict__ iq, float *__restrict__ dsc, int n, int ld, long n_frames,
+                                                    float kscale)
+{
+    const long total = n_frames * (long)ld;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const long f = i / ld;
+        const int t = (int)(i - f * ld);
+        const float2 *x = iq + (size_t)f * n;
+        dsc[i] = t < n - 1 ? pss::disc_sample(x[t + 1], x[t], kscale, SWAPPED) : 0.0f;
+    }
+}
+
 #include "pss_nfm_fused.h"
 #include "pss_nfm_mfma.h"
 namespace {
@@ -2251,12 +2270,28 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             // fused path: u[] stays on chip; small L2-resident scratch for the irregular head / tail of u
             const size_t szH = align256((size_t)tiles * fused::HEAD * TILE * sizeof(double));
             const size_t szT = align256((size_t)tiles * (EDGE + 1) * TILE * sizeof(double));
+            // discriminator rows: handed over by the spectrum kernel (ctx->disc_ready), or option "disc_rows": a pass of their own
+            const bool disc_in = (ctx->disc_rows || ctx->disc_ready) && !ctx->fir_mfma;
+            const int ld = ctx->disc_ready ? ctx->disc_ld : pss_disc_ld(n);
+            if (disc_in && !ctx->disc_ready) {
+                r = pss_ensure_buffer(ctx, &ctx->disc_buf, &ctx->disc_bytes, (size_t)n_frames * ld * sizeof(float), "discriminator rows");
+                if (r) return r;
+            }
             r = pss_ensure_scratch(ctx, szY + szA + szH + szT);
             if (r) return r;
             char *base = reinterpret_cast<char *>(ctx->scratch);
             double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);
             double *Uh = reinterpret_cast<double *>(base + szY + szA), *Ut = reinterpret_cast<double *>(base + szY + szA + szH);
+            float *Dsc = reinterpret_cast<float *>(ctx->disc_buf);
             pss_time_begin(ctx);
+            if (disc_in && !ctx->disc_ready) {
+                pss_kernel_begin(ctx, "k_disc_rows");
+                const long tot = n_frames * (long)ld;
+                const unsigned g = (unsigned)std::min<long>((tot + 255) / 256, 65536);
+                if (swapped) hipLaunchKernelGGL(k_disc_rows<true>, dim3(g), dim3(256), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Dsc, n, ld, n_frames, kscale);
+                else hipLaunchKernelGGL(k_disc_rows<false>, dim3(g), dim3(256), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Dsc, n, ld, n_frames, kscale);
+                pss_kernel_end(ctx);
+            }
             pss_kernel_begin(ctx, "k_nfm_fwd");
             if (ctx->fir_mfma) {
                 // opt-in: the FIR as a Toeplitz product on the matrix pipe (another summation order: float64 audio differs in
@@ -2267,11 +2302,15 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
                 else
                     hipLaunchKernelGGL(fusedm::k_nfm_fwd_mfma<false>, dim3((unsigned)tiles), dim3(fusedm::WG), fusedm::LDS_BYTES,
                                        PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
+            } else if (disc_in) {
+                auto kf = b121 ? fused::k_nfm_fwd<true, false, true> : fused::k_nfm_fwd<false, false, true>;
+                hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, targ, Dsc, ld);
             } else {
                 auto kf = b121 ? (swapped ? fused::k_nfm_fwd<true, true> : fused::k_nfm_fwd<true, false>)
                                : (swapped ? fused::k_nfm_fwd<false, true> : fused::k_nfm_fwd<false, false>);
                 hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, targ);
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, targ, nullptr, 0);
             }
             pss_kernel_end(ctx);
             auto launch_bwd = [=]() -> int {
@@ -2962,7 +3001,57 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
         pss_time_end(ctx);
         return rn ? rn : (rd ? rd : rj);
     }
-    // Default schedule (pipe_overlap = 2): forward kernel (VALU-bound, fills the machine) ->
+    // Opt-in schedule for 1024-point frames in large batches (option "disc_spectrum" = 1): the spectrum kernel goes FIRST and hands
+    // the NFM discriminator rows to the forward kernel —
+    //   spectrum (+ discriminator rows) -> forward kernel (reads 4 coalesced bytes per sample instead of the IQ again)
+    //     -> { backward pass || post-process -> display lines }.
+    // Same results bit for bit (the same disc_sample on the same samples).  Measured at cfg 2: the forward kernel drops from 0.58-0.62
+    // to 0.45 ms, but the spectrum kernel (two wavefronts per SIMD: it cannot hide the discriminator's dependent chains) grows from
+    // 0.17 to 0.35 ms and the post-process loses its place beside nothing but the backward pass: 1.11 against 1.09 ms per step.
+    if (ctx->disc_spectrum && n == 1024 && !ctx->fir_mfma && !ctx->no_fused && ctx->fft_lean <= 0 &&
+        (ctx->no_small_batch || n_frames > ctx->small_batch_max) && !ctx->post_legacy) {
+        const int ld = pss_disc_ld(n);
+        int r = pss_ensure_buffer(ctx, &ctx->disc_buf, &ctx->disc_bytes, (size_t)n_frames * ld * sizeof(float), "discriminator rows");
+        ctx->disc_ld = ld;
+        ctx->disc_kscale = (float)(fs / (2.0 * M_PI));
+        ctx->disc_ready = false;
+        if (!r) {
+            PssFlagScope emit(ctx->disc_emit, true);
+            r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+        }
+        ctx->pending_bwd = nullptr;
+        if (!r && ctx->disc_ready) {
+            PssFlagScope defer(ctx->defer_bwd, true);
+            r = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
+        } else if (!r) {
+            r = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);   // the spectrum took a kernel without the hand-over
+        }
+        ctx->disc_ready = false;
+        auto chain = [&]() -> int {
+            int q = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+            if (!q) q = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+            return q;
+        };
+        if (ctx->pending_bwd) {
+            auto bwd = ctx->pending_bwd;
+            ctx->pending_bwd = nullptr;
+            if (!r) r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
+            if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
+            if (!r) {
+                PssStreamScope side(ctx->cur, ctx->stream2);
+                r = chain();
+            }
+            const int rb = bwd();
+            int rj = pss_hip_check(ctx, hipEventRecord(ctx->ev_join, ctx->stream2), "hipEventRecord(join)");
+            if (!rj) rj = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)");
+            if (!r) r = rb ? rb : rj;
+        } else if (!r) {
+            r = chain();
+        }
+        pss_time_end(ctx);
+        return r;
+    }
+    // Otherwise (pipe_overlap = 2): forward kernel (VALU-bound, fills the machine) ->
     //   { backward pass (latency-bound, one wavefront per SIMD)  ||  spectrum -> post-process -> display lines }.
     // pipe_overlap = 0 keeps the spectrum in front of the fork (alone on the machine: 0.17 instead of 0.2 ms, but the backward
     // pass then waits for it): 1.14-1.16 ms per step at cfg 2 against 1.12 ms.

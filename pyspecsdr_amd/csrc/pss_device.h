@@ -16,7 +16,7 @@ namespace pss {
 // VRCP14PS bit-exact model (x86 AVX-512 reciprocal approximation): 64-segment piecewise-linear in the
 // top 16 mantissa bits.  Table derived and exhaustively verified by tools/derive_rcp14.c.
 // {intercept, slope} per segment, one 8-byte load per lookup
-__constant__ uint2 RCP14_AB[64] = {
+static __constant__ uint2 RCP14_AB[64] = {
     {67107072u, 1009u}, {66074112u, 977u}, {65073664u, 949u}, {64102400u, 921u},
     {63159040u, 893u}, {62244608u, 869u}, {61354752u, 843u}, {60491264u, 821u},
     {59650560u, 797u}, {58833920u, 777u}, {58038272u, 755u}, {57264640u, 735u},
@@ -67,7 +67,10 @@ __device__ __noinline__ float atan2f_svml_rare(float y, float x)
 // numpy.arctan2(float32) under NumPy's AVX512_SKX dispatch == Intel SVML __svml_atan2f16 (np.angle at
 // signal_processing.py:94).  Main path for 2^-125 <= |x|,|y| < 2^123; zero operands follow the routine's
 // vector fix-up; NaN/inf/denormal/huge operands use IEEE special values / a double-precision fallback.
-__device__ __forceinline__ float atan2f_svml(float y, float x)
+// The routine's main path, branch-free; `inr` tells whether the operands were in its range (otherwise the value is meaningless and
+// atan2f_svml_rare has the answer).  Split out so that a batch of independent samples can be evaluated as interleaved straight-line
+// chains with ONE (wave-uniform, almost never taken) fix-up branch behind them.
+__device__ __forceinline__ float atan2f_svml_main(float y, float x, bool &inr)
 {
     const float PIO2 = 0x1.921fb6p+0f, PI = 0x1.921fb6p+1f;
     uint32_t xb = f2u(x), yb = f2u(y);
@@ -79,8 +82,7 @@ __device__ __forceinline__ float atan2f_svml(float y, float x)
     bool k1 = ay < ax;
     float a = k1 ? ay : -ax;
     float b = k1 ? ax : ay;
-    bool inr = (fabsf(a) >= 0x1p-125f) && (b < 0x1p123f);
-    if (__builtin_expect(!inr, 0)) return atan2f_svml_rare(y, x);
+    inr = (fabsf(a) >= 0x1p-125f) && (b < 0x1p123f);
     float base = k1 ? 0.0f : PIO2;
     float r0 = rcp14f(b);
     float e = __fmaf_rn(-b, r0, 1.0f);
@@ -104,15 +106,36 @@ __device__ __forceinline__ float atan2f_svml(float y, float x)
     return u2f(f2u(r) | sy);
 }
 
+__device__ __forceinline__ float atan2f_svml(float y, float x)
+{
+    bool inr;
+    // (the range test comes first in the instruction stream: the compiler hoists it and skips the rest when it fails)
+    const float r = atan2f_svml_main(y, x, inr);
+    if (__builtin_expect(!inr, 0)) return atan2f_svml_rare(y, x);
+    return r;
+}
+
 // FM discriminator sample: float32(angle(a * conj(b))) * float32(fs/2pi)   (signal_processing.py:94,97)
 // a = samples[i+1], b = samples[i].  NumPy's complex64 multiply is the FMA form; `swapped` selects the
 // operand order NumPy's temporary elision produces for frames with N-1 >= 32768.
-__device__ __forceinline__ float disc_sample(float2 a, float2 b, float kscale, bool swapped)
+__device__ __forceinline__ void disc_product(float2 a, float2 b, bool swapped, float &re, float &im)
 {
     float c = b.x, d = -b.y;
-    float re = __fmaf_rn(a.x, c, -__fmul_rn(a.y, d));
-    float im = swapped ? __fmaf_rn(a.y, c, __fmul_rn(a.x, d)) : __fmaf_rn(a.x, d, __fmul_rn(a.y, c));
+    re = __fmaf_rn(a.x, c, -__fmul_rn(a.y, d));
+    im = swapped ? __fmaf_rn(a.y, c, __fmul_rn(a.x, d)) : __fmaf_rn(a.x, d, __fmul_rn(a.y, c));
+}
+__device__ __forceinline__ float disc_sample(float2 a, float2 b, float kscale, bool swapped)
+{
+    float re, im;
+    disc_product(a, b, swapped, re, im);
     return __fmul_rn(atan2f_svml(im, re), kscale);
+}
+// the same without the branch to the rare path: `ok` = false where the caller must redo the sample with disc_sample
+__device__ __forceinline__ float disc_sample_main(float2 a, float2 b, float kscale, bool swapped, bool &ok)
+{
+    float re, im;
+    disc_product(a, b, swapped, re, im);
+    return __fmul_rn(atan2f_svml_main(im, re, ok), kscale);
 }
 
 // Inner product in the accumulation order of OpenBLAS ddot (kernel/x86_64/ddot.c + ddot_microk_skylakex-2.c), which is

@@ -609,6 +609,18 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
                 : split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true, false>
                 : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, true> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, false>;
     const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2) : C::LDS;
+    float *dsc = nullptr;
+    if constexpr (LOG_R3 == 2 && !SCAN) {
+        // pss_frame_pipeline_nfm: this launch also writes the NFM discriminator rows (its own instantiations of the unsplit kernel)
+        if (ctx->disc_emit && split && !exact) {
+            dsc = reinterpret_cast<float *>(ctx->disc_buf);
+            kern = pss_r16::k_spectrum_r16<2, false, true, false, false, true>;
+        } else if (ctx->disc_emit && !split) {
+            dsc = reinterpret_cast<float *>(ctx->disc_buf);
+            kern = exact ? (prefetch ? pss_r16::k_spectrum_r16<2, false, false, true, true, true> : pss_r16::k_spectrum_r16<2, false, false, false, true, true>)
+                         : (prefetch ? pss_r16::k_spectrum_r16<2, false, false, true, false, true> : pss_r16::k_spectrum_r16<2, false, false, false, false, true>);
+        }
+    }
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -621,9 +633,10 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_spectrum");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db, tw,
-                       win, n_frames, d_peak, d_bw, d_count, bin_hz, spec_flags(ctx));
+                       win, n_frames, d_peak, d_bw, d_count, bin_hz, spec_flags(ctx), dsc, ctx->disc_ld, ctx->disc_kscale);
     pss_kernel_end(ctx);
     pss_time_end(ctx);
+    if (dsc) ctx->disc_ready = true;
     return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_r16 launch");
 }
 

@@ -192,10 +192,18 @@ __device__ __forceinline__ void for_halves(const float *const (&blk)[NB], const 
 
 // SWAPPED: operand order of the discriminator's complex product for frames of 32 769 samples and more (disc_sample); a template
 // parameter because as a run-time flag both orders were evaluated and selected per sample.
-template <bool B121, bool SWAPPED = false>
+// DISC_IN (opt-in: options "disc_rows" / "disc_spectrum"): the discriminator was evaluated by the producer of `dsc` (k_disc_rows, or
+// the 1024-point spectrum kernel, which holds every sample of the frame in registers anyway: k_spectrum_r16<..., DISC>): rows of `ld`
+// floats per frame, d[t] at [t], zeros from t = n - 1 to the row's end (ld >= n + 2 FC, a multiple of 4: the fetch runs one chunk
+// ahead).  The workers then fetch a chunk as 16-byte pieces, consecutive lanes on consecutive pieces of a frame (6 pieces of a frame,
+// then the next frame: ~12 frames per load instruction) and only move them into the window, instead of 72 bytes of IQ per lane at a
+// stride of one frame (64 different lines per load instruction) that the discriminator then waits for: 0.45 instead of 0.58-0.62 ms
+// at cfg 2.  (With all arithmetic removed the IQ loads alone keep the default kernel at 0.45 ms, 0.17 ms without them.)
+template <bool B121, bool SWAPPED = false, bool DISC_IN = false>
 __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
                                                     double *__restrict__ Uh, double *__restrict__ Utl, int n,
-                                                    long n_frames, NfmCoef c, float kscale, TapsArg taps)
+                                                    long n_frames, NfmCoef c, float kscale, TapsArg taps,
+                                                    const float *__restrict__ dsc = nullptr, int ld = 0)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
@@ -221,7 +229,11 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
         const long ff = tile * TILE + fl;
         const float2 *x = iq + (size_t)(ff < n_frames ? ff : n_frames - 1) * n;
         float d = 0.0f;
-        if (t >= 0 && t < M) d = disc_sample(x[t + 1], x[t], kscale, SWAPPED);
+        if constexpr (DISC_IN) {
+            if (t >= 0) d = dsc[(size_t)(ff < n_frames ? ff : n_frames - 1) * ld + t];
+        } else {
+            if (t >= 0 && t < M) d = disc_sample(x[t + 1], x[t], kscale, SWAPPED);
+        }
         win[fl * WSTR + l] = d;
     }
     __syncthreads();
@@ -326,7 +338,25 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
                 // is free.  The loads are issued after the FIR so they do not occupy registers across it — the other
                 // three waves of the SIMD cover their latency.
                 float dn[OPT];
-                {
+                if constexpr (DISC_IN) {
+                    // the next chunk's FC floats of every frame of the tile: TILE * FC / 4 pieces of 16 bytes over the 64 * NFW worker threads.
+                    // Buffer addressing: the tile's rows as one resource (scalar), the chunk as the scalar offset, one 32-bit byte offset per
+                    // lane — plain pointers became 64-bit per-lane addresses that were hoisted out of the chunk loop and spilled
+                    constexpr int PPF = FC / 4, NP = TILE * PPF / (64 * NFW);
+                    static_assert(FC % 4 == 0 && (TILE * PPF) % (64 * NFW) == 0 && NP * 4 == OPT, "piece split");
+                    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+                    const int wt = tid - 64;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float *>(dsc + (size_t)tile * TILE * ld), 0, (int)(TILE * ld * sizeof(float)), 0x00020000);
+                    const int last = (int)((n_frames - 1 - tile * TILE) < TILE - 1 ? (n_frames - 1 - tile * TILE) : TILE - 1);  // masked frames replay the last one
+#pragma unroll
+                    for (int r = 0; r < NP; r++) {
+                        const int item = wt + 64 * NFW * r, fl = item / PPF, pc = item % PPF;
+                        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((fl < last ? fl : last) * ld + 4 * pc) * 4, (HEAD + (ch + 1) * FC) * 4, 0);
+                        dn[4 * r] = __uint_as_float(v.x); dn[4 * r + 1] = __uint_as_float(v.y);
+                        dn[4 * r + 2] = __uint_as_float(v.z); dn[4 * r + 3] = __uint_as_float(v.w);
+                    }
+                } else {
                     float2 pre[OPT + 1];
                     const int left = M - tn;  // discriminator samples of this batch inside the frame (one scalar per chunk: the bounds n / M themselves live in spilled SGPRs)
 #pragma unroll
@@ -336,9 +366,21 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
                 }
                 lds_barrier();  // A
                 // the oldest block (logical 0) becomes the newest (logical 3 of the next chunk)
-                float *nb = row + rot * FC + OPT * J;
+                if constexpr (DISC_IN) {
+                    constexpr int PPF = FC / 4, NP = TILE * PPF / (64 * NFW);
+                    const int wt = tid - 64;
 #pragma unroll
-                for (int e = 0; e < OPT; e++) nb[e] = dn[e];
+                    for (int r = 0; r < NP; r++) {
+                        const int item = wt + 64 * NFW * r, fl = item / PPF, pc = item % PPF;
+                        float *nb = win + fl * WSTR + rot * FC + 4 * pc;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) nb[k] = dn[4 * r + k];
+                    }
+                } else {
+                    float *nb = row + rot * FC + OPT * J;
+#pragma unroll
+                    for (int e = 0; e < OPT; e++) nb[e] = dn[e];
+                }
                 rot = (rot + 1) & (NB - 1);
                 lds_barrier();  // B
             } else {

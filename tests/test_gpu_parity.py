@@ -1485,6 +1485,17 @@ def test_frame_pipeline_equals_separate_calls():
             e.sync()
             for k in a:
                 assert torch.equal(a2[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k, sched)
+        # opt-in: the NFM discriminator rows as a pass of their own / handed over by the 1024-point spectrum kernel
+        for opt in ("disc_rows", "disc_spectrum"):
+            a3 = bufs()
+            e.set_option(opt, 1)
+            try:
+                e.frame_pipeline_nfm(iq, nf, n, fs, a3["db"], a3["post"], a3["lo"], a3["hi"], 112, a3["g"], a3["c"], a3["pcm"])
+            finally:
+                e.set_option(opt, 0)
+            e.sync()
+            for k in a:
+                assert torch.equal(a3[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k, opt)
         # the fused spectrum + post-process kernel (1024-point frames) against the two separate kernels
         c = bufs()
         e.spectrum_db_post(iq, nf, n, c["db"], c["post"], c["lo"], c["hi"])

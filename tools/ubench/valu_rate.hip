@@ -1,0 +1,73 @@
+// valu_rate.hip — machine-wide issue rate of VALU instruction classes on gfx950 (hipEvent timing, every SIMD holding W wavefronts):
+// wavefront-instructions x 64 lanes / time, and the clocks one wavefront-instruction occupies its SIMD if the shader clock is F GHz.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/ubench/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate [GHz]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#pragma clang fp contract(off)
+
+constexpr int CH = 8, UNR = 8;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(double *out, double a, double b, int iters)
+{
+    double v[CH];
+    float f[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) { v[c] = a + threadIdx.x * 1e-9 + c; f[c] = (float)v[c]; }
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int r = 0; r < UNR; r++) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                if (MODE == 0) v[c] = __fma_rn(v[c], b, a);                                    // v_fma_f64
+                if (MODE == 1) v[c] = v[c] + a;                                                // v_add_f64
+                if (MODE == 2) v[c] = v[c] * b;                                                // v_mul_f64
+                if (MODE == 3) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[c]) : "v"((float)b), "v"((float)a));   // not packed
+                if (MODE == 4) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(v[c]) : "v"(f[c]));  // v_cvt_f64_f32
+                if (MODE == 5) asm volatile("v_add_u32 %0, %0, %1" : "+v"(reinterpret_cast<unsigned &>(f[c])) : "v"(i));
+            }
+        }
+    }
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < CH; c++) s += v[c] + f[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int MODE>
+void run(const char *name, int wg_per_cu, double ghz)
+{
+    const int blocks = 256 * wg_per_cu, iters = 20000;
+    double *d;
+    hipMalloc(&d, (size_t)blocks * 256 * sizeof(double));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1.0000001, 0.9999999, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+    }
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double winstr = (double)blocks * 4 * iters * UNR * CH;   // wavefront-instructions of the measured class
+    const double per_simd = winstr / 1024.0;                        // issued by one SIMD
+    printf("%-14s %d wavefronts/SIMD: %8.3f ms  %7.2f T lane-ops/s  -> %5.2f clk per wavefront-instruction at %.2f GHz\n", name, wg_per_cu, ms,
+           winstr * 64 / (ms * 1e-3) / 1e12, ms * 1e-3 * ghz * 1e9 / per_simd, ghz);
+    hipFree(d);
+}
+
+int main(int argc, char **argv)
+{
+    const double ghz = argc > 1 ? atof(argv[1]) : 2.4;
+    for (int w : {1, 2, 4}) {
+        run<0>("v_fma_f64", w, ghz);
+        run<1>("v_add_f64", w, ghz);
+        run<2>("v_mul_f64", w, ghz);
+        run<3>("v_fma_f32", w, ghz);
+        run<4>("v_cvt_f64_f32", w, ghz);
+        run<5>("v_add_u32", w, ghz);
+    }
+    return 0;
+}
