@@ -27,7 +27,8 @@ constexpr int NB = 4;          // window blocks
 constexpr int WCOLS = NB * FC; // 96 window columns: logical column l <-> time 24 c - 8 + l at chunk c
 constexpr int WSTR = 97;       // float row stride (odd: conflict-free for lane = frame at a fixed column)
 constexpr int HEAD = 64;       // outputs produced by the prologue
-constexpr int NFW = 3;         // FIR worker waves (4 x 6 outputs in 5-wave workgroups measured slower: 0.89 vs 0.67 ms)
+constexpr int NFW = 3;         // FIR worker waves (measured slower: 4 x 6 outputs in 5-wave workgroups 0.89 vs 0.67 ms; 2 x 12 outputs in
+                               // 3-wave workgroups with 168 VGPRs each 0.88 vs 0.60 ms)
 constexpr int OPT = FC / NFW;  // FIR outputs per worker thread and chunk
 constexpr int WG = 64 * (1 + NFW);
 constexpr int HTAPS = 80;     // LDS copy of the reversed taps for the left-edge outputs: 65 taps + 15 zero slots (clamp-free tail loads)
