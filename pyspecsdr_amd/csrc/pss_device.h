@@ -34,11 +34,13 @@ static __constant__ uint2 RCP14_AB[64] = {
     {35791360u, 289u}, {35495680u, 285u}, {35204352u, 279u}, {34919168u, 275u},
     {34638080u, 271u}, {34361088u, 267u}, {34088192u, 263u}, {33819392u, 259u}};
 
-__device__ __forceinline__ float rcp14f(float x)
+// `tab`: the segment table — RCP14_AB itself (constant memory: a vector load of ~300 clocks even when it hits), or a copy the kernel
+// keeps in LDS (k_nfm_fwd, k_spectrum_r16<DISC>: the lookup sits in the middle of every sample's dependent chain)
+__device__ __forceinline__ float rcp14f(float x, const uint2 *tab = RCP14_AB)
 {
     uint32_t u = f2u(x), sign = u & 0x80000000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
     uint32_t idx = m >> 17, low = (m >> 7) & 1023u;
-    const uint2 ab = RCP14_AB[idx];
+    const uint2 ab = tab[idx];
     uint32_t v = (ab.x - ab.y * low) >> 9;
     uint32_t r = sign | ((253u - e) << 23) | ((v & 0xffffu) << 7);
     uint32_t r0 = sign | ((254u - e) << 23);
@@ -70,7 +72,7 @@ __device__ __noinline__ float atan2f_svml_rare(float y, float x)
 // The routine's main path, branch-free; `inr` tells whether the operands were in its range (otherwise the value is meaningless and
 // atan2f_svml_rare has the answer).  Split out so that a batch of independent samples can be evaluated as interleaved straight-line
 // chains with ONE (wave-uniform, almost never taken) fix-up branch behind them.
-__device__ __forceinline__ float atan2f_svml_main(float y, float x, bool &inr)
+__device__ __forceinline__ float atan2f_svml_main(float y, float x, bool &inr, const uint2 *tab = RCP14_AB)
 {
     const float PIO2 = 0x1.921fb6p+0f, PI = 0x1.921fb6p+1f;
     uint32_t xb = f2u(x), yb = f2u(y);
@@ -84,7 +86,7 @@ __device__ __forceinline__ float atan2f_svml_main(float y, float x, bool &inr)
     float b = k1 ? ax : ay;
     inr = (fabsf(a) >= 0x1p-125f) && (b < 0x1p123f);
     float base = k1 ? 0.0f : PIO2;
-    float r0 = rcp14f(b);
+    float r0 = rcp14f(b, tab);
     float e = __fmaf_rn(-b, r0, 1.0f);
     float r1 = __fmaf_rn(r0, e, r0);
     float q0 = __fmul_rn(a, r1);
@@ -106,11 +108,11 @@ __device__ __forceinline__ float atan2f_svml_main(float y, float x, bool &inr)
     return u2f(f2u(r) | sy);
 }
 
-__device__ __forceinline__ float atan2f_svml(float y, float x)
+__device__ __forceinline__ float atan2f_svml(float y, float x, const uint2 *tab = RCP14_AB)
 {
     bool inr;
     // (the range test comes first in the instruction stream: the compiler hoists it and skips the rest when it fails)
-    const float r = atan2f_svml_main(y, x, inr);
+    const float r = atan2f_svml_main(y, x, inr, tab);
     if (__builtin_expect(!inr, 0)) return atan2f_svml_rare(y, x);
     return r;
 }
@@ -124,18 +126,18 @@ __device__ __forceinline__ void disc_product(float2 a, float2 b, bool swapped, f
     re = __fmaf_rn(a.x, c, -__fmul_rn(a.y, d));
     im = swapped ? __fmaf_rn(a.y, c, __fmul_rn(a.x, d)) : __fmaf_rn(a.x, d, __fmul_rn(a.y, c));
 }
-__device__ __forceinline__ float disc_sample(float2 a, float2 b, float kscale, bool swapped)
+__device__ __forceinline__ float disc_sample(float2 a, float2 b, float kscale, bool swapped, const uint2 *tab = RCP14_AB)
 {
     float re, im;
     disc_product(a, b, swapped, re, im);
-    return __fmul_rn(atan2f_svml(im, re), kscale);
+    return __fmul_rn(atan2f_svml(im, re, tab), kscale);
 }
 // the same without the branch to the rare path: `ok` = false where the caller must redo the sample with disc_sample
-__device__ __forceinline__ float disc_sample_main(float2 a, float2 b, float kscale, bool swapped, bool &ok)
+__device__ __forceinline__ float disc_sample_main(float2 a, float2 b, float kscale, bool swapped, bool &ok, const uint2 *tab = RCP14_AB)
 {
     float re, im;
     disc_product(a, b, swapped, re, im);
-    return __fmul_rn(atan2f_svml_main(im, re, ok), kscale);
+    return __fmul_rn(atan2f_svml_main(im, re, ok, tab), kscale);
 }
 
 // Inner product in the accumulation order of OpenBLAS ddot (kernel/x86_64/ddot.c + ddot_microk_skylakex-2.c), which is

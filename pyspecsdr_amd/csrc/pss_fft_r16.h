@@ -382,7 +382,9 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
                          : ex_all + (size_t)FPW * C::EX;  // W_T^(m1*j2), [m1][j2]
     __shared__ float red_f[4];
     __shared__ int red_i[4];
+    __shared__ uint2 rtab[DISC ? 64 : 1];   // the discriminator's reciprocal table (pss_device.h rcp14f): its lookup sits in every sample's dependent chain
     const int tid = threadIdx.x;
+    if (DISC && tid < 64) rtab[tid] = pss::RCP14_AB[tid];
     const int fl = tid / T;   // frame slot inside the workgroup
     const int t = tid % T;    // thread inside the frame: n1 in stage 1, (k2, m1) in stage 2, rho in stage 3
     double2 *ex = ex_all + (size_t)fl * C::EX;
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
                 for (int n2 = g4; n2 < g4 + DB; n2++) {
                     const float2 nxt = (t == T - 1) ? nb[n2 + 1] : nb[n2];   // x[j + 1] for j = t + 64 n2
                     bool ok;
-                    dv[n2] = pss::disc_sample_main(nxt, nx[n2], kscale, false, ok);
+                    dv[n2] = pss::disc_sample_main(nxt, nx[n2], kscale, false, ok, rtab);
                     redo = redo || !ok;
                 }
                 if (__builtin_amdgcn_ballot_w64(redo)) {

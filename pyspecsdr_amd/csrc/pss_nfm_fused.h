@@ -32,7 +32,7 @@ constexpr int NFW = 3;         // FIR worker waves (measured slower: 4 x 6 outpu
 constexpr int OPT = FC / NFW;  // FIR outputs per worker thread and chunk
 constexpr int WG = 64 * (1 + NFW);
 constexpr int HTAPS = 80;     // LDS copy of the reversed taps for the left-edge outputs: 65 taps + 15 zero slots (clamp-free tail loads)
-constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double) + HTAPS * sizeof(double);
+constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double) + HTAPS * sizeof(double) + 64 * sizeof(uint2);
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence that also waits for every
 // outstanding GLOBAL store of the wave (vmcnt(0)); the IIR wave has 24 y_fwd row stores in flight per chunk, and
@@ -210,6 +210,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
     double *ubuf = reinterpret_cast<double *>(smem + (size_t)TILE * WSTR * sizeof(float));  // [FC][TILE]
     double *ltaps = ubuf + (size_t)TILE * FC;                                        // reversed taps (left-edge dots)
+    uint2 *ltab = reinterpret_cast<uint2 *>(ltaps + HTAPS);                          // the discriminator's reciprocal table (pss_device.h rcp14f)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: everything indexed by the role / chunk stays scalar
     const long tile = blockIdx.x;
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
     double *Uht = Uh + (size_t)tile * HEAD * TILE + lane;
     double *Utt = Utl + (size_t)tile * (EDGE + 1) * TILE + lane;
 #define YAT(p) Yt[(size_t)(p) * TILE]
+    if (tid >= 128 && tid < 192) ltab[tid - 128] = RCP14_AB[tid - 128];
     if (tid < HTAPS) ltaps[tid] = tid < 65 ? taps.rev[tid] : 0.0;  // ltaps[m] = taps[64 - m]: output i pairs x[j] with ltaps[64 - i + j]
     // ---- prologue: discriminator of times 0..87 into logical columns 8..95 (physical = logical at chunk 0)
     for (int idx = tid; idx < TILE * WCOLS; idx += WG) {
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
 #pragma unroll
                     for (int e = 0; e <= OPT; e++) pre[e] = (e <= left) ? xq[tn + e] : make_float2(0.0f, 0.0f);
 #pragma unroll
-                    for (int e = 0; e < OPT; e++) dn[e] = (e < left) ? disc_sample(pre[e + 1], pre[e], kscale, SWAPPED) : 0.0f;
+                    for (int e = 0; e < OPT; e++) dn[e] = (e < left) ? disc_sample(pre[e + 1], pre[e], kscale, SWAPPED, ltab) : 0.0f;
                 }
                 lds_barrier();  // A
                 // the oldest block (logical 0) becomes the newest (logical 3 of the next chunk)
