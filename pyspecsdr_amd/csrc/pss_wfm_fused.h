@@ -22,7 +22,7 @@ using namespace pss;
 constexpr int CH = 16;                 // input samples staged per chunk
 constexpr int XSTR = TILE + 1;         // float2 row stride of the transposed input chunk
 constexpr int RING = EDGE + 1;         // 28 most recent outputs per channel
-constexpr size_t LDS_BYTES = (size_t)CH * XSTR * sizeof(float2) + (size_t)RING * 2 * TILE * sizeof(double);
+constexpr size_t LDS_BYTES = (size_t)CH * XSTR * sizeof(float2) + (size_t)RING * 2 * TILE * sizeof(double) + 64 * sizeof(uint2);
 
 __device__ __forceinline__ double vreg(double v)
 {
@@ -62,7 +62,9 @@ __global__ __launch_bounds__(TILE) void k_wfm_fwd(const float2 *__restrict__ iq,
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *xs = reinterpret_cast<float2 *>(smem);                                   // [CH][XSTR]
     double *ring = reinterpret_cast<double *>(smem + (size_t)CH * XSTR * sizeof(float2));  // [RING][2][TILE]
+    uint2 *ltab = reinterpret_cast<uint2 *>(ring + (size_t)RING * 2 * TILE);          // the discriminator's reciprocal table (rcp14f): in every step's chain
     const int lane = threadIdx.x;
+    ltab[lane] = pss::RCP14_AB[lane];   // one wavefront per workgroup: visible to itself in program order
     const long tile = blockIdx.x;
     const long f0 = tile * TILE;
     const int M = n - 1;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(TILE) void k_wfm_fwd(const float2 *__restrict__ iq,
                 if (t < cnt) {
                     const float2 cur = xs[t * XSTR + lane];
                     if (i < 0) { prev = cur; continue; }
-                    const double d = (double)disc_sample(cur, prev, 1.0f, swapped != 0);  // :122 (x1.0f is exact)
+                    const double d = (double)disc_sample(cur, prev, 1.0f, swapped != 0, ltab);  // :122 (x1.0f is exact)
                     prev = cur;
                     const double a = lp3(d, zlp);                                                              // :126
                     const double p = bp5(pil, d, zpi);                                                         // :129
