@@ -156,3 +156,22 @@ def test_zero_edit_dropin_resolves_the_reference_module_names(tmp_path):
     out = subprocess.run([sys.executable, "-m", "pyspecsdr_amd.run", str(app), "--demod", "WFM"], cwd=root, check=True,
                          capture_output=True, text=True, timeout=300).stdout
     assert "ARGS ['--demod', 'WFM']" in out
+
+
+def test_bench_profile_digest_accounting():
+    """bench.py quotes PMC-derived numbers only from a digest taken on THIS source tree (hash of pyspecsdr_amd/csrc); the VALU issue
+    accounting weighs float64-class instructions at 4 clocks and 32-bit ones at 2 (tools/ubench/valu_rate.hip)."""
+    import json
+    import bench
+    dig = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    k = dig["kernels"]["k_nfm_fwd"]
+    f64 = sum(k[c] for c in ("sq_insts_valu_add_f64", "sq_insts_valu_mul_f64", "sq_insts_valu_fma_f64", "sq_insts_valu_cvt"))
+    want = (f64 / bench.VALU_RATE_F64 + (k["valu_insts"] - f64) / bench.VALU_RATE_B32) * 1e3
+    assert abs(bench.valu_issue_ms(k) - want) < 1e-9 and 0.2 < want < 0.6          # ~0.33 ms of pure issue per launch
+    traffic, busy, note = bench.profiled("k_nfm_fwd", dig["n_frames"])
+    sv = bench.step_valu(["k_nfm_fwd", "k_spectrum", "k_post", "k_disp_rows", "k_nfm_bwd"], dig["n_frames"], 1.1)
+    if dig["src_hash"] == bench.source_hash():
+        assert traffic == k["traffic_bytes"] and 0.3 < busy < 1.0 and 0.3 < sv["frac"] < 1.0
+    else:                                                                            # stale digest: nothing is quoted from it
+        assert traffic is None and busy is None and sv is None and "is from source" in note
+    assert bench.profiled("k_nfm_fwd", dig["n_frames"] + 1)[1] is None               # another batch size: no busy fraction
