@@ -175,3 +175,20 @@ def test_bench_profile_digest_accounting():
     else:                                                                            # stale digest: nothing is quoted from it
         assert traffic is None and busy is None and sv is None and "is from source" in note
     assert bench.profiled("k_nfm_fwd", dig["n_frames"] + 1)[1] is None               # another batch size: no busy fraction
+
+
+def test_microbenchmarks_compile_for_gfx950():
+    """The measurement programs DESIGN.md cites (tools/ubench/*.hip) still build (hipcc cross-compiles without a GPU)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    cc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(cc):
+        pytest.skip("hipcc not available")
+    srcs = sorted(glob.glob(os.path.join(ROOT, "tools", "ubench", "*.hip")))
+    assert srcs
+    with tempfile.TemporaryDirectory() as d:
+        procs = [subprocess.Popen([cc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-w", "-c", s, "-o",
+                                   os.path.join(d, os.path.basename(s) + ".o")]) for s in srcs]
+        assert all(p.wait() == 0 for p in procs)
