@@ -2,7 +2,11 @@
 """bench.py — BASELINE.json headline metric on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+--gpus N means N ranks, one per GPU, whoever starts them: run without a launcher, the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`; run under one, it checks that the launcher's
+WORLD_SIZE is N.  Fewer than N visible GPUs, or a world size other than N, end the run with a message and exit status 2 — never a
+one-GPU number labelled N.  The result line carries the world size RCCL reported and the library's version.
 
 One "step" = one pass of the hot path over one batch of synthetic FM-modulated IQ already resident in HBM
 (BASELINE.json configs[1] = 65 536 frames x 1024 points @ 2.4 MS/s per GPU), for EVERY frame of the batch:
@@ -176,11 +180,65 @@ def cpu_baseline(iq_host, fs, taps, sos, zi, min_wall_s=1.0, max_wall_s=25.0):
     }
 
 
+def verify_step(eng, iq, fs, d_db, d_post, pk, o_col, o_pcm, n_out, window):
+    """Outside the timed region: the outputs the LAST timed step left in HBM against the CPU oracle (oracle/pss_oracle.c, the checker,
+    never the thing measured) on blocks of consecutive frames spread over the batch — dB rows (1e-4 relative), post-processed
+    rows (same tolerance), NFM int16 PCM (equal), waterfall lines (equal to the oracle's quantiser run on the rows the device produced;
+    lines whose 30-row history starts before the block are skipped except in the block that starts at frame 0)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    nf, n = iq.shape[0], iq.shape[1]
+    m = n - 4
+    blk = min(nf, window + 10)
+    starts = sorted({0, max(0, nf // 3 - 7), max(0, (2 * nf) // 3 + 5), nf - blk})
+    taps, sos, zi = eng.nfm_filters(fs)
+    glyph = pk[:o_col].view(torch.int8).view(nf, DISP_W)
+    colour = pk[o_col:o_pcm].view(torch.int8).view(nf, DISP_W)
+    pcm = pk[o_pcm:].view(torch.int16).view(nf, n_out, 2)
+    res = {"frames": 0, "lines_checked": 0, "db_max_rel": 0.0, "post_max_rel": 0.0, "pcm_equal": True, "lines_equal": True,
+           "blocks": [[s0, s0 + blk] for s0 in starts]}
+    rel = lambda got, ref: float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)))
+    for s0 in starts:
+        sl = slice(s0, s0 + blk)
+        h_iq = iq[sl].cpu().numpy().view(np.complex64).reshape(blk, n)
+        buf = O.HeadlineBuffers(blk, n, fs, DISP_W)
+        O.batch_headline(h_iq, fs, taps, sos, zi, buf, 1, window)
+        g_db, g_pcm = d_db[sl].cpu().numpy(), pcm[sl].cpu().numpy()
+        res["db_max_rel"] = max(res["db_max_rel"], rel(g_db.astype(np.float64), buf.db.astype(np.float64)))
+        res["pcm_equal"] = res["pcm_equal"] and bool(np.array_equal(g_pcm, buf.pcm))
+        if d_post is not None:
+            g_post = np.ascontiguousarray(d_post[sl].cpu().numpy())
+            ref_post = np.stack([O.postprocess(g_db[k].astype(np.float64)) for k in range(blk)])
+            res["post_max_rel"] = max(res["post_max_rel"], rel(g_post.astype(np.float64), ref_post))
+            O.lib().pss_o_waterfall_rows(g_post.reshape(-1), blk, m, window, DISP_W, buf.glyph.reshape(-1), buf.colour.reshape(-1), 1)
+        first = 0 if s0 == 0 else window - 1        # lines with a complete history inside the block
+        res["lines_equal"] = res["lines_equal"] and bool(np.array_equal(glyph[sl].cpu().numpy()[first:], buf.glyph[first:])
+                                                         and np.array_equal(colour[sl].cpu().numpy()[first:], buf.colour[first:]))
+        res["frames"] += blk
+        res["lines_checked"] += blk - first
+    res["ok"] = bool(res["db_max_rel"] <= 1e-4 and res["post_max_rel"] <= 1e-4 and res["pcm_equal"] and res["lines_equal"])
+    res["note"] = ("outputs of the last timed step vs the CPU oracle, outside the timed region: dB and post-processed rows within 1e-4 * "
+                   "max(|ref|, 1), int16 PCM and waterfall lines (glyph + colour) equal")
+    return res
+
+
+def dry_run(args, world, rank):
+    """The launch path without a GPU (tests): N ranks rendezvous over gloo and rank 0 prints one line that says who was there."""
+    import torch.distributed as dist
+    pids = [os.getpid()]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        pids = [None] * world
+        dist.all_gather_object(pids, os.getpid())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "gpus_arg": args.gpus, "pids": pids, "value": None}), flush=True)
+
+
 def main():
-    # stdout carries ONE line: the result.  Everything else this process or its libraries print there (RCCL's version banner is a
-    # C-level printf that libc flushes at exit, i.e. AFTER a Python print) is sent to stderr by pointing fd 1 at fd 2 for the run.
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -192,11 +250,19 @@ def main():
     ap.add_argument("--no-side", action="store_true",
                     help="skip the untimed side measurements (standalone kernels, the 30-row reading, exchange alone): under a profiler "
                          "every launch then belongs to a step of the default schedule")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step's outputs")
+    ap.add_argument("--dry-run", action="store_true", help="launch path only (gloo rendezvous, no GPU work): what the CPU test runs")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # N ranks for --gpus N: re-executes under torch.distributed.run when started bare; exits 2 on any mismatch (pyspecsdr_amd/launch.py)
+    from pyspecsdr_amd.launch import ensure_ranks
+    world, rank, local_rank = ensure_ranks(args.gpus, __file__, sys.argv[1:], need_gpus=not args.dry_run)
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    # stdout carries ONE line: the result.  Everything else this process or its libraries print there (RCCL's version banner is a
+    # C-level printf that libc flushes at exit, i.e. AFTER a Python print) is sent to stderr by pointing fd 1 at fd 2 for the run.
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     dist = None
     if world > 1 or os.environ.get("PSS_BENCH_DIST") == "1":   # PSS_BENCH_DIST=1: exercise the RCCL path on one GPU
         import torch.distributed as dist
@@ -287,6 +353,15 @@ def main():
     eng.enable_timing(False)
 
     # ---- outside the timed region -------------------------------------------------------------------------------------
+    verified = None
+    if not args.no_verify:
+        last = (args.steps - 1) & 1 if args.steps else 0
+        verified = verify_step(eng, iq, FS, d_db[last % len(d_db)], d_post, packed[last], o_col, o_pcm, n_out, WF_WINDOW)
+        if dist is not None:      # every rank checks its own outputs; the line reports the conjunction
+            okt = torch.tensor([1 if verified["ok"] else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            verified["ok_all_ranks"] = bool(okt.item())
+
     def timed(fn, reps=5):
         fn(); fence()
         t = time.perf_counter()
@@ -404,6 +479,11 @@ def main():
                                     "db": "RCCL gather to rank 0 of every rank's float32 dB rows, inside the timed region",
                                     "none": "none (one rank)"}[exch]},
             "roofline": roof,
+            "verified": verified,
+            "ranks": {"world": world if dist is None else dist.get_world_size(), "gpus_arg": args.gpus,
+                      "backend": None if dist is None else dist.get_backend(),
+                      "rccl_version": None if dist is None else ".".join(map(str, torch.cuda.nccl.version())),
+                      "devices_visible": torch.cuda.device_count()},
             "src_hash": source_hash(),
         }
         out.update(side)
@@ -419,6 +499,9 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if verified is not None and not verified.get("ok_all_ranks", verified["ok"]):
+        sys.stderr.write(f"bench.py: the timed steps' outputs do NOT match the oracle: {verified}\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -64,10 +64,17 @@ class ShardedScanner:
 
     def sweep(self, d_iq_local):
         """Queue one sweep over this rank's block (d_iq_local: interleaved complex64 [count][n_fft] on this rank's GPU)
-        and its gather.  Asynchronous; returns a handle for result()."""
+        and its gather.  Asynchronous; returns a handle for result().
+
+        Ordering against the caller: everything queued so far on torch's CURRENT stream — the producer of d_iq_local, and the
+        consumers of an earlier result() (its tensors are views / concatenations of the buffer set this sweep is about to reuse)
+        — finishes before this sweep's scan and gather start."""
         b = self.k & 1
         self.k += 1
         buf = self.bufs[b]
+        cur = torch.cuda.current_stream(self.device)
+        self.comp.wait_stream(cur)
+        self.comm.wait_stream(cur)
         if self.sent[b] is not None:
             self.comp.wait_event(self.sent[b])
         db = buf.view("db") if self.gather_db else self.db_local[b]
@@ -78,10 +85,10 @@ class ShardedScanner:
             with torch.cuda.stream(self.comm):
                 if self.host_stage:
                     h = buf.raw.cpu()            # synchronous on the comm stream
-                    dist.gather(h, list(self.recv[b].unbind(0)) if self.rank == self.dst else None, dst=self.dst, group=self.group)
+                    dist.gather(h, list(self.recv[b].unbind(0)) if self.rank == self.dst else None, group=self.group, group_dst=self.dst)
                 else:
-                    dist.gather(buf.raw, list(self.recv[b].unbind(0)) if self.rank == self.dst else None, dst=self.dst,
-                                group=self.group)
+                    dist.gather(buf.raw, list(self.recv[b].unbind(0)) if self.rank == self.dst else None, group=self.group,
+                                group_dst=self.dst)
                 self.sent[b] = self.comm.record_event()
         return b
 
@@ -139,7 +146,7 @@ def sharded_stream_display(engine, h_iq_local, fs, chunk_frames, mode="waterfall
         return lines, pcm
     # one packed message per rank: [lines... | pcm]
     dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", engine.device)
-    counts = shard_counts_from(torch.tensor([h_iq_local.shape[0]], dtype=torch.int64), group)
+    counts = shard_counts_from(torch.tensor([h_iq_local.shape[0]], dtype=torch.int64), group, device=dev)
     fields = [(f"l{i}", (disp_w,), torch.int8) for i in range(len(lines))] + [("pcm", tuple(pcm.shape[1:]), torch.int16)]
     buf = ShardBuffer(fields, max(counts), dev)
     for i, a in enumerate(lines):
@@ -151,12 +158,13 @@ def sharded_stream_display(engine, h_iq_local, fs, chunk_frames, mode="waterfall
     return tuple(got[f"l{i}"].cpu().numpy() for i in range(len(lines))), got["pcm"].cpu().numpy()
 
 
-def shard_counts_from(count_tensor, group=None):
-    """All ranks' block sizes (blocks need not come from shard_range: a capture is cut where the caller cut it)."""
+def shard_counts_from(count_tensor, group=None, device=None):
+    """All ranks' block sizes (blocks need not come from shard_range: a capture is cut where the caller cut it).
+    device: where the collective's buffers live (the engine's GPU for RCCL; default: the tensor's own device, or the host under gloo)."""
     world, _ = _world_rank(group)
     if world == 1:
         return [int(count_tensor.item())]
-    dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    dev = "cpu" if dist.get_backend(group) == "gloo" else (device if device is not None else count_tensor.device)
     allc = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allc, count_tensor.to(dev), group=group)
     return [int(c) for c in allc.tolist()]
@@ -165,7 +173,7 @@ def shard_counts_from(count_tensor, group=None):
 def _gather_uneven(buf, counts, dst, group):
     world, rank = _world_rank(group)
     out = torch.empty((world, buf.nbytes), dtype=torch.uint8, device=buf.raw.device) if rank == dst else None
-    dist.gather(buf.raw, list(out.unbind(0)) if rank == dst else None, dst=dst, group=group)
+    dist.gather(buf.raw, list(out.unbind(0)) if rank == dst else None, group=group, group_dst=dst)
     if rank != dst:
         return None
     return unpack_gathered(buf, out, counts)

@@ -67,6 +67,8 @@ class ShardBuffer:
 def gather_packed(buf, n_items, dst=0, group=None, out=None):
     """ONE collective for everything a rank produced: gather (dst = rank) or all_gather (dst = None) of `buf.raw`.
 
+    `dst` (here and everywhere in this package) is a rank of `group`, not a global rank: with a sub-group the two differ, and
+    torch.distributed's plain dst= / peer= arguments mean global ranks — hence group_dst= / group_peer= below.
     Returns on the receiving rank(s) a dict name -> [n_items, *shape] tensor in item order (blocks of shard_range(),
     the per-rank padding dropped); None on the others.  `out`: optional preallocated [world, buf.nbytes] uint8 tensor
     on the receiving rank (reused across sweeps).  With one rank nothing is communicated.
@@ -82,7 +84,7 @@ def gather_packed(buf, n_items, dst=0, group=None, out=None):
     else:
         if rank == dst and out is None:
             out = torch.empty((world, buf.nbytes), dtype=torch.uint8, device=buf.raw.device)
-        dist.gather(buf.raw, list(out.unbind(0)) if rank == dst else None, dst=dst, group=group)
+        dist.gather(buf.raw, list(out.unbind(0)) if rank == dst else None, group=group, group_dst=dst)   # dst is a rank OF THE GROUP
         if rank != dst:
             return None
     return unpack_gathered(buf, out, counts)
@@ -147,7 +149,7 @@ def halo_from_left(local, halo, group=None):
         if b > a:
             t = torch.empty((b - a,) + tail, dtype=local.dtype, device=local.device)
             pieces.append(t)
-            ops.append(dist.P2POp(dist.irecv, t, s, group))
+            ops.append(dist.P2POp(dist.irecv, t, group=group, group_peer=s))   # peers are ranks of the group
     keep = []
     for r in range(rank + 1, world):               # what the ranks to my right need from me
         a, b = need(r)
@@ -155,7 +157,7 @@ def halo_from_left(local, halo, group=None):
         if b > a:
             t = local[a - starts[rank]:b - starts[rank]].contiguous()
             keep.append(t)
-            ops.append(dist.P2POp(dist.isend, t, r, group))
+            ops.append(dist.P2POp(dist.isend, t, group=group, group_peer=r))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()

@@ -135,3 +135,71 @@ def test_halo_exchange_feeds_ring_accumulators(world, n_rows):
     for p in procs:
         p.join(timeout=120)
     assert done == list(range(world)) and all(p.exitcode == 0 for p in procs)
+
+
+def _subgroup_worker(rank, world, port, q):
+    """A sub-group that does not contain global rank 0: group ranks and global ranks differ, so a gather `dst` or a halo
+    peer taken for a global rank would address the wrong process (or hang)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        members = list(range(1, world))
+        grp = dist.new_group(ranks=members)        # collective over ALL ranks
+        if rank in members:
+            gw, gr = dist.get_world_size(grp), dist.get_rank(grp)
+            assert (gw, gr) == (world - 1, rank - 1)
+            n_items = 11
+            start, count = shard_range(n_items, gr, gw)
+            mine = torch.arange(start, start + count, dtype=torch.float64).unsqueeze(1) * torch.tensor([1.0, -2.0])
+            for dst in (0, gw - 1):                # a rank OF THE GROUP (global rank dst + 1)
+                full = gather_rows(mine, n_items, dst=dst, group=grp)
+                if gr == dst:
+                    assert torch.equal(full, torch.arange(n_items, dtype=torch.float64).unsqueeze(1) * torch.tensor([1.0, -2.0]))
+                else:
+                    assert full is None
+            assert torch.equal(gather_rows(mine, n_items, dst=None, group=grp)[:, 0], torch.arange(n_items, dtype=torch.float64))
+            left = halo_from_left(mine, 5, group=grp)
+            assert torch.equal(left[:, 0], torch.arange(max(0, start - 5), start, dtype=torch.float64))
+        dist.barrier()
+        q.put(rank)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sub_group_ranks_are_group_ranks():
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    done = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    assert done == list(range(world)) and all(p.exitcode == 0 for p in procs)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` — no launcher — must become two processes that rendezvous, and print ONE result line saying so; a
+    launcher whose world size is not --gpus, or fewer visible GPUs than --gpus, must end the run with exit status 2 (no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and len(set(lines[0]["pids"])) == 2, r.stdout
+    # under a launcher with another world size
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert r.returncode == 2 and "launcher started 1 rank" in r.stderr
+    if not torch.cuda.is_available():   # the real run refuses to label a 1-GPU (here: 0-GPU) box as 2 GPUs
+        for script in ("bench.py", os.path.join("tools", "bench_multi.py")):
+            r = subprocess.run([sys.executable, os.path.join(root, script), "--gpus", "2"], capture_output=True, text=True, env=env,
+                               timeout=120)
+            assert r.returncode == 2 and "GPU(s) are visible" in r.stderr, (script, r.stderr[-500:])

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Multi-rank benchmark of the sharded configs (BASELINE.json configs[3] / configs[4] halves that need > 1 GPU).
 
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        tools/bench_multi.py --config cfg4 [--steps K]
-    (N = 1 works too: PSS_BENCH_DIST=1 python tools/bench_multi.py --config cfg4 initialises RCCL with one rank.)
+    python tools/bench_multi.py --gpus N --config cfg4 [--steps K]
+    (starts N ranks itself — pyspecsdr_amd/launch.py: re-executes under python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 — or checks the world size of the launcher it was started under; fewer than N visible GPUs: exit 2.
+    N = 1 works too: PSS_BENCH_DIST=1 python tools/bench_multi.py --config cfg4 initialises RCCL with one rank.)
 
 cfg5: 10 s @ 10 MS/s capture in 2048-pt frames, every rank streams its block from its own pinned host memory through
 spectrum + post-process + display accumulator + NFM and gets display lines + int16 PCM back (PCIe-inclusive rate).
@@ -70,6 +71,7 @@ def cfg5(args, eng, dev, world, rank, use_dist, fence, maxr):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (default: the launcher's WORLD_SIZE, else 1)")
     ap.add_argument("--config", choices=["cfg4", "cfg5"], default="cfg4")
     ap.add_argument("--seconds", type=float, default=10.0, help="cfg5: length of the capture at 10 MS/s")
     ap.add_argument("--steps", type=int, default=20)
@@ -77,9 +79,9 @@ def main():
     ap.add_argument("--slices", type=int, default=8192)
     ap.add_argument("--n-fft", type=int, default=4096)
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from pyspecsdr_amd.launch import ensure_ranks
+    gpus = args.gpus if args.gpus is not None else int(os.environ.get("WORLD_SIZE", "1"))
+    world, rank, local_rank = ensure_ranks(gpus, __file__, sys.argv[1:])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29534")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
