@@ -48,48 +48,25 @@ void *pss_get_stream(pss_ctx *ctx);
 int pss_sync(pss_ctx *ctx);
 const char *pss_last_error(pss_ctx *ctx); /* ctx may be NULL: error of the last failed pss_create */
 int pss_device_count(void);
-/* Tuning / testing switches; every alternative path produces identical bits (one exception, last).  Returns PSS_E_ARG for unknown keys.
- *   "nfm_fused" (1)            0: lane-per-frame three-kernel NFM path (front, edge, iir) instead of the fused kernels
- *   "wfm_fused" (1)            0: k_wfm_front + lane-per-frame decimator instead of the fused WFM forward kernel
+/* Switches.  Returns PSS_E_ARG for unknown keys.  Every alternative path produces the same int16 samples and float64 audio.
+ *   "nfm_fused" (1)            0: lane-per-frame three-kernel NFM path (front, edge, iir) instead of the fused kernels (test fallback)
+ *   "wfm_fused" (1)            0: k_wfm_front + lane-per-frame decimator instead of the fused WFM forward kernel (test fallback)
  *   "small_batch" (1)          0: never take the latency-oriented small-batch kernels (one lane per filter section)
  *   "small_batch_max" (8192)   largest NFM frame count that takes them;  "wfm_small_batch_max" (8192) likewise for WFM
  *   "ssb_hilbert" (1)          0: demodulate_ssb skips the reference's hilbert() FFT round trip (the identity on the real part it
  *                              keeps, up to ~1e-16); 1: executed for power-of-two frames of 256..1048576 samples
- *   "fuse_post" (0)            1: pss_spectrum_db_post takes the fused spectrum + post-process kernel for 1024-point frames
- *   "disc_rows" (0)            1: the NFM discriminator as a pass of its own (float32 rows) that the forward kernel then reads in
- *                              16-byte pieces instead of fetching the IQ at one line per lane (forward kernel 0.62 -> 0.45 ms at cfg 2, the
- *                              pass itself 0.23 ms: a measurement aid).  "disc_spectrum" (0) 1: pss_frame_pipeline_nfm lets the 1024-point
- *                              spectrum kernel write those rows and runs spectrum -> forward -> {backward || post-process -> lines}
- *                              (1.11 against 1.09 ms per step at cfg 2: not the default).  Same results bit for bit.
- *   "pipe_overlap" (2)         schedule of pss_frame_pipeline_nfm.  2: forward kernel -> {backward pass || spectrum -> post-process ->
- *                              lines}; 0: forward kernel -> spectrum -> {backward pass || post-process -> lines} (2 % slower);
- *                              1: the whole display chain on the side stream from the start (5 % faster when the forward kernel
- *                              reaches the dispatcher first, 8 % slower when it does not)
- *   "post_legacy" (0)          1: the post-process takes the LDS bitonic sort / LDS-histogram radix select kernels instead of
- *                              the register-resident binary-search select;  "post_sort_max" (8192): longest row the legacy
- *                              path sorts (longer rows: radix select)
- *   "fft_split" (-1 = auto)    1 / 0: force / forbid the component-wise LDS exchanges of the register FFT (auto: N = 256)
- *   "fft_big_scratch" (0)      1: N = 8192 / 16384 on the scratch-based pre-pass kernel instead of the four-stage register kernel
  *   "db_exact" (0)             1: compute_fft's dB rows (pss_spectrum_db and everything built on it) are evaluated to float64 accuracy and
  *                              rounded once: the float32 row then IS the float32 rounding of the reference's float64 row (all 69 490
  *                              golden values; measured on FM frames: 5 of 8.4 million bins off by one ulp, where the value lies within
  *                              ~1e-15 of a rounding boundary).  0 (default): float32 evaluation of the logarithm, 1-2 ulp from that
  *                              (the contract is 1e-4 relative); the exact evaluation costs the spectrum kernels 15-25 % (0.17 -> 0.20 ms
- *                              at cfg 2, 0.75 -> 0.91 ms at 8192 x 16384) and the bench step 3 %; "fuse_post" / "fft_lean" need 0
+ *                              at cfg 2, 0.75 -> 0.91 ms at 8192 x 16384) and the bench step 3 %
  *   "scan_exact" (1)           0: scanner slices (pss_scan, pss_scan_threshold) get their dB values from compute_fft's float64 / hardware-log2
  *                              evaluation (1e-4 relative; 30 % faster at 8192 x 4096) instead of NumPy's float32 chain bit for bit
- *   "fft_lean" (0)             1: N = 1024 / 2048 spectra on the 112-VGPR component-wise-exchange kernel (k_spectrum_lean) instead of
- *                              k_spectrum_r16 (same results within the dB tolerance, not bit-identical: twiddle powers by product chains)
- *   "fft_xl4096" (1)           0: N = 4096 (spectrum and scanner slice) on the three-stage kernel with complex LDS exchanges
- *                              (k_spectrum_r16<4>: 240 VGPRs, two workgroups per CU) instead of the component-wise-exchange kernel
- *                              (128 VGPRs, four workgroups per CU)
- *   "fft_prefetch" (-1 = auto) 1 / 0: force / forbid requesting the next frame's samples before transforming the current one
- *                              (auto: N = 1024 and 2048)
- * The ONE switch that changes results:
- *   "fir_mfma" (0)             1: the NFM forward kernel runs its 65-tap FIR as a Toeplitz product on the matrix pipe
- *                              (v_mfma_f64_16x16x4_f64): another summation order than the reference's OpenBLAS ddot, so the float64
- *                              audio differs in the last bits (~1e-16 relative); int16 PCM differs only where a sample lies
- *                              within ~3e-11 of an integer boundary.  Faster (0.60 against 0.71 ms at cfg 2: the VALU keeps only discriminator + IIR). */
+ * Kernel-selection knobs of earlier rounds' A/B measurements ("fft_split", "fft_prefetch", "fft_xl4096", "fft_big_scratch", "post_legacy",
+ * "post_sort_max") exist only in builds with -DPSS_VARIANTS (tools/build_variant.py); the experiments that lost — the FIR on the matrix
+ * pipe, discriminator rows handed from the spectrum kernel, the fused spectrum + post-process kernel, the 112-VGPR spectrum kernel, the
+ * alternative pipeline schedules, CU-mask partitioning — are documented with their measurements in DESIGN.md and no longer compiled in. */
 int pss_set_option(pss_ctx *ctx, const char *key, int value);
 
 /* ---- filter design (host side, pure C++; replaces the per-call SciPy design work) -------------- */
@@ -129,10 +106,7 @@ int pss_spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft,
  * without a finite value): what the display accumulators below normalise with. */
 int pss_spectrum_post_extremes(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_row_lo,
                                float *d_row_hi);
-/* compute_fft and the post-process of the same frames in one call (d_db, d_post, and — both or neither — the row extremes);
- * 1024-point frames run as ONE kernel: the dB row goes from the transform's registers through LDS into the post-process
- * (option "fuse_post"; default 0: measured no faster inside a pipeline step — 0.52 ms against 0.30 + 0.19 — because the
- * post-process then runs at the transform's two wavefronts per SIMD), other lengths as the two launches. */
+/* compute_fft and the post-process of the same frames in one call (d_db, d_post, and — both or neither — the row extremes): two launches. */
 int pss_spectrum_db_post(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db, float *d_post, float *d_row_lo,
                          float *d_row_hi);
 /* Finite extremes of arbitrary rows (np.min / np.max over all_data[np.isfinite(all_data)], pyspecsdr.py:1356-1358, per row). */

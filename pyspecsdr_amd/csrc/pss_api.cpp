@@ -139,8 +139,8 @@ extern "C" void pss_destroy(pss_ctx *ctx)
         hipFree(kv.second.d_leaf_off); hipFree(kv.second.d_leaf_len); hipFree(kv.second.d_node_l);
         hipFree(kv.second.d_node_r); hipFree(kv.second.d_level_start); hipFree(kv.second.d_roots);
     }
+    for (auto &kv : ctx->nfm) if (kv.second.d_rev) hipFree(kv.second.d_rev);
     if (ctx->scratch) hipFree(ctx->scratch);
-    if (ctx->disc_buf) hipFree(ctx->disc_buf);
     if (ctx->scratch_fft) hipFree(ctx->scratch_fft);
     if (ctx->scratch_iqc) hipFree(ctx->scratch_iqc);
     if (ctx->d_hann) hipFree(ctx->d_hann);
@@ -184,22 +184,18 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "wfm_fused")) { ctx->no_wfm_fused = (value == 0); return PSS_OK; }
     if (!strcmp(key, "small_batch")) { ctx->no_small_batch = (value == 0); return PSS_OK; }
     if (!strcmp(key, "small_batch_max")) { ctx->small_batch_max = value; return PSS_OK; }
+    if (!strcmp(key, "wfm_small_batch_max")) { ctx->wfm_small_batch_max = value; return PSS_OK; }
+    if (!strcmp(key, "ssb_hilbert")) { ctx->ssb_hilbert = value != 0; return PSS_OK; }
+    if (!strcmp(key, "scan_exact")) { ctx->scan_exact = value != 0; return PSS_OK; }
+    if (!strcmp(key, "db_exact")) { ctx->db_exact = value != 0; return PSS_OK; }
+#ifdef PSS_VARIANTS   // kernel-selection knobs for A/B measurements: variant builds only (tools/build_variant.py <name> -DPSS_VARIANTS)
     if (!strcmp(key, "fft_split")) { ctx->fft_split = value; return PSS_OK; }
     if (!strcmp(key, "fft_big_scratch")) { ctx->fft_big_scratch = value != 0; return PSS_OK; }
     if (!strcmp(key, "fft_prefetch")) { ctx->fft_prefetch = value; return PSS_OK; }
-    if (!strcmp(key, "post_sort_max")) { ctx->post_sort_max = value; return PSS_OK; }
-    if (!strcmp(key, "ssb_hilbert")) { ctx->ssb_hilbert = value != 0; return PSS_OK; }
-    if (!strcmp(key, "disc_rows")) { ctx->disc_rows = value != 0; return PSS_OK; }
-    if (!strcmp(key, "disc_spectrum")) { ctx->disc_spectrum = (int)value; return PSS_OK; }
-    if (!strcmp(key, "fir_mfma")) { ctx->fir_mfma = value != 0; return PSS_OK; }
     if (!strcmp(key, "fft_xl4096")) { ctx->fft_xl4096 = value != 0; return PSS_OK; }
-    if (!strcmp(key, "fft_lean")) { ctx->fft_lean = value; return PSS_OK; }
-    if (!strcmp(key, "scan_exact")) { ctx->scan_exact = value != 0; return PSS_OK; }
-    if (!strcmp(key, "db_exact")) { ctx->db_exact = value != 0; return PSS_OK; }
-    if (!strcmp(key, "pipe_overlap")) { ctx->pipe_overlap_mode = value; return PSS_OK; }
-    if (!strcmp(key, "fuse_post")) { ctx->fuse_post = value != 0; return PSS_OK; }
+    if (!strcmp(key, "post_sort_max")) { ctx->post_sort_max = value; return PSS_OK; }
     if (!strcmp(key, "post_legacy")) { ctx->post_legacy = value != 0; return PSS_OK; }
-    if (!strcmp(key, "wfm_small_batch_max")) { ctx->wfm_small_batch_max = value; return PSS_OK; }
+#endif
     return pss_fail(ctx, PSS_E_ARG, std::string("unknown option: ") + key);
 }
 

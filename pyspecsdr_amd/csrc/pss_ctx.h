@@ -14,6 +14,8 @@ struct PssNfmFilt {
     double taps[65];
     double sos[24];
     double zi[8];
+    double *d_rev = nullptr;   // device copy of the reversed taps (rev[j] = taps[64 - j], 65 doubles + padding): the fused NFM kernel's
+                               // hand-scheduled FIR fetches its taps from here with scalar loads; made on first use, owned by the context
 };
 
 struct PssWfmFilt {
@@ -77,25 +79,9 @@ struct pss_ctx {
     long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~12000)
     long wfm_small_batch_max = 8192;  // option "wfm_small_batch_max" (measured crossover with the fused kernels ~12000 frames)
     bool ssb_hilbert = true;   // option "ssb_hilbert": run the reference's hilbert() round trip inside demodulate_ssb where a register transform exists for the frame length
-    bool fir_mfma = false;
     bool db_exact = false;         // true: compute_fft's dB rows evaluated to float64 accuracy and rounded once (= float32 of the reference's float64 rows); false: float32 evaluation, 1-2 ulp off, 15-25 % faster kernels
     bool scan_exact = true;        // scanner slices: NumPy's float32 chain bit for bit (scan_db_np); false: the float64 / hardware-log2 dB of compute_fft
-    int fft_lean = 0;              // N = 1024 / 2048 on k_spectrum_lean (112 VGPRs): 0 never (default), 1 always, -1 = only beside the NFM backward pass
-    bool spectrum_beside = false;  // set by pss_frame_pipeline_nfm around its side chain
     bool fft_xl4096 = true;        // N = 4096 on the component-wise-exchange kernel (pss_fft_xl.h, R4 = 1) instead of k_spectrum_r16<4>
-    // NFM discriminator rows handed from one kernel to the next (k_nfm_fwd<DISC_IN>): ld floats per frame.  Producers: the
-    // spectrum kernel of pss_frame_pipeline_nfm (disc_emit set around its launch; 1024-point frames), or k_disc_rows
-    // (option "disc_rows": its own pass, for measurements).
-    void *disc_buf = nullptr;
-    size_t disc_bytes = 0;
-    int disc_ld = 0;
-    float disc_kscale = 0.0f;
-    bool disc_rows = false;
-    bool disc_emit = false;        // the next 1024-point spectrum launch also writes the discriminator rows
-    bool disc_ready = false;       // ... and has done so: the NFM demodulator reads them instead of the IQ
-    int disc_spectrum = 0;         // option "disc_spectrum" (opt-in): pss_frame_pipeline_nfm uses that hand-over for 1024-point frames
-    int pipe_overlap_mode = 2;     // pss_frame_pipeline_nfm schedule: 2 fwd -> {bwd || spectrum -> post -> lines}; 0 / 1: see pss.h "pipe_overlap"     // option "fir_mfma": NFM forward kernel with the FIR on the matrix pipe (NOT bit-identical float64; opt-in)
-    bool fuse_post = false;    // option "fuse_post": 1024-point frames take the fused spectrum + post-process kernel in pss_spectrum_db_post
     bool post_legacy = false;  // option "post_legacy": LDS bitonic sort / LDS-histogram radix select instead of the register select
     int post_sort_max = 8192;  // option "post_sort_max": longest row that takes the LDS bitonic sort, else radix select (measured crossover 8192..16384)
     bool fft_big_scratch = false;  // option "fft_big_scratch": N = 8192 / 16384 on the scratch-based radix-R pre-pass kernel (A/B reference)

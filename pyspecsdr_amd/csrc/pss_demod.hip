@@ -47,6 +47,10 @@ struct WfmCoef {
 struct TapsArg {
     double fwd[65];  // taps[j]
     double rev[65];  // taps[64 - j]
+    // rev[0..63] in the order the fused NFM kernel's ring FIR consumes them (pss_nfm_fused.h fir_ring): phase k (16 taps), half h = the
+    // accumulator lanes l = 2h, 2h + 1 -> ya[l], ya[l+1], ya[l+4], ya[l+5], yb[l], yb[l+1], yb[l+4], yb[l+5] with ya[i] = rev[8k + i],
+    // yb[i] = rev[32 + 8k + i]: one 64-byte scalar load per half phase
+    double ring[64];
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -341,25 +345,8 @@ __global__ __launch_bounds__(TILE) void k_nfm_iir(const double *__restrict__ U, 
 }  // namespace
 // floats per discriminator row: the frame's n - 1 values, zero-filled up to the end: the workers fetch one chunk (24 values) past the
 // last one they use, i.e. up to index n + 45
-static inline int pss_disc_ld(int n) { return (n + 48 + 3) & ~3; }
-
-// Discriminator rows for k_nfm_fwd<..., DISC_IN> when no spectrum kernel produces them: d[f][t] = disc_sample(x[t + 1], x[t]) for
-// t < n - 1, zeros up to the row's end (ld floats per frame).  One thread per element, coalesced both ways.
-template <bool SWAPPED>
-__global__ __launch_bounds__(256) void k_disc_rows(const float2 *__restrict__ iq, float *__restrict__ dsc, int n, int ld, long n_frames,
-                                                    float kscale)
-{
-    const long total = n_frames * (long)ld;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-        const long f = i / ld;
-        const int t = (int)(i - f * ld);
-        const float2 *x = iq + (size_t)f * n;
-        dsc[i] = t < n - 1 ? pss::disc_sample(x[t + 1], x[t], kscale, SWAPPED) : 0.0f;
-    }
-}
 
 #include "pss_nfm_fused.h"
-#include "pss_nfm_mfma.h"
 namespace {
 
 // ---------------------------------------------------------------------------------------------------
@@ -2115,6 +2102,23 @@ int nfm_filters(pss_ctx *ctx, double fs, PssNfmFilt **out)
     return PSS_OK;
 }
 
+// the reversed taps in device memory (fir_ring_asm's scalar loads); uploaded once per coefficient set
+int nfm_dev_taps(pss_ctx *ctx, PssNfmFilt *f, const double **out)
+{
+    if (!f->d_rev) {
+        double rev[72] = {0.0};
+        for (int j = 0; j < 65; j++) rev[j] = f->taps[64 - j];
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&f->d_rev), sizeof(rev));
+        if (e == hipSuccess) e = hipMemcpy(f->d_rev, rev, sizeof(rev), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (f->d_rev) { hipFree(f->d_rev); f->d_rev = nullptr; }
+            return pss_fail(ctx, PSS_E_HIP, std::string("device taps: ") + hipGetErrorString(e));
+        }
+    }
+    *out = f->d_rev;
+    return PSS_OK;
+}
+
 int wfm_filters(pss_ctx *ctx, double fs, PssWfmFilt **out)
 {
     auto it = ctx->wfm.find(fs);
@@ -2150,6 +2154,13 @@ TapsArg make_taps(const double *taps)
 {
     TapsArg t;
     for (int j = 0; j < 65; j++) { t.fwd[j] = taps[j]; t.rev[j] = taps[64 - j]; }
+    for (int k = 0; k < 4; k++)
+        for (int h = 0; h < 2; h++) {
+            double *r = t.ring + (2 * k + h) * 8;
+            const int l = 2 * h;
+            r[0] = t.rev[8 * k + l]; r[1] = t.rev[8 * k + l + 1]; r[2] = t.rev[8 * k + l + 4]; r[3] = t.rev[8 * k + l + 5];
+            r[4] = t.rev[32 + 8 * k + l]; r[5] = t.rev[32 + 8 * k + l + 1]; r[6] = t.rev[32 + 8 * k + l + 4]; r[7] = t.rev[32 + 8 * k + l + 5];
+        }
     return t;
 }
 
@@ -2270,47 +2281,21 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             // fused path: u[] stays on chip; small L2-resident scratch for the irregular head / tail of u
             const size_t szH = align256((size_t)tiles * fused::HEAD * TILE * sizeof(double));
             const size_t szT = align256((size_t)tiles * (EDGE + 1) * TILE * sizeof(double));
-            // discriminator rows: handed over by the spectrum kernel (ctx->disc_ready), or option "disc_rows": a pass of their own
-            const bool disc_in = (ctx->disc_rows || ctx->disc_ready) && !ctx->fir_mfma;
-            const int ld = ctx->disc_ready ? ctx->disc_ld : pss_disc_ld(n);
-            if (disc_in && !ctx->disc_ready) {
-                r = pss_ensure_buffer(ctx, &ctx->disc_buf, &ctx->disc_bytes, (size_t)n_frames * ld * sizeof(float), "discriminator rows");
-                if (r) return r;
-            }
             r = pss_ensure_scratch(ctx, szY + szA + szH + szT);
+            if (r) return r;
+            const double *d_rev = nullptr;
+            r = nfm_dev_taps(ctx, flt, &d_rev);
             if (r) return r;
             char *base = reinterpret_cast<char *>(ctx->scratch);
             double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);
             double *Uh = reinterpret_cast<double *>(base + szY + szA), *Ut = reinterpret_cast<double *>(base + szY + szA + szH);
-            float *Dsc = reinterpret_cast<float *>(ctx->disc_buf);
             pss_time_begin(ctx);
-            if (disc_in && !ctx->disc_ready) {
-                pss_kernel_begin(ctx, "k_disc_rows");
-                const long tot = n_frames * (long)ld;
-                const unsigned g = (unsigned)std::min<long>((tot + 255) / 256, 65536);
-                if (swapped) hipLaunchKernelGGL(k_disc_rows<true>, dim3(g), dim3(256), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Dsc, n, ld, n_frames, kscale);
-                else hipLaunchKernelGGL(k_disc_rows<false>, dim3(g), dim3(256), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Dsc, n, ld, n_frames, kscale);
-                pss_kernel_end(ctx);
-            }
             pss_kernel_begin(ctx, "k_nfm_fwd");
-            if (ctx->fir_mfma) {
-                // opt-in: the FIR as a Toeplitz product on the matrix pipe (another summation order: float64 audio differs in
-                // the last bits from the reference's OpenBLAS order — see pss_nfm_mfma.h)
-                if (b121)
-                    hipLaunchKernelGGL(fusedm::k_nfm_fwd_mfma<true>, dim3((unsigned)tiles), dim3(fusedm::WG), fusedm::LDS_BYTES,
-                                       PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
-                else
-                    hipLaunchKernelGGL(fusedm::k_nfm_fwd_mfma<false>, dim3((unsigned)tiles), dim3(fusedm::WG), fusedm::LDS_BYTES,
-                                       PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, swapped, targ);
-            } else if (disc_in) {
-                auto kf = b121 ? fused::k_nfm_fwd<true, false, true> : fused::k_nfm_fwd<false, false, true>;
-                hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, targ, Dsc, ld);
-            } else {
+            {
                 auto kf = b121 ? (swapped ? fused::k_nfm_fwd<true, true> : fused::k_nfm_fwd<true, false>)
                                : (swapped ? fused::k_nfm_fwd<false, true> : fused::k_nfm_fwd<false, false>);
                 hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, targ, nullptr, 0);
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, targ, d_rev);
             }
             pss_kernel_end(ctx);
             auto launch_bwd = [=]() -> int {
@@ -2975,86 +2960,12 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
     if (n_frames > 0 && (!d_db || !d_post || !d_row_lo || !d_row_hi || !d_glyph || !d_colour || !d_pcm))
         return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_nfm: null buffer");
     pss_time_begin(ctx);
-    if (ctx->pipe_overlap_mode == 1) {
-        // Opt-in schedule: the display chain needs only the IQ, so it goes to the side stream at once —
-        //   main: forward kernel -> backward pass        side: spectrum -> post-process -> display lines
-        // 1.11 ms per step at cfg 2 against 1.18 ms WHEN the forward kernel's workgroups reach the dispatcher first (it then
-        // fills every CU — 4 workgroups x 37.6 KB LDS, 4 x 124 VGPRs per SIMD — and the chain runs in its wake, beside the
-        // backward pass).  When the spectrum wins that race (an event packet in front of the forward kernel is enough: bench.py's
-        // own bracketing) its persistent workgroups hold half of every CU for their whole life and the step takes 1.19-1.26 ms:
-        // not the default.  Also measured and rejected: capping the forward kernel at 3 / 2 workgroups per CU to make room
-        // (forward 0.64 -> 0.80 / 0.83 ms, step 1.17 / 1.35 ms), two fully decoupled streams with no join per step (1.15 ms).
-        int r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
-        if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
-        if (r) { pss_time_end(ctx); return r; }
-        const int rn = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
-        int rd;
-        {
-            PssStreamScope side(ctx->cur, ctx->stream2);
-            rd = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
-            if (!rd) rd = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
-            if (!rd) rd = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
-        }
-        // joined whatever happened above: the main stream must not run ahead of work already queued on the side stream
-        int rj = pss_hip_check(ctx, hipEventRecord(ctx->ev_join, ctx->stream2), "hipEventRecord(join)");
-        if (!rj) rj = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)");
-        pss_time_end(ctx);
-        return rn ? rn : (rd ? rd : rj);
-    }
-    // Opt-in schedule for 1024-point frames in large batches (option "disc_spectrum" = 1): the spectrum kernel goes FIRST and hands
-    // the NFM discriminator rows to the forward kernel —
-    //   spectrum (+ discriminator rows) -> forward kernel (reads 4 coalesced bytes per sample instead of the IQ again)
-    //     -> { backward pass || post-process -> display lines }.
-    // Same results bit for bit (the same disc_sample on the same samples).  Measured at cfg 2: the forward kernel drops from 0.58-0.62
-    // to 0.45 ms, but the spectrum kernel (two wavefronts per SIMD: it cannot hide the discriminator's dependent chains) grows from
-    // 0.17 to 0.35 ms and the post-process loses its place beside nothing but the backward pass: 1.11 against 1.09 ms per step.
-    if (ctx->disc_spectrum && n == 1024 && !ctx->fir_mfma && !ctx->no_fused && ctx->fft_lean <= 0 &&
-        (ctx->no_small_batch || n_frames > ctx->small_batch_max) && !ctx->post_legacy) {
-        const int ld = pss_disc_ld(n);
-        int r = pss_ensure_buffer(ctx, &ctx->disc_buf, &ctx->disc_bytes, (size_t)n_frames * ld * sizeof(float), "discriminator rows");
-        ctx->disc_ld = ld;
-        ctx->disc_kscale = (float)(fs / (2.0 * M_PI));
-        ctx->disc_ready = false;
-        if (!r) {
-            PssFlagScope emit(ctx->disc_emit, true);
-            r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
-        }
-        ctx->pending_bwd = nullptr;
-        if (!r && ctx->disc_ready) {
-            PssFlagScope defer(ctx->defer_bwd, true);
-            r = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
-        } else if (!r) {
-            r = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);   // the spectrum took a kernel without the hand-over
-        }
-        ctx->disc_ready = false;
-        auto chain = [&]() -> int {
-            int q = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
-            if (!q) q = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
-            return q;
-        };
-        if (ctx->pending_bwd) {
-            auto bwd = ctx->pending_bwd;
-            ctx->pending_bwd = nullptr;
-            if (!r) r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
-            if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
-            if (!r) {
-                PssStreamScope side(ctx->cur, ctx->stream2);
-                r = chain();
-            }
-            const int rb = bwd();
-            int rj = pss_hip_check(ctx, hipEventRecord(ctx->ev_join, ctx->stream2), "hipEventRecord(join)");
-            if (!rj) rj = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)");
-            if (!r) r = rb ? rb : rj;
-        } else if (!r) {
-            r = chain();
-        }
-        pss_time_end(ctx);
-        return r;
-    }
-    // Otherwise (pipe_overlap = 2): forward kernel (VALU-bound, fills the machine) ->
+    // Schedule: forward kernel (VALU-bound, fills the machine) ->
     //   { backward pass (latency-bound, one wavefront per SIMD)  ||  spectrum -> post-process -> display lines }.
-    // pipe_overlap = 0 keeps the spectrum in front of the fork (alone on the machine: 0.17 instead of 0.2 ms, but the backward
-    // pass then waits for it): 1.14-1.16 ms per step at cfg 2 against 1.12 ms.
+    // Measured alternatives (rounds 2 / 3): the spectrum in front of the fork (+2 %); the whole display chain on the side
+    // stream from the start (-5 % when the forward kernel reaches the dispatcher first, +8 % when it does not); the two streams on
+    // disjoint CU masks (hipExtStreamCreateWithCUMask, 128..240 of 256 CUs for the forward kernel: +5 % at best — both halves of the
+    // step scale with the CUs they get); the spectrum kernel handing discriminator rows to the forward kernel (+2 %).
     int r2;
     ctx->pending_bwd = nullptr;
     {
@@ -3062,16 +2973,12 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
         r2 = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
     }
     int r = r2;
-    const bool spectrum_beside_bwd = ctx->pipe_overlap_mode == 2 && ctx->pending_bwd;
-    if (!r && !spectrum_beside_bwd) r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+    const bool beside_bwd = (bool)ctx->pending_bwd;
+    if (!r && !beside_bwd) r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
     auto display_chain = [&]() -> int {
-        int q;
-        if (spectrum_beside_bwd) {  // (option "fuse_post": spectrum and post-process of 1024-point frames in one kernel)
-            PssFlagScope beside(ctx->spectrum_beside, true);
-            q = pss_spectrum_db_post(ctx, d_iq, n_frames, n, d_db, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
-        }
-        else
-            q = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+        int q = PSS_OK;
+        if (beside_bwd) q = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+        if (!q) q = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
         if (!q) q = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
         return q;
     };
@@ -3104,6 +3011,11 @@ extern "C" int pss_set_nfm_filters(pss_ctx *ctx, double fs, const double *taps65
     memcpy(f.taps, taps65, sizeof(f.taps));
     memcpy(f.sos, sos4x6, sizeof(f.sos));
     memcpy(f.zi, zi4x2, sizeof(f.zi));
+    auto old = ctx->nfm.find(fs);
+    if (old != ctx->nfm.end() && old->second.d_rev) {   // the device copy of the replaced taps may still be read by queued launches
+        hipStreamSynchronize(ctx->stream);
+        hipFree(old->second.d_rev);
+    }
     ctx->nfm[fs] = f;
     return PSS_OK;
 }
@@ -3142,3 +3054,7 @@ extern "C" int pss_get_ssb_taps(pss_ctx *ctx, double fs, double *taps65)
     if (taps65) memcpy(taps65, t, sizeof(double) * 65);
     return PSS_OK;
 }
+
+#ifdef PSS_UBENCH   // role micro-benchmarks of the fused NFM forward kernel: variant builds only (tools/build_variant.py ubench -DPSS_UBENCH)
+#include "pss_ubench.h"
+#endif

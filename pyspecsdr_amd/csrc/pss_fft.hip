@@ -22,7 +22,6 @@
 #include "pss_fft_r16.h"
 #include "pss_fft_xl.h"
 #include "pss_post.h"
-#include "pss_specpost.h"
 #include "pss_hilbert.h"
 
 namespace {
@@ -609,18 +608,6 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
                 : split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true, false>
                 : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, true> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, false>;
     const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2) : C::LDS;
-    float *dsc = nullptr;
-    if constexpr (LOG_R3 == 2 && !SCAN) {
-        // pss_frame_pipeline_nfm: this launch also writes the NFM discriminator rows (its own instantiations of the unsplit kernel)
-        if (ctx->disc_emit && split && !exact) {
-            dsc = reinterpret_cast<float *>(ctx->disc_buf);
-            kern = pss_r16::k_spectrum_r16<2, false, true, false, false, true>;
-        } else if (ctx->disc_emit && !split) {
-            dsc = reinterpret_cast<float *>(ctx->disc_buf);
-            kern = exact ? (prefetch ? pss_r16::k_spectrum_r16<2, false, false, true, true, true> : pss_r16::k_spectrum_r16<2, false, false, false, true, true>)
-                         : (prefetch ? pss_r16::k_spectrum_r16<2, false, false, true, false, true> : pss_r16::k_spectrum_r16<2, false, false, false, false, true>);
-        }
-    }
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -633,10 +620,9 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_spectrum");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db, tw,
-                       win, n_frames, d_peak, d_bw, d_count, bin_hz, spec_flags(ctx), dsc, ctx->disc_ld, ctx->disc_kscale);
+                       win, n_frames, d_peak, d_bw, d_count, bin_hz, spec_flags(ctx));
     pss_kernel_end(ctx);
     pss_time_end(ctx);
-    if (dsc) ctx->disc_ready = true;
     return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_r16 launch");
 }
 
@@ -654,25 +640,6 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     const double *win;
     int r = pss_fft_tables(ctx, n_fft, &tw, &win);
     if (r) return r;
-    // N = 1024 / 2048 on the 112-VGPR kernel: opt-in ("fft_lean" = 1, or -1: only where the spectrum shares the machine with the NFM
-    // backward pass).  Measured: alone 0.434 against 0.412 ms at 131072 x 1024, 0.513 against 0.540 ms at 65536 x 2048; inside the
-    // bench step 0.326 against 0.303 ms — the wide kernel's slowdown beside the backward pass is not an occupancy effect
-    if (!SCAN && !ctx->db_exact && (n_fft == 1024 || n_fft == 2048) && (ctx->fft_lean > 0 || (ctx->fft_lean < 0 && ctx->spectrum_beside))) {
-        auto go = [&](auto kern, size_t lds, int fpw) -> int {
-            if (lds > 64 * 1024)
-                PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const long groups = (n_frames + fpw - 1) / fpw, cap = 256L * 4 * 2;
-            pss_time_begin(ctx);
-            pss_kernel_begin(ctx, "k_spectrum");
-            hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(256), lds, PSS_STREAM(ctx),
-                               reinterpret_cast<const float2 *>(d_iq), d_db, tw, win, n_frames, spec_flags(ctx));
-            pss_kernel_end(ctx);
-            pss_time_end(ctx);
-            return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_lean launch");
-        };
-        if (n_fft == 1024) return go(pss_xl::k_spectrum_lean<2, true>, pss_xl::CfgL<2>::LDS, pss_xl::CfgL<2>::FPW);
-        return go(pss_xl::k_spectrum_lean<3, true>, pss_xl::CfgL<3>::LDS, pss_xl::CfgL<3>::FPW);
-    }
     // register-resident radix-16 kernel for the sizes that fit one workgroup (256 <= N <= 4096)
     switch (n_fft) {
     case 256: return launch_r16<0, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
@@ -1355,8 +1322,10 @@ int display_rows(pss_ctx *ctx, const T *d_post, long n_frames, int len, const T 
 
 }  // namespace
 
-// compute_fft + post-process (+ row extremes) of the same frames: one fused kernel for 1024-point frames (option "fuse_post"),
-// the two launches otherwise.  d_lo / d_hi may both be NULL.
+// compute_fft + post-process (+ row extremes) of the same frames, as two launches.  d_lo / d_hi may both be NULL.
+// (A fused kernel for 1024-point frames — the dB row handed from the transform's registers through LDS to the post-process — was built
+// in round 2 and measured no faster inside a pipeline step: 0.52 ms against 0.30 + 0.19, the post-process then runs at the
+// transform's two wavefronts per SIMD; removed in round 3.)
 extern "C" int pss_spectrum_db_post(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db, float *d_post,
                                     float *d_row_lo, float *d_row_hi)
 {
@@ -1365,28 +1334,6 @@ extern "C" int pss_spectrum_db_post(pss_ctx *ctx, const float *d_iq, long n_fram
     if (n_frames < 0 || (n_frames > 0 && (!d_iq || !d_db || !d_post))) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_db_post: null buffer");
     if ((d_row_lo == nullptr) != (d_row_hi == nullptr)) return pss_fail(ctx, PSS_E_ARG, "row extremes: pass both arrays or neither");
     if (n_frames == 0) return PSS_OK;
-    if (n_fft == 1024 && ctx->fuse_post && !ctx->post_legacy && !ctx->db_exact) {
-        const double2 *tw;
-        const double *win;
-        int r = pss_fft_tables(ctx, n_fft, &tw, &win);
-        if (r) return r;
-        using C = pss_r16::Cfg<2>;
-        const bool prefetch = ctx->fft_prefetch != 0;
-        auto kern = prefetch ? pss_sp::k_spectrum_post_1024<true> : pss_sp::k_spectrum_post_1024<false>;
-        if (C::LDS > 64 * 1024)
-            PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-        const long groups = (n_frames + C::FPW - 1) / C::FPW;
-        int per_cu = (int)((160 * 1024) / (C::LDS + 256));
-        if (per_cu > 2) per_cu = 2;
-        const long cap = 256L * per_cu * 2;
-        pss_time_begin(ctx);
-        pss_kernel_begin(ctx, "k_spectrum_post");
-        hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(256), C::LDS, PSS_STREAM(ctx),
-                           reinterpret_cast<const float2 *>(d_iq), d_db, d_post, d_row_lo, d_row_hi, tw, win, n_frames, spec_flags(ctx));
-        pss_kernel_end(ctx);
-        pss_time_end(ctx);
-        return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_post launch");
-    }
     int r = pss_spectrum_db(ctx, d_iq, n_frames, n_fft, d_db);
     if (!r) r = spectrum_post(ctx, d_db, n_frames, n_fft, d_post, d_row_lo, d_row_hi);
     return r;

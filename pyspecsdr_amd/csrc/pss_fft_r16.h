@@ -15,7 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pss_npf32.h"
-#include "pss_device.h"   // disc_sample (k_spectrum_r16<..., DISC>)
+#include "pss_device.h"
 
 namespace pss_r16 {
 
@@ -361,19 +361,12 @@ __device__ __forceinline__ void r16_core_split(double2 (&v)[16], double *ex, con
 
 // EXACT: dB rows by db_of_exact (compile-time: the float64 evaluation next to the float32 one in ONE kernel costs both of them
 // registers — measured 0.41 -> 0.45 ms for the default path at 131072 x 1024)
-// DISC (N = 1024: a frame = one wavefront, thread t holds x[t + 64 n2]): the kernel also writes the frame's NFM discriminator row
-// d[j] = disc_sample(x[j + 1], x[j]) (signal_processing.py:94,97) to dsc[f * ld + j], zeros from j = N - 1 to the row's end — the
-// samples are in registers here anyway and this kernel waits for HBM, while the demodulator's forward kernel (k_nfm_fwd<DISC_IN>),
-// which is short of issue slots and fetched the IQ a second time at one line per lane, then reads 4 coalesced bytes per sample.
-// x[j + 1] comes from the next lane (DPP wave rotate), for lane 63 from lane 0's next register.
-template <int LOG_R3, bool SCAN, bool SPLIT = false, bool PREFETCH = false, bool EXACT = false, bool DISC = false>
+template <int LOG_R3, bool SCAN, bool SPLIT = false, bool PREFETCH = false, bool EXACT = false>
 __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__ iq, float *__restrict__ db,
                                                       const double2 *__restrict__ tw, const double *__restrict__ win,
                                                       long n_frames, float *__restrict__ peak, double *__restrict__ bw,
-                                                      int *__restrict__ count, double bin_hz, int flags,
-                                                      float *__restrict__ dsc = nullptr, int ld = 0, float kscale = 0.0f)
+                                                      int *__restrict__ count, double bin_hz, int flags)
 {
-    static_assert(!DISC || (LOG_R3 == 2 && !SCAN), "the discriminator rows are written by the 1024-point spectrum kernel");
     using C = Cfg<LOG_R3>;
     constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = C::FPW;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -382,9 +375,7 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
                          : ex_all + (size_t)FPW * C::EX;  // W_T^(m1*j2), [m1][j2]
     __shared__ float red_f[4];
     __shared__ int red_i[4];
-    __shared__ uint2 rtab[DISC ? 64 : 1];   // the discriminator's reciprocal table (pss_device.h rcp14f): its lookup sits in every sample's dependent chain
     const int tid = threadIdx.x;
-    if (DISC && tid < 64) rtab[tid] = pss::RCP14_AB[tid];
     const int fl = tid / T;   // frame slot inside the workgroup
     const int t = tid % T;    // thread inside the frame: n1 in stage 1, (k2, m1) in stage 2, rho in stage 3
     double2 *ex = ex_all + (size_t)fl * C::EX;
@@ -417,43 +408,6 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
         const bool valid = f < n_frames;
         double2 v[16];
         if constexpr (!PREFETCH) fetch(g);
-        if constexpr (DISC) {
-            float *drow = dsc + (size_t)(valid ? f : 0) * ld;
-            float2 nb[17];   // nb[n2] = the next lane's nx[n2] (lane 63: lane 0's)
-#pragma unroll
-            for (int n2 = 0; n2 < 16; n2++) {
-                nb[n2].x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(nx[n2].x), DPP_NEXT_LANE, 0xf, 0xf, false));
-                nb[n2].y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(nx[n2].y), DPP_NEXT_LANE, 0xf, 0xf, false));
-            }
-            nb[16] = make_float2(0.0f, 0.0f);
-            // independent samples as interleaved straight-line chains, DB at a time (register budget); the routine's rare path
-            // (zero / NaN / denormal / huge operands) behind ONE wave-uniform branch per group
-            float dv[16];
-            constexpr int DB = 4;
-#pragma unroll
-            for (int g4 = 0; g4 < 16; g4 += DB) {
-                bool redo = false;
-#pragma unroll
-                for (int n2 = g4; n2 < g4 + DB; n2++) {
-                    const float2 nxt = (t == T - 1) ? nb[n2 + 1] : nb[n2];   // x[j + 1] for j = t + 64 n2
-                    bool ok;
-                    dv[n2] = pss::disc_sample_main(nxt, nx[n2], kscale, false, ok, rtab);
-                    redo = redo || !ok;
-                }
-                if (__builtin_amdgcn_ballot_w64(redo)) {
-#pragma unroll
-                    for (int n2 = g4; n2 < g4 + DB; n2++) {
-                        const float2 nxt = (t == T - 1) ? nb[n2 + 1] : nb[n2];
-                        dv[n2] = pss::disc_sample(nxt, nx[n2], kscale, false);
-                    }
-                }
-            }
-            if (t == T - 1) dv[15] = 0.0f;                               // j = N - 1: the first of the row's trailing zeros
-#pragma unroll
-            for (int n2 = 0; n2 < 16; n2++)
-                if (valid) drow[t + T * n2] = dv[n2];
-            if (valid && t < ld - N) drow[N + t] = 0.0f;
-        }
 #pragma unroll
         for (int n2 = 0; n2 < 16; n2++) v[n2] = make_double2((double)nx[n2].x * w[n2], (double)nx[n2].y * w[n2]);
         if (PREFETCH && g + gridDim.x < groups) fetch(g + gridDim.x);

@@ -242,106 +242,4 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *
     }
 }
 
-// ---- N = 256 * R3 (R3 = 4, 8: N = 1024, 2048) on the same recipe: two radix-16 stages + one radix-R3, component-wise exchanges,
-// twiddle powers by product chains, window and samples through buffer loads — 128 VGPRs instead of k_spectrum_r16's 240.
-// Built on the idea that inside pss_frame_pipeline_nfm, where the spectrum runs BESIDE the NFM backward pass (one 96-VGPR
-// wavefront per SIMD: room for one 240-VGPR wavefront but for three of these), the narrow kernel would win.  It does not
-// (0.326 against 0.303 ms in the bench step; alone 5 % slower at N = 1024, 5 % faster at N = 2048): opt-in, option "fft_lean".
-// T = 16 R3 threads per frame, FPW = 256 / T frames per workgroup; T = 64: a frame is one wavefront and needs no barrier.
-template <int LOG_R3>
-struct CfgL {
-    static constexpr int R3 = 1 << LOG_R3;
-    static constexpr int T = 16 * R3;
-    static constexpr int N = 16 * T;
-    static constexpr int FPW = 256 / T;
-    static constexpr int E1 = T + R3;               // exchange 1 row stride (doubles): 17 R3 k2 + m1 hits 32 different bank pairs
-    static constexpr int E2 = 256 + 32 / R3;        // exchange 2 plane stride (doubles)
-    static constexpr int EXD = (16 * E1 > R3 * E2) ? 16 * E1 : R3 * E2;   // doubles per frame
-    static constexpr size_t LDS = (size_t)FPW * EXD * sizeof(double);
-};
-
-template <bool WAVE_LOCAL, class Wr, class Rd>
-__device__ __forceinline__ void exchange_l(double2 (&v)[16], Wr wr, Rd rd)
-{
-    double im[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { *wr(i) = v[brev(i, 4)].x; im[i] = v[brev(i, 4)].y; }
-    pss_r16::frame_sync<WAVE_LOCAL>();
-#pragma unroll
-    for (int i = 0; i < 16; i++) v[i].x = *rd(i);
-    pss_r16::frame_sync<WAVE_LOCAL>();
-#pragma unroll
-    for (int i = 0; i < 16; i++) *wr(i) = im[i];
-    pss_r16::frame_sync<WAVE_LOCAL>();
-#pragma unroll
-    for (int i = 0; i < 16; i++) v[i].y = *rd(i);
-    pss_r16::frame_sync<WAVE_LOCAL>();
-}
-
-template <int LOG_R3, bool WINDOW>
-__global__ __launch_bounds__(256, 4) void k_spectrum_lean(const float2 *__restrict__ iq, float *__restrict__ db,
-                                                          const double2 *__restrict__ tw, const double *__restrict__ win,
-                                                          long n_frames, int flags)
-{
-    using C = CfgL<LOG_R3>;
-    constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = C::FPW, E1 = C::E1, E2 = C::E2;
-    constexpr bool WL = T <= 64;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, fl = tid / T, t = tid % T;
-    double *ex = reinterpret_cast<double *>(smem) + (size_t)fl * C::EXD;
-    const int k2s = t / R3, m1s = t % R3;                      // stage-2 role
-    const double2 w1 = tw[t];                                  // W_N^t
-    const double2 w2 = tw[(size_t)m1s * 16];                   // W_T^m1 = W_N^(16 m1)
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(win, WINDOW ? N * 8 : 0);
-    const long groups = (n_frames + FPW - 1) / FPW;
-    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
-        const long f = g * FPW + fl;
-        const bool valid = f < n_frames;
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc(iq + (size_t)(valid ? f : 0) * N, N * 8);
-        const __amdgpu_buffer_rsrc_t ro = make_rsrc(db + (size_t)(valid ? f : 0) * N, valid ? N * 4 : 0);   // ragged tail: stores dropped
-        double2 u1 = w1, u2 = w2;
-        asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y));    // keeps the 30 powers from being hoisted and spilled
-        double2 v[16];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            float2 s[8];
-            double wv[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) s[q] = buf_load_f2(rx, t * 8, T * (8 * h + q) * 8);
-#pragma unroll
-            for (int q = 0; q < 8; q++) wv[q] = WINDOW ? buf_load_f64(rw, t * 8, T * (8 * h + q) * 8) : 1.0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) v[8 * h + q] = make_double2((double)s[q].x * wv[q], (double)s[q].y * wv[q]);
-            sched_fence();
-        }
-        // stage 1: 16-point DFT over n2, times W_N^(t k2) -> L1[k2][t]; thread (k2s, m1s) gathers L1[k2s][m1s + R3 m2]
-        fft_reg<16>(v);
-        twiddle_powers(v, u1);
-        {
-            double *wb = ex + t, *rb = ex + k2s * E1 + m1s;
-            exchange_l<WL>(v, [&](int k2) { return wb + k2 * E1; }, [&](int m2) { return rb + R3 * m2; });
-        }
-        // stage 2: 16-point DFT over m2, times W_T^(m1s j2) -> L2[m1s][16 j2 + k2s]; thread t gathers L2[m1][t + T c]
-        fft_reg<16>(v);
-        if constexpr (R3 > 1) twiddle_powers(v, u2);
-        {
-            double *wb = ex + m1s * E2 + k2s, *rb = ex + t;
-            exchange_l<WL>(v, [&](int j2) { return wb + 16 * j2; }, [&](int i) { return rb + (i % R3) * E2 + T * (i / R3); });
-        }
-        // stage 3: radix-R3 butterflies over m1; bin 256 j1 + t + T c: T consecutive bins per store instruction
-#pragma unroll
-        for (int c = 0; c < 16 / R3; c++) {
-            double2 b[R3];
-#pragma unroll
-            for (int m1 = 0; m1 < R3; m1++) b[m1] = v[c * R3 + m1];
-            fft_reg<R3>(b);
-#pragma unroll
-            for (int j1 = 0; j1 < R3; j1++) {
-                const double2 X = b[brev(j1, LOG_R3)];
-                buf_store_f32(ro, t * 4, ((256 * j1 + T * c + N / 2) & (N - 1)) * 4, pss_r16::db_of_fast(X.x * X.x + X.y * X.y + 1e-10));
-            }
-        }
-    }
-}
-
 }  // namespace pss_xl

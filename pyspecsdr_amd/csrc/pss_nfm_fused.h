@@ -17,15 +17,22 @@
 // computes u[0..63] with the predicated per-lane ddot and parks them in a small global scratch (L2-resident), the
 // workers park the last 28 outputs likewise, and the IIR wave builds the extension from those.
 #pragma once
+#include "pss_fir_ring_asm.h"
+
+#ifdef PSS_UBENCH   // per-workgroup start / end times of k_nfm_fwd (s_memrealtime, 100 MHz): dispatch skew and tail (tools/ubench_fwd.py stamps)
+__device__ unsigned long long pss_dbg_stamps[4 * 4096];
+#endif
 
 namespace fused {
 
 using namespace pss;
+constexpr unsigned gridDim_cus = 256;   // compute units of the part (MI355X): workgroup i runs on CU i mod 256 while the grid fits the machine
 
 constexpr int FC = 24;         // time steps per chunk
 constexpr int NB = 4;          // window blocks
 constexpr int WCOLS = NB * FC; // 96 window columns: logical column l <-> time 24 c - 8 + l at chunk c
-constexpr int WSTR = 97;       // float row stride (odd: conflict-free for lane = frame at a fixed column)
+constexpr int WSTR = 100;      // float row stride: rows 16-byte aligned (the FIR reads 4 columns per ds_read_b128) and 25 x 16 bytes apart —
+                               // odd in 16-byte units, so the 16 lanes a b128 access services together hit 16 different bank groups
 constexpr int HEAD = 64;       // outputs produced by the prologue
 constexpr int NFW = 3;         // FIR worker waves (measured slower: 4 x 6 outputs in 5-wave workgroups 0.89 vs 0.67 ms; 2 x 12 outputs in
                                // 3-wave workgroups with 168 VGPRs each 0.88 vs 0.60 ms)
@@ -39,7 +46,39 @@ constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE 
 // draining them twice per chunk serialised the whole pipeline on the store round trip.
 __device__ __forceinline__ void lds_barrier()
 {
+#ifdef PSS_EXP_NOBAR   // timing experiment only (results are wrong): no workgroup barriers inside the chunk loop
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void lds_barrier_b()
+{
+#ifdef PSS_EXP_NOBAR_B  // timing experiment only: barrier B dropped
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    lds_barrier();
+#endif
+}
+
+// Time-sliced issue priority.  The SIMD's arbiter serves the OLDEST ready wavefront first: of the four workgroups a CU holds (they all
+// start within 1.3 us of each other) the first-dispatched one runs at the pace of a workgroup that has the CU to itself and is done after
+// 0.32 ms, the others after 0.40 / 0.50 / 0.59 ms (per-workgroup s_memrealtime stamps, tools/ubench_stamps.py) — a staircase whose last
+// steps run with three, two, one wavefront per SIMD and hide no latency.  The user priority (which the arbiter ranks above age) therefore
+// rotates with the 100 MHz real-time counter (every 41 us: all workgroups of a CU read the same clock, so their priorities stay distinct)
+// and the workgroup's slot on its CU: 363 / 418 / 495 / 545 us instead of 324 / 405 / 503 / 587, the launch 5 % shorter (paired A/B,
+// tools/ab_fwd.py; rotating per chunk of the workgroup's own progress instead: 3 %; shorter periods: less).
+#ifndef PSS_PRIO_TIME_SHIFT
+#define PSS_PRIO_TIME_SHIFT 12
+#endif
+__device__ __forceinline__ void prio_rotate(int v)
+{
+    switch (v & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
 }
 
 struct Iir4 {
@@ -79,56 +118,8 @@ __device__ __forceinline__ double pipe_step(const NfmCoef &c, Iir4 &st, double x
     return xn[3];
 }
 
-// FBH consecutive full-window FIR outputs (outputs 4H .. 4H+3 of the thread's 8) for worker third J.  Window column
-// of x(c') (c' = 0..71 relative to the thread's first output) is l = 8 + 8 J + c'; blk[b] points at this frame's
-// row inside logical block b.  Four outputs at a time keeps the accumulators at 16 doubles (the kernel must fit
-// the 128-VGPR budget of 4 waves/SIMD).
-constexpr int FBH = 4;
+constexpr int FBH = 4;        // outputs per FIR statement (pss_fir_ring_asm.h)
 static_assert(FC % NFW == 0 && OPT % FBH == 0 && OPT <= 8, "chunk / worker split");
-template <int J, int H>
-__device__ __forceinline__ void fir_batch(const float *const (&blk)[NB], const double *__restrict__ yrev, double (&out)[OPT])
-{
-    auto x = [&](int cc) {
-        const int l = 8 + OPT * J + FBH * H + cc;
-        return (double)blk[l / FC][l % FC];
-    };
-    double s[FBH][4];
-    // Four phases of 16 taps; k is a run-time loop index (keeps only 16 taps live in SGPRs, and converted window values
-    // from one phase out of the next), but the column arithmetic must stay compile-time, so the cases are spelled out.
-    // Phase 0 (which STARTS the sums) runs ahead of the loop: with all four cases in the loop the accumulators were copied
-    // (16 v_mov_b64 per pass) where the starting case and the accumulating cases join.
-    auto phase = [&](auto KC, int k) {
-        constexpr int K = decltype(KC)::value;
-        double ya[8], yb[8];
-#pragma unroll
-        for (int l = 0; l < 8; l++) { ya[l] = yrev[8 * k + l]; yb[l] = yrev[32 + 8 * k + l]; }
-#pragma unroll
-        for (int o = 0; o < FBH; o++) {
-#pragma unroll
-            for (int l = 0; l < 4; l++) {
-                double lo = __fma_rn(x(8 * K + o + 32 + l), yb[l], __fma_rn(x(8 * K + o + l), ya[l], 0.0));
-                double hi = __fma_rn(x(8 * K + o + 36 + l), yb[l + 4], __fma_rn(x(8 * K + o + l + 4), ya[l + 4], 0.0));
-                double a = __dadd_rn(lo, hi);
-                s[o][l] = (K == 0) ? a : __dadd_rn(s[o][l], a);
-            }
-        }
-    };
-    int k0 = 0;
-    asm volatile("" : "+s"(k0));  // opaque zero: constant tap indices would be hoisted out of the chunk loop and held in SGPRs for good
-    phase(std::integral_constant<int, 0>{}, k0);
-#pragma unroll 1
-    for (int k = 1; k < 4; k++) {
-        if (k == 1) phase(std::integral_constant<int, 1>{}, k);
-        else if (k == 2) phase(std::integral_constant<int, 2>{}, k);
-        else phase(std::integral_constant<int, 3>{}, k);
-    }
-    const double y64 = yrev[64];
-#pragma unroll
-    for (int o = 0; o < FBH; o++) {
-        double dot = __dadd_rn(__dadd_rn(s[o][0], s[o][2]), __dadd_rn(s[o][1], s[o][3]));
-        out[FBH * H + o] = __fma_rn(y64, x(o + 64), dot);
-    }
-}
 
 // The ddot tree (pss_device.h) for a WAVE-UNIFORM length n = 1..64: the left-edge FIR outputs, lane = frame.  x[j] is the
 // lane's window row (float32 discriminator at time j), y[j] the tap that meets it (LDS, same address in every lane).
@@ -137,8 +128,17 @@ __device__ __forceinline__ void fir_batch(const float *const (&blk)[NB], const d
 // loaded ahead of their dependent FMA chain.  (The rolled ddot_skx_uniform this replaces paid one exposed LDS round trip
 // per element: 0.045 ms of the kernel's 0.69.)
 template <int S32, bool H16>
-__device__ __forceinline__ double ddot_head_body(const float *__restrict__ x, const double *__restrict__ y)
+__device__ __forceinline__ double ddot_head_body(const float *__restrict__ row, const double *__restrict__ y)
 {
+    // the row's first 32 S32 + 16 H16 floats by 16-byte reads (the row stride of 25 x 16 bytes is conflict-free for ds_read_b128 and
+    // 4-way conflicting for single floats at lane = frame)
+    constexpr int NX = 32 * S32 + (H16 ? 16 : 0);
+    float x[NX];
+#pragma unroll
+    for (int g = 0; g < NX / 4; g++) {
+        const float4 v = *reinterpret_cast<const float4 *>(row + 4 * g);
+        x[4 * g] = v.x; x[4 * g + 1] = v.y; x[4 * g + 2] = v.z; x[4 * g + 3] = v.w;
+    }
     double s[4];
 #pragma unroll
     for (int l = 0; l < 4; l++) {
@@ -163,19 +163,25 @@ __device__ __forceinline__ double ddot_head_body(const float *__restrict__ x, co
     return __dadd_rn(__dadd_rn(s[0], s[2]), __dadd_rn(s[1], s[3]));
 }
 
-__device__ __forceinline__ double ddot_head(const float *__restrict__ x, const double *__restrict__ y, int n)
+// row: the lane's window row in LDS (16-byte aligned), x[j] = row[j]
+__device__ __forceinline__ double ddot_head(const float *__restrict__ row, const double *__restrict__ y, int n)
 {
     const int n1 = n & -16;
     double dot = 0.0;
-    if (n1 == 16) dot = ddot_head_body<0, true>(x, y);
-    else if (n1 == 32) dot = ddot_head_body<1, false>(x, y);
-    else if (n1 == 48) dot = ddot_head_body<1, true>(x, y);
-    else if (n1 == 64) dot = ddot_head_body<2, false>(x, y);
+    if (n1 == 16) dot = ddot_head_body<0, true>(row, y);
+    else if (n1 == 32) dot = ddot_head_body<1, false>(row, y);
+    else if (n1 == 48) dot = ddot_head_body<1, true>(row, y);
+    else if (n1 == 64) dot = ddot_head_body<2, false>(row, y);
     // tail operands: all loads ahead of the chain (y has 15 zero slots behind the taps, x is a window row: in bounds)
-    float xt[15];
+    float xt[16];
     double yt[15];
 #pragma unroll
-    for (int t = 0; t < 15; t++) { xt[t] = x[n1 + t]; yt[t] = y[n1 + t]; }
+    for (int g = 0; g < 4; g++) {
+        const float4 v = *reinterpret_cast<const float4 *>(row + n1 + 4 * g);
+        xt[4 * g] = v.x; xt[4 * g + 1] = v.y; xt[4 * g + 2] = v.z; xt[4 * g + 3] = v.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 15; t++) yt[t] = y[n1 + t];
     const int cnt = n - n1;
 #pragma unroll
     for (int t = 0; t < 15; t++)
@@ -183,28 +189,14 @@ __device__ __forceinline__ double ddot_head(const float *__restrict__ x, const d
     return dot;
 }
 
-template <int J, int H = 0, class Put>
-__device__ __forceinline__ void for_halves(const float *const (&blk)[NB], const double *__restrict__ yrev, double (&out)[OPT], Put put)
-{
-    fir_batch<J, H>(blk, yrev, out);
-    put(out, H);
-    if constexpr ((H + 1) * FBH < OPT) for_halves<J, H + 1>(blk, yrev, out, put);
-}
-
 // SWAPPED: operand order of the discriminator's complex product for frames of 32 769 samples and more (disc_sample); a template
 // parameter because as a run-time flag both orders were evaluated and selected per sample.
-// DISC_IN (opt-in: options "disc_rows" / "disc_spectrum"): the discriminator was evaluated by the producer of `dsc` (k_disc_rows, or
-// the 1024-point spectrum kernel, which holds every sample of the frame in registers anyway: k_spectrum_r16<..., DISC>): rows of `ld`
-// floats per frame, d[t] at [t], zeros from t = n - 1 to the row's end (ld >= n + 2 FC, a multiple of 4: the fetch runs one chunk
-// ahead).  The workers then fetch a chunk as 16-byte pieces, consecutive lanes on consecutive pieces of a frame (6 pieces of a frame,
-// then the next frame: ~12 frames per load instruction) and only move them into the window, instead of 72 bytes of IQ per lane at a
-// stride of one frame (64 different lines per load instruction) that the discriminator then waits for: 0.45 instead of 0.58-0.62 ms
-// at cfg 2.  (With all arithmetic removed the IQ loads alone keep the default kernel at 0.45 ms, 0.17 ms without them.)
-template <bool B121, bool SWAPPED = false, bool DISC_IN = false>
+// d_rev: the reversed taps in device memory (PssNfmFilt::d_rev): the FIR statement's scalar tap loads.
+template <bool B121, bool SWAPPED = false>
 __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
                                                     double *__restrict__ Uh, double *__restrict__ Utl, int n,
                                                     long n_frames, NfmCoef c, float kscale, TapsArg taps,
-                                                    const float *__restrict__ dsc = nullptr, int ld = 0)
+                                                    const double *__restrict__ d_rev)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
@@ -214,16 +206,19 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: everything indexed by the role / chunk stays scalar
     const long tile = blockIdx.x;
+    const int slot = (int)(blockIdx.x / gridDim_cus);   // which of its CU's (up to) four workgroups this one is: consecutive workgroups go to consecutive CUs
     const int M = n - 1;                      // FIR outputs per frame (M >= 128 guaranteed by the caller)
     const long L = (long)M + 2 * EDGE;
     const int NC = (M - HEAD + FC - 1) / FC;  // worker chunks
     const long f = tile * TILE + lane;
     const long fr = f < n_frames ? f : n_frames - 1;  // masked lanes replay the last frame (results dropped)
-    const float2 *xq = iq + (size_t)fr * n;
     double *Yt = Y + (size_t)tile * L * TILE + lane;
     double *Uht = Uh + (size_t)tile * HEAD * TILE + lane;
     double *Utt = Utl + (size_t)tile * (EDGE + 1) * TILE + lane;
 #define YAT(p) Yt[(size_t)(p) * TILE]
+#ifdef PSS_UBENCH
+    if (threadIdx.x == 0 && blockIdx.x < 4096) pss_dbg_stamps[4 * blockIdx.x] = wall_clock64();
+#endif
     if (tid >= 128 && tid < 192) ltab[tid - 128] = RCP14_AB[tid - 128];
     if (tid < HTAPS) ltaps[tid] = tid < 65 ? taps.rev[tid] : 0.0;  // ltaps[m] = taps[64 - m]: output i pairs x[j] with ltaps[64 - i + j]
     // ---- prologue: discriminator of times 0..87 into logical columns 8..95 (physical = logical at chunk 0)
@@ -232,14 +227,13 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
         const long ff = tile * TILE + fl;
         const float2 *x = iq + (size_t)(ff < n_frames ? ff : n_frames - 1) * n;
         float d = 0.0f;
-        if constexpr (DISC_IN) {
-            if (t >= 0) d = dsc[(size_t)(ff < n_frames ? ff : n_frames - 1) * ld + t];
-        } else {
-            if (t >= 0 && t < M) d = disc_sample(x[t + 1], x[t], kscale, SWAPPED);
-        }
+        if (t >= 0 && t < M) d = disc_sample(x[t + 1], x[t], kscale, SWAPPED);
         win[fl * WSTR + l] = d;
     }
     __syncthreads();
+#ifdef PSS_UBENCH
+    if (threadIdx.x == 0 && blockIdx.x < 4096) pss_dbg_stamps[4 * blockIdx.x + 2] = wall_clock64();
+#endif
     // The first 64 FIR outputs have windows shorter than 65 samples, i.e. each its own ddot shape.  With lane = frame
     // the length is wave-uniform: the four waves take 16 outputs each (interleaved, so the dot lengths balance) and
     // park them in Uh (L2) for the IIR wave.
@@ -252,11 +246,18 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+#ifdef PSS_UBENCH
+    if (threadIdx.x == 0 && blockIdx.x < 4096) pss_dbg_stamps[4 * blockIdx.x + 3] = wall_clock64();
+#endif
     if (wave == 0) {
         // =============================== IIR wave ===============================
         Iir4 st;
         long p = 0;  // stream position of the next input; outputs lag by 3
+#ifdef PSS_EXP_NOSTORE   // timing experiment only: y_fwd rows all land on the tile's first rows (L2-resident)
+        auto emit = [&](double v) { YAT((p - 3) & 15) = v; };
+#else
         auto emit = [&](double v) { YAT(p - 3) = v; };
+#endif
         // odd extension head + u[0..63] from the prologue (scipy odd_ext: ext[p] = 2u[0] - u[27-p])
         const double u0 = Uht[0];
         const double two_u0 = __dmul_rn(2.0, u0);
@@ -276,6 +277,9 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
         // chunks from the workers
         double reg[FC];
         for (int ch = 0; ch <= NC; ch++) {
+#ifndef PSS_EXP_NOPRIO
+            prio_rotate(slot + (int)(wall_clock64() >> PSS_PRIO_TIME_SHIFT));
+#endif
             if (ch >= 1) {
                 const int cnt = (M - HEAD - (ch - 1) * FC) < FC ? (M - HEAD - (ch - 1) * FC) : FC;
                 if (cnt == FC) {
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
                 lds_barrier();  // A: workers finished FIR(ch) -> ubuf
 #pragma unroll
                 for (int t = 0; t < FC; t++) reg[t] = ubuf[t * TILE + lane];
-                lds_barrier();  // B
+                lds_barrier_b();  // B
             } else {
                 __syncthreads();  // final A/B: full fences, the workers' global Utt rows must be visible
                 __syncthreads();
@@ -314,78 +318,94 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
         // =============================== FIR workers ===============================
         const int J = wave - 1;  // third of the chunk handled by this wave (wave-uniform)
         float *row = win + lane * WSTR;
+        // the tile's frames as a buffer resource; masked lanes (frames past the batch) replay the tile's last frame
+        const long tfr = (n_frames - tile * TILE) < TILE ? (n_frames - tile * TILE) : TILE;
+        const __amdgpu_buffer_rsrc_t rs_iq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(iq + (size_t)tile * TILE * n), 0,
+                                                                                (int)(tfr * n * (long)sizeof(float2)), 0x00020000);
+        const int voff_iq = (int)((lane < tfr ? lane : tfr - 1) * (long)n * (long)sizeof(float2));
         int rot = 0;  // physical block of logical block 0
         for (int ch = 0; ch <= NC; ch++) {
+#ifndef PSS_EXP_NOPRIO
+            prio_rotate(slot + (int)(wall_clock64() >> PSS_PRIO_TIME_SHIFT));
+#endif
             if (ch < NC) {
                 const int ibase = HEAD + ch * FC + OPT * J;  // first output index of this thread's batch
                 const int tn = HEAD + (ch + 1) * FC + OPT * J;  // time of this thread's first new sample of the next chunk
-                const float *blk[NB];
+                // ring position of this thread's first window column (logical 8 + OPT J) in the chunk's rotation: wave-uniform, a multiple of 4
+                int q = 8 + OPT * J + FC * rot;
+                q = q >= WCOLS ? q - WCOLS : q;
+                const unsigned row_addr = (unsigned)(uintptr_t)row;
+                const bool tail = ibase + OPT > M - 1 - EDGE;      // (wave-uniform) some of these outputs also go to the tail scratch
+                // The next chunk's nine IQ samples are REQUESTED here, ahead of the FIR, and consumed behind it (18 VGPRs beside the FIR
+                // statement's 94): a CU's wavefronts run the chunk in lockstep, so a load waited for right behind its issue is a stall every
+                // SIMD takes at the same moment.  Buffer loads (the tile's frames as one resource in SGPRs, one 32-bit byte offset per lane,
+                // the sample index in the scalar offset): no 64-bit per-lane pointer lives across the FIR statement, and a read past the
+                // tile's last sample returns zeros instead of needing a branch.
+                typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+                v2u_t raw[OPT + 1];
 #pragma unroll
-                for (int b = 0; b < NB; b++) blk[b] = row + ((b + rot) & (NB - 1)) * FC;
-                auto put = [&](const double (&out)[OPT], int h) {
-#pragma unroll
-                    for (int o = FBH * h; o < FBH * h + FBH; o++) {
-                        const int i = ibase + o;
-                        ubuf[(OPT * J + o) * TILE + lane] = out[o];
-                        if (i < M && i >= M - 1 - EDGE) Utt[(size_t)(i - (M - 1 - EDGE)) * TILE] = out[o];
-                    }
-                };
-                {
-                    double out[OPT];
-                    if (J == 0) { for_halves<0>(blk, taps.rev, out, put); }
-                    else if (J == 1) { for_halves<1>(blk, taps.rev, out, put); }
-                    else if (J == 2 || NFW == 3) { for_halves<2>(blk, taps.rev, out, put); }
-                    else { for_halves<NFW - 1>(blk, taps.rev, out, put); }
+                for (int e = 0; e <= OPT; e++) {
+#ifdef PSS_EXP_L2IQ   // timing experiment only: every chunk re-reads the frame's first samples (always cache hits)
+                    raw[e] = __builtin_amdgcn_raw_buffer_load_b64(rs_iq, voff_iq, ((tn & 31) + e) * 8, 0);
+#else
+                    raw[e] = __builtin_amdgcn_raw_buffer_load_b64(rs_iq, voff_iq, (tn + e) * 8, 0);
+#endif
                 }
-                // discriminator of the next chunk's 8 samples (9 complex); kept in registers until the window block
-                // is free.  The loads are issued after the FIR so they do not occupy registers across it — the other
-                // three waves of the SIMD cover their latency.
-                float dn[OPT];
-                if constexpr (DISC_IN) {
-                    // the next chunk's FC floats of every frame of the tile: TILE * FC / 4 pieces of 16 bytes over the 64 * NFW worker threads.
-                    // Buffer addressing: the tile's rows as one resource (scalar), the chunk as the scalar offset, one 32-bit byte offset per
-                    // lane — plain pointers became 64-bit per-lane addresses that were hoisted out of the chunk loop and spilled
-                    constexpr int PPF = FC / 4, NP = TILE * PPF / (64 * NFW);
-                    static_assert(FC % 4 == 0 && (TILE * PPF) % (64 * NFW) == 0 && NP * 4 == OPT, "piece split");
-                    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-                    const int wt = tid - 64;
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<float *>(dsc + (size_t)tile * TILE * ld), 0, (int)(TILE * ld * sizeof(float)), 0x00020000);
-                    const int last = (int)((n_frames - 1 - tile * TILE) < TILE - 1 ? (n_frames - 1 - tile * TILE) : TILE - 1);  // masked frames replay the last one
+#pragma unroll 1
+                for (int h = 0; h < OPT / FBH; h++) {
+                    int qh = q + FBH * h;
+                    qh = qh >= WCOLS ? qh - WCOLS : qh;
+                    double *us = ubuf + (OPT * J + FBH * h) * TILE + lane;
+                    // the hand-scheduled FIR (pss_fir_ring_asm.h): four outputs straight into the u chunk buffer
+                    fir_ring_asm(row_addr, (unsigned)(uintptr_t)us, qh, d_rev);
+                    if (tail) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the statement's own LDS writes (the compiler does not count them)
 #pragma unroll
-                    for (int r = 0; r < NP; r++) {
-                        const int item = wt + 64 * NFW * r, fl = item / PPF, pc = item % PPF;
-                        const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((fl < last ? fl : last) * ld + 4 * pc) * 4, (HEAD + (ch + 1) * FC) * 4, 0);
-                        dn[4 * r] = __uint_as_float(v.x); dn[4 * r + 1] = __uint_as_float(v.y);
-                        dn[4 * r + 2] = __uint_as_float(v.z); dn[4 * r + 3] = __uint_as_float(v.w);
+                        for (int o = 0; o < FBH; o++) {
+                            const int i = ibase + FBH * h + o;
+                            if (i < M && i >= M - 1 - EDGE) Utt[(size_t)(i - (M - 1 - EDGE)) * TILE] = us[o * TILE];
+                        }
                     }
-                } else {
+                }
+                // discriminator of the next chunk's 8 samples (9 complex, requested above); kept in registers until the window block is free
+                float dn[OPT];
+                {
+                    // The eight discriminator values are evaluated as eight interleaved branch-free chains (the routine's main path; `ok` =
+                    // operands in its range) with ONE almost-never-taken fix-up block behind them — per-sample `e < left` branches put every
+                    // sample into a basic block of its own, i.e. eight serial ~45-instruction dependent chains (208 clocks per sample in
+                    // the role benchmark).
                     float2 pre[OPT + 1];
-                    const int left = M - tn;  // discriminator samples of this batch inside the frame (one scalar per chunk: the bounds n / M themselves live in spilled SGPRs)
+                    const int left = M - tn;  // discriminator samples of this batch inside the frame (wave-uniform)
 #pragma unroll
-                    for (int e = 0; e <= OPT; e++) pre[e] = (e <= left) ? xq[tn + e] : make_float2(0.0f, 0.0f);
+                    for (int e = 0; e <= OPT; e++) {
+                        // (the empty statement uses the loaded value unconditionally: without it the compiler sinks every load into the
+                        // `e <= left` arm — a branch and a full vmcnt(0) wait per sample)
+                        asm volatile("" : "+v"(raw[e]));
+                        pre[e] = (e <= left) ? make_float2(__uint_as_float(raw[e].x), __uint_as_float(raw[e].y)) : make_float2(0.0f, 0.0f);
+                    }
+                    bool ok[OPT], allok = true;
 #pragma unroll
-                    for (int e = 0; e < OPT; e++) dn[e] = (e < left) ? disc_sample(pre[e + 1], pre[e], kscale, SWAPPED, ltab) : 0.0f;
+                    for (int e = 0; e < OPT; e++) {
+                        dn[e] = disc_sample_main(pre[e + 1], pre[e], kscale, SWAPPED, ok[e], ltab);
+                        allok = allok && (ok[e] || e >= left);
+                    }
+                    if (__builtin_expect(!allok, 0)) {   // zeros, denormals, infinities, NaNs: the routine's special-value path
+#pragma unroll
+                        for (int e = 0; e < OPT; e++)
+                            if (!ok[e] && e < left) dn[e] = disc_sample(pre[e + 1], pre[e], kscale, SWAPPED, ltab);
+                    }
+#pragma unroll
+                    for (int e = 0; e < OPT; e++) dn[e] = (e < left) ? dn[e] : 0.0f;
                 }
                 lds_barrier();  // A
                 // the oldest block (logical 0) becomes the newest (logical 3 of the next chunk)
-                if constexpr (DISC_IN) {
-                    constexpr int PPF = FC / 4, NP = TILE * PPF / (64 * NFW);
-                    const int wt = tid - 64;
+                {
+                    float4 *nb = reinterpret_cast<float4 *>(row + rot * FC + OPT * J);   // 16-byte stores (rows are 16-byte aligned, 25 x 16 bytes apart)
 #pragma unroll
-                    for (int r = 0; r < NP; r++) {
-                        const int item = wt + 64 * NFW * r, fl = item / PPF, pc = item % PPF;
-                        float *nb = win + fl * WSTR + rot * FC + 4 * pc;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) nb[k] = dn[4 * r + k];
-                    }
-                } else {
-                    float *nb = row + rot * FC + OPT * J;
-#pragma unroll
-                    for (int e = 0; e < OPT; e++) nb[e] = dn[e];
+                    for (int e = 0; e < OPT / 4; e++) nb[e] = make_float4(dn[4 * e], dn[4 * e + 1], dn[4 * e + 2], dn[4 * e + 3]);
                 }
                 rot = (rot + 1) & (NB - 1);
-                lds_barrier();  // B
+                lds_barrier_b();  // B
             } else {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __syncthreads();  // A
@@ -393,6 +413,9 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
             }
         }
     }
+#ifdef PSS_UBENCH
+    if (lane == 0 && blockIdx.x < 4096) atomicMax(&pss_dbg_stamps[4 * blockIdx.x + 1], wall_clock64());
+#endif
 #undef YAT
 }
 

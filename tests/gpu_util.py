@@ -51,3 +51,13 @@ def demod(mode, iq2d, fs, want_audio=True):
     e.demod(mode, d_iq, nf, n, fs, d_pcm, d_au)
     e.sync()
     return host(d_pcm), (host(d_au) if want_audio else None)
+
+
+def has_option(key, default):
+    """True if this build of the library knows the (kernel-selection, -DPSS_VARIANTS) option `key`; sets it to `default`."""
+    from pyspecsdr_amd.engine import PssError
+    try:
+        engine().set_option(key, default)
+        return True
+    except PssError:
+        return False

@@ -26,6 +26,12 @@ __global__ __launch_bounds__(256) void k(double *out, double a, double b, int it
                 if (MODE == 3) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[c]) : "v"((float)b), "v"((float)a));   // not packed
                 if (MODE == 4) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(v[c]) : "v"(f[c]));  // v_cvt_f64_f32
                 if (MODE == 5) asm volatile("v_add_u32 %0, %0, %1" : "+v"(reinterpret_cast<unsigned &>(f[c])) : "v"(i));
+                // operand forms of the fused NFM kernel's FIR: a tap in an SGPR pair, the accumulator started with an inline zero
+                if (MODE == 6) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(v[c]) : "v"(v[(c + 1) % CH]), "s"(b));          // acc += x * s[tap]
+                if (MODE == 7) asm volatile("v_fma_f64 %0, %1, %2, 0" : "=v"(v[c]) : "v"(v[(c + 1) % CH]), "s"(b));           // acc = x * s[tap] + 0
+                if (MODE == 8) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(v[c]) : "v"(v[(c + 1) % CH]), "v"(v[(c + 2) % CH]));   // three VGPR pairs
+                if (MODE == 9) { asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(v[c]) : "v"(f[c]));                                // cvt feeding an fma
+                                 asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(v[(c + 3) % CH]) : "v"(v[c]), "s"(b)); }
             }
         }
     }
@@ -68,6 +74,10 @@ int main(int argc, char **argv)
         run<3>("v_fma_f32", w, ghz);
         run<4>("v_cvt_f64_f32", w, ghz);
         run<5>("v_add_u32", w, ghz);
+        run<6>("fma v,s,acc", w, ghz);
+        run<7>("fma v,s,0", w, ghz);
+        run<8>("fma v,v,acc", w, ghz);
+        run<9>("cvt+fma (x2)", w, ghz);
     }
     return 0;
 }
