@@ -54,8 +54,8 @@ ALGO_BYTES = {
     "k_spectrum": N_FFT * 8 + N_FFT * 4,            # IQ in + float32 dB out
     "k_nfm_fwd": N_FFT * 8,                         # IQ in (y_fwd is an internal hand-off, not algorithmic)
     "k_nfm_bwd": 40,                                # 10 x 2 x int16 out
-    "k_post": N_FFT * 4 + (N_FFT - 4) * 4 + 8,      # dB row in, post-processed row + its extremes out
-    "k_disp_rows": (N_FFT - 4) * 4 + 2 * DISP_W,    # post-processed row in, glyph + colour line out
+    "k_post": N_FFT * 4 + 12,                       # dB row in; clamp threshold + extremes out (the post-processed row is not materialised)
+    "k_disp_rows": N_FFT * 4 + 2 * DISP_W,          # dB row in (the cells' elements of the post-processed row are rebuilt), glyph + colour line out
     "k_slide_extremes": 8 + 16,
     "k_nfm_front": N_FFT * 8, "k_nfm_edge": 0, "k_nfm_iir": 40,   # three-kernel fallback path (PSS_NO_FUSED=1)
     # 12 328 B/frame (IQ read once, dB row, PCM) + the materialised waterfall line (glyph and colour)
@@ -110,6 +110,27 @@ def valu_issue_ms(d):
     f64 = sum(d.get(k, 0.0) or 0.0 for k in ("sq_insts_valu_add_f64", "sq_insts_valu_mul_f64", "sq_insts_valu_fma_f64", "sq_insts_valu_cvt"))
     b32 = max(d["valu_insts"] - f64, 0.0)
     return (f64 / VALU_RATE_F64 + b32 / VALU_RATE_B32) * 1e3
+
+
+def step_traffic(kernels, n_frames):
+    """HBM bytes of one step from the committed counter digest (FETCH_SIZE x 2 + WRITE_SIZE per kernel, same source-hash rule as
+    profiled()): the sum over the step's kernels, and its ratio to SURVEY §8(d)'s algorithmic bytes of the path (IQ read once, dB
+    row, PCM: 12 328 B per frame) — how many bytes the step moves per byte it has to."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        if t.get("src_hash") != source_hash():
+            return None, None
+        ks = t["kernels"]
+        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel"}
+        tot = 0.0
+        for k in kernels:
+            d = ks.get(names.get(k, k))
+            if not d or d.get("traffic_bytes") is None:
+                return None, None
+            tot += d["traffic_bytes"] * n_frames / float(t["n_frames"])
+        return tot, tot / ((N_FFT * 8 + N_FFT * 4 + 40) * float(n_frames))
+    except Exception:  # noqa: BLE001
+        return None, None
 
 
 def step_valu(kernels, n_frames, ms_per_step):
@@ -208,9 +229,20 @@ def verify_step(eng, iq, fs, d_db, d_post, pk, o_col, o_pcm, n_out, window):
         res["pcm_equal"] = res["pcm_equal"] and bool(np.array_equal(g_pcm, buf.pcm))
         if d_post is not None:
             g_post = np.ascontiguousarray(d_post[sl].cpu().numpy())
-            ref_post = np.stack([O.postprocess(g_db[k].astype(np.float64)) for k in range(blk)])
-            res["post_max_rel"] = max(res["post_max_rel"], rel(g_post.astype(np.float64), ref_post))
-            O.lib().pss_o_waterfall_rows(g_post.reshape(-1), blk, m, window, DISP_W, buf.glyph.reshape(-1), buf.colour.reshape(-1), 1)
+        else:
+            # the step did not materialise the post-processed rows: rebuild them on the host from the device's float32 dB rows exactly
+            # as the display kernel does per cell (np.convolve's order in float64, rounded to float32, clamped at float32(median - 10))
+            d64 = g_db.astype(np.float64)
+            acc = d64[:, 0:m] * 0.2
+            for k in range(1, 5):
+                acc = acc + d64[:, k:k + m] * 0.2
+            sm = acc.astype(np.float32)
+            srt = np.sort(sm, axis=1)
+            med = 0.5 * (srt[:, (m - 1) // 2].astype(np.float64) + srt[:, m // 2].astype(np.float64))
+            g_post = np.ascontiguousarray(np.maximum(sm, (med - 10.0).astype(np.float32)[:, None]))
+        ref_post = np.stack([O.postprocess(g_db[k].astype(np.float64)) for k in range(blk)])
+        res["post_max_rel"] = max(res["post_max_rel"], rel(g_post.astype(np.float64), ref_post))
+        O.lib().pss_o_waterfall_rows(g_post.reshape(-1), blk, m, window, DISP_W, buf.glyph.reshape(-1), buf.colour.reshape(-1), 1)
         first = 0 if s0 == 0 else window - 1        # lines with a complete history inside the block
         res["lines_equal"] = res["lines_equal"] and bool(np.array_equal(glyph[sl].cpu().numpy()[first:], buf.glyph[first:])
                                                          and np.array_equal(colour[sl].cpu().numpy()[first:], buf.colour[first:]))
@@ -250,6 +282,8 @@ def main():
     ap.add_argument("--no-side", action="store_true",
                     help="skip the untimed side measurements (standalone kernels, the 30-row reading, exchange alone): under a profiler "
                          "every launch then belongs to a step of the default schedule")
+    ap.add_argument("--materialise-post", action="store_true",
+                    help="also write the post-processed rows [frames][1020] float32 to HBM (default: the display lines are built without them)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step's outputs")
     ap.add_argument("--dry-run", action="store_true", help="launch path only (gloo rendezvous, no GPU work): what the CPU test runs")
     args = ap.parse_args()
@@ -283,7 +317,8 @@ def main():
     torch.cuda.synchronize(dev)            # the IQ batch is produced on torch's stream, consumed on the library's
     n_out = eng.demod_out_len(0, n, FS)
     m = n - 4
-    d_post = torch.empty((nf, m), dtype=torch.float32, device=dev)
+    d_post = torch.empty((nf, m), dtype=torch.float32, device=dev)      # side measurements; the timed step writes it only with --materialise-post
+    step_post = d_post if args.materialise_post else None
     d_lo = torch.empty((nf,), dtype=torch.float32, device=dev)
     d_hi = torch.empty((nf,), dtype=torch.float32, device=dev)
     # two output sets: step k+1 computes into one while step k's is in flight to rank 0.  A set is ONE packed buffer
@@ -302,7 +337,7 @@ def main():
     def compute(b):
         db = d_db[b % len(d_db)]
         base = packed[b].data_ptr()
-        eng.frame_pipeline_nfm(iq, nf, n, FS, db, d_post, d_lo, d_hi, DISP_W, base, base + o_col, base + o_pcm, window=WF_WINDOW)
+        eng.frame_pipeline_nfm(iq, nf, n, FS, db, step_post, d_lo, d_hi, DISP_W, base, base + o_col, base + o_pcm, window=WF_WINDOW)
 
     def exchange(b):
         src = packed[b] if exch == "display" else d_db[b % len(d_db)].view(torch.uint8).view(-1)
@@ -356,7 +391,7 @@ def main():
     verified = None
     if not args.no_verify:
         last = (args.steps - 1) & 1 if args.steps else 0
-        verified = verify_step(eng, iq, FS, d_db[last % len(d_db)], d_post, packed[last], o_col, o_pcm, n_out, WF_WINDOW)
+        verified = verify_step(eng, iq, FS, d_db[last % len(d_db)], step_post, packed[last], o_col, o_pcm, n_out, WF_WINDOW)
         if dist is not None:      # every rank checks its own outputs; the line reports the conjunction
             okt = torch.tensor([1 if verified["ok"] else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
@@ -382,7 +417,10 @@ def main():
         eng.sync()
         spec_alone = eng.kernel_times().get("k_spectrum", [])
         for _ in range(5):      # likewise the post-process kernel
-            eng.spectrum_post_extremes(d_db[0], nf, n, d_post, d_lo, d_hi)
+            if step_post is None:
+                eng.spectrum_post_thresholds(d_db[0], nf, n, d_post, d_lo, d_hi)     # (d_post's first nf floats receive the thresholds)
+            else:
+                eng.spectrum_post_extremes(d_db[0], nf, n, d_post, d_lo, d_hi)
         eng.sync()
         post_alone = eng.kernel_times().get("k_post", [])
         for _ in range(5):      # and the demodulator with nothing beside it
@@ -446,6 +484,7 @@ def main():
                                  "ops_per_sample": NFM_FWD_F64_OPS_PER_SAMPLE,
                                  "note": "the kernel's binding roof: 63 fma + 51 add + 12 mul float64 per sample are fixed by the "
                                          "reference's accumulation order; peak = 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz"}
+        roof["traffic_step"], roof["traffic_ratio"] = step_traffic(list(ktimes), nf)
         sv = step_valu(list(ktimes), nf, elapsed / args.steps * 1e3)
         if sv:
             roof["step_valu"] = sv
@@ -473,6 +512,8 @@ def main():
             "config": {"workload": f"{nf} frames x {n}-pt complex64 @2.4 MS/s per GPU, every frame: compute_fft dB spectrum + "
                                    f"post-process (smoothing, median clamp) + waterfall display line + NFM demod -> int16 stereo "
                                    f"(BASELINE.json configs[1])",
+                       "materialised": {"db_rows": True, "pcm": True, "waterfall_lines": True, "row_extremes": True,
+                                        "post_processed_rows": bool(args.materialise_post)},
                        "frames_per_gpu": nf, "n_fft": n, "sample_rate": FS, "parallelism": f"frames sharded x{world}",
                        "exchange": {"display": "RCCL gather to rank 0 of every rank's waterfall lines + PCM (one packed buffer per step), "
                                                "overlapped with the next step, inside the timed region",

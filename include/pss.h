@@ -174,7 +174,9 @@ int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, doub
  * NFM demod -> d_pcm; compute_fft -> d_db [n_frames][n]; post-process -> d_post [n_frames][n-4] and the row extremes
  * (d_row_lo / d_row_hi: [n_halo + n_frames], the first n_halo entries supplied by the caller as for pss_waterfall_rows);
  * waterfall line per frame -> d_glyph / d_colour [n_frames][disp_w].  The same results as the separate calls; part of the
- * display chain runs on a side stream beside the demodulator's backward pass and is joined before the call returns. */
+ * display chain runs on a side stream beside the demodulator's backward pass and is joined before the call returns.
+ * d_post may be NULL: the post-processed rows are then not written to memory at all (a third of the chain's HBM traffic) — the
+ * display lines are the same bytes, rebuilt from the dB rows and the 12 bytes per row that pss_spectrum_post_thresholds leaves. */
 int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
                            float *d_row_lo, float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
                            int8_t *d_colour, int16_t *d_pcm);
@@ -277,6 +279,18 @@ int pss_persistence_rows(pss_ctx *ctx, const float *d_post, long n_frames, int l
                          int n_halo, int window, int disp_h, int disp_w, int8_t *d_y);
 int pss_persistence_rows_f64(pss_ctx *ctx, const double *d_post, long n_frames, int len, const double *d_row_lo,
                              const double *d_row_hi, int n_halo, int window, int disp_h, int disp_w, int8_t *d_y);
+/* The same WITHOUT materialised post-processed rows (float32 path; n_fft a multiple of 4, n_fft - 4 <= 32768).
+ * pss_spectrum_post_thresholds: the post-process of pyspecsdr.py:2278-2283 reduced to what the accumulators need of every row —
+ * d_row_thr float32 [n_frames] (the clamp threshold float32(median - 10)) and the finite extremes of the clamped row.
+ * pss_waterfall_rows_db / pss_persistence_rows_db: the display lines from the dB rows [n_frames][n_fft] and those thresholds; element j
+ * of a post-processed row is rebuilt where a cell needs it — float32(sum of 5 dB values * 0.2 in np.convolve's order) clamped at the
+ * threshold, bit for bit what pss_spectrum_post writes — so the lines are byte-identical to pss_waterfall_rows on materialised rows. */
+int pss_spectrum_post_thresholds(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_row_thr, float *d_row_lo,
+                                 float *d_row_hi);
+int pss_waterfall_rows_db(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, const float *d_row_thr, const float *d_row_lo,
+                          const float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph, int8_t *d_colour);
+int pss_persistence_rows_db(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, const float *d_row_thr, const float *d_row_lo,
+                            const float *d_row_hi, int n_halo, int window, int disp_h, int disp_w, int8_t *d_y);
 
 /* ---- host-buffer convenience (single frame, synchronous; what the drop-in Python module calls) --- */
 int pss_h_compute_fft(pss_ctx *ctx, const float *h_iq, int n, double *h_db);

@@ -42,6 +42,9 @@ _SIGS = {
     "pss_waterfall_rows_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
     "pss_persistence_rows": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "pss_persistence_rows_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "pss_spectrum_post_thresholds": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, _p]),
+    "pss_waterfall_rows_db": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "pss_persistence_rows_db": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "pss_scan": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p]),
     "pss_scan_threshold": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, C.c_double, _p, _p, _p, _p]),
     "pss_hilbert": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),

@@ -57,6 +57,8 @@ struct pss_ctx {
     size_t scratch_scan_bytes = 0;
     void *scratch_pk = nullptr;
     size_t scratch_pk_bytes = 0;
+    void *scratch_post = nullptr;  // pss_frame_pipeline_nfm without materialised post-processed rows: the rows' clamp thresholds
+    size_t scratch_post_bytes = 0;
     void *scratch_win = nullptr;   // sliding-window extremes of the batched display accumulators
     size_t scratch_win_bytes = 0;
     float *d_hann = nullptr;       // pss_classify: scipy's periodic Hann window (1024, float32) and sum(win * win)

@@ -2957,8 +2957,20 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
 {
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
-    if (n_frames > 0 && (!d_db || !d_post || !d_row_lo || !d_row_hi || !d_glyph || !d_colour || !d_pcm))
+    if (n_frames > 0 && (!d_db || !d_row_lo || !d_row_hi || !d_glyph || !d_colour || !d_pcm))
         return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_nfm: null buffer");
+    // d_post == NULL: the post-processed rows are not materialised — the post-process leaves 12 bytes per row (clamp threshold,
+    // extremes) and the display kernel rebuilds the elements its cells need from the dB rows (rows of a multiple of 4 points up to
+    // 32 772; other lengths go through a context-owned scratch copy of the rows)
+    float *d_thr = nullptr;
+    if (n_frames > 0 && !d_post) {
+        const bool direct = (n & 3) == 0 && n - 4 <= 32768 && !ctx->post_legacy;
+        const size_t need = direct ? (size_t)n_frames * sizeof(float) : (size_t)n_frames * (n - 4) * sizeof(float);
+        int rq = pss_ensure_buffer(ctx, &ctx->scratch_post, &ctx->scratch_post_bytes, need, "post-process scratch");
+        if (rq) return rq;
+        if (direct) d_thr = reinterpret_cast<float *>(ctx->scratch_post);
+        else d_post = reinterpret_cast<float *>(ctx->scratch_post);
+    }
     pss_time_begin(ctx);
     // Schedule: forward kernel (VALU-bound, fills the machine) ->
     //   { backward pass (latency-bound, one wavefront per SIMD)  ||  spectrum -> post-process -> display lines }.
@@ -2978,6 +2990,11 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
     auto display_chain = [&]() -> int {
         int q = PSS_OK;
         if (beside_bwd) q = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+        if (d_thr) {
+            if (!q) q = pss_spectrum_post_thresholds(ctx, d_db, n_frames, n, d_thr, d_row_lo + n_halo, d_row_hi + n_halo);
+            if (!q) q = pss_waterfall_rows_db(ctx, d_db, n_frames, n, d_thr, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+            return q;
+        }
         if (!q) q = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
         if (!q) q = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
         return q;

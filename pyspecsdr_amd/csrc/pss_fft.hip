@@ -1210,7 +1210,7 @@ extern "C" int pss_scan_threshold(pss_ctx *ctx, const float *d_iq, long n_slices
 namespace {
 
 template <int EPL, int W>
-int launch_post_sel(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_lo, float *d_hi)
+int launch_post_sel(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_lo, float *d_hi, float *d_thr)
 {
     constexpr int T = 64 * W, RPW = W == 1 ? 4 : 1;
     const size_t lds = (size_t)RPW * (T + 1) * pss_post::PostCfg<EPL>::S * sizeof(float);
@@ -1221,31 +1221,38 @@ int launch_post_sel(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, f
     const long cap = 256L * (W == 1 ? 6 : (W <= 4 ? 4 : 1));
     pss_kernel_begin(ctx, "k_post");
     hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(W == 1 ? 256 : 64 * W), lds, PSS_STREAM(ctx), d_db,
-                       d_post, n_fft, n_frames, d_lo, d_hi);
+                       d_post, n_fft, n_frames, d_lo, d_hi, d_thr);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_post_sel launch");
 }
 
-// smoothing + median clamp of n_frames rows; d_lo / d_hi (both or neither) receive the finite extremes of every clamped row
-int spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_lo, float *d_hi)
+// the register select kernel (k_post_sel) serves rows of a multiple of 4 points up to 32 772; only it can leave the rows unwritten
+bool post_sel_serves(const pss_ctx *ctx, int n_fft) { return !ctx->post_legacy && n_fft - 4 <= 32768 && (n_fft & 3) == 0; }
+
+// smoothing + median clamp of n_frames rows; d_lo / d_hi (both or neither) receive the finite extremes of every clamped row.
+// d_post == nullptr (with d_thr, d_lo, d_hi; rows k_post_sel serves): the rows are not written, only their clamp thresholds
+// float32(median - 10) and extremes — 12 bytes per row instead of 4 (n_fft - 4).
+int spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_lo, float *d_hi, float *d_thr = nullptr)
 {
-    if (n_frames < 0 || (n_frames > 0 && (!d_db || !d_post))) return pss_fail(ctx, PSS_E_ARG, "null pointer");
+    if (n_frames < 0 || (n_frames > 0 && (!d_db || (!d_post && !(d_thr && d_lo))))) return pss_fail(ctx, PSS_E_ARG, "null pointer");
+    if (!d_post && n_fft >= 8 && !post_sel_serves(ctx, n_fft))
+        return pss_fail(ctx, PSS_E_ARG, "post-process without materialised rows: n_fft must be a multiple of 4 and at most 32772");
     if ((d_lo == nullptr) != (d_hi == nullptr)) return pss_fail(ctx, PSS_E_ARG, "row extremes: pass both arrays or neither");
     if (n_fft < 8 || n_fft > (1 << 20)) return pss_fail(ctx, PSS_E_ARG, "post-process supports 8 <= n_fft <= 1048576");
     if (n_frames == 0) return PSS_OK;
     const int m = n_fft - 4;
     int r = PSS_OK;
     pss_time_begin(ctx);
-    if (!ctx->post_legacy && m <= 32768 && (n_fft & 3) == 0) {
+    if (post_sel_serves(ctx, n_fft)) {
         // register-resident binary-search select: one wavefront per row up to 2048 points, 4 / 16 wavefronts above
-        if (m <= 256) r = launch_post_sel<4, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
-        else if (m <= 512) r = launch_post_sel<8, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
-        else if (m <= 1024) r = launch_post_sel<16, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
-        else if (m <= 2048) r = launch_post_sel<32, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
-        else if (m <= 4096) r = launch_post_sel<16, 4>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
-        else if (m <= 8192) r = launch_post_sel<32, 4>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
-        else if (m <= 16384) r = launch_post_sel<16, 16>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
-        else r = launch_post_sel<32, 16>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi);
+        if (m <= 256) r = launch_post_sel<4, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
+        else if (m <= 512) r = launch_post_sel<8, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
+        else if (m <= 1024) r = launch_post_sel<16, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
+        else if (m <= 2048) r = launch_post_sel<32, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
+        else if (m <= 4096) r = launch_post_sel<16, 4>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
+        else if (m <= 8192) r = launch_post_sel<32, 4>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
+        else if (m <= 16384) r = launch_post_sel<16, 16>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
+        else r = launch_post_sel<32, 16>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
     } else if (n_fft > ctx->post_sort_max) {
         // rows too long for registers / the LDS sort: MSD radix select with an LDS histogram
         pss_kernel_begin(ctx, "k_post");
@@ -1295,9 +1302,10 @@ int row_extremes(pss_ctx *ctx, const T *d_rows, long n_rows, int len, T *d_lo, T
 }
 
 // MODE 0: waterfall line (glyph, colour); MODE 1: persistence trace (y).  d_lo / d_hi: [n_halo + n_frames] row extremes.
+// d_thr != nullptr: d_post holds the float32 dB rows (len + 4 points each), the post-processed rows are rebuilt per cell
 template <class T, int MODE>
 int display_rows(pss_ctx *ctx, const T *d_post, long n_frames, int len, const T *d_lo, const T *d_hi, int n_halo, int window,
-                 int disp_h, int disp_w, int8_t *d_a, int8_t *d_b)
+                 int disp_h, int disp_w, int8_t *d_a, int8_t *d_b, const float *d_thr = nullptr)
 {
     if (n_frames < 0 || len < 2 || disp_w < 1 || disp_h < 1 || disp_h > 127 || window < 1 || n_halo < 0 ||
         (n_frames > 0 && (!d_post || !d_lo || !d_hi || !d_a || (MODE == 0 && !d_b))))
@@ -1313,8 +1321,18 @@ int display_rows(pss_ctx *ctx, const T *d_post, long n_frames, int len, const T 
     pss_kernel_end(ctx);
     const long cells = n_frames * disp_w;
     pss_kernel_begin(ctx, "k_disp_rows");
-    hipLaunchKernelGGL((pss_post::k_disp_rows<T, MODE>), dim3((unsigned)((cells + 255) / 256 < 16384 ? (cells + 255) / 256 : 16384)),
-                       dim3(256), 0, PSS_STREAM(ctx), d_post, wlo, whi, n_frames, len, disp_w, disp_h, d_a, d_b);
+    const dim3 dgrid((unsigned)((cells + 255) / 256 < 16384 ? (cells + 255) / 256 : 16384));
+    if constexpr (sizeof(T) == 4) {
+        if (d_thr)
+            hipLaunchKernelGGL((pss_post::k_disp_rows<T, MODE, true>), dgrid, dim3(256), 0, PSS_STREAM(ctx), d_post, wlo, whi, n_frames, len,
+                               disp_w, disp_h, d_a, d_b, d_thr);
+        else
+            hipLaunchKernelGGL((pss_post::k_disp_rows<T, MODE>), dgrid, dim3(256), 0, PSS_STREAM(ctx), d_post, wlo, whi, n_frames, len, disp_w,
+                               disp_h, d_a, d_b, nullptr);
+    } else {
+        hipLaunchKernelGGL((pss_post::k_disp_rows<T, MODE>), dgrid, dim3(256), 0, PSS_STREAM(ctx), d_post, wlo, whi, n_frames, len, disp_w,
+                           disp_h, d_a, d_b, nullptr);
+    }
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_disp_rows launch");
@@ -1366,6 +1384,33 @@ extern "C" int pss_row_extremes_f64(pss_ctx *ctx, const double *d_rows, long n_r
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
     return row_extremes<double>(ctx, d_rows, n_rows, len, d_row_lo, d_row_hi);
+}
+
+// The post-process WITHOUT writing the post-processed rows: per row the clamp threshold float32(median - 10) and the finite extremes of
+// the clamped row (12 bytes).  pss_waterfall_rows_db / pss_persistence_rows_db rebuild the elements a display line needs from the dB rows.
+extern "C" int pss_spectrum_post_thresholds(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_row_thr, float *d_row_lo,
+                                            float *d_row_hi)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames > 0 && (!d_row_thr || !d_row_lo || !d_row_hi)) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_post_thresholds: null buffer");
+    return spectrum_post(ctx, d_db, n_frames, n_fft, nullptr, d_row_lo, d_row_hi, d_row_thr);
+}
+extern "C" int pss_waterfall_rows_db(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, const float *d_row_thr, const float *d_row_lo,
+                                     const float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph, int8_t *d_colour)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames > 0 && !d_row_thr) return pss_fail(ctx, PSS_E_ARG, "pss_waterfall_rows_db: null thresholds");
+    return display_rows<float, 0>(ctx, d_db, n_frames, n_fft - 4, d_row_lo, d_row_hi, n_halo, window, 1, disp_w, d_glyph, d_colour, d_row_thr);
+}
+extern "C" int pss_persistence_rows_db(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, const float *d_row_thr,
+                                       const float *d_row_lo, const float *d_row_hi, int n_halo, int window, int disp_h, int disp_w, int8_t *d_y)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames > 0 && !d_row_thr) return pss_fail(ctx, PSS_E_ARG, "pss_persistence_rows_db: null thresholds");
+    return display_rows<float, 1>(ctx, d_db, n_frames, n_fft - 4, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_y, nullptr, d_row_thr);
 }
 
 extern "C" int pss_waterfall_rows(pss_ctx *ctx, const float *d_post, long n_frames, int len, const float *d_row_lo,

@@ -206,9 +206,11 @@ __device__ __forceinline__ void row_sync()
 // stores to out4), the row's finite extremes.  slot[j]: LDS slot of the 4-element chunk j * T + t.  Ends with a row_sync
 // (the buffer may be overwritten afterwards).  FULL: the row has exactly T * EPL points (padding = the last thread's last
 // four slots only).
+// out4 == nullptr: the clamped row is NOT written (the display kernels can rebuild any element of it from the dB row and the clamp
+// threshold: k_disp_rows<..., FROM_DB>); row_thr (nullable) receives the row's clamp threshold float32(median - 10).
 template <int EPL, int W, bool FULL>
 __device__ __forceinline__ void post_row_staged(float *buf, const int (&slot)[EPL / 4], int t, int m, unsigned *red, int wave, int lane,
-                                                int &phase, float4 *out4, float *row_lo, float *row_hi, long f)
+                                                int &phase, float4 *out4, float *row_lo, float *row_hi, long f, float *row_thr = nullptr)
 {
     constexpr int T = 64 * W, S = PostCfg<EPL>::S, Q = EPL / 4;
     constexpr int PAD_FROM = FULL ? EPL - 4 : 0;
@@ -252,7 +254,9 @@ __device__ __forceinline__ void post_row_staged(float *buf, const int (&slot)[EP
     // fd[fd < thr] = thr (:2282-2283).  float32(max(s, thr)) = max(float32(s), float32(thr)) (rounding is monotonic), and
     // the maximum of two floats is the maximum of their ordered images
     const unsigned thr = f2ord((float)(med - 10.0));
+    if (row_thr && t == 0) row_thr[f] = ord2f(thr);
     row_sync<W == 1>();                      // every thread has read its input window
+    if (out4) {
 #pragma unroll
     for (int i = 0; i < Q; i++) {
         float o[4];
@@ -268,6 +272,7 @@ __device__ __forceinline__ void post_row_staged(float *buf, const int (&slot)[EP
     for (int j = 0; j < Q; j++) {
         const int c = j * T + t;
         if (c < m4) out4[c] = *reinterpret_cast<const float4 *>(buf + slot[j]);
+    }
     }
     if (row_lo) {
         // finite extremes of the clamped row, as the accumulators' np.isfinite masks see them.  A row whose smoothed
@@ -299,7 +304,7 @@ __device__ __forceinline__ void post_row_staged(float *buf, const int (&slot)[EP
 template <int EPL, int W, bool FULL>
 __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_post_sel(const float *__restrict__ db, float *__restrict__ post, int N,
                                                                      long n_frames, float *__restrict__ row_lo,
-                                                                     float *__restrict__ row_hi)
+                                                                     float *__restrict__ row_hi, float *__restrict__ row_thr)
 {
     constexpr int T = 64 * W;                    // threads per row
     constexpr int RPW = W == 1 ? 4 : 1;          // rows per workgroup
@@ -335,8 +340,8 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_post_sel(const float 
         // rows of more than T * EPL points (N - 4 <= T * EPL < N): the last thread's window reaches into one more chunk
         if (!FULL && t == 0 && T * Q < n4) *reinterpret_cast<float4 *>(buf + T * S) = row4[T * Q];
         row_sync<W == 1>();
-        post_row_staged<EPL, W, FULL>(buf, slot, t, m, red, wave, lane, phase, reinterpret_cast<float4 *>(post + (size_t)f * m), row_lo,
-                                      row_hi, f);
+        post_row_staged<EPL, W, FULL>(buf, slot, t, m, red, wave, lane, phase,
+                                      post ? reinterpret_cast<float4 *>(post + (size_t)f * m) : nullptr, row_lo, row_hi, f, row_thr);
     }
 }
 
@@ -393,8 +398,8 @@ __global__ __launch_bounds__(256) void k_slide_extremes(const T *__restrict__ ro
 }
 
 // np.interp(np.linspace(0, len-1, W), np.arange(len), row)[x] in float64 (pyspecsdr.py:1379-1383 / :1550-1554)
-template <class T>
-__device__ __forceinline__ double interp_at(const T *row, int len, int W, int x)
+template <class Row>
+__device__ __forceinline__ double interp_at(const Row &row, int len, int W, int x)
 {
     const double stop = (double)(len - 1);
     double xp;
@@ -409,22 +414,47 @@ __device__ __forceinline__ double interp_at(const T *row, int len, int W, int x)
     return slope * (xp - (double)j) + (double)row[j];
 }
 
+// element j of the post-processed row rebuilt from the float32 dB row and the row's clamp threshold, bit for bit what k_post_sel
+// stores: float32(sum_k (double)db[j + k] * 0.2) in np.convolve's order, then the maximum with the threshold on the ordered images
+struct PostFromDb {
+    const float *db;       // the frame's dB row (n_fft = len + 4 points)
+    unsigned thr;          // ordered image of the clamp threshold
+    __device__ __forceinline__ float operator[](int j) const
+    {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc += (double)db[j + k] * 0.2;
+        const unsigned kk = f2ord((float)acc);
+        return ord2f(kk > thr ? kk : thr);
+    }
+};
+
 // One display line per frame: the NEWEST row of the history as the reference draws it at frame i (waterfall line y = 0).
 //   MODE 0  waterfall (pyspecsdr.py:1386-1403): glyph 0 '.', 1 '-', 2 '=', 3 '#'; colour int(norm * 5); -1: not finite.
 //           No zero-range guard (:1389), as in the reference.
 //   MODE 1  persistence (:1556-1563): y = int((1 - norm) * (disp_h - 1)) of the newest trace, -1 if not drawn (not finite or
 //           outside the grid); range 0 -> 1 (:1528-1530).
-template <class T, int MODE>
+// FROM_DB: `post` holds the float32 dB rows (len + 4 points each) and row_thr the clamp thresholds: the post-processed rows were
+// never written (the line needs two neighbouring elements of it per cell: 10 dB values).
+template <class T, int MODE, bool FROM_DB = false>
 __global__ __launch_bounds__(256) void k_disp_rows(const T *__restrict__ post, const double *__restrict__ win_lo,
                                                    const double *__restrict__ win_hi, long n_frames, int len, int disp_w,
-                                                   int disp_h, int8_t *__restrict__ out_a, int8_t *__restrict__ out_b)
+                                                   int disp_h, int8_t *__restrict__ out_a, int8_t *__restrict__ out_b,
+                                                   const float *__restrict__ row_thr = nullptr)
 {
     const long total = n_frames * disp_w;
     for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
         const long f = c / disp_w;
         const int x = (int)(c - f * disp_w);
         const double lo = win_lo[f], hi = win_hi[f];
-        const double v = interp_at(post + (size_t)f * len, len, disp_w, x);
+        double v;
+        if constexpr (FROM_DB) {
+            static_assert(sizeof(T) == 4, "dB rows are float32");
+            const PostFromDb row{reinterpret_cast<const float *>(post) + (size_t)f * (len + 4), f2ord(row_thr[f])};
+            v = interp_at(row, len, disp_w, x);
+        } else {
+            v = interp_at(post + (size_t)f * len, len, disp_w, x);
+        }
         if (MODE == 0) {
             int8_t g = -1, ci = -1;
             if (isfinite(v)) {

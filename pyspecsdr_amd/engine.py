@@ -156,6 +156,19 @@ class Engine:
         self._ck(fn(self.h, _ptr(d_post), n_frames, length, _ptr(d_row_lo), _ptr(d_row_hi), n_halo, window, disp_h, disp_w,
                     _ptr(d_y)))
 
+    def spectrum_post_thresholds(self, d_db, n_frames, n_fft, d_row_thr, d_row_lo, d_row_hi):
+        """The post-process without writing the rows: clamp threshold and finite extremes per row (inputs of *_rows_db)."""
+        self._ck(self.lib.pss_spectrum_post_thresholds(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_row_thr), _ptr(d_row_lo), _ptr(d_row_hi)))
+
+    def waterfall_rows_db(self, d_db, n_frames, n_fft, d_row_thr, d_row_lo, d_row_hi, disp_w, d_glyph, d_colour, n_halo=0, window=30):
+        """waterfall_rows from the dB rows + clamp thresholds (the post-processed rows are never written)."""
+        self._ck(self.lib.pss_waterfall_rows_db(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_row_thr), _ptr(d_row_lo), _ptr(d_row_hi), n_halo,
+                                                window, disp_w, _ptr(d_glyph), _ptr(d_colour)))
+
+    def persistence_rows_db(self, d_db, n_frames, n_fft, d_row_thr, d_row_lo, d_row_hi, disp_h, disp_w, d_y, n_halo=0, window=10):
+        self._ck(self.lib.pss_persistence_rows_db(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_row_thr), _ptr(d_row_lo), _ptr(d_row_hi), n_halo,
+                                                  window, disp_h, disp_w, _ptr(d_y)))
+
     def scan(self, d_iq, n_slices, n_fft, fs, d_db, d_peak, d_bw, d_count):
         self._ck(self.lib.pss_scan(self.h, _ptr(d_iq), n_slices, n_fft, float(fs), _ptr(d_db), _ptr(d_peak),
                                    _ptr(d_bw), _ptr(d_count)))
@@ -207,7 +220,7 @@ class Engine:
     def frame_pipeline_nfm(self, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, disp_w, d_glyph, d_colour, d_pcm,
                            n_halo=0, window=30):
         """One main-loop iteration for a batch of read buffers: NFM -> int16, dB row, post-processed row (+ extremes),
-        waterfall line (pyspecsdr.py:2262-2283 + draw_waterfall)."""
+        waterfall line (pyspecsdr.py:2262-2283 + draw_waterfall).  d_post=None: the post-processed rows are not materialised."""
         self._ck(self.lib.pss_frame_pipeline_nfm(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
                                                  _ptr(d_row_hi), n_halo, window, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_pcm)))
 

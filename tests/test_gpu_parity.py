@@ -1453,24 +1453,123 @@ def test_frame_pipeline_equals_separate_calls():
 
 
 def test_full_size_headline_properties():
-    """BASELINE.json cfg 2 size (65 536 x 1024): size-independent properties of the fused headline call."""
+    """BASELINE.json cfg 2 size (65 536 x 1024) through pss_frame_pipeline_nfm — the call bench.py times: size-independent properties
+    of every output (dB rows, post-processed rows, waterfall lines, PCM), an oracle spot check, and the variant that does not
+    materialise the post-processed rows (d_post = NULL) byte for byte."""
     e = G.engine()
-    nf, n, fs = 65536, 1024, 2.4e6
+    nf, n, fs, W, win = 65536, 1024, 2.4e6, 112, 30
     gen = torch.Generator(device="cuda").manual_seed(1234)
     base = torch.randn((512, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3
     iq = base.repeat(nf // 512, 1, 1).contiguous()            # every block of 512 frames repeats
-    d_db = G.empty((nf, n), torch.float32)
+    d_db, d_post = G.empty((nf, n), torch.float32), G.empty((nf, n - 4), torch.float32)
+    d_lo, d_hi = G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
+    d_g, d_c = G.empty((nf, W), torch.int8), G.empty((nf, W), torch.int8)
     d_pcm = G.empty((nf, 10, 2), torch.int16)
-    e.spectrum_nfm(iq, nf, n, fs, d_db, d_pcm)
+    e.frame_pipeline_nfm(iq, nf, n, fs, d_db, d_post, d_lo, d_hi, W, d_g, d_c, d_pcm, window=win)
     e.sync()
-    db, pcm = d_db.view(nf // 512, 512, n), d_pcm.view(nf // 512, 512, 10, 2)
-    assert bool((db == db[0:1]).all()) and bool((pcm == pcm[0:1]).all())     # batch-position independence
+    R = nf // 512
+    db, post, pcm = d_db.view(R, 512, n), d_post.view(R, 512, n - 4), d_pcm.view(R, 512, 10, 2)
+    assert bool((db == db[0:1]).all()) and bool((pcm == pcm[0:1]).all()) and bool((post == post[0:1]).all())   # batch-position independence
+    assert bool((d_lo.view(R, 512) == d_lo[:512]).all()) and bool((d_hi.view(R, 512) == d_hi[:512]).all())
+    # a waterfall line depends on the 29 rows before it: from the second repeat on every line's history is periodic too
+    g, c = d_g.view(R, 512, W), d_c.view(R, 512, W)
+    assert bool((g[1:] == g[1:2]).all()) and bool((c[1:] == c[1:2]).all())
+    assert bool((g[0, win - 1:] == g[1, win - 1:]).all()) and bool((c[0, win - 1:] == c[1, win - 1:]).all())   # first repeat: once its history is full
     assert bool((d_pcm[..., 0] == d_pcm[..., 1]).all())                       # L == R
     assert int(d_pcm.abs().max()) == 31128                                    # peak sample -> trunc(0.95*32767)
     assert bool((d_pcm.abs().amax(dim=(1, 2)) == 31128).all())                # in every frame
-    # spot-check 64 frames of the big batch against the oracle
+    # spot-check 64 frames of the big batch against the oracle: PCM, dB rows, post-processed rows, lines
     taps, sos, zi = e.nfm_filters(fs)
     h = base[:64].cpu().numpy().view(np.complex64).reshape(64, n)
-    hp = d_pcm[:64].cpu().numpy()
+    hp, hdb, hpost = d_pcm[:64].cpu().numpy(), d_db[:64].cpu().numpy(), np.ascontiguousarray(d_post[:64].cpu().numpy())
     for k in range(64):
         assert np.array_equal(hp[k], O.pcm16_stereo(O.demod_nfm(h[k], fs, taps, sos, zi)))
+        ref = O.compute_fft(h[k])
+        assert np.all(np.abs(hdb[k] - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0))
+        rp = O.postprocess(hdb[k].astype(np.float64))
+        assert np.all(np.abs(hpost[k] - rp) <= 1e-4 * np.maximum(np.abs(rp), 1.0))
+    buf = O.HeadlineBuffers(64, n, fs, W)
+    O.lib().pss_o_waterfall_rows(hpost.reshape(-1), 64, n - 4, win, W, buf.glyph.reshape(-1), buf.colour.reshape(-1), 1)
+    assert np.array_equal(d_g[:64].cpu().numpy(), buf.glyph) and np.array_equal(d_c[:64].cpu().numpy(), buf.colour)
+    # the same step without materialised post-processed rows
+    d_g2, d_c2, d_lo2, d_hi2 = G.empty((nf, W), torch.int8), G.empty((nf, W), torch.int8), G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
+    d_pcm2 = G.empty((nf, 10, 2), torch.int16)
+    d_db2 = G.empty((nf, n), torch.float32)
+    e.frame_pipeline_nfm(iq, nf, n, fs, d_db2, None, d_lo2, d_hi2, W, d_g2, d_c2, d_pcm2, window=win)
+    e.sync()
+    for a, b in ((d_g, d_g2), (d_c, d_c2), (d_lo, d_lo2), (d_hi, d_hi2), (d_pcm, d_pcm2), (d_db, d_db2)):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+
+
+@pytest.mark.parametrize("nf,n,fs", [(96, 32768, 1.024e6), (12, 32768, 2.4e6), (300, 8192, 2.4e6)])
+def test_frame_pipeline_at_the_reference_read_buffer_size(nf, n, fs):
+    """The main loop reads 32 768 samples per iteration by default (pyspecsdr.py:2236; 8 192 .. 1 048 576): the pipeline call at that
+    frame length against the separate entry points byte for byte, against the oracle on a few frames, with and without
+    materialised post-processed rows (small and large batches: both NFM kernel families)."""
+    e = G.engine()
+    W = 112
+    gen = torch.Generator(device="cuda").manual_seed(n + nf)
+    t = torch.arange(n, device="cuda", dtype=torch.float64) / fs
+    ph = 2 * np.pi * 4e3 * torch.cumsum(torch.sin(2 * np.pi * 700 * t).unsqueeze(0) * torch.linspace(0.2, 1.0, nf, device="cuda", dtype=torch.float64).unsqueeze(1), dim=1) / fs
+    iq = torch.stack([0.4 * torch.cos(ph), 0.4 * torch.sin(ph)], dim=-1).float() + 0.03 * torch.randn((nf, n, 2), generator=gen, device="cuda")
+    iq = iq.contiguous()
+    torch.cuda.synchronize()
+    n_out = e.demod_out_len(0, n, fs)
+    def bufs():
+        return dict(db=G.empty((nf, n), torch.float32), post=G.empty((nf, n - 4), torch.float32), lo=G.empty((nf,), torch.float32),
+                    hi=G.empty((nf,), torch.float32), g=G.empty((nf, W), torch.int8), c=G.empty((nf, W), torch.int8),
+                    pcm=G.empty((nf, n_out, 2), torch.int16))
+    a, b, c = bufs(), bufs(), bufs()
+    e.frame_pipeline_nfm(iq, nf, n, fs, a["db"], a["post"], a["lo"], a["hi"], W, a["g"], a["c"], a["pcm"])
+    e.spectrum_nfm(iq, nf, n, fs, b["db"], b["pcm"])
+    e.spectrum_post_extremes(b["db"], nf, n, b["post"], b["lo"], b["hi"])
+    e.waterfall_rows(b["post"], nf, n - 4, b["lo"], b["hi"], W, b["g"], b["c"])
+    e.frame_pipeline_nfm(iq, nf, n, fs, c["db"], None, c["lo"], c["hi"], W, c["g"], c["c"], c["pcm"])
+    e.sync()
+    for k in a:
+        assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, n, k)
+        if k != "post":
+            assert torch.equal(a[k].view(torch.uint8), c[k].view(torch.uint8)), (nf, n, k, "no materialised rows")
+    taps, sos, zi = e.nfm_filters(fs)
+    for k in (0, nf // 2, nf - 1):
+        h = iq[k].cpu().numpy().view(np.complex64).reshape(n)
+        assert np.array_equal(a["pcm"][k].cpu().numpy(), O.pcm16_stereo(O.demod_nfm(h, fs, taps, sos, zi))), (n, k)
+        ref = O.compute_fft(h)
+        assert np.all(np.abs(a["db"][k].cpu().numpy() - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0))
+
+
+@pytest.mark.parametrize("n", [256, 1024, 2048, 4096, 16384])
+def test_display_lines_without_materialised_rows(n):
+    """pss_spectrum_post_thresholds + pss_waterfall_rows_db / pss_persistence_rows_db (the post-processed rows are never written: 12 bytes
+    per row instead of 4 (n - 4)) against the materialised path, byte for byte — ties, a constant row, non-finite values, a halo."""
+    rng = np.random.default_rng(n)
+    nf, W, H = 75, 112, 36
+    db = (rng.standard_normal((nf, n)) * 6.0 - 35.0).astype(np.float32)
+    db[0, : n // 2] = np.round(db[0, : n // 2])
+    db[1] = -42.5
+    db[2, 100:140] += 50.0
+    db[3, 10:20] = np.inf
+    db[4, 30] = np.nan
+    e = G.engine()
+    d_db = G.dev(db)
+    halo = 7
+    lo, hi = G.empty((halo + nf,), torch.float32), G.empty((halo + nf,), torch.float32)
+    lo[:halo] = torch.tensor(rng.uniform(-60, -50, halo).astype(np.float32)); hi[:halo] = torch.tensor(rng.uniform(-20, -5, halo).astype(np.float32))
+    lo2, hi2 = lo.clone(), hi.clone()
+    d_post, d_thr = G.empty((nf, n - 4), torch.float32), G.empty((nf,), torch.float32)
+    e.spectrum_post_extremes(d_db, nf, n, d_post, lo[halo:], hi[halo:])
+    e.spectrum_post_thresholds(d_db, nf, n, d_thr, lo2[halo:], hi2[halo:])
+    e.sync()
+    assert torch.equal(lo.view(torch.int32), lo2.view(torch.int32)) and torch.equal(hi.view(torch.int32), hi2.view(torch.int32))
+    post, thr = G.host(d_post), G.host(d_thr)
+    for f in (0, 2, nf - 1):
+        sm = np.convolve(db[f].astype(np.float64), np.ones(5) / 5, mode="valid").astype(np.float32)
+        assert thr[f] == np.float32(np.median(sm).astype(np.float64) - 10.0) and thr[f] <= post[f].min(), (n, f)
+    out = [[G.empty((nf, W), torch.int8) for _ in range(3)] for _ in range(2)]
+    e.waterfall_rows(d_post, nf, n - 4, lo, hi, W, out[0][0], out[0][1], n_halo=halo, window=30)
+    e.persistence_rows(d_post, nf, n - 4, lo, hi, H, W, out[0][2], n_halo=halo, window=10)
+    e.waterfall_rows_db(d_db, nf, n, d_thr, lo2, hi2, W, out[1][0], out[1][1], n_halo=halo, window=30)
+    e.persistence_rows_db(d_db, nf, n, d_thr, lo2, hi2, H, W, out[1][2], n_halo=halo, window=10)
+    e.sync()
+    for k in range(3):
+        assert torch.equal(out[0][k], out[1][k]), (n, k)
