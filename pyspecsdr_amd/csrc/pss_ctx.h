@@ -14,7 +14,7 @@ struct PssNfmFilt {
     double taps[65];
     double sos[24];
     double zi[8];
-    double *d_rev = nullptr;   // device copy of the reversed taps (rev[j] = taps[64 - j], 65 doubles + padding): the fused NFM kernel's
+    double *d_rev = nullptr;   // device copy of the reversed taps (rev[j] = taps[64 - j], 65 doubles + 15 zeros): the fused NFM kernel's
                                // hand-scheduled FIR fetches its taps from here with scalar loads; made on first use, owned by the context
 };
 

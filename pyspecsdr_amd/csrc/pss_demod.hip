@@ -2106,7 +2106,7 @@ int nfm_filters(pss_ctx *ctx, double fs, PssNfmFilt **out)
 int nfm_dev_taps(pss_ctx *ctx, PssNfmFilt *f, const double **out)
 {
     if (!f->d_rev) {
-        double rev[72] = {0.0};
+        double rev[80] = {0.0};   // 65 taps + 15 zero slots (the left-edge dots read up to 14 elements past their last tap)
         for (int j = 0; j < 65; j++) rev[j] = f->taps[64 - j];
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&f->d_rev), sizeof(rev));
         if (e == hipSuccess) e = hipMemcpy(f->d_rev, rev, sizeof(rev), hipMemcpyHostToDevice);
@@ -2295,7 +2295,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
                 auto kf = b121 ? (swapped ? fused::k_nfm_fwd<true, true> : fused::k_nfm_fwd<true, false>)
                                : (swapped ? fused::k_nfm_fwd<false, true> : fused::k_nfm_fwd<false, false>);
                 hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, targ, d_rev);
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, d_rev);
             }
             pss_kernel_end(ctx);
             auto launch_bwd = [=]() -> int {

@@ -38,8 +38,7 @@ constexpr int NFW = 3;         // FIR worker waves (measured slower: 4 x 6 outpu
                                // 3-wave workgroups with 168 VGPRs each 0.88 vs 0.60 ms)
 constexpr int OPT = FC / NFW;  // FIR outputs per worker thread and chunk
 constexpr int WG = 64 * (1 + NFW);
-constexpr int HTAPS = 80;     // LDS copy of the reversed taps for the left-edge outputs: 65 taps + 15 zero slots (clamp-free tail loads)
-constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double) + HTAPS * sizeof(double) + 64 * sizeof(uint2);
+constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double) + 64 * sizeof(uint2);
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence that also waits for every
 // outstanding GLOBAL store of the wave (vmcnt(0)); the IIR wave has 24 y_fwd row stores in flight per chunk, and
@@ -191,18 +190,17 @@ __device__ __forceinline__ double ddot_head(const float *__restrict__ row, const
 
 // SWAPPED: operand order of the discriminator's complex product for frames of 32 769 samples and more (disc_sample); a template
 // parameter because as a run-time flag both orders were evaluated and selected per sample.
-// d_rev: the reversed taps in device memory (PssNfmFilt::d_rev): the FIR statement's scalar tap loads.
+// d_rev: the reversed taps in device memory (PssNfmFilt::d_rev; rev[j] = taps[64 - j], 15 zeros behind them): scalar tap loads of the
+// FIR statement and of the left-edge dots (output i pairs x[j] with rev[64 - i + j]).
 template <bool B121, bool SWAPPED = false>
 __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
                                                     double *__restrict__ Uh, double *__restrict__ Utl, int n,
-                                                    long n_frames, NfmCoef c, float kscale, TapsArg taps,
-                                                    const double *__restrict__ d_rev)
+                                                    long n_frames, NfmCoef c, float kscale, const double *__restrict__ d_rev)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
     double *ubuf = reinterpret_cast<double *>(smem + (size_t)TILE * WSTR * sizeof(float));  // [FC][TILE]
-    double *ltaps = ubuf + (size_t)TILE * FC;                                        // reversed taps (left-edge dots)
-    uint2 *ltab = reinterpret_cast<uint2 *>(ltaps + HTAPS);                          // the discriminator's reciprocal table (pss_device.h rcp14f)
+    uint2 *ltab = reinterpret_cast<uint2 *>(ubuf + (size_t)TILE * FC);                        // the discriminator's reciprocal table (pss_device.h rcp14f)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: everything indexed by the role / chunk stays scalar
     const long tile = blockIdx.x;
@@ -220,15 +218,52 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
     if (threadIdx.x == 0 && blockIdx.x < 4096) pss_dbg_stamps[4 * blockIdx.x] = wall_clock64();
 #endif
     if (tid >= 128 && tid < 192) ltab[tid - 128] = RCP14_AB[tid - 128];
-    if (tid < HTAPS) ltaps[tid] = tid < 65 ? taps.rev[tid] : 0.0;  // ltaps[m] = taps[64 - m]: output i pairs x[j] with ltaps[64 - i + j]
-    // ---- prologue: discriminator of times 0..87 into logical columns 8..95 (physical = logical at chunk 0)
-    for (int idx = tid; idx < TILE * WCOLS; idx += WG) {
-        const int fl = idx / WCOLS, l = idx % WCOLS, t = l - 8;
-        const long ff = tile * TILE + fl;
-        const float2 *x = iq + (size_t)(ff < n_frames ? ff : n_frames - 1) * n;
-        float d = 0.0f;
-        if (t >= 0 && t < M) d = disc_sample(x[t + 1], x[t], kscale, SWAPPED);
-        win[fl * WSTR + l] = d;
+    // ---- prologue: discriminator of times 0..87 into logical columns 8..95 (physical = logical at chunk 0).
+    // Thread (frame tid / 4, part tid % 4) fills the 24 columns 8 + 24 part .. of its frame: its 26 samples come as thirteen 16-byte
+    // buffer loads requested together, the discriminator values as three batches of eight interleaved branch-free chains, the
+    // columns leave as six 16-byte LDS stores.  (One sample per thread and pass — load, wait, evaluate, store, 24 times — took 25 us
+    // of the kernel's 520: every pass paid the full memory latency.)
+    {
+        typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+        const int fl = tid >> 2, part = tid & 3, t0 = 24 * part;
+        const long tfr = (n_frames - tile * TILE) < TILE ? (n_frames - tile * TILE) : TILE;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(iq + (size_t)tile * TILE * n), 0,
+                                                                             (int)(tfr * n * (long)sizeof(float2)), 0x00020000);
+        const int voff = (int)((fl < tfr ? fl : tfr - 1) * (long)n * (long)sizeof(float2)) + t0 * (int)sizeof(float2);
+        float2 x[26];
+        v4u_t raw[13];
+#pragma unroll
+        for (int g = 0; g < 13; g++) raw[g] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 16 * g, 0);   // all thirteen requests first
+        __syncthreads();      // the reciprocal table's LDS copy (a lookup in constant memory is a ~300-clock vector load in every chain)
+#pragma unroll
+        for (int g = 0; g < 13; g++) {
+            x[2 * g] = make_float2(__uint_as_float(raw[g].x), __uint_as_float(raw[g].y));
+            x[2 * g + 1] = make_float2(__uint_as_float(raw[g].z), __uint_as_float(raw[g].w));
+        }
+        float4 *dst = reinterpret_cast<float4 *>(win + fl * WSTR + 8 + t0);
+        if (part == 0) *reinterpret_cast<float4 *>(win + fl * WSTR) = make_float4(0.0f, 0.0f, 0.0f, 0.0f),
+                       *reinterpret_cast<float4 *>(win + fl * WSTR + 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // columns 0..7: times -8..-1
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            float d[8];
+            bool ok[8], allok = true;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                d[e] = disc_sample_main(x[8 * b + e + 1], x[8 * b + e], kscale, SWAPPED, ok[e], ltab);
+                allok = allok && ok[e];
+            }
+            if (__builtin_expect(!allok, 0)) {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    if (!ok[e]) d[e] = disc_sample(x[8 * b + e + 1], x[8 * b + e], kscale, SWAPPED, ltab);
+            }
+            if (t0 + 8 * b < WCOLS - 8) {      // part 3 owns only 16 columns (times 72..87)
+#pragma unroll
+                for (int e = 0; e < 8; e++) d[e] = (t0 + 8 * b + e < M) ? d[e] : 0.0f;
+                dst[2 * b] = make_float4(d[0], d[1], d[2], d[3]);
+                dst[2 * b + 1] = make_float4(d[4], d[5], d[6], d[7]);
+            }
+        }
     }
     __syncthreads();
 #ifdef PSS_UBENCH
@@ -241,7 +276,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
         const float *row0 = win + lane * WSTR + 8;  // time t of this lane's frame at row0[t] (chunk-0 layout)
 #pragma unroll 1
         for (int i = wave; i < HEAD; i += 1 + NFW) {
-            Uht[(size_t)i * TILE] = ddot_head(row0, ltaps + (64 - i), i + 1);
+            Uht[(size_t)i * TILE] = ddot_head(row0, d_rev + (64 - i), i + 1);   // taps by scalar loads (wave-uniform address)
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

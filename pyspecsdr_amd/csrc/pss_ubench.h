@@ -17,8 +17,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_ub_role(const float2 *__restric
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);
     double *ubuf = reinterpret_cast<double *>(smem + (size_t)TILE * WSTR * sizeof(float));
-    double *ltaps = ubuf + (size_t)TILE * FC;
-    uint2 *ltab = reinterpret_cast<uint2 *>(ltaps + HTAPS);
+    uint2 *ltab = reinterpret_cast<uint2 *>(ubuf + (size_t)TILE * FC);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long tile = blockIdx.x;
