@@ -77,6 +77,8 @@ struct pss_ctx {
     size_t scratch_fft_bytes = 0;
     void *stage = nullptr;         // device staging of the host-buffer convenience calls (grow-only)
     size_t stage_bytes = 0;
+    bool fft_two_per_wg = false;   // (-DPSS_VARIANTS builds) N = 2048 spectra with two frames per 256-thread workgroup (the round-2 shape)
+    int pipe_sched = 0;        // (-DPSS_VARIANTS builds) schedule experiments of pss_frame_pipeline_nfm
     bool no_wfm_fused = false;  // option "wfm_fused" = 0: k_wfm_front + k_nfm_iir path (A/B testing)
     long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~12000)
     long wfm_small_batch_max = 8192;  // option "wfm_small_batch_max" (measured crossover with the fused kernels ~12000 frames)

@@ -2999,6 +2999,39 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
         if (!q) q = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
         return q;
     };
+#ifdef PSS_VARIANTS   // schedule experiments (option "pipe_sched"; the default schedule is below)
+    if (ctx->pipe_sched && ctx->pending_bwd) {
+        auto bwd = ctx->pending_bwd;
+        ctx->pending_bwd = nullptr;
+        auto post_disp = [&]() -> int {
+            int q = d_thr ? pss_spectrum_post_thresholds(ctx, d_db, n_frames, n, d_thr, d_row_lo + n_halo, d_row_hi + n_halo)
+                          : pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+            if (!q) q = d_thr ? pss_waterfall_rows_db(ctx, d_db, n_frames, n, d_thr, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour)
+                              : pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+            return q;
+        };
+        if (ctx->pipe_sched == 4) {          // everything in order on one stream
+            r = bwd();
+            if (!r) r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+            if (!r) r = post_disp();
+        } else if (ctx->pipe_sched == 1) {   // forward -> spectrum -> { backward || post-process -> lines }
+            r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+            hipEventRecord(ctx->ev_fork, ctx->stream);
+            hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+            { PssStreamScope side(ctx->cur, ctx->stream2); if (!r) r = post_disp(); }
+            const int rb = bwd();
+            hipEventRecord(ctx->ev_join, ctx->stream2);
+            hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+            if (!r) r = rb;
+        } else if (ctx->pipe_sched == 6) {   // forward -> backward -> { spectrum -> post -> lines } nothing beside (same as 4 but bwd first) 
+            r = bwd();
+            if (!r) r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+            if (!r) r = post_disp();
+        }
+        pss_time_end(ctx);
+        return r;
+    }
+#endif
     if (ctx->pending_bwd) {
         auto bwd = ctx->pending_bwd;
         ctx->pending_bwd = nullptr;

@@ -607,19 +607,31 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
                          : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, false, false, true, true> : pss_r16::k_spectrum_r16<LOG_R3, false, false, false, true>)
                 : split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true, false>
                 : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, true> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, false>;
-    const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2) : C::LDS;
+    size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2) : C::LDS;
+    int fpw = C::FPW;
+    if constexpr (LOG_R3 == 3 && !SCAN) {
+        // N = 2048 (two wavefronts per frame): one frame per 128-thread workgroup
+        if (!split && !ctx->fft_two_per_wg) {
+            kern = exact ? (prefetch ? pss_r16::k_spectrum_r16<3, false, false, true, true, true> : pss_r16::k_spectrum_r16<3, false, false, false, true, true>)
+                         : (prefetch ? pss_r16::k_spectrum_r16<3, false, false, true, false, true> : pss_r16::k_spectrum_r16<3, false, false, false, false, true>);
+            fpw = 1;
+            lds = (size_t)C::EX * sizeof(double2) + (size_t)C::R3 * 16 * sizeof(double2);
+        }
+    }
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long groups = (n_frames + C::FPW - 1) / C::FPW;
+    const long groups = (n_frames + fpw - 1) / fpw;
+    const int wg_threads = fpw * C::T;
     int per_cu = (int)((160 * 1024) / (lds + 256));
-    if (per_cu > (split ? 4 : 2)) per_cu = split ? 4 : 2;  // 124 VGPRs: at most four 256-thread workgroups per CU
+    const int vgpr_cap = (split ? 4 : 2) * 256 / wg_threads;   // 124 / 240 VGPRs: at most four / two 256-thread workgroups' worth of wavefronts per CU
+    if (per_cu > vgpr_cap) per_cu = vgpr_cap;
     if (per_cu < 1) per_cu = 1;
     const long cap = 256L * per_cu * 2;
     const int grid = (int)(groups < cap ? groups : cap);
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_spectrum");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db, tw,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(wg_threads), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db, tw,
                        win, n_frames, d_peak, d_bw, d_count, bin_hz, spec_flags(ctx));
     pss_kernel_end(ctx);
     pss_time_end(ctx);

@@ -361,21 +361,26 @@ __device__ __forceinline__ void r16_core_split(double2 (&v)[16], double *ex, con
 
 // EXACT: dB rows by db_of_exact (compile-time: the float64 evaluation next to the float32 one in ONE kernel costs both of them
 // registers — measured 0.41 -> 0.45 ms for the default path at 131072 x 1024)
-template <int LOG_R3, bool SCAN, bool SPLIT = false, bool PREFETCH = false, bool EXACT = false>
+// ONE (frames of two or more wavefronts, i.e. N >= 2048): one frame per workgroup instead of 256 / T — the three exchange barriers of a
+// transform then hold up the frame's own wavefronts only, not the other frame's as well.
+template <int LOG_R3, bool SCAN, bool SPLIT = false, bool PREFETCH = false, bool EXACT = false, bool ONE = false>
 __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__ iq, float *__restrict__ db,
                                                       const double2 *__restrict__ tw, const double *__restrict__ win,
                                                       long n_frames, float *__restrict__ peak, double *__restrict__ bw,
                                                       int *__restrict__ count, double bin_hz, int flags)
 {
     using C = Cfg<LOG_R3>;
-    constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = C::FPW;
+    constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = ONE ? 1 : C::FPW;
+    static_assert(!ONE || (T >= 128 && !SCAN && !SPLIT), "one frame per workgroup: compute_fft rows of frames of >= 2 wavefronts");
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *ex_all = reinterpret_cast<double2 *>(smem);
     double2 *tw2 = SPLIT ? reinterpret_cast<double2 *>(smem + (size_t)FPW * C::EX * sizeof(double))
                          : ex_all + (size_t)FPW * C::EX;  // W_T^(m1*j2), [m1][j2]
     __shared__ float red_f[4];
     __shared__ int red_i[4];
+    __shared__ uint4 l10[SCAN ? 16 : 1];       // the float32 log10 model's coefficient sets (pss_npf32.h): LDS copy for the scanner's exact rows
     const int tid = threadIdx.x;
+    if (SCAN && tid < 16) l10[tid] = pss::L10_PACK[tid];
     const int fl = tid / T;   // frame slot inside the workgroup
     const int t = tid % T;    // thread inside the frame: n1 in stage 1, (k2, m1) in stage 2, rho in stage 3
     double2 *ex = ex_all + (size_t)fl * C::EX;
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
         auto emit = [&](int i, int k, double2 X) {
             // compute_fft: float64 all the way, dB rounded to float32; scanner slice: NumPy's complex64 spectrum + float32 chain
             float d;
-            if constexpr (SCAN) d = (flags & FLAG_SCAN_EXACT) ? pss::scan_db_np(X.x, X.y) : db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
+            if constexpr (SCAN) d = (flags & FLAG_SCAN_EXACT) ? pss::scan_db_np(X.x, X.y, l10) : db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
             else d = EXACT ? db_of_exact(X.x * X.x + X.y * X.y + 1e-10) : db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
             if (out) out[(k + N / 2) & (N - 1)] = d;  // fftshift; T consecutive bins per store instruction
             dbv[i] = d;

@@ -179,8 +179,11 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ float red_f[16];
     __shared__ int red_i[16];
+    __shared__ uint4 l10[SCAN ? 16 : 1];       // the float32 log10 model's coefficient sets (pss_npf32.h): LDS copy for the scanner's exact rows
     double *ex = reinterpret_cast<double *>(smem);
     const int t = threadIdx.x;
+    if (SCAN && t < 16) l10[t] = pss::L10_PACK[t];
+    if (SCAN) __syncthreads();
     const double2 w1 = tw[t];                                  // W_N^t
     const double2 w2 = tw[(size_t)(t % T2) * 16];              // W_T^b = W_N^(16 b)
     const double2 w3 = tw[(size_t)(t % R4) * 256];             // W_T2^c = W_N^(256 c)
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *
         xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int i, int j, int k, double2 X) {
             // fftshift; bin 4096 k + T j + t: T consecutive bins per store instruction
             float d;
-            if constexpr (SCAN) d = (flags & pss_r16::FLAG_SCAN_EXACT) ? pss::scan_db_np(X.x, X.y) : pss_r16::db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
+            if constexpr (SCAN) d = (flags & pss_r16::FLAG_SCAN_EXACT) ? pss::scan_db_np(X.x, X.y, l10) : pss_r16::db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
             else d = EXACT ? pss_r16::db_of_exact(X.x * X.x + X.y * X.y + 1e-10) : pss_r16::db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
             buf_store_f32(ro, t * 4, ((4096 * k + T * j + N / 2) & (N - 1)) * 4, d);
             if (SCAN) { held[i * T + t] = d; lmax = fmaxf(lmax, d); }

@@ -89,7 +89,9 @@ static __constant__ uint4 L10_PACK[16] = {
     {0xbe20ffffu, 0x3e0b7033u, 0xbe5f0570u, 0x3ede597fu}, {0xbe103a0bu, 0x3e102c90u, 0xbe5e92d0u, 0x3ede5b50u},
     {0xbe01a91cu, 0x3e12ebadu, 0xbe5e662bu, 0x3ede5bcau}, {0xbde9e84eu, 0x3e141ff8u, 0xbe5e5c08u, 0x3ede5bd9u}};
 
-__device__ __forceinline__ float scan_db_np(double re, double im)
+// tab: L10_PACK itself (constant memory: every lookup a vector load in the middle of the bin's dependent chain) or a copy the kernel
+// keeps in LDS (the scanner kernels: 16 entries)
+__device__ __forceinline__ float scan_db_np(double re, double im, const uint4 *tab = L10_PACK)
 {
 #pragma clang fp contract(off)
     // np.abs(complex64): cabsf_np without its early return (a select instead: the scanner evaluates this for every bin)
@@ -106,7 +108,7 @@ __device__ __forceinline__ float scan_db_np(double re, double im)
     const bool up = man >= 0x400000u;
     const uint32_t mb = (up ? (126u << 23) : (127u << 23)) | man;
     const int k = (int)(b >> 23) - 127 + (up ? 1 : 0);
-    const uint4 c = L10_PACK[(mb >> 19) & 15u];
+    const uint4 c = tab[(mb >> 19) & 15u];
     const float q = u2f(mb) - 1.0f;
     float t = __fmaf_rn(u2f(c.x), q, u2f(c.y));
     t = __fmaf_rn(t, q, u2f(c.z));
