@@ -2913,6 +2913,14 @@ extern "C" int pss_get_wfm_filters(pss_ctx *ctx, double fs, double *lp3x6, doubl
     return PSS_OK;
 }
 
+#ifdef PSS_VARIANTS
+__global__ void k_spin(long ticks)     // ~10 ns per tick of the 100 MHz counter
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
+}
+#endif
+
 extern "C" int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db,
                                 int16_t *d_pcm)
 {
@@ -2978,6 +2986,30 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
     // stream from the start (-5 % when the forward kernel reaches the dispatcher first, +8 % when it does not); the two streams on
     // disjoint CU masks (hipExtStreamCreateWithCUMask, 128..240 of 256 CUs for the forward kernel: +5 % at best — both halves of the
     // step scale with the CUs they get); the spectrum kernel handing discriminator rows to the forward kernel (+2 %).
+#ifdef PSS_VARIANTS
+    if (ctx->pipe_sched == 3 || ctx->pipe_sched == 5) {
+        // the display chain on the side stream FROM THE START of the step, but a few microseconds behind the forward kernel (a spin kernel),
+        // so that the forward kernel's workgroups are all resident before the chain's ask for room; the chain then fills the CUs as the
+        // forward kernel's workgroups retire (0.36 .. 0.55 ms after the launch).  sched 5: the spin only, no chain overlap control.
+        hipEventRecord(ctx->ev_fork, ctx->stream);
+        hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+        int rq;
+        {
+            PssStreamScope side(ctx->cur, ctx->stream2);
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, ctx->stream2, (long)(ctx->pipe_sched == 3 ? 2000 : 200));
+            rq = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+            if (!rq) rq = d_thr ? pss_spectrum_post_thresholds(ctx, d_db, n_frames, n, d_thr, d_row_lo + n_halo, d_row_hi + n_halo)
+                                : pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+            if (!rq) rq = d_thr ? pss_waterfall_rows_db(ctx, d_db, n_frames, n, d_thr, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour)
+                                : pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+        }
+        const int rn = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
+        hipEventRecord(ctx->ev_join, ctx->stream2);
+        hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+        pss_time_end(ctx);
+        return rn ? rn : rq;
+    }
+#endif
     int r2;
     ctx->pending_bwd = nullptr;
     {

@@ -80,6 +80,30 @@ if os.path.exists(p):
     if os.path.exists(lg):
         lines += [l.rstrip() for l in open(lg) if l.startswith("alone:")]
 
+# register / LDS use from the code object (tools/kernel_resources.py -> profiles/kernel_resources.json), NOT from the profiler's dispatch
+# record: rocprofv3's VGPR_Count / LDS_Block_Size columns were wrong for these kernels (round 2: 64 / 0 reported for k_nfm_fwd)
+res_by_short = collections.defaultdict(list)
+try:
+    kr = json.load(open(os.path.join(ROOT, "profiles", "kernel_resources.json")))
+    if kr.get("src_hash") == source_hash():
+        for full, k in kr["kernels"].items():
+            res_by_short[k["short"]].append(k)
+    else:
+        lines.append(f"== profiles/kernel_resources.json is from source {kr.get('src_hash')}: rerun tools/kernel_resources.py")
+except Exception:  # noqa: BLE001
+    pass
+
+
+def code_object(n):
+    ks = res_by_short.get(n)
+    if not ks:
+        return {}
+    v = [k["vgpr"] for k in ks]
+    return {"vgpr_code_object": max(v) if min(v) == max(v) else [min(v), max(v)], "vgpr_spill": max(k["vgpr_spill"] for k in ks),
+            "sgpr_spill": max(k["sgpr_spill"] for k in ks), "lds_static_bytes": max(k["lds_static"] for k in ks),
+            "scratch_bytes": max(k["scratch"] for k in ks), "instantiations": len(ks)}
+
+
 digest = {"src_hash": source_hash(), "git": git_head(), "n_frames": N_FRAMES,
           "profile": f"profiles/{tag}_summary.txt (tools/prof_round.sh {tag})", "kernels": {}}
 meta = {}
@@ -93,8 +117,7 @@ for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         n = kname(r["Kernel_Name"])
         if n and r["Counter_Name"] == ctr:
             acc[(n, int(float(r["Grid_Size"])))].append(float(r["Counter_Value"]))
-            meta[n] = {"vgpr": r.get("VGPR_Count"), "accum_vgpr": r.get("Accum_VGPR_Count"), "lds_bytes": r.get("LDS_Block_Size"),
-                       "workgroup": r.get("Workgroup_Size")}
+            meta[n] = {"workgroup": r.get("Workgroup_Size"), "lds_bytes_dispatch": r.get("LDS_Block_Size"), **code_object(n)}
     lines.append(f"== rocprofv3 --pmc {ctr} (KiB per dispatch, by launch shape; gfx950: FETCH_SIZE under-reports wide coalesced "
                  f"reads by 2x — MI355X_MICROARCH.md §HBM)")
     best = {}
@@ -138,7 +161,7 @@ sq_lines = [f"== SQ counters per launch (mean over dispatches), python bench.py 
 seen = {}
 for (n, g), d in sorted(sq.items()):
     v = {k: sum(x) / len(x) for k, x in d.items()}
-    sq_lines.append(f"{n} grid={g} vgpr={meta.get(n, {}).get('vgpr')} lds={meta.get(n, {}).get('lds_bytes')}")
+    sq_lines.append(f"{n} grid={g} vgpr(code object)={meta.get(n, {}).get('vgpr_code_object')} static lds={meta.get(n, {}).get('lds_static_bytes')}")
     wc = v.get("SQ_WAVE_CYCLES", 0)
     for k in sorted(v):
         extra = f"  ({v[k] / wc:.3f} of wave cycles)" if wc and k.startswith(("SQ_WAIT", "SQ_ACTIVE")) else ""
