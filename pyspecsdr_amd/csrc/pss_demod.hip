@@ -2277,7 +2277,9 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         // a handful of long frames (the interactive loop: one 32768-sample buffer per call) cannot fill lane-per-frame
         // wavefronts: below this many frames the decimator runs as a 4-lane systolic array per frame instead
         const bool small_batch = !ctx->no_small_batch && n_frames <= ctx->small_batch_max;
-        if (n - 1 >= 128 && !ctx->no_fused && !small_batch) {
+        // (the fused kernels exist for decimator sections 1..3 with numerator exactly [1, 2, 1] — every cheby1 low-pass SOS; injected
+        // tables of another shape take the three-kernel path)
+        if (n - 1 >= 128 && !ctx->no_fused && !small_batch && b121) {
             // fused path: u[] stays on chip; small L2-resident scratch for the irregular head / tail of u
             const size_t szH = align256((size_t)tiles * fused::HEAD * TILE * sizeof(double));
             const size_t szT = align256((size_t)tiles * (EDGE + 1) * TILE * sizeof(double));
@@ -2292,20 +2294,15 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             pss_time_begin(ctx);
             pss_kernel_begin(ctx, "k_nfm_fwd");
             {
-                auto kf = b121 ? (swapped ? fused::k_nfm_fwd<true, true> : fused::k_nfm_fwd<true, false>)
-                               : (swapped ? fused::k_nfm_fwd<false, true> : fused::k_nfm_fwd<false, false>);
+                auto kf = swapped ? fused::k_nfm_fwd<true, true> : fused::k_nfm_fwd<true, false>;
                 hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
                                    reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, d_rev);
             }
             pss_kernel_end(ctx);
             auto launch_bwd = [=]() -> int {
                 pss_kernel_begin(ctx, "k_nfm_bwd");
-                if (b121)
-                    hipLaunchKernelGGL(fused::k_nfm_bwd<true>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af, n, q,
-                                       n_out, n_frames, c, d_pcm, d_audio);
-                else
-                    hipLaunchKernelGGL(fused::k_nfm_bwd<false>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af, n, q,
-                                       n_out, n_frames, c, d_pcm, d_audio);
+                hipLaunchKernelGGL(fused::k_nfm_bwd<true>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af, n, q,
+                                   n_out, n_frames, c, d_pcm, d_audio);
                 pss_kernel_end(ctx);
                 return pss_hip_check(ctx, hipGetLastError(), "k_nfm_bwd launch");
             };
@@ -2495,7 +2492,10 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const size_t szY = align256((size_t)T2 * L * TILE * sizeof(double));
         const size_t szA = align256((size_t)T2 * n_out * TILE * sizeof(double));
         const size_t szM = align256((size_t)T2 * TILE * sizeof(double));
-        r = pss_ensure_scratch(ctx, (ctx->no_wfm_fused ? szU : 0) + szY + szA + szM);
+        bool b121_dec = true;  // decimator sections 1..3 with numerator exactly [1, 2, 1]: the fused kernels' shape
+        for (int s1 = 1; s1 < 4; s1++)
+            b121_dec = b121_dec && flt->sos[6 * s1] == 1.0 && flt->sos[6 * s1 + 1] == 2.0 && flt->sos[6 * s1 + 2] == 1.0;
+        r = pss_ensure_scratch(ctx, ((ctx->no_wfm_fused || !b121_dec) ? szU : 0) + szY + szA + szM);
         if (r) return r;
         char *base = reinterpret_cast<char *>(ctx->scratch);
         double *U = reinterpret_cast<double *>(base), *Y = reinterpret_cast<double *>(base + szU);
@@ -2568,23 +2568,18 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             pss_time_end(ctx);
             return pss_hip_check(ctx, hipGetLastError(), "wfm small-batch launch");
         }
-        if (!ctx->no_wfm_fused) {
-            // fused path: forward decimator pass inside the front kernel, y_fwd planar-transposed, u[] never stored
+        if (!ctx->no_wfm_fused && b121) {
+            // fused path (decimator sections 1..3 with numerator [1, 2, 1]): forward decimator pass inside the front kernel, y_fwd planar-transposed, u[] never stored
             double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);
             double *MXf = reinterpret_cast<double *>(base + szY + szA);
-            auto kf = spec ? (b121 ? wfmf::k_wfm_fwd<true, true> : wfmf::k_wfm_fwd<true, false>)
-                           : (b121 ? wfmf::k_wfm_fwd<false, true> : wfmf::k_wfm_fwd<false, false>);
+            auto kf = spec ? wfmf::k_wfm_fwd<true, true> : wfmf::k_wfm_fwd<false, true>;
             pss_kernel_begin(ctx, "k_wfm_fwd");
             hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(TILE), wfmf::LDS_BYTES, PSS_STREAM(ctx),
                                reinterpret_cast<const float2 *>(d_iq), Yf, n, n_frames, swapped, wc, c);
             pss_kernel_end(ctx);
             pss_kernel_begin(ctx, "k_nfm_bwd");
-            if (b121)
-                hipLaunchKernelGGL((fused::k_nfm_bwd<true, true>), dim3((unsigned)(2 * tiles)), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af,
-                                   n, q, n_out, 2 * tiles * TILE, c, nullptr, MXf);
-            else
-                hipLaunchKernelGGL((fused::k_nfm_bwd<false, true>), dim3((unsigned)(2 * tiles)), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af,
-                                   n, q, n_out, 2 * tiles * TILE, c, nullptr, MXf);
+            hipLaunchKernelGGL((fused::k_nfm_bwd<true, true>), dim3((unsigned)(2 * tiles)), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af,
+                               n, q, n_out, 2 * tiles * TILE, c, nullptr, MXf);
             pss_kernel_end(ctx);
             size_t tot = (size_t)n_frames * n_out;
             size_t g2 = (tot + TPB - 1) / TPB;

@@ -597,18 +597,19 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     using C = pss_r16::Cfg<LOG_R3>;
     // component-wise LDS exchanges (half the LDS, twice the barriers) pay only at N = 256, where the plain kernel fits a
     // single 80 KB workgroup per CU: 0.29 -> 0.20 ms for 262144 frames; at 512...2048 they measured 20 % slower
-    const bool split = ctx->fft_split >= 0 ? ctx->fft_split != 0 : LOG_R3 == 0;
-    // next-frame prefetch (option "fft_prefetch", -1 = automatic), A/B in one process: N = 1024: 0.198 -> 0.185 ms (65536 frames),
-    // 2048: 0.234 -> 0.226 ms; 512: no change; 4096: 0.27 -> 0.35 ms (274 VGPRs: one wavefront per SIMD); 256: the split kernel wins
-    const bool prefetch = !split && (ctx->fft_prefetch >= 0 ? ctx->fft_prefetch != 0 : (LOG_R3 == 2 || LOG_R3 == 3));
-    // "db_exact" (compute_fft rows only): its own instantiations of the same three variants (244 VGPRs with the prefetch: no spill)
+    // next-frame prefetch, A/B in one process: N = 1024: 0.198 -> 0.185 ms (65536 frames), 2048: 0.234 -> 0.226 ms; 512: no change;
+    // 4096: 0.27 -> 0.35 ms (274 VGPRs: one wavefront per SIMD); 256: the split kernel wins
+    // "db_exact" (compute_fft rows only): its own instantiations (244 VGPRs with the prefetch: no spill)
     const bool exact = !SCAN && ctx->db_exact;
+    int fpw = C::FPW;
+#ifdef PSS_VARIANTS   // every combination, steered by the options "fft_split" / "fft_prefetch" / "fft_two_per_wg" (A/B builds)
+    const bool split = ctx->fft_split >= 0 ? ctx->fft_split != 0 : LOG_R3 == 0;
+    const bool prefetch = !split && (ctx->fft_prefetch >= 0 ? ctx->fft_prefetch != 0 : (LOG_R3 == 2 || LOG_R3 == 3));
     auto kern = exact ? (split ? pss_r16::k_spectrum_r16<LOG_R3, false, true, false, true>
                          : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, false, false, true, true> : pss_r16::k_spectrum_r16<LOG_R3, false, false, false, true>)
                 : split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true, false>
                 : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, true> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, false>;
     size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2) : C::LDS;
-    int fpw = C::FPW;
     if constexpr (LOG_R3 == 3 && !SCAN) {
         // N = 2048 (two wavefronts per frame): one frame per 128-thread workgroup
         if (!split && !ctx->fft_two_per_wg) {
@@ -618,6 +619,13 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
             lds = (size_t)C::EX * sizeof(double2) + (size_t)C::R3 * 16 * sizeof(double2);
         }
     }
+#else                 // the product library carries the measured winner per length only (12 instantiations instead of 49)
+    constexpr bool split = LOG_R3 == 0, prefetch = LOG_R3 == 2 || LOG_R3 == 3, one = LOG_R3 == 3 && !SCAN;
+    auto kern = exact ? pss_r16::k_spectrum_r16<LOG_R3, false, split, prefetch, true, one> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, split, prefetch, false, one>;
+    if (one) fpw = 1;
+    const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2)
+                             : (size_t)fpw * C::EX * sizeof(double2) + (size_t)C::R3 * 16 * sizeof(double2);
+#endif
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -661,7 +669,9 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     case 4096:
         // default: the component-wise-exchange kernel below (128 VGPRs, 35 KB LDS: four workgroups per CU; 3.3 against 2.4-2.7 TB/s);
         // "fft_xl4096" = 0 or "fft_big_scratch" = 1: the three-stage kernel with complex exchanges (two workgroups per CU)
+#ifdef PSS_VARIANTS
         if (!ctx->fft_xl4096 || ctx->fft_big_scratch) return launch_r16<4, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
+#endif
         break;
     default: break;
     }
