@@ -190,6 +190,7 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "scan_exact")) { ctx->scan_exact = value != 0; return PSS_OK; }
     if (!strcmp(key, "db_exact")) { ctx->db_exact = value != 0; return PSS_OK; }
 #ifdef PSS_VARIANTS   // kernel-selection knobs for A/B measurements: variant builds only (tools/build_variant.py <name> -DPSS_VARIANTS)
+    if (!strcmp(key, "ssb_unfused")) { ctx->ssb_unfused = value != 0; return PSS_OK; }
     if (!strcmp(key, "fft_two_per_wg")) { ctx->fft_two_per_wg = value != 0; return PSS_OK; }
     if (!strcmp(key, "pipe_sched")) { ctx->pipe_sched = value; return PSS_OK; }
     if (!strcmp(key, "fft_split")) { ctx->fft_split = value; return PSS_OK; }

@@ -77,6 +77,7 @@ struct pss_ctx {
     size_t scratch_fft_bytes = 0;
     void *stage = nullptr;         // device staging of the host-buffer convenience calls (grow-only)
     size_t stage_bytes = 0;
+    bool ssb_unfused = false;      // (-DPSS_VARIANTS builds) demodulate_ssb at 8192 / 16384 samples as k_ssb_fir + k_hilbert_xl (the round-2 shape)
     bool fft_two_per_wg = false;   // (-DPSS_VARIANTS builds) N = 2048 spectra with two frames per 256-thread workgroup (the round-2 shape)
     int pipe_sched = 0;        // (-DPSS_VARIANTS builds) schedule experiments of pss_frame_pipeline_nfm
     bool no_wfm_fused = false;  // option "wfm_fused" = 0: k_wfm_front + k_nfm_iir path (A/B testing)
@@ -159,3 +160,5 @@ bool pss_hilbert_supported(int n);
 int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits,
                      int16_t *d_pcm);
 int pss_fft_tables(pss_ctx *ctx, int n, const double2 **tw, const double **win);
+bool pss_ssb_fused_supported(int n);
+int pss_ssb_hilbert_fused(pss_ctx *ctx, const float *d_iq, long n_rows, int n, const double *taps65, double *d_audio, int16_t *d_pcm);

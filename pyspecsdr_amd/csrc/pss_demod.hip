@@ -2432,6 +2432,13 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const TapsArg targ = make_taps(taps);
         pss_time_begin(ctx);
         PSS_HIP(ctx, hipMemsetAsync(mxb, 0, (size_t)n_frames * sizeof(double), PSS_STREAM(ctx)));
+        if (ctx->ssb_hilbert && pss_ssb_fused_supported(n) && !ctx->ssb_unfused) {
+            // frames of 8192 / 16 384 samples: FIR, hilbert() round trip, normalisation and PCM in ONE kernel (no float64 round trip of
+            // the FIR output through HBM)
+            r = pss_ssb_hilbert_fused(ctx, d_iq, n_frames, n, taps, d_audio, d_pcm);
+            pss_time_end(ctx);
+            return r ? r : pss_hip_check(ctx, hipGetLastError(), "ssb launch");
+        }
         const int cpf = (n + 1023) / 1024;
         long total = n_frames * cpf;
         long g = total < 16384 ? total : 16384;

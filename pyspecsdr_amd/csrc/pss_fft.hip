@@ -1163,6 +1163,30 @@ int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double
 #undef HIL_R16
 }
 
+// demodulate_ssb for frames of 8192 / 16 384 samples in one kernel (pss_hilbert.h k_ssb_hilbert_xl): FIR (real part, zdot order) +
+// hilbert() round trip + normalisation + PCM.  taps65: firwin's taps[0..64].
+bool pss_ssb_fused_supported(int n) { return n == 8192 || n == 16384; }
+int pss_ssb_hilbert_fused(pss_ctx *ctx, const float *d_iq, long n_rows, int n, const double *taps65, double *d_audio, int16_t *d_pcm)
+{
+    if (!pss_ssb_fused_supported(n)) return pss_fail(ctx, PSS_E_ARG, "fused SSB: frames of 8192 or 16384 samples");
+    if (n_rows == 0) return PSS_OK;
+    const double2 *tw;
+    const double *win;
+    int r = pss_fft_tables(ctx, n, &tw, &win);
+    if (r) return r;
+    pss_hil::SsbTaps tp;
+    for (int j = 0; j < 72; j++) { tp.rev[j] = j < 65 ? taps65[64 - j] : 0.0; tp.fwd[j] = j < 65 ? taps65[j] : 0.0; }
+    auto go = [&](auto kern, size_t lds, int threads, long cap) -> int {
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        pss_kernel_begin(ctx, "k_ssb_hilbert");
+        hipLaunchKernelGGL(kern, dim3((unsigned)(n_rows < cap ? n_rows : cap)), dim3(threads), lds, PSS_STREAM(ctx),
+                           reinterpret_cast<const float2 *>(d_iq), d_audio, tw, n_rows, reinterpret_cast<unsigned *>(d_pcm), tp);
+        pss_kernel_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "k_ssb_hilbert launch");
+    };
+    return n == 8192 ? go(pss_hil::k_ssb_hilbert_xl<1>, pss_xl::CfgX<1>::LDS, 512, 512) : go(pss_hil::k_ssb_hilbert_xl<2>, pss_xl::CfgX<2>::LDS, 1024, 256);
+}
+
 extern "C" int pss_hilbert(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_analytic)
 {
     if (!ctx) return PSS_E_ARG;

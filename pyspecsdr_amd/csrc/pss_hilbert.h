@@ -192,4 +192,141 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_hilbert_xl(const double *x
     }
 }
 
+// ---- demodulate_ssb in ONE kernel for frames of 8192 / 16 384 samples (round 3) ---------------------------------------------------
+// signal_processing.py:203-216: z = lfilter(taps, 1, x) (complex 65-tap FIR: scipy -> np.convolve -> cblas_zdotu, of which only the
+// real part survives :205), hilbert(real(z)), its real part, / max|.| * 0.95, int16.  k_ssb_fir used to write real(z) as float64
+// (1.07 GB at cfg 3) for k_hilbert_xl to read straight back; here the FIR runs inside the transform kernel:
+//   1. the frame's I samples (taps and window are real: Q never reaches the real part) are staged as float64 in the exchange buffer,
+//      element i at i + i / 16 (rows of 16 + one pad: a thread's window of consecutive elements is conflict-free at a lane stride of 17);
+//   2. thread t computes its 16 CONSECUTIVE outputs 16 t .. 16 t + 15, two at a time, in the accumulation order of OpenBLAS's
+//      zdot_microk_haswell (8 accumulators (a, p) per output over 8 steps of 8 elements: element j = 8 it + 2 a + p; the pairs
+//      (acc[0] + acc[1]) + (acc[2] + acc[3]) per p; c0 + c1; fma(x[i], tap[0], .)) — k_ssb_fir's tree bit for bit — with the taps as
+//      scalar operands (kernarg) and a sliding window of 9 inputs per step; the 64 outputs whose windows are shorter than 65 taps
+//      (their own zdot shapes) by the lanes of wavefront 0 with the predicated per-lane tree (zdot_re_skx_lane, as k_ssb_edge);
+//   3. the outputs go back into the (now free) staging area and are re-read in the transform's input layout x[t + T q].
+// From there on k_hilbert_xl<LOG_R4, 2>: forward transform, one-sided mask, inverse transform, frame peak, normalisation, PCM.
+struct SsbTaps {
+    double rev[72];   // rev[j] = taps[64 - j] (65 taps, zeros behind them)
+    double fwd[72];   // taps[j]
+};
+
+__device__ __forceinline__ int pad17(int i) { return i + (i >> 4); }
+
+template <int LOG_R4>
+__global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_hilbert_xl(const float2 *__restrict__ iq, double *out, const double2 *__restrict__ tw,
+                                                                     long n_rows, unsigned *__restrict__ pcm, SsbTaps taps)
+{
+    __shared__ double red[2][16];
+    __shared__ double ltaps[72];
+    using C = pss_xl::CfgX<LOG_R4>;
+    constexpr int T = C::T, N = C::N, T2 = C::T2, R4 = C::R4;
+    static_assert(N + N / 16 <= C::EXD, "the padded staging area must fit the exchange buffer");
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *ex = reinterpret_cast<double *>(smem);
+    const int t = threadIdx.x;
+    const double2 w1 = tw[t], w2 = tw[(size_t)(t % T2) * 16], w3 = tw[(size_t)(t % R4) * 256];
+    if (t < 72) ltaps[t] = taps.fwd[t];
+    constexpr double INV_N = 1.0 / (double)N;
+    for (long f = blockIdx.x; f < n_rows; f += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t rx = pss_xl::make_rsrc(iq + (size_t)f * N, N * 8);
+        const __amdgpu_buffer_rsrc_t ro = pss_xl::make_rsrc(out + (out ? (size_t)f * N : 0), out ? N * 8 : 0);
+        const __amdgpu_buffer_rsrc_t rp = pss_xl::make_rsrc(pcm + (pcm ? (size_t)f * N : 0), pcm ? N * 4 : 0);
+        // (tt: the thread index behind an opaque statement per frame — with the plain index the compiler computes the ~200 per-lane LDS
+        // addresses of the staging accesses, the windows and the edge tree once, ahead of the frame loop, and spills them: 196 VGPRs)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        // element t + T q of the frame sits at pad17(t) + q (T + T / 16): one lane address, the rest immediate offsets
+        double *sb = ex + pad17(tt);
+        constexpr int QS = T + T / 16;
+        // 1. stage the in-phase samples
+        __syncthreads();                          // the previous frame's last exchange is done with the buffer
+#pragma unroll
+        for (int q = 0; q < 16; q++) sb[q * QS] = (double)pss_xl::buf_load_f2(rx, tt * 8, T * q * 8).x;
+        __syncthreads();
+        // 2. the FIR: outputs 16 t + c, c = 0..15 (threads 0..3 own the left edge: wavefront 0's lanes compute it below)
+        double o16[16];
+        if (t >= 4) {
+            const double *xw = ex + 17 * (tt - 4);   // x[16 t - 64 + e] at xw[e + (e >> 4)]
+            // four outputs per pass (c = 4 g .. 4 g + 3), a ROLLED loop (unrolled, the scheduler interleaved the passes and spilled 194
+            // VGPRs).  The FIR is LDS-bandwidth-bound: B outputs per pass read (16 / B) 8 (B + 7) window elements per thread — 576 at
+            // B = 2 (measured: the fused kernel no faster than k_ssb_fir + k_hilbert_xl), 352 at B = 4 (32 accumulators: the register
+            // budget's limit beside the 16 finished outputs).  o16[] stays in registers without run-time indexing: every finished output
+            // shifts it down by one and takes the last slot.
+#pragma unroll 1
+            for (int g = 0; g < 4; g++) {
+                int z = 0;
+                asm volatile("" : "+s"(z));         // opaque zero: the taps are re-read per pass, not hoisted into 130 loop-invariant SGPRs
+                double acc[4][4][2];
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    double xs[11];
+#pragma unroll
+                    for (int e = 0; e < 11; e++) { const int k = 4 * g + 8 * it + e; xs[e] = xw[k + (k >> 4)]; }
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int pp = 0; pp < 2; pp++) {
+                            const double y = taps.rev[z + 8 * it + 2 * a + pp];
+#pragma unroll
+                            for (int o = 0; o < 4; o++)
+                                acc[o][a][pp] = __fma_rn(xs[o + 2 * a + pp], y, it == 0 ? 0.0 : acc[o][a][pp]);
+                        }
+                }
+                const int k64 = 4 * g + 64;
+                const double y64 = taps.rev[z + 64];
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    const double c0 = __dadd_rn(__dadd_rn(acc[o][0][0], acc[o][1][0]), __dadd_rn(acc[o][2][0], acc[o][3][0]));
+                    const double c1 = __dadd_rn(__dadd_rn(acc[o][0][1], acc[o][1][1]), __dadd_rn(acc[o][2][1], acc[o][3][1]));
+                    const int k = k64 + o;
+                    const double r = __fma_rn(xw[k + (k >> 4)], y64, __dadd_rn(c0, c1));
+#pragma unroll
+                    for (int c = 0; c < 15; c++) o16[c] = o16[c + 1];      // after sixteen shifts o16[c] = output 16 t + c
+                    o16[15] = r;
+                }
+            }
+        }
+        double edge = 0.0;
+        if (t < 64) edge = pss::zdot_re_skx_lane([&](int j) { return ex[pad17(j)]; }, [&](int j) { return ltaps[tt - j]; }, tt + 1);   // (tt: the tree's predicates stay inside the loop)
+        __syncthreads();                          // every window has been read: the staging area takes the outputs
+        if (t >= 4) {
+#pragma unroll
+            for (int c = 0; c < 16; c++) ex[17 * tt + c] = o16[c];      // pad17(16 t + c) = 17 t + c
+        }
+        if (t < 64) sb[0] = edge;
+        __syncthreads();
+        double2 u1 = w1, u2 = w2, u3 = w3;
+        asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
+        double2 v[16], y[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = make_double2(sb[q * QS], 0.0);
+        __syncthreads();                          // ... before the first exchange writes into the buffer
+        pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int, int j, int k, double2 X) { y[j + (16 / R4) * k] = X; });
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = mask_conj(y[q], q, t);
+        asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
+        double m = 0.0;
+        pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int, int j, int k, double2 W) {
+            const int q = j + (16 / R4) * k;
+            const double re = W.x * INV_N;
+            y[q].x = re;
+            m = nanmax(m, fabs(re));
+        });
+        for (int off = 32; off > 0; off >>= 1) m = nanmax(m, __shfl_xor(m, off));
+        const int par = (int)(((f - blockIdx.x) / gridDim.x) & 1);
+        if ((t & 63) == 0) red[par][t >> 6] = m;
+        __syncthreads();
+        m = red[par][0];
+#pragma unroll
+        for (int w = 1; w < T / 64; w++) m = nanmax(m, red[par][w]);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const double a = normalise95(y[q].x, m);
+            pss_xl::v2u_t pk = {(unsigned)__double2loint(a), (unsigned)__double2hiint(a)};
+            __builtin_amdgcn_raw_buffer_store_b64(pk, ro, t * 8, T * q * 8, 0);       // out == NULL: zero-sized resource, dropped
+            __builtin_amdgcn_raw_buffer_store_b32(pcm_pair(a), rp, t * 4, T * q * 4, 0);
+        }
+    }
+}
+
 }  // namespace pss_hil
