@@ -153,6 +153,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     if (ctx->scratch_pk) hipFree(ctx->scratch_pk);
     if (ctx->scratch_win) hipFree(ctx->scratch_win);
     if (ctx->scratch_post) hipFree(ctx->scratch_post);
+    if (ctx->prog) hipFree(ctx->prog);
     if (ctx->stage) hipFree(ctx->stage);
     hipEventDestroy(ctx->ev0);
     hipEventDestroy(ctx->ev1);

@@ -57,6 +57,7 @@ struct pss_ctx {
     size_t scratch_scan_bytes = 0;
     void *scratch_pk = nullptr;
     size_t scratch_pk_bytes = 0;
+    void *prog = nullptr;          // k_nfm_fwd: per-CU progress words of its workgroups (priority balancing)
     void *scratch_post = nullptr;  // pss_frame_pipeline_nfm without materialised post-processed rows: the rows' clamp thresholds
     size_t scratch_post_bytes = 0;
     void *scratch_win = nullptr;   // sliding-window extremes of the batched display accumulators

@@ -2288,6 +2288,10 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             const double *d_rev = nullptr;
             r = nfm_dev_taps(ctx, flt, &d_rev);
             if (r) return r;
+            if (!ctx->prog) {    // progress words of the forward kernel's workgroups (256 CUs x 4 slots)
+                PSS_HIP(ctx, hipMalloc(&ctx->prog, 4096));
+                PSS_HIP(ctx, hipMemset(ctx->prog, 0, 4096));
+            }
             char *base = reinterpret_cast<char *>(ctx->scratch);
             double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);
             double *Uh = reinterpret_cast<double *>(base + szY + szA), *Ut = reinterpret_cast<double *>(base + szY + szA + szH);
@@ -2296,7 +2300,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             {
                 auto kf = swapped ? fused::k_nfm_fwd<true, true> : fused::k_nfm_fwd<true, false>;
                 hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, d_rev);
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, d_rev, reinterpret_cast<unsigned *>(ctx->prog));
             }
             pss_kernel_end(ctx);
             auto launch_bwd = [=]() -> int {

@@ -38,7 +38,7 @@ constexpr int NFW = 3;         // FIR worker waves (measured slower: 4 x 6 outpu
                                // 3-wave workgroups with 168 VGPRs each 0.88 vs 0.60 ms)
 constexpr int OPT = FC / NFW;  // FIR outputs per worker thread and chunk
 constexpr int WG = 64 * (1 + NFW);
-constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double) + 64 * sizeof(uint2);
+constexpr size_t LDS_BYTES = (size_t)TILE * WSTR * sizeof(float) + (size_t)TILE * FC * sizeof(double) + 64 * sizeof(uint2) + 16;   // + the workgroup's priority word
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence that also waits for every
 // outstanding GLOBAL store of the wave (vmcnt(0)); the IIR wave has 24 y_fwd row stores in flight per chunk, and
@@ -60,16 +60,16 @@ __device__ __forceinline__ void lds_barrier_b()
 #endif
 }
 
-// Time-sliced issue priority.  The SIMD's arbiter serves the OLDEST ready wavefront first: of the four workgroups a CU holds (they all
+// Balanced issue priority.  The SIMD's arbiter serves the OLDEST ready wavefront first: of the four workgroups a CU holds (they all
 // start within 1.3 us of each other) the first-dispatched one runs at the pace of a workgroup that has the CU to itself and is done after
 // 0.32 ms, the others after 0.40 / 0.50 / 0.59 ms (per-workgroup s_memrealtime stamps, tools/ubench_stamps.py) — a staircase whose last
-// steps run with three, two, one wavefront per SIMD and hide no latency.  The user priority (which the arbiter ranks above age) therefore
-// rotates with the 100 MHz real-time counter (every 41 us: all workgroups of a CU read the same clock, so their priorities stay distinct)
-// and the workgroup's slot on its CU: 363 / 418 / 495 / 545 us instead of 324 / 405 / 503 / 587, the launch 5 % shorter (paired A/B,
-// tools/ab_fwd.py; rotating per chunk of the workgroup's own progress instead: 3 %; shorter periods: less).
-#ifndef PSS_PRIO_TIME_SHIFT
-#define PSS_PRIO_TIME_SHIFT 12
-#endif
+// steps run with three, two, one wavefront per SIMD and hide no latency.  The user priority (s_setprio: ranked above age by the arbiter)
+// therefore follows PROGRESS: once per chunk the IIR wavefront publishes the workgroup's chunk index in a per-CU word array (global
+// memory, 16 bytes per CU), reads its three neighbours' and takes as priority the number of them that are ahead; the workers pick it
+// up from LDS behind barrier A.  All four workgroups of a CU then finish within 2 % of each other (493 .. 502 us) and the launch is
+// 4 % shorter than with the priority rotating on the real-time counter (every 41 us: 363 / 418 / 495 / 545 us), 9 % shorter than with
+// none (paired A/B, tools/ab_fwd.py).  Workgroup i runs on CU i mod 256 while the grid fits the machine (HW_ID probe,
+// tools/ubench/simd_placement_probe.hip); for other grids the words are merely a worse hint.
 __device__ __forceinline__ void prio_rotate(int v)
 {
     switch (v & 3) {
@@ -195,16 +195,19 @@ __device__ __forceinline__ double ddot_head(const float *__restrict__ row, const
 template <bool B121, bool SWAPPED = false>
 __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
                                                     double *__restrict__ Uh, double *__restrict__ Utl, int n,
-                                                    long n_frames, NfmCoef c, float kscale, const double *__restrict__ d_rev)
+                                                    long n_frames, NfmCoef c, float kscale, const double *__restrict__ d_rev,
+                                                    unsigned *prog)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
     double *ubuf = reinterpret_cast<double *>(smem + (size_t)TILE * WSTR * sizeof(float));  // [FC][TILE]
-    uint2 *ltab = reinterpret_cast<uint2 *>(ubuf + (size_t)TILE * FC);                        // the discriminator's reciprocal table (pss_device.h rcp14f)
+    uint2 *ltab = reinterpret_cast<uint2 *>(ubuf + (size_t)TILE * FC);
+    int *lprio = reinterpret_cast<int *>(ltab + 64);                                // priority of the workgroup, handed from the IIR wavefront to the workers                        // the discriminator's reciprocal table (pss_device.h rcp14f)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: everything indexed by the role / chunk stays scalar
     const long tile = blockIdx.x;
-    const int slot = (int)(blockIdx.x / gridDim_cus);   // which of its CU's (up to) four workgroups this one is: consecutive workgroups go to consecutive CUs
+    const int slot = (int)(blockIdx.x / gridDim_cus) & 3;   // which of its CU's (up to) four workgroups this one is: consecutive workgroups go to consecutive CUs
+    const int cu = (int)(blockIdx.x % gridDim_cus);
     const int M = n - 1;                      // FIR outputs per frame (M >= 128 guaranteed by the caller)
     const long L = (long)M + 2 * EDGE;
     const int NC = (M - HEAD + FC - 1) / FC;  // worker chunks
@@ -312,9 +315,6 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
         // chunks from the workers
         double reg[FC];
         for (int ch = 0; ch <= NC; ch++) {
-#ifndef PSS_EXP_NOPRIO
-            prio_rotate(slot + (int)(wall_clock64() >> PSS_PRIO_TIME_SHIFT));
-#endif
             if (ch >= 1) {
                 const int cnt = (M - HEAD - (ch - 1) * FC) < FC ? (M - HEAD - (ch - 1) * FC) : FC;
                 if (cnt == FC) {
@@ -327,6 +327,20 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
                 }
             }
             if (ch < NC) {
+#ifndef PSS_EXP_NOPRIO
+                // progress balancing: the workgroup publishes its chunk index and ranks it among the (up to) four workgroups of its CU —
+                // the one furthest behind issues first
+                {
+                    unsigned *pc = prog + 4 * cu;
+                    if (lane == 0) __hip_atomic_store(pc + slot, (unsigned)ch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int rank = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) rank += __hip_atomic_load(pc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)ch + 1u ? 1 : 0;
+                    rank = __builtin_amdgcn_readfirstlane(rank);
+                    if (lane == 0) *lprio = rank;
+                    prio_rotate(rank);
+                }
+#endif
                 lds_barrier();  // A: workers finished FIR(ch) -> ubuf
 #pragma unroll
                 for (int t = 0; t < FC; t++) reg[t] = ubuf[t * TILE + lane];
@@ -360,9 +374,6 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
         const int voff_iq = (int)((lane < tfr ? lane : tfr - 1) * (long)n * (long)sizeof(float2));
         int rot = 0;  // physical block of logical block 0
         for (int ch = 0; ch <= NC; ch++) {
-#ifndef PSS_EXP_NOPRIO
-            prio_rotate(slot + (int)(wall_clock64() >> PSS_PRIO_TIME_SHIFT));
-#endif
             if (ch < NC) {
                 const int ibase = HEAD + ch * FC + OPT * J;  // first output index of this thread's batch
                 const int tn = HEAD + (ch + 1) * FC + OPT * J;  // time of this thread's first new sample of the next chunk
@@ -433,6 +444,9 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
                     for (int e = 0; e < OPT; e++) dn[e] = (e < left) ? dn[e] : 0.0f;
                 }
                 lds_barrier();  // A
+#ifndef PSS_EXP_NOPRIO
+                prio_rotate(__builtin_amdgcn_readfirstlane(*lprio));
+#endif
                 // the oldest block (logical 0) becomes the newest (logical 3 of the next chunk)
                 {
                     float4 *nb = reinterpret_cast<float4 *>(row + rot * FC + OPT * J);   // 16-byte stores (rows are 16-byte aligned, 25 x 16 bytes apart)
