@@ -58,6 +58,9 @@ _SIGS = {
     "pss_demod_out_len": (C.c_int, [C.c_int, C.c_int, C.c_double]),
     "pss_spectrum_nfm": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
     "pss_frame_pipeline_nfm": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "pss_frame_pipeline_nfm_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "pss_spectrum_db_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
+    "pss_spectrum_post_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, _p]),
     "pss_waterfall_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "pss_persistence_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "pss_spectrogram_cells": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_int, C.c_int, _p, _p, _p]),

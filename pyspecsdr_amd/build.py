@@ -63,7 +63,7 @@ def build(force=False, verbose=False):
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
     if force or _stale(OUT, objs):
-        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--strip-all", "-o", OUT] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

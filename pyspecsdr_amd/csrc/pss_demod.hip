@@ -2965,6 +2965,26 @@ extern "C" int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, 
 // demodulate_signal(samples, fs, 'NFM') -> int16; compute_fft -> dB row; smoothing + median clamp; waterfall accumulator
 // line.  The demodulator's backward pass is latency-bound (one wavefront per SIMD), the whole display chain is HBM-bound:
 // behind the forward kernel the two run side by side on two streams (fork / join with events).
+// The same iteration with the reference's own row type: float64 dB rows, float64 post-processed rows and extremes, the waterfall line
+// quantised from those (pss_waterfall_rows_f64) — the cells the reference draws from this IQ, not those of the float32 rows.  Plain
+// kernels in order on the context's stream; the demodulator is the same.
+extern "C" int pss_frame_pipeline_nfm_f64(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, double *d_db, double *d_post,
+                                          double *d_row_lo, double *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
+                                          int8_t *d_colour, int16_t *d_pcm)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames > 0 && (!d_db || !d_post || !d_row_lo || !d_row_hi || !d_glyph || !d_colour || !d_pcm))
+        return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_nfm_f64: null buffer");
+    pss_time_begin(ctx);
+    int r = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
+    if (!r) r = pss_spectrum_db_f64(ctx, d_iq, n_frames, n, d_db);
+    if (!r) r = pss_spectrum_post_f64(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+    if (!r) r = pss_waterfall_rows_f64(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+    pss_time_end(ctx);
+    return r;
+}
+
 extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
                                       float *d_row_lo, float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
                                       int8_t *d_colour, int16_t *d_pcm)

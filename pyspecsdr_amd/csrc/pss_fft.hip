@@ -104,7 +104,9 @@ __device__ __forceinline__ int digit_reverse(int p, int logn)
 
 using pss_r16::db_of;   // 10 log10(pw) to float64 accuracy, rounded once to float32 (pss_fft_r16.h)
 
-template <bool SCAN, bool EXACT = false>
+// D64: the row type of the reference itself — db points at float64 rows, 10 log10(|X|^2 + 1e-10) evaluated in float64 as compute_fft does
+// (np.abs = hypot, squared, + 1e-10, log10); for callers that need the display cells of the float64 rows (pss_spectrum_db_f64).
+template <bool SCAN, bool EXACT = false, bool D64 = false>
 __global__ __launch_bounds__(TPB) void k_spectrum(const float2 *__restrict__ iq, float *__restrict__ db,
                                                   const double2 *__restrict__ tw, const double *__restrict__ win,
                                                   int N, int logNsub, int R, long n_frames, int staged,
@@ -149,6 +151,11 @@ __global__ __launch_bounds__(TPB) void k_spectrum(const float2 *__restrict__ iq,
                 double pw = v.x * v.x + v.y * v.y + 1e-10;
                 int k = R * digit_reverse(p, logNsub) + r;
                 int o = (k + (N >> 1)) & (N - 1);  // fftshift
+                if constexpr (D64) {
+                    const double a = hypot(v.x, v.y);
+                    reinterpret_cast<double *>(db)[(size_t)f * N + o] = 10.0 * log10(a * a + 1e-10);
+                    continue;
+                }
                 float d;
                 if constexpr (SCAN) d = (flags & pss_r16::FLAG_SCAN_EXACT) ? pss::scan_db_np(v.x, v.y) : pss_r16::db_of_fast(pw);
                 else d = EXACT ? pss_r16::db_of_exact(pw) : pss_r16::db_of_fast(pw);   // scanner slice: NumPy's complex64 spectrum + float32 chain
@@ -311,6 +318,81 @@ __global__ __launch_bounds__(1024) void k_post_select(const float *__restrict__ 
     }
 }
 
+// The caller's post-process on float64 rows (the reference's own row type, pyspecsdr.py:2278-2283): np.convolve(row, ones(5) / 5,
+// 'valid') — five products by 0.2 summed left to right, no fused multiply-adds —, np.median of the float64 values (mean of the two
+// middle order statistics for an even count; NaN if the row holds one), everything below median - 10 raised to it.  Any row length:
+// the order statistics come from a most-significant-byte-first radix select over the order-preserving integer image of the doubles.
+__device__ __forceinline__ unsigned long long d2ord(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord2d(unsigned long long o)
+{
+    return __longlong_as_double((long long)((o >> 63) ? (o & 0x7fffffffffffffffull) : ~o));
+}
+
+__global__ __launch_bounds__(256) void k_post_f64(const double *__restrict__ db, double *__restrict__ post, int N, long n_frames)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long sel_prefix;
+    __shared__ unsigned sel_k;
+    const int tid = threadIdx.x, m = N - 4;
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const double *row = db + (size_t)f * N;
+        double *o = post + (size_t)f * m;
+        int nan_here = 0;
+        for (int i = tid; i < m; i += 256) {
+            double acc = 0.0;
+            {
+#pragma clang fp contract(off)   // this unit is compiled with contraction on, and HIP's __dmul_rn / __dadd_rn are plain operators
+                for (int k = 0; k < 5; k++) acc = acc + row[i + k] * 0.2;
+            }
+            o[i] = acc;
+            nan_here |= acc != acc;
+        }
+        const int has_nan = __syncthreads_or(nan_here);      // also orders the stores above before the reads below
+        auto select = [&](unsigned k) {                      // k-th smallest (0-based) of the smoothed row, as its ordered-integer image
+            unsigned long long prefix = 0, mask = 0;
+            for (int shift = 56; shift >= 0; shift -= 8) {
+                hist[tid] = 0;
+                __syncthreads();
+                for (int i = tid; i < m; i += 256) {
+                    const unsigned long long q = d2ord(o[i]);
+                    if ((q & mask) == prefix) atomicAdd(&hist[(unsigned)(q >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned cum = 0, b = 0;
+                    for (; b < 255; b++) {
+                        if (cum + hist[b] > k) break;
+                        cum += hist[b];
+                    }
+                    sel_prefix = prefix | ((unsigned long long)b << shift);
+                    sel_k = k - cum;
+                }
+                __syncthreads();
+                prefix = sel_prefix;
+                k = sel_k;
+                mask |= 255ull << shift;
+                __syncthreads();
+            }
+            return prefix;
+        };
+        if (!has_nan && m > 0) {
+            double med;
+            if (m & 1) med = ord2d(select((unsigned)(m >> 1)));
+            else med = 0.5 * (ord2d(select((unsigned)(m >> 1) - 1)) + ord2d(select((unsigned)(m >> 1))));
+            const double thr = med - 10.0;
+            for (int i = tid; i < m; i += 256) {
+                const double v = o[i];
+                if (v < thr) o[i] = thr;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // np.interp(np.linspace(0, len-1, W), np.arange(len), row)[i]
 template <class T>
 __device__ __forceinline__ double interp_row(const T *row, int len, int W, int i)
@@ -332,15 +414,6 @@ __device__ __forceinline__ double interp_row(const T *row, int len, int W, int i
 // order-preserving 64-bit image of the values, then numpy's _lerp), display range (:424-427), clip + x**0.7 (:442-445),
 // np.interp to the display width (:448-452), bar height int(value*H) and the glyph / colour of every cell (:455-490).
 // glyph: 0 '.', 1 '-', 2 '=', 3 '#', 4 ' '; colour: curses pair (1 = cleared cell); -1: column not drawn (non-finite).
-__device__ __forceinline__ unsigned long long d2ord(double v)
-{
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double ord2d(unsigned long long o)
-{
-    return __longlong_as_double((long long)((o >> 63) ? (o & 0x7fffffffffffffffull) : ~o));
-}
 
 template <class T>
 __global__ __launch_bounds__(1024) void k_spectrogram(const T *__restrict__ rows, long n_rows, int len, int disp_h, int disp_w,
@@ -838,9 +911,18 @@ struct BsLoadConv {
         return make_double2(p.x, -p.y);
     }
 };
+// the plain complex store; hilbert != 0: scipy.signal.hilbert's spectrum mask (1 at DC and Nyquist, 2 below, 0 above) and the conjugate that
+// turns the next forward transform into the inverse one
 struct BsStoreC {
-    double2 *A; size_t M;
-    __device__ void operator()(long f, size_t k, double2 X) const { A[(size_t)f * M + k] = X; }
+    double2 *A; size_t M; int hilbert;
+    __device__ void operator()(long f, size_t k, double2 X) const
+    {
+        if (hilbert) {
+            const double h = (k == 0 || k == M / 2) ? 1.0 : (k < M / 2 ? 2.0 : 0.0);
+            X = make_double2(X.x * h, -(X.y * h));
+        }
+        A[(size_t)f * M + k] = X;
+    }
 };
 struct BsStoreDb {
     float *db; const double2 *chirp; int n, shift; double inv_m; bool np32; int flags;   // np32: the scanner's float32 chain (scan_db_np)
@@ -914,7 +996,7 @@ int bs_plan(pss_ctx *ctx, int n, pss_ctx::Bluestein **out)
         int r = pss_fft_tables(ctx, M, &tw, &wm);
         if (!r) r = pss_ensure_buffer(ctx, &ctx->scratch_fft, &ctx->scratch_fft_bytes, (size_t)M * sizeof(double2), "spectrum scratch");
         if (!r) r = bs_pass1(ctx, BsLoadArr{d_b}, tw, reinterpret_cast<double2 *>(ctx->scratch_fft), M >> 8, 1);
-        if (!r) r = bs_pass2(ctx, reinterpret_cast<const double2 *>(ctx->scratch_fft), BsStoreC{p.d_B, (size_t)M}, tw, M >> 8, 1);
+        if (!r) r = bs_pass2(ctx, reinterpret_cast<const double2 *>(ctx->scratch_fft), BsStoreC{p.d_B, (size_t)M, 0}, tw, M >> 8, 1);
         hipStreamSynchronize(PSS_STREAM(ctx));
         hipFree(d_b);
         if (r) return r;
@@ -951,7 +1033,7 @@ int bluestein_db(pss_ctx *ctx, const float *d_iq, long n_frames, int n, bool win
         r = bs_pass1(ctx, BsLoadX{x, p->d_chirp, window ? p->d_win : nullptr, n}, tw, Y, NS, nf);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_bluestein_p2");
-        if (!r) r = bs_pass2(ctx, Y, BsStoreC{A, M}, tw, NS, nf);
+        if (!r) r = bs_pass2(ctx, Y, BsStoreC{A, M, 0}, tw, NS, nf);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_bluestein_p1");
         if (!r) r = bs_pass1(ctx, BsLoadConv{A, p->d_B, M}, tw, Y, NS, nf);
@@ -1040,9 +1122,8 @@ struct HilLoadZ {
 };
 // OUT 0: complex128 analytic signal; 1: real part + the row's peak |re| (bit pattern, atomicMax; one atomic per wavefront and call:
 // every lane of the calling kernels is active here)
-template <int OUT>
 struct HilStoreOut {
-    double *out; unsigned long long *mxbits; size_t n; double inv_n;
+    double *out; unsigned long long *mxbits; size_t n; double inv_n; int OUT;
     __device__ void operator()(long f, size_t k, double2 W) const
     {
         const double re = W.x * inv_n, im = -(W.y * inv_n);
@@ -1091,9 +1172,7 @@ int hilbert_long(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_
     const HilLoadZ lz{Z, N};
     const double inv_n = 1.0 / (double)n;
     pss_kernel_begin(ctx, "k_hilbert");
-    auto second = [&](auto pass) -> int {
-        return out_mode == 0 ? pass(HilStoreOut<0>{d_out, nullptr, N, inv_n}) : pass(HilStoreOut<1>{d_out, d_maxbits, N, inv_n});
-    };
+    auto second = [&](auto pass) -> int { return pass(HilStoreOut{d_out, out_mode == 0 ? nullptr : d_maxbits, N, inv_n, out_mode}); };
     if (n == 32768) {
         r = big_pass<3>(ctx, lx, sz, tw, n_rows, S, grid);
         if (!r) r = second([&](auto st) { return big_pass<3>(ctx, lz, st, tw, n_rows, S, grid); });
@@ -1103,7 +1182,7 @@ int hilbert_long(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_
     } else {
         const int NS = n >> 8;
         r = bs_pass1(ctx, lx, tw, S, NS, n_rows);
-        if (!r) r = bs_pass2(ctx, S, sz, tw, NS, n_rows);
+        if (!r) r = bs_pass2(ctx, S, BsStoreC{Z, N, 1}, tw, NS, n_rows);
         if (!r) r = bs_pass1(ctx, lz, tw, S, NS, n_rows);
         if (!r) r = second([&](auto st) { return bs_pass2(ctx, S, st, tw, NS, n_rows); });
         if (!r) r = pss_hip_check(ctx, hipGetLastError(), "hilbert two-pass launch");
@@ -1207,6 +1286,36 @@ extern "C" int pss_spectrum_db(pss_ctx *ctx, const float *d_iq, long n_frames, i
     return launch_spectrum<false>(ctx, d_iq, n_frames, n_fft, d_db, nullptr, nullptr, nullptr, 0.0);
 }
 
+// float64 dB rows, float64 post-processed rows: what the reference's display functions are fed (compute_fft returns float64).  For callers
+// that want the display cells of the reference itself and not those of the float32 rows (the rows agree to 1e-7, a cell can differ where
+// a value sits on a quantisation edge: <= 2e-3 of the cells); not a throughput path — one plain kernel each.
+extern "C" int pss_spectrum_db_f64(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, double *d_db)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames < 0 || (n_frames > 0 && (!d_iq || !d_db))) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_db_f64: null buffer / negative n_frames");
+    if (n_fft < 16 || n_fft > 65536 || (n_fft & (n_fft - 1)))
+        return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_db_f64: n_fft must be a power of two in [16, 65536]");
+    if (n_frames == 0) return PSS_OK;
+    const double2 *tw;
+    const double *win;
+    int r = pss_fft_tables(ctx, n_fft, &tw, &win);
+    if (r) return r;
+    const int logn = ilog2(n_fft), logNsub = logn < LOG_NSUB_MAX ? logn : LOG_NSUB_MAX;
+    const size_t lds = ((size_t)1 << logNsub) * sizeof(double2);
+    auto kern = k_spectrum<false, false, true>;
+    if (lds > 64 * 1024) PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((160 * 1024) / (lds + 64));
+    per_cu = per_cu > 8 ? 8 : per_cu;
+    pss_time_begin(ctx);
+    pss_kernel_begin(ctx, "k_spectrum_f64");
+    hipLaunchKernelGGL(kern, dim3(grid_for(n_frames, per_cu)), dim3(TPB), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq),
+                       reinterpret_cast<float *>(d_db), tw, win, n_fft, logNsub, n_fft >> logNsub, n_frames, 0, nullptr, nullptr, nullptr, 0.0, 0);
+    pss_kernel_end(ctx);
+    pss_time_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_spectrum (float64 rows) launch");
+}
+
 // dB rows of the scanner's unwindowed fft into d_db or, when the caller wants only the per-slice numbers, into scratch
 static int scan_rows(pss_ctx *ctx, const float *d_iq, long n_slices, int n, float *d_db, const float **rows)
 {
@@ -1260,7 +1369,9 @@ int launch_post_sel(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, f
 {
     constexpr int T = 64 * W, RPW = W == 1 ? 4 : 1;
     const size_t lds = (size_t)RPW * (T + 1) * pss_post::PostCfg<EPL>::S * sizeof(float);
-    auto kern = n_fft == T * EPL ? pss_post::k_post_sel<EPL, W, true> : pss_post::k_post_sel<EPL, W, false>;
+    // the exact-fit specialisation (no padding tests) only for the read-buffer lengths of the display path: 1024, 2048, 4096 points
+    constexpr bool FULL_BUILT = W == 1 ? EPL >= 16 : (W == 4 && EPL == 16);
+    auto kern = FULL_BUILT && n_fft == T * EPL ? pss_post::k_post_sel<EPL, W, FULL_BUILT> : pss_post::k_post_sel<EPL, W, false>;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long groups = (n_frames + RPW - 1) / RPW;
@@ -1430,6 +1541,23 @@ extern "C" int pss_row_extremes_f64(pss_ctx *ctx, const double *d_rows, long n_r
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
     return row_extremes<double>(ctx, d_rows, n_rows, len, d_row_lo, d_row_hi);
+}
+
+extern "C" int pss_spectrum_post_f64(pss_ctx *ctx, const double *d_db, long n_frames, int n_fft, double *d_post, double *d_row_lo, double *d_row_hi)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames < 0 || n_fft < 5 || (n_frames > 0 && (!d_db || !d_post))) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_post_f64: bad argument");
+    if ((d_row_lo == nullptr) != (d_row_hi == nullptr)) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_post_f64: row_lo and row_hi go together");
+    if (n_frames == 0) return PSS_OK;
+    pss_time_begin(ctx);
+    pss_kernel_begin(ctx, "k_post_f64");
+    hipLaunchKernelGGL(k_post_f64, dim3((unsigned)(n_frames < 2048 ? n_frames : 2048)), dim3(256), 0, PSS_STREAM(ctx), d_db, d_post, n_fft, n_frames);
+    pss_kernel_end(ctx);
+    int r = pss_hip_check(ctx, hipGetLastError(), "k_post_f64 launch");
+    if (!r && d_row_lo) r = row_extremes<double>(ctx, d_post, n_frames, n_fft - 4, d_row_lo, d_row_hi);
+    pss_time_end(ctx);
+    return r;
 }
 
 // The post-process WITHOUT writing the post-processed rows: per row the clamp threshold float32(median - 10) and the finite extremes of

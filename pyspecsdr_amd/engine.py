@@ -224,6 +224,21 @@ class Engine:
         self._ck(self.lib.pss_frame_pipeline_nfm(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
                                                  _ptr(d_row_hi), n_halo, window, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_pcm)))
 
+    def frame_pipeline_nfm_f64(self, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, disp_w, d_glyph, d_colour, d_pcm,
+                               n_halo=0, window=30):
+        """frame_pipeline_nfm with the reference's own row type: float64 dB rows, post-processed rows and extremes; the waterfall lines
+        are then the cells the reference draws from this IQ (compute_fft returns float64, signal_processing.py:243-264)."""
+        self._ck(self.lib.pss_frame_pipeline_nfm_f64(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
+                                                     _ptr(d_row_hi), n_halo, window, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_pcm)))
+
+    def spectrum_db_f64(self, d_iq, n_frames, n_fft, d_db):
+        """compute_fft's float64 rows (n_fft: power of two in 16..65536)."""
+        self._ck(self.lib.pss_spectrum_db_f64(self.h, _ptr(d_iq), n_frames, n_fft, _ptr(d_db)))
+
+    def spectrum_post_f64(self, d_db, n_frames, n_fft, d_post, d_row_lo=None, d_row_hi=None):
+        """The caller's smoothing + median clamp on float64 rows (pyspecsdr.py:2278-2283), optionally the rows' finite extremes."""
+        self._ck(self.lib.pss_spectrum_post_f64(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_post), _ptr(d_row_lo), _ptr(d_row_hi)))
+
     def waterfall_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_glyph, d_colour, f64=False):
         fn = self.lib.pss_waterfall_cells_f64 if f64 else self.lib.pss_waterfall_cells
         self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour)))

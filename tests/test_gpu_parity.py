@@ -266,6 +266,61 @@ def test_batched_accumulators_vs_reference_histories(golden):
     assert np.mean(G.host(d_g) != gl) < 2e-3 and np.mean(G.host(d_c) != co) < 2e-3
 
 
+def test_float64_rows_pipeline_draws_the_reference_cells(golden):
+    """pss_frame_pipeline_nfm_f64: float64 dB rows, float64 post-processed rows, and the waterfall lines the REFERENCE drew from the same
+    read buffers (tests/golden/caller_iq.npz -> caller.npz, draw_waterfall through a fake screen) — every cell, from IQ.  The float32
+    pipeline on the same buffers may differ in a cell where a value sits on a quantisation edge."""
+    g, q = golden["caller"], golden["caller_iq"]
+    iq = np.ascontiguousarray(q["iq"])
+    nf, n = iq.shape
+    H, W = [int(v) for v in g["hw"]]
+    dw, fs = W - 8, 2.4e6
+    e = G.engine()
+    q_out = e.demod_out_len(0, n, fs)
+    d_iq = G.dev(iq)
+    d_db, d_post = G.empty((nf, n), torch.float64), G.empty((nf, n - 4), torch.float64)
+    d_lo, d_hi = G.empty((nf,), torch.float64), G.empty((nf,), torch.float64)
+    d_g, d_c = G.empty((nf, dw), torch.int8), G.empty((nf, dw), torch.int8)
+    d_pcm = G.empty((nf, q_out, 2), torch.int16)
+    e.frame_pipeline_nfm_f64(d_iq, nf, n, fs, d_db, d_post, d_lo, d_hi, dw, d_g, d_c, d_pcm)
+    e.sync()
+    db, post = G.host(d_db), G.host(d_post)
+    assert np.allclose(db, q["db"], rtol=1e-9, atol=1e-9)                    # compute_fft's float64 rows
+    assert np.allclose(post, g["rows"], rtol=1e-9, atol=1e-9)                # the caller's post-processed rows ...
+    assert np.array_equal(post, np.stack([O.postprocess(r) for r in db]))    # ... and bit for bit np.convolve / np.median / the clamp on the dB rows
+    assert np.array_equal(G.host(d_lo), post.min(axis=1)) and np.array_equal(G.host(d_hi), post.max(axis=1))
+    gl, co = G.host(d_g), G.host(d_c)
+    for i in range(nf):                                                      # line y = 0 of the reference's grid at frame i is the newest row
+        assert np.array_equal(gl[i], g["wf_glyph"][i][0]) and np.array_equal(co[i], g["wf_colour"][i][0]), i
+    # the PCM is the float32 pipeline's (same demodulator)
+    d_db32, d_lo32, d_hi32 = G.empty((nf, n), torch.float32), G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
+    d_g2, d_c2, d_pcm2 = G.empty((nf, dw), torch.int8), G.empty((nf, dw), torch.int8), G.empty((nf, q_out, 2), torch.int16)
+    e.frame_pipeline_nfm(d_iq, nf, n, fs, d_db32, None, d_lo32, d_hi32, dw, d_g2, d_c2, d_pcm2)
+    e.sync()
+    assert np.array_equal(G.host(d_pcm), G.host(d_pcm2))
+    assert np.allclose(G.host(d_db32), db, rtol=1e-4, atol=1e-4)
+    assert np.mean(G.host(d_g2) != gl) < 2e-3 and np.mean(G.host(d_c2) != co) < 2e-3
+    # the two halves separately, other lengths, a row with a NaN (np.median -> NaN: nothing is clamped)
+    rng = np.random.default_rng(5)
+    for n2 in (16, 64, 4096, 16384):
+        x = (rng.standard_normal((3, n2)) + 1j * rng.standard_normal((3, n2))).astype(np.complex64)
+        d_b, d_p = G.empty((3, n2), torch.float64), G.empty((3, n2 - 4), torch.float64)
+        e.spectrum_db_f64(G.dev(x), 3, n2, d_b)
+        e.spectrum_post_f64(d_b, 3, n2, d_p)
+        e.sync()
+        want = np.stack([O.compute_fft(f) for f in x])
+        assert np.allclose(G.host(d_b), want, rtol=1e-9, atol=1e-9), n2
+        assert np.array_equal(G.host(d_p), np.stack([O.postprocess(r) for r in G.host(d_b)])), n2
+    rows = rng.standard_normal((2, 1024)) * 10 - 40
+    rows[1, 500] = np.nan
+    d_p = G.empty((2, 1020), torch.float64)
+    e.spectrum_post_f64(G.dev(rows), 2, 1024, d_p)
+    e.sync()
+    sm = np.stack([np.convolve(r, np.ones(5) / 5, mode="valid") for r in rows])
+    assert np.array_equal(G.host(d_p)[0], O.postprocess(rows[0]))
+    assert np.array_equal(G.host(d_p)[1], sm[1], equal_nan=True)
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f", "g"])
 def test_nfm_vs_golden_bit_exact(golden, tag):
     g = golden["nfm"]

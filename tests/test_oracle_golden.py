@@ -180,6 +180,18 @@ def test_waterfall_and_persistence(golden):
         assert np.array_equal(O.persistence_cells(ring, dh, dw), g["ps_colour"][i]), i
 
 
+def test_reference_cells_from_iq(golden):
+    """caller_iq.npz: the read buffers behind caller.npz's rows.  compute_fft -> smoothing + clamp -> draw_waterfall, the oracle from IQ
+    to cells: the float64 rows agree with the reference's to rounding (the transform is not pocketfft's), the cells are equal."""
+    g, q = golden["caller"], golden["caller_iq"]
+    H, W = [int(v) for v in g["hw"]]
+    rows = np.stack([O.postprocess(O.compute_fft(f)) for f in q["iq"]])
+    assert np.allclose(rows, g["rows"], rtol=1e-9, atol=1e-9)
+    for i in range(len(rows)):
+        gl, co = O.waterfall_cells(rows[max(0, i + 1 - 30):i + 1], H - 4, W - 8)
+        assert np.array_equal(gl, g["wf_glyph"][i]) and np.array_equal(co, g["wf_colour"][i]), i
+
+
 def test_raw_and_unknown_modes(golden):
     g = golden["am_ssb"]
     # RAW goes through iq_correction first (signal_processing.py:222-225): float32 (N,), not plain real()

@@ -781,9 +781,27 @@ def gen_caller():
     save("caller", **d)
 
 
+def gen_caller_iq():
+    """The read buffers behind caller.npz's `rows` (the same seeded generator and scalings as gen_caller), stored so that a test can go
+    from IQ to the reference's waterfall cells; checked here against the stored rows through the reference's compute_fft."""
+    iq = fm_iq(34, 1024, 2.4e6, 71)
+    iq[5] *= 3.0
+    iq[20] *= 0.1
+    rows = []
+    for f in iq:
+        fd = sp.compute_fft(f)
+        fd = np.convolve(fd, np.ones(5) / 5, mode="valid")
+        thr = np.median(fd) - 10
+        fd[fd < thr] = thr
+        rows.append(fd)
+    have = np.load(os.path.join(OUT, "caller.npz"))["rows"]
+    assert np.array_equal(np.stack(rows), have), "caller.npz was generated from different read buffers"
+    save("caller_iq", iq=iq, db=np.stack([sp.compute_fft(f) for f in iq]))
+
+
 if __name__ == "__main__":
     gens = [gen_atan2, gen_atan2f_bits, gen_spectrum, gen_nfm, gen_am_ssb, gen_power, gen_iqcorr, gen_wfm, gen_bandpass, gen_afsk, gen_classify, gen_classify_short, gen_log10f,
-            gen_decoders, gen_scanner, gen_caller]
+            gen_decoders, gen_scanner, gen_caller, gen_caller_iq]
     want = sys.argv[1:]                      # e.g. `python tools/make_goldens.py decoders` regenerates one fixture
     for g in gens:
         if not want or g.__name__[4:] in want:
