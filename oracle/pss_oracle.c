@@ -9,8 +9,9 @@
  *   atan2f / cabsf / pairwise sums / discriminator ........ bit-exact float32
  *   sosfilt / sosfiltfilt / AM chain ...................... bit-exact float64
  *   65-tap FIR (OpenBLAS ddot / zdot accumulation order) ... bit-exact float64 -> NFM audio bit-exact float64
- *   SSB ................................................... real FIR bit-exact; the reference's hilbert() FFT
- *                                                           round trip adds ~1e-16 noise (atol 1e-14), int16 exact
+ *   SSB ................................................... bit-exact float64 for frames of 2^k samples (real FIR + SciPy's
+ *                                                           hilbert() round trip, pss_pocketfft.c); other lengths skip the
+ *                                                           round trip (~1e-16 noise, atol 1e-14), int16 exact
  *   spectrum dB, power dB, scanner dB ..................... tolerance (rtol 1e-9 f64 / few ulp f32)
  */
 #include "pss_oracle.h"
@@ -977,6 +978,12 @@ void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio)
     double tr[65];
     for (int j = 0; j < 65; j++) tr[j] = taps[64 - j];
     for (int i = 0; i < n; i++) audio[i] = fir65z_at(taps, tr, r, i, n);                    /* :204/:209 real part */
+    if (n >= 2 && (n & (n - 1)) == 0) {                                                    /* :205/:210 hilbert(), :213 its real part */
+        double *an = (double *)malloc(sizeof(double) * 2 * n);
+        pss_o_hilbert(audio, n, an);                                                        /* pss_pocketfft.c: SciPy's transform bit for bit */
+        for (int i = 0; i < n; i++) audio[i] = an[2 * i];
+        free(an);
+    }                                                                                       /* other lengths: the round trip is skipped (~1e-16) */
     double mx = 0.0;
     int has_nan = 0;
     for (int i = 0; i < n; i++) { double a = fabs(audio[i]); if (a != a) has_nan = 1; if (a > mx) mx = a; }

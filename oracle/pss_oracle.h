@@ -57,6 +57,12 @@ void pss_o_demod_am(const float *iq, int n, const double *sos, int nsec, double 
 /* demodulate_ssb — signal_processing.py:198-217. taps[65] = firwin(65, 3000/fs). audio[n].
  * hilbert(real(z)).real is restated as real(z) (identity up to 1e-15 round-off). */
 void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio);
+/* pss_pocketfft.c: scipy.signal.hilbert of a real float64 row of n = 2^k samples, bit for bit (out: n complex128 values, interleaved);
+ * the plan's twiddle table exp(2 pi i k / n); the forward / inverse halves alone (scipy.fft.fft of a real row, scipy.fft.ifft). */
+void pss_o_hilbert(const double *x, int n, double *out);
+void pss_o_pocketfft_twiddles(int n, double *tw_re_im);
+void pss_o_rfft_full(const double *x, int n, double *out);
+void pss_o_cifft(const double *in, int n, double *out);
 /* demodulate_wfm — signal_processing.py:119-176 (called on iq_correction()'s output, :222-228).
  * lp_sos[3][6] = butter(5, 15000/(fs/2), 'low'); pilot_sos[5][6] = butter(5, [18800, 19200]/(fs/2), 'band');
  * lmr_sos[5][6] = butter(5, [23000, 53000]/(fs/2), 'band'); alpha = exp(-1/(75e-6 fs)); dec_sos/dec_zi as for NFM;

@@ -20,7 +20,7 @@ _i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
 
 
 def build(force=False):
-    src = [os.path.join(ODIR, f) for f in ("pss_oracle.c", "pss_oracle.h", "Makefile")]
+    src = [os.path.join(ODIR, f) for f in ("pss_oracle.c", "pss_pocketfft.c", "pss_oracle.h", "Makefile")]
     if force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in src):
         subprocess.run(["make", "-C", ODIR], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return SO
@@ -73,6 +73,11 @@ def lib():
                                       C.c_void_p, C.c_void_p]
         L.pss_o_demod_am.argtypes = [_f32p, C.c_int, _f64p, C.c_int, _f64p]
         L.pss_o_demod_ssb.argtypes = [_f32p, C.c_int, _f64p, _f64p]
+        for f in ("pss_o_hilbert", "pss_o_rfft_full", "pss_o_cifft"):
+            getattr(L, f).restype = None
+            getattr(L, f).argtypes = [_f64p, C.c_int, _f64p]
+        L.pss_o_pocketfft_twiddles.restype = None
+        L.pss_o_pocketfft_twiddles.argtypes = [C.c_int, _f64p]
         L.pss_o_pcm16_stereo.argtypes = [_f64p, C.c_int, _i16p]
         L.pss_o_agc_step.restype = C.c_int
         L.pss_o_agc_step.argtypes = [C.c_float, C.c_int, C.c_int]
@@ -276,6 +281,20 @@ def demod_ssb(iq, taps):
     out = np.empty(len(iq), np.float64)
     lib().pss_o_demod_ssb(_iq(iq), len(iq), np.ascontiguousarray(taps, np.float64), out)
     return out
+
+
+def hilbert(x):
+    """scipy.signal.hilbert of a real float64 row of 2^k samples (pss_pocketfft.c)."""
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty(2 * len(x), np.float64)
+    lib().pss_o_hilbert(x, len(x), out)
+    return out.view(np.complex128)
+
+
+def pocketfft_twiddles(n):
+    out = np.empty(2 * n, np.float64)
+    lib().pss_o_pocketfft_twiddles(n, out)
+    return out.view(np.complex128)
 
 
 def pcm16_stereo(audio):

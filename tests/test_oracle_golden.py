@@ -109,9 +109,33 @@ def test_ssb(golden, tag):
     taps = g[f"ssb_taps_{tag}"]
     for k, iq in enumerate(g[f"ssb_iq_{tag}"]):
         audio = O.demod_ssb(iq, taps)
-        # real FIR is bit-exact; scipy's hilbert() FFT round trip perturbs it by ~1e-16
-        assert np.allclose(audio, g[f"ssb_audio_{tag}"][k], rtol=0, atol=2e-14)
+        n = len(iq)
+        if n & (n - 1) == 0:
+            # frames of 2^k samples: the real FIR and SciPy's hilbert() round trip (pss_pocketfft.c), every bit of the float64 audio
+            assert np.array_equal(audio, g[f"ssb_audio_{tag}"][k]), (tag, k)
+        else:
+            assert np.allclose(audio, g[f"ssb_audio_{tag}"][k], rtol=0, atol=2e-14)
         assert np.array_equal(O.pcm16_stereo(audio), g[f"ssb_pcm_{tag}"][k])
+
+
+def test_pocketfft_model_is_scipy_bit_for_bit():
+    """oracle/pss_pocketfft.c against SciPy itself (where this test runs): the real forward transform, the complex inverse and
+    scipy.signal.hilbert for every power of two up to 2^17, and the plan's twiddle products."""
+    import scipy.fft as sf
+    import scipy.signal as ss
+    L = O.lib()
+    rng = np.random.default_rng(11)
+    for n in [2 ** k for k in range(1, 18)]:
+        x = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4)
+        f = np.empty(2 * n)
+        L.pss_o_rfft_full(x, n, f)
+        assert np.array_equal(f.view(np.complex128), sf.fft(x)), n
+        z = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        o = np.empty(2 * n)
+        L.pss_o_cifft(np.ascontiguousarray(z).view(np.float64), n, o)
+        assert np.array_equal(o.view(np.complex128), sf.ifft(z)), n
+        assert np.array_equal(O.hilbert(x), ss.hilbert(x)), n
+    assert np.array_equal(O.hilbert(np.zeros(64)), ss.hilbert(np.zeros(64)))
 
 
 @pytest.mark.parametrize("n", [7, 100, 1024, 16384, 20000, 32768, 40001])
