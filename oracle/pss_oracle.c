@@ -971,14 +971,17 @@ int pss_o_demod_wfm(const float *iq, int n, int q, const double *lp_sos, const d
 }
 
 /* demodulate_ssb — signal_processing.py:198-217 (USB and LSB branches are the same code) */
-void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio)
+void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio) { pss_o_demod_ssb_ex(iq, n, taps, audio, 1); }
+
+/* with_hilbert = 0: the chain without :205 / :210 (what the library's option "ssb_hilbert" = 0 computes) */
+void pss_o_demod_ssb_ex(const float *iq, int n, const double *taps, double *audio, int with_hilbert)
 {
     double *r = (double *)malloc(sizeof(double) * n);
     for (int i = 0; i < n; i++) r[i] = (double)iq[2 * i];
     double tr[65];
     for (int j = 0; j < 65; j++) tr[j] = taps[64 - j];
     for (int i = 0; i < n; i++) audio[i] = fir65z_at(taps, tr, r, i, n);                    /* :204/:209 real part */
-    if (n >= 2 && (n & (n - 1)) == 0) {                                                    /* :205/:210 hilbert(), :213 its real part */
+    if (with_hilbert && n >= 2 && (n & (n - 1)) == 0) {                                     /* :205/:210 hilbert(), :213 its real part */
         double *an = (double *)malloc(sizeof(double) * 2 * n);
         pss_o_hilbert(audio, n, an);                                                        /* pss_pocketfft.c: SciPy's transform bit for bit */
         for (int i = 0; i < n; i++) audio[i] = an[2 * i];

@@ -133,6 +133,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     PssDevGuard guard(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->tw) hipFree(kv.second);
+    for (auto &kv : ctx->tw_pf) hipFree(kv.second);
     for (auto &kv : ctx->win) hipFree(kv.second);
     for (auto &kv : ctx->bs) { hipFree(kv.second.d_chirp); hipFree(kv.second.d_B); hipFree(kv.second.d_win); }
     for (auto &kv : ctx->plans) {
@@ -188,6 +189,7 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "small_batch_max")) { ctx->small_batch_max = value; return PSS_OK; }
     if (!strcmp(key, "wfm_small_batch_max")) { ctx->wfm_small_batch_max = value; return PSS_OK; }
     if (!strcmp(key, "ssb_hilbert")) { ctx->ssb_hilbert = value != 0; return PSS_OK; }
+    if (!strcmp(key, "hilbert_exact")) { ctx->hilbert_exact = value != 0; return PSS_OK; }
     if (!strcmp(key, "scan_exact")) { ctx->scan_exact = value != 0; return PSS_OK; }
     if (!strcmp(key, "db_exact")) { ctx->db_exact = value != 0; return PSS_OK; }
 #ifdef PSS_VARIANTS   // kernel-selection knobs for A/B measurements: variant builds only (tools/build_variant.py <name> -DPSS_VARIANTS)

@@ -44,6 +44,7 @@ struct pss_ctx {
     std::string err;
     std::map<int, double2 *> tw;       // exp(-2 pi i k / N), k < N
     std::map<int, double *> win;       // np.hamming(N)
+    std::map<int, double2 *> tw_pf;    // exp(+2 pi i k / N) as pocketfft tabulates it (pss_hilbert_pf.h), k < N
     struct Bluestein { double2 *d_chirp; double2 *d_B; double *d_win; int M; };
     std::map<int, Bluestein> bs;       // per frame length that is not a power of two (pss_fft.hip)
     std::map<double, PssNfmFilt> nfm;  // per sample rate
@@ -84,6 +85,7 @@ struct pss_ctx {
     bool no_wfm_fused = false;  // option "wfm_fused" = 0: k_wfm_front + k_nfm_iir path (A/B testing)
     long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~12000)
     long wfm_small_batch_max = 8192;  // option "wfm_small_batch_max" (measured crossover with the fused kernels ~12000 frames)
+    bool hilbert_exact = false;   // option "hilbert_exact": scipy.signal.hilbert bit for bit (pocketfft's butterfly order, pss_hilbert_pf.h) for rows of 256..16384 samples
     bool ssb_hilbert = true;   // option "ssb_hilbert": run the reference's hilbert() round trip inside demodulate_ssb where a register transform exists for the frame length
     bool db_exact = false;         // true: compute_fft's dB rows evaluated to float64 accuracy and rounded once (= float32 of the reference's float64 rows); false: float32 evaluation, 1-2 ulp off, 15-25 % faster kernels
     bool scan_exact = true;        // scanner slices: NumPy's float32 chain bit for bit (scan_db_np); false: the float64 / hardware-log2 dB of compute_fft

@@ -2436,7 +2436,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const TapsArg targ = make_taps(taps);
         pss_time_begin(ctx);
         PSS_HIP(ctx, hipMemsetAsync(mxb, 0, (size_t)n_frames * sizeof(double), PSS_STREAM(ctx)));
-        if (ctx->ssb_hilbert && pss_ssb_fused_supported(n) && !ctx->ssb_unfused) {
+        if (ctx->ssb_hilbert && pss_ssb_fused_supported(n) && !ctx->ssb_unfused && !ctx->hilbert_exact) {
             // frames of 8192 / 16 384 samples: FIR, hilbert() round trip, normalisation and PCM in ONE kernel (no float64 round trip of
             // the FIR output through HBM)
             r = pss_ssb_hilbert_fused(ctx, d_iq, n_frames, n, taps, d_audio, d_pcm);

@@ -23,6 +23,7 @@
 #include "pss_fft_xl.h"
 #include "pss_post.h"
 #include "pss_hilbert.h"
+#include "pss_hilbert_pf.h"
 
 namespace {
 
@@ -1195,11 +1196,88 @@ int hilbert_long(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_
 
 bool pss_hilbert_supported(int n) { return n >= 256 && n <= (1 << 20) && !(n & (n - 1)); }
 
+// exp(2 pi i k / n), k < n, as pocketfft's plans tabulate it (sincos_2pibyn<double>: every value the product of two entries of two small
+// tables — index & mask and index >> shift —, each entry cos / sin of a multiple of pi / (4 n) folded into the first octant; libm's cos
+// and sin in double, as in SciPy's build).  One table per length serves the real forward and the complex inverse plan (pss_hilbert_pf.h).
+static int pf_twiddles(pss_ctx *ctx, int n, const double2 **tw)
+{
+    auto it = ctx->tw_pf.find(n);
+    if (it == ctx->tw_pf.end()) {
+        const size_t N = (size_t)n;
+        const long double pi = 3.141592653589793238462643383279502884197L;
+        const double ang = (double)(0.25L * pi / (long double)n);
+        auto calc = [&](size_t x) {
+            x <<= 3;
+            if (x < 4 * N) {
+                if (x < 2 * N) {
+                    if (x < N) return make_double2(std::cos((double)x * ang), std::sin((double)x * ang));
+                    return make_double2(std::sin((double)(2 * N - x) * ang), std::cos((double)(2 * N - x) * ang));
+                }
+                x -= 2 * N;
+                if (x < N) return make_double2(-std::sin((double)x * ang), std::cos((double)x * ang));
+                return make_double2(-std::cos((double)(2 * N - x) * ang), std::sin((double)(2 * N - x) * ang));
+            }
+            x = 8 * N - x;
+            if (x < 2 * N) {
+                if (x < N) return make_double2(std::cos((double)x * ang), -std::sin((double)x * ang));
+                return make_double2(std::sin((double)(2 * N - x) * ang), -std::cos((double)(2 * N - x) * ang));
+            }
+            x -= 6 * N;
+            if (x < N) return make_double2(-std::sin((double)x * ang), -std::cos((double)x * ang));
+            return make_double2(-std::cos((double)(2 * N - x) * ang), -std::sin((double)(2 * N - x) * ang));
+        };
+        const size_t nval = (N + 2) / 2;
+        size_t shift = 1;
+        while (((size_t)1 << shift) * ((size_t)1 << shift) < nval) ++shift;
+        const size_t mask = ((size_t)1 << shift) - 1;
+        std::vector<double2> v1(mask + 1), v2((nval + mask) / (mask + 1)), h(N);
+        v1[0] = make_double2(1.0, 0.0);
+        for (size_t i = 1; i < v1.size(); i++) v1[i] = calc(i);
+        v2[0] = make_double2(1.0, 0.0);
+        for (size_t i = 1; i < v2.size(); i++) v2[i] = calc(i * (mask + 1));
+        for (size_t k = 0; k < N; k++) {
+            const size_t idx = 2 * k <= N ? k : N - k;
+            const double2 x1 = v1[idx & mask], x2 = v2[idx >> shift];
+            const volatile double a = x1.x * x2.x, b = x1.y * x2.y, c = x1.x * x2.y, d = x1.y * x2.x;   // separate products: no contraction
+            h[k] = make_double2(a - b, 2 * k <= N ? c + d : -(c + d));
+        }
+        double2 *d = nullptr;
+        PSS_HIP(ctx, hipMalloc(&d, sizeof(double2) * N));
+        PSS_HIP(ctx, hipMemcpy(d, h.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+        ctx->tw_pf[n] = d;
+    }
+    *tw = ctx->tw_pf[n];
+    return PSS_OK;
+}
+
+// option "hilbert_exact": pocketfft's own butterfly order (pss_hilbert_pf.h), rows of 256 .. 16384 samples
+static int hilbert_pf(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits,
+                      int16_t *d_pcm)
+{
+    const double2 *tw;
+    int r = pf_twiddles(ctx, n, &tw);
+    if (r) return r;
+    const size_t lds = (size_t)n * sizeof(double);
+    const int ept = n >= 1024 ? 16 : 8;
+    auto kern = n >= 16384 ? pss_pf::k_hilbert_pf<16, 1024> : (ept == 16 ? pss_pf::k_hilbert_pf<16, 512> : pss_pf::k_hilbert_pf<8, 64>);
+    if (lds > 64 * 1024)
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((160 * 1024) / (lds + 512));
+    per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+    const long cap = 256L * per_cu;
+    pss_kernel_begin(ctx, "k_hilbert");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_rows < cap ? n_rows : cap)), dim3(n / ept), lds, PSS_STREAM(ctx), d_x, d_out, tw, ilog2(n), n_rows,
+                       out_mode, d_maxbits, reinterpret_cast<unsigned *>(d_pcm));
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_hilbert_pf launch");
+}
+
 int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits,
                      int16_t *d_pcm)
 {
     if (!pss_hilbert_supported(n)) return pss_fail(ctx, PSS_E_ARG, "pss_hilbert: the row length must be a power of two in [256, 1048576]");
     if (n_rows == 0) return PSS_OK;
+    if (ctx->hilbert_exact && n <= 16384) return hilbert_pf(ctx, d_x, n_rows, n, d_out, out_mode, d_maxbits, d_pcm);
     const double2 *tw;
     const double *win;
     int r = pss_fft_tables(ctx, n, &tw, &win);

@@ -73,6 +73,7 @@ def lib():
                                       C.c_void_p, C.c_void_p]
         L.pss_o_demod_am.argtypes = [_f32p, C.c_int, _f64p, C.c_int, _f64p]
         L.pss_o_demod_ssb.argtypes = [_f32p, C.c_int, _f64p, _f64p]
+        L.pss_o_demod_ssb_ex.argtypes = [_f32p, C.c_int, _f64p, _f64p, C.c_int]
         for f in ("pss_o_hilbert", "pss_o_rfft_full", "pss_o_cifft"):
             getattr(L, f).restype = None
             getattr(L, f).argtypes = [_f64p, C.c_int, _f64p]
@@ -277,9 +278,10 @@ def demod_am(iq, sos):
     return out
 
 
-def demod_ssb(iq, taps):
+def demod_ssb(iq, taps, hilbert=True):
+    """hilbert=False: without the hilbert() round trip (the library's option "ssb_hilbert" = 0)."""
     out = np.empty(len(iq), np.float64)
-    lib().pss_o_demod_ssb(_iq(iq), len(iq), np.ascontiguousarray(taps, np.float64), out)
+    lib().pss_o_demod_ssb_ex(_iq(iq), len(iq), np.ascontiguousarray(taps, np.float64), out, 1 if hilbert else 0)
     return out
 
 

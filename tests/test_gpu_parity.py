@@ -441,9 +441,45 @@ def test_ssb_vs_golden(golden, tag, mode):
         assert np.array_equal(pcm, g[f"ssb_pcm_{tag}"]), hil
         # float64: the reference's own round trip is pocketfft, ours the register transform — both leave ~1e-16 of rounding
         assert np.allclose(audio, g[f"ssb_audio_{tag}"], rtol=0, atol=2e-14), hil
+    if True:
+        # option "hilbert_exact": pocketfft's own butterfly order — the float64 audio of the reference, every bit
+        e.set_option("hilbert_exact", 1)
+        try:
+            pcm, audio = G.demod(mode, g[f"ssb_iq_{tag}"], fs)
+        finally:
+            e.set_option("hilbert_exact", 0)
+        assert np.array_equal(pcm, g[f"ssb_pcm_{tag}"])
+        assert np.array_equal(audio, g[f"ssb_audio_{tag}"])
+        for k, iq in enumerate(g[f"ssb_iq_{tag}"]):
+            assert np.array_equal(audio[k], O.demod_ssb(iq, taps))
     for k, iq in enumerate(g[f"ssb_iq_{tag}"]):
-        assert np.array_equal(res[0][k], O.demod_ssb(iq, taps))   # without the round trip: bit-exact vs the oracle's zdot-order FIR
+        assert np.array_equal(res[0][k], O.demod_ssb(iq, taps, hilbert=False))   # without the round trip: the zdot-order FIR, bit-exact
     assert np.max(np.abs(res[1] - res[0])) < 1e-14
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_hilbert_exact_is_scipy_bit_for_bit(n):
+    """Option "hilbert_exact": pss_hilbert replays pocketfft (real radix-4 / 2 forward passes, complex radix-8 / 4 / 2 inverse passes,
+    its twiddle products): the analytic signal equals scipy.signal.hilbert — through the oracle's restatement, which is pinned to SciPy
+    bit for bit on the CPU side — on every bit; the default register transform stays within 2e-14."""
+    rng = np.random.default_rng(n)
+    rows = 5 if n < 16384 else 3
+    x = rng.standard_normal((rows, n)) * 10.0 ** rng.integers(-2, 3, size=(rows, 1))
+    x[0, ::7] = 0.0
+    e = G.engine()
+    d_x, d_out = G.dev(x), G.empty((rows, n), torch.complex128)
+    e.set_option("hilbert_exact", 1)
+    try:
+        e.hilbert(d_x, rows, n, d_out)
+        e.sync()
+    finally:
+        e.set_option("hilbert_exact", 0)
+    got = G.host(d_out)
+    want = np.stack([O.hilbert(r) for r in x])
+    assert np.array_equal(got.view(np.float64).view(np.uint64), want.view(np.float64).view(np.uint64))
+    e.hilbert(d_x, rows, n, d_out)
+    e.sync()
+    assert np.max(np.abs(G.host(d_out) - want)) < 2e-14 * np.max(np.abs(x))
 
 
 def test_ssb_on_the_reference_read_buffer_sizes():
@@ -467,7 +503,7 @@ def test_ssb_on_the_reference_read_buffer_sizes():
         assert np.array_equal(res[1][0], res[0][0]), n
         assert np.max(np.abs(res[1][1] - res[0][1])) < 1e-13, n
         taps = e.ssb_taps(fs)
-        assert np.array_equal(res[0][1][0], O.demod_ssb(iq[0], taps)), n
+        assert np.array_equal(res[0][1][0], O.demod_ssb(iq[0], taps, hilbert=False)), n
 
 
 @pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 1048576])
