@@ -1292,6 +1292,14 @@ int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double
         pss_kernel_end(ctx);
         return pss_hip_check(ctx, hipGetLastError(), "k_hilbert launch");
     };
+    auto go_xl = [&](auto kern, size_t lds, int threads, long cap) -> int {
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        pss_kernel_begin(ctx, "k_hilbert");
+        hipLaunchKernelGGL(kern, dim3((unsigned)(n_rows < cap ? n_rows : cap)), dim3(threads), lds, PSS_STREAM(ctx), d_x, d_out, tw, n_rows,
+                           d_maxbits, reinterpret_cast<unsigned *>(d_pcm), out_mode);
+        pss_kernel_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "k_hilbert_xl launch");
+    };
 #define HIL_R16(L)                                                                                                           \
     {                                                                                                                        \
         using C = pss_r16::Cfg<L>;                                                                                           \
@@ -1308,14 +1316,8 @@ int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double
     case 1024: HIL_R16(2)
     case 2048: HIL_R16(3)
     case 4096: HIL_R16(4)
-    case 8192:
-        return out_mode == 0 ? go(pss_hil::k_hilbert_xl<1, 0>, pss_xl::CfgX<1>::LDS, 512, n_rows, 512)
-             : out_mode == 1 ? go(pss_hil::k_hilbert_xl<1, 1>, pss_xl::CfgX<1>::LDS, 512, n_rows, 512)
-                             : go(pss_hil::k_hilbert_xl<1, 2>, pss_xl::CfgX<1>::LDS, 512, n_rows, 512);
-    default:
-        return out_mode == 0 ? go(pss_hil::k_hilbert_xl<2, 0>, pss_xl::CfgX<2>::LDS, 1024, n_rows, 256)
-             : out_mode == 1 ? go(pss_hil::k_hilbert_xl<2, 1>, pss_xl::CfgX<2>::LDS, 1024, n_rows, 256)
-                             : go(pss_hil::k_hilbert_xl<2, 2>, pss_xl::CfgX<2>::LDS, 1024, n_rows, 256);
+    case 8192: return go_xl(pss_hil::k_hilbert_xl<1>, pss_xl::CfgX<1>::LDS, 512, 512);
+    default: return go_xl(pss_hil::k_hilbert_xl<2>, pss_xl::CfgX<2>::LDS, 1024, 256);
     }
 #undef HIL_R16
 }

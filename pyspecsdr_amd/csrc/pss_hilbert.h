@@ -126,10 +126,12 @@ __global__ __launch_bounds__(256) void k_hilbert_r16(const double *x, double *ou
 }
 
 // N = 4096 * R4 (R4 = 2, 4): one workgroup of T = N / 16 threads per frame
-template <int LOG_R4, int OUT>
+// (OUT is a launch argument here, not a template parameter: the epilogue is a few stores per value; three instantiations per length
+// were 75 KB of code object)
+template <int LOG_R4>
 __global__ __launch_bounds__(256 << LOG_R4, 4) void k_hilbert_xl(const double *x, double *out,
                                                                  const double2 *__restrict__ tw, long n_rows,
-                                                                 unsigned long long *__restrict__ mxbits, unsigned *__restrict__ pcm)
+                                                                 unsigned long long *__restrict__ mxbits, unsigned *__restrict__ pcm, int OUT)
 {
     __shared__ double red[2][16];            // OUT = 2: wave maxima, double-buffered by loop parity
     using C = pss_xl::CfgX<LOG_R4>;
@@ -156,21 +158,23 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_hilbert_xl(const double *x
         double m = 0.0;
         pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int, int j, int k, double2 W) {
             const int q = j + (16 / R4) * k;
-            const double re = W.x * INV_N, im = -(W.y * INV_N);
-            if (OUT == 0) {
-                const unsigned lo = (unsigned)__double2loint(re), hi = (unsigned)__double2hiint(re);
-                const unsigned li = (unsigned)__double2loint(im), hj = (unsigned)__double2hiint(im);
-                typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-                v4u_t pk = {lo, hi, li, hj};
-                __builtin_amdgcn_raw_buffer_store_b128(pk, ro, t * 16, T * q * 16, 0);
-            } else if (OUT == 1) {
-                pss_xl::v2u_t pk = {(unsigned)__double2loint(re), (unsigned)__double2hiint(re)};
-                __builtin_amdgcn_raw_buffer_store_b64(pk, ro, t * 8, T * q * 8, 0);
-            } else {
-                y[q].x = re;
-            }
-            m = nanmax(m, fabs(re));
+            y[q] = make_double2(W.x * INV_N, -(W.y * INV_N));
+            m = nanmax(m, fabs(y[q].x));
         });
+        if (OUT == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+                v4u_t pk = {(unsigned)__double2loint(y[q].x), (unsigned)__double2hiint(y[q].x), (unsigned)__double2loint(y[q].y), (unsigned)__double2hiint(y[q].y)};
+                __builtin_amdgcn_raw_buffer_store_b128(pk, ro, t * 16, T * q * 16, 0);
+            }
+        } else if (OUT == 1) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                pss_xl::v2u_t pk = {(unsigned)__double2loint(y[q].x), (unsigned)__double2hiint(y[q].x)};
+                __builtin_amdgcn_raw_buffer_store_b64(pk, ro, t * 8, T * q * 8, 0);
+            }
+        }
         if (OUT == 2) {
             // frame peak over the workgroup (= the frame), then demodulate_ssb's normalisation and the int16 conversion from registers
             for (int off = 32; off > 0; off >>= 1) m = nanmax(m, __shfl_xor(m, off));

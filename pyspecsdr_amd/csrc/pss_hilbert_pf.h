@@ -188,9 +188,10 @@ __global__ __launch_bounds__(MAXT) void k_hilbert_pf(const double *x, double *ou
                 for (int e = 0; e < EPT; e++) {
                     const int b = cc_addr(e);
                     const bool low = b > 0 && b < (N >> 1);
-                    const double pr = A[low ? 2 * b - 1 : (b == 0 ? 0 : N - 1)], pq = A[low ? 2 * b : 0];
-                    re[e] = low ? 2.0 * pr : ((b == 0 || b == (N >> 1)) ? pr : 0.0);
-                    im[e] = low ? 2.0 * pq : 0.0;
+                    // (scale factors instead of selects on the products: branch-free; x * 1.0 and x * 0.0 are what SciPy's X * h does)
+                    const double sr = low ? 2.0 : ((b == 0 || b == (N >> 1)) ? 1.0 : 0.0), sq = low ? 2.0 : 0.0;
+                    re[e] = A[low ? 2 * b - 1 : (b == 0 ? 0 : N - 1)] * sr;
+                    im[e] = A[low ? 2 * b : 0] * sq;
                 }
             }                                        // later passes: the exchange behind the previous pass has filled re[] / im[]
             auto bmul = [&](c2 v, int j, int i) {
