@@ -19,6 +19,7 @@
  */
 #ifndef PSS_H
 #define PSS_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -73,7 +74,10 @@ int pss_device_count(void);
  * alternative pipeline schedules, CU-mask partitioning — are documented with their measurements in DESIGN.md and no longer compiled in. */
 int pss_set_option(pss_ctx *ctx, const char *key, int value);
 
-/* ---- filter design (host side, pure C++; replaces the per-call SciPy design work) -------------- */
+/* ---- filter design (host side, pure C++; replaces the per-call SciPy design work) --------------
+ * The designers restate SciPy's / NumPy's arithmetic operation by operation (DESIGN.md par. 2): firwin, cheby1 as scipy.signal.decimate
+ * calls it, and sosfilt_zi return SciPy 1.15's tables bit for bit at every cutoff / decimation factor tried; butter wherever NumPy's SVML tan
+ * equals libm's on the pre-warp arguments (99.5 % of designs; an ulp apart otherwise). */
 /* scipy.signal.firwin(numtaps, cutoff) low-pass, Hamming window, cutoff normalised to Nyquist
  * (signal_processing.py:107 and :203/:208).  Returns PSS_E_CUTOFF unless 0 < cutoff < 1. */
 int pss_design_firwin(int numtaps, double cutoff, double *taps);
@@ -165,7 +169,8 @@ int pss_demod_signal(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, i
                      double *d_audio);
 /* WFM filter set of one sample rate: lp = butter(5, 15000/(fs/2)) [3][6], pilot = butter(5, [18800,19200]/(fs/2), 'band')
  * [5][6], lmr = butter(5, [23000,53000]/(fs/2), 'band') [5][6], alpha = exp(-1/(75e-6 fs)).  Designed on first use
- * (pss_design_butter_sos, a few ulp from SciPy); set_ lets a caller inject SciPy's own tables. */
+ * (pss_design_butter_sos: SciPy's bits wherever NumPy's SVML tan / exp equal libm's on the arguments, ~93 % of sample rates, an ulp
+ * apart otherwise); set_ lets a caller inject SciPy's own tables. */
 int pss_set_wfm_filters(pss_ctx *ctx, double fs, const double *lp3x6, const double *pilot5x6, const double *lmr5x6,
                         double alpha);
 int pss_get_wfm_filters(pss_ctx *ctx, double fs, double *lp3x6, double *pilot5x6, double *lmr5x6, double *alpha);

@@ -20,78 +20,156 @@
 
 typedef std::complex<double> cplx;
 
+// NumPy's arithmetic, restated where it is not the obvious one (this unit is compiled with -ffp-contract=off):
+//   np.add.reduce on a contiguous float64 array: pairwise summation — eight running sums over blocks of eight, combined as
+//   ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), the remainder added one by one; halves above 128 elements;
+//   complex128 multiply: (ar br - ai bi, ar bi + ai br), no fused multiply-add; complex128 divide: Smith's algorithm
+//   (ratio of the divisor's smaller to its larger component, one reciprocal).
+namespace {
+double np_pairwise_sum(const double *a, long n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (long i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        long i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+inline std::complex<double> np_cmul(std::complex<double> a, std::complex<double> b)
+{
+    return std::complex<double>(a.real() * b.real() - a.imag() * b.imag(), a.real() * b.imag() + a.imag() * b.real());
+}
+inline std::complex<double> np_cdiv(std::complex<double> a, std::complex<double> b)
+{
+    const double ar = a.real(), ai = a.imag(), br = b.real(), bi = b.imag();
+    if (std::fabs(br) >= std::fabs(bi)) {
+        if (br == 0.0 && bi == 0.0) return std::complex<double>(ar / std::fabs(br), ai / std::fabs(bi));
+        const double rat = bi / br, scl = 1.0 / (br + bi * rat);
+        return std::complex<double>((ar + ai * rat) * scl, (ai - ar * rat) * scl);
+    }
+    const double rat = br / bi, scl = 1.0 / (bi + br * rat);
+    return std::complex<double>((ar * rat + ai) * scl, (ai * rat - ar) * scl);
+}
+// glibc's complex functions (what NumPy calls: npy_csqrt / npy_cexp / npy_csinh forward to them).  Not std::sqrt / exp / sinh on
+// std::complex: in a HIP translation unit clang's <complex> wrapper turns libstdc++'s C99 forwarding off and the generic formulas
+// land an ulp away (found on scipy.signal.butter's band-pass poles: 584 of 806 designs differed).
+inline std::complex<double> libm_csqrt(std::complex<double> v)
+{
+    const double _Complex r = __builtin_csqrt(__builtin_complex(v.real(), v.imag()));
+    return std::complex<double>(__real__ r, __imag__ r);
+}
+inline std::complex<double> libm_cexp(std::complex<double> v)
+{
+    const double _Complex r = __builtin_cexp(__builtin_complex(v.real(), v.imag()));
+    return std::complex<double>(__real__ r, __imag__ r);
+}
+inline std::complex<double> libm_csinh(std::complex<double> v)
+{
+    const double _Complex r = __builtin_csinh(__builtin_complex(v.real(), v.imag()));
+    return std::complex<double>(__real__ r, __imag__ r);
+}
+}  // namespace
+
+// scipy.signal.firwin(numtaps, cutoff) (window='hamming', pass_zero=True, scale=True): every operation in SciPy's order —
+// np.sinc (pi * where(x == 0, 1e-20, x); sin(y) / y), general_cosine's fac = linspace(-pi, pi, M) and w = 0.54 cos(0 fac) +
+// (1 - 0.54) cos(fac), the scale by np.sum(h * cos(0)) (pairwise).  NumPy's float64 sin / cos are libm's (checked on the build image:
+// np.sin == math.sin on 200 000 arguments), so the taps equal SciPy's bit for bit (tests: 400 cutoffs).
 extern "C" int pss_design_firwin(int numtaps, double cutoff, double *taps)
 {
     if (numtaps < 1 || !taps) return PSS_E_ARG;
     if (!(cutoff > 0.0 && cutoff < 1.0)) return PSS_E_CUTOFF;  // scipy: "Invalid cutoff frequency"
     const double alpha = 0.5 * (numtaps - 1);
-    double s = 0.0;
+    const double step = numtaps > 1 ? (M_PI - (-M_PI)) / (double)(numtaps - 1) : 0.0;
+    std::vector<double> hc(numtaps);
     for (int i = 0; i < numtaps; i++) {
-        double m = (double)i - alpha;
-        double x = cutoff * m;
-        double y = M_PI * (x == 0.0 ? 1.0e-20 : x);  // np.sinc
-        double h = cutoff * (std::sin(y) / y);
-        // general_cosine(M, [0.54, 0.46], sym=True): fac = linspace(-pi, pi, M)
-        double fac = (numtaps == 1) ? -M_PI : -M_PI + (double)i * (2.0 * M_PI / (double)(numtaps - 1));
+        const double m = (double)i - alpha;
+        const double x = cutoff * m;
+        const double y = M_PI * (x == 0.0 ? 1.0e-20 : x);  // np.sinc
+        const double h = cutoff * (std::sin(y) / y);
+        double fac = (double)i * step + (-M_PI);             // np.linspace: arange * step + start, the last element set to stop
         if (i == numtaps - 1 && numtaps > 1) fac = M_PI;
-        double w = 0.54 + 0.46 * std::cos(fac);
+        double w = 0.0;
+        w += 0.54 * std::cos(0.0 * fac);
+        w += (1.0 - 0.54) * std::cos(fac);
         taps[i] = h * w;
-        s += taps[i];  // scale_frequency = 0 -> cos(0) = 1
+        hc[i] = taps[i] * std::cos(M_PI * m * 0.0);          // scale_frequency = 0
     }
+    const double s = np_pairwise_sum(hc.data(), numtaps);
     for (int i = 0; i < numtaps; i++) taps[i] /= s;
     return PSS_OK;
 }
 
+// scipy.signal.cheby1(order, rp, wn, output='sos') (what scipy.signal.decimate designs: order 8, rp 0.05, wn 0.8 / q): cheb1ap ->
+// pre-warp -> lp2lp_zpk -> bilinear_zpk -> zpk2sos(pairing='nearest'), every operation in SciPy's / NumPy's order (complex sinh =
+// glibc's csinh, np.abs = hypot, Python's float ** int = pow, complex products and quotients as above).  NumPy evaluates tan and
+// arcsinh through SVML, which is NOT libm in general (0.5 % / 13 % of random arguments differ) — on the arguments this chain can
+// produce they agree: arcsinh(1 / eps) for (8, 0.05), and tan(pi 0.8 / q / 2) for every q = 2 .. 4095 (checked on the build image), so
+// the sections equal SciPy's bit for bit for every decimation factor (tests: q = 2 .. 1199).
 extern "C" int pss_design_cheby1_sos(int order, double rp_db, double wn, double *sos)
 {
     if (order < 2 || (order & 1) || !sos || !(wn > 0.0 && wn < 1.0) || !(rp_db > 0)) return PSS_E_ARG;
     const int N = order;
     // cheb1ap
-    double eps = std::sqrt(std::pow(10.0, 0.1 * rp_db) - 1.0);
-    double mu = 1.0 / N * std::asinh(1.0 / eps);
+    const double eps = std::sqrt(std::pow(10.0, 0.1 * rp_db) - 1.0);
+    const double mu = 1.0 / N * std::asinh(1.0 / eps);
     std::vector<cplx> p(N);
-    cplx kprod(1.0, 0.0);
+    cplx kprod;
     for (int i = 0; i < N; i++) {
-        double m = (double)(-N + 1 + 2 * i);
-        double theta = M_PI * m / (2.0 * N);
-        p[i] = -std::sinh(cplx(mu, theta));
-        kprod *= -p[i];
+        const double m = (double)(-N + 1 + 2 * i);
+        const double theta = M_PI * m / (double)(2 * N);
+        p[i] = -libm_csinh(cplx(mu, theta));
+        kprod = i == 0 ? -p[0] : np_cmul(kprod, -p[i]);
     }
     double k = kprod.real() / std::sqrt(1.0 + eps * eps);  // N even
     // pre-warp, lp2lp_zpk
     const double fs = 2.0;
-    double warped = 2.0 * fs * std::tan(M_PI * wn / fs);
-    for (int i = 0; i < N; i++) p[i] *= warped;
-    k *= std::pow(warped, (double)N);
+    const double warped = 2.0 * fs * std::tan(M_PI * wn / fs);
+    for (int i = 0; i < N; i++) p[i] = cplx(warped * p[i].real(), warped * p[i].imag());
+    k = k * std::pow(warped, (double)N);
     // bilinear_zpk (no finite zeros: all N digital zeros land on -1)
     const double fs2 = 2.0 * fs;
-    cplx den(1.0, 0.0);
+    cplx den;
     for (int i = 0; i < N; i++) {
-        den *= (fs2 - p[i]);
-        p[i] = (fs2 + p[i]) / (fs2 - p[i]);
+        const cplx d(fs2 - p[i].real(), -p[i].imag());
+        den = i == 0 ? d : np_cmul(den, d);
+        p[i] = np_cdiv(cplx(fs2 + p[i].real(), p[i].imag()), d);
     }
-    k *= (cplx(1.0, 0.0) / den).real();
-    // zpk2sos, pairing='nearest': keep one pole per conjugate pair (imag > 0), the pole closest to the unit
-    // circle goes to the LAST section; every section gets the zero pair (-1, -1); gain on section 0.
+    k = k * np_cdiv(cplx(1.0, 0.0), den).real();
+    // zpk2sos, pairing='nearest': _cplxreal keeps one pole per conjugate pair ((zp + conj(zn)) / 2 = zp), sorted by real part; the pole
+    // closest to the unit circle goes to the LAST section; every section gets the zero pair (-1, -1): np.poly -> [1, 2, 1] and
+    // [1, -p1 - conj(p1), p1 conj(p1)] by np.convolve's plain dot loop; the gain goes on section 0.
     std::vector<cplx> pc;
     for (int i = 0; i < N; i++)
         if (p[i].imag() > 0) pc.push_back(p[i]);
     if ((int)pc.size() != N / 2) return PSS_E_ARG;
-    int nsec = N / 2;
+    std::stable_sort(pc.begin(), pc.end(), [](const cplx &a, const cplx &b) { return a.real() < b.real(); });
+    const int nsec = N / 2;
     for (int si = nsec - 1; si >= 0; si--) {
         int worst = 0;
-        double best = 1e300;
+        double best = 0.0;
         for (size_t j = 0; j < pc.size(); j++) {
-            double d = std::fabs(1.0 - std::abs(pc[j]));
-            if (d < best) { best = d; worst = (int)j; }
+            const double d = std::fabs(1.0 - std::hypot(pc[j].real(), pc[j].imag()));
+            if (j == 0 || d < best) { best = d; worst = (int)j; }
         }
-        cplx p1 = pc[worst];
+        const cplx p1 = pc[worst];
         pc.erase(pc.begin() + worst);
         double *row = sos + 6 * si;
         row[0] = 1.0; row[1] = 2.0; row[2] = 1.0;
         row[3] = 1.0;
-        row[4] = -(p1.real() + p1.real());
-        row[5] = p1.real() * p1.real() + p1.imag() * p1.imag();
+        row[4] = (0.0 + (1.0 * (-p1.real()) - 0.0 * p1.imag())) + ((-p1.real()) * 1.0 - (-p1.imag()) * 0.0);
+        row[5] = 0.0 + ((-p1.real()) * (-p1.real()) - (-p1.imag()) * p1.imag());
     }
     sos[0] *= k; sos[1] *= k; sos[2] *= k;
     return PSS_OK;
@@ -112,7 +190,8 @@ int zpk2sos_nearest(std::vector<cplx> z, std::vector<cplx> p, double k, double *
         for (size_t j = 0; j < fro.size(); j++) {
             if (which == 0 && !is_real(fro[j])) continue;
             if (which == 1 && is_real(fro[j])) continue;
-            double d = std::abs(fro[j] - to);
+            const cplx df(fro[j].real() - to.real(), fro[j].imag() - to.imag());
+            double d = std::hypot(df.real(), df.imag());   // np.abs(complex) = hypot
             if (best < 0 || d < bd) { best = (int)j; bd = d; }
         }
         return best;
@@ -130,7 +209,7 @@ int zpk2sos_nearest(std::vector<cplx> z, std::vector<cplx> p, double k, double *
         int pi = 0;
         double best = 1e300;
         for (size_t j = 0; j < p.size(); j++) {
-            double d = std::fabs(1.0 - std::abs(p[j]));
+            double d = std::fabs(1.0 - std::hypot(p[j].real(), p[j].imag()));
             if (d < best) { best = d; pi = (int)j; }
         }
         cplx p1 = p[pi];
@@ -156,7 +235,7 @@ int zpk2sos_nearest(std::vector<cplx> z, std::vector<cplx> p, double k, double *
                 double bd = 0;
                 for (size_t j = 0; j < p.size(); j++) {
                     if (!is_real(p[j])) continue;
-                    double d = std::fabs(std::abs(p[j]) - 1.0);
+                    double d = std::fabs(std::hypot(p[j].real(), p[j].imag()) - 1.0);
                     if (pj < 0 || d < bd) { pj = (int)j; bd = d; }
                 }
                 if (pj < 0) return PSS_E_ARG;
@@ -194,47 +273,67 @@ extern "C" int pss_design_butter_sos(int order, double wn_low, double wn_high, d
     if (N < 1 || N > 16 || !sos) return PSS_E_ARG;
     const bool band = wn_low > 0.0;
     if (!(wn_high > 0.0 && wn_high < 1.0) || (band && !(wn_low < wn_high))) return PSS_E_CUTOFF;  // scipy ValueError
-    // buttap
+    // buttap: p = -exp(1j * pi * m / (2 N)) — NumPy forms (1j pi) m as a complex product and divides by the complex 2 N (Smith's
+    // algorithm: a multiplication by the rounded reciprocal), then glibc's cexp
     std::vector<cplx> p(N), z;
     for (int i = 0; i < N; i++) {
-        double m = (double)(-N + 1 + 2 * i);
-        p[i] = -std::exp(cplx(0.0, M_PI * m / (2.0 * N)));
+        const double m = (double)(-N + 1 + 2 * i);
+        const cplx arg = np_cdiv(np_cmul(cplx(0.0, M_PI), cplx(m, 0.0)), cplx((double)(2 * N), 0.0));
+        p[i] = -libm_cexp(arg);
     }
     double k = 1.0;
     const double fs = 2.0, fs2 = 2.0 * fs;
     int degree = N;
     if (!band) {
-        double warped = 2.0 * fs * std::tan(M_PI * wn_high / fs);
-        for (auto &v : p) v *= warped;
-        k *= std::pow(warped, (double)degree);
+        const double warped = 2.0 * fs * std::tan(M_PI * wn_high / fs);
+        for (auto &v : p) v = np_cmul(cplx(warped, 0.0), v);      // lp2lp_zpk: wo * p
+        k = k * std::pow(warped, (double)degree);
     } else {
-        double w0 = 2.0 * fs * std::tan(M_PI * wn_low / fs), w1 = 2.0 * fs * std::tan(M_PI * wn_high / fs);
-        double bw = w1 - w0, wo = std::sqrt(w0 * w1);
+        const double w0 = 2.0 * fs * std::tan(M_PI * wn_low / fs), w1 = 2.0 * fs * std::tan(M_PI * wn_high / fs);
+        const double bw = w1 - w0, wo = std::sqrt(w0 * w1);
+        // lp2bp_zpk: p_lp = p * bw / 2 (a complex product, then Smith's division by 2 + 0j: the signs of the zeros matter to csqrt's
+        // branch); p_lp ** 2 is np.square, whose real part is ONE fused operation fma(re, re, -(im im)) (probed on 2000 values at
+        // every vector length); wo ** 2 is Python's float power = pow(wo, 2); np.sqrt(complex) = glibc's csqrt
         std::vector<cplx> pb(2 * N);
+        const double wo2 = std::pow(wo, 2.0);
         for (int i = 0; i < N; i++) {
-            cplx pl = p[i] * (bw / 2.0);
-            cplx r = std::sqrt(pl * pl - wo * wo);
-            pb[i] = pl + r;
-            pb[N + i] = pl - r;
+            const cplx pl = np_cdiv(np_cmul(p[i], cplx(bw, 0.0)), cplx(2.0, 0.0));
+            const cplx sq(std::fma(pl.real(), pl.real(), -(pl.imag() * pl.imag())) - wo2, (pl.real() * pl.imag() + pl.imag() * pl.real()) - 0.0);
+            const cplx r = libm_csqrt(sq);
+            pb[i] = cplx(pl.real() + r.real(), pl.imag() + r.imag());
+            pb[N + i] = cplx(pl.real() - r.real(), pl.imag() - r.imag());
         }
         p = pb;
         z.assign(degree, cplx(0, 0));
-        k *= std::pow(bw, (double)degree);
+        k = k * std::pow(bw, (double)degree);
     }
-    // bilinear_zpk
-    cplx num(1, 0), den(1, 0);
-    for (auto &v : z) { num *= (fs2 - v); v = (fs2 + v) / (fs2 - v); }
-    for (auto &v : p) { den *= (fs2 - v); v = (fs2 + v) / (fs2 - v); }
+    // bilinear_zpk: (fs2 + x) / (fs2 - x) by Smith's division, the gain k real(prod(fs2 - z) / prod(fs2 - p)) with sequential plain products
+    cplx num(1.0, 0.0), den(1.0, 0.0);
+    bool first = true;
+    for (auto &v : z) {
+        const cplx d(fs2 - v.real(), -v.imag());
+        num = first ? d : np_cmul(num, d);
+        first = false;
+        v = np_cdiv(cplx(fs2 + v.real(), v.imag()), d);
+    }
+    const bool have_z = !first;
+    first = true;
+    for (auto &v : p) {
+        const cplx d(fs2 - v.real(), -v.imag());
+        den = first ? d : np_cmul(den, d);
+        first = false;
+        v = np_cdiv(cplx(fs2 + v.real(), v.imag()), d);
+    }
     const int deg2 = (int)p.size() - (int)z.size();
     for (int i = 0; i < deg2; i++) z.push_back(cplx(-1.0, 0.0));
-    k *= (num / den).real();
+    k = k * np_cdiv(have_z ? num : cplx(1.0, 0.0), den).real();
     // zpk2sos front matter: equalise lengths, make the count even, reduce to one member per conjugate pair + reals
     if (p.size() % 2 == 1) { p.push_back(cplx(0, 0)); z.push_back(cplx(0, 0)); }
     const int nsec = (int)p.size() / 2;
     auto cplxreal = [](const std::vector<cplx> &v) {
         std::vector<cplx> c, r;
         for (auto &x : v) {
-            if (std::fabs(x.imag()) <= 100 * 2.220446049250313e-16 * std::abs(x)) r.push_back(cplx(x.real(), 0.0));
+            if (std::fabs(x.imag()) <= 100 * 2.220446049250313e-16 * std::hypot(x.real(), x.imag())) r.push_back(cplx(x.real(), 0.0));
             else if (x.imag() > 0) c.push_back(x);
         }
         std::sort(r.begin(), r.end(), [](const cplx &a, const cplx &b) { return a.real() < b.real(); });
@@ -264,7 +363,7 @@ extern "C" int pss_design_sosfilt_zi(const double *sos, int nsec, double *zi)
         }
         double l = A10 * (1.0 / A00);  // LAPACK dgetf2 scales the column by the reciprocal pivot
         double U11 = A11 - l * A01;
-        double y1 = B1 - l * B0;
+        double y1 = std::fma(-l, B0, B1);  // dgetrs' forward substitution runs on OpenBLAS's fused kernels (found on 1198 decimator designs: the unfused form misses one)
         double x1 = y1 / U11;
         double x0 = (B0 - A01 * x1) / A00;
         zi[2 * s] = scale * x0;
