@@ -52,7 +52,7 @@ bad = 0
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 for it in range(cases):
     nf = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 130, 300]))
-    n = int(rng.choice([29, 64, 129, 257, 1000, 1024, 2049, 4096, 9000, 33000]))
+    n = int(rng.choice([29, 64, 129, 256, 257, 512, 1000, 1024, 2048, 2049, 4096, 8192, 9000, 16384, 33000]))
     fs = float(rng.choice([2.4e6, 1.024e6, 2.048e6, 250e3, 10e6]))
     iq = rnd_iq(nf, n)
     pick = sorted(set([0, nf - 1, int(rng.integers(0, nf))]))
@@ -79,12 +79,18 @@ for it in range(cases):
         pcm2, au2 = G.demod(L.MODE_USB, iq, fs)  # frames of 256..16384 samples): the same int16, float64 within the round trip's rounding
         e.set_option("ssb_hilbert", 1)
         pcm3, au3 = G.demod(L.MODE_USB, iq, fs)
+        au4 = None
+        if n & (n - 1) == 0 and 256 <= n <= 16384:   # option "hilbert_exact": SciPy's hilbert() replayed — the reference's float64 audio, every bit
+            e.set_option("hilbert_exact", 1)
+            pcm4, au4 = G.demod(L.MODE_USB, iq, fs)
+            e.set_option("hilbert_exact", 0)
         d_p = G.empty((nf,), torch.float32); e.power_db(G.dev(iq), nf, n, d_p)
         d_c = G.empty((nf, n, 2), torch.float32); e.iq_correction(G.dev(iq), nf, n, d_c, None); e.sync()
         p = G.host(d_p); corr = G.host(d_c).reshape(nf, -1).view(np.complex64)
         for f in pick:
             if not np.array_equal(au[f], O.demod_am(iq[f], am), equal_nan=True): bad += 1; print("AM", nf, n, f)
             if not np.array_equal(au2[f], O.demod_ssb(iq[f], stp, hilbert=False), equal_nan=True): bad += 1; print("SSB", nf, n, f)
+            if au4 is not None and not np.array_equal(au4[f], O.demod_ssb(iq[f], stp), equal_nan=True): bad += 1; print("SSB hilbert_exact", nf, n, f)
             if not np.array_equal(pcm3[f], pcm2[f]): bad += 1; print("SSB-hilbert int16", nf, n, f, int((pcm3[f] != pcm2[f]).sum()))
             if not np.allclose(au3[f], au2[f], rtol=0, atol=1e-13, equal_nan=True): bad += 1; print("SSB-hilbert f64", nf, n, f, np.nanmax(np.abs(au3[f] - au2[f])))
             ref = O.iq_correction(iq[f])   # NaN payloads / signs differ between x86 and the GPU: compare values, NaN == NaN
