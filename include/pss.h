@@ -76,8 +76,8 @@ int pss_set_option(pss_ctx *ctx, const char *key, int value);
 
 /* ---- filter design (host side, pure C++; replaces the per-call SciPy design work) --------------
  * The designers restate SciPy's / NumPy's arithmetic operation by operation (DESIGN.md par. 2): firwin, cheby1 as scipy.signal.decimate
- * calls it, and sosfilt_zi return SciPy 1.15's tables bit for bit at every cutoff / decimation factor tried; butter wherever NumPy's SVML tan
- * equals libm's on the pre-warp arguments (99.5 % of designs; an ulp apart otherwise). */
+ * calls it, sosfilt_zi and butter return SciPy 1.15's tables bit for bit at every cutoff / decimation factor / sample rate tried (the pre-warp
+ * tan is NumPy's SVML routine restated, pss_h_np_f64). */
 /* scipy.signal.firwin(numtaps, cutoff) low-pass, Hamming window, cutoff normalised to Nyquist
  * (signal_processing.py:107 and :203/:208).  Returns PSS_E_CUTOFF unless 0 < cutoff < 1. */
 int pss_design_firwin(int numtaps, double cutoff, double *taps);
@@ -90,6 +90,9 @@ int pss_design_cheby1_sos(int order, double rp_db, double wn, double *sos);
 int pss_design_butter_sos(int order, double wn_low, double wn_high, double *sos, int *nsec);
 /* scipy.signal.sosfilt_zi(sos).  zi[nsec][2]. */
 int pss_design_sosfilt_zi(const double *sos, int nsec, double *zi);
+/* NumPy's float64 tan (op 0) / exp (op 1) as the reference's SciPy calls evaluate them (NumPy's AVX512_SKX dispatch: SVML, an ulp from libm
+ * on 0.5 % / 5 % of arguments) — the two primitives the designers need beyond libm; host arrays. */
+int pss_h_np_f64(int op, const double *x, long n, double *out);
 /* butter(5, [300, 3000]/(22050/2), 'band', output='sos') — the fixed AM filter (signal_processing.py:188-191,
  * :39-41; pyspecconst.py:3,5).  sos[5][6]. */
 int pss_am_bandpass_sos(double *sos);
@@ -169,8 +172,7 @@ int pss_demod_signal(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, i
                      double *d_audio);
 /* WFM filter set of one sample rate: lp = butter(5, 15000/(fs/2)) [3][6], pilot = butter(5, [18800,19200]/(fs/2), 'band')
  * [5][6], lmr = butter(5, [23000,53000]/(fs/2), 'band') [5][6], alpha = exp(-1/(75e-6 fs)).  Designed on first use
- * (pss_design_butter_sos: SciPy's bits wherever NumPy's SVML tan / exp equal libm's on the arguments, ~93 % of sample rates, an ulp
- * apart otherwise); set_ lets a caller inject SciPy's own tables. */
+ * (pss_design_butter_sos and NumPy's exp restated: SciPy 1.15's / NumPy's bits); set_ lets a caller inject another SciPy build's tables. */
 int pss_set_wfm_filters(pss_ctx *ctx, double fs, const double *lp3x6, const double *pilot5x6, const double *lmr5x6,
                         double alpha);
 int pss_get_wfm_filters(pss_ctx *ctx, double fs, double *lp3x6, double *pilot5x6, double *lmr5x6, double *alpha);

@@ -61,6 +61,7 @@ _SIGS = {
     "pss_frame_pipeline_nfm_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "pss_spectrum_db_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
     "pss_spectrum_post_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, _p]),
+    "pss_h_np_f64": (C.c_int, [C.c_int, _p, C.c_long, _p]),
     "pss_waterfall_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "pss_persistence_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "pss_spectrogram_cells": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_int, C.c_int, _p, _p, _p]),

@@ -164,4 +164,7 @@ int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double
                      int16_t *d_pcm);
 int pss_fft_tables(pss_ctx *ctx, int n, const double2 **tw, const double **win);
 bool pss_ssb_fused_supported(int n);
+// NumPy's float64 tan / exp under its AVX512_SKX dispatch (SVML's _ha routines restated, pss_design.cpp)
+double pss_np_tan(double x);
+double pss_np_exp(double x);
 int pss_ssb_hilbert_fused(pss_ctx *ctx, const float *d_iq, long n_rows, int n, const double *taps65, double *d_audio, int16_t *d_pcm);

@@ -2130,7 +2130,7 @@ int wfm_filters(pss_ctx *ctx, double fs, PssWfmFilt **out)
         if (!r) r = pss_design_butter_sos(5, (38000.0 - 15000.0) / nyq, (38000.0 + 15000.0) / nyq, f.lmr, nullptr);
         // scipy: "Digital filter critical frequencies must be 0 < Wn < 1" (53 kHz must be below fs/2)
         if (r) return pss_fail(ctx, r, "butter: digital filter critical frequencies must be 0 < Wn < 1 (WFM needs fs > 106 kHz)");
-        f.alpha = exp(-1.0 / (75e-6 * fs));
+        f.alpha = pss_np_exp(-1.0 / (75e-6 * fs));   // np.exp, not libm's (signal_processing.py:145)
         ctx->wfm[fs] = f;
     }
     *out = &ctx->wfm[fs];

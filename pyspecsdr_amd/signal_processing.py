@@ -44,8 +44,8 @@ def get_engine(device=0):
 
 # ---- coefficient tables --------------------------------------------------------------------------------------------
 # The reference designs its filters with SciPy on every call; libpss.so designs them natively once per sample rate
-# (pss_design_*): SciPy's own bits for NFM / SSB / AM, and for WFM wherever NumPy's SVML tan / exp equal glibc's on the
-# arguments (~93 % of sample rates).  A host that runs the reference has SciPy by definition, so this shim asks THAT SciPy for the tables once
+# (pss_design_*): SciPy 1.15's own bits on NumPy's AVX512_SKX dispatch (DESIGN.md par. 2).  A host that runs the reference has SciPy by
+# definition, so this shim asks THAT SciPy — whatever its version and NumPy's dispatch — for the tables once
 # per sample rate and injects them (pss_set_*_filters): the GPU path then reproduces the reference's float64 bits
 # whatever SciPy version the host carries.  Only the coefficient design happens here — never sample data.
 USE_SCIPY_DESIGNS = True

@@ -7,6 +7,7 @@ Bars: int16 PCM bit-exact; float64 audio bit-exact for NFM/AM (SSB: 2e-14, the r
 round trip); float32 dB within 1e-4 RELATIVE of the reference's float64 value.
 """
 import json
+import math
 
 import numpy as np
 import pytest
@@ -694,21 +695,29 @@ def test_wfm_vs_golden_bit_exact(golden, tag):
 
 
 def test_wfm_designed_filters_and_shim(golden):
-    # library-designed Butterworth/cheby1 tables (a few ulp from SciPy's): int16 identical, float64 within 1e-9
+    # library-designed tables: SciPy's bits since round 3 (the designers restate SciPy's / NumPy's arithmetic incl. NumPy's SVML tan / exp),
+    # so a context that never saw a SciPy table produces the reference's float64 audio and int16 PCM bit for bit
     g = golden["wfm"]
     from pyspecsdr_amd.engine import Engine
     e2 = Engine(0)
     for tag in ("a", "c", "d", "e"):
         fs = float(g[f"fs_{tag}"])
+        lp, pil, lmr, alpha = e2.wfm_filters(fs)
+        key = str(int(fs))
+        assert np.array_equal(lp, g[f"lp_sos_{key}"]) and np.array_equal(pil, g[f"pilot_sos_{key}"]) and np.array_equal(lmr, g[f"lmr_sos_{key}"])
+        assert alpha == float(np.exp(-1 / (75e-6 * fs)))
         pcm, audio = _wfm(e2, g[f"iq_{tag}"], fs)
-        want, wpcm = g[f"audio_{tag}"], g[f"pcm_{tag}"]
-        assert np.allclose(audio, want, rtol=0, atol=1e-9)
-        # int16 identical, except possibly the frame's peak sample: the reference normalises BOTH channels by the larger
-        # of two peaks that differ by ~1e-17, so which channel reads 32767 and which 32766 there is decided by the last
-        # bit of the coefficient tables (inject SciPy's tables for bit-exactness, as the test above does)
-        peak = np.abs(want) > 1 - 1e-9
-        assert np.array_equal(pcm[~peak], wpcm[~peak]), tag
-        assert np.all(np.abs(pcm[peak].astype(int) - wpcm[peak]) <= 1), tag
+        assert np.array_equal(audio, g[f"audio_{tag}"]), tag
+        assert np.array_equal(pcm, g[f"pcm_{tag}"]), tag
+    # the de-emphasis coefficient and the pre-warped tables at sample rates where NumPy's SVML exp / tan are NOT libm's
+    import scipy.signal as ss
+    n_svml = 0
+    for fs in np.linspace(300e3, 12e6, 400):
+        lp, pil, lmr, alpha = e2.wfm_filters(float(fs))
+        n_svml += float(np.exp(-1 / (75e-6 * fs))) != math.exp(-1 / (75e-6 * fs))
+        assert alpha == float(np.exp(-1 / (75e-6 * fs))), fs
+        assert np.array_equal(lmr, ss.butter(5, [23000 / (fs / 2), 53000 / (fs / 2)], btype="band", output="sos")), fs
+    assert n_svml > 5
     e2.close()
     import pyspecsdr_amd.signal_processing as sp
     x = g["iq_a"][0]
