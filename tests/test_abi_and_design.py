@@ -119,6 +119,20 @@ def test_ssb_taps_design(golden):
         assert np.array_equal(taps, g[f"ssb_taps_{tag}"])
 
 
+def _numpy_on_avx512_skx():
+    """The live comparisons below restate NumPy's AVX512_SKX code paths (the reference environment of the goldens: SVML tan / exp, np.square's
+    fused real part); on a host whose NumPy dispatches otherwise they would compare against a different NumPy."""
+    try:
+        from numpy._core._multiarray_umath import __cpu_features__ as f
+    except ImportError:
+        return False
+    return bool(f.get("AVX512_SKX"))
+
+
+needs_skx = pytest.mark.skipif(not _numpy_on_avx512_skx(), reason="NumPy is not on its AVX512_SKX dispatch here (the goldens cover the tables)")
+
+
+@needs_skx
 def test_designers_equal_scipy_on_sweeps():
     """The library's own designers against SciPy itself (where the test runs): firwin for the NFM / SSB cutoffs at 120 sample rates,
     scipy.signal.decimate's cheby1(8, 0.05, 0.8 / q) sections and their sosfilt_zi for q = 2 .. 400, butter(5) low / band for the WFM
@@ -153,6 +167,7 @@ def test_designers_equal_scipy_on_sweeps():
     assert n_exact > 340
 
 
+@needs_skx
 def test_numpy_float64_tan_and_exp_models():
     """pss_h_np_f64: NumPy's float64 tan / exp (SVML's __svml_tan8_ha / __svml_exp8_ha under the AVX512_SKX dispatch, an ulp from libm on
     0.5 % / 5 % of arguments) restated in the library — every bit of np.tan / np.exp on 10^6 arguments each, incl. the pre-warp and
