@@ -2,7 +2,7 @@
 """A/B timing of k_nfm_fwd across several builds of the library IN ONE PROCESS, interleaved round by round (run-to-run drift of the
 box — clocks, temperature — is ~4 %, more than most kernel changes: only paired measurements resolve them).
 
-    python tools/ab_fwd.py [lib.so[:opt=val,...]] ...      (default: the product library; name 'X' = pyspecsdr_amd/libpss_X.so)
+    python tools/ab_fwd.py [--frames F] [--n N] [lib.so[:opt=val,...]] ...      (default: the product library; name 'X' = pyspecsdr_amd/libpss_X.so)
 Prints per build the mean / min launch time of k_nfm_fwd at BASELINE cfg 2 over all rounds, and the PCM checksum."""
 import ctypes as C
 import os
@@ -19,9 +19,14 @@ from pyspecsdr_amd.engine import Engine
 
 from ab_fwd_common import engine_for
 
-specs = sys.argv[1:] or ["product"]
-dev = torch.device("cuda", 0)
+args = sys.argv[1:]
 nf, n = bench.N_FRAMES, bench.N_FFT
+if "--frames" in args:                    # other batch sizes / frame lengths: --frames F --n N
+    i = args.index("--frames"); nf = int(args[i + 1]); del args[i:i + 2]
+if "--n" in args:
+    i = args.index("--n"); n = int(args[i + 1]); del args[i:i + 2]
+specs = args or ["product"]
+dev = torch.device("cuda", 0)
 iq = bench.synth_fm_iq(nf, n, bench.FS, dev, seed=20260930)
 pcm = torch.empty((nf, 10, 2), dtype=torch.int16, device=dev)
 engs = [engine_for(s) for s in specs]
