@@ -56,7 +56,7 @@ int pss_device_count(void);
  *   "small_batch_max" (8192)   largest NFM frame count that takes them;  "wfm_small_batch_max" (8192) likewise for WFM
  *   "ssb_hilbert" (1)          0: demodulate_ssb skips the reference's hilbert() FFT round trip (the identity on the real part it
  *                              keeps, up to ~1e-16); 1: executed for power-of-two frames of 256..1048576 samples
- *   "hilbert_exact" (0)        1: pss_hilbert and demodulate_ssb's hilbert() run pocketfft's own butterfly order for rows of 256..16384
+ *   "hilbert_exact" (0)        1: pss_hilbert and demodulate_ssb's hilbert() run pocketfft's own butterfly order for rows of 256..1048576
  *                              samples (real radix-4 / radix-2 forward passes, complex radix-8 / 4 / 2 inverse passes, its twiddle products):
  *                              the analytic signal and the SSB float64 audio then equal SciPy's on every bit.  0 (default): the register
  *                              transforms, within 2e-14 of it (int16 PCM equal either way) and about twice as fast

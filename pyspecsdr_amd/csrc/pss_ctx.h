@@ -85,7 +85,7 @@ struct pss_ctx {
     bool no_wfm_fused = false;  // option "wfm_fused" = 0: k_wfm_front + k_nfm_iir path (A/B testing)
     long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~12000)
     long wfm_small_batch_max = 8192;  // option "wfm_small_batch_max" (measured crossover with the fused kernels ~12000 frames)
-    bool hilbert_exact = false;   // option "hilbert_exact": scipy.signal.hilbert bit for bit (pocketfft's butterfly order, pss_hilbert_pf.h) for rows of 256..16384 samples
+    bool hilbert_exact = false;   // option "hilbert_exact": scipy.signal.hilbert bit for bit (pocketfft's butterfly order, pss_hilbert_pf.h) for rows of 256..1048576 samples
     bool ssb_hilbert = true;   // option "ssb_hilbert": run the reference's hilbert() round trip inside demodulate_ssb where a register transform exists for the frame length
     bool db_exact = false;         // true: compute_fft's dB rows evaluated to float64 accuracy and rounded once (= float32 of the reference's float64 rows); false: float32 evaluation, 1-2 ulp off, 15-25 % faster kernels
     bool scan_exact = true;        // scanner slices: NumPy's float32 chain bit for bit (scan_db_np); false: the float64 / hardware-log2 dB of compute_fft

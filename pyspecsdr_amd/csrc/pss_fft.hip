@@ -1250,6 +1250,26 @@ static int pf_twiddles(pss_ctx *ctx, int n, const double2 **tw)
     return PSS_OK;
 }
 
+// option "hilbert_exact" for rows of 2^15 .. 2^20 samples: the same passes through two scratch arrays per workgroup in global memory
+static int hilbert_pf_long(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits)
+{
+    if (out_mode != 0 && out_mode != 1) return pss_fail(ctx, PSS_E_ARG, "pss_hilbert: rows longer than 16384 samples have no fused demodulator tail");
+    const double2 *tw;
+    int r = pf_twiddles(ctx, n, &tw);
+    if (r) return r;
+    const size_t per_wg = (size_t)n * 2 * sizeof(double2);
+    long grid = (long)(((size_t)1 << 30) / per_wg);       // at most 1 GiB of scratch
+    grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
+    if (grid > n_rows) grid = n_rows;
+    r = pss_ensure_buffer(ctx, &ctx->scratch_fft, &ctx->scratch_fft_bytes, (size_t)grid * per_wg, "hilbert (exact) scratch");
+    if (r) return r;
+    pss_kernel_begin(ctx, "k_hilbert");
+    hipLaunchKernelGGL(pss_pf::k_hilbert_pf_long, dim3((unsigned)grid), dim3(1024), 0, PSS_STREAM(ctx), d_x, d_out, tw, ilog2(n), n_rows, out_mode,
+                       d_maxbits, reinterpret_cast<double *>(ctx->scratch_fft));
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_hilbert_pf_long launch");
+}
+
 // option "hilbert_exact": pocketfft's own butterfly order (pss_hilbert_pf.h), rows of 256 .. 16384 samples
 static int hilbert_pf(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits,
                       int16_t *d_pcm)
@@ -1278,6 +1298,7 @@ int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double
     if (!pss_hilbert_supported(n)) return pss_fail(ctx, PSS_E_ARG, "pss_hilbert: the row length must be a power of two in [256, 1048576]");
     if (n_rows == 0) return PSS_OK;
     if (ctx->hilbert_exact && n <= 16384) return hilbert_pf(ctx, d_x, n_rows, n, d_out, out_mode, d_maxbits, d_pcm);
+    if (ctx->hilbert_exact) return hilbert_pf_long(ctx, d_x, n_rows, n, d_out, out_mode, d_maxbits);
     const double2 *tw;
     const double *win;
     int r = pss_fft_tables(ctx, n, &tw, &win);

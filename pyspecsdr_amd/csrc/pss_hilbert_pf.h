@@ -1,7 +1,7 @@
 // pss_hilbert_pf.h — scipy.signal.hilbert along rows, BIT FOR BIT (option "hilbert_exact"): the reference's SSB demodulator calls
 // hilbert() (signal_processing.py:205, :210), SciPy runs it on pocketfft (scipy.fft: third-party, vendored in SciPy as
 // scipy/_lib/pocketfft — not part of the reference tree), and a transform with any other butterfly order lands 1e-16 away from it.
-// This kernel replays pocketfft's published algorithm for rows of N = 2^k samples, 256 <= N <= 16384 (oracle/pss_pocketfft.c is the
+// These kernels replay pocketfft's published algorithm for rows of N = 2^k samples, 256 <= N <= 16384 in LDS / registers (longer rows: below) (oracle/pss_pocketfft.c is the
 // CPU restatement the tests compare with, itself equal to SciPy on every bit):
 //   forward  : the REAL transform (rfftp) — radix-4 passes radf4 from ido = 1 upwards, a last radix-2 pass radf2 when k is odd — on the
 //              row as N float64 in LDS, FFTPACK half-complex result r0, r1, i1, ..., r_{N/2};
@@ -327,6 +327,163 @@ __global__ __launch_bounds__(MAXT) void k_hilbert_pf(const double *x, double *ou
                 if (out) out[(size_t)f * N + idx] = a;
                 if (pcm) pcm[(size_t)f * N + idx] = pss_hil::pcm_pair(a);
             }
+        }
+    }
+}
+
+}  // namespace pss_pf
+
+// ---- rows longer than 16 384 samples (the reference's read buffers go up to 2^20): the same passes through global memory -------------
+// One workgroup of 1024 threads per row, grid-strided; pocketfft's two ping-pong arrays are two scratch arrays per workgroup (real
+// float64 for the forward transform, complex128 for the inverse — the real ones alias the first complex one), a workgroup barrier
+// between passes.  No register residency, no LDS: an exactness path (L2-resident up to ~2^17 samples), not a throughput one.
+namespace pss_pf {
+
+__global__ __launch_bounds__(1024) void k_hilbert_pf_long(const double *x, double *out, const double2 *__restrict__ tw, int logn, long n_rows,
+                                                          int out_mode, unsigned long long *__restrict__ mxbits, double *scratch)
+{
+#pragma clang fp contract(off)
+    const int t = threadIdx.x, T = blockDim.x;
+    const size_t N = (size_t)1 << logn;
+    // per workgroup: two arrays of N complex128; the forward transform's two real arrays live in the first
+    double2 *C0 = reinterpret_cast<double2 *>(scratch) + (size_t)blockIdx.x * 2 * N, *C1 = C0 + N;
+    double *R0 = reinterpret_cast<double *>(C1), *R1 = R0 + N;       // (in C1: C0 receives the masked spectrum)
+    const double fct = 1.0 / (double)N;
+    for (long f = blockIdx.x; f < n_rows; f += gridDim.x) {
+        const double *row = x + (size_t)f * N;
+        __syncthreads();
+        for (size_t e = t; e < N; e += T) R0[e] = row[e];
+        __syncthreads();
+        double *cc = R0, *ch = R1;
+        // forward: radf4 with ido = 1, 4, 16, ...
+        for (int lido = 0; lido + 2 <= logn; lido += 2) {
+            const size_t ido = (size_t)1 << lido, l1 = N >> (lido + 2);
+            auto CC = [&](size_t a, size_t b, size_t c) -> double { return cc[a + ido * (b + l1 * c)]; };
+            auto CH = [&](size_t a, size_t b, size_t c) -> double & { return ch[a + ido * (b + 4 * c)]; };
+            const size_t half = ido >> 1;            // slots per k: s = 0 (the two twiddle-free butterflies), s = 1 .. ido/2 - 1
+            const size_t units = l1 * (ido == 1 ? 1 : half);
+            for (size_t u = t; u < units; u += T) {
+                const size_t k = ido == 1 ? u : u / half, s = ido == 1 ? 0 : u % half;
+                if (s == 0) {
+                    const double c0 = CC(0, k, 0), c1 = CC(0, k, 1), c2_ = CC(0, k, 2), c3 = CC(0, k, 3);
+                    const double tr1 = c3 + c1, tr2 = c0 + c2_;
+                    CH(0, 0, k) = tr2 + tr1; CH(ido - 1, 3, k) = tr2 - tr1; CH(0, 2, k) = c3 - c1; CH(ido - 1, 1, k) = c0 - c2_;
+                    if (ido > 1) {
+                        const double d0 = CC(ido - 1, k, 0), d1 = CC(ido - 1, k, 1), d2 = CC(ido - 1, k, 2), d3 = CC(ido - 1, k, 3);
+                        const double ti1 = -HSQT2 * (d1 + d3), tb = HSQT2 * (d1 - d3);
+                        CH(ido - 1, 0, k) = d0 + tb; CH(ido - 1, 2, k) = d0 - tb; CH(0, 3, k) = ti1 + d2; CH(0, 1, k) = ti1 - d2;
+                    }
+                } else {
+                    const size_t i = 2 * s, ic = ido - i;
+                    const double2 w1 = tw[1 * l1 * s], w2 = tw[2 * l1 * s], w3 = tw[3 * l1 * s];
+                    const double a0 = CC(i - 1, k, 0), b0 = CC(i, k, 0), a1 = CC(i - 1, k, 1), b1 = CC(i, k, 1);
+                    const double a2 = CC(i - 1, k, 2), b2 = CC(i, k, 2), a3 = CC(i - 1, k, 3), b3 = CC(i, k, 3);
+                    const double cr2 = w1.x * a1 + w1.y * b1, ci2 = w1.x * b1 - w1.y * a1;
+                    const double cr3 = w2.x * a2 + w2.y * b2, ci3 = w2.x * b2 - w2.y * a2;
+                    const double cr4 = w3.x * a3 + w3.y * b3, ci4 = w3.x * b3 - w3.y * a3;
+                    const double tr1 = cr4 + cr2, tr4 = cr4 - cr2, ti1 = ci2 + ci4, ti4 = ci2 - ci4;
+                    const double tr2 = a0 + cr3, tr3 = a0 - cr3, ti2 = b0 + ci3, ti3 = b0 - ci3;
+                    CH(i - 1, 0, k) = tr2 + tr1; CH(ic - 1, 3, k) = tr2 - tr1; CH(i, 0, k) = ti1 + ti2; CH(ic, 3, k) = ti1 - ti2;
+                    CH(i - 1, 2, k) = tr3 + ti4; CH(ic - 1, 1, k) = tr3 - ti4; CH(i, 2, k) = tr4 + ti3; CH(ic, 1, k) = tr4 - ti3;
+                }
+            }
+            __syncthreads();
+            double *q = cc; cc = ch; ch = q;
+        }
+        if (logn & 1) {
+            const size_t ido = N >> 1;               // radf2, l1 = 1
+            for (size_t s = t; s < (ido >> 1); s += T) {
+                if (s == 0) {
+                    const double c0 = cc[0], c1 = cc[ido], e0 = cc[ido - 1], e1 = cc[2 * ido - 1];
+                    ch[0] = c0 + c1; ch[2 * ido - 1] = c0 - c1; ch[ido] = -e1; ch[ido - 1] = e0;
+                } else {
+                    const size_t i = 2 * s, ic = ido - i;
+                    const double2 w = tw[s];
+                    const double a0 = cc[i - 1], b0 = cc[i], a1 = cc[i - 1 + ido], b1 = cc[i + ido];
+                    const double tr2 = w.x * a1 + w.y * b1, ti2 = w.x * b1 - w.y * a1;
+                    ch[i - 1] = a0 + tr2; ch[ic - 1 + ido] = a0 - tr2; ch[i] = ti2 + b0; ch[ic + ido] = ti2 - b0;
+                }
+            }
+            __syncthreads();
+            double *q = cc; cc = ch; ch = q;
+        }
+        // the masked spectrum out of the half-complex row (cc) into C0
+        for (size_t b = t; b < N; b += T) {
+            const bool low = b > 0 && b < (N >> 1);
+            const double sr = low ? 2.0 : ((b == 0 || b == (N >> 1)) ? 1.0 : 0.0), sq = low ? 2.0 : 0.0;
+            C0[b] = make_double2(cc[low ? 2 * b - 1 : (b == 0 ? 0 : N - 1)] * sr, cc[low ? 2 * b : 0] * sq);
+        }
+        __syncthreads();
+        // inverse: factors 8 .. 8 (4) with the 2 in front, l1 = 1 upwards
+        const int n8 = logn / 3, rem = logn % 3, npass = n8 + (rem ? 1 : 0);
+        double2 *pc = C0, *ph = C1;
+        int ll1 = 0;
+        auto add = [](c2 a, c2 b) {
+#pragma clang fp contract(off)
+            c2 o = {a.r + b.r, a.i + b.i}; return o; };
+        auto sub = [](c2 a, c2 b) {
+#pragma clang fp contract(off)
+            c2 o = {a.r - b.r, a.i - b.i}; return o; };
+        auto rot90 = [](c2 a) { c2 o = {-a.i, a.r}; return o; };
+        auto rot45 = [](c2 a) {
+#pragma clang fp contract(off)
+            c2 o = {HSQT2 * (a.r - a.i), HSQT2 * (a.i + a.r)}; return o; };
+        auto rot135 = [](c2 a) {
+#pragma clang fp contract(off)
+            c2 o = {HSQT2 * (-a.r - a.i), HSQT2 * (a.r - a.i)}; return o; };
+        for (int pi = 0; pi < npass; pi++) {
+            const int lip = rem == 1 ? (pi == 0 ? 1 : 3) : (pi < n8 ? 3 : 2);
+            const int lido = logn - ll1 - lip;
+            const size_t ido = (size_t)1 << lido, l1 = (size_t)1 << ll1, ip = (size_t)1 << lip;
+            auto bmul = [&](c2 v, size_t j, size_t i) {
+#pragma clang fp contract(off)
+                const double2 wj = tw[j * l1 * i];
+                c2 o = {v.r * wj.x - v.i * wj.y, v.r * wj.y + v.i * wj.x};
+                if (i == 0) o = v;
+                return o;
+            };
+            for (size_t u = t; u < (N >> lip); u += T) {
+                const size_t k = u >> lido, i = u & (ido - 1);
+                c2 c[8], o[8];
+                for (size_t j = 0; j < ip; j++) { const double2 v = pc[i + ido * (j + ip * k)]; c[j].r = v.x; c[j].i = v.y; }
+                if (lip == 3) {
+                    c2 a1 = add(c[1], c[5]), a5 = sub(c[1], c[5]), a3 = add(c[3], c[7]), a7 = sub(c[3], c[7]);
+                    { const c2 q = a1; a1 = add(a1, a3); a3 = sub(q, a3); }
+                    a3 = rot90(a3);
+                    a7 = rot90(a7);
+                    { const c2 q = a5; a5 = add(a5, a7); a7 = sub(q, a7); }
+                    a5 = rot45(a5);
+                    a7 = rot135(a7);
+                    c2 a0 = add(c[0], c[4]), a4 = sub(c[0], c[4]), a2 = add(c[2], c[6]), a6 = sub(c[2], c[6]);
+                    { const c2 q = a0; a0 = add(a0, a2); a2 = sub(q, a2); }
+                    a6 = rot90(a6);
+                    { const c2 q = a4; a4 = add(a4, a6); a6 = sub(q, a6); }
+                    o[0] = add(a0, a1); o[4] = bmul(sub(a0, a1), 4, i); o[2] = bmul(add(a2, a3), 2, i); o[6] = bmul(sub(a2, a3), 6, i);
+                    o[1] = bmul(add(a4, a5), 1, i); o[5] = bmul(sub(a4, a5), 5, i); o[3] = bmul(add(a6, a7), 3, i); o[7] = bmul(sub(a6, a7), 7, i);
+                } else if (lip == 2) {
+                    const c2 t2 = add(c[0], c[2]), t1 = sub(c[0], c[2]), t3 = add(c[1], c[3]);
+                    const c2 t4 = rot90(sub(c[1], c[3]));
+                    o[0] = add(t2, t3); o[1] = bmul(add(t1, t4), 1, i); o[2] = bmul(sub(t2, t3), 2, i); o[3] = bmul(sub(t1, t4), 3, i);
+                } else {
+                    o[0] = add(c[0], c[1]); o[1] = bmul(sub(c[0], c[1]), 1, i);
+                }
+                for (size_t j = 0; j < ip; j++) ph[i + ido * (k + l1 * j)] = make_double2(o[j].r, o[j].i);
+            }
+            __syncthreads();
+            double2 *q = pc; pc = ph; ph = q;
+            ll1 += lip;
+        }
+        double m = 0.0;
+        for (size_t e = t; e < N; e += T) {
+            const double2 v = pc[e];
+            const double a = v.x * fct, b = v.y * fct;
+            if (out_mode == 0) reinterpret_cast<double2 *>(out)[(size_t)f * N + e] = make_double2(a, b);
+            else out[(size_t)f * N + e] = a;
+            m = pss_hil::nanmax(m, fabs(a));
+        }
+        if (out_mode == 1 && mxbits) {
+            for (int off = 32; off > 0; off >>= 1) m = pss_hil::nanmax(m, __shfl_xor(m, off));
+            if ((t & 63) == 0) atomicMax(&mxbits[f], (unsigned long long)__double_as_longlong(m));
         }
     }
 }

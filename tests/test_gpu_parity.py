@@ -458,13 +458,13 @@ def test_ssb_vs_golden(golden, tag, mode):
     assert np.max(np.abs(res[1] - res[0])) < 1e-14
 
 
-@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 1048576])
 def test_hilbert_exact_is_scipy_bit_for_bit(n):
     """Option "hilbert_exact": pss_hilbert replays pocketfft (real radix-4 / 2 forward passes, complex radix-8 / 4 / 2 inverse passes,
     its twiddle products): the analytic signal equals scipy.signal.hilbert — through the oracle's restatement, which is pinned to SciPy
     bit for bit on the CPU side — on every bit; the default register transform stays within 2e-14."""
     rng = np.random.default_rng(n)
-    rows = 5 if n < 16384 else 3
+    rows = 5 if n < 16384 else (3 if n <= 131072 else 2)      # above 16 384 samples: the same passes through global memory
     x = rng.standard_normal((rows, n)) * 10.0 ** rng.integers(-2, 3, size=(rows, 1))
     x[0, ::7] = 0.0
     e = G.engine()
@@ -505,6 +505,15 @@ def test_ssb_on_the_reference_read_buffer_sizes():
         assert np.max(np.abs(res[1][1] - res[0][1])) < 1e-13, n
         taps = e.ssb_taps(fs)
         assert np.array_equal(res[0][1][0], O.demod_ssb(iq[0], taps, hilbert=False)), n
+        if n <= 65536:
+            e.set_option("hilbert_exact", 1)     # the reference's float64 audio at its own read-buffer sizes, every bit
+            try:
+                pcm_x, au_x = G.demod(L.MODE_USB, iq, fs)
+            finally:
+                e.set_option("hilbert_exact", 0)
+            assert np.array_equal(pcm_x, res[1][0]), n
+            for k in range(len(iq)):
+                assert np.array_equal(au_x[k], O.demod_ssb(iq[k], taps)), (n, k)
 
 
 @pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 1048576])

@@ -32,7 +32,7 @@ def timed(fn, reps=6):
     return {k: sum(v) / reps for k, v in kt.items()}
 
 
-for n in (256, 512, 1024, 2048, 4096, 8192, 16384):
+for n in (256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 131072, 1048576):
     rows = tot // n
     res = []
     for ex in (0, 1):
