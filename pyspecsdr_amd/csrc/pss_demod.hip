@@ -465,79 +465,127 @@ __device__ __forceinline__ double dpp_row_shr1(double v)
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(64) void k_am_sys(const float *__restrict__ env, const float *__restrict__ mu,
-                                               double *__restrict__ Yf, double *__restrict__ mxout, int n,
-                                               long n_frames, AmCoef c)
+__global__ __launch_bounds__(128) void k_am_sys(const float *__restrict__ env, const float *__restrict__ mu,
+                                                double *__restrict__ Yf, double *__restrict__ mxout, int n,
+                                                long n_frames, AmCoef c)
 {
-    // Block-systolic (see k_iir4_sys): at macro-step m lane (frame g, section s) filters the whole 64-sample block m - s
-    // and leaves it in LDS, in place, for lane (g, s + 1).  12 frames x 5 sections per wavefront (4 lanes idle).
-    __shared__ double ebuf[SYS_G][SYS_T + 1];                  // envelope - mean, the input block of section 0
+    // Block-systolic (see k_iir4_sys): at macro-step m lane (frame g, section s) of wavefront 0 filters the whole 64-sample block
+    // m - s and leaves it in LDS, in place, for lane (g, s + 1).  12 frames x 5 sections per wavefront (4 lanes idle).
+    // Wavefront 1 does the memory traffic (round 3): it loads block m + 2, stages block m + 1 (envelope - mean) and writes block m - 5
+    // back while wavefront 0 runs the 64 recurrence steps of block m.  (As one wavefront the kernel waited for its own stores and
+    // prefetches — s_waitcnt vmcnt(0) in front of the recurrence loop — every block: 3.9 us per block of which the recurrence is 1.3;
+    // now 3.1 us.  Ablations: without the recurrence arithmetic 2.4 us, without it and without any global access still 2.0 us — the LDS
+    // hand-offs and the two barriers of a block are the floor of this shape.)
+    __shared__ double ebuf[2][SYS_G][SYS_T + 1];               // envelope - mean, the input block of section 0 (two blocks in flight)
     __shared__ double xbuf[SYS_G][AM_NS - 1][SYS_T + 1];       // block handed from section s to s + 1 (in place)
-    __shared__ double ybuf[SYS_G][SYS_T + 1];                  // block leaving the last section
-    const int lane = threadIdx.x;
+    __shared__ double ybuf[2][SYS_G][SYS_T + 1];               // block leaving the last section
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long f0 = (long)blockIdx.x * SYS_G;
+    const long nblk = ((long)n + SYS_T - 1) / SYS_T;
+    const long nstep = nblk + AM_NS - 1;
+    if (wave == 1) {
+        // ---------------- memory wavefront: lane = sample inside a block ----------------
+        double mxl[SYS_G];
+#pragma unroll
+        for (int gg = 0; gg < SYS_G; gg++) mxl[gg] = 0.0;
+        float preA[SYS_G], preB[SYS_G], mus[SYS_G];   // two blocks in flight: block k is loaded into preA (k even) / preB (k odd), three steps ahead
+#pragma unroll
+        for (int gg = 0; gg < SYS_G; gg++) mus[gg] = (f0 + gg < n_frames) ? mu[f0 + gg] : 0.0f;
+        unsigned nanmask = 0;  // bit gg: a NaN was seen in frame gg by this lane
+        auto load = [&](long blk, float (&pre)[SYS_G]) {
+            const long i = blk * SYS_T + lane;
+            if ((blk + 1) * SYS_T <= n && f0 + SYS_G <= n_frames) {   // wave-uniform: twelve unconditional loads
+                const float *src = env + (size_t)f0 * n + i;
+#pragma unroll
+                for (int gg = 0; gg < SYS_G; gg++) pre[gg] = src[(size_t)gg * n];
+            } else {
+#pragma unroll
+                for (int gg = 0; gg < SYS_G; gg++) {
+                    const long ff = f0 + gg;
+                    pre[gg] = (ff < n_frames && i < n) ? env[(size_t)ff * n + i] : 0.0f;
+                }
+            }
+        };
+        auto stage = [&](long blk, float (&pre)[SYS_G]) {     // pre[] holds block blk
+#pragma unroll
+            for (int gg = 0; gg < SYS_G; gg++) {
+                const long ff = f0 + gg;
+                double e = 0.0;
+                if (ff < n_frames && blk * SYS_T + lane < n) e = (double)__fsub_rn(pre[gg], mus[gg]);  // float32 subtract (:185)
+                ebuf[blk & 1][gg][lane] = e;
+            }
+        };
+        auto writeback = [&](long blk, int par) {  // ybuf[par] holds block blk of every frame
+            double yv[SYS_G];
+#pragma unroll
+            for (int gg = 0; gg < SYS_G; gg++) yv[gg] = ybuf[par][gg][lane];
+            const long i = blk * SYS_T + lane;
+#pragma unroll
+            for (int gg = 0; gg < SYS_G; gg++) {
+                const long ff = f0 + gg;
+                if (ff < n_frames && i < n) {
+                    const double v = yv[gg];
+                    Yf[(size_t)ff * n + i] = v;
+                    const double av = fabs(v);
+                    if (av != av) nanmask |= 1u << gg;
+                    mxl[gg] = av > mxl[gg] ? av : mxl[gg];
+                }
+            }
+        };
+        load(0, preA);
+        stage(0, preA);
+        if (nblk > 1) load(1, preB);
+        if (nblk > 2) load(2, preA);
+        fused::lds_barrier();   // LDS-only: the memory wavefront's loads and stores stay in flight across it
+        // beside macro-step m: block m + 1 into the other input buffer, block m + 3 requested, the block macro-step m - 1 finished written back
+        auto beside = [&](long m, float (&pre)[SYS_G]) {     // pre: the set holding block m + 1
+            if (m + 1 < nblk) stage(m + 1, pre);
+            if (m + 3 < nblk) load(m + 3, pre);
+            if (m >= AM_NS) writeback(m - AM_NS, (int)((m - 1) & 1));
+            fused::lds_barrier();
+        };
+        for (long m = 0; m < nstep; m += 2) {
+            beside(m, preB);
+            if (m + 1 < nstep) beside(m + 1, preA);
+        }
+        writeback(nblk - 1, (int)((nstep - 1) & 1));
+        // per-frame peak: max over the 64 lanes (np.max propagates NaN)
+#pragma unroll
+        for (int gg = 0; gg < SYS_G; gg++) {
+            double mm = mxl[gg];
+            int nn = (nanmask >> gg) & 1;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_xor(mm, off);
+                mm = o > mm ? o : mm;
+                nn |= __shfl_xor(nn, off);
+            }
+            if (lane == 0 && f0 + gg < n_frames) mxout[f0 + gg] = nn ? __builtin_nan("") : mm;
+        }
+        return;
+    }
+    // ---------------- recurrence wavefront ----------------
     const int g = lane / AM_NS, s = lane - AM_NS * g;          // lanes 60..63: g = 12 -> idle
     const bool lane_on = g < SYS_G;
-    const long f0 = (long)blockIdx.x * SYS_G;
     Biquad cs = c.s[0];
 #pragma unroll
     for (int k = 1; k < AM_NS; k++)
         if (s == k) cs = c.s[k];
     double z0 = 0.0, z1 = 0.0;
-    // peak tracking happens where the outputs are written back (lane = time there): mxl[gg] = max over this lane's samples
-    double mxl[SYS_G];
-#pragma unroll
-    for (int gg = 0; gg < SYS_G; gg++) mxl[gg] = 0.0;
-    float pre[SYS_G];  // |x| of the next block (SYS_G frame rows, one sample per lane), loaded while the current one runs
-    float mus[SYS_G];
-#pragma unroll
-    for (int gg = 0; gg < SYS_G; gg++) mus[gg] = (f0 + gg < n_frames) ? mu[f0 + gg] : 0.0f;
-    const long nblk = ((long)n + SYS_T - 1) / SYS_T;
-    auto prefetch = [&](long blk) {
-#pragma unroll
-        for (int gg = 0; gg < SYS_G; gg++) {
-            const long ff = f0 + gg, i = blk * SYS_T + lane;
-            pre[gg] = (ff < n_frames && i < n) ? env[(size_t)ff * n + i] : 0.0f;
-        }
-    };
-    unsigned nanmask = 0;  // bit gg: a NaN was seen in frame gg by this lane
-    auto writeback = [&](long blk) {  // ybuf holds block blk of every frame, lane = sample inside the block
-#pragma unroll
-        for (int gg = 0; gg < SYS_G; gg++) {
-            const long ff = f0 + gg, i = blk * SYS_T + lane;
-            if (ff < n_frames && i < n) {
-                const double v = ybuf[gg][lane];
-                Yf[(size_t)ff * n + i] = v;
-                const double av = fabs(v);
-                if (av != av) nanmask |= 1u << gg;
-                mxl[gg] = av > mxl[gg] ? av : mxl[gg];
-            }
-        }
-    };
     auto step = [&](double x) {
         const double xn = __dadd_rn(__dmul_rn(cs.b0, x), z0);
         z0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, x), __dmul_rn(cs.a1, xn)), z1);
         z1 = __dsub_rn(__dmul_rn(cs.b2, x), __dmul_rn(cs.a2, xn));
         return xn;
     };
-    prefetch(0);
-    for (long m = 0; m < nblk + AM_NS - 1; m++) {
-        if (m < nblk) {
-#pragma unroll
-            for (int gg = 0; gg < SYS_G; gg++) {
-                const long ff = f0 + gg;
-                double e = 0.0;
-                if (ff < n_frames && m * SYS_T + lane < n) e = (double)__fsub_rn(pre[gg], mus[gg]);  // float32 subtract (:185)
-                ebuf[gg][lane] = e;
-            }
-        }
-        if (m >= AM_NS) writeback(m - AM_NS);   // the last section finished block m - 5 in the previous macro-step
-        if (m + 1 < nblk) prefetch(m + 1);
-        fused::lds_barrier();
+    fused::lds_barrier();
+    for (long m = 0; m < nstep; m++) {
         const long blk = m - s;
         const bool active = lane_on && blk >= 0 && blk < nblk;
         const int gi = lane_on ? g : 0;
-        const double *src = s == 0 ? ebuf[gi] : xbuf[gi][s > 0 ? s - 1 : 0];
-        double *dst = s == AM_NS - 1 ? ybuf[gi] : xbuf[gi][s < AM_NS - 1 ? s : 0];
+        const double *src = s == 0 ? ebuf[m & 1][gi] : xbuf[gi][s > 0 ? s - 1 : 0];
+        double *dst = s == AM_NS - 1 ? ybuf[m & 1][gi] : xbuf[gi][s < AM_NS - 1 ? s : 0];
         const int cnt = !active ? 0 : ((n - blk * SYS_T) < SYS_T ? (int)(n - blk * SYS_T) : SYS_T);
         if (__all(!active || cnt == SYS_T)) {  // one code path per macro-step for the whole wavefront (in-place hand-off)
             if (active) {
@@ -560,20 +608,6 @@ __global__ __launch_bounds__(64) void k_am_sys(const float *__restrict__ env, co
             }
         }
         fused::lds_barrier();
-    }
-    writeback(nblk - 1);
-    // per-frame peak: max over the 64 lanes (np.max propagates NaN)
-#pragma unroll
-    for (int gg = 0; gg < SYS_G; gg++) {
-        double mm = mxl[gg];
-        int nn = (nanmask >> gg) & 1;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double o = __shfl_xor(mm, off);
-            mm = o > mm ? o : mm;
-            nn |= __shfl_xor(nn, off);
-        }
-        if (lane == 0 && f0 + gg < n_frames) mxout[f0 + gg] = nn ? __builtin_nan("") : mm;
     }
 }
 
@@ -2407,7 +2441,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         if (r) return r;
         pss_kernel_begin(ctx, "k_am_iir");
         if (n_frames < 32768)  // few frames: spread the sections over lanes (5.3x more wavefronts)
-            hipLaunchKernelGGL(k_am_sys, dim3((unsigned)((n_frames + SYS_G - 1) / SYS_G)), dim3(64), 0, PSS_STREAM(ctx), env, mu, Yf,
+            hipLaunchKernelGGL(k_am_sys, dim3((unsigned)((n_frames + SYS_G - 1) / SYS_G)), dim3(128), 0, PSS_STREAM(ctx), env, mu, Yf,
                                mx, n, n_frames, c);
         else
             hipLaunchKernelGGL(k_am_iir, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), env, mu, Yf, mx, n, n_frames, c);

@@ -58,6 +58,58 @@ __global__ void kf(float *out, float a, float b, int iters, unsigned long long *
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
+// the serial biquad step of the systolic IIR kernels (k_am_sys, k_iir4_sys): nine float64 operations per sample, four of them on the
+// recurrence's critical path; ORDER 0 as the source states it, ORDER 1 with the three input products of the NEXT sample issued early
+template <int ORDER>
+__global__ void kbq(double *out, double b0, double b1, double b2, double a1, double a2, int iters, unsigned long long *cyc)
+{
+    double z0 = threadIdx.x * 1e-9, z1 = 0.5, x = 1.0 + threadIdx.x * 1e-7, acc = 0.0;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    if (ORDER == 0) {
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const double xn = b0 * x + z0;
+                z0 = (b1 * x - a1 * xn) + z1;
+                z1 = b2 * x - a2 * xn;
+                acc += xn; x = x * 0.999999;
+            }
+        }
+    } else {
+        double p0 = b0 * x, p1 = b1 * x, p2 = b2 * x;
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const double xn = p0 + z0;
+                x = x * 0.999999;
+                const double q0 = b0 * x, q1 = b1 * x, q2 = b2 * x;     // next sample's products: off the critical path
+                const double t1 = a1 * xn, t2 = a2 * xn;
+                z0 = (p1 - t1) + z1;
+                z1 = p2 - t2;
+                acc += xn;
+                p0 = q0; p1 = q1; p2 = q2;
+                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc + z0 + z1;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+template <int ORDER>
+void runbq(const char *name, int waves_per_simd)
+{
+    double *out; unsigned long long *cyc, h;
+    hipMalloc(&out, 8 * 1024 * 1024); hipMalloc(&cyc, 8);
+    int iters = 2000;
+    hipLaunchKernelGGL((kbq<ORDER>), dim3(1), dim3(64 * 4 * waves_per_simd), 0, 0, out, 0.9, -1.7, 0.8, -1.6, 0.7, iters, cyc);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL((kbq<ORDER>), dim3(1), dim3(64 * 4 * waves_per_simd), 0, 0, out, 0.9, -1.7, 0.8, -1.6, 0.7, iters, cyc);
+    hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+    printf("%-28s waves/SIMD=%d : %.1f clk per sample (11 float64 instructions)\n", name, waves_per_simd, (double)h / (iters * 8.0));
+    hipFree(out); hipFree(cyc);
+}
+
 template <int MODE, int CHAINS>
 void runf(const char *name, int waves_per_simd)
 {
@@ -92,6 +144,7 @@ void run(const char *name, int waves_per_simd)
 
 int main()
 {
+    runbq<0>("biquad step, source order", 1); runbq<1>("biquad step, products early", 1); runbq<0>("biquad step, source order", 2); runbq<1>("biquad step, products early", 2);
     run<0, 1>("fma_f64", 1); run<0, 2>("fma_f64", 1); run<0, 4>("fma_f64", 1); run<0, 8>("fma_f64", 1);
     run<0, 1>("fma_f64", 2); run<0, 4>("fma_f64", 2); run<0, 4>("fma_f64", 3); run<0, 4>("fma_f64", 4);
     run<0, 1>("fma_f64", 4); run<0, 2>("fma_f64", 4);
