@@ -748,77 +748,117 @@ __global__ __launch_bounds__(128) void k_ssb_edge(const float2 *__restrict__ iq,
 // has left a section is never read.
 // ---------------------------------------------------------------------------------------------------
 constexpr int IS_G = 16, IS_T = 64;
-__global__ __launch_bounds__(64) void k_iir4_sys(const double *__restrict__ in, long in_stride, int backward, long L, long T,
-                                                 NfmCoef c, double *__restrict__ out, long out_stride, int q, int n_out,
-                                                 double *__restrict__ mxout, long n_rows)
+__global__ __launch_bounds__(128) void k_iir4_sys(const double *__restrict__ in, long in_stride, int backward, long L, long T,
+                                                  NfmCoef c, double *__restrict__ out, long out_stride, int q, int n_out,
+                                                  double *__restrict__ mxout, long n_rows)
 {
-    // Block-systolic: at macro-step m lane (frame g, section s) filters the whole 64-sample block m - s of its frame and
+    // Block-systolic: at macro-step m lane (frame g, section s) of wavefront 0 filters the whole 64-sample block m - s of its frame and
     // leaves it in LDS for lane (g, s + 1), which filters it one macro-step later.  Inside a block a lane's only
     // dependent chain is its own state (xn -> a1*xn -> ... -> z0 -> next xn); nothing crosses lanes sample by sample.
-    __shared__ double ebuf[IS_G][IS_T + 1];             // staged input block of section 0
+    // Wavefront 1 does the memory traffic (round 3, as in k_am_sys): loads three blocks ahead, stages the next input block, writes the
+    // finished one back — the recurrence wavefront never waits for a global access.
+    __shared__ double ebuf[2][IS_G][IS_T + 1];          // staged input block of section 0 (two blocks in flight)
     // block handed from section s to s + 1, IN PLACE: within a group of 8 steps every lane first reads its 8 inputs, then
     // writes its 8 outputs, and a wavefront's LDS operations execute in program order — so lane s overwrites positions
     // t0..t0+7 of its row only after lane s + 1 has read them (the previous block), and never touches t0 + 8... early
     __shared__ double xbuf[IS_G][3][IS_T + 1];
-    __shared__ double ybuf[IS_G][IS_T + 1];             // block leaving section 3
-    const int lane = threadIdx.x, g = lane >> 2, s = lane & 3;  // 16 frames x 4 sections
+    __shared__ double ybuf[2][IS_G][IS_T + 1];          // block leaving section 3
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long f0 = (long)blockIdx.x * IS_G;
+    const long nblk = (T + IS_T - 1) / IS_T;
+    const long nstep = nblk + 3;
+    if (wave == 1) {
+        // ---------------- memory wavefront: lane = sample inside a block ----------------
+        double mxl[IS_G];
+        unsigned nanmask = 0;
+#pragma unroll
+        for (int gg = 0; gg < IS_G; gg++) mxl[gg] = 0.0;
+        double preA[IS_G], preB[IS_G];        // block k is loaded into preA (k even) / preB (k odd)
+        auto load = [&](long blk, double (&pre)[IS_G]) {
+#pragma unroll
+            for (int gg = 0; gg < IS_G; gg++) {
+                const long ff = f0 + gg, r = blk * IS_T + lane;
+                pre[gg] = (ff < n_rows && r < T) ? in[(size_t)ff * in_stride + (backward ? L - 1 - r : r)] : 0.0;
+            }
+        };
+        auto stage = [&](long blk, double (&pre)[IS_G]) {
+#pragma unroll
+            for (int gg = 0; gg < IS_G; gg++) ebuf[blk & 1][gg][lane] = pre[gg];
+        };
+        auto writeback = [&](long blk, int par) {  // ybuf[par] holds block blk of every frame, lane = sample inside the block
+            double yv[IS_G];
+#pragma unroll
+            for (int gg = 0; gg < IS_G; gg++) yv[gg] = ybuf[par][gg][lane];
+#pragma unroll
+            for (int gg = 0; gg < IS_G; gg++) {
+                const long ff = f0 + gg, r = blk * IS_T + lane;
+                if (ff < n_rows && r < T) {
+                    const double v = yv[gg];
+                    if (!backward) out[(size_t)ff * out_stride + r] = v;
+                    else {
+                        const int p = (int)(L - 1 - r - EDGE);  // position after the 27-sample trim (0 <= p < M survive it)
+                        const unsigned j = (unsigned)p / (unsigned)q;
+                        if (p >= 0 && p < (int)(L - 2 * EDGE) && j * (unsigned)q == (unsigned)p) {
+                            out[(size_t)ff * out_stride + j] = v;
+                            const double av = fabs(v);
+                            if (av != av) nanmask |= 1u << gg;
+                            mxl[gg] = av > mxl[gg] ? av : mxl[gg];
+                        }
+                    }
+                }
+            }
+        };
+        load(0, preA);
+        stage(0, preA);
+        if (nblk > 1) load(1, preB);
+        if (nblk > 2) load(2, preA);
+        fused::lds_barrier();   // LDS-only: the memory wavefront's loads and stores stay in flight across it
+        auto beside = [&](long m, double (&pre)[IS_G]) {     // pre: the set holding block m + 1
+            if (m + 1 < nblk) stage(m + 1, pre);
+            if (m + 3 < nblk) load(m + 3, pre);
+            if (m >= 4) writeback(m - 4, (int)((m - 1) & 1));    // section 3 finished block m - 4 in the previous macro-step
+            fused::lds_barrier();
+        };
+        for (long m = 0; m < nstep; m += 2) {
+            beside(m, preB);
+            if (m + 1 < nstep) beside(m + 1, preA);
+        }
+        writeback(nblk - 1, (int)((nstep - 1) & 1));
+        if (backward) {
+#pragma unroll
+            for (int gg = 0; gg < IS_G; gg++) {
+                double mm = mxl[gg];
+                int nn = (nanmask >> gg) & 1;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double o = __shfl_xor(mm, off);
+                    mm = o > mm ? o : mm;
+                    nn |= __shfl_xor(nn, off);
+                }
+                if (lane == 0 && f0 + gg < n_rows) mxout[f0 + gg] = nn ? __builtin_nan("") : mm;
+            }
+        }
+        return;
+    }
+    // ---------------- recurrence wavefront: 16 frames x 4 sections ----------------
+    const int g = lane >> 2, s = lane & 3;
     const long fg = (f0 + g < n_rows) ? f0 + g : n_rows - 1;
     const Biquad cs = c.s[s];
     const double x0 = in[(size_t)fg * in_stride + (backward ? L - 1 : 0)];
     double z0 = __dmul_rn(c.zi[2 * s], x0), z1 = __dmul_rn(c.zi[2 * s + 1], x0);
-    double mxl[IS_G];
-    unsigned nanmask = 0;
-#pragma unroll
-    for (int gg = 0; gg < IS_G; gg++) mxl[gg] = 0.0;
-    double pre[IS_G];
-    const long nblk = (T + IS_T - 1) / IS_T;
-    auto prefetch = [&](long blk) {
-#pragma unroll
-        for (int gg = 0; gg < IS_G; gg++) {
-            const long ff = f0 + gg, r = blk * IS_T + lane;
-            pre[gg] = (ff < n_rows && r < T) ? in[(size_t)ff * in_stride + (backward ? L - 1 - r : r)] : 0.0;
-        }
-    };
-    auto writeback = [&](long blk) {  // ybuf holds block blk of every frame, lane = sample inside the block
-#pragma unroll
-        for (int gg = 0; gg < IS_G; gg++) {
-            const long ff = f0 + gg, r = blk * IS_T + lane;
-            if (ff < n_rows && r < T) {
-                const double v = ybuf[gg][lane];
-                if (!backward) out[(size_t)ff * out_stride + r] = v;
-                else {
-                    const int p = (int)(L - 1 - r - EDGE);  // position after the 27-sample trim (0 <= p < M survive it)
-                    const unsigned j = (unsigned)p / (unsigned)q;
-                    if (p >= 0 && p < (int)(L - 2 * EDGE) && j * (unsigned)q == (unsigned)p) {
-                        out[(size_t)ff * out_stride + j] = v;
-                        const double av = fabs(v);
-                        if (av != av) nanmask |= 1u << gg;
-                        mxl[gg] = av > mxl[gg] ? av : mxl[gg];
-                    }
-                }
-            }
-        }
-    };
     auto step = [&](double x) {
         const double xn = __dadd_rn(__dmul_rn(cs.b0, x), z0);
         z0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, x), __dmul_rn(cs.a1, xn)), z1);
         z1 = __dsub_rn(__dmul_rn(cs.b2, x), __dmul_rn(cs.a2, xn));
         return xn;
     };
-    prefetch(0);
-    for (long m = 0; m < nblk + 3; m++) {
-        if (m < nblk) {
-#pragma unroll
-            for (int gg = 0; gg < IS_G; gg++) ebuf[gg][lane] = pre[gg];
-        }
-        if (m >= 4) writeback(m - 4);          // section 3 finished block m - 4 in the previous macro-step
-        if (m + 1 < nblk) prefetch(m + 1);
-        fused::lds_barrier();
+    fused::lds_barrier();
+    for (long m = 0; m < nstep; m++) {
         const long blk = m - s;
         const bool active = blk >= 0 && blk < nblk;
-        const double *src = s == 0 ? ebuf[g] : xbuf[g][s > 0 ? s - 1 : 0];
-        double *dst = s == 3 ? ybuf[g] : xbuf[g][s];
+        const double *src = s == 0 ? ebuf[m & 1][g] : xbuf[g][s > 0 ? s - 1 : 0];
+        double *dst = s == 3 ? ybuf[m & 1][g] : xbuf[g][s];
         const int cnt = !active ? 0 : ((T - blk * IS_T) < IS_T ? (int)(T - blk * IS_T) : IS_T);
         // all lanes must walk the block in lockstep for the in-place hand-off: one code path per macro-step, chosen wave-wide
         if (__all(!active || cnt == IS_T)) {
@@ -842,21 +882,6 @@ __global__ __launch_bounds__(64) void k_iir4_sys(const double *__restrict__ in, 
             }
         }
         fused::lds_barrier();
-    }
-    writeback(nblk - 1);
-    if (backward) {
-#pragma unroll
-        for (int gg = 0; gg < IS_G; gg++) {
-            double mm = mxl[gg];
-            int nn = (nanmask >> gg) & 1;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double o = __shfl_xor(mm, off);
-                mm = o > mm ? o : mm;
-                nn |= __shfl_xor(nn, off);
-            }
-            if (lane == 0 && f0 + gg < n_rows) mxout[f0 + gg] = nn ? __builtin_nan("") : mm;
-        }
     }
 }
 
@@ -2393,10 +2418,10 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             double *MX = reinterpret_cast<double *>(b2 + szU + szY2 + szA2);
             const unsigned gs = (unsigned)((n_frames + IS_G - 1) / IS_G);
             pss_kernel_begin(ctx, "k_iir4_sys");
-            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(64), 0, PSS_STREAM(ctx), U, Lp, 0, L, L, c, Y2, L, q, n_out, nullptr, n_frames);
+            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(128), 0, PSS_STREAM(ctx), U, Lp, 0, L, L, c, Y2, L, q, n_out, nullptr, n_frames);
             pss_kernel_end(ctx);
             pss_kernel_begin(ctx, "k_iir4_sys");
-            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(64), 0, PSS_STREAM(ctx), Y2, L, 1, L, L - EDGE, c, A2, (long)n_out, q, n_out, MX,
+            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(128), 0, PSS_STREAM(ctx), Y2, L, 1, L, L - EDGE, c, A2, (long)n_out, q, n_out, MX,
                                n_frames);
             pss_kernel_end(ctx);
             size_t tot = (size_t)n_frames * n_out;
@@ -2599,10 +2624,10 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             pss_kernel_end(ctx);
             const unsigned gs = (unsigned)((rows + IS_G - 1) / IS_G);
             pss_kernel_begin(ctx, "k_iir4_sys");
-            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(64), 0, PSS_STREAM(ctx), U2, Lp, 0, L, L, c, Y2, L, q, n_out, nullptr, rows);
+            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(128), 0, PSS_STREAM(ctx), U2, Lp, 0, L, L, c, Y2, L, q, n_out, nullptr, rows);
             pss_kernel_end(ctx);
             pss_kernel_begin(ctx, "k_iir4_sys");
-            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(64), 0, PSS_STREAM(ctx), Y2, L, 1, L, L - EDGE, c, A2, (long)n_out, q, n_out, MX2, rows);
+            hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(128), 0, PSS_STREAM(ctx), Y2, L, 1, L, L - EDGE, c, A2, (long)n_out, q, n_out, MX2, rows);
             pss_kernel_end(ctx);
             size_t tot = (size_t)n_frames * n_out;
             size_t g2 = (tot + TPB - 1) / TPB;
