@@ -493,7 +493,7 @@ __global__ __launch_bounds__(128) void k_am_sys(const float *__restrict__ env, c
 #pragma unroll
         for (int gg = 0; gg < SYS_G; gg++) mus[gg] = (f0 + gg < n_frames) ? mu[f0 + gg] : 0.0f;
         unsigned nanmask = 0;  // bit gg: a NaN was seen in frame gg by this lane
-        auto load = [&](long blk, float (&pre)[SYS_G]) {
+        auto load = [&](long blk, float (&pre)[SYS_G]) __attribute__((always_inline)) {
             const long i = blk * SYS_T + lane;
             if ((blk + 1) * SYS_T <= n && f0 + SYS_G <= n_frames) {   // wave-uniform: twelve unconditional loads
                 const float *src = env + (size_t)f0 * n + i;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(128) void k_am_sys(const float *__restrict__ env, c
                 }
             }
         };
-        auto stage = [&](long blk, float (&pre)[SYS_G]) {     // pre[] holds block blk
+        auto stage = [&](long blk, float (&pre)[SYS_G]) __attribute__((always_inline)) {     // pre[] holds block blk
 #pragma unroll
             for (int gg = 0; gg < SYS_G; gg++) {
                 const long ff = f0 + gg;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(128) void k_am_sys(const float *__restrict__ env, c
                 ebuf[blk & 1][gg][lane] = e;
             }
         };
-        auto writeback = [&](long blk, int par) {  // ybuf[par] holds block blk of every frame
+        auto writeback = [&](long blk, int par) __attribute__((always_inline)) {  // ybuf[par] holds block blk of every frame
             double yv[SYS_G];
 #pragma unroll
             for (int gg = 0; gg < SYS_G; gg++) yv[gg] = ybuf[par][gg][lane];
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(128) void k_am_sys(const float *__restrict__ env, c
         if (nblk > 2) load(2, preA);
         fused::lds_barrier();   // LDS-only: the memory wavefront's loads and stores stay in flight across it
         // beside macro-step m: block m + 1 into the other input buffer, block m + 3 requested, the block macro-step m - 1 finished written back
-        auto beside = [&](long m, float (&pre)[SYS_G]) {     // pre: the set holding block m + 1
+        auto beside = [&](long m, float (&pre)[SYS_G]) __attribute__((always_inline)) {     // pre: the set holding block m + 1
             if (m + 1 < nblk) stage(m + 1, pre);
             if (m + 3 < nblk) load(m + 3, pre);
             if (m >= AM_NS) writeback(m - AM_NS, (int)((m - 1) & 1));
@@ -775,18 +775,20 @@ __global__ __launch_bounds__(128) void k_iir4_sys(const double *__restrict__ in,
 #pragma unroll
         for (int gg = 0; gg < IS_G; gg++) mxl[gg] = 0.0;
         double preA[IS_G], preB[IS_G];        // block k is loaded into preA (k even) / preB (k odd)
-        auto load = [&](long blk, double (&pre)[IS_G]) {
+        // (always_inline: a lambda left as a call keeps what it captures by reference — mxl[], the row pointers — in scratch memory;
+        // measured on this kernel: 297 scratch accesses, 11.4 instead of 4.1 ms for 64 frames of 32 768 samples)
+        auto load = [&](long blk, double (&pre)[IS_G]) __attribute__((always_inline)) {
 #pragma unroll
             for (int gg = 0; gg < IS_G; gg++) {
                 const long ff = f0 + gg, r = blk * IS_T + lane;
                 pre[gg] = (ff < n_rows && r < T) ? in[(size_t)ff * in_stride + (backward ? L - 1 - r : r)] : 0.0;
             }
         };
-        auto stage = [&](long blk, double (&pre)[IS_G]) {
+        auto stage = [&](long blk, double (&pre)[IS_G]) __attribute__((always_inline)) {
 #pragma unroll
             for (int gg = 0; gg < IS_G; gg++) ebuf[blk & 1][gg][lane] = pre[gg];
         };
-        auto writeback = [&](long blk, int par) {  // ybuf[par] holds block blk of every frame, lane = sample inside the block
+        auto writeback = [&](long blk, int par) __attribute__((always_inline)) {  // ybuf[par] holds block blk of every frame, lane = sample inside the block
             double yv[IS_G];
 #pragma unroll
             for (int gg = 0; gg < IS_G; gg++) yv[gg] = ybuf[par][gg][lane];
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(128) void k_iir4_sys(const double *__restrict__ in,
         if (nblk > 1) load(1, preB);
         if (nblk > 2) load(2, preA);
         fused::lds_barrier();   // LDS-only: the memory wavefront's loads and stores stay in flight across it
-        auto beside = [&](long m, double (&pre)[IS_G]) {     // pre: the set holding block m + 1
+        auto beside = [&](long m, double (&pre)[IS_G]) __attribute__((always_inline)) {     // pre: the set holding block m + 1
             if (m + 1 < nblk) stage(m + 1, pre);
             if (m + 3 < nblk) load(m + 3, pre);
             if (m >= 4) writeback(m - 4, (int)((m - 1) & 1));    // section 3 finished block m - 4 in the previous macro-step
