@@ -19,7 +19,16 @@
 
 namespace pss_r16 {
 
+// Complex product with explicit fused multiply-adds (4 instructions instead of 6).  pss_device.h switches contraction off for
+// everything that includes it — the demodulators' bit-exactness contract — so nothing in the transforms was fused until round 3;
+// their results are tolerance-bound (or rounded to float32 with ~1e-15 of margin), and the float64 pipe is what paces them.
+#ifdef PSS_EXP_NOFMA
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double power_of(double2 X) { return X.x * X.x + X.y * X.y + 1e-10; }
+#else
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x)); }
+__device__ __forceinline__ double power_of(double2 X) { return fma(X.x, X.x, fma(X.y, X.y, 1e-10)); }   // |X|^2 + 1e-10
+#endif
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 
@@ -215,7 +224,11 @@ __device__ __forceinline__ float db_of_fast(double pw)
     const float far = 3.0102999566398120f * __log2f((float)pw);
     const float s = t * __builtin_amdgcn_rcpf(2.0f + t);
     const float s2 = s * s;
+#ifdef PSS_EXP_NOFMA
     const float p = s * (2.0f + s2 * (0.66666667f + s2 * (0.4f + s2 * (0.28571429f + s2 * 0.22222222f))));
+#else
+    const float p = s * fmaf(s2, fmaf(s2, fmaf(s2, fmaf(s2, 0.22222222f, 0.28571429f), 0.4f), 0.66666667f), 2.0f);
+#endif
     return fabsf(t) < 0.25f ? 4.342944819032518f * p : far;
 }
 
@@ -224,6 +237,29 @@ constexpr int FLAG_SCAN_EXACT = 1, FLAG_DB_EXACT = 2;
 __device__ __forceinline__ float db_of(double pw, int flags = 0, const double2 *tab = DB_TAB)
 {
     return (flags & FLAG_DB_EXACT) ? db_of_exact(pw, tab) : db_of_fast(pw);
+}
+
+// Buffer addressing: resource descriptor (scalar base + size) + ONE per-lane byte offset + a scalar offset per access.  With
+// plain pointers the compiler materialises a 64-bit per-lane address for every row of the frame, hoists the 48 of them out
+// of the persistent frame loop and spills them (measured: 180 VGPRs of spills in a 128-VGPR kernel).
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float2 buf_load_f2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void buf_store_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff, float x)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
 }
 
 // DPP control "wave_rol:1" (gfx9): every lane reads its upper neighbour, lane 63 reads lane 0
@@ -279,13 +315,41 @@ __device__ __forceinline__ void r16_core(double2 (&v)[16], double2 *ex, const do
 #pragma unroll
     for (int m2 = 0; m2 < 16; m2++) v[m2] = ex[k2s * C::E1_STRIDE + m1s + R3 * m2];
     frame_sync<WAVE_LOCAL>();
+#ifndef PSS_EXP_TW2_AT_USE
+    // the stage-2 twiddles W_T^(m1 j2) come from LDS: requested TWD outputs ahead of their use, the first ones before the
+    // butterflies (read at the use, each of the 15 products waited for an LDS round trip with six instructions to cover it)
+    constexpr int TWD = 4;
+    const double2 *twp = tw2 + m1s * 16;
+    double2 tq[TWD];
+    if constexpr (R3 > 1) {
+#pragma unroll
+        for (int d = 0; d < TWD; d++) tq[d] = twp[1 + d];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     fft_reg<16>(v);
+#ifdef PSS_EXP_TW2_AT_USE
 #pragma unroll
     for (int j2 = 0; j2 < 16; j2++) {
         double2 z = v[brev(j2, 4)];
         if (R3 > 1) z = cmul(z, tw2[m1s * 16 + j2]);
         ex[m1s * C::E2_STRIDE + 16 * j2 + k2s] = z;
     }
+#else
+    {
+#pragma unroll
+        for (int j2 = 0; j2 < 16; j2++) {   // j2 = 0 is a product with 1
+            double2 z = v[brev(j2, 4)];
+            if constexpr (R3 > 1) {
+                if (j2 >= 1) {
+                    z = cmul(z, tq[(j2 - 1) % TWD]);
+                    if (j2 + TWD < 16) tq[(j2 - 1) % TWD] = twp[j2 + TWD];
+                }
+            }
+            ex[m1s * C::E2_STRIDE + 16 * j2 + k2s] = z;
+        }
+    }
+#endif
     frame_sync<WAVE_LOCAL>();
 #pragma unroll
     for (int c = 0; c < 16 / R3; c++) {
@@ -403,7 +467,11 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
     float2 nx[16];
     auto fetch = [&](long g) {
         const long f = g * FPW + fl;
+#ifdef PSS_EXP_SPEC_L2IQ   // timing experiment: every load hits the cache
+        const float2 *x = iq + (size_t)(f < n_frames ? (f & 15) : 0) * N;
+#else
         const float2 *x = iq + (size_t)(f < n_frames ? f : 0) * N;
+#endif
 #pragma unroll
         for (int n2 = 0; n2 < 16; n2++) nx[n2] = x[t + T * n2];
     };
@@ -416,15 +484,30 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
 #pragma unroll
         for (int n2 = 0; n2 < 16; n2++) v[n2] = make_double2((double)nx[n2].x * w[n2], (double)nx[n2].y * w[n2]);
         if (PREFETCH && g + gridDim.x < groups) fetch(g + gridDim.x);
-        float *out = (db && valid) ? db + (size_t)f * N : nullptr;
+        // Row stores.  PREFETCH kernels: through a buffer resource over the workgroup's FPW rows — frames past the end (and
+        // db == NULL) fall outside its size and the hardware drops them, so the 16 stores are UNCONDITIONAL in the instruction
+        // stream.  With `if (out)` around them the compiler has to assume at the loop head that the prefetched loads may be the
+        // youngest memory operations and waits for vmcnt(0) — i.e. for the acknowledgement of the stores just issued — once per
+        // frame; now it waits for the loads only (vmcnt counts in order: the 16 younger stores stay in flight).  1024 / 2048
+        // points: +3.5 / +4 % paired; without prefetch the loads ARE the youngest operations and plain pointers are 4-6 % faster.
+        float *out = (!PREFETCH && db && valid) ? db + (size_t)f * N : nullptr;
+        const long f_first = g * FPW;
+        const long rows_here = n_frames - f_first < FPW ? n_frames - f_first : FPW;
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc((PREFETCH && db) ? db + (size_t)f_first * N : nullptr, (PREFETCH && db) ? (unsigned)(rows_here * N * 4) : 0u);
+        const int ro_lane = (fl * N + t) * 4;
         float lmax = -INFINITY;
         float dbv[16];
         auto emit = [&](int i, int k, double2 X) {
             // compute_fft: float64 all the way, dB rounded to float32; scanner slice: NumPy's complex64 spectrum + float32 chain
             float d;
-            if constexpr (SCAN) d = (flags & FLAG_SCAN_EXACT) ? pss::scan_db_np(X.x, X.y, l10) : db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
-            else d = EXACT ? db_of_exact(X.x * X.x + X.y * X.y + 1e-10) : db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
-            if (out) out[(k + N / 2) & (N - 1)] = d;  // fftshift; T consecutive bins per store instruction
+            if constexpr (SCAN) d = (flags & FLAG_SCAN_EXACT) ? pss::scan_db_np(X.x, X.y, l10) : db_of_fast(power_of(X));
+            else d = EXACT ? db_of_exact(power_of(X)) : db_of_fast(power_of(X));
+#ifdef PSS_EXP_SPEC_NODB
+            d = (float)X.x + (float)X.y;
+#endif
+            // fftshift; T consecutive bins per store instruction (k - t is a multiple of T, so the row offset is a compile-time constant)
+            if constexpr (PREFETCH) buf_store_f32(ro, ro_lane, (((k - t) + N / 2) & (N - 1)) * 4, d);
+            else if (out) out[(k + N / 2) & (N - 1)] = d;
             dbv[i] = d;
             lmax = fmaxf(lmax, d);
         };
@@ -515,7 +598,7 @@ __global__ __launch_bounds__(256) void k_spectrum_r16_big(const float2 *__restri
             for (int n2 = 0; n2 < 16; n2++) v[n2] = scr[(size_t)r * NS + t + T * n2];
             r16_core<4>(v, ex, tw1, tw2, t, [&](int, int kp, double2 X) {
                 const int k = R * kp + r;
-                out[(k + N / 2) & (N - 1)] = db_of(X.x * X.x + X.y * X.y + 1e-10, flags);
+                out[(k + N / 2) & (N - 1)] = db_of(power_of(X), flags);
             });
             __syncthreads();
         }
@@ -645,7 +728,7 @@ __global__ __launch_bounds__(256) void k_huge_p2(const double2 *__restrict__ Y, 
         float *out = db + (size_t)f * N;
         r16_core<LOG_R3>(v, ex, tw1, tw2, t, [&](int, int kp, double2 X) {
             const size_t k = (size_t)256 * kp + r;
-            out[(k + N / 2) & (N - 1)] = db_of(X.x * X.x + X.y * X.y + 1e-10, flags);
+            out[(k + N / 2) & (N - 1)] = db_of(power_of(X), flags);
         });
         __syncthreads();
     }

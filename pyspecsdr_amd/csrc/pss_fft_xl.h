@@ -59,28 +59,11 @@ __device__ __forceinline__ void twiddle_powers(double2 (&v)[16], double2 w)
     v[brev(15, 4)] = cmul(v[brev(15, 4)], po);
 }
 
-// Buffer addressing: resource descriptor (scalar base + size) + ONE per-lane byte offset + a scalar offset per access.  With
-// plain pointers the compiler materialises a 64-bit per-lane address for every row of the frame, hoists the 48 of them out
-// of the persistent frame loop and spills them (measured: 180 VGPRs of spills in a 128-VGPR kernel).
-typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float2 buf_load_f2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
-{
-    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
-}
-__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, int voff, int soff)
-{
-    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return __hiloint2double((int)v.y, (int)v.x);
-}
-__device__ __forceinline__ void buf_store_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff, float x)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
-}
+using pss_r16::v2u_t;
+using pss_r16::make_rsrc;
+using pss_r16::buf_load_f2;
+using pss_r16::buf_load_f64;
+using pss_r16::buf_store_f32;
 
 // keeps the compiler from hoisting the next block's loads (and their registers) above this point
 __device__ __forceinline__ void sched_fence() { asm volatile("" ::: "memory"); }
@@ -89,6 +72,8 @@ __device__ __forceinline__ void sched_fence() { asm volatile("" ::: "memory"); }
 // wr(i) / rd(i) return the LDS location of the i-th value written / read as (base pointer, COMPILE-TIME element offset), so
 // that every access is one VGPR base + an immediate offset (the DS offset field holds 65535 bytes; bases are shared by as
 // many accesses as that reach allows).  Four workgroup barriers.
+// (Measured: the last barrier moved in FRONT of the next exchange's writes — a transform stage later, when every wavefront
+// has long finished reading — changes nothing at N = 4096 / 8192 and costs 5 % at 16 384.)
 template <class Wr, class Rd>
 __device__ __forceinline__ void exchange(double2 (&v)[16], Wr wr, Rd rd)
 {
@@ -189,8 +174,16 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *
     const double2 w3 = tw[(size_t)(t % R4) * 256];             // W_T2^c = W_N^(256 c)
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(win, WINDOW ? N * 8 : 0);
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+#ifdef PSS_EXP_SPEC_L2IQ   // timing experiment: every load hits the cache
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(iq + (size_t)(f & 15) * N, N * 8);
+#else
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(iq + (size_t)f * N, N * 8);
+#endif
+#ifdef PSS_EXP_SPEC_NOSTORE   // timing experiment: the row is computed and dropped by the bounds check
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc(db + (size_t)f * N, (flags & 0x100) ? N * 4 : 0);
+#else
         const __amdgpu_buffer_rsrc_t ro = make_rsrc(db ? db + (size_t)f * N : nullptr, db ? N * 4 : 0);   // no rows wanted: every store dropped
+#endif
         // the 45 twiddle powers are loop-invariant and the compiler would compute them once, park them in scratch memory
         // (180 VGPRs) and reload them every frame; recomputing them from the three bases is cheaper than that traffic
         double2 u1 = w1, u2 = w2, u3 = w3;
@@ -213,8 +206,11 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_spectrum_xl(const float2 *
         xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int i, int j, int k, double2 X) {
             // fftshift; bin 4096 k + T j + t: T consecutive bins per store instruction
             float d;
-            if constexpr (SCAN) d = (flags & pss_r16::FLAG_SCAN_EXACT) ? pss::scan_db_np(X.x, X.y, l10) : pss_r16::db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
-            else d = EXACT ? pss_r16::db_of_exact(X.x * X.x + X.y * X.y + 1e-10) : pss_r16::db_of_fast(X.x * X.x + X.y * X.y + 1e-10);
+            if constexpr (SCAN) d = (flags & pss_r16::FLAG_SCAN_EXACT) ? pss::scan_db_np(X.x, X.y, l10) : pss_r16::db_of_fast(pss_r16::power_of(X));
+            else d = EXACT ? pss_r16::db_of_exact(pss_r16::power_of(X)) : pss_r16::db_of_fast(pss_r16::power_of(X));
+#ifdef PSS_EXP_SPEC_NODB
+            d = (float)X.x + (float)X.y;
+#endif
             buf_store_f32(ro, t * 4, ((4096 * k + T * j + N / 2) & (N - 1)) * 4, d);
             if (SCAN) { held[i * T + t] = d; lmax = fmaxf(lmax, d); }
         });

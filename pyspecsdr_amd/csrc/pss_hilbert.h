@@ -166,7 +166,13 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_hilbert_xl(const double *x
             for (int q = 0; q < 16; q++) {
                 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
                 v4u_t pk = {(unsigned)__double2loint(y[q].x), (unsigned)__double2hiint(y[q].x), (unsigned)__double2loint(y[q].y), (unsigned)__double2hiint(y[q].y)};
-                __builtin_amdgcn_raw_buffer_store_b128(pk, ro, t * 16, T * q * 16, 0);
+                // The row offset rides in the per-lane offset, NOT in the scalar-offset operand: behind a 128-bit buffer store whose
+                // soffset is an SGPR the compiler's hazard recogniser leaves no wait state before a VALU write of the data registers
+                // (LLVM: "this hazard only exists if soffset is not a register"), and gfx950 does sample the data late — the
+                // `m = nanmax(...)` code that followed the last store overwrote lo(y[15].y) in lanes 12-15 of each row of 16 on a
+                // cold launch (first use of the kernel in a process: 16-48 wrong samples, relative error 1e-7).  With a constant
+                // soffset the recogniser inserts the wait states itself.  tools/check_store_hazard.py scans the ISA for the pattern.
+                __builtin_amdgcn_raw_buffer_store_b128(pk, ro, t * 16 + T * q * 16, 0, 0);
             }
         } else if (OUT == 1) {
 #pragma unroll

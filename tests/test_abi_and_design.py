@@ -263,3 +263,30 @@ def test_microbenchmarks_compile_for_gfx950():
         procs = [subprocess.Popen([cc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-w", "-c", s, "-o",
                                    os.path.join(d, os.path.basename(s) + ".o")]) for s in srcs]
         assert all(p.wait() == 0 for p in procs)
+
+
+def test_no_unprotected_wide_buffer_store_hazard():
+    """gfx950 samples the data registers of a > 64-bit buffer store late even when the store's scalar offset is an SGPR, a case LLVM's
+    hazard recogniser skips: a VALU write of those registers in the next two issue slots corrupts the stored value (k_hilbert_xl, round 3:
+    16-48 wrong samples on a cold launch).  tools/check_store_hazard.py scans the kernels' ISA for the pattern; the checker itself is
+    exercised on a hand-written positive and negative."""
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_store_hazard as C
+    with tempfile.TemporaryDirectory() as d:
+        bad = os.path.join(d, "bad.s")
+        open(bad, "w").write("_Zk:\n\tbuffer_store_dwordx4 v[14:17], v106, s[20:23], s86 offen\n\tv_and_b32_e32 v16, 0x7fffffff, v75\n\ts_endpgm\n")
+        ok = os.path.join(d, "ok.s")
+        open(ok, "w").write("_Zk:\n\tbuffer_store_dwordx4 v[14:17], v106, s[20:23], s86 offen\n\ts_nop 1\n\tv_and_b32_e32 v16, 0x7fffffff, v75\n"
+                            "\tbuffer_store_dwordx4 v[14:17], v2, s[20:23], 0 offen\n\tv_mov_b32_e32 v14, 0\n"      # constant soffset: the compiler's job
+                            "\tbuffer_store_dwordx2 v[14:15], v2, s[20:23], s3 offen\n\tv_mov_b32_e32 v14, 0\n\ts_endpgm\n")
+        assert len(C.scan(bad)) == 1 and C.scan(ok) == []
+    cc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(cc):
+        pytest.skip("hipcc not available")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py")], check=True, capture_output=True, timeout=900)
+    hits = [h for f in ("pss_fft.s", "pss_demod.s") for h in C.scan(os.path.join(ROOT, "pyspecsdr_amd", "_build", "asm", f))]
+    assert hits == [], hits

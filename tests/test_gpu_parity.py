@@ -516,6 +516,38 @@ def test_ssb_on_the_reference_read_buffer_sizes():
                 assert np.array_equal(au_x[k], O.demod_ssb(iq[k], taps)), (n, k)
 
 
+_COLD = r"""
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+import gpu_util as G
+e = G.engine()
+n, nf = int(sys.argv[1]), 9
+x = np.random.default_rng(n).standard_normal((nf, n))
+d_x = G.dev(x)
+outs = []
+for rep in range(3):
+    d_out = G.empty((nf, n, 2), torch.float64)
+    e.hilbert(d_x, nf, n, d_out); e.sync()
+    outs.append(G.host(d_out).view(np.uint64).copy())
+print("COLD_DIFF", int((outs[0] != outs[2]).sum()), int((outs[1] != outs[2]).sum()))
+"""
+
+
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_hilbert_first_launch_in_a_process_equals_later_ones(n):
+    """A kernel's very first launch in a process (cold instruction cache) stretches the window of the store-data hazard that
+    k_hilbert_xl's 128-bit buffer stores had (round 3: 16-48 samples with a wrong low word, first launch only; the CPU-side guard is
+    test_no_unprotected_wide_buffer_store_hazard).  Fresh interpreter, the transform as its first GPU work, three launches bit-equal."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for _ in range(3):
+        out = subprocess.run([sys.executable, "-c", _COLD, str(n)], cwd=root, check=True, capture_output=True, text=True, timeout=300).stdout
+        assert "COLD_DIFF 0 0" in out, out
+
+
 @pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 1048576])
 def test_hilbert_rows(n):
     """pss_hilbert = scipy.signal.hilbert along rows (fft, one-sided mask, ifft; _signaltools.py:2318), both transforms in one
