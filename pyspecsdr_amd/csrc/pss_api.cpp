@@ -199,7 +199,7 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "fft_split")) { ctx->fft_split = value; return PSS_OK; }
     if (!strcmp(key, "fft_big_scratch")) { ctx->fft_big_scratch = value != 0; return PSS_OK; }
     if (!strcmp(key, "fft_prefetch")) { ctx->fft_prefetch = value; return PSS_OK; }
-    if (!strcmp(key, "fft_xl4096")) { ctx->fft_xl4096 = value != 0; return PSS_OK; }
+    if (!strcmp(key, "fft_xl4096")) { ctx->fft_xl4096 = value; return PSS_OK; }
     if (!strcmp(key, "post_sort_max")) { ctx->post_sort_max = value; return PSS_OK; }
     if (!strcmp(key, "post_legacy")) { ctx->post_legacy = value != 0; return PSS_OK; }
 #endif

@@ -89,7 +89,7 @@ struct pss_ctx {
     bool ssb_hilbert = true;   // option "ssb_hilbert": run the reference's hilbert() round trip inside demodulate_ssb where a register transform exists for the frame length
     bool db_exact = false;         // true: compute_fft's dB rows evaluated to float64 accuracy and rounded once (= float32 of the reference's float64 rows); false: float32 evaluation, 1-2 ulp off, 15-25 % faster kernels
     bool scan_exact = true;        // scanner slices: NumPy's float32 chain bit for bit (scan_db_np); false: the float64 / hardware-log2 dB of compute_fft
-    bool fft_xl4096 = true;        // N = 4096 on the component-wise-exchange kernel (pss_fft_xl.h, R4 = 1) instead of k_spectrum_r16<4>
+    int fft_xl4096 = -1;           // N = 4096 on the component-wise-exchange kernel (pss_fft_xl.h, R4 = 1) instead of k_spectrum_r16<4>; -1 = scanner slices only
     bool post_legacy = false;  // option "post_legacy": LDS bitonic sort / LDS-histogram radix select instead of the register select
     int post_sort_max = 8192;  // option "post_sort_max": longest row that takes the LDS bitonic sort, else radix select (measured crossover 8192..16384)
     bool fft_big_scratch = false;  // option "fft_big_scratch": N = 8192 / 16384 on the scratch-based radix-R pre-pass kernel (A/B reference)

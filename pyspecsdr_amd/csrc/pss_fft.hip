@@ -672,33 +672,35 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     // component-wise LDS exchanges (half the LDS, twice the barriers) pay only at N = 256, where the plain kernel fits a
     // single 80 KB workgroup per CU: 0.29 -> 0.20 ms for 262144 frames; at 512...2048 they measured 20 % slower
     // next-frame prefetch, A/B in one process: N = 1024: 0.198 -> 0.185 ms (65536 frames), 2048: 0.234 -> 0.226 ms; 512: no change;
-    // 4096: 0.27 -> 0.35 ms (274 VGPRs: one wavefront per SIMD); 256: the split kernel wins
+    // 4096: 0.27 -> 0.35 ms (274 VGPRs: one wavefront per SIMD) in round 2; since the stage-2 twiddles are fetched from LDS a few products
+    // ahead the kernel has 238 VGPRs with the prefetch, and with conflict-free exchanges it is the fastest 4096-point kernel:
+    // 0.200 ms per 2^26 samples against 0.210 without the prefetch and 0.233 for k_spectrum_xl<0>; 256: the split kernel wins
     // "db_exact" (compute_fft rows only): its own instantiations (244 VGPRs with the prefetch: no spill)
     const bool exact = !SCAN && ctx->db_exact;
     int fpw = C::FPW;
 #ifdef PSS_VARIANTS   // every combination, steered by the options "fft_split" / "fft_prefetch" / "fft_two_per_wg" (A/B builds)
     const bool split = ctx->fft_split >= 0 ? ctx->fft_split != 0 : LOG_R3 == 0;
-    const bool prefetch = !split && (ctx->fft_prefetch >= 0 ? ctx->fft_prefetch != 0 : (LOG_R3 == 2 || LOG_R3 == 3));
+    const bool prefetch = !split && (ctx->fft_prefetch >= 0 ? ctx->fft_prefetch != 0 : (LOG_R3 >= 2 && !(LOG_R3 == 4 && SCAN)));
     auto kern = exact ? (split ? pss_r16::k_spectrum_r16<LOG_R3, false, true, false, true>
                          : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, false, false, true, true> : pss_r16::k_spectrum_r16<LOG_R3, false, false, false, true>)
                 : split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true, false>
                 : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, true> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, false, false>;
-    size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2) : C::LDS;
+    size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::TW2 * sizeof(double2) : C::LDS;
     if constexpr (LOG_R3 == 3 && !SCAN) {
         // N = 2048 (two wavefronts per frame): one frame per 128-thread workgroup
         if (!split && !ctx->fft_two_per_wg) {
             kern = exact ? (prefetch ? pss_r16::k_spectrum_r16<3, false, false, true, true, true> : pss_r16::k_spectrum_r16<3, false, false, false, true, true>)
                          : (prefetch ? pss_r16::k_spectrum_r16<3, false, false, true, false, true> : pss_r16::k_spectrum_r16<3, false, false, false, false, true>);
             fpw = 1;
-            lds = (size_t)C::EX * sizeof(double2) + (size_t)C::R3 * 16 * sizeof(double2);
+            lds = (size_t)C::EX * sizeof(double2) + (size_t)C::TW2 * sizeof(double2);
         }
     }
 #else                 // the product library carries the measured winner per length only (12 instantiations instead of 49)
-    constexpr bool split = LOG_R3 == 0, prefetch = LOG_R3 == 2 || LOG_R3 == 3, one = LOG_R3 == 3 && !SCAN;
+    constexpr bool split = LOG_R3 == 0, prefetch = LOG_R3 >= 2 && !(LOG_R3 == 4 && SCAN), one = LOG_R3 == 3 && !SCAN;
     auto kern = exact ? pss_r16::k_spectrum_r16<LOG_R3, false, split, prefetch, true, one> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, split, prefetch, false, one>;
     if (one) fpw = 1;
-    const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::R3 * 16 * sizeof(double2)
-                             : (size_t)fpw * C::EX * sizeof(double2) + (size_t)C::R3 * 16 * sizeof(double2);
+    const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::TW2 * sizeof(double2)
+                             : (size_t)fpw * C::EX * sizeof(double2) + (size_t)C::TW2 * sizeof(double2);
 #endif
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -741,10 +743,15 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
     case 1024: return launch_r16<2, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
     case 2048: return launch_r16<3, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
     case 4096:
-        // default: the component-wise-exchange kernel below (128 VGPRs, 35 KB LDS: four workgroups per CU; 3.3 against 2.4-2.7 TB/s);
-        // "fft_xl4096" = 0 or "fft_big_scratch" = 1: the three-stage kernel with complex exchanges (two workgroups per CU)
+        // compute_fft rows: the three-stage kernel with complex exchanges (two workgroups per CU, next frame prefetched): 4.0 TB/s since
+        // round 3 (conflict-free layouts, fused multiply-adds); scanner slices: the component-wise-exchange kernel below (128 VGPRs,
+        // 35 KB LDS: four workgroups per CU), which hides the exact float32 chain's dependent arithmetic better.
+        // "fft_xl4096" = 0 / 1 (variant builds): one of the two for both.
 #ifdef PSS_VARIANTS
-        if (!ctx->fft_xl4096 || ctx->fft_big_scratch) return launch_r16<4, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
+        if ((ctx->fft_xl4096 >= 0 ? !ctx->fft_xl4096 : !SCAN) || ctx->fft_big_scratch)
+            return launch_r16<4, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
+#else
+        if constexpr (!SCAN) return launch_r16<4, SCAN>(ctx, d_iq, n_frames, d_db, tw, win, d_peak, d_bw, d_count, bin_hz);
 #endif
         break;
     default: break;
@@ -763,11 +770,17 @@ int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, f
             return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_xl launch");
         };
         if (!SCAN && ctx->db_exact) {
+#ifdef PSS_VARIANTS
             if (n_fft == 4096) return go(pss_xl::k_spectrum_xl<0, true, false, true>, pss_xl::CfgX<0>::LDS, 256, 4);
+#endif
             if (n_fft == 8192) return go(pss_xl::k_spectrum_xl<1, true, false, true>, pss_xl::CfgX<1>::LDS, 512, 2);
             return go(pss_xl::k_spectrum_xl<2, true, false, true>, pss_xl::CfgX<2>::LDS, 1024, 1);
         }
+#ifdef PSS_VARIANTS
         if (n_fft == 4096) return go(pss_xl::k_spectrum_xl<0, !SCAN, SCAN>, pss_xl::CfgX<0>::LDS, 256, 4);
+#else
+        if constexpr (SCAN) return go(pss_xl::k_spectrum_xl<0, false, true>, pss_xl::CfgX<0>::LDS, 256, 4);
+#endif
         if (n_fft == 8192) return go(pss_xl::k_spectrum_xl<1, true>, pss_xl::CfgX<1>::LDS, 512, 2);
         return go(pss_xl::k_spectrum_xl<2, true>, pss_xl::CfgX<2>::LDS, 1024, 1);
     }

@@ -34,7 +34,13 @@ struct CfgX {
     static constexpr int N = 16 * T;
     static constexpr int T2 = 16 * R4;              // T / 16
     static constexpr int E2 = T2 + R4;              // row stride of exchange 2 (doubles): groups of R4 lanes land R4 apart mod 32
-    static constexpr int P3 = 16 * 272 + 32 / R4;   // plane stride of exchange 3 (doubles): 17-double rows, planes 32/R4 apart mod 32
+#ifdef PSS_EXP_OLDPAD
+    static constexpr int P3 = 16 * 272 + 32 / R4;
+#else
+    // plane stride of exchange 3 (doubles): 17-double rows; a ds_write_b64 is served 16 consecutive lanes at a time against 32 banks
+    // (16 eight-byte slots): 16 / R4 values of r2 x R4 planes -> slots 17 r2 + P3 c, all different iff P3 = 16 / R4 (mod 16)
+    static constexpr int P3 = 16 * 272 + 16 / R4;
+#endif
     static constexpr int EXD = (R4 * P3 > 256 * E2) ? R4 * P3 : 256 * E2;   // doubles (>= 16 T for exchange 1)
     static constexpr size_t LDS = (size_t)EXD * sizeof(double);
 };

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_hilbert_r16(const double *x, double *ou
     tw1[0] = make_double2(1.0, 0.0);
 #pragma unroll
     for (int k2 = 1; k2 < 16; k2++) tw1[k2] = tw[(size_t)t * k2];
-    if (tid < R3 * 16) tw2[tid] = tw[(size_t)((tid / 16) * (tid % 16)) * 16];
+    if (tid < R3 * 16) tw2[C::tw2_slot(tid)] = tw[(size_t)((tid / 16) * (tid % 16)) * 16];
     __syncthreads();
     constexpr bool WL = T <= 64;
     constexpr double INV_N = 1.0 / (double)N;

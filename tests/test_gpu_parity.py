@@ -37,13 +37,13 @@ def test_spectrum_vs_golden(golden, n):
     assert np.all(rel_err(db, ref)[big] <= 1e-4)
     assert np.all(np.abs(db - ref)[~big] <= 1e-6)
     assert np.max(np.abs(db - ref)) < 2e-5  # in practice: float32 rounding of the output only
-    if n == 4096 and G.has_option("fft_xl4096", 1):   # (variant builds) the three-stage kernel with complex exchanges against the same golden
+    if n == 4096 and G.has_option("fft_xl4096", -1):   # (variant builds) the component-wise-exchange kernel against the same golden
         e = G.engine()
-        e.set_option("fft_xl4096", 0)
+        e.set_option("fft_xl4096", 1)
         try:
             db0 = G.spectrum(iq)
         finally:
-            e.set_option("fft_xl4096", 1)
+            e.set_option("fft_xl4096", -1)
         assert np.all(rel_err(db0, ref)[big] <= 1e-4) and np.max(np.abs(db0 - ref)) < 2e-5
         assert np.max(np.abs(db0 - db)) < 2e-5
 
@@ -89,7 +89,7 @@ def test_spectrum_split_exchange_is_bit_identical():
             finally:
                 e.set_option("fft_split", -1)
                 e.set_option("fft_prefetch", -1)
-        e.set_option("fft_xl4096", 1)
+        e.set_option("fft_xl4096", -1)
         assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32)), n
         assert np.array_equal(res[0].view(np.uint32), res[2].view(np.uint32)), n
 
@@ -1299,14 +1299,14 @@ def test_scanner(golden, n):
     assert np.array_equal(cnt, g[f"count_{n}"].astype(cnt.dtype)) and np.array_equal(bw, g[f"bw_{n}"])
     for k in range(ns):
         assert pk[k] == db[k].max() and cnt[k] == int(np.sum(db[k] > pk[k] - np.float32(20)))  # self-consistent
-    if n == 4096 and G.has_option("fft_xl4096", 1):   # (variant builds) the other N = 4096 kernel produces the same rows
+    if n == 4096 and G.has_option("fft_xl4096", -1):   # (variant builds) the other N = 4096 kernel produces the same rows
         e.set_option("fft_xl4096", 0)
         try:
             d_db2 = G.empty((ns, n), torch.float32)
             e.scan(G.dev(iq), ns, n, 2.4e6, d_db2, d_pk, d_bw, d_cnt)
             e.sync()
         finally:
-            e.set_option("fft_xl4096", 1)
+            e.set_option("fft_xl4096", -1)
         assert np.array_equal(G.host(d_db2).view(np.uint32), ref.view(np.uint32))
 
 
