@@ -548,6 +548,62 @@ def test_hilbert_first_launch_in_a_process_equals_later_ones(n):
         assert "COLD_DIFF 0 0" in out, out
 
 
+_COLD_ALL = r"""
+import os, sys, zlib
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+import gpu_util as G
+from pyspecsdr_amd import _lib as L
+e = G.engine()
+rng = np.random.default_rng(7)
+def iq(nf, n):
+    t = np.arange(n)
+    return (0.1 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n))) + 0.5 * np.exp(2j * np.pi * rng.uniform(-0.3, 0.3, (nf, 1)) * t)).astype(np.complex64)
+cases = []
+for n in (256, 1024, 2048, 4096, 8192, 16384, 3000):
+    cases.append(("spectrum", n, G.dev(iq(40, n)), 40))
+for n in (1024, 4096):
+    cases.append(("scan", n, G.dev(iq(40, n)), 40))
+for mode, n, nf in ((L.MODE_NFM, 1024, 300), (L.MODE_NFM, 32768, 2), (L.MODE_AM, 16384, 9), (L.MODE_USB, 16384, 9), (L.MODE_USB, 2048, 40), (L.MODE_WFM, 2048, 130), (L.MODE_WFM, 32768, 1)):
+    cases.append(("demod%d" % mode, n, G.dev(iq(nf, n)), nf))
+cases.append(("power", 16384, G.dev(iq(9, 16384)), 9))
+cases.append(("iqcorr", 4096, G.dev(iq(9, 4096)), 9))
+def run(kind, n, d, nf):
+    fs = 2.4e6 if n <= 4096 else 250e3
+    if kind == "spectrum":
+        o = G.empty((nf, n), torch.float32); e.spectrum_db(d, nf, n, o); e.sync(); return [G.host(o)]
+    if kind == "scan":
+        o, pk, bw, c = G.empty((nf, n), torch.float32), G.empty((nf,), torch.float32), G.empty((nf,), torch.float64), G.empty((nf,), torch.int32)
+        e.scan(d, nf, n, fs, o, pk, bw, c); e.sync(); return [G.host(o), G.host(pk), G.host(c)]
+    if kind.startswith("demod"):
+        mode = int(kind[5:]); n_out = e.demod_out_len(mode, n, fs)
+        pcm, au = G.empty((nf, n_out, 2), torch.int16), G.empty((nf, n_out * (2 if mode == L.MODE_WFM else 1)), torch.float64)
+        e.demod(mode, d, nf, n, fs, pcm, au); e.sync(); return [G.host(pcm), G.host(au)]
+    if kind == "power":
+        o = G.empty((nf,), torch.float32); e.power_db(d, nf, n, o); e.sync(); return [G.host(o)]
+    o = G.empty((nf, n, 2), torch.float32); e.iq_correction(d, nf, n, o); e.sync(); return [G.host(o)]
+bad = []
+first = [[zlib.crc32(a.tobytes()) for a in run(*c)] for c in cases]     # every kernel family's first launch in this process
+for rep in range(2):
+    for c, f in zip(cases, first):
+        if [zlib.crc32(a.tobytes()) for a in run(*c)] != f: bad.append((c[0], c[1], rep))
+print("COLD_ALL", len(cases), bad)
+"""
+
+
+def test_first_launches_in_a_process_equal_later_ones():
+    """Every kernel family's first launch in a fresh interpreter against its second and third on the same input, byte for byte
+    (spectra 256 ... 16384 and a Bluestein length, scanner slices, NFM / AM / SSB / WFM on both batch shapes, power, iq_correction):
+    the generic form of the Hilbert check below — a hazard that only a cold instruction cache exposes shows up here."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for _ in range(2):
+        out = subprocess.run([sys.executable, "-c", _COLD_ALL], cwd=root, check=True, capture_output=True, text=True, timeout=600).stdout
+        assert "COLD_ALL 18 []" in out, out[-2000:]
+
+
 @pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 1048576])
 def test_hilbert_rows(n):
     """pss_hilbert = scipy.signal.hilbert along rows (fft, one-sided mask, ifft; _signaltools.py:2318), both transforms in one
