@@ -961,6 +961,19 @@ __device__ __forceinline__ float wg_rsum(const PlanDev &p, float *part, float *v
     }
     for (int slot = tid; slot < p.n_leaves * 8; slot += T) {
         const int l = slot >> 3, k = slot & 7, off = p.leaf_off[l], len = p.leaf_len[l];
+#ifndef PSS_EXP_RSUM4
+        if (len == 128) {
+            // a full leaf: all 16 operands of this accumulator requested before the dependent chain of additions starts (four ahead,
+            // a CU's 2048 threads kept ~64 KB in flight and the pass ran at 3.7 TB/s)
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = elem(off + 8 * j + k);
+            float r = v[0];
+#pragma unroll
+            for (int j = 1; j < 16; j++) r = __fadd_rn(r, v[j]);
+            part[slot] = r;
+        } else
+#endif
         if (len >= 8) {
             // the additions are a dependent chain in numpy's order; the operands are not: fetch four ahead of the chain
             float r = elem(off + k);
@@ -2137,7 +2150,7 @@ int launch_pairwise(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
-    long g = n_frames < 8192 ? n_frames : 8192;  // several frames per workgroup: the plan tables are copied to LDS once
+    long g = n_frames < 8192 ? n_frames : 8192;  // several frames per workgroup: the plan tables are copied to LDS once (a grid capped at what the CUs hold at once — 2048 workgroups — measured 20 % slower: the dispatcher's backfill of finished workgroups is the better balance)
     pss_kernel_begin(ctx, "k_pairwise");
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, rp,
                        part_slots, vals, d_out, d_env);
@@ -2266,7 +2279,7 @@ extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames,
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const RedPlan &a = rp, &b = cp;
-    long g = n_frames < 8192 ? n_frames : 8192;  // several frames per workgroup: the plan tables are copied to LDS once
+    long g = n_frames < 8192 ? n_frames : 8192;  // several frames per workgroup: the plan tables are copied to LDS once (a grid capped at what the CUs hold at once — 2048 workgroups — measured 20 % slower: the dispatcher's backfill of finished workgroups is the better balance)
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_iqcorr");
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, a, b,
