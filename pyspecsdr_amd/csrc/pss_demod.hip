@@ -589,6 +589,7 @@ __global__ __launch_bounds__(128) void k_am_sys(const float *__restrict__ env, c
         const int cnt = !active ? 0 : ((n - blk * SYS_T) < SYS_T ? (int)(n - blk * SYS_T) : SYS_T);
         if (__all(!active || cnt == SYS_T)) {  // one code path per macro-step for the whole wavefront (in-place hand-off)
             if (active) {
+#ifdef PSS_EXP_SYS_NOPF
                 for (int t0 = 0; t0 < SYS_T; t0 += 8) {
                     double e8[8], y8[8];
 #pragma unroll
@@ -598,6 +599,33 @@ __global__ __launch_bounds__(128) void k_am_sys(const float *__restrict__ env, c
 #pragma unroll
                     for (int k = 0; k < 8; k++) dst[t0 + k] = y8[k];
                 }
+#else
+                // two groups of eight per turn, each group's inputs requested from LDS before the OTHER group's recurrence steps (a lone
+                // wavefront: the LDS round trip of a group otherwise stands in front of its 8 x 48 clocks); reading ahead is safe for the
+                // in-place hand-off — a position is read before this macro-step's write of it either way.  No register copies: the two
+                // groups alternate between two register sets (a rotating single set cost 16 moves per group and lost 14 %).
+                static_assert(SYS_T % 16 == 0, "block length");
+                double ea[8], eb[8], y8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) ea[k] = src[k];
+#pragma unroll 1
+                for (int t0 = 0; t0 < SYS_T; t0 += 16) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) eb[k] = src[t0 + 8 + k];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) y8[k] = step(ea[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dst[t0 + k] = y8[k];
+                    if (t0 + 16 < SYS_T) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) ea[k] = src[t0 + 16 + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) y8[k] = step(eb[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dst[t0 + 8 + k] = y8[k];
+                }
+#endif
             }
         } else {
             for (int t = 0; t < SYS_T; t++) {
@@ -865,6 +893,7 @@ __global__ __launch_bounds__(128) void k_iir4_sys(const double *__restrict__ in,
         // all lanes must walk the block in lockstep for the in-place hand-off: one code path per macro-step, chosen wave-wide
         if (__all(!active || cnt == IS_T)) {
             if (active) {
+#ifdef PSS_EXP_SYS_NOPF
                 for (int t0 = 0; t0 < IS_T; t0 += 8) {
                     double e8[8], y8[8];
 #pragma unroll
@@ -874,6 +903,33 @@ __global__ __launch_bounds__(128) void k_iir4_sys(const double *__restrict__ in,
 #pragma unroll
                     for (int k = 0; k < 8; k++) dst[t0 + k] = y8[k];
                 }
+#else
+                // two groups of eight per turn, each group's inputs requested from LDS before the OTHER group's recurrence steps (a lone
+                // wavefront: the LDS round trip of a group otherwise stands in front of its 8 x 48 clocks); reading ahead is safe for the
+                // in-place hand-off — a position is read before this macro-step's write of it either way.  No register copies: the two
+                // groups alternate between two register sets (a rotating single set cost 16 moves per group and lost 14 %).
+                static_assert(IS_T % 16 == 0, "block length");
+                double ea[8], eb[8], y8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) ea[k] = src[k];
+#pragma unroll 1
+                for (int t0 = 0; t0 < IS_T; t0 += 16) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) eb[k] = src[t0 + 8 + k];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) y8[k] = step(ea[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dst[t0 + k] = y8[k];
+                    if (t0 + 16 < IS_T) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) ea[k] = src[t0 + 16 + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) y8[k] = step(eb[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dst[t0 + 8 + k] = y8[k];
+                }
+#endif
             }
         } else {
             for (int t = 0; t < IS_T; t++) {  // a partial block somewhere: masked steps, read-then-write per position
