@@ -16,8 +16,9 @@
 #include <hip/hip_runtime.h>
 // From here to the end of the including unit (pss_fft.hip: this header, the display quantisers, the Bluestein functors) float
 // expressions are evaluated as written — no fused multiply-adds the reference's NumPy statements do not contain (np.convolve's
-// products and sums, the normalisation / interpolation arithmetic of the display code).  The transform kernels are defined
-// in the headers included BEFORE this one (pss_fft_r16.h, pss_fft_xl.h) and keep the unit's default contraction.
+// products and sums, the normalisation / interpolation arithmetic of the display code).  (pss_device.h already switches
+// contraction off for every unit that includes it — the transform kernels in pss_fft_r16.h / pss_fft_xl.h write the fused
+// multiply-adds they want as explicit fma(); the pragma here keeps this header correct on its own.)
 #pragma clang fp contract(off)
 
 namespace pss_post {
