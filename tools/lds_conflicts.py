@@ -11,7 +11,7 @@ import csv
 import glob
 import sys
 
-for d in sys.argv[1:]:
+for d in [a for a in sys.argv[1:]]:
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     if not f:
         print(d, "no counter_collection.csv")
@@ -19,13 +19,14 @@ for d in sys.argv[1:]:
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
     for r in csv.DictReader(open(f[0])):
-        k = r["Kernel_Name"].split("(")[0][-70:]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
     for k in sorted(acc):
-        if "spectrum" not in k and "hilbert" not in k:
-            continue
         c = acc[k]
+        if c["SQ_LDS_IDX_ACTIVE"] == 0:
+            continue
         n = cnt[(k, "SQ_LDS_IDX_ACTIVE")]
+        busy = f"  LDS cycles / wave cycles {c['SQ_LDS_IDX_ACTIVE'] / c['SQ_WAVE_CYCLES']:.3f}" if c.get("SQ_WAVE_CYCLES") else ""
         print(f"{d.rstrip('/').split('/')[-1]:14s} {k:72s} launches {n:3d}  LDS_IDX_ACTIVE {c['SQ_LDS_IDX_ACTIVE'] / n:.3e}  "
-              f"BANK_CONFLICT {c['SQ_LDS_BANK_CONFLICT'] / n:.3e}  share {c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_LDS_IDX_ACTIVE'], 1):.3f}")
+              f"BANK_CONFLICT {c['SQ_LDS_BANK_CONFLICT'] / n:.3e}  share {c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_LDS_IDX_ACTIVE'], 1):.3f}{busy}")
