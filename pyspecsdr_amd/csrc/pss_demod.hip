@@ -1463,6 +1463,7 @@ struct CascLane {
 struct CascArg { CascLane lane[16]; };
 constexpr int CS_T = 64;
 
+#ifdef PSS_EXP_CASC_ONEWAVE
 template <int MODE>  // 1: discriminator -> a, p, m      2: m, p, a -> u_l, u_r (+ odd extension)
 __global__ __launch_bounds__(64) void k_wfm_casc(const float2 *__restrict__ iq, double *__restrict__ Aa, double *__restrict__ Pp,
                                                  double *__restrict__ Mm, double *U, int n, long n_frames, long Lp, int swapped,
@@ -1573,6 +1574,165 @@ __global__ __launch_bounds__(64) void k_wfm_casc(const float2 *__restrict__ iq, 
         }
     }
 }
+
+#else
+// Two wavefronts per workgroup (round 3, as k_am_sys / k_iir4_sys): wavefront 0 runs the sample-systolic recurrence, wavefront 1 the
+// memory side — raw inputs of block m + 3 requested, block m + 1 computed (the discriminator in pass 1, m * 2p in pass 2) and staged,
+// block m - 1 written back — through double-buffered LDS blocks and LDS-only barriers.  As one wavefront the kernel computed four
+// discriminator samples per lane and waited for its own loads and stores between any two 64-step blocks.
+template <int MODE>  // 1: discriminator -> a, p, m      2: m, p, a -> u_l, u_r (+ odd extension)
+__global__ __launch_bounds__(128) void k_wfm_casc(const float2 *__restrict__ iq, double *__restrict__ Aa, double *__restrict__ Pp,
+                                                  double *__restrict__ Mm, double *U, int n, long n_frames, long Lp, int swapped,
+                                                  CascArg arg)
+{
+    constexpr int NIN = 2, NOUT = 3;
+    __shared__ double ebuf[2][4][NIN][CS_T + 1];
+    __shared__ double ybuf[2][4][NOUT + 1][CS_T + 1];  // row NOUT: dump row
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long f0 = (long)blockIdx.x * 4;
+    const int M = n - 1;
+    const int DA = (MODE == 1) ? 2 : 3, DB = (MODE == 1) ? 5 : 3, DC = 4;  // pipeline delay of each output row
+    const long TT = (long)M + 5;  // steps incl. drain of the deepest cascade
+    const long nblk = (TT + CS_T - 1) / CS_T;
+    const double SIN_PI = 0x1.1a62633145c07p-53;  // np.sin(np.pi)
+    if (wave == 1) {
+        // ---------------- memory wavefront: lane = sample inside a block ----------------
+        struct Raw { float2 x0[4], x1[4]; double m[4], p[4], a[4]; };
+        Raw rawA, rawB;
+        auto load = [&](long blk, Raw &r) __attribute__((always_inline)) {
+            const long i = blk * CS_T + lane;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const long f = f0 + g;
+                const bool ok = f < n_frames && i < M;
+                if (MODE == 1) {
+                    const float2 *x = iq + (size_t)(f < n_frames ? f : 0) * n;
+                    r.x0[g] = ok ? x[i] : make_float2(0.0f, 0.0f);
+                    r.x1[g] = ok ? x[i + 1] : make_float2(0.0f, 0.0f);
+                } else {
+                    const size_t o = (size_t)(f < n_frames ? f : 0) * M;
+                    r.m[g] = ok ? Mm[o + i] : 0.0;
+                    r.p[g] = ok ? Pp[o + i] : 0.0;
+                    r.a[g] = (f < n_frames && i - 3 >= 0 && i - 3 < M) ? Aa[o + i - 3] : 0.0;   // a[], aligned with the mixing lanes
+                }
+            }
+        };
+        auto stage = [&](long blk, const Raw &r) __attribute__((always_inline)) {
+            const long i = blk * CS_T + lane;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const long f = f0 + g;
+                double e0 = 0.0, e1 = 0.0;
+                if (f < n_frames) {
+                    if (MODE == 1) {
+                        if (i < M) e0 = (double)disc_sample(r.x1[g], r.x0[g], 1.0f, swapped != 0);  // :122
+                    } else {
+                        if (i < M) e0 = __dmul_rn(r.m[g], __dmul_rn(2.0, r.p[g]));  // :134
+                        if (i - 3 >= 0 && i - 3 < M) e1 = r.a[g];
+                    }
+                }
+                ebuf[blk & 1][g][0][lane] = e0;
+                ebuf[blk & 1][g][1][lane] = e1;
+            }
+        };
+        auto writeback = [&](long blk) __attribute__((always_inline)) {   // ybuf[blk & 1] holds what the array produced during block blk
+            const long c0 = blk * CS_T;
+            const int par = (int)(blk & 1);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const long f = f0 + g;
+                if (f >= n_frames) continue;
+                const long ia = c0 + lane - DA, ib = c0 + lane - DB, ic = c0 + lane - DC;
+                if (MODE == 1) {
+                    if (ia >= 0 && ia < M) Aa[(size_t)f * M + ia] = ybuf[par][g][0][lane];
+                    if (ib >= 0 && ib < M) {
+                        const double y = ybuf[par][g][1][lane];  // :130 np.sin(np.unwrap(np.angle(real))) = 0 or sin(pi)
+                        Pp[(size_t)f * M + ib] = (y != y) ? y : ((y < 0.0 || (y == 0.0 && __builtin_signbit(y))) ? SIN_PI : 0.0);
+                    }
+                    if (ic >= 0 && ic < M) Mm[(size_t)f * M + ic] = ybuf[par][g][2][lane];
+                } else {
+                    if (ia >= 0 && ia < M) U[(size_t)(2 * f) * Lp + EDGE + ia] = ybuf[par][g][0][lane];
+                    if (ib >= 0 && ib < M) U[(size_t)(2 * f + 1) * Lp + EDGE + ib] = ybuf[par][g][1][lane];
+                }
+            }
+        };
+        load(0, rawA);
+        stage(0, rawA);
+        if (nblk > 1) load(1, rawB);
+        if (nblk > 2) load(2, rawA);
+        fused::lds_barrier();
+        auto beside = [&](long m, Raw &r) __attribute__((always_inline)) {     // r: the set holding block m + 1
+            if (m + 1 < nblk) stage(m + 1, r);
+            if (m + 3 < nblk) load(m + 3, r);
+            if (m >= 1) writeback(m - 1);
+            fused::lds_barrier();
+        };
+        for (long m = 0; m < nblk; m += 2) {
+            beside(m, rawB);
+            if (m + 1 < nblk) beside(m + 1, rawA);
+        }
+        writeback(nblk - 1);
+        if (MODE == 2) {
+            // odd extension (scipy _arraytools.odd_ext) of both channel rows from this wavefront's own stores
+            __threadfence();
+            for (int g = 0; g < 4; g++) {
+                const long f = f0 + g;
+                if (f >= n_frames) continue;
+                for (int ch = 0; ch < 2; ch++) {
+                    double *u = U + (size_t)(2 * f + ch) * Lp + EDGE;
+                    if (lane < EDGE) {
+                        const double u0 = __builtin_nontemporal_load(u), ul = __builtin_nontemporal_load(u + M - 1);
+                        const double a = __builtin_nontemporal_load(u + EDGE - lane), b = __builtin_nontemporal_load(u + M - 2 - lane);
+                        u[lane - EDGE] = __dsub_rn(__dmul_rn(2.0, u0), a);
+                        u[M + lane] = __dsub_rn(__dmul_rn(2.0, ul), b);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---------------- recurrence wavefront: one frame per 16-lane DPP row, one filter section per lane ----------------
+    const int row = lane >> 4, r = lane & 15;
+    const CascLane me = arg.lane[r];
+    double z0 = 0.0, z1 = me.onepole ? -0.0 : 0.0, xprev = 0.0;
+    const int oslot = me.out_slot >= 0 ? me.out_slot : NOUT;
+    fused::lds_barrier();
+    for (long blk = 0; blk < nblk; blk++) {
+        const long c0 = blk * CS_T;
+        const int par = (int)(blk & 1);
+        const double *e0p = ebuf[par][row][0], *e1p = ebuf[par][row][1];
+        double *const yp = ybuf[par][row][oslot];
+        const int cnt = (TT - c0) < CS_T ? (int)(TT - c0) : CS_T;
+        auto one = [&](int t, double e, double a) {
+            const double from_prev = dpp_row_shr1(xprev);
+            double x = me.head ? e : from_prev;
+            if (MODE == 2) {
+                const double mixed = __dmul_rn(me.mix > 0 ? __dadd_rn(a, from_prev) : __dsub_rn(a, from_prev), 0.5);  // :140-141
+                x = me.mix ? mixed : x;
+            }
+            const double xn = __dadd_rn(__dmul_rn(me.c.b0, x), z0);
+            z0 = __dadd_rn(__dsub_rn(__dmul_rn(me.c.b1, x), __dmul_rn(me.c.a1, xn)), z1);
+            const double n1 = __dsub_rn(__dmul_rn(me.c.b2, x), __dmul_rn(me.c.a2, xn));
+            z1 = me.onepole ? -0.0 : n1;
+            xprev = xn;
+            yp[t] = xn;
+        };
+        if (cnt == CS_T) {
+            for (int t0 = 0; t0 < CS_T; t0 += 8) {
+                double e8[8], a8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { e8[k] = e0p[t0 + k]; a8[k] = (MODE == 2) ? e1p[t0 + k] : 0.0; }
+#pragma unroll
+                for (int k = 0; k < 8; k++) one(t0 + k, e8[k], a8[k]);
+            }
+        } else {
+            for (int t = 0; t < cnt; t++) one(t, e0p[t], (MODE == 2) ? e1p[t] : 0.0);
+        }
+        fused::lds_barrier();
+    }
+}
+#endif
 
 }  // namespace
 #include "pss_wfm_fused.h"
@@ -2686,11 +2846,16 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             }
             const unsigned gc = (unsigned)((n_frames + 3) / 4);
             pss_kernel_begin(ctx, "k_wfm_casc");
-            hipLaunchKernelGGL(k_wfm_casc<1>, dim3(gc), dim3(64), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Aa, Pp, Mm,
+#ifdef PSS_EXP_CASC_ONEWAVE
+            constexpr int CASC_THREADS = 64;
+#else
+            constexpr int CASC_THREADS = 128;
+#endif
+            hipLaunchKernelGGL(k_wfm_casc<1>, dim3(gc), dim3(CASC_THREADS), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Aa, Pp, Mm,
                                U2, n, n_frames, Lp, swapped, a1);
             pss_kernel_end(ctx);
             pss_kernel_begin(ctx, "k_wfm_casc");
-            hipLaunchKernelGGL(k_wfm_casc<2>, dim3(gc), dim3(64), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Aa, Pp, Mm,
+            hipLaunchKernelGGL(k_wfm_casc<2>, dim3(gc), dim3(CASC_THREADS), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Aa, Pp, Mm,
                                U2, n, n_frames, Lp, swapped, a2);
             pss_kernel_end(ctx);
             const unsigned gs = (unsigned)((rows + IS_G - 1) / IS_G);
