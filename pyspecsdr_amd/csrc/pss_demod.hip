@@ -1463,120 +1463,8 @@ struct CascLane {
 struct CascArg { CascLane lane[16]; };
 constexpr int CS_T = 64;
 
-#ifdef PSS_EXP_CASC_ONEWAVE
-template <int MODE>  // 1: discriminator -> a, p, m      2: m, p, a -> u_l, u_r (+ odd extension)
-__global__ __launch_bounds__(64) void k_wfm_casc(const float2 *__restrict__ iq, double *__restrict__ Aa, double *__restrict__ Pp,
-                                                 double *__restrict__ Mm, double *U, int n, long n_frames, long Lp, int swapped,
-                                                 CascArg arg)
-{
-    constexpr int NIN = 2, NOUT = 3;
-    __shared__ double ebuf[4][NIN][CS_T + 1];
-    __shared__ double ybuf[4][NOUT + 1][CS_T + 1];  // row NOUT: dump row
-    const int lane = threadIdx.x, row = lane >> 4, r = lane & 15;
-    const CascLane me = arg.lane[r];
-    const long f0 = (long)blockIdx.x * 4;
-    const int M = n - 1;
-    const int DA = (MODE == 1) ? 2 : 3, DB = (MODE == 1) ? 5 : 3, DC = 4;  // pipeline delay of each output row
-    const long TT = (long)M + 5;  // steps incl. drain of the deepest cascade
-    double z0 = 0.0, z1 = me.onepole ? -0.0 : 0.0, xprev = 0.0;
-    double *const yp = ybuf[row][me.out_slot >= 0 ? me.out_slot : NOUT];
-    const double SIN_PI = 0x1.1a62633145c07p-53;  // np.sin(np.pi)
-    double pre[4][NIN];
-    auto prefetch = [&](long c0) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const long f = f0 + g, i = c0 + lane;
-            pre[g][0] = 0.0; pre[g][1] = 0.0;
-            if (f < n_frames) {
-                if (MODE == 1) {
-                    if (i < M) {
-                        const float2 *x = iq + (size_t)f * n;
-                        pre[g][0] = (double)disc_sample(x[i + 1], x[i], 1.0f, swapped != 0);  // :122
-                    }
-                } else {
-                    if (i < M) pre[g][0] = __dmul_rn(Mm[(size_t)f * M + i], __dmul_rn(2.0, Pp[(size_t)f * M + i]));  // :134
-                    if (i - 3 >= 0 && i - 3 < M) pre[g][1] = Aa[(size_t)f * M + i - 3];  // a[], aligned with the mixing lanes
-                }
-            }
-        }
-    };
-    auto writeback = [&](long c0) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const long f = f0 + g;
-            if (f >= n_frames) continue;
-            const long ia = c0 + lane - DA, ib = c0 + lane - DB, ic = c0 + lane - DC;
-            if (MODE == 1) {
-                if (ia >= 0 && ia < M) Aa[(size_t)f * M + ia] = ybuf[g][0][lane];
-                if (ib >= 0 && ib < M) {
-                    const double y = ybuf[g][1][lane];  // :130 np.sin(np.unwrap(np.angle(real))) = 0 or sin(pi)
-                    Pp[(size_t)f * M + ib] = (y != y) ? y : ((y < 0.0 || (y == 0.0 && __builtin_signbit(y))) ? SIN_PI : 0.0);
-                }
-                if (ic >= 0 && ic < M) Mm[(size_t)f * M + ic] = ybuf[g][2][lane];
-            } else {
-                if (ia >= 0 && ia < M) U[(size_t)(2 * f) * Lp + EDGE + ia] = ybuf[g][0][lane];
-                if (ib >= 0 && ib < M) U[(size_t)(2 * f + 1) * Lp + EDGE + ib] = ybuf[g][1][lane];
-            }
-        }
-    };
-    prefetch(0);
-    for (long c0 = 0; c0 < TT; c0 += CS_T) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) { ebuf[g][0][lane] = pre[g][0]; ebuf[g][1][lane] = pre[g][1]; }
-        if (c0 > 0) writeback(c0 - CS_T);
-        if (c0 + CS_T < TT) prefetch(c0 + CS_T);
-        fused::lds_barrier();
-        const int cnt = (TT - c0) < CS_T ? (int)(TT - c0) : CS_T;
-        auto one = [&](int t, double e, double a) {
-            const double from_prev = dpp_row_shr1(xprev);
-            double x = me.head ? e : from_prev;
-            if (MODE == 2) {
-                const double mixed = __dmul_rn(me.mix > 0 ? __dadd_rn(a, from_prev) : __dsub_rn(a, from_prev), 0.5);  // :140-141
-                x = me.mix ? mixed : x;
-            }
-            const double xn = __dadd_rn(__dmul_rn(me.c.b0, x), z0);
-            z0 = __dadd_rn(__dsub_rn(__dmul_rn(me.c.b1, x), __dmul_rn(me.c.a1, xn)), z1);
-            const double n1 = __dsub_rn(__dmul_rn(me.c.b2, x), __dmul_rn(me.c.a2, xn));
-            z1 = me.onepole ? -0.0 : n1;
-            xprev = xn;
-            yp[t] = xn;
-        };
-        if (cnt == CS_T) {
-            for (int t0 = 0; t0 < CS_T; t0 += 8) {
-                double e8[8], a8[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) { e8[k] = ebuf[row][0][t0 + k]; a8[k] = (MODE == 2) ? ebuf[row][1][t0 + k] : 0.0; }
-#pragma unroll
-                for (int k = 0; k < 8; k++) one(t0 + k, e8[k], a8[k]);
-            }
-        } else {
-            for (int t = 0; t < cnt; t++) one(t, ebuf[row][0][t], (MODE == 2) ? ebuf[row][1][t] : 0.0);
-        }
-        fused::lds_barrier();
-    }
-    writeback(((TT - 1) / CS_T) * CS_T);
-    if (MODE == 2) {
-        // odd extension (scipy _arraytools.odd_ext) of both channel rows from this wavefront's own stores
-        __threadfence();
-        fused::lds_barrier();
-        for (int g = 0; g < 4; g++) {
-            const long f = f0 + g;
-            if (f >= n_frames) continue;
-            for (int ch = 0; ch < 2; ch++) {
-                double *u = U + (size_t)(2 * f + ch) * Lp + EDGE;
-                if (lane < EDGE) {
-                    const double u0 = __builtin_nontemporal_load(u), ul = __builtin_nontemporal_load(u + M - 1);
-                    const double a = __builtin_nontemporal_load(u + EDGE - lane), b = __builtin_nontemporal_load(u + M - 2 - lane);
-                    u[lane - EDGE] = __dsub_rn(__dmul_rn(2.0, u0), a);
-                    u[M + lane] = __dsub_rn(__dmul_rn(2.0, ul), b);
-                }
-            }
-        }
-    }
-}
-
-#else
-// Two wavefronts per workgroup (round 3, as k_am_sys / k_iir4_sys): wavefront 0 runs the sample-systolic recurrence, wavefront 1 the
+// (Kept for A/B builds, -DPSS_EXP_CASC_SAMPLE; the product runs k_wfm_blk below.)  Two wavefronts per workgroup (round 3, as k_am_sys /
+// k_iir4_sys): wavefront 0 runs the sample-systolic recurrence, wavefront 1 the
 // memory side — raw inputs of block m + 3 requested, block m + 1 computed (the discriminator in pass 1, m * 2p in pass 2) and staged,
 // block m - 1 written back — through double-buffered LDS blocks and LDS-only barriers.  As one wavefront the kernel computed four
 // discriminator samples per lane and waited for its own loads and stores between any two 64-step blocks.
@@ -1732,7 +1620,208 @@ __global__ __launch_bounds__(128) void k_wfm_casc(const float2 *__restrict__ iq,
         fused::lds_barrier();
     }
 }
-#endif
+
+
+// ---------------------------------------------------------------------------------------------------
+// WFM for small batches, BLOCK-systolic (late round 3): the same two passes as k_wfm_casc, but a lane filters a whole
+// 64-sample block of its section and leaves it in LDS for the next section's lane (as k_iir4_sys / k_am_sys do) instead of
+// handing every sample to its neighbour by DPP.  The recurrence step is then nothing but sosfilt's nine float64 operations and
+// the one-pole pin (no DPP moves, no head / mix selects: ~11 instead of 15-22 instructions on a lone wavefront), and the L / R
+// matrix of pass 2 is computed by the memory wavefront, sample-parallel, between the LP15k chain and the de-emphasis lanes.
+//   pass 1 (14 lanes per frame): d -> LP15k (3) -> a ; d -> BP pilot (5) -> 1-pole -> y -> pilot value p ; d -> BP 23..53k (5) -> m
+//   pass 2 ( 5 lanes per frame): m * (2 p) -> LP15k (3) -> lp ; memory wavefront: (a +- lp) / 2 ; de-emphasis 1-pole per channel -> u_l, u_r
+// Same operations on the same sample sequences as k_wfm_casc (zero initial state everywhere), so the same bits.
+// ---------------------------------------------------------------------------------------------------
+struct BlkLane {
+    Biquad c;
+    int src, dst;    // LDS row (per frame) read / written; rows >= dbl0 are double-buffered by macro-step parity
+    int depth;       // the lane works on block (macro-step - depth); -1: idle lane
+    int onepole;
+};
+struct BlkArg { BlkLane lane[16]; };
+constexpr int WB_T = 64, WB_G = 4;
+
+template <int MODE>
+__global__ __launch_bounds__(128) void k_wfm_blk(const float2 *__restrict__ iq, double *__restrict__ Aa, double *__restrict__ Pp,
+                                                 double *__restrict__ Mm, double *U, int n, long n_frames, long Lp, int swapped,
+                                                 BlkArg arg)
+{
+    // rows per frame.  Pass 1: 0,1 = d (staged, two blocks in flight); 2,3 hand-offs of chain a; 4,5 = a out; 6..10 hand-offs of the pilot
+    // chain; 11,12 = y out; 13..16 hand-offs of the m chain; 17,18 = m out.  Pass 2: 0,1 = m*2p; 2,3 hand-offs; 4,5 = lp out; 6,7 = l in;
+    // 8,9 = r in; 10,11 = u_l out; 12,13 = u_r out.  (src / dst name the EVEN row of a double-buffered pair; the odd one is + 1.)
+    constexpr int NROWS = MODE == 1 ? 19 : 14;
+    __shared__ double rows[WB_G][NROWS][WB_T + 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long f0 = (long)blockIdx.x * WB_G;
+    const int M = n - 1;
+    const long nblk = ((long)M + WB_T - 1) / WB_T;
+    constexpr int DEEP = MODE == 1 ? 5 : 4;       // depth of the deepest lane
+    const long nstep = nblk + DEEP;
+    const double SIN_PI = 0x1.1a62633145c07p-53;  // np.sin(np.pi)
+    auto is_dbl = [](int row) { return MODE == 1 ? (row <= 1 || row == 4 || row == 5 || row == 11 || row == 12 || row >= 17)
+                                                 : (row <= 1 || row >= 4); };
+    if (wave == 1) {
+        // ---------------- memory wavefront: lane = sample inside a block ----------------
+        struct Raw { float2 x0[WB_G], x1[WB_G]; double m[WB_G], p[WB_G]; };
+        Raw rawA, rawB;
+        auto load = [&](long blk, Raw &r) __attribute__((always_inline)) {
+            const long i = blk * WB_T + lane;
+#pragma unroll
+            for (int g = 0; g < WB_G; g++) {
+                const long f = f0 + g;
+                const bool ok = f < n_frames && i < M;
+                if (MODE == 1) {
+                    const float2 *x = iq + (size_t)(f < n_frames ? f : 0) * n;
+                    r.x0[g] = ok ? x[i] : make_float2(0.0f, 0.0f);
+                    r.x1[g] = ok ? x[i + 1] : make_float2(0.0f, 0.0f);
+                } else {
+                    const size_t o = (size_t)(f < n_frames ? f : 0) * M;
+                    r.m[g] = ok ? Mm[o + i] : 0.0;
+                    r.p[g] = ok ? Pp[o + i] : 0.0;
+                }
+            }
+        };
+        auto stage = [&](long blk, const Raw &r) __attribute__((always_inline)) {
+            const long i = blk * WB_T + lane;
+#pragma unroll
+            for (int g = 0; g < WB_G; g++) {
+                double e = 0.0;
+                if (f0 + g < n_frames && i < M) {
+                    if (MODE == 1) e = (double)disc_sample(r.x1[g], r.x0[g], 1.0f, swapped != 0);  // :122
+                    else e = __dmul_rn(r.m[g], __dmul_rn(2.0, r.p[g]));                             // :134
+                }
+                rows[g][(int)(blk & 1)][lane] = e;
+            }
+        };
+        // what the recurrence wavefront finished during macro-step ms (ms >= 0): written back / passed on
+        auto drain = [&](long ms) __attribute__((always_inline)) {
+            const int par = (int)(ms & 1);
+#pragma unroll
+            for (int g = 0; g < WB_G; g++) {
+                const long f = f0 + g;
+                if (f >= n_frames) continue;
+                if (MODE == 1) {
+                    const long ba = ms - 2, by = ms - 5, bm = ms - 4;
+                    const long ia = ba * WB_T + lane, iy = by * WB_T + lane, im = bm * WB_T + lane;
+                    if (ba >= 0 && ba < nblk && ia < M) Aa[(size_t)f * M + ia] = rows[g][4 + par][lane];
+                    if (by >= 0 && by < nblk && iy < M) {
+                        const double y = rows[g][11 + par][lane];  // :130 np.sin(np.unwrap(np.angle(real))) = 0 or sin(pi)
+                        Pp[(size_t)f * M + iy] = (y != y) ? y : ((y < 0.0 || (y == 0.0 && __builtin_signbit(y))) ? SIN_PI : 0.0);
+                    }
+                    if (bm >= 0 && bm < nblk && im < M) Mm[(size_t)f * M + im] = rows[g][17 + par][lane];
+                } else {
+                    // the LP15k chain finished block ms - 2: L / R matrix (:140-141), staged for the de-emphasis lanes (macro-step ms + 2)
+                    const long bl = ms - 2, il = bl * WB_T + lane;
+                    if (bl >= 0 && bl < nblk) {
+                        double l = 0.0, r = 0.0;
+                        if (il < M) {
+                            const double a = Aa[(size_t)f * M + il], lp = rows[g][4 + par][lane];
+                            l = __dmul_rn(__dadd_rn(a, lp), 0.5);
+                            r = __dmul_rn(__dsub_rn(a, lp), 0.5);
+                        }
+                        rows[g][6 + par][lane] = l;      // read by the de-emphasis lanes at macro-step ms + 2 (same parity)
+                        rows[g][8 + par][lane] = r;
+                    }
+                    const long bu = ms - 4, iu = bu * WB_T + lane;
+                    if (bu >= 0 && bu < nblk && iu < M) {
+                        U[(size_t)(2 * f) * Lp + EDGE + iu] = rows[g][10 + par][lane];
+                        U[(size_t)(2 * f + 1) * Lp + EDGE + iu] = rows[g][12 + par][lane];
+                    }
+                }
+            }
+        };
+        load(0, rawA);
+        stage(0, rawA);
+        if (nblk > 1) load(1, rawB);
+        if (nblk > 2) load(2, rawA);
+        fused::lds_barrier();
+        auto beside = [&](long m, Raw &r) __attribute__((always_inline)) {     // r: the set holding block m + 1
+            if (m + 1 < nblk) stage(m + 1, r);
+            if (m + 3 < nblk) load(m + 3, r);
+            if (m >= 1) drain(m - 1);
+            fused::lds_barrier();
+        };
+        for (long m = 0; m < nstep; m += 2) {
+            beside(m, rawB);
+            if (m + 1 < nstep) beside(m + 1, rawA);
+        }
+        drain(nstep - 1);
+        if (MODE == 2) {
+            // odd extension (scipy _arraytools.odd_ext) of both channel rows from this wavefront's own stores
+            __threadfence();
+            for (int g = 0; g < WB_G; g++) {
+                const long f = f0 + g;
+                if (f >= n_frames) continue;
+                for (int ch = 0; ch < 2; ch++) {
+                    double *u = U + (size_t)(2 * f + ch) * Lp + EDGE;
+                    if (lane < EDGE) {
+                        const double u0 = __builtin_nontemporal_load(u), ul = __builtin_nontemporal_load(u + M - 1);
+                        const double a = __builtin_nontemporal_load(u + EDGE - lane), b = __builtin_nontemporal_load(u + M - 2 - lane);
+                        u[lane - EDGE] = __dsub_rn(__dmul_rn(2.0, u0), a);
+                        u[M + lane] = __dsub_rn(__dmul_rn(2.0, ul), b);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---------------- recurrence wavefront: one frame per 16 lanes, one filter section per lane ----------------
+    const int g = lane >> 4;
+    const BlkLane me = arg.lane[lane & 15];
+    const bool lane_on = me.depth >= 0;
+    const bool src_dbl = is_dbl(me.src), dst_dbl = is_dbl(me.dst);
+    double z0 = 0.0, z1 = me.onepole ? -0.0 : 0.0;
+    auto step = [&](double x) {
+        const double xn = __dadd_rn(__dmul_rn(me.c.b0, x), z0);
+        z0 = __dadd_rn(__dsub_rn(__dmul_rn(me.c.b1, x), __dmul_rn(me.c.a1, xn)), z1);
+        const double n1 = __dsub_rn(__dmul_rn(me.c.b2, x), __dmul_rn(me.c.a2, xn));
+        z1 = me.onepole ? -0.0 : n1;
+        return xn;
+    };
+    fused::lds_barrier();
+    for (long m = 0; m < nstep; m++) {
+        const long blk = m - me.depth;
+        const bool active = lane_on && blk >= 0 && blk < nblk;
+        const int par = (int)(m & 1);
+        const double *src = rows[g][me.src + (src_dbl ? par : 0)];
+        double *dst = rows[g][me.dst + (dst_dbl ? par : 0)];
+        const int cnt = !active ? 0 : (((long)M - blk * WB_T) < WB_T ? (int)((long)M - blk * WB_T) : WB_T);
+        // in-place hand-off: all lanes walk the block in lockstep, reads of a group of eight before its writes (k_iir4_sys)
+        if (__all(!active || cnt == WB_T)) {
+            if (active) {
+                double ea[8], eb[8], y8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) ea[k] = src[k];
+#pragma unroll 1
+                for (int t0 = 0; t0 < WB_T; t0 += 16) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) eb[k] = src[t0 + 8 + k];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) y8[k] = step(ea[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dst[t0 + k] = y8[k];
+                    if (t0 + 16 < WB_T) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) ea[k] = src[t0 + 16 + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) y8[k] = step(eb[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dst[t0 + 8 + k] = y8[k];
+                }
+            }
+        } else {
+            for (int t = 0; t < WB_T; t++) {
+                if (t < cnt) {
+                    const double e = src[t];
+                    dst[t] = step(e);
+                }
+            }
+        }
+        fused::lds_barrier();
+    }
+}
 
 }  // namespace
 #include "pss_wfm_fused.h"
@@ -2833,6 +2922,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             double *Aa = reinterpret_cast<double *>(b2), *Pp = reinterpret_cast<double *>(b2 + szR), *Mm = reinterpret_cast<double *>(b2 + 2 * szR);
             double *U2 = reinterpret_cast<double *>(b2 + 3 * szR), *Y2 = reinterpret_cast<double *>(b2 + 3 * szR + szU);
             double *A2 = reinterpret_cast<double *>(b2 + 3 * szR + szU + szY2), *MX2 = reinterpret_cast<double *>(b2 + 3 * szR + szU + szY2 + szA2);
+#ifdef PSS_EXP_CASC_SAMPLE
             CascArg a1, a2;
             const Biquad idle{0.0, 0.0, 0.0, 0.0, 0.0};
             for (int i = 0; i < 16; i++) a1.lane[i] = a2.lane[i] = CascLane{idle, 1, 0, 0, -1};
@@ -2846,11 +2936,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             }
             const unsigned gc = (unsigned)((n_frames + 3) / 4);
             pss_kernel_begin(ctx, "k_wfm_casc");
-#ifdef PSS_EXP_CASC_ONEWAVE
-            constexpr int CASC_THREADS = 64;
-#else
             constexpr int CASC_THREADS = 128;
-#endif
             hipLaunchKernelGGL(k_wfm_casc<1>, dim3(gc), dim3(CASC_THREADS), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Aa, Pp, Mm,
                                U2, n, n_frames, Lp, swapped, a1);
             pss_kernel_end(ctx);
@@ -2858,6 +2944,29 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             hipLaunchKernelGGL(k_wfm_casc<2>, dim3(gc), dim3(CASC_THREADS), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Aa, Pp, Mm,
                                U2, n, n_frames, Lp, swapped, a2);
             pss_kernel_end(ctx);
+#else
+            BlkArg a1, a2;
+            const Biquad idle{0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int i = 0; i < 16; i++) a1.lane[i] = a2.lane[i] = BlkLane{idle, 0, 0, -1, 0};
+            // pass 1 (rows: 0,1 d | 2,3 | 4,5 a | 6..10 | 11,12 y | 13..16 | 17,18 m)
+            for (int i = 0; i < 3; i++) a1.lane[i] = BlkLane{wc.lp[i], i == 0 ? 0 : 1 + i, i == 2 ? 4 : 2 + i, i, 0};               // a: rows 0 -> 2 -> 3 -> 4
+            for (int i = 0; i < 5; i++) a1.lane[3 + i] = BlkLane{wc.pil[i], i == 0 ? 0 : 5 + i, 6 + i, i, 0};                          // pilot band-pass: 0 -> 6 .. 10
+            a1.lane[8] = BlkLane{Biquad{1.0, 0.0, 0.0, -0.99, 0.0}, 10, 11, 5, 1};                                                       // lfilter([1],[1,-0.99]) -> y
+            for (int i = 0; i < 5; i++) a1.lane[9 + i] = BlkLane{wc.lmr[i], i == 0 ? 0 : 12 + i, i == 4 ? 17 : 13 + i, i, 0};           // m: 0 -> 13 .. 16 -> 17
+            // pass 2 (rows: 0,1 m*2p | 2,3 | 4,5 lp | 6,7 l | 8,9 r | 10,11 u_l | 12,13 u_r)
+            for (int i = 0; i < 3; i++) a2.lane[i] = BlkLane{wc.lp[i], i == 0 ? 0 : 1 + i, i == 2 ? 4 : 2 + i, i, 0};               // :137
+            a2.lane[3] = BlkLane{Biquad{wc.b0d, 0.0, 0.0, wc.a1d, 0.0}, 6, 10, 4, 1};                                                    // de-emphasis, left
+            a2.lane[4] = BlkLane{Biquad{wc.b0d, 0.0, 0.0, wc.a1d, 0.0}, 8, 12, 4, 1};                                                    // de-emphasis, right
+            const unsigned gc = (unsigned)((n_frames + WB_G - 1) / WB_G);
+            pss_kernel_begin(ctx, "k_wfm_casc");
+            hipLaunchKernelGGL(k_wfm_blk<1>, dim3(gc), dim3(128), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Aa, Pp, Mm,
+                               U2, n, n_frames, Lp, swapped, a1);
+            pss_kernel_end(ctx);
+            pss_kernel_begin(ctx, "k_wfm_casc");
+            hipLaunchKernelGGL(k_wfm_blk<2>, dim3(gc), dim3(128), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Aa, Pp, Mm,
+                               U2, n, n_frames, Lp, swapped, a2);
+            pss_kernel_end(ctx);
+#endif
             const unsigned gs = (unsigned)((rows + IS_G - 1) / IS_G);
             pss_kernel_begin(ctx, "k_iir4_sys");
             hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(128), 0, PSS_STREAM(ctx), U2, Lp, 0, L, L, c, Y2, L, q, n_out, nullptr, rows);
