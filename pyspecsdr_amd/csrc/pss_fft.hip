@@ -671,7 +671,8 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     using C = pss_r16::Cfg<LOG_R3>;
     // component-wise LDS exchanges (half the LDS, twice the barriers) pay only at N = 256, where the plain kernel fits a
     // single 80 KB workgroup per CU: 0.29 -> 0.20 ms for 262144 frames; at 512...2048 they measured 20 % slower
-    // next-frame prefetch, A/B in one process: N = 1024: 0.198 -> 0.185 ms (65536 frames), 2048: 0.234 -> 0.226 ms; 512: no change;
+    // next-frame prefetch, A/B in one process: N = 1024: 0.198 -> 0.185 ms (65536 frames), 2048: 0.234 -> 0.226 ms; 512: no change in round 2,
+    // 0.163 -> 0.160 ms with the round-3 kernels (on since then);
     // 4096: 0.27 -> 0.35 ms (274 VGPRs: one wavefront per SIMD) in round 2; since the stage-2 twiddles are fetched from LDS a few products
     // ahead the kernel has 238 VGPRs with the prefetch, and with conflict-free exchanges it is the fastest 4096-point kernel:
     // 0.200 ms per 2^26 samples against 0.210 without the prefetch and 0.233 for k_spectrum_xl<0>; 256: the split kernel wins
@@ -680,7 +681,7 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     int fpw = C::FPW;
 #ifdef PSS_VARIANTS   // every combination, steered by the options "fft_split" / "fft_prefetch" / "fft_two_per_wg" (A/B builds)
     const bool split = ctx->fft_split >= 0 ? ctx->fft_split != 0 : LOG_R3 == 0;
-    const bool prefetch = !split && (ctx->fft_prefetch >= 0 ? ctx->fft_prefetch != 0 : (LOG_R3 >= 2 && !(LOG_R3 == 4 && SCAN)));
+    const bool prefetch = !split && (ctx->fft_prefetch >= 0 ? ctx->fft_prefetch != 0 : (LOG_R3 >= 1 && !(LOG_R3 == 4 && SCAN)));
     auto kern = exact ? (split ? pss_r16::k_spectrum_r16<LOG_R3, false, true, false, true>
                          : prefetch ? pss_r16::k_spectrum_r16<LOG_R3, false, false, true, true> : pss_r16::k_spectrum_r16<LOG_R3, false, false, false, true>)
                 : split ? pss_r16::k_spectrum_r16<LOG_R3, SCAN, true, false>
@@ -696,7 +697,7 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
         }
     }
 #else                 // the product library carries the measured winner per length only (12 instantiations instead of 49)
-    constexpr bool split = LOG_R3 == 0, prefetch = LOG_R3 >= 2 && !(LOG_R3 == 4 && SCAN), one = LOG_R3 == 3 && !SCAN;
+    constexpr bool split = LOG_R3 == 0, prefetch = LOG_R3 >= 1 && !(LOG_R3 == 4 && SCAN), one = LOG_R3 == 3 && !SCAN;
     auto kern = exact ? pss_r16::k_spectrum_r16<LOG_R3, false, split, prefetch, true, one> : pss_r16::k_spectrum_r16<LOG_R3, SCAN, split, prefetch, false, one>;
     if (one) fpw = 1;
     const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::TW2 * sizeof(double2)
