@@ -1823,6 +1823,182 @@ __global__ __launch_bounds__(128) void k_wfm_blk(const float2 *__restrict__ iq, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Both WFM passes in ONE block-systolic array (late round 3): 19 lanes per frame (the 14 of pass 1, the LP15k chain and the two
+// de-emphasis lanes of pass 2), three frames per wavefront.  The memory wavefront feeds pass 2 from pass 1's LDS rows — pilot value
+// and m * 2p when the pilot chain has finished a block, the L / R matrix when the second LP15k chain has — so a, p and m never go
+// through global memory and the second pass's latency (~1.1 ms for a 32768-sample frame) disappears.  Every buffer a lane or the memory
+// wavefront writes is a ring indexed by BLOCK number, as long as its value has to live (a: 9 blocks, m: 3, the rest 2).
+// Timeline of block b (macro-steps): staged b-1 | a ready b+2 | m ready b+4 | y ready b+5 | m*2p staged b+6 | LP15k b+7..b+9 |
+// matrix staged b+10 | de-emphasis b+11 | u_l, u_r written back b+12.
+// ---------------------------------------------------------------------------------------------------
+struct MrgLane {
+    Biquad c;
+    int src, src_ring, dst, dst_ring;   // first row of the ring read / written, ring length (1: a plain hand-off row)
+    int depth;                          // the lane works on block (macro-step - depth); -1: idle lane
+    int onepole;
+};
+struct MrgArg { MrgLane lane[19]; };
+constexpr int WM_T = 64, WM_G = 3, WM_ROWS = 41;
+// rows per frame: D1 0-1 | a hand-offs 2-3 | A 4-12 | pilot hand-offs 13-17 | Y 18-19 | m hand-offs 20-23 | Mo 24-26 | D2 27-28 |
+// lp hand-offs 29-30 | LP 31-32 | DL 33-34 | DR 35-36 | UL 37-38 | UR 39-40
+constexpr int WM_D1 = 0, WM_A = 4, WM_Y = 18, WM_MO = 24, WM_D2 = 27, WM_LP = 31, WM_DL = 33, WM_DR = 35, WM_UL = 37, WM_UR = 39;
+
+__global__ __launch_bounds__(128) void k_wfm_mrg(const float2 *__restrict__ iq, double *U, int n, long n_frames, long Lp, int swapped, MrgArg arg)
+{
+    __shared__ double rows[WM_G][WM_ROWS][WM_T + 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long f0 = (long)blockIdx.x * WM_G;
+    const int M = n - 1;
+    const long nblk = ((long)M + WM_T - 1) / WM_T;
+    constexpr int DEEP = 11;
+    const long nstep = nblk + DEEP;
+    const double SIN_PI = 0x1.1a62633145c07p-53;  // np.sin(np.pi)
+    if (wave == 1) {
+        // ---------------- memory wavefront: lane = sample inside a block ----------------
+        struct Raw { float2 x0[WM_G], x1[WM_G]; };
+        Raw rawA, rawB;
+        auto load = [&](long blk, Raw &r) __attribute__((always_inline)) {
+            const long i = blk * WM_T + lane;
+#pragma unroll
+            for (int g = 0; g < WM_G; g++) {
+                const long f = f0 + g;
+                const bool ok = f < n_frames && i < M;
+                const float2 *x = iq + (size_t)(f < n_frames ? f : 0) * n;
+                r.x0[g] = ok ? x[i] : make_float2(0.0f, 0.0f);
+                r.x1[g] = ok ? x[i + 1] : make_float2(0.0f, 0.0f);
+            }
+        };
+        auto stage = [&](long blk, const Raw &r) __attribute__((always_inline)) {
+            const long i = blk * WM_T + lane;
+#pragma unroll
+            for (int g = 0; g < WM_G; g++) {
+                double e = 0.0;
+                if (f0 + g < n_frames && i < M) e = (double)disc_sample(r.x1[g], r.x0[g], 1.0f, swapped != 0);  // :122
+                rows[g][WM_D1 + (int)(blk & 1)][lane] = e;
+            }
+        };
+        // after macro-step ms: what the recurrence wavefront has finished is passed on / written back
+        auto drain = [&](long ms) __attribute__((always_inline)) {
+            const long b6 = ms - 5, b9 = ms - 9, b11 = ms - 11;
+#pragma unroll
+            for (int g = 0; g < WM_G; g++) {
+                const long f = f0 + g;
+                if (f >= n_frames) continue;
+                if (b6 >= 0 && b6 < nblk) {   // pilot chain done with block b6 (m since the step before): m * (2 p), :130-134
+                    const double y = rows[g][WM_Y + (int)(b6 & 1)][lane];
+                    const double pv = (y != y) ? y : ((y < 0.0 || (y == 0.0 && __builtin_signbit(y))) ? SIN_PI : 0.0);
+                    const double mv = rows[g][WM_MO + (int)(b6 % 3)][lane];
+                    rows[g][WM_D2 + (int)(b6 & 1)][lane] = (b6 * WM_T + lane < M) ? __dmul_rn(mv, __dmul_rn(2.0, pv)) : 0.0;
+                }
+                if (b9 >= 0 && b9 < nblk) {   // second LP15k chain done with block b9: L / R matrix (:140-141) for the de-emphasis lanes
+                    const double a = rows[g][WM_A + (int)(b9 % 9)][lane], lp = rows[g][WM_LP + (int)(b9 & 1)][lane];
+                    const bool in = b9 * WM_T + lane < M;
+                    rows[g][WM_DL + (int)(b9 & 1)][lane] = in ? __dmul_rn(__dadd_rn(a, lp), 0.5) : 0.0;
+                    rows[g][WM_DR + (int)(b9 & 1)][lane] = in ? __dmul_rn(__dsub_rn(a, lp), 0.5) : 0.0;
+                }
+                if (b11 >= 0 && b11 < nblk) {
+                    const long iu = b11 * WM_T + lane;
+                    if (iu < M) {
+                        U[(size_t)(2 * f) * Lp + EDGE + iu] = rows[g][WM_UL + (int)(b11 & 1)][lane];
+                        U[(size_t)(2 * f + 1) * Lp + EDGE + iu] = rows[g][WM_UR + (int)(b11 & 1)][lane];
+                    }
+                }
+            }
+        };
+        load(0, rawA);
+        stage(0, rawA);
+        if (nblk > 1) load(1, rawB);
+        if (nblk > 2) load(2, rawA);
+        fused::lds_barrier();
+        auto beside = [&](long m, Raw &r) __attribute__((always_inline)) {     // r: the set holding block m + 1
+            if (m + 1 < nblk) stage(m + 1, r);
+            if (m + 3 < nblk) load(m + 3, r);
+            if (m >= 1) drain(m - 1);
+            fused::lds_barrier();
+        };
+        for (long m = 0; m < nstep; m += 2) {
+            beside(m, rawB);
+            if (m + 1 < nstep) beside(m + 1, rawA);
+        }
+        drain(nstep - 1);
+        // odd extension (scipy _arraytools.odd_ext) of both channel rows from this wavefront's own stores
+        __threadfence();
+        for (int g = 0; g < WM_G; g++) {
+            const long f = f0 + g;
+            if (f >= n_frames) continue;
+            for (int ch = 0; ch < 2; ch++) {
+                double *u = U + (size_t)(2 * f + ch) * Lp + EDGE;
+                if (lane < EDGE) {
+                    const double u0 = __builtin_nontemporal_load(u), ul = __builtin_nontemporal_load(u + M - 1);
+                    const double a = __builtin_nontemporal_load(u + EDGE - lane), b = __builtin_nontemporal_load(u + M - 2 - lane);
+                    u[lane - EDGE] = __dsub_rn(__dmul_rn(2.0, u0), a);
+                    u[M + lane] = __dsub_rn(__dmul_rn(2.0, ul), b);
+                }
+            }
+        }
+        return;
+    }
+    // ---------------- recurrence wavefront: 19 lanes per frame, one filter section per lane ----------------
+    const int g_raw = lane / 19, role = lane - 19 * g_raw;
+    const bool lane_in = g_raw < WM_G;
+    const int g = lane_in ? g_raw : 0;
+    const MrgLane me = arg.lane[role];
+    const bool lane_on = lane_in && me.depth >= 0;
+    double z0 = 0.0, z1 = me.onepole ? -0.0 : 0.0;
+    auto step = [&](double x) {
+        const double xn = __dadd_rn(__dmul_rn(me.c.b0, x), z0);
+        z0 = __dadd_rn(__dsub_rn(__dmul_rn(me.c.b1, x), __dmul_rn(me.c.a1, xn)), z1);
+        const double n1 = __dsub_rn(__dmul_rn(me.c.b2, x), __dmul_rn(me.c.a2, xn));
+        z1 = me.onepole ? -0.0 : n1;
+        return xn;
+    };
+    fused::lds_barrier();
+    for (long m = 0; m < nstep; m++) {
+        const long blk = m - me.depth;
+        const bool active = lane_on && blk >= 0 && blk < nblk;
+        const long bsafe = active ? blk : 0;
+        const double *src = rows[g][me.src + (int)(bsafe % me.src_ring)];
+        double *dst = rows[g][me.dst + (int)(bsafe % me.dst_ring)];
+        const int cnt = !active ? 0 : (((long)M - blk * WM_T) < WM_T ? (int)((long)M - blk * WM_T) : WM_T);
+        // in-place hand-off: all lanes walk the block in lockstep, reads of a group of eight before its writes (k_iir4_sys)
+        if (__all(!active || cnt == WM_T)) {
+            if (active) {
+                double ea[8], eb[8], y8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) ea[k] = src[k];
+#pragma unroll 1
+                for (int t0 = 0; t0 < WM_T; t0 += 16) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) eb[k] = src[t0 + 8 + k];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) y8[k] = step(ea[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dst[t0 + k] = y8[k];
+                    if (t0 + 16 < WM_T) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) ea[k] = src[t0 + 16 + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) y8[k] = step(eb[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dst[t0 + 8 + k] = y8[k];
+                }
+            }
+        } else {
+            for (int t = 0; t < WM_T; t++) {
+                if (t < cnt) {
+                    const double e = src[t];
+                    dst[t] = step(e);
+                }
+            }
+        }
+        fused::lds_barrier();
+    }
+}
+
 }  // namespace
 #include "pss_wfm_fused.h"
 namespace {
@@ -2945,6 +3121,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
                                U2, n, n_frames, Lp, swapped, a2);
             pss_kernel_end(ctx);
 #else
+#ifdef PSS_EXP_WFM_TWOPASS
             BlkArg a1, a2;
             const Biquad idle{0.0, 0.0, 0.0, 0.0, 0.0};
             for (int i = 0; i < 16; i++) a1.lane[i] = a2.lane[i] = BlkLane{idle, 0, 0, -1, 0};
@@ -2966,6 +3143,30 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             hipLaunchKernelGGL(k_wfm_blk<2>, dim3(gc), dim3(128), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Aa, Pp, Mm,
                                U2, n, n_frames, Lp, swapped, a2);
             pss_kernel_end(ctx);
+#else
+            {
+                MrgArg am;
+                const Biquad idle{0.0, 0.0, 0.0, 0.0, 0.0};
+                for (int i = 0; i < 19; i++) am.lane[i] = MrgLane{idle, 0, 1, 0, 1, -1, 0};
+                // pass 1: a (rows D1 -> 2 -> 3 -> A ring), pilot band-pass (D1 -> 13..17) + 1-pole (17 -> Y), m (D1 -> 20..23 -> Mo ring)
+                for (int i = 0; i < 3; i++)
+                    am.lane[i] = MrgLane{wc.lp[i], i == 0 ? WM_D1 : 1 + i, i == 0 ? 2 : 1, i == 2 ? WM_A : 2 + i, i == 2 ? 9 : 1, i, 0};
+                for (int i = 0; i < 5; i++) am.lane[3 + i] = MrgLane{wc.pil[i], i == 0 ? WM_D1 : 12 + i, i == 0 ? 2 : 1, 13 + i, 1, i, 0};
+                am.lane[8] = MrgLane{Biquad{1.0, 0.0, 0.0, -0.99, 0.0}, 17, 1, WM_Y, 2, 5, 1};                        // lfilter([1],[1,-0.99]) -> y
+                for (int i = 0; i < 5; i++)
+                    am.lane[9 + i] = MrgLane{wc.lmr[i], i == 0 ? WM_D1 : 19 + i, i == 0 ? 2 : 1, i == 4 ? WM_MO : 20 + i, i == 4 ? 3 : 1, i, 0};
+                // pass 2: LP15k on m * 2p (D2 -> 29 -> 30 -> LP), de-emphasis per channel (DL -> UL, DR -> UR)
+                for (int i = 0; i < 3; i++)
+                    am.lane[14 + i] = MrgLane{wc.lp[i], i == 0 ? WM_D2 : 28 + i, i == 0 ? 2 : 1, i == 2 ? WM_LP : 29 + i, i == 2 ? 2 : 1, 7 + i, 0};
+                am.lane[17] = MrgLane{Biquad{wc.b0d, 0.0, 0.0, wc.a1d, 0.0}, WM_DL, 2, WM_UL, 2, 11, 1};
+                am.lane[18] = MrgLane{Biquad{wc.b0d, 0.0, 0.0, wc.a1d, 0.0}, WM_DR, 2, WM_UR, 2, 11, 1};
+                const unsigned gm = (unsigned)((n_frames + WM_G - 1) / WM_G);
+                pss_kernel_begin(ctx, "k_wfm_casc");
+                hipLaunchKernelGGL(k_wfm_mrg, dim3(gm), dim3(128), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), U2, n, n_frames, Lp,
+                                   swapped, am);
+                pss_kernel_end(ctx);
+            }
+#endif
 #endif
             const unsigned gs = (unsigned)((rows + IS_G - 1) / IS_G);
             pss_kernel_begin(ctx, "k_iir4_sys");
