@@ -1838,32 +1838,46 @@ struct MrgLane {
     int src, src_ring, dst, dst_ring;   // first row of the ring read / written, ring length (1: a plain hand-off row)
     int depth;                          // the lane works on block (macro-step - depth); -1: idle lane
     int onepole;
+    double zi0, zi1;                    // FWD decimator lanes: initial state per unit of the sequence's first sample (sosfilt_zi); else 0
+    int chan;                           // FWD decimator lanes: 0 / 1 = left / right (whose first sample scales zi); else -1
 };
-struct MrgArg { MrgLane lane[19]; };
-constexpr int WM_T = 64, WM_G = 3, WM_ROWS = 41;
+struct MrgArg { MrgLane lane[27]; };
+constexpr int WM_T = 64;
 // rows per frame: D1 0-1 | a hand-offs 2-3 | A 4-12 | pilot hand-offs 13-17 | Y 18-19 | m hand-offs 20-23 | Mo 24-26 | D2 27-28 |
-// lp hand-offs 29-30 | LP 31-32 | DL 33-34 | DR 35-36 | UL 37-38 | UR 39-40
-constexpr int WM_D1 = 0, WM_A = 4, WM_Y = 18, WM_MO = 24, WM_D2 = 27, WM_LP = 31, WM_DL = 33, WM_DR = 35, WM_UL = 37, WM_UR = 39;
+// lp hand-offs 29-30 | LP 31-32 | DL 33-34 | DR 35-36 | UL 37-39 | UR 40-42 | (FWD) EL 43-44 | ER 45-46 | decimator hand-offs 47-49 (left),
+// 50-52 (right) | YL 53-54 | YR 55-56
+constexpr int WM_D1 = 0, WM_A = 4, WM_Y = 18, WM_MO = 24, WM_D2 = 27, WM_LP = 31, WM_DL = 33, WM_DR = 35, WM_UL = 37, WM_UR = 40,
+              WM_EL = 43, WM_ER = 45, WM_YL = 53, WM_YR = 55;
 
-__global__ __launch_bounds__(128) void k_wfm_mrg(const float2 *__restrict__ iq, double *U, int n, long n_frames, long Lp, int swapped, MrgArg arg)
+// FWD: the FORWARD half of the zero-phase decimator runs in the same array (8 more lanes per frame, two frames per wavefront): the
+// memory wavefront builds SciPy's odd extension (_arraytools.odd_ext: 27 reflected samples either side) from the u_l / u_r rings block by
+// block — the extended sequence's blocks are 27 samples out of step with u's — and writes y_fwd in the layout the backward launch of
+// k_iir4_sys reads.  u itself then never leaves the CU either.
+template <bool FWD>
+__global__ __launch_bounds__(128) void k_wfm_mrg(const float2 *__restrict__ iq, double *UY, int n, long n_frames, long row_stride, int swapped,
+                                                 MrgArg arg)
 {
-    __shared__ double rows[WM_G][WM_ROWS][WM_T + 1];
+    constexpr int NL = FWD ? 27 : 19, G = FWD ? 2 : 3, NROWS = FWD ? 57 : 43;
+    __shared__ double rows[G][NROWS][WM_T + 1];
+    __shared__ double x0s[G][2];                 // FWD: first sample of each channel's extended sequence
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long f0 = (long)blockIdx.x * WM_G;
+    const long f0 = (long)blockIdx.x * G;
     const int M = n - 1;
+    const long L = (long)M + 2 * EDGE;
     const long nblk = ((long)M + WM_T - 1) / WM_T;
-    constexpr int DEEP = 11;
-    const long nstep = nblk + DEEP;
+    const long nblk_e = (L + WM_T - 1) / WM_T;   // blocks of the odd-extended sequence
+    constexpr int DEEP = FWD ? 16 : 11;
+    const long nstep = (FWD ? nblk_e : nblk) + DEEP;
     const double SIN_PI = 0x1.1a62633145c07p-53;  // np.sin(np.pi)
     if (wave == 1) {
         // ---------------- memory wavefront: lane = sample inside a block ----------------
-        struct Raw { float2 x0[WM_G], x1[WM_G]; };
+        struct Raw { float2 x0[G], x1[G]; };
         Raw rawA, rawB;
         auto load = [&](long blk, Raw &r) __attribute__((always_inline)) {
             const long i = blk * WM_T + lane;
 #pragma unroll
-            for (int g = 0; g < WM_G; g++) {
+            for (int g = 0; g < G; g++) {
                 const long f = f0 + g;
                 const bool ok = f < n_frames && i < M;
                 const float2 *x = iq + (size_t)(f < n_frames ? f : 0) * n;
@@ -1874,7 +1888,7 @@ __global__ __launch_bounds__(128) void k_wfm_mrg(const float2 *__restrict__ iq, 
         auto stage = [&](long blk, const Raw &r) __attribute__((always_inline)) {
             const long i = blk * WM_T + lane;
 #pragma unroll
-            for (int g = 0; g < WM_G; g++) {
+            for (int g = 0; g < G; g++) {
                 double e = 0.0;
                 if (f0 + g < n_frames && i < M) e = (double)disc_sample(r.x1[g], r.x0[g], 1.0f, swapped != 0);  // :122
                 rows[g][WM_D1 + (int)(blk & 1)][lane] = e;
@@ -1882,9 +1896,9 @@ __global__ __launch_bounds__(128) void k_wfm_mrg(const float2 *__restrict__ iq, 
         };
         // after macro-step ms: what the recurrence wavefront has finished is passed on / written back
         auto drain = [&](long ms) __attribute__((always_inline)) {
-            const long b6 = ms - 5, b9 = ms - 9, b11 = ms - 11;
+            const long b6 = ms - 5, b9 = ms - 9, b11 = ms - 11, b16 = ms - 16;
 #pragma unroll
-            for (int g = 0; g < WM_G; g++) {
+            for (int g = 0; g < G; g++) {
                 const long f = f0 + g;
                 if (f >= n_frames) continue;
                 if (b6 >= 0 && b6 < nblk) {   // pilot chain done with block b6 (m since the step before): m * (2 p), :130-134
@@ -1899,11 +1913,37 @@ __global__ __launch_bounds__(128) void k_wfm_mrg(const float2 *__restrict__ iq, 
                     rows[g][WM_DL + (int)(b9 & 1)][lane] = in ? __dmul_rn(__dadd_rn(a, lp), 0.5) : 0.0;
                     rows[g][WM_DR + (int)(b9 & 1)][lane] = in ? __dmul_rn(__dsub_rn(a, lp), 0.5) : 0.0;
                 }
-                if (b11 >= 0 && b11 < nblk) {
-                    const long iu = b11 * WM_T + lane;
-                    if (iu < M) {
-                        U[(size_t)(2 * f) * Lp + EDGE + iu] = rows[g][WM_UL + (int)(b11 & 1)][lane];
-                        U[(size_t)(2 * f + 1) * Lp + EDGE + iu] = rows[g][WM_UR + (int)(b11 & 1)][lane];
+                if constexpr (!FWD) {
+                    if (b11 >= 0 && b11 < nblk) {
+                        const long iu = b11 * WM_T + lane;
+                        if (iu < M) {
+                            UY[(size_t)(2 * f) * row_stride + EDGE + iu] = rows[g][WM_UL + (int)(b11 % 3)][lane];
+                            UY[(size_t)(2 * f + 1) * row_stride + EDGE + iu] = rows[g][WM_UR + (int)(b11 % 3)][lane];
+                        }
+                    }
+                } else {
+                    if (b11 >= 0 && b11 < nblk_e) {
+                        // block b11 of the odd-extended sequences (scipy _arraytools.odd_ext): ext[p] = 2 u[0] - u[27 - p] (p < 27),
+                        // u[p - 27], 2 u[M-1] - u[2M + 25 - p] (p >= 27 + M); u[i] sits in ring row (i / 64) % 3, column i % 64
+                        const long pidx = b11 * WM_T + lane;
+#pragma unroll
+                        for (int ch = 0; ch < 2; ch++) {
+                            const int ub = ch ? WM_UR : WM_UL;
+                            auto uat = [&](long i) { return rows[g][ub + (int)((i / WM_T) % 3)][(int)(i % WM_T)]; };
+                            double v = 0.0;
+                            if (pidx < EDGE) v = __dsub_rn(__dmul_rn(2.0, uat(0)), uat(EDGE - pidx));
+                            else if (pidx < EDGE + M) v = uat(pidx - EDGE);
+                            else if (pidx < L) v = __dsub_rn(__dmul_rn(2.0, uat(M - 1)), uat(2L * M + 25 - pidx));
+                            rows[g][(ch ? WM_ER : WM_EL) + (int)(b11 & 1)][lane] = v;
+                            if (pidx == 0) x0s[g][ch] = v;
+                        }
+                    }
+                    if (b16 >= 0 && b16 < nblk_e) {   // forward decimator pass done with block b16: y_fwd rows [2 f + channel][L]
+                        const long iy = b16 * WM_T + lane;
+                        if (iy < L) {
+                            UY[(size_t)(2 * f) * row_stride + iy] = rows[g][WM_YL + (int)(b16 & 1)][lane];
+                            UY[(size_t)(2 * f + 1) * row_stride + iy] = rows[g][WM_YR + (int)(b16 & 1)][lane];
+                        }
                     }
                 }
             }
@@ -1924,29 +1964,33 @@ __global__ __launch_bounds__(128) void k_wfm_mrg(const float2 *__restrict__ iq, 
             if (m + 1 < nstep) beside(m + 1, rawA);
         }
         drain(nstep - 1);
-        // odd extension (scipy _arraytools.odd_ext) of both channel rows from this wavefront's own stores
-        __threadfence();
-        for (int g = 0; g < WM_G; g++) {
-            const long f = f0 + g;
-            if (f >= n_frames) continue;
-            for (int ch = 0; ch < 2; ch++) {
-                double *u = U + (size_t)(2 * f + ch) * Lp + EDGE;
-                if (lane < EDGE) {
-                    const double u0 = __builtin_nontemporal_load(u), ul = __builtin_nontemporal_load(u + M - 1);
-                    const double a = __builtin_nontemporal_load(u + EDGE - lane), b = __builtin_nontemporal_load(u + M - 2 - lane);
-                    u[lane - EDGE] = __dsub_rn(__dmul_rn(2.0, u0), a);
-                    u[M + lane] = __dsub_rn(__dmul_rn(2.0, ul), b);
+        if constexpr (!FWD) {
+            // odd extension (scipy _arraytools.odd_ext) of both channel rows from this wavefront's own stores
+            __threadfence();
+            for (int g = 0; g < G; g++) {
+                const long f = f0 + g;
+                if (f >= n_frames) continue;
+                for (int ch = 0; ch < 2; ch++) {
+                    double *u = UY + (size_t)(2 * f + ch) * row_stride + EDGE;
+                    if (lane < EDGE) {
+                        const double u0 = __builtin_nontemporal_load(u), ul = __builtin_nontemporal_load(u + M - 1);
+                        const double a = __builtin_nontemporal_load(u + EDGE - lane), b = __builtin_nontemporal_load(u + M - 2 - lane);
+                        u[lane - EDGE] = __dsub_rn(__dmul_rn(2.0, u0), a);
+                        u[M + lane] = __dsub_rn(__dmul_rn(2.0, ul), b);
+                    }
                 }
             }
         }
         return;
     }
-    // ---------------- recurrence wavefront: 19 lanes per frame, one filter section per lane ----------------
-    const int g_raw = lane / 19, role = lane - 19 * g_raw;
-    const bool lane_in = g_raw < WM_G;
+    // ---------------- recurrence wavefront: NL lanes per frame, one filter section per lane ----------------
+    const int g_raw = lane / NL, role = lane - NL * g_raw;
+    const bool lane_in = g_raw < G;
     const int g = lane_in ? g_raw : 0;
     const MrgLane me = arg.lane[role];
     const bool lane_on = lane_in && me.depth >= 0;
+    const long my_nblk = (FWD && me.chan >= 0) ? nblk_e : nblk;   // the decimator lanes walk the extended sequence
+    const long my_len = (FWD && me.chan >= 0) ? L : (long)M;
     double z0 = 0.0, z1 = me.onepole ? -0.0 : 0.0;
     auto step = [&](double x) {
         const double xn = __dadd_rn(__dmul_rn(me.c.b0, x), z0);
@@ -1958,11 +2002,16 @@ __global__ __launch_bounds__(128) void k_wfm_mrg(const float2 *__restrict__ iq, 
     fused::lds_barrier();
     for (long m = 0; m < nstep; m++) {
         const long blk = m - me.depth;
-        const bool active = lane_on && blk >= 0 && blk < nblk;
+        const bool active = lane_on && blk >= 0 && blk < my_nblk;
         const long bsafe = active ? blk : 0;
         const double *src = rows[g][me.src + (int)(bsafe % me.src_ring)];
         double *dst = rows[g][me.dst + (int)(bsafe % me.dst_ring)];
-        const int cnt = !active ? 0 : (((long)M - blk * WM_T) < WM_T ? (int)((long)M - blk * WM_T) : WM_T);
+        const int cnt = !active ? 0 : ((my_len - blk * WM_T) < WM_T ? (int)(my_len - blk * WM_T) : WM_T);
+        if (FWD && active && blk == 0 && me.chan >= 0) {   // sosfiltfilt: every section starts from zi * (first sample of the extended sequence)
+            const double x0 = x0s[g][me.chan];
+            z0 = __dmul_rn(me.zi0, x0);
+            z1 = __dmul_rn(me.zi1, x0);
+        }
         // in-place hand-off: all lanes walk the block in lockstep, reads of a group of eight before its writes (k_iir4_sys)
         if (__all(!active || cnt == WM_T)) {
             if (active) {
@@ -3147,31 +3196,46 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             {
                 MrgArg am;
                 const Biquad idle{0.0, 0.0, 0.0, 0.0, 0.0};
-                for (int i = 0; i < 19; i++) am.lane[i] = MrgLane{idle, 0, 1, 0, 1, -1, 0};
+                for (int i = 0; i < 27; i++) am.lane[i] = MrgLane{idle, 0, 1, 0, 1, -1, 0, 0.0, 0.0, -1};
                 // pass 1: a (rows D1 -> 2 -> 3 -> A ring), pilot band-pass (D1 -> 13..17) + 1-pole (17 -> Y), m (D1 -> 20..23 -> Mo ring)
                 for (int i = 0; i < 3; i++)
-                    am.lane[i] = MrgLane{wc.lp[i], i == 0 ? WM_D1 : 1 + i, i == 0 ? 2 : 1, i == 2 ? WM_A : 2 + i, i == 2 ? 9 : 1, i, 0};
-                for (int i = 0; i < 5; i++) am.lane[3 + i] = MrgLane{wc.pil[i], i == 0 ? WM_D1 : 12 + i, i == 0 ? 2 : 1, 13 + i, 1, i, 0};
-                am.lane[8] = MrgLane{Biquad{1.0, 0.0, 0.0, -0.99, 0.0}, 17, 1, WM_Y, 2, 5, 1};                        // lfilter([1],[1,-0.99]) -> y
+                    am.lane[i] = MrgLane{wc.lp[i], i == 0 ? WM_D1 : 1 + i, i == 0 ? 2 : 1, i == 2 ? WM_A : 2 + i, i == 2 ? 9 : 1, i, 0, 0.0, 0.0, -1};
+                for (int i = 0; i < 5; i++) am.lane[3 + i] = MrgLane{wc.pil[i], i == 0 ? WM_D1 : 12 + i, i == 0 ? 2 : 1, 13 + i, 1, i, 0, 0.0, 0.0, -1};
+                am.lane[8] = MrgLane{Biquad{1.0, 0.0, 0.0, -0.99, 0.0}, 17, 1, WM_Y, 2, 5, 1, 0.0, 0.0, -1};            // lfilter([1],[1,-0.99]) -> y
                 for (int i = 0; i < 5; i++)
-                    am.lane[9 + i] = MrgLane{wc.lmr[i], i == 0 ? WM_D1 : 19 + i, i == 0 ? 2 : 1, i == 4 ? WM_MO : 20 + i, i == 4 ? 3 : 1, i, 0};
+                    am.lane[9 + i] = MrgLane{wc.lmr[i], i == 0 ? WM_D1 : 19 + i, i == 0 ? 2 : 1, i == 4 ? WM_MO : 20 + i, i == 4 ? 3 : 1, i, 0, 0.0, 0.0, -1};
                 // pass 2: LP15k on m * 2p (D2 -> 29 -> 30 -> LP), de-emphasis per channel (DL -> UL, DR -> UR)
                 for (int i = 0; i < 3; i++)
-                    am.lane[14 + i] = MrgLane{wc.lp[i], i == 0 ? WM_D2 : 28 + i, i == 0 ? 2 : 1, i == 2 ? WM_LP : 29 + i, i == 2 ? 2 : 1, 7 + i, 0};
-                am.lane[17] = MrgLane{Biquad{wc.b0d, 0.0, 0.0, wc.a1d, 0.0}, WM_DL, 2, WM_UL, 2, 11, 1};
-                am.lane[18] = MrgLane{Biquad{wc.b0d, 0.0, 0.0, wc.a1d, 0.0}, WM_DR, 2, WM_UR, 2, 11, 1};
-                const unsigned gm = (unsigned)((n_frames + WM_G - 1) / WM_G);
+                    am.lane[14 + i] = MrgLane{wc.lp[i], i == 0 ? WM_D2 : 28 + i, i == 0 ? 2 : 1, i == 2 ? WM_LP : 29 + i, i == 2 ? 2 : 1, 7 + i, 0, 0.0, 0.0, -1};
+                am.lane[17] = MrgLane{Biquad{wc.b0d, 0.0, 0.0, wc.a1d, 0.0}, WM_DL, 2, WM_UL, 3, 11, 1, 0.0, 0.0, -1};
+                am.lane[18] = MrgLane{Biquad{wc.b0d, 0.0, 0.0, wc.a1d, 0.0}, WM_DR, 2, WM_UR, 3, 11, 1, 0.0, 0.0, -1};
+#ifdef PSS_EXP_WFM_NOFWD
+                const unsigned gm = (unsigned)((n_frames + 2) / 3);
                 pss_kernel_begin(ctx, "k_wfm_casc");
-                hipLaunchKernelGGL(k_wfm_mrg, dim3(gm), dim3(128), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), U2, n, n_frames, Lp,
+                hipLaunchKernelGGL(k_wfm_mrg<false>, dim3(gm), dim3(128), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), U2, n, n_frames, Lp,
                                    swapped, am);
                 pss_kernel_end(ctx);
+#else
+                // forward half of the zero-phase decimator, per channel (EL -> 47 -> 48 -> 49 -> YL, ER -> 50 -> 51 -> 52 -> YR)
+                for (int ch = 0; ch < 2; ch++)
+                    for (int i = 0; i < 4; i++)
+                        am.lane[19 + 4 * ch + i] = MrgLane{c.s[i], i == 0 ? (ch ? WM_ER : WM_EL) : 46 + 3 * ch + i, i == 0 ? 2 : 1,
+                                                           i == 3 ? (ch ? WM_YR : WM_YL) : 47 + 3 * ch + i, i == 3 ? 2 : 1, 13 + i, 0, c.zi[2 * i], c.zi[2 * i + 1], ch};
+                const unsigned gm = (unsigned)((n_frames + 1) / 2);
+                pss_kernel_begin(ctx, "k_wfm_casc");
+                hipLaunchKernelGGL(k_wfm_mrg<true>, dim3(gm), dim3(128), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), Y2, n, n_frames, L,
+                                   swapped, am);
+                pss_kernel_end(ctx);
+#endif
             }
 #endif
 #endif
             const unsigned gs = (unsigned)((rows + IS_G - 1) / IS_G);
+#if defined(PSS_EXP_CASC_SAMPLE) || defined(PSS_EXP_WFM_TWOPASS) || defined(PSS_EXP_WFM_NOFWD)
             pss_kernel_begin(ctx, "k_iir4_sys");
             hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(128), 0, PSS_STREAM(ctx), U2, Lp, 0, L, L, c, Y2, L, q, n_out, nullptr, rows);
             pss_kernel_end(ctx);
+#endif
             pss_kernel_begin(ctx, "k_iir4_sys");
             hipLaunchKernelGGL(k_iir4_sys, dim3(gs), dim3(128), 0, PSS_STREAM(ctx), Y2, L, 1, L, L - EDGE, c, A2, (long)n_out, q, n_out, MX2, rows);
             pss_kernel_end(ctx);
