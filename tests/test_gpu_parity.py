@@ -851,6 +851,26 @@ def test_wfm_batch_vs_oracle():
         assert np.all(np.abs(audio).max(axis=(1, 2)) == 1.0)
 
 
+def test_wfm_small_batch_array_at_block_edges():
+    """The small-batch WFM path is ONE block-systolic array since round 3 (k_wfm_mrg: both filter passes and the forward decimator, 64-sample
+    blocks, the odd-extended sequence 27 samples out of step with them): frame lengths around every block boundary of the audio row
+    (M = n - 1) and of its extension (M + 54), one to five frames (two frames per workgroup), against the oracle bit for bit."""
+    rng = np.random.default_rng(77)
+    e = G.engine()
+    fs = 250e3
+    lp, pil, lmr, alpha = e.wfm_filters(fs)
+    _, sos, zi = e.nfm_filters(fs)
+    filt = dict(lp_sos=lp, pilot_sos=pil, lmr_sos=lmr, alpha=alpha, dec_sos=sos, dec_zi=zi)
+    for n in (29, 30, 37, 38, 64, 65, 66, 74, 75, 76, 92, 128, 129, 130, 139, 193, 1000, 4097):
+        for nf in (1, 2, 3, 5):
+            ph = np.cumsum(rng.standard_normal((nf, n)) * 0.2, axis=1)
+            iq = (0.5 * np.exp(1j * ph) + 0.02 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
+            pcm, audio = _wfm(e, iq, fs, dispatcher=False)
+            for f in range(nf):
+                a = O.demod_wfm(iq[f], fs, filt)
+                assert np.array_equal(audio[f].view(np.uint64), a.view(np.uint64)), (n, nf, f)
+
+
 def test_wfm_fused_and_unfused_paths_agree():
     # the fused forward kernel (k_wfm_fwd + k_nfm_bwd) and the k_wfm_front + k_nfm_iir path must produce identical bits
     rng = np.random.default_rng(99)
