@@ -53,7 +53,7 @@ int pss_device_count(void);
  *   "nfm_fused" (1)            0: lane-per-frame three-kernel NFM path (front, edge, iir) instead of the fused kernels (test fallback)
  *   "wfm_fused" (1)            0: k_wfm_front + lane-per-frame decimator instead of the fused WFM forward kernel (test fallback)
  *   "small_batch" (1)          0: never take the latency-oriented small-batch kernels (one lane per filter section)
- *   "small_batch_max" (8192)   largest NFM frame count that takes them;  "wfm_small_batch_max" (8192) likewise for WFM
+ *   "small_batch_max" (8192)   largest NFM frame count that takes them;  "wfm_small_batch_max" (6000) likewise for WFM
  *   "ssb_hilbert" (1)          0: demodulate_ssb skips the reference's hilbert() FFT round trip (the identity on the real part it
  *                              keeps, up to ~1e-16); 1: executed for power-of-two frames of 256..1048576 samples
  *   "hilbert_exact" (0)        1: pss_hilbert and demodulate_ssb's hilbert() run pocketfft's own butterfly order for rows of 256..1048576
