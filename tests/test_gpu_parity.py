@@ -184,6 +184,7 @@ def test_post_process_select_kernel_equals_sort_kernel(n):
         try:
             d_post = G.empty((nf, n - 4), torch.float32)
             d_post.fill_(float("nan"))
+            torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own: order them
             e.spectrum_post(d_db, nf, n, d_post)
             e.sync()
             res.append(G.host(d_post))
@@ -1291,6 +1292,7 @@ def test_kernel_timing_and_filter():
     try:
         eng.spectrum_nfm(iq, nf, n, fs, db, pcm); eng.sync()
         want = (db.clone(), pcm.clone())
+        torch.cuda.synchronize()          # the clones run on torch's stream
         eng.enable_timing(True)
         eng.spectrum_nfm(iq, nf, n, fs, db, pcm); eng.sync()
         every = eng.kernel_times()
@@ -1680,6 +1682,7 @@ def test_full_size_headline_properties():
     gen = torch.Generator(device="cuda").manual_seed(1234)
     base = torch.randn((512, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3
     iq = base.repeat(nf // 512, 1, 1).contiguous()            # every block of 512 frames repeats
+    torch.cuda.synchronize()                                  # torch's stream produced iq; the library runs on its own stream
     d_db, d_post = G.empty((nf, n), torch.float32), G.empty((nf, n - 4), torch.float32)
     d_lo, d_hi = G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
     d_g, d_c = G.empty((nf, W), torch.int8), G.empty((nf, W), torch.int8)
@@ -1775,6 +1778,7 @@ def test_display_lines_without_materialised_rows(n):
     lo, hi = G.empty((halo + nf,), torch.float32), G.empty((halo + nf,), torch.float32)
     lo[:halo] = torch.tensor(rng.uniform(-60, -50, halo).astype(np.float32)); hi[:halo] = torch.tensor(rng.uniform(-20, -5, halo).astype(np.float32))
     lo2, hi2 = lo.clone(), hi.clone()
+    torch.cuda.synchronize()              # torch's stream wrote lo / hi and their clones; the library runs on its own stream
     d_post, d_thr = G.empty((nf, n - 4), torch.float32), G.empty((nf,), torch.float32)
     e.spectrum_post_extremes(d_db, nf, n, d_post, lo[halo:], hi[halo:])
     e.spectrum_post_thresholds(d_db, nf, n, d_thr, lo2[halo:], hi2[halo:])
