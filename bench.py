@@ -285,6 +285,9 @@ def main():
     ap.add_argument("--materialise-post", action="store_true",
                     help="also write the post-processed rows [frames][1020] float32 to HBM (default: the display lines are built without them)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step's outputs")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other BASELINE.json configs (cfg 3, cfg 4, cfg 5 resident + streamed, the WFM step) that the default one-GPU "
+                         "run times and verifies after the headline (tools/bench_configs.py)")
     ap.add_argument("--dry-run", action="store_true", help="launch path only (gloo rendezvous, no GPU work): what the CPU test runs")
     args = ap.parse_args()
 
@@ -310,7 +313,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from pyspecsdr_amd.engine import Engine
-    eng = Engine(local_rank)
+    eng = Engine(local_rank, order="none")   # this script orders its streams by hand (fences, events)
     comp = torch.cuda.ExternalStream(eng.stream_handle(), device=dev)   # the library's stream, for event ordering
     nf, n = args.frames, N_FFT
     iq = synth_fm_iq(nf, n, FS, dev, seed=20260928 + 2 + rank)
@@ -453,6 +456,19 @@ def main():
             side["exchange_display_bytes_per_rank"] = set_bytes
             side["exchange_db_ms"] = xfer(d_db[0].view(torch.uint8).view(-1), nf * n * 4)
             side["exchange_db_bytes_per_rank"] = nf * n * 4
+            # how much of the in-region exchange the next step's compute hid: 1 = all of it, 0 = none (step = compute + exchange)
+            xms = side["exchange_display_ms"] if exch == "display" else side["exchange_db_ms"]
+            side["overlap_frac"] = 1.0 - (elapsed / args.steps * 1e3 - side["compute_ms"]) / xms if xms > 0 else None
+            side["overlap_note"] = ("overlap_frac = 1 - (ms_per_step - compute_ms) / exchange_ms of the exchange inside the timed region "
+                                    f"({exch}); all three measured on this rank (rank 0, the gather's root)")
+
+    other = None
+    if world == 1 and dist is None and not args.no_other_configs:
+        # the other BASELINE.json configs and the WFM step: timed, priced and oracle-verified one after the other, outside the headline's
+        # timed region (which ended above); a failing verification fails the run like the headline's
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs
+        other = bench_configs.other_configs(eng, dev, verify=not args.no_verify)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -465,8 +481,12 @@ def main():
         ms = ktimes[dom]
         achieved = ALGO_BYTES.get(dom, ALGO_BYTES["path"]) * nf / (ms * 1e-3) / 1e9
         traffic, valu_busy, prof_note = profiled(dom, nf)
-        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy, "profile": prof_note,
+        # "bound" names the roof that binds the dominant kernel: k_nfm_fwd's float64 operation count per sample is fixed by the reference's
+        # summation order and sits below the HBM ceiling; achieved / peak / frac stay the HBM figures the contract asks
+        # for, the binding roof's own numbers are in "f64_issue"
+        roof = {"bound": "f64_issue" if dom == "k_nfm_fwd" else "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_busy_frac": valu_busy,
+                "profile": prof_note,
                 "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
                 "kernel_ms_note": f"{dom}: HIP events inside the timed region; the others: untimed survey pass before it",
                 "path_achieved": ALGO_BYTES["path"] * nf / (elapsed / args.steps) / 1e9,
@@ -528,12 +548,18 @@ def main():
             "src_hash": source_hash(),
         }
         out.update(side)
+        if other is not None:
+            out["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             taps, sos, zi = eng.nfm_filters(FS)
             out["cpu_baseline"] = cpu_baseline(iq.cpu().numpy().view(np.complex64).reshape(-1, n), FS, taps, sos, zi)
             out["cpu_baseline"]["value"] /= 1e6
             out["cpu_baseline"]["single_thread_value"] /= 1e6
             out["cpu_baseline"]["unit"] = "MSamples/s"
+            # the reference ITSELF (per-frame NumPy / SciPy calls, filters redesigned on every call) cannot travel to this box; its only
+            # measurement is the build container's: the C port above is ~75x faster than what it restates
+            out["cpu_baseline"]["reference_numpy"] = {"value": 0.635, "unit": "MSamples/s", "where": "build container only (8-core Xeon, 1 thread, "
+                                                      "NumPy 2.2.6 / SciPy 1.15.3); not measured on this box"}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -543,6 +569,11 @@ def main():
     if verified is not None and not verified.get("ok_all_ranks", verified["ok"]):
         sys.stderr.write(f"bench.py: the timed steps' outputs do NOT match the oracle: {verified}\n")
         sys.exit(3)
+    if other is not None and not args.no_verify:
+        bad = {k: v.get("verified") or v.get("error") for k, v in other.items() if not (v.get("verified") or {}).get("ok", False)}
+        if bad:
+            sys.stderr.write(f"bench.py: other_configs outputs do NOT match the oracle: {bad}\n")
+            sys.exit(3)
 
 
 if __name__ == "__main__":

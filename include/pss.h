@@ -46,6 +46,16 @@ int pss_set_stream(pss_ctx *ctx, void *hip_stream);
 /* The hipStream_t (as void*) the context's work is queued on: lets a caller order its own streams / events against it
  * (e.g. torch.cuda.ExternalStream(pss_get_stream(ctx)) to overlap an RCCL gather with the next batch). */
 void *pss_get_stream(pss_ctx *ctx);
+/* Order the context's stream against a caller's stream (hipStream_t as void*, NULL = the default stream) WITHOUT adopting it — the context
+ * keeps its own non-blocking stream, which the legacy default stream does not synchronise with:
+ *   pss_order_after:  work queued on the context from now on starts after everything queued on the caller's stream so far (inputs the
+ *                     caller produced, outputs it cleared);
+ *   pss_order_before: work queued on the caller's stream from now on starts after everything the context has queued so far (results).
+ * One event record + one stream wait each (~2 us), nothing blocks the host.  A single-threaded caller that fills buffers on its stream,
+ * calls an entry point and reads the results on its stream — the call order of the reference's loop, pyspecsdr.py:2250-2283 — brackets every
+ * call with the pair; pyspecsdr_amd.engine.Engine does so by default with torch's current stream. */
+int pss_order_after(pss_ctx *ctx, void *hip_stream);
+int pss_order_before(pss_ctx *ctx, void *hip_stream);
 int pss_sync(pss_ctx *ctx);
 const char *pss_last_error(pss_ctx *ctx); /* ctx may be NULL: error of the last failed pss_create */
 int pss_device_count(void);
@@ -191,6 +201,18 @@ int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, doub
 int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
                            float *d_row_lo, float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
                            int8_t *d_colour, int16_t *d_pcm);
+
+/* The same iteration in ANY of the main loop's demodulation modes — demodulate_signal(samples, fs, CURRENT_DEMOD) (pyspecsdr.py:2262), whose
+ * default is WFM (:2855) — and for either batched display accumulator.  mode: PSS_MODE_*, with demodulate_signal's dispatcher semantics (WFM
+ * frames are IQ-corrected first, signal_processing.py:222-225; compute_fft sees the samples as read, pyspecsdr.py:2275).  d_pcm int16
+ * [n_frames][pss_demod_out_len(mode, n, fs)][2].  display 0: waterfall line, d_line_a = glyph, d_line_b = colour (window: 30 in the reference);
+ * display 1: persistence trace, d_line_a = row index per column, d_line_b unused (may be NULL), disp_h <= 127 (window: 10 in the reference).
+ * The other arguments and the results are those of the separate calls (pss_demod_signal, pss_spectrum_db, pss_spectrum_post_extremes /
+ * _thresholds, pss_waterfall_rows[_db] / pss_persistence_rows[_db]); NFM runs the schedule of pss_frame_pipeline_nfm, the other modes run the
+ * display chain on the side stream beside the whole demodulator.  PSS_E_ARG for n < 8 (no post-processed row), n_halo < 0, window < 1. */
+int pss_frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
+                       float *d_row_lo, float *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w, int8_t *d_line_a,
+                       int8_t *d_line_b, int16_t *d_pcm);
 
 /* The reference's own row type.  compute_fft returns float64 rows (signal_processing.py:243-264) and the caller smooths, clamps and
  * draws them in float64 (pyspecsdr.py:2278-2283, :1342-1406); the float32 rows above agree with them to 1e-7 relative, but a display cell

@@ -1332,3 +1332,63 @@ void pss_o_waterfall_rows(const float *rows, long n_frames, int len, int window,
     free(rlo);
     free(rhi);
 }
+
+/* Batched persistence accumulator: for every frame the row index of the NEWEST trace's '*' in every display column as draw_persistence
+ * (pyspecsdr.py:1512-1564) places it with the history of the last `window` rows — min / max over the finite values of rows
+ * i-window+1 .. i (:1525-1527), range 0 -> 1 (:1528-1530), np.interp to disp_w (:1547-1551), y = int((1 - norm) * (disp_h - 1))
+ * (:1555-1556), drawn only inside the grid (:1557).  rows float32 [n_frames][len]; y int8 [n_frames][disp_w], -1 where nothing is drawn. */
+void pss_o_persistence_rows(const float *rows, long n_frames, int len, int window, int disp_h, int disp_w, int8_t *ycell, int n_threads)
+{
+    double *rlo = (double *)malloc(sizeof(double) * (n_frames > 0 ? n_frames : 1));
+    double *rhi = (double *)malloc(sizeof(double) * (n_frames > 0 ? n_frames : 1));
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+#endif
+    for (long f = 0; f < n_frames; f++) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int k = 0; k < len; k++) {
+            const double v = (double)rows[f * len + k];
+            if (isfinite(v)) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        }
+        rlo[f] = lo;
+        rhi[f] = hi;
+    }
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+#endif
+    for (long f = 0; f < n_frames; f++) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (long p = f - (window - 1) < 0 ? 0 : f - (window - 1); p <= f; p++) {
+            lo = rlo[p] < lo ? rlo[p] : lo;
+            hi = rhi[p] > hi ? rhi[p] : hi;
+        }
+        double range = hi - lo;
+        if (range == 0) range = 1;
+        const float *row = rows + f * len;
+        const double stop = (double)(len - 1);
+        for (int x = 0; x < disp_w; x++) {
+            double xp, v;
+            if (disp_w == 1) xp = 0.0;
+            else {
+                const double step = stop / (double)(disp_w - 1);
+                xp = (x == disp_w - 1) ? stop : (double)x * step;
+            }
+            if (xp >= stop) v = (double)row[len - 1];
+            else {
+                const int j = (int)xp;
+                const double slope = ((double)row[j + 1] - (double)row[j]) / ((double)(j + 1) - (double)j);
+                v = slope * (xp - (double)j) + (double)row[j];
+            }
+            int8_t y8 = -1;
+            if (isfinite(v)) {
+                const int y = (int)((1 - (v - lo) / range) * (disp_h - 1));
+                if (y >= 0 && y < disp_h) y8 = (int8_t)y;
+            }
+            ycell[f * disp_w + x] = y8;
+        }
+    }
+    free(rlo);
+    free(rhi);
+}
+

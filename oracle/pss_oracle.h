@@ -125,6 +125,7 @@ void pss_o_batch_spectrum_post_nfm(const float *iq, long n_frames, int n, double
 /* batched waterfall accumulator: newest display line per frame, history of `window` rows (pyspecsdr.py:1342-1406). */
 void pss_o_waterfall_rows(const float *rows, long n_frames, int len, int window, int disp_w, int8_t *glyph, int8_t *colour,
                           int n_threads);
+void pss_o_persistence_rows(const float *rows, long n_frames, int len, int window, int disp_h, int disp_w, int8_t *ycell, int n_threads);
 
 #ifdef __cplusplus
 }

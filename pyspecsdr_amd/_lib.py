@@ -19,6 +19,8 @@ _SIGS = {
     "pss_destroy": (None, [_p]),
     "pss_set_stream": (C.c_int, [_p, _p]),
     "pss_get_stream": (_p, [_p]),
+    "pss_order_after": (C.c_int, [_p, _p]),
+    "pss_order_before": (C.c_int, [_p, _p]),
     "pss_sync": (C.c_int, [_p]),
     "pss_last_error": (C.c_char_p, [_p]),
     "pss_device_count": (C.c_int, []),
@@ -58,6 +60,7 @@ _SIGS = {
     "pss_demod_out_len": (C.c_int, [C.c_int, C.c_int, C.c_double]),
     "pss_spectrum_nfm": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
     "pss_frame_pipeline_nfm": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "pss_frame_pipeline": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "pss_frame_pipeline_nfm_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "pss_spectrum_db_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
     "pss_spectrum_post_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, _p]),

@@ -104,6 +104,7 @@ extern "C" int pss_create(int device, pss_ctx **out)
     } restore{prev, device};
     pss_ctx *ctx = new pss_ctx();
     ctx->device = device;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) ctx->n_cus = cus; }
     { const char *e = getenv("PSS_NO_FUSED"); ctx->no_fused = e && e[0] == '1'; }
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) ctx->own_stream = true;
@@ -162,6 +163,8 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     hipStreamDestroy(ctx->stream2);
     hipEventDestroy(ctx->ev_fork);
     hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_in) hipEventDestroy(ctx->ev_in);
+    if (ctx->ev_out) hipEventDestroy(ctx->ev_out);
     for (auto &k : ctx->krecs) { hipEventDestroy(k.e0); hipEventDestroy(k.e1); }
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -175,6 +178,32 @@ extern "C" int pss_set_stream(pss_ctx *ctx, void *hip_stream)
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     ctx->own_stream = false;
+    return PSS_OK;
+}
+
+// Ordering against a caller's stream without giving up the context's own (non-blocking) stream: one event record + one stream wait each,
+// nothing blocks the host.
+extern "C" int pss_order_after(pss_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    if (s == ctx->stream) return PSS_OK;
+    if (!ctx->ev_in) PSS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
+    PSS_HIP(ctx, hipEventRecord(ctx->ev_in, s));
+    PSS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
+    return PSS_OK;
+}
+
+extern "C" int pss_order_before(pss_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    if (s == ctx->stream) return PSS_OK;
+    if (!ctx->ev_out) PSS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_out, hipEventDisableTiming));
+    PSS_HIP(ctx, hipEventRecord(ctx->ev_out, ctx->stream));
+    PSS_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_out, 0));
     return PSS_OK;
 }
 

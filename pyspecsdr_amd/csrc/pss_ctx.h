@@ -37,6 +37,8 @@ struct pss_ctx {
     hipStream_t stream2 = nullptr;  // side stream: the spectrum kernel of pss_spectrum_nfm runs beside the demodulator
     hipStream_t cur = nullptr;      // stream the next launches go to (nullptr = `stream`)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;   // pss_order_after / pss_order_before (created on first use)
+    int n_cus = 0;                                  // hipDeviceProp_t::multiProcessorCount
     bool fork_after_fwd = false;
     bool did_fork = false;
     bool defer_bwd = false;              // the fused NFM path launches only its forward kernel and parks the backward launch here:
@@ -59,6 +61,7 @@ struct pss_ctx {
     void *scratch_pk = nullptr;
     size_t scratch_pk_bytes = 0;
     void *prog = nullptr;          // k_nfm_fwd: per-CU progress words of its workgroups (priority balancing)
+    unsigned prog_epoch = 0;       // launch counter stamped into those words (16 bits, never 0)
     void *scratch_post = nullptr;  // pss_frame_pipeline_nfm without materialised post-processed rows: the rows' clamp thresholds
     size_t scratch_post_bytes = 0;
     void *scratch_win = nullptr;   // sliding-window extremes of the batched display accumulators

@@ -2523,16 +2523,59 @@ __global__ __launch_bounds__(256) void k_row_normalise(const double *__restrict_
 }
 
 // adjust_gain (pyspecsdr.py:898-919), sequential by nature.
-__global__ void k_agc(const float *__restrict__ power, long n, int idx, int n_gains, int *__restrict__ out)
+// adjust_gain (pyspecsdr.py:898-919) over a series of power readings.  A step maps the gain index x to min(x + 1, n_gains - 1), max(x - 1, 0)
+// or x, and WHICH of the three depends on the reading alone — so the series is a composition of maps of the form
+// f(x) = min(max(x + a, lo), hi), a family closed under composition ((a1, lo1, hi1) then (a2, lo2, hi2) = (a1 + a2, clamp(lo1 + a2, lo2, hi2),
+// clamp(hi1 + a2, lo2, hi2))): integer arithmetic, exact, and associative — one workgroup composes per-thread chunks, scans the 1024 chunk maps
+// through LDS and replays each chunk from its true starting index (the single-thread loop took 0.9 ms for 8192 readings: one dependent
+// global load per step).
+struct AgcMap { long long a, lo, hi; };
+constexpr long long AGC_INF = 1LL << 60;
+__device__ __forceinline__ AgcMap agc_then(const AgcMap f, const AgcMap g)
 {
-    if (blockIdx.x || threadIdx.x) return;
-    for (long i = 0; i < n; i++) {
-        float diff = __fsub_rn(-30.0f, power[i]);
-        if (!(fabsf(diff) < 2.0f)) {
-            if (diff > 0) { idx += 1; if (idx > n_gains - 1) idx = n_gains - 1; }
-            else { idx -= 1; if (idx < 0) idx = 0; }
-        }
-        out[i] = idx;
+    auto cl = [&](long long v) { return v < g.lo ? g.lo : (v > g.hi ? g.hi : v); };
+    return AgcMap{f.a + g.a, cl(f.lo + g.a), cl(f.hi + g.a)};
+}
+__device__ __forceinline__ int agc_dir(float p)   // +1 / -1 / 0 exactly as the reference's comparisons fall (NaN readings step down)
+{
+    const float diff = __fsub_rn(-30.0f, p);
+    if (fabsf(diff) < 2.0f) return 0;
+    return diff > 0 ? 1 : -1;
+}
+constexpr int AGC_T = 1024;
+__global__ __launch_bounds__(AGC_T) void k_agc(const float *__restrict__ power, long n, int idx, int n_gains, int *__restrict__ out)
+{
+    __shared__ AgcMap sm[2][AGC_T];
+    const int t = threadIdx.x;
+    const long per = (n + AGC_T - 1) / AGC_T, i0 = (long)t * per, i1 = i0 + per < n ? i0 + per : n;
+    const AgcMap up{1, -AGC_INF, (long long)n_gains - 1}, down{-1, 0, AGC_INF};
+    AgcMap m{0, -AGC_INF, AGC_INF};
+    for (long i = i0; i < i1; i++) {
+        const int d = agc_dir(power[i]);
+        if (d) m = agc_then(m, d > 0 ? up : down);
+    }
+    sm[0][t] = m;
+    __syncthreads();
+    int cur = 0;
+    for (int off = 1; off < AGC_T; off <<= 1) {      // inclusive scan of the chunk maps (earlier map first)
+        AgcMap v = sm[cur][t];
+        if (t >= off) v = agc_then(sm[cur][t - off], v);
+        sm[cur ^ 1][t] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    long long x = idx;
+    if (t > 0) {
+        const AgcMap pre = sm[cur][t - 1];
+        x = x + pre.a;
+        x = x < pre.lo ? pre.lo : (x > pre.hi ? pre.hi : x);
+    }
+    int xi = (int)x;
+    for (long i = i0; i < i1; i++) {
+        const int d = agc_dir(power[i]);
+        if (d > 0) { xi += 1; if (xi > n_gains - 1) xi = n_gains - 1; }
+        else if (d < 0) { xi -= 1; if (xi < 0) xi = 0; }
+        out[i] = xi;
     }
 }
 
@@ -2842,7 +2885,7 @@ extern "C" int pss_agc_steps(pss_ctx *ctx, const float *d_power, long n, int sta
     if (!d_power || !d_idx_out || n < 0 || n_gains < 1) return pss_fail(ctx, PSS_E_ARG, "bad agc arguments");
     if (n == 0) return PSS_OK;
     pss_kernel_begin(ctx, "k_agc");
-    hipLaunchKernelGGL(k_agc, dim3(1), dim3(1), 0, PSS_STREAM(ctx), d_power, n, start_idx, n_gains, d_idx_out);
+    hipLaunchKernelGGL(k_agc, dim3(1), dim3(AGC_T), 0, PSS_STREAM(ctx), d_power, n, start_idx, n_gains, d_idx_out);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_agc launch");
 }
@@ -2887,7 +2930,9 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const bool small_batch = !ctx->no_small_batch && n_frames <= ctx->small_batch_max;
         // (the fused kernels exist for decimator sections 1..3 with numerator exactly [1, 2, 1] — every cheby1 low-pass SOS; injected
         // tables of another shape take the three-kernel path)
-        if (n - 1 >= 128 && !ctx->no_fused && !small_batch && b121) {
+        // (and for tiles of less than 2 GiB of IQ: the forward kernel addresses a tile of 64 frames through one buffer resource with 32-bit
+        // offsets — frames of 4 Mi samples and more take the three-kernel path)
+        if (n - 1 >= 128 && !ctx->no_fused && !small_batch && b121 && (long)TILE * n * (long)sizeof(float2) < (1L << 31)) {
             // fused path: u[] stays on chip; small L2-resident scratch for the irregular head / tail of u
             const size_t szH = align256((size_t)tiles * fused::HEAD * TILE * sizeof(double));
             const size_t szT = align256((size_t)tiles * (EDGE + 1) * TILE * sizeof(double));
@@ -2896,10 +2941,13 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             const double *d_rev = nullptr;
             r = nfm_dev_taps(ctx, flt, &d_rev);
             if (r) return r;
-            if (!ctx->prog) {    // progress words of the forward kernel's workgroups (256 CUs x 4 slots)
-                PSS_HIP(ctx, hipMalloc(&ctx->prog, 4096));
-                PSS_HIP(ctx, hipMemset(ctx->prog, 0, 4096));
+            const unsigned ncu = ctx->n_cus > 0 ? (unsigned)ctx->n_cus : 256u;
+            if (!ctx->prog) {    // progress words of the forward kernel's workgroups (16 bytes per CU: up to four workgroups share one)
+                PSS_HIP(ctx, hipMalloc(&ctx->prog, 16 * (size_t)ncu));
+                PSS_HIP(ctx, hipMemsetAsync(ctx->prog, 0, 16 * (size_t)ncu, PSS_STREAM(ctx)));   // ordered before the first launch
             }
+            ctx->prog_epoch = (ctx->prog_epoch + 1u) & 0xffffu;   // every launch ranks only against words of its own epoch (never reset)
+            if (ctx->prog_epoch == 0) ctx->prog_epoch = 1;
             char *base = reinterpret_cast<char *>(ctx->scratch);
             double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);
             double *Uh = reinterpret_cast<double *>(base + szY + szA), *Ut = reinterpret_cast<double *>(base + szY + szA + szH);
@@ -2908,7 +2956,8 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             {
                 auto kf = swapped ? fused::k_nfm_fwd<true, true> : fused::k_nfm_fwd<true, false>;
                 hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, d_rev, reinterpret_cast<unsigned *>(ctx->prog));
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, d_rev, reinterpret_cast<unsigned *>(ctx->prog),
+                                   ncu, ctx->prog_epoch);
             }
             pss_kernel_end(ctx);
             auto launch_bwd = [=]() -> int {
@@ -3658,14 +3707,68 @@ extern "C" int pss_frame_pipeline_nfm_f64(pss_ctx *ctx, const float *d_iq, long 
     return r;
 }
 
-extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
-                                      float *d_row_lo, float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
-                                      int8_t *d_colour, int16_t *d_pcm)
+// display: 0 = the waterfall accumulator's newest line (d_glyph, d_colour), 1 = the persistence accumulator's newest trace (d_glyph = row
+// index per column, d_colour unused).  Lines of the display chain, whichever stream it is queued on:
+static int pipeline_lines(pss_ctx *ctx, int display, const float *d_db, const float *d_post, const float *d_thr, long n_frames, int n,
+                          const float *d_row_lo, const float *d_row_hi, int n_halo, int window, int disp_h, int disp_w, int8_t *d_glyph,
+                          int8_t *d_colour)
 {
-    if (!ctx) return PSS_E_ARG;
-    PSS_GUARD(ctx);
-    if (n_frames > 0 && (!d_db || !d_row_lo || !d_row_hi || !d_glyph || !d_colour || !d_pcm))
-        return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_nfm: null buffer");
+    if (d_thr)
+        return display ? pss_persistence_rows_db(ctx, d_db, n_frames, n, d_thr, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph)
+                       : pss_waterfall_rows_db(ctx, d_db, n_frames, n, d_thr, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+    return display ? pss_persistence_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph)
+                   : pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+}
+
+static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
+                          float *d_row_lo, float *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
+                          int8_t *d_glyph, int8_t *d_colour, int16_t *d_pcm)
+{
+    if (n_frames < 0 || n_halo < 0 || window < 1 || disp_w < 1 || (display != 0 && display != 1) || (display == 1 && (disp_h < 1 || disp_h > 127)))
+        return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline: bad frame count, halo, window or display geometry");
+    if (n < 8) return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline: frames of fewer than 8 samples have no post-processed row to draw");
+    if (n_frames > 0 && (!d_iq || !d_db || !d_row_lo || !d_row_hi || !d_glyph || (!d_colour && display == 0) || !d_pcm))
+        return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline: null buffer");
+    if (mode != PSS_MODE_NFM) {
+        // AM / USB / LSB / WFM (demodulate_signal's dispatcher semantics: WFM frames are IQ-corrected first, signal_processing.py:222-225).
+        // None of these demodulators has the NFM path's two-phase shape, so the display chain simply runs on the side stream beside the whole
+        // demodulator: WFM's forward kernel keeps one wavefront per SIMD busy for ~1 ms (float64 issue), AM's recurrence kernel two thirds
+        // of the SIMDs — the HBM-bound chain fits in beside them.
+        float *d_thr2 = nullptr;
+        if (n_frames > 0 && !d_post) {
+            const bool direct = (n & 3) == 0 && n - 4 <= 32768 && !ctx->post_legacy;
+            const size_t need = direct ? (size_t)n_frames * sizeof(float) : (size_t)n_frames * (n - 4) * sizeof(float);
+            int rq = pss_ensure_buffer(ctx, &ctx->scratch_post, &ctx->scratch_post_bytes, need, "post-process scratch");
+            if (rq) return rq;
+            if (direct) d_thr2 = reinterpret_cast<float *>(ctx->scratch_post);
+            else d_post = reinterpret_cast<float *>(ctx->scratch_post);
+        }
+        pss_time_begin(ctx);
+        int r = PSS_OK;
+        const float *d_in = d_iq;
+        if (mode == PSS_MODE_WFM && n_frames > 0) {   // the correction first, alone: the chain beside it would only share its HBM bandwidth
+            r = pss_ensure_buffer(ctx, &ctx->scratch_iqc, &ctx->scratch_iqc_bytes, (size_t)n_frames * n * sizeof(float2), "iq_correction scratch");
+            if (!r) r = pss_iq_correction(ctx, d_iq, n_frames, n, reinterpret_cast<float *>(ctx->scratch_iqc), nullptr);
+            d_in = reinterpret_cast<const float *>(ctx->scratch_iqc);
+        }
+        if (r) { pss_time_end(ctx); return r; }
+        r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
+        if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
+        if (r) { pss_time_end(ctx); return r; }
+        const int rd = pss_demod(ctx, mode, d_in, n_frames, n, fs, d_pcm, nullptr);   // main stream
+        int rc;
+        {
+            PssStreamScope side(ctx->cur, ctx->stream2);
+            rc = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);     // compute_fft sees the samples as read (pyspecsdr.py:2275), not the corrected ones
+            if (!rc) rc = d_thr2 ? pss_spectrum_post_thresholds(ctx, d_db, n_frames, n, d_thr2, d_row_lo + n_halo, d_row_hi + n_halo)
+                                 : pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+            if (!rc) rc = pipeline_lines(ctx, display, d_db, d_post, d_thr2, n_frames, n, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph, d_colour);
+        }
+        int rj = pss_hip_check(ctx, hipEventRecord(ctx->ev_join, ctx->stream2), "hipEventRecord(join)");
+        if (!rj) rj = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)");
+        pss_time_end(ctx);
+        return rd ? rd : (rc ? rc : rj);
+    }
     // d_post == NULL: the post-processed rows are not materialised — the post-process leaves 12 bytes per row (clamp threshold,
     // extremes) and the display kernel rebuilds the elements its cells need from the dB rows (rows of a multiple of 4 points up to
     // 32 772; other lengths go through a context-owned scratch copy of the rows)
@@ -3723,11 +3826,11 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
         if (beside_bwd) q = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
         if (d_thr) {
             if (!q) q = pss_spectrum_post_thresholds(ctx, d_db, n_frames, n, d_thr, d_row_lo + n_halo, d_row_hi + n_halo);
-            if (!q) q = pss_waterfall_rows_db(ctx, d_db, n_frames, n, d_thr, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+            if (!q) q = pipeline_lines(ctx, display, d_db, nullptr, d_thr, n_frames, n, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph, d_colour);
             return q;
         }
         if (!q) q = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
-        if (!q) q = pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
+        if (!q) q = pipeline_lines(ctx, display, d_db, d_post, nullptr, n_frames, n, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph, d_colour);
         return q;
     };
 #ifdef PSS_VARIANTS   // schedule experiments (option "pipe_sched"; the default schedule is below)
@@ -3781,6 +3884,27 @@ extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_fr
     }
     pss_time_end(ctx);
     return r;
+}
+
+extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
+                                      float *d_row_lo, float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
+                                      int8_t *d_colour, int16_t *d_pcm)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    return frame_pipeline(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, n_halo, window, 0, 0, disp_w, d_glyph,
+                          d_colour, d_pcm);
+}
+
+extern "C" int pss_frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
+                                  float *d_row_lo, float *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
+                                  int8_t *d_line_a, int8_t *d_line_b, int16_t *d_pcm)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (mode < PSS_MODE_NFM || mode > PSS_MODE_WFM) return pss_fail(ctx, PSS_E_ARG, "unknown demodulation mode");
+    return frame_pipeline(ctx, mode, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w, d_line_a,
+                          d_line_b, d_pcm);
 }
 
 extern "C" int pss_set_nfm_filters(pss_ctx *ctx, double fs, const double *taps65, const double *sos4x6, const double *zi4x2)

@@ -26,7 +26,9 @@ __device__ unsigned long long pss_dbg_stamps[4 * 4096];
 namespace fused {
 
 using namespace pss;
-constexpr unsigned gridDim_cus = 256;   // compute units of the part (MI355X): workgroup i runs on CU i mod 256 while the grid fits the machine
+// Progress balancing groups the workgroups of a launch by the compute unit they are expected to share: consecutive workgroups go to consecutive
+// CUs while the grid fits the machine, so workgroup i is taken to run on CU i mod ncu (ncu = hipDeviceProp's multiProcessorCount, a kernel
+// argument: 256 on an unpartitioned MI355X).  The grouping only steers s_setprio; a wrong guess costs balance, never results.
 
 constexpr int FC = 24;         // time steps per chunk
 constexpr int NB = 4;          // window blocks
@@ -196,7 +198,7 @@ template <bool B121, bool SWAPPED = false>
 __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y,
                                                     double *__restrict__ Uh, double *__restrict__ Utl, int n,
                                                     long n_frames, NfmCoef c, float kscale, const double *__restrict__ d_rev,
-                                                    unsigned *prog)
+                                                    unsigned *prog, unsigned ncu, unsigned epoch)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *win = reinterpret_cast<float *>(smem);                                   // [TILE][WSTR]
@@ -206,8 +208,8 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: everything indexed by the role / chunk stays scalar
     const long tile = blockIdx.x;
-    const int slot = (int)(blockIdx.x / gridDim_cus) & 3;   // which of its CU's (up to) four workgroups this one is: consecutive workgroups go to consecutive CUs
-    const int cu = (int)(blockIdx.x % gridDim_cus);
+    const int slot = (int)(blockIdx.x / ncu) & 3;   // which of its CU's (up to) four workgroups this one is: consecutive workgroups go to consecutive CUs
+    const int cu = (int)(blockIdx.x % ncu);
     const int M = n - 1;                      // FIR outputs per frame (M >= 128 guaranteed by the caller)
     const long L = (long)M + 2 * EDGE;
     const int NC = (M - HEAD + FC - 1) / FC;  // worker chunks
@@ -332,10 +334,15 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
                 // the one furthest behind issues first
                 {
                     unsigned *pc = prog + 4 * cu;
-                    if (lane == 0) __hip_atomic_store(pc + slot, (unsigned)ch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // a word = launch epoch (upper 16 bits) | chunk index + 1: what an earlier launch left behind never counts as "ahead"
+                    const unsigned mine = (epoch << 16) | (((unsigned)ch + 1u) & 0xffffu);
+                    if (lane == 0) __hip_atomic_store(pc + slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     int rank = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) rank += __hip_atomic_load(pc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)ch + 1u ? 1 : 0;
+                    for (int k = 0; k < 4; k++) {
+                        const unsigned v = __hip_atomic_load(pc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        rank += ((v >> 16) == (epoch & 0xffffu) && v > mine) ? 1 : 0;
+                    }
                     rank = __builtin_amdgcn_readfirstlane(rank);
                     if (lane == 0) *lprio = rank;
                     prio_rotate(rank);

@@ -6,6 +6,7 @@ plain HIP behind a C ABI.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -29,7 +30,16 @@ def _ptr(x):
 
 
 class Engine:
-    def __init__(self, device=0, stream=None):
+    """order: how calls are ordered against the caller's own GPU work.
+         "torch" (default when torch is loaded): the library keeps its own non-blocking stream — which the default stream does NOT
+                 synchronise with — and every device-pointer entry point is bracketed with pss_order_after / pss_order_before against
+                 torch.cuda.current_stream(): buffers the caller filled on its stream are ready before the kernels read them, and torch work
+                 queued after the call sees the results.  No host synchronisation; ~5 us per call.
+         "none":  no ordering — for pipelines that order by hand (bench.py, multi.py: events / fences around many calls); the caller must
+                 torch.cuda.synchronize() (or record / wait events on stream_handle()) between its own stream's work and the calls.
+       stream: run on this hipStream_t / torch stream instead of the library's own (ordering is then the stream's own)."""
+
+    def __init__(self, device=0, stream=None, order=None):
         self.lib = L.load()
         h = C.c_void_p()
         r = self.lib.pss_create(int(device), C.byref(h))
@@ -39,10 +49,33 @@ class Engine:
         self.device = device
         if stream is not None:
             self.set_stream(stream)
+        if order is None:
+            order = "none" if stream is not None else "torch"
+        assert order in ("torch", "none")
+        self.order = order
         # PSS_OPTIONS="key=value,key=value": pss_set_option switches for A/B measurements without touching the caller
         for kv in filter(None, os.environ.get("PSS_OPTIONS", "").split(",")):
             k, _, v = kv.partition("=")
             self.set_option(k.strip(), int(v))
+
+    def _caller_stream(self):
+        """torch's current stream on this engine's device as a hipStream_t (int), or None when there is nothing to order against."""
+        if self.order != "torch":
+            return None
+        torch = sys.modules.get("torch")
+        if torch is None or not torch.cuda.is_available() or not torch.cuda.is_initialized():
+            return None
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _dev(self, fn, *args):
+        """A device-pointer entry point, ordered after the caller's stream and the caller's stream after it (order = "torch")."""
+        cs = self._caller_stream()
+        if cs is not None:
+            self._ck(self.lib.pss_order_after(self.h, cs))
+        r = fn(self.h, *args)
+        if cs is not None:
+            self.lib.pss_order_before(self.h, cs)
+        self._ck(r)
 
     def close(self):
         if getattr(self, "h", None):
@@ -123,174 +156,193 @@ class Engine:
 
     # -- batched device entry points (asynchronous on the engine's stream)
     def spectrum_db(self, d_iq, n_frames, n_fft, d_db):
-        self._ck(self.lib.pss_spectrum_db(self.h, _ptr(d_iq), n_frames, n_fft, _ptr(d_db)))
+        self._dev(self.lib.pss_spectrum_db, _ptr(d_iq), n_frames, n_fft, _ptr(d_db))
 
     def spectrum_post(self, d_db, n_frames, n_fft, d_post):
-        self._ck(self.lib.pss_spectrum_post(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_post)))
+        self._dev(self.lib.pss_spectrum_post, _ptr(d_db), n_frames, n_fft, _ptr(d_post))
 
     def spectrum_post_extremes(self, d_db, n_frames, n_fft, d_post, d_row_lo, d_row_hi):
         """Post-process + the finite min / max of every post-processed row (inputs of waterfall_rows / persistence_rows)."""
-        self._ck(self.lib.pss_spectrum_post_extremes(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_post), _ptr(d_row_lo),
-                                                     _ptr(d_row_hi)))
+        self._dev(self.lib.pss_spectrum_post_extremes, _ptr(d_db), n_frames, n_fft, _ptr(d_post), _ptr(d_row_lo),
+                                                     _ptr(d_row_hi))
 
     def spectrum_db_post(self, d_iq, n_frames, n_fft, d_db, d_post, d_row_lo=None, d_row_hi=None):
         """compute_fft + post-process (+ row extremes) in one call; one fused kernel for 1024-point frames."""
-        self._ck(self.lib.pss_spectrum_db_post(self.h, _ptr(d_iq), n_frames, n_fft, _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
-                                               _ptr(d_row_hi)))
+        self._dev(self.lib.pss_spectrum_db_post, _ptr(d_iq), n_frames, n_fft, _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
+                                               _ptr(d_row_hi))
 
     def row_extremes(self, d_rows, n_rows, length, d_row_lo, d_row_hi, f64=False):
         fn = self.lib.pss_row_extremes_f64 if f64 else self.lib.pss_row_extremes
-        self._ck(fn(self.h, _ptr(d_rows), n_rows, length, _ptr(d_row_lo), _ptr(d_row_hi)))
+        self._dev(fn, _ptr(d_rows), n_rows, length, _ptr(d_row_lo), _ptr(d_row_hi))
 
     def waterfall_rows(self, d_post, n_frames, length, d_row_lo, d_row_hi, disp_w, d_glyph, d_colour, n_halo=0, window=30,
                        f64=False):
         """Batched waterfall accumulator: the newest display line of every frame (history of `window` rows)."""
         fn = self.lib.pss_waterfall_rows_f64 if f64 else self.lib.pss_waterfall_rows
-        self._ck(fn(self.h, _ptr(d_post), n_frames, length, _ptr(d_row_lo), _ptr(d_row_hi), n_halo, window, disp_w,
-                    _ptr(d_glyph), _ptr(d_colour)))
+        self._dev(fn, _ptr(d_post), n_frames, length, _ptr(d_row_lo), _ptr(d_row_hi), n_halo, window, disp_w,
+                    _ptr(d_glyph), _ptr(d_colour))
 
     def persistence_rows(self, d_post, n_frames, length, d_row_lo, d_row_hi, disp_h, disp_w, d_y, n_halo=0, window=10,
                          f64=False):
         """Batched persistence accumulator: the newest trace's row index per column for every frame."""
         fn = self.lib.pss_persistence_rows_f64 if f64 else self.lib.pss_persistence_rows
-        self._ck(fn(self.h, _ptr(d_post), n_frames, length, _ptr(d_row_lo), _ptr(d_row_hi), n_halo, window, disp_h, disp_w,
-                    _ptr(d_y)))
+        self._dev(fn, _ptr(d_post), n_frames, length, _ptr(d_row_lo), _ptr(d_row_hi), n_halo, window, disp_h, disp_w,
+                    _ptr(d_y))
 
     def spectrum_post_thresholds(self, d_db, n_frames, n_fft, d_row_thr, d_row_lo, d_row_hi):
         """The post-process without writing the rows: clamp threshold and finite extremes per row (inputs of *_rows_db)."""
-        self._ck(self.lib.pss_spectrum_post_thresholds(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_row_thr), _ptr(d_row_lo), _ptr(d_row_hi)))
+        self._dev(self.lib.pss_spectrum_post_thresholds, _ptr(d_db), n_frames, n_fft, _ptr(d_row_thr), _ptr(d_row_lo), _ptr(d_row_hi))
 
     def waterfall_rows_db(self, d_db, n_frames, n_fft, d_row_thr, d_row_lo, d_row_hi, disp_w, d_glyph, d_colour, n_halo=0, window=30):
         """waterfall_rows from the dB rows + clamp thresholds (the post-processed rows are never written)."""
-        self._ck(self.lib.pss_waterfall_rows_db(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_row_thr), _ptr(d_row_lo), _ptr(d_row_hi), n_halo,
-                                                window, disp_w, _ptr(d_glyph), _ptr(d_colour)))
+        self._dev(self.lib.pss_waterfall_rows_db, _ptr(d_db), n_frames, n_fft, _ptr(d_row_thr), _ptr(d_row_lo), _ptr(d_row_hi), n_halo,
+                                                window, disp_w, _ptr(d_glyph), _ptr(d_colour))
 
     def persistence_rows_db(self, d_db, n_frames, n_fft, d_row_thr, d_row_lo, d_row_hi, disp_h, disp_w, d_y, n_halo=0, window=10):
-        self._ck(self.lib.pss_persistence_rows_db(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_row_thr), _ptr(d_row_lo), _ptr(d_row_hi), n_halo,
-                                                  window, disp_h, disp_w, _ptr(d_y)))
+        self._dev(self.lib.pss_persistence_rows_db, _ptr(d_db), n_frames, n_fft, _ptr(d_row_thr), _ptr(d_row_lo), _ptr(d_row_hi), n_halo,
+                                                  window, disp_h, disp_w, _ptr(d_y))
 
     def scan(self, d_iq, n_slices, n_fft, fs, d_db, d_peak, d_bw, d_count):
-        self._ck(self.lib.pss_scan(self.h, _ptr(d_iq), n_slices, n_fft, float(fs), _ptr(d_db), _ptr(d_peak),
-                                   _ptr(d_bw), _ptr(d_count)))
+        self._dev(self.lib.pss_scan, _ptr(d_iq), n_slices, n_fft, float(fs), _ptr(d_db), _ptr(d_peak),
+                                   _ptr(d_bw), _ptr(d_count))
 
     def scan_threshold(self, d_iq, n_slices, n, fs, threshold_db, d_db=None, d_peak=None, d_bw=None, d_count=None):
         """The sweep driver's per-read numbers (pyspecsdr.py:1049-1057): max power, bins above an absolute threshold, bandwidth."""
-        self._ck(self.lib.pss_scan_threshold(self.h, _ptr(d_iq), n_slices, n, float(fs), float(threshold_db), _ptr(d_db), _ptr(d_peak),
-                                             _ptr(d_bw), _ptr(d_count)))
+        self._dev(self.lib.pss_scan_threshold, _ptr(d_iq), n_slices, n, float(fs), float(threshold_db), _ptr(d_db), _ptr(d_peak),
+                                             _ptr(d_bw), _ptr(d_count))
 
     def hilbert(self, d_x, n_rows, n, d_analytic):
         """scipy.signal.hilbert along float64 rows -> complex128 rows (n: power of two in 256..1048576)."""
-        self._ck(self.lib.pss_hilbert(self.h, _ptr(d_x), n_rows, n, _ptr(d_analytic)))
+        self._dev(self.lib.pss_hilbert, _ptr(d_x), n_rows, n, _ptr(d_analytic))
 
     def power_db(self, d_iq, n_frames, n, d_power):
-        self._ck(self.lib.pss_power_db(self.h, _ptr(d_iq), n_frames, n, _ptr(d_power)))
+        self._dev(self.lib.pss_power_db, _ptr(d_iq), n_frames, n, _ptr(d_power))
 
     def iq_correction(self, d_iq, n_frames, n, d_out_iq=None, d_raw=None):
-        self._ck(self.lib.pss_iq_correction(self.h, _ptr(d_iq), n_frames, n, _ptr(d_out_iq), _ptr(d_raw)))
+        self._dev(self.lib.pss_iq_correction, _ptr(d_iq), n_frames, n, _ptr(d_out_iq), _ptr(d_raw))
 
     def agc_steps(self, d_power, n, start_idx, n_gains, d_idx):
-        self._ck(self.lib.pss_agc_steps(self.h, _ptr(d_power), n, start_idx, n_gains, _ptr(d_idx)))
+        self._dev(self.lib.pss_agc_steps, _ptr(d_power), n, start_idx, n_gains, _ptr(d_idx))
 
     def demod(self, mode, d_iq, n_frames, n, fs, d_pcm=None, d_audio=None):
-        self._ck(self.lib.pss_demod(self.h, mode, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_pcm), _ptr(d_audio)))
+        self._dev(self.lib.pss_demod, mode, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_pcm), _ptr(d_audio))
 
     def demod_signal(self, mode, d_iq, n_frames, n, fs, d_pcm=None, d_audio=None):
         """Dispatcher semantics (demodulate_signal): WFM frames are IQ-corrected first."""
-        self._ck(self.lib.pss_demod_signal(self.h, mode, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_pcm), _ptr(d_audio)))
+        self._dev(self.lib.pss_demod_signal, mode, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_pcm), _ptr(d_audio))
 
     def wfm_filters(self, fs):
         lp, pil, lmr = np.empty((3, 6)), np.empty((5, 6)), np.empty((5, 6))
         import ctypes as C
         a = C.c_double()
-        self._ck(self.lib.pss_get_wfm_filters(self.h, float(fs), _ptr(lp), _ptr(pil), _ptr(lmr), C.addressof(a)))
+        self._dev(self.lib.pss_get_wfm_filters, float(fs), _ptr(lp), _ptr(pil), _ptr(lmr), C.addressof(a))
         return lp, pil, lmr, a.value
 
     def set_wfm_filters(self, fs, lp, pilot, lmr, alpha):
         c = lambda x: np.ascontiguousarray(x, np.float64)
         lp, pilot, lmr = c(lp), c(pilot), c(lmr)
         assert lp.shape == (3, 6) and pilot.shape == (5, 6) and lmr.shape == (5, 6)
-        self._ck(self.lib.pss_set_wfm_filters(self.h, float(fs), _ptr(lp), _ptr(pilot), _ptr(lmr), float(alpha)))
+        self._dev(self.lib.pss_set_wfm_filters, float(fs), _ptr(lp), _ptr(pilot), _ptr(lmr), float(alpha))
 
     def demod_out_len(self, mode, n, fs):
         return int(self.lib.pss_demod_out_len(mode, n, float(fs)))
 
     def spectrum_nfm(self, d_iq, n_frames, n, fs, d_db, d_pcm):
-        self._ck(self.lib.pss_spectrum_nfm(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_pcm)))
+        self._dev(self.lib.pss_spectrum_nfm, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_pcm))
 
     def frame_pipeline_nfm(self, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, disp_w, d_glyph, d_colour, d_pcm,
                            n_halo=0, window=30):
         """One main-loop iteration for a batch of read buffers: NFM -> int16, dB row, post-processed row (+ extremes),
         waterfall line (pyspecsdr.py:2262-2283 + draw_waterfall).  d_post=None: the post-processed rows are not materialised."""
-        self._ck(self.lib.pss_frame_pipeline_nfm(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
-                                                 _ptr(d_row_hi), n_halo, window, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_pcm)))
+        self._dev(self.lib.pss_frame_pipeline_nfm, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
+                                                 _ptr(d_row_hi), n_halo, window, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_pcm))
+
+    def frame_pipeline(self, mode, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, disp_w, d_line_a, d_line_b, d_pcm,
+                       n_halo=0, window=None, display="waterfall", disp_h=36):
+        """One main-loop iteration per read buffer in any demodulation mode (dispatcher semantics: WFM is IQ-corrected first) and for either
+        batched display accumulator: display "waterfall" -> (glyph, colour) lines, "persistence" -> the newest trace's row index (d_line_b
+        unused).  window defaults to the reference's history length (30 / 10)."""
+        disp = {"waterfall": 0, "persistence": 1}[display]
+        window = (30, 10)[disp] if window is None else int(window)
+        self._dev(self.lib.pss_frame_pipeline, int(mode), _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
+                                             _ptr(d_row_hi), n_halo, window, disp, disp_h, disp_w, _ptr(d_line_a), _ptr(d_line_b), _ptr(d_pcm))
 
     def frame_pipeline_nfm_f64(self, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, disp_w, d_glyph, d_colour, d_pcm,
                                n_halo=0, window=30):
         """frame_pipeline_nfm with the reference's own row type: float64 dB rows, post-processed rows and extremes; the waterfall lines
         are then the cells the reference draws from this IQ (compute_fft returns float64, signal_processing.py:243-264)."""
-        self._ck(self.lib.pss_frame_pipeline_nfm_f64(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
-                                                     _ptr(d_row_hi), n_halo, window, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_pcm)))
+        self._dev(self.lib.pss_frame_pipeline_nfm_f64, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
+                                                     _ptr(d_row_hi), n_halo, window, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_pcm))
 
     def spectrum_db_f64(self, d_iq, n_frames, n_fft, d_db):
         """compute_fft's float64 rows (n_fft: power of two in 16..65536)."""
-        self._ck(self.lib.pss_spectrum_db_f64(self.h, _ptr(d_iq), n_frames, n_fft, _ptr(d_db)))
+        self._dev(self.lib.pss_spectrum_db_f64, _ptr(d_iq), n_frames, n_fft, _ptr(d_db))
 
     def spectrum_post_f64(self, d_db, n_frames, n_fft, d_post, d_row_lo=None, d_row_hi=None):
         """The caller's smoothing + median clamp on float64 rows (pyspecsdr.py:2278-2283), optionally the rows' finite extremes."""
-        self._ck(self.lib.pss_spectrum_post_f64(self.h, _ptr(d_db), n_frames, n_fft, _ptr(d_post), _ptr(d_row_lo), _ptr(d_row_hi)))
+        self._dev(self.lib.pss_spectrum_post_f64, _ptr(d_db), n_frames, n_fft, _ptr(d_post), _ptr(d_row_lo), _ptr(d_row_hi))
 
     def waterfall_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_glyph, d_colour, f64=False):
         fn = self.lib.pss_waterfall_cells_f64 if f64 else self.lib.pss_waterfall_cells
-        self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour)))
+        self._dev(fn, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour))
 
     def spectrogram_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_glyph, d_colour, d_range=None, f64=False):
         fn = self.lib.pss_spectrogram_cells_f64 if f64 else self.lib.pss_spectrogram_cells
-        self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_range)))
+        self._dev(fn, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_range))
 
     def gradient_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_glyph, d_colour, f64=False):
         fn = self.lib.pss_gradient_cells_f64 if f64 else self.lib.pss_gradient_cells
-        self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour)))
+        self._dev(fn, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour))
 
     def surface_cells(self, d_row, length, max_h, max_w, d_colour, f64=False):
         fn = self.lib.pss_surface_cells_f64 if f64 else self.lib.pss_surface_cells
-        self._ck(fn(self.h, _ptr(d_row), length, max_h, max_w, _ptr(d_colour)))
+        self._dev(fn, _ptr(d_row), length, max_h, max_w, _ptr(d_colour))
 
     def vector_cells(self, d_iq, n, max_h, max_w, d_grid):
-        self._ck(self.lib.pss_vector_cells(self.h, _ptr(d_iq), n, max_h, max_w, _ptr(d_grid)))
+        self._dev(self.lib.pss_vector_cells, _ptr(d_iq), n, max_h, max_w, _ptr(d_grid))
 
     def morse_edges(self, d_iq, n_frames, n, cap, d_rise, d_fall, d_counts, threshold_db=-20.0):
-        self._ck(self.lib.pss_morse_edges(self.h, _ptr(d_iq), n_frames, n, float(threshold_db), cap, _ptr(d_rise), _ptr(d_fall),
-                                          _ptr(d_counts)))
+        self._dev(self.lib.pss_morse_edges, _ptr(d_iq), n_frames, n, float(threshold_db), cap, _ptr(d_rise), _ptr(d_fall),
+                                          _ptr(d_counts))
 
     def classify(self, d_iq, n_frames, n, fs, d_label=None, d_bw=None, d_mi=None, d_flat=None, d_psd=None):
         """classify_signal for a batch (pss_classify): any of label int32 / bw float64 / mi float32 / flat float32 / psd float32 [.,1024]."""
-        self._ck(self.lib.pss_classify(self.h, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_label), _ptr(d_bw), _ptr(d_mi),
-                                       _ptr(d_flat), _ptr(d_psd)))
+        self._dev(self.lib.pss_classify, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_label), _ptr(d_bw), _ptr(d_mi),
+                                       _ptr(d_flat), _ptr(d_psd))
 
     def class_name(self, label):
         return self.lib.pss_class_name(int(label)).decode()
 
     def persistence_cells(self, d_rows, n_rows, length, disp_h, disp_w, d_colour, f64=False):
         fn = self.lib.pss_persistence_cells_f64 if f64 else self.lib.pss_persistence_cells
-        self._ck(fn(self.h, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_colour)))
+        self._dev(fn, _ptr(d_rows), n_rows, length, disp_h, disp_w, _ptr(d_colour))
 
     # -- stateful display accumulators (device ring of the last rows)
     def ring_create(self, max_rows, length):
         h = C.c_void_p()
-        self._ck(self.lib.pss_ring_create(self.h, max_rows, length, C.byref(h)))
+        self._dev(self.lib.pss_ring_create, max_rows, length, C.byref(h))
         return h
+
+    def _ring(self, fn, ring, *args):
+        cs = self._caller_stream()
+        if cs is not None:
+            self._ck(self.lib.pss_order_after(self.h, cs))
+        r = fn(ring, *args)
+        if cs is not None:
+            self.lib.pss_order_before(self.h, cs)
+        self._ck(r)
 
     def ring_destroy(self, ring):
         self.lib.pss_ring_destroy(ring)
 
     def ring_push(self, ring, d_row):
-        self._ck(self.lib.pss_ring_push(ring, _ptr(d_row)))
+        self._ring(self.lib.pss_ring_push, ring, _ptr(d_row))
 
     def ring_waterfall(self, ring, disp_h, disp_w, d_glyph, d_colour):
-        self._ck(self.lib.pss_ring_waterfall(ring, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour)))
+        self._ring(self.lib.pss_ring_waterfall, ring, disp_h, disp_w, _ptr(d_glyph), _ptr(d_colour))
 
     def ring_persistence(self, ring, disp_h, disp_w, d_colour):
-        self._ck(self.lib.pss_ring_persistence(ring, disp_h, disp_w, _ptr(d_colour)))
+        self._ring(self.lib.pss_ring_persistence, ring, disp_h, disp_w, _ptr(d_colour))
 
     # -- streamed capture from host memory (chunked, double-buffered H2D / compute / D2H)
     def pinned_empty(self, shape, dtype):
@@ -426,13 +478,13 @@ class Engine:
 
     def sosfilt(self, d_x, n_rows, n, sos, d_y):
         sos = np.ascontiguousarray(sos, np.float64)
-        self._ck(self.lib.pss_sosfilt(self.h, _ptr(d_x), n_rows, n, _ptr(sos), sos.shape[0], _ptr(d_y)))
+        self._dev(self.lib.pss_sosfilt, _ptr(d_x), n_rows, n, _ptr(sos), sos.shape[0], _ptr(d_y))
 
     def afsk_bits(self, d_audio, n_rows, n, fs, d_bits, sos1200=None, sos2200=None):
         c = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)
         s1, s2 = c(sos1200), c(sos2200)
-        self._ck(self.lib.pss_afsk_bits(self.h, _ptr(d_audio), n_rows, n, float(fs), _ptr(s1), _ptr(s2),
-                                        5 if s1 is None else s1.shape[0], _ptr(d_bits)))
+        self._dev(self.lib.pss_afsk_bits, _ptr(d_audio), n_rows, n, float(fs), _ptr(s1), _ptr(s2),
+                                        5 if s1 is None else s1.shape[0], _ptr(d_bits))
 
     def h_afsk_bits(self, x, fs, sos1200=None, sos2200=None, normalise=False):
         """decode_afsk's bit list for one host buffer of real audio (float64) -> uint8 array; normalise=True divides by
@@ -450,10 +502,10 @@ class Engine:
 
     def np_f32(self, op, d_a, d_b, n, d_out):
         """NumPy's float32 arctan2 (op 0) / log10 (1) / abs of a + ib (2), element by element (pss_np_f32)."""
-        self._ck(self.lib.pss_np_f32(self.h, int(op), _ptr(d_a), _ptr(d_b), int(n), _ptr(d_out)))
+        self._dev(self.lib.pss_np_f32, int(op), _ptr(d_a), _ptr(d_b), int(n), _ptr(d_out))
 
     def row_normalise(self, d_x, n_rows, n, d_y):
-        self._ck(self.lib.pss_row_normalise(self.h, _ptr(d_x), n_rows, n, _ptr(d_y)))
+        self._dev(self.lib.pss_row_normalise, _ptr(d_x), n_rows, n, _ptr(d_y))
 
     def afsk_n_bits(self, n, fs):
         return self.lib.pss_afsk_n_bits(int(n), float(fs))

@@ -89,6 +89,7 @@ def lib():
         L.pss_o_batch_spectrum_post_nfm.argtypes = [_f32p, C.c_long, C.c_int, C.c_double, C.c_int, _f64p, _f64p, _f64p, _f32p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, _i16p, C.c_int]
         L.pss_o_waterfall_rows.argtypes = [_f32p, C.c_long, C.c_int, C.c_int, C.c_int, _i8p, _i8p, C.c_int]
+        L.pss_o_persistence_rows.argtypes = [_f32p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _i8p, C.c_int]
         _lib = L
     return _lib
 
@@ -366,3 +367,19 @@ def batch_headline(iq2d, fs, taps, sos, zi, buf, n_threads=1, window=30):
     L.pss_o_waterfall_rows(buf.post[:nf].reshape(-1), nf, n - 4, window, buf.glyph.shape[1], buf.glyph[:nf].reshape(-1),
                            buf.colour[:nf].reshape(-1), n_threads)
     return buf
+
+
+def persistence_rows(rows, window, disp_h, disp_w, n_threads=1):
+    """Newest persistence trace's row index per column for every frame (float32 post-processed rows [n_frames][len])."""
+    rows = np.ascontiguousarray(rows, np.float32)
+    y = np.empty((rows.shape[0], disp_w), np.int8)
+    lib().pss_o_persistence_rows(rows.reshape(-1), rows.shape[0], rows.shape[1], window, disp_h, disp_w, y.reshape(-1), n_threads)
+    return y
+
+
+def waterfall_rows(rows, window, disp_w, n_threads=1):
+    rows = np.ascontiguousarray(rows, np.float32)
+    g = np.empty((rows.shape[0], disp_w), np.int8)
+    c = np.empty((rows.shape[0], disp_w), np.int8)
+    lib().pss_o_waterfall_rows(rows.reshape(-1), rows.shape[0], rows.shape[1], window, disp_w, g.reshape(-1), c.reshape(-1), n_threads)
+    return g, c

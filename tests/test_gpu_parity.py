@@ -184,7 +184,6 @@ def test_post_process_select_kernel_equals_sort_kernel(n):
         try:
             d_post = G.empty((nf, n - 4), torch.float32)
             d_post.fill_(float("nan"))
-            torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own: order them
             e.spectrum_post(d_db, nf, n, d_post)
             e.sync()
             res.append(G.host(d_post))
@@ -1292,7 +1291,6 @@ def test_kernel_timing_and_filter():
     try:
         eng.spectrum_nfm(iq, nf, n, fs, db, pcm); eng.sync()
         want = (db.clone(), pcm.clone())
-        torch.cuda.synchronize()          # the clones run on torch's stream
         eng.enable_timing(True)
         eng.spectrum_nfm(iq, nf, n, fs, db, pcm); eng.sync()
         every = eng.kernel_times()
@@ -1356,6 +1354,24 @@ def test_agc(golden):
         e.agc_steps(d_p, len(g["agc_powers"]), start, n, d_idx)
         e.sync()
         assert list(G.host(d_idx)) == list(g[f"agc_traj_{start}"])
+    # long series (the stepper composes chunk maps and scans them): random walks that hit both rails, dead-band readings, NaN / inf readings,
+    # starting indices outside the table — against the oracle's sequential adjust_gain, for lengths around the kernel's chunking
+    rng = np.random.default_rng(11)
+    for length in (1, 2, 1023, 1024, 1025, 8192, 65536, 100003):
+        for ng, start in ((29, 20), (3, 1), (1, 0), (29, 40), (29, -5)):
+            p = (-30.0 + rng.choice([-40.0, -3.0, -1.5, 0.0, 1.5, 3.0, 40.0], size=length) + rng.standard_normal(length) * 0.4).astype(np.float32)
+            p[rng.integers(0, length, size=max(1, length // 500))] = rng.choice([np.nan, np.inf, -np.inf])
+            if length > 4000:
+                p[length // 3:length // 3 + 700] = -80.0          # a long climb to the top rail, then a long fall to the bottom one
+                p[length // 2:length // 2 + 900] = 20.0
+            d_idx = G.empty((length,), torch.int32)
+            e.agc_steps(G.dev(p), length, start, ng, d_idx)
+            e.sync()
+            idx, want = start, np.empty(length, np.int32)
+            for i, v in enumerate(p):
+                idx = O.agc_step(v, idx, ng)
+                want[i] = idx
+            assert np.array_equal(G.host(d_idx), want), (length, ng, start)
 
 
 @pytest.mark.parametrize("n", [2048, 4096])
@@ -1673,6 +1689,107 @@ def test_frame_pipeline_equals_separate_calls():
             assert torch.equal(c[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, k)
 
 
+@pytest.mark.parametrize("mode", [L.MODE_NFM, L.MODE_WFM, L.MODE_AM, L.MODE_USB, L.MODE_LSB])
+@pytest.mark.parametrize("display", ["waterfall", "persistence"])
+def test_frame_pipeline_modes_equal_separate_calls(mode, display):
+    """pss_frame_pipeline: the main-loop iteration (pyspecsdr.py:2262-2283 + the draw) in every mode demodulate_signal serves — WFM, the
+    reference's default (:2855), through the dispatcher's iq_correction — and for both batched accumulators, against the separate entry
+    points byte for byte; with materialised post-processed rows and without; small batches (systolic kernels) and large ones."""
+    e = G.engine()
+    gen = torch.Generator(device="cuda").manual_seed(123 + mode)
+    shapes = ((7000, 1024, 2.4e6), (40, 8192, 2.4e6)) if mode in (L.MODE_NFM, L.MODE_WFM) else ((600, 1024, 2.4e6), (33, 8192, 2.4e6), (9, 16384, 2.4e6))
+    for nf, n, fs in shapes:
+        iq = torch.randn((nf, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3 + 0.05
+        torch.cuda.synchronize()
+        n_out = e.demod_out_len(mode, n, fs)
+        H, W = 36, 112
+
+        def bufs():
+            return dict(db=G.empty((nf, n), torch.float32), post=G.empty((nf, n - 4), torch.float32), lo=G.empty((nf,), torch.float32),
+                        hi=G.empty((nf,), torch.float32), a=G.empty((nf, W), torch.int8), b=torch.zeros((nf, W), dtype=torch.int8, device="cuda"),
+                        pcm=G.empty((nf, n_out, 2), torch.int16))
+        x, y, z = bufs(), bufs(), bufs()
+        torch.cuda.synchronize()
+        e.frame_pipeline(mode, iq, nf, n, fs, x["db"], x["post"], x["lo"], x["hi"], W, x["a"], x["b"], x["pcm"], display=display, disp_h=H)
+        e.frame_pipeline(mode, iq, nf, n, fs, z["db"], None, z["lo"], z["hi"], W, z["a"], z["b"], z["pcm"], display=display, disp_h=H)
+        e.demod_signal(mode, iq, nf, n, fs, y["pcm"], None)
+        e.spectrum_db(iq, nf, n, y["db"])
+        e.spectrum_post_extremes(y["db"], nf, n, y["post"], y["lo"], y["hi"])
+        if display == "waterfall":
+            e.waterfall_rows(y["post"], nf, n - 4, y["lo"], y["hi"], W, y["a"], y["b"])
+        else:
+            e.persistence_rows(y["post"], nf, n - 4, y["lo"], y["hi"], H, W, y["a"])
+        e.sync()
+        for k in x:
+            assert torch.equal(x[k].view(torch.uint8), y[k].view(torch.uint8)), (mode, display, nf, n, k)
+            if k != "post":
+                assert torch.equal(z[k].view(torch.uint8), y[k].view(torch.uint8)), (mode, display, nf, n, k, "rows not materialised")
+    # argument errors come back as errors, before any allocation or launch (n_halo < 0, frames too short for a post-processed row)
+    from pyspecsdr_amd.engine import PssError
+    with pytest.raises(PssError):
+        e.frame_pipeline(mode, iq, 1, 1024, 2.4e6, x["db"], None, x["lo"], x["hi"], W, x["a"], x["b"], x["pcm"], n_halo=-1)
+    with pytest.raises(PssError):
+        e.frame_pipeline(mode, iq, 1, 3, 2.4e6, x["db"], None, x["lo"], x["hi"], W, x["a"], x["b"], x["pcm"])
+
+
+def test_calls_are_ordered_against_the_callers_stream_without_a_synchronize():
+    """The single-threaded call order of the reference's loop (pyspecsdr.py:2250-2283): fill a buffer, call, read the result — with the fills and
+    the reads on torch's stream and NO synchronize anywhere.  The library runs on its own non-blocking stream; Engine (order = "torch", the
+    default) brackets every device entry point with pss_order_after / pss_order_before, so each call sees the input written just before it and
+    torch sees the outputs right after it.  Two alternating inputs, 200 iterations, ten entry points; outputs pre-filled with a sentinel."""
+    e = G.engine()
+    assert e.order == "torch"
+    nf, n, fs = 768, 1024, 2.4e6
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    src = [torch.randn((nf, n, 2), generator=gen, device="cuda", dtype=torch.float32) * s + 0.01 for s in (0.3, 0.05)]
+    n_out = e.demod_out_len(L.MODE_NFM, n, fs)
+    W = 112
+
+    def outputs():
+        return dict(db=G.empty((nf, n), torch.float32), post=G.empty((nf, n - 4), torch.float32), thr=G.empty((nf,), torch.float32),
+                    lo=G.empty((nf,), torch.float32), hi=G.empty((nf,), torch.float32), g=G.empty((nf, W), torch.int8), c=G.empty((nf, W), torch.int8),
+                    pcm=G.empty((nf, n_out, 2), torch.int16), pcm_am=G.empty((nf, n, 2), torch.int16), pw=G.empty((nf,), torch.float32),
+                    sdb=G.empty((nf, n), torch.float32), spk=G.empty((nf,), torch.float32), sbw=G.empty((nf,), torch.float64),
+                    scnt=G.empty((nf,), torch.int32), corr=G.empty((nf, n, 2), torch.float32), g2=G.empty((nf, W), torch.int8),
+                    c2=G.empty((nf, W), torch.int8), pdb=G.empty((nf, n), torch.float32), plo=G.empty((nf,), torch.float32),
+                    phi=G.empty((nf,), torch.float32), ppcm=G.empty((nf, n_out, 2), torch.int16))
+
+    def run(iq, o):
+        e.spectrum_db(iq, nf, n, o["db"])
+        e.spectrum_post_extremes(o["db"], nf, n, o["post"], o["lo"], o["hi"])
+        e.spectrum_post_thresholds(o["db"], nf, n, o["thr"], o["lo"], o["hi"])
+        e.waterfall_rows(o["post"], nf, n - 4, o["lo"], o["hi"], W, o["g"], o["c"])
+        e.demod(L.MODE_NFM, iq, nf, n, fs, o["pcm"], None)
+        e.demod(L.MODE_AM, iq, nf, n, fs, o["pcm_am"], None)
+        e.power_db(iq, nf, n, o["pw"])
+        e.scan(iq, nf, n, fs, o["sdb"], o["spk"], o["sbw"], o["scnt"])
+        e.iq_correction(iq, nf, n, o["corr"], None)
+        e.frame_pipeline_nfm(iq, nf, n, fs, o["pdb"], None, o["plo"], o["phi"], W, o["g2"], o["c2"], o["ppcm"])
+
+    want = []
+    for k in range(2):                       # expected outputs, produced with full synchronisation
+        o = outputs()
+        torch.cuda.synchronize()
+        run(src[k], o)
+        e.sync()
+        torch.cuda.synchronize()
+        want.append({key: v.clone() for key, v in o.items()})
+    torch.cuda.synchronize()
+    iq, o = torch.empty_like(src[0]), outputs()
+    keys = list(o)
+    mism = torch.zeros((200, len(keys)), dtype=torch.int32, device="cuda")     # filled on the device: no host round trip inside the loop
+    for it in range(200):
+        k = it & 1
+        iq.copy_(src[k])                     # torch's stream, straight before the calls
+        for v in o.values():
+            v.fill_(0x55 if v.dtype in (torch.int8, torch.int16, torch.int32) else 1.0e30)
+        run(iq, o)
+        for j, key in enumerate(keys):       # torch's stream again, no e.sync(): the comparison kernels must see the results
+            mism[it, j] = (o[key].view(torch.uint8) != want[k][key].view(torch.uint8)).any()
+    bad = [(int(a), keys[int(b)]) for a, b in mism.nonzero().cpu().numpy()]
+    assert not bad, bad[:10]
+
+
 def test_full_size_headline_properties():
     """BASELINE.json cfg 2 size (65 536 x 1024) through pss_frame_pipeline_nfm — the call bench.py times: size-independent properties
     of every output (dB rows, post-processed rows, waterfall lines, PCM), an oracle spot check, and the variant that does not
@@ -1682,7 +1799,6 @@ def test_full_size_headline_properties():
     gen = torch.Generator(device="cuda").manual_seed(1234)
     base = torch.randn((512, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3
     iq = base.repeat(nf // 512, 1, 1).contiguous()            # every block of 512 frames repeats
-    torch.cuda.synchronize()                                  # torch's stream produced iq; the library runs on its own stream
     d_db, d_post = G.empty((nf, n), torch.float32), G.empty((nf, n - 4), torch.float32)
     d_lo, d_hi = G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
     d_g, d_c = G.empty((nf, W), torch.int8), G.empty((nf, W), torch.int8)
@@ -1778,7 +1894,6 @@ def test_display_lines_without_materialised_rows(n):
     lo, hi = G.empty((halo + nf,), torch.float32), G.empty((halo + nf,), torch.float32)
     lo[:halo] = torch.tensor(rng.uniform(-60, -50, halo).astype(np.float32)); hi[:halo] = torch.tensor(rng.uniform(-20, -5, halo).astype(np.float32))
     lo2, hi2 = lo.clone(), hi.clone()
-    torch.cuda.synchronize()              # torch's stream wrote lo / hi and their clones; the library runs on its own stream
     d_post, d_thr = G.empty((nf, n - 4), torch.float32), G.empty((nf,), torch.float32)
     e.spectrum_post_extremes(d_db, nf, n, d_post, lo[halo:], hi[halo:])
     e.spectrum_post_thresholds(d_db, nf, n, d_thr, lo2[halo:], hi2[halo:])

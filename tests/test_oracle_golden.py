@@ -204,6 +204,29 @@ def test_waterfall_and_persistence(golden):
         assert np.array_equal(O.persistence_cells(ring, dh, dw), g["ps_colour"][i]), i
 
 
+def test_batched_accumulator_rows_are_the_newest_line_of_the_pinned_grids(golden):
+    """pss_o_waterfall_rows / pss_o_persistence_rows (the checkers of the batched display calls, float32 rows) against the grid functions the
+    test above pins to the reference's own draws: waterfall line y = 0; persistence: the newest trace's cells — its colour is unique once the
+    history is full (int(1 + 5 (1 - 0.7)) = 2), so the cells holding it are exactly (y[x], x)."""
+    g = golden["caller"]
+    rows = np.ascontiguousarray(g["rows"].astype(np.float32))
+    H, W = [int(v) for v in g["hw"]]
+    dh, dw = H - 4, W - 8
+    gl, co = O.waterfall_rows(rows, 30, dw)
+    ys = O.persistence_rows(rows, 10, dh, dw)
+    for i in range(len(rows)):
+        g2, c2 = O.waterfall_cells(rows[max(0, i + 1 - 30):i + 1].astype(np.float64), dh, dw)
+        assert np.array_equal(gl[i], g2[0]) and np.array_equal(co[i], c2[0]), i
+        ring = rows[max(0, i + 1 - 10):i + 1].astype(np.float64)
+        cells = O.persistence_cells(ring, dh, dw)
+        cp_new = int(1 + 5 * (1 - 0.7 ** (10 - (len(ring) - 1))))
+        assert np.all(ys[i] >= 0) and np.all(cells[ys[i], np.arange(dw)] == cp_new), i
+        if len(ring) == 10:
+            want = np.zeros_like(cells, dtype=bool)
+            want[ys[i], np.arange(dw)] = True
+            assert np.array_equal(cells == cp_new, want), i
+
+
 def test_reference_cells_from_iq(golden):
     """caller_iq.npz: the read buffers behind caller.npz's rows.  compute_fft -> smoothing + clamp -> draw_waterfall, the oracle from IQ
     to cells: the float64 rows agree with the reference's to rounding (the transform is not pocketfft's), the cells are equal."""

@@ -1,171 +1,448 @@
 #!/usr/bin/env python3
-"""Time the library on the other BASELINE.json configs (device-resident inputs, HIP-event kernel times).
+"""The other BASELINE.json configs on one GPU: timed, priced against the HBM roof and verified against the CPU oracle.
 
-    python tools/bench_configs.py [cfg3] [cfg4] [cfg5] [cfg5stream] [big] [wfm]
+bench.py imports other_configs() and prints its result as the "other_configs" object of its one JSON line (after the headline's timed
+region, never inside it); standalone:
+
+    python tools/bench_configs.py [cfg3] [cfg4] [cfg5_resident] [cfg5_streamed] [wfm_step] [--no-verify] [--launch-only]
+
+Per config (SURVEY.md §8(d) for the shapes, the synthetic inputs and the algorithmic bytes):
+    ms            wall time of one pass of the config's calls (host clock between stream fences, mean of `reps` passes, events off)
+    kernel_ms     mean launch duration of every kernel of a pass (HIP events on the library's stream, a second set of passes)
+    algo_bytes    ALGORITHMIC bytes of a pass (inputs read once + outputs written once), frac = algo_bytes / ms / 8 TB/s
+    traffic_bytes HBM bytes of a pass from the committed rocprofv3 counter digest (profiles/hbm_traffic.json "configs", FETCH_SIZE x 2 +
+                  WRITE_SIZE) and traffic_ratio = traffic / algo — only when the digest was taken from this source tree (src_hash), else null
+    verified      a few frames of the pass's outputs against the CPU oracle (oracle/pss_oracle.c — the checker, outside every timed region)
+cfg5_streamed is PCIe-bound: its fraction is H2D bytes per second against this box's measured pinned-memory copy rate.
 """
+import ctypes as C
 import json
-import sys
 import os
+import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
 from pyspecsdr_amd import _lib as L
-from pyspecsdr_amd.engine import Engine
 
-dev = torch.device("cuda", 0)
-eng = Engine(0)
-
-
-def rand_iq(nf, n, scale=0.3):
-    g = torch.Generator(device=dev).manual_seed(7)
-    return (torch.randn((nf, n, 2), generator=g, device=dev, dtype=torch.float32) * scale + 0.2).contiguous()
+HBM_PEAK = 8.0e12
+DISP_H, DISP_W = 36, 112
 
 
-def timed(name, fn, reps=5):
-    fn(); eng.sync(); torch.cuda.synchronize()
-    eng.enable_timing(True)
+# ---- synthetic inputs, generated on the device in chunks ------------------------------------------------------------------
+def _audio(t, ph0):
+    return (0.5 * torch.sin(2 * np.pi * 400 * t + ph0) + 0.3 * torch.sin(2 * np.pi * 1000 * t + 2 * ph0)
+            + 0.2 * torch.sin(2 * np.pi * 2500 * t + 3 * ph0))
+
+
+def synth(kind, nf, n, fs, dev, seed, chunk=2048):
+    """kind: "fm" (5 kHz deviation, A = 0.5, sigma = 0.02), "am" ((1 + 0.5 m) 0.5 e^{j0.3} + noise), "ssb" (m shifted by +1.5 kHz),
+    "scan" (noise at sigma = 0.01, tones at hashed bins, every 8th slice a 200 kHz-wide FM carrier).  float32 [nf][n][2]."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    iq = torch.empty((nf, n, 2), device=dev, dtype=torch.float32)
+    t = torch.arange(n, device=dev, dtype=torch.float64) / fs
+    for f0 in range(0, nf, chunk):
+        f1 = min(nf, f0 + chunk)
+        idx = torch.arange(f0, f1, device=dev, dtype=torch.float64).unsqueeze(1)
+        ph0 = 0.1 * idx
+        if kind == "fm":
+            ph = 2 * np.pi * 5e3 * torch.cumsum(_audio(t, ph0), dim=1) / fs + ph0
+            re, im, sg = 0.5 * torch.cos(ph), 0.5 * torch.sin(ph), 0.02
+        elif kind == "am":
+            a = (1 + 0.5 * _audio(t, ph0)) * 0.5
+            re, im, sg = a * np.cos(0.3), a * np.sin(0.3), 0.02
+        elif kind == "ssb":
+            re = sum(A * torch.cos(2 * np.pi * (f + 1500.0) * t + k * ph0) for k, (A, f) in enumerate(((0.5, 400), (0.3, 1000), (0.2, 2500)), 1)) * 0.5
+            im = sum(A * torch.sin(2 * np.pi * (f + 1500.0) * t + k * ph0) for k, (A, f) in enumerate(((0.5, 400), (0.3, 1000), (0.2, 2500)), 1)) * 0.5
+            sg = 0.02
+        else:  # scan
+            h = (idx.long() * 2654435761) & 0xFFFFFFFF
+            b1, b2 = (h % n).double() - n / 2, ((h >> 11) % n).double() - n / 2
+            k = torch.arange(n, device=dev, dtype=torch.float64)
+            re = 0.3 * torch.cos(2 * np.pi * b1 * k / n) + 0.05 * torch.cos(2 * np.pi * b2 * k / n)
+            im = 0.3 * torch.sin(2 * np.pi * b1 * k / n) + 0.05 * torch.sin(2 * np.pi * b2 * k / n)
+            wide = ((idx.long() % 8) == 0).double()
+            ph = 2 * np.pi * 75e3 * torch.cumsum(_audio(t * 40, ph0), dim=1) / fs
+            re, im, sg = re + wide * 0.4 * torch.cos(ph), im + wide * 0.4 * torch.sin(ph), 0.01
+        iq[f0:f1, :, 0] = re.float()
+        iq[f0:f1, :, 1] = im.float()
+        iq[f0:f1] += sg * torch.randn((f1 - f0, n, 2), generator=g, device=dev, dtype=torch.float32)
+    return iq
+
+
+# ---- timing ----------------------------------------------------------------------------------------------------------------------------
+def _fence(eng):
+    eng.sync()
+    torch.cuda.synchronize()
+
+
+def timed(eng, fn, reps, launch_only=False):
+    """-> (ms per pass with events off, {kernel: mean ms per launch, launches per pass})."""
+    fn(); _fence(eng)
+    if launch_only:       # under rocprofv3: a few plain passes, nothing else
+        fn(); _fence(eng)
+        return None, {}
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
-    eng.sync(); torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / reps
-    kt = {k: round(sum(v) / len(v), 4) for k, v in eng.kernel_times().items()}
+    _fence(eng)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    eng.enable_timing(True)
+    eng.kernel_times()
+    kreps = max(2, min(reps, 5))
+    for _ in range(kreps):
+        fn()
+    _fence(eng)
+    kt = {k: {"ms": round(sum(v) / len(v), 4), "launches": len(v) // kreps} for k, v in eng.kernel_times().items()}
     eng.enable_timing(False)
-    return {"call": name, "wall_ms": round(wall * 1e3, 4), "kernel_ms": kt}
+    return ms, kt
 
 
-def cfg3():
-    nf, n, fs = 8192, 16384, 2.4e6
-    iq = rand_iq(nf, n)
+def source_hash():
+    """sha256 over the kernel sources (the same rule as bench.py's): profiles are only quoted next to the binary they were taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pyspecsdr_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _digest(config):
+    """Counter traffic of one pass of `config` from the committed digest, or (None, note)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        if t.get("src_hash") != source_hash():
+            return None, f"profiles/hbm_traffic.json is from source {t.get('src_hash')}, this tree is {source_hash()}"
+        c = t.get("configs", {}).get(config)
+        if not c:
+            return None, "no counter pass for this config in the digest"
+        return c, t.get("profile")
+    except Exception as ex:  # noqa: BLE001
+        return None, f"no digest ({type(ex).__name__})"
+
+
+def _entry(config, workload, ms, kt, algo_bytes, samples, verified, extra=None):
+    e = {"workload": workload, "ms": None if ms is None else round(ms, 4), "kernel_ms": kt, "algo_bytes": algo_bytes}
+    if ms:
+        e["samples_per_s"] = samples / (ms * 1e-3)
+        e["achieved_GBs"] = algo_bytes / (ms * 1e-3) / 1e9
+        e["frac"] = algo_bytes / (ms * 1e-3) / HBM_PEAK
+    d, note = _digest(config)
+    e["traffic_bytes"] = d["traffic_bytes"] if d else None
+    e["traffic_ratio"] = (d["traffic_bytes"] / algo_bytes) if d else None
+    if d and d.get("kernels"):
+        e["traffic_by_kernel"] = d["kernels"]
+    e["profile"] = note
+    e["verified"] = verified
+    if extra:
+        e.update(extra)
+    return e
+
+
+def _rel(got, ref):
+    return float(np.max(np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1.0)))
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    return O
+
+
+def _host_iq(iq, k):
+    return iq[k].cpu().numpy().view(np.complex64).reshape(-1)
+
+
+# ---- configs ---------------------------------------------------------------------------------------------------------------------------
+def cfg3(eng, dev, verify=True, launch_only=False, nf=8192):
+    """BASELINE configs[2]: 16 384-point spectra x 8192 frames, AM + SSB (Hilbert) demodulation, AGC on (power per frame + stepper)."""
+    n, fs = 16384, 2.4e6
+    iq_am = synth("am", nf, n, fs, dev, 20260928 + 3)
+    iq_ssb = synth("ssb", nf, n, fs, dev, 20260928 + 13)
     db = torch.empty((nf, n), dtype=torch.float32, device=dev)
-    pcm = torch.empty((nf, n, 2), dtype=torch.int16, device=dev)
+    pcm_am = torch.empty((nf, n, 2), dtype=torch.int16, device=dev)
+    pcm_usb = torch.empty((nf, n, 2), dtype=torch.int16, device=dev)
     pw = torch.empty((nf,), dtype=torch.float32, device=dev)
-    out = [timed("spectrum_db 16384", lambda: eng.spectrum_db(iq, nf, n, db)),
-           timed("demod AM", lambda: eng.demod(L.MODE_AM, iq, nf, n, fs, pcm, None)),
-           timed("demod USB", lambda: eng.demod(L.MODE_USB, iq, nf, n, fs, pcm, None)),
-           timed("power_db", lambda: eng.power_db(iq, nf, n, pw))]
-    tot = sum(o["wall_ms"] for o in out)
-    return {"config": "cfg3 8192 x 16384 AM+SSB+power+spectrum", "calls": out, "samples_per_s": nf * n / (tot * 1e-3)}
+    gi = torch.empty((nf,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def one():
+        eng.power_db(iq_am, nf, n, pw)                    # measure_signal_power (pyspecsdr.py:2251) ...
+        eng.agc_steps(pw, nf, 20, 29, gi)                 # ... and the gain stepper (:898-919), interval gate off
+        eng.demod(L.MODE_AM, iq_am, nf, n, fs, pcm_am, None)
+        eng.demod(L.MODE_USB, iq_ssb, nf, n, fs, pcm_usb, None)
+        eng.spectrum_db(iq_am, nf, n, db)                 # compute_fft (:2275)
+    ms, kt = timed(eng, one, 5, launch_only)
+    ver = None
+    if verify and not launch_only:
+        O = _oracle()
+        sos = np.empty((5, 6))
+        eng.lib.pss_am_bandpass_sos(sos.ctypes.data)
+        taps = eng.ssb_taps(fs)
+        frames = sorted({0, nf // 2 + 1, nf - 1})
+        ver = {"frames": frames, "db_max_rel": 0.0, "am_pcm_equal": True, "usb_pcm_equal": True, "power_bits_equal": True}
+        h_pw = pw.cpu().numpy()
+        for k in frames:
+            x, y = _host_iq(iq_am, k), _host_iq(iq_ssb, k)
+            ver["db_max_rel"] = max(ver["db_max_rel"], _rel(db[k].cpu().numpy(), O.compute_fft(x)))
+            ver["am_pcm_equal"] &= bool(np.array_equal(pcm_am[k].cpu().numpy(), O.pcm16_stereo(O.demod_am(x, sos))))
+            ver["usb_pcm_equal"] &= bool(np.array_equal(pcm_usb[k].cpu().numpy(), O.pcm16_stereo(O.demod_ssb(y, taps))))
+            ver["power_bits_equal"] &= bool(h_pw[k].tobytes() == np.float32(O.power_db(x)).tobytes())
+        idx, traj = 20, []
+        for p in h_pw:
+            idx = O.agc_step(p, idx, 29)
+            traj.append(idx)
+        ver["agc_trajectory_equal"] = bool(np.array_equal(gi.cpu().numpy(), np.array(traj, np.int32)))
+        ver["ok"] = bool(ver["db_max_rel"] <= 1e-4 and ver["am_pcm_equal"] and ver["usb_pcm_equal"] and ver["power_bits_equal"]
+                         and ver["agc_trajectory_equal"])
+    # 131 072 IQ + 65 536 dB + 2 x 65 536 PCM + 4 power per frame (the second IQ batch of the SSB leg is the same 131 072
+    # bytes the table counts once: both demodulators are fed their own modulation here, so it is counted too)
+    algo = nf * (2 * n * 8 + n * 4 + 2 * n * 4 + 4 + 4)
+    return _entry("cfg3", f"{nf} frames x {n}-pt @2.4 MS/s: measure_signal_power + AGC steps, demodulate AM, demodulate USB (hilbert round "
+                  f"trip executed) -> int16 stereo, compute_fft dB rows (BASELINE.json configs[2])", ms, kt, algo, nf * n, ver)
 
 
-def cfg4():
-    ns, n, fs = 8192, 4096, 2.4e6
-    iq = rand_iq(ns, n)
+def cfg4(eng, dev, verify=True, launch_only=False, ns=8192):
+    """BASELINE configs[3] on one GPU: 8192 scanner slices x 4096 points (pyspecsdr.py:2539-2552), exact float32 rows."""
+    n, fs = 4096, 2.4e6
+    iq = synth("scan", ns, n, fs, dev, 20260928 + 4)
     db = torch.empty((ns, n), dtype=torch.float32, device=dev)
     pk = torch.empty((ns,), dtype=torch.float32, device=dev)
     bw = torch.empty((ns,), dtype=torch.float64, device=dev)
     cnt = torch.empty((ns,), dtype=torch.int32, device=dev)
-    o = timed("scan 4096", lambda: eng.scan(iq, ns, n, fs, db, pk, bw, cnt), reps=20)
-    ms = list(o["kernel_ms"].values())[0]
-    return {"config": "cfg4 8192 slices x 4096 scanner", "calls": [o], "samples_per_s": ns * n / (o["wall_ms"] * 1e-3),
-            "hbm_GBs": ns * (n * 8 + n * 4 + 16) / (ms * 1e-3) / 1e9}
+    torch.cuda.synchronize()
+    ms, kt = timed(eng, lambda: eng.scan(iq, ns, n, fs, db, pk, bw, cnt), 20, launch_only)
+    ver = None
+    if verify and not launch_only:
+        O = _oracle()
+        frames = sorted({0, 8, ns // 2 + 3, ns - 1})
+        ver = {"slices": frames, "db_values": 0, "db_values_differing": 0, "db_max_ulp": 0, "peak_bits_equal": True, "count_equal": True,
+               "bandwidth_equal": True}
+        for k in frames:
+            odb, opk, obw, ocnt = O.scan_slice(_host_iq(iq, k), fs)
+            g = db[k].cpu().numpy()
+            ulp = np.abs(g.view(np.int32).astype(np.int64) - odb.view(np.int32).astype(np.int64))
+            ver["db_values"] += n
+            ver["db_values_differing"] += int((ulp != 0).sum())
+            ver["db_max_ulp"] = max(ver["db_max_ulp"], int(ulp.max()))
+            ver["peak_bits_equal"] &= bool(pk[k].cpu().numpy().tobytes() == np.float32(opk).tobytes())
+            ver["count_equal"] &= bool(int(cnt[k]) == ocnt)
+            ver["bandwidth_equal"] &= bool(float(bw[k]) == obw)
+        # two float64 transforms agree to ~1e-16 of the largest bin: a weak bin beside a strong carrier may round the other way
+        ver["ok"] = bool(ver["db_max_ulp"] <= 2 and ver["db_values_differing"] <= 4 and ver["peak_bits_equal"] and ver["count_equal"]
+                         and ver["bandwidth_equal"])
+    algo = ns * (n * 8 + n * 4 + 16)
+    return _entry("cfg4", f"{ns} slices x {n}-pt: unwindowed fft, float32 dB row (the reference's bits), peak, 20-dB-down count, bandwidth "
+                  f"(BASELINE.json configs[3], one GPU's whole sweep)", ms, kt, algo, ns * n, ver)
 
 
-def cfg5():
-    nf, n, fs = 48828, 2048, 10e6
-    iq = rand_iq(nf, n)
+def _check_nfm_display(O, eng, iq, n, fs, db, ya, pcm, nf, window, blocks, mode):
+    """dB rows, PCM and the display lines of blocks of consecutive frames against the oracle (lines: the oracle's quantiser on the rows the
+    device produced, history complete inside the block except for the block that starts at frame 0)."""
+    taps, sos, zi = eng.nfm_filters(fs)
+    m = n - 4
+    res = {"blocks": blocks, "db_max_rel": 0.0, "pcm_equal": True, "lines_equal": True, "lines_checked": 0}
+    for s0, s1 in blocks:
+        g_db = db[s0:s1].cpu().numpy()
+        for k in (s0, s1 - 1):
+            x = _host_iq(iq, k)
+            res["db_max_rel"] = max(res["db_max_rel"], _rel(g_db[k - s0], O.compute_fft(x)))
+            res["pcm_equal"] &= bool(np.array_equal(pcm[k].cpu().numpy(), O.pcm16_stereo(O.demod_nfm(x, fs, taps, sos, zi))))
+        d64 = g_db.astype(np.float64)
+        acc = d64[:, 0:m] * 0.2
+        for k in range(1, 5):
+            acc = acc + d64[:, k:k + m] * 0.2
+        sm = acc.astype(np.float32)
+        srt = np.sort(sm, axis=1)
+        med = 0.5 * (srt[:, (m - 1) // 2].astype(np.float64) + srt[:, m // 2].astype(np.float64))
+        post = np.ascontiguousarray(np.maximum(sm, (med - 10.0).astype(np.float32)[:, None]))
+        first = 0 if s0 == 0 else window - 1
+        if mode == "persistence":
+            want = O.persistence_rows(post, window, DISP_H, DISP_W)
+            res["lines_equal"] &= bool(np.array_equal(ya[s0:s1].cpu().numpy()[first:], want[first:]))
+        else:
+            wg, wc = O.waterfall_rows(post, window, DISP_W)
+            res["lines_equal"] &= bool(np.array_equal(ya[0][s0:s1].cpu().numpy()[first:], wg[first:])
+                                       and np.array_equal(ya[1][s0:s1].cpu().numpy()[first:], wc[first:]))
+        res["lines_checked"] += (s1 - s0) - first
+    res["ok"] = bool(res["db_max_rel"] <= 1e-4 and res["pcm_equal"] and res["lines_equal"])
+    return res
+
+
+def cfg5_resident(eng, dev, verify=True, launch_only=False, nf=48828):
+    """BASELINE configs[4] with the capture resident in HBM: 10 s @ 10 MS/s as 48 828 frames x 2048, per frame dB row, persistence
+    accumulator trace (history 10), NFM -> int16 stereo."""
+    n, fs, window = 2048, 10e6, 10
+    iq = synth("fm", nf, n, fs, dev, 20260928 + 5)
+    n_out = eng.demod_out_len(L.MODE_NFM, n, fs)
     db = torch.empty((nf, n), dtype=torch.float32, device=dev)
-    post = torch.empty((nf, n - 4), dtype=torch.float32, device=dev)
-    n_out = eng.demod_out_len(L.MODE_NFM, n, fs)
+    lo, hi = torch.empty((nf,), dtype=torch.float32, device=dev), torch.empty((nf,), dtype=torch.float32, device=dev)
+    y = torch.empty((nf, DISP_W), dtype=torch.int8, device=dev)
     pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
-    out = [timed("spectrum_nfm 2048 @10MS/s", lambda: eng.spectrum_nfm(iq, nf, n, fs, db, pcm)),
-           timed("spectrum_post 2048", lambda: eng.spectrum_post(db, nf, n, post))]
-    return {"config": "cfg5 48828 x 2048 @10 MS/s (device-resident)", "calls": out,
-            "samples_per_s": nf * n / (out[0]["wall_ms"] * 1e-3)}
+    torch.cuda.synchronize()
+    ms, kt = timed(eng, lambda: eng.frame_pipeline(L.MODE_NFM, iq, nf, n, fs, db, None, lo, hi, DISP_W, y, None, pcm, window=window,
+                                                   display="persistence", disp_h=DISP_H), 8, launch_only)
+    ver = None
+    if verify and not launch_only:
+        blk = window + 10
+        blocks = [[s, s + blk] for s in sorted({0, nf // 2 - 3, nf - blk})]
+        ver = _check_nfm_display(_oracle(), eng, iq, n, fs, db, y, pcm, nf, window, blocks, "persistence")
+    algo = nf * (n * 8 + n * 4 + n_out * 4 + DISP_W)
+    return _entry("cfg5_resident", f"{nf} frames x {n}-pt @10 MS/s resident in HBM, every frame: compute_fft dB row + post-process + persistence "
+                  f"trace (history {window}) + NFM -> int16 stereo (BASELINE.json configs[4] without the upload)", ms, kt, algo, nf * n, ver)
 
 
-def cfg5stream():
-    """10 s @ 10 MS/s capture in pinned host memory -> chunked H2D / compute / D2H (PCIe-inclusive rate)."""
-    nf, n, fs = 48828, 2048, 10e6
+def cfg5_streamed(eng, dev, verify=True, launch_only=False, nf=48828, chunk=4096):
+    """BASELINE configs[4]: the capture in pinned host memory, chunked hipMemcpyAsync upload double-buffered against compute and download;
+    per frame the persistence trace + PCM come back.  PCIe-bound: priced against this box's measured pinned H2D copy rate."""
+    n, fs, window = 2048, 10e6, 10
+    d_iq = synth("fm", nf, n, fs, dev, 20260928 + 5)
     h_iq = eng.pinned_empty((nf, n), np.complex64)
-    rng = np.random.default_rng(3)
-    h_iq.view(np.float32)[:] = rng.standard_normal((nf, 2 * n), dtype=np.float32) * 0.3
+    torch.from_numpy(h_iq.view(np.float32).reshape(nf, n, 2)).copy_(d_iq)
+    torch.cuda.synchronize()
     n_out = eng.demod_out_len(L.MODE_NFM, n, fs)
-    h_db = eng.pinned_empty((nf, n), np.float32)
-    h_pcm = eng.pinned_empty((nf, n_out, 2), np.int16)
-    res = []
-    for chunk, with_db in ((4096, True), (4096, False), (1024, True), (16384, True)):
-        eng.stream_spectrum_nfm(h_iq, fs, chunk, h_db if with_db else None, h_pcm)
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            eng.stream_spectrum_nfm(h_iq, fs, chunk, h_db if with_db else None, h_pcm)
-        dt = (time.perf_counter() - t0) / reps
-        res.append({"chunk_frames": chunk, "dB_rows_downloaded": with_db, "wall_ms": round(dt * 1e3, 2),
-                    "samples_per_s": nf * n / dt, "h2d_GBs": nf * n * 8 / dt / 1e9})
-    # the same capture through the display pipeline: per frame a waterfall line + PCM come back (BASELINE configs[4])
-    outp = {"lines": (eng.pinned_empty((nf, 112), np.int8), eng.pinned_empty((nf, 112), np.int8)), "pcm": h_pcm,
+    outp = {"lines": (eng.pinned_empty((nf, DISP_W), np.int8),), "pcm": eng.pinned_empty((nf, n_out, 2), np.int16),
             "row_lo": eng.pinned_empty((nf,), np.float32), "row_hi": eng.pinned_empty((nf,), np.float32)}
-    for chunk in (4096, 8192, 16384):
-        eng.stream_display_nfm(h_iq, fs, chunk, out=outp)
+
+    def one():
+        eng.stream_display_nfm(h_iq, fs, chunk, mode="persistence", window=window, disp_h=DISP_H, disp_w=DISP_W, out=outp)
+    one()
+    ms = None
+    if not launch_only:
         t0 = time.perf_counter()
         for _ in range(3):
-            eng.stream_display_nfm(h_iq, fs, chunk, out=outp)
-        dt = (time.perf_counter() - t0) / 3
-        res.append({"call": "stream_display_nfm", "chunk_frames": chunk, "wall_ms": round(dt * 1e3, 2), "samples_per_s": nf * n / dt,
-                    "h2d_GBs": nf * n * 8 / dt / 1e9})
-    return {"config": "cfg5 streamed: 48828 x 2048 @10 MS/s from pinned host memory", "runs": res}
-
-
-def big():
-    out = []
-    for n, nf in ((32768, 2048), (65536, 256), (1 << 20, 8)):
-        iq = rand_iq(nf, n)
+            one()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+    # the link: a plain pinned -> device copy of the same bytes on torch's stream
+    link = None
+    if not launch_only:
+        src = torch.from_numpy(h_iq.view(np.float32).reshape(-1))
+        dst = torch.empty_like(d_iq).view(-1)
+        dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        link = nf * n * 8 / ((time.perf_counter() - t0) / 3) / 1e9
+        del dst
+    ver = None
+    if verify and not launch_only:
+        # the resident pipeline on the same frames must give the same bytes; its outputs are oracle-checked in cfg5_resident
         db = torch.empty((nf, n), dtype=torch.float32, device=dev)
-        out.append(timed(f"spectrum_db {n} x{nf}", lambda: eng.spectrum_db(iq, nf, n, db), reps=2))
-    n, nf, fs = 32768, 4096, 2.4e6
-    iq = rand_iq(nf, n)
-    n_out = eng.demod_out_len(L.MODE_NFM, n, fs)
-    pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
-    out.append(timed("demod NFM 32768 x4096", lambda: eng.demod(L.MODE_NFM, iq, nf, n, fs, pcm, None), reps=2))
-    return {"config": "reference-default buffer sizes", "calls": out}
+        lo, hi = torch.empty((nf,), dtype=torch.float32, device=dev), torch.empty((nf,), dtype=torch.float32, device=dev)
+        y = torch.empty((nf, DISP_W), dtype=torch.int8, device=dev)
+        pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        eng.frame_pipeline(L.MODE_NFM, d_iq, nf, n, fs, db, None, lo, hi, DISP_W, y, None, pcm, window=window, display="persistence", disp_h=DISP_H)
+        eng.sync()
+        ver = {"lines_equal_resident": bool(np.array_equal(outp["lines"][0], y.cpu().numpy())),
+               "pcm_equal_resident": bool(np.array_equal(outp["pcm"], pcm.cpu().numpy())),
+               "extremes_equal_resident": bool(np.array_equal(outp["row_lo"], lo.cpu().numpy()) and np.array_equal(outp["row_hi"], hi.cpu().numpy()))}
+        O = _oracle()
+        taps, sos, zi = eng.nfm_filters(fs)
+        ks = sorted({0, chunk - 1, chunk, nf - 1})
+        ver["pcm_equal_oracle"] = bool(all(np.array_equal(outp["pcm"][k], O.pcm16_stereo(O.demod_nfm(h_iq[k], fs, taps, sos, zi))) for k in ks))
+        ver["frames"] = ks
+        ver["ok"] = bool(ver["lines_equal_resident"] and ver["pcm_equal_resident"] and ver["extremes_equal_resident"] and ver["pcm_equal_oracle"])
+    for a in (h_iq, outp["lines"][0], outp["pcm"], outp["row_lo"], outp["row_hi"]):
+        eng.pinned_free(a)
+    algo = nf * (n * 8 + n * 4 + n_out * 4 + DISP_W)
+    e = _entry("cfg5_streamed", f"10 s @ 10 MS/s capture ({nf} frames x {n}-pt) in pinned host memory -> chunks of {chunk} frames, hipMemcpyAsync "
+               f"double-buffered (three streams, two buffer sets): persistence trace + NFM int16 per frame back in host memory "
+               f"(BASELINE.json configs[4])", ms, {}, algo, nf * n, ver)
+    if ms:
+        e["h2d_GBs"] = nf * n * 8 / (ms * 1e-3) / 1e9
+        e["link_h2d_GBs"] = link
+        e["frac_of_link"] = e["h2d_GBs"] / link if link else None
+        e["bound"] = "pcie"
+        e["note"] = "PCIe-inclusive: never the headline value; frac = algorithmic HBM bytes / wall / 8 TB/s is reported for uniformity only"
+    return e
 
 
-def wfm():
-    """The reference's default mode (pyspecsdr.py --demod WFM): iq_correction + demodulate_wfm, cfg2-sized batch."""
-    nf, n, fs = 65536, 1024, 2.4e6
-    iq = rand_iq(nf, n)
+def wfm_step(eng, dev, verify=True, launch_only=False, nf=65536):
+    """The headline step in the reference's DEFAULT mode (--demod WFM, pyspecsdr.py:2855): iq_correction + demodulate_wfm -> int16 stereo,
+    compute_fft dB row, post-process, waterfall line — pss_frame_pipeline(PSS_MODE_WFM) at cfg-2 size."""
+    n, fs, window = 1024, 2.4e6, 30
+    iq = synth("fm", nf, n, fs, dev, 20260928 + 6)
     n_out = eng.demod_out_len(L.MODE_WFM, n, fs)
-    pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
-    corr = torch.empty((nf, n, 2), dtype=torch.float32, device=dev)
-    out = [timed("iq_correction 1024", lambda: eng.iq_correction(iq, nf, n, corr, None)),
-           timed("demod_signal WFM", lambda: eng.demod_signal(L.MODE_WFM, iq, nf, n, fs, pcm, None), reps=3)]
-    return {"config": "WFM 65536 x 1024 @2.4 MS/s (device-resident)", "calls": out,
-            "samples_per_s": nf * n / (out[1]["wall_ms"] * 1e-3)}
-
-
-def classify():
-    """classify_signal over a scanner sweep: cfg-4-sized slices (8192 x 4096) and the reference's own dwell (64 x 240 000)."""
-    out = []
-    for nf, n in ((8192, 4096), (64, 240000)):
-        iq = rand_iq(nf, n)
-        lab = torch.empty((nf,), dtype=torch.int32, device=dev)
-        bw = torch.empty((nf,), dtype=torch.float64, device=dev)
-        mi = torch.empty((nf,), dtype=torch.float32, device=dev)
-        fl = torch.empty((nf,), dtype=torch.float32, device=dev)
-        out.append(timed(f"classify {n} x{nf}", lambda: eng.classify(iq, nf, n, 2.4e6, lab, bw, mi, fl, None), reps=3))
-    return {"config": "classify_signal (Welch PSD + modulation index + flatness + label)", "calls": out}
-
-
-def sweep():
-    """The sweep driver's reads (pyspecsdr.py:1022-1093): 0.1 s dwells of 240 000 samples — not a power of two, i.e. the Bluestein
-    path — spectrum rows + max power + bins above a threshold, and classify_signal on the same reads."""
-    nf, n = 64, 240000
-    iq = rand_iq(nf, n)
     db = torch.empty((nf, n), dtype=torch.float32, device=dev)
-    pk = torch.empty((nf,), dtype=torch.float32, device=dev)
-    bw = torch.empty((nf,), dtype=torch.float64, device=dev)
-    cnt = torch.empty((nf,), dtype=torch.int32, device=dev)
-    out = [timed(f"scan_threshold {n} x{nf}", lambda: eng.scan_threshold(iq, nf, n, 2.4e6, -10.0, db, pk, bw, cnt), reps=3),
-           timed(f"spectrum_db (Hamming) {n} x{nf}", lambda: eng.spectrum_db(iq, nf, n, db), reps=3)]
-    return {"config": "sweep driver reads, 64 x 240000 (Bluestein, M = 2^19)", "calls": out,
-            "samples_per_s": nf * n / (out[0]["wall_ms"] * 1e-3)}
+    lo, hi = torch.empty((nf,), dtype=torch.float32, device=dev), torch.empty((nf,), dtype=torch.float32, device=dev)
+    gl, co = torch.empty((nf, DISP_W), dtype=torch.int8, device=dev), torch.empty((nf, DISP_W), dtype=torch.int8, device=dev)
+    pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    ms, kt = timed(eng, lambda: eng.frame_pipeline(L.MODE_WFM, iq, nf, n, fs, db, None, lo, hi, DISP_W, gl, co, pcm, window=window), 8, launch_only)
+    ver = None
+    if verify and not launch_only:
+        O = _oracle()
+        lp, pil, lmr, alpha = eng.wfm_filters(fs)
+        _, sos, zi = eng.nfm_filters(fs)
+        filt = dict(lp_sos=lp, pilot_sos=pil, lmr_sos=lmr, alpha=alpha, dec_sos=sos, dec_zi=zi)
+        blk = window + 10
+        blocks = [[s, s + blk] for s in sorted({0, nf // 2 - 3, nf - blk})]
+        ver = {"blocks": blocks, "db_max_rel": 0.0, "pcm_equal": True, "lines_equal": True}
+        m = n - 4
+        for s0, s1 in blocks:
+            g_db = db[s0:s1].cpu().numpy()
+            for k in (s0, s1 - 1):
+                x = _host_iq(iq, k)
+                ver["db_max_rel"] = max(ver["db_max_rel"], _rel(g_db[k - s0], O.compute_fft(x)))
+                a = O.demod_wfm(O.iq_correction(x), fs, filt)
+                ver["pcm_equal"] &= bool(np.array_equal(pcm[k].cpu().numpy(), np.int16(a * 32767)))
+            d64 = g_db.astype(np.float64)
+            acc = d64[:, 0:m] * 0.2
+            for k in range(1, 5):
+                acc = acc + d64[:, k:k + m] * 0.2
+            sm = acc.astype(np.float32)
+            srt = np.sort(sm, axis=1)
+            med = 0.5 * (srt[:, (m - 1) // 2].astype(np.float64) + srt[:, m // 2].astype(np.float64))
+            post = np.ascontiguousarray(np.maximum(sm, (med - 10.0).astype(np.float32)[:, None]))
+            wg, wc = O.waterfall_rows(post, window, DISP_W)
+            first = 0 if s0 == 0 else window - 1
+            ver["lines_equal"] &= bool(np.array_equal(gl[s0:s1].cpu().numpy()[first:], wg[first:]) and np.array_equal(co[s0:s1].cpu().numpy()[first:], wc[first:]))
+        ver["ok"] = bool(ver["db_max_rel"] <= 1e-4 and ver["pcm_equal"] and ver["lines_equal"])
+    algo = nf * (n * 8 + n * 4 + n_out * 4 + 2 * DISP_W)
+    return _entry("wfm_step", f"{nf} frames x {n}-pt @2.4 MS/s, every frame: demodulate_signal(WFM) = iq_correction + demodulate_wfm -> int16 stereo, "
+                  f"compute_fft dB row + post-process + waterfall line (the cfg-2 step in the reference's default mode)", ms, kt, algo, nf * n, ver)
+
+
+CONFIGS = {"cfg3": cfg3, "cfg4": cfg4, "cfg5_resident": cfg5_resident, "cfg5_streamed": cfg5_streamed, "wfm_step": wfm_step}
+
+
+def other_configs(eng, dev, verify=True, which=None, launch_only=False, small=False):
+    """-> {config: entry}.  small: a fraction of every batch (CPU-less smoke of the code path on a GPU box with little time)."""
+    out = {}
+    for name in (which or list(CONFIGS)):
+        kw = {}
+        if small:
+            kw = {"cfg3": {"nf": 256}, "cfg4": {"ns": 512}, "cfg5_resident": {"nf": 4100}, "cfg5_streamed": {"nf": 4100, "chunk": 1024},
+                  "wfm_step": {"nf": 8192}}[name]
+        t0 = time.perf_counter()
+        try:
+            out[name] = CONFIGS[name](eng, dev, verify=verify, launch_only=launch_only, **kw)
+        except Exception as ex:  # noqa: BLE001  (a failing config must not take the headline line with it)
+            out[name] = {"error": f"{type(ex).__name__}: {ex}", "verified": {"ok": False}}
+        out[name]["bench_wall_s"] = round(time.perf_counter() - t0, 2)
+        torch.cuda.empty_cache()
+    return out
+
+
+def all_verified(oc):
+    return all((e.get("verified") or {}).get("ok", False) for e in oc.values())
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5"]
-    for w in which:
-        print(json.dumps(globals()[w]()), flush=True)
+    from pyspecsdr_amd.engine import Engine
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    dev = torch.device("cuda", 0)
+    eng = Engine(0, order="none")
+    res = other_configs(eng, dev, verify="--no-verify" not in sys.argv, which=args or None, launch_only="--launch-only" in sys.argv,
+                        small="--small" in sys.argv)
+    print(json.dumps(res), flush=True)
+    if "--no-verify" not in sys.argv and "--launch-only" not in sys.argv and not all_verified(res):
+        sys.exit(3)

@@ -93,7 +93,7 @@ def main():
 
     from pyspecsdr_amd.engine import Engine
     from pyspecsdr_amd.multi import ShardedScanner
-    eng = Engine(local_rank)
+    eng = Engine(local_rank, order="none")   # this script orders its streams by hand (fences, events)
     fs, n = 2.4e6, args.n_fft
 
     def fence():
