@@ -89,6 +89,7 @@ struct pss_ctx {
     long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~12000)
     long wfm_small_batch_max = 6000;  // option "wfm_small_batch_max" (crossover with the fused kernels, 1024-sample frames: ~12000 frames in round 2, ~6000 since the small-batch path is one array: 0.58 / 1.13 ms at 4096 / 8192 frames against 0.83)
     bool hilbert_exact = false;   // option "hilbert_exact": scipy.signal.hilbert bit for bit (pocketfft's butterfly order, pss_hilbert_pf.h) for rows of 256..1048576 samples
+    bool ssb_rfft = true;      // option "ssb_rfft": frames of 8192 / 16384 samples evaluate hilbert() as a real transform pair (k_ssb_rfft); 0: two full-length complex transforms (k_ssb_hilbert_xl)
     bool ssb_hilbert = true;   // option "ssb_hilbert": run the reference's hilbert() round trip inside demodulate_ssb where a register transform exists for the frame length
     bool db_exact = false;         // true: compute_fft's dB rows evaluated to float64 accuracy and rounded once (= float32 of the reference's float64 rows); false: float32 evaluation, 1-2 ulp off, 15-25 % faster kernels
     bool scan_exact = true;        // scanner slices: NumPy's float32 chain bit for bit (scan_db_np); false: the float64 / hardware-log2 dB of compute_fft

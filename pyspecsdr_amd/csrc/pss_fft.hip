@@ -1378,7 +1378,12 @@ int pss_ssb_hilbert_fused(pss_ctx *ctx, const float *d_iq, long n_rows, int n, c
         pss_kernel_end(ctx);
         return pss_hip_check(ctx, hipGetLastError(), "k_ssb_hilbert launch");
     };
-    return n == 8192 ? go(pss_hil::k_ssb_hilbert_xl<1>, pss_xl::CfgX<1>::LDS, 512, 512) : go(pss_hil::k_ssb_hilbert_xl<2>, pss_xl::CfgX<2>::LDS, 1024, 256);
+    if (ctx->ssb_rfft) {
+        // hilbert() as a real transform pair (k_ssb_rfft): two half-length transforms, 256 / 512 threads per frame, 4 / 2 frames resident per CU
+        const long ncu = ctx->n_cus > 0 ? ctx->n_cus : 256;
+        return n == 8192 ? go(pss_hil::k_ssb_rfft<0>, pss_xl::CfgX<0>::LDS, 256, 4 * ncu) : go(pss_hil::k_ssb_rfft<1>, pss_xl::CfgX<1>::LDS, 512, 2 * ncu);
+    }
+    return n == 8192 ? go(pss_hil::k_ssb_hilbert_xl<1>, pss_hil::SsbLay<1>::LDS, 512, 512) : go(pss_hil::k_ssb_hilbert_xl<2>, pss_hil::SsbLay<2>::LDS, 1024, 256);
 }
 
 extern "C" int pss_hilbert(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_analytic)

@@ -202,18 +202,26 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_hilbert_xl(const double *x
     }
 }
 
-// ---- demodulate_ssb in ONE kernel for frames of 8192 / 16 384 samples (round 3) ---------------------------------------------------
+// ---- demodulate_ssb in ONE kernel for frames of 8192 / 16 384 samples (round 3; LDS plan of round 4) -------------------------------
 // signal_processing.py:203-216: z = lfilter(taps, 1, x) (complex 65-tap FIR: scipy -> np.convolve -> cblas_zdotu, of which only the
 // real part survives :205), hilbert(real(z)), its real part, / max|.| * 0.95, int16.  k_ssb_fir used to write real(z) as float64
 // (1.07 GB at cfg 3) for k_hilbert_xl to read straight back; here the FIR runs inside the transform kernel:
-//   1. the frame's I samples (taps and window are real: Q never reaches the real part) are staged as float64 in the exchange buffer,
-//      element i at i + i / 16 (rows of 16 + one pad: a thread's window of consecutive elements is conflict-free at a lane stride of 17);
-//   2. thread t computes its 16 CONSECUTIVE outputs 16 t .. 16 t + 15, two at a time, in the accumulation order of OpenBLAS's
+//   1. the frame's I samples (taps and window are real: Q never reaches the real part) are staged in LDS AS THE FLOAT32 THEY ARE, element i
+//      at i + i / 16 (rows of 16 + one pad: a thread's window of consecutive elements is conflict-free at a lane stride of 17) — half the
+//      bytes of the float64 staging of round 3, which leaves room beside it for half of the outputs (below);
+//   2. thread t computes its 16 CONSECUTIVE outputs 16 t .. 16 t + 15, four at a time, in the accumulation order of OpenBLAS's
 //      zdot_microk_haswell (8 accumulators (a, p) per output over 8 steps of 8 elements: element j = 8 it + 2 a + p; the pairs
 //      (acc[0] + acc[1]) + (acc[2] + acc[3]) per p; c0 + c1; fma(x[i], tap[0], .)) — k_ssb_fir's tree bit for bit — with the taps as
-//      scalar operands (kernarg) and a sliding window of 9 inputs per step; the 64 outputs whose windows are shorter than 65 taps
-//      (their own zdot shapes) by the lanes of wavefront 0 with the predicated per-lane tree (zdot_re_skx_lane, as k_ssb_edge);
-//   3. the outputs go back into the (now free) staging area and are re-read in the transform's input layout x[t + T q].
+//      scalar operands (kernarg); a window element is read and converted to float64 ONCE per pass and feeds every accumulator that
+//      takes it in that step (an accumulator's own sequence of fused multiply-adds is what the tree fixes, not the order between
+//      accumulators); the 64 outputs whose windows are shorter than 65 taps (their own zdot shapes) by the lanes of wavefront 0 with
+//      the predicated per-lane tree (zdot_re_skx_lane, as k_ssb_edge);
+//   3. outputs 0..7 of a thread go straight into region A of the exchange buffer (beside the staged samples: nothing is held in
+//      registers for them), outputs 8..15 wait in 16 VGPRs for the barrier behind the last window read and then take region B, the
+//      dead staging area; both regions hold a thread's 8 doubles at 9 t + c (conflict-free 8-byte stores), and the transform's input
+//      layout x[t + T q] reads them back with one lane address per region.
+// Round 3's form (float64 staging, all 16 outputs in registers through the barrier, eleven converted window elements live per step)
+// needed 166 / 184 VGPRs on a budget of 128: 38 / 56 spilled, 148 / 220 bytes of scratch per lane, 2.5 x the algorithmic HBM bytes.
 // From there on k_hilbert_xl<LOG_R4, 2>: forward transform, one-sided mask, inverse transform, frame peak, normalisation, PCM.
 struct SsbTaps {
     double rev[72];   // rev[j] = taps[64 - j] (65 taps, zeros behind them)
@@ -223,16 +231,29 @@ struct SsbTaps {
 __device__ __forceinline__ int pad17(int i) { return i + (i >> 4); }
 
 template <int LOG_R4>
+struct SsbLay {
+    using C = pss_xl::CfgX<LOG_R4>;
+    static constexpr int T = C::T, N = C::N;
+    static constexpr int FLT = N + N / 16;                 // float32 slots of the staged samples
+    static constexpr int HALF = 9 * T;                     // doubles of one output region: thread t's 8 outputs at 9 t + c
+    static constexpr int A0 = HALF + 16;                   // region A (doubles from the buffer's start); region B = [0, HALF)
+    static_assert((size_t)FLT * 4 <= (size_t)HALF * 8, "region B covers the staged samples it replaces");
+    static constexpr int EXD = (A0 + HALF > C::EXD) ? A0 + HALF : C::EXD;
+    static constexpr size_t LDS = (size_t)EXD * sizeof(double);
+};
+
+template <int LOG_R4>
 __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_hilbert_xl(const float2 *__restrict__ iq, double *out, const double2 *__restrict__ tw,
                                                                      long n_rows, unsigned *__restrict__ pcm, SsbTaps taps)
 {
     __shared__ double red[2][16];
     __shared__ double ltaps[72];
     using C = pss_xl::CfgX<LOG_R4>;
+    using LY = SsbLay<LOG_R4>;
     constexpr int T = C::T, N = C::N, T2 = C::T2, R4 = C::R4;
-    static_assert(N + N / 16 <= C::EXD, "the padded staging area must fit the exchange buffer");
     extern __shared__ __align__(16) unsigned char smem[];
     double *ex = reinterpret_cast<double *>(smem);
+    float *exf = reinterpret_cast<float *>(smem);
     const int t = threadIdx.x;
     const double2 w1 = tw[t], w2 = tw[(size_t)(t % T2) * 16], w3 = tw[(size_t)(t % R4) * 256];
     if (t < 72) ltaps[t] = taps.fwd[t];
@@ -241,82 +262,88 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_hilbert_xl(const float
         const __amdgpu_buffer_rsrc_t rx = pss_xl::make_rsrc(iq + (size_t)f * N, N * 8);
         const __amdgpu_buffer_rsrc_t ro = pss_xl::make_rsrc(out + (out ? (size_t)f * N : 0), out ? N * 8 : 0);
         const __amdgpu_buffer_rsrc_t rp = pss_xl::make_rsrc(pcm + (pcm ? (size_t)f * N : 0), pcm ? N * 4 : 0);
-        // (tt: the thread index behind an opaque statement per frame — with the plain index the compiler computes the ~200 per-lane LDS
-        // addresses of the staging accesses, the windows and the edge tree once, ahead of the frame loop, and spills them: 196 VGPRs)
+        // (tt: the thread index behind an opaque statement per frame — with the plain index the compiler computes the per-lane LDS addresses
+        // of the staging accesses, the windows and the edge tree once, ahead of the frame loop, and spills them)
         int tt = t;
         asm volatile("" : "+v"(tt));
         // element t + T q of the frame sits at pad17(t) + q (T + T / 16): one lane address, the rest immediate offsets
-        double *sb = ex + pad17(tt);
+        float *sb = exf + pad17(tt);
         constexpr int QS = T + T / 16;
         // 1. stage the in-phase samples
         __syncthreads();                          // the previous frame's last exchange is done with the buffer
 #pragma unroll
-        for (int q = 0; q < 16; q++) sb[q * QS] = (double)pss_xl::buf_load_f2(rx, tt * 8, T * q * 8).x;
+        for (int q = 0; q < 16; q++) sb[q * QS] = pss_xl::buf_load_f2(rx, tt * 8, T * q * 8).x;
         __syncthreads();
         // 2. the FIR: outputs 16 t + c, c = 0..15 (threads 0..3 own the left edge: wavefront 0's lanes compute it below)
-        double o16[16];
+        double o8[8];                              // outputs 8..15 (region B is still the staging area)
+        double *pa = ex + LY::A0 + 9 * tt;         // this thread's 8 slots of region A
         if (t >= 4) {
-            const double *xw = ex + 17 * (tt - 4);   // x[16 t - 64 + e] at xw[e + (e >> 4)]
-            // four outputs per pass (c = 4 g .. 4 g + 3), a ROLLED loop (unrolled, the scheduler interleaved the passes and spilled 194
-            // VGPRs).  The FIR is LDS-bandwidth-bound: B outputs per pass read (16 / B) 8 (B + 7) window elements per thread — 576 at
-            // B = 2 (measured: the fused kernel no faster than k_ssb_fir + k_hilbert_xl), 352 at B = 4 (32 accumulators: the register
-            // budget's limit beside the 16 finished outputs).  o16[] stays in registers without run-time indexing: every finished output
-            // shifts it down by one and takes the last slot.
-#pragma unroll 1
+            const float *xw = exf + 17 * (tt - 4);   // x[16 t - 64 + e] at xw[e + (e >> 4)]
+            // four outputs per pass (c = 4 g .. 4 g + 3): 32 accumulators.  The passes are unrolled (every window address is the lane base
+            // + an immediate) and fenced from each other: interleaved by the scheduler they would need four sets of accumulators.
+#pragma unroll
             for (int g = 0; g < 4; g++) {
                 int z = 0;
                 asm volatile("" : "+s"(z));         // opaque zero: the taps are re-read per pass, not hoisted into 130 loop-invariant SGPRs
                 double acc[4][4][2];
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
-                    double xs[11];
 #pragma unroll
-                    for (int e = 0; e < 11; e++) { const int k = 4 * g + 8 * it + e; xs[e] = xw[k + (k >> 4)]; }
+                    for (int e = 0; e < 11; e++) {
+                        const int k = 4 * g + 8 * it + e;
+                        const double xv = (double)xw[k + (k >> 4)];
 #pragma unroll
-                    for (int a = 0; a < 4; a++)
+                        for (int a = 0; a < 4; a++)
 #pragma unroll
-                        for (int pp = 0; pp < 2; pp++) {
-                            const double y = taps.rev[z + 8 * it + 2 * a + pp];
-#pragma unroll
-                            for (int o = 0; o < 4; o++)
-                                acc[o][a][pp] = __fma_rn(xs[o + 2 * a + pp], y, it == 0 ? 0.0 : acc[o][a][pp]);
-                        }
+                            for (int pp = 0; pp < 2; pp++) {
+                                const int o = e - 2 * a - pp;
+                                if (o >= 0 && o < 4)
+                                    acc[o][a][pp] = __fma_rn(xv, taps.rev[z + 8 * it + 2 * a + pp], it == 0 ? 0.0 : acc[o][a][pp]);
+                            }
+                    }
                 }
-                const int k64 = 4 * g + 64;
                 const double y64 = taps.rev[z + 64];
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
                     const double c0 = __dadd_rn(__dadd_rn(acc[o][0][0], acc[o][1][0]), __dadd_rn(acc[o][2][0], acc[o][3][0]));
                     const double c1 = __dadd_rn(__dadd_rn(acc[o][0][1], acc[o][1][1]), __dadd_rn(acc[o][2][1], acc[o][3][1]));
-                    const int k = k64 + o;
-                    const double r = __fma_rn(xw[k + (k >> 4)], y64, __dadd_rn(c0, c1));
-#pragma unroll
-                    for (int c = 0; c < 15; c++) o16[c] = o16[c + 1];      // after sixteen shifts o16[c] = output 16 t + c
-                    o16[15] = r;
+                    const int k = 4 * g + 64 + o;
+                    const double r = __fma_rn((double)xw[k + (k >> 4)], y64, __dadd_rn(c0, c1));
+                    if (g < 2) pa[4 * g + o] = r;
+                    else o8[4 * (g - 2) + o] = r;
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         double edge = 0.0;
-        if (t < 64) edge = pss::zdot_re_skx_lane([&](int j) { return ex[pad17(j)]; }, [&](int j) { return ltaps[tt - j]; }, tt + 1);   // (tt: the tree's predicates stay inside the loop)
-        __syncthreads();                          // every window has been read: the staging area takes the outputs
+        if (t < 64) {
+            edge = pss::zdot_re_skx_lane([&](int j) { return (double)exf[pad17(j)]; }, [&](int j) { return ltaps[tt - j]; }, tt + 1);   // (tt: the tree's predicates stay inside the loop)
+            if ((tt & 15) < 8) ex[LY::A0 + 9 * (tt >> 4) + (tt & 15)] = edge;      // element tt = output (tt & 15) of thread tt >> 4
+        }
+        __syncthreads();                          // every window has been read: the staging area becomes region B
         if (t >= 4) {
 #pragma unroll
-            for (int c = 0; c < 16; c++) ex[17 * tt + c] = o16[c];      // pad17(16 t + c) = 17 t + c
+            for (int c = 0; c < 8; c++) ex[9 * tt + c] = o8[c];
         }
-        if (t < 64) sb[0] = edge;
+        if (t < 64 && (tt & 15) >= 8) ex[9 * (tt >> 4) + (tt & 15) - 8] = edge;
         __syncthreads();
         double2 u1 = w1, u2 = w2, u3 = w3;
         asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
         double2 v[16], y[16];
+        {
+            // element t + T q: output (t & 15) of thread (t >> 4) + (T / 16) q — one region and one lane address per thread
+            const double *src = ex + ((tt & 8) ? 0 : LY::A0) + 9 * (tt >> 4) + (tt & 7);
+            const double *src_hi = src + 9 * (T / 16) * 8;      // q >= 8 (beyond the offset field's reach from src at N = 16384)
 #pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = make_double2(sb[q * QS], 0.0);
+            for (int q = 0; q < 16; q++) v[q] = make_double2((q < 8 ? src : src_hi)[9 * (T / 16) * (q & 7)], 0.0);
+        }
         __syncthreads();                          // ... before the first exchange writes into the buffer
-        pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int, int j, int k, double2 X) { y[j + (16 / R4) * k] = X; });
+        pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, tt, [&](int, int j, int k, double2 X) { y[j + (16 / R4) * k] = X; });
 #pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = mask_conj(y[q], q, t);
+        for (int q = 0; q < 16; q++) v[q] = mask_conj(y[q], q, tt);
         asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
         double m = 0.0;
-        pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, t, [&](int, int j, int k, double2 W) {
+        pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, tt, [&](int, int j, int k, double2 W) {
             const int q = j + (16 / R4) * k;
             const double re = W.x * INV_N;
             y[q].x = re;
@@ -335,6 +362,203 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_hilbert_xl(const float
             pss_xl::v2u_t pk = {(unsigned)__double2loint(a), (unsigned)__double2hiint(a)};
             __builtin_amdgcn_raw_buffer_store_b64(pk, ro, t * 8, T * q * 8, 0);       // out == NULL: zero-sized resource, dropped
             __builtin_amdgcn_raw_buffer_store_b32(pcm_pair(a), rp, t * 4, T * q * 4, 0);
+        }
+    }
+}
+
+
+// ---- demodulate_ssb in one kernel, hilbert() evaluated as a REAL transform pair (round 4) ------------------------------------------------
+// hilbert(r) of a real row r of N samples is fft -> one-sided mask -> ifft, and demodulate_ssb keeps the real part (signal_processing.py:205-213).
+// Both transforms are evaluated here the way real-input FFTs are (pocketfft's r2c does the same for scipy): with z[m] = r[2m] + i r[2m+1] and
+// Z = FFT_M(z), M = N / 2,
+//     E[k] = (Z[k] + conj Z[M-k]) / 2,   O[k] = (Z[k] - conj Z[M-k]) / 2i,   X[k] = E[k] + W_N^k O[k],   conj X[M-k] = E[k] - W_N^k O[k]
+// is the spectrum of r; the analytic signal's spectrum is Y = h X (h = 1, 2 .. 2, 1, 0 .. 0), and the REAL part of ifft(Y) is the inverse real
+// transform of its Hermitian part H[k] = (Y[k] + conj Y[N-k]) / 2 (= X[k]: the mask doubles, the Hermitian part halves — both exact):
+//     Z'[k] = (H[k] + conj H[M-k]) / 2 + i (H[k] - conj H[M-k]) / 2 conj W_N^k,   z' = IFFT_M(Z'),   real(hilbert(r))[2m], [2m+1] = Re, Im z'[m].
+// Two M-point transforms instead of two N-point ones: half the butterflies and half the exchange traffic, and — what matters most — a frame of
+// 16 384 samples is a workgroup of 512 threads with 70 KB of LDS, so TWO frames are resident per CU and one's LDS / HBM phases run under the
+// other's arithmetic (the N-point form is one 1024-thread workgroup per CU whose phases can only follow each other: DESIGN.md §4).
+// The pair (k, M - k) lives in threads t and T - t: one component-wise exchange fetches the partner, the rest is local to a thread.
+//   1. the frame's I samples are staged in LDS as float32, unpadded (element i at i);
+//   2. thread t computes the FIR outputs 2 (t + T q), 2 (t + T q) + 1, q < 16 — exactly its transform inputs z[t + T q], so the FIR output
+//      never passes through LDS — a pair at a time in zdot_microk_haswell's order (k_ssb_fir's tree bit for bit; 16 accumulators), the pair's
+//      66-element window by 33 conflict-free 8-byte reads; the 64 outputs with shorter windows (z[0..31]: q = 0, t < 32) by the predicated
+//      per-lane tree;
+//   3. FFT_M, partner exchange + the algebra above, FFT_M on the conjugate, frame peak, normalisation, float64 audio + int16 PCM.
+__device__ __forceinline__ double2 rf_cq(int q)     // exp(-2 pi i q / 32) = W_N^(T q), N = 32 T
+{
+    constexpr double tab[16][2] = {
+        {1.0, -0.0},
+        {0.9807852804032304, -0.19509032201612825},
+        {0.9238795325112867, -0.3826834323650898},
+        {0.8314696123025452, -0.5555702330196022},
+        {0.7071067811865476, -0.7071067811865475},
+        {0.5555702330196023, -0.8314696123025452},
+        {0.38268343236508984, -0.9238795325112867},
+        {0.19509032201612833, -0.9807852804032304},
+        {6.123233995736766e-17, -1.0},
+        {-0.1950903220161282, -0.9807852804032304},
+        {-0.3826834323650897, -0.9238795325112867},
+        {-0.555570233019602, -0.8314696123025455},
+        {-0.7071067811865475, -0.7071067811865476},
+        {-0.8314696123025453, -0.5555702330196022},
+        {-0.9238795325112867, -0.3826834323650899},
+        {-0.9807852804032304, -0.1950903220161286}};
+    return make_double2(tab[q][0], tab[q][1]);
+}
+
+template <int LOG_R4>   // of the M-point transform: M = 4096 << LOG_R4, frames of N = 2 M samples
+__global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_rfft(const float2 *__restrict__ iq, double *out, const double2 *__restrict__ tw,
+                                                               long n_rows, unsigned *__restrict__ pcm, SsbTaps taps)
+{
+    __shared__ double red[2][8];
+    __shared__ double ltaps[72];
+    using C = pss_xl::CfgX<LOG_R4>;
+    constexpr int T = C::T, M = C::N, N = 2 * M, T2 = C::T2, R4 = C::R4;
+    static_assert((size_t)N * 4 <= C::LDS && 16 * T + 1 <= C::EXD, "staged samples and the partner exchange fit the exchange buffer");
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *ex = reinterpret_cast<double *>(smem);
+    float *exf = reinterpret_cast<float *>(smem);
+    const int t = threadIdx.x;
+    // tw = exp(-2 pi i k / N), k < N: the M-point transform's bases are its even entries
+    const double2 w1 = tw[2 * t], w2 = tw[(size_t)(t % T2) * 32], w3 = tw[(size_t)(t % R4) * 512];
+    const double2 wn0 = tw[t];                               // W_N^t
+    if (t < 72) ltaps[t] = taps.fwd[t];
+    constexpr double INV_M = 1.0 / (double)M;
+    for (long f = blockIdx.x; f < n_rows; f += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t rx = pss_xl::make_rsrc(iq + (size_t)f * N, N * 8);
+        const __amdgpu_buffer_rsrc_t ro = pss_xl::make_rsrc(out + (out ? (size_t)f * N : 0), out ? N * 8 : 0);
+        const __amdgpu_buffer_rsrc_t rp = pss_xl::make_rsrc(pcm + (pcm ? (size_t)f * N : 0), pcm ? N * 4 : 0);
+        int tt = t;
+        asm volatile("" : "+v"(tt));              // per-lane addresses are recomputed per frame, not hoisted out of the loop and spilled
+        // 1. stage the in-phase samples (the first four bytes of every complex64)
+        __syncthreads();                          // the previous frame's last exchange is done with the buffer
+#pragma unroll
+        for (int q = 0; q < 32; q++) exf[tt + T * q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, tt * 8, T * q * 8, 0));
+        __syncthreads();
+        // 2. the FIR, straight into the transform's input registers: v[q] = (r[2 (t + T q)], r[2 (t + T q) + 1])
+        double2 v[16];
+#pragma unroll 1
+        for (int g = 0; g < 4; g++) {
+            int z = 0;
+            asm volatile("" : "+s"(z));           // opaque zero: the taps are re-read per group, not hoisted into 130 loop-invariant SGPRs
+            const float *xg = exf + 2 * tt - 64 + 8 * T * g;          // window of the group's first pair: r[2 (t + 4 T g) - 64 ..]
+            double2 r4[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // (q = 0, t < 32: the window starts before the frame — those 64 outputs are the edge tree's below; read in bounds)
+                const float *xp = (i == 0) ? ((g == 0 && tt < 32) ? exf : xg) : xg + 2 * T * i;
+                double acc[2][4][2];
+                float2 nx = *reinterpret_cast<const float2 *>(xp);
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const float2 p0 = nx, p1 = *reinterpret_cast<const float2 *>(xp + 8 * it + 2), p2 = *reinterpret_cast<const float2 *>(xp + 8 * it + 4),
+                                 p3 = *reinterpret_cast<const float2 *>(xp + 8 * it + 6);
+                    nx = *reinterpret_cast<const float2 *>(xp + 8 * it + 8);
+                    const double xs[9] = {(double)p0.x, (double)p0.y, (double)p1.x, (double)p1.y, (double)p2.x,
+                                          (double)p2.y, (double)p3.x, (double)p3.y, (double)nx.x};
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int pp = 0; pp < 2; pp++) {
+                            const double y = taps.rev[z + 8 * it + 2 * a + pp];
+                            acc[0][a][pp] = __fma_rn(xs[2 * a + pp], y, it == 0 ? 0.0 : acc[0][a][pp]);
+                            acc[1][a][pp] = __fma_rn(xs[2 * a + pp + 1], y, it == 0 ? 0.0 : acc[1][a][pp]);
+                        }
+                }
+                const double y64 = taps.rev[z + 64];
+                double r[2];
+#pragma unroll
+                for (int o = 0; o < 2; o++) {
+                    const double c0 = __dadd_rn(__dadd_rn(acc[o][0][0], acc[o][1][0]), __dadd_rn(acc[o][2][0], acc[o][3][0]));
+                    const double c1 = __dadd_rn(__dadd_rn(acc[o][0][1], acc[o][1][1]), __dadd_rn(acc[o][2][1], acc[o][3][1]));
+                    r[o] = __fma_rn((double)(o ? nx.y : nx.x), y64, __dadd_rn(c0, c1));
+                }
+                r4[i] = make_double2(r[0], r[1]);
+            }
+            // v[] without run-time indexing: every group shifts it down by four and takes the last four slots
+#pragma unroll
+            for (int c = 0; c < 12; c++) v[c] = v[c + 4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[12 + i] = r4[i];
+        }
+        if (t < 32) {   // the left edge: outputs 2 t and 2 t + 1 of 2 t + 1 and 2 t + 2 terms (their own zdot shapes)
+            const int i0 = 2 * tt;
+            v[0].x = pss::zdot_re_skx_lane([&](int j) { return (double)exf[j]; }, [&](int j) { return ltaps[i0 - j]; }, i0 + 1);
+            v[0].y = pss::zdot_re_skx_lane([&](int j) { return (double)exf[j]; }, [&](int j) { return ltaps[i0 + 1 - j]; }, i0 + 2);
+        }
+        __syncthreads();                          // every window has been read: the buffer is the transforms' now
+        double2 u1 = w1, u2 = w2, u3 = w3;
+        asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
+        // 3. Z = FFT_M(z): bin t + T q in y[q]
+        double2 y[16];
+        pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, tt, [&](int, int j, int k, double2 X) { y[j + (16 / R4) * k] = X; });
+        // 4. the partner Z[M - k]: thread T - t, slot 15 - q (thread 0: itself, slot (16 - q) mod 16 — its slot 0 is duplicated behind the rows)
+        double oi[16];
+        {
+            double *wr = ex + tt;
+            const double *rd = ex + T - tt;
+#pragma unroll
+            for (int q = 0; q < 16; q++) wr[q * T] = y[q].x;
+            if (t == 0) ex[16 * T] = y[0].x;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const double px = rd[(15 - q) * T], zx = y[q].x;
+                y[q].x = 0.5 * (zx + px);         // Re E
+                oi[q] = -0.5 * (zx - px);         // Im O
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; q++) wr[q * T] = y[q].y;
+            if (t == 0) ex[16 * T] = y[0].y;
+            __syncthreads();
+            double2 wn = wn0;
+            asm volatile("" : "+v"(wn.x), "+v"(wn.y));
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const double py = rd[(15 - q) * T], zy = y[q].y;
+                const double2 E = make_double2(y[q].x, 0.5 * (zy - py)), O = make_double2(0.5 * (zy + py), oi[q]);
+                const double2 W = pss_r16::cmul(wn, rf_cq(q));                       // W_N^(t + T q)
+                const double2 WO = pss_r16::cmul(W, O);
+                const double2 X = make_double2(E.x + WO.x, E.y + WO.y);              // spectrum of the real row at bin k
+                const double2 Xc = make_double2(E.x - WO.x, E.y - WO.y);             // conj of it at bin M - k
+                // one-sided mask (2; bins 0 and M: 1) and the Hermitian part of the masked spectrum (halves it again; bins 0 / M keep it)
+                const bool ends = (q == 0) && (t == 0);
+                const double hk = ends ? 1.0 : 2.0, hh = ends ? 1.0 : 0.5;
+                const double2 H = make_double2(X.x * hk * hh, X.y * hk * hh), Hc = make_double2(Xc.x * hk * hh, Xc.y * hk * hh);
+                const double2 E2 = make_double2(0.5 * (H.x + Hc.x), 0.5 * (H.y + Hc.y));
+                const double2 D = make_double2(0.5 * (H.x - Hc.x), 0.5 * (H.y - Hc.y));
+                const double2 O2 = pss_r16::cmul(D, make_double2(W.x, -W.y));
+                v[q] = make_double2(E2.x - O2.y, -(E2.y + O2.x));                    // conj(Z'[k]): ifft = conj(fft(conj .)) / M
+            }
+            __syncthreads();                      // the partner reads are done before the next exchange writes
+        }
+        asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
+        // 5. z' = IFFT_M(Z'): sample pair m = t + T q in y[q]
+        double m = 0.0;
+        pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, tt, [&](int, int j, int k, double2 W) {
+            const int q = j + (16 / R4) * k;
+            y[q] = make_double2(W.x * INV_M, -(W.y * INV_M));
+            m = nanmax(nanmax(m, fabs(y[q].x)), fabs(y[q].y));
+        });
+        // 6. frame peak, normalisation, float64 audio and int16 stereo PCM (samples 2 m, 2 m + 1 side by side)
+        for (int off = 32; off > 0; off >>= 1) m = nanmax(m, __shfl_xor(m, off));
+        const int par = (int)(((f - blockIdx.x) / gridDim.x) & 1);
+        if ((t & 63) == 0) red[par][t >> 6] = m;
+        __syncthreads();
+        m = red[par][0];
+#pragma unroll
+        for (int w = 1; w < T / 64; w++) m = nanmax(m, red[par][w]);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const double a0 = normalise95(y[q].x, m), a1 = normalise95(y[q].y, m);
+            typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+            const v4u_t pk = {(unsigned)__double2loint(a0), (unsigned)__double2hiint(a0), (unsigned)__double2loint(a1), (unsigned)__double2hiint(a1)};
+            // (row offset in the per-lane operand, constant soffset: the store-data hazard note in k_hilbert_xl)
+            __builtin_amdgcn_raw_buffer_store_b128(pk, ro, tt * 16 + T * q * 16, 0, 0);      // out == NULL: zero-sized resource, dropped
+            const pss_xl::v2u_t pp = {pcm_pair(a0), pcm_pair(a1)};
+            __builtin_amdgcn_raw_buffer_store_b64(pp, rp, tt * 8 + T * q * 8, 0, 0);
         }
     }
 }
