@@ -425,6 +425,10 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_rfft(const float2 *__r
     const double2 wn0 = tw[t];                               // W_N^t
     if (t < 72) ltaps[t] = taps.fwd[t];
     constexpr double INV_M = 1.0 / (double)M;
+#ifdef PSS_EXP_STAGGER   // timing experiment: the second workgroup of a CU starts late, so that the two are in different phases
+    if ((blockIdx.x / 256) & 1)
+        for (int i = 0; i < PSS_EXP_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+#endif
     for (long f = blockIdx.x; f < n_rows; f += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rx = pss_xl::make_rsrc(iq + (size_t)f * N, N * 8);
         const __amdgpu_buffer_rsrc_t ro = pss_xl::make_rsrc(out + (out ? (size_t)f * N : 0), out ? N * 8 : 0);
@@ -452,6 +456,7 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_rfft(const float2 *__r
                 float2 nx = *reinterpret_cast<const float2 *>(xp);
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
+                    asm volatile("" : "+s"(z));   // ... nor kept across steps: a step's 8 taps (16 SGPRs) are loaded for that step (all 65 live at once spill)
                     const float2 p0 = nx, p1 = *reinterpret_cast<const float2 *>(xp + 8 * it + 2), p2 = *reinterpret_cast<const float2 *>(xp + 8 * it + 4),
                                  p3 = *reinterpret_cast<const float2 *>(xp + 8 * it + 6);
                     nx = *reinterpret_cast<const float2 *>(xp + 8 * it + 8);

@@ -160,8 +160,12 @@ def _host_iq(iq, k):
 
 
 # ---- configs ---------------------------------------------------------------------------------------------------------------------------
-def cfg3(eng, dev, verify=True, launch_only=False, nf=8192):
-    """BASELINE configs[2]: 16 384-point spectra x 8192 frames, AM + SSB (Hilbert) demodulation, AGC on (power per frame + stepper)."""
+def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=False):
+    """BASELINE configs[2]: 16 384-point spectra x 8192 frames, AM + SSB (Hilbert) demodulation, AGC on (power per frame + stepper).
+    two_contexts=True runs the AM demodulator on a SECOND context (its own stream) beside the SSB demodulator and the spectrum — measured
+    in round 4: 3.75-3.88 ms against 3.83 ms in order on one stream (every kernel stretches by what it shares: the SSB workgroups hold 140 of a
+    CU's 160 KB of LDS, the AM workgroups need 50 KB, so the two partition the CUs instead of sharing them); kept as a switch, off."""
+    from pyspecsdr_amd.engine import Engine
     n, fs = 16384, 2.4e6
     iq_am = synth("am", nf, n, fs, dev, 20260928 + 3)
     iq_ssb = synth("ssb", nf, n, fs, dev, 20260928 + 13)
@@ -171,14 +175,31 @@ def cfg3(eng, dev, verify=True, launch_only=False, nf=8192):
     pw = torch.empty((nf,), dtype=torch.float32, device=dev)
     gi = torch.empty((nf,), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
+    eng2 = Engine(eng.device, order="none") if two_contexts else eng
+
+    class Both:       # what timed() needs of an engine: fence both contexts, merge their per-kernel event times
+        def sync(self):
+            eng.sync(); eng2.sync()
+
+        def enable_timing(self, on):
+            eng.enable_timing(on)
+            if eng2 is not eng:
+                eng2.enable_timing(on)
+
+        def kernel_times(self):
+            kt = eng.kernel_times()
+            if eng2 is not eng:
+                for k, v in eng2.kernel_times().items():
+                    kt.setdefault(k, []).extend(v)
+            return kt
 
     def one():
+        eng2.demod(L.MODE_AM, iq_am, nf, n, fs, pcm_am, None)     # second context: beside everything below
         eng.power_db(iq_am, nf, n, pw)                    # measure_signal_power (pyspecsdr.py:2251) ...
         eng.agc_steps(pw, nf, 20, 29, gi)                 # ... and the gain stepper (:898-919), interval gate off
-        eng.demod(L.MODE_AM, iq_am, nf, n, fs, pcm_am, None)
         eng.demod(L.MODE_USB, iq_ssb, nf, n, fs, pcm_usb, None)
         eng.spectrum_db(iq_am, nf, n, db)                 # compute_fft (:2275)
-    ms, kt = timed(eng, one, 5, launch_only)
+    ms, kt = timed(Both(), one, 5, launch_only)
     ver = None
     if verify and not launch_only:
         O = _oracle()
@@ -201,11 +222,17 @@ def cfg3(eng, dev, verify=True, launch_only=False, nf=8192):
         ver["agc_trajectory_equal"] = bool(np.array_equal(gi.cpu().numpy(), np.array(traj, np.int32)))
         ver["ok"] = bool(ver["db_max_rel"] <= 1e-4 and ver["am_pcm_equal"] and ver["usb_pcm_equal"] and ver["power_bits_equal"]
                          and ver["agc_trajectory_equal"])
+    if eng2 is not eng:
+        eng2.close()
     # 131 072 IQ + 65 536 dB + 2 x 65 536 PCM + 4 power per frame (the second IQ batch of the SSB leg is the same 131 072
     # bytes the table counts once: both demodulators are fed their own modulation here, so it is counted too)
     algo = nf * (2 * n * 8 + n * 4 + 2 * n * 4 + 4 + 4)
-    return _entry("cfg3", f"{nf} frames x {n}-pt @2.4 MS/s: measure_signal_power + AGC steps, demodulate AM, demodulate USB (hilbert round "
-                  f"trip executed) -> int16 stereo, compute_fft dB rows (BASELINE.json configs[2])", ms, kt, algo, nf * n, ver)
+    e = _entry("cfg3", f"{nf} frames x {n}-pt @2.4 MS/s: measure_signal_power + AGC steps, demodulate AM, demodulate USB (hilbert round "
+               f"trip executed) -> int16 stereo, compute_fft dB rows (BASELINE.json configs[2])", ms, kt, algo, nf * n, ver)
+    e["contexts"] = 2 if two_contexts else 1
+    if kt:
+        e["kernel_ms_sum"] = round(sum(v["ms"] * v["launches"] for v in kt.values()), 4)
+    return e
 
 
 def cfg4(eng, dev, verify=True, launch_only=False, ns=8192):
