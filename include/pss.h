@@ -271,6 +271,27 @@ int pss_morse_edges(pss_ctx *ctx, const float *d_iq, long n_frames, int n, doubl
 int pss_h_morse_edges(pss_ctx *ctx, const float *h_iq, int n, double threshold_db, int cap, int32_t *h_rise, int32_t *h_fall,
                       int *n_rise, int *n_fall);
 
+/* The decoders' per-message halves (host side; no GPU work, no context): what decode_morse does with its rise / fall indices
+ * (decoders.py:167-231) and what decode_aprs does with its bit stream (decode_ax25_frame + decode_aprs_payload, decoders.py:6-88).
+ *   pss_h_morse_decode: rise / fall = the int32 sample indices pss_morse_edges / pss_h_morse_edges return.  Pulse lengths and gaps in
+ *       seconds, two pulse classes (the reference: scipy.cluster.vq.kmeans(durations, 2) from random starting points; here the partition
+ *       Lloyd's iteration leaves unchanged with the smallest mean distance, class means summed in observation order — the reference's
+ *       centroids wherever its answer does not depend on its random draw, i.e. for every keyed signal), symbols, letter gaps (> 3 dots),
+ *       word gaps (> 7 dots), ITU table ('?' for an unknown symbol).  text: NUL-terminated ASCII, returns its length (0: no pulse);
+ *       timing3 = (dot, dash, mean gap) in seconds.  PSS_E_ARG: bad arguments, text_cap too small, edges that do not alternate.
+ *   pss_h_ax25_frame: bits = one 0/1 value per byte.  First flag 01111110, bits up to the next flag with stuffed zeros dropped, bytes LSB
+ *       first, "SOURCE>DEST:info" (addresses: 7-bit characters shifted down by one, stripped of white space).  Returns 1 and the packet
+ *       in out (*out_len bytes = the characters' code points 0..255, not NUL-terminated: info may hold NULs), 0 when there is no frame of
+ *       at least 14 bytes (the reference returns None), PSS_E_ARG on bad arguments or out_cap too small.
+ *   pss_h_decode_morse / pss_h_decode_aprs: the whole decoders on one host buffer — edges / normalisation + AFSK bit slicer on the GPU, the
+ *       functions above behind them.  h_audio is real float64 (np.real of a complex buffer is the caller's, decoders.py:122-123). */
+int pss_h_morse_decode(const int32_t *rise, long n_rise, const int32_t *fall, long n_fall, double fs, char *text, long text_cap,
+                       double *timing3);
+int pss_h_ax25_frame(const uint8_t *bits, long n_bits, char *out, long out_cap, long *out_len);
+int pss_h_decode_morse(pss_ctx *ctx, const float *h_iq, int n, double fs, double threshold_db, char *text, long text_cap, double *timing3);
+int pss_h_decode_aprs(pss_ctx *ctx, const double *h_audio, int n, double fs, const double *sos1200, const double *sos2200, int nsec,
+                      char *out, long out_cap, long *out_len);
+
 /* classify_signal (signal_processing.py:296-322; helpers estimate_bandwidth :267-280, estimate_modulation_index :283-293) for
  * a batch of scanner reads, as the function runs once its missing `welch` import is supplied (in the reference it raises
  * NameError on every call: SURVEY App. C2, §8(f) #3).  d_iq: interleaved complex64 [n_frames][n], n >= 1.  n >= 1024: Welch

@@ -76,6 +76,10 @@ _SIGS = {
     "pss_vector_cells": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "pss_morse_edges": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, C.c_int, _p, _p, _p]),
     "pss_h_morse_edges": (C.c_int, [_p, _p, C.c_int, C.c_double, C.c_int, _p, _p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pss_h_morse_decode": (C.c_int, [_p, C.c_long, _p, C.c_long, C.c_double, _p, C.c_long, _p]),
+    "pss_h_ax25_frame": (C.c_int, [_p, C.c_long, _p, C.c_long, C.POINTER(C.c_long)]),
+    "pss_h_decode_morse": (C.c_int, [_p, _p, C.c_int, C.c_double, C.c_double, _p, C.c_long, _p]),
+    "pss_h_decode_aprs": (C.c_int, [_p, _p, C.c_int, C.c_double, _p, _p, C.c_int, _p, C.c_long, C.POINTER(C.c_long)]),
     "pss_classify": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, _p]),
     "pss_class_name": (C.c_char_p, [C.c_int]),
     "pss_h_classify_signal": (C.c_int, [_p, _p, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_float),

@@ -26,6 +26,7 @@ UNITS = [
     ("pss_demod.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-instcombine-max-copied-from-constant-users=4000"]),
     ("pss_api.cpp", ["-x", "hip"]),
     ("pss_design.cpp", ["-x", "hip", "-ffp-contract=off"]),
+    ("pss_decode.cpp", ["-x", "hip", "-ffp-contract=off"]),   # host only: the decoders' per-message halves
 ]
 
 

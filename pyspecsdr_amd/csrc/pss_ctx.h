@@ -39,6 +39,8 @@ struct pss_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;   // pss_order_after / pss_order_before (created on first use)
     int n_cus = 0;                                  // hipDeviceProp_t::multiProcessorCount
+    int fwd_cap = 0;                // > 0: k_nfm_fwd launches at most this many workgroups per CU (each walks several tiles)
+    int pipe_overlap = 0;           // option "pipe_overlap": pss_frame_pipeline's NFM schedule with the display chain beside the WHOLE demodulator, forward kernel capped at this many workgroups per CU (0: chain beside the backward pass only)
     bool fork_after_fwd = false;
     bool did_fork = false;
     bool defer_bwd = false;              // the fused NFM path launches only its forward kernel and parks the backward launch here:

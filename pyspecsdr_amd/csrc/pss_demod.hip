@@ -2955,9 +2955,15 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             pss_kernel_begin(ctx, "k_nfm_fwd");
             {
                 auto kf = swapped ? fused::k_nfm_fwd<true, true> : fused::k_nfm_fwd<true, false>;
-                hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, d_rev, reinterpret_cast<unsigned *>(ctx->prog),
-                                   ncu, ctx->prog_epoch);
+                // fwd_cap > 0 (set by the pipeline's overlap schedule): at most that many workgroups per CU at a time — the batch's tiles go
+                // out as consecutive grids of fwd_cap * CUs workgroups on the same stream (a grid starts when its predecessor has drained)
+                const long gmax = (ctx->fwd_cap > 0 && (long)ctx->fwd_cap * ncu < tiles) ? (long)ctx->fwd_cap * ncu : tiles;
+                for (long t0 = 0; t0 < tiles; t0 += gmax) {
+                    const long gnow = tiles - t0 < gmax ? tiles - t0 : gmax;
+                    hipLaunchKernelGGL(kf, dim3((unsigned)gnow), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
+                                       reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, d_rev,
+                                       reinterpret_cast<unsigned *>(ctx->prog), ncu, ctx->prog_epoch, t0);
+                }
             }
             pss_kernel_end(ctx);
             auto launch_bwd = [=]() -> int {
@@ -3814,8 +3820,18 @@ static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_fram
 #endif
     int r2;
     ctx->pending_bwd = nullptr;
+    const bool overlap = ctx->pipe_overlap > 0;
+    if (overlap) {
+        // overlap schedule: the display chain needs nothing of the demodulator, so the side stream is released BEFORE the forward kernel
+        // is queued — and the forward kernel is capped at pipe_overlap workgroups per CU (each walks several tiles), so that the chain's
+        // workgroups find registers and LDS on every CU from the first microsecond instead of waiting for forward workgroups to retire
+        int rf = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
+        if (!rf) rf = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
+        if (rf) { pss_time_end(ctx); return rf; }
+    }
     {
         PssFlagScope defer(ctx->defer_bwd, true);
+        PssScoped<int> cap(ctx->fwd_cap, overlap ? ctx->pipe_overlap : 0);
         r2 = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
     }
     int r = r2;
@@ -3869,8 +3885,10 @@ static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_fram
     if (ctx->pending_bwd) {
         auto bwd = ctx->pending_bwd;
         ctx->pending_bwd = nullptr;
-        if (!r) r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
-        if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
+        if (!overlap) {
+            if (!r) r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
+            if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
+        }
         if (!r) {
             PssStreamScope side(ctx->cur, ctx->stream2);
             r = display_chain();

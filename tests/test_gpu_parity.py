@@ -1279,6 +1279,36 @@ def test_decoder_front_halves(golden):
             assert np.array_equal(r[k, :len(orr)], orr) and np.array_equal(f[k, :len(off)], off), (n, k)
 
 
+def test_decoders_end_to_end_vs_reference(golden):
+    """The reference's decoders from samples to message: decode_morse(IQ) -> (text, timing) — envelope mask and edges on
+    the GPU (pss_morse_edges), timing / classes / table in the library's host code (pss_h_morse_decode) — and decode_aprs(audio) -> packets
+    — normalisation + Bell-202 bit slicer on the GPU, AX.25 framing on the host (pss_h_ax25_frame) — against what the reference returned
+    for the same buffers (decoders.npz).  'noise': the reference's own answer depends on its random kmeans start; checked for being a
+    decode at all."""
+    import json
+    from pyspecsdr_amd import decoders as D
+    import pyspecsdr_amd.signal_processing as sp
+    g = golden["decoders"]
+    for tag in g["mtags"]:
+        text, tm = D.decode_morse(g[f"m_iq_{tag}"], float(g[f"m_fs_{tag}"]))
+        got = np.array([float(tm["dot"]), float(tm["dash"]), float(tm["gap"])])
+        if tag == "noise":
+            assert len(text) >= 1 and 0 < got[0] < got[1]
+            continue
+        assert text == str(g[f"m_text_{tag}"]), tag
+        assert np.array_equal(got.view(np.uint64), g[f"m_timing_{tag}"].view(np.uint64)), (tag, got)
+    keep = sp.USE_SCIPY_DESIGNS
+    try:
+        for scipy_tables in (True, False):         # the host's SciPy tables injected / the library's own designers
+            sp.USE_SCIPY_DESIGNS = scipy_tables
+            for tag in g["atags"]:
+                want = json.loads(str(g[f"a_packets_{tag}"]))
+                assert D.decode_aprs(g[f"a_x_{tag}"], float(g[f"a_fs_{tag}"])) == want, (tag, scipy_tables)
+                assert D.decode_afsk(np.real(g[f"a_x_{tag}"]) / np.max(np.abs(np.real(g[f"a_x_{tag}"]))), float(g[f"a_fs_{tag}"])) == [int(b) for b in g[f"a_bits_{tag}"]]
+    finally:
+        sp.USE_SCIPY_DESIGNS = keep
+
+
 def test_kernel_timing_and_filter():
     """pss_kernel_times lists every launch; pss_timing_filter keeps one kernel's events only; results do not change."""
     eng = G.engine()
