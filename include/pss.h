@@ -424,6 +424,17 @@ int pss_h_stream_display_nfm(pss_ctx *ctx, const float *h_iq, long n_frames, int
                              int window, int disp_h, int disp_w, const float *h_halo_lo, const float *h_halo_hi, int n_halo,
                              int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm, float *h_db, float *h_row_lo, float *h_row_hi);
 
+/* The same capture (a fresh history: no halo), and additionally the FULL display grid as the reference's screen shows it after the LAST
+ * frame of every chunk: draw_waterfall / draw_persistence redraw all `window` lines / traces of the history with the history's current extremes
+ * on every frame (pyspecsdr.py:1342-1406, :1512-1564), so older lines cannot be rebuilt from the per-frame lines above — a display refreshed
+ * once per chunk needs this grid.  h_grid_a (+ h_grid_b: the waterfall's colour plane) int8 [n_chunks][disp_h][disp_w], n_chunks =
+ * ceil(n_frames / chunk_frames); cell values as pss_waterfall_cells / pss_persistence_cells (which produce it from the last `window`
+ * post-processed rows, carried from chunk to chunk on the device).  For a resident batch with materialised post-processed rows the grid after
+ * frame f is pss_waterfall_cells(d_post + (f - w + 1) * len, w, ...), w = min(window, f + 1). */
+int pss_h_stream_display_nfm_grids(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames, int mode,
+                                   int window, int disp_h, int disp_w, int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm,
+                                   float *h_row_lo, float *h_row_hi, int8_t *h_grid_a, int8_t *h_grid_b);
+
 /* Kernel-only time of the most recent batched call on this context, measured with HIP events on the
  * context's stream (ms); negative if timing is disabled.  pss_enable_timing(ctx, 1) turns it on. */
 int pss_enable_timing(pss_ctx *ctx, int on);

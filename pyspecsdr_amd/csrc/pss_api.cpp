@@ -625,13 +625,15 @@ extern "C" int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n
 // (copy stream), two buffer sets.  The row extremes of the whole capture stay in one device array, so a frame's history
 // window reaches back across chunk boundaries; h_halo_lo / h_halo_hi (n_halo values each, may be NULL) are the extremes of
 // the rows that precede this capture (previous capture, or the left neighbour's tail when the capture is sharded).
-extern "C" int pss_h_stream_display_nfm(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
-                                        int mode, int window, int disp_h, int disp_w, const float *h_halo_lo,
-                                        const float *h_halo_hi, int n_halo, int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm,
-                                        float *h_db, float *h_row_lo, float *h_row_hi)
+static int stream_display(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
+                          int mode, int window, int disp_h, int disp_w, const float *h_halo_lo,
+                          const float *h_halo_hi, int n_halo, int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm,
+                          float *h_db, float *h_row_lo, float *h_row_hi, int8_t *h_grid_a, int8_t *h_grid_b)
 {
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
+    if (h_grid_a && (window > 64 || (mode == 0 && !h_grid_b)))
+        return pss_fail(ctx, PSS_E_ARG, "stream display grids: window <= 64, and both planes for the waterfall");
     if (!h_iq || !h_pcm || !h_line_a || n_frames < 0 || n < 8 || chunk_frames < 1 || window < 1 || disp_w < 1 || disp_h < 1 ||
         disp_h > 127 || n_halo < 0 || (mode != 0 && mode != 1) || (mode == 0 && !h_line_b) || (n_halo > 0 && (!h_halo_lo || !h_halo_hi)))
         return pss_fail(ctx, PSS_E_ARG, "bad stream-display arguments");
@@ -659,6 +661,20 @@ extern "C" int pss_h_stream_display_nfm(pss_ctx *ctx, const float *h_iq, long n_
     }
     if (!rc) rc = stream_buf(ctx, 10, post_b, &d_post);
     if (!rc) rc = stream_buf(ctx, 11, 2 * n_ext * sizeof(float), &d_ext);
+    // full screens (h_grid_a): after the LAST frame of every chunk the whole grid as the reference redraws it — all lines / traces of the
+    // history normalised with the history's current extremes (pyspecsdr.py:1342-1406, :1512-1564) — from the last `window` post-processed
+    // rows, which are carried from chunk to chunk in a small device buffer
+    void *d_ga[2] = {nullptr, nullptr}, *d_gb[2] = {nullptr, nullptr}, *d_tail[2] = {nullptr, nullptr};
+    const size_t grid_b = (size_t)disp_h * disp_w, tail_b = (size_t)window * m * sizeof(float);
+    if (h_grid_a) {
+        for (int i = 0; i < 2; i++) {
+            if (!rc) rc = stream_buf(ctx, 12 + i, grid_b, &d_ga[i]);
+            if (!rc && mode == 0) rc = stream_buf(ctx, 14 + i, grid_b, &d_gb[i]);
+            if (!rc) rc = stream_buf(ctx, 16 + i, tail_b, &d_tail[i]);
+        }
+    }
+    long tail_rows = 0;   // rows of the history held in d_tail[tail_cur], oldest first
+    int tail_cur = 0;
     if (rc) return rc;
     auto cleanup = [&]() { stream_drain(ctx); };
 #define STREAM_HIP(call)                                          \
@@ -696,8 +712,27 @@ extern "C" int pss_h_stream_display_nfm(pss_ctx *ctx, const float *h_iq, long n_
             else rc = pss_persistence_rows(ctx, (const float *)d_post, cnt, m, lo_k, hi_k, halo_k, window, disp_h, disp_w, (int8_t *)d_la[b]);
         }
         if (rc) { cleanup(); return rc; }
+        if (h_grid_a) {
+            // history after this chunk = the last `window` rows of (history before it ++ the chunk's rows)
+            const long take = cnt < window ? cnt : window, keep = (tail_rows + take > window) ? window - take : tail_rows;
+            float *dst = (float *)d_tail[tail_cur ^ 1];
+            if (keep > 0)
+                STREAM_HIP(hipMemcpyAsync(dst, (const float *)d_tail[tail_cur] + (size_t)(tail_rows - keep) * m, (size_t)keep * m * sizeof(float),
+                                          hipMemcpyDeviceToDevice, ctx->stream));
+            STREAM_HIP(hipMemcpyAsync(dst + (size_t)keep * m, (const float *)d_post + (size_t)(cnt - take) * m, (size_t)take * m * sizeof(float),
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+            tail_cur ^= 1;
+            tail_rows = keep + take;
+            if (mode == 0) rc = pss_waterfall_cells(ctx, dst, (int)tail_rows, m, disp_h, disp_w, (int8_t *)d_ga[b], (int8_t *)d_gb[b]);
+            else rc = pss_persistence_cells(ctx, dst, (int)tail_rows, m, disp_h, disp_w, (int8_t *)d_ga[b]);
+            if (rc) { cleanup(); return rc; }
+        }
         STREAM_HIP(hipEventRecord(cmp_done[b], ctx->stream));
         STREAM_HIP(hipStreamWaitEvent(s_dn, cmp_done[b], 0));
+        if (h_grid_a) {
+            STREAM_HIP(hipMemcpyAsync(h_grid_a + (size_t)k * grid_b, d_ga[b], grid_b, hipMemcpyDeviceToHost, s_dn));
+            if (mode == 0) STREAM_HIP(hipMemcpyAsync(h_grid_b + (size_t)k * grid_b, d_gb[b], grid_b, hipMemcpyDeviceToHost, s_dn));
+        }
         if (h_db) STREAM_HIP(hipMemcpyAsync(h_db + (size_t)f0 * n, d_db[b], (size_t)cnt * n * sizeof(float), hipMemcpyDeviceToHost, s_dn));
         STREAM_HIP(hipMemcpyAsync(h_line_a + (size_t)f0 * disp_w, d_la[b], (size_t)cnt * disp_w, hipMemcpyDeviceToHost, s_dn));
         if (mode == 0) STREAM_HIP(hipMemcpyAsync(h_line_b + (size_t)f0 * disp_w, d_lb[b], (size_t)cnt * disp_w, hipMemcpyDeviceToHost, s_dn));
@@ -710,4 +745,22 @@ extern "C" int pss_h_stream_display_nfm(pss_ctx *ctx, const float *h_iq, long n_
 #undef STREAM_HIP
     cleanup();
     return PSS_OK;
+}
+
+extern "C" int pss_h_stream_display_nfm(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
+                                        int mode, int window, int disp_h, int disp_w, const float *h_halo_lo,
+                                        const float *h_halo_hi, int n_halo, int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm,
+                                        float *h_db, float *h_row_lo, float *h_row_hi)
+{
+    return stream_display(ctx, h_iq, n_frames, n, fs, chunk_frames, mode, window, disp_h, disp_w, h_halo_lo, h_halo_hi, n_halo, h_line_a,
+                          h_line_b, h_pcm, h_db, h_row_lo, h_row_hi, nullptr, nullptr);
+}
+
+extern "C" int pss_h_stream_display_nfm_grids(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
+                                              int mode, int window, int disp_h, int disp_w, int8_t *h_line_a, int8_t *h_line_b,
+                                              int16_t *h_pcm, float *h_row_lo, float *h_row_hi, int8_t *h_grid_a, int8_t *h_grid_b)
+{
+    if (ctx && !h_grid_a) return pss_fail(ctx, PSS_E_ARG, "pss_h_stream_display_nfm_grids: h_grid_a is null");
+    return stream_display(ctx, h_iq, n_frames, n, fs, chunk_frames, mode, window, disp_h, disp_w, nullptr, nullptr, 0, h_line_a, h_line_b,
+                          h_pcm, nullptr, h_row_lo, h_row_hi, h_grid_a, h_grid_b);
 }

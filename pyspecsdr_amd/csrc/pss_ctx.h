@@ -74,8 +74,8 @@ struct pss_ctx {
     // (creating and freeing them per capture cost ~2 ms of a 17 ms capture)
     hipStream_t st_up = nullptr, st_dn = nullptr;
     hipEvent_t st_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // up_done[2], cmp_done[2], dn_done[2]
-    void *st_buf[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t st_cap[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void *st_buf[18] = {};         // [0..11]: the chunk buffer sets; [12..15]: per-chunk display grids (two sets x two planes); [16..17]: the last `window` post-processed rows (ping-pong)
+    size_t st_cap[18] = {};
     float *d_hann_short = nullptr;  // the same for reads shorter than 1024 samples (window length = read length hann_short_n)
     float hann_short_sum = 0.0f;
     int hann_short_n = 0;

@@ -395,6 +395,26 @@ class Engine:
                                                    _ptr(hl), _ptr(hh), n_halo, _ptr(la), _ptr(lb), _ptr(pcm), _ptr(db), _ptr(lo), _ptr(hi)))
         return {"lines": (la, lb) if m == 0 else (la,), "pcm": pcm, "row_lo": lo, "row_hi": hi, "db": db}
 
+    def stream_display_nfm_grids(self, h_iq, fs, chunk_frames, mode="waterfall", window=None, disp_h=36, disp_w=112):
+        """stream_display_nfm for a capture with a fresh history, plus the FULL display grid after the last frame of every chunk (what the
+        reference's screen shows: every line / trace of the history redrawn with the current extremes).  Returns the stream_display_nfm dict
+        + "grids": (glyph, colour) int8 [n_chunks][disp_h][disp_w] for the waterfall, (colour,) for persistence."""
+        assert h_iq.dtype == np.complex64 and h_iq.ndim == 2 and h_iq.flags.c_contiguous
+        nf, n = h_iq.shape
+        m = 0 if mode == "waterfall" else 1
+        window = (30 if m == 0 else 10) if window is None else int(window)
+        n_out = self.demod_out_len(L.MODE_NFM, n, fs)
+        n_chunks = (nf + int(chunk_frames) - 1) // int(chunk_frames)
+        la = np.empty((nf, disp_w), np.int8)
+        lb = np.empty((nf, disp_w), np.int8) if m == 0 else None
+        pcm = np.empty((nf, n_out, 2), np.int16)
+        lo, hi = np.empty(nf, np.float32), np.empty(nf, np.float32)
+        ga = np.empty((n_chunks, disp_h, disp_w), np.int8)
+        gb = np.empty((n_chunks, disp_h, disp_w), np.int8) if m == 0 else None
+        self._ck(self.lib.pss_h_stream_display_nfm_grids(self.h, _ptr(h_iq), nf, n, float(fs), int(chunk_frames), m, window, disp_h, disp_w,
+                                                         _ptr(la), _ptr(lb), _ptr(pcm), _ptr(lo), _ptr(hi), _ptr(ga), _ptr(gb)))
+        return {"lines": (la, lb) if m == 0 else (la,), "pcm": pcm, "row_lo": lo, "row_hi": hi, "grids": (ga, gb) if m == 0 else (ga,)}
+
     def stream_spectrum_nfm(self, h_iq, fs, chunk_frames, h_db=None, h_pcm=None):
         """h_iq: complex64 [n_frames, n] host array (pinned for overlap).  Returns (h_db or None, h_pcm)."""
         assert h_iq.dtype == np.complex64 and h_iq.ndim == 2 and h_iq.flags.c_contiguous

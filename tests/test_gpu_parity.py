@@ -1690,6 +1690,47 @@ def test_streamed_display_equals_resident_pipeline():
     e.pinned_free(h_iq)
 
 
+@pytest.mark.parametrize("mode,window", [("waterfall", 30), ("persistence", 10)])
+def test_streamed_capture_full_display_grids(mode, window):
+    """pss_h_stream_display_nfm_grids: besides the per-frame lines, the FULL screen after the last frame of every chunk — every line / trace
+    of the history redrawn with the history's current extremes, as draw_waterfall / draw_persistence do on every frame (pyspecsdr.py:1342-1406,
+    :1512-1564).  Chunks shorter and longer than the history, a ragged last chunk; against the oracle's grid functions (pinned to the
+    reference's own draws by tests/test_oracle_golden.py) on the device's post-processed rows, and against the resident call
+    pss_waterfall_cells / pss_persistence_cells on materialised rows."""
+    e = G.engine()
+    nf, n, fs = 230, 2048, 10e6
+    H, W = 36, 112
+    rng = np.random.default_rng(33)
+    t = np.arange(n) / fs
+    iq = (0.4 * np.exp(2j * np.pi * (3e5 * t[None, :] + rng.random((nf, 1)))) * (1 + 0.8 * rng.random((nf, 1)))
+          + 0.03 * (rng.standard_normal((nf, n)) + 1j * rng.standard_normal((nf, n)))).astype(np.complex64)
+    iq[100:105] *= 25.0
+    d_iq = G.dev(iq)
+    d_db, d_post = G.empty((nf, n), torch.float32), G.empty((nf, n - 4), torch.float32)
+    e.spectrum_db(d_iq, nf, n, d_db)
+    e.spectrum_post(d_db, nf, n, d_post)
+    e.sync()
+    post = G.host(d_post)
+    for chunk in (7, 64, 100):
+        got = e.stream_display_nfm_grids(iq, fs, chunk, mode=mode, window=window, disp_h=H, disp_w=W)
+        plain = e.stream_display_nfm(iq, fs, chunk, mode=mode, window=window, disp_h=H, disp_w=W)
+        assert all(np.array_equal(a, b) for a, b in zip(got["lines"], plain["lines"])) and np.array_equal(got["pcm"], plain["pcm"])
+        n_chunks = (nf + chunk - 1) // chunk
+        assert got["grids"][0].shape == (n_chunks, H, W)
+        for k in range(n_chunks):
+            last = min(nf, (k + 1) * chunk) - 1
+            rows = post[max(0, last + 1 - window):last + 1]
+            if mode == "waterfall":
+                wg, wc = O.waterfall_cells(rows.astype(np.float64), H, W)
+                assert np.array_equal(got["grids"][0][k], wg) and np.array_equal(got["grids"][1][k], wc), (chunk, k)
+                d_g, d_c = G.empty((H, W), torch.int8), G.empty((H, W), torch.int8)
+                e.waterfall_cells(d_post[max(0, last + 1 - window):last + 1], len(rows), n - 4, H, W, d_g, d_c)
+                e.sync()
+                assert np.array_equal(G.host(d_g), got["grids"][0][k]) and np.array_equal(G.host(d_c), got["grids"][1][k])
+            else:
+                assert np.array_equal(got["grids"][0][k], O.persistence_cells(rows.astype(np.float64), H, W)), (chunk, k)
+
+
 def test_frame_pipeline_equals_separate_calls():
     """pss_frame_pipeline_nfm (what bench.py times: one main-loop iteration per frame of the batch, display chain on a side
     stream beside the demodulator's backward pass) against the separate entry points, byte for byte."""
