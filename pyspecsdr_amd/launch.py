@@ -25,7 +25,9 @@ def _free_port():
 
 
 def under_launcher():
-    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    """torch.distributed.run / torchrun export LOCAL_RANK (and TORCHELASTIC_RUN_ID) beside WORLD_SIZE / RANK; a scheduler wrapper that only
+    exports WORLD_SIZE and RANK is not a launcher of ours."""
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ and ("LOCAL_RANK" in os.environ or "TORCHELASTIC_RUN_ID" in os.environ)
 
 
 def ensure_ranks(gpus, script, argv, need_gpus=True):
@@ -55,8 +57,17 @@ def ensure_ranks(gpus, script, argv, need_gpus=True):
         return 1, 0, 0
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(script)] + list(argv)
-    sys.stderr.write("launching: " + " ".join(cmd) + "\n")
-    sys.stderr.flush()
-    sys.exit(subprocess.run(cmd, env=env).returncode)
+    # the port is free when it is probed, not necessarily when the rendezvous binds it: a clash (the launcher's own exit status for a
+    # rendezvous failure) is retried on another port
+    rc = 1
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(script)] + list(argv)
+        sys.stderr.write("launching: " + " ".join(cmd) + "\n")
+        sys.stderr.flush()
+        p = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(p.stderr)
+        rc = p.returncode
+        if rc == 0 or not any(m in p.stderr for m in ("Address already in use", "EADDRINUSE", "address already in use")):
+            break
+    sys.exit(rc)

@@ -17,6 +17,18 @@ import torch
 import torch.distributed as dist
 
 
+def _torch_version_ok():
+    try:
+        return tuple(int(x) for x in torch.__version__.split("+")[0].split(".")[:2]) >= (2, 6)
+    except ValueError:
+        return True            # an unparsable development version string: assume recent
+
+
+if not _torch_version_ok():
+    raise ImportError(f"pyspecsdr_amd.shard / .multi address sub-group peers by their rank IN THE GROUP (dist.gather(group_dst=), "
+                      f"dist.P2POp(group_peer=)), which torch.distributed has since 2.6; this is torch {torch.__version__}")
+
+
 def shard_range(n_items, rank, world):
     """Contiguous block of rank `rank`: items [start, start+count), sizes differ by at most one."""
     base, rem = divmod(int(n_items), int(world))

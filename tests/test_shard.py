@@ -194,10 +194,20 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and len(set(lines[0]["pids"])) == 2, r.stdout
+    # the shape the driver's scaling run has: eight ranks on one node
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and len(set(lines[0]["pids"])) == 8, r.stdout
     # under a launcher with another world size
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=120)
     assert r.returncode == 2 and "launcher started 1 rank" in r.stderr
+    # WORLD_SIZE / RANK alone (a scheduler wrapper, not torchrun) do not count as a launcher: the script starts its own ranks
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), timeout=300)
+    assert r.returncode == 0 and json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 2, r.stderr[-500:]
     if not torch.cuda.is_available():   # the real run refuses to label a 1-GPU (here: 0-GPU) box as 2 GPUs
         for script in ("bench.py", os.path.join("tools", "bench_multi.py")):
             r = subprocess.run([sys.executable, os.path.join(root, script), "--gpus", "2"], capture_output=True, text=True, env=env,

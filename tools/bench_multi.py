@@ -12,6 +12,11 @@ cfg4: scanner sweep of 8192 centre-frequency slices x 4096-pt FFT (pyspecsdr.py:
 ranks (strong scaling: the sweep is fixed), results gathered to rank 0 over RCCL.  Reported separately, as SURVEY §7.2 #5
 asks: compute alone, the gather alone (full float32 dB rows: 16 KiB per slice; and the 16 B per slice of peak /
 bandwidth / count), and back-to-back sweeps with the gather of sweep k overlapping the compute of sweep k+1.
+cfg4host: the same sweep with the IQ where a scanner actually has it — in HOST memory, every rank holding its block of slices in its own
+pinned buffer and uploading it over its own PCIe link inside the timed region (chunked, double-buffered against the scan), and only the
+16 bytes per slice of (peak, bandwidth, count) gathered.  This is the cfg-4 quantity that CAN scale with the GPU count: with the IQ
+already resident, one GPU does the whole sweep in 0.16 ms, less than the 0.22 ms a 128 MiB dB gather into one GPU takes over seven xGMI
+links, so "resident IQ -> gathered dB rows" is below 1x at eight GPUs by construction (DESIGN.md par. 6).
 One JSON line on rank 0.
 """
 import argparse
@@ -69,10 +74,83 @@ def cfg5(args, eng, dev, world, rank, use_dist, fence, maxr):
         dist.destroy_process_group()
 
 
+def cfg4host(args, eng, dev, world, rank, use_dist, fence, maxr):
+    """Host IQ sharded over the ranks' PCIe links -> scan -> gathered (peak, bandwidth, count)."""
+    from pyspecsdr_amd.shard import scan_buffer, shard_counts, shard_range
+    fs, n, ns = 2.4e6, args.n_fft, args.slices
+    start, count = shard_range(ns, rank, world)
+    g = torch.Generator().manual_seed(4 + rank)
+    h = torch.empty((max(count, 1), n, 2), dtype=torch.float32, pin_memory=True)
+    h.normal_(0.0, 0.01, generator=g)
+    tt = torch.arange(n, dtype=torch.float32)
+    for k in range(0, count, 8):      # 1 slice in 8 carries a carrier (SURVEY par. 8d)
+        ph = 2 * torch.pi * (0.05 + 0.4 * float(torch.rand(1, generator=g))) * tt
+        h[k, :, 0] += 0.3 * torch.cos(ph)
+        h[k, :, 1] += 0.3 * torch.sin(ph)
+    nchunk = max(1, min(args.chunks, count))
+    per = (count + nchunk - 1) // nchunk
+    d = [torch.empty((per, n, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+    buf = scan_buffer(ns, n, False, dev, None)
+    up, comm = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    comp = torch.cuda.ExternalStream(eng.stream_handle(), device=dev)
+    recv = torch.empty((world, buf.nbytes), dtype=torch.uint8, device=dev) if (use_dist and rank == 0) else None
+    free = [None, None]
+    pk, bw, cn = buf.view("peak"), buf.view("bw"), buf.view("cnt")
+
+    def sweep():
+        for c in range(nchunk):
+            b, c0, c1 = c & 1, c * per, min(count, (c + 1) * per)
+            if c1 <= c0:
+                break
+            if free[b] is not None:
+                up.wait_event(free[b])            # the scan of the chunk that used this buffer has finished
+            with torch.cuda.stream(up):
+                d[b][:c1 - c0].copy_(h[c0:c1], non_blocking=True)
+                ev = up.record_event()
+            comp.wait_event(ev)
+            eng.scan(d[b], c1 - c0, n, fs, None, pk[c0:], bw[c0:], cn[c0:])
+            free[b] = comp.record_event()
+        if use_dist:
+            comm.wait_stream(comp)
+            with torch.cuda.stream(comm):
+                dist.gather(buf.raw, list(recv.unbind(0)) if rank == 0 else None, dst=0)
+
+    for _ in range(args.warmup):
+        sweep()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sweep()
+    fence()
+    el = maxr(time.perf_counter() - t0) / args.steps
+    # the upload alone (this rank's block, no scan, no gather): what the link gives
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for c in range(nchunk):
+            c0, c1 = c * per, min(count, (c + 1) * per)
+            if c1 > c0:
+                with torch.cuda.stream(up):
+                    d[c & 1][:c1 - c0].copy_(h[c0:c1], non_blocking=True)
+    fence()
+    el_up = maxr(time.perf_counter() - t0) / args.steps
+    res = {"config": "cfg4host", "n_gpus": world, "slices": ns, "n_fft": n, "steps": args.steps, "slices_per_rank": max(shard_counts(ns, world)),
+           "chunks_per_rank": nchunk, "sweep_ms_host_iq_gather_peaks": el * 1e3, "samples_per_s": ns * n / el,
+           "h2d_GBps_per_rank": count * n * 8 / el / 1e9, "upload_alone_ms": el_up * 1e3, "upload_alone_GBps_per_rank": count * n * 8 / el_up / 1e9,
+           "message_bytes_per_rank": buf.nbytes,
+           "note": "IQ in pinned host memory, one block of slices per rank, uploaded inside the timed region; 16 B per slice gathered"}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (default: the launcher's WORLD_SIZE, else 1)")
-    ap.add_argument("--config", choices=["cfg4", "cfg5"], default="cfg4")
+    ap.add_argument("--config", choices=["cfg4", "cfg4host", "cfg5"], default="cfg4")
+    ap.add_argument("--chunks", type=int, default=4, help="cfg4host: upload / scan chunks per rank and sweep")
     ap.add_argument("--seconds", type=float, default=10.0, help="cfg5: length of the capture at 10 MS/s")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -111,6 +189,8 @@ def main():
 
     if args.config == "cfg5":
         return cfg5(args, eng, dev, world, rank, use_dist, fence, maxr)
+    if args.config == "cfg4host":
+        return cfg4host(args, eng, dev, world, rank, use_dist, fence, maxr)
     res = {"config": args.config, "n_gpus": world, "slices": args.slices, "n_fft": n, "steps": args.steps}
     for gather_db in (True, False):
         sc = ShardedScanner(eng, args.slices, n, fs, gather_db=gather_db, dst=0)
