@@ -8,6 +8,9 @@ cd "$(dirname "$0")/.."
 cp gpurun_out/prof_$TAG/${TAG}_summary.txt gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv gpurun_out/prof_$TAG/${TAG}_sq_counters.txt profiles/
 cp gpurun_out/prof_$TAG/hbm_traffic.json profiles/hbm_traffic.json
 [ -f gpurun_out/prof_other_$TAG/${TAG}_summary.txt ] && cp gpurun_out/prof_other_$TAG/${TAG}_summary.txt profiles/${TAG}_other_configs_kernel_stats_and_hbm.txt
+# tools/prof_configs.sh: every config of bench.py's other_configs, per-config counters (supersedes prof_other.sh's file)
+[ -f gpurun_out/prof_cfgs_$TAG/${TAG}_configs_summary.txt ] && cp gpurun_out/prof_cfgs_$TAG/${TAG}_configs_summary.txt profiles/${TAG}_other_configs_kernel_stats_and_hbm.txt
+[ -f gpurun_out/fuzz_gpu.txt ] && grep -v "amdgpu.ids" gpurun_out/fuzz_gpu.txt > profiles/${TAG}_fuzz_gpu_vs_oracle.txt
 [ -f gpurun_out/shim_latency.txt ] && grep -v "amdgpu.ids" gpurun_out/shim_latency.txt > profiles/${TAG}_shim_latency.txt
 [ -f gpurun_out/cfg5stream.txt ] && grep '^{"config"' gpurun_out/cfg5stream.txt > profiles/${TAG}_cfg5_streamed.json
 [ -f gpurun_out/bench_line.json ] && cp gpurun_out/bench_line.json profiles/${TAG}_bench_line.json

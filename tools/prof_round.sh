@@ -11,8 +11,8 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side"
-SHORT="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side"
+CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side --no-other-configs"
+SHORT="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side --no-other-configs"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o kt -- $CMD > "$OUT/kt.log" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT" -o write -- $CMD > "$OUT/write.log" 2>&1
