@@ -446,17 +446,6 @@ __global__ __launch_bounds__(TILE) void k_am_iir(const float *__restrict__ env, 
     if (f < n_frames) mxout[f] = nan ? __builtin_nan("") : mx;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// AM band-pass for SMALL batches: with lane = frame (k_am_iir) a batch of F frames keeps only F/64 wavefronts busy
-// (BASELINE cfg 3: 8192 frames = 128 waves on a 1024-SIMD part).  Here the five sections of one frame sit in five
-// adjacent lanes and the recurrence runs as a block-systolic array: lane (g, s) filters 64-sample blocks and hands each
-// to lane (g, s+1) through LDS.  A wavefront carries 12 frames (60 lanes) -> 5.3x more wavefronts than lane = frame,
-// each step one section's state update instead of 45 instructions.
-// Every section still executes exactly biquad_step()'s operations on exactly its own sample sequence (zero initial
-// state, filled and drained with zeros), so the output bits are those of k_am_iir.
-// ---------------------------------------------------------------------------------------------------
-constexpr int SYS_G = 12, SYS_T = 64;
-
 __device__ __forceinline__ double dpp_row_shr1(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -465,66 +454,127 @@ __device__ __forceinline__ double dpp_row_shr1(double v)
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(128) void k_am_sys(const float *__restrict__ env, const float *__restrict__ mu,
+// ---------------------------------------------------------------------------------------------------
+// AM band-pass for SMALL batches (BASELINE cfg 3: 8192 frames; the shim's single buffer).  With lane = frame (k_am_iir) a batch of F
+// frames keeps only F / 64 wavefronts busy; here the five sections of one frame sit in five lanes and the recurrence runs as a systolic
+// array: a wavefront carries 12 frames (5.3x more wavefronts), each lane one section's state update per sample instead of 45 instructions.
+// GROUP-systolic (round 4): a section hands its output to the next one in REGISTERS, eight samples at a time.  The lanes of a 16-lane
+// DPP row are laid out r = 3 s + g' (section s = 0..4, frame g' = 0..2 of the row; r = 15 idle), so `row_shr:3` moves the eight outputs
+// of (g', s) to (g', s + 1): 16 v_mov_b32_dpp per group-step.  The lanes r < 3 (section 0) have no source lane inside their row: with
+// bound_ctrl off they keep the DPP's `old` operand — the eight input samples they just read from LDS — so the hand-off needs no select.
+// At group-step j lane s works on group j - s; only section 0's LDS reads (the staged envelope - mean) and section 4's LDS writes (a
+// 128-sample ring per frame) carry data.  Every section still executes exactly biquad_step()'s operations on exactly its own sample
+// sequence from a (+0, +0) state (the first group-steps of a lane, before its data arrives, run on a copy of the state that is not
+// committed), so the output bits are k_am_iir's.
+// Four wavefronts per workgroup: the recurrence, two that load and stage the even / odd input blocks, one that stores — see the kernel.
+// History: round 3's k_am_sys handed whole 64-sample blocks from section to section through LDS (128 full-wavefront LDS instructions per
+// block) and had ONE memory wavefront: 3.1 us per block, 0.82 ms at cfg 3.  This kernel: 2.5 us per block, 0.64 ms (one workgroup alone:
+// 2.0 us, of which the 576 float64 instructions of a block are 1.05 us, the 32 ds_write_b128 of the outputs 0.35 us — ~26 clocks of
+// issue each, masked or not — and the 128 DPP moves 0.1 us; NOTEBOOK.md has the ablations).
+// ---------------------------------------------------------------------------------------------------
+#ifndef PSS_GRP_Q
+#define PSS_GRP_Q 8
+#endif
+constexpr int GRP_G = 12, GRP_T = 64, GRP_Q = PSS_GRP_Q;   // samples per group-step
+constexpr int GRP_OFF = (5 - 1) * GRP_Q;                     // the last section runs this many samples behind the first
+static_assert(GRP_T % (2 * GRP_Q) == 0 && GRP_OFF <= GRP_T, "whole pairs of group-steps per block; the output ring holds two blocks");
+constexpr int GRP_ES = GRP_T + 2;          // input row stride (doubles): even -> 16-byte aligned rows for ds_read_b128
+constexpr int GRP_YS = 2 * GRP_T + 2;      // output ring row stride
+
+__device__ __forceinline__ double dpp_row_shr3_keep(double old, double src)
+{
+    // row_shr:3, bound_ctrl off: lanes whose source lane lies outside their row of 16 keep `old`
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0x113, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0x113, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(256) void k_am_grp(const float *__restrict__ env, const float *__restrict__ mu,
                                                 double *__restrict__ Yf, double *__restrict__ mxout, int n,
                                                 long n_frames, AmCoef c)
 {
-    // Block-systolic (see k_iir4_sys): at macro-step m lane (frame g, section s) of wavefront 0 filters the whole 64-sample block
-    // m - s and leaves it in LDS, in place, for lane (g, s + 1).  12 frames x 5 sections per wavefront (4 lanes idle).
-    // Wavefront 1 does the memory traffic (round 3): it loads block m + 2, stages block m + 1 (envelope - mean) and writes block m - 5
-    // back while wavefront 0 runs the 64 recurrence steps of block m.  (As one wavefront the kernel waited for its own stores and
-    // prefetches — s_waitcnt vmcnt(0) in front of the recurrence loop — every block: 3.9 us per block of which the recurrence is 1.3;
-    // now 3.1 us.  Ablations: without the recurrence arithmetic 2.4 us, without it and without any global access still 2.0 us — the LDS
-    // hand-offs and the two barriers of a block are the floor of this shape.)
-    __shared__ double ebuf[2][SYS_G][SYS_T + 1];               // envelope - mean, the input block of section 0 (two blocks in flight)
-    __shared__ double xbuf[SYS_G][AM_NS - 1][SYS_T + 1];       // block handed from section s to s + 1 (in place)
-    __shared__ double ybuf[2][SYS_G][SYS_T + 1];               // block leaving the last section
+    __shared__ __align__(16) double ebuf[2][GRP_G][GRP_ES];   // envelope - mean: input block m in ebuf[m & 1]
+    __shared__ __align__(16) double ybuf[GRP_G + 1][GRP_YS];  // last section's output, sample i at i & 127; row GRP_G: where the other lanes' stores go
     const int lane = threadIdx.x & 63;
+    // role of this wavefront: 0 recurrence, 1 / 2 loads of the even / odd blocks, 3 stores.  (The dispatcher puts wavefront w of the three
+    // workgroups that share a CU on three different SIMDs — tools/ubench/simd_placement_probe.hip 683 25152 — so every recurrence wavefront
+    // has a SIMD's issue slots to itself, next to two load / store wavefronts of the other workgroups; rotating the roles by workgroup
+    // index undid that and cost 60 %.)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long f0 = (long)blockIdx.x * SYS_G;
-    const long nblk = ((long)n + SYS_T - 1) / SYS_T;
-    const long nstep = nblk + AM_NS - 1;
-    if (wave == 1) {
-        // ---------------- memory wavefront: lane = sample inside a block ----------------
-        double mxl[SYS_G];
+    const long f0 = (long)blockIdx.x * GRP_G;
+    const long nblk = ((long)n + GRP_T - 1) / GRP_T;
+    // macro-step m = 0 .. nblk: the recurrence wavefront runs the 64 / GRP_Q group-steps of input block m (block nblk: zeros, four
+    // group-steps — the drain of sections 1..4); the load wavefront of block m + 1's parity stages it and requests block m + 3; the store
+    // wavefront writes back the 64 outputs [64 (m - 1) - GRP_OFF, 64 m - GRP_OFF) that were complete when macro-step m - 1 ended.
+    // Loads and stores sit in DIFFERENT wavefronts, and each load wavefront has ONE block in flight: gfx9 counts loads and stores in one
+    // counter (vmcnt) and completes them out of order with respect to each other, so a wavefront with stores in flight can only wait for a
+    // load with vmcnt(0) — the whole store round trip, every block (round 3's single memory wavefront did) — and the compiler's counter
+    // bookkeeping gives vmcnt(0) in a loop with two blocks in flight as well.  Here
+    // a load wavefront's vmcnt(0) waits for exactly the block it needs, requested two macro-steps earlier; the store wavefront never waits.
+    if (wave == 1 || wave == 2) {
+        // ---------------- load wavefronts: lane = sample inside a block; this one owns the blocks of parity par ----------------
+        const int par = wave - 1;
+        float pre[GRP_G], mus[GRP_G];
 #pragma unroll
-        for (int gg = 0; gg < SYS_G; gg++) mxl[gg] = 0.0;
-        float preA[SYS_G], preB[SYS_G], mus[SYS_G];   // two blocks in flight: block k is loaded into preA (k even) / preB (k odd), three steps ahead
-#pragma unroll
-        for (int gg = 0; gg < SYS_G; gg++) mus[gg] = (f0 + gg < n_frames) ? mu[f0 + gg] : 0.0f;
-        unsigned nanmask = 0;  // bit gg: a NaN was seen in frame gg by this lane
-        auto load = [&](long blk, float (&pre)[SYS_G]) __attribute__((always_inline)) {
-            const long i = blk * SYS_T + lane;
-            if ((blk + 1) * SYS_T <= n && f0 + SYS_G <= n_frames) {   // wave-uniform: twelve unconditional loads
+        for (int gg = 0; gg < GRP_G; gg++) mus[gg] = (f0 + gg < n_frames) ? mu[f0 + gg] : 0.0f;
+        auto load = [&](long blk) __attribute__((always_inline)) {
+            const long i = blk * GRP_T + lane;
+            if ((blk + 1) * GRP_T <= n && f0 + GRP_G <= n_frames) {
                 const float *src = env + (size_t)f0 * n + i;
 #pragma unroll
-                for (int gg = 0; gg < SYS_G; gg++) pre[gg] = src[(size_t)gg * n];
+                for (int gg = 0; gg < GRP_G; gg++) pre[gg] = src[(size_t)gg * n];
             } else {
 #pragma unroll
-                for (int gg = 0; gg < SYS_G; gg++) {
+                for (int gg = 0; gg < GRP_G; gg++) {
                     const long ff = f0 + gg;
                     pre[gg] = (ff < n_frames && i < n) ? env[(size_t)ff * n + i] : 0.0f;
                 }
             }
         };
-        auto stage = [&](long blk, float (&pre)[SYS_G]) __attribute__((always_inline)) {     // pre[] holds block blk
+        auto stage = [&](long blk) __attribute__((always_inline)) {     // pre[] holds block blk (blk >= nblk: zeros)
+            if ((blk + 1) * GRP_T <= n && f0 + GRP_G <= n_frames) {     // a whole block of twelve frames (wave-uniform): no selects
 #pragma unroll
-            for (int gg = 0; gg < SYS_G; gg++) {
+                for (int gg = 0; gg < GRP_G; gg++) ebuf[blk & 1][gg][lane] = (double)__fsub_rn(pre[gg], mus[gg]);
+                return;
+            }
+#pragma unroll
+            for (int gg = 0; gg < GRP_G; gg++) {
                 const long ff = f0 + gg;
                 double e = 0.0;
-                if (ff < n_frames && blk * SYS_T + lane < n) e = (double)__fsub_rn(pre[gg], mus[gg]);  // float32 subtract (:185)
+                if (ff < n_frames && blk * GRP_T + lane < n) e = (double)__fsub_rn(pre[gg], mus[gg]);  // float32 subtract (:185)
                 ebuf[blk & 1][gg][lane] = e;
             }
         };
-        auto writeback = [&](long blk, int par) __attribute__((always_inline)) {  // ybuf[par] holds block blk of every frame
-            double yv[SYS_G];
+        load(par);
+        if (par == 0) {
+            stage(0);
+            load(2);
+        }
+        fused::lds_barrier();
+        for (long m = 0; m <= nblk; m++) {
+            if (((m + 1) & 1) == par) {         // block m + 1 is this wavefront's: into ebuf[par] while the recurrence reads the other buffer
+                stage(m + 1);
+                load(m + 3);
+            }
+            fused::lds_barrier();
+        }
+        return;
+    }
+    if (wave == 3) {
+        // ---------------- store wavefront: lane = sample inside a 64-sample window of the output ring ----------------
+        double mxl[GRP_G];
 #pragma unroll
-            for (int gg = 0; gg < SYS_G; gg++) yv[gg] = ybuf[par][gg][lane];
-            const long i = blk * SYS_T + lane;
+        for (int gg = 0; gg < GRP_G; gg++) mxl[gg] = 0.0;
+        unsigned nanmask = 0;
+        auto writeback = [&](long k) __attribute__((always_inline)) {  // outputs [64 k - OFF, 64 k - OFF + 64): complete when macro-step k has ended
+            const long i = k * GRP_T - GRP_OFF + lane;
+            double yv[GRP_G];
 #pragma unroll
-            for (int gg = 0; gg < SYS_G; gg++) {
+            for (int gg = 0; gg < GRP_G; gg++) yv[gg] = ybuf[gg][(int)(i & (2 * GRP_T - 1))];
+#pragma unroll
+            for (int gg = 0; gg < GRP_G; gg++) {
                 const long ff = f0 + gg;
-                if (ff < n_frames && i < n) {
+                if (ff < n_frames && i >= 0 && i < n) {
                     const double v = yv[gg];
                     Yf[(size_t)ff * n + i] = v;
                     const double av = fabs(v);
@@ -533,26 +583,14 @@ __global__ __launch_bounds__(128) void k_am_sys(const float *__restrict__ env, c
                 }
             }
         };
-        load(0, preA);
-        stage(0, preA);
-        if (nblk > 1) load(1, preB);
-        if (nblk > 2) load(2, preA);
-        fused::lds_barrier();   // LDS-only: the memory wavefront's loads and stores stay in flight across it
-        // beside macro-step m: block m + 1 into the other input buffer, block m + 3 requested, the block macro-step m - 1 finished written back
-        auto beside = [&](long m, float (&pre)[SYS_G]) __attribute__((always_inline)) {     // pre: the set holding block m + 1
-            if (m + 1 < nblk) stage(m + 1, pre);
-            if (m + 3 < nblk) load(m + 3, pre);
-            if (m >= AM_NS) writeback(m - AM_NS, (int)((m - 1) & 1));
+        fused::lds_barrier();
+        for (long m = 0; m <= nblk; m++) {
+            if (m >= 1) writeback(m - 1);
             fused::lds_barrier();
-        };
-        for (long m = 0; m < nstep; m += 2) {
-            beside(m, preB);
-            if (m + 1 < nstep) beside(m + 1, preA);
         }
-        writeback(nblk - 1, (int)((nstep - 1) & 1));
-        // per-frame peak: max over the 64 lanes (np.max propagates NaN)
+        writeback(nblk);   // (the range [64 nblk - GRP_OFF, 64 nblk): complete after the drain)
 #pragma unroll
-        for (int gg = 0; gg < SYS_G; gg++) {
+        for (int gg = 0; gg < GRP_G; gg++) {
             double mm = mxl[gg];
             int nn = (nanmask >> gg) & 1;
 #pragma unroll
@@ -566,73 +604,89 @@ __global__ __launch_bounds__(128) void k_am_sys(const float *__restrict__ env, c
         return;
     }
     // ---------------- recurrence wavefront ----------------
-    const int g = lane / AM_NS, s = lane - AM_NS * g;          // lanes 60..63: g = 12 -> idle
-    const bool lane_on = g < SYS_G;
+    __builtin_amdgcn_s_setprio(3);                             // the SIMD's other wavefronts (loads / stores of other workgroups) fill its gaps
+    const int row = lane >> 4, r = lane & 15;
+    const int s = r / 3, g3 = r - 3 * s;                       // r = 15: s = 5 -> idle lane
+    const int g = row * 3 + g3;
     Biquad cs = c.s[0];
 #pragma unroll
     for (int k = 1; k < AM_NS; k++)
         if (s == k) cs = c.s[k];
     double z0 = 0.0, z1 = 0.0;
-    auto step = [&](double x) {
-        const double xn = __dadd_rn(__dmul_rn(cs.b0, x), z0);
-        z0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, x), __dmul_rn(cs.a1, xn)), z1);
-        z1 = __dsub_rn(__dmul_rn(cs.b2, x), __dmul_rn(cs.a2, xn));
-        return xn;
-    };
-    fused::lds_barrier();
-    for (long m = 0; m < nstep; m++) {
-        const long blk = m - s;
-        const bool active = lane_on && blk >= 0 && blk < nblk;
-        const int gi = lane_on ? g : 0;
-        const double *src = s == 0 ? ebuf[m & 1][gi] : xbuf[gi][s > 0 ? s - 1 : 0];
-        double *dst = s == AM_NS - 1 ? ybuf[m & 1][gi] : xbuf[gi][s < AM_NS - 1 ? s : 0];
-        const int cnt = !active ? 0 : ((n - blk * SYS_T) < SYS_T ? (int)(n - blk * SYS_T) : SYS_T);
-        if (__all(!active || cnt == SYS_T)) {  // one code path per macro-step for the whole wavefront (in-place hand-off)
-            if (active) {
-#ifdef PSS_EXP_SYS_NOPF
-                for (int t0 = 0; t0 < SYS_T; t0 += 8) {
-                    double e8[8], y8[8];
+    double pa[GRP_Q], pb[GRP_Q];                               // this lane's outputs of the last two group-steps (alternating: no copies)
 #pragma unroll
-                    for (int k = 0; k < 8; k++) e8[k] = src[t0 + k];
+    for (int k = 0; k < GRP_Q; k++) pa[k] = pb[k] = 0.0;
+    const double *const ein = &ebuf[0][g][0];                  // (every lane reads its frame's row: only section 0 uses what it read)
+    // every lane stores every group-step — the last sections into their frame's ring, the others into a shared dump row: a store under
+    // `if (s == 4)` is a branch around it, and a basic-block boundary per group-step keeps the scheduler from running the next group's
+    // hand-off and first steps under the tail of this group's dependent chain (measured: 0.4 us of a 2.0 us block)
+    double *const yout = &ybuf[s == AM_NS - 1 ? g : GRP_G][0];
+    // one group-step: e[] = the frame's next eight input samples (used by section 0; the DPP overwrites the other lanes' in place),
+    // pin = the previous group-step's outputs, pout = this one's; jg = global group-step index
+    auto group = [&](double (&e)[GRP_Q], const double (&pin)[GRP_Q], double (&pout)[GRP_Q], long jg, bool gate) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) y8[k] = step(e8[k]);
+        for (int k = 0; k < GRP_Q; k++) e[k] = dpp_row_shr3_keep(e[k], pin[k]);
+        double a0 = z0, a1 = z1;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) dst[t0 + k] = y8[k];
-                }
-#else
-                // two groups of eight per turn, each group's inputs requested from LDS before the OTHER group's recurrence steps (a lone
-                // wavefront: the LDS round trip of a group otherwise stands in front of its 8 x 48 clocks); reading ahead is safe for the
-                // in-place hand-off — a position is read before this macro-step's write of it either way.  No register copies: the two
-                // groups alternate between two register sets (a rotating single set cost 16 moves per group and lost 14 %).
-                static_assert(SYS_T % 16 == 0, "block length");
-                double ea[8], eb[8], y8[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) ea[k] = src[k];
-#pragma unroll 1
-                for (int t0 = 0; t0 < SYS_T; t0 += 16) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) eb[k] = src[t0 + 8 + k];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) y8[k] = step(ea[k]);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) dst[t0 + k] = y8[k];
-                    if (t0 + 16 < SYS_T) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) ea[k] = src[t0 + 16 + k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) y8[k] = step(eb[k]);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) dst[t0 + 8 + k] = y8[k];
-                }
-#endif
-            }
+        for (int k = 0; k < GRP_Q; k++) {
+            const double xn = __dadd_rn(__dmul_rn(cs.b0, e[k]), a0);
+            a0 = __dadd_rn(__dsub_rn(__dmul_rn(cs.b1, e[k]), __dmul_rn(cs.a1, xn)), a1);
+            a1 = __dsub_rn(__dmul_rn(cs.b2, e[k]), __dmul_rn(cs.a2, xn));
+            pout[k] = xn;
+        }
+        if (gate) {                                            // the lane's data has not arrived yet (jg < s): the state stays (+0, +0)
+            const bool on = jg >= s;
+            z0 = on ? a0 : z0;
+            z1 = on ? a1 : z1;
         } else {
-            for (int t = 0; t < SYS_T; t++) {
-                if (t < cnt) {
-                    const double e = src[t];
-                    dst[t] = step(e);
-                }
+            z0 = a0;
+            z1 = a1;
+        }
+        if (!gate || jg >= AM_NS - 1) {   // (wave-uniform; a constant in the unrolled first block) group jg - 4 of the last section into the ring
+            double *dst = yout + (int)(((jg - (AM_NS - 1)) * GRP_Q) & (2 * GRP_T - 1));
+#pragma unroll
+            for (int k = 0; k < GRP_Q; k += 2) *reinterpret_cast<double2 *>(dst + k) = make_double2(pout[k], pout[k + 1]);
+        }
+    };
+    auto fetch = [&](double (&e)[GRP_Q], int par, int jj) __attribute__((always_inline)) {  // group jj of the block in ebuf[par]
+        const double *src = ein + par * (GRP_G * GRP_ES) + jj * GRP_Q;
+#pragma unroll
+        for (int k = 0; k < GRP_Q; k += 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(src + k);
+            e[k] = v.x;
+            e[k + 1] = v.y;
+        }
+    };
+    fused::lds_barrier();                                      // block 0 is staged
+    for (long m = 0; m <= nblk; m++) {
+        const int par = (int)(m & 1);
+        const long j0 = m * (GRP_T / GRP_Q);
+        double ea[GRP_Q], eb[GRP_Q];
+        fetch(ea, par, 0);
+        if (m == 0) {                                          // the first block: sections 1..4 start one group-step apart
+#pragma unroll
+            for (int jj = 0; jj < GRP_T / GRP_Q; jj += 2) {
+                fetch(eb, par, jj + 1);
+                group(ea, pb, pa, j0 + jj, jj < AM_NS - 1);
+                if (jj + 2 < GRP_T / GRP_Q) fetch(ea, par, jj + 2);
+                group(eb, pa, pb, j0 + jj + 1, jj + 1 < AM_NS - 1);
+            }
+        } else if (m < nblk) {
+#pragma unroll
+            for (int jj = 0; jj < GRP_T / GRP_Q; jj += 2) {
+                fetch(eb, par, jj + 1);
+                group(ea, pb, pa, j0 + jj, false);
+                if (jj + 2 < GRP_T / GRP_Q) fetch(ea, par, jj + 2);
+                group(eb, pa, pb, j0 + jj + 1, false);
+            }
+        } else {                                               // the drain: four group-steps on the zero block
+            static_assert((AM_NS - 1) % 2 == 0, "the drain is whole pairs of group-steps");
+#pragma unroll
+            for (int jj = 0; jj < AM_NS - 1; jj += 2) {
+                fetch(eb, par, jj + 1);
+                group(ea, pb, pa, j0 + jj, nblk == 0);
+                if (jj + 2 < AM_NS - 1) fetch(ea, par, jj + 2);
+                group(eb, pa, pb, j0 + jj + 1, nblk == 0);
             }
         }
         fused::lds_barrier();
@@ -3069,8 +3123,8 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         r = launch_pairwise<1>(ctx, d_iq, n_frames, n, mu, env);
         if (r) return r;
         pss_kernel_begin(ctx, "k_am_iir");
-        if (n_frames < 32768)  // few frames: spread the sections over lanes (5.3x more wavefronts)
-            hipLaunchKernelGGL(k_am_sys, dim3((unsigned)((n_frames + SYS_G - 1) / SYS_G)), dim3(128), 0, PSS_STREAM(ctx), env, mu, Yf,
+        if (n_frames < 32768)  // few frames: spread the sections over lanes (5.3x more wavefronts), register hand-offs between them
+            hipLaunchKernelGGL(k_am_grp, dim3((unsigned)((n_frames + GRP_G - 1) / GRP_G)), dim3(256), 0, PSS_STREAM(ctx), env, mu, Yf,
                                mx, n, n_frames, c);
         else
             hipLaunchKernelGGL(k_am_iir, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), env, mu, Yf, mx, n, n_frames, c);

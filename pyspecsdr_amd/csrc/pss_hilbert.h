@@ -420,9 +420,6 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_rfft(const float2 *__r
     double *ex = reinterpret_cast<double *>(smem);
     float *exf = reinterpret_cast<float *>(smem);
     const int t = threadIdx.x;
-    // tw = exp(-2 pi i k / N), k < N: the M-point transform's bases are its even entries
-    const double2 w1 = tw[2 * t], w2 = tw[(size_t)(t % T2) * 32], w3 = tw[(size_t)(t % R4) * 512];
-    const double2 wn0 = tw[t];                               // W_N^t
     if (t < 72) ltaps[t] = taps.fwd[t];
     constexpr double INV_M = 1.0 / (double)M;
 #ifdef PSS_EXP_STAGGER   // timing experiment: the second workgroup of a CU starts late, so that the two are in different phases
@@ -493,7 +490,12 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_rfft(const float2 *__r
             v[0].y = pss::zdot_re_skx_lane([&](int j) { return (double)exf[j]; }, [&](int j) { return ltaps[i0 + 1 - j]; }, i0 + 2);
         }
         __syncthreads();                          // every window has been read: the buffer is the transforms' now
-        double2 u1 = w1, u2 = w2, u3 = w3;
+        // tw = exp(-2 pi i k / N), k < N: the M-point transform's bases are its even entries.  Fetched per frame, here (the table is 256 KB,
+        // L2-resident): held across the frame loop and the FIR these 16 registers are spilled (37 -> 21 spilled VGPRs at N = 16384; the
+        // kernel's time is the same either way, 1.39 ms min in a paired A/B — the scratch traffic was never what paced it)
+        int t3 = tt;
+        asm volatile("" : "+v"(t3));
+        double2 u1 = tw[2 * t3], u2 = tw[(size_t)(t3 % T2) * 32], u3 = tw[(size_t)(t3 % R4) * 512];
         asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
         // 3. Z = FFT_M(z): bin t + T q in y[q]
         double2 y[16];
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_rfft(const float2 *__r
             for (int q = 0; q < 16; q++) wr[q * T] = y[q].y;
             if (t == 0) ex[16 * T] = y[0].y;
             __syncthreads();
-            double2 wn = wn0;
+            double2 wn = tw[t3];                  // W_N^t
             asm volatile("" : "+v"(wn.x), "+v"(wn.y));
 #pragma unroll
             for (int q = 0; q < 16; q++) {

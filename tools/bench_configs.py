@@ -160,11 +160,13 @@ def _host_iq(iq, k):
 
 
 # ---- configs ---------------------------------------------------------------------------------------------------------------------------
-def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=False):
+def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=True):
     """BASELINE configs[2]: 16 384-point spectra x 8192 frames, AM + SSB (Hilbert) demodulation, AGC on (power per frame + stepper).
-    two_contexts=True runs the AM demodulator on a SECOND context (its own stream) beside the SSB demodulator and the spectrum — measured
-    in round 4: 3.75-3.88 ms against 3.83 ms in order on one stream (every kernel stretches by what it shares: the SSB workgroups hold 140 of a
-    CU's 160 KB of LDS, the AM workgroups need 50 KB, so the two partition the CUs instead of sharing them); kept as a switch, off."""
+    two_contexts=True (the default): the AM demodulator runs on a SECOND context (pss_create: its own stream) beside the power / AGC /
+    SSB / spectrum calls of the first — the two demodulators work on different buffers, nothing orders them.  With round 3's AM kernel
+    (50 KB of LDS per workgroup, three per CU) this gained nothing (3.75-3.88 against 3.83 ms: the SSB workgroups hold 140 of a CU's
+    160 KB, so the two kernels partitioned the CUs); round 4's k_am_grp needs 27 KB and is paced by one wavefront per SIMD, so the
+    SSB / spectrum workgroups run beside it: 3.36-3.38 ms against 3.66-3.74 in order on one stream (`ms_one_stream` in the entry)."""
     from pyspecsdr_amd.engine import Engine
     n, fs = 16384, 2.4e6
     iq_am = synth("am", nf, n, fs, dev, 20260928 + 3)
@@ -199,7 +201,12 @@ def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=False):
         eng.agc_steps(pw, nf, 20, 29, gi)                 # ... and the gain stepper (:898-919), interval gate off
         eng.demod(L.MODE_USB, iq_ssb, nf, n, fs, pcm_usb, None)
         eng.spectrum_db(iq_am, nf, n, db)                 # compute_fft (:2275)
-    ms, kt = timed(Both(), one, 5, launch_only)
+    ms, kt = timed(Both(), one, 10, launch_only)
+    ms_one = None
+    if eng2 is not eng and not launch_only:      # the same calls in order on one stream, for the record
+        keep, eng2 = eng2, eng
+        ms_one, _ = timed(Both(), one, 10, False)
+        eng2 = keep
     ver = None
     if verify and not launch_only:
         O = _oracle()
@@ -230,6 +237,8 @@ def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=False):
     e = _entry("cfg3", f"{nf} frames x {n}-pt @2.4 MS/s: measure_signal_power + AGC steps, demodulate AM, demodulate USB (hilbert round "
                f"trip executed) -> int16 stereo, compute_fft dB rows (BASELINE.json configs[2])", ms, kt, algo, nf * n, ver)
     e["contexts"] = 2 if two_contexts else 1
+    if ms_one is not None:
+        e["ms_one_stream"] = round(ms_one, 4)
     if kt:
         e["kernel_ms_sum"] = round(sum(v["ms"] * v["launches"] for v in kt.values()), 4)
     return e

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mean / min launch times of the kernels of ONE demodulate call at a given batch shape (HIP events), for the library PSS_LIBRARY selects:
 
-    PSS_LIBRARY=pyspecsdr_amd/libpss_x.so python tools/time_demod.py USB 8192 16384 [fs] [reps]
+    PSS_LIBRARY=pyspecsdr_amd/libpss_x.so PSS_OPTS="am_lds_handoff=1" python tools/time_demod.py USB 8192 16384 [fs] [reps]
 """
 import os
 import sys
@@ -17,6 +17,9 @@ nf, n = int(sys.argv[2]), int(sys.argv[3])
 fs = float(sys.argv[4]) if len(sys.argv) > 4 else 2.4e6
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
 e = Engine(0, order="none")
+for kv in os.environ.get("PSS_OPTS", "").split(","):      # PSS_OPTS="am_lds_handoff=1,small_batch=0"
+    if kv:
+        e.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 g = torch.Generator(device="cuda").manual_seed(7)
 iq = torch.randn((nf, n, 2), generator=g, device="cuda", dtype=torch.float32) * 0.3 + 0.2
 n_out = e.demod_out_len(mode, n, fs)

@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O2 tools/ubench/simd_placement_probe.hip -o /tmp/simd_probe && /tmp/simd_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <map>
 
@@ -20,12 +21,14 @@ __global__ __launch_bounds__(256, 4) void probe(unsigned *out, long spin)
     }
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const int wgs = 1024;
+    // simd_probe [workgroups] [dynamic LDS bytes]   (k_am_grp's shape: 683 workgroups x 256 threads, 25152 bytes of LDS)
+    const int wgs = argc > 1 ? atoi(argv[1]) : 1024;
+    const int lds = argc > 2 ? atoi(argv[2]) : 37 * 1024;
     unsigned *d;
     hipMalloc(&d, wgs * 4 * 2 * sizeof(unsigned));
-    hipLaunchKernelGGL(probe, dim3(wgs), dim3(256), 37 * 1024, 0, d, 2000000L);
+    hipLaunchKernelGGL(probe, dim3(wgs), dim3(256), lds, 0, d, 2000000L);
     hipDeviceSynchronize();
     std::vector<unsigned> h(wgs * 8);
     hipMemcpy(h.data(), d, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
