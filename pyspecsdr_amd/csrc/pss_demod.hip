@@ -506,11 +506,12 @@ __global__ __launch_bounds__(256) void k_am_grp(const float *__restrict__ env, c
     // macro-step m = 0 .. nblk: the recurrence wavefront runs the 64 / GRP_Q group-steps of input block m (block nblk: zeros, four
     // group-steps — the drain of sections 1..4); the load wavefront of block m + 1's parity stages it and requests block m + 3; the store
     // wavefront writes back the 64 outputs [64 (m - 1) - GRP_OFF, 64 m - GRP_OFF) that were complete when macro-step m - 1 ended.
-    // Loads and stores sit in DIFFERENT wavefronts, and each load wavefront has ONE block in flight: gfx9 counts loads and stores in one
-    // counter (vmcnt) and completes them out of order with respect to each other, so a wavefront with stores in flight can only wait for a
-    // load with vmcnt(0) — the whole store round trip, every block (round 3's single memory wavefront did) — and the compiler's counter
-    // bookkeeping gives vmcnt(0) in a loop with two blocks in flight as well.  Here
-    // a load wavefront's vmcnt(0) waits for exactly the block it needs, requested two macro-steps earlier; the store wavefront never waits.
+    // Loads and stores sit in DIFFERENT wavefronts, and each load wavefront has ONE block in flight.  Round 3's single memory wavefront
+    // kept two blocks of loads and a block of stores in flight and needed the oldest twelve loads to stage a block; the waits the compiler
+    // put there were vmcnt(11) .. vmcnt(0) — everything younger drained too, i.e. the round trip of the stores just issued, every block
+    // (its in-order counting does not survive this loop's bounds-checked paths; a loads-only wavefront with two blocks in flight got the
+    // same).  Here vmcnt(0) is the right wait: a load wavefront waits for exactly the block it requested two macro-steps earlier, and the
+    // store wavefront never waits.
     if (wave == 1 || wave == 2) {
         // ---------------- load wavefronts: lane = sample inside a block; this one owns the blocks of parity par ----------------
         const int par = wave - 1;
