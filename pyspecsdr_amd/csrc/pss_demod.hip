@@ -3845,7 +3845,7 @@ static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_fram
     pss_time_begin(ctx);
     // Schedule: forward kernel (VALU-bound, fills the machine) ->
     //   { backward pass (latency-bound, one wavefront per SIMD)  ||  spectrum -> post-process -> display lines }.
-    // Measured alternatives (rounds 2 / 3): the spectrum in front of the fork (+2 %); the whole display chain on the side
+    // Measured alternatives (rounds 2 - 4, NOTEBOOK.md R4-08 and A5): the spectrum in front of the fork (+2 %); the whole display chain on the side
     // stream from the start (-5 % when the forward kernel reaches the dispatcher first, +8 % when it does not); the two streams on
     // disjoint CU masks (hipExtStreamCreateWithCUMask, 128..240 of 256 CUs for the forward kernel: +5 % at best — both halves of the
     // step scale with the CUs they get); the spectrum kernel handing discriminator rows to the forward kernel (+2 %).

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_hilbert_xl(const float
 //     Z'[k] = (H[k] + conj H[M-k]) / 2 + i (H[k] - conj H[M-k]) / 2 conj W_N^k,   z' = IFFT_M(Z'),   real(hilbert(r))[2m], [2m+1] = Re, Im z'[m].
 // Two M-point transforms instead of two N-point ones: half the butterflies and half the exchange traffic, and — what matters most — a frame of
 // 16 384 samples is a workgroup of 512 threads with 70 KB of LDS, so TWO frames are resident per CU and one's LDS / HBM phases run under the
-// other's arithmetic (the N-point form is one 1024-thread workgroup per CU whose phases can only follow each other: DESIGN.md §4).
+// other's arithmetic (the N-point form is one 1024-thread workgroup per CU whose phases can only follow each other: DESIGN.md §4.2).
 // The pair (k, M - k) lives in threads t and T - t: one component-wise exchange fetches the partner, the rest is local to a thread.
 //   1. the frame's I samples are staged in LDS as float32, unpadded (element i at i);
 //   2. thread t computes the FIR outputs 2 (t + T q), 2 (t + T q) + 1, q < 16 — exactly its transform inputs z[t + T q], so the FIR output
