@@ -1982,3 +1982,28 @@ def test_display_lines_without_materialised_rows(n):
     e.sync()
     for k in range(3):
         assert torch.equal(out[0][k], out[1][k]), (n, k)
+
+
+@pytest.mark.gpu
+def test_am_small_batch_array_at_group_and_block_edges():
+    """k_am_grp (round 4): the AM band-pass as a group-systolic array — five section lanes per frame handing groups of eight samples on in
+    registers, 64-sample blocks staged by two load wavefronts, a 128-sample output ring drained by a store wavefront 32 samples out of step
+    with the blocks.  Frame lengths around every group / block / ring boundary, batches around the 12 frames of a wavefront and the lanes of
+    its DPP rows, a silent frame (0 / 0 -> NaN audio, PCM 0) and leading zeros, against the oracle: float64 audio bits and int16 PCM."""
+    rng = np.random.default_rng(404)
+    e = G.engine()
+    sos = np.empty((5, 6))
+    e.lib.pss_am_bandpass_sos(sos.ctypes.data)
+    for n in (1, 2, 7, 8, 9, 31, 32, 33, 39, 40, 41, 63, 64, 65, 95, 96, 97, 127, 128, 129, 191, 192, 193, 1000, 4097):
+        for nf in (1, 2, 3, 4, 11, 12, 13, 25):
+            iq = (0.3 + 0.2 * rng.standard_normal((nf, n)) + 0.2j * rng.standard_normal((nf, n))).astype(np.complex64)
+            if nf >= 3:
+                iq[1] = 0                       # silence
+                iq[2, : n // 2] = 0             # leading zeros, then signal
+            pcm, audio = G.demod(L.MODE_AM, iq, 2.4e6)
+            for f in range(nf):
+                a = O.demod_am(iq[f], sos)
+                fin = ~np.isnan(a)
+                assert np.array_equal(np.isnan(audio[f]), ~fin), (n, nf, f)
+                assert np.array_equal(audio[f][fin].view(np.uint64), a[fin].view(np.uint64)), (n, nf, f)    # bits: -0.0 is not +0.0 here
+                assert np.array_equal(pcm[f], O.pcm16_stereo(a)), (n, nf, f)
