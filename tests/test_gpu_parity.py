@@ -2007,3 +2007,28 @@ def test_am_small_batch_array_at_group_and_block_edges():
                 assert np.array_equal(np.isnan(audio[f]), ~fin), (n, nf, f)
                 assert np.array_equal(audio[f][fin].view(np.uint64), a[fin].view(np.uint64)), (n, nf, f)    # bits: -0.0 is not +0.0 here
                 assert np.array_equal(pcm[f], O.pcm16_stereo(a)), (n, nf, f)
+
+
+@pytest.mark.gpu
+def test_bench_other_configs_small_batches_verify():
+    """tools/bench_configs.py — what bench.py's `other_configs` runs after the headline — at a fraction of every batch: each config must time,
+    carry its fields and pass its own oracle / resident-pipeline verification (cfg 3 on two contexts, cfg 4, cfg 5 resident and streamed, WFM
+    step).  The full batches run in the driver's bench; this keeps the code path under pytest."""
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, _os.path.join(root, "tools"))
+    import bench_configs as BC
+    from pyspecsdr_amd.engine import Engine
+    eng = Engine(0, order="none")
+    try:
+        oc = BC.other_configs(eng, torch.device("cuda", 0), verify=True, small=True)
+    finally:
+        eng.close()
+    assert set(oc) == {"cfg3", "cfg4", "cfg5_resident", "cfg5_streamed", "wfm_step"}
+    for name, e in oc.items():
+        assert "error" not in e, (name, e.get("error"))
+        assert e["verified"]["ok"], (name, e["verified"])
+        assert e["ms"] > 0 and e["algo_bytes"] > 0 and 0 < e["frac"] < 1, name
+    assert oc["cfg3"]["contexts"] == 2 and oc["cfg3"]["ms_one_stream"] > 0
+    assert oc["cfg5_streamed"]["h2d_GBs"] > 1 and oc["cfg5_streamed"]["bound"] == "pcie"

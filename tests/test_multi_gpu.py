@@ -227,3 +227,33 @@ def test_two_contexts_in_one_process_interleaved():
     for k in out["a"]:
         assert torch.equal(out["a"][k].cpu(), out["b"][k].cpu()), k
     b.close(); a.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("script,extra", [("bench.py", ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--frames", "4096"]),
+                                          ("tools/bench_multi.py", ["--config", "cfg4"])])
+def test_rccl_path_runs_with_one_rank(script, extra):
+    """The nccl (= RCCL) side of the multi-GPU drivers with a world of ONE rank (PSS_BENCH_DIST=1): process-group initialisation on the GPU,
+    the packed gather to rank 0 on the side stream, the barrier fences and the all-reduce of the verification flag — everything an N-rank
+    run executes except the transport between GPUs, which a one-GPU box cannot show.  bench.py's line must carry the exchange fields."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PSS_BENCH_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, script)] + extra, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    if script == "bench.py":
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["ranks"]["backend"] == "nccl" and line["n_gpus"] == 1
+        assert line["verified"]["ok"] and line["verified"]["ok_all_ranks"]
+        assert line["exchange_display_ms"] is not None and line["compute_ms"] is not None and line["overlap_frac"] is not None
