@@ -2010,10 +2010,11 @@ def test_am_small_batch_array_at_group_and_block_edges():
 
 
 @pytest.mark.gpu
-def test_bench_other_configs_small_batches_verify():
-    """tools/bench_configs.py — what bench.py's `other_configs` runs after the headline — at a fraction of every batch: each config must time,
-    carry its fields and pass its own oracle / resident-pipeline verification (cfg 3 on two contexts, cfg 4, cfg 5 resident and streamed, WFM
-    step).  The full batches run in the driver's bench; this keeps the code path under pytest."""
+@pytest.mark.parametrize("small", [True, False])
+def test_bench_other_configs_verify(small):
+    """tools/bench_configs.py — what bench.py's `other_configs` runs after the headline — at a fraction of every batch and at the FULL
+    BASELINE batches (cfg 3: 8192 x 16 384, cfg 4: 8192 x 4096, cfg 5: 48 828 x 2048 resident and streamed, WFM step: 65 536 x 1024): each
+    config must time, carry its fields and pass its own oracle / resident-pipeline verification (cfg 3 on two contexts)."""
     import os as _os
     import sys as _sys
     root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
@@ -2022,7 +2023,7 @@ def test_bench_other_configs_small_batches_verify():
     from pyspecsdr_amd.engine import Engine
     eng = Engine(0, order="none")
     try:
-        oc = BC.other_configs(eng, torch.device("cuda", 0), verify=True, small=True)
+        oc = BC.other_configs(eng, torch.device("cuda", 0), verify=True, small=small)
     finally:
         eng.close()
     assert set(oc) == {"cfg3", "cfg4", "cfg5_resident", "cfg5_streamed", "wfm_step"}
