@@ -358,93 +358,11 @@ namespace {
 // (k_pairwise itself follows the shared reduction helpers further down)
 
 // ---------------------------------------------------------------------------------------------------
-// AM: envelope - mean (float32) -> 5-section Butterworth band-pass, forward only, zero state (float64).
-// One wavefront per tile of 64 frames, lane = frame (the recurrence is serial in time).  The five sections run
-// as a skewed pipeline (section s works on sample t-s: five independent dependency chains per step); because the
-// filter starts from a zero state, the pipeline is filled and drained by simply feeding zeros (a biquad with zero
-// state maps 0 to 0 exactly), so every step is the same straight-line code.  Each lane walks its own IQ row with
-// 16-byte loads (two samples) through a 2 x 16-deep register prefetch and writes y[] back to its own row.
+// AM: envelope - mean (float32) -> 5-section Butterworth band-pass, forward only, zero state (float64): k_am_grp below.
+// (Rounds 1-3 also had k_am_iir, one lane per frame with the five sections as a skewed pipeline, for batches of 32 768 frames and more;
+// the section-per-lane array is faster at every batch size since round 4 — 0.99 against 1.66 ms at 262 144 x 1024 — and it is gone.)
 // ---------------------------------------------------------------------------------------------------
 constexpr int AM_NS = 5;
-constexpr int AM_CH = 16;
-
-__global__ __launch_bounds__(TILE) void k_am_iir(const float *__restrict__ env, const float *__restrict__ mu,
-                                                 double *__restrict__ Yf, double *__restrict__ mxout, int n,
-                                                 long n_frames, AmCoef c)
-{
-    const int lane = threadIdx.x;
-    const long f = (long)blockIdx.x * TILE + lane;
-    const long fr = f < n_frames ? f : n_frames - 1;  // masked lanes replay the last frame (results dropped)
-    const float *x = env + (size_t)fr * n;            // |samples| (float32), written by k_pairwise<1>
-    double *y = Yf + (size_t)fr * n;
-    const float m = mu[fr];
-    double z[2 * AM_NS], p[AM_NS - 1];
-#pragma unroll
-    for (int i = 0; i < 2 * AM_NS; i++) z[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < AM_NS - 1; i++) p[i] = 0.0;
-    auto step = [&](double xin) {
-        double xs[AM_NS], b0x[AM_NS], v[AM_NS], w[AM_NS], xn[AM_NS], t[AM_NS], u[AM_NS];
-        xs[0] = xin;
-#pragma unroll
-        for (int k = 1; k < AM_NS; k++) xs[k] = p[k - 1];
-#pragma unroll
-        for (int k = 0; k < AM_NS; k++) {
-            b0x[k] = __dmul_rn(c.s[k].b0, xs[k]);
-            v[k] = __dmul_rn(c.s[k].b1, xs[k]);
-            w[k] = __dmul_rn(c.s[k].b2, xs[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < AM_NS; k++) xn[k] = __dadd_rn(b0x[k], z[2 * k]);
-#pragma unroll
-        for (int k = 0; k < AM_NS; k++) { t[k] = __dmul_rn(c.s[k].a1, xn[k]); u[k] = __dmul_rn(c.s[k].a2, xn[k]); }
-#pragma unroll
-        for (int k = 0; k < AM_NS; k++) { v[k] = __dsub_rn(v[k], t[k]); w[k] = __dsub_rn(w[k], u[k]); }
-#pragma unroll
-        for (int k = 0; k < AM_NS; k++) { z[2 * k] = __dadd_rn(v[k], z[2 * k + 1]); z[2 * k + 1] = w[k]; }
-#pragma unroll
-        for (int k = 0; k < AM_NS - 1; k++) p[k] = xn[k];
-        return xn[AM_NS - 1];
-    };
-    auto envelope = [&](float a) { return (double)__fsub_rn(a, m); };  // float32 subtract (:185)
-    double mx = 0.0;
-    bool nan = false;
-    auto keep = [&](long t, double v) {  // output of step t belongs to sample t - (AM_NS - 1)
-        const long i = t - (AM_NS - 1);
-        if (i >= 0) {
-            y[i] = v;
-            double av = fabs(v);
-            nan = nan || (av != av);
-            mx = av > mx ? av : mx;
-        }
-    };
-    const long T = (long)n + AM_NS - 1;            // steps incl. drain
-    const bool aligned = ((size_t)fr * n) % 4 == 0;  // 16-byte loads need a sample offset that is a multiple of 4
-    const long nfull = aligned ? n / AM_CH : 0;
-    float b0[AM_CH], b1[AM_CH];
-    auto loadc = [&](float (&b)[AM_CH], long r) {
-        const float4 *q = reinterpret_cast<const float4 *>(x + r);
-#pragma unroll
-        for (int k = 0; k < AM_CH / 4; k++) { float4 v4 = q[k]; b[4 * k] = v4.x; b[4 * k + 1] = v4.y; b[4 * k + 2] = v4.z; b[4 * k + 3] = v4.w; }
-    };
-    auto runc = [&](float (&b)[AM_CH], long r) {
-#pragma unroll
-        for (int k = 0; k < AM_CH; k++) keep(r + k, step(envelope(b[k])));
-    };
-    long r = 0;
-    if (nfull > 0) loadc(b0, 0);
-    for (long ch = 0; ch < nfull; ch += 2) {
-        if (ch + 1 < nfull) loadc(b1, r + AM_CH);
-        runc(b0, r);
-        if (ch + 1 < nfull) {
-            if (ch + 2 < nfull) loadc(b0, r + 2 * AM_CH);
-            runc(b1, r + AM_CH);
-        }
-        r += 2 * AM_CH;
-    }
-    for (r = nfull * AM_CH; r < T; r++) keep(r, step(r < n ? envelope(x[r]) : 0.0));
-    if (f < n_frames) mxout[f] = nan ? __builtin_nan("") : mx;
-}
 
 __device__ __forceinline__ double dpp_row_shr1(double v)
 {
@@ -455,9 +373,9 @@ __device__ __forceinline__ double dpp_row_shr1(double v)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// AM band-pass for SMALL batches (BASELINE cfg 3: 8192 frames; the shim's single buffer).  With lane = frame (k_am_iir) a batch of F
-// frames keeps only F / 64 wavefronts busy; here the five sections of one frame sit in five lanes and the recurrence runs as a systolic
-// array: a wavefront carries 12 frames (5.3x more wavefronts), each lane one section's state update per sample instead of 45 instructions.
+// AM band-pass (every batch size).  With one lane per frame a batch of F frames keeps only F / 64 wavefronts busy, each running 45 dependent
+// float64 instructions per sample; here the five sections of one frame sit in five lanes and the recurrence runs as a systolic array: a
+// wavefront carries 12 frames (5.3x more wavefronts), each lane one section's state update per sample.
 // GROUP-systolic (round 4): a section hands its output to the next one in REGISTERS, eight samples at a time.  The lanes of a 16-lane
 // DPP row are laid out r = 3 s + g' (section s = 0..4, frame g' = 0..2 of the row; r = 15 idle), so `row_shr:3` moves the eight outputs
 // of (g', s) to (g', s + 1): 16 v_mov_b32_dpp per group-step.  The lanes r < 3 (section 0) have no source lane inside their row: with
@@ -465,7 +383,7 @@ __device__ __forceinline__ double dpp_row_shr1(double v)
 // At group-step j lane s works on group j - s; only section 0's LDS reads (the staged envelope - mean) and section 4's LDS writes (a
 // 128-sample ring per frame) carry data.  Every section still executes exactly biquad_step()'s operations on exactly its own sample
 // sequence from a (+0, +0) state (the first group-steps of a lane, before its data arrives, run on a copy of the state that is not
-// committed), so the output bits are k_am_iir's.
+// committed), so the output bits are those of a plain per-frame cascade (the oracle's).
 // Four wavefronts per workgroup: the recurrence, two that load and stage the even / odd input blocks, one that stores — see the kernel.
 // History: round 3's k_am_sys handed whole 64-sample blocks from section to section through LDS (128 full-wavefront LDS instructions per
 // block) and had ONE memory wavefront: 3.1 us per block, 0.82 ms at cfg 3.  This kernel: 2.5 us per block, 0.64 ms (one workgroup alone:
@@ -3123,12 +3041,8 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         pss_time_begin(ctx);
         r = launch_pairwise<1>(ctx, d_iq, n_frames, n, mu, env);
         if (r) return r;
-        pss_kernel_begin(ctx, "k_am_iir");
-        if (n_frames < 32768)  // few frames: spread the sections over lanes (5.3x more wavefronts), register hand-offs between them
-            hipLaunchKernelGGL(k_am_grp, dim3((unsigned)((n_frames + GRP_G - 1) / GRP_G)), dim3(256), 0, PSS_STREAM(ctx), env, mu, Yf,
-                               mx, n, n_frames, c);
-        else
-            hipLaunchKernelGGL(k_am_iir, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx), env, mu, Yf, mx, n, n_frames, c);
+        pss_kernel_begin(ctx, "k_am_grp");
+        hipLaunchKernelGGL(k_am_grp, dim3((unsigned)((n_frames + GRP_G - 1) / GRP_G)), dim3(256), 0, PSS_STREAM(ctx), env, mu, Yf, mx, n, n_frames, c);
         pss_kernel_end(ctx);
         size_t total = (size_t)n_frames * n;
         size_t g = (total + TPB - 1) / TPB;

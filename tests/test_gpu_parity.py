@@ -2007,6 +2007,15 @@ def test_am_small_batch_array_at_group_and_block_edges():
                 assert np.array_equal(np.isnan(audio[f]), ~fin), (n, nf, f)
                 assert np.array_equal(audio[f][fin].view(np.uint64), a[fin].view(np.uint64)), (n, nf, f)    # bits: -0.0 is not +0.0 here
                 assert np.array_equal(pcm[f], O.pcm16_stereo(a)), (n, nf, f)
+    # a batch far beyond the CUs' capacity for resident workgroups (rounds 1-3 switched to a lane-per-frame kernel at 32 768 frames)
+    nf, n = 70000, 300
+    iq = (0.3 + 0.2 * rng.standard_normal((nf, n)) + 0.2j * rng.standard_normal((nf, n))).astype(np.complex64)
+    pcm, audio = G.demod(L.MODE_AM, iq, 2.4e6)
+    for f in (0, 11, 12, 4097, 32767, 32768, 69999):
+        a = O.demod_am(iq[f], sos)
+        assert np.array_equal(audio[f].view(np.uint64), a.view(np.uint64)), f
+        assert np.array_equal(pcm[f], O.pcm16_stereo(a)), f
+
 
 
 @pytest.mark.gpu
