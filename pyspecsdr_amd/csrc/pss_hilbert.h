@@ -439,6 +439,19 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_rfft(const float2 *__r
         __syncthreads();
         // 2. the FIR, straight into the transform's input registers: v[q] = (r[2 (t + T q)], r[2 (t + T q) + 1])
         double2 v[16];
+        // the pipeline's state: the five sample pairs and eight taps of the step about to run (primed with the first window's first step)
+        const double y64h = taps.rev[64];
+        float2 c0, c1, c2, c3, c4;
+        double tc[8];
+        {
+            const float *x0 = (tt < 32) ? exf : exf + 2 * tt - 64;
+            c0 = *reinterpret_cast<const float2 *>(x0); c1 = *reinterpret_cast<const float2 *>(x0 + 2); c2 = *reinterpret_cast<const float2 *>(x0 + 4);
+            c3 = *reinterpret_cast<const float2 *>(x0 + 6); c4 = *reinterpret_cast<const float2 *>(x0 + 8);
+            int z0 = 0;
+            asm volatile("" : "+s"(z0));
+#pragma unroll
+            for (int k = 0; k < 8; k++) tc[k] = taps.rev[z0 + k];
+        }
 #pragma unroll 1
         for (int g = 0; g < 4; g++) {
             int z = 0;
@@ -450,25 +463,53 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_rfft(const float2 *__r
                 // (q = 0, t < 32: the window starts before the frame — those 64 outputs are the edge tree's below; read in bounds)
                 const float *xp = (i == 0) ? ((g == 0 && tt < 32) ? exf : xg) : xg + 2 * T * i;
                 double acc[2][4][2];
-                float2 nx = *reinterpret_cast<const float2 *>(xp);
+                // software pipeline over the steps of the windows: the NEXT step's samples (LDS) and taps (kernarg segment: scalar loads) — at a
+                // window's last step: the next window's first step — are requested before this step's sixteen FMAs and waited for at the top of the
+                // next step.  Requested at the step that uses them, every step began with an s_waitcnt lgkmcnt(0) on loads issued two
+                // instructions earlier: an LDS + scalar-cache round trip per step, 128 of them per thread and frame.
+                const float *xnext = (i < 3) ? xg + 2 * T * (i + 1) : (g < 3 ? xg + 8 * T : xg);   // (after the last window: any in-bounds address, unused)
+                float2 nx7 = c4;
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
-                    asm volatile("" : "+s"(z));   // ... nor kept across steps: a step's 8 taps (16 SGPRs) are loaded for that step (all 65 live at once spill)
-                    const float2 p0 = nx, p1 = *reinterpret_cast<const float2 *>(xp + 8 * it + 2), p2 = *reinterpret_cast<const float2 *>(xp + 8 * it + 4),
-                                 p3 = *reinterpret_cast<const float2 *>(xp + 8 * it + 6);
-                    nx = *reinterpret_cast<const float2 *>(xp + 8 * it + 8);
-                    const double xs[9] = {(double)p0.x, (double)p0.y, (double)p1.x, (double)p1.y, (double)p2.x,
-                                          (double)p2.y, (double)p3.x, (double)p3.y, (double)nx.x};
+                    const double xs[9] = {(double)c0.x, (double)c0.y, (double)c1.x, (double)c1.y, (double)c2.x,
+                                          (double)c2.y, (double)c3.x, (double)c3.y, (double)c4.x};
+                    if (it == 7) nx7 = c4;
+                    __builtin_amdgcn_sched_barrier(0);
+                    float2 n0 = c4, n1, n2, n3, n4;
+                    double tn[8];
+                    if (it < 7) {
+                        asm volatile("" : "+s"(z));   // (a step's 8 taps = 16 SGPRs, two steps' worth live: all 65 at once spill)
+                        n1 = *reinterpret_cast<const float2 *>(xp + 8 * it + 10);
+                        n2 = *reinterpret_cast<const float2 *>(xp + 8 * it + 12);
+                        n3 = *reinterpret_cast<const float2 *>(xp + 8 * it + 14);
+                        n4 = *reinterpret_cast<const float2 *>(xp + 8 * it + 16);
+#pragma unroll
+                        for (int k = 0; k < 8; k++) tn[k] = taps.rev[z + 8 * it + 8 + k];
+                    } else {
+                        asm volatile("" : "+s"(z));
+                        n0 = *reinterpret_cast<const float2 *>(xnext);
+                        n1 = *reinterpret_cast<const float2 *>(xnext + 2);
+                        n2 = *reinterpret_cast<const float2 *>(xnext + 4);
+                        n3 = *reinterpret_cast<const float2 *>(xnext + 6);
+                        n4 = *reinterpret_cast<const float2 *>(xnext + 8);
+#pragma unroll
+                        for (int k = 0; k < 8; k++) tn[k] = taps.rev[z + k];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int a = 0; a < 4; a++)
 #pragma unroll
                         for (int pp = 0; pp < 2; pp++) {
-                            const double y = taps.rev[z + 8 * it + 2 * a + pp];
+                            const double y = tc[2 * a + pp];
                             acc[0][a][pp] = __fma_rn(xs[2 * a + pp], y, it == 0 ? 0.0 : acc[0][a][pp]);
                             acc[1][a][pp] = __fma_rn(xs[2 * a + pp + 1], y, it == 0 ? 0.0 : acc[1][a][pp]);
                         }
+                    c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) tc[k] = tn[k];
                 }
-                const double y64 = taps.rev[z + 64];
+                const float2 nx = nx7;
+                const double y64 = y64h;
                 double r[2];
 #pragma unroll
                 for (int o = 0; o < 2; o++) {
