@@ -294,12 +294,20 @@ static void fft_f64(double *re, double *im, int n)
             t = im[i]; im[i] = im[j]; im[j] = t;
         }
     }
-    double *wr = (double *)malloc(sizeof(double) * (n / 2 + 1));
-    double *wi = (double *)malloc(sizeof(double) * (n / 2 + 1));
-    for (int k = 0; k < n / 2; k++) {
-        double ang = -2.0 * M_PI * (double)k / (double)n;
-        wr[k] = cos(ang);
-        wi[k] = sin(ang);
+    /* the twiddles of the most recent length, kept per thread (the batched drivers transform thousands of frames of one length: the
+     * cos / sin of every frame were a third of compute_fft's time); same values, same arithmetic */
+    static __thread double *wr = NULL, *wi = NULL;
+    static __thread int w_n = 0;
+    if (w_n != n) {
+        free(wr); free(wi);
+        wr = (double *)malloc(sizeof(double) * (n / 2 + 1));
+        wi = (double *)malloc(sizeof(double) * (n / 2 + 1));
+        for (int k = 0; k < n / 2; k++) {
+            double ang = -2.0 * M_PI * (double)k / (double)n;
+            wr[k] = cos(ang);
+            wi[k] = sin(ang);
+        }
+        w_n = n;
     }
     for (int len = 2; len <= n; len <<= 1) {
         int half = len >> 1, step = n / len;
@@ -314,8 +322,6 @@ static void fft_f64(double *re, double *im, int n)
                 im[i + k] += ti;
             }
     }
-    free(wr);
-    free(wi);
 }
 
 /* Any length: powers of two go to fft_f64; other lengths (np.fft.fft takes any n; the sweep driver reads int(0.1 fs)
@@ -359,8 +365,16 @@ static void fft_any_f64(double *re, double *im, int n)
 void pss_o_compute_fft(const float *iq, int n, double *db)
 {
     double *re = (double *)malloc(sizeof(double) * n), *im = (double *)malloc(sizeof(double) * n);
+    static __thread double *win = NULL;     /* np.hamming(n) of the most recent length, per thread */
+    static __thread int win_n = 0;
+    if (win_n != n) {
+        free(win);
+        win = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
+        for (int i = 0; i < n; i++) win[i] = (n == 1) ? 1.0 : 0.54 - 0.46 * cos(2.0 * M_PI * (double)i / (double)(n - 1));
+        win_n = n;
+    }
     for (int i = 0; i < n; i++) {
-        double w = (n == 1) ? 1.0 : 0.54 - 0.46 * cos(2.0 * M_PI * (double)i / (double)(n - 1));
+        const double w = win[i];
         re[i] = (double)iq[2 * i] * w;
         im[i] = (double)iq[2 * i + 1] * w;
     }
@@ -1246,12 +1260,17 @@ void pss_o_batch_spectrum_post_nfm(const float *iq, long n_frames, int n, double
     int n_out = (int)(((long)n - 1 + q - 1) / q);
     (void)n_threads;
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(n_threads) schedule(static)
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+    /* scratch once per thread, contiguous blocks of frames per thread (schedule(static)) */
+    double *db = (double *)malloc(sizeof(double) * n);
+    double *po = (double *)malloc(sizeof(double) * n);
+    double *au = (double *)malloc(sizeof(double) * (n_out + 1));
+#ifdef _OPENMP
+#pragma omp for schedule(static)
 #endif
     for (long f = 0; f < n_frames; f++) {
-        double *db = (double *)malloc(sizeof(double) * n);
-        double *po = (double *)malloc(sizeof(double) * n);
-        double *au = (double *)malloc(sizeof(double) * (n_out + 1));
         pss_o_compute_fft(iq + 2 * f * n, n, db);
         for (int k = 0; k < n; k++) db_out[f * n + k] = (float)db[k];
         if (post_out) {
@@ -1267,9 +1286,10 @@ void pss_o_batch_spectrum_post_nfm(const float *iq, long n_frames, int n, double
         }
         pss_o_demod_nfm(iq + 2 * f * n, n, fs, q, taps, sos, zi, au, 0, 0);
         pss_o_pcm16_stereo(au, n_out, pcm_out + 2 * f * n_out);
-        free(db);
-        free(po);
-        free(au);
+    }
+    free(db);
+    free(po);
+    free(au);
     }
 }
 
@@ -1392,3 +1412,72 @@ void pss_o_persistence_rows(const float *rows, long n_frames, int len, int windo
     free(rhi);
 }
 
+
+/* The reference's own step per read buffer with its own row type — float64 from IQ to cells: compute_fft returns float64
+ * (signal_processing.py:243-264), the caller smooths and clamps those rows (pyspecsdr.py:2278-2283), draw_waterfall normalises and
+ * quantises them (:1342-1406).  db_out / post_out / pcm_out may be NULL; lo_out / hi_out: finite extremes of every post-processed row. */
+void pss_o_batch_headline_f64(const float *iq, long n_frames, int n, double fs, int q, const double *taps, const double *sos,
+                              const double *zi, double *db_out, double *post_out, double *lo_out, double *hi_out, int16_t *pcm_out,
+                              int n_threads)
+{
+    int n_out = (int)(((long)n - 1 + q - 1) / q);
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+        double *db = (double *)malloc(sizeof(double) * n);
+        double *po = (double *)malloc(sizeof(double) * n);
+        double *au = (double *)malloc(sizeof(double) * (n_out + 1));
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (long f = 0; f < n_frames; f++) {
+            pss_o_compute_fft(iq + 2 * f * n, n, db);
+            if (db_out) memcpy(db_out + f * n, db, sizeof(double) * n);
+            pss_o_postprocess(db, n, po);
+            if (post_out) memcpy(post_out + f * (n - 4), po, sizeof(double) * (n - 4));
+            double lo = INFINITY, hi = -INFINITY;
+            for (int k = 0; k < n - 4; k++) {
+                const double v = po[k];
+                if (isfinite(v)) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+            }
+            lo_out[f] = lo;
+            hi_out[f] = hi;
+            if (pcm_out) {
+                pss_o_demod_nfm(iq + 2 * f * n, n, fs, q, taps, sos, zi, au, 0, 0);
+                pss_o_pcm16_stereo(au, n_out, pcm_out + 2 * f * n_out);
+            }
+        }
+        free(db); free(po); free(au);
+    }
+}
+
+/* pss_o_waterfall_rows on float64 rows, with the rows' extremes supplied (row_lo / row_hi [n_frames], e.g. from pss_o_batch_headline_f64). */
+void pss_o_waterfall_rows_f64(const double *rows, const double *row_lo, const double *row_hi, long n_frames, int len, int window, int disp_w,
+                              int8_t *glyph, int8_t *colour, int n_threads)
+{
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+#endif
+    for (long f = 0; f < n_frames; f++) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (long p = f - (window - 1) < 0 ? 0 : f - (window - 1); p <= f; p++) {
+            lo = row_lo[p] < lo ? row_lo[p] : lo;
+            hi = row_hi[p] > hi ? row_hi[p] : hi;
+        }
+        const double *row = rows + f * len;
+        for (int x = 0; x < disp_w; x++) {
+            const double v = interp_row(row, len, disp_w, x);
+            int8_t g = -1, ci = -1;
+            if (isfinite(v)) {
+                const double nv = (v - lo) / (hi - lo);
+                ci = (int8_t)(int)(nv * 5);
+                g = nv > 0.75 ? 3 : nv > 0.5 ? 2 : nv > 0.25 ? 1 : 0;
+            }
+            glyph[f * disp_w + x] = g;
+            colour[f * disp_w + x] = ci;
+        }
+    }
+}

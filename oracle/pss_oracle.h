@@ -122,6 +122,14 @@ void pss_o_batch_spectrum_nfm(const float *iq, long n_frames, int n, double fs, 
 void pss_o_batch_spectrum_post_nfm(const float *iq, long n_frames, int n, double fs, int q, const double *taps,
                                    const double *sos, const double *zi, float *db_out, float *post_out, float *lo_out,
                                    float *hi_out, int16_t *pcm_out, int n_threads);
+/* the same step in the reference's own row type, float64 from IQ to cells (compute_fft returns float64; pyspecsdr.py:2278-2283 and
+ * draw_waterfall :1342-1406 work on those rows): dB / post-processed rows (nullable), finite extremes per row, NFM PCM (nullable); and the
+ * waterfall line of every frame from float64 rows and their extremes */
+void pss_o_batch_headline_f64(const float *iq, long n_frames, int n, double fs, int q, const double *taps, const double *sos,
+                              const double *zi, double *db_out, double *post_out, double *lo_out, double *hi_out, int16_t *pcm_out,
+                              int n_threads);
+void pss_o_waterfall_rows_f64(const double *rows, const double *row_lo, const double *row_hi, long n_frames, int len, int window, int disp_w,
+                              int8_t *glyph, int8_t *colour, int n_threads);
 /* batched waterfall accumulator: newest display line per frame, history of `window` rows (pyspecsdr.py:1342-1406). */
 void pss_o_waterfall_rows(const float *rows, long n_frames, int len, int window, int disp_w, int8_t *glyph, int8_t *colour,
                           int n_threads);

@@ -144,6 +144,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     for (auto &kv : ctx->nfm) if (kv.second.d_rev) hipFree(kv.second.d_rev);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->scratch_fft) hipFree(ctx->scratch_fft);
+    if (ctx->scratch_hil) hipFree(ctx->scratch_hil);
     if (ctx->scratch_iqc) hipFree(ctx->scratch_iqc);
     if (ctx->d_hann) hipFree(ctx->d_hann);
     if (ctx->d_hann_short) hipFree(ctx->d_hann_short);
@@ -224,10 +225,10 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "hilbert_exact")) { ctx->hilbert_exact = value != 0; return PSS_OK; }
     if (!strcmp(key, "scan_exact")) { ctx->scan_exact = value != 0; return PSS_OK; }
     if (!strcmp(key, "db_exact")) { ctx->db_exact = value != 0; return PSS_OK; }
+    if (!strcmp(key, "f64_plain")) { ctx->f64_plain = value != 0; return PSS_OK; }
 #ifdef PSS_VARIANTS   // kernel-selection knobs for A/B measurements: variant builds only (tools/build_variant.py <name> -DPSS_VARIANTS)
     if (!strcmp(key, "ssb_unfused")) { ctx->ssb_unfused = value != 0; return PSS_OK; }
     if (!strcmp(key, "fft_two_per_wg")) { ctx->fft_two_per_wg = value != 0; return PSS_OK; }
-    if (!strcmp(key, "pipe_sched")) { ctx->pipe_sched = value; return PSS_OK; }
     if (!strcmp(key, "fft_split")) { ctx->fft_split = value; return PSS_OK; }
     if (!strcmp(key, "fft_big_scratch")) { ctx->fft_big_scratch = value != 0; return PSS_OK; }
     if (!strcmp(key, "fft_prefetch")) { ctx->fft_prefetch = value; return PSS_OK; }

@@ -82,11 +82,12 @@ struct pss_ctx {
     size_t scratch_iqc_bytes = 0;
     void *scratch_fft = nullptr;   // spectrum scratch: separate, the spectrum kernel may run on the side stream
     size_t scratch_fft_bytes = 0;
+    void *scratch_hil = nullptr;   // hilbert() of rows longer than 16384 samples (spectrum Z + pre-pass scratch): the demodulator's, never shared with the side stream's spectrum
+    size_t scratch_hil_bytes = 0;
     void *stage = nullptr;         // device staging of the host-buffer convenience calls (grow-only)
     size_t stage_bytes = 0;
     bool ssb_unfused = false;      // (-DPSS_VARIANTS builds) demodulate_ssb at 8192 / 16384 samples as k_ssb_fir + k_hilbert_xl (the round-2 shape)
     bool fft_two_per_wg = false;   // (-DPSS_VARIANTS builds) N = 2048 spectra with two frames per 256-thread workgroup (the round-2 shape)
-    int pipe_sched = 0;        // (-DPSS_VARIANTS builds) schedule experiments of pss_frame_pipeline_nfm
     bool no_wfm_fused = false;  // option "wfm_fused" = 0: k_wfm_front + k_nfm_iir path (A/B testing)
     long small_batch_max = 8192;  // option "small_batch_max": largest frame count that takes the small-batch path (measured crossover ~12000)
     long wfm_small_batch_max = 6000;  // option "wfm_small_batch_max" (crossover with the fused kernels, 1024-sample frames: ~12000 frames in round 2, ~6000 since the small-batch path is one array: 0.58 / 1.13 ms at 4096 / 8192 frames against 0.83)
@@ -94,6 +95,7 @@ struct pss_ctx {
     bool ssb_rfft = true;      // option "ssb_rfft": frames of 8192 / 16384 samples evaluate hilbert() as a real transform pair (k_ssb_rfft); 0: two full-length complex transforms (k_ssb_hilbert_xl)
     bool ssb_hilbert = true;   // option "ssb_hilbert": run the reference's hilbert() round trip inside demodulate_ssb where a register transform exists for the frame length
     bool db_exact = false;         // true: compute_fft's dB rows evaluated to float64 accuracy and rounded once (= float32 of the reference's float64 rows); false: float32 evaluation, 1-2 ulp off, 15-25 % faster kernels
+    bool f64_plain = false;        // option "f64_plain": the float64-row entry points (pss_spectrum_db_f64, pss_spectrum_post_f64, pss_frame_pipeline_nfm_f64) on the plain round-3 kernels (generic LDS transform with hypot / log10, radix select) instead of the register kernels: A/B reference
     bool scan_exact = true;        // scanner slices: NumPy's float32 chain bit for bit (scan_db_np); false: the float64 / hardware-log2 dB of compute_fft
     int fft_xl4096 = -1;           // N = 4096 on the component-wise-exchange kernel (pss_fft_xl.h, R4 = 1) instead of k_spectrum_r16<4>; -1 = scanner slices only
     bool post_legacy = false;  // option "post_legacy": LDS bitonic sort / LDS-histogram radix select instead of the register select
@@ -169,6 +171,13 @@ bool pss_hilbert_supported(int n);
 int pss_hilbert_rows(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_out, int out_mode, unsigned long long *d_maxbits,
                      int16_t *d_pcm);
 int pss_fft_tables(pss_ctx *ctx, int n, const double2 **tw, const double **win);
+// pss_frame_pipeline's display chain behind the dB rows (rows of either type): thresholds + extremes + the rows resampled to the display
+// width in one pass (no post-processed rows in memory), sliding extremes, the line of every frame.  d_vals: n_frames x disp_w doubles.
+bool pss_post_sel_serves(const pss_ctx *ctx, int n_fft, bool f64);
+int pss_chain_vals_f32(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_lo, float *d_hi, int n_halo, int window, int display,
+                       int disp_h, int disp_w, int8_t *d_a, int8_t *d_b, double *d_vals);
+int pss_chain_vals_f64(pss_ctx *ctx, const double *d_db, long n_frames, int n_fft, double *d_lo, double *d_hi, int n_halo, int window, int display,
+                       int disp_h, int disp_w, int8_t *d_a, int8_t *d_b, double *d_vals);
 bool pss_ssb_fused_supported(int n);
 // NumPy's float64 tan / exp under its AVX512_SKX dispatch (SVML's _ha routines restated, pss_design.cpp)
 double pss_np_tan(double x);

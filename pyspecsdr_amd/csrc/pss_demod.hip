@@ -3616,13 +3616,6 @@ extern "C" int pss_get_wfm_filters(pss_ctx *ctx, double fs, double *lp3x6, doubl
     return PSS_OK;
 }
 
-#ifdef PSS_VARIANTS
-__global__ void k_spin(long ticks)     // ~10 ns per tick of the 100 MHz counter
-{
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
-}
-#endif
 
 extern "C" int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db,
                                 int16_t *d_pcm)
@@ -3659,65 +3652,77 @@ extern "C" int pss_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, 
 }
 
 // One iteration of the reference's main loop for a whole batch of read buffers (pyspecsdr.py:2262-2283 + the display call):
-// demodulate_signal(samples, fs, 'NFM') -> int16; compute_fft -> dB row; smoothing + median clamp; waterfall accumulator
-// line.  The demodulator's backward pass is latency-bound (one wavefront per SIMD), the whole display chain is HBM-bound:
-// behind the forward kernel the two run side by side on two streams (fork / join with events).
-// The same iteration with the reference's own row type: float64 dB rows, float64 post-processed rows and extremes, the waterfall line
-// quantised from those (pss_waterfall_rows_f64) — the cells the reference draws from this IQ, not those of the float32 rows.  Plain
-// kernels in order on the context's stream; the demodulator is the same.
-extern "C" int pss_frame_pipeline_nfm_f64(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, double *d_db, double *d_post,
-                                          double *d_row_lo, double *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
-                                          int8_t *d_colour, int16_t *d_pcm)
+// demodulate_signal(samples, fs, mode) -> int16; compute_fft -> dB row; smoothing + median clamp; display accumulator line.
+// Rows of either type through the SAME schedule: TR = float (pss_frame_pipeline[_nfm]: float32 dB rows, the contract of the spectrum
+// output) or TR = double (pss_frame_pipeline_nfm_f64: the reference's own row type from IQ to cells — compute_fft returns float64 and the
+// caller smooths, clamps and draws float64: these are the reference's cells).
+namespace {
+inline int pipe_spectrum(pss_ctx *ctx, const float *d_iq, long nf, int n, float *d_db) { return pss_spectrum_db(ctx, d_iq, nf, n, d_db); }
+inline int pipe_spectrum(pss_ctx *ctx, const float *d_iq, long nf, int n, double *d_db) { return pss_spectrum_db_f64(ctx, d_iq, nf, n, d_db); }
+inline int pipe_post(pss_ctx *ctx, const float *d_db, long nf, int n, float *d_post, float *lo, float *hi) { return pss_spectrum_post_extremes(ctx, d_db, nf, n, d_post, lo, hi); }
+inline int pipe_post(pss_ctx *ctx, const double *d_db, long nf, int n, double *d_post, double *lo, double *hi) { return pss_spectrum_post_f64(ctx, d_db, nf, n, d_post, lo, hi); }
+inline int pipe_lines(pss_ctx *ctx, int display, const float *d_post, long nf, int len, const float *lo, const float *hi, int n_halo, int window, int disp_h,
+                      int disp_w, int8_t *a, int8_t *b)
 {
-    if (!ctx) return PSS_E_ARG;
-    PSS_GUARD(ctx);
-    if (n_frames > 0 && (!d_db || !d_post || !d_row_lo || !d_row_hi || !d_glyph || !d_colour || !d_pcm))
-        return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_nfm_f64: null buffer");
-    pss_time_begin(ctx);
-    int r = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
-    if (!r) r = pss_spectrum_db_f64(ctx, d_iq, n_frames, n, d_db);
-    if (!r) r = pss_spectrum_post_f64(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
-    if (!r) r = pss_waterfall_rows_f64(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
-    pss_time_end(ctx);
-    return r;
+    return display ? pss_persistence_rows(ctx, d_post, nf, len, lo, hi, n_halo, window, disp_h, disp_w, a)
+                   : pss_waterfall_rows(ctx, d_post, nf, len, lo, hi, n_halo, window, disp_w, a, b);
 }
+inline int pipe_lines(pss_ctx *ctx, int display, const double *d_post, long nf, int len, const double *lo, const double *hi, int n_halo, int window, int disp_h,
+                      int disp_w, int8_t *a, int8_t *b)
+{
+    return display ? pss_persistence_rows_f64(ctx, d_post, nf, len, lo, hi, n_halo, window, disp_h, disp_w, a)
+                   : pss_waterfall_rows_f64(ctx, d_post, nf, len, lo, hi, n_halo, window, disp_w, a, b);
+}
+inline int pipe_chain_vals(pss_ctx *ctx, const float *d_db, long nf, int n, float *lo, float *hi, int n_halo, int window, int display, int disp_h, int disp_w,
+                           int8_t *a, int8_t *b, double *vals)
+{
+    return pss_chain_vals_f32(ctx, d_db, nf, n, lo, hi, n_halo, window, display, disp_h, disp_w, a, b, vals);
+}
+inline int pipe_chain_vals(pss_ctx *ctx, const double *d_db, long nf, int n, double *lo, double *hi, int n_halo, int window, int display, int disp_h, int disp_w,
+                           int8_t *a, int8_t *b, double *vals)
+{
+    return pss_chain_vals_f64(ctx, d_db, nf, n, lo, hi, n_halo, window, display, disp_h, disp_w, a, b, vals);
+}
+}  // namespace
 
 // display: 0 = the waterfall accumulator's newest line (d_glyph, d_colour), 1 = the persistence accumulator's newest trace (d_glyph = row
-// index per column, d_colour unused).  Lines of the display chain, whichever stream it is queued on:
-static int pipeline_lines(pss_ctx *ctx, int display, const float *d_db, const float *d_post, const float *d_thr, long n_frames, int n,
-                          const float *d_row_lo, const float *d_row_hi, int n_halo, int window, int disp_h, int disp_w, int8_t *d_glyph,
-                          int8_t *d_colour)
-{
-    if (d_thr)
-        return display ? pss_persistence_rows_db(ctx, d_db, n_frames, n, d_thr, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph)
-                       : pss_waterfall_rows_db(ctx, d_db, n_frames, n, d_thr, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
-    return display ? pss_persistence_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph)
-                   : pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
-}
-
-static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
-                          float *d_row_lo, float *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
+// index per column, d_colour unused).
+// d_post == NULL: the post-processed rows are not materialised.  Rows the register select serves (a multiple of 4 points, up to 32 772 /
+// float64: 16 388): ONE pass over the dB rows leaves per row the extremes and the row resampled to the display width (disp_w float64
+// values: what the accumulators normalise and quantise), and the lines are quantised from those — the same bytes as from materialised rows.
+// Other lengths go through a context-owned scratch copy of the rows.
+template <class TR>
+static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, TR *d_db, TR *d_post,
+                          TR *d_row_lo, TR *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
                           int8_t *d_glyph, int8_t *d_colour, int16_t *d_pcm)
 {
+    constexpr bool F64 = sizeof(TR) == 8;
     if (n_frames < 0 || n_halo < 0 || window < 1 || disp_w < 1 || (display != 0 && display != 1) || (display == 1 && (disp_h < 1 || disp_h > 127)))
         return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline: bad frame count, halo, window or display geometry");
     if (n < 8) return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline: frames of fewer than 8 samples have no post-processed row to draw");
     if (n_frames > 0 && (!d_iq || !d_db || !d_row_lo || !d_row_hi || !d_glyph || (!d_colour && display == 0) || !d_pcm))
         return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline: null buffer");
+    double *d_vals = nullptr;
+    if (n_frames > 0 && !d_post) {
+        const bool direct = pss_post_sel_serves(ctx, n, F64) && !(F64 && ctx->f64_plain);
+        const size_t need = direct ? (size_t)n_frames * disp_w * sizeof(double) : (size_t)n_frames * (n - 4) * sizeof(TR);
+        int rq = pss_ensure_buffer(ctx, &ctx->scratch_post, &ctx->scratch_post_bytes, need, "post-process scratch");
+        if (rq) return rq;
+        if (direct) d_vals = reinterpret_cast<double *>(ctx->scratch_post);
+        else d_post = reinterpret_cast<TR *>(ctx->scratch_post);
+    }
+    // the display chain behind the dB rows, on whichever stream it is queued
+    auto chain_behind_db = [&]() -> int {
+        if (d_vals) return pipe_chain_vals(ctx, d_db, n_frames, n, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w, d_glyph, d_colour, d_vals);
+        int q = pipe_post(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+        if (!q) q = pipe_lines(ctx, display, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph, d_colour);
+        return q;
+    };
     if (mode != PSS_MODE_NFM) {
         // AM / USB / LSB / WFM (demodulate_signal's dispatcher semantics: WFM frames are IQ-corrected first, signal_processing.py:222-225).
         // None of these demodulators has the NFM path's two-phase shape, so the display chain simply runs on the side stream beside the whole
         // demodulator: WFM's forward kernel keeps one wavefront per SIMD busy for ~1 ms (float64 issue), AM's recurrence kernel two thirds
         // of the SIMDs — the HBM-bound chain fits in beside them.
-        float *d_thr2 = nullptr;
-        if (n_frames > 0 && !d_post) {
-            const bool direct = (n & 3) == 0 && n - 4 <= 32768 && !ctx->post_legacy;
-            const size_t need = direct ? (size_t)n_frames * sizeof(float) : (size_t)n_frames * (n - 4) * sizeof(float);
-            int rq = pss_ensure_buffer(ctx, &ctx->scratch_post, &ctx->scratch_post_bytes, need, "post-process scratch");
-            if (rq) return rq;
-            if (direct) d_thr2 = reinterpret_cast<float *>(ctx->scratch_post);
-            else d_post = reinterpret_cast<float *>(ctx->scratch_post);
-        }
         pss_time_begin(ctx);
         int r = PSS_OK;
         const float *d_in = d_iq;
@@ -3734,59 +3739,22 @@ static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_fram
         int rc;
         {
             PssStreamScope side(ctx->cur, ctx->stream2);
-            rc = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);     // compute_fft sees the samples as read (pyspecsdr.py:2275), not the corrected ones
-            if (!rc) rc = d_thr2 ? pss_spectrum_post_thresholds(ctx, d_db, n_frames, n, d_thr2, d_row_lo + n_halo, d_row_hi + n_halo)
-                                 : pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
-            if (!rc) rc = pipeline_lines(ctx, display, d_db, d_post, d_thr2, n_frames, n, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph, d_colour);
+            rc = pipe_spectrum(ctx, d_iq, n_frames, n, d_db);     // compute_fft sees the samples as read (pyspecsdr.py:2275), not the corrected ones
+            if (!rc) rc = chain_behind_db();
         }
         int rj = pss_hip_check(ctx, hipEventRecord(ctx->ev_join, ctx->stream2), "hipEventRecord(join)");
         if (!rj) rj = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)");
         pss_time_end(ctx);
         return rd ? rd : (rc ? rc : rj);
     }
-    // d_post == NULL: the post-processed rows are not materialised — the post-process leaves 12 bytes per row (clamp threshold,
-    // extremes) and the display kernel rebuilds the elements its cells need from the dB rows (rows of a multiple of 4 points up to
-    // 32 772; other lengths go through a context-owned scratch copy of the rows)
-    float *d_thr = nullptr;
-    if (n_frames > 0 && !d_post) {
-        const bool direct = (n & 3) == 0 && n - 4 <= 32768 && !ctx->post_legacy;
-        const size_t need = direct ? (size_t)n_frames * sizeof(float) : (size_t)n_frames * (n - 4) * sizeof(float);
-        int rq = pss_ensure_buffer(ctx, &ctx->scratch_post, &ctx->scratch_post_bytes, need, "post-process scratch");
-        if (rq) return rq;
-        if (direct) d_thr = reinterpret_cast<float *>(ctx->scratch_post);
-        else d_post = reinterpret_cast<float *>(ctx->scratch_post);
-    }
     pss_time_begin(ctx);
     // Schedule: forward kernel (VALU-bound, fills the machine) ->
     //   { backward pass (latency-bound, one wavefront per SIMD)  ||  spectrum -> post-process -> display lines }.
-    // Measured alternatives (rounds 2 - 4, NOTEBOOK.md R4-08 and A5): the spectrum in front of the fork (+2 %); the whole display chain on the side
-    // stream from the start (-5 % when the forward kernel reaches the dispatcher first, +8 % when it does not); the two streams on
-    // disjoint CU masks (hipExtStreamCreateWithCUMask, 128..240 of 256 CUs for the forward kernel: +5 % at best — both halves of the
-    // step scale with the CUs they get); the spectrum kernel handing discriminator rows to the forward kernel (+2 %).
-#ifdef PSS_VARIANTS
-    if (ctx->pipe_sched == 3 || ctx->pipe_sched == 5) {
-        // the display chain on the side stream FROM THE START of the step, but a few microseconds behind the forward kernel (a spin kernel),
-        // so that the forward kernel's workgroups are all resident before the chain's ask for room; the chain then fills the CUs as the
-        // forward kernel's workgroups retire (0.36 .. 0.55 ms after the launch).  sched 5: the spin only, no chain overlap control.
-        hipEventRecord(ctx->ev_fork, ctx->stream);
-        hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
-        int rq;
-        {
-            PssStreamScope side(ctx->cur, ctx->stream2);
-            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, ctx->stream2, (long)(ctx->pipe_sched == 3 ? 2000 : 200));
-            rq = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
-            if (!rq) rq = d_thr ? pss_spectrum_post_thresholds(ctx, d_db, n_frames, n, d_thr, d_row_lo + n_halo, d_row_hi + n_halo)
-                                : pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
-            if (!rq) rq = d_thr ? pss_waterfall_rows_db(ctx, d_db, n_frames, n, d_thr, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour)
-                                : pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
-        }
-        const int rn = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
-        hipEventRecord(ctx->ev_join, ctx->stream2);
-        hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
-        pss_time_end(ctx);
-        return rn ? rn : rq;
-    }
-#endif
+    // Measured alternatives (rounds 2 - 4, NOTEBOOK.md R4-08 and A5; the code of those experiments left the tree in round 5): the spectrum in
+    // front of the fork (+2 %); the whole display chain on the side stream from the start (-5 % when the forward kernel reaches the dispatcher
+    // first, +8 % when it does not); the two streams on disjoint CU masks (hipExtStreamCreateWithCUMask, 128..240 of 256 CUs for the forward
+    // kernel: +5 % at best — both halves of the step scale with the CUs they get); the spectrum kernel handing discriminator rows to the
+    // forward kernel (+2 %); everything in order on one stream; forward -> spectrum -> { backward || post-process -> lines }.
     int r2;
     ctx->pending_bwd = nullptr;
     const bool overlap = ctx->pipe_overlap > 0;
@@ -3805,52 +3773,13 @@ static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_fram
     }
     int r = r2;
     const bool beside_bwd = (bool)ctx->pending_bwd;
-    if (!r && !beside_bwd) r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
+    if (!r && !beside_bwd) r = pipe_spectrum(ctx, d_iq, n_frames, n, d_db);
     auto display_chain = [&]() -> int {
         int q = PSS_OK;
-        if (beside_bwd) q = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
-        if (d_thr) {
-            if (!q) q = pss_spectrum_post_thresholds(ctx, d_db, n_frames, n, d_thr, d_row_lo + n_halo, d_row_hi + n_halo);
-            if (!q) q = pipeline_lines(ctx, display, d_db, nullptr, d_thr, n_frames, n, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph, d_colour);
-            return q;
-        }
-        if (!q) q = pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
-        if (!q) q = pipeline_lines(ctx, display, d_db, d_post, nullptr, n_frames, n, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph, d_colour);
+        if (beside_bwd) q = pipe_spectrum(ctx, d_iq, n_frames, n, d_db);
+        if (!q) q = chain_behind_db();
         return q;
     };
-#ifdef PSS_VARIANTS   // schedule experiments (option "pipe_sched"; the default schedule is below)
-    if (ctx->pipe_sched && ctx->pending_bwd) {
-        auto bwd = ctx->pending_bwd;
-        ctx->pending_bwd = nullptr;
-        auto post_disp = [&]() -> int {
-            int q = d_thr ? pss_spectrum_post_thresholds(ctx, d_db, n_frames, n, d_thr, d_row_lo + n_halo, d_row_hi + n_halo)
-                          : pss_spectrum_post_extremes(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
-            if (!q) q = d_thr ? pss_waterfall_rows_db(ctx, d_db, n_frames, n, d_thr, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour)
-                              : pss_waterfall_rows(ctx, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_w, d_glyph, d_colour);
-            return q;
-        };
-        if (ctx->pipe_sched == 4) {          // everything in order on one stream
-            r = bwd();
-            if (!r) r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
-            if (!r) r = post_disp();
-        } else if (ctx->pipe_sched == 1) {   // forward -> spectrum -> { backward || post-process -> lines }
-            r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
-            hipEventRecord(ctx->ev_fork, ctx->stream);
-            hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
-            { PssStreamScope side(ctx->cur, ctx->stream2); if (!r) r = post_disp(); }
-            const int rb = bwd();
-            hipEventRecord(ctx->ev_join, ctx->stream2);
-            hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
-            if (!r) r = rb;
-        } else if (ctx->pipe_sched == 6) {   // forward -> backward -> { spectrum -> post -> lines } nothing beside (same as 4 but bwd first) 
-            r = bwd();
-            if (!r) r = pss_spectrum_db(ctx, d_iq, n_frames, n, d_db);
-            if (!r) r = post_disp();
-        }
-        pss_time_end(ctx);
-        return r;
-    }
-#endif
     if (ctx->pending_bwd) {
         auto bwd = ctx->pending_bwd;
         ctx->pending_bwd = nullptr;
@@ -3873,14 +3802,29 @@ static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_fram
     return r;
 }
 
+// The iteration with the reference's own row type: float64 dB rows, float64 post-processed rows (d_post may be NULL: not materialised) and
+// extremes, the waterfall line quantised from those — the cells the reference draws from this IQ, not those of the float32 rows.  The same
+// schedule and the same kernel families as the float32 call (register transform with a float64 dB evaluation and 8-byte stores, register
+// select on 64-bit keys); option "f64_plain" = 1: the plain round-3 kernels.  n: a power of two in [16, 65536].
+extern "C" int pss_frame_pipeline_nfm_f64(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, double *d_db, double *d_post,
+                                          double *d_row_lo, double *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
+                                          int8_t *d_colour, int16_t *d_pcm)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n < 16 || n > 65536 || (n & (n - 1))) return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_nfm_f64: n must be a power of two in [16, 65536]");
+    return frame_pipeline<double>(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, n_halo, window, 0, 0, disp_w, d_glyph,
+                                  d_colour, d_pcm);
+}
+
 extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
                                       float *d_row_lo, float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
                                       int8_t *d_colour, int16_t *d_pcm)
 {
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
-    return frame_pipeline(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, n_halo, window, 0, 0, disp_w, d_glyph,
-                          d_colour, d_pcm);
+    return frame_pipeline<float>(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, n_halo, window, 0, 0, disp_w, d_glyph,
+                                 d_colour, d_pcm);
 }
 
 extern "C" int pss_frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
@@ -3890,8 +3834,8 @@ extern "C" int pss_frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, lon
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
     if (mode < PSS_MODE_NFM || mode > PSS_MODE_WFM) return pss_fail(ctx, PSS_E_ARG, "unknown demodulation mode");
-    return frame_pipeline(ctx, mode, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w, d_line_a,
-                          d_line_b, d_pcm);
+    return frame_pipeline<float>(ctx, mode, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w, d_line_a,
+                                 d_line_b, d_pcm);
 }
 
 extern "C" int pss_set_nfm_filters(pss_ctx *ctx, double fs, const double *taps65, const double *sos4x6, const double *zi4x2)

@@ -723,6 +723,34 @@ int launch_r16(pss_ctx *ctx, const float *d_iq, long n_frames, float *d_db, cons
     return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_r16 launch");
 }
 
+// float64 dB rows (the reference's own row type) from the register kernels: the measured winner per length, float64 evaluation, 8-byte stores
+template <int LOG_R3>
+int launch_r16_f64(pss_ctx *ctx, const float *d_iq, long n_frames, double *d_db, const double2 *tw, const double *win)
+{
+    using C = pss_r16::Cfg<LOG_R3>;
+    constexpr bool split = LOG_R3 == 0, prefetch = LOG_R3 >= 1, one = LOG_R3 == 3;
+    auto kern = pss_r16::k_spectrum_r16<LOG_R3, false, split, prefetch, true, one, true>;
+    const int fpw = one ? 1 : C::FPW;
+    const size_t lds = split ? (size_t)C::FPW * C::EX * sizeof(double) + (size_t)C::TW2 * sizeof(double2)
+                             : (size_t)fpw * C::EX * sizeof(double2) + (size_t)C::TW2 * sizeof(double2);
+    if (lds > 64 * 1024)
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long groups = (n_frames + fpw - 1) / fpw;
+    const int wg_threads = fpw * C::T;
+    int per_cu = (int)((160 * 1024) / (lds + 256));
+    const int vgpr_cap = (split ? 4 : 2) * 256 / wg_threads;
+    if (per_cu > vgpr_cap) per_cu = vgpr_cap;
+    if (per_cu < 1) per_cu = 1;
+    const long cap = 256L * per_cu * 2;
+    pss_time_begin(ctx);
+    pss_kernel_begin(ctx, "k_spectrum");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(wg_threads), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq),
+                       reinterpret_cast<float *>(d_db), tw, win, n_frames, (float *)nullptr, (double *)nullptr, (int *)nullptr, 0.0, spec_flags(ctx));
+    pss_kernel_end(ctx);
+    pss_time_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_spectrum_r16 (float64 rows) launch");
+}
+
 template <bool SCAN>
 int launch_spectrum(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db, float *d_peak, double *d_bw,
                     int32_t *d_count, double bin_hz)
@@ -1179,9 +1207,11 @@ int hilbert_long(pss_ctx *ctx, const double *d_x, long n_rows, int n, double *d_
     const int grid = (int)(n_rows < 512 ? n_rows : 512);
     // Z [n_rows][N] + the per-workgroup pre-pass scratch [grid][N] (N <= 65536) or the pass-1 output Y [n_rows][N] (N >= 2^17)
     const size_t szZ = (size_t)n_rows * N * sizeof(double2), szS = (n <= 65536 ? (size_t)grid : (size_t)n_rows) * N * sizeof(double2);
-    int r = pss_ensure_buffer(ctx, &ctx->scratch_fft, &ctx->scratch_fft_bytes, szZ + szS, "hilbert spectrum");
+    // its own buffer, not scratch_fft: pss_frame_pipeline runs pss_spectrum_db (whose 2^15 .. 2^20-point kernels use scratch_fft) on the side
+    // stream at the same time as the demodulator that calls this
+    int r = pss_ensure_buffer(ctx, &ctx->scratch_hil, &ctx->scratch_hil_bytes, szZ + szS, "hilbert spectrum");
     if (r) return r;
-    double2 *Z = reinterpret_cast<double2 *>(ctx->scratch_fft), *S = Z + (size_t)n_rows * N;
+    double2 *Z = reinterpret_cast<double2 *>(ctx->scratch_hil), *S = Z + (size_t)n_rows * N;
     const HilLoadReal lx{d_x, N};
     const HilStoreMasked sz{Z, N};
     const HilLoadZ lz{Z, N};
@@ -1275,11 +1305,11 @@ static int hilbert_pf_long(pss_ctx *ctx, const double *d_x, long n_rows, int n, 
     long grid = (long)(((size_t)1 << 30) / per_wg);       // at most 1 GiB of scratch
     grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
     if (grid > n_rows) grid = n_rows;
-    r = pss_ensure_buffer(ctx, &ctx->scratch_fft, &ctx->scratch_fft_bytes, (size_t)grid * per_wg, "hilbert (exact) scratch");
+    r = pss_ensure_buffer(ctx, &ctx->scratch_hil, &ctx->scratch_hil_bytes, (size_t)grid * per_wg, "hilbert (exact) scratch");
     if (r) return r;
     pss_kernel_begin(ctx, "k_hilbert");
     hipLaunchKernelGGL(pss_pf::k_hilbert_pf_long, dim3((unsigned)grid), dim3(1024), 0, PSS_STREAM(ctx), d_x, d_out, tw, ilog2(n), n_rows, out_mode,
-                       d_maxbits, reinterpret_cast<double *>(ctx->scratch_fft));
+                       d_maxbits, reinterpret_cast<double *>(ctx->scratch_hil));
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_hilbert_pf_long launch");
 }
@@ -1421,6 +1451,17 @@ extern "C" int pss_spectrum_db_f64(pss_ctx *ctx, const float *d_iq, long n_frame
     const double *win;
     int r = pss_fft_tables(ctx, n_fft, &tw, &win);
     if (r) return r;
+    // 256 .. 4096 points: the register kernels (option "f64_plain" = 1: the generic LDS transform with hypot / log10, the round-3 path)
+    if (!ctx->f64_plain) {
+        switch (n_fft) {
+        case 256: return launch_r16_f64<0>(ctx, d_iq, n_frames, d_db, tw, win);
+        case 512: return launch_r16_f64<1>(ctx, d_iq, n_frames, d_db, tw, win);
+        case 1024: return launch_r16_f64<2>(ctx, d_iq, n_frames, d_db, tw, win);
+        case 2048: return launch_r16_f64<3>(ctx, d_iq, n_frames, d_db, tw, win);
+        case 4096: return launch_r16_f64<4>(ctx, d_iq, n_frames, d_db, tw, win);
+        default: break;
+        }
+    }
     const int logn = ilog2(n_fft), logNsub = logn < LOG_NSUB_MAX ? logn : LOG_NSUB_MAX;
     const size_t lds = ((size_t)1 << logNsub) * sizeof(double2);
     auto kern = k_spectrum<false, false, true>;
@@ -1484,33 +1525,56 @@ extern "C" int pss_scan_threshold(pss_ctx *ctx, const float *d_iq, long n_slices
 
 namespace {
 
-template <int EPL, int W>
-int launch_post_sel(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_lo, float *d_hi, float *d_thr)
+template <int EPL, int W, class TR>
+int launch_post_sel(pss_ctx *ctx, const TR *d_db, long n_frames, int n_fft, TR *d_post, TR *d_lo, TR *d_hi, TR *d_thr, double *d_vals = nullptr,
+                    int disp_w = 0)
 {
     constexpr int T = 64 * W, RPW = W == 1 ? 4 : 1;
-    const size_t lds = (size_t)RPW * (T + 1) * pss_post::PostCfg<EPL>::S * sizeof(float);
+    const size_t lds = (size_t)RPW * (T + 1) * pss_post::PostCfg<EPL, TR>::S * sizeof(TR);
     // the exact-fit specialisation (no padding tests) only for the read-buffer lengths of the display path: 1024, 2048, 4096 points
     constexpr bool FULL_BUILT = W == 1 ? EPL >= 16 : (W == 4 && EPL == 16);
-    auto kern = FULL_BUILT && n_fft == T * EPL ? pss_post::k_post_sel<EPL, W, FULL_BUILT> : pss_post::k_post_sel<EPL, W, false>;
+    auto kern = FULL_BUILT && n_fft == T * EPL ? pss_post::k_post_sel<EPL, W, FULL_BUILT, TR> : pss_post::k_post_sel<EPL, W, false, TR>;
     if (lds > 64 * 1024)
         PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long groups = (n_frames + RPW - 1) / RPW;
-    const long cap = 256L * (W == 1 ? 6 : (W <= 4 ? 4 : 1));
+    long per_cu = (long)((160 * 1024) / (lds + 512));
+    const long want = W == 1 ? 6 : (W <= 4 ? 4 : 1);
+    per_cu = per_cu < 1 ? 1 : (per_cu > want ? want : per_cu);
+    const long cap = 256L * per_cu;
     pss_kernel_begin(ctx, "k_post");
     hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(W == 1 ? 256 : 64 * W), lds, PSS_STREAM(ctx), d_db,
-                       d_post, n_fft, n_frames, d_lo, d_hi, d_thr);
+                       d_post, n_fft, n_frames, d_lo, d_hi, d_thr, d_vals, disp_w);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_post_sel launch");
 }
 
-// the register select kernel (k_post_sel) serves rows of a multiple of 4 points up to 32 772; only it can leave the rows unwritten
-bool post_sel_serves(const pss_ctx *ctx, int n_fft) { return !ctx->post_legacy && n_fft - 4 <= 32768 && (n_fft & 3) == 0; }
+// the register select kernel (k_post_sel) serves rows of a multiple of 4 points up to 32 772 (float64 rows: up to 16 388 — the staging
+// buffer of a longer row does not fit the LDS); only it can leave the rows unwritten
+bool post_sel_serves(const pss_ctx *ctx, int n_fft, bool f64 = false) { return !ctx->post_legacy && n_fft - 4 <= (f64 ? 16384 : 32768) && (n_fft & 3) == 0; }
+
+// the register select over rows of either type: rows written (d_post) or not, thresholds (d_thr), extremes, resampled rows (d_vals)
+template <class TR>
+int post_sel_any(pss_ctx *ctx, const TR *d_db, long n_frames, int n_fft, TR *d_post, TR *d_lo, TR *d_hi, TR *d_thr, double *d_vals, int disp_w)
+{
+    const int m = n_fft - 4;
+    if (m <= 256) return launch_post_sel<4, 1, TR>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr, d_vals, disp_w);
+    if (m <= 512) return launch_post_sel<8, 1, TR>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr, d_vals, disp_w);
+    if (m <= 1024) return launch_post_sel<16, 1, TR>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr, d_vals, disp_w);
+    if (m <= 2048) return launch_post_sel<32, 1, TR>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr, d_vals, disp_w);
+    if (m <= 4096) return launch_post_sel<16, 4, TR>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr, d_vals, disp_w);
+    if (m <= 8192) return launch_post_sel<32, 4, TR>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr, d_vals, disp_w);
+    if (m <= 16384) return launch_post_sel<16, 16, TR>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr, d_vals, disp_w);
+    if constexpr (sizeof(TR) == 4) return launch_post_sel<32, 16, TR>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr, d_vals, disp_w);
+    return pss_fail(ctx, PSS_E_ARG, "float64 rows longer than 16388 points: no register select");
+}
 
 // smoothing + median clamp of n_frames rows; d_lo / d_hi (both or neither) receive the finite extremes of every clamped row.
 // d_post == nullptr (with d_thr, d_lo, d_hi; rows k_post_sel serves): the rows are not written, only their clamp thresholds
 // float32(median - 10) and extremes — 12 bytes per row instead of 4 (n_fft - 4).
-int spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_lo, float *d_hi, float *d_thr = nullptr)
+int spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_post, float *d_lo, float *d_hi, float *d_thr = nullptr,
+                  double *d_vals = nullptr, int disp_w = 0)
 {
+    if (d_vals && !post_sel_serves(ctx, n_fft)) return pss_fail(ctx, PSS_E_ARG, "resampled rows: only from the register select kernel");
     if (n_frames < 0 || (n_frames > 0 && (!d_db || (!d_post && !(d_thr && d_lo))))) return pss_fail(ctx, PSS_E_ARG, "null pointer");
     if (!d_post && n_fft >= 8 && !post_sel_serves(ctx, n_fft))
         return pss_fail(ctx, PSS_E_ARG, "post-process without materialised rows: n_fft must be a multiple of 4 and at most 32772");
@@ -1522,14 +1586,7 @@ int spectrum_post(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, flo
     pss_time_begin(ctx);
     if (post_sel_serves(ctx, n_fft)) {
         // register-resident binary-search select: one wavefront per row up to 2048 points, 4 / 16 wavefronts above
-        if (m <= 256) r = launch_post_sel<4, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
-        else if (m <= 512) r = launch_post_sel<8, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
-        else if (m <= 1024) r = launch_post_sel<16, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
-        else if (m <= 2048) r = launch_post_sel<32, 1>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
-        else if (m <= 4096) r = launch_post_sel<16, 4>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
-        else if (m <= 8192) r = launch_post_sel<32, 4>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
-        else if (m <= 16384) r = launch_post_sel<16, 16>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
-        else r = launch_post_sel<32, 16>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr);
+        r = post_sel_any<float>(ctx, d_db, n_frames, n_fft, d_post, d_lo, d_hi, d_thr, d_vals, disp_w);
     } else if (n_fft > ctx->post_sort_max) {
         // rows too long for registers / the LDS sort: MSD radix select with an LDS histogram
         pss_kernel_begin(ctx, "k_post");
@@ -1579,13 +1636,14 @@ int row_extremes(pss_ctx *ctx, const T *d_rows, long n_rows, int len, T *d_lo, T
 }
 
 // MODE 0: waterfall line (glyph, colour); MODE 1: persistence trace (y).  d_lo / d_hi: [n_halo + n_frames] row extremes.
-// d_thr != nullptr: d_post holds the float32 dB rows (len + 4 points each), the post-processed rows are rebuilt per cell
+// d_thr != nullptr: d_post holds the dB rows (len + 4 points each), the post-processed rows are rebuilt per cell
+// d_vals != nullptr: the rows already resampled to disp_w columns (k_post_sel's `vals`); d_post / d_thr are not read
 template <class T, int MODE>
 int display_rows(pss_ctx *ctx, const T *d_post, long n_frames, int len, const T *d_lo, const T *d_hi, int n_halo, int window,
-                 int disp_h, int disp_w, int8_t *d_a, int8_t *d_b, const float *d_thr = nullptr)
+                 int disp_h, int disp_w, int8_t *d_a, int8_t *d_b, const T *d_thr = nullptr, const double *d_vals = nullptr)
 {
     if (n_frames < 0 || len < 2 || disp_w < 1 || disp_h < 1 || disp_h > 127 || window < 1 || n_halo < 0 ||
-        (n_frames > 0 && (!d_post || !d_lo || !d_hi || !d_a || (MODE == 0 && !d_b))))
+        (n_frames > 0 && ((!d_post && !d_vals) || !d_lo || !d_hi || !d_a || (MODE == 0 && !d_b))))
         return pss_fail(ctx, PSS_E_ARG, "bad display-rows arguments");
     if (n_frames == 0) return PSS_OK;
     int r = pss_ensure_buffer(ctx, &ctx->scratch_win, &ctx->scratch_win_bytes, (size_t)n_frames * 2 * sizeof(double), "window extremes");
@@ -1599,17 +1657,14 @@ int display_rows(pss_ctx *ctx, const T *d_post, long n_frames, int len, const T 
     const long cells = n_frames * disp_w;
     pss_kernel_begin(ctx, "k_disp_rows");
     const dim3 dgrid((unsigned)((cells + 255) / 256 < 16384 ? (cells + 255) / 256 : 16384));
-    if constexpr (sizeof(T) == 4) {
-        if (d_thr)
-            hipLaunchKernelGGL((pss_post::k_disp_rows<T, MODE, true>), dgrid, dim3(256), 0, PSS_STREAM(ctx), d_post, wlo, whi, n_frames, len,
-                               disp_w, disp_h, d_a, d_b, d_thr);
-        else
-            hipLaunchKernelGGL((pss_post::k_disp_rows<T, MODE>), dgrid, dim3(256), 0, PSS_STREAM(ctx), d_post, wlo, whi, n_frames, len, disp_w,
-                               disp_h, d_a, d_b, nullptr);
-    } else {
+    if (d_vals)
+        hipLaunchKernelGGL((pss_post::k_disp_vals<MODE>), dgrid, dim3(256), 0, PSS_STREAM(ctx), d_vals, wlo, whi, n_frames, disp_w, disp_h, d_a, d_b);
+    else if (d_thr)
+        hipLaunchKernelGGL((pss_post::k_disp_rows<T, MODE, true>), dgrid, dim3(256), 0, PSS_STREAM(ctx), d_post, wlo, whi, n_frames, len,
+                           disp_w, disp_h, d_a, d_b, d_thr);
+    else
         hipLaunchKernelGGL((pss_post::k_disp_rows<T, MODE>), dgrid, dim3(256), 0, PSS_STREAM(ctx), d_post, wlo, whi, n_frames, len, disp_w,
-                           disp_h, d_a, d_b, nullptr);
-    }
+                           disp_h, d_a, d_b, (const T *)nullptr);
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_disp_rows launch");
@@ -1670,6 +1725,12 @@ extern "C" int pss_spectrum_post_f64(pss_ctx *ctx, const double *d_db, long n_fr
     if (n_frames < 0 || n_fft < 5 || (n_frames > 0 && (!d_db || !d_post))) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_post_f64: bad argument");
     if ((d_row_lo == nullptr) != (d_row_hi == nullptr)) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_post_f64: row_lo and row_hi go together");
     if (n_frames == 0) return PSS_OK;
+    if (!ctx->f64_plain && n_fft >= 8 && post_sel_serves(ctx, n_fft, true)) {   // the register select on 64-bit keys (option "f64_plain" = 1: the radix-select kernel below)
+        pss_time_begin(ctx);
+        const int rq = post_sel_any<double>(ctx, d_db, n_frames, n_fft, d_post, d_row_lo, d_row_hi, nullptr, nullptr, 0);
+        pss_time_end(ctx);
+        return rq;
+    }
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_post_f64");
     hipLaunchKernelGGL(k_post_f64, dim3((unsigned)(n_frames < 2048 ? n_frames : 2048)), dim3(256), 0, PSS_STREAM(ctx), d_db, d_post, n_fft, n_frames);
@@ -1705,6 +1766,34 @@ extern "C" int pss_persistence_rows_db(pss_ctx *ctx, const float *d_db, long n_f
     PSS_GUARD(ctx);
     if (n_frames > 0 && !d_row_thr) return pss_fail(ctx, PSS_E_ARG, "pss_persistence_rows_db: null thresholds");
     return display_rows<float, 1>(ctx, d_db, n_frames, n_fft - 4, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_y, nullptr, d_row_thr);
+}
+
+// The display chain of pss_frame_pipeline behind the dB rows, for rows of either type (pss_ctx.h): post-process WITHOUT materialised rows —
+// thresholds, extremes and the rows resampled to the display width in ONE pass over the dB rows (k_post_sel's `vals`) —, then the sliding
+// extremes and the line of every frame from the resampled values.  display 0: waterfall (a = glyph, b = colour), 1: persistence (a = y).
+// Serves the lengths the register select serves (pss_post_sel_serves); d_vals: n_frames x disp_w doubles of scratch.
+bool pss_post_sel_serves(const pss_ctx *ctx, int n_fft, bool f64) { return n_fft >= 8 && post_sel_serves(ctx, n_fft, f64); }
+template <class TR>
+static int chain_vals(pss_ctx *ctx, const TR *d_db, long n_frames, int n_fft, TR *d_lo, TR *d_hi, int n_halo, int window, int display, int disp_h,
+                      int disp_w, int8_t *d_a, int8_t *d_b, double *d_vals)
+{
+    if (n_frames == 0) return PSS_OK;
+    pss_time_begin(ctx);
+    int r = post_sel_any<TR>(ctx, d_db, n_frames, n_fft, (TR *)nullptr, d_lo + n_halo, d_hi + n_halo, (TR *)nullptr, d_vals, disp_w);
+    if (!r) r = display ? display_rows<TR, 1>(ctx, (const TR *)nullptr, n_frames, n_fft - 4, d_lo, d_hi, n_halo, window, disp_h, disp_w, d_a, nullptr, (const TR *)nullptr, d_vals)
+                        : display_rows<TR, 0>(ctx, (const TR *)nullptr, n_frames, n_fft - 4, d_lo, d_hi, n_halo, window, 1, disp_w, d_a, d_b, (const TR *)nullptr, d_vals);
+    pss_time_end(ctx);
+    return r;
+}
+int pss_chain_vals_f32(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_lo, float *d_hi, int n_halo, int window, int display,
+                       int disp_h, int disp_w, int8_t *d_a, int8_t *d_b, double *d_vals)
+{
+    return chain_vals<float>(ctx, d_db, n_frames, n_fft, d_lo, d_hi, n_halo, window, display, disp_h, disp_w, d_a, d_b, d_vals);
+}
+int pss_chain_vals_f64(pss_ctx *ctx, const double *d_db, long n_frames, int n_fft, double *d_lo, double *d_hi, int n_halo, int window, int display,
+                       int disp_h, int disp_w, int8_t *d_a, int8_t *d_b, double *d_vals)
+{
+    return chain_vals<double>(ctx, d_db, n_frames, n_fft, d_lo, d_hi, n_halo, window, display, disp_h, disp_w, d_a, d_b, d_vals);
 }
 
 extern "C" int pss_waterfall_rows(pss_ctx *ctx, const float *d_post, long n_frames, int len, const float *d_row_lo,

@@ -195,6 +195,26 @@ static __constant__ double2 DB_TAB[97] = {
     {0x1.571ed3c506b3ap-1, 0x1.63fd857fc49bap-3},
     {0x1.5555555555555p-1, 0x1.68a288b60b7fdp-3}};
 
+// the float64 value itself (the reference's own row type, pss_spectrum_db_f64): within ~1e-14 dB of np.log10's
+__device__ __forceinline__ double db64_of_exact(double pw, const double2 *tab = DB_TAB)
+{
+    const unsigned hi = (unsigned)__double2hiint(pw), lo = (unsigned)__double2loint(pw);
+    const bool up = (hi & 0xfffffu) >= 0x80000u;
+    const int e = (int)(hi >> 20) - 1023 + (up ? 1 : 0);
+    const double z = __hiloint2double((int)((hi & 0xfffffu) | (up ? 0x3fe00000u : 0x3ff00000u)), (int)lo);
+    const int i = (int)fma(z, 128.0, -95.5);
+    const double2 tc = tab[i];
+    const double r = fma(z, tc.x, -1.0);
+    double p = fma(r, -0x1.5555555555555p-3, 0x1.999999999999ap-3);
+    p = fma(p, r, -0.25);
+    p = fma(p, r, 0x1.5555555555555p-2);
+    p = fma(p, r, -0.5);
+    p = fma(p, r, 1.0);
+    double res = fma(p * r, 0x1.bcb7b1526e50ep-2, tc.y);
+    res = fma((double)e, 0x1.34413509f79ffp-2, res);
+    return hi >= 0x7ff00000u ? pw : 10.0 * res;                          // +inf, NaN
+}
+
 __device__ __forceinline__ float db_of_exact(double pw, const double2 *tab = DB_TAB)
 {
     const unsigned hi = (unsigned)__double2hiint(pw), lo = (unsigned)__double2loint(pw);
@@ -260,6 +280,13 @@ __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, int vof
 __device__ __forceinline__ void buf_store_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff, float x)
 {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, int voff, int soff, double x)
+{
+    v2u_t v;
+    v.x = (unsigned)__double2loint(x);
+    v.y = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 
 // DPP control "wave_rol:1" (gfx9): every lane reads its upper neighbour, lane 63 reads lane 0
@@ -447,7 +474,9 @@ __device__ __forceinline__ void r16_core_split(double2 (&v)[16], double *ex, con
 // registers — measured 0.41 -> 0.45 ms for the default path at 131072 x 1024)
 // ONE (frames of two or more wavefronts, i.e. N >= 2048): one frame per workgroup instead of 256 / T — the three exchange barriers of a
 // transform then hold up the frame's own wavefronts only, not the other frame's as well.
-template <int LOG_R3, bool SCAN, bool SPLIT = false, bool PREFETCH = false, bool EXACT = false, bool ONE = false>
+// D64 (with EXACT): `db` points at float64 rows — the reference's own row type (compute_fft returns float64): the value db_of_exact rounds,
+// stored unrounded, 8 bytes per bin (pss_spectrum_db_f64, the cell-exact pipeline pss_frame_pipeline_nfm_f64).
+template <int LOG_R3, bool SCAN, bool SPLIT = false, bool PREFETCH = false, bool EXACT = false, bool ONE = false, bool D64 = false>
 __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__ iq, float *__restrict__ db,
                                                       const double2 *__restrict__ tw, const double *__restrict__ win,
                                                       long n_frames, float *__restrict__ peak, double *__restrict__ bw,
@@ -456,6 +485,8 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
     using C = Cfg<LOG_R3>;
     constexpr int R3 = C::R3, T = C::T, N = C::N, FPW = ONE ? 1 : C::FPW;
     static_assert(!ONE || (T >= 128 && !SCAN && !SPLIT), "one frame per workgroup: compute_fft rows of frames of >= 2 wavefronts");
+    static_assert(!D64 || (EXACT && !SCAN), "float64 rows: compute_fft rows by the float64 evaluation");
+    constexpr int OB = D64 ? 8 : 4;            // bytes per output bin
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *ex_all = reinterpret_cast<double2 *>(smem);
     double2 *tw2 = SPLIT ? reinterpret_cast<double2 *>(smem + (size_t)FPW * C::EX * sizeof(double))
@@ -510,14 +541,20 @@ __global__ __launch_bounds__(256) void k_spectrum_r16(const float2 *__restrict__
         // youngest memory operations and waits for vmcnt(0) — i.e. for the acknowledgement of the stores just issued — once per
         // frame; now it waits for the loads only (vmcnt counts in order: the 16 younger stores stay in flight).  1024 / 2048
         // points: +3.5 / +4 % paired; without prefetch the loads ARE the youngest operations and plain pointers are 4-6 % faster.
-        float *out = (!PREFETCH && db && valid) ? db + (size_t)f * N : nullptr;
+        float *out = (!PREFETCH && db && valid) ? db + (size_t)f * N * (OB / 4) : nullptr;
         const long f_first = g * FPW;
         const long rows_here = n_frames - f_first < FPW ? n_frames - f_first : FPW;
-        const __amdgpu_buffer_rsrc_t ro = make_rsrc((PREFETCH && db) ? db + (size_t)f_first * N : nullptr, (PREFETCH && db) ? (unsigned)(rows_here * N * 4) : 0u);
-        const int ro_lane = (fl * N + t) * 4;
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc((PREFETCH && db) ? db + (size_t)f_first * N * (OB / 4) : nullptr, (PREFETCH && db) ? (unsigned)(rows_here * N * OB) : 0u);
+        const int ro_lane = (fl * N + t) * OB;
         float lmax = -INFINITY;
         float dbv[16];
         auto emit = [&](int i, int k, double2 X) {
+            if constexpr (D64) {
+                const double d64 = db64_of_exact(power_of(X));
+                if constexpr (PREFETCH) buf_store_f64(ro, ro_lane, (((k - t) + N / 2) & (N - 1)) * 8, d64);
+                else if (out) reinterpret_cast<double *>(out)[(k + N / 2) & (N - 1)] = d64;
+                return;
+            }
             // compute_fft: float64 all the way, dB rounded to float32; scanner slice: NumPy's complex64 spectrum + float32 chain
             float d;
             if constexpr (SCAN) d = (flags & FLAG_SCAN_EXACT) ? pss::scan_db_np(X.x, X.y, l10) : db_of_fast(power_of(X));

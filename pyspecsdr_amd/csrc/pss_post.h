@@ -32,42 +32,84 @@ __device__ __forceinline__ unsigned f2ord(float v)
 __device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float(o ^ ((unsigned)((int)~o >> 31) | 0x80000000u)); }
 constexpr unsigned ORD_NEG_INF = 0x007fffffu, ORD_POS_INF = 0xff800000u;  // images of -inf / +inf: finite values lie strictly between
 
+// The same image for float64 (the reference's own row type: compute_fft returns float64 and the caller smooths, clamps and draws in
+// float64 — pss_frame_pipeline_nfm_f64), and the per-type constants the select works with.
+__device__ __forceinline__ unsigned long long d2ord(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return u ^ ((unsigned long long)((long long)u >> 63) | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord2d(unsigned long long o)
+{
+    return __longlong_as_double((long long)(o ^ ((unsigned long long)((long long)~o >> 63) | 0x8000000000000000ull)));
+}
+template <class T> struct Ord;
+template <> struct Ord<float> {
+    using K = unsigned;
+    static constexpr K PAD = 0xffffffffu, NEG_INF = ORD_NEG_INF, POS_INF = ORD_POS_INF;
+    static constexpr int BITS = 32;
+    static __device__ __forceinline__ K enc(float v) { return f2ord(v); }
+    static __device__ __forceinline__ float dec(K k) { return ord2f(k); }
+    static __device__ __forceinline__ int top_bit(K x) { return 31 - __builtin_clz(x); }
+};
+template <> struct Ord<double> {
+    using K = unsigned long long;
+    static constexpr K PAD = 0xffffffffffffffffull, NEG_INF = 0x000fffffffffffffull, POS_INF = 0xfff0000000000000ull;
+    static constexpr int BITS = 64;
+    static __device__ __forceinline__ K enc(double v) { return d2ord(v); }
+    static __device__ __forceinline__ double dec(K k) { return ord2d(k); }
+    static __device__ __forceinline__ int top_bit(K x) { return 63 - __builtin_clzll(x); }
+};
+
 // ---- wavefront reductions on the DPP crossbar (no LDS, no SALU chains) ---------------------------------------------------
 // quad_perm / row_half_mirror / row_mirror leave every lane of a 16-lane row with its row's result; the four row results are
-// then read with v_readlane and combined on the scalar unit.
+// then read with v_readlane and combined on the scalar unit.  K = unsigned or unsigned long long (two DPP moves per step).
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v)
 {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
-struct OpAdd { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return a + b; } };
-struct OpFAdd { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return __float_as_uint(__uint_as_float(a) + __uint_as_float(b)); } };
-struct OpMin { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return a < b ? a : b; } };
-struct OpMax { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return a > b ? a : b; } };
-
-template <class Op>
-__device__ __forceinline__ unsigned wave_reduce(unsigned v)
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_k(unsigned v) { return dpp_u32<CTRL>(v); }
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_k(unsigned long long v)
 {
-    v = Op::f(v, dpp_u32<0xB1>(v));    // quad_perm [1,0,3,2]
-    v = Op::f(v, dpp_u32<0x4E>(v));    // quad_perm [2,3,0,1]
-    v = Op::f(v, dpp_u32<0x141>(v));   // row_half_mirror
-    v = Op::f(v, dpp_u32<0x140>(v));   // row_mirror
-    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
-    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned lo = dpp_u32<CTRL>((unsigned)v), hi = dpp_u32<CTRL>((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned readlane_k(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ unsigned long long readlane_k(unsigned long long v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+struct OpAdd { template <class K> static __device__ __forceinline__ K f(K a, K b) { return a + b; } };
+struct OpFAdd { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return __float_as_uint(__uint_as_float(a) + __uint_as_float(b)); } };
+struct OpMin { template <class K> static __device__ __forceinline__ K f(K a, K b) { return a < b ? a : b; } };
+struct OpMax { template <class K> static __device__ __forceinline__ K f(K a, K b) { return a > b ? a : b; } };
+
+template <class Op, class K>
+__device__ __forceinline__ K wave_reduce(K v)
+{
+    v = Op::f(v, dpp_k<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = Op::f(v, dpp_k<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = Op::f(v, dpp_k<0x141>(v));   // row_half_mirror
+    v = Op::f(v, dpp_k<0x140>(v));   // row_mirror
+    const K a = readlane_k(v, 0), b = readlane_k(v, 16), c = readlane_k(v, 32), d = readlane_k(v, 48);
     return Op::f(Op::f(a, b), Op::f(c, d));
 }
 
-// the same over the W wavefronts of a row (W = 1: nothing more to do); `red` is double-buffered: one barrier per reduction
-template <class Op, int W>
-__device__ __forceinline__ unsigned row_reduce(unsigned v, unsigned *red, int wave, int lane, int &phase)
+// the same over the W wavefronts of a row (W = 1: nothing more to do); `red` (2 W 64-bit slots) is double-buffered: one barrier per reduction
+template <class Op, int W, class K>
+__device__ __forceinline__ K row_reduce(K v, unsigned long long *red, int wave, int lane, int &phase)
 {
     v = wave_reduce<Op>(v);
     if constexpr (W == 1) return v;
-    unsigned *slot = red + (phase & 1) * W;
+    K *slot = reinterpret_cast<K *>(red + (phase & 1) * W);
     phase++;
     if (lane == 0) slot[wave] = v;
     __syncthreads();
-    unsigned s = slot[0];
+    K s = slot[0];
 #pragma unroll
     for (int w = 1; w < W; w++) s = Op::f(s, slot[w]);
     return s;
@@ -76,9 +118,8 @@ __device__ __forceinline__ unsigned row_reduce(unsigned v, unsigned *red, int wa
 // number of keys of the row below `trial`.  The per-lane count is accumulated on the vector unit (v_cmp + v_addc per
 // element) and reduced once: counting each register slot with ballot + s_bcnt1 + s_add instead put 2 scalar instructions
 // per element on the CU's single scalar unit and made the kernel scalar-issue bound (measured: 0.23 ms at 65536 x 1024).
-template <int EPL, int W>
-__device__ __forceinline__ unsigned count_below(const unsigned (&key)[EPL], unsigned trial, unsigned *red, int wave, int lane,
-                                                int &phase)
+template <int EPL, int W, class K>
+__device__ __forceinline__ unsigned count_below(const K (&key)[EPL], K trial, unsigned long long *red, int wave, int lane, int &phase)
 {
     unsigned c = 0;
 #pragma unroll
@@ -86,7 +127,7 @@ __device__ __forceinline__ unsigned count_below(const unsigned (&key)[EPL], unsi
     return row_reduce<OpAdd, W>(c, red, wave, lane, phase);
 }
 
-// k-th smallest (0-based) of the row's n_valid keys (padding slots hold 0xffffffff) and, in `next`, the (k+1)-th: binary
+// k-th smallest (0-based) of the row's n_valid keys (padding slots hold the all-ones key) and, in `next`, the (k+1)-th: binary
 // search on the key bits below the common prefix of the row's minimum and maximum (returned in mn / mx); stops as soon as
 // one candidate is left in the bracket, and that last pass also finds the smallest key above the bracket (= rank k + 1).
 // PAD_FROM: first register slot that may hold padding (EPL: none anywhere).
@@ -95,50 +136,56 @@ __device__ __forceinline__ unsigned count_below(const unsigned (&key)[EPL], unsi
 // and the search then halves such a bracket instead of spending its first steps on the empty stretch between the noise
 // floor and the row's extremes (measured on FM / noise / weak-tone rows: 10.4-10.7 counting passes instead of 15-19).
 // A wrong guess costs four counts and changes nothing else: every result is decided by exact counts.
-template <int EPL, int W, int PAD_FROM>
-__device__ __forceinline__ unsigned select_kth(const unsigned (&key)[EPL], unsigned k, unsigned n_valid, unsigned &next, unsigned &mn,
-                                               unsigned &mx, unsigned *red, int wave, int lane, int &phase, float guess = NAN)
+// T = float: 32-bit keys; T = double: 64-bit keys (the search stops when ONE key is left in the bracket, so the number of passes depends on
+// how close the row's values lie to its median, not on the key width).
+template <int EPL, int W, int PAD_FROM, class T>
+__device__ __forceinline__ typename Ord<T>::K select_kth(const typename Ord<T>::K (&key)[EPL], unsigned k, unsigned n_valid,
+                                                         typename Ord<T>::K &next, typename Ord<T>::K &mn, typename Ord<T>::K &mx,
+                                                         unsigned long long *red, int wave, int lane, int &phase, float guess = NAN)
 {
-    unsigned a = 0xffffffffu, b0 = 0u, b2 = 0u;
+    using O = Ord<T>;
+    using K = typename O::K;
+    constexpr K PAD = O::PAD;
+    K a = PAD, b0 = 0, b2 = 0;
 #pragma unroll
     for (int r = 0; r < EPL; r++) {
-        a = key[r] < a ? key[r] : a;                          // padding = 0xffffffff never lowers the minimum
+        a = key[r] < a ? key[r] : a;                          // padding = all ones never lowers the minimum
         if (r < PAD_FROM) b0 = key[r] > b0 ? key[r] : b0;     // never padding: taken as it is
-        else { const unsigned kp = key[r] + 1u; b2 = kp > b2 ? kp : b2; }  // padding wraps to 0, the neutral element
+        else { const K kp = key[r] + 1u; b2 = kp > b2 ? kp : b2; }  // padding wraps to 0, the neutral element
     }
     if (PAD_FROM < EPL) { b2 = b2 ? b2 - 1u : 0u; b0 = b2 > b0 ? b2 : b0; }
     mn = row_reduce<OpMin, W>(a, red, wave, lane, phase);
     mx = row_reduce<OpMax, W>(b0, red, wave, lane, phase);
-    // smallest key above v among the row's keys (0xffffffff if there is none but padding)
-    auto above = [&](unsigned v) {
-        unsigned c = 0xffffffffu;
+    // smallest key above v among the row's keys (all ones if there is none but padding)
+    auto above = [&](K v) {
+        K c = PAD;
 #pragma unroll
         for (int r = 0; r < EPL; r++) c = (key[r] > v && key[r] < c) ? key[r] : c;
         return row_reduce<OpMin, W>(c, red, wave, lane, phase);
     };
     if (mn == mx) { next = mn; return mn; }                   // a constant row (n_valid >= 2 wherever next is used)
-    if (guess == guess && mx != 0xffffffffu) {
+    if (guess == guess && mx != PAD) {
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; attempt++) {
             const float d = attempt ? 2.0f : 0.5f;
-            unsigned lo = f2ord(guess - d), hi = f2ord(guess + d);
+            K lo = O::enc((T)(guess - d)), hi = O::enc((T)(guess + d));
             lo = lo < mn ? mn : lo;
             hi = hi > mx ? mx : hi;
             if (lo > hi) continue;
-            unsigned n_lo = count_below<EPL, W>(key, lo, red, wave, lane, phase);          // #keys < lo
-            unsigned n_hi = count_below<EPL, W>(key, hi + 1u, red, wave, lane, phase);     // #keys <= hi
+            unsigned n_lo = count_below<EPL, W>(key, lo, red, wave, lane, phase);             // #keys < lo
+            unsigned n_hi = count_below<EPL, W>(key, (K)(hi + 1u), red, wave, lane, phase);   // #keys <= hi
             if (!(n_lo <= k && k < n_hi)) continue;
             // rank k lies in [lo, hi]: halve the bracket until one key (or one value) is left
 #pragma unroll 1
             while (n_hi - n_lo > 1u && lo < hi) {
-                const unsigned trial = lo + ((hi - lo + 1u) >> 1);
+                const K trial = lo + ((hi - lo + 1u) >> 1);
                 const unsigned c = count_below<EPL, W>(key, trial, red, wave, lane, phase);
                 if (c <= k) { lo = trial; n_lo = c; } else { hi = trial - 1u; n_hi = c; }
             }
             if (n_hi - n_lo == 1u) {
                 // the one key in [lo, hi] has rank k; exactly k + 1 keys are <= hi, so rank k + 1 is the smallest key above hi
-                unsigned cand = 0xffffffffu, nx = 0xffffffffu;
-                const unsigned span = hi - lo;
+                K cand = PAD, nx = PAD;
+                const K span = hi - lo;
 #pragma unroll
                 for (int r = 0; r < EPL; r++) {
                     const bool in = key[r] - lo <= span;
@@ -153,22 +200,22 @@ __device__ __forceinline__ unsigned select_kth(const unsigned (&key)[EPL], unsig
             return lo;
         }
     }
-    int b = 31 - __builtin_clz(mn ^ mx);                      // highest bit in which two keys of the row differ
-    unsigned lo = mn & ~((2u << b) - 1u);                     // all keys lie in [lo, lo + 2^(b+1))
+    int b = O::top_bit(mn ^ mx);                              // highest bit in which two keys of the row differ
+    K lo = mn & ~((((K)2) << b) - 1u);                        // all keys lie in [lo, lo + 2^(b+1))
     unsigned n_lo = 0, n_hi = n_valid;                        // #keys < lo, #keys < lo + 2^(b+1)
 #pragma unroll 1
     for (; b >= 0; b--) {
-        const unsigned trial = lo | (1u << b);
+        const K trial = lo | (((K)1) << b);
         const unsigned c = count_below<EPL, W>(key, trial, red, wave, lane, phase);
         if (c <= k) { lo = trial; n_lo = c; } else n_hi = c;
         if (n_hi - n_lo == 1) {
             // one key left in [lo, lo + 2^b): rank k.  Exactly k keys lie below it, so rank k + 1 is the smallest key at or
             // above lo + 2^b: both come out of one sweep (key - lo wraps to huge values for keys below lo).
-            unsigned cand = 0xffffffffu, nx = 0xffffffffu;
-            const unsigned span = 1u << b;
+            K cand = PAD, nx = PAD;
+            const K span = ((K)1) << b;
 #pragma unroll
             for (int r = 0; r < EPL; r++) {
-                const unsigned d = key[r] - lo;
+                const K d = key[r] - lo;
                 const bool in = d < span;
                 cand = in ? key[r] : cand;
                 nx = (!in && key[r] >= lo && key[r] < nx) ? key[r] : nx;
@@ -183,11 +230,15 @@ __device__ __forceinline__ unsigned select_kth(const unsigned (&key)[EPL], unsig
     return lo;
 }
 
-// LDS row stride (floats) of a thread's EPL consecutive elements: EPL + 4 (or + 8), chosen = 4 mod 8 so that the 16 lanes
-// a ds_read_b128 / ds_write_b128 services together start 16 bytes apart modulo the 64 banks (conflict-free)
-template <int EPL>
+// LDS row stride (elements) of a thread's EPL consecutive elements: the stride in bytes is = 16 mod 32, so that the 16 lanes
+// a ds_read_b128 / ds_write_b128 services together start 16 bytes apart modulo the 64 banks (conflict-free).
+// float: EPL + 4 (or + 8); double: EPL + 2.
+template <int EPL, class T = float>
 struct PostCfg {
-    static constexpr int S = ((EPL + 4) % 8 == 4) ? EPL + 4 : EPL + 8;
+    static constexpr int S = sizeof(T) == 8 ? EPL + 2 : (((EPL + 4) % 8 == 4) ? EPL + 4 : EPL + 8);
+    static constexpr int CH = 16 / sizeof(T);     // elements per 16-byte chunk (the unit of the global accesses)
+    static constexpr int Q = EPL / CH;            // chunks per thread
+    static constexpr int TAILQ = 4 / CH;          // chunks of the next thread's first four elements
 };
 
 template <bool WAVE_LOCAL>
@@ -202,127 +253,182 @@ __device__ __forceinline__ void row_sync()
     }
 }
 
+// np.interp(np.linspace(0, len-1, W), np.arange(len), row)[x] in float64 (pyspecsdr.py:1379-1383 / :1550-1554)
+template <class Row>
+__device__ __forceinline__ double interp_at(const Row &row, int len, int W, int x)
+{
+    const double stop = (double)(len - 1);
+    double xp;
+    if (W == 1) xp = 0.0;
+    else {
+        const double step = stop / (double)(W - 1);
+        xp = (x == W - 1) ? stop : (double)x * step;
+    }
+    if (xp >= stop) return (double)row[len - 1];
+    const int j = (int)xp;
+    const double slope = ((double)row[j + 1] - (double)row[j]) / ((double)(j + 1) - (double)j);
+    return slope * (xp - (double)j) + (double)row[j];
+}
+
+// a row in the staging layout (element e at buf[(e / EPL) * S + e % EPL])
+template <int EPL, class T>
+struct StagedRow {
+    const T *buf;
+    __device__ __forceinline__ T operator[](int e) const { return buf[(e / EPL) * PostCfg<EPL, T>::S + (e % EPL)]; }
+};
+
 // One row, staged in LDS in the per-thread-consecutive layout (element e at buf[(e / EPL) * S + e % EPL]) and already
 // synchronised: 5-tap smoothing, median, clamp, the clamped row out through the same staging buffer (coalesced 16-byte
-// stores to out4), the row's finite extremes.  slot[j]: LDS slot of the 4-element chunk j * T + t.  Ends with a row_sync
+// stores to out4), the row's finite extremes.  slot[j]: LDS slot of the 16-byte chunk j * T + t.  Ends with a row_sync
 // (the buffer may be overwritten afterwards).  FULL: the row has exactly T * EPL points (padding = the last thread's last
 // four slots only).
 // out4 == nullptr: the clamped row is NOT written (the display kernels can rebuild any element of it from the dB row and the clamp
-// threshold: k_disp_rows<..., FROM_DB>); row_thr (nullable) receives the row's clamp threshold float32(median - 10).
-template <int EPL, int W, bool FULL>
-__device__ __forceinline__ void post_row_staged(float *buf, const int (&slot)[EPL / 4], int t, int m, unsigned *red, int wave, int lane,
-                                                int &phase, float4 *out4, float *row_lo, float *row_hi, long f, float *row_thr = nullptr)
+// threshold: k_disp_rows<..., FROM_DB>); row_thr (nullable) receives the row's clamp threshold (float32(median - 10); float64 rows: median - 10).
+// vals (nullable, with disp_w): the row resampled to the display width — np.interp(np.linspace(0, m - 1, disp_w), np.arange(m), row), float64,
+// what draw_waterfall / draw_persistence normalise and quantise (pyspecsdr.py:1379-1383, :1550-1554) — so that the display kernel of a batch
+// reads disp_w values per row instead of the row (k_disp_vals).
+// TR = float: the float32 rows of pss_spectrum_db (sums in float64, rounded once); TR = double: the reference's own row type throughout
+// (np.median of a row with a NaN is NaN and clamps nothing).
+template <int EPL, int W, bool FULL, class TR>
+__device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostCfg<EPL, TR>::Q], int t, int m, unsigned long long *red, int wave,
+                                                int lane, int &phase, float4 *out4, TR *row_lo, TR *row_hi, long f, TR *row_thr = nullptr,
+                                                double *vals = nullptr, int disp_w = 0)
 {
-    constexpr int T = 64 * W, S = PostCfg<EPL>::S, Q = EPL / 4;
+    using O = Ord<TR>;
+    using K = typename O::K;
+    using PC = PostCfg<EPL, TR>;
+    constexpr int T = 64 * W, S = PC::S, Q = PC::Q, CH = PC::CH;
     constexpr int PAD_FROM = FULL ? EPL - 4 : 0;
-    const int m4 = m >> 2;
+    constexpr bool F64 = sizeof(TR) == 8;
+    const int mq = m / CH;                       // whole 16-byte chunks of the output row (m % CH == 0: m = N - 4, N % 4 == 0)
     const int nv = m - t * EPL;                  // this thread's slots r < nv hold elements of the smoothed row
     // EPL consecutive elements + the next thread's first four (the 5-tap window of the last four outputs)
-    unsigned key[EPL];
+    K key[EPL];
     float lsum = 0.0f;
+    bool nan_here = false;
     {
-        float x[EPL + 4];
-#pragma unroll
-        for (int i = 0; i < Q + 1; i++) {
-            const float4 v = *reinterpret_cast<const float4 *>(buf + (i < Q ? t * S + 4 * i : (t + 1) * S));
-            x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
-        }
-        // np.convolve(fd, ones(5)/5, 'valid') in float64 (pyspecsdr.py:2279); the row is kept as the order-preserving
-        // integer image of its float32 value (4 bytes per element instead of 12)
         double xd[EPL + 4];
 #pragma unroll
-        for (int i = 0; i < EPL + 4; i++) xd[i] = (double)x[i];
+        for (int i = 0; i < Q + PC::TAILQ; i++) {
+            const float4 v = *reinterpret_cast<const float4 *>(buf + (i < Q ? t * S + CH * i : (t + 1) * S + CH * (i - Q)));
+            if constexpr (F64) {
+                xd[2 * i] = __hiloint2double(__float_as_int(v.y), __float_as_int(v.x));
+                xd[2 * i + 1] = __hiloint2double(__float_as_int(v.w), __float_as_int(v.z));
+            } else {
+                xd[4 * i] = (double)v.x; xd[4 * i + 1] = (double)v.y; xd[4 * i + 2] = (double)v.z; xd[4 * i + 3] = (double)v.w;
+            }
+        }
+        // np.convolve(fd, ones(5)/5, 'valid') in float64 (pyspecsdr.py:2279); the row is kept as the order-preserving
+        // integer image of its value (float32 rows: of the float32 rounding of the sum — 4 bytes per element instead of 12)
 #pragma unroll
         for (int r = 0; r < EPL; r++) {
             double acc = 0.0;
 #pragma unroll
             for (int k = 0; k < 5; k++) acc += xd[r + k] * 0.2;
-            const float sm = (float)acc;
-            key[r] = f2ord(sm);
+            const TR sm = (TR)acc;
+            key[r] = O::enc(sm);
             // padding sorts above everything
             const bool pad = FULL ? (r >= PAD_FROM && t == T - 1) : r >= nv;
-            key[r] = pad ? 0xffffffffu : key[r];
-            lsum += pad ? 0.0f : sm;
+            key[r] = pad ? O::PAD : key[r];
+            lsum += pad ? 0.0f : (float)sm;
+            if constexpr (F64) nan_here |= !pad && sm != sm;
         }
     }
     // the row's mean: where the median search starts looking (select_kth; a hint only, never part of a result)
     const float guess = __uint_as_float(row_reduce<OpFAdd, W>(__float_as_uint(lsum), red, wave, lane, phase)) / (float)m;
     // np.median: the middle order statistic, or the mean of the two middle ones
     const unsigned k1 = (unsigned)((m - 1) >> 1);
-    unsigned mn, mx, v2;
-    const unsigned v1 = select_kth<EPL, W, PAD_FROM>(key, k1, (unsigned)m, v2, mn, mx, red, wave, lane, phase, guess);
-    const double med = (m & 1) ? (double)ord2f(v1) : 0.5 * ((double)ord2f(v1) + (double)ord2f(v2));
+    K mn, mx, v2;
+    const K v1 = select_kth<EPL, W, PAD_FROM, TR>(key, k1, (unsigned)m, v2, mn, mx, red, wave, lane, phase, guess);
+    const double med = (m & 1) ? (double)O::dec(v1) : 0.5 * ((double)O::dec(v1) + (double)O::dec(v2));
     // fd[fd < thr] = thr (:2282-2283).  float32(max(s, thr)) = max(float32(s), float32(thr)) (rounding is monotonic), and
     // the maximum of two floats is the maximum of their ordered images
-    const unsigned thr = f2ord((float)(med - 10.0));
-    if (row_thr && t == 0) row_thr[f] = ord2f(thr);
+    K thr = O::enc((TR)(med - 10.0));
+    if constexpr (F64) {
+        // np.median of a row that holds a NaN is NaN, and `fd < NaN` selects nothing: the lowest image clamps nothing (and survives the
+        // round trip through row_thr: enc(dec(0)) = 0)
+        bool has_nan;
+        if constexpr (W == 1) has_nan = __ballot(nan_here) != 0ull;
+        else has_nan = __syncthreads_or(nan_here) != 0;
+        if (has_nan || !(med == med)) thr = 0;
+    }
+    if (row_thr && t == 0) row_thr[f] = O::dec(thr);
     row_sync<W == 1>();                      // every thread has read its input window
-    if (out4) {
+    if (out4 || vals) {
 #pragma unroll
-    for (int i = 0; i < Q; i++) {
-        float o[4];
+        for (int i = 0; i < Q; i++) {
+            TR o[CH];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const unsigned kk = key[4 * i + k];
-            o[k] = ord2f(kk > thr ? kk : thr);
+            for (int k = 0; k < CH; k++) {
+                const K kk = key[CH * i + k];
+                o[k] = O::dec(kk > thr ? kk : thr);
+            }
+            if constexpr (F64) *reinterpret_cast<double2 *>(buf + t * S + CH * i) = make_double2(o[0], o[1]);
+            else *reinterpret_cast<float4 *>(buf + t * S + CH * i) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        *reinterpret_cast<float4 *>(buf + t * S + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-    row_sync<W == 1>();
+        row_sync<W == 1>();
+        if (out4) {
 #pragma unroll
-    for (int j = 0; j < Q; j++) {
-        const int c = j * T + t;
-        if (c < m4) out4[c] = *reinterpret_cast<const float4 *>(buf + slot[j]);
-    }
+            for (int j = 0; j < Q; j++) {
+                const int c = j * T + t;
+                if (c < mq) out4[c] = *reinterpret_cast<const float4 *>(buf + slot[j]);
+            }
+        }
+        if (vals) {
+            const StagedRow<EPL, TR> row{buf};
+            for (int x = t; x < disp_w; x += T) vals[(size_t)f * disp_w + x] = interp_at(row, m, disp_w, x);
+        }
     }
     if (row_lo) {
         // finite extremes of the clamped row, as the accumulators' np.isfinite masks see them.  A row whose smoothed
         // values are all finite (any real dB row): min / max commute with the clamp.
-        unsigned a, b;
-        if (mn > ORD_NEG_INF && mx < ORD_POS_INF) {
+        K a, b;
+        if (mn > O::NEG_INF && mx < O::POS_INF) {
             a = mn > thr ? mn : thr;
             b = mx > thr ? mx : thr;
         } else {
-            a = 0xffffffffu; b = 0u;
+            a = O::PAD; b = 0;
 #pragma unroll
             for (int r = 0; r < EPL; r++) {
-                const unsigned kk = key[r] > thr ? key[r] : thr;
-                const bool fin = key[r] != 0xffffffffu && kk > ORD_NEG_INF && kk < ORD_POS_INF;
+                const K kk = key[r] > thr ? key[r] : thr;
+                const bool fin = key[r] != O::PAD && kk > O::NEG_INF && kk < O::POS_INF;
                 a = (fin && kk < a) ? kk : a;
                 b = (fin && kk > b) ? kk : b;
             }
             a = row_reduce<OpMin, W>(a, red, wave, lane, phase);
             b = row_reduce<OpMax, W>(b, red, wave, lane, phase);
-            if (a > b) { a = f2ord(INFINITY); b = f2ord(-INFINITY); }  // no finite value: the neutral pair
+            if (a > b) { a = O::enc((TR)INFINITY); b = O::enc((TR)-INFINITY); }  // no finite value: the neutral pair
         }
-        if (t == 0) { row_lo[f] = ord2f(a); row_hi[f] = ord2f(b); }
+        if (t == 0) { row_lo[f] = O::dec(a); row_hi[f] = O::dec(b); }
     }
     row_sync<W == 1>();                      // the staging buffer may be overwritten now
 }
 
 // Requires N % 4 == 0 (16-byte aligned rows) and N - 4 <= 64 * W * EPL.  FULL: N == 64 * W * EPL exactly (the power-of-two
 // read buffers), where the only padding is the last thread's last four slots.
-template <int EPL, int W, bool FULL>
-__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_post_sel(const float *__restrict__ db, float *__restrict__ post, int N,
-                                                                     long n_frames, float *__restrict__ row_lo,
-                                                                     float *__restrict__ row_hi, float *__restrict__ row_thr)
+template <int EPL, int W, bool FULL, class TR = float>
+__global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_post_sel(const TR *__restrict__ db, TR *__restrict__ post, int N,
+                                                                     long n_frames, TR *__restrict__ row_lo,
+                                                                     TR *__restrict__ row_hi, TR *__restrict__ row_thr,
+                                                                     double *__restrict__ vals, int disp_w)
 {
+    using PC = PostCfg<EPL, TR>;
     constexpr int T = 64 * W;                    // threads per row
     constexpr int RPW = W == 1 ? 4 : 1;          // rows per workgroup
-    constexpr int S = PostCfg<EPL>::S, Q = EPL / 4;
+    constexpr int S = PC::S, Q = PC::Q, CH = PC::CH;
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ unsigned red[2 * (W > 1 ? W : 1)];
+    __shared__ unsigned long long red[2 * (W > 1 ? W : 1)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = W == 1 ? lane : tid;           // thread inside the row
-    float *buf = reinterpret_cast<float *>(smem) + (W == 1 ? wave : 0) * (T + 1) * S;
-    const int m = N - 4, n4 = N >> 2;
+    TR *buf = reinterpret_cast<TR *>(smem) + (W == 1 ? wave : 0) * (T + 1) * S;
+    const int m = N - 4, nq = N / CH;
     int phase = 0;
-    // LDS slot of the 4-element chunk c = j * T + t (the unit of the coalesced global accesses)
+    // LDS slot of the 16-byte chunk c = j * T + t (the unit of the coalesced global accesses)
     int slot[Q];
 #pragma unroll
     for (int j = 0; j < Q; j++) {
-        const int e0 = 4 * (j * T + t);
+        const int e0 = CH * (j * T + t);
         slot[j] = (e0 / EPL) * S + (e0 % EPL);
     }
     const long groups = (n_frames + RPW - 1) / RPW;
@@ -334,15 +440,16 @@ __global__ __launch_bounds__(W == 1 ? 256 : 64 * W) void k_post_sel(const float 
 #pragma unroll
         for (int j = 0; j < Q; j++) {
             const int c = j * T + t;
-            q[j] = row4[(FULL || c < n4) ? c : 0];   // chunks past the row re-read chunk 0 (their elements are never used)
+            q[j] = row4[(FULL || c < nq) ? c : 0];   // chunks past the row re-read chunk 0 (their elements are never used)
         }
 #pragma unroll
         for (int j = 0; j < Q; j++) *reinterpret_cast<float4 *>(buf + slot[j]) = q[j];
-        // rows of more than T * EPL points (N - 4 <= T * EPL < N): the last thread's window reaches into one more chunk
-        if (!FULL && t == 0 && T * Q < n4) *reinterpret_cast<float4 *>(buf + T * S) = row4[T * Q];
+        // rows of more than T * EPL points (N - 4 <= T * EPL < N): the last thread's window reaches into four more elements
+        if (!FULL && t < PC::TAILQ && T * Q + t < nq) *reinterpret_cast<float4 *>(buf + T * S + CH * t) = row4[T * Q + t];
         row_sync<W == 1>();
-        post_row_staged<EPL, W, FULL>(buf, slot, t, m, red, wave, lane, phase,
-                                      post ? reinterpret_cast<float4 *>(post + (size_t)f * m) : nullptr, row_lo, row_hi, f, row_thr);
+        post_row_staged<EPL, W, FULL, TR>(buf, slot, t, m, red, wave, lane, phase,
+                                          post ? reinterpret_cast<float4 *>(post + (size_t)f * m) : nullptr, row_lo, row_hi, f, row_thr, vals,
+                                          disp_w);
     }
 }
 
@@ -398,50 +505,60 @@ __global__ __launch_bounds__(256) void k_slide_extremes(const T *__restrict__ ro
     }
 }
 
-// np.interp(np.linspace(0, len-1, W), np.arange(len), row)[x] in float64 (pyspecsdr.py:1379-1383 / :1550-1554)
-template <class Row>
-__device__ __forceinline__ double interp_at(const Row &row, int len, int W, int x)
-{
-    const double stop = (double)(len - 1);
-    double xp;
-    if (W == 1) xp = 0.0;
-    else {
-        const double step = stop / (double)(W - 1);
-        xp = (x == W - 1) ? stop : (double)x * step;
-    }
-    if (xp >= stop) return (double)row[len - 1];
-    const int j = (int)xp;
-    const double slope = ((double)row[j + 1] - (double)row[j]) / ((double)(j + 1) - (double)j);
-    return slope * (xp - (double)j) + (double)row[j];
-}
-
-// element j of the post-processed row rebuilt from the float32 dB row and the row's clamp threshold, bit for bit what k_post_sel
-// stores: float32(sum_k (double)db[j + k] * 0.2) in np.convolve's order, then the maximum with the threshold on the ordered images
+// element j of the post-processed row rebuilt from the dB row and the row's clamp threshold, bit for bit what k_post_sel
+// stores: (float32 rows: the float32 rounding of) sum_k (double)db[j + k] * 0.2 in np.convolve's order, then the maximum with the
+// threshold on the ordered images
+template <class T>
 struct PostFromDb {
-    const float *db;       // the frame's dB row (n_fft = len + 4 points)
-    unsigned thr;          // ordered image of the clamp threshold
-    __device__ __forceinline__ float operator[](int j) const
+    const T *db;                  // the frame's dB row (n_fft = len + 4 points)
+    typename Ord<T>::K thr;       // ordered image of the clamp threshold
+    __device__ __forceinline__ T operator[](int j) const
     {
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < 5; k++) acc += (double)db[j + k] * 0.2;
-        const unsigned kk = f2ord((float)acc);
-        return ord2f(kk > thr ? kk : thr);
+        const typename Ord<T>::K kk = Ord<T>::enc((T)acc);
+        return Ord<T>::dec(kk > thr ? kk : thr);
     }
 };
 
-// One display line per frame: the NEWEST row of the history as the reference draws it at frame i (waterfall line y = 0).
+// one display cell from the resampled value v and the window extremes:
 //   MODE 0  waterfall (pyspecsdr.py:1386-1403): glyph 0 '.', 1 '-', 2 '=', 3 '#'; colour int(norm * 5); -1: not finite.
 //           No zero-range guard (:1389), as in the reference.
 //   MODE 1  persistence (:1556-1563): y = int((1 - norm) * (disp_h - 1)) of the newest trace, -1 if not drawn (not finite or
 //           outside the grid); range 0 -> 1 (:1528-1530).
-// FROM_DB: `post` holds the float32 dB rows (len + 4 points each) and row_thr the clamp thresholds: the post-processed rows were
+template <int MODE>
+__device__ __forceinline__ void quantise_cell(double v, double lo, double hi, int disp_h, int8_t &a, int8_t &b)
+{
+    if (MODE == 0) {
+        int8_t g = -1, ci = -1;
+        if (isfinite(v)) {
+            const double nv = (v - lo) / (hi - lo);
+            ci = (int8_t)(int)(nv * 5);
+            g = nv > 0.75 ? 3 : nv > 0.5 ? 2 : nv > 0.25 ? 1 : 0;
+        }
+        a = g;
+        b = ci;
+    } else {
+        int8_t y8 = -1;
+        if (isfinite(v)) {
+            double range = hi - lo;
+            if (range == 0) range = 1;
+            const int y = (int)((1 - (v - lo) / range) * (disp_h - 1));
+            if (y >= 0 && y < disp_h) y8 = (int8_t)y;
+        }
+        a = y8;
+    }
+}
+
+// One display line per frame: the NEWEST row of the history as the reference draws it at frame i (waterfall line y = 0).
+// FROM_DB: `post` holds the dB rows (len + 4 points each) and row_thr the clamp thresholds: the post-processed rows were
 // never written (the line needs two neighbouring elements of it per cell: 10 dB values).
 template <class T, int MODE, bool FROM_DB = false>
 __global__ __launch_bounds__(256) void k_disp_rows(const T *__restrict__ post, const double *__restrict__ win_lo,
                                                    const double *__restrict__ win_hi, long n_frames, int len, int disp_w,
                                                    int disp_h, int8_t *__restrict__ out_a, int8_t *__restrict__ out_b,
-                                                   const float *__restrict__ row_thr = nullptr)
+                                                   const T *__restrict__ row_thr = nullptr)
 {
     const long total = n_frames * disp_w;
     for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
@@ -450,31 +567,31 @@ __global__ __launch_bounds__(256) void k_disp_rows(const T *__restrict__ post, c
         const double lo = win_lo[f], hi = win_hi[f];
         double v;
         if constexpr (FROM_DB) {
-            static_assert(sizeof(T) == 4, "dB rows are float32");
-            const PostFromDb row{reinterpret_cast<const float *>(post) + (size_t)f * (len + 4), f2ord(row_thr[f])};
+            const PostFromDb<T> row{post + (size_t)f * (len + 4), Ord<T>::enc(row_thr[f])};
             v = interp_at(row, len, disp_w, x);
         } else {
             v = interp_at(post + (size_t)f * len, len, disp_w, x);
         }
-        if (MODE == 0) {
-            int8_t g = -1, ci = -1;
-            if (isfinite(v)) {
-                const double nv = (v - lo) / (hi - lo);
-                ci = (int8_t)(int)(nv * 5);
-                g = nv > 0.75 ? 3 : nv > 0.5 ? 2 : nv > 0.25 ? 1 : 0;
-            }
-            out_a[c] = g;
-            out_b[c] = ci;
-        } else {
-            int8_t y8 = -1;
-            if (isfinite(v)) {
-                double range = hi - lo;
-                if (range == 0) range = 1;
-                const int y = (int)((1 - (v - lo) / range) * (disp_h - 1));
-                if (y >= 0 && y < disp_h) y8 = (int8_t)y;
-            }
-            out_a[c] = y8;
-        }
+        int8_t a, b = 0;
+        quantise_cell<MODE>(v, lo, hi, disp_h, a, b);
+        out_a[c] = a;
+        if (MODE == 0) out_b[c] = b;
+    }
+}
+
+// The same line from the row already resampled to the display width (k_post_sel's `vals`): disp_w float64 values per frame instead of the row.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_disp_vals(const double *__restrict__ vals, const double *__restrict__ win_lo,
+                                                   const double *__restrict__ win_hi, long n_frames, int disp_w, int disp_h,
+                                                   int8_t *__restrict__ out_a, int8_t *__restrict__ out_b)
+{
+    const long total = n_frames * disp_w;
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
+        const long f = c / disp_w;
+        int8_t a, b = 0;
+        quantise_cell<MODE>(vals[c], win_lo[f], win_hi[f], disp_h, a, b);
+        out_a[c] = a;
+        if (MODE == 0) out_b[c] = b;
     }
 }
 

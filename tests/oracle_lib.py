@@ -89,6 +89,9 @@ def lib():
         L.pss_o_batch_spectrum_post_nfm.argtypes = [_f32p, C.c_long, C.c_int, C.c_double, C.c_int, _f64p, _f64p, _f64p, _f32p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, _i16p, C.c_int]
         L.pss_o_waterfall_rows.argtypes = [_f32p, C.c_long, C.c_int, C.c_int, C.c_int, _i8p, _i8p, C.c_int]
+        L.pss_o_batch_headline_f64.argtypes = [_f32p, C.c_long, C.c_int, C.c_double, C.c_int, _f64p, _f64p, _f64p, C.c_void_p, C.c_void_p,
+                                               _f64p, _f64p, C.c_void_p, C.c_int]
+        L.pss_o_waterfall_rows_f64.argtypes = [_f64p, _f64p, _f64p, C.c_long, C.c_int, C.c_int, C.c_int, _i8p, _i8p, C.c_int]
         L.pss_o_persistence_rows.argtypes = [_f32p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _i8p, C.c_int]
         _lib = L
     return _lib
@@ -367,6 +370,29 @@ def batch_headline(iq2d, fs, taps, sos, zi, buf, n_threads=1, window=30):
     L.pss_o_waterfall_rows(buf.post[:nf].reshape(-1), nf, n - 4, window, buf.glyph.shape[1], buf.glyph[:nf].reshape(-1),
                            buf.colour[:nf].reshape(-1), n_threads)
     return buf
+
+
+def headline_f64(iq2d, fs, taps, sos, zi, window=30, disp_w=112, n_threads=1, pcm=True, keep_db=False):
+    """The reference's own step from IQ in its own row type (float64 rows from compute_fft to the cells): per frame the post-processed
+    row, its extremes, the waterfall line (glyph, colour) with a history of `window` rows, the NFM int16 PCM.  -> dict."""
+    iq2d = np.ascontiguousarray(iq2d, np.complex64)
+    nf, n = iq2d.shape
+    q = int(fs / 22050)
+    n_out = (n - 1 + q - 1) // q
+    out = {"post": np.empty((nf, n - 4), np.float64), "lo": np.empty(nf, np.float64), "hi": np.empty(nf, np.float64),
+           "glyph": np.empty((nf, disp_w), np.int8), "colour": np.empty((nf, disp_w), np.int8)}
+    if pcm:
+        out["pcm"] = np.empty((nf, n_out, 2), np.int16)
+    if keep_db:
+        out["db"] = np.empty((nf, n), np.float64)
+    L = lib()
+    L.pss_o_batch_headline_f64(iq2d.view(np.float32).reshape(-1), nf, n, fs, q, np.ascontiguousarray(taps, np.float64),
+                               np.ascontiguousarray(sos, np.float64), np.ascontiguousarray(zi, np.float64),
+                               out["db"].ctypes.data if keep_db else None, out["post"].ctypes.data, out["lo"], out["hi"],
+                               out["pcm"].ctypes.data if pcm else None, n_threads)
+    L.pss_o_waterfall_rows_f64(out["post"].reshape(-1), out["lo"], out["hi"], nf, n - 4, window, disp_w, out["glyph"].reshape(-1),
+                               out["colour"].reshape(-1), n_threads)
+    return out
 
 
 def persistence_rows(rows, window, disp_h, disp_w, n_threads=1):

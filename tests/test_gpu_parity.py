@@ -322,6 +322,115 @@ def test_float64_rows_pipeline_draws_the_reference_cells(golden):
     assert np.array_equal(G.host(d_p)[1], sm[1], equal_nan=True)
 
 
+def test_float64_pipeline_register_kernels_equal_plain_kernels_and_numpy():
+    """The float64-row entry points on the register kernels (k_spectrum_r16<..., D64>, k_post_sel<..., double>, the lines from the rows
+    resampled in the same pass) against the plain round-3 kernels (option "f64_plain") and NumPy: dB rows within 1e-11 of each other
+    (np.log10 against the table evaluation), the post-process bit for bit np.convolve / np.median / the clamp of the SAME dB rows at
+    every length the register select serves, rows with a NaN / infinities, materialised and not materialised rows giving the same lines."""
+    e = G.engine()
+    rng = np.random.default_rng(11)
+    for n in (256, 512, 1024, 2048, 4096):
+        x = ((rng.standard_normal((37, n)) + 1j * rng.standard_normal((37, n))) * 0.2).astype(np.complex64)
+        d_a, d_b = G.empty((37, n), torch.float64), G.empty((37, n), torch.float64)
+        e.spectrum_db_f64(G.dev(x), 37, n, d_a)
+        e.set_option("f64_plain", 1)
+        e.spectrum_db_f64(G.dev(x), 37, n, d_b)
+        e.set_option("f64_plain", 0)
+        e.sync()
+        want = np.stack([O.compute_fft(f) for f in x])
+        assert np.allclose(G.host(d_a), want, rtol=1e-11, atol=1e-11), n
+        assert np.allclose(G.host(d_a), G.host(d_b), rtol=1e-11, atol=1e-11), n
+    for n in (8, 12, 64, 260, 516, 1000, 1024, 1028, 2048, 3000, 4096, 5000, 8192, 16384, 16388):
+        nf = 9
+        rows = rng.standard_normal((nf, n)) * 6.0 - 50.0
+        rows[1] = np.round(rows[1])                         # many equal values: ties at the median
+        rows[2, :] = -47.25                                 # a constant row
+        if n >= 64:
+            rows[3, 5:9] = np.inf
+            rows[4, 7] = -np.inf
+            rows[5, n // 2] = np.nan                        # np.median -> NaN: nothing is clamped
+            rows[6, 3] = np.inf; rows[6, 30] = -np.inf      # inf - inf inside a window never meets here; both kinds of infinity in one row
+        d_rows = G.dev(rows)
+        outs = []
+        for plain in (0, 1):
+            e.set_option("f64_plain", plain)
+            d_p, d_lo, d_hi = G.empty((nf, n - 4), torch.float64), G.empty((nf,), torch.float64), G.empty((nf,), torch.float64)
+            e.spectrum_post_f64(d_rows, nf, n, d_p, d_lo, d_hi)
+            e.sync()
+            outs.append((G.host(d_p), G.host(d_lo), G.host(d_hi)))
+        e.set_option("f64_plain", 0)
+        m = n - 4
+        for k in range(nf):
+            sm = rows[k, 0:m] * 0.2
+            for j in range(1, 5):
+                sm = sm + rows[k, j:j + m] * 0.2
+            with np.errstate(invalid="ignore"):
+                med = np.median(sm)
+                want = sm.copy()
+                want[want < med - 10] = med - 10
+            assert np.array_equal(outs[0][0][k], want, equal_nan=True), (n, k)
+            fin = want[np.isfinite(want)]
+            if fin.size:
+                assert outs[0][1][k] == fin.min() and outs[0][2][k] == fin.max(), (n, k)
+            else:
+                assert outs[0][1][k] == np.inf and outs[0][2][k] == -np.inf, (n, k)
+        assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True), n
+        assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2]), n
+    # the pipeline: rows not materialised (one pass leaves extremes + the rows resampled to the display width) == rows materialised
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    for nf, n, fs, W in ((3000, 1024, 2.4e6, 112), (100, 4096, 2.4e6, 200), (64, 256, 2.4e6, 300), (20, 8192, 2.4e6, 112)):
+        iq = torch.randn((nf, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3
+        n_out = e.demod_out_len(0, n, fs)
+        def bufs():
+            return dict(db=G.empty((nf, n), torch.float64), lo=G.empty((nf,), torch.float64), hi=G.empty((nf,), torch.float64),
+                        g=G.empty((nf, W), torch.int8), c=G.empty((nf, W), torch.int8), pcm=G.empty((nf, n_out, 2), torch.int16))
+        a, b = bufs(), bufs()
+        d_post = G.empty((nf, n - 4), torch.float64)
+        torch.cuda.synchronize()
+        e.frame_pipeline_nfm_f64(iq, nf, n, fs, a["db"], d_post, a["lo"], a["hi"], W, a["g"], a["c"], a["pcm"])
+        e.frame_pipeline_nfm_f64(iq, nf, n, fs, b["db"], None, b["lo"], b["hi"], W, b["g"], b["c"], b["pcm"])
+        e.sync()
+        for k in a:
+            assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, n, k)
+        # and the float32 pipeline's lines without materialised rows == with them (the resampled-row path against k_disp_rows)
+        def bufs32():
+            return dict(db=G.empty((nf, n), torch.float32), lo=G.empty((nf,), torch.float32), hi=G.empty((nf,), torch.float32),
+                        g=G.empty((nf, W), torch.int8), c=G.empty((nf, W), torch.int8), pcm=G.empty((nf, n_out, 2), torch.int16))
+        a, b = bufs32(), bufs32()
+        d_post32 = G.empty((nf, n - 4), torch.float32)
+        e.frame_pipeline_nfm(iq, nf, n, fs, a["db"], d_post32, a["lo"], a["hi"], W, a["g"], a["c"], a["pcm"])
+        e.frame_pipeline_nfm(iq, nf, n, fs, b["db"], None, b["lo"], b["hi"], W, b["g"], b["c"], b["pcm"])
+        e.sync()
+        for k in a:
+            assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, n, k, "float32 rows")
+
+
+def test_full_size_float64_pipeline_cells_equal_the_oracle_from_iq():
+    """BASELINE.json cfg 2 size (65 536 x 1024) through pss_frame_pipeline_nfm_f64 without materialised rows — the cell-exact step bench.py
+    times: EVERY waterfall cell (glyph and colour, 2 x 7.3 million) and every int16 PCM sample against the oracle's own step from IQ in the
+    reference's row type (float64 compute_fft rows -> np.convolve / np.median / clamp -> draw_waterfall's min / max over the last 30 rows,
+    np.interp, quantisation), and the row extremes to 1e-11."""
+    e = G.engine()
+    nf, n, fs, W, win = 65536, 1024, 2.4e6, 112, 30
+    import bench
+    iq = bench.synth_fm_iq(nf, n, fs, torch.device("cuda", 0), seed=777)
+    torch.cuda.synchronize()
+    d_db = G.empty((nf, n), torch.float64)
+    d_lo, d_hi = G.empty((nf,), torch.float64), G.empty((nf,), torch.float64)
+    d_g, d_c = G.empty((nf, W), torch.int8), G.empty((nf, W), torch.int8)
+    d_pcm = G.empty((nf, 10, 2), torch.int16)
+    e.frame_pipeline_nfm_f64(iq, nf, n, fs, d_db, None, d_lo, d_hi, W, d_g, d_c, d_pcm, window=win)
+    e.sync()
+    taps, sos, zi = e.nfm_filters(fs)
+    import os
+    o = O.headline_f64(iq.cpu().numpy().view(np.complex64).reshape(nf, n), fs, taps, sos, zi, win, W, len(os.sched_getaffinity(0)))
+    assert np.array_equal(G.host(d_pcm), o["pcm"])
+    assert np.allclose(G.host(d_lo), o["lo"], rtol=0, atol=1e-10) and np.allclose(G.host(d_hi), o["hi"], rtol=0, atol=1e-10)
+    g, c = G.host(d_g), G.host(d_c)
+    bad = int(np.count_nonzero(g != o["glyph"])) + int(np.count_nonzero(c != o["colour"]))
+    assert bad == 0, f"{bad} of {2 * g.size} cells differ from the oracle's cells computed from IQ"
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f", "g"])
 def test_nfm_vs_golden_bit_exact(golden, tag):
     g = golden["nfm"]
@@ -1768,7 +1877,10 @@ def test_frame_pipeline_modes_equal_separate_calls(mode, display):
     points byte for byte; with materialised post-processed rows and without; small batches (systolic kernels) and large ones."""
     e = G.engine()
     gen = torch.Generator(device="cuda").manual_seed(123 + mode)
-    shapes = ((7000, 1024, 2.4e6), (40, 8192, 2.4e6)) if mode in (L.MODE_NFM, L.MODE_WFM) else ((600, 1024, 2.4e6), (33, 8192, 2.4e6), (9, 16384, 2.4e6))
+    # 32 768 (the reference's default read, pyspecsdr.py:2236) and 65 536 samples: hilbert() of USB / LSB frames and the side stream's
+    # spectrum both take their scratch-based kernels there — each has its own scratch buffer (they once shared ctx->scratch_fft)
+    shapes = ((7000, 1024, 2.4e6), (40, 8192, 2.4e6)) if mode in (L.MODE_NFM, L.MODE_WFM) else ((600, 1024, 2.4e6), (33, 8192, 2.4e6), (9, 16384, 2.4e6),
+                                                                                                  (5, 32768, 2.4e6), (3, 65536, 2.4e6), (2, 131072, 2.4e6))
     for nf, n, fs in shapes:
         iq = torch.randn((nf, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3 + 0.05
         torch.cuda.synchronize()
