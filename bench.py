@@ -10,10 +10,15 @@ one-GPU number labelled N.  The result line carries the world size RCCL reported
 
 One "step" = one pass of the hot path over one batch of synthetic FM-modulated IQ already resident in HBM
 (BASELINE.json configs[1] = 65 536 frames x 1024 points @ 2.4 MS/s per GPU), for EVERY frame of the batch:
-    compute_fft dB spectrum (signal_processing.py:243-264)            -> float32 [frames][1024]
-    the caller's smoothing + median clamp (pyspecsdr.py:2278-2283)     -> float32 [frames][1020]
-    the waterfall accumulator's newest display line (:1342-1406)       -> int8 glyph + colour [frames][112]
+    compute_fft dB spectrum (signal_processing.py:243-264)            -> float64 [frames][1024] (the reference's own row type)
+    the caller's smoothing + median clamp (pyspecsdr.py:2278-2283)     -> row extremes + the row resampled to the display width (the rows
+                                                                          themselves only with --materialise-post)
+    the waterfall accumulator's newest display line (:1342-1406)       -> int8 glyph + colour [frames][112]: the reference's cells
     demodulate_nfm -> int16 stereo (signal_processing.py:91-116)       -> int16 [frames][10][2]
+--rows f32 times the same step on float32 dB rows (pss_frame_pipeline_nfm: 1e-4-relative spectra, a display cell may differ from the
+reference's where a value sits on a quantisation edge); the default line carries that step too, as other_configs.cfg2_f32_rows.
+The timed region (K steps between fences) is run R times (--regions, default 5): ms_per_step / value are the MEDIAN region's, with the
+minimum, maximum and the shader clock before / after beside them.
 Frames are independent, so N GPUs each process their own batch (weak scaling).  The one exchange step of the path
 (BASELINE.json north_star: "a trivial RCCL gather over xGMI") is INSIDE the timed region when N > 1: after every step
 each rank's display lines + PCM (one packed buffer, 17 MB) are gathered to rank 0 over RCCL, on a side stream,
@@ -49,18 +54,25 @@ WF_WINDOW = 30        # WATERFALL_MAX_LINES (pyspecsdr.py:131)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 F64_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9  # float64 VALU: 16 lanes / clk / SIMD x 1024 SIMDs x 2.4 GHz = 39.3e12 (= 78.6 TFLOP/s FMA)
 
-# algorithmic bytes per frame: what each kernel must move if nothing is re-read or spilled
-ALGO_BYTES = {
-    "k_spectrum": N_FFT * 8 + N_FFT * 4,            # IQ in + float32 dB out
-    "k_nfm_fwd": N_FFT * 8,                         # IQ in (y_fwd is an internal hand-off, not algorithmic)
-    "k_nfm_bwd": 40,                                # 10 x 2 x int16 out
-    "k_post": N_FFT * 4 + 12,                       # dB row in; clamp threshold + extremes out (the post-processed row is not materialised)
-    "k_disp_rows": N_FFT * 4 + 2 * DISP_W,          # dB row in (the cells' elements of the post-processed row are rebuilt), glyph + colour line out
-    "k_slide_extremes": 8 + 16,
-    "k_nfm_front": N_FFT * 8, "k_nfm_edge": 0, "k_nfm_iir": 40,   # three-kernel fallback path (PSS_NO_FUSED=1)
-    # 12 328 B/frame (IQ read once, dB row, PCM) + the materialised waterfall line (glyph and colour)
-    "path": N_FFT * 8 + N_FFT * 4 + 40 + 2 * DISP_W,
-}
+SURVEY_BYTES_PER_FRAME = N_FFT * 8 + N_FFT * 4 + 40   # IQ read once, a float32 dB row, the PCM = 12 328 B
+
+
+def algo_bytes(row_bytes):
+    """algorithmic bytes per frame: what each kernel must move if nothing is re-read or spilled; row_bytes = 4 / 8 per dB bin"""
+    return {
+        "k_spectrum": N_FFT * 8 + N_FFT * row_bytes,    # IQ in + dB row out
+        "k_nfm_fwd": N_FFT * 8,                         # IQ in (y_fwd is an internal hand-off, not algorithmic)
+        "k_nfm_bwd": 40,                                # 10 x 2 x int16 out
+        "k_post": N_FFT * row_bytes + 2 * row_bytes + DISP_W * 8,   # dB row in; extremes + the row resampled to the display width out
+        "k_disp_rows": DISP_W * 8 + 2 * DISP_W,         # resampled row in, glyph + colour line out
+        "k_slide_extremes": 2 * row_bytes + 16,
+        "k_nfm_front": N_FFT * 8, "k_nfm_edge": 0, "k_nfm_iir": 40,   # three-kernel fallback path (PSS_NO_FUSED=1)
+        # what the step has to move: IQ read once, the dB row, the PCM, the waterfall line (glyph and colour)
+        "path": N_FFT * 8 + N_FFT * row_bytes + 40 + 2 * DISP_W,
+    }
+
+
+ALGO_BYTES = algo_bytes(8)   # (main() replaces it with the timed row type's)
 HBM_BOUND = ("k_spectrum", "k_post", "k_disp_rows")
 # float64 VALU operations per input sample and lane of k_nfm_fwd, fixed by the reference's accumulation order (DESIGN.md §4;
 # measured with SQ_INSTS_VALU_{FMA,ADD,MUL}_F64: profiles/r02_valu_instruction_mix.txt): 63 fma + 51 add + 12 mul
@@ -121,14 +133,14 @@ def step_traffic(kernels, n_frames):
         if t.get("src_hash") != source_hash():
             return None, None
         ks = t["kernels"]
-        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel"}
+        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel", "k_disp_rows": "k_disp_vals"}
         tot = 0.0
         for k in kernels:
             d = ks.get(names.get(k, k))
             if not d or d.get("traffic_bytes") is None:
                 return None, None
             tot += d["traffic_bytes"] * n_frames / float(t["n_frames"])
-        return tot, tot / ((N_FFT * 8 + N_FFT * 4 + 40) * float(n_frames))
+        return tot, tot / (SURVEY_BYTES_PER_FRAME * float(n_frames))
     except Exception:  # noqa: BLE001
         return None, None
 
@@ -142,7 +154,7 @@ def step_valu(kernels, n_frames, ms_per_step):
         if t.get("src_hash") != source_hash() or n_frames != t["n_frames"]:
             return None
         ks = t["kernels"]
-        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel"}
+        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel", "k_disp_rows": "k_disp_vals"}
         per = {}
         for k in kernels:
             d = ks.get(names.get(k, k))
@@ -171,86 +183,101 @@ def synth_fm_iq(n_frames, n, fs, device, seed):
     return iq.contiguous()
 
 
-def cpu_baseline(iq_host, fs, taps, sos, zi, min_wall_s=1.0, max_wall_s=25.0):
-    """The oracle's port of the same step (spectrum + post-process + waterfall line + NFM + int16), OpenMP over frames, on
-    the whole batch, repeated until every thread has had >= min_wall_s of work (the all-core number is not a 6 ms burst)."""
+def host_cpu():
+    """CPU model string, hardware threads, and the threads this process may use (affinity capped by the cgroup quota)."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores = os.cpu_count() or 1
+    quota = None
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except OSError:
+        pass
+    return {"model": model, "hw_threads": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_max": quota,
+            "threads_usable": O.threads_available()}
+
+
+def cpu_baseline(iq_host, fs, taps, sos, zi, min_wall_s=1.0, max_wall_s=25.0):
+    """The oracle's port of the same step in the reference's own row type (float64 compute_fft rows, post-process, waterfall line, NFM +
+    int16: oracle_lib.headline_f64), OpenMP over contiguous blocks of frames (scratch and tables once per thread), on as many threads as
+    this process may run on, repeated until every thread has had >= min_wall_s of work (the all-core number is not a 6 ms burst)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    host = host_cpu()
+    cores = host["threads_usable"]
     nf, n = iq_host.shape
-    buf = O.HeadlineBuffers(nf, n, fs, DISP_W)
+    b1 = O.headline_f64_buffers(512, n, fs, DISP_W)
+    O.headline_f64(iq_host[:512], fs, taps, sos, zi, WF_WINDOW, DISP_W, 1, out=b1)      # tables, page faults
     t0 = time.perf_counter()
-    O.batch_headline(iq_host[:512], fs, taps, sos, zi, buf, 1)
+    O.headline_f64(iq_host[:512], fs, taps, sos, zi, WF_WINDOW, DISP_W, 1, out=b1)
     per_frame_1t = (time.perf_counter() - t0) / 512
     # one pass ~ 2 s of wall time on this host (the whole batch on a 256-thread box, fewer frames on a small one)
     nf = int(min(nf, max(cores * 64, 2.0 / per_frame_1t * cores)))
     iq_host = iq_host[:nf]
-    O.batch_headline(iq_host, fs, taps, sos, zi, buf, cores)        # warm-up: thread pool, page faults of the outputs
+    buf = O.headline_f64_buffers(nf, n, fs, DISP_W)
+    O.headline_f64(iq_host, fs, taps, sos, zi, WF_WINDOW, DISP_W, cores, out=buf)        # warm-up: thread pool, page faults of the outputs
     reps, t0 = 0, time.perf_counter()
     while True:
-        O.batch_headline(iq_host, fs, taps, sos, zi, buf, cores)
+        O.headline_f64(iq_host, fs, taps, sos, zi, WF_WINDOW, DISP_W, cores, out=buf)
         reps += 1
         wall = time.perf_counter() - t0
         if wall >= min_wall_s and (wall >= max_wall_s or reps >= 3):
             break
     return {
         "value": reps * nf * n / wall, "unit": "IQ samples/s", "cores": cores, "kind": "port",
-        "sample": f"{nf} frames x {n} pts x {reps} passes in {wall:.2f} s wall (spectrum + post-process + waterfall line + NFM + "
-                  f"int16, filters designed once), OpenMP over frames, {wall:.2f} s busy per thread",
+        "sample": f"{nf} frames x {n} pts x {reps} passes in {wall:.2f} s wall (float64 spectrum rows + post-process + waterfall line + NFM + "
+                  f"int16, filters and tables designed once), OpenMP over contiguous blocks of frames on {cores} threads",
         "single_thread_value": n / per_frame_1t,
+        "scaling": (reps * nf * n / wall) / (n / per_frame_1t) / cores,
+        "host": host,
     }
 
 
-def verify_step(eng, iq, fs, d_db, d_post, pk, o_col, o_pcm, n_out, window):
+def shader_clock_mhz():
+    """Current shader clock of GPU 0 (MHz) from sysfs (pp_dpm_sclk: the level marked '*'), else rocm-smi, else None."""
+    import glob
+    import re
+    import subprocess
+    try:
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            for line in open(f):
+                if "*" in line:
+                    m = re.search(r"(\d+)\s*Mhz", line, re.I)
+                    if m:
+                        return int(m.group(1))
+    except OSError:
+        pass
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "-d", "0"], capture_output=True, text=True, timeout=20).stdout
+        m = re.search(r"sclk clock level:?\s*\S*\s*\((\d+)Mhz\)", out, re.I)
+        return int(m.group(1)) if m else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def verify_step(eng, iq, fs, d_db, d_lo, d_hi, pk, o_col, o_pcm, n_out, window, rows_f64):
     """Outside the timed region: the outputs the LAST timed step left in HBM against the CPU oracle (oracle/pss_oracle.c, the checker,
-    never the thing measured) on blocks of consecutive frames spread over the batch — dB rows (1e-4 relative), post-processed
-    rows (same tolerance), NFM int16 PCM (equal), waterfall lines (equal to the oracle's quantiser run on the rows the device produced;
-    lines whose 30-row history starts before the block are skipped except in the block that starts at frame 0)."""
+    never the thing measured) on blocks of 256 consecutive frames spread over the batch: the oracle runs its OWN step from the IQ in the
+    reference's row type (float64 rows from compute_fft to the cells) — dB rows, row extremes, NFM int16 PCM (equal) and every display cell
+    of the lines whose 30-row history lies inside the block (tools/bench_configs.py check_from_iq: cells_differing is a count)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs
     import oracle_lib as O
-    nf, n = iq.shape[0], iq.shape[1]
-    m = n - 4
-    blk = min(nf, window + 10)
-    starts = sorted({0, max(0, nf // 3 - 7), max(0, (2 * nf) // 3 + 5), nf - blk})
-    taps, sos, zi = eng.nfm_filters(fs)
+    nf = iq.shape[0]
     glyph = pk[:o_col].view(torch.int8).view(nf, DISP_W)
     colour = pk[o_col:o_pcm].view(torch.int8).view(nf, DISP_W)
     pcm = pk[o_pcm:].view(torch.int16).view(nf, n_out, 2)
-    res = {"frames": 0, "lines_checked": 0, "db_max_rel": 0.0, "post_max_rel": 0.0, "pcm_equal": True, "lines_equal": True,
-           "blocks": [[s0, s0 + blk] for s0 in starts]}
-    rel = lambda got, ref: float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)))
-    for s0 in starts:
-        sl = slice(s0, s0 + blk)
-        h_iq = iq[sl].cpu().numpy().view(np.complex64).reshape(blk, n)
-        buf = O.HeadlineBuffers(blk, n, fs, DISP_W)
-        O.batch_headline(h_iq, fs, taps, sos, zi, buf, 1, window)
-        g_db, g_pcm = d_db[sl].cpu().numpy(), pcm[sl].cpu().numpy()
-        res["db_max_rel"] = max(res["db_max_rel"], rel(g_db.astype(np.float64), buf.db.astype(np.float64)))
-        res["pcm_equal"] = res["pcm_equal"] and bool(np.array_equal(g_pcm, buf.pcm))
-        if d_post is not None:
-            g_post = np.ascontiguousarray(d_post[sl].cpu().numpy())
-        else:
-            # the step did not materialise the post-processed rows: rebuild them on the host from the device's float32 dB rows exactly
-            # as the display kernel does per cell (np.convolve's order in float64, rounded to float32, clamped at float32(median - 10))
-            d64 = g_db.astype(np.float64)
-            acc = d64[:, 0:m] * 0.2
-            for k in range(1, 5):
-                acc = acc + d64[:, k:k + m] * 0.2
-            sm = acc.astype(np.float32)
-            srt = np.sort(sm, axis=1)
-            med = 0.5 * (srt[:, (m - 1) // 2].astype(np.float64) + srt[:, m // 2].astype(np.float64))
-            g_post = np.ascontiguousarray(np.maximum(sm, (med - 10.0).astype(np.float32)[:, None]))
-        ref_post = np.stack([O.postprocess(g_db[k].astype(np.float64)) for k in range(blk)])
-        res["post_max_rel"] = max(res["post_max_rel"], rel(g_post.astype(np.float64), ref_post))
-        O.lib().pss_o_waterfall_rows(g_post.reshape(-1), blk, m, window, DISP_W, buf.glyph.reshape(-1), buf.colour.reshape(-1), 1)
-        first = 0 if s0 == 0 else window - 1        # lines with a complete history inside the block
-        res["lines_equal"] = res["lines_equal"] and bool(np.array_equal(glyph[sl].cpu().numpy()[first:], buf.glyph[first:])
-                                                         and np.array_equal(colour[sl].cpu().numpy()[first:], buf.colour[first:]))
-        res["frames"] += blk
-        res["lines_checked"] += blk - first
-    res["ok"] = bool(res["db_max_rel"] <= 1e-4 and res["post_max_rel"] <= 1e-4 and res["pcm_equal"] and res["lines_equal"])
-    res["note"] = ("outputs of the last timed step vs the CPU oracle, outside the timed region: dB and post-processed rows within 1e-4 * "
-                   "max(|ref|, 1), int16 PCM and waterfall lines (glyph + colour) equal")
+    res = bench_configs.check_from_iq(O, eng, iq, iq.shape[1], fs, d_db, d_lo, d_hi, (glyph, colour), pcm, window, rows_f64=rows_f64)
+    res["note"] = ("outputs of the last timed step vs the CPU oracle's own step from the IQ (float64 rows), outside the timed region, spot-checked "
+                   "on the listed blocks: dB rows and extremes within tolerance, int16 PCM equal, display cells counted")
     return res
 
 
@@ -278,6 +305,10 @@ def main():
     ap.add_argument("--frames", type=int, default=N_FRAMES, help="frames per GPU per step (default: BASELINE cfg 2)")
     ap.add_argument("--exchange", choices=["display", "db", "none"], default="display",
                     help="what is gathered to rank 0 inside the timed region when N > 1")
+    ap.add_argument("--rows", choices=["f64", "f32"], default="f64",
+                    help="row type of the timed step: f64 = the reference's own (compute_fft returns float64; the display cells are the reference's), "
+                         "f32 = float32 dB rows (the other one is timed and verified as other_configs.cfg2_f32_rows / cfg2_exact_cells)")
+    ap.add_argument("--regions", type=int, default=5, help="how many times the K-step timed region is run (median reported, min / max beside it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true",
                     help="skip the untimed side measurements (standalone kernels, the 30-row reading, exchange alone): under a profiler "
@@ -316,31 +347,36 @@ def main():
     eng = Engine(local_rank, order="none")   # this script orders its streams by hand (fences, events)
     comp = torch.cuda.ExternalStream(eng.stream_handle(), device=dev)   # the library's stream, for event ordering
     nf, n = args.frames, N_FFT
+    global ALGO_BYTES
+    rows_f64 = args.rows == "f64"
+    row_dt = torch.float64 if rows_f64 else torch.float32
+    ALGO_BYTES = algo_bytes(8 if rows_f64 else 4)
     iq = synth_fm_iq(nf, n, FS, dev, seed=20260928 + 2 + rank)
     torch.cuda.synchronize(dev)            # the IQ batch is produced on torch's stream, consumed on the library's
     n_out = eng.demod_out_len(0, n, FS)
     m = n - 4
-    d_post = torch.empty((nf, m), dtype=torch.float32, device=dev)      # side measurements; the timed step writes it only with --materialise-post
+    d_post = torch.empty((nf, m), dtype=row_dt, device=dev)      # side measurements; the timed step writes it only with --materialise-post
     step_post = d_post if args.materialise_post else None
-    d_lo = torch.empty((nf,), dtype=torch.float32, device=dev)
-    d_hi = torch.empty((nf,), dtype=torch.float32, device=dev)
+    d_lo = torch.empty((nf,), dtype=row_dt, device=dev)
+    d_hi = torch.empty((nf,), dtype=row_dt, device=dev)
     # two output sets: step k+1 computes into one while step k's is in flight to rank 0.  A set is ONE packed buffer
     # [glyph | colour | pcm] (one message per rank and step) + the dB rows.
     o_col, o_pcm, set_bytes = nf * DISP_W, 2 * nf * DISP_W, 2 * nf * DISP_W + nf * n_out * 4
     packed = [torch.empty((set_bytes,), dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_db = [torch.empty((nf, n), dtype=torch.float32, device=dev) for _ in range(2 if (dist and args.exchange == "db") else 1)]
+    d_db = [torch.empty((nf, n), dtype=row_dt, device=dev) for _ in range(2 if (dist and args.exchange == "db") else 1)]
+    pipeline = eng.frame_pipeline_nfm_f64 if rows_f64 else eng.frame_pipeline_nfm
     exch = args.exchange if dist is not None else "none"
     comm = torch.cuda.Stream(device=dev) if exch != "none" else None
     recv = None
     if exch != "none" and rank == 0:
-        per = set_bytes if exch == "display" else nf * n * 4
+        per = set_bytes if exch == "display" else nf * n * d_db[0].element_size()
         recv = torch.empty((world, per), dtype=torch.uint8, device=dev)
     sent = [None, None]     # event: set b's gather has finished (the set may be overwritten)
 
     def compute(b):
         db = d_db[b % len(d_db)]
         base = packed[b].data_ptr()
-        eng.frame_pipeline_nfm(iq, nf, n, FS, db, step_post, d_lo, d_hi, DISP_W, base, base + o_col, base + o_pcm, window=WF_WINDOW)
+        pipeline(iq, nf, n, FS, db, step_post, d_lo, d_hi, DISP_W, base, base + o_col, base + o_pcm, window=WF_WINDOW)
 
     def exchange(b):
         src = packed[b] if exch == "display" else d_db[b % len(d_db)].view(torch.uint8).view(-1)
@@ -378,15 +414,24 @@ def main():
     dom = max(ktimes, key=ktimes.get)
     eng.timing_filter(dom)
     fence()
-    # timed region: exactly K steps (compute + exchange), barrier + synchronize on both sides
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)   # the dominant kernel's launches are bracketed by HIP events; read back after the fence
-    fence()
-    elapsed = time.perf_counter() - t0
-    live = eng.kernel_times().get(dom, [])
-    assert len(live) >= args.steps and len(live) % args.steps == 0, (dom, len(live))   # some kernels launch twice a step
-    ktimes[dom] = sum(live) / len(live)   # mean launch duration over the K timed steps
+    # timed region: exactly K steps (compute + exchange), barrier + synchronize on both sides — run R times back to back in this process;
+    # the line reports the MEDIAN region (ms_per_step, value) with the fastest and slowest beside it and the shader clock around them
+    clk0 = shader_clock_mhz() if rank == 0 else None
+    regions, live_all = [], []
+    for _ in range(max(1, args.regions)):
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)   # the dominant kernel's launches are bracketed by HIP events; read back after the fence
+        fence()
+        regions.append(time.perf_counter() - t0)
+        live = eng.kernel_times().get(dom, [])
+        assert len(live) >= args.steps and len(live) % args.steps == 0, (dom, len(live))   # some kernels launch twice a step
+        live_all.append(sum(live) / len(live))
+    clk1 = shader_clock_mhz() if rank == 0 else None
+    order = sorted(range(len(regions)), key=lambda i: regions[i])
+    mid = order[len(order) // 2]
+    elapsed = regions[mid]
+    ktimes[dom] = live_all[mid]   # mean launch duration over the K steps of the median region
     eng.timing_filter(None)
     eng.enable_timing(False)
 
@@ -394,7 +439,7 @@ def main():
     verified = None
     if not args.no_verify:
         last = (args.steps - 1) & 1 if args.steps else 0
-        verified = verify_step(eng, iq, FS, d_db[last % len(d_db)], step_post, packed[last], o_col, o_pcm, n_out, WF_WINDOW)
+        verified = verify_step(eng, iq, FS, d_db[last % len(d_db)], d_lo, d_hi, packed[last], o_col, o_pcm, n_out, WF_WINDOW, rows_f64)
         if dist is not None:      # every rank checks its own outputs; the line reports the conjunction
             okt = torch.tensor([1 if verified["ok"] else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
@@ -412,16 +457,17 @@ def main():
     if not args.no_side:
         # each HBM-bound kernel alone (inside a step the spectrum and the post-process run beside the backward IIR pass)
         eng.enable_timing(True)
+        spectrum = eng.spectrum_db_f64 if rows_f64 else eng.spectrum_db
         for _ in range(2):
-            eng.spectrum_db(iq, nf, n, d_db[0])
+            spectrum(iq, nf, n, d_db[0])
         eng.sync(); eng.kernel_times()
         for _ in range(5):
-            eng.spectrum_db(iq, nf, n, d_db[0])
+            spectrum(iq, nf, n, d_db[0])
         eng.sync()
         spec_alone = eng.kernel_times().get("k_spectrum", [])
-        for _ in range(5):      # likewise the post-process kernel
-            if step_post is None:
-                eng.spectrum_post_thresholds(d_db[0], nf, n, d_post, d_lo, d_hi)     # (d_post's first nf floats receive the thresholds)
+        for _ in range(5):      # likewise the post-process kernel (here with the rows written: the separate entry points have no resampled-row output)
+            if rows_f64:
+                eng.spectrum_post_f64(d_db[0], nf, n, d_post, d_lo, d_hi)
             else:
                 eng.spectrum_post_extremes(d_db[0], nf, n, d_post, d_lo, d_hi)
         eng.sync()
@@ -436,11 +482,12 @@ def main():
         d_g30 = torch.empty((36, DISP_W), dtype=torch.int8, device=dev)
         d_c30 = torch.empty((36, DISP_W), dtype=torch.int8, device=dev)
 
-        def step30():
-            eng.spectrum_nfm(iq, nf, n, FS, d_db[0], packed[0].data_ptr() + o_pcm)
-            eng.spectrum_post(d_db[0][nf - WF:], WF, n, d_post)
-            eng.waterfall_cells(d_post, WF, m, 36, DISP_W, d_g30, d_c30)
-        side["ms_per_step_newest_30_rows_only"] = timed(step30)
+        if not rows_f64:
+            def step30():
+                eng.spectrum_nfm(iq, nf, n, FS, d_db[0], packed[0].data_ptr() + o_pcm)
+                eng.spectrum_post(d_db[0][nf - WF:], WF, n, d_post)
+                eng.waterfall_cells(d_post, WF, m, 36, DISP_W, d_g30, d_c30)
+            side["ms_per_step_newest_30_rows_only"] = timed(step30)
         if exch != "none":
             # compute alone, and the exchange alone (both variants), so that overlap can be read off
             side["compute_ms"] = timed(lambda: compute(0))
@@ -454,8 +501,8 @@ def main():
                 return timed(go, 3)
             side["exchange_display_ms"] = xfer(packed[0], set_bytes)
             side["exchange_display_bytes_per_rank"] = set_bytes
-            side["exchange_db_ms"] = xfer(d_db[0].view(torch.uint8).view(-1), nf * n * 4)
-            side["exchange_db_bytes_per_rank"] = nf * n * 4
+            side["exchange_db_ms"] = xfer(d_db[0].view(torch.uint8).view(-1), nf * n * d_db[0].element_size())
+            side["exchange_db_bytes_per_rank"] = nf * n * d_db[0].element_size()
             # how much of the in-region exchange the next step's compute hid: 1 = all of it, 0 = none (step = compute + exchange)
             xms = side["exchange_display_ms"] if exch == "display" else side["exchange_db_ms"]
             side["overlap_frac"] = 1.0 - (elapsed / args.steps * 1e3 - side["compute_ms"]) / xms if xms > 0 else None
@@ -468,7 +515,7 @@ def main():
         # timed region (which ended above); a failing verification fails the run like the headline's
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_configs
-        other = bench_configs.other_configs(eng, dev, verify=not args.no_verify)
+        other = bench_configs.other_configs(eng, dev, verify=not args.no_verify, skip=("cfg2_exact_cells" if rows_f64 else "cfg2_f32_rows",))
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -490,7 +537,10 @@ def main():
                 "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
                 "kernel_ms_note": f"{dom}: HIP events inside the timed region; the others: untimed survey pass before it",
                 "path_achieved": ALGO_BYTES["path"] * nf / (elapsed / args.steps) / 1e9,
-                "path_frac": ALGO_BYTES["path"] * nf / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
+                "path_frac": ALGO_BYTES["path"] * nf / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                "path_bytes_per_frame": ALGO_BYTES["path"],
+                # the same with SURVEY §8(d)'s per-frame bytes (IQ once + a float32 dB row + PCM = 12 328 B), whatever row type is timed
+                "frac_survey_bytes": SURVEY_BYTES_PER_FRAME * nf / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
         if dom_alone:
             ams = sum(dom_alone) / len(dom_alone)
             aa = ALGO_BYTES.get(dom, ALGO_BYTES["path"]) * nf / (ams * 1e-3) / 1e9
@@ -519,19 +569,28 @@ def main():
             hb["k_spectrum_standalone"] = {"ms": round(sms, 4), "achieved": sa, "frac": sa / HBM_PEAK_GBS}
         if post_alone:
             pms = sum(post_alone) / len(post_alone)
-            pa = ALGO_BYTES["k_post"] * nf / (pms * 1e-3) / 1e9
+            rb = 8 if rows_f64 else 4
+            pa = (N_FFT * rb + (N_FFT - 4) * rb + 2 * rb) * nf / (pms * 1e-3) / 1e9     # standalone: rows in, post-processed rows + extremes out
             hb["k_post_standalone"] = {"ms": round(pms, 4), "achieved": pa, "frac": pa / HBM_PEAK_GBS}
         roof["hbm_bound_kernels"] = hb
+        row_desc = "float64 rows, the reference's own type" if rows_f64 else "float32 rows"
         out = {
             "metric": "IQ MSamples/sec end-to-end (FFT+dB+FM demod)",
             "value": value / 1e6, "unit": "MSamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
+            "regions": {"n": len(regions), "ms_per_step": [round(r / args.steps * 1e3, 5) for r in regions],
+                        "reported": "median region (value, ms_per_step, roofline)", "shader_clock_mhz_before": clk0, "shader_clock_mhz_after": clk1},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 front end / f64 FFT+FIR+IIR / int16 PCM", "data": "synthetic",
-            "config": {"workload": f"{nf} frames x {n}-pt complex64 @2.4 MS/s per GPU, every frame: compute_fft dB spectrum + "
+            "dtype": ("complex64 IQ / f64 FFT + dB rows + post-process + FIR + IIR / int16 PCM" if rows_f64
+                      else "f32 front end / f64 FFT+FIR+IIR / f32 dB rows / int16 PCM"),
+            "data": "synthetic",
+            "config": {"workload": f"{nf} frames x {n}-pt complex64 @2.4 MS/s per GPU, every frame: compute_fft dB spectrum "
+                                   f"({row_desc}) + "
                                    f"post-process (smoothing, median clamp) + waterfall display line + NFM demod -> int16 stereo "
                                    f"(BASELINE.json configs[1])",
+                       "rows": args.rows,
                        "materialised": {"db_rows": True, "pcm": True, "waterfall_lines": True, "row_extremes": True,
                                         "post_processed_rows": bool(args.materialise_post)},
                        "frames_per_gpu": nf, "n_fft": n, "sample_rate": FS, "parallelism": f"frames sharded x{world}",

@@ -1481,3 +1481,32 @@ void pss_o_waterfall_rows_f64(const double *rows, const double *row_lo, const do
         }
     }
 }
+
+/* pss_o_persistence_rows on float64 rows with the rows' extremes supplied (draw_persistence :1512-1564, newest trace per frame). */
+void pss_o_persistence_rows_f64(const double *rows, const double *row_lo, const double *row_hi, long n_frames, int len, int window, int disp_h,
+                                int disp_w, int8_t *ycell, int n_threads)
+{
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+#endif
+    for (long f = 0; f < n_frames; f++) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (long p = f - (window - 1) < 0 ? 0 : f - (window - 1); p <= f; p++) {
+            lo = row_lo[p] < lo ? row_lo[p] : lo;
+            hi = row_hi[p] > hi ? row_hi[p] : hi;
+        }
+        double range = hi - lo;
+        if (range == 0) range = 1;
+        const double *row = rows + f * len;
+        for (int x = 0; x < disp_w; x++) {
+            const double v = interp_row(row, len, disp_w, x);
+            int8_t y8 = -1;
+            if (isfinite(v)) {
+                const int y = (int)((1 - (v - lo) / range) * (disp_h - 1));
+                if (y >= 0 && y < disp_h) y8 = (int8_t)y;
+            }
+            ycell[f * disp_w + x] = y8;
+        }
+    }
+}

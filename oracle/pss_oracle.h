@@ -130,6 +130,8 @@ void pss_o_batch_headline_f64(const float *iq, long n_frames, int n, double fs, 
                               int n_threads);
 void pss_o_waterfall_rows_f64(const double *rows, const double *row_lo, const double *row_hi, long n_frames, int len, int window, int disp_w,
                               int8_t *glyph, int8_t *colour, int n_threads);
+void pss_o_persistence_rows_f64(const double *rows, const double *row_lo, const double *row_hi, long n_frames, int len, int window, int disp_h,
+                                int disp_w, int8_t *ycell, int n_threads);
 /* batched waterfall accumulator: newest display line per frame, history of `window` rows (pyspecsdr.py:1342-1406). */
 void pss_o_waterfall_rows(const float *rows, long n_frames, int len, int window, int disp_w, int8_t *glyph, int8_t *colour,
                           int n_threads);

@@ -92,6 +92,7 @@ def lib():
         L.pss_o_batch_headline_f64.argtypes = [_f32p, C.c_long, C.c_int, C.c_double, C.c_int, _f64p, _f64p, _f64p, C.c_void_p, C.c_void_p,
                                                _f64p, _f64p, C.c_void_p, C.c_int]
         L.pss_o_waterfall_rows_f64.argtypes = [_f64p, _f64p, _f64p, C.c_long, C.c_int, C.c_int, C.c_int, _i8p, _i8p, C.c_int]
+        L.pss_o_persistence_rows_f64.argtypes = [_f64p, _f64p, _f64p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _i8p, C.c_int]
         L.pss_o_persistence_rows.argtypes = [_f32p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _i8p, C.c_int]
         _lib = L
     return _lib
@@ -372,11 +373,21 @@ def batch_headline(iq2d, fs, taps, sos, zi, buf, n_threads=1, window=30):
     return buf
 
 
-def headline_f64(iq2d, fs, taps, sos, zi, window=30, disp_w=112, n_threads=1, pcm=True, keep_db=False):
-    """The reference's own step from IQ in its own row type (float64 rows from compute_fft to the cells): per frame the post-processed
-    row, its extremes, the waterfall line (glyph, colour) with a history of `window` rows, the NFM int16 PCM.  -> dict."""
-    iq2d = np.ascontiguousarray(iq2d, np.complex64)
-    nf, n = iq2d.shape
+def threads_available():
+    """Host threads this process may actually run on: the affinity mask, capped by the cgroup's CPU quota (a container on a 256-thread box
+    may own far fewer)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
+def headline_f64_buffers(nf, n, fs, disp_w=112, pcm=True, keep_db=False):
     q = int(fs / 22050)
     n_out = (n - 1 + q - 1) // q
     out = {"post": np.empty((nf, n - 4), np.float64), "lo": np.empty(nf, np.float64), "hi": np.empty(nf, np.float64),
@@ -385,13 +396,30 @@ def headline_f64(iq2d, fs, taps, sos, zi, window=30, disp_w=112, n_threads=1, pc
         out["pcm"] = np.empty((nf, n_out, 2), np.int16)
     if keep_db:
         out["db"] = np.empty((nf, n), np.float64)
+    return out
+
+
+def headline_f64(iq2d, fs, taps, sos, zi, window=30, disp_w=112, n_threads=1, pcm=True, keep_db=False, out=None, display="waterfall", disp_h=36):
+    """The reference's own step from IQ in its own row type (float64 rows from compute_fft to the cells): per frame the post-processed
+    row, its extremes, the display line with a history of `window` rows — waterfall (glyph, colour) or persistence (row index per column,
+    in "glyph") —, the NFM int16 PCM.  -> dict (`out`: buffers of a previous call / headline_f64_buffers, reused)."""
+    iq2d = np.ascontiguousarray(iq2d, np.complex64)
+    nf, n = iq2d.shape
+    q = int(fs / 22050)
+    if out is None:
+        out = headline_f64_buffers(nf, n, fs, disp_w, pcm, keep_db)
+    pcm, keep_db = "pcm" in out, "db" in out
     L = lib()
     L.pss_o_batch_headline_f64(iq2d.view(np.float32).reshape(-1), nf, n, fs, q, np.ascontiguousarray(taps, np.float64),
                                np.ascontiguousarray(sos, np.float64), np.ascontiguousarray(zi, np.float64),
                                out["db"].ctypes.data if keep_db else None, out["post"].ctypes.data, out["lo"], out["hi"],
                                out["pcm"].ctypes.data if pcm else None, n_threads)
-    L.pss_o_waterfall_rows_f64(out["post"].reshape(-1), out["lo"], out["hi"], nf, n - 4, window, disp_w, out["glyph"].reshape(-1),
-                               out["colour"].reshape(-1), n_threads)
+    if display == "persistence":
+        L.pss_o_persistence_rows_f64(out["post"].reshape(-1), out["lo"], out["hi"], nf, n - 4, window, disp_h, disp_w,
+                                     out["glyph"].reshape(-1), n_threads)
+    else:
+        L.pss_o_waterfall_rows_f64(out["post"].reshape(-1), out["lo"], out["hi"], nf, n - 4, window, disp_w, out["glyph"].reshape(-1),
+                                   out["colour"].reshape(-1), n_threads)
     return out
 
 

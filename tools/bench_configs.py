@@ -278,36 +278,46 @@ def cfg4(eng, dev, verify=True, launch_only=False, ns=8192):
                   f"(BASELINE.json configs[3], one GPU's whole sweep)", ms, kt, algo, ns * n, ver)
 
 
-def _check_nfm_display(O, eng, iq, n, fs, db, ya, pcm, nf, window, blocks, mode):
-    """dB rows, PCM and the display lines of blocks of consecutive frames against the oracle (lines: the oracle's quantiser on the rows the
-    device produced, history complete inside the block except for the block that starts at frame 0)."""
+CELLS_F32_MAX_FRAC = 2e-3   # float32 dB rows agree with the reference's float64 rows to ~1e-7; a cell differs where a value sits on a quantisation edge
+
+
+def check_from_iq(O, eng, iq, n, fs, db, lo, hi, lines, pcm, window, mode="waterfall", rows_f64=False, demod="nfm", blk=None, starts=None):
+    """Blocks of consecutive frames of a step's outputs against the oracle's OWN step from IQ in the reference's row type (float64 compute_fft
+    rows -> np.convolve / np.median / clamp -> min / max over the last `window` rows, np.interp, quantisation: oracle_lib.headline_f64) —
+    not against a quantiser run on the device's rows.  dB rows (1e-4 * max(|ref|, 1) for float32 rows, 1e-9 for float64 rows), row extremes,
+    int16 PCM (equal; demod "nfm" only: other demodulators are checked by the caller), and the display cells: `cells_differing` counts
+    every glyph / colour (or persistence row index) that is not the oracle's, over the lines whose history lies inside the block (all lines
+    of a block that starts at frame 0).  float64 rows: 0 is required; float32 rows: at most CELLS_F32_MAX_FRAC of the cells."""
+    nf = iq.shape[0]
+    blk = min(nf, blk or (window + 226))
+    starts = sorted({0, max(0, nf // 3 - 7), max(0, (2 * nf) // 3 + 5), nf - blk}) if starts is None else starts
     taps, sos, zi = eng.nfm_filters(fs)
-    m = n - 4
-    res = {"blocks": blocks, "db_max_rel": 0.0, "pcm_equal": True, "lines_equal": True, "lines_checked": 0}
-    for s0, s1 in blocks:
-        g_db = db[s0:s1].cpu().numpy()
-        for k in (s0, s1 - 1):
-            x = _host_iq(iq, k)
-            res["db_max_rel"] = max(res["db_max_rel"], _rel(g_db[k - s0], O.compute_fft(x)))
-            res["pcm_equal"] &= bool(np.array_equal(pcm[k].cpu().numpy(), O.pcm16_stereo(O.demod_nfm(x, fs, taps, sos, zi))))
-        d64 = g_db.astype(np.float64)
-        acc = d64[:, 0:m] * 0.2
-        for k in range(1, 5):
-            acc = acc + d64[:, k:k + m] * 0.2
-        sm = acc.astype(np.float32)
-        srt = np.sort(sm, axis=1)
-        med = 0.5 * (srt[:, (m - 1) // 2].astype(np.float64) + srt[:, m // 2].astype(np.float64))
-        post = np.ascontiguousarray(np.maximum(sm, (med - 10.0).astype(np.float32)[:, None]))
+    thr = O.threads_available()
+    res = {"blocks": [[s0, s0 + blk] for s0 in starts], "frames": 0, "lines_checked": 0, "cells_checked": 0, "cells_differing": 0,
+           "db_max_rel": 0.0, "extremes_max_abs": 0.0, "pcm_equal": True, "rows": "float64" if rows_f64 else "float32",
+           "reference": "oracle's step from IQ in float64 rows (the reference's own row type)"}
+    W = lines[0].shape[1]
+    for s0 in starts:
+        sl = slice(s0, s0 + blk)
+        h_iq = iq[sl].cpu().numpy().view(np.complex64).reshape(blk, n)
+        o = O.headline_f64(h_iq, fs, taps, sos, zi, window, W, thr, pcm=(demod == "nfm"), keep_db=True, display=mode, disp_h=DISP_H)
+        g_db = db[sl].cpu().numpy().astype(np.float64)
+        res["db_max_rel"] = max(res["db_max_rel"], float(np.max(np.abs(g_db - o["db"]) / np.maximum(np.abs(o["db"]), 1.0))))
+        res["extremes_max_abs"] = max(res["extremes_max_abs"], float(np.max(np.abs(lo[sl].cpu().numpy().astype(np.float64) - o["lo"]))),
+                                      float(np.max(np.abs(hi[sl].cpu().numpy().astype(np.float64) - o["hi"]))))
+        if demod == "nfm":
+            res["pcm_equal"] &= bool(np.array_equal(pcm[sl].cpu().numpy(), o["pcm"]))
         first = 0 if s0 == 0 else window - 1
-        if mode == "persistence":
-            want = O.persistence_rows(post, window, DISP_H, DISP_W)
-            res["lines_equal"] &= bool(np.array_equal(ya[s0:s1].cpu().numpy()[first:], want[first:]))
-        else:
-            wg, wc = O.waterfall_rows(post, window, DISP_W)
-            res["lines_equal"] &= bool(np.array_equal(ya[0][s0:s1].cpu().numpy()[first:], wg[first:])
-                                       and np.array_equal(ya[1][s0:s1].cpu().numpy()[first:], wc[first:]))
-        res["lines_checked"] += (s1 - s0) - first
-    res["ok"] = bool(res["db_max_rel"] <= 1e-4 and res["pcm_equal"] and res["lines_equal"])
+        for got, want in zip(lines, (o["glyph"], o["colour"])):
+            g = got[sl].cpu().numpy()[first:]
+            res["cells_checked"] += int(g.size)
+            res["cells_differing"] += int(np.count_nonzero(g != want[first:]))
+        res["frames"] += blk
+        res["lines_checked"] += blk - first
+    res["cells_differing_frac"] = res["cells_differing"] / max(1, res["cells_checked"])
+    cells_ok = res["cells_differing"] == 0 if rows_f64 else res["cells_differing_frac"] <= CELLS_F32_MAX_FRAC
+    res["ok"] = bool(res["db_max_rel"] <= (1e-9 if rows_f64 else 1e-4) and res["extremes_max_abs"] <= (1e-9 if rows_f64 else 1e-4)
+                     and res["pcm_equal"] and cells_ok)
     return res
 
 
@@ -326,9 +336,7 @@ def cfg5_resident(eng, dev, verify=True, launch_only=False, nf=48828):
                                                    display="persistence", disp_h=DISP_H), 8, launch_only)
     ver = None
     if verify and not launch_only:
-        blk = window + 10
-        blocks = [[s, s + blk] for s in sorted({0, nf // 2 - 3, nf - blk})]
-        ver = _check_nfm_display(_oracle(), eng, iq, n, fs, db, y, pcm, nf, window, blocks, "persistence")
+        ver = check_from_iq(_oracle(), eng, iq, n, fs, db, lo, hi, (y,), pcm, window, mode="persistence", blk=window + 54)
     algo = nf * (n * 8 + n * 4 + n_out * 4 + DISP_W)
     return _entry("cfg5_resident", f"{nf} frames x {n}-pt @10 MS/s resident in HBM, every frame: compute_fft dB row + post-process + persistence "
                   f"trace (history {window}) + NFM -> int16 stereo (BASELINE.json configs[4] without the upload)", ms, kt, algo, nf * n, ver)
@@ -419,45 +427,64 @@ def wfm_step(eng, dev, verify=True, launch_only=False, nf=65536):
         lp, pil, lmr, alpha = eng.wfm_filters(fs)
         _, sos, zi = eng.nfm_filters(fs)
         filt = dict(lp_sos=lp, pilot_sos=pil, lmr_sos=lmr, alpha=alpha, dec_sos=sos, dec_zi=zi)
-        blk = window + 10
-        blocks = [[s, s + blk] for s in sorted({0, nf // 2 - 3, nf - blk})]
-        ver = {"blocks": blocks, "db_max_rel": 0.0, "pcm_equal": True, "lines_equal": True}
-        m = n - 4
-        for s0, s1 in blocks:
-            g_db = db[s0:s1].cpu().numpy()
+        ver = check_from_iq(O, eng, iq, n, fs, db, lo, hi, (gl, co), None, window, demod="wfm", blk=window + 98)
+        for s0, s1 in ver["blocks"]:
             for k in (s0, s1 - 1):
-                x = _host_iq(iq, k)
-                ver["db_max_rel"] = max(ver["db_max_rel"], _rel(g_db[k - s0], O.compute_fft(x)))
-                a = O.demod_wfm(O.iq_correction(x), fs, filt)
+                a = O.demod_wfm(O.iq_correction(_host_iq(iq, k)), fs, filt)
                 ver["pcm_equal"] &= bool(np.array_equal(pcm[k].cpu().numpy(), np.int16(a * 32767)))
-            d64 = g_db.astype(np.float64)
-            acc = d64[:, 0:m] * 0.2
-            for k in range(1, 5):
-                acc = acc + d64[:, k:k + m] * 0.2
-            sm = acc.astype(np.float32)
-            srt = np.sort(sm, axis=1)
-            med = 0.5 * (srt[:, (m - 1) // 2].astype(np.float64) + srt[:, m // 2].astype(np.float64))
-            post = np.ascontiguousarray(np.maximum(sm, (med - 10.0).astype(np.float32)[:, None]))
-            wg, wc = O.waterfall_rows(post, window, DISP_W)
-            first = 0 if s0 == 0 else window - 1
-            ver["lines_equal"] &= bool(np.array_equal(gl[s0:s1].cpu().numpy()[first:], wg[first:]) and np.array_equal(co[s0:s1].cpu().numpy()[first:], wc[first:]))
-        ver["ok"] = bool(ver["db_max_rel"] <= 1e-4 and ver["pcm_equal"] and ver["lines_equal"])
+        ver["pcm_frames"] = [k for s0, s1 in ver["blocks"] for k in (s0, s1 - 1)]
+        ver["ok"] = bool(ver["ok"] and ver["pcm_equal"])
     algo = nf * (n * 8 + n * 4 + n_out * 4 + 2 * DISP_W)
     return _entry("wfm_step", f"{nf} frames x {n}-pt @2.4 MS/s, every frame: demodulate_signal(WFM) = iq_correction + demodulate_wfm -> int16 stereo, "
                   f"compute_fft dB row + post-process + waterfall line (the cfg-2 step in the reference's default mode)", ms, kt, algo, nf * n, ver)
 
 
-CONFIGS = {"cfg3": cfg3, "cfg4": cfg4, "cfg5_resident": cfg5_resident, "cfg5_streamed": cfg5_streamed, "wfm_step": wfm_step}
+def cfg2_rows(eng, dev, verify=True, launch_only=False, nf=65536, rows="f32"):
+    """The cfg 2 step (bench.py's headline workload) on the OTHER row type than the headline's: rows = "f32": float32 dB rows
+    (pss_frame_pipeline_nfm: the spectrum output's contract is 1e-4 relative; display cells may differ from the reference's where a value sits
+    on a quantisation edge — counted below); rows = "f64": float64 rows from IQ to cells (pss_frame_pipeline_nfm_f64: the reference's cells)."""
+    n, fs, window = 1024, 2.4e6, 30
+    iq = synth("fm", nf, n, fs, dev, 20260928 + 2)
+    f64 = rows == "f64"
+    dt = torch.float64 if f64 else torch.float32
+    n_out = eng.demod_out_len(L.MODE_NFM, n, fs)
+    db = torch.empty((nf, n), dtype=dt, device=dev)
+    lo, hi = torch.empty((nf,), dtype=dt, device=dev), torch.empty((nf,), dtype=dt, device=dev)
+    gl, co = torch.empty((nf, DISP_W), dtype=torch.int8, device=dev), torch.empty((nf, DISP_W), dtype=torch.int8, device=dev)
+    pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    fn = eng.frame_pipeline_nfm_f64 if f64 else eng.frame_pipeline_nfm
+    ms, kt = timed(eng, lambda: fn(iq, nf, n, fs, db, None, lo, hi, DISP_W, gl, co, pcm, window=window), 20, launch_only)
+    ver = None
+    if verify and not launch_only:
+        ver = check_from_iq(_oracle(), eng, iq, n, fs, db, lo, hi, (gl, co), pcm, window, rows_f64=f64)
+    algo = nf * (n * 8 + n * (8 if f64 else 4) + n_out * 4 + 2 * DISP_W)
+    name = "cfg2_exact_cells" if f64 else "cfg2_f32_rows"
+    return _entry(name, f"{nf} frames x {n}-pt @2.4 MS/s, the headline step with {'float64' if f64 else 'float32'} dB rows: compute_fft + post-process + "
+                  f"waterfall line + NFM -> int16 ({'pss_frame_pipeline_nfm_f64: the cells the reference draws' if f64 else 'pss_frame_pipeline_nfm'})",
+                  ms, kt, algo, nf * n, ver)
 
 
-def other_configs(eng, dev, verify=True, which=None, launch_only=False, small=False):
-    """-> {config: entry}.  small: a fraction of every batch (CPU-less smoke of the code path on a GPU box with little time)."""
+def cfg2_f32_rows(eng, dev, **kw):
+    return cfg2_rows(eng, dev, rows="f32", **kw)
+
+
+def cfg2_exact_cells(eng, dev, **kw):
+    return cfg2_rows(eng, dev, rows="f64", **kw)
+
+
+CONFIGS = {"cfg2_f32_rows": cfg2_f32_rows, "cfg2_exact_cells": cfg2_exact_cells, "cfg3": cfg3, "cfg4": cfg4, "cfg5_resident": cfg5_resident, "cfg5_streamed": cfg5_streamed, "wfm_step": wfm_step}
+
+
+def other_configs(eng, dev, verify=True, which=None, launch_only=False, small=False, skip=()):
+    """-> {config: entry}.  small: a fraction of every batch (CPU-less smoke of the code path on a GPU box with little time).
+    skip: configs to leave out (bench.py leaves out the cfg 2 entry of its own headline's row type)."""
     out = {}
-    for name in (which or list(CONFIGS)):
+    for name in (which or [c for c in CONFIGS if c not in skip]):
         kw = {}
         if small:
             kw = {"cfg3": {"nf": 256}, "cfg4": {"ns": 512}, "cfg5_resident": {"nf": 4100}, "cfg5_streamed": {"nf": 4100, "chunk": 1024},
-                  "wfm_step": {"nf": 8192}}[name]
+                  "wfm_step": {"nf": 8192}, "cfg2_f32_rows": {"nf": 4096}, "cfg2_exact_cells": {"nf": 4096}}[name]
         t0 = time.perf_counter()
         try:
             out[name] = CONFIGS[name](eng, dev, verify=verify, launch_only=launch_only, **kw)
