@@ -180,6 +180,11 @@ int pss_demod_out_len(int mode, int n, double fs);
  * demodulate_signal (:220-240): identical for NFM/AM/USB/LSB, and for WFM it applies iq_correction first (:222-225). */
 int pss_demod_signal(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, int16_t *d_pcm,
                      double *d_audio);
+/* measure_signal_power (signal_processing.py:325-328) and demodulate of the same read buffers, as the main loop runs them back to back
+ * (pyspecsdr.py:2251, :2262).  d_power float32 [n_frames]: pss_power_db's bits; d_pcm / d_audio: pss_demod's.  For AM the power and the
+ * demodulator's mean of |x| are reduced in ONE pass over the IQ; for the other modes this is the two calls in order. */
+int pss_demod_power(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, int16_t *d_pcm, double *d_audio,
+                    float *d_power);
 /* WFM filter set of one sample rate: lp = butter(5, 15000/(fs/2)) [3][6], pilot = butter(5, [18800,19200]/(fs/2), 'band')
  * [5][6], lmr = butter(5, [23000,53000]/(fs/2), 'band') [5][6], alpha = exp(-1/(75e-6 fs)).  Designed on first use
  * (pss_design_butter_sos and NumPy's exp restated: SciPy 1.15's / NumPy's bits); set_ lets a caller inject another SciPy build's tables. */

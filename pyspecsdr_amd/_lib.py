@@ -55,6 +55,7 @@ _SIGS = {
     "pss_agc_steps": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_int, _p]),
     "pss_demod": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
     "pss_demod_signal": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
+    "pss_demod_power": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p]),
     "pss_set_wfm_filters": (C.c_int, [_p, C.c_double, _p, _p, _p, C.c_double]),
     "pss_get_wfm_filters": (C.c_int, [_p, C.c_double, _p, _p, _p, _p]),
     "pss_demod_out_len": (C.c_int, [C.c_int, C.c_int, C.c_double]),

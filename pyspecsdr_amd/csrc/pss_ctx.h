@@ -41,6 +41,7 @@ struct pss_ctx {
     int n_cus = 0;                                  // hipDeviceProp_t::multiProcessorCount
     int fwd_cap = 0;                // > 0: k_nfm_fwd launches at most this many workgroups per CU (each walks several tiles)
     int pipe_overlap = 0;           // option "pipe_overlap": pss_frame_pipeline's NFM schedule with the display chain beside the WHOLE demodulator, forward kernel capped at this many workgroups per CU (0: chain beside the backward pass only)
+    float *power_out = nullptr;     // pss_demod_power -> pss_demod(AM): the power dB of the same frames from the mean pass (consumed there)
     bool fork_after_fwd = false;
     bool did_fork = false;
     bool defer_bwd = false;              // the fused NFM path launches only its forward kernel and parks the backward launch here:

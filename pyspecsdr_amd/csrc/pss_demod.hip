@@ -1196,6 +1196,118 @@ __global__ __launch_bounds__(256) void k_pairwise(const float2 *__restrict__ iq,
     }
 }
 
+// Two real float32 reductions over the SAME elements with the SAME (real) plan in one walk: elem(i) -> (a_i, b_i); both sums have numpy's
+// bits (the trees are identical, the additions component-wise).  part / val: float2 arrays of the slot counts of the float versions.
+template <bool WT = false, class F>
+__device__ __forceinline__ float2 wg_rsum2(const PlanDev &p, float2 *part, float2 *val, F elem, float2 carry, bool have)
+{
+    const int tid = threadIdx.x, T = blockDim.x;
+    auto add = [](float2 a, float2 b) { return make_float2(__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y)); };
+    if constexpr (WT) {
+        const int lane = tid & 63;
+        const int l = lane >> 3, k = lane & 7, off = l * 128;
+        float2 r = elem(off + k);
+#pragma unroll
+        for (int i = 8; i < 128; i += 8) r = add(r, elem(off + i + k));
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) r = add(r, make_float2(__shfl_xor(r.x, m), __shfl_xor(r.y, m)));
+        return r;
+    }
+    for (int slot = tid; slot < p.n_leaves * 8; slot += T) {
+        const int l = slot >> 3, k = slot & 7, off = p.leaf_off[l], len = p.leaf_len[l];
+        if (len == 128) {
+            float2 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = elem(off + 8 * j + k);
+            float2 r = v[0];
+#pragma unroll
+            for (int j = 1; j < 16; j++) r = add(r, v[j]);
+            part[slot] = r;
+        } else if (len >= 8) {
+            float2 r = elem(off + k);
+            const int end = len - (len % 8);
+            for (int i = 8; i < end; i += 8) r = add(r, elem(off + i + k));
+            part[slot] = r;
+        }
+    }
+    __syncthreads();
+    for (int l = tid; l < p.n_leaves; l += T) {
+        const int off = p.leaf_off[l], len = p.leaf_len[l];
+        float2 res;
+        if (len < 8) {
+            res = make_float2(0.0f, 0.0f);
+            for (int i = 0; i < len; i++) res = add(res, elem(off + i));
+        } else {
+            const float2 *r = part + 8 * l;
+            res = add(add(add(r[0], r[1]), add(r[2], r[3])), add(add(r[4], r[5]), add(r[6], r[7])));
+            for (int i = len - (len % 8); i < len; i++) res = add(res, elem(off + i));
+        }
+        val[l] = res;
+    }
+    __syncthreads();
+    for (int lv = 0; lv < p.n_levels; lv++) {
+        for (int k = p.level_start[lv] + tid; k < p.level_start[lv + 1]; k += T) val[p.n_leaves + k] = add(val[p.node_l[k]], val[p.node_r[k]]);
+        __syncthreads();
+    }
+    const int res = p.n_leaves + p.level_start[p.n_levels];
+    if (tid == 0) {
+        float2 acc = have ? add(carry, val[p.roots[0]]) : val[p.roots[0]];
+        for (int k = 1; k < p.n_roots; k++) acc = add(acc, val[p.roots[k]]);
+        val[res] = acc;
+    }
+    __syncthreads();
+    const float2 sum = val[res];
+    __syncthreads();
+    return sum;
+}
+template <bool WT = false, class F>
+__device__ __forceinline__ float2 frame_rsum2(const RedPlan &rp, float2 *part, float2 *val, F elem)
+{
+    if constexpr (WT) return wg_rsum2<true>(rp.tail, part, val, elem, make_float2(0.0f, 0.0f), false);
+    float2 acc = make_float2(0.0f, 0.0f);
+    bool have = false;
+    for (int g = 0; g < rp.n_full; g++) {
+        const int base = g * rp.glen;
+        acc = wg_rsum2(rp.full, part, val, [&](int i) { return elem(base + i); }, acc, have);
+        have = true;
+    }
+    if (rp.tail.n_leaves) {
+        const int base = rp.n_full * rp.glen;
+        acc = wg_rsum2(rp.tail, part, val, [&](int i) { return elem(base + i); }, acc, have);
+    }
+    return acc;
+}
+
+// measure_signal_power (signal_processing.py:325-328) AND the AM demodulator's mean of |x| + envelope (:182-185) from ONE pass over the
+// frame: both are float32 np.mean reductions of functions of the same np.abs value (|x|^2 and |x|), so both trees are walked together —
+// the main loop measures the power of every read buffer before it demodulates it (pyspecsdr.py:2251, :2262): one IQ read instead of two.
+template <bool WT = false>
+__global__ __launch_bounds__(256) void k_pairwise2(const float2 *__restrict__ iq, int n, long n_frames, RedPlan rp, int part_slots, int val_slots,
+                                                   float *__restrict__ out_power, float *__restrict__ out_mean, float *__restrict__ env)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *part = reinterpret_cast<float2 *>(smem), *val = part + part_slots;
+    {
+        int *cur = reinterpret_cast<int *>(val + val_slots);
+        plan_to_lds(rp.full, cur);
+        plan_to_lds(rp.tail, cur);
+        __syncthreads();
+    }
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const float2 *x = iq + (size_t)f * n;
+        const float2 sum = frame_rsum2<WT>(rp, part, val, [&](int i) {
+            const float2 v = x[i];
+            const float m = cabsf_np(v.x, v.y);
+            if (env) env[(size_t)f * n + i] = m;
+            return make_float2(__fmul_rn(m, m), m);
+        });
+        if (threadIdx.x == 0) {
+            out_power[f] = __fmul_rn(10.0f, log10f_np(__fadd_rn(__fdiv_rn(sum.x, (float)n), 1e-10f)));
+            out_mean[f] = __fdiv_rn(sum.y, (float)n);
+        }
+    }
+}
+
 // STAGED: the frame is copied to LDS once and every pass reads it from there (frames up to 8192 samples).
 // LDS: [frame: n float2 if STAGED][part: part_slots float2][val: val_slots float2]
 template <bool STAGED, bool WT = false>
@@ -2708,6 +2820,28 @@ int launch_pairwise(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float
     return pss_hip_check(ctx, hipGetLastError(), "k_pairwise launch");
 }
 
+int launch_pairwise2(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_power, float *d_mean, float *d_env)
+{
+    RedPlan rp;
+    int leaves, vals;
+    int r = get_red_plan(ctx, n, false, &rp, &leaves, &vals);
+    if (r) return r;
+    const int part_slots = 8 * leaves;
+    const size_t lds = sizeof(float2) * (size_t)(part_slots + vals) + plan_lds_bytes(rp);
+    const int lanes = 8 * leaves;
+    const int T = lanes <= 64 ? 64 : (lanes <= 128 ? 128 : 256);
+    const bool wt = T == 64 && !rp.n_full && rp.tail.wave_tree;
+    auto kern = wt ? k_pairwise2<true> : k_pairwise2<false>;
+    if (lds > 64 * 1024)
+        PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long g = n_frames < 8192 ? n_frames : 8192;
+    pss_kernel_begin(ctx, "k_pairwise");
+    hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, rp, part_slots, vals,
+                       d_power, d_mean, d_env);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_pairwise2 launch");
+}
+
 int nfm_filters(pss_ctx *ctx, double fs, PssNfmFilt **out)
 {
     auto it = ctx->nfm.find(fs);
@@ -3039,8 +3173,10 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         AmCoef c;
         for (int s = 0; s < 5; s++) c.s[s] = Biquad{sos[6 * s], sos[6 * s + 1], sos[6 * s + 2], sos[6 * s + 4], sos[6 * s + 5]};
         pss_time_begin(ctx);
-        r = launch_pairwise<1>(ctx, d_iq, n_frames, n, mu, env);
-        if (r) return r;
+        // (pss_demod_power: measure_signal_power of the same frames comes out of the same pass over the IQ)
+        r = ctx->power_out ? launch_pairwise2(ctx, d_iq, n_frames, n, ctx->power_out, mu, env) : launch_pairwise<1>(ctx, d_iq, n_frames, n, mu, env);
+        ctx->power_out = nullptr;
+        if (r) { pss_time_end(ctx); return r; }
         pss_kernel_begin(ctx, "k_am_grp");
         hipLaunchKernelGGL(k_am_grp, dim3((unsigned)((n_frames + GRP_G - 1) / GRP_G)), dim3(256), 0, PSS_STREAM(ctx), env, mu, Yf, mx, n, n_frames, c);
         pss_kernel_end(ctx);
@@ -3340,6 +3476,26 @@ extern "C" int pss_demod_signal(pss_ctx *ctx, int mode, const float *d_iq, long 
     pss_time_begin(ctx);
     r = pss_iq_correction(ctx, d_iq, n_frames, n, reinterpret_cast<float *>(ctx->scratch_iqc), nullptr);
     if (!r) r = pss_demod(ctx, mode, reinterpret_cast<const float *>(ctx->scratch_iqc), n_frames, n, fs, d_pcm, d_audio);
+    pss_time_end(ctx);
+    return r;
+}
+
+// measure_signal_power + demodulate of the same read buffers, as the main loop runs them back to back (pyspecsdr.py:2251, :2262): d_power
+// float32 [n_frames] = 10 log10(mean |x|^2 + 1e-10) (pss_power_db's bits), then pss_demod.  AM: both np.mean reductions (|x|^2 and |x|) come
+// out of ONE pass over the IQ (k_pairwise2); the other modes: the two calls in order.
+extern "C" int pss_demod_power(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, int16_t *d_pcm, double *d_audio,
+                               float *d_power)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (!d_power && n_frames > 0) return pss_fail(ctx, PSS_E_ARG, "pss_demod_power: d_power is null");
+    if (mode == PSS_MODE_AM && n_frames > 0 && n >= 1 && d_iq) {
+        PssScoped<float *> want(ctx->power_out, d_power);
+        return pss_demod(ctx, mode, d_iq, n_frames, n, fs, d_pcm, d_audio);
+    }
+    pss_time_begin(ctx);
+    int r = pss_power_db(ctx, d_iq, n_frames, n, d_power);
+    if (!r) r = pss_demod(ctx, mode, d_iq, n_frames, n, fs, d_pcm, d_audio);
     pss_time_end(ctx);
     return r;
 }

@@ -80,22 +80,37 @@ __device__ __forceinline__ void sched_fence() { asm volatile("" ::: "memory"); }
 // many accesses as that reach allows).  Four workgroup barriers.
 // (Measured: the last barrier moved in FRONT of the next exchange's writes — a transform stage later, when every wavefront
 // has long finished reading — changes nothing at N = 4096 / 8192 and costs 5 % at 16 384.)
-template <class Wr, class Rd>
+// WAVE_LOCAL: every value a thread reads was written by a lane of its OWN wavefront (exchange 2: thread (r, b) -> thread (16 r + r2, c) keeps r,
+// and r is constant over a wavefront or a power-of-two part of one), into a part of the buffer no other wavefront touches during this
+// exchange: a wavefront's LDS instructions execute in order, so the four workgroup barriers become compiler fences and the wavefronts of a
+// frame stop marching in step for a third of the transform (the caller separates the exchange from its neighbours' buffer-wide accesses).
+template <bool WAVE_LOCAL = false>
+__device__ __forceinline__ void xsync()
+{
+    if constexpr (WAVE_LOCAL) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+template <bool WAVE_LOCAL = false, class Wr, class Rd>
 __device__ __forceinline__ void exchange(double2 (&v)[16], Wr wr, Rd rd)
 {
     double im[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { *wr(i) = v[brev(i, 4)].x; im[i] = v[brev(i, 4)].y; }
-    __syncthreads();
+    xsync<WAVE_LOCAL>();
 #pragma unroll
     for (int i = 0; i < 16; i++) v[i].x = *rd(i);
-    __syncthreads();
+    xsync<WAVE_LOCAL>();
 #pragma unroll
     for (int i = 0; i < 16; i++) *wr(i) = im[i];
-    __syncthreads();
+    xsync<WAVE_LOCAL>();
 #pragma unroll
     for (int i = 0; i < 16; i++) v[i].y = *rd(i);
-    __syncthreads();
+    xsync<WAVE_LOCAL>();
 }
 
 // One frame whose 16 stage-1 inputs x[t + T q] (windowed, as complex float64) are in v[].  w1 = W_N^t, w2 = W_T^(t % T2),
@@ -125,8 +140,16 @@ __device__ __forceinline__ void xl_core(double2 (&v)[16], double *ex, double2 w1
     // takes L2[g][c + R4 q3]: a 32-lane group is 32 / R4 rows x R4 doubles, rows E2 = R4 (mod 32) apart -> 32 distinct
     // bank pairs.
     {
+        // rows 16 r .. 16 r + 15 are written and read by the T2 threads of ONE r only (g3 / 16 = t / T2 = r): wave-local — no workgroup
+        // barrier inside; the one behind it keeps exchange 3's buffer-wide writes away from wavefronts still reading here
+        // (exchange 1 ended with a workgroup barrier after its reads)
         double *wb = ex + (r_s * 16) * E2 + b_s, *rb = ex + g3 * E2 + c_s;
+#ifdef PSS_EXP_XL_BARRIERS
         exchange(v, [&](int r2) { return wb + r2 * E2; }, [&](int q) { return rb + R4 * q; });
+#else
+        exchange<true>(v, [&](int r2) { return wb + r2 * E2; }, [&](int q) { return rb + R4 * q; });
+        __syncthreads();
+#endif
     }
     // ---- stage 3
     fft_reg<16>(v);

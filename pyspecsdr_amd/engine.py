@@ -73,9 +73,18 @@ class Engine:
         if cs is not None:
             self._ck(self.lib.pss_order_after(self.h, cs))
         r = fn(self.h, *args)
-        if cs is not None:
-            self.lib.pss_order_before(self.h, cs)
-        self._ck(r)
+        rb = self.lib.pss_order_before(self.h, cs) if cs is not None else 0
+        self._ck(r)        # the call's own failure first,
+        self._ck(rb)       # then a failed event record / stream wait: torch's work would not be ordered after the results
+
+    def order_after(self, stream):
+        """Work queued on this engine from now on starts after everything queued on `stream` (a hipStream_t as int, or an object with
+        .cuda_stream) so far — e.g. another Engine's stream_handle()."""
+        self._ck(self.lib.pss_order_after(self.h, _ptr(getattr(stream, "cuda_stream", stream))))
+
+    def order_before(self, stream):
+        """Work queued on `stream` from now on starts after everything this engine has queued so far."""
+        self._ck(self.lib.pss_order_before(self.h, _ptr(getattr(stream, "cuda_stream", stream))))
 
     def close(self):
         if getattr(self, "h", None):
@@ -231,18 +240,22 @@ class Engine:
         """Dispatcher semantics (demodulate_signal): WFM frames are IQ-corrected first."""
         self._dev(self.lib.pss_demod_signal, mode, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_pcm), _ptr(d_audio))
 
+    def demod_power(self, mode, d_iq, n_frames, n, fs, d_pcm, d_audio, d_power):
+        """measure_signal_power + demodulate of the same read buffers (pyspecsdr.py:2251, :2262); AM: one pass over the IQ for both means."""
+        self._dev(self.lib.pss_demod_power, mode, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_pcm), _ptr(d_audio), _ptr(d_power))
+
     def wfm_filters(self, fs):
         lp, pil, lmr = np.empty((3, 6)), np.empty((5, 6)), np.empty((5, 6))
         import ctypes as C
         a = C.c_double()
-        self._dev(self.lib.pss_get_wfm_filters, float(fs), _ptr(lp), _ptr(pil), _ptr(lmr), C.addressof(a))
+        self._ck(self.lib.pss_get_wfm_filters(self.h, float(fs), _ptr(lp), _ptr(pil), _ptr(lmr), C.addressof(a)))   # host-only: no stream ordering
         return lp, pil, lmr, a.value
 
     def set_wfm_filters(self, fs, lp, pilot, lmr, alpha):
         c = lambda x: np.ascontiguousarray(x, np.float64)
         lp, pilot, lmr = c(lp), c(pilot), c(lmr)
         assert lp.shape == (3, 6) and pilot.shape == (5, 6) and lmr.shape == (5, 6)
-        self._dev(self.lib.pss_set_wfm_filters, float(fs), _ptr(lp), _ptr(pilot), _ptr(lmr), float(alpha))
+        self._ck(self.lib.pss_set_wfm_filters(self.h, float(fs), _ptr(lp), _ptr(pilot), _ptr(lmr), float(alpha)))
 
     def demod_out_len(self, mode, n, fs):
         return int(self.lib.pss_demod_out_len(mode, n, float(fs)))
@@ -320,7 +333,7 @@ class Engine:
     # -- stateful display accumulators (device ring of the last rows)
     def ring_create(self, max_rows, length):
         h = C.c_void_p()
-        self._dev(self.lib.pss_ring_create, max_rows, length, C.byref(h))
+        self._ck(self.lib.pss_ring_create(self.h, max_rows, length, C.byref(h)))
         return h
 
     def _ring(self, fn, ring, *args):

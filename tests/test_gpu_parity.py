@@ -322,6 +322,33 @@ def test_float64_rows_pipeline_draws_the_reference_cells(golden):
     assert np.array_equal(G.host(d_p)[1], sm[1], equal_nan=True)
 
 
+@pytest.mark.parametrize("mode", [L.MODE_AM, L.MODE_NFM, L.MODE_USB])
+def test_demod_power_equals_the_two_calls(mode):
+    """pss_demod_power: measure_signal_power + demodulate of the same frames (pyspecsdr.py:2251, :2262); for AM both float32 means come out
+    of one pass over the IQ (two pairwise trees walked together) — the power bits and the PCM / audio must be those of the separate calls."""
+    e = G.engine()
+    gen = torch.Generator(device="cuda").manual_seed(31 + mode)
+    for nf, n in ((700, 1024), (5, 7), (40, 5000), (9, 16384), (3, 40001), (2, 262144)):
+        if mode != L.MODE_AM and n < 64:
+            continue
+        fs = 2.4e6
+        iq = torch.randn((nf, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3 + 0.1
+        torch.cuda.synchronize()
+        n_out = e.demod_out_len(mode, n, fs)
+        pa, pb = G.empty((nf, n_out, 2), torch.int16), G.empty((nf, n_out, 2), torch.int16)
+        aa, ab = G.empty((nf, n_out), torch.float64), G.empty((nf, n_out), torch.float64)
+        wa, wb = G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
+        e.demod_power(mode, iq, nf, n, fs, pa, aa, wa)
+        e.power_db(iq, nf, n, wb)
+        e.demod(mode, iq, nf, n, fs, pb, ab)
+        e.sync()
+        assert torch.equal(wa.view(torch.int32), wb.view(torch.int32)), (mode, nf, n)
+        assert torch.equal(pa, pb) and torch.equal(aa.view(torch.int64), ab.view(torch.int64)), (mode, nf, n)
+    for k in range(3):   # power bits against the oracle (NumPy's float32 pairwise mean + SVML log10)
+        x = iq[k % nf].cpu().numpy().view(np.complex64).reshape(-1)
+        assert wa[k % nf].cpu().numpy().tobytes() == np.float32(O.power_db(x)).tobytes()
+
+
 def test_float64_pipeline_register_kernels_equal_plain_kernels_and_numpy():
     """The float64-row entry points on the register kernels (k_spectrum_r16<..., D64>, k_post_sel<..., double>, the lines from the rows
     resampled in the same pass) against the plain round-3 kernels (option "f64_plain") and NumPy: dB rows within 1e-11 of each other

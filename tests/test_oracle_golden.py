@@ -429,3 +429,21 @@ def test_reference_is_not_bit_stable_across_cpu_dispatch(golden):
     _, disc, _ = O.demod_nfm(g["iq_a"][0], float(g["fs_a"]), taps, sos, zi, stages=True)
     assert np.array_equal(disc.view(np.uint32), g["disc_a"].view(np.uint32))
     assert not np.array_equal(disc.view(np.uint32), d["avx2_fma3_disc_a"].view(np.uint32))
+
+
+def test_headline_f64_from_iq_draws_the_reference_cells(golden):
+    """oracle_lib.headline_f64 — the checker bench.py, smoke() and the -m gpu tests hold the device's display lines against: the oracle's own
+    step from IQ in the reference's row type (float64 compute_fft rows -> np.convolve / np.median / clamp -> draw_waterfall) must draw the cells
+    the REFERENCE drew from the same read buffers (tests/golden/caller_iq.npz -> caller.npz, draw_waterfall through a fake screen), every one."""
+    g, q, nfm = golden["caller"], golden["caller_iq"], golden["nfm"]
+    iq = np.ascontiguousarray(q["iq"])
+    H, W = [int(v) for v in g["hw"]]
+    tag = [t for t in "abcdefg" if float(nfm[f"fs_{t}"]) == 2.4e6][0]
+    o = O.headline_f64(iq, 2.4e6, nfm[f"taps_{tag}"], nfm[f"sos_{tag}"], nfm[f"zi_{tag}"], 30, W - 8, 2, keep_db=True)
+    assert np.allclose(o["db"], q["db"], rtol=1e-9, atol=1e-9)
+    assert np.allclose(o["post"], g["rows"], rtol=1e-9, atol=1e-9)
+    for i in range(len(iq)):
+        assert np.array_equal(o["glyph"][i], g["wf_glyph"][i][0]) and np.array_equal(o["colour"][i], g["wf_colour"][i][0]), i
+    # the PCM of the same call is the golden NFM path's (frame by frame)
+    for i in (0, 7, len(iq) - 1):
+        assert np.array_equal(o["pcm"][i], O.pcm16_stereo(O.demod_nfm(iq[i], 2.4e6, nfm[f"taps_{tag}"], nfm[f"sos_{tag}"], nfm[f"zi_{tag}"])))

@@ -196,11 +196,14 @@ def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=True):
             return kt
 
     def one():
-        eng2.demod(L.MODE_AM, iq_am, nf, n, fs, pcm_am, None)     # second context: beside everything below
-        eng.power_db(iq_am, nf, n, pw)                    # measure_signal_power (pyspecsdr.py:2251) ...
-        eng.agc_steps(pw, nf, 20, 29, gi)                 # ... and the gain stepper (:898-919), interval gate off
+        # second context, beside everything below: measure_signal_power (pyspecsdr.py:2251) + demodulate AM (:2262) of the same read
+        # buffers — the power and the demodulator's mean of |x| from ONE pass over the IQ (pss_demod_power)
+        eng2.demod_power(L.MODE_AM, iq_am, nf, n, fs, pcm_am, None, pw)
         eng.demod(L.MODE_USB, iq_ssb, nf, n, fs, pcm_usb, None)
         eng.spectrum_db(iq_am, nf, n, db)                 # compute_fft (:2275)
+        if eng2 is not eng:
+            eng.order_after(eng2.stream_handle())         # the power values come from the other context's stream
+        eng.agc_steps(pw, nf, 20, 29, gi)                 # the gain stepper (:898-919), interval gate off
     ms, kt = timed(Both(), one, 10, launch_only)
     ms_one = None
     if eng2 is not eng and not launch_only:      # the same calls in order on one stream, for the record

@@ -32,7 +32,7 @@ def main():
         g, c = torch.empty((nf, W), dtype=torch.int8, device=dev), torch.empty((nf, W), dtype=torch.int8, device=dev)
         pcm = torch.empty((nf, 10, 2), dtype=torch.int16, device=dev)
         fn = eng.frame_pipeline_nfm if name == "f32" else eng.frame_pipeline_nfm_f64
-        call = lambda: fn(iq, nf, n, fs, db, None, lo, hi, W, g, c, pcm)
+        call = (lambda fn=fn, db=db, lo=lo, hi=hi, g=g, c=c, pcm=pcm: fn(iq, nf, n, fs, db, None, lo, hi, W, g, c, pcm))
         out[name] = (call, (db, lo, hi, g, c, pcm))
     for rep in range(3):
         for name in ("f32", "f64"):
