@@ -3421,19 +3421,28 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(TILE), wfmf::LDS_BYTES, PSS_STREAM(ctx),
                                reinterpret_cast<const float2 *>(d_iq), Yf, n, n_frames, swapped, wc, c);
             pss_kernel_end(ctx);
-            pss_kernel_begin(ctx, "k_nfm_bwd");
-            hipLaunchKernelGGL((fused::k_nfm_bwd<true, true>), dim3((unsigned)(2 * tiles)), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af,
-                               n, q, n_out, 2 * tiles * TILE, c, nullptr, MXf);
-            pss_kernel_end(ctx);
-            size_t tot = (size_t)n_frames * n_out;
-            size_t g2 = (tot + TPB - 1) / TPB;
-            if (g2 > 16384) g2 = 16384;
-            pss_kernel_begin(ctx, "k_wfm_finalize");
-            hipLaunchKernelGGL(k_wfm_finalize, dim3((unsigned)g2), dim3(TPB), 0, PSS_STREAM(ctx), Af, MXf, n_out, n_frames, 1, d_pcm,
-                               d_audio);
-            pss_kernel_end(ctx);
+            auto launch_bwd = [=]() -> int {
+                pss_kernel_begin(ctx, "k_nfm_bwd");
+                hipLaunchKernelGGL((fused::k_nfm_bwd<true, true>), dim3((unsigned)(2 * tiles)), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af,
+                                   n, q, n_out, 2 * tiles * TILE, c, nullptr, MXf);
+                pss_kernel_end(ctx);
+                size_t tot = (size_t)n_frames * n_out;
+                size_t g2 = (tot + TPB - 1) / TPB;
+                if (g2 > 16384) g2 = 16384;
+                pss_kernel_begin(ctx, "k_wfm_finalize");
+                hipLaunchKernelGGL(k_wfm_finalize, dim3((unsigned)g2), dim3(TPB), 0, PSS_STREAM(ctx), Af, MXf, n_out, n_frames, 1, d_pcm,
+                                   d_audio);
+                pss_kernel_end(ctx);
+                return pss_hip_check(ctx, hipGetLastError(), "wfm fused launch (backward)");
+            };
+            if (ctx->defer_bwd) {  // pss_frame_pipeline places the backward pass + the L / R normalisation itself (beside the display chain)
+                ctx->pending_bwd = launch_bwd;
+                pss_time_end(ctx);
+                return pss_hip_check(ctx, hipGetLastError(), "wfm fused launch");
+            }
+            const int rb = launch_bwd();
             pss_time_end(ctx);
-            return pss_hip_check(ctx, hipGetLastError(), "wfm fused launch");
+            return rb;
         }
         pss_kernel_begin(ctx, "k_wfm_front");
         hipLaunchKernelGGL(spec ? k_wfm_front<true> : k_wfm_front<false>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx),
@@ -3848,9 +3857,24 @@ inline int pipe_chain_vals(pss_ctx *ctx, const double *d_db, long nf, int n, dou
 // values: what the accumulators normalise and quantise), and the lines are quantised from those — the same bytes as from materialised rows.
 // Other lengths go through a context-owned scratch copy of the rows.
 template <class TR>
+static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, TR *d_db, TR *d_post,
+                               TR *d_row_lo, TR *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
+                               int8_t *d_glyph, int8_t *d_colour, int16_t *d_pcm);
+template <class TR>
 static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, TR *d_db, TR *d_post,
                           TR *d_row_lo, TR *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
                           int8_t *d_glyph, int8_t *d_colour, int16_t *d_pcm)
+{
+    pss_time_begin(ctx);     // one bracket around the whole call (the nested pairs inside are no-ops)
+    const int r = frame_pipeline_impl<TR>(ctx, mode, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w,
+                                          d_glyph, d_colour, d_pcm);
+    pss_time_end(ctx);
+    return r;
+}
+template <class TR>
+static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, TR *d_db, TR *d_post,
+                               TR *d_row_lo, TR *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
+                               int8_t *d_glyph, int8_t *d_colour, int16_t *d_pcm)
 {
     constexpr bool F64 = sizeof(TR) == 8;
     if (n_frames < 0 || n_halo < 0 || window < 1 || disp_w < 1 || (display != 0 && display != 1) || (display == 1 && (disp_h < 1 || disp_h > 127)))
@@ -3874,21 +3898,23 @@ static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_fram
         if (!q) q = pipe_lines(ctx, display, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph, d_colour);
         return q;
     };
-    if (mode != PSS_MODE_NFM) {
-        // AM / USB / LSB / WFM (demodulate_signal's dispatcher semantics: WFM frames are IQ-corrected first, signal_processing.py:222-225).
-        // None of these demodulators has the NFM path's two-phase shape, so the display chain simply runs on the side stream beside the whole
-        // demodulator: WFM's forward kernel keeps one wavefront per SIMD busy for ~1 ms (float64 issue), AM's recurrence kernel two thirds
-        // of the SIMDs — the HBM-bound chain fits in beside them.
+    const float *d_in = d_iq;     // what the demodulator reads (WFM: the IQ-corrected frames)
+    if (mode == PSS_MODE_WFM && n_frames > 0) {
+        // demodulate_signal's dispatcher semantics: WFM frames are IQ-corrected first (signal_processing.py:222-225) — the correction alone,
+        // in front of everything: a chain beside it would only share its HBM bandwidth
         pss_time_begin(ctx);
-        int r = PSS_OK;
-        const float *d_in = d_iq;
-        if (mode == PSS_MODE_WFM && n_frames > 0) {   // the correction first, alone: the chain beside it would only share its HBM bandwidth
-            r = pss_ensure_buffer(ctx, &ctx->scratch_iqc, &ctx->scratch_iqc_bytes, (size_t)n_frames * n * sizeof(float2), "iq_correction scratch");
-            if (!r) r = pss_iq_correction(ctx, d_iq, n_frames, n, reinterpret_cast<float *>(ctx->scratch_iqc), nullptr);
-            d_in = reinterpret_cast<const float *>(ctx->scratch_iqc);
-        }
-        if (r) { pss_time_end(ctx); return r; }
-        r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
+        int r = pss_ensure_buffer(ctx, &ctx->scratch_iqc, &ctx->scratch_iqc_bytes, (size_t)n_frames * n * sizeof(float2), "iq_correction scratch");
+        if (!r) r = pss_iq_correction(ctx, d_iq, n_frames, n, reinterpret_cast<float *>(ctx->scratch_iqc), nullptr);
+        pss_time_end(ctx);
+        if (r) return r;
+        d_in = reinterpret_cast<const float *>(ctx->scratch_iqc);
+    }
+    if (mode != PSS_MODE_NFM && mode != PSS_MODE_WFM) {
+        // AM / USB / LSB: neither demodulator has the two-phase shape of the FM paths, so the display chain simply runs on the side stream
+        // beside the whole demodulator (AM's recurrence kernel keeps two thirds of the SIMDs busy with one wavefront each — the HBM-bound
+        // chain fits in beside it).
+        pss_time_begin(ctx);
+        int r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
         if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
         if (r) { pss_time_end(ctx); return r; }
         const int rd = pss_demod(ctx, mode, d_in, n_frames, n, fs, d_pcm, nullptr);   // main stream
@@ -3904,8 +3930,10 @@ static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_fram
         return rd ? rd : (rc ? rc : rj);
     }
     pss_time_begin(ctx);
-    // Schedule: forward kernel (VALU-bound, fills the machine) ->
+    // NFM and WFM.  Schedule: forward kernel (VALU-bound, fills the machine) ->
     //   { backward pass (latency-bound, one wavefront per SIMD)  ||  spectrum -> post-process -> display lines }.
+    // (WFM until round 4: the chain beside the whole demodulator.  k_wfm_fwd's four workgroups per CU hold 150 of a CU's 160 KB of LDS, so the
+    // spectrum kernel's 70 KB workgroups only ran as forward workgroups retired: 1.2 ms for a 0.17 ms kernel, and the chain was the critical path.)
     // Measured alternatives (rounds 2 - 4, NOTEBOOK.md R4-08 and A5; the code of those experiments left the tree in round 5): the spectrum in
     // front of the fork (+2 %); the whole display chain on the side stream from the start (-5 % when the forward kernel reaches the dispatcher
     // first, +8 % when it does not); the two streams on disjoint CU masks (hipExtStreamCreateWithCUMask, 128..240 of 256 CUs for the forward
@@ -3925,7 +3953,7 @@ static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_fram
     {
         PssFlagScope defer(ctx->defer_bwd, true);
         PssScoped<int> cap(ctx->fwd_cap, overlap ? ctx->pipe_overlap : 0);
-        r2 = pss_demod(ctx, PSS_MODE_NFM, d_iq, n_frames, n, fs, d_pcm, nullptr);
+        r2 = pss_demod(ctx, mode, d_in, n_frames, n, fs, d_pcm, nullptr);
     }
     int r = r2;
     const bool beside_bwd = (bool)ctx->pending_bwd;
