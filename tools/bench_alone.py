@@ -37,10 +37,18 @@ def run(name, fn, kernel, nbytes, reps=8):
     print(f"alone: {name:44s} {ms:8.4f} ms  {nbytes / ms / 1e9:6.2f} TB/s algorithmic = {nbytes / ms / 1e9 / 8.0:5.3f} of the 8 TB/s HBM peak")
 
 
-run("k_spectrum_r16 65536 x 1024 (FM IQ)", lambda: e.spectrum_db(iq, nf, n, db), "k_spectrum", nf * bench.ALGO_BYTES["k_spectrum"])
-run("k_post_sel 65536 x 1024 (the FM spectra)", lambda: e.spectrum_post_extremes(db, nf, n, post, lo, hi), "k_post", nf * bench.ALGO_BYTES["k_post"])
-run("k_disp_rows 65536 x 1020 -> 112 cells", lambda: e.waterfall_rows(post, nf, n - 4, lo, hi, bench.DISP_W, g, c), "k_disp_rows",
-    nf * bench.ALGO_BYTES["k_disp_rows"])
+# float32 rows (pss_spectrum_db and the separate post-process / display entry points: rows written)
+run("k_spectrum_r16 65536 x 1024 (FM IQ), f32 rows", lambda: e.spectrum_db(iq, nf, n, db), "k_spectrum", nf * (n * 8 + n * 4))
+run("k_post_sel 65536 x 1024 f32 rows in + out", lambda: e.spectrum_post_extremes(db, nf, n, post, lo, hi), "k_post", nf * (n * 4 + (n - 4) * 4 + 8))
+run("k_disp_rows 65536 x 1020 f32 -> 112 cells", lambda: e.waterfall_rows(post, nf, n - 4, lo, hi, bench.DISP_W, g, c), "k_disp_rows",
+    nf * ((n - 4) * 4 + 2 * bench.DISP_W))
+# float64 rows (the bench step's row type: the reference's own)
+db64 = torch.empty((nf, n), dtype=torch.float64, device=dev)
+post64 = torch.empty((nf, n - 4), dtype=torch.float64, device=dev)
+lo64, hi64 = torch.empty(nf, dtype=torch.float64, device=dev), torch.empty(nf, dtype=torch.float64, device=dev)
+run("k_spectrum_r16 65536 x 1024 (FM IQ), f64 rows", lambda: e.spectrum_db_f64(iq, nf, n, db64), "k_spectrum", nf * (n * 8 + n * 8))
+run("k_post_sel 65536 x 1024 f64 rows in + out", lambda: e.spectrum_post_f64(db64, nf, n, post64, lo64, hi64), "k_post", nf * (n * 8 + (n - 4) * 8 + 16))
+del db64, post64
 n_out = e.demod_out_len(0, n, bench.FS)
 pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)
 run("k_nfm_fwd 65536 x 1024 (demodulator alone)", lambda: e.demod(0, iq, nf, n, bench.FS, pcm, None), "k_nfm_fwd", nf * bench.ALGO_BYTES["k_nfm_fwd"])
