@@ -172,6 +172,12 @@ int pss_agc_steps(pss_ctx *ctx, const float *d_power, long n, int start_idx, int
 int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, int16_t *d_pcm,
               double *d_audio);
 int pss_demod_out_len(int mode, int n, double fs);
+/* demodulate_nfm / demodulate_wfm's `target_rate` argument (signal_processing.py:91, :119; default DEFAULT_SAMPLE_RATE = 22050): the decimation
+ * factor is int(sample_rate / target_rate) (:111).  pss_set_target_rate changes it for the context (and drops the cached decimator designs);
+ * pss_demod_out_len_ctx is pss_demod_out_len at the context's target rate, pss_demod_out_len_rate at an explicit one. */
+int pss_set_target_rate(pss_ctx *ctx, double target_rate);
+int pss_demod_out_len_ctx(pss_ctx *ctx, int mode, int n, double fs);
+int pss_demod_out_len_rate(int mode, int n, double fs, double target_rate);
 
 /* PSS_MODE_WFM = demodulate_wfm (signal_processing.py:119-176): discriminator, L+R / pilot / L-R Butterworth branches,
  * 75 us de-emphasis, zero-phase decimation, joint peak normalisation.  n_out = ceil((n-1)/int(fs/22050)); here
@@ -269,8 +275,9 @@ int pss_vector_cells(pss_ctx *ctx, const float *d_iq, int n, int max_h, int max_
  * and the indices of the rising / falling transitions of that mask (np.diff + np.where), i.e. the arrays rise_times /
  * fall_times the timing logic of decode_morse (:167 ff., stays in the reference's own decoders.py) starts from.
  * d_iq: interleaved complex64 [n_frames][n]; d_rise / d_fall: int32 [n_frames][cap], in increasing order; d_counts: int32
- * [n_frames][2] = the TRUE numbers of rises and falls (entries beyond cap are dropped).  threshold_db must be -20.0, the
- * value the reference calls it with (pyspecsdr.py:573): the comparison is pinned to NumPy's float32 log10 at that point. */
+ * [n_frames][2] = the TRUE numbers of rises and falls (entries beyond cap are dropped).  threshold_db: any value — the mask is
+ * float32(20 log10(envelope + 1e-10)) > float32(threshold_db) with NumPy's float32 log10 bit for bit (the reference calls it with -20,
+ * pyspecsdr.py:573: that case is one comparison against a precomputed float32 cut). */
 int pss_morse_edges(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double threshold_db, int cap, int32_t *d_rise,
                     int32_t *d_fall, int32_t *d_counts);
 int pss_h_morse_edges(pss_ctx *ctx, const float *h_iq, int n, double threshold_db, int cap, int32_t *h_rise, int32_t *h_fall,

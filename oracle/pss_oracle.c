@@ -571,6 +571,33 @@ void pss_o_morse_edges(const float *iq, long n, int32_t *rise, int32_t *fall, lo
     *n_rise = nr; *n_fall = nf;
 }
 
+/* decode_morse's mask at ANY threshold (decoders.py:149-156): envelope_db = 20 * np.log10(envelope + 1e-10) in float32 (NumPy's SVML log10
+ * model above), signals = envelope_db > threshold with the Python scalar cast to float32 (NEP 50: a weak scalar beside a float32 array). */
+void pss_o_morse_edges_thr(const float *iq, long n, double threshold, int32_t *rise, int32_t *fall, long cap, long *n_rise, long *n_fall)
+{
+    const float thr = (float)threshold;
+    float mx = -INFINITY;
+    int has_nan = 0;
+    for (long i = 0; i < n; i++) {
+        float e = pss_o_cabsf(iq[2 * i], iq[2 * i + 1]);
+        if (e != e) has_nan = 1;
+        if (e > mx) mx = e;
+    }
+    if (has_nan) mx = NAN;
+    long nr = 0, nf = 0;
+    int prev = 0;
+    for (long i = 0; i < n; i++) {
+        float v = pss_o_cabsf(iq[2 * i], iq[2 * i + 1]) / mx + (float)1e-10;
+        int sgn = 20.0f * pss_o_log10f_np(v) > thr; /* false for NaN */
+        if (i > 0) {
+            if (!prev && sgn) { if (nr < cap) rise[nr] = (int32_t)(i - 1); nr++; }
+            if (prev && !sgn) { if (nf < cap) fall[nf] = (int32_t)(i - 1); nf++; }
+        }
+        prev = sgn;
+    }
+    *n_rise = nr; *n_fall = nf;
+}
+
 static int cmp_double(const void *a, const void *b)
 {
     double x = *(const double *)a, y = *(const double *)b;

@@ -105,6 +105,7 @@ void pss_o_hann_f32(float *w, int n);
 int pss_o_classify(const float *iq, long n, double fs, double *bw_out, float *mi_out, float *flat_out, float *psd_out);
 /* decode_morse front half (decoders.py:149-165, threshold -20 dB): indices of the rising / falling transitions */
 void pss_o_morse_edges(const float *iq, long n, int32_t *rise, int32_t *fall, long cap, long *n_rise, long *n_fall);
+void pss_o_morse_edges_thr(const float *iq, long n, double threshold, int32_t *rise, int32_t *fall, long cap, long *n_rise, long *n_fall);
 int pss_o_scan_threshold(const float *iq, int n, double fs, double threshold_db, float *db, float *peak, double *bw);
 void pss_o_vector_cells(const float *iq, int n, int max_h, int max_w, int8_t *grid);
 /* spectrum display quantiser — draw_spectrogram, pyspecsdr.py:398-498.  row[len] = one post-processed dB row.

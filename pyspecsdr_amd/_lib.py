@@ -59,6 +59,9 @@ _SIGS = {
     "pss_set_wfm_filters": (C.c_int, [_p, C.c_double, _p, _p, _p, C.c_double]),
     "pss_get_wfm_filters": (C.c_int, [_p, C.c_double, _p, _p, _p, _p]),
     "pss_demod_out_len": (C.c_int, [C.c_int, C.c_int, C.c_double]),
+    "pss_set_target_rate": (C.c_int, [_p, C.c_double]),
+    "pss_demod_out_len_ctx": (C.c_int, [_p, C.c_int, C.c_int, C.c_double]),
+    "pss_demod_out_len_rate": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double]),
     "pss_spectrum_nfm": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
     "pss_frame_pipeline_nfm": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "pss_frame_pipeline": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),

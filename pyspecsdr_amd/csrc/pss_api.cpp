@@ -226,6 +226,7 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "scan_exact")) { ctx->scan_exact = value != 0; return PSS_OK; }
     if (!strcmp(key, "db_exact")) { ctx->db_exact = value != 0; return PSS_OK; }
     if (!strcmp(key, "f64_plain")) { ctx->f64_plain = value != 0; return PSS_OK; }
+    if (!strcmp(key, "wfm_corr_copy")) { ctx->wfm_corr_copy = value != 0; return PSS_OK; }
 #ifdef PSS_VARIANTS   // kernel-selection knobs for A/B measurements: variant builds only (tools/build_variant.py <name> -DPSS_VARIANTS)
     if (!strcmp(key, "ssb_unfused")) { ctx->ssb_unfused = value != 0; return PSS_OK; }
     if (!strcmp(key, "fft_two_per_wg")) { ctx->fft_two_per_wg = value != 0; return PSS_OK; }
@@ -332,8 +333,8 @@ static int h_demod_impl(pss_ctx *ctx, int mode, const float *h_iq, int n, double
 {
     if (!ctx) return PSS_E_ARG;
     if (!h_iq || n < 1 || (!h_audio_stereo && !h_pcm)) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
-    int n_out = pss_demod_out_len(mode, n, fs);
-    if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "unknown mode or sample rate below 22050 Hz");
+    int n_out = pss_demod_out_len_ctx(ctx, mode, n, fs);
+    if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "unknown mode or sample rate below the target rate");
     const bool stereo = mode == PSS_MODE_WFM;
     const size_t o_pcm = up256(sizeof(float) * 2 * n), o_au = o_pcm + up256(sizeof(int16_t) * 2 * n_out);
     int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_au + up256(sizeof(double) * 2 * n_out), "staging");
@@ -377,8 +378,8 @@ extern "C" int pss_h_demodulate_batch(pss_ctx *ctx, int mode, const float *h_iq,
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
     if (!h_iq || !h_pcm || n_frames < 0 || n < 1 || chunk_frames < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
-    const int n_out = pss_demod_out_len(mode, n, fs);
-    if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "unknown mode or sample rate below 22050 Hz");
+    const int n_out = pss_demod_out_len_ctx(ctx, mode, n, fs);
+    if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "unknown mode or sample rate below the target rate");
     if (chunk_frames > n_frames) chunk_frames = n_frames;
     if (n_frames == 0) return PSS_OK;
     const size_t iq_b = up256((size_t)chunk_frames * n * 2 * sizeof(float));
@@ -564,8 +565,8 @@ extern "C" int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
     if (!h_iq || !h_pcm || n_frames < 0 || n < 1 || chunk_frames < 1) return pss_fail(ctx, PSS_E_ARG, "bad stream arguments");
-    const int n_out = pss_demod_out_len(PSS_MODE_NFM, n, fs);
-    if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "sample rate below 22050 Hz");
+    const int n_out = pss_demod_out_len_ctx(ctx, PSS_MODE_NFM, n, fs);
+    if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "sample rate below the target rate");
     if (n_frames == 0) return PSS_OK;
     if (chunk_frames > n_frames) chunk_frames = n_frames;
     const size_t iq_b = (size_t)chunk_frames * n * 2 * sizeof(float), db_b = (size_t)chunk_frames * n * sizeof(float),
@@ -638,8 +639,8 @@ static int stream_display(pss_ctx *ctx, const float *h_iq, long n_frames, int n,
     if (!h_iq || !h_pcm || !h_line_a || n_frames < 0 || n < 8 || chunk_frames < 1 || window < 1 || disp_w < 1 || disp_h < 1 ||
         disp_h > 127 || n_halo < 0 || (mode != 0 && mode != 1) || (mode == 0 && !h_line_b) || (n_halo > 0 && (!h_halo_lo || !h_halo_hi)))
         return pss_fail(ctx, PSS_E_ARG, "bad stream-display arguments");
-    const int n_out = pss_demod_out_len(PSS_MODE_NFM, n, fs);
-    if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "sample rate below 22050 Hz");
+    const int n_out = pss_demod_out_len_ctx(ctx, PSS_MODE_NFM, n, fs);
+    if (n_out < 0) return pss_fail(ctx, PSS_E_ARG, "sample rate below the target rate");
     if (n_frames == 0) return PSS_OK;
     if (chunk_frames > n_frames) chunk_frames = n_frames;
     const int m = n - 4;

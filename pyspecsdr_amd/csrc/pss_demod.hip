@@ -1308,11 +1308,34 @@ __global__ __launch_bounds__(256) void k_pairwise2(const float2 *__restrict__ iq
     }
 }
 
+// iq_correction's elementwise tail (signal_processing.py:55-80) for one sample, given the frame's five scalars: scl = 1 / q_amplitude (:55),
+// ia = 1 / alpha and qa2 = -sin(phi) / alpha (:67-68), sc = 1 / cos(phi) (:71), g = sqrt(input_power / var(corrected)) (:80).  Shared by
+// k_iqcorr (which also derives the scalars) and the fused WFM forward kernel, which applies the correction as it reads the raw IQ.
+struct IqcScal { float scl, ia, qa2, sc, g; };
+__device__ __forceinline__ float2 iqc_corrected(float2 v, float scl, float ia, float qa2, float sc)
+{
+    // :67-71 (the 1j*q_new complex multiply only touches the sign of zeros)
+    const float is = __fmul_rn(v.x, scl), qs = __fmul_rn(v.y, scl);
+    const float i_new = __fmul_rn(ia, is), q_new = __fadd_rn(__fmul_rn(qa2, is), qs);
+    const float jr = __fmaf_rn(0.0f, q_new, -0.0f), ji = __fmaf_rn(0.0f, 0.0f, q_new);
+    return make_float2(__fmul_rn(__fadd_rn(i_new, jr), sc), __fmul_rn(__fadd_rn(0.0f, ji), sc));
+}
+__device__ __forceinline__ float2 iqc_apply(float2 v, const IqcScal &k)
+{
+    float2 c = iqc_corrected(v, k.scl, k.ia, k.qa2, k.sc);
+    c.x = __fmul_rn(c.x, k.g);
+    c.y = __fmul_rn(c.y, k.g);
+    return c;
+}
+
 // STAGED: the frame is copied to LDS once and every pass reads it from there (frames up to 8192 samples).
+// scal (nullable): the frame's five scalars [n_frames][8] (IqcScal + padding) — with out == raw == nullptr the corrected frame is not
+// written at all (pss_frame_pipeline(WFM): the forward kernel corrects the samples as it loads them).
 // LDS: [frame: n float2 if STAGED][part: part_slots float2][val: val_slots float2]
 template <bool STAGED, bool WT = false>
 __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, int n, long n_frames, RedPlan rp, RedPlan cp,
-                                                int part_slots, int val_slots, float2 *__restrict__ out, float *__restrict__ raw)
+                                                int part_slots, int val_slots, float2 *__restrict__ out, float *__restrict__ raw,
+                                                float *__restrict__ scal)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *xs = reinterpret_cast<float2 *>(smem);
@@ -1360,13 +1383,7 @@ __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, i
         }), fn));
         const float cosphi = sqrtf(__fsub_rn(1.0f, __fmul_rn(sinphi, sinphi)));  // :64
         const float ia = __fdiv_rn(1.0f, alpha), qa2 = __fdiv_rn(-sinphi, alpha), sc = __fdiv_rn(1.0f, cosphi);
-        auto corrected = [&](int i) {  // :67-71 (the 1j*q_new complex multiply only touches the sign of zeros)
-            float2 v = X(i);
-            const float is = __fmul_rn(v.x, scl), qs = __fmul_rn(v.y, scl);
-            const float i_new = __fmul_rn(ia, is), q_new = __fadd_rn(__fmul_rn(qa2, is), qs);
-            const float jr = __fmaf_rn(0.0f, q_new, -0.0f), ji = __fmaf_rn(0.0f, 0.0f, q_new);
-            return make_float2(__fmul_rn(__fadd_rn(i_new, jr), sc), __fmul_rn(__fadd_rn(0.0f, ji), sc));
-        };
+        auto corrected = [&](int i) { return iqc_corrected(X(i), scl, ia, qa2, sc); };
         // :80 var(corrected), rescale to the input power
         s = frame_csum<WT>(cp, cpart, cval, corrected);
         const float m3r = __fdiv_rn(s.x, fn), m3i = __fdiv_rn(s.y, fn);
@@ -1376,12 +1393,18 @@ __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, i
             return __fadd_rn(__fmul_rn(dr, dr), __fmul_rn(di, di));  // np.var fast path: squares, then add (no fma)
         }), fn);
         const float g = sqrtf(__fdiv_rn(input_power, v2));
-        for (int i = threadIdx.x; i < n; i += T) {
-            float2 c = corrected(i);
-            c.x = __fmul_rn(c.x, g);
-            c.y = __fmul_rn(c.y, g);
-            if (out) out[(size_t)f * n + i] = c;
-            if (raw) raw[(size_t)f * n + i] = c.x;  // demodulate_signal(..., 'RAW'): np.real(samples) (:238)
+        if (scal && threadIdx.x == 0) {
+            float *k = scal + (size_t)f * 8;
+            k[0] = scl; k[1] = ia; k[2] = qa2; k[3] = sc; k[4] = g;
+        }
+        if (out || raw) {
+            for (int i = threadIdx.x; i < n; i += T) {
+                float2 c = corrected(i);
+                c.x = __fmul_rn(c.x, g);
+                c.y = __fmul_rn(c.y, g);
+                if (out) out[(size_t)f * n + i] = c;
+                if (raw) raw[(size_t)f * n + i] = c.x;  // demodulate_signal(..., 'RAW'): np.real(samples) (:238)
+            }
         }
         __syncthreads();  // xs is overwritten by the next frame
     }
@@ -2489,9 +2512,12 @@ __global__ __launch_bounds__(256) void k_cls_welch_short(const float2 *__restric
 // NumPy's SVML log10f (probed in the reference environment, see oracle/pss_oracle.c); the rise / fall indices of
 // np.diff(signals) are compacted IN ORDER: each wavefront owns a contiguous quarter of the frame, counts its transitions
 // (ballot + popcount), the four totals are scanned, then a second sweep writes them.  One workgroup per frame.
+// generic: any threshold — the mask is 20 * np.log10(envelope + 1e-10) > float32(threshold) evaluated as NumPy does (float32 throughout, the
+// SVML log10 model of pss_npf32.h: bit for bit on every positive float32); else the reference's own -20 dB, folded into one comparison with CUT,
+// the smallest float32 whose dB value exceeds -20.
 __global__ __launch_bounds__(256) void k_morse_edges(const float2 *__restrict__ iq, int n, long n_frames, int cap,
                                                      int32_t *__restrict__ rise, int32_t *__restrict__ fall,
-                                                     int32_t *__restrict__ counts)
+                                                     int32_t *__restrict__ counts, float thr, int generic)
 {
     __shared__ float red[4];
     __shared__ int rnan[4], cr[4], cf[4];
@@ -2518,7 +2544,8 @@ __global__ __launch_bounds__(256) void k_morse_edges(const float2 *__restrict__ 
         if (rnan[0] | rnan[1] | rnan[2] | rnan[3]) mx = NAN;  // np.max propagates NaN: then nothing is above the threshold
         auto sig = [&](int i) {
             const float2 v = x[i];
-            return __fadd_rn(__fdiv_rn(cabsf_np(v.x, v.y), mx), (float)1e-10) >= CUT;
+            const float p = __fadd_rn(__fdiv_rn(cabsf_np(v.x, v.y), mx), (float)1e-10);
+            return generic ? __fmul_rn(20.0f, log10f_np(p)) > thr : p >= CUT;
         };
         const int nt = n - 1;                                   // transitions i = 0 .. n-2 (between samples i and i+1)
         const int seg = ((nt + 3) / 4 + 63) & ~63;              // per wavefront, a multiple of 64
@@ -2847,8 +2874,8 @@ int nfm_filters(pss_ctx *ctx, double fs, PssNfmFilt **out)
     auto it = ctx->nfm.find(fs);
     if (it == ctx->nfm.end()) {
         PssNfmFilt f;
-        int q = (int)(fs / 22050.0);
-        if (q < 1) return pss_fail(ctx, PSS_E_ARG, "sample rate below 22050 Hz: decimation factor int(fs/22050) is 0");
+        int q = (int)(fs / ctx->target_rate);
+        if (q < 1) return pss_fail(ctx, PSS_E_ARG, "sample rate below the target rate: decimation factor int(fs / target_rate) is 0");
         int r = pss_design_firwin(65, 15000.0 / (fs / 2.0), f.taps);
         if (r) return pss_fail(ctx, r, "firwin: invalid cutoff frequency (15 kHz must be below fs/2)");
         r = pss_design_cheby1_sos(8, 0.05, 0.8 / q, f.sos);
@@ -2926,24 +2953,52 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
-extern "C" int pss_demod_out_len(int mode, int n, double fs)
+extern "C" int pss_demod_out_len_rate(int mode, int n, double fs, double target_rate)
 {
     if (n <= 0) return 0;
     if (mode == PSS_MODE_NFM || mode == PSS_MODE_WFM) {
-        int q = (int)(fs / 22050.0);
+        if (!(target_rate > 0.0)) return PSS_E_ARG;
+        int q = (int)(fs / target_rate);
         if (q < 1) return PSS_E_ARG;
         return (n - 1 + q - 1) / q;
     }
     if (mode == PSS_MODE_AM || mode == PSS_MODE_USB || mode == PSS_MODE_LSB) return n;
     return PSS_E_ARG;
 }
+extern "C" int pss_demod_out_len(int mode, int n, double fs) { return pss_demod_out_len_rate(mode, n, fs, 22050.0); }
+extern "C" int pss_demod_out_len_ctx(pss_ctx *ctx, int mode, int n, double fs)
+{
+    return ctx ? pss_demod_out_len_rate(mode, n, fs, ctx->target_rate) : PSS_E_ARG;
+}
 
+// demodulate_nfm / demodulate_wfm's target_rate argument (signal_processing.py:91, :119; default 22050 = DEFAULT_SAMPLE_RATE): the decimation
+// factor is int(sample_rate / target_rate).  Changing it drops the cached decimator designs (cheby1(8, 0.05, 0.8 / q) + zi per sample rate).
+extern "C" int pss_set_target_rate(pss_ctx *ctx, double target_rate)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (!(target_rate > 0.0)) return pss_fail(ctx, PSS_E_ARG, "pss_set_target_rate: the target rate must be positive");
+    if (target_rate == ctx->target_rate) return PSS_OK;
+    hipStreamSynchronize(ctx->stream);      // queued launches may still read the device copies of the taps
+    for (auto &kv : ctx->nfm)
+        if (kv.second.d_rev) hipFree(kv.second.d_rev);
+    ctx->nfm.clear();
+    ctx->target_rate = target_rate;
+    return PSS_OK;
+}
+
+static int iq_correction_launch(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out_iq, float *d_raw, float *d_scal);
 extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out_iq, float *d_raw)
 {
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
     if (n_frames < 0 || n <= 0 || (n_frames > 0 && (!d_iq || (!d_out_iq && !d_raw)))) return pss_fail(ctx, PSS_E_ARG, "pss_iq_correction: bad argument");
     if (n_frames == 0) return PSS_OK;
+    return iq_correction_launch(ctx, d_iq, n_frames, n, d_out_iq, d_raw, nullptr);
+}
+// d_scal (nullable): float32 [n_frames][8], the frames' five correction scalars (IqcScal); d_out_iq / d_raw may then both be NULL
+static int iq_correction_launch(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_out_iq, float *d_raw, float *d_scal)
+{
     RedPlan rp, cp;
     int rl, rv, cl, cv;
     int r = get_red_plan(ctx, n, false, &rp, &rl, &rv);
@@ -2967,7 +3022,7 @@ extern "C" int pss_iq_correction(pss_ctx *ctx, const float *d_iq, long n_frames,
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_iqcorr");
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(T), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n, n_frames, a, b,
-                       (int)part_slots, (int)val_slots, reinterpret_cast<float2 *>(d_out_iq), d_raw);
+                       (int)part_slots, (int)val_slots, reinterpret_cast<float2 *>(d_out_iq), d_raw, d_scal);
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_iqcorr launch");
@@ -3012,7 +3067,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         int r = nfm_filters(ctx, fs, &flt);
         if (r) return r;
         if (n_frames == 0) return PSS_OK;
-        const int q = (int)(fs / 22050.0);
+        const int q = (int)(fs / ctx->target_rate);
         const int n_out = (n - 1 + q - 1) / q;
         const long L = (long)(n - 1) + 2 * EDGE;
         const long Lp = (L + 1) & ~1L;  // even row stride -> 16-byte aligned rows of u
@@ -3251,7 +3306,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         return pss_hip_check(ctx, hipGetLastError(), "ssb launch");
     }
     if (mode == PSS_MODE_WFM) {
-        const int q = (int)(fs / 22050.0);
+        const int q = (int)(fs / ctx->target_rate);
         if (q < 2) return pss_fail(ctx, PSS_E_ARG, "WFM: sample rates below 44.1 kHz (no decimation stage) are not supported");
         if (n - 1 <= EDGE)
             return pss_fail(ctx, PSS_E_PADLEN, "The length of the input vector x must be greater than padlen, which is 27.");
@@ -3299,6 +3354,26 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         for (const double *bp : {wf->pilot, wf->lmr})
             spec = spec && is_num(bp + 6, 1, 2, 1) && is_num(bp + 12, 1, 0, -1) && is_num(bp + 18, 1, -2, 1) && is_num(bp + 24, 1, -2, 1);
         pss_time_begin(ctx);
+        // demodulate_signal's dispatcher (pss_demod_signal, pss_frame_pipeline): d_iq holds the frames as read and iq_correction comes first
+        // (signal_processing.py:222-225).  The fused forward kernel corrects the samples as it loads them, from a pre-pass that leaves five
+        // scalars per frame (no corrected copy of the batch: 8 bytes per sample neither written nor read back); the other kernel families
+        // read a corrected copy from the context's scratch.
+        const bool correct = ctx->wfm_correct;
+        ctx->wfm_correct = false;
+        ctx->wfm_scal = nullptr;
+        if (correct) {
+            const bool fused_path = !(!ctx->no_small_batch && n_frames <= ctx->wfm_small_batch_max) && !ctx->no_wfm_fused && b121 && !ctx->wfm_corr_copy;
+            if (fused_path) {
+                r = pss_ensure_buffer(ctx, &ctx->scratch_iqc, &ctx->scratch_iqc_bytes, (size_t)n_frames * 8 * sizeof(float), "iq_correction scalars");
+                if (!r) r = iq_correction_launch(ctx, d_iq, n_frames, n, nullptr, nullptr, reinterpret_cast<float *>(ctx->scratch_iqc));
+                ctx->wfm_scal = reinterpret_cast<const float *>(ctx->scratch_iqc);
+            } else {
+                r = pss_ensure_buffer(ctx, &ctx->scratch_iqc, &ctx->scratch_iqc_bytes, (size_t)n_frames * n * sizeof(float2), "iq_correction scratch");
+                if (!r) r = iq_correction_launch(ctx, d_iq, n_frames, n, reinterpret_cast<float *>(ctx->scratch_iqc), nullptr, nullptr);
+                d_iq = reinterpret_cast<const float *>(ctx->scratch_iqc);
+            }
+            if (r) { pss_time_end(ctx); return r; }
+        }
         if (!ctx->no_small_batch && n_frames <= ctx->wfm_small_batch_max) {
             // a handful of frames: one lane per filter SECTION instead of one lane per frame (k_wfm_casc, k_iir4_sys)
             const int M = n - 1;
@@ -3416,10 +3491,14 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             // fused path (decimator sections 1..3 with numerator [1, 2, 1]): forward decimator pass inside the front kernel, y_fwd planar-transposed, u[] never stored
             double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);
             double *MXf = reinterpret_cast<double *>(base + szY + szA);
-            auto kf = spec ? wfmf::k_wfm_fwd<true, true> : wfmf::k_wfm_fwd<false, true>;
+            // ctx->wfm_scal (pss_demod_signal / pss_frame_pipeline, WFM): d_iq holds the frames as read, corrected on the fly by the kernel
+            const float *scal = ctx->wfm_scal;
+            ctx->wfm_scal = nullptr;
+            auto kf = scal ? (spec ? wfmf::k_wfm_fwd<true, true, true> : wfmf::k_wfm_fwd<false, true, true>)
+                           : (spec ? wfmf::k_wfm_fwd<true, true> : wfmf::k_wfm_fwd<false, true>);
             pss_kernel_begin(ctx, "k_wfm_fwd");
             hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(TILE), wfmf::LDS_BYTES, PSS_STREAM(ctx),
-                               reinterpret_cast<const float2 *>(d_iq), Yf, n, n_frames, swapped, wc, c);
+                               reinterpret_cast<const float2 *>(d_iq), Yf, n, n_frames, swapped, wc, c, scal);
             pss_kernel_end(ctx);
             auto launch_bwd = [=]() -> int {
                 pss_kernel_begin(ctx, "k_nfm_bwd");
@@ -3479,14 +3558,8 @@ extern "C" int pss_demod_signal(pss_ctx *ctx, int mode, const float *d_iq, long 
     if (mode != PSS_MODE_WFM) return pss_demod(ctx, mode, d_iq, n_frames, n, fs, d_pcm, d_audio);
     if (n_frames < 0 || n < 1 || (n_frames > 0 && !d_iq)) return pss_fail(ctx, PSS_E_ARG, "bad demod arguments");
     if (n_frames == 0) return pss_demod(ctx, mode, d_iq, n_frames, n, fs, d_pcm, d_audio);
-    int r = pss_ensure_buffer(ctx, &ctx->scratch_iqc, &ctx->scratch_iqc_bytes, (size_t)n_frames * n * sizeof(float2),
-                              "iq_correction scratch");
-    if (r) return r;
-    pss_time_begin(ctx);
-    r = pss_iq_correction(ctx, d_iq, n_frames, n, reinterpret_cast<float *>(ctx->scratch_iqc), nullptr);
-    if (!r) r = pss_demod(ctx, mode, reinterpret_cast<const float *>(ctx->scratch_iqc), n_frames, n, fs, d_pcm, d_audio);
-    pss_time_end(ctx);
-    return r;
+    PssFlagScope corr(ctx->wfm_correct, true);    // the WFM branch of pss_demod runs iq_correction itself (scalars pre-pass or a corrected copy)
+    return pss_demod(ctx, mode, d_iq, n_frames, n, fs, d_pcm, d_audio);
 }
 
 // measure_signal_power + demodulate of the same read buffers, as the main loop runs them back to back (pyspecsdr.py:2251, :2262): d_power
@@ -3542,15 +3615,12 @@ extern "C" int pss_morse_edges(pss_ctx *ctx, const float *d_iq, long n_frames, i
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
     if (n_frames < 0 || n < 1 || cap < 0) return pss_fail(ctx, PSS_E_ARG, "pss_morse_edges: bad argument");
-    if (threshold_db != -20.0)
-        return pss_fail(ctx, PSS_E_ARG, "pss_morse_edges: only the reference's threshold of -20 dB is pinned (the comparison replays "
-                                        "NumPy's float32 log10 at that one point)");
     if (n_frames == 0) return PSS_OK;
     if (!d_iq || !d_counts || (cap > 0 && (!d_rise || !d_fall))) return pss_fail(ctx, PSS_E_ARG, "pss_morse_edges: null buffer");
     const long g = n_frames < 16384 ? n_frames : 16384;
     pss_kernel_begin(ctx, "k_morse_edges");
     hipLaunchKernelGGL(k_morse_edges, dim3((unsigned)g), dim3(256), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), n,
-                       n_frames, cap, d_rise, d_fall, d_counts);
+                       n_frames, cap, d_rise, d_fall, d_counts, (float)threshold_db, threshold_db != -20.0 ? 1 : 0);
     pss_kernel_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_morse_edges launch");
 }
@@ -3898,17 +3968,10 @@ static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n
         if (!q) q = pipe_lines(ctx, display, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph, d_colour);
         return q;
     };
-    const float *d_in = d_iq;     // what the demodulator reads (WFM: the IQ-corrected frames)
-    if (mode == PSS_MODE_WFM && n_frames > 0) {
-        // demodulate_signal's dispatcher semantics: WFM frames are IQ-corrected first (signal_processing.py:222-225) — the correction alone,
-        // in front of everything: a chain beside it would only share its HBM bandwidth
-        pss_time_begin(ctx);
-        int r = pss_ensure_buffer(ctx, &ctx->scratch_iqc, &ctx->scratch_iqc_bytes, (size_t)n_frames * n * sizeof(float2), "iq_correction scratch");
-        if (!r) r = pss_iq_correction(ctx, d_iq, n_frames, n, reinterpret_cast<float *>(ctx->scratch_iqc), nullptr);
-        pss_time_end(ctx);
-        if (r) return r;
-        d_in = reinterpret_cast<const float *>(ctx->scratch_iqc);
-    }
+    // WFM: demodulate_signal's dispatcher semantics — the frames are IQ-corrected first (signal_processing.py:222-225); pss_demod's WFM
+    // branch does it (wfm_correct): a scalars pre-pass in front of the forward kernel, alone on the machine
+    const float *d_in = d_iq;
+    PssFlagScope corr(ctx->wfm_correct, mode == PSS_MODE_WFM && n_frames > 0);
     if (mode != PSS_MODE_NFM && mode != PSS_MODE_WFM) {
         // AM / USB / LSB: neither demodulator has the two-phase shape of the FM paths, so the display chain simply runs on the side stream
         // beside the whole demodulator (AM's recurrence kernel keeps two thirds of the SIMDs busy with one wavefront each — the HBM-bound

@@ -55,9 +55,12 @@ __device__ __forceinline__ double bq(const BqV &c, double x, double &z0, double 
 }
 
 // SPEC: the Butterworth rows have SciPy's usual numerator shapes; B121: decimator sections 1..3 are [1, 2, 1].
-template <bool SPEC, bool B121>
+// CORR: `iq` holds the frames as read and `scal` their iq_correction scalars (k_iqcorr's pre-pass, [n_frames][8]): every sample is corrected
+// (signal_processing.py:55-80, iqc_apply: the bits of pss_iq_correction's output) as it leaves the transposed chunk — the corrected copy of
+// the batch (8 bytes per sample written and read back) never exists.
+template <bool SPEC, bool B121, bool CORR = false>
 __global__ __launch_bounds__(TILE) void k_wfm_fwd(const float2 *__restrict__ iq, double *__restrict__ Y, int n,
-                                                  long n_frames, int swapped, WfmCoef wc, NfmCoef dc)
+                                                  long n_frames, int swapped, WfmCoef wc, NfmCoef dc, const float *__restrict__ scal)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *xs = reinterpret_cast<float2 *>(smem);                                   // [CH][XSTR]
@@ -67,6 +70,12 @@ __global__ __launch_bounds__(TILE) void k_wfm_fwd(const float2 *__restrict__ iq,
     ltab[lane] = pss::RCP14_AB[lane];   // one wavefront per workgroup: visible to itself in program order
     const long tile = blockIdx.x;
     const long f0 = tile * TILE;
+    IqcScal kc{1.0f, 1.0f, 0.0f, 1.0f, 1.0f};
+    if constexpr (CORR) {
+        const long fr = f0 + lane < n_frames ? f0 + lane : n_frames - 1;
+        const float4 a = *reinterpret_cast<const float4 *>(scal + (size_t)fr * 8);
+        kc = IqcScal{a.x, a.y, a.z, a.w, scal[(size_t)fr * 8 + 4]};
+    }
     const int M = n - 1;
     const long L = (long)M + 2 * EDGE;
     double *YL = Y + (size_t)(2 * tile) * L * TILE + lane, *YR = YL + (size_t)L * TILE;
@@ -158,7 +167,8 @@ __global__ __launch_bounds__(TILE) void k_wfm_fwd(const float2 *__restrict__ iq,
             for (int u = 0; u < 4; u++) {
                 const int t = t4 + u, i = e0 + t - 1;
                 if (t < cnt) {
-                    const float2 cur = xs[t * XSTR + lane];
+                    float2 cur = xs[t * XSTR + lane];
+                    if constexpr (CORR) cur = iqc_apply(cur, kc);
                     if (i < 0) { prev = cur; continue; }
                     const double d = (double)disc_sample(cur, prev, 1.0f, swapped != 0, ltab);  // :122 (x1.0f is exact)
                     prev = cur;

@@ -258,7 +258,12 @@ class Engine:
         self._ck(self.lib.pss_set_wfm_filters(self.h, float(fs), _ptr(lp), _ptr(pilot), _ptr(lmr), float(alpha)))
 
     def demod_out_len(self, mode, n, fs):
-        return int(self.lib.pss_demod_out_len(mode, n, float(fs)))
+        """Output samples per frame at this engine's target rate (set_target_rate; 22050 unless changed)."""
+        return int(self.lib.pss_demod_out_len_ctx(self.h, mode, n, float(fs)))
+
+    def set_target_rate(self, target_rate):
+        """demodulate_nfm / demodulate_wfm's target_rate (signal_processing.py:91, :119): decimation factor int(fs / target_rate)."""
+        self._ck(self.lib.pss_set_target_rate(self.h, float(target_rate)))
 
     def spectrum_nfm(self, d_iq, n_frames, n, fs, d_db, d_pcm):
         self._dev(self.lib.pss_spectrum_nfm, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_pcm))
@@ -450,7 +455,7 @@ class Engine:
         iq = np.ascontiguousarray(iq, np.complex64)
         n_out = self.demod_out_len(mode, len(iq), fs)
         if n_out < 0:
-            raise ValueError("sample rate below 22050 Hz or unknown mode")
+            raise ValueError("sample rate below the target rate or unknown mode")
         audio = np.empty((n_out, 2), np.float64)
         pcm = np.empty((n_out, 2), np.int16)
         self._ck(self.lib.pss_h_demodulate(self.h, mode, _ptr(iq), len(iq), float(fs), _ptr(audio), _ptr(pcm)))
@@ -460,7 +465,7 @@ class Engine:
         iq = np.ascontiguousarray(iq, np.complex64)
         n_out = self.demod_out_len(mode, len(iq), fs)
         if n_out < 0:
-            raise ValueError("sample rate below 22050 Hz or unknown mode")
+            raise ValueError("sample rate below the target rate or unknown mode")
         audio = np.empty((n_out, 2), np.float64)
         pcm = np.empty((n_out, 2), np.int16)
         self._ck(self.lib.pss_h_demodulate_signal(self.h, mode, _ptr(iq), len(iq), float(fs), _ptr(audio), _ptr(pcm)))
@@ -472,7 +477,7 @@ class Engine:
         nf, n = frames.shape
         n_out = self.demod_out_len(mode, n, fs)
         if n_out < 0:
-            raise ValueError("sample rate below 22050 Hz or unknown mode")
+            raise ValueError("sample rate below the target rate or unknown mode")
         pcm = np.empty((nf, n_out, 2), np.int16)
         self._ck(self.lib.pss_h_demodulate_batch(self.h, mode, _ptr(frames), nf, n, float(fs), int(chunk_frames), _ptr(pcm)))
         return pcm
@@ -485,9 +490,6 @@ class Engine:
 
     def h_morse_edges(self, iq, threshold_db=-20.0):
         """-> (rise_times, fall_times) int32 arrays of decode_morse (decoders.py:159-161) for one buffer."""
-        if float(threshold_db) != -20.0:
-            raise NotImplementedError("morse edges: only the reference's threshold of -20 dB is served (the comparison is pinned to "
-                                      "NumPy's float32 log10 at exactly that point, pyspecsdr.py:573)")
         iq = np.ascontiguousarray(iq, np.complex64)
         cap = max(len(iq) // 2 + 1, 1)
         rise, fall = np.empty(cap, np.int32), np.empty(cap, np.int32)

@@ -52,6 +52,20 @@ USE_SCIPY_DESIGNS = True
 _designed = set()
 
 
+_target_rate = float(DEFAULT_SAMPLE_RATE)     # what the engine's decimator is currently designed for
+
+
+def _set_target_rate(target_rate):
+    """demodulate_nfm / _wfm(target_rate=...): decimation factor int(sample_rate / target_rate) (signal_processing.py:111)."""
+    global _target_rate
+    tr = float(target_rate)
+    if tr != _target_rate:
+        get_engine().set_target_rate(tr)       # drops the engine's cached decimator designs
+        for k in [k for k in _designed if k[0] in ('nfm', 'wfm')]:
+            _designed.discard(k)
+        _target_rate = tr
+
+
 def _inject_designs(kind, fs):
     key = (kind, float(fs))
     if not USE_SCIPY_DESIGNS or key in _designed:
@@ -63,7 +77,7 @@ def _inject_designs(kind, fs):
         return
     e = get_engine()
     fs = float(fs)
-    q = int(fs / DEFAULT_SAMPLE_RATE)
+    q = int(fs / _target_rate)
     if kind == 'wfm':
         nyq = fs / 2
         lp = ss.butter(BUTTER_ORDER, 15000 / nyq, btype='low', output='sos')                     # :126 -> :39
@@ -108,8 +122,6 @@ def mono_to_stereo(mono_audio):
 def bandpass_filter(data, lowcut, highcut, sample_rate):
     """signal_processing.py:34-42 (imported by decoders.py:3): butter(5) low-/band-pass SOS + sosfilt -> float64 (N,)."""
     d = np.asarray(data)
-    if d.ndim != 1 or np.iscomplexobj(d):
-        raise NotImplementedError("bandpass_filter: only 1-D real input is accelerated")
     sos = None
     if USE_SCIPY_DESIGNS:
         try:
@@ -119,7 +131,18 @@ def bandpass_filter(data, lowcut, highcut, sample_rate):
                    ss.butter(BUTTER_ORDER, [lowcut / nyq, highcut / nyq], btype='band', output='sos'))
         except ImportError:
             pass
-    return get_engine().h_bandpass_filter(d, lowcut, highcut, sample_rate, sos)
+    e = get_engine()
+    one = lambda row: e.h_bandpass_filter(row, lowcut, highcut, sample_rate, sos)
+    if d.ndim == 0:
+        raise ValueError("bandpass_filter: sosfilt needs at least one axis")           # (sosfilt raises on a 0-d input as well)
+    # sosfilt filters along the last axis; complex input: real coefficients act on the two components separately (result complex128)
+    rows = d.reshape(-1, d.shape[-1])
+    if np.iscomplexobj(d):
+        out = np.stack([one(np.ascontiguousarray(r.real)) + 1j * one(np.ascontiguousarray(r.imag)) for r in rows]) if len(rows) else \
+            np.zeros(rows.shape, np.complex128)
+    else:
+        out = np.stack([one(np.ascontiguousarray(r)) for r in rows]) if len(rows) else np.zeros(rows.shape, np.float64)
+    return out.reshape(d.shape)
 
 
 # signal_processing.py:296-322 calls `welch`, which the module never imports: in the reference the function
@@ -165,8 +188,7 @@ def compute_fft(samples):
 
 
 def demodulate_nfm(samples, sample_rate, target_rate=DEFAULT_SAMPLE_RATE):
-    if target_rate != DEFAULT_SAMPLE_RATE:
-        raise NotImplementedError("only the reference's fixed target_rate=22050 is accelerated")
+    _set_target_rate(target_rate)
     _inject_designs('nfm', sample_rate)
     audio, _ = get_engine().h_demodulate(L.MODE_NFM, _samples(samples), sample_rate)
     return audio
@@ -175,8 +197,7 @@ def demodulate_nfm(samples, sample_rate, target_rate=DEFAULT_SAMPLE_RATE):
 def demodulate_wfm(samples, sample_rate, target_rate=DEFAULT_SAMPLE_RATE):
     """signal_processing.py:119-176 -> float64 (n_out, 2) = column_stack((left, right)).  (The reference's RDS hooks at
     :165-174 call undefined names inside a try/except and never produce anything; nothing to mirror.)"""
-    if target_rate != DEFAULT_SAMPLE_RATE:
-        raise NotImplementedError("only the reference's fixed target_rate=22050 is accelerated")
+    _set_target_rate(target_rate)
     _inject_designs('wfm', sample_rate)
     audio, _ = get_engine().h_demodulate(L.MODE_WFM, _samples(samples), sample_rate)
     return audio
@@ -206,6 +227,7 @@ def demodulate_signal(samples, sample_rate, mode='NFM'):
         # :222-225 + :238 — every non-voice mode is IQ-corrected first; RAW then returns the I samples (float32)
         return get_engine().h_raw(_samples(samples))
     elif mode == 'WFM':
+        _set_target_rate(DEFAULT_SAMPLE_RATE)
         _inject_designs('wfm', sample_rate)
         audio, _ = get_engine().h_demodulate_signal(L.MODE_WFM, _samples(samples), sample_rate)  # :222-228
         return audio

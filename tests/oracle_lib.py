@@ -139,10 +139,10 @@ def iq_correction(iq):
     return out
 
 
-def demod_wfm(iq, fs, filt):
+def demod_wfm(iq, fs, filt, target_rate=22050):
     """filt: dict with lp_sos, pilot_sos, lmr_sos, alpha, dec_sos, dec_zi.  Returns (n_out, 2) float64 or None (ValueError)."""
     n = len(iq)
-    q = int(fs / 22050)
+    q = int(fs / target_rate)
     cap = max(n, 1)
     left, right = np.empty(cap), np.empty(cap)
     c = lambda a: np.ascontiguousarray(a, np.float64)
@@ -230,11 +230,18 @@ def hann(n):
     return w
 
 
-def morse_edges(iq):
-    """-> (rise_times, fall_times) int32 arrays of decode_morse (decoders.py:159-161), threshold -20 dB."""
+def morse_edges(iq, threshold=-20):
+    """-> (rise_times, fall_times) int32 arrays of decode_morse (decoders.py:159-161); threshold in dB (the reference's own: -20)."""
     n = len(iq)
     rise, fall = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.int32)
     nr, nf = C.c_long(), C.c_long()
+    if float(threshold) != -20.0:
+        L = lib()
+        L.pss_o_morse_edges_thr.restype = None
+        L.pss_o_morse_edges_thr.argtypes = [_f32p, C.c_long, C.c_double, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"),
+                                            np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.pss_o_morse_edges_thr(_iq(iq), n, float(threshold), rise, fall, n, C.byref(nr), C.byref(nf))
+        return rise[:nr.value].copy(), fall[:nf.value].copy()
     lib().pss_o_morse_edges(_iq(iq), n, rise, fall, n, C.byref(nr), C.byref(nf))
     return rise[:nr.value].copy(), fall[:nf.value].copy()
 
@@ -259,9 +266,9 @@ def scan_slice(iq, fs):
     return db, np.float32(pk.value), bw.value, cnt
 
 
-def demod_nfm(iq, fs, taps, sos, zi, stages=False):
+def demod_nfm(iq, fs, taps, sos, zi, stages=False, target_rate=22050):
     n = len(iq)
-    q = int(fs / 22050)
+    q = int(fs / target_rate)
     n_out = max((n - 1 + q - 1) // q, 0)
     audio = np.empty(max(n_out, 1), np.float64)
     disc = np.empty(max(n - 1, 1), np.float32)

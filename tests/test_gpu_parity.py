@@ -349,6 +349,34 @@ def test_demod_power_equals_the_two_calls(mode):
         assert wa[k % nf].cpu().numpy().tobytes() == np.float32(O.power_db(x)).tobytes()
 
 
+def test_wfm_correction_in_the_forward_kernel_equals_the_corrected_copy():
+    """demodulate_signal(WFM) = iq_correction + demodulate_wfm (signal_processing.py:222-228).  Large batches: a pre-pass leaves the five
+    correction scalars per frame and the fused forward kernel corrects every sample as it loads it — against the path that writes the
+    corrected copy of the batch first (option "wfm_corr_copy"), and against iq_correction + demod as separate calls: the same PCM and audio bits."""
+    e = G.engine()
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    for nf, n, fs in ((7000, 1024, 2.4e6), (6100, 2048, 1.024e6), (3, 4096, 2.4e6)):
+        iq = torch.randn((nf, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3 + torch.tensor([0.05, -0.02], device="cuda")
+        iq[..., 1] *= 0.8                                     # an amplitude imbalance for the correction to act on
+        torch.cuda.synchronize()
+        n_out = e.demod_out_len(L.MODE_WFM, n, fs)
+        outs = []
+        for copy in (0, 1):
+            e.set_option("wfm_corr_copy", copy)
+            pcm, au = G.empty((nf, n_out, 2), torch.int16), G.empty((nf, n_out, 2), torch.float64)
+            e.demod_signal(L.MODE_WFM, iq, nf, n, fs, pcm, au)
+            e.sync()
+            outs.append((pcm, au))
+        e.set_option("wfm_corr_copy", 0)
+        corr = G.empty((nf, n, 2), torch.float32)
+        pcm, au = G.empty((nf, n_out, 2), torch.int16), G.empty((nf, n_out, 2), torch.float64)
+        e.iq_correction(iq, nf, n, corr, None)
+        e.demod(L.MODE_WFM, corr, nf, n, fs, pcm, au)
+        e.sync()
+        for p2, a2 in outs:
+            assert torch.equal(p2, pcm) and torch.equal(a2.view(torch.int64), au.view(torch.int64)), (nf, n)
+
+
 def test_float64_pipeline_register_kernels_equal_plain_kernels_and_numpy():
     """The float64-row entry points on the register kernels (k_spectrum_r16<..., D64>, k_post_sel<..., double>, the lines from the rows
     resampled in the same pass) against the plain round-3 kernels (option "f64_plain") and NumPy: dB rows within 1e-11 of each other
@@ -1397,8 +1425,10 @@ def test_decoder_front_halves(golden):
     e.sync()
     with np.errstate(invalid="ignore"):
         assert np.array_equal(G.host(d_y), rows / np.max(np.abs(rows), axis=1, keepdims=True), equal_nan=True)
-    with pytest.raises(NotImplementedError):
-        e.h_morse_edges(g["m_iq_one"], threshold_db=-15.0)       # only the reference's -20 dB is pinned
+    for thr in (-15.0, -33.3, -1.5):                             # any threshold (the reference's -20 is one precomputed cut): against the oracle
+        r, f = e.h_morse_edges(g["m_iq_cq"], threshold_db=thr)
+        wr, wf = O.morse_edges(g["m_iq_cq"], thr)
+        assert np.array_equal(r, wr) and np.array_equal(f, wf), thr
     rng = np.random.default_rng(9)
     for nf, n in ((33, 5000), (7, 2), (4, 70001), (300, 777)):
         key = np.repeat(rng.integers(0, 2, (nf, n // 40 + 1)), 40, axis=1)[:, :n] * rng.uniform(0.05, 1.0, (nf, 1))
@@ -1443,6 +1473,69 @@ def test_decoders_end_to_end_vs_reference(golden):
                 assert D.decode_afsk(np.real(g[f"a_x_{tag}"]) / np.max(np.abs(np.real(g[f"a_x_{tag}"]))), float(g[f"a_fs_{tag}"])) == [int(b) for b in g[f"a_bits_{tag}"]]
     finally:
         sp.USE_SCIPY_DESIGNS = keep
+
+
+def test_round5_arguments_vs_reference_goldens(golden):
+    """The arguments the drop-in module used to refuse (tests/golden/args.npz, tools/make_goldens_round5.py): demodulate_nfm / demodulate_wfm
+    with target_rate != 22050 (any decimation factor int(fs / target_rate)), decode_morse with threshold != -20, bandpass_filter on complex
+    and 2-D input — through the reference-named functions of pyspecsdr_amd.signal_processing / .decoders, against what the reference returned."""
+    import pyspecsdr_amd.signal_processing as sp
+    from pyspecsdr_amd import decoders as D
+    g = golden["args"]
+    keep = sp.USE_SCIPY_DESIGNS
+    try:
+        for scipy_tables in (True, False):             # SciPy's own tables injected / the library's designers
+            sp.USE_SCIPY_DESIGNS = scipy_tables
+            sp._designed.clear()
+            for t in g["rate_tags"]:
+                fs, tr = float(g[f"fs_{t}"]), int(g[f"tr_{t}"])
+                fn = sp.demodulate_nfm if str(t).startswith("n") else sp.demodulate_wfm
+                for k, x in enumerate(g[f"iq_{t}"]):
+                    a = fn(x, fs, tr)
+                    assert a.shape == g[f"audio_{t}"][k].shape, (t, a.shape)
+                    assert np.array_equal(a, g[f"audio_{t}"][k]), (t, scipy_tables)
+                    assert np.array_equal(np.int16(a * 32767), g[f"pcm_{t}"][k]), t
+            # ... and back to the default rate: the goldens of rounds 1-4 still hold
+            n = golden["nfm"]
+            assert np.array_equal(sp.demodulate_nfm(n["iq_a"][0], float(n["fs_a"]))[:, 0], n["audio_a"][0])
+    finally:
+        sp.USE_SCIPY_DESIGNS = keep
+        sp._designed.clear()
+        sp._set_target_rate(sp.DEFAULT_SAMPLE_RATE)
+    # batched device entry point with the target rate set on the engine
+    e = G.engine()
+    t = "n2"
+    fs, tr, iq = float(g[f"fs_{t}"]), float(g[f"tr_{t}"]), g[f"iq_{t}"]
+    try:
+        e.set_target_rate(tr)
+        e.set_nfm_filters(fs, g[f"taps_{t}"], g[f"sos_{t}"], g[f"zi_{t}"])
+        nf, n = iq.shape
+        n_out = e.demod_out_len(L.MODE_NFM, n, fs)
+        assert n_out == g[f"audio_{t}"].shape[1]
+        big = np.tile(iq, (5000, 1))                    # 10 000 frames: the fused large-batch kernels
+        for batch in (iq, big):
+            d_pcm, d_au = G.empty((len(batch), n_out, 2), torch.int16), G.empty((len(batch), n_out), torch.float64)
+            e.demod(L.MODE_NFM, G.dev(batch), len(batch), n, fs, d_pcm, d_au)
+            e.sync()
+            assert np.array_equal(G.host(d_au)[:nf], g[f"audio_{t}"][..., 0]) and np.array_equal(G.host(d_pcm)[:nf], g[f"pcm_{t}"])
+            assert np.array_equal(G.host(d_pcm)[-nf:], g[f"pcm_{t}"])
+    finally:
+        e.set_target_rate(22050)
+    for t in g["morse_tags"]:
+        x, fs, thr = g[f"m_iq_{t}"], float(g[f"m_fs_{t}"]), float(g[f"m_thr_{t}"])
+        r, f = D.morse_edges(x, thr)
+        assert np.array_equal(r, g[f"m_rise_{t}"]) and np.array_equal(f, g[f"m_fall_{t}"]), t
+        text, tm = D.decode_morse(x, fs, thr)
+        got = np.array([float(tm["dot"]), float(tm["dash"]), float(tm["gap"])])
+        if len(g[f"m_rise_{t}"]) < 40:                  # (the noisy cases: the reference's own answer hangs on its random kmeans start)
+            assert text == str(g[f"m_text_{t}"]), (t, text)
+            assert np.array_equal(got.view(np.uint64), g[f"m_timing_{t}"].view(np.uint64)), (t, got)
+    for t in g["bandpass_tags"]:
+        lo, hi, fs = [float(v) for v in g[f"b_args_{t}"]]
+        y = sp.bandpass_filter(g[f"b_x_{t}"], lo, hi, fs)
+        want = g[f"b_y_{t}"]
+        assert y.dtype == want.dtype and y.shape == want.shape, (t, y.dtype, y.shape)
+        assert np.array_equal(y, want), t
 
 
 def test_kernel_timing_and_filter():

@@ -447,3 +447,24 @@ def test_headline_f64_from_iq_draws_the_reference_cells(golden):
     # the PCM of the same call is the golden NFM path's (frame by frame)
     for i in (0, 7, len(iq) - 1):
         assert np.array_equal(o["pcm"][i], O.pcm16_stereo(O.demod_nfm(iq[i], 2.4e6, nfm[f"taps_{tag}"], nfm[f"sos_{tag}"], nfm[f"zi_{tag}"])))
+
+
+def test_round5_arguments_oracle_vs_reference(golden):
+    """tests/golden/args.npz (tools/make_goldens_round5.py): the reference's demodulate_nfm / _wfm at target rates other than 22050
+    (signal_processing.py:111: int(sample_rate / target_rate)) and decode_morse's mask at thresholds other than -20 dB (decoders.py:156) —
+    the oracle's restatement bit for bit."""
+    g = golden["args"]
+    for t in g["rate_tags"]:
+        fs, tr = float(g[f"fs_{t}"]), float(g[f"tr_{t}"])
+        for k, x in enumerate(g[f"iq_{t}"]):
+            if str(t).startswith("n"):
+                a = O.demod_nfm(x, fs, g[f"taps_{t}"], g[f"sos_{t}"], g[f"zi_{t}"], target_rate=tr)
+                assert np.array_equal(a, g[f"audio_{t}"][k][:, 0]), t
+                assert np.array_equal(O.pcm16_stereo(a), g[f"pcm_{t}"][k]), t
+            else:
+                filt = dict(lp_sos=g[f"lp_{t}"], pilot_sos=g[f"pil_{t}"], lmr_sos=g[f"lmr_{t}"], alpha=float(g[f"alpha_{t}"]),
+                            dec_sos=g[f"sos_{t}"], dec_zi=g[f"zi_{t}"])
+                assert np.array_equal(O.demod_wfm(x, fs, filt, target_rate=tr), g[f"audio_{t}"][k]), t
+    for t in g["morse_tags"]:
+        r, f = O.morse_edges(g[f"m_iq_{t}"], float(g[f"m_thr_{t}"]))
+        assert np.array_equal(r, g[f"m_rise_{t}"]) and np.array_equal(f, g[f"m_fall_{t}"]), t
