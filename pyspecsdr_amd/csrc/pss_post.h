@@ -130,22 +130,18 @@ __device__ __forceinline__ unsigned count_below(const K (&key)[EPL], K trial, un
 // k-th smallest (0-based) of the row's n_valid keys (padding slots hold the all-ones key) and, in `next`, the (k+1)-th: binary
 // search on the key bits below the common prefix of the row's minimum and maximum (returned in mn / mx); stops as soon as
 // one candidate is left in the bracket, and that last pass also finds the smallest key above the bracket (= rank k + 1).
+// below / upto: the numbers of keys < and <= the returned value (the ranks below .. upto - 1 hold that value).
 // PAD_FROM: first register slot that may hold padding (EPL: none anywhere).
-// `guess`: a value near which the order statistic is expected (the row's mean: most of a dB row is noise floor) or NaN.  The
-// brackets [guess - 0.5, guess + 0.5] and [guess - 2, guess + 2] are tried first — two counts tell whether rank k lies inside —
-// and the search then halves such a bracket instead of spending its first steps on the empty stretch between the noise
-// floor and the row's extremes (measured on FM / noise / weak-tone rows: 10.4-10.7 counting passes instead of 15-19).
-// A wrong guess costs four counts and changes nothing else: every result is decided by exact counts.
-// T = float: 32-bit keys; T = double: 64-bit keys (the search stops when ONE key is left in the bracket, so the number of passes depends on
-// how close the row's values lie to its median, not on the key width).
-template <int EPL, int W, int PAD_FROM, class T>
-__device__ __forceinline__ typename Ord<T>::K select_kth(const typename Ord<T>::K (&key)[EPL], unsigned k, unsigned n_valid,
-                                                         typename Ord<T>::K &next, typename Ord<T>::K &mn, typename Ord<T>::K &mx,
-                                                         unsigned long long *red, int wave, int lane, int &phase, float guess = NAN)
+// guess: enc(d) = the key of (guess + d) for a value near which the order statistic is expected (the row's mean: most of a dB row is
+// noise floor); have_guess = false: none.  The brackets [guess - 0.5, guess + 0.5] and [guess - 2, guess + 2] are tried first — two
+// counts tell whether rank k lies inside — and the search then halves such a bracket instead of spending its first steps on the empty
+// stretch between the noise floor and the row's extremes (measured on FM / noise / weak-tone rows: 10.4-10.7 counting passes instead of
+// 15-19).  A wrong guess costs four counts and changes nothing else: every result is decided by exact counts.
+template <int EPL, int W, int PAD_FROM, class K, class Enc>
+__device__ __forceinline__ K select_kth(const K (&key)[EPL], unsigned k, unsigned n_valid, K &next, K &mn, K &mx, unsigned &below, unsigned &upto,
+                                        unsigned long long *red, int wave, int lane, int &phase, bool have_guess, Enc enc)
 {
-    using O = Ord<T>;
-    using K = typename O::K;
-    constexpr K PAD = O::PAD;
+    constexpr K PAD = (K)~(K)0;
     K a = PAD, b0 = 0, b2 = 0;
 #pragma unroll
     for (int r = 0; r < EPL; r++) {
@@ -163,12 +159,12 @@ __device__ __forceinline__ typename Ord<T>::K select_kth(const typename Ord<T>::
         for (int r = 0; r < EPL; r++) c = (key[r] > v && key[r] < c) ? key[r] : c;
         return row_reduce<OpMin, W>(c, red, wave, lane, phase);
     };
-    if (mn == mx) { next = mn; return mn; }                   // a constant row (n_valid >= 2 wherever next is used)
-    if (guess == guess && mx != PAD) {
+    if (mn == mx) { next = mn; below = 0; upto = n_valid; return mn; }   // a constant row (n_valid >= 2 wherever next is used)
+    if (have_guess && mx != PAD) {
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; attempt++) {
             const float d = attempt ? 2.0f : 0.5f;
-            K lo = O::enc((T)(guess - d)), hi = O::enc((T)(guess + d));
+            K lo = enc(-d), hi = enc(d);
             lo = lo < mn ? mn : lo;
             hi = hi > mx ? mx : hi;
             if (lo > hi) continue;
@@ -182,6 +178,7 @@ __device__ __forceinline__ typename Ord<T>::K select_kth(const typename Ord<T>::
                 const unsigned c = count_below<EPL, W>(key, trial, red, wave, lane, phase);
                 if (c <= k) { lo = trial; n_lo = c; } else { hi = trial - 1u; n_hi = c; }
             }
+            below = n_lo; upto = n_hi;
             if (n_hi - n_lo == 1u) {
                 // the one key in [lo, hi] has rank k; exactly k + 1 keys are <= hi, so rank k + 1 is the smallest key above hi
                 K cand = PAD, nx = PAD;
@@ -189,7 +186,7 @@ __device__ __forceinline__ typename Ord<T>::K select_kth(const typename Ord<T>::
 #pragma unroll
                 for (int r = 0; r < EPL; r++) {
                     const bool in = key[r] - lo <= span;
-                    cand = in ? key[r] : cand;
+                    cand = (in && key[r] < cand) ? key[r] : cand;     // (the minimum: padding keys may lie inside the bracket as well)
                     nx = (key[r] > hi && key[r] < nx) ? key[r] : nx;
                 }
                 cand = row_reduce<OpMin, W>(cand, red, wave, lane, phase);
@@ -200,7 +197,7 @@ __device__ __forceinline__ typename Ord<T>::K select_kth(const typename Ord<T>::
             return lo;
         }
     }
-    int b = O::top_bit(mn ^ mx);                              // highest bit in which two keys of the row differ
+    int b = (int)(8 * sizeof(K)) - 1 - (sizeof(K) == 8 ? __builtin_clzll((unsigned long long)(mn ^ mx)) : __builtin_clz((unsigned)(mn ^ mx)));   // highest bit in which two keys of the row differ
     K lo = mn & ~((((K)2) << b) - 1u);                        // all keys lie in [lo, lo + 2^(b+1))
     unsigned n_lo = 0, n_hi = n_valid;                        // #keys < lo, #keys < lo + 2^(b+1)
 #pragma unroll 1
@@ -217,17 +214,67 @@ __device__ __forceinline__ typename Ord<T>::K select_kth(const typename Ord<T>::
             for (int r = 0; r < EPL; r++) {
                 const K d = key[r] - lo;
                 const bool in = d < span;
-                cand = in ? key[r] : cand;
+                cand = (in && key[r] < cand) ? key[r] : cand;         // (the minimum: padding keys may lie inside the bracket as well)
                 nx = (!in && key[r] >= lo && key[r] < nx) ? key[r] : nx;
             }
             cand = row_reduce<OpMin, W>(cand, red, wave, lane, phase);
             next = row_reduce<OpMin, W>(nx, red, wave, lane, phase);
+            below = n_lo; upto = n_hi;
             return cand;
         }
     }
     // every bit decided with several equal keys left: lo is repeated n_hi - n_lo times, ranks n_lo .. n_hi - 1
+    below = n_lo; upto = n_hi;
     next = (k + 1u < n_hi) ? lo : above(lo);
     return lo;
+}
+
+// The same order statistics of 64-bit keys (float64 rows) held as two 32-bit words per element: the search runs on the HIGH words alone
+// — sign, exponent and the top 20 mantissa bits: 3e-5 dB apart for a dB value, while a row's neighbours near its median lie ~5e-3 dB apart —
+// at the cost of the 32-bit search (v_cmp_u32 + v_addc per element and pass; a 64-bit compare issues at half that rate), and ends with
+// ONE key holding rank k's high word in all but ~1 % of the rows; the low words then come out of masked 32-bit reductions.  Rows in which
+// several keys share that high word run a second 32-bit search over their low words.  Every result is decided by exact counts.
+// v1 / v2: ranks k and k + 1; mn / mx: the row's extreme keys (mx: undefined when a key's high word is all ones — a NaN payload —, in which
+// case the caller's `mx < POS_INF` test fails and it takes its per-element path).
+template <int EPL, int W, int PAD_FROM>
+__device__ __forceinline__ void select_kth64(const unsigned (&kh)[EPL], const unsigned (&kl)[EPL], unsigned k, unsigned n_valid,
+                                             unsigned long long &v1, unsigned long long &v2, unsigned long long &mn, unsigned long long &mx,
+                                             unsigned long long *red, int wave, int lane, int &phase, float guess)
+{
+    unsigned nexth, mnh, mxh, below, upto;
+    const unsigned vh1 = select_kth<EPL, W, PAD_FROM, unsigned>(kh, k, n_valid, nexth, mnh, mxh, below, upto, red, wave, lane, phase, guess == guess,
+                                                                [&](float d) { return (unsigned)(d2ord((double)(guess + d)) >> 32); });
+    // smallest / largest low word among the keys whose high word is h
+    auto lo_min = [&](unsigned h) {
+        unsigned c = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < EPL; r++) c = (kh[r] == h && kl[r] < c) ? kl[r] : c;
+        return row_reduce<OpMin, W>(c, red, wave, lane, phase);
+    };
+    auto lo_max = [&](unsigned h) {
+        unsigned c = 0u;
+#pragma unroll
+        for (int r = 0; r < EPL; r++) c = (kh[r] == h && kl[r] > c) ? kl[r] : c;
+        return row_reduce<OpMax, W>(c, red, wave, lane, phase);
+    };
+    auto join = [](unsigned h, unsigned l) { return ((unsigned long long)h << 32) | l; };
+    if (upto - below == 1u) {
+        v1 = join(vh1, lo_min(vh1));               // the only key with this high word
+        v2 = join(nexth, lo_min(nexth));           // rank k + 1: the smallest key of the next occupied high word
+    } else {
+        // ranks below .. upto - 1 share the high word: the (k - below)-th smallest low word among them (32-bit search, no guess);
+        // the other elements take the padding key (a low word of all ones is indistinguishable from padding and equal to it)
+        unsigned t[EPL];
+#pragma unroll
+        for (int r = 0; r < EPL; r++) t[r] = kh[r] == vh1 ? kl[r] : 0xffffffffu;
+        unsigned nextl, mnl, mxl, b2, u2;
+        const unsigned l1 = select_kth<EPL, W, 0, unsigned>(t, k - below, upto - below, nextl, mnl, mxl, b2, u2, red, wave, lane, phase, false,
+                                                            [](float) { return 0u; });
+        v1 = join(vh1, l1);
+        v2 = (k + 1u < upto) ? join(vh1, nextl) : join(nexth, lo_min(nexth));
+    }
+    mn = join(mnh, lo_min(mnh));
+    mx = join(mxh, lo_max(mxh));
 }
 
 // LDS row stride (elements) of a thread's EPL consecutive elements: the stride in bytes is = 16 mod 32, so that the 16 lanes
@@ -303,7 +350,8 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
     const int mq = m / CH;                       // whole 16-byte chunks of the output row (m % CH == 0: m = N - 4, N % 4 == 0)
     const int nv = m - t * EPL;                  // this thread's slots r < nv hold elements of the smoothed row
     // EPL consecutive elements + the next thread's first four (the 5-tap window of the last four outputs)
-    K key[EPL];
+    K key[EPL];                                  // (float64 rows: the two words of a key live in kh / kl below; `key` is then unused)
+    unsigned kh[F64 ? EPL : 1], kl[F64 ? EPL : 1];
     float lsum = 0.0f;
     bool nan_here = false;
     {
@@ -326,10 +374,11 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
 #pragma unroll
             for (int k = 0; k < 5; k++) acc += xd[r + k] * 0.2;
             const TR sm = (TR)acc;
-            key[r] = O::enc(sm);
             // padding sorts above everything
             const bool pad = FULL ? (r >= PAD_FROM && t == T - 1) : r >= nv;
-            key[r] = pad ? O::PAD : key[r];
+            const K kk0 = pad ? O::PAD : O::enc(sm);
+            if constexpr (F64) { kh[r] = (unsigned)(kk0 >> 32); kl[r] = (unsigned)kk0; }
+            else key[r] = kk0;
             lsum += pad ? 0.0f : (float)sm;
             if constexpr (F64) nan_here |= !pad && sm != sm;
         }
@@ -338,8 +387,16 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
     const float guess = __uint_as_float(row_reduce<OpFAdd, W>(__float_as_uint(lsum), red, wave, lane, phase)) / (float)m;
     // np.median: the middle order statistic, or the mean of the two middle ones
     const unsigned k1 = (unsigned)((m - 1) >> 1);
-    K mn, mx, v2;
-    const K v1 = select_kth<EPL, W, PAD_FROM, TR>(key, k1, (unsigned)m, v2, mn, mx, red, wave, lane, phase, guess);
+    K mn, mx, v1, v2;
+    if constexpr (F64) {
+        select_kth64<EPL, W, PAD_FROM>(kh, kl, k1, (unsigned)m, v1, v2, mn, mx, red, wave, lane, phase, guess);
+#pragma unroll
+        for (int r = 0; r < EPL; r++) key[r] = ((K)kh[r] << 32) | kl[r];     // (register pairs: no instruction)
+    } else {
+        unsigned below, upto;
+        v1 = select_kth<EPL, W, PAD_FROM, K>(key, k1, (unsigned)m, v2, mn, mx, below, upto, red, wave, lane, phase, guess == guess,
+                                             [&](float d) { return f2ord(guess + d); });
+    }
     const double med = (m & 1) ? (double)O::dec(v1) : 0.5 * ((double)O::dec(v1) + (double)O::dec(v2));
     // fd[fd < thr] = thr (:2282-2283).  float32(max(s, thr)) = max(float32(s), float32(thr)) (rounding is monotonic), and
     // the maximum of two floats is the maximum of their ordered images

@@ -400,6 +400,8 @@ def test_float64_pipeline_register_kernels_equal_plain_kernels_and_numpy():
         rows = rng.standard_normal((nf, n)) * 6.0 - 50.0
         rows[1] = np.round(rows[1])                         # many equal values: ties at the median
         rows[2, :] = -47.25                                 # a constant row
+        rows[7] = -50.0 + rng.standard_normal(n) * 1e-7     # values that differ in the LOW word of their keys only (the two-level select's second search)
+        rows[8, : n // 2] = np.round(rows[8, : n // 2] * 4e4) / 4e4 + rng.integers(0, 3, n // 2) * 1e-12   # many small groups sharing a high word
         if n >= 64:
             rows[3, 5:9] = np.inf
             rows[4, 7] = -np.inf
