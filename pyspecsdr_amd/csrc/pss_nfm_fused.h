@@ -296,6 +296,8 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
 #ifdef PSS_EXP_NOSTORE   // timing experiment only: y_fwd rows all land on the tile's first rows (L2-resident)
         auto emit = [&](double v) { YAT((p - 3) & 15) = v; };
 #else
+        // (non-temporal stores here, so that the 614 MB of y_fwd rows do not push IQ lines out of the L2 between the two chunks that touch them:
+        // FETCH_SIZE 747 -> 693 MB, launch time unchanged at 0.459 / 0.460 ms in a paired A/B — NOTEBOOK R5-07; not kept)
         auto emit = [&](double v) { YAT(p - 3) = v; };
 #endif
         // odd extension head + u[0..63] from the prologue (scipy odd_ext: ext[p] = 2u[0] - u[27-p])
