@@ -262,14 +262,25 @@ __device__ __forceinline__ void select_kth64(const unsigned (&kh)[EPL], const un
         v1 = join(vh1, lo_min(vh1));               // the only key with this high word
         v2 = join(nexth, lo_min(nexth));           // rank k + 1: the smallest key of the next occupied high word
     } else {
-        // ranks below .. upto - 1 share the high word: the (k - below)-th smallest low word among them (32-bit search, no guess);
-        // the other elements take the padding key (a low word of all ones is indistinguishable from padding and equal to it)
-        unsigned t[EPL];
+        // ranks below .. upto - 1 share the high word: the (k - below)-th smallest low word among them (32-bit search, no guess); the other
+        // elements take the padding key.  A group member whose low word is all ones (every value whose float64 image ends in 32 zero bits,
+        // e.g. -50.0) looks like padding to that search: those members are counted apart — they are the group's largest keys — and the search
+        // runs over the rest.
+        unsigned t[EPL], ones = 0;
 #pragma unroll
-        for (int r = 0; r < EPL; r++) t[r] = kh[r] == vh1 ? kl[r] : 0xffffffffu;
-        unsigned nextl, mnl, mxl, b2, u2;
-        const unsigned l1 = select_kth<EPL, W, 0, unsigned>(t, k - below, upto - below, nextl, mnl, mxl, b2, u2, red, wave, lane, phase, false,
-                                                            [](float) { return 0u; });
+        for (int r = 0; r < EPL; r++) {
+            const bool member = kh[r] == vh1;
+            t[r] = member ? kl[r] : 0xffffffffu;
+            ones += (member && kl[r] == 0xffffffffu) ? 1u : 0u;
+        }
+        ones = row_reduce<OpAdd, W>(ones, red, wave, lane, phase);
+        const unsigned j = k - below, c = upto - below - ones;       // rank inside the group; members below the all-ones keys
+        unsigned l1 = 0xffffffffu, nextl = 0xffffffffu;
+        if (j < c) {
+            unsigned mnl, mxl, b2, u2;
+            l1 = select_kth<EPL, W, 0, unsigned>(t, j, c, nextl, mnl, mxl, b2, u2, red, wave, lane, phase, false, [](float) { return 0u; });
+            if (j + 1u >= c) nextl = 0xffffffffu;                    // (rank j + 1 of the group is an all-ones member, or lies outside: decided below)
+        }
         v1 = join(vh1, l1);
         v2 = (k + 1u < upto) ? join(vh1, nextl) : join(nexth, lo_min(nexth));
     }

@@ -2269,7 +2269,8 @@ def test_bench_other_configs_verify(small):
         oc = BC.other_configs(eng, torch.device("cuda", 0), verify=True, small=small)
     finally:
         eng.close()
-    assert set(oc) == {"cfg3", "cfg4", "cfg5_resident", "cfg5_streamed", "wfm_step"}
+    assert set(oc) == {"cfg2_f32_rows", "cfg2_exact_cells", "cfg3", "cfg4", "cfg5_resident", "cfg5_streamed", "wfm_step"}
+    assert oc["cfg2_exact_cells"]["verified"]["cells_differing"] == 0 and oc["cfg2_exact_cells"]["verified"]["rows"] == "float64"
     for name, e in oc.items():
         assert "error" not in e, (name, e.get("error"))
         assert e["verified"]["ok"], (name, e["verified"])
