@@ -582,7 +582,13 @@ __global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_rfft(const float2 *__r
             }
             __syncthreads();                      // the partner reads are done before the next exchange writes
         }
-        asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
+        // the three twiddle bases again, from the (L2-resident) table: held across the partner exchange above they were ten spilled VGPRs
+        {
+            int t4 = tt;
+            asm volatile("" : "+v"(t4));
+            u1 = tw[2 * t4]; u2 = tw[(size_t)(t4 % T2) * 32]; u3 = tw[(size_t)(t4 % R4) * 512];
+            asm volatile("" : "+v"(u1.x), "+v"(u1.y), "+v"(u2.x), "+v"(u2.y), "+v"(u3.x), "+v"(u3.y));
+        }
         // 5. z' = IFFT_M(Z'): sample pair m = t + T q in y[q]
         double m = 0.0;
         pss_xl::xl_core<LOG_R4>(v, ex, u1, u2, u3, tt, [&](int, int j, int k, double2 W) {
