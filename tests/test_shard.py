@@ -204,10 +204,25 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=120)
     assert r.returncode == 2 and "launcher started 1 rank" in r.stderr
-    # WORLD_SIZE / RANK alone (a scheduler wrapper, not torchrun) do not count as a launcher: the script starts its own ranks
+    # WORLD_SIZE = 1 / RANK = 0 alone (what a batch environment leaves behind, not torchrun) do not count as a launcher: the script starts its own ranks
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="1", RANK="0"), timeout=300)
     assert r.returncode == 0 and json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 2, r.stderr[-500:]
+    # ... but a rank of a MULTI-rank job started by a scheduler wrapper (srun / mpirun export WORLD_SIZE and RANK, no LOCAL_RANK) never
+    # launches ranks of its own: another world size than --gpus is an error, the local rank comes from the wrapper's per-node index
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="4", RANK="1", SLURM_LOCALID="1"), timeout=120)
+    assert r.returncode == 2 and "launcher started 4 rank" in r.stderr, r.stderr[-500:]
+    from pyspecsdr_amd import launch
+    keep = dict(os.environ)
+    try:
+        for k in ("LOCAL_RANK", "TORCHELASTIC_RUN_ID"):
+            os.environ.pop(k, None)
+        os.environ.update(WORLD_SIZE="4", RANK="3", SLURM_LOCALID="1")
+        assert launch.under_launcher() and launch.ensure_ranks(4, "bench.py", [], need_gpus=False) == (4, 3, 1)
+    finally:
+        os.environ.clear()
+        os.environ.update(keep)
     if not torch.cuda.is_available():   # the real run refuses to label a 1-GPU (here: 0-GPU) box as 2 GPUs
         for script in ("bench.py", os.path.join("tools", "bench_multi.py")):
             r = subprocess.run([sys.executable, os.path.join(root, script), "--gpus", "2"], capture_output=True, text=True, env=env,
