@@ -228,7 +228,9 @@ int pss_frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_frames,
 /* The reference's own row type.  compute_fft returns float64 rows (signal_processing.py:243-264) and the caller smooths, clamps and
  * draws them in float64 (pyspecsdr.py:2278-2283, :1342-1406); the float32 rows above agree with them to 1e-7 relative, but a display cell
  * can differ where a value sits on a quantisation edge (<= 2e-3 of the cells).  These entry points keep float64 throughout, so the
- * display lines are the reference's cells; plain kernels, not a throughput path.  n_fft: a power of two in [16, 65536].
+ * display lines are the reference's cells.  Since round 5 they run on the register kernels of the float32 calls (float64 dB values stored from
+ * the transform's registers for 256 .. 4096 points, register select on 64-bit keys up to 16 388 points; option "f64_plain" = 1: the plain
+ * round-3 kernels) and pss_frame_pipeline_nfm_f64 is the step bench.py times.  n_fft: a power of two in [16, 65536].
  *   pss_spectrum_db_f64:   d_db float64 [n_frames][n_fft] = 10 log10(|fftshift(fft(iq * hamming))|^2 + 1e-10)
  *   pss_spectrum_post_f64: d_post float64 [n_frames][n_fft - 4]; d_row_lo / d_row_hi [n_frames] (both or neither): finite extremes
  *   pss_frame_pipeline_nfm_f64: pss_frame_pipeline_nfm with float64 rows, extremes (and halo) */
@@ -238,6 +240,11 @@ int pss_spectrum_post_f64(pss_ctx *ctx, const double *d_db, long n_frames, int n
 int pss_frame_pipeline_nfm_f64(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, double *d_db, double *d_post,
                                double *d_row_lo, double *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
                                int8_t *d_colour, int16_t *d_pcm);
+/* pss_frame_pipeline (any demodulation mode, waterfall line or persistence trace) with float64 rows: the cells of either batched accumulator
+ * as the reference draws them from this IQ.  d_post may be NULL (rows of up to 16 388 points are then never materialised). */
+int pss_frame_pipeline_f64(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, double *d_db, double *d_post,
+                           double *d_row_lo, double *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w, int8_t *d_line_a,
+                           int8_t *d_line_b, int16_t *d_pcm);
 
 /* Waterfall / persistence quantisers over a ring of post-processed rows (pyspecsdr.py:1342-1406,
  * :1512-1564).  d_rows float32 [n_rows][len], oldest first (n_rows <= 30 / <= 10).

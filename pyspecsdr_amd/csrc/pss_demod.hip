@@ -4064,6 +4064,19 @@ extern "C" int pss_frame_pipeline_nfm_f64(pss_ctx *ctx, const float *d_iq, long 
                                   d_colour, d_pcm);
 }
 
+// ... in ANY demodulation mode and for either batched display accumulator (pss_frame_pipeline's arguments, float64 rows)
+extern "C" int pss_frame_pipeline_f64(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, double *d_db, double *d_post,
+                                      double *d_row_lo, double *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
+                                      int8_t *d_line_a, int8_t *d_line_b, int16_t *d_pcm)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (mode < PSS_MODE_NFM || mode > PSS_MODE_WFM) return pss_fail(ctx, PSS_E_ARG, "unknown demodulation mode");
+    if (n < 16 || n > 65536 || (n & (n - 1))) return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_f64: n must be a power of two in [16, 65536]");
+    return frame_pipeline<double>(ctx, mode, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w, d_line_a,
+                                  d_line_b, d_pcm);
+}
+
 extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,
                                       float *d_row_lo, float *d_row_hi, int n_halo, int window, int disp_w, int8_t *d_glyph,
                                       int8_t *d_colour, int16_t *d_pcm)

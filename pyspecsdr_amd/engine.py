@@ -292,6 +292,14 @@ class Engine:
         self._dev(self.lib.pss_frame_pipeline_nfm_f64, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
                                                      _ptr(d_row_hi), n_halo, window, disp_w, _ptr(d_glyph), _ptr(d_colour), _ptr(d_pcm))
 
+    def frame_pipeline_f64(self, mode, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, disp_w, d_line_a, d_line_b, d_pcm,
+                           n_halo=0, window=None, display="waterfall", disp_h=36):
+        """frame_pipeline with float64 rows: any mode, waterfall line or persistence trace — the reference's cells."""
+        disp = {"waterfall": 0, "persistence": 1}[display]
+        window = (30, 10)[disp] if window is None else int(window)
+        self._dev(self.lib.pss_frame_pipeline_f64, int(mode), _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
+                  _ptr(d_row_hi), n_halo, window, disp, disp_h, disp_w, _ptr(d_line_a), _ptr(d_line_b), _ptr(d_pcm))
+
     def spectrum_db_f64(self, d_iq, n_frames, n_fft, d_db):
         """compute_fft's float64 rows (n_fft: power of two in 16..65536)."""
         self._dev(self.lib.pss_spectrum_db_f64, _ptr(d_iq), n_frames, n_fft, _ptr(d_db))

@@ -488,6 +488,54 @@ def test_full_size_float64_pipeline_cells_equal_the_oracle_from_iq():
     assert bad == 0, f"{bad} of {2 * g.size} cells differ from the oracle's cells computed from IQ"
 
 
+@pytest.mark.parametrize("display", ["waterfall", "persistence"])
+def test_float64_pipeline_every_mode_and_display_cells_equal_the_oracle_from_iq(display):
+    """pss_frame_pipeline_f64: the cell-exact step for both batched accumulators (draw_waterfall's line, draw_persistence's newest trace,
+    pyspecsdr.py:1342-1406 / :1512-1564) and every demodulation mode — cells against the oracle's own step from the IQ (float64 rows), PCM
+    against the float32-row call of the same mode (same demodulator); a capture cut in two blocks with the extremes halo gives the same lines."""
+    e = G.engine()
+    import bench
+    nf, n, fs, W, H = 3000, 2048, 10e6, 112, 36
+    win = 30 if display == "waterfall" else 10
+    iq = bench.synth_fm_iq(nf, n, fs, torch.device("cuda", 0), seed=4242)
+    torch.cuda.synchronize()
+    taps, sos, zi = e.nfm_filters(fs)
+    o = O.headline_f64(iq.cpu().numpy().view(np.complex64).reshape(nf, n), fs, taps, sos, zi, win, W, O.threads_available(), pcm=True,
+                       display=display, disp_h=H)
+    want = (o["glyph"], o["colour"]) if display == "waterfall" else (o["glyph"],)
+    for mode in (L.MODE_NFM, L.MODE_AM, L.MODE_USB, L.MODE_WFM):
+        n_out = e.demod_out_len(mode, n, fs)
+        d_db = G.empty((nf, n), torch.float64)
+        d_lo, d_hi = G.empty((nf,), torch.float64), G.empty((nf,), torch.float64)
+        d_a, d_b = G.empty((nf, W), torch.int8), torch.zeros((nf, W), dtype=torch.int8, device="cuda")
+        d_pcm = G.empty((nf, n_out, 2), torch.int16)
+        e.frame_pipeline_f64(mode, iq, nf, n, fs, d_db, None, d_lo, d_hi, W, d_a, d_b, d_pcm, display=display, disp_h=H)
+        e.sync()
+        got = (G.host(d_a), G.host(d_b)) if display == "waterfall" else (G.host(d_a),)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), (mode, display, int(np.count_nonzero(g != w)))
+        if mode == L.MODE_NFM:
+            assert np.array_equal(G.host(d_pcm), o["pcm"])
+        d_db32, d_lo32, d_hi32 = G.empty((nf, n), torch.float32), G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
+        d_a2, d_b2, d_pcm2 = G.empty((nf, W), torch.int8), G.empty((nf, W), torch.int8), G.empty((nf, n_out, 2), torch.int16)
+        e.frame_pipeline(mode, iq, nf, n, fs, d_db32, None, d_lo32, d_hi32, W, d_a2, d_b2, d_pcm2, display=display, disp_h=H)
+        e.sync()
+        assert torch.equal(d_pcm, d_pcm2), mode
+    # two blocks, the second continuing the first's history through the halo of row extremes
+    cut = 1777
+    d_db = G.empty((nf, n), torch.float64)
+    lo, hi = G.empty((nf,), torch.float64), G.empty((nf,), torch.float64)
+    a, b = G.empty((nf, W), torch.int8), torch.zeros((nf, W), dtype=torch.int8, device="cuda")
+    pcm = G.empty((nf, e.demod_out_len(L.MODE_NFM, n, fs), 2), torch.int16)
+    e.frame_pipeline_f64(L.MODE_NFM, iq[:cut], cut, n, fs, d_db[:cut], None, lo, hi, W, a[:cut], b[:cut], pcm[:cut], display=display, disp_h=H)
+    e.frame_pipeline_f64(L.MODE_NFM, iq[cut:], nf - cut, n, fs, d_db[cut:], None, lo, hi, W, a[cut:], b[cut:], pcm[cut:], n_halo=cut,
+                         display=display, disp_h=H)
+    e.sync()
+    got = (G.host(a), G.host(b)) if display == "waterfall" else (G.host(a),)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w), display
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f", "g"])
 def test_nfm_vs_golden_bit_exact(golden, tag):
     g = golden["nfm"]
