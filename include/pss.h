@@ -453,6 +453,13 @@ int pss_h_stream_display_nfm(pss_ctx *ctx, const float *h_iq, long n_frames, int
 int pss_h_stream_display_nfm_grids(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames, int mode,
                                    int window, int disp_h, int disp_w, int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm,
                                    float *h_row_lo, float *h_row_hi, int8_t *h_grid_a, int8_t *h_grid_b);
+/* pss_h_stream_display_nfm with compute_fft's own float64 rows from the transform to the cells (n: a power of two in [16, 65536]): the lines —
+ * and, with h_grid_a (+ h_grid_b for the waterfall; then no halo), the full screens after every chunk — are the cells the reference draws
+ * from this capture.  h_halo_lo / _hi, h_db, h_row_lo / _hi: float64.  The capture is PCIe-bound either way (same time as the float32 call). */
+int pss_h_stream_display_nfm_f64(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames, int mode,
+                                 int window, int disp_h, int disp_w, const double *h_halo_lo, const double *h_halo_hi, int n_halo,
+                                 int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm, double *h_db, double *h_row_lo, double *h_row_hi,
+                                 int8_t *h_grid_a, int8_t *h_grid_b);
 
 /* Kernel-only time of the most recent batched call on this context, measured with HIP events on the
  * context's stream (ms); negative if timing is disabled.  pss_enable_timing(ctx, 1) turns it on. */

@@ -117,6 +117,8 @@ _SIGS = {
                                            C.c_int, _p, _p, _p, _p, _p, _p]),
     "pss_h_stream_display_nfm_grids": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p,
                                                  _p, _p, _p, _p, _p]),
+    "pss_h_stream_display_nfm_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p,
+                                               C.c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
     "pss_enable_timing": (C.c_int, [_p, C.c_int]),
     "pss_last_kernel_ms": (C.c_float, [_p]),
     "pss_kernel_times": (C.c_int, [_p, C.c_char_p, C.c_int]),

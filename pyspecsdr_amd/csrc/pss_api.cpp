@@ -627,10 +627,31 @@ extern "C" int pss_h_stream_spectrum_nfm(pss_ctx *ctx, const float *h_iq, long n
 // (copy stream), two buffer sets.  The row extremes of the whole capture stay in one device array, so a frame's history
 // window reaches back across chunk boundaries; h_halo_lo / h_halo_hi (n_halo values each, may be NULL) are the extremes of
 // the rows that precede this capture (previous capture, or the left neighbour's tail when the capture is sharded).
+// TR = float: float32 dB / post-processed rows (the float32 pipeline's cells); TR = double: compute_fft's own float64 rows from the transform to the
+// cells (pss_h_stream_display_nfm_f64: the reference's cells; the capture is PCIe-bound either way).
+namespace {
+inline int sd_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long cnt, int n, double fs, float *d_db, int16_t *d_pcm) { return pss_spectrum_nfm(ctx, d_iq, cnt, n, fs, d_db, d_pcm); }
+inline int sd_spectrum_nfm(pss_ctx *ctx, const float *d_iq, long cnt, int n, double fs, double *d_db, int16_t *d_pcm)
+{
+    int r = pss_demod(ctx, PSS_MODE_NFM, d_iq, cnt, n, fs, d_pcm, nullptr);
+    return r ? r : pss_spectrum_db_f64(ctx, d_iq, cnt, n, d_db);
+}
+inline int sd_post(pss_ctx *ctx, const float *d_db, long cnt, int n, float *d_post, float *lo, float *hi) { return pss_spectrum_post_extremes(ctx, d_db, cnt, n, d_post, lo, hi); }
+inline int sd_post(pss_ctx *ctx, const double *d_db, long cnt, int n, double *d_post, double *lo, double *hi) { return pss_spectrum_post_f64(ctx, d_db, cnt, n, d_post, lo, hi); }
+inline int sd_wf_rows(pss_ctx *c, const float *p, long n, int m, const float *lo, const float *hi, int h, int w, int dw, int8_t *a, int8_t *b) { return pss_waterfall_rows(c, p, n, m, lo, hi, h, w, dw, a, b); }
+inline int sd_wf_rows(pss_ctx *c, const double *p, long n, int m, const double *lo, const double *hi, int h, int w, int dw, int8_t *a, int8_t *b) { return pss_waterfall_rows_f64(c, p, n, m, lo, hi, h, w, dw, a, b); }
+inline int sd_ps_rows(pss_ctx *c, const float *p, long n, int m, const float *lo, const float *hi, int h, int w, int dh, int dw, int8_t *a) { return pss_persistence_rows(c, p, n, m, lo, hi, h, w, dh, dw, a); }
+inline int sd_ps_rows(pss_ctx *c, const double *p, long n, int m, const double *lo, const double *hi, int h, int w, int dh, int dw, int8_t *a) { return pss_persistence_rows_f64(c, p, n, m, lo, hi, h, w, dh, dw, a); }
+inline int sd_wf_cells(pss_ctx *c, const float *r, int nr, int m, int dh, int dw, int8_t *a, int8_t *b) { return pss_waterfall_cells(c, r, nr, m, dh, dw, a, b); }
+inline int sd_wf_cells(pss_ctx *c, const double *r, int nr, int m, int dh, int dw, int8_t *a, int8_t *b) { return pss_waterfall_cells_f64(c, r, nr, m, dh, dw, a, b); }
+inline int sd_ps_cells(pss_ctx *c, const float *r, int nr, int m, int dh, int dw, int8_t *a) { return pss_persistence_cells(c, r, nr, m, dh, dw, a); }
+inline int sd_ps_cells(pss_ctx *c, const double *r, int nr, int m, int dh, int dw, int8_t *a) { return pss_persistence_cells_f64(c, r, nr, m, dh, dw, a); }
+}  // namespace
+template <class TR>
 static int stream_display(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
-                          int mode, int window, int disp_h, int disp_w, const float *h_halo_lo,
-                          const float *h_halo_hi, int n_halo, int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm,
-                          float *h_db, float *h_row_lo, float *h_row_hi, int8_t *h_grid_a, int8_t *h_grid_b)
+                          int mode, int window, int disp_h, int disp_w, const TR *h_halo_lo,
+                          const TR *h_halo_hi, int n_halo, int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm,
+                          TR *h_db, TR *h_row_lo, TR *h_row_hi, int8_t *h_grid_a, int8_t *h_grid_b)
 {
     if (!ctx) return PSS_E_ARG;
     PSS_GUARD(ctx);
@@ -644,8 +665,8 @@ static int stream_display(pss_ctx *ctx, const float *h_iq, long n_frames, int n,
     if (n_frames == 0) return PSS_OK;
     if (chunk_frames > n_frames) chunk_frames = n_frames;
     const int m = n - 4;
-    const size_t iq_b = (size_t)chunk_frames * n * 2 * sizeof(float), db_b = (size_t)chunk_frames * n * sizeof(float),
-                 post_b = (size_t)chunk_frames * m * sizeof(float), pcm_b = (size_t)chunk_frames * n_out * 2 * sizeof(int16_t),
+    const size_t iq_b = (size_t)chunk_frames * n * 2 * sizeof(float), db_b = (size_t)chunk_frames * n * sizeof(TR),
+                 post_b = (size_t)chunk_frames * m * sizeof(TR), pcm_b = (size_t)chunk_frames * n_out * 2 * sizeof(int16_t),
                  line_b = (size_t)chunk_frames * disp_w;
     int rc = stream_res(ctx);
     if (rc) return rc;
@@ -662,12 +683,12 @@ static int stream_display(pss_ctx *ctx, const float *h_iq, long n_frames, int n,
         if (!rc && mode == 0) rc = stream_buf(ctx, 8 + i, line_b, &d_lb[i]);
     }
     if (!rc) rc = stream_buf(ctx, 10, post_b, &d_post);
-    if (!rc) rc = stream_buf(ctx, 11, 2 * n_ext * sizeof(float), &d_ext);
+    if (!rc) rc = stream_buf(ctx, 11, 2 * n_ext * sizeof(TR), &d_ext);
     // full screens (h_grid_a): after the LAST frame of every chunk the whole grid as the reference redraws it — all lines / traces of the
     // history normalised with the history's current extremes (pyspecsdr.py:1342-1406, :1512-1564) — from the last `window` post-processed
     // rows, which are carried from chunk to chunk in a small device buffer
     void *d_ga[2] = {nullptr, nullptr}, *d_gb[2] = {nullptr, nullptr}, *d_tail[2] = {nullptr, nullptr};
-    const size_t grid_b = (size_t)disp_h * disp_w, tail_b = (size_t)window * m * sizeof(float);
+    const size_t grid_b = (size_t)disp_h * disp_w, tail_b = (size_t)window * m * sizeof(TR);
     if (h_grid_a) {
         for (int i = 0; i < 2; i++) {
             if (!rc) rc = stream_buf(ctx, 12 + i, grid_b, &d_ga[i]);
@@ -684,10 +705,10 @@ static int stream_display(pss_ctx *ctx, const float *h_iq, long n_frames, int n,
         rc = pss_hip_check(ctx, (call), #call);                   \
         if (rc) { cleanup(); return rc; }                         \
     } while (0)
-    float *d_lo = reinterpret_cast<float *>(d_ext), *d_hi = d_lo + n_ext;
+    TR *d_lo = reinterpret_cast<TR *>(d_ext), *d_hi = d_lo + n_ext;
     if (n_halo) {
-        STREAM_HIP(hipMemcpyAsync(d_lo, h_halo_lo, sizeof(float) * n_halo, hipMemcpyHostToDevice, ctx->stream));
-        STREAM_HIP(hipMemcpyAsync(d_hi, h_halo_hi, sizeof(float) * n_halo, hipMemcpyHostToDevice, ctx->stream));
+        STREAM_HIP(hipMemcpyAsync(d_lo, h_halo_lo, sizeof(TR) * n_halo, hipMemcpyHostToDevice, ctx->stream));
+        STREAM_HIP(hipMemcpyAsync(d_hi, h_halo_hi, sizeof(TR) * n_halo, hipMemcpyHostToDevice, ctx->stream));
     }
     const long n_chunks = (n_frames + chunk_frames - 1) / chunk_frames;
     for (long k = 0; k < n_chunks; k++) {
@@ -705,32 +726,32 @@ static int stream_display(pss_ctx *ctx, const float *h_iq, long n_frames, int n,
         if (k >= 2) STREAM_HIP(hipStreamWaitEvent(ctx->stream, dn_done[b], 0));
         {
             PssFlagScope keep(ctx->no_small_batch, true);   // chunks of a stream are throughput work: fused large-batch kernels
-            rc = pss_spectrum_nfm(ctx, (const float *)d_iq[b], cnt, n, fs, (float *)d_db[b], (int16_t *)d_pcm[b]);
+            rc = sd_spectrum_nfm(ctx, (const float *)d_iq[b], cnt, n, fs, (TR *)d_db[b], (int16_t *)d_pcm[b]);
         }
         // rows f0 .. f0+cnt-1 of the capture sit at positions n_halo + f0 .. of the extremes arrays; their history reaches
         // back over everything before them (previous chunks and the caller's halo)
-        if (!rc) rc = pss_spectrum_post_extremes(ctx, (const float *)d_db[b], cnt, n, (float *)d_post, d_lo + n_halo + f0, d_hi + n_halo + f0);
+        if (!rc) rc = sd_post(ctx, (const TR *)d_db[b], cnt, n, (TR *)d_post, d_lo + n_halo + f0, d_hi + n_halo + f0);
         const long before = (long)n_halo + f0;
         const int halo_k = (int)(before < (long)(window - 1) ? before : (long)(window - 1));
-        const float *lo_k = d_lo + n_halo + f0 - halo_k, *hi_k = d_hi + n_halo + f0 - halo_k;
+        const TR *lo_k = d_lo + n_halo + f0 - halo_k, *hi_k = d_hi + n_halo + f0 - halo_k;
         if (!rc) {
-            if (mode == 0) rc = pss_waterfall_rows(ctx, (const float *)d_post, cnt, m, lo_k, hi_k, halo_k, window, disp_w, (int8_t *)d_la[b], (int8_t *)d_lb[b]);
-            else rc = pss_persistence_rows(ctx, (const float *)d_post, cnt, m, lo_k, hi_k, halo_k, window, disp_h, disp_w, (int8_t *)d_la[b]);
+            if (mode == 0) rc = sd_wf_rows(ctx, (const TR *)d_post, cnt, m, lo_k, hi_k, halo_k, window, disp_w, (int8_t *)d_la[b], (int8_t *)d_lb[b]);
+            else rc = sd_ps_rows(ctx, (const TR *)d_post, cnt, m, lo_k, hi_k, halo_k, window, disp_h, disp_w, (int8_t *)d_la[b]);
         }
         if (rc) { cleanup(); return rc; }
         if (h_grid_a) {
             // history after this chunk = the last `window` rows of (history before it ++ the chunk's rows)
             const long take = cnt < window ? cnt : window, keep = (tail_rows + take > window) ? window - take : tail_rows;
-            float *dst = (float *)d_tail[tail_cur ^ 1];
+            TR *dst = (TR *)d_tail[tail_cur ^ 1];
             if (keep > 0)
-                STREAM_HIP(hipMemcpyAsync(dst, (const float *)d_tail[tail_cur] + (size_t)(tail_rows - keep) * m, (size_t)keep * m * sizeof(float),
+                STREAM_HIP(hipMemcpyAsync(dst, (const TR *)d_tail[tail_cur] + (size_t)(tail_rows - keep) * m, (size_t)keep * m * sizeof(TR),
                                           hipMemcpyDeviceToDevice, ctx->stream));
-            STREAM_HIP(hipMemcpyAsync(dst + (size_t)keep * m, (const float *)d_post + (size_t)(cnt - take) * m, (size_t)take * m * sizeof(float),
+            STREAM_HIP(hipMemcpyAsync(dst + (size_t)keep * m, (const TR *)d_post + (size_t)(cnt - take) * m, (size_t)take * m * sizeof(TR),
                                       hipMemcpyDeviceToDevice, ctx->stream));
             tail_cur ^= 1;
             tail_rows = keep + take;
-            if (mode == 0) rc = pss_waterfall_cells(ctx, dst, (int)tail_rows, m, disp_h, disp_w, (int8_t *)d_ga[b], (int8_t *)d_gb[b]);
-            else rc = pss_persistence_cells(ctx, dst, (int)tail_rows, m, disp_h, disp_w, (int8_t *)d_ga[b]);
+            if (mode == 0) rc = sd_wf_cells(ctx, dst, (int)tail_rows, m, disp_h, disp_w, (int8_t *)d_ga[b], (int8_t *)d_gb[b]);
+            else rc = sd_ps_cells(ctx, dst, (int)tail_rows, m, disp_h, disp_w, (int8_t *)d_ga[b]);
             if (rc) { cleanup(); return rc; }
         }
         STREAM_HIP(hipEventRecord(cmp_done[b], ctx->stream));
@@ -739,15 +760,15 @@ static int stream_display(pss_ctx *ctx, const float *h_iq, long n_frames, int n,
             STREAM_HIP(hipMemcpyAsync(h_grid_a + (size_t)k * grid_b, d_ga[b], grid_b, hipMemcpyDeviceToHost, s_dn));
             if (mode == 0) STREAM_HIP(hipMemcpyAsync(h_grid_b + (size_t)k * grid_b, d_gb[b], grid_b, hipMemcpyDeviceToHost, s_dn));
         }
-        if (h_db) STREAM_HIP(hipMemcpyAsync(h_db + (size_t)f0 * n, d_db[b], (size_t)cnt * n * sizeof(float), hipMemcpyDeviceToHost, s_dn));
+        if (h_db) STREAM_HIP(hipMemcpyAsync(h_db + (size_t)f0 * n, d_db[b], (size_t)cnt * n * sizeof(TR), hipMemcpyDeviceToHost, s_dn));
         STREAM_HIP(hipMemcpyAsync(h_line_a + (size_t)f0 * disp_w, d_la[b], (size_t)cnt * disp_w, hipMemcpyDeviceToHost, s_dn));
         if (mode == 0) STREAM_HIP(hipMemcpyAsync(h_line_b + (size_t)f0 * disp_w, d_lb[b], (size_t)cnt * disp_w, hipMemcpyDeviceToHost, s_dn));
         STREAM_HIP(hipMemcpyAsync(h_pcm + (size_t)f0 * n_out * 2, d_pcm[b], (size_t)cnt * n_out * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, s_dn));
         STREAM_HIP(hipEventRecord(dn_done[b], s_dn));
     }
     STREAM_HIP(hipStreamSynchronize(ctx->stream));
-    if (h_row_lo) STREAM_HIP(hipMemcpy(h_row_lo, d_lo + n_halo, sizeof(float) * n_frames, hipMemcpyDeviceToHost));
-    if (h_row_hi) STREAM_HIP(hipMemcpy(h_row_hi, d_hi + n_halo, sizeof(float) * n_frames, hipMemcpyDeviceToHost));
+    if (h_row_lo) STREAM_HIP(hipMemcpy(h_row_lo, d_lo + n_halo, sizeof(TR) * n_frames, hipMemcpyDeviceToHost));
+    if (h_row_hi) STREAM_HIP(hipMemcpy(h_row_hi, d_hi + n_halo, sizeof(TR) * n_frames, hipMemcpyDeviceToHost));
 #undef STREAM_HIP
     cleanup();
     return PSS_OK;
@@ -758,8 +779,20 @@ extern "C" int pss_h_stream_display_nfm(pss_ctx *ctx, const float *h_iq, long n_
                                         const float *h_halo_hi, int n_halo, int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm,
                                         float *h_db, float *h_row_lo, float *h_row_hi)
 {
-    return stream_display(ctx, h_iq, n_frames, n, fs, chunk_frames, mode, window, disp_h, disp_w, h_halo_lo, h_halo_hi, n_halo, h_line_a,
-                          h_line_b, h_pcm, h_db, h_row_lo, h_row_hi, nullptr, nullptr);
+    return stream_display<float>(ctx, h_iq, n_frames, n, fs, chunk_frames, mode, window, disp_h, disp_w, h_halo_lo, h_halo_hi, n_halo, h_line_a,
+                                 h_line_b, h_pcm, h_db, h_row_lo, h_row_hi, nullptr, nullptr);
+}
+
+// ... with compute_fft's own float64 rows from the transform to the cells: the lines (and grids) the reference draws from this capture
+extern "C" int pss_h_stream_display_nfm_f64(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
+                                            int mode, int window, int disp_h, int disp_w, const double *h_halo_lo,
+                                            const double *h_halo_hi, int n_halo, int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm,
+                                            double *h_db, double *h_row_lo, double *h_row_hi, int8_t *h_grid_a, int8_t *h_grid_b)
+{
+    if (ctx && (n < 16 || n > 65536 || (n & (n - 1)))) return pss_fail(ctx, PSS_E_ARG, "pss_h_stream_display_nfm_f64: n must be a power of two in [16, 65536]");
+    if (ctx && h_grid_a && n_halo > 0) return pss_fail(ctx, PSS_E_ARG, "pss_h_stream_display_nfm_f64: grids need a fresh history (no halo)");
+    return stream_display<double>(ctx, h_iq, n_frames, n, fs, chunk_frames, mode, window, disp_h, disp_w, h_halo_lo, h_halo_hi, n_halo, h_line_a,
+                                  h_line_b, h_pcm, h_db, h_row_lo, h_row_hi, h_grid_a, h_grid_b);
 }
 
 extern "C" int pss_h_stream_display_nfm_grids(pss_ctx *ctx, const float *h_iq, long n_frames, int n, double fs, long chunk_frames,
@@ -767,6 +800,6 @@ extern "C" int pss_h_stream_display_nfm_grids(pss_ctx *ctx, const float *h_iq, l
                                               int16_t *h_pcm, float *h_row_lo, float *h_row_hi, int8_t *h_grid_a, int8_t *h_grid_b)
 {
     if (ctx && !h_grid_a) return pss_fail(ctx, PSS_E_ARG, "pss_h_stream_display_nfm_grids: h_grid_a is null");
-    return stream_display(ctx, h_iq, n_frames, n, fs, chunk_frames, mode, window, disp_h, disp_w, nullptr, nullptr, 0, h_line_a, h_line_b,
-                          h_pcm, nullptr, h_row_lo, h_row_hi, h_grid_a, h_grid_b);
+    return stream_display<float>(ctx, h_iq, n_frames, n, fs, chunk_frames, mode, window, disp_h, disp_w, nullptr, nullptr, 0, h_line_a, h_line_b,
+                                 h_pcm, nullptr, h_row_lo, h_row_hi, h_grid_a, h_grid_b);
 }

@@ -421,6 +421,41 @@ class Engine:
                                                    _ptr(hl), _ptr(hh), n_halo, _ptr(la), _ptr(lb), _ptr(pcm), _ptr(db), _ptr(lo), _ptr(hi)))
         return {"lines": (la, lb) if m == 0 else (la,), "pcm": pcm, "row_lo": lo, "row_hi": hi, "db": db}
 
+    def stream_display_nfm_f64(self, h_iq, fs, chunk_frames, mode="waterfall", window=None, disp_h=36, disp_w=112, halo=None, want_db=False,
+                               grids=False, out=None):
+        """stream_display_nfm with compute_fft's own float64 rows from the transform to the cells: the lines (and, grids=True, the full screen
+        after every chunk) the REFERENCE draws from this capture.  halo / row_lo / row_hi / db: float64.  PCIe-bound like the float32 call."""
+        assert h_iq.dtype == np.complex64 and h_iq.ndim == 2 and h_iq.flags.c_contiguous
+        nf, n = h_iq.shape
+        m = 0 if mode == "waterfall" else 1
+        window = (30 if m == 0 else 10) if window is None else int(window)
+        n_out = self.demod_out_len(L.MODE_NFM, n, fs)
+        n_chunks = (nf + int(chunk_frames) - 1) // int(chunk_frames) if nf else 0
+        if out is not None:      # a previous call's dict / arrays from pinned_empty(): downloads into pinned memory stay asynchronous
+            la, lb = (out["lines"] + (None,))[:2]
+            pcm, db, lo, hi = out["pcm"], out.get("db"), out["row_lo"], out["row_hi"]
+            assert la.shape == (nf, disp_w) and pcm.shape == (nf, n_out, 2) and lo.dtype == np.float64 and len(lo) == nf and len(hi) == nf
+        else:
+            la = np.empty((nf, disp_w), np.int8)
+            lb = np.empty((nf, disp_w), np.int8) if m == 0 else None
+            pcm = np.empty((nf, n_out, 2), np.int16)
+            db = np.empty((nf, n), np.float64) if want_db else None
+            lo, hi = np.empty(nf, np.float64), np.empty(nf, np.float64)
+        ga = np.empty((n_chunks, disp_h, disp_w), np.int8) if grids else None
+        gb = np.empty((n_chunks, disp_h, disp_w), np.int8) if grids and m == 0 else None
+        hl = hh = None
+        n_halo = 0
+        if halo is not None and len(halo[0]):
+            hl, hh = np.ascontiguousarray(halo[0], np.float64), np.ascontiguousarray(halo[1], np.float64)
+            n_halo = len(hl)
+        self._ck(self.lib.pss_h_stream_display_nfm_f64(self.h, _ptr(h_iq), nf, n, float(fs), int(chunk_frames), m, window, disp_h, disp_w,
+                                                       _ptr(hl), _ptr(hh), n_halo, _ptr(la), _ptr(lb), _ptr(pcm), _ptr(db), _ptr(lo), _ptr(hi),
+                                                       _ptr(ga), _ptr(gb)))
+        out = {"lines": (la, lb) if m == 0 else (la,), "pcm": pcm, "row_lo": lo, "row_hi": hi, "db": db}
+        if grids:
+            out["grids"] = (ga, gb) if m == 0 else (ga,)
+        return out
+
     def stream_display_nfm_grids(self, h_iq, fs, chunk_frames, mode="waterfall", window=None, disp_h=36, disp_w=112):
         """stream_display_nfm for a capture with a fresh history, plus the FULL display grid after the last frame of every chunk (what the
         reference's screen shows: every line / trace of the history redrawn with the current extremes).  Returns the stream_display_nfm dict

@@ -536,6 +536,42 @@ def test_float64_pipeline_every_mode_and_display_cells_equal_the_oracle_from_iq(
         assert np.array_equal(g, w), display
 
 
+@pytest.mark.parametrize("mode", ["waterfall", "persistence"])
+def test_streamed_capture_float64_rows_draws_the_oracle_cells(mode):
+    """pss_h_stream_display_nfm_f64 (BASELINE configs[4] with the reference's own row type): a host capture streamed in chunks — lines, PCM and
+    row extremes against the oracle's own step from the IQ, the full screen after every chunk against the oracle's grid of the last `window`
+    rows, and a capture cut in two with the float64 halo."""
+    e = G.engine()
+    import bench
+    nf, n, fs, W, H = 1100, 2048, 10e6, 112, 36
+    window = 30 if mode == "waterfall" else 10
+    iq = bench.synth_fm_iq(nf, n, fs, torch.device("cuda", 0), seed=99).cpu().numpy().view(np.complex64).reshape(nf, n)
+    taps, sos, zi = e.nfm_filters(fs)
+    o = O.headline_f64(iq, fs, taps, sos, zi, window, W, O.threads_available(), display=mode, disp_h=H)
+    want = (o["glyph"], o["colour"]) if mode == "waterfall" else (o["glyph"],)
+    for chunk in (256, 1100, 97):
+        got = e.stream_display_nfm_f64(iq, fs, chunk, mode=mode, disp_h=H, disp_w=W, grids=True, want_db=(chunk == 256))
+        for g, w in zip(got["lines"], want):
+            assert np.array_equal(g, w), (mode, chunk, int(np.count_nonzero(g != w)))
+        assert np.array_equal(got["pcm"], o["pcm"])
+        assert np.allclose(got["row_lo"], o["lo"], rtol=0, atol=1e-10) and np.allclose(got["row_hi"], o["hi"], rtol=0, atol=1e-10)
+        n_chunks = (nf + chunk - 1) // chunk
+        for k in range(n_chunks):
+            last = min(nf, (k + 1) * chunk) - 1
+            rows = o["post"][max(0, last + 1 - window):last + 1]
+            if mode == "waterfall":
+                wg, wc = O.waterfall_cells(rows, H, W)
+                assert np.array_equal(got["grids"][0][k], wg) and np.array_equal(got["grids"][1][k], wc), (chunk, k)
+            else:
+                assert np.array_equal(got["grids"][0][k], O.persistence_cells(rows, H, W)), (chunk, k)
+    cut = 613
+    a = e.stream_display_nfm_f64(np.ascontiguousarray(iq[:cut]), fs, 200, mode=mode, disp_h=H, disp_w=W)
+    b = e.stream_display_nfm_f64(np.ascontiguousarray(iq[cut:]), fs, 200, mode=mode, disp_h=H, disp_w=W,
+                                 halo=(a["row_lo"][cut - (window - 1):], a["row_hi"][cut - (window - 1):]))
+    for i, w in enumerate(want):
+        assert np.array_equal(np.concatenate([a["lines"][i], b["lines"][i]]), w)
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f", "g"])
 def test_nfm_vs_golden_bit_exact(golden, tag):
     g = golden["nfm"]

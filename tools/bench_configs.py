@@ -366,6 +366,17 @@ def cfg5_streamed(eng, dev, verify=True, launch_only=False, nf=48828, chunk=4096
         for _ in range(3):
             one()
         ms = (time.perf_counter() - t0) / 3 * 1e3
+    # the same capture with float64 rows from the transform to the cells (pss_h_stream_display_nfm_f64: the reference's cells)
+    ms64, out64 = None, None
+    if not launch_only:
+        out64 = {"lines": (eng.pinned_empty((nf, DISP_W), np.int8),), "pcm": eng.pinned_empty((nf, n_out, 2), np.int16),
+                 "row_lo": eng.pinned_empty((nf,), np.float64), "row_hi": eng.pinned_empty((nf,), np.float64)}
+        one64 = lambda: eng.stream_display_nfm_f64(h_iq, fs, chunk, mode="persistence", window=window, disp_h=DISP_H, disp_w=DISP_W, out=out64)
+        one64()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            one64()
+        ms64 = (time.perf_counter() - t0) / 3 * 1e3
     # the link: a plain pinned -> device copy of the same bytes on torch's stream
     link = None
     if not launch_only:
@@ -396,14 +407,22 @@ def cfg5_streamed(eng, dev, verify=True, launch_only=False, nf=48828, chunk=4096
         ks = sorted({0, chunk - 1, chunk, nf - 1})
         ver["pcm_equal_oracle"] = bool(all(np.array_equal(outp["pcm"][k], O.pcm16_stereo(O.demod_nfm(h_iq[k], fs, taps, sos, zi))) for k in ks))
         ver["frames"] = ks
-        ver["ok"] = bool(ver["lines_equal_resident"] and ver["pcm_equal_resident"] and ver["extremes_equal_resident"] and ver["pcm_equal_oracle"])
-    for a in (h_iq, outp["lines"][0], outp["pcm"], outp["row_lo"], outp["row_hi"]):
+        # the float64-row capture: persistence traces against the oracle's own step from the IQ on the first chunk (its history starts at frame 0)
+        blk = min(nf, 512)
+        o = O.headline_f64(h_iq[:blk], fs, taps, sos, zi, window, DISP_W, O.threads_available(), pcm=True, display="persistence", disp_h=DISP_H)
+        ver["f64_cells_checked"] = int(blk * DISP_W)
+        ver["f64_cells_differing"] = int(np.count_nonzero(out64["lines"][0][:blk] != o["glyph"]))
+        ver["f64_pcm_equal_float32_capture"] = bool(np.array_equal(out64["pcm"], outp["pcm"]))
+        ver["ok"] = bool(ver["lines_equal_resident"] and ver["pcm_equal_resident"] and ver["extremes_equal_resident"] and ver["pcm_equal_oracle"]
+                         and ver["f64_cells_differing"] == 0 and ver["f64_pcm_equal_float32_capture"])
+    for a in (h_iq, outp["lines"][0], outp["pcm"], outp["row_lo"], outp["row_hi"]) + ((out64["lines"][0], out64["pcm"], out64["row_lo"], out64["row_hi"]) if out64 else ()):
         eng.pinned_free(a)
     algo = nf * (n * 8 + n * 4 + n_out * 4 + DISP_W)
     e = _entry("cfg5_streamed", f"10 s @ 10 MS/s capture ({nf} frames x {n}-pt) in pinned host memory -> chunks of {chunk} frames, hipMemcpyAsync "
                f"double-buffered (three streams, two buffer sets): persistence trace + NFM int16 per frame back in host memory "
                f"(BASELINE.json configs[4])", ms, {}, algo, nf * n, ver)
     if ms:
+        e["ms_float64_rows"] = None if ms64 is None else round(ms64, 4)   # pss_h_stream_display_nfm_f64: the cell-exact capture
         e["h2d_GBs"] = nf * n * 8 / (ms * 1e-3) / 1e9
         e["link_h2d_GBs"] = link
         e["frac_of_link"] = e["h2d_GBs"] / link if link else None
