@@ -117,18 +117,21 @@ class ShardedScanner:
 
 
 def sharded_stream_display(engine, h_iq_local, fs, chunk_frames, mode="waterfall", window=None, disp_h=36, disp_w=112, group=None,
-                           gather_dst=None, out=None):
+                           gather_dst=None, out=None, rows="f32"):
     """Every rank streams its block of a capture (h_iq_local: complex64 [count_r][n], pinned) and ends up with the display
     lines + PCM of its frames, exactly as one rank streaming the whole capture would produce them.
 
     out: a result dict of Engine.stream_display_nfm to write into (arrays from Engine.pinned_empty keep the downloads asynchronous).
+    rows: "f32" (Engine.stream_display_nfm) or "f64" (Engine.stream_display_nfm_f64: compute_fft's own float64 rows from the transform to the
+    cells — the reference's cells; the halo of row extremes is float64 then: 16 bytes per row).
     gather_dst=None: results stay on the ranks (each writes its part of the FIFO / screen log); an int gathers
     (lines..., pcm) to that rank over the process group (one packed message per rank) and returns them in frame order
     there, None elsewhere.  Returns (lines tuple, pcm) of this rank's block otherwise.
     """
     world, rank = _world_rank(group)
     window = (30 if mode == "waterfall" else 10) if window is None else int(window)
-    res = engine.stream_display_nfm(h_iq_local, fs, chunk_frames, mode=mode, window=window, disp_h=disp_h, disp_w=disp_w, out=out)
+    stream = engine.stream_display_nfm_f64 if rows == "f64" else engine.stream_display_nfm
+    res = stream(h_iq_local, fs, chunk_frames, mode=mode, window=window, disp_h=disp_h, disp_w=disp_w, out=out)
     lines, pcm = res["lines"], res["pcm"]
     if world > 1:
         # extremes of the rows preceding this block: 8 bytes per row from the left neighbour(s), all messages posted at once
@@ -138,8 +141,8 @@ def sharded_stream_display(engine, h_iq_local, fs, chunk_frames, mode="waterfall
         fix = min(window - 1, h_iq_local.shape[0])
         if len(halo) and fix:
             # only the first window-1 frames of the block see the halo; redo them with it (their history is complete now)
-            r2 = engine.stream_display_nfm(np.ascontiguousarray(h_iq_local[:fix]), fs, fix, mode=mode, window=window, disp_h=disp_h,
-                                           disp_w=disp_w, halo=(halo[:, 0], halo[:, 1]))
+            r2 = stream(np.ascontiguousarray(h_iq_local[:fix]), fs, fix, mode=mode, window=window, disp_h=disp_h,
+                        disp_w=disp_w, halo=(halo[:, 0], halo[:, 1]))
             for dst_a, src_a in zip(lines, r2["lines"]):
                 dst_a[:fix] = src_a
     if gather_dst is None or world == 1:

@@ -135,7 +135,7 @@ def _stream_iq(n_frames, n):
     return iq
 
 
-def _stream_worker(rank, world, port, backend, n_frames, n, fs, mode, q):
+def _stream_worker(rank, world, port, backend, n_frames, n, fs, mode, q, rows="f32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -153,7 +153,7 @@ def _stream_worker(rank, world, port, backend, n_frames, n, fs, mode, q):
         start, count = shard_range(n_frames, rank, world)
         h = e.pinned_empty((count, n), np.complex64)       # every rank its own pinned buffer / PCIe link
         h[:] = _stream_iq(n_frames, n)[start:start + count]
-        res = sharded_stream_display(e, h, fs, 64, mode=mode, gather_dst=0)
+        res = sharded_stream_display(e, h, fs, 64, mode=mode, gather_dst=0, rows=rows)
         if rank == 0:
             q.put(res)
         e.pinned_free(h)
@@ -163,11 +163,11 @@ def _stream_worker(rank, world, port, backend, n_frames, n, fs, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "waterfall"), (3, "persistence")])
-def test_sharded_stream_equals_single_rank(world, mode):
+@pytest.mark.parametrize("world,mode,rows", [(2, "waterfall", "f32"), (3, "persistence", "f32"), (2, "persistence", "f64"), (3, "waterfall", "f64")])
+def test_sharded_stream_equals_single_rank(world, mode, rows):
     """BASELINE configs[4] on N ranks: each rank streams its block of the capture from its own pinned memory; display
     lines (history continued across the block boundaries through the halo of row extremes) and PCM gathered to rank 0 must
-    equal one rank streaming the whole capture."""
+    equal one rank streaming the whole capture — with float32 rows and with the cell-exact float64 rows."""
     from pyspecsdr_amd.engine import Engine
     ngpu = torch.cuda.device_count()
     backend = "nccl" if ngpu >= world else "gloo"
@@ -175,13 +175,13 @@ def test_sharded_stream_equals_single_rank(world, mode):
     e = Engine(0)
     h = e.pinned_empty((n_frames, n), np.complex64)
     h[:] = _stream_iq(n_frames, n)
-    want = e.stream_display_nfm(h, fs, 64, mode=mode)
+    want = (e.stream_display_nfm_f64 if rows == "f64" else e.stream_display_nfm)(h, fs, 64, mode=mode)
     e.pinned_free(h)
     e.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, backend, n_frames, n, fs, mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, backend, n_frames, n, fs, mode, q, rows)) for r in range(world)]
     for p in procs:
         p.start()
     lines, pcm = q.get(timeout=300)
