@@ -33,7 +33,8 @@ typedef enum {
     PSS_E_HIP = -2,      /* HIP runtime error / no device */
     PSS_E_PADLEN = -3,   /* NFM: n-1 <= 27 -> the reference raises ValueError (scipy sosfiltfilt padlen)   */
     PSS_E_CUTOFF = -4,   /* NFM/SSB: cutoff >= Nyquist -> the reference raises ValueError (scipy firwin)  */
-    PSS_E_NOMEM = -5
+    PSS_E_NOMEM = -5,
+    PSS_E_COMM = -6      /* multi-GPU exchange: librccl not found, no communicator, or an RCCL error (text in pss_last_error) */
 } pss_status;
 
 typedef enum { PSS_MODE_NFM = 0, PSS_MODE_AM = 1, PSS_MODE_USB = 2, PSS_MODE_LSB = 3, PSS_MODE_WFM = 4 } pss_mode;
@@ -460,6 +461,33 @@ int pss_h_stream_display_nfm_f64(pss_ctx *ctx, const float *h_iq, long n_frames,
                                  int window, int disp_h, int disp_w, const double *h_halo_lo, const double *h_halo_hi, int n_halo,
                                  int8_t *h_line_a, int8_t *h_line_b, int16_t *h_pcm, double *h_db, double *h_row_lo, double *h_row_hi,
                                  int8_t *h_grid_a, int8_t *h_grid_b);
+
+/* ---- Multi-GPU: the path's exchange steps (one process per GPU, RCCL over xGMI) ----------------------------------------------------------
+ * The path shards by contiguous blocks of independent frames / scanner slices (the sweep of pyspecsdr.py:2514-2590; every read buffer of
+ * the loop :2236-2283 is processed on its own): every rank runs the single-GPU entry points above on its block, with NO collective in
+ * the data path.  What crosses ranks is the gather of a rank's results to one rank (or all), and — for the display accumulators — the row
+ * extremes of the frames just before a rank's block.  A Python host does both over torch.distributed (pyspecsdr_amd/shard.py); these
+ * entry points are the same two steps for a host without it, queued on the context's stream.  librccl.so.1 is opened at the first call
+ * ($PSS_RCCL_LIB, the loader's path, /opt/rocm/lib; a copy the process already holds is shared) — the library does not link against it,
+ * and a lone rank (n_ranks = 1, id = NULL) never touches it.  Errors: PSS_E_COMM. */
+#define PSS_COMM_ID_BYTES 128
+/* contiguous blocks whose sizes differ by at most one: items [*start, *start + *count) belong to `rank` */
+int pss_shard_range(long n_items, int rank, int n_ranks, long *start, long *count);
+/* rank 0: a rendezvous id (ncclGetUniqueId) to hand to every other rank by whatever the host has — a file, a socket, its launcher */
+int pss_comm_id(void *id /* PSS_COMM_ID_BYTES */);
+/* every rank, after pss_create on ITS device: join the communicator (ncclCommInitRank; blocks until all n_ranks have called) */
+int pss_comm_init(pss_ctx *ctx, const void *id, int rank, int n_ranks);
+int pss_comm_free(pss_ctx *ctx);                              /* also done by pss_destroy */
+int pss_comm_size(pss_ctx *ctx, int *rank, int *n_ranks);     /* (0, 1) without a communicator */
+/* ONE collective for everything a rank produced in a sharded pass: every rank contributes `bytes` bytes (its packed result buffer, sized
+ * for the largest block); d_all on the receiving rank(s): n_ranks x bytes, rank r's buffer at r * bytes.  dst < 0: all-gather; dst >= 0:
+ * gather to that rank as grouped point-to-point messages (each peer's own xGMI link to the root; d_all is ignored elsewhere). */
+int pss_gather_packed(pss_ctx *ctx, const void *d_local, size_t bytes, void *d_all, int dst);
+/* The rows preceding this rank's block, up to `halo` of them (waterfall: the (lo, hi) extremes of 30 post-processed rows, persistence: 10
+ * — pyspecsdr.py:130-132, :151-154; what pss_waterfall_rows' d_halo_lo / _hi take).  d_rows: this rank's counts[rank] rows of row_bytes
+ * each, in frame order; counts: every rank's block size (the same n_ranks values on every rank, e.g. from pss_shard_range); d_halo:
+ * room for `halo` rows; *n_halo = rows received = min(halo, rows before this block), in global order. */
+int pss_halo_from_left(pss_ctx *ctx, const void *d_rows, const long *counts, size_t row_bytes, long halo, void *d_halo, long *n_halo);
 
 /* Kernel-only time of the most recent batched call on this context, measured with HIP events on the
  * context's stream (ms); negative if timing is disabled.  pss_enable_timing(ctx, 1) turns it on. */

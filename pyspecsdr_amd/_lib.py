@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # PSS_LIBRARY: load another build of the same ABI (kernel experiments: tools/build_variant.py)
 LIB_PATH = os.environ.get("PSS_LIBRARY") or os.path.join(HERE, "libpss.so")
 
-PSS_OK, PSS_E_ARG, PSS_E_HIP, PSS_E_PADLEN, PSS_E_CUTOFF, PSS_E_NOMEM = 0, -1, -2, -3, -4, -5
+PSS_OK, PSS_E_ARG, PSS_E_HIP, PSS_E_PADLEN, PSS_E_CUTOFF, PSS_E_NOMEM, PSS_E_COMM = 0, -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
 MODE_NFM, MODE_AM, MODE_USB, MODE_LSB, MODE_WFM = 0, 1, 2, 3, 4
 NP_ARCTAN2, NP_LOG10, NP_ABS = 0, 1, 2          # pss_np_f32 operations
 
@@ -119,6 +120,13 @@ _SIGS = {
                                                  _p, _p, _p, _p, _p]),
     "pss_h_stream_display_nfm_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p,
                                                C.c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "pss_shard_range": (C.c_int, [C.c_long, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "pss_comm_id": (C.c_int, [_p]),
+    "pss_comm_init": (C.c_int, [_p, _p, C.c_int, C.c_int]),
+    "pss_comm_free": (C.c_int, [_p]),
+    "pss_comm_size": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pss_gather_packed": (C.c_int, [_p, _p, C.c_size_t, _p, C.c_int]),
+    "pss_halo_from_left": (C.c_int, [_p, _p, C.POINTER(C.c_long), C.c_size_t, C.c_long, _p, C.POINTER(C.c_long)]),
     "pss_enable_timing": (C.c_int, [_p, C.c_int]),
     "pss_last_kernel_ms": (C.c_float, [_p]),
     "pss_kernel_times": (C.c_int, [_p, C.c_char_p, C.c_int]),

@@ -27,6 +27,7 @@ UNITS = [
     ("pss_api.cpp", ["-x", "hip"]),
     ("pss_design.cpp", ["-x", "hip", "-ffp-contract=off"]),
     ("pss_decode.cpp", ["-x", "hip", "-ffp-contract=off"]),   # host only: the decoders' per-message halves
+    ("pss_comm.cpp", ["-x", "hip"]),                          # host only: the exchange steps over RCCL (dlopen, no link dependency)
 ]
 
 
@@ -64,7 +65,7 @@ def build(force=False, verbose=False):
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
     if force or _stale(OUT, objs):
-        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--strip-all", "-o", OUT] + objs
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--strip-all", "-o", OUT] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

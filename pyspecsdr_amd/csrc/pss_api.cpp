@@ -133,6 +133,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     if (!ctx) return;
     PssDevGuard guard(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) pss_comm_free(ctx);
     for (auto &kv : ctx->tw) hipFree(kv.second);
     for (auto &kv : ctx->tw_pf) hipFree(kv.second);
     for (auto &kv : ctx->win) hipFree(kv.second);

@@ -110,6 +110,8 @@ struct pss_ctx {
     int fft_split = -1;  // option "fft_split": component-wise LDS exchanges in k_spectrum_r16; -1 = automatic (N = 256 only)
     bool no_small_batch = false;  // option "small_batch" = 0: never take the systolic small-batch NFM path (A/B testing)
     bool no_fused = false;  // PSS_NO_FUSED=1: use the three-kernel NFM path (A/B and fallback testing)
+    void *comm = nullptr;          // pss_comm_init: the RCCL communicator (ncclComm_t) of this context's rank; collectives run on the context's stream
+    int comm_rank = 0, comm_n = 1;
     bool timing = false;
     std::string tfilter;  // pss_timing_filter: only launches of this kernel get events (and no per-call events); empty = all
     bool kskip = false;

@@ -108,6 +108,40 @@ class Engine:
     def set_stream(self, stream):
         self._ck(self.lib.pss_set_stream(self.h, _ptr(getattr(stream, "cuda_stream", stream))))
 
+    # ---- the exchange steps behind the C ABI (RCCL; include/pss.h "Multi-GPU") — what shard.py does over torch.distributed, for hosts without it
+    def comm_id(self):
+        """Rank 0: the 128-byte rendezvous id to hand to every other rank."""
+        buf = C.create_string_buffer(L.COMM_ID_BYTES)
+        r = self.lib.pss_comm_id(buf)
+        if r != 0:
+            raise PssError(r, "pss_comm_id: librccl.so.1 not available (set PSS_RCCL_LIB)")
+        return buf.raw
+
+    def comm_init(self, comm_id, rank, n_ranks):
+        """Join the communicator (blocks until all n_ranks have called).  comm_id None with n_ranks 1: a lone rank, no RCCL."""
+        if comm_id is not None and len(comm_id) != L.COMM_ID_BYTES:
+            raise ValueError("comm_id: the 128 bytes of Engine.comm_id()")
+        self._ck(self.lib.pss_comm_init(self.h, comm_id, int(rank), int(n_ranks)))
+
+    def comm_free(self):
+        self._ck(self.lib.pss_comm_free(self.h))
+
+    def comm_size(self):
+        rank, n = C.c_int(), C.c_int()
+        self._ck(self.lib.pss_comm_size(self.h, C.byref(rank), C.byref(n)))
+        return rank.value, n.value
+
+    def gather_packed(self, d_local, nbytes, d_all, dst=0):
+        """Every rank's `nbytes` bytes at d_local -> d_all (n_ranks x nbytes, rank order) on rank dst, or on all ranks with dst None."""
+        self._dev(self.lib.pss_gather_packed, _ptr(d_local), int(nbytes), _ptr(d_all), -1 if dst is None else int(dst))
+
+    def halo_from_left(self, d_rows, counts, row_bytes, halo, d_halo):
+        """The rows that precede this rank's block (at most `halo`), from its left neighbours; returns how many arrived."""
+        arr = (C.c_long * len(counts))(*[int(c) for c in counts])
+        got = C.c_long()
+        self._dev(self.lib.pss_halo_from_left, _ptr(d_rows), arr, int(row_bytes), int(halo), _ptr(d_halo), C.byref(got))
+        return got.value
+
     def stream_handle(self):
         """The hipStream_t this engine queues its work on, as an integer (e.g. for torch.cuda.ExternalStream)."""
         return int(self.lib.pss_get_stream(self.h) or 0)

@@ -40,7 +40,19 @@ def shard_counts(n_items, world):
     return [shard_range(n_items, r, world)[1] for r in range(world)]
 
 
+class EngineGroup:
+    """A `group` whose exchange steps run BEHIND THE C ABI (pss_gather_packed / pss_halo_from_left: libpss.so opens librccl itself) instead
+    of over torch.distributed — the route a host without torch takes (include/pss.h "Multi-GPU", examples/pss_gather_example.c).
+    engine: an Engine that has joined a communicator (Engine.comm_init)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.rank, self.world = engine.comm_size()
+
+
 def _world_rank(group=None):
+    if isinstance(group, EngineGroup):
+        return group.world, group.rank
     if not dist.is_initialized():
         return 1, 0
     return dist.get_world_size(group), dist.get_rank(group)
@@ -89,7 +101,13 @@ def gather_packed(buf, n_items, dst=0, group=None, out=None):
     counts = shard_counts(n_items, world)
     if world == 1:
         return {n: buf.view(n)[:counts[0]] for n, _, _ in buf.fields}
-    if dst is None:
+    if isinstance(group, EngineGroup):
+        if (dst is None or rank == dst) and out is None:
+            out = torch.empty((world, buf.nbytes), dtype=torch.uint8, device=buf.raw.device)
+        group.engine.gather_packed(buf.raw, buf.nbytes, out, dst)
+        if dst is not None and rank != dst:
+            return None
+    elif dst is None:
         if out is None:
             out = torch.empty((world, buf.nbytes), dtype=torch.uint8, device=buf.raw.device)
         dist.all_gather_into_tensor(out.view(-1), buf.raw, group=group)
@@ -147,6 +165,16 @@ def halo_from_left(local, halo, group=None):
         return empty
     cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     allc = torch.empty(world, dtype=torch.int64, device=local.device)
+    if isinstance(group, EngineGroup):
+        group.engine.gather_packed(cnt, 8, allc, None)
+        counts = [int(c) for c in allc.tolist()]
+        have = min(int(halo), sum(counts[:rank]))
+        got = torch.empty((have,) + tail, dtype=local.dtype, device=local.device)
+        rows = local.contiguous()
+        row_bytes = rows.element_size() * int(np.prod(tail, dtype=np.int64))
+        n_got = group.engine.halo_from_left(rows, counts, row_bytes, int(halo), got)
+        assert n_got == have, (n_got, have)
+        return got
     dist.all_gather_into_tensor(allc, cnt, group=group)
     counts = [int(c) for c in allc.tolist()]
     starts = [sum(counts[:r]) for r in range(world)]

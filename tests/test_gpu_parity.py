@@ -1689,6 +1689,106 @@ def test_c_abi_from_plain_c(tmp_path):
     assert [int(v) for v in out[1].split()[1:]] == [int(v) for v in pcm[:, 0]]
 
 
+def _sweep_slices(start, count, n):
+    """examples/pss_sweep_ranks.c's synthetic slices [start, start + count) as complex64 rows."""
+    i = np.arange(n)
+    rows = np.empty((count, n), np.complex64)
+    for k in range(count):
+        g = start + k
+        f1, f2, a1 = (16 + (29 * g) % (n - 32)) / n, ((7 * g) % n) / n, 0.1 + 0.01 * (g % 50)
+        rows[k] = ((a1 * np.cos(2 * np.pi * f1 * i) + 0.003 * np.cos(2 * np.pi * f2 * i)).astype(np.float32)
+                   + 1j * (a1 * np.sin(2 * np.pi * f1 * i) + 0.003 * np.sin(2 * np.pi * f2 * i)).astype(np.float32))
+    return rows
+
+
+def _build_sweep_example(tmp_path):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pss_sweep_ranks")
+    subprocess.run(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
+                    os.path.join(root, "examples", "pss_sweep_ranks.c"), "-L" + os.path.join(root, "pyspecsdr_amd"), "-lpss",
+                    "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-o", exe], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, "pyspecsdr_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    return exe, env
+
+
+def _check_sweep_output(lines, n_slices, n):
+    e = G.engine()
+    d_iq = G.dev(_sweep_slices(0, n_slices, n))
+    pk, bw, cnt = G.empty((n_slices,), torch.float32), G.empty((n_slices,), torch.float64), G.empty((n_slices,), torch.int32)
+    e.scan(d_iq, n_slices, n, 2.4e6, None, pk, bw, cnt)
+    e.sync()
+    pk, bw, cnt = G.host(pk), G.host(bw), G.host(cnt)
+    got = [ln.split() for ln in lines if ln.startswith("slice ")]
+    assert [int(g[1]) for g in got] == list(range(n_slices)), "every slice once, in sweep order"
+    for g in got:
+        k = int(g[1])
+        # (libm's and NumPy's cos / sin may round a sample differently: the peaks agree to 1e-4 dB, the counts exactly)
+        assert abs(float(g[3]) - float(pk[k])) < 1e-4 and int(g[5]) == int(cnt[k]) and abs(float(g[7]) - float(bw[k])) < 1e-3
+    return pk
+
+
+def test_exchange_steps_behind_the_c_abi_one_rank():
+    """pss_comm_* / pss_gather_packed / pss_halo_from_left through a REAL RCCL communicator of one rank (what one GPU can run), and the
+    lone-rank mode that never opens librccl; EngineGroup routes shard.py's helpers through them."""
+    from pyspecsdr_amd.engine import Engine
+    from pyspecsdr_amd.shard import EngineGroup, ShardBuffer, gather_packed, halo_from_left
+    e = Engine(0)
+    try:
+        assert e.comm_size() == (0, 1)
+        src = torch.arange(5000, dtype=torch.int32, device="cuda").view(torch.uint8)
+        for real in (False, True):
+            e.comm_init(e.comm_id() if real else None, 0, 1)
+            assert e.comm_size() == (0, 1)
+            for dst in (0, None):
+                out = torch.zeros_like(src)
+                e.gather_packed(src, src.numel(), out, dst)
+                e.sync()
+                assert torch.equal(out, src)
+            halo = torch.empty((4,), dtype=torch.float32, device="cuda")
+            assert e.halo_from_left(src, [1250], 16, 4, halo) == 0
+            with pytest.raises(Exception):
+                e.gather_packed(src, src.numel(), out, 1)             # dst outside the communicator
+            if real:
+                with pytest.raises(Exception):
+                    e.comm_init(e.comm_id(), 0, 1)                    # already joined
+            grp = EngineGroup(e)
+            assert (grp.rank, grp.world) == (0, 1)
+            buf = ShardBuffer([("x", (3,), torch.float32)], 7, "cuda")
+            buf.view("x")[:] = torch.arange(21, dtype=torch.float32, device="cuda").view(7, 3)
+            assert torch.equal(gather_packed(buf, 7, dst=0, group=grp)["x"], buf.view("x"))
+            assert halo_from_left(buf.view("x"), 3, group=grp).shape == (0, 3)
+            e.comm_free()
+    finally:
+        e.close()
+
+
+def test_sharded_sweep_from_plain_c(tmp_path):
+    """examples/pss_sweep_ranks.c (no Python, no torch in the process): a one-rank RCCL communicator and the lone-rank mode give the
+    single-GPU sweep; with two GPUs visible, two processes do (each on its own device, the gather and the halo over RCCL)."""
+    import subprocess
+    exe, env = _build_sweep_example(tmp_path)
+    n_slices, n = 37, 4096
+    outs = []
+    for idf in ("-", str(tmp_path / "id1")):
+        r = subprocess.run([exe, "0", "1", idf, str(n_slices), str(n)], check=True, capture_output=True, text=True, env=env, timeout=300)
+        lines = [ln for ln in r.stdout.split("\n") if ln.startswith(("rank ", "slice "))]     # (RCCL prints a version banner of its own)
+        assert lines[0].split()[:6] == ["rank", "0", "block", "0", str(n_slices), "halo"] and len(lines[0].split()) == 6
+        _check_sweep_output(lines, n_slices, n)
+        outs.append(lines)
+    assert outs[0] == outs[1]
+    if torch.cuda.device_count() < 2:
+        return
+    idf = str(tmp_path / "id2")
+    procs = [subprocess.Popen([exe, str(r), "2", idf, str(n_slices), str(n)], stdout=subprocess.PIPE, text=True, env=env) for r in (0, 1)]
+    texts = [[ln for ln in p.communicate(timeout=600)[0].split("\n") if ln.startswith(("rank ", "slice "))] for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    pk = _check_sweep_output(texts[0], n_slices, n)
+    head1 = texts[1][0].split()
+    assert head1[:5] == ["rank", "1", "block", "19", "18"]
+    assert np.allclose([float(v) for v in head1[6:]], pk[16:19], atol=1e-4)       # the three peaks before rank 1's block
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()
@@ -2359,5 +2459,5 @@ def test_bench_other_configs_verify(small):
         assert "error" not in e, (name, e.get("error"))
         assert e["verified"]["ok"], (name, e["verified"])
         assert e["ms"] > 0 and e["algo_bytes"] > 0 and 0 < e["frac"] < 1, name
-    assert oc["cfg3"]["contexts"] == 2 and oc["cfg3"]["ms_one_stream"] > 0
+    assert oc["cfg3"]["contexts"] == 1 and oc["cfg3"]["ms_two_contexts"] > 0
     assert oc["cfg5_streamed"]["h2d_GBs"] > 1 and oc["cfg5_streamed"]["bound"] == "pcie"

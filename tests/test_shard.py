@@ -14,6 +14,21 @@ from pyspecsdr_amd.shard import (ShardBuffer, gather_packed, gather_rows, halo_f
 import oracle_lib as O
 
 
+def test_c_abi_shard_range_is_the_python_one():
+    """pss_shard_range (the partitioning a host without Python uses, include/pss.h "Multi-GPU") == shard.shard_range."""
+    import ctypes as C
+    from pyspecsdr_amd import _lib as L
+    lib = L.load()
+    for n in (0, 1, 7, 8, 37, 8192, 65536, 1000003):
+        for world in (1, 2, 3, 8, 13):
+            for rank in range(world):
+                st, cnt = C.c_long(-1), C.c_long(-1)
+                assert lib.pss_shard_range(n, rank, world, C.byref(st), C.byref(cnt)) == 0
+                assert (st.value, cnt.value) == shard_range(n, rank, world)
+    assert lib.pss_shard_range(8, 2, 2, None, None) == L.PSS_E_ARG and lib.pss_shard_range(-1, 0, 1, None, None) == L.PSS_E_ARG
+    assert lib.pss_shard_range(8, 0, 0, None, None) == L.PSS_E_ARG
+
+
 def test_shard_range_partitions_exactly():
     for n in (0, 1, 7, 8, 8192, 48828, 65536):
         for w in (1, 2, 3, 4, 8):

@@ -162,11 +162,12 @@ def _host_iq(iq, k):
 # ---- configs ---------------------------------------------------------------------------------------------------------------------------
 def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=True):
     """BASELINE configs[2]: 16 384-point spectra x 8192 frames, AM + SSB (Hilbert) demodulation, AGC on (power per frame + stepper).
-    two_contexts=True (the default): the AM demodulator runs on a SECOND context (pss_create: its own stream) beside the power / AGC /
-    SSB / spectrum calls of the first — the two demodulators work on different buffers, nothing orders them.  With round 3's AM kernel
-    (50 KB of LDS per workgroup, three per CU) this gained nothing (3.75-3.88 against 3.83 ms: the SSB workgroups hold 140 of a CU's
-    160 KB, so the two kernels partitioned the CUs); round 4's k_am_grp needs 27 KB and is paced by one wavefront per SIMD, so the
-    SSB / spectrum workgroups run beside it: 3.36-3.38 ms against 3.66-3.74 in order on one stream (`ms_one_stream` in the entry)."""
+    `ms` = the calls in order on ONE context / stream (what a host gets without doing anything).  two_contexts=True also times the AM
+    demodulator on a SECOND context (pss_create: its own stream) beside the power / AGC / SSB / spectrum calls of the first — the two
+    demodulators work on different buffers, nothing orders them — and records it as `ms_two_contexts`.  History: round 3's AM kernel
+    (50 KB of LDS per workgroup) gained nothing from that, round 4's k_am_grp did (3.36-3.38 against 3.66-3.74 ms in order); since
+    round 5 (power + AM mean in one IQ pass, the SSB kernel's shorter prologue) the in-order schedule is the faster one again
+    (3.14-3.24 against 3.33-3.39 ms: NOTEBOOK R5-04)."""
     from pyspecsdr_amd.engine import Engine
     n, fs = 16384, 2.4e6
     iq_am = synth("am", nf, n, fs, dev, 20260928 + 3)
@@ -177,7 +178,7 @@ def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=True):
     pw = torch.empty((nf,), dtype=torch.float32, device=dev)
     gi = torch.empty((nf,), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    eng2 = Engine(eng.device, order="none") if two_contexts else eng
+    eng2 = eng
 
     class Both:       # what timed() needs of an engine: fence both contexts, merge their per-kernel event times
         def sync(self):
@@ -205,11 +206,10 @@ def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=True):
             eng.order_after(eng2.stream_handle())         # the power values come from the other context's stream
         eng.agc_steps(pw, nf, 20, 29, gi)                 # the gain stepper (:898-919), interval gate off
     ms, kt = timed(Both(), one, 10, launch_only)
-    ms_one = None
-    if eng2 is not eng and not launch_only:      # the same calls in order on one stream, for the record
-        keep, eng2 = eng2, eng
-        ms_one, _ = timed(Both(), one, 10, False)
-        eng2 = keep
+    ms_two = None
+    if two_contexts and not launch_only:         # the AM leg on a second context, for the record
+        eng2 = Engine(eng.device, order="none")
+        ms_two, _ = timed(Both(), one, 10, False)
     ver = None
     if verify and not launch_only:
         O = _oracle()
@@ -239,9 +239,9 @@ def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=True):
     algo = nf * (2 * n * 8 + n * 4 + 2 * n * 4 + 4 + 4)
     e = _entry("cfg3", f"{nf} frames x {n}-pt @2.4 MS/s: measure_signal_power + AGC steps, demodulate AM, demodulate USB (hilbert round "
                f"trip executed) -> int16 stereo, compute_fft dB rows (BASELINE.json configs[2])", ms, kt, algo, nf * n, ver)
-    e["contexts"] = 2 if two_contexts else 1
-    if ms_one is not None:
-        e["ms_one_stream"] = round(ms_one, 4)
+    e["contexts"] = 1
+    if ms_two is not None:
+        e["ms_two_contexts"] = round(ms_two, 4)
     if kt:
         e["kernel_ms_sum"] = round(sum(v["ms"] * v["launches"] for v in kt.values()), 4)
     return e
