@@ -2459,5 +2459,5 @@ def test_bench_other_configs_verify(small):
         assert "error" not in e, (name, e.get("error"))
         assert e["verified"]["ok"], (name, e["verified"])
         assert e["ms"] > 0 and e["algo_bytes"] > 0 and 0 < e["frac"] < 1, name
-    assert oc["cfg3"]["contexts"] == 1 and oc["cfg3"]["ms_two_contexts"] > 0
+    assert oc["cfg3"]["contexts"] == 2 and oc["cfg3"]["ms_one_stream"] > 0
     assert oc["cfg5_streamed"]["h2d_GBs"] > 1 and oc["cfg5_streamed"]["bound"] == "pcie"

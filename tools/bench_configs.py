@@ -80,16 +80,22 @@ def _fence(eng):
 
 
 def timed(eng, fn, reps, launch_only=False):
-    """-> (ms per pass with events off, {kernel: mean ms per launch, launches per pass})."""
+    """-> (ms per pass with events off, {kernel: mean ms per launch, launches per pass}).  ms = the median of three loops of `reps` passes
+    behind two warm-up passes: the first loop of a process runs ~6 % slow whatever it times (measured on cfg 3 by swapping the order of
+    its two schedules), which a single loop behind a single warm-up pass attributed to whichever schedule came first."""
     fn(); _fence(eng)
     if launch_only:       # under rocprofv3: a few plain passes, nothing else
         fn(); _fence(eng)
         return None, {}
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    _fence(eng)
-    ms = (time.perf_counter() - t0) / reps * 1e3
+    fn(); _fence(eng)
+    loops = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        _fence(eng)
+        loops.append((time.perf_counter() - t0) / reps * 1e3)
+    ms = sorted(loops)[1]
     eng.enable_timing(True)
     eng.kernel_times()
     kreps = max(2, min(reps, 5))
@@ -162,12 +168,12 @@ def _host_iq(iq, k):
 # ---- configs ---------------------------------------------------------------------------------------------------------------------------
 def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=True):
     """BASELINE configs[2]: 16 384-point spectra x 8192 frames, AM + SSB (Hilbert) demodulation, AGC on (power per frame + stepper).
-    `ms` = the calls in order on ONE context / stream (what a host gets without doing anything).  two_contexts=True also times the AM
-    demodulator on a SECOND context (pss_create: its own stream) beside the power / AGC / SSB / spectrum calls of the first — the two
-    demodulators work on different buffers, nothing orders them — and records it as `ms_two_contexts`.  History: round 3's AM kernel
-    (50 KB of LDS per workgroup) gained nothing from that, round 4's k_am_grp did (3.36-3.38 against 3.66-3.74 ms in order); since
-    round 5 (power + AM mean in one IQ pass, the SSB kernel's shorter prologue) the in-order schedule is the faster one again
-    (3.14-3.24 against 3.33-3.39 ms: NOTEBOOK R5-04)."""
+    two_contexts=True (the default, `ms`): the AM demodulator runs on a SECOND context (pss_create: its own stream) beside the power / AGC /
+    SSB / spectrum calls of the first — the two demodulators work on different buffers, nothing orders them; the same calls in order on
+    ONE context are timed too (`ms_one_stream`).  History: round 3's AM kernel (50 KB of LDS per workgroup) gained nothing from the second
+    context, round 4's k_am_grp did (3.36-3.38 against 3.66-3.74 ms in order); round 5 (power + AM mean in one IQ pass): 3.05-3.14 against
+    3.20 ms.  (A first round-5 reading, "the contexts no longer help", came from timing each schedule with ONE loop behind one warm-up pass:
+    whichever loop ran first in the process read ~6 % slow — timed() now takes the median of three loops; NOTEBOOK R5-10.)"""
     from pyspecsdr_amd.engine import Engine
     n, fs = 16384, 2.4e6
     iq_am = synth("am", nf, n, fs, dev, 20260928 + 3)
@@ -178,7 +184,7 @@ def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=True):
     pw = torch.empty((nf,), dtype=torch.float32, device=dev)
     gi = torch.empty((nf,), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    eng2 = eng
+    eng2 = Engine(eng.device, order="none") if two_contexts else eng
 
     class Both:       # what timed() needs of an engine: fence both contexts, merge their per-kernel event times
         def sync(self):
@@ -206,10 +212,11 @@ def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=True):
             eng.order_after(eng2.stream_handle())         # the power values come from the other context's stream
         eng.agc_steps(pw, nf, 20, 29, gi)                 # the gain stepper (:898-919), interval gate off
     ms, kt = timed(Both(), one, 10, launch_only)
-    ms_two = None
-    if two_contexts and not launch_only:         # the AM leg on a second context, for the record
-        eng2 = Engine(eng.device, order="none")
-        ms_two, _ = timed(Both(), one, 10, False)
+    ms_one = None
+    if eng2 is not eng and not launch_only:      # the same calls in order on one stream, for the record
+        keep, eng2 = eng2, eng
+        ms_one, _ = timed(Both(), one, 10, False)
+        eng2 = keep
     ver = None
     if verify and not launch_only:
         O = _oracle()
@@ -239,9 +246,9 @@ def cfg3(eng, dev, verify=True, launch_only=False, nf=8192, two_contexts=True):
     algo = nf * (2 * n * 8 + n * 4 + 2 * n * 4 + 4 + 4)
     e = _entry("cfg3", f"{nf} frames x {n}-pt @2.4 MS/s: measure_signal_power + AGC steps, demodulate AM, demodulate USB (hilbert round "
                f"trip executed) -> int16 stereo, compute_fft dB rows (BASELINE.json configs[2])", ms, kt, algo, nf * n, ver)
-    e["contexts"] = 1
-    if ms_two is not None:
-        e["ms_two_contexts"] = round(ms_two, 4)
+    e["contexts"] = 2 if two_contexts else 1
+    if ms_one is not None:
+        e["ms_one_stream"] = round(ms_one, 4)
     if kt:
         e["kernel_ms_sum"] = round(sum(v["ms"] * v["launches"] for v in kt.values()), 4)
     return e
