@@ -1351,41 +1351,77 @@ __global__ __launch_bounds__(256) void k_iqcorr(const float2 *__restrict__ iq, i
     }
     const float fn = (float)n;
     const int T = blockDim.x;
+    // WT (one wavefront per frame, 1024 samples): the NEXT frame's 16 samples per lane are requested before this frame's reductions and
+    // staged behind them — the wavefront no longer sits through a global round trip per frame
+    float2 nxt[WT ? 16 : 1];
+    if constexpr (WT) {
+        if ((long)blockIdx.x < n_frames) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) nxt[j] = iq[(size_t)blockIdx.x * n + threadIdx.x + 64 * j];
+        }
+    }
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const float2 *xg = iq + (size_t)f * n;
-        if (STAGED) {
+        if constexpr (WT) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) xs[threadIdx.x + 64 * j] = nxt[j];
+            if (f + gridDim.x < n_frames) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) nxt[j] = iq[(size_t)(f + gridDim.x) * n + threadIdx.x + 64 * j];
+            }
+            __syncthreads();
+        } else if (STAGED) {
             for (int i = threadIdx.x; i < n; i += T) xs[i] = xg[i];
             __syncthreads();
         }
         auto X = [&](int i) { return STAGED ? xs[i] : xg[i]; };
+        // The eight reductions in DEPENDENCY order rather than source order: (:48 mean, :52 q power) need only the samples, (:49 second mean,
+        // :60 alpha, :61 sin phi) need those two, (:49 variance, :80 mean of the corrected frame) the next three.  Each reduction is the same
+        // tree as before (same bits); with one wavefront per frame (WT) they are straight-line code and the independent ones of a group
+        // overlap their 16-deep dependent addition chains instead of running them back to back.
         // :48 centered = samples - mean(samples)
         float2 s = frame_csum<WT>(cp, cpart, cval, X);
+        // :52 q_amplitude
+        const float qsum = frame_rsum<WT>(rp, rpart, rval, [&](int i) { float q = X(i).y; return __fmul_rn(q, q); });
         const float mr = __fdiv_rn(s.x, fn), mi = __fdiv_rn(s.y, fn);
+        const float qa = sqrtf(__fmul_rn(2.0f, __fdiv_rn(qsum, fn)));
+        const float scl = __fdiv_rn(1.0f, qa);  // :55 complex64 / float32 scalar multiplies by the reciprocal
         // :49 input_power = var(centered): mean again, re^2 + im^2 as three separately rounded float32 operations, mean
         s = frame_csum<WT>(cp, cpart, cval, [&](int i) { float2 v = X(i); return make_float2(__fsub_rn(v.x, mr), __fsub_rn(v.y, mi)); });
-        const float m2r = __fdiv_rn(s.x, fn), m2i = __fdiv_rn(s.y, fn);
-        const float input_power = __fdiv_rn(frame_rsum<WT>(rp, rpart, rval, [&](int i) {
-            float2 v = X(i);
-            const float dr = __fsub_rn(__fsub_rn(v.x, mr), m2r), di = __fsub_rn(__fsub_rn(v.y, mi), m2i);
-            return __fadd_rn(__fmul_rn(dr, dr), __fmul_rn(di, di));  // np.var fast path: squares, then add (no fma)
-        }), fn);
-        // :52 q_amplitude
-        const float qa = sqrtf(__fmul_rn(2.0f, __fdiv_rn(frame_rsum<WT>(rp, rpart, rval, [&](int i) { float q = X(i).y; return __fmul_rn(q, q); }), fn)));
-        const float scl = __fdiv_rn(1.0f, qa);  // :55 complex64 / float32 scalar multiplies by the reciprocal
         // :60-61 alpha, sin(phi)
-        const float alpha = sqrtf(__fmul_rn(2.0f, __fdiv_rn(frame_rsum<WT>(rp, rpart, rval, [&](int i) {
-            const float is = __fmul_rn(X(i).x, scl);
-            return __fmul_rn(is, is);
-        }), fn)));
-        const float sinphi = __fmul_rn(__fdiv_rn(2.0f, alpha), __fdiv_rn(frame_rsum<WT>(rp, rpart, rval, [&](int i) {
-            float2 v = X(i);
-            return __fmul_rn(__fmul_rn(v.x, scl), __fmul_rn(v.y, scl));
-        }), fn));
+        float asum, psum;
+        if constexpr (WT) {     // both trees in one walk over the same elements (wg_rsum2: component-wise, numpy's bits for both)
+            const float2 ap = frame_rsum2<true>(rp, cpart, cval, [&](int i) {
+                float2 v = X(i);
+                const float is = __fmul_rn(v.x, scl);
+                return make_float2(__fmul_rn(is, is), __fmul_rn(is, __fmul_rn(v.y, scl)));
+            });
+            asum = ap.x;
+            psum = ap.y;
+        } else {
+            asum = frame_rsum<WT>(rp, rpart, rval, [&](int i) {
+                const float is = __fmul_rn(X(i).x, scl);
+                return __fmul_rn(is, is);
+            });
+            psum = frame_rsum<WT>(rp, rpart, rval, [&](int i) {
+                float2 v = X(i);
+                return __fmul_rn(__fmul_rn(v.x, scl), __fmul_rn(v.y, scl));
+            });
+        }
+        const float m2r = __fdiv_rn(s.x, fn), m2i = __fdiv_rn(s.y, fn);
+        const float alpha = sqrtf(__fmul_rn(2.0f, __fdiv_rn(asum, fn)));
+        const float sinphi = __fmul_rn(__fdiv_rn(2.0f, alpha), __fdiv_rn(psum, fn));
         const float cosphi = sqrtf(__fsub_rn(1.0f, __fmul_rn(sinphi, sinphi)));  // :64
         const float ia = __fdiv_rn(1.0f, alpha), qa2 = __fdiv_rn(-sinphi, alpha), sc = __fdiv_rn(1.0f, cosphi);
         auto corrected = [&](int i) { return iqc_corrected(X(i), scl, ia, qa2, sc); };
+        const float ipsum = frame_rsum<WT>(rp, rpart, rval, [&](int i) {
+            float2 v = X(i);
+            const float dr = __fsub_rn(__fsub_rn(v.x, mr), m2r), di = __fsub_rn(__fsub_rn(v.y, mi), m2i);
+            return __fadd_rn(__fmul_rn(dr, dr), __fmul_rn(di, di));  // np.var fast path: squares, then add (no fma)
+        });
         // :80 var(corrected), rescale to the input power
         s = frame_csum<WT>(cp, cpart, cval, corrected);
+        const float input_power = __fdiv_rn(ipsum, fn);
         const float m3r = __fdiv_rn(s.x, fn), m3i = __fdiv_rn(s.y, fn);
         const float v2 = __fdiv_rn(frame_rsum<WT>(rp, rpart, rval, [&](int i) {
             float2 c = corrected(i);
@@ -3502,15 +3538,8 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             pss_kernel_end(ctx);
             auto launch_bwd = [=]() -> int {
                 pss_kernel_begin(ctx, "k_nfm_bwd");
-                hipLaunchKernelGGL((fused::k_nfm_bwd<true, true>), dim3((unsigned)(2 * tiles)), dim3(TILE), 0, PSS_STREAM(ctx), Yf, Af,
-                                   n, q, n_out, 2 * tiles * TILE, c, nullptr, MXf);
-                pss_kernel_end(ctx);
-                size_t tot = (size_t)n_frames * n_out;
-                size_t g2 = (tot + TPB - 1) / TPB;
-                if (g2 > 16384) g2 = 16384;
-                pss_kernel_begin(ctx, "k_wfm_finalize");
-                hipLaunchKernelGGL(k_wfm_finalize, dim3((unsigned)g2), dim3(TPB), 0, PSS_STREAM(ctx), Af, MXf, n_out, n_frames, 1, d_pcm,
-                                   d_audio);
+                hipLaunchKernelGGL((fused::k_nfm_bwd<true, true>), dim3((unsigned)tiles), dim3(2 * TILE), 0, PSS_STREAM(ctx), Yf, Af,
+                                   n, q, n_out, n_frames, c, d_pcm, d_audio);      // both channels of a tile: joint normalisation + stereo PCM inside
                 pss_kernel_end(ctx);
                 return pss_hip_check(ctx, hipGetLastError(), "wfm fused launch (backward)");
             };
@@ -4005,14 +4034,6 @@ static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n
     int r2;
     ctx->pending_bwd = nullptr;
     const bool overlap = ctx->pipe_overlap > 0;
-    if (overlap) {
-        // overlap schedule: the display chain needs nothing of the demodulator, so the side stream is released BEFORE the forward kernel
-        // is queued — and the forward kernel is capped at pipe_overlap workgroups per CU (each walks several tiles), so that the chain's
-        // workgroups find registers and LDS on every CU from the first microsecond instead of waiting for forward workgroups to retire
-        int rf = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
-        if (!rf) rf = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
-        if (rf) { pss_time_end(ctx); return rf; }
-    }
     {
         PssFlagScope defer(ctx->defer_bwd, true);
         PssScoped<int> cap(ctx->fwd_cap, overlap ? ctx->pipe_overlap : 0);

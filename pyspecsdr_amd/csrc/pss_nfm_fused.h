@@ -480,14 +480,19 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
 
 // Backward pass of sosfiltfilt over y_fwd (read in reverse from Y[tile][p][lane]), decimation [::q], peak
 // normalisation, stereo int16 / float64 audio.  One wavefront per tile, lane = frame.
+// WFM: a workgroup is the TWO rows of a tile of frames — wavefront 0 the left channel (row tile 2 t), wavefront 1 the right one (2 t + 1) —
+// so that demodulate_wfm's joint peak normalisation of the two decimated channels (:157-163: audio / max(max|l|, max|r|), column_stack, no
+// 0.95) happens here: the two peaks meet in LDS and each wavefront writes its channel of the stereo frames (until R5-11 a separate
+// k_wfm_finalize launch read both peaks and both rows back: 0.047 ms of the 1.55 ms WFM step).
 template <bool B121, bool WFM = false>
-__global__ __launch_bounds__(TILE) void k_nfm_bwd(const double *__restrict__ Y, double *__restrict__ A, int n, int q,
+__global__ __launch_bounds__(WFM ? 2 * TILE : TILE) void k_nfm_bwd(const double *__restrict__ Y, double *__restrict__ A, int n, int q,
                                                   int n_out, long n_frames, NfmCoef c, int16_t *__restrict__ pcm,
                                                   double *__restrict__ audio)
 {
-    const int lane = threadIdx.x;
-    const long tile = blockIdx.x;
-    const long f = tile * TILE + lane;
+    const int lane = threadIdx.x & (TILE - 1);
+    const int chan = WFM ? (int)(threadIdx.x >> 6) : 0;
+    const long tile = WFM ? 2 * (long)blockIdx.x + chan : (long)blockIdx.x;
+    const long f = (long)blockIdx.x * TILE + lane;
     const int M = n - 1;
     const long L = (long)M + 2 * EDGE;
     const double *Yt = Y + (size_t)tile * L * TILE + lane;
@@ -517,8 +522,19 @@ __global__ __launch_bounds__(TILE) void k_nfm_bwd(const double *__restrict__ Y, 
                                 }
                             });
     if (nan) mx = __builtin_nan("");
-    if (WFM) {  // rows are (tile, channel, frame-in-tile): k_wfm_finalize normalises the two channels jointly
-        audio[f] = mx;
+    if constexpr (WFM) {
+        __shared__ double mxs[2][TILE];
+        mxs[chan][lane] = mx;
+        __syncthreads();
+        const double ml = mxs[0][lane], mr = mxs[1][lane];
+        const double mxj = (mr > ml) ? mr : ml;          // python max(a, b): b only if b > a
+        if (f < n_frames) {
+            for (int k = 0; k < n_out; k++) {
+                const double a = __ddiv_rn(At[(size_t)k * TILE], mxj);
+                if (audio) audio[2 * ((size_t)f * n_out + k) + chan] = a;
+                if (pcm) pcm[2 * ((size_t)f * n_out + k) + chan] = pcm16(a);
+            }
+        }
         return;
     }
     if (f < n_frames) {
