@@ -990,13 +990,15 @@ def test_iq_correction_and_raw_bit_exact(golden):
 def test_iq_correction_batch_vs_oracle():
     rng = np.random.default_rng(808)
     e = G.engine()
-    for nf, n in [(300, 1024), (5, 9000), (40000, 256), (3, 77)]:
+    # (20 000 x 1024: more frames than workgroups — every workgroup of the one-wavefront-per-frame kernel walks two or three frames, the next
+    # one prefetched while the current one is reduced)
+    for nf, n in [(300, 1024), (20000, 1024), (5, 9000), (40000, 256), (3, 77)]:
         iq = ((rng.standard_normal((nf, n)) * 0.3 + 0.04) + 1j * (rng.standard_normal((nf, n)) * 0.2 - 0.03)).astype(np.complex64)
         d_out = G.empty((nf, n, 2), torch.float32)
         e.iq_correction(G.dev(iq), nf, n, d_out, None)
         e.sync()
         got = G.host(d_out).reshape(nf, -1).view(np.complex64)
-        for f in list(range(min(nf, 40))) + [nf - 1]:
+        for f in sorted(set(list(range(min(nf, 40))) + [nf - 1] + [k for k in (8191, 8192, 8195, 16384, 16390, 19998) if k < nf])):
             assert np.array_equal(got[f].view(np.uint32), O.iq_correction(iq[f]).view(np.uint32)), (nf, n, f)
         # property at batch size: the output power equals the (DC-removed) input power, and the I/Q imbalance is gone
         c = got.astype(np.complex128)
