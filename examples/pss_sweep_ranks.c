@@ -4,7 +4,7 @@
  * accumulators (pss_halo_from_left) is shown on the per-slice peaks.
  *   gcc -O2 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/pss_sweep_ranks.c -Lpyspecsdr_amd -lpss -L/opt/rocm/lib -lamdhip64 -lm -o /tmp/pss_sweep_ranks
  *   LD_LIBRARY_PATH=pyspecsdr_amd:/opt/rocm/lib /tmp/pss_sweep_ranks RANK N_RANKS ID_FILE [n_slices] [n]
- * Rendezvous: rank 0 writes the 128-byte id to ID_FILE, the others wait for the file.  ID_FILE "-" with N_RANKS 1: a lone rank, RCCL is
+ * Rendezvous: rank 0 writes the 128-byte id to ID_FILE (which must not exist beforehand), the others wait for the file.  ID_FILE "-" with N_RANKS 1: a lone rank, RCCL is
  * never opened.  Start one process per rank (any launcher: a shell loop, mpirun, srun); rank r takes device r mod pss_device_count().
  * Rank 0 prints one line per slice in sweep order: "slice k peak <dB> count <bins>"; every rank prints its halo. */
 #include <hip/hip_runtime_api.h>
