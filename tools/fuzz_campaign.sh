@@ -7,3 +7,8 @@ for s in 51 52 53; do echo -n "edge seed $s: "; FUZZ_EDGE=1 FUZZ_SEED=$s timeout
 for s in 61 62 63; do echo -n "fuzz2 seed $s: "; FUZZ_SEED=$s timeout 900 python tools/fuzz_gpu_vs_oracle2.py 150 2>&1 | tail -1; done
 } > gpurun_out/fuzz_big.txt 2>&1
 tail -16 gpurun_out/fuzz_big.txt
+{
+echo "# tools/fuzz_pipeline_f64.py FUZZ_SEED=71..76 x 150 cases: pss_frame_pipeline_f64 (random frame length, batch, history, display geometry, mode, signal, cut + halo) — cells, extremes, NFM PCM against the oracle's step from IQ"
+for s in 71 72 73 74 75 76; do echo -n "pipeline seed $s: "; FUZZ_SEED=$s timeout 900 python tools/fuzz_pipeline_f64.py 150 2>&1 | tail -1; done
+} > gpurun_out/fuzz_pipe.txt 2>&1
+cat gpurun_out/fuzz_pipe.txt
