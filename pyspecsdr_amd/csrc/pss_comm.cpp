@@ -171,7 +171,7 @@ extern "C" int pss_gather_packed(pss_ctx *ctx, const void *d_local, size_t bytes
     if (bytes == 0) return PSS_OK;
     hipStream_t st = PSS_STREAM(ctx);
     char *mine = recv ? static_cast<char *>(d_all) + (size_t)me * bytes : nullptr;
-    if (n == 1 || !ctx->comm) {
+    if (!ctx->comm) {       // a lone rank without RCCL: the gather is a copy (a one-rank communicator takes the RCCL calls below like any other)
         if (n != 1) return pss_fail(ctx, PSS_E_COMM, "pss_gather_packed: no communicator");
         if (mine != d_local) PSS_HIP(ctx, hipMemcpyAsync(mine, d_local, bytes, hipMemcpyDeviceToDevice, st));
         return PSS_OK;
