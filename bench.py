@@ -240,26 +240,31 @@ def cpu_baseline(iq_host, fs, taps, sos, zi, min_wall_s=1.0, max_wall_s=25.0):
     }
 
 
-def shader_clock_mhz():
-    """Current shader clock of GPU 0 (MHz) from sysfs (pp_dpm_sclk: the level marked '*'), else rocm-smi, else None."""
+def shader_clock_mhz(device_index=0):
+    """Current shader clock (MHz) of the GPU this process computes on, from sysfs: the DRM card whose PCI address is the HIP device's (a box
+    shows every GPU of the host under /sys/class/drm, the container computes on one of them), hwmon freq1_input (Hz; 'sclk') or, failing
+    that, the pp_dpm_sclk level marked '*'.  None when the card cannot be identified."""
     import glob
     import re
-    import subprocess
     try:
-        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
-            for line in open(f):
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}."
+    except Exception:  # noqa: BLE001
+        return None
+    for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+        try:
+            if bdf not in os.path.realpath(card):
+                continue
+            for f in sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*", "freq1_input"))):
+                return int(round(int(open(f).read().strip()) / 1e6))
+            for line in open(os.path.join(card, "pp_dpm_sclk")):
                 if "*" in line:
                     m = re.search(r"(\d+)\s*Mhz", line, re.I)
                     if m:
                         return int(m.group(1))
-    except OSError:
-        pass
-    try:
-        out = subprocess.run(["rocm-smi", "--showclocks", "-d", "0"], capture_output=True, text=True, timeout=20).stdout
-        m = re.search(r"sclk clock level:?\s*\S*\s*\((\d+)Mhz\)", out, re.I)
-        return int(m.group(1)) if m else None
-    except Exception:  # noqa: BLE001
-        return None
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def verify_step(eng, iq, fs, d_db, d_lo, d_hi, pk, o_col, o_pcm, n_out, window, rows_f64):
@@ -416,7 +421,16 @@ def main():
     fence()
     # timed region: exactly K steps (compute + exchange), barrier + synchronize on both sides — run R times back to back in this process;
     # the line reports the MEDIAN region (ms_per_step, value) with the fastest and slowest beside it and the shader clock around them
-    clk0 = shader_clock_mhz() if rank == 0 else None
+    def clock_under_load():
+        # the shader clock is sampled WHILE untimed steps are in the queue: read on an idle GPU, sysfs reports the idle level (159 MHz on
+        # this part), which says nothing about the clock the timed steps ran at
+        for k in range(max(8, args.steps)):
+            compute(k & 1)
+        c = shader_clock_mhz(dev.index or 0) if rank == 0 else None
+        fence()
+        eng.kernel_times()       # (drop the event records of these untimed steps)
+        return c
+    clk0 = clock_under_load()
     regions, live_all = [], []
     for _ in range(max(1, args.regions)):
         t0 = time.perf_counter()
@@ -427,7 +441,9 @@ def main():
         live = eng.kernel_times().get(dom, [])
         assert len(live) >= args.steps and len(live) % args.steps == 0, (dom, len(live))   # some kernels launch twice a step
         live_all.append(sum(live) / len(live))
-    clk1 = shader_clock_mhz() if rank == 0 else None
+    eng.timing_filter(None)
+    eng.enable_timing(False)
+    clk1 = clock_under_load()
     order = sorted(range(len(regions)), key=lambda i: regions[i])
     mid = order[len(order) // 2]
     elapsed = regions[mid]
