@@ -219,8 +219,6 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "small_batch")) { ctx->no_small_batch = (value == 0); return PSS_OK; }
     if (!strcmp(key, "small_batch_max")) { ctx->small_batch_max = value; return PSS_OK; }
     if (!strcmp(key, "wfm_small_batch_max")) { ctx->wfm_small_batch_max = value; return PSS_OK; }
-    if (!strcmp(key, "pipe_overlap")) { ctx->pipe_overlap = value < 0 ? 0 : (value > 4 ? 4 : value); return PSS_OK; }
-    if (!strcmp(key, "fwd_cap")) { ctx->fwd_cap = value < 0 ? 0 : value; return PSS_OK; }
     if (!strcmp(key, "ssb_rfft")) { ctx->ssb_rfft = value != 0; return PSS_OK; }
     if (!strcmp(key, "ssb_hilbert")) { ctx->ssb_hilbert = value != 0; return PSS_OK; }
     if (!strcmp(key, "hilbert_exact")) { ctx->hilbert_exact = value != 0; return PSS_OK; }

@@ -39,8 +39,6 @@ struct pss_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;   // pss_order_after / pss_order_before (created on first use)
     int n_cus = 0;                                  // hipDeviceProp_t::multiProcessorCount
-    int fwd_cap = 0;                // > 0: k_nfm_fwd launches at most this many workgroups per CU (each walks several tiles)
-    int pipe_overlap = 0;           // option "pipe_overlap": pss_frame_pipeline's NFM schedule with the display chain beside the WHOLE demodulator, forward kernel capped at this many workgroups per CU (0: chain beside the backward pass only)
     double target_rate = 22050.0;   // demodulate_nfm / _wfm's target_rate (pss_set_target_rate): decimation factor int(fs / target_rate)
     bool wfm_correct = false;       // pss_demod(WFM) is handed the frames AS READ and applies iq_correction itself (consumed there; set by pss_demod_signal / pss_frame_pipeline)
     const float *wfm_scal = nullptr;   // ... the per-frame correction scalars for the fused forward kernel

@@ -3153,15 +3153,9 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             pss_kernel_begin(ctx, "k_nfm_fwd");
             {
                 auto kf = swapped ? fused::k_nfm_fwd<true, true> : fused::k_nfm_fwd<true, false>;
-                // fwd_cap > 0 (set by the pipeline's overlap schedule): at most that many workgroups per CU at a time — the batch's tiles go
-                // out as consecutive grids of fwd_cap * CUs workgroups on the same stream (a grid starts when its predecessor has drained)
-                const long gmax = (ctx->fwd_cap > 0 && (long)ctx->fwd_cap * ncu < tiles) ? (long)ctx->fwd_cap * ncu : tiles;
-                for (long t0 = 0; t0 < tiles; t0 += gmax) {
-                    const long gnow = tiles - t0 < gmax ? tiles - t0 : gmax;
-                    hipLaunchKernelGGL(kf, dim3((unsigned)gnow), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
-                                       reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, d_rev,
-                                       reinterpret_cast<unsigned *>(ctx->prog), ncu, ctx->prog_epoch, t0);
-                }
+                hipLaunchKernelGGL(kf, dim3((unsigned)tiles), dim3(fused::WG), fused::LDS_BYTES, PSS_STREAM(ctx),
+                                   reinterpret_cast<const float2 *>(d_iq), Yf, Uh, Ut, n, n_frames, c, kscale, d_rev,
+                                   reinterpret_cast<unsigned *>(ctx->prog), ncu, ctx->prog_epoch, 0L);
             }
             pss_kernel_end(ctx);
             auto launch_bwd = [=]() -> int {
@@ -3343,7 +3337,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
     }
     if (mode == PSS_MODE_WFM) {
         const int q = (int)(fs / ctx->target_rate);
-        if (q < 2) return pss_fail(ctx, PSS_E_ARG, "WFM: sample rates below 44.1 kHz (no decimation stage) are not supported");
+        if (q < 2) return pss_fail(ctx, PSS_E_ARG, "WFM: sample_rate < 2 * target_rate (decimation factor int(fs / target_rate) < 2: the reference then skips its decimate() stage) is not supported");
         if (n - 1 <= EDGE)
             return pss_fail(ctx, PSS_E_PADLEN, "The length of the input vector x must be greater than padlen, which is 27.");
         PssWfmFilt *wf;
@@ -4033,10 +4027,8 @@ static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n
     // forward kernel (+2 %); everything in order on one stream; forward -> spectrum -> { backward || post-process -> lines }.
     int r2;
     ctx->pending_bwd = nullptr;
-    const bool overlap = ctx->pipe_overlap > 0;
     {
         PssFlagScope defer(ctx->defer_bwd, true);
-        PssScoped<int> cap(ctx->fwd_cap, overlap ? ctx->pipe_overlap : 0);
         r2 = pss_demod(ctx, mode, d_in, n_frames, n, fs, d_pcm, nullptr);
     }
     int r = r2;
@@ -4051,10 +4043,9 @@ static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n
     if (ctx->pending_bwd) {
         auto bwd = ctx->pending_bwd;
         ctx->pending_bwd = nullptr;
-        if (!overlap) {
-            if (!r) r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
-            if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
-        }
+        // the side stream ALWAYS waits for the main stream here: the chain reads d_iq and writes d_db / the scratch, all ordered on ctx->stream
+        if (!r) r = pss_hip_check(ctx, hipEventRecord(ctx->ev_fork, ctx->stream), "hipEventRecord(fork)");
+        if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
         if (!r) {
             PssStreamScope side(ctx->cur, ctx->stream2);
             r = display_chain();

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WG, 1 + NFW) void k_nfm_fwd(const float2 *__restric
     int *lprio = reinterpret_cast<int *>(ltab + 64);                                // priority of the workgroup, handed from the IIR wavefront to the workers                        // the discriminator's reciprocal table (pss_device.h rcp14f)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: everything indexed by the role / chunk stays scalar
-    const long tile = tile0 + blockIdx.x;   // (tile0 > 0: the batch's tiles are launched in several grids — pss_frame_pipeline's overlap schedule)
+    const long tile = tile0 + blockIdx.x;   // (tile0: first tile of this grid; the product launches the whole batch as one grid, tile0 = 0)
     const int slot = (int)(blockIdx.x / ncu) & 3;   // which of its CU's (up to) four workgroups this one is: consecutive workgroups go to consecutive CUs
     const int cu = (int)(blockIdx.x % ncu);
     const int M = n - 1;                      // FIR outputs per frame (M >= 128 guaranteed by the caller)

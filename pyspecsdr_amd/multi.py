@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 import numpy as np
 
-from .shard import ShardBuffer, gather_packed, halo_from_left, scan_buffer, shard_counts, shard_range, unpack_gathered
+from .shard import EngineGroup, ShardBuffer, gather_packed, halo_from_left, scan_buffer, shard_counts, shard_range, unpack_gathered
 
 
 def _world_rank(group=None):
@@ -51,6 +51,10 @@ class ShardedScanner:
                                                 for _ in range(2)]
         # gloo (tests on a box with fewer GPUs than ranks) cannot gather device tensors: stage through the host
         # an initialised process group means "exchange", also with a single rank (exercises the RCCL path on one GPU)
+        if isinstance(group, EngineGroup):
+            raise TypeError("ShardedScanner overlaps its gather on a torch.distributed side stream; an EngineGroup (C-ABI exchange) serves the "
+                            "blocking helpers: gather_packed, halo_from_left, sharded_stream_display (or call pss_gather_packed directly, "
+                            "examples/pss_sweep_ranks.c)")
         self.exchange = dist.is_initialized()
         self.host_stage = self.exchange and dist.get_backend(group) == "gloo"
         self.comp = torch.cuda.ExternalStream(engine.stream_handle(), device=self.device)
@@ -135,7 +139,7 @@ def sharded_stream_display(engine, h_iq_local, fs, chunk_frames, mode="waterfall
     lines, pcm = res["lines"], res["pcm"]
     if world > 1:
         # extremes of the rows preceding this block: 8 bytes per row from the left neighbour(s), all messages posted at once
-        dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", engine.device)
+        dev = "cpu" if _backend(group) == "gloo" else torch.device("cuda", engine.device)
         ext = torch.from_numpy(np.stack([res["row_lo"], res["row_hi"]], axis=1)).to(dev)
         halo = halo_from_left(ext, window - 1, group=group).cpu().numpy()
         fix = min(window - 1, h_iq_local.shape[0])
@@ -148,7 +152,7 @@ def sharded_stream_display(engine, h_iq_local, fs, chunk_frames, mode="waterfall
     if gather_dst is None or world == 1:
         return lines, pcm
     # one packed message per rank: [lines... | pcm]
-    dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", engine.device)
+    dev = "cpu" if _backend(group) == "gloo" else torch.device("cuda", engine.device)
     counts = shard_counts_from(torch.tensor([h_iq_local.shape[0]], dtype=torch.int64), group, device=dev)
     fields = [(f"l{i}", (disp_w,), torch.int8) for i in range(len(lines))] + [("pcm", tuple(pcm.shape[1:]), torch.int16)]
     buf = ShardBuffer(fields, max(counts), dev)
@@ -161,22 +165,38 @@ def sharded_stream_display(engine, h_iq_local, fs, chunk_frames, mode="waterfall
     return tuple(got[f"l{i}"].cpu().numpy() for i in range(len(lines))), got["pcm"].cpu().numpy()
 
 
+def _backend(group):
+    """"engine" for an EngineGroup (exchange steps behind the C ABI: device buffers, the engine's stream), else the process group's backend."""
+    return "engine" if isinstance(group, EngineGroup) else dist.get_backend(group)
+
+
 def shard_counts_from(count_tensor, group=None, device=None):
     """All ranks' block sizes (blocks need not come from shard_range: a capture is cut where the caller cut it).
     device: where the collective's buffers live (the engine's GPU for RCCL; default: the tensor's own device, or the host under gloo)."""
     world, _ = _world_rank(group)
     if world == 1:
         return [int(count_tensor.item())]
-    dev = "cpu" if dist.get_backend(group) == "gloo" else (device if device is not None else count_tensor.device)
+    dev = "cpu" if _backend(group) == "gloo" else (device if device is not None else count_tensor.device)
     allc = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(allc, count_tensor.to(dev), group=group)
+    if isinstance(group, EngineGroup):
+        cnt = count_tensor.to(dev)
+        group.before(dev)
+        group.engine.gather_packed(cnt, 8, allc, None)
+        group.after()
+    else:
+        dist.all_gather_into_tensor(allc, count_tensor.to(dev), group=group)
     return [int(c) for c in allc.tolist()]
 
 
 def _gather_uneven(buf, counts, dst, group):
     world, rank = _world_rank(group)
     out = torch.empty((world, buf.nbytes), dtype=torch.uint8, device=buf.raw.device) if rank == dst else None
-    dist.gather(buf.raw, list(out.unbind(0)) if rank == dst else None, group=group, group_dst=dst)
+    if isinstance(group, EngineGroup):
+        group.before(buf.raw.device)
+        group.engine.gather_packed(buf.raw, buf.nbytes, out, dst)
+        group.after()
+    else:
+        dist.gather(buf.raw, list(out.unbind(0)) if rank == dst else None, group=group, group_dst=dst)
     if rank != dst:
         return None
     return unpack_gathered(buf, out, counts)

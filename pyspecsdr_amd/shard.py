@@ -42,12 +42,23 @@ def shard_counts(n_items, world):
 
 class EngineGroup:
     """A `group` whose exchange steps run BEHIND THE C ABI (pss_gather_packed / pss_halo_from_left: libpss.so opens librccl itself) instead
-    of over torch.distributed — the route a host without torch takes (include/pss.h "Multi-GPU", examples/pss_gather_example.c).
-    engine: an Engine that has joined a communicator (Engine.comm_init)."""
+    of over torch.distributed — the route a host without torch takes (include/pss.h "Multi-GPU", examples/pss_sweep_ranks.c).
+    engine: an Engine that has joined a communicator (Engine.comm_init).
+    Ordering: the C-ABI collectives run on the ENGINE's stream.  before() orders that stream behind torch's current stream (the producer
+    of the buffers), after() waits for the collective on the host — the helpers below read the results straight away (counts -> Python
+    ints, gathered views), so a blocking wait is the right one whatever `order` the Engine was created with.
+    Exercised with one rank only (tests/test_gpu_parity.py; the boxes this was built on expose one GPU): the multi-rank branches follow
+    pss_comm.cpp's grouped send / receive, which a second rank has never executed."""
 
     def __init__(self, engine):
         self.engine = engine
         self.rank, self.world = engine.comm_size()
+
+    def before(self, device):
+        self.engine.order_after(torch.cuda.current_stream(device).cuda_stream)
+
+    def after(self):
+        self.engine.sync()
 
 
 def _world_rank(group=None):
@@ -104,7 +115,9 @@ def gather_packed(buf, n_items, dst=0, group=None, out=None):
     if isinstance(group, EngineGroup):
         if (dst is None or rank == dst) and out is None:
             out = torch.empty((world, buf.nbytes), dtype=torch.uint8, device=buf.raw.device)
+        group.before(buf.raw.device)
         group.engine.gather_packed(buf.raw, buf.nbytes, out, dst)
+        group.after()
         if dst is not None and rank != dst:
             return None
     elif dst is None:
@@ -166,13 +179,16 @@ def halo_from_left(local, halo, group=None):
     cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     allc = torch.empty(world, dtype=torch.int64, device=local.device)
     if isinstance(group, EngineGroup):
+        group.before(local.device)                      # cnt / local come from torch's stream
         group.engine.gather_packed(cnt, 8, allc, None)
+        group.after()                                   # the counts are read on the host next
         counts = [int(c) for c in allc.tolist()]
         have = min(int(halo), sum(counts[:rank]))
         got = torch.empty((have,) + tail, dtype=local.dtype, device=local.device)
         rows = local.contiguous()
         row_bytes = rows.element_size() * int(np.prod(tail, dtype=np.int64))
         n_got = group.engine.halo_from_left(rows, counts, row_bytes, int(halo), got)
+        group.after()
         assert n_got == have, (n_got, have)
         return got
     dist.all_gather_into_tensor(allc, cnt, group=group)

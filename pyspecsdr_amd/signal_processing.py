@@ -66,6 +66,22 @@ def _set_target_rate(target_rate):
         _target_rate = tr
 
 
+class _rate:
+    """`with _rate(target_rate):` — the engine's decimator is designed for target_rate inside the block and for the default 22 050 Hz after it,
+    whatever happens inside: a non-default rate never outlives the call that asked for it (demodulate_pcm, formats.demodulate_batch and every
+    direct get_engine() batch / pipeline call see the reference's default, as demodulate_signal + write_to_pipe would)."""
+
+    def __init__(self, target_rate):
+        self.tr = target_rate
+
+    def __enter__(self):
+        _set_target_rate(self.tr)
+
+    def __exit__(self, *exc):
+        _set_target_rate(DEFAULT_SAMPLE_RATE)
+        return False
+
+
 def _inject_designs(kind, fs):
     key = (kind, float(fs))
     if not USE_SCIPY_DESIGNS or key in _designed:
@@ -188,18 +204,18 @@ def compute_fft(samples):
 
 
 def demodulate_nfm(samples, sample_rate, target_rate=DEFAULT_SAMPLE_RATE):
-    _set_target_rate(target_rate)
-    _inject_designs('nfm', sample_rate)
-    audio, _ = get_engine().h_demodulate(L.MODE_NFM, _samples(samples), sample_rate)
+    with _rate(target_rate):
+        _inject_designs('nfm', sample_rate)
+        audio, _ = get_engine().h_demodulate(L.MODE_NFM, _samples(samples), sample_rate)
     return audio
 
 
 def demodulate_wfm(samples, sample_rate, target_rate=DEFAULT_SAMPLE_RATE):
     """signal_processing.py:119-176 -> float64 (n_out, 2) = column_stack((left, right)).  (The reference's RDS hooks at
     :165-174 call undefined names inside a try/except and never produce anything; nothing to mirror.)"""
-    _set_target_rate(target_rate)
-    _inject_designs('wfm', sample_rate)
-    audio, _ = get_engine().h_demodulate(L.MODE_WFM, _samples(samples), sample_rate)
+    with _rate(target_rate):
+        _inject_designs('wfm', sample_rate)
+        audio, _ = get_engine().h_demodulate(L.MODE_WFM, _samples(samples), sample_rate)
     return audio
 
 
@@ -227,7 +243,6 @@ def demodulate_signal(samples, sample_rate, mode='NFM'):
         # :222-225 + :238 — every non-voice mode is IQ-corrected first; RAW then returns the I samples (float32)
         return get_engine().h_raw(_samples(samples))
     elif mode == 'WFM':
-        _set_target_rate(DEFAULT_SAMPLE_RATE)
         _inject_designs('wfm', sample_rate)
         audio, _ = get_engine().h_demodulate_signal(L.MODE_WFM, _samples(samples), sample_rate)  # :222-228
         return audio

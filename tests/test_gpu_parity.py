@@ -1583,8 +1583,12 @@ def test_round5_arguments_vs_reference_goldens(golden):
                     assert a.shape == g[f"audio_{t}"][k].shape, (t, a.shape)
                     assert np.array_equal(a, g[f"audio_{t}"][k]), (t, scipy_tables)
                     assert np.array_equal(np.int16(a * 32767), g[f"pcm_{t}"][k]), t
-            # ... and back to the default rate: the goldens of rounds 1-4 still hold
+            # a non-default rate never outlives the call that asked for it: straight after one, the int16 path that has no target_rate
+            # argument (demodulate_pcm = demodulate_signal + write_to_pipe) and the batched host call give the default-rate goldens
             n = golden["nfm"]
+            sp.demodulate_nfm(n["iq_a"][0], float(n["fs_a"]), 11025)
+            assert sp._target_rate == float(sp.DEFAULT_SAMPLE_RATE)
+            assert np.array_equal(sp.demodulate_pcm(n["iq_a"][0], float(n["fs_a"]), "NFM"), n["pcm_a"][0])
             assert np.array_equal(sp.demodulate_nfm(n["iq_a"][0], float(n["fs_a"]))[:, 0], n["audio_a"][0])
     finally:
         sp.USE_SCIPY_DESIGNS = keep

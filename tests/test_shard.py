@@ -209,6 +209,8 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and len(set(lines[0]["pids"])) == 2, r.stdout
+    # the line ENDS with the compact per-config summary (a record that keeps only the tail of the line still certifies every config)
+    assert list(lines[0])[-1] == "summary" and r.stdout.rstrip().endswith("}}"), r.stdout
     # the shape the driver's scaling run has: eight ranks on one node
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True, text=True,
                        env=env, timeout=600)
@@ -243,3 +245,32 @@ def test_bench_gpus_flag_starts_that_many_ranks():
             r = subprocess.run([sys.executable, os.path.join(root, script), "--gpus", "2"], capture_output=True, text=True, env=env,
                                timeout=120)
             assert r.returncode == 2 and "GPU(s) are visible" in r.stderr, (script, r.stderr[-500:])
+
+
+def test_bench_summary_is_last_and_small():
+    """bench.py's `summary` (the LAST key of the JSON line): every BASELINE config's time, SURVEY-bytes fraction, traffic ratio, oracle
+    verdict and differing-cell count in <= 1500 characters — built here from the committed line of a real run and from a worst-case line."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    lines = sorted(f for f in os.listdir(os.path.join(root, "profiles")) if f.endswith("_bench_line.json"))
+    out = json.load(open(os.path.join(root, "profiles", lines[-1])))
+    s = bench.summary_of(out)
+    txt = json.dumps(s, separators=(",", ":"))      # the separators bench.py prints its line with
+    assert len(txt) <= bench.SUMMARY_MAX_CHARS
+    for name in ("cfg3", "cfg4", "cfg5_resident", "cfg5_streamed", "wfm_step"):
+        assert name in s and {"ms", "fs", "tr", "ok", "cd"} <= set(s[name]), (name, s.get(name))
+        assert s[name]["ms"] == round(out["other_configs"][name]["ms"], 4)
+    assert s["headline"]["ms"] == round(out["ms_per_step"], 4) and s["src_hash"] == out["src_hash"]
+    # worst case: every config present, every number long, every config failing with an error text
+    worst = {"ms_per_step": 1234.56789, "ms_per_step_min": 1234.56789, "ms_per_step_max": 1234.56789, "src_hash": "f" * 16,
+             "regions": {"shader_clock_mhz_before": 2400, "shader_clock_mhz_after": 2400}, "config": {"rows": "f64"},
+             "verified": {"ok": False, "cells_differing": 14680064},
+             "roofline": {"frac_survey_bytes": 0.123456, "traffic_ratio": 12.3456, "kernel": "k_spectrum_post_fused", "frac": 0.123456,
+                          "kernel_ms": {"k_spectrum_post_fused": 1234.56789}, "traffic_source": "digest@" + "f" * 16},
+             "other_configs": {n: {"ms": 12345.6789, "frac_survey_bytes": 0.123456, "traffic_ratio_survey": 12.3456, "ms_one_stream": 12345.6789,
+                                   "ms_float64_rows": 12345.6789, "frac_of_link": 0.98765, "error": "RuntimeError: " + "x" * 200,
+                                   "verified": {"ok": False, "cells_differing": 14680064}} for n in bench.SUMMARY_CONFIGS}}
+    assert len(json.dumps(bench.summary_of(worst), separators=(",", ":"))) <= bench.SUMMARY_MAX_CHARS
