@@ -10,13 +10,19 @@ one-GPU number labelled N.  The result line carries the world size RCCL reported
 
 One "step" = one pass of the hot path over one batch of synthetic FM-modulated IQ already resident in HBM
 (BASELINE.json configs[1] = 65 536 frames x 1024 points @ 2.4 MS/s per GPU), for EVERY frame of the batch:
-    compute_fft dB spectrum (signal_processing.py:243-264)            -> float64 [frames][1024] (the reference's own row type)
-    the caller's smoothing + median clamp (pyspecsdr.py:2278-2283)     -> row extremes + the row resampled to the display width (the rows
-                                                                          themselves only with --materialise-post)
+    compute_fft dB spectrum (signal_processing.py:243-264)            -> computed in float64 (the reference's own arithmetic), the row
+                                                                          WRITTEN as float32 [frames][1024]: the float64 value rounded once
+                                                                          (north_star: "float32 dB spectra", SURVEY §8(d): 4 bytes per bin)
+    the caller's smoothing + median clamp (pyspecsdr.py:2278-2283)     -> float64, from the transform's registers: row extremes + the row
+                                                                          resampled to the display width (the rows themselves only with
+                                                                          --rows f64 --materialise-post)
     the waterfall accumulator's newest display line (:1342-1406)       -> int8 glyph + colour [frames][112]: the reference's cells
     demodulate_nfm -> int16 stereo (signal_processing.py:91-116)       -> int16 [frames][10][2]
---rows f32 times the same step on float32 dB rows (pss_frame_pipeline_nfm: 1e-4-relative spectra, a display cell may differ from the
-reference's where a value sits on a quantisation edge); the default line carries that step too, as other_configs.cfg2_f32_rows.
+That is --rows cells (pss_frame_pipeline_cells; since round 6 the transform and the post-process of a 1024-point frame are ONE kernel,
+k_spectrum_post, so the float64 rows never travel through HBM).  --rows f64: the same arithmetic with the float64 rows written
+(pss_frame_pipeline_nfm_f64, round 5's timed step); --rows f32: float32 arithmetic behind the transform (pss_frame_pipeline_nfm: a display
+cell may differ from the reference's where a value sits on a quantisation edge).  The default line carries those two steps as
+other_configs.cfg2_exact_cells / cfg2_f32_rows.
 The timed region (K steps between fences) is run R times (--regions, default 5): ms_per_step / value are the MEDIAN region's, with the
 minimum, maximum and the shader clock before / after beside them.
 Frames are independent, so N GPUs each process their own batch (weak scaling).  The one exchange step of the path
@@ -61,6 +67,8 @@ def algo_bytes(row_bytes):
     """algorithmic bytes per frame: what each kernel must move if nothing is re-read or spilled; row_bytes = 4 / 8 per dB bin"""
     return {
         "k_spectrum": N_FFT * 8 + N_FFT * row_bytes,    # IQ in + dB row out
+        # the fused transform + post-process (pss_spec_post.h): IQ in; dB row, extremes and the row resampled to the display width out
+        "k_spectrum_post": N_FFT * 8 + N_FFT * row_bytes + 16 + DISP_W * 8,
         "k_nfm_fwd": N_FFT * 8,                         # IQ in (y_fwd is an internal hand-off, not algorithmic)
         "k_nfm_bwd": 40,                                # 10 x 2 x int16 out
         "k_post": N_FFT * row_bytes + 2 * row_bytes + DISP_W * 8,   # dB row in; extremes + the row resampled to the display width out
@@ -73,7 +81,7 @@ def algo_bytes(row_bytes):
 
 
 ALGO_BYTES = algo_bytes(8)   # (main() replaces it with the timed row type's)
-HBM_BOUND = ("k_spectrum", "k_post", "k_disp_rows")
+HBM_BOUND = ("k_spectrum", "k_spectrum_post", "k_post", "k_disp_rows")
 # float64 VALU operations per input sample and lane of k_nfm_fwd, fixed by the reference's accumulation order (DESIGN.md §4;
 # measured with SQ_INSTS_VALU_{FMA,ADD,MUL}_F64: profiles/r02_valu_instruction_mix.txt): 63 fma + 51 add + 12 mul
 NFM_FWD_F64_OPS_PER_SAMPLE = 126
@@ -133,7 +141,7 @@ def step_traffic(kernels, n_frames):
         if t.get("src_hash") != source_hash():
             return None, None
         ks = t["kernels"]
-        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel", "k_disp_rows": "k_disp_vals"}
+        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel", "k_disp_rows": "k_disp_vals"}   # (k_spectrum_post: its own name)
         tot = 0.0
         for k in kernels:
             d = ks.get(names.get(k, k))
@@ -267,7 +275,7 @@ def shader_clock_mhz(device_index=0):
     return None
 
 
-def verify_step(eng, iq, fs, d_db, d_lo, d_hi, pk, o_col, o_pcm, n_out, window, rows_f64):
+def verify_step(eng, iq, fs, d_db, d_lo, d_hi, pk, o_col, o_pcm, n_out, window, exact_cells):
     """Outside the timed region: the outputs the LAST timed step left in HBM against the CPU oracle (oracle/pss_oracle.c, the checker,
     never the thing measured) on blocks of 256 consecutive frames spread over the batch: the oracle runs its OWN step from the IQ in the
     reference's row type (float64 rows from compute_fft to the cells) — dB rows, row extremes, NFM int16 PCM (equal) and every display cell
@@ -280,7 +288,7 @@ def verify_step(eng, iq, fs, d_db, d_lo, d_hi, pk, o_col, o_pcm, n_out, window, 
     glyph = pk[:o_col].view(torch.int8).view(nf, DISP_W)
     colour = pk[o_col:o_pcm].view(torch.int8).view(nf, DISP_W)
     pcm = pk[o_pcm:].view(torch.int16).view(nf, n_out, 2)
-    res = bench_configs.check_from_iq(O, eng, iq, iq.shape[1], fs, d_db, d_lo, d_hi, (glyph, colour), pcm, window, rows_f64=rows_f64)
+    res = bench_configs.check_from_iq(O, eng, iq, iq.shape[1], fs, d_db, d_lo, d_hi, (glyph, colour), pcm, window, rows_f64=exact_cells)
     res["note"] = ("outputs of the last timed step vs the CPU oracle's own step from the IQ (float64 rows), outside the timed region, spot-checked "
                    "on the listed blocks: dB rows and extremes within tolerance, int16 PCM equal, display cells counted")
     return res
@@ -312,6 +320,8 @@ def summary_of(out):
             c["ms64"] = _r(e.get("ms_float64_rows"))
         if name == "cfg3":
             c["ms1"] = _r(e.get("ms_one_stream"))
+        if name == "wfm_step":
+            c["msx"] = _r(e.get("ms_cells_entry"))      # the same step through the cell-exact entry (pss_frame_pipeline_cells)
         if e.get("error"):
             c["err"] = str(e["error"])[:60]
         s[name] = c
@@ -355,9 +365,10 @@ def main():
     ap.add_argument("--frames", type=int, default=N_FRAMES, help="frames per GPU per step (default: BASELINE cfg 2)")
     ap.add_argument("--exchange", choices=["display", "db", "none"], default="display",
                     help="what is gathered to rank 0 inside the timed region when N > 1")
-    ap.add_argument("--rows", choices=["f64", "f32"], default="f64",
-                    help="row type of the timed step: f64 = the reference's own (compute_fft returns float64; the display cells are the reference's), "
-                         "f32 = float32 dB rows (the other one is timed and verified as other_configs.cfg2_f32_rows / cfg2_exact_cells)")
+    ap.add_argument("--rows", choices=["cells", "f64", "f32"], default="cells",
+                    help="the timed step: cells = float64 arithmetic from the IQ to the display cells (the reference's cells), the dB row written as float32 "
+                         "(the float64 value rounded once); f64 = the same with the float64 rows written; f32 = float32 rows and float32-row "
+                         "post-process (the other two are timed and verified as other_configs.cfg2_exact_cells / cfg2_f32_rows)")
     ap.add_argument("--regions", type=int, default=5, help="how many times the K-step timed region is run (median reported, min / max beside it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true",
@@ -398,23 +409,28 @@ def main():
     comp = torch.cuda.ExternalStream(eng.stream_handle(), device=dev)   # the library's stream, for event ordering
     nf, n = args.frames, N_FFT
     global ALGO_BYTES
-    rows_f64 = args.rows == "f64"
-    row_dt = torch.float64 if rows_f64 else torch.float32
+    rows_f64 = args.rows == "f64"             # float64 rows in memory
+    exact = args.rows in ("cells", "f64")     # float64 arithmetic from the IQ to the cells: the reference's cells
+    row_dt = torch.float64 if rows_f64 else torch.float32     # dB rows as written
+    ext_dt = torch.float64 if exact else torch.float32        # row extremes (and the side measurements' post-processed rows)
     ALGO_BYTES = algo_bytes(8 if rows_f64 else 4)
     iq = synth_fm_iq(nf, n, FS, dev, seed=20260928 + 2 + rank)
     torch.cuda.synchronize(dev)            # the IQ batch is produced on torch's stream, consumed on the library's
     n_out = eng.demod_out_len(0, n, FS)
     m = n - 4
-    d_post = torch.empty((nf, m), dtype=row_dt, device=dev)      # side measurements; the timed step writes it only with --materialise-post
+    d_post = torch.empty((nf, m), dtype=ext_dt, device=dev)      # side measurements; the timed step writes it only with --materialise-post
+    if args.materialise_post and args.rows == "cells":
+        sys.exit("bench.py: --materialise-post goes with --rows f64 or f32 (the cells step never writes the post-processed rows)")
     step_post = d_post if args.materialise_post else None
-    d_lo = torch.empty((nf,), dtype=row_dt, device=dev)
-    d_hi = torch.empty((nf,), dtype=row_dt, device=dev)
+    d_lo = torch.empty((nf,), dtype=ext_dt, device=dev)
+    d_hi = torch.empty((nf,), dtype=ext_dt, device=dev)
     # two output sets: step k+1 computes into one while step k's is in flight to rank 0.  A set is ONE packed buffer
     # [glyph | colour | pcm] (one message per rank and step) + the dB rows.
     o_col, o_pcm, set_bytes = nf * DISP_W, 2 * nf * DISP_W, 2 * nf * DISP_W + nf * n_out * 4
     packed = [torch.empty((set_bytes,), dtype=torch.uint8, device=dev) for _ in range(2)]
     d_db = [torch.empty((nf, n), dtype=row_dt, device=dev) for _ in range(2 if (dist and args.exchange == "db") else 1)]
     pipeline = eng.frame_pipeline_nfm_f64 if rows_f64 else eng.frame_pipeline_nfm
+    from pyspecsdr_amd import _lib as L
     exch = args.exchange if dist is not None else "none"
     comm = torch.cuda.Stream(device=dev) if exch != "none" else None
     recv = None
@@ -426,7 +442,10 @@ def main():
     def compute(b):
         db = d_db[b % len(d_db)]
         base = packed[b].data_ptr()
-        pipeline(iq, nf, n, FS, db, step_post, d_lo, d_hi, DISP_W, base, base + o_col, base + o_pcm, window=WF_WINDOW)
+        if args.rows == "cells":
+            eng.frame_pipeline_cells(L.MODE_NFM, iq, nf, n, FS, db, None, d_lo, d_hi, DISP_W, base, base + o_col, base + o_pcm, window=WF_WINDOW)
+        else:
+            pipeline(iq, nf, n, FS, db, step_post, d_lo, d_hi, DISP_W, base, base + o_col, base + o_pcm, window=WF_WINDOW)
 
     def exchange(b):
         src = packed[b] if exch == "display" else d_db[b % len(d_db)].view(torch.uint8).view(-1)
@@ -500,7 +519,7 @@ def main():
     verified = None
     if not args.no_verify:
         last = (args.steps - 1) & 1 if args.steps else 0
-        verified = verify_step(eng, iq, FS, d_db[last % len(d_db)], d_lo, d_hi, packed[last], o_col, o_pcm, n_out, WF_WINDOW, rows_f64)
+        verified = verify_step(eng, iq, FS, d_db[last % len(d_db)], d_lo, d_hi, packed[last], o_col, o_pcm, n_out, WF_WINDOW, exact)
         if dist is not None:      # every rank checks its own outputs; the line reports the conjunction
             okt = torch.tensor([1 if verified["ok"] else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
@@ -518,21 +537,32 @@ def main():
     if not args.no_side:
         # each HBM-bound kernel alone (inside a step the spectrum and the post-process run beside the backward IIR pass)
         eng.enable_timing(True)
-        spectrum = eng.spectrum_db_f64 if rows_f64 else eng.spectrum_db
-        for _ in range(2):
-            spectrum(iq, nf, n, d_db[0])
-        eng.sync(); eng.kernel_times()
-        for _ in range(5):
-            spectrum(iq, nf, n, d_db[0])
-        eng.sync()
-        spec_alone = eng.kernel_times().get("k_spectrum", [])
-        for _ in range(5):      # likewise the post-process kernel (here with the rows written: the separate entry points have no resampled-row output)
-            if rows_f64:
-                eng.spectrum_post_f64(d_db[0], nf, n, d_post, d_lo, d_hi)
-            else:
-                eng.spectrum_post_extremes(d_db[0], nf, n, d_post, d_lo, d_hi)
-        eng.sync()
-        post_alone = eng.kernel_times().get("k_post", [])
+        if args.rows == "cells":
+            # the display half of the step alone (pss_spectrum_cells: the fused transform + post-process kernel, then the lines)
+            base = packed[0].data_ptr()
+            for _ in range(2):
+                eng.spectrum_cells(iq, nf, n, d_db[0], None, d_lo, d_hi, DISP_W, base, base + o_col, window=WF_WINDOW)
+            eng.sync(); eng.kernel_times()
+            for _ in range(5):
+                eng.spectrum_cells(iq, nf, n, d_db[0], None, d_lo, d_hi, DISP_W, base, base + o_col, window=WF_WINDOW)
+            eng.sync()
+            spec_alone = eng.kernel_times().get("k_spectrum_post", [])
+        else:
+            spectrum = eng.spectrum_db_f64 if rows_f64 else eng.spectrum_db
+            for _ in range(2):
+                spectrum(iq, nf, n, d_db[0])
+            eng.sync(); eng.kernel_times()
+            for _ in range(5):
+                spectrum(iq, nf, n, d_db[0])
+            eng.sync()
+            spec_alone = eng.kernel_times().get("k_spectrum", [])
+            for _ in range(5):      # likewise the post-process kernel (here with the rows written: the separate entry points have no resampled-row output)
+                if rows_f64:
+                    eng.spectrum_post_f64(d_db[0], nf, n, d_post, d_lo, d_hi)
+                else:
+                    eng.spectrum_post_extremes(d_db[0], nf, n, d_post, d_lo, d_hi)
+            eng.sync()
+            post_alone = eng.kernel_times().get("k_post", [])
         for _ in range(5):      # and the demodulator with nothing beside it
             eng.demod(0, iq, nf, n, FS, packed[0].data_ptr() + o_pcm, None)
         eng.sync()
@@ -543,7 +573,7 @@ def main():
         d_g30 = torch.empty((36, DISP_W), dtype=torch.int8, device=dev)
         d_c30 = torch.empty((36, DISP_W), dtype=torch.int8, device=dev)
 
-        if not rows_f64:
+        if args.rows == "f32":
             def step30():
                 eng.spectrum_nfm(iq, nf, n, FS, d_db[0], packed[0].data_ptr() + o_pcm)
                 eng.spectrum_post(d_db[0][nf - WF:], WF, n, d_post)
@@ -576,7 +606,7 @@ def main():
         # timed region (which ended above); a failing verification fails the run like the headline's
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_configs
-        other = bench_configs.other_configs(eng, dev, verify=not args.no_verify, skip=("cfg2_exact_cells" if rows_f64 else "cfg2_f32_rows",))
+        other = bench_configs.other_configs(eng, dev, verify=not args.no_verify, skip={"cells": (), "f64": ("cfg2_exact_cells",), "f32": ("cfg2_f32_rows",)}[args.rows])
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -628,16 +658,18 @@ def main():
                 a = ALGO_BYTES[k] * nf / (ktimes[k] * 1e-3) / 1e9
                 hb[k] = {"ms": round(ktimes[k], 4), "achieved": a, "frac": a / HBM_PEAK_GBS}
         if spec_alone:
+            sk = "k_spectrum_post" if args.rows == "cells" else "k_spectrum"
             sms = sum(spec_alone) / len(spec_alone)
-            sa = ALGO_BYTES["k_spectrum"] * nf / (sms * 1e-3) / 1e9
-            hb["k_spectrum_standalone"] = {"ms": round(sms, 4), "achieved": sa, "frac": sa / HBM_PEAK_GBS}
+            sa = ALGO_BYTES[sk] * nf / (sms * 1e-3) / 1e9
+            hb[sk + "_standalone"] = {"ms": round(sms, 4), "achieved": sa, "frac": sa / HBM_PEAK_GBS}
         if post_alone:
             pms = sum(post_alone) / len(post_alone)
             rb = 8 if rows_f64 else 4
             pa = (N_FFT * rb + (N_FFT - 4) * rb + 2 * rb) * nf / (pms * 1e-3) / 1e9     # standalone: rows in, post-processed rows + extremes out
             hb["k_post_standalone"] = {"ms": round(pms, 4), "achieved": pa, "frac": pa / HBM_PEAK_GBS}
         roof["hbm_bound_kernels"] = hb
-        row_desc = "float64 rows, the reference's own type" if rows_f64 else "float32 rows"
+        row_desc = {"cells": "computed in float64, the row written as float32 = the float64 value rounded once", "f64": "float64 rows, the reference's own type",
+                    "f32": "float32 rows"}[args.rows]
         out = {
             "metric": "IQ MSamples/sec end-to-end (FFT+dB+FM demod)",
             "value": value / 1e6, "unit": "MSamples/s",
@@ -647,15 +679,16 @@ def main():
             "regions": {"n": len(regions), "ms_per_step": [round(r / args.steps * 1e3, 5) for r in regions],
                         "reported": "median region (value, ms_per_step, roofline)", "shader_clock_mhz_before": clk0, "shader_clock_mhz_after": clk1},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("complex64 IQ / f64 FFT + dB rows + post-process + FIR + IIR / int16 PCM" if rows_f64
-                      else "f32 front end / f64 FFT+FIR+IIR / f32 dB rows / int16 PCM"),
+            "dtype": {"cells": "complex64 IQ / f64 FFT + dB + post-process + FIR + IIR / dB rows stored as f32 / int16 PCM",
+                      "f64": "complex64 IQ / f64 FFT + dB rows + post-process + FIR + IIR / int16 PCM",
+                      "f32": "f32 front end / f64 FFT+FIR+IIR / f32 dB rows / int16 PCM"}[args.rows],
             "data": "synthetic",
             "config": {"workload": f"{nf} frames x {n}-pt complex64 @2.4 MS/s per GPU, every frame: compute_fft dB spectrum "
                                    f"({row_desc}) + "
                                    f"post-process (smoothing, median clamp) + waterfall display line + NFM demod -> int16 stereo "
                                    f"(BASELINE.json configs[1])",
                        "rows": args.rows,
-                       "materialised": {"db_rows": True, "pcm": True, "waterfall_lines": True, "row_extremes": True,
+                       "materialised": {"db_rows": {"cells": "float32", "f64": "float64", "f32": "float32"}[args.rows], "pcm": True, "waterfall_lines": True, "row_extremes": True,
                                         "post_processed_rows": bool(args.materialise_post)},
                        "frames_per_gpu": nf, "n_fft": n, "sample_rate": FS, "parallelism": f"frames sharded x{world}",
                        "exchange": {"display": "RCCL gather to rank 0 of every rank's waterfall lines + PCM (one packed buffer per step), "

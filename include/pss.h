@@ -249,6 +249,23 @@ int pss_frame_pipeline_f64(pss_ctx *ctx, int mode, const float *d_iq, long n_fra
                            double *d_row_lo, double *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w, int8_t *d_line_a,
                            int8_t *d_line_b, int16_t *d_pcm);
 
+/* The cell-exact iteration with the dB ROW materialised as float32.  Everything is computed in float64 from the IQ to the display cells, as
+ * in pss_frame_pipeline_f64 (compute_fft signal_processing.py:243-264, the caller's smoothing + median clamp pyspecsdr.py:2278-2283, the
+ * accumulators :1342-1406 / :1512-1564), but what is written per bin is compute_fft's float64 value ROUNDED ONCE to float32 — d_db32
+ * [n_frames][n], the spectrum output's own contract (1e-4 relative; the rounding is ~6e-8) and SURVEY's 4 bytes per bin — and, only if
+ * d_db64 != NULL, the float64 value as well.  1024-point frames: the transform and the post-process of a frame are ONE kernel
+ * (k_spectrum_post: the frame's float64 dB values go from the transform's registers through LDS into the select; option "fuse_post" = 0:
+ * two kernels) — the float64 rows never travel through HBM unless asked for.  Other lengths: the float64 rows go through d_db64 or a
+ * context-owned scratch, and a conversion pass writes d_db32.  The float64 entry points above use the fused kernel too (their d_db = d_db64).
+ *   pss_frame_pipeline_cells: pss_frame_pipeline_f64's arguments with (d_db32, d_db64) in place of d_db and no d_post; this is the step bench.py times
+ *   pss_spectrum_cells:       its display half alone — compute_fft -> post-process -> display line of every frame, no demodulator
+ *                             (d_db32 or d_db64 may be NULL, not both) */
+int pss_frame_pipeline_cells(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, float *d_db32, double *d_db64,
+                             double *d_row_lo, double *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
+                             int8_t *d_line_a, int8_t *d_line_b, int16_t *d_pcm);
+int pss_spectrum_cells(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_db32, double *d_db64, double *d_row_lo,
+                       double *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w, int8_t *d_line_a, int8_t *d_line_b);
+
 /* Waterfall / persistence quantisers over a ring of post-processed rows (pyspecsdr.py:1342-1406,
  * :1512-1564).  d_rows float32 [n_rows][len], oldest first (n_rows <= 30 / <= 10).
  * d_glyph/d_colour int8 [disp_h][disp_w] (-1 = not drawn; persistence: 0 = empty). */

@@ -68,6 +68,8 @@ _SIGS = {
     "pss_frame_pipeline": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "pss_frame_pipeline_nfm_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "pss_frame_pipeline_f64": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "pss_frame_pipeline_cells": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "pss_spectrum_cells": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "pss_spectrum_db_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
     "pss_spectrum_post_f64": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p, _p]),
     "pss_h_np_f64": (C.c_int, [C.c_int, _p, C.c_long, _p]),

@@ -156,6 +156,7 @@ extern "C" void pss_destroy(pss_ctx *ctx)
     if (ctx->scratch_scan) hipFree(ctx->scratch_scan);
     if (ctx->scratch_pk) hipFree(ctx->scratch_pk);
     if (ctx->scratch_win) hipFree(ctx->scratch_win);
+    if (ctx->scratch_db64) hipFree(ctx->scratch_db64);
     if (ctx->scratch_post) hipFree(ctx->scratch_post);
     if (ctx->prog) hipFree(ctx->prog);
     if (ctx->stage) hipFree(ctx->stage);
@@ -219,6 +220,7 @@ extern "C" int pss_set_option(pss_ctx *ctx, const char *key, int value)
     if (!strcmp(key, "small_batch")) { ctx->no_small_batch = (value == 0); return PSS_OK; }
     if (!strcmp(key, "small_batch_max")) { ctx->small_batch_max = value; return PSS_OK; }
     if (!strcmp(key, "wfm_small_batch_max")) { ctx->wfm_small_batch_max = value; return PSS_OK; }
+    if (!strcmp(key, "fuse_post")) { ctx->fuse_post = value != 0; return PSS_OK; }
     if (!strcmp(key, "ssb_rfft")) { ctx->ssb_rfft = value != 0; return PSS_OK; }
     if (!strcmp(key, "ssb_hilbert")) { ctx->ssb_hilbert = value != 0; return PSS_OK; }
     if (!strcmp(key, "hilbert_exact")) { ctx->hilbert_exact = value != 0; return PSS_OK; }

@@ -39,6 +39,7 @@ struct pss_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;   // pss_order_after / pss_order_before (created on first use)
     int n_cus = 0;                                  // hipDeviceProp_t::multiProcessorCount
+    int fuse_post = 1;              // option "fuse_post" (float64-row pipelines, 1024-point frames): 1 = transform + post-process in ONE kernel (pss_spec_post.h), 0 = two kernels (A/B reference)
     double target_rate = 22050.0;   // demodulate_nfm / _wfm's target_rate (pss_set_target_rate): decimation factor int(fs / target_rate)
     bool wfm_correct = false;       // pss_demod(WFM) is handed the frames AS READ and applies iq_correction itself (consumed there; set by pss_demod_signal / pss_frame_pipeline)
     const float *wfm_scal = nullptr;   // ... the per-frame correction scalars for the fused forward kernel
@@ -69,6 +70,8 @@ struct pss_ctx {
     unsigned prog_epoch = 0;       // launch counter stamped into those words (16 bits, never 0)
     void *scratch_post = nullptr;  // pss_frame_pipeline_nfm without materialised post-processed rows: the rows' clamp thresholds
     size_t scratch_post_bytes = 0;
+    void *scratch_db64 = nullptr;  // pss_frame_pipeline_cells / pss_spectrum_cells with float32 rows only, on lengths the fused kernel does not serve: the float64 rows
+    size_t scratch_db64_bytes = 0;
     void *scratch_win = nullptr;   // sliding-window extremes of the batched display accumulators
     size_t scratch_win_bytes = 0;
     float *d_hann = nullptr;       // pss_classify: scipy's periodic Hann window (1024, float32) and sum(win * win)
@@ -179,6 +182,9 @@ int pss_fft_tables(pss_ctx *ctx, int n, const double2 **tw, const double **win);
 // pss_frame_pipeline's display chain behind the dB rows (rows of either type): thresholds + extremes + the rows resampled to the display
 // width in one pass (no post-processed rows in memory), sliding extremes, the line of every frame.  d_vals: n_frames x disp_w doubles.
 bool pss_post_sel_serves(const pss_ctx *ctx, int n_fft, bool f64);
+bool pss_spec_post_serves(const pss_ctx *ctx, int n_fft);
+int pss_spec_post_chain(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db32, double *d_db64, double *d_lo, double *d_hi, int n_halo,
+                        int window, int display, int disp_h, int disp_w, int8_t *d_a, int8_t *d_b, double *d_vals);
 int pss_chain_vals_f32(pss_ctx *ctx, const float *d_db, long n_frames, int n_fft, float *d_lo, float *d_hi, int n_halo, int window, int display,
                        int disp_h, int disp_w, int8_t *d_a, int8_t *d_b, double *d_vals);
 int pss_chain_vals_f64(pss_ctx *ctx, const double *d_db, long n_frames, int n_fft, double *d_lo, double *d_hi, int n_halo, int window, int display,

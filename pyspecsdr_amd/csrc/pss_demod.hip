@@ -3952,28 +3952,36 @@ inline int pipe_chain_vals(pss_ctx *ctx, const double *d_db, long nf, int n, dou
 template <class TR>
 static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, TR *d_db, TR *d_post,
                                TR *d_row_lo, TR *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
-                               int8_t *d_glyph, int8_t *d_colour, int16_t *d_pcm);
+                               int8_t *d_glyph, int8_t *d_colour, int16_t *d_pcm, float *d_db32, bool demodulate);
+// d_db32 (float64 rows only; NULL otherwise): the dB rows ALSO (or, with d_db == NULL, ONLY) as float32 — compute_fft's float64 value rounded once
+// demodulate = false: the display half alone (pss_spectrum_cells): no demodulator, d_pcm unused
 template <class TR>
 static int frame_pipeline(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, TR *d_db, TR *d_post,
                           TR *d_row_lo, TR *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
-                          int8_t *d_glyph, int8_t *d_colour, int16_t *d_pcm)
+                          int8_t *d_glyph, int8_t *d_colour, int16_t *d_pcm, float *d_db32 = nullptr, bool demodulate = true)
 {
     pss_time_begin(ctx);     // one bracket around the whole call (the nested pairs inside are no-ops)
     const int r = frame_pipeline_impl<TR>(ctx, mode, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w,
-                                          d_glyph, d_colour, d_pcm);
+                                          d_glyph, d_colour, d_pcm, d_db32, demodulate);
     pss_time_end(ctx);
     return r;
 }
+
+__global__ __launch_bounds__(256) void k_rows_f64_to_f32(const double *__restrict__ src, float *__restrict__ dst, long count)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+
 template <class TR>
 static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, TR *d_db, TR *d_post,
                                TR *d_row_lo, TR *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w,
-                               int8_t *d_glyph, int8_t *d_colour, int16_t *d_pcm)
+                               int8_t *d_glyph, int8_t *d_colour, int16_t *d_pcm, float *d_db32, bool demodulate)
 {
     constexpr bool F64 = sizeof(TR) == 8;
     if (n_frames < 0 || n_halo < 0 || window < 1 || disp_w < 1 || (display != 0 && display != 1) || (display == 1 && (disp_h < 1 || disp_h > 127)))
         return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline: bad frame count, halo, window or display geometry");
     if (n < 8) return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline: frames of fewer than 8 samples have no post-processed row to draw");
-    if (n_frames > 0 && (!d_iq || !d_db || !d_row_lo || !d_row_hi || !d_glyph || (!d_colour && display == 0) || !d_pcm))
+    if (n_frames > 0 && (!d_iq || (!d_db && !d_db32) || !d_row_lo || !d_row_hi || !d_glyph || (!d_colour && display == 0) || (!d_pcm && demodulate)))
         return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline: null buffer");
     double *d_vals = nullptr;
     if (n_frames > 0 && !d_post) {
@@ -3984,13 +3992,39 @@ static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n
         if (direct) d_vals = reinterpret_cast<double *>(ctx->scratch_post);
         else d_post = reinterpret_cast<TR *>(ctx->scratch_post);
     }
-    // the display chain behind the dB rows, on whichever stream it is queued
-    auto chain_behind_db = [&]() -> int {
+    // 1024-point frames, float64 rows, rows not materialised: the transform and the post-process are ONE kernel (pss_spec_post.h; option
+    // "fuse_post" = 0: the two kernels) — the float64 rows never go through HBM unless the caller asks for them (d_db)
+    bool fused = false;
+    if constexpr (F64) fused = ctx->fuse_post && d_vals && pss_spec_post_serves(ctx, n);
+    if (n_frames > 0 && !d_db && !fused) {     // float32 rows only, but this path needs the float64 rows in memory: the context's scratch
+        int rq = pss_ensure_buffer(ctx, &ctx->scratch_db64, &ctx->scratch_db64_bytes, (size_t)n_frames * n * sizeof(TR), "float64 dB rows");
+        if (rq) return rq;
+        d_db = reinterpret_cast<TR *>(ctx->scratch_db64);
+    }
+    // compute_fft of every frame and the display chain behind it, on whichever stream it is queued
+    auto spectrum_and_chain = [&]() -> int {
+        if constexpr (F64) {
+            if (fused)
+                return pss_spec_post_chain(ctx, d_iq, n_frames, n, d_db32, d_db, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w, d_glyph,
+                                           d_colour, d_vals);
+        }
+        int q = pipe_spectrum(ctx, d_iq, n_frames, n, d_db);     // compute_fft sees the samples as read (pyspecsdr.py:2275), not the corrected ones
+        if (q) return q;
+        if (d_db32 && n_frames > 0) {
+            const long count = n_frames * (long)n;
+            pss_kernel_begin(ctx, "k_rows_f64_to_f32");
+            hipLaunchKernelGGL(k_rows_f64_to_f32, dim3((unsigned)((count + 255) / 256 < 16384 ? (count + 255) / 256 : 16384)), dim3(256), 0, PSS_STREAM(ctx),
+                               reinterpret_cast<const double *>(d_db), d_db32, count);
+            pss_kernel_end(ctx);
+            q = pss_hip_check(ctx, hipGetLastError(), "k_rows_f64_to_f32 launch");
+            if (q) return q;
+        }
         if (d_vals) return pipe_chain_vals(ctx, d_db, n_frames, n, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w, d_glyph, d_colour, d_vals);
-        int q = pipe_post(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
+        q = pipe_post(ctx, d_db, n_frames, n, d_post, d_row_lo + n_halo, d_row_hi + n_halo);
         if (!q) q = pipe_lines(ctx, display, d_post, n_frames, n - 4, d_row_lo, d_row_hi, n_halo, window, disp_h, disp_w, d_glyph, d_colour);
         return q;
     };
+    if (!demodulate) return spectrum_and_chain();
     // WFM: demodulate_signal's dispatcher semantics — the frames are IQ-corrected first (signal_processing.py:222-225); pss_demod's WFM
     // branch does it (wfm_correct): a scalars pre-pass in front of the forward kernel, alone on the machine
     const float *d_in = d_iq;
@@ -4007,8 +4041,7 @@ static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n
         int rc;
         {
             PssStreamScope side(ctx->cur, ctx->stream2);
-            rc = pipe_spectrum(ctx, d_iq, n_frames, n, d_db);     // compute_fft sees the samples as read (pyspecsdr.py:2275), not the corrected ones
-            if (!rc) rc = chain_behind_db();
+            rc = spectrum_and_chain();
         }
         int rj = pss_hip_check(ctx, hipEventRecord(ctx->ev_join, ctx->stream2), "hipEventRecord(join)");
         if (!rj) rj = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)");
@@ -4032,14 +4065,6 @@ static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n
         r2 = pss_demod(ctx, mode, d_in, n_frames, n, fs, d_pcm, nullptr);
     }
     int r = r2;
-    const bool beside_bwd = (bool)ctx->pending_bwd;
-    if (!r && !beside_bwd) r = pipe_spectrum(ctx, d_iq, n_frames, n, d_db);
-    auto display_chain = [&]() -> int {
-        int q = PSS_OK;
-        if (beside_bwd) q = pipe_spectrum(ctx, d_iq, n_frames, n, d_db);
-        if (!q) q = chain_behind_db();
-        return q;
-    };
     if (ctx->pending_bwd) {
         auto bwd = ctx->pending_bwd;
         ctx->pending_bwd = nullptr;
@@ -4048,14 +4073,14 @@ static int frame_pipeline_impl(pss_ctx *ctx, int mode, const float *d_iq, long n
         if (!r) r = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0), "hipStreamWaitEvent(fork)");
         if (!r) {
             PssStreamScope side(ctx->cur, ctx->stream2);
-            r = display_chain();
+            r = spectrum_and_chain();
         }
         const int rb = bwd();                      // main stream; launched whatever happened above (the PCM must be produced)
         int rj = pss_hip_check(ctx, hipEventRecord(ctx->ev_join, ctx->stream2), "hipEventRecord(join)");
         if (!rj) rj = pss_hip_check(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0), "hipStreamWaitEvent(join)");
         if (!r) r = rb ? rb : rj;
     } else if (!r) {
-        r = display_chain();                       // the demodulator took a path without a separate backward kernel
+        r = spectrum_and_chain();                  // the demodulator took a path without a separate backward kernel
     }
     pss_time_end(ctx);
     return r;
@@ -4087,6 +4112,33 @@ extern "C" int pss_frame_pipeline_f64(pss_ctx *ctx, int mode, const float *d_iq,
     if (n < 16 || n > 65536 || (n & (n - 1))) return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_f64: n must be a power of two in [16, 65536]");
     return frame_pipeline<double>(ctx, mode, d_iq, n_frames, n, fs, d_db, d_post, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w, d_line_a,
                                   d_line_b, d_pcm);
+}
+
+// The cell-exact iteration with the dB rows materialised as float32 (compute_fft's float64 value rounded once: the spectrum output's own contract),
+// and as float64 too if d_db64 != NULL; float64 from the IQ to the cells either way.
+extern "C" int pss_frame_pipeline_cells(pss_ctx *ctx, int mode, const float *d_iq, long n_frames, int n, double fs, float *d_db32, double *d_db64,
+                                        double *d_row_lo, double *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w, int8_t *d_line_a,
+                                        int8_t *d_line_b, int16_t *d_pcm)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (mode < PSS_MODE_NFM || mode > PSS_MODE_WFM) return pss_fail(ctx, PSS_E_ARG, "unknown demodulation mode");
+    if (n < 16 || n > 65536 || (n & (n - 1))) return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_cells: n must be a power of two in [16, 65536]");
+    if (n_frames > 0 && !d_db32) return pss_fail(ctx, PSS_E_ARG, "pss_frame_pipeline_cells: d_db32 is null");
+    return frame_pipeline<double>(ctx, mode, d_iq, n_frames, n, fs, d_db64, nullptr, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w, d_line_a,
+                                  d_line_b, d_pcm, d_db32);
+}
+
+// ... and its display half alone: compute_fft -> post-process -> display line of every frame, no demodulator
+extern "C" int pss_spectrum_cells(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_db32, double *d_db64, double *d_row_lo,
+                                  double *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w, int8_t *d_line_a, int8_t *d_line_b)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n < 16 || n > 65536 || (n & (n - 1))) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_cells: n must be a power of two in [16, 65536]");
+    if (n_frames > 0 && !d_db32 && !d_db64) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_cells: no row buffer");
+    return frame_pipeline<double>(ctx, PSS_MODE_NFM, d_iq, n_frames, n, 0.0, d_db64, nullptr, d_row_lo, d_row_hi, n_halo, window, display, disp_h, disp_w,
+                                  d_line_a, d_line_b, nullptr, d_db32, false);
 }
 
 extern "C" int pss_frame_pipeline_nfm(pss_ctx *ctx, const float *d_iq, long n_frames, int n, double fs, float *d_db, float *d_post,

@@ -22,6 +22,7 @@
 #include "pss_fft_r16.h"
 #include "pss_fft_xl.h"
 #include "pss_post.h"
+#include "pss_spec_post.h"
 #include "pss_hilbert.h"
 #include "pss_hilbert_pf.h"
 
@@ -1794,6 +1795,36 @@ int pss_chain_vals_f64(pss_ctx *ctx, const double *d_db, long n_frames, int n_ff
                        int disp_h, int disp_w, int8_t *d_a, int8_t *d_b, double *d_vals)
 {
     return chain_vals<double>(ctx, d_db, n_frames, n_fft, d_lo, d_hi, n_halo, window, display, disp_h, disp_w, d_a, d_b, d_vals);
+}
+
+// The fused transform + post-process (pss_spec_post.h) and the lines from its resampled rows: compute_fft -> cells for 1024-point frames without
+// the float64 rows going through HBM.  d_db32 / d_db64: the dB row as float32 and / or float64 (either may be NULL, not both).
+bool pss_spec_post_serves(const pss_ctx *ctx, int n_fft) { return n_fft == 1024 && !ctx->f64_plain && !ctx->post_legacy; }
+int pss_spec_post_chain(pss_ctx *ctx, const float *d_iq, long n_frames, int n_fft, float *d_db32, double *d_db64, double *d_lo, double *d_hi,
+                        int n_halo, int window, int display, int disp_h, int disp_w, int8_t *d_a, int8_t *d_b, double *d_vals)
+{
+    if (!pss_spec_post_serves(ctx, n_fft) || (!d_db32 && !d_db64)) return pss_fail(ctx, PSS_E_ARG, "fused transform + post-process: 1024-point frames, a row buffer");
+    if (n_frames == 0) return PSS_OK;
+    const double2 *tw;
+    const double *win;
+    int r = pss_fft_tables(ctx, n_fft, &tw, &win);
+    if (r) return r;
+    using C = pss_r16::Cfg<2>;
+    auto kern = d_db32 ? (d_db64 ? pss_sp::k_spectrum_post<true, true> : pss_sp::k_spectrum_post<true, false>) : pss_sp::k_spectrum_post<false, true>;
+    const size_t lds = (size_t)C::FPW * C::EX * sizeof(double2) + (size_t)C::TW2 * sizeof(double2);
+    if (lds > 64 * 1024) PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long groups = (n_frames + C::FPW - 1) / C::FPW;
+    const long cap = 256L * 2 * 2;       // two 256-thread workgroups per CU (LDS, registers), two rounds
+    pss_time_begin(ctx);
+    pss_kernel_begin(ctx, "k_spectrum_post");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(256), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db32,
+                       d_db64, tw, win, n_frames, d_lo + n_halo, d_hi + n_halo, d_vals, disp_w);
+    pss_kernel_end(ctx);
+    r = pss_hip_check(ctx, hipGetLastError(), "k_spectrum_post launch");
+    if (!r) r = display ? display_rows<double, 1>(ctx, (const double *)nullptr, n_frames, n_fft - 4, d_lo, d_hi, n_halo, window, disp_h, disp_w, d_a, nullptr, (const double *)nullptr, d_vals)
+                        : display_rows<double, 0>(ctx, (const double *)nullptr, n_frames, n_fft - 4, d_lo, d_hi, n_halo, window, 1, disp_w, d_a, d_b, (const double *)nullptr, d_vals);
+    pss_time_end(ctx);
+    return r;
 }
 
 extern "C" int pss_waterfall_rows(pss_ctx *ctx, const float *d_post, long n_frames, int len, const float *d_row_lo,

@@ -334,6 +334,24 @@ class Engine:
         self._dev(self.lib.pss_frame_pipeline_f64, int(mode), _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db), _ptr(d_post), _ptr(d_row_lo),
                   _ptr(d_row_hi), n_halo, window, disp, disp_h, disp_w, _ptr(d_line_a), _ptr(d_line_b), _ptr(d_pcm))
 
+    def frame_pipeline_cells(self, mode, d_iq, n_frames, n, fs, d_db32, d_db64, d_row_lo, d_row_hi, disp_w, d_line_a, d_line_b, d_pcm,
+                             n_halo=0, window=None, display="waterfall", disp_h=36):
+        """The cell-exact iteration (float64 from the IQ to the cells, frame_pipeline_f64's results) with the dB rows written as float32
+        (d_db32: compute_fft's float64 value rounded once) and, if d_db64 is not None, as float64 too.  1024-point frames: the transform and
+        the post-process are one kernel and the float64 rows never go through HBM unless d_db64 asks for them."""
+        disp = {"waterfall": 0, "persistence": 1}[display]
+        window = (30, 10)[disp] if window is None else int(window)
+        self._dev(self.lib.pss_frame_pipeline_cells, int(mode), _ptr(d_iq), n_frames, n, float(fs), _ptr(d_db32), _ptr(d_db64), _ptr(d_row_lo),
+                  _ptr(d_row_hi), n_halo, window, disp, disp_h, disp_w, _ptr(d_line_a), _ptr(d_line_b), _ptr(d_pcm))
+
+    def spectrum_cells(self, d_iq, n_frames, n, d_db32, d_db64, d_row_lo, d_row_hi, disp_w, d_line_a, d_line_b, n_halo=0, window=None,
+                       display="waterfall", disp_h=36):
+        """frame_pipeline_cells' display half alone: compute_fft -> post-process -> display line of every frame (no demodulator)."""
+        disp = {"waterfall": 0, "persistence": 1}[display]
+        window = (30, 10)[disp] if window is None else int(window)
+        self._dev(self.lib.pss_spectrum_cells, _ptr(d_iq), n_frames, n, _ptr(d_db32), _ptr(d_db64), _ptr(d_row_lo), _ptr(d_row_hi), n_halo, window,
+                  disp, disp_h, disp_w, _ptr(d_line_a), _ptr(d_line_b))
+
     def spectrum_db_f64(self, d_iq, n_frames, n_fft, d_db):
         """compute_fft's float64 rows (n_fft: power of two in 16..65536)."""
         self._dev(self.lib.pss_spectrum_db_f64, _ptr(d_iq), n_frames, n_fft, _ptr(d_db))

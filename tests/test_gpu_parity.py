@@ -486,6 +486,104 @@ def test_full_size_float64_pipeline_cells_equal_the_oracle_from_iq():
     g, c = G.host(d_g), G.host(d_c)
     bad = int(np.count_nonzero(g != o["glyph"])) + int(np.count_nonzero(c != o["colour"]))
     assert bad == 0, f"{bad} of {2 * g.size} cells differ from the oracle's cells computed from IQ"
+    # the step bench.py times since round 6 — pss_frame_pipeline_cells: the same arithmetic, the dB row written as float32 — leaves the same bytes
+    d_db32 = G.empty((nf, n), torch.float32)
+    d_lo2, d_hi2 = G.empty((nf,), torch.float64), G.empty((nf,), torch.float64)
+    d_g2, d_c2, d_pcm2 = G.empty((nf, W), torch.int8), G.empty((nf, W), torch.int8), G.empty((nf, 10, 2), torch.int16)
+    e.frame_pipeline_cells(L.MODE_NFM, iq, nf, n, fs, d_db32, None, d_lo2, d_hi2, W, d_g2, d_c2, d_pcm2, window=win)
+    e.sync()
+    assert torch.equal(d_g2, d_g) and torch.equal(d_c2, d_c) and torch.equal(d_pcm2, d_pcm)
+    assert torch.equal(d_lo2.view(torch.int64), d_lo.view(torch.int64)) and torch.equal(d_hi2.view(torch.int64), d_hi.view(torch.int64))
+    assert torch.equal(d_db32.view(torch.int32), d_db.float().view(torch.int32))
+
+
+def test_fused_transform_post_kernel_equals_the_two_kernels():
+    """k_spectrum_post (pss_spec_post.h: compute_fft and the caller's post-process of a 1024-point frame in ONE kernel, the float64 dB values
+    handed from the transform's registers through LDS to the select) against the two kernels it replaces (option "fuse_post" = 0:
+    k_spectrum_r16<D64> -> k_post_sel<double>): dB rows, row extremes and display lines bit for bit, on batches that end inside a workgroup,
+    frames of zeros (a constant row), with a NaN / an infinity among the samples, a pure tone, and amplitudes so small that the rows differ in
+    the low words of their values only; every entry point that reaches the kernel (pss_frame_pipeline_f64 in every mode, both displays, with a
+    halo; pss_frame_pipeline_cells, whose float32 row must be the float64 row rounded once; pss_spectrum_cells), and the lengths the fused
+    kernel does not serve through pss_frame_pipeline_cells' conversion pass."""
+    e = G.engine()
+    fs, W, H = 2.4e6, 112, 36
+    gen = torch.Generator(device="cuda").manual_seed(606)
+    try:
+        for nf in (1, 3, 4, 5, 1027, 3001):
+            n = 1024
+            iq = torch.randn((nf, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3
+            if nf >= 5:
+                iq[1] = 0.0                                           # every bin -100 dB exactly: a constant row
+                iq[2] *= 1e-19                                        # |X|^2 far below the 1e-10 floor: values that differ in their low words only
+                t = torch.arange(n, device="cuda", dtype=torch.float64)
+                iq[3, :, 0] = torch.cos(2 * np.pi * 100.25 * t / n).float(); iq[3, :, 1] = torch.sin(2 * np.pi * 100.25 * t / n).float()
+                iq[4, 17, 0] = float("nan")                           # every bin NaN: np.median -> NaN, nothing clamped, no finite extreme
+            if nf >= 1027:
+                iq[1000, 5, 1] = float("inf")                         # inf * window -> inf / NaN bins
+                iq[nf - 1] *= 30.0
+            torch.cuda.synchronize()
+            for mode in ((L.MODE_NFM, L.MODE_AM, L.MODE_USB, L.MODE_WFM) if nf == 1027 else (L.MODE_NFM,)):
+                for display in ("waterfall", "persistence"):
+                    n_out = e.demod_out_len(mode, n, fs)
+                    outs = []
+                    for fuse in (0, 1):
+                        e.set_option("fuse_post", fuse)
+                        o = dict(db=G.empty((nf, n), torch.float64), lo=torch.zeros((7 + nf,), dtype=torch.float64, device="cuda") - 55.0,
+                                 hi=torch.zeros((7 + nf,), dtype=torch.float64, device="cuda") - 20.0,
+                                 a=torch.zeros((nf, W), dtype=torch.int8, device="cuda"), b=torch.zeros((nf, W), dtype=torch.int8, device="cuda"),
+                                 pcm=G.empty((nf, n_out, 2), torch.int16))
+                        e.frame_pipeline_f64(mode, iq, nf, n, fs, o["db"], None, o["lo"], o["hi"], W, o["a"], o["b"], o["pcm"], n_halo=7, display=display,
+                                             disp_h=H)
+                        e.sync()
+                        outs.append(o)
+                    for k in outs[0]:
+                        assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), (nf, mode, display, k)
+                    # the cells entry: the same lines / extremes / PCM, the float32 row = the float64 row rounded once; with and without the float64 row
+                    e.set_option("fuse_post", 1)
+                    for want64 in (False, True):
+                        c = dict(db32=G.empty((nf, n), torch.float32), db64=G.empty((nf, n), torch.float64) if want64 else None,
+                                 lo=torch.zeros((7 + nf,), dtype=torch.float64, device="cuda") - 55.0, hi=torch.zeros((7 + nf,), dtype=torch.float64, device="cuda") - 20.0,
+                                 a=torch.zeros((nf, W), dtype=torch.int8, device="cuda"), b=torch.zeros((nf, W), dtype=torch.int8, device="cuda"),
+                                 pcm=G.empty((nf, n_out, 2), torch.int16))
+                        e.frame_pipeline_cells(mode, iq, nf, n, fs, c["db32"], c["db64"], c["lo"], c["hi"], W, c["a"], c["b"], c["pcm"], n_halo=7,
+                                               display=display, disp_h=H)
+                        e.sync()
+                        for k in ("lo", "hi", "a", "b", "pcm"):
+                            assert torch.equal(outs[0][k].view(torch.uint8), c[k].view(torch.uint8)), (nf, mode, display, k, "cells")
+                        assert torch.equal(c["db32"].view(torch.int32), outs[0]["db"].float().view(torch.int32)), (nf, mode, "db32")
+                        if want64:
+                            assert torch.equal(c["db64"].view(torch.int64), outs[0]["db"].view(torch.int64)), (nf, mode, "db64")
+            # the display half alone
+            s = dict(db32=G.empty((nf, n), torch.float32), lo=G.empty((nf,), torch.float64), hi=G.empty((nf,), torch.float64),
+                     a=torch.zeros((nf, W), dtype=torch.int8, device="cuda"), b=torch.zeros((nf, W), dtype=torch.int8, device="cuda"))
+            r = dict(db=G.empty((nf, n), torch.float64), lo=G.empty((nf,), torch.float64), hi=G.empty((nf,), torch.float64),
+                     a=torch.zeros((nf, W), dtype=torch.int8, device="cuda"), b=torch.zeros((nf, W), dtype=torch.int8, device="cuda"),
+                     pcm=G.empty((nf, e.demod_out_len(L.MODE_NFM, n, fs), 2), torch.int16))
+            e.spectrum_cells(iq, nf, n, s["db32"], None, s["lo"], s["hi"], W, s["a"], s["b"])
+            e.set_option("fuse_post", 0)
+            e.frame_pipeline_f64(L.MODE_NFM, iq, nf, n, fs, r["db"], None, r["lo"], r["hi"], W, r["a"], r["b"], r["pcm"])
+            e.sync()
+            for k in ("lo", "hi", "a", "b"):
+                assert torch.equal(s[k].view(torch.uint8), r[k].view(torch.uint8)), (nf, k, "spectrum_cells")
+            assert torch.equal(s["db32"].view(torch.int32), r["db"].float().view(torch.int32))
+        # other lengths through the cells entry (float64 rows in the context's scratch + the conversion pass)
+        e.set_option("fuse_post", 1)
+        for nf, n in ((300, 512), (100, 2048), (9, 8192)):
+            iq = torch.randn((nf, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3
+            torch.cuda.synchronize()
+            n_out = e.demod_out_len(L.MODE_NFM, n, fs)
+            r = dict(db=G.empty((nf, n), torch.float64), lo=G.empty((nf,), torch.float64), hi=G.empty((nf,), torch.float64),
+                     a=torch.zeros((nf, W), dtype=torch.int8, device="cuda"), b=torch.zeros((nf, W), dtype=torch.int8, device="cuda"), pcm=G.empty((nf, n_out, 2), torch.int16))
+            c = dict(db32=G.empty((nf, n), torch.float32), lo=G.empty((nf,), torch.float64), hi=G.empty((nf,), torch.float64),
+                     a=torch.zeros((nf, W), dtype=torch.int8, device="cuda"), b=torch.zeros((nf, W), dtype=torch.int8, device="cuda"), pcm=G.empty((nf, n_out, 2), torch.int16))
+            e.frame_pipeline_f64(L.MODE_NFM, iq, nf, n, fs, r["db"], None, r["lo"], r["hi"], W, r["a"], r["b"], r["pcm"])
+            e.frame_pipeline_cells(L.MODE_NFM, iq, nf, n, fs, c["db32"], None, c["lo"], c["hi"], W, c["a"], c["b"], c["pcm"])
+            e.sync()
+            for k in ("lo", "hi", "a", "b", "pcm"):
+                assert torch.equal(r[k].view(torch.uint8), c[k].view(torch.uint8)), (nf, n, k)
+            assert torch.equal(c["db32"].view(torch.int32), r["db"].float().view(torch.int32)), (nf, n)
+    finally:
+        e.set_option("fuse_post", 1)
 
 
 @pytest.mark.parametrize("display", ["waterfall", "persistence"])

@@ -48,6 +48,11 @@ post64 = torch.empty((nf, n - 4), dtype=torch.float64, device=dev)
 lo64, hi64 = torch.empty(nf, dtype=torch.float64, device=dev), torch.empty(nf, dtype=torch.float64, device=dev)
 run("k_spectrum_r16 65536 x 1024 (FM IQ), f64 rows", lambda: e.spectrum_db_f64(iq, nf, n, db64), "k_spectrum", nf * (n * 8 + n * 8))
 run("k_post_sel 65536 x 1024 f64 rows in + out", lambda: e.spectrum_post_f64(db64, nf, n, post64, lo64, hi64), "k_post", nf * (n * 8 + (n - 4) * 8 + 16))
+# the fused transform + post-process kernel of the timed step (pss_spectrum_cells: float32 row, extremes, resampled row out), alone
+run("k_spectrum_post 65536 x 1024 (FM IQ), f32 rows", lambda: e.spectrum_cells(iq, nf, n, db, None, lo64, hi64, bench.DISP_W, g, c, window=bench.WF_WINDOW),
+    "k_spectrum_post", nf * bench.algo_bytes(4)["k_spectrum_post"])
+run("k_spectrum_post 65536 x 1024 (FM IQ), f64 rows", lambda: e.spectrum_cells(iq, nf, n, None, db64, lo64, hi64, bench.DISP_W, g, c, window=bench.WF_WINDOW),
+    "k_spectrum_post", nf * bench.algo_bytes(8)["k_spectrum_post"])
 del db64, post64
 n_out = e.demod_out_len(0, n, bench.FS)
 pcm = torch.empty((nf, n_out, 2), dtype=torch.int16, device=dev)

@@ -302,7 +302,8 @@ CELLS_F32_MAX_FRAC = 2e-3   # float32 dB rows agree with the reference's float64
 def check_from_iq(O, eng, iq, n, fs, db, lo, hi, lines, pcm, window, mode="waterfall", rows_f64=False, demod="nfm", blk=None, starts=None):
     """Blocks of consecutive frames of a step's outputs against the oracle's OWN step from IQ in the reference's row type (float64 compute_fft
     rows -> np.convolve / np.median / clamp -> min / max over the last `window` rows, np.interp, quantisation: oracle_lib.headline_f64) —
-    not against a quantiser run on the device's rows.  dB rows (1e-4 * max(|ref|, 1) for float32 rows, 1e-9 for float64 rows), row extremes,
+    not against a quantiser run on the device's rows.  rows_f64: the step computes in float64 from the IQ to the cells (extremes to 1e-9, 0 cells
+    differing required), whatever type its dB rows are WRITTEN in (db.dtype: float64 rows to 1e-9, float32 rows to 1e-4 * max(|ref|, 1)).  Row extremes,
     int16 PCM (equal; demod "nfm" only: other demodulators are checked by the caller), and the display cells: `cells_differing` counts
     every glyph / colour (or persistence row index) that is not the oracle's, over the lines whose history lies inside the block (all lines
     of a block that starts at frame 0).  float64 rows: 0 is required; float32 rows: at most CELLS_F32_MAX_FRAC of the cells."""
@@ -334,7 +335,9 @@ def check_from_iq(O, eng, iq, n, fs, db, lo, hi, lines, pcm, window, mode="water
         res["lines_checked"] += blk - first
     res["cells_differing_frac"] = res["cells_differing"] / max(1, res["cells_checked"])
     cells_ok = res["cells_differing"] == 0 if rows_f64 else res["cells_differing_frac"] <= CELLS_F32_MAX_FRAC
-    res["ok"] = bool(res["db_max_rel"] <= (1e-9 if rows_f64 else 1e-4) and res["extremes_max_abs"] <= (1e-9 if rows_f64 else 1e-4)
+    db_f64 = db.dtype == torch.float64      # rows as written: float64, or float32 (the cells step writes the float64 value rounded once)
+    res["db_rows"] = "float64" if db_f64 else "float32"
+    res["ok"] = bool(res["db_max_rel"] <= (1e-9 if db_f64 else 1e-4) and res["extremes_max_abs"] <= (1e-9 if rows_f64 else 1e-4)
                      and res["pcm_equal"] and cells_ok)
     return res
 
@@ -449,7 +452,9 @@ def cfg5_streamed(eng, dev, verify=True, launch_only=False, nf=48828, chunk=4096
 
 def wfm_step(eng, dev, verify=True, launch_only=False, nf=65536):
     """The headline step in the reference's DEFAULT mode (--demod WFM, pyspecsdr.py:2855): iq_correction + demodulate_wfm -> int16 stereo,
-    compute_fft dB row, post-process, waterfall line — pss_frame_pipeline(PSS_MODE_WFM) at cfg-2 size."""
+    compute_fft dB row, post-process, waterfall line at cfg-2 size.  `ms`: pss_frame_pipeline(PSS_MODE_WFM), float32 rows behind the transform
+    (the round-5 entry: cells counted against the oracle's); `ms_cells_entry`: pss_frame_pipeline_cells(PSS_MODE_WFM) — float64 from the IQ to
+    the cells (the reference's cells, required equal), transform + post-process in one kernel, the dB row written as float32."""
     n, fs, window = 1024, 2.4e6, 30
     iq = synth("fm", nf, n, fs, dev, 20260928 + 6)
     n_out = eng.demod_out_len(L.MODE_WFM, n, fs)
@@ -472,14 +477,29 @@ def wfm_step(eng, dev, verify=True, launch_only=False, nf=65536):
                 ver["pcm_equal"] &= bool(np.array_equal(pcm[k].cpu().numpy(), np.int16(a * 32767)))
         ver["pcm_frames"] = [k for s0, s1 in ver["blocks"] for k in (s0, s1 - 1)]
         ver["ok"] = bool(ver["ok"] and ver["pcm_equal"])
+    # the same step through the cell-exact entry
+    ms_c, ver_c = None, None
+    if not launch_only:
+        lo64, hi64 = torch.empty((nf,), dtype=torch.float64, device=dev), torch.empty((nf,), dtype=torch.float64, device=dev)
+        pcm_c = torch.empty_like(pcm)
+        ms_c, _ = timed(eng, lambda: eng.frame_pipeline_cells(L.MODE_WFM, iq, nf, n, fs, db, None, lo64, hi64, DISP_W, gl, co, pcm_c, window=window), 8, False)
+        if verify:
+            ver_c = check_from_iq(_oracle(), eng, iq, n, fs, db, lo64, hi64, (gl, co), None, window, rows_f64=True, demod="wfm", blk=window + 98)
+            ver_c["pcm_equal"] = bool(torch.equal(pcm_c, pcm))
+            ver_c["ok"] = bool(ver_c["ok"] and ver_c["pcm_equal"])
+            ver["cells_entry"] = {k: ver_c[k] for k in ("cells_checked", "cells_differing", "db_max_rel", "extremes_max_abs", "pcm_equal", "ok")}
+            ver["ok"] = bool(ver["ok"] and ver_c["ok"])
     algo = nf * (n * 8 + n * 4 + n_out * 4 + 2 * DISP_W)
-    return _entry("wfm_step", f"{nf} frames x {n}-pt @2.4 MS/s, every frame: demodulate_signal(WFM) = iq_correction + demodulate_wfm -> int16 stereo, "
-                  f"compute_fft dB row + post-process + waterfall line (the cfg-2 step in the reference's default mode)", ms, kt, algo, nf * n, ver,
-                  survey_bytes=nf * (n * 8 + n * 4 + n_out * 4))         # cfg 2's formula with the WFM step's PCM
+    e = _entry("wfm_step", f"{nf} frames x {n}-pt @2.4 MS/s, every frame: demodulate_signal(WFM) = iq_correction + demodulate_wfm -> int16 stereo, "
+               f"compute_fft dB row + post-process + waterfall line (the cfg-2 step in the reference's default mode)", ms, kt, algo, nf * n, ver,
+               survey_bytes=nf * (n * 8 + n * 4 + n_out * 4))         # cfg 2's formula with the WFM step's PCM
+    e["ms_cells_entry"] = None if ms_c is None else round(ms_c, 4)
+    return e
 
 
 def cfg2_rows(eng, dev, verify=True, launch_only=False, nf=65536, rows="f32"):
-    """The cfg 2 step (bench.py's headline workload) on the OTHER row type than the headline's: rows = "f32": float32 dB rows
+    """The cfg 2 step (bench.py's headline workload) as its two other entry points (the headline times pss_frame_pipeline_cells: float64
+    arithmetic, float32 rows written): rows = "f32": float32 dB rows
     (pss_frame_pipeline_nfm: the spectrum output's contract is 1e-4 relative; display cells may differ from the reference's where a value sits
     on a quantisation edge — counted below); rows = "f64": float64 rows from IQ to cells (pss_frame_pipeline_nfm_f64: the reference's cells)."""
     n, fs, window = 1024, 2.4e6, 30
