@@ -364,7 +364,6 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
     K key[EPL];                                  // (float64 rows: the two words of a key live in kh / kl below; `key` is then unused)
     unsigned kh[F64 ? EPL : 1], kl[F64 ? EPL : 1];
     float lsum = 0.0f;
-    bool nan_here = false;
     {
         double xd[EPL + 4];
 #pragma unroll
@@ -391,7 +390,6 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
             if constexpr (F64) { kh[r] = (unsigned)(kk0 >> 32); kl[r] = (unsigned)kk0; }
             else key[r] = kk0;
             lsum += pad ? 0.0f : (float)sm;
-            if constexpr (F64) nan_here |= !pad && sm != sm;
         }
     }
     // the row's mean: where the median search starts looking (select_kth; a hint only, never part of a result)
@@ -414,10 +412,9 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
     K thr = O::enc((TR)(med - 10.0));
     if constexpr (F64) {
         // np.median of a row that holds a NaN is NaN, and `fd < NaN` selects nothing: the lowest image clamps nothing (and survives the
-        // round trip through row_thr: enc(dec(0)) = 0)
-        bool has_nan;
-        if constexpr (W == 1) has_nan = __ballot(nan_here) != 0ull;
-        else has_nan = __syncthreads_or(nan_here) != 0;
+        // round trip through row_thr: enc(dec(0)) = 0).  A row holds a NaN iff its largest key lies above +inf's image (a NaN with the sign
+        // bit clear) or its smallest below -inf's (sign bit set): the row's extreme keys are known to every thread (no per-element test).
+        const bool has_nan = mx > O::POS_INF || mn < O::NEG_INF;
         if (has_nan || !(med == med)) thr = 0;
     }
     if (row_thr && t == 0) row_thr[f] = O::dec(thr);

@@ -30,6 +30,19 @@ __global__ __launch_bounds__(256) void k(double *out, double a, double b, int it
                 if (MODE == 6) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(v[c]) : "v"(v[(c + 1) % CH]), "s"(b));          // acc += x * s[tap]
                 if (MODE == 7) asm volatile("v_fma_f64 %0, %1, %2, 0" : "=v"(v[c]) : "v"(v[(c + 1) % CH]), "s"(b));           // acc = x * s[tap] + 0
                 if (MODE == 8) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(v[c]) : "v"(v[(c + 1) % CH]), "v"(v[(c + 2) % CH]));   // three VGPR pairs
+                // round 6: the classes the counting select (pss_post.h) and the float32 scanner epilogue are made of
+                if (MODE == 10) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v[c]) : "v"(v[(c + 1) % CH]), "v"(v[(c + 2) % CH]));   // packed: two float32 FMAs per lane
+                if (MODE == 11) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(v[c]) : "v"(v[(c + 1) % CH]));
+                if (MODE == 12) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(f[c]), "v"(f[(c + 1) % CH]) : "vcc");                  // compare into VCC
+                if (MODE == 13) { asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(reinterpret_cast<unsigned &>(f[c])) : "v"(f[(c + 1) % CH]), "v"(i) : "vcc"); }   // the counting pair (x2)
+                if (MODE == 14) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[c]) : "v"(f[(c + 1) % CH]) : "vcc");
+                if (MODE == 15) asm volatile("v_min_u32 %0, %0, %1" : "+v"(reinterpret_cast<unsigned &>(f[c])) : "v"(i));
+                if (MODE == 16) asm volatile("v_cmp_gt_u64 vcc, %0, %1" : : "v"(v[c]), "v"(v[(c + 1) % CH]) : "vcc");                  // 64-bit compare
+                if (MODE == 17) asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(reinterpret_cast<unsigned &>(f[c])));   // a DPP step of a wave reduction (with its hazard nop)
+                if (MODE == 18) { unsigned s_; asm volatile("v_readlane_b32 %0, %1, 16" : "=s"(s_) : "v"(f[c])); asm volatile("" :: "s"(s_)); }
+                if (MODE == 19) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(f[c]) : "v"(f[(c + 1) % CH]), "s"((unsigned long long)blockIdx.x * 0x9e3779b97f4a7c15ull));   // mask in an SGPR pair
+                if (MODE == 20) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[c]) : "v"(f[(c + 1) % CH]) : "vcc");   // compare + select (x2)
+                if (MODE == 21) { float t_; asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(t_) : "v"(f[c]), "v"(f[(c + 1) % CH]) : "vcc"); asm volatile("" :: "v"(t_)); }   // result never read
                 if (MODE == 9) { asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(v[c]) : "v"(f[c]));                                // cvt feeding an fma
                                  asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(v[(c + 3) % CH]) : "v"(v[c]), "s"(b)); }
             }
@@ -78,6 +91,18 @@ int main(int argc, char **argv)
         run<7>("fma v,s,0", w, ghz);
         run<8>("fma v,v,acc", w, ghz);
         run<9>("cvt+fma (x2)", w, ghz);
+        run<10>("v_pk_fma_f32", w, ghz);
+        run<11>("v_pk_mul_f32", w, ghz);
+        run<12>("v_cmp_lt_u32", w, ghz);
+        run<13>("cmp+addc (x2)", w, ghz);
+        run<14>("v_cndmask_b32", w, ghz);
+        run<15>("v_min_u32", w, ghz);
+        run<16>("v_cmp_gt_u64", w, ghz);
+        run<17>("nop+add_dpp", w, ghz);
+        run<18>("v_readlane", w, ghz);
+        run<19>("cndmask sgpr", w, ghz);
+        run<20>("cmp+cndmask(x2)", w, ghz);
+        run<21>("cndmask indep", w, ghz);
     }
     return 0;
 }
