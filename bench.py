@@ -608,6 +608,22 @@ def main():
         import bench_configs
         other = bench_configs.other_configs(eng, dev, verify=not args.no_verify, skip={"cells": (), "f64": ("cfg2_exact_cells",), "f32": ("cfg2_f32_rows",)}[args.rows])
 
+    # per-rank readings gathered over the process group, so that ONE line shows whether a slow N-GPU step is rank 0's gather sharing its own
+    # step's HBM (rank 0's compute_ms against the others'), the exchange itself, or a slower GPU (clocks): BASELINE.md §10's suspects (i) - (iii)
+    per_rank = None
+    if dist is not None:
+        mine = torch.tensor([elapsed / args.steps * 1e3, side.get("compute_ms") or float("nan"), float(clk0 or 0), float(clk1 or 0),
+                             ktimes.get("k_nfm_fwd", float("nan"))], dtype=torch.float64, device=dev)
+        if rank != 0:      # (rank 0 sampled its clock above; the other ranks read theirs here, under a short load)
+            for k in range(8):
+                compute(k & 1)
+            mine[2] = mine[3] = float(shader_clock_mhz(dev.index or 0) or 0)
+            eng.sync()
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        cols = torch.stack(allr).cpu().tolist()
+        per_rank = {"ms_per_step": [round(c[0], 4) for c in cols], "compute_ms": [None if c[1] != c[1] else round(c[1], 4) for c in cols],
+                    "shader_clock_mhz": [int(c[2]) or None for c in cols], "k_nfm_fwd_ms": [None if c[4] != c[4] else round(c[4], 4) for c in cols]}
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -703,6 +719,16 @@ def main():
                       "devices_visible": torch.cuda.device_count()},
             "src_hash": source_hash(),
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            # BASELINE.md §10, from the measured single-GPU parts: every rank computes its own batch (no data-path collective), the 17 MB
+            # gather of lines + PCM rides behind the next step -> ms_per_step = the 1-GPU step + launch / event overhead; "1 GPU" = 0.98-1.05 ms
+            one = (0.98, 1.05)
+            out["predicted"] = {"ms_per_step": [one[0] + 0.03, one[1] + 0.10], "scaling_vs_1gpu": [round(world * one[0] / (one[1] + 0.10), 2), float(world)],
+                                "exchange_display_ms": [0.15, 0.25], "basis": "BASELINE.md §10 (default --exchange display, weak scaling)",
+                                "if_slower": "(i) rank 0's compute_ms above the others' = its gather shares its step's HBM / copy engines; (ii) "
+                                             "exchange_display_ms >> 0.25 = RCCL serialises the peers; (iii) per_rank.shader_clock_mhz / "
+                                             "k_nfm_fwd_ms differ = a slower GPU"}
         out.update(side)
         if other is not None:
             out["other_configs"] = other

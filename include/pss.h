@@ -266,6 +266,20 @@ int pss_frame_pipeline_cells(pss_ctx *ctx, int mode, const float *d_iq, long n_f
 int pss_spectrum_cells(pss_ctx *ctx, const float *d_iq, long n_frames, int n, float *d_db32, double *d_db64, double *d_row_lo,
                        double *d_row_hi, int n_halo, int window, int display, int disp_h, int disp_w, int8_t *d_line_a, int8_t *d_line_b);
 
+/* complex128 read buffers.  The reference's SDR buffer is complex64 (pyspecsdr.py:1887), but its functions accept any array, and handed
+ * complex128 they compute in float64 from the first statement on.  These entry points serve compute_fft (signal_processing.py:243-264: the
+ * window product is float64 x float64) and demodulate_am (:179-195: np.abs / np.mean / the subtraction in float64 — the same scaled hypot and
+ * pairwise tree as the complex64 loops, one type wider) for such buffers: float64 dB rows to ~1e-10 of NumPy's, AM audio and int16 PCM bit
+ * for bit (tests/golden/c128.npz).  Plain kernels — a conformance path for callers that hold float64 samples, not a throughput path.
+ * The other demodulators narrow complex128 input to complex64 (np.angle on complex128 is libm's float64 atan2: not restated).
+ *   d_iq / h_iq: interleaved float64 (re, im); n_fft a power of two in [16, 65536] (PSS_E_ARG otherwise); demodulate_am: any n >= 1
+ *   pss_demod_am_c128: d_pcm int16 [n_frames][n][2] and / or d_audio float64 [n_frames][n] (mono); pss_h_*: one buffer, host pointers,
+ *   h_audio_stereo float64 [n][2] */
+int pss_spectrum_db_c128(pss_ctx *ctx, const double *d_iq, long n_frames, int n_fft, double *d_db);
+int pss_demod_am_c128(pss_ctx *ctx, const double *d_iq, long n_frames, int n, int16_t *d_pcm, double *d_audio);
+int pss_h_compute_fft_c128(pss_ctx *ctx, const double *h_iq, int n, double *h_db);
+int pss_h_demodulate_am_c128(pss_ctx *ctx, const double *h_iq, int n, double *h_audio_stereo, int16_t *h_pcm);
+
 /* Waterfall / persistence quantisers over a ring of post-processed rows (pyspecsdr.py:1342-1406,
  * :1512-1564).  d_rows float32 [n_rows][len], oldest first (n_rows <= 30 / <= 10).
  * d_glyph/d_colour int8 [disp_h][disp_w] (-1 = not drawn; persistence: 0 = empty). */

@@ -388,6 +388,25 @@ void pss_o_compute_fft(const float *iq, int n, double *db)
     free(im);
 }
 
+/* compute_fft on a complex128 buffer (`samples * window` is then a float64 product of float64 samples, :247): the same statements, no narrowing. */
+void pss_o_compute_fft_c128(const double *iq, int n, double *db)
+{
+    double *re = (double *)malloc(sizeof(double) * n), *im = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) {
+        const double w = (n == 1) ? 1.0 : 0.54 - 0.46 * cos(2.0 * M_PI * (double)i / (double)(n - 1));
+        re[i] = iq[2 * i] * w;
+        im[i] = iq[2 * i + 1] * w;
+    }
+    fft_any_f64(re, im, n);
+    for (int k = 0; k < n; k++) {
+        int src = (k + (n + 1) / 2) % n;
+        double a = hypot(re[src], im[src]);
+        db[k] = 10.0 * log10(a * a + 1e-10);
+    }
+    free(re);
+    free(im);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * classify_signal — signal_processing.py:296-322 (helpers :267-293), SURVEY §8(f) #3.
  * The reference calls `welch` without importing it (NameError on every call, App. C2); this is the function as it
@@ -905,6 +924,60 @@ void pss_o_demod_am(const float *iq, int n, const double *sos, int nsec, double 
     if (has_nan) mx = NAN;
     for (int i = 0; i < n; i++) audio[i] = (audio[i] / mx) * 0.95;                  /* :194 */
     free(e);
+}
+
+/* demodulate_am on a complex128 buffer (signal_processing.py:179-195 with float64 samples): numpy.abs(complex128) is the same scaled hypot as
+ * the complex64 loop, in float64 — mx * sqrt(fma(r, r, 1)), r = mn / mx (probed: 200 000 random values, every bit) —, np.mean the same pairwise
+ * tree over float64 (8192-element buffer chunks added up in order; blocks of 128 with 8 accumulators), the subtraction float64. */
+double pss_o_cabs(double re, double im)
+{
+    double a = fabs(re), b = fabs(im);
+    double mx = a > b ? a : b, mn = a > b ? b : a;
+    if (mx == 0.0) return 0.0;
+    double r = mn / mx;
+    return mx * sqrt(fma(r, r, 1.0));
+}
+static double pairwise_chunk_f64(const double *a, long n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (long i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        long i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        long n2 = n / 2;
+        n2 -= n2 % 8;
+        return pairwise_chunk_f64(a, n2) + pairwise_chunk_f64(a + n2, n - n2);
+    }
+}
+double pss_o_pairwise_sum_f64(const double *a, long n)
+{
+    const long B = 8192;
+    if (n <= B) return pairwise_chunk_f64(a, n);
+    double acc = pairwise_chunk_f64(a, B);
+    for (long st = B; st < n; st += B) acc += pairwise_chunk_f64(a + st, (n - st) < B ? (n - st) : B);
+    return acc;
+}
+void pss_o_demod_am_c128(const double *iq, int n, const double *sos, int nsec, double *audio)
+{
+    for (int i = 0; i < n; i++) audio[i] = pss_o_cabs(iq[2 * i], iq[2 * i + 1]);   /* :182 */
+    const double mu = pss_o_pairwise_sum_f64(audio, n) / (double)n;                /* :185 np.mean (float64) */
+    for (int i = 0; i < n; i++) audio[i] = audio[i] - mu;
+    double z[16] = {0};
+    sosfilt_inplace(sos, nsec, audio, n, z);                                       /* :191 -> :42 sosfilt */
+    double mx = 0.0;
+    int has_nan = 0;
+    for (int i = 0; i < n; i++) { double a = fabs(audio[i]); if (a != a) has_nan = 1; if (a > mx) mx = a; }
+    if (has_nan) mx = NAN;
+    for (int i = 0; i < n; i++) audio[i] = (audio[i] / mx) * 0.95;                 /* :194 */
 }
 
 /* scipy.signal.lfilter(b=[b0], a=[1, a1], x) — _sigtools._linear_filter (lfilter.c.in, double loop), b zero-padded

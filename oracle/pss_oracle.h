@@ -35,6 +35,7 @@ float pss_o_log10f_ref(float x);             /* = pss_o_log10f_np (kept for call
 
 /* compute_fft — signal_processing.py:243-264.  db[n] float64, DC-centred. */
 void pss_o_compute_fft(const float *iq, int n, double *db);
+void pss_o_compute_fft_c128(const double *iq, int n, double *db);     /* complex128 buffer: float64 window product */
 /* caller post-process — pyspecsdr.py:2278-2283.  out[n-4]. */
 void pss_o_postprocess(const double *db, int n, double *out);
 /* measure_signal_power — signal_processing.py:325-328 (float32 throughout). */
@@ -54,6 +55,9 @@ int pss_o_demod_nfm(const float *iq, int n, double fs, int q, const double *taps
                     const double *zi, double *audio, float *disc_out, double *fir_out);
 /* demodulate_am — signal_processing.py:179-195 (+ bandpass_filter :34-42). sos[5][6]. audio[n]. */
 void pss_o_demod_am(const float *iq, int n, const double *sos, int nsec, double *audio);
+void pss_o_demod_am_c128(const double *iq, int n, const double *sos, int nsec, double *audio);   /* complex128 buffer: float64 abs / mean */
+double pss_o_cabs(double re, double im);
+double pss_o_pairwise_sum_f64(const double *a, long n);
 /* demodulate_ssb — signal_processing.py:198-217. taps[65] = firwin(65, 3000/fs). audio[n].
  * hilbert(real(z)).real is restated as real(z) (identity up to 1e-15 round-off). */
 void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio);

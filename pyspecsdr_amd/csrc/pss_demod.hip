@@ -3625,6 +3625,157 @@ extern "C" int pss_sosfilt(pss_ctx *ctx, const double *d_x, long n_rows, int n, 
     return pss_hip_check(ctx, hipGetLastError(), "k_sosfilt launch");
 }
 
+// ---- complex128 read buffers: demodulate_am in float64 from the first statement (signal_processing.py:179-195) ---------------------------------
+// The reference's SDR buffer is complex64, but handed complex128 its functions compute in float64: np.abs(complex128) is the same scaled hypot
+// as the complex64 loop in float64 (mx * sqrt(fma(r, r, 1)), r = mn / mx; probed bit for bit), np.mean the same pairwise tree over float64
+// (8192-element chunks added in order; blocks of 128 with 8 accumulators), the subtraction float64; sosfilt and the normalisation are float64
+// anyway.  Plain kernels, one workgroup per frame, the mean by one thread — a conformance path, not a throughput path.
+namespace {
+__device__ double cabs_np64(double re, double im)
+{
+    const double a = fabs(re), b = fabs(im);
+    const double mx = a > b ? a : b, mn = a > b ? b : a;
+    if (mx == 0.0) return 0.0;
+    const double r = __ddiv_rn(mn, mx);
+    return __dmul_rn(mx, __dsqrt_rn(__fma_rn(r, r, 1.0)));
+}
+// numpy's DOUBLE_pairwise_sum over a[0 .. n), n <= 8192: the recursion as an explicit post-order walk (depth <= 7)
+__device__ double pairwise_chunk_f64(const double *a, int n)
+{
+    struct Fr { int off, len, st; double left; };
+    Fr stk[12];
+    int sp = 0;
+    double ret = 0.0;
+    stk[sp++] = Fr{0, n, 0, 0.0};
+    while (sp > 0) {
+        Fr &fr = stk[sp - 1];
+        if (fr.len <= 128) {
+            const double *x = a + fr.off;
+            const int len = fr.len;
+            double res;
+            if (len < 8) {
+                res = 0.0;
+                for (int i = 0; i < len; i++) res = __dadd_rn(res, x[i]);
+            } else {
+                double r[8];
+                for (int j = 0; j < 8; j++) r[j] = x[j];
+                int i = 8;
+                for (; i < len - (len % 8); i += 8)
+                    for (int j = 0; j < 8; j++) r[j] = __dadd_rn(r[j], x[i + j]);
+                res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])), __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+                for (; i < len; i++) res = __dadd_rn(res, x[i]);
+            }
+            ret = res;
+            sp--;
+        } else if (fr.st == 0) {
+            int n2 = fr.len / 2;
+            n2 -= n2 % 8;
+            fr.st = 1;
+            stk[sp] = Fr{fr.off, n2, 0, 0.0};
+            sp++;
+        } else if (fr.st == 1) {
+            int n2 = fr.len / 2;
+            n2 -= n2 % 8;
+            fr.left = ret;
+            fr.st = 2;
+            stk[sp] = Fr{fr.off + n2, fr.len - n2, 0, 0.0};
+            sp++;
+        } else {
+            ret = __dadd_rn(fr.left, ret);
+            sp--;
+        }
+    }
+    return ret;
+}
+// envelope |x| (float64), its mean, X[f][i] = |x[i]| - mean
+__global__ __launch_bounds__(256) void k_am_env_c128(const double2 *__restrict__ iq, int n, long n_frames, double *__restrict__ X)
+{
+    __shared__ double mu_s;
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const double2 *x = iq + (size_t)f * n;
+        double *e = X + (size_t)f * n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) e[i] = cabs_np64(x[i].x, x[i].y);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double acc = pairwise_chunk_f64(e, n < 8192 ? n : 8192);
+            for (int st = 8192; st < n; st += 8192) acc = __dadd_rn(acc, pairwise_chunk_f64(e + st, (n - st) < 8192 ? (n - st) : 8192));
+            mu_s = __ddiv_rn(acc, (double)n);
+        }
+        __syncthreads();
+        const double mu = mu_s;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) e[i] = __dsub_rn(e[i], mu);
+        __syncthreads();
+    }
+}
+// audio / np.max(np.abs(audio)) * 0.95 (:194; np.max propagates a NaN), mono float64 and / or int16 stereo
+__global__ __launch_bounds__(256) void k_norm_rows_f64(const double *__restrict__ Y, int n, long n_frames, int16_t *__restrict__ pcm, double *__restrict__ audio)
+{
+    __shared__ double red[256];
+    __shared__ int nan_s[256];
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const double *y = Y + (size_t)f * n;
+        double mx = 0.0;
+        int has_nan = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const double a = fabs(y[i]);
+            has_nan |= a != a;
+            mx = a > mx ? a : mx;
+        }
+        red[threadIdx.x] = mx;
+        nan_s[threadIdx.x] = has_nan;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) {
+                red[threadIdx.x] = red[threadIdx.x + st] > red[threadIdx.x] ? red[threadIdx.x + st] : red[threadIdx.x];
+                nan_s[threadIdx.x] |= nan_s[threadIdx.x + st];
+            }
+            __syncthreads();
+        }
+        const double peak = nan_s[0] ? __builtin_nan("") : red[0];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const double a = __dmul_rn(__ddiv_rn(y[i], peak), 0.95);
+            if (audio) audio[(size_t)f * n + i] = a;
+            if (pcm) {
+                const uint16_t s16 = (uint16_t)pcm16(a);
+                reinterpret_cast<uint32_t *>(pcm)[(size_t)f * n + i] = (uint32_t)s16 | ((uint32_t)s16 << 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+// demodulate_am of complex128 frames: d_iq interleaved float64 (re, im) [n_frames][n]; d_pcm int16 [n_frames][n][2] and / or d_audio float64
+// [n_frames][n] (mono, before stereo duplication).  Same results as the reference handed a complex128 buffer (tests/golden/c128.npz).
+extern "C" int pss_demod_am_c128(pss_ctx *ctx, const double *d_iq, long n_frames, int n, int16_t *d_pcm, double *d_audio)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames < 0 || n < 1 || (n_frames > 0 && (!d_iq || (!d_pcm && !d_audio)))) return pss_fail(ctx, PSS_E_ARG, "pss_demod_am_c128: bad argument");
+    if (n_frames == 0) return PSS_OK;
+    const size_t rows = align256((size_t)n_frames * n * sizeof(double));
+    int r = pss_ensure_scratch(ctx, 2 * rows);
+    if (r) return r;
+    double *X = reinterpret_cast<double *>(ctx->scratch), *Y = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->scratch) + rows);
+    double sos[30];
+    pss_am_bandpass_sos(sos);
+    pss_time_begin(ctx);
+    pss_kernel_begin(ctx, "k_am_env_c128");
+    hipLaunchKernelGGL(k_am_env_c128, dim3((unsigned)(n_frames < 4096 ? n_frames : 4096)), dim3(256), 0, PSS_STREAM(ctx), reinterpret_cast<const double2 *>(d_iq), n,
+                       n_frames, X);
+    pss_kernel_end(ctx);
+    r = pss_hip_check(ctx, hipGetLastError(), "k_am_env_c128 launch");
+    if (!r) r = pss_sosfilt(ctx, X, n_frames, n, sos, 5, Y);
+    if (!r) {
+        pss_kernel_begin(ctx, "k_norm_rows_f64");
+        hipLaunchKernelGGL(k_norm_rows_f64, dim3((unsigned)(n_frames < 4096 ? n_frames : 4096)), dim3(256), 0, PSS_STREAM(ctx), Y, n, n_frames, d_pcm, d_audio);
+        pss_kernel_end(ctx);
+        r = pss_hip_check(ctx, hipGetLastError(), "k_norm_rows_f64 launch");
+    }
+    pss_time_end(ctx);
+    return r;
+}
+
 extern "C" int pss_afsk_n_bits(int n, double fs)
 {
     const int w = (int)(fs / 1200.0);

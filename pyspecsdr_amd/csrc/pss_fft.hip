@@ -108,7 +108,8 @@ using pss_r16::db_of;   // 10 log10(pw) to float64 accuracy, rounded once to flo
 
 // D64: the row type of the reference itself — db points at float64 rows, 10 log10(|X|^2 + 1e-10) evaluated in float64 as compute_fft does
 // (np.abs = hypot, squared, + 1e-10, log10); for callers that need the display cells of the float64 rows (pss_spectrum_db_f64).
-template <bool SCAN, bool EXACT = false, bool D64 = false>
+// IN64 (with D64): `iq` points at complex128 frames (interleaved float64): `samples * window` is then a float64 product of float64 samples (:247)
+template <bool SCAN, bool EXACT = false, bool D64 = false, bool IN64 = false>
 __global__ __launch_bounds__(TPB) void k_spectrum(const float2 *__restrict__ iq, float *__restrict__ db,
                                                   const double2 *__restrict__ tw, const double *__restrict__ win,
                                                   int N, int logNsub, int R, long n_frames, int staged,
@@ -123,22 +124,26 @@ __global__ __launch_bounds__(TPB) void k_spectrum(const float2 *__restrict__ iq,
     __shared__ int red_i[TPB / 64];
     const int tid = threadIdx.x;
     for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
-        const float2 *x = iq + (size_t)f * N;
+        const float2 *x = iq + (size_t)f * N * (IN64 ? 2 : 1);
         float *out = db ? db + (size_t)f * N : nullptr;
+        auto sample = [&](int idx) -> double2 {
+            if constexpr (IN64) return reinterpret_cast<const double2 *>(x)[idx];
+            else { const float2 v = x[idx]; return make_double2((double)v.x, (double)v.y); }
+        };
         for (int r = 0; r < R; r++) {
             for (int n = tid; n < Nsub; n += TPB) {
                 double2 acc;
                 if (R == 1) {
-                    float2 v = x[n];
+                    double2 v = sample(n);
                     double w = SCAN ? 1.0 : win[n];
-                    acc = make_double2((double)v.x * w, (double)v.y * w);
+                    acc = make_double2(v.x * w, v.y * w);
                 } else {
                     acc = make_double2(0.0, 0.0);
                     for (int q = 0; q < R; q++) {
                         int idx = n + Nsub * q;
-                        float2 v = x[idx];
+                        double2 v = sample(idx);
                         double w = SCAN ? 1.0 : win[idx];
-                        double2 a = make_double2((double)v.x * w, (double)v.y * w);
+                        double2 a = make_double2(v.x * w, v.y * w);
                         int e = (q * r) & (R - 1);  // W_R^{qr} = tw[((q r) mod R) * Nsub]
                         acc = cadd(acc, cmul(a, tw[(size_t)e * Nsub]));
                     }
@@ -1476,6 +1481,36 @@ extern "C" int pss_spectrum_db_f64(pss_ctx *ctx, const float *d_iq, long n_frame
     pss_kernel_end(ctx);
     pss_time_end(ctx);
     return pss_hip_check(ctx, hipGetLastError(), "k_spectrum (float64 rows) launch");
+}
+
+// compute_fft of complex128 frames (signal_processing.py:243-264 handed a complex128 buffer: float64 from the window product on): d_iq interleaved
+// float64 (re, im) [n_frames][n_fft], d_db float64 [n_frames][n_fft].  The plain LDS transform (a conformance path: the reference's SDR
+// buffer is complex64); n_fft a power of two in [16, 65536].
+extern "C" int pss_spectrum_db_c128(pss_ctx *ctx, const double *d_iq, long n_frames, int n_fft, double *d_db)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames < 0 || (n_frames > 0 && (!d_iq || !d_db))) return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_db_c128: null buffer / negative n_frames");
+    if (n_fft < 16 || n_fft > 65536 || (n_fft & (n_fft - 1)))
+        return pss_fail(ctx, PSS_E_ARG, "pss_spectrum_db_c128: n_fft must be a power of two in [16, 65536]");
+    if (n_frames == 0) return PSS_OK;
+    const double2 *tw;
+    const double *win;
+    int r = pss_fft_tables(ctx, n_fft, &tw, &win);
+    if (r) return r;
+    const int logn = ilog2(n_fft), logNsub = logn < LOG_NSUB_MAX ? logn : LOG_NSUB_MAX;
+    const size_t lds = ((size_t)1 << logNsub) * sizeof(double2);
+    auto kern = k_spectrum<false, false, true, true>;
+    if (lds > 64 * 1024) PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((160 * 1024) / (lds + 64));
+    per_cu = per_cu > 8 ? 8 : per_cu;
+    pss_time_begin(ctx);
+    pss_kernel_begin(ctx, "k_spectrum_c128");
+    hipLaunchKernelGGL(kern, dim3(grid_for(n_frames, per_cu)), dim3(TPB), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq),
+                       reinterpret_cast<float *>(d_db), tw, win, n_fft, logNsub, n_fft >> logNsub, n_frames, 0, nullptr, nullptr, nullptr, 0.0, 0);
+    pss_kernel_end(ctx);
+    pss_time_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_spectrum (complex128 frames) launch");
 }
 
 // dB rows of the scanner's unwindowed fft into d_db or, when the caller wants only the per-slice numbers, into scratch

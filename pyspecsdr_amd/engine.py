@@ -546,6 +546,27 @@ class Engine:
         self._ck(self.lib.pss_h_compute_fft(self.h, _ptr(iq), len(iq), _ptr(out)))
         return out
 
+    def h_compute_fft_c128(self, iq):
+        """compute_fft of a complex128 buffer, float64 from the window product on (len(iq): a power of two in 16..65536)."""
+        iq = np.ascontiguousarray(iq, np.complex128)
+        out = np.empty(len(iq), np.float64)
+        self._ck(self.lib.pss_h_compute_fft_c128(self.h, _ptr(iq), len(iq), _ptr(out)))
+        return out
+
+    def h_demodulate_am_c128(self, iq):
+        """demodulate_am of a complex128 buffer (float64 np.abs / np.mean): (audio float64 (n, 2), pcm int16 (n, 2))."""
+        iq = np.ascontiguousarray(iq, np.complex128)
+        audio = np.empty((len(iq), 2), np.float64)
+        pcm = np.empty((len(iq), 2), np.int16)
+        self._ck(self.lib.pss_h_demodulate_am_c128(self.h, _ptr(iq), len(iq), _ptr(audio), _ptr(pcm)))
+        return audio, pcm
+
+    def spectrum_db_c128(self, d_iq, n_frames, n_fft, d_db):
+        self._dev(self.lib.pss_spectrum_db_c128, _ptr(d_iq), n_frames, n_fft, _ptr(d_db))
+
+    def demod_am_c128(self, d_iq, n_frames, n, d_pcm, d_audio):
+        self._dev(self.lib.pss_demod_am_c128, _ptr(d_iq), n_frames, n, _ptr(d_pcm), _ptr(d_audio))
+
     def h_demodulate(self, mode, iq, fs):
         iq = np.ascontiguousarray(iq, np.complex64)
         n_out = self.demod_out_len(mode, len(iq), fs)

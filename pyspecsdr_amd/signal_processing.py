@@ -114,8 +114,8 @@ _warned_narrowing = False
 
 def _samples(samples):
     """The reference's read buffer is complex64 (pyspecsdr.py:1885-1891) and the kernels replay NumPy's complex64
-    arithmetic; wider input (complex128) would make the reference compute in float64, which is NOT what happens here —
-    it is narrowed, with a one-time warning."""
+    arithmetic; wider input (complex128) makes the reference compute in float64.  compute_fft (power-of-two lengths) and
+    demodulate_am serve such buffers in float64 (pss_h_*_c128); everywhere else it is narrowed, with a one-time warning."""
     global _warned_narrowing
     s = np.asarray(samples)
     if s.ndim != 1:
@@ -199,7 +199,15 @@ def iq_correction(samples):
     return get_engine().h_iq_correction(_samples(samples))
 
 
+def _is_c128(samples):
+    s = np.asarray(samples)
+    return s.ndim == 1 and s.dtype == np.complex128
+
+
 def compute_fft(samples):
+    # a complex128 buffer of a power-of-two length: float64 from the window product on, as the reference computes it (no narrowing)
+    if _is_c128(samples) and 16 <= len(samples) <= 65536 and (len(samples) & (len(samples) - 1)) == 0:
+        return get_engine().h_compute_fft_c128(samples)
     return get_engine().h_compute_fft(_samples(samples))
 
 
@@ -220,6 +228,8 @@ def demodulate_wfm(samples, sample_rate, target_rate=DEFAULT_SAMPLE_RATE):
 
 
 def demodulate_am(samples):
+    if _is_c128(samples) and len(samples) >= 1:        # float64 np.abs / np.mean, as the reference computes it for such a buffer (no narrowing)
+        return get_engine().h_demodulate_am_c128(samples)[0]
     audio, _ = get_engine().h_demodulate(L.MODE_AM, _samples(samples), float(DEFAULT_SAMPLE_RATE))
     return audio
 

@@ -41,6 +41,7 @@ def lib():
         L.pss_o_cabsf.argtypes = [C.c_float, C.c_float]
         L.pss_o_pairwise_sum_f32.restype = C.c_float
         L.pss_o_pairwise_sum_f32.argtypes = [_f32p, C.c_long]
+        L.pss_o_cabs.restype, L.pss_o_cabs.argtypes = C.c_double, [C.c_double, C.c_double]
         L.pss_o_compute_fft.argtypes = [_f32p, C.c_int, _f64p]
         L.pss_o_postprocess.argtypes = [_f64p, C.c_int, _f64p]
         L.pss_o_iq_correction.argtypes = [_f32p, C.c_int, _f32p]
@@ -123,6 +124,27 @@ def cabsf(re, im):
 def compute_fft(iq):
     out = np.empty(len(iq), np.float64)
     lib().pss_o_compute_fft(_iq(iq), len(iq), out)
+    return out
+
+
+def compute_fft_c128(iq):
+    """compute_fft of a complex128 buffer (float64 window product)."""
+    x = np.ascontiguousarray(iq, np.complex128)
+    out = np.empty(len(x), np.float64)
+    f = lib().pss_o_compute_fft_c128
+    f.argtypes, f.restype = [_f64p, C.c_int, _f64p], None
+    f(x.view(np.float64), len(x), out)
+    return out
+
+
+def demod_am_c128(iq, sos):
+    """demodulate_am of a complex128 buffer (float64 np.abs / np.mean)."""
+    x = np.ascontiguousarray(iq, np.complex128)
+    sos = np.ascontiguousarray(sos, np.float64)
+    out = np.empty(len(x), np.float64)
+    f = lib().pss_o_demod_am_c128
+    f.argtypes, f.restype = [_f64p, C.c_int, _f64p, C.c_int, _f64p], None
+    f(x.view(np.float64), len(x), sos, sos.shape[0], out)
     return out
 
 

@@ -468,3 +468,28 @@ def test_round5_arguments_oracle_vs_reference(golden):
     for t in g["morse_tags"]:
         r, f = O.morse_edges(g[f"m_iq_{t}"], float(g[f"m_thr_{t}"]))
         assert np.array_equal(r, g[f"m_rise_{t}"]) and np.array_equal(f, g[f"m_fall_{t}"]), t
+
+
+def test_round6_complex128_buffers_oracle_vs_reference(golden):
+    """tests/golden/c128.npz (tools/make_goldens_round6.py: the reference handed complex128 read buffers — it then computes compute_fft and
+    demodulate_am in float64 from the first statement): the oracle's float64 restatements — np.abs(complex128) as the scaled hypot in float64,
+    np.mean as the float64 pairwise tree — give the reference's audio and int16 PCM bit for bit at every length (1024 ... 32 768, 1000, 37) and
+    its dB rows to 1e-9; the inputs are not representable in complex64 (narrowing them changes the results, which is what rounds 1-5 did)."""
+    g = golden["c128"]
+    sos = g["am_sos"]
+    for t in g["tags"]:
+        for k, x in enumerate(g[f"iq_{t}"]):
+            assert x.dtype == np.complex128 and not np.array_equal(x, x.astype(np.complex64).astype(np.complex128))
+            assert np.array_equal(np.array([O.lib().pss_o_cabs(float(v.real), float(v.imag)) for v in x[:64]]), g[f"abs_{t}"][:64]) or k > 0
+            db = O.compute_fft_c128(x)
+            assert np.allclose(db, g[f"db_{t}"][k], rtol=1e-9, atol=1e-9), (t, k)
+            au = O.demod_am_c128(x, sos)
+            assert np.array_equal(au, g[f"audio_{t}"][k]), (t, k)
+            assert np.array_equal(np.int16(au * 32767), g[f"pcm_{t}"][k]), (t, k)
+            # narrowing to complex64 first (rounds 1-5) does NOT give these bits
+            if len(x) >= 1000:
+                assert not np.array_equal(O.demod_am(x.astype(np.complex64), sos), g[f"audio_{t}"][k])
+    with np.errstate(all="ignore"):
+        z = g["iq_z"][0]
+        assert np.array_equal(O.compute_fft_c128(z), g["db_z"][0])                 # every bin exactly -100 dB
+        assert np.all(np.isnan(O.demod_am_c128(z, sos))) and np.all(np.isnan(g["audio_z"][0]))   # silence -> 0 / 0

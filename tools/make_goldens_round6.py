@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Golden vectors for complex128 read buffers (tests/golden/c128.npz) — made like tools/make_goldens.py: the build container imports the
+reference's own module from /root/reference, feeds it seeded synthetic inputs and stores DATA only (inputs, outputs, SciPy's filter table).
+
+The reference's SDR read buffer is complex64 (pyspecsdr.py:1887), but its functions accept any array; handed complex128 they compute in float64
+from the first statement on:
+    compute_fft    (signal_processing.py:243-264): `samples * window` is a float64 product of float64 samples
+    demodulate_am  (:179-195): np.abs / np.mean / the subtraction in float64 (complex64 input: float32)
+Rounds 1-5 narrowed such input to complex64 with a warning; round 6 serves these two functions in float64.
+
+    python tools/make_goldens_round6.py
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import numpy as np
+import scipy.signal as ss
+
+import make_goldens as mg            # the generators' helpers (stamp, save); importing it stubs nothing and writes nothing
+import signal_processing as sp      # the reference hot path
+
+
+def main():
+    d = {}
+    rng = np.random.default_rng(606)
+    tags = []
+    for tag, nf, n in (("a", 3, 1024), ("b", 1, 4096), ("c", 1, 16384), ("d", 2, 1000), ("e", 1, 32768), ("f", 2, 37)):
+        t = np.arange(n) / 2.4e6
+        iq = np.empty((nf, n), np.complex128)
+        for f in range(nf):
+            m = 0.5 * np.sin(2 * np.pi * 40e3 * t + 0.3 * f) + 0.3 * np.sin(2 * np.pi * 90e3 * t + 0.1 * f)
+            iq[f] = (1 + 0.5 * m) * 0.5 * np.exp(1j * (0.3 + 2 * np.pi * 1234.5 * t)) + 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        iq *= 1.0 + 1e-9 * rng.standard_normal((nf, n))        # values that are NOT representable in complex64: narrowing would change every result
+        d[f"iq_{tag}"] = iq
+        d[f"db_{tag}"] = np.stack([sp.compute_fft(x) for x in iq])                       # float64 [nf][n]
+        aud = np.stack([sp.demodulate_am(x) for x in iq])                                # float64 [nf][n][2]
+        assert np.array_equal(aud[..., 0], aud[..., 1])                                  # mono_to_stereo: the columns are equal, one is stored
+        d[f"audio_{tag}"] = aud[..., 0]
+        d[f"pcm_{tag}"] = np.int16(aud[..., 0] * 32767)
+        d[f"abs_{tag}"] = np.abs(iq[0])
+        d[f"mean_{tag}"] = np.array(np.mean(np.abs(iq[0])))
+        tags.append(tag)
+    # a frame of zeros (np.abs = 0, silence -> NaN audio -> int16 0), one with an infinity
+    z = np.zeros(512, np.complex128)
+    with np.errstate(all="ignore"):
+        d["iq_z"], d["db_z"], d["audio_z"] = z[None], sp.compute_fft(z)[None], sp.demodulate_am(z)[None][..., 0]
+        d["pcm_z"] = np.int16(np.nan_to_num(d["audio_z"], nan=0.0) * 32767)      # np.int16(NaN) = 0 on x86 (App. C); stored explicitly
+    d["tags"] = np.array(tags)
+    d["am_sos"] = ss.butter(5, [300 / 11025, 3000 / 11025], btype="band", output="sos")   # demodulate_am's filter (:188-191, fs fixed at 22 050)
+    mg.save("c128", **d)
+
+
+if __name__ == "__main__":
+    main()
