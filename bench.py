@@ -664,6 +664,17 @@ def main():
                                  "ops_per_sample": NFM_FWD_F64_OPS_PER_SAMPLE,
                                  "note": "the kernel's binding roof: 63 fma + 51 add + 12 mul float64 per sample are fixed by the "
                                          "reference's accumulation order; peak = 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz"}
+        elif "k_nfm_fwd" in ktimes:
+            # the step's other long kernel (the forward demodulator and the fused transform + post-process kernel are within a few per cent of each
+            # other; which of the two the untimed survey pass ranks first varies from run to run): its own numbers, from the survey pass
+            fms = ktimes["k_nfm_fwd"]
+            ops = NFM_FWD_F64_OPS_PER_SAMPLE * float(nf) * n / (fms * 1e-3)
+            roof["k_nfm_fwd"] = {"ms": round(fms, 4), "hbm_frac": ALGO_BYTES["k_nfm_fwd"] * nf / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "f64_issue_frac": ops / F64_PEAK_LANEOPS, "limiter": "f64_issue",
+                                 "note": "untimed survey pass (every launch bracketed by events, which stretches it); 126 float64 operations per "
+                                         "sample fixed by the reference's accumulation order against 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz"}
+        if dom == "k_spectrum_post":
+            roof["limiter"] = "valu_issue"      # ~2500 VALU wave-instructions per row, most of the 4-clk class (profiles/r06_valu_rate.txt, NOTEBOOK R6-04)
         roof["traffic_step"], roof["traffic_ratio"] = step_traffic(list(ktimes), nf)
         sv = step_valu(list(ktimes), nf, elapsed / args.steps * 1e3)
         if sv:
