@@ -170,8 +170,10 @@ def step_valu(kernels, n_frames, ms_per_step):
                 per[k] = round(valu_issue_ms(d), 4)
         issue_ms = sum(per.values())
         return {"issue_ms": issue_ms, "by_kernel_ms": per, "frac": issue_ms / ms_per_step,
-                "note": "VALU wave-instructions of the step's kernels by class (float64 + conversions: 4 clk, 32-bit: 2 clk per "
-                        "wavefront-instruction; rates measured by tools/ubench/valu_rate.hip) = pure issue time, over the measured step"}
+                "note": "VALU wave-instructions of the step's kernels by class (float64 + conversions: 4 clk, everything else priced at the "
+                        "float32-FMA / integer-add rate of 2.45 clk per wavefront-instruction; rates measured by tools/ubench/valu_rate.hip) = pure "
+                        "issue time, over the measured step.  A LOWER bound: integer compare / min / select / cross-lane instructions issue at the "
+                        "float64 rate (profiles/r06_valu_rate.txt), and the select kernels are made of them"}
     except Exception:  # noqa: BLE001
         return None
 

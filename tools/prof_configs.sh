@@ -8,7 +8,7 @@ TAG=${1:-r04}
 OUT=gpurun_out/prof_cfgs_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-for CFG in cfg2_f32_rows cfg3 cfg4 cfg5_resident wfm_step; do
+for CFG in cfg2_f32_rows cfg2_exact_cells cfg3 cfg4 cfg5_resident wfm_step; do
     CMD="python tools/bench_configs.py $CFG --launch-only"
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o ${CFG}_kt -- $CMD > "$OUT/${CFG}_kt.log" 2>&1
     timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT" -o ${CFG}_fetch -- $CMD > "$OUT/${CFG}_fetch.log" 2>&1
