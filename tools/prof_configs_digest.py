@@ -40,7 +40,7 @@ def source_hash():
 lines = [f"== per-config profile {tag}: source hash {source_hash()}; each config = python tools/bench_configs.py <cfg> --launch-only "
          f"({PASSES} plain passes), rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs"]
 configs = {}
-for cfg in ("cfg2_f32_rows", "cfg3", "cfg4", "cfg5_resident", "wfm_step"):
+for cfg in ("cfg2_f32_rows", "cfg2_exact_cells", "cfg3", "cfg4", "cfg5_resident", "wfm_step"):
     ctr = {}
     for name, c in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         p = os.path.join(out, f"{cfg}_{name}_counter_collection.csv")
