@@ -615,7 +615,7 @@ def main():
     per_rank = None
     if dist is not None:
         mine = torch.tensor([elapsed / args.steps * 1e3, side.get("compute_ms") or float("nan"), float(clk0 or 0), float(clk1 or 0),
-                             ktimes.get("k_nfm_fwd", float("nan"))], dtype=torch.float64, device=dev)
+                             ktimes.get(dom, float("nan"))], dtype=torch.float64, device=dev)
         if rank != 0:      # (rank 0 sampled its clock above; the other ranks read theirs here, under a short load)
             for k in range(8):
                 compute(k & 1)
@@ -625,7 +625,8 @@ def main():
         dist.all_gather(allr, mine)
         cols = torch.stack(allr).cpu().tolist()
         per_rank = {"ms_per_step": [round(c[0], 4) for c in cols], "compute_ms": [None if c[1] != c[1] else round(c[1], 4) for c in cols],
-                    "shader_clock_mhz": [int(c[2]) or None for c in cols], "k_nfm_fwd_ms": [None if c[4] != c[4] else round(c[4], 4) for c in cols]}
+                    "shader_clock_mhz": [int(c[2]) or None for c in cols], "dominant_kernel": dom,
+                    "dominant_kernel_ms": [None if c[4] != c[4] else round(c[4], 4) for c in cols]}
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -741,7 +742,7 @@ def main():
                                 "exchange_display_ms": [0.15, 0.25], "basis": "BASELINE.md §10 (default --exchange display, weak scaling)",
                                 "if_slower": "(i) rank 0's compute_ms above the others' = its gather shares its step's HBM / copy engines; (ii) "
                                              "exchange_display_ms >> 0.25 = RCCL serialises the peers; (iii) per_rank.shader_clock_mhz / "
-                                             "k_nfm_fwd_ms differ = a slower GPU"}
+                                             "dominant_kernel_ms differ = a slower GPU"}
         out.update(side)
         if other is not None:
             out["other_configs"] = other

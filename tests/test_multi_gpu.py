@@ -257,3 +257,26 @@ def test_rccl_path_runs_with_one_rank(script, extra):
         assert line["ranks"]["backend"] == "nccl" and line["n_gpus"] == 1
         assert line["verified"]["ok"] and line["verified"]["ok_all_ranks"]
         assert line["exchange_display_ms"] is not None and line["compute_ms"] is not None and line["overlap_frac"] is not None
+        # the fields the first N > 1 record is to be read against: per-rank readings gathered over the process group, the prediction
+        pr = line["per_rank"]
+        assert len(pr["ms_per_step"]) == 1 and pr["compute_ms"][0] is not None and pr["dominant_kernel_ms"][0] is not None
+        assert line["predicted"]["ms_per_step"][0] < line["predicted"]["ms_per_step"][1] and "if_slower" in line["predicted"]
+        assert list(line)[-1] == "summary" and line["summary"]["headline"]["rows"] == "cells" and line["summary"]["headline"]["cd"] == 0
+
+
+@pytest.mark.parametrize("rows", ["f64", "f32"])
+def test_bench_other_row_types_still_run(rows):
+    """bench.py --rows f64 / f32 (round 5's timed step and the float32-row step; the default since round 6 is --rows cells): a short run at a
+    fraction of the batch must verify against the oracle and print the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rows", rows, "--steps", "3", "--warmup", "1", "--regions", "2", "--frames", "4096",
+                        "--no-cpu-baseline", "--no-other-configs"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["rows"] == rows and line["verified"]["ok"] and line["config"]["materialised"]["db_rows"] == {"f64": "float64", "f32": "float32"}[rows]
+    if rows == "f64":
+        assert line["verified"]["cells_differing"] == 0
