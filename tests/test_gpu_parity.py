@@ -566,6 +566,25 @@ def test_fused_transform_post_kernel_equals_the_two_kernels():
             for k in ("lo", "hi", "a", "b"):
                 assert torch.equal(s[k].view(torch.uint8), r[k].view(torch.uint8)), (nf, k, "spectrum_cells")
             assert torch.equal(s["db32"].view(torch.int32), r["db"].float().view(torch.int32))
+        # display widths around the wavefront size and beyond the row length, an empty batch
+        nf, n = 257, 1024
+        iq = torch.randn((nf, n, 2), generator=gen, device="cuda", dtype=torch.float32) * 0.3
+        torch.cuda.synchronize()
+        for Wd in (1, 2, 63, 64, 65, 300, 1020, 1500):
+            outs = []
+            for fuse in (0, 1):
+                e.set_option("fuse_post", fuse)
+                o = dict(db=G.empty((nf, n), torch.float64), lo=G.empty((nf,), torch.float64), hi=G.empty((nf,), torch.float64),
+                         a=torch.zeros((nf, Wd), dtype=torch.int8, device="cuda"), b=torch.zeros((nf, Wd), dtype=torch.int8, device="cuda"))
+                e.spectrum_cells(iq, nf, n, None, o["db"], o["lo"], o["hi"], Wd, o["a"], o["b"])
+                e.sync()
+                outs.append(o)
+            for k in outs[0]:
+                assert torch.equal(outs[0][k].view(torch.uint8), outs[1][k].view(torch.uint8)), (Wd, k)
+        e.set_option("fuse_post", 1)
+        e.spectrum_cells(iq, 0, n, None, None, None, None, 112, None, None)        # nothing to do, nothing dereferenced
+        e.frame_pipeline_cells(L.MODE_NFM, iq, 0, n, fs, None, None, None, None, 112, None, None, None)
+        e.sync()
         # other lengths through the cells entry (float64 rows in the context's scratch + the conversion pass)
         e.set_option("fuse_post", 1)
         for nf, n in ((300, 512), (100, 2048), (9, 8192)):
