@@ -1726,6 +1726,21 @@ def test_round6_complex128_buffers_vs_reference_goldens(golden):
             want = O.demod_am_c128(x, sos)
             got = sp.demodulate_am(x)[:, 0]
         assert np.array_equal(got, want, equal_nan=True), n
+    # demodulate_nfm at a decimation factor of ONE (target_rate above half the sample rate: nothing is dropped, n - 1 output samples)
+    keep = sp.USE_SCIPY_DESIGNS
+    try:
+        for scipy_tables in (True, False):
+            sp.USE_SCIPY_DESIGNS = scipy_tables
+            sp._designed.clear()
+            for t in g["q1_tags"]:
+                fs, tr = float(g[f"n_fs_{t}"]), int(g[f"n_tr_{t}"])
+                for k, x in enumerate(g[f"n_iq_{t}"]):
+                    a = sp.demodulate_nfm(x, fs, tr)
+                    assert a.shape == (len(x) - 1, 2) and np.array_equal(a[:, 0], g[f"n_audio_{t}"][k]), (t, k, scipy_tables)
+                    assert np.array_equal(np.int16(a[:, 0] * 32767), g[f"n_pcm_{t}"][k]), (t, k)
+    finally:
+        sp.USE_SCIPY_DESIGNS = keep
+        sp._designed.clear()
     # the other functions still narrow a complex128 buffer (with the one-time warning)
     sp._warned_narrowing = False
     with pytest.warns(RuntimeWarning):

@@ -489,6 +489,12 @@ def test_round6_complex128_buffers_oracle_vs_reference(golden):
             # narrowing to complex64 first (rounds 1-5) does NOT give these bits
             if len(x) >= 1000:
                 assert not np.array_equal(O.demod_am(x.astype(np.complex64), sos), g[f"audio_{t}"][k])
+    # demodulate_nfm at a decimation factor of one (target_rate above half the sample rate)
+    for t in g["q1_tags"]:
+        fs, tr = float(g[f"n_fs_{t}"]), float(g[f"n_tr_{t}"])
+        for k, x in enumerate(g[f"n_iq_{t}"]):
+            a = O.demod_nfm(x, fs, g[f"n_taps_{t}"], g[f"n_sos_{t}"], g[f"n_zi_{t}"], target_rate=tr)
+            assert a.shape == (len(x) - 1,) and np.array_equal(a, g[f"n_audio_{t}"][k]), (t, k)
     with np.errstate(all="ignore"):
         z = g["iq_z"][0]
         assert np.array_equal(O.compute_fft_c128(z), g["db_z"][0])                 # every bin exactly -100 dB

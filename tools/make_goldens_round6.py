@@ -49,6 +49,20 @@ def main():
     with np.errstate(all="ignore"):
         d["iq_z"], d["db_z"], d["audio_z"] = z[None], sp.compute_fft(z)[None], sp.demodulate_am(z)[None][..., 0]
         d["pcm_z"] = np.int16(np.nan_to_num(d["audio_z"], nan=0.0) * 32767)      # np.int16(NaN) = 0 on x86 (App. C); stored explicitly
+    # demodulate_nfm at a decimation factor of ONE (target_rate above half the sample rate: decimate(x, 1) = cheby1(8, 0.05, 0.8) both ways, no
+    # samples dropped) — the reference's `int(sample_rate / target_rate)` (:111) reaches it; ADVICE r5 asked for a vector
+    qt = []
+    for tag, n, fs, tr, seed in (("q1a", 2048, 52920.0, 44100, 71), ("q1b", 1500, 96000.0, 50000, 72)):
+        iq = mg.fm_iq(2, n, fs, seed, dev=3e3)
+        aud = np.stack([sp.demodulate_nfm(f, fs, tr) for f in iq])
+        assert int(fs / tr) == 1 and aud.shape == (2, n - 1, 2)
+        sos = ss.cheby1(8, 0.05, 0.8, output="sos")
+        d[f"n_iq_{tag}"], d[f"n_fs_{tag}"], d[f"n_tr_{tag}"] = iq, np.array(fs), np.array(tr)
+        d[f"n_audio_{tag}"], d[f"n_pcm_{tag}"] = aud[..., 0], np.int16(aud[..., 0] * 32767)
+        d[f"n_taps_{tag}"] = ss.firwin(numtaps=65, cutoff=15000 / (fs / 2))
+        d[f"n_sos_{tag}"], d[f"n_zi_{tag}"] = sos, ss.sosfilt_zi(sos)
+        qt.append(tag)
+    d["q1_tags"] = np.array(qt)
     d["tags"] = np.array(tags)
     d["am_sos"] = ss.butter(5, [300 / 11025, 3000 / 11025], btype="band", output="sos")   # demodulate_am's filter (:188-191, fs fixed at 22 050)
     mg.save("c128", **d)
