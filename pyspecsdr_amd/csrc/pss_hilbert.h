@@ -407,8 +407,11 @@ __device__ __forceinline__ double2 rf_cq(int q)     // exp(-2 pi i q / 32) = W_N
     return make_double2(tab[q][0], tab[q][1]);
 }
 
+#ifndef PSS_EXP_SSB_WAVES    // timing experiment: -DPSS_EXP_SSB_WAVES=2 gives the kernel 256 VGPRs (no spill) at one resident frame per CU
+#define PSS_EXP_SSB_WAVES 4
+#endif
 template <int LOG_R4>   // of the M-point transform: M = 4096 << LOG_R4, frames of N = 2 M samples
-__global__ __launch_bounds__(256 << LOG_R4, 4) void k_ssb_rfft(const float2 *__restrict__ iq, double *out, const double2 *__restrict__ tw,
+__global__ __launch_bounds__(256 << LOG_R4, PSS_EXP_SSB_WAVES) void k_ssb_rfft(const float2 *__restrict__ iq, double *out, const double2 *__restrict__ tw,
                                                                long n_rows, unsigned *__restrict__ pcm, SsbTaps taps)
 {
     __shared__ double red[2][8];
