@@ -176,8 +176,8 @@ int pss_demod_out_len(int mode, int n, double fs);
 /* demodulate_nfm / demodulate_wfm's `target_rate` argument (signal_processing.py:91, :119; default DEFAULT_SAMPLE_RATE = 22050): the decimation
  * factor is int(sample_rate / target_rate) (:111).  pss_set_target_rate changes it for the context (and drops the cached decimator designs);
  * pss_demod_out_len_ctx is pss_demod_out_len at the context's target rate, pss_demod_out_len_rate at an explicit one.
- * Limitation: WFM needs int(sample_rate / target_rate) >= 2 (the reference skips its decimate() stage when the factor is 1, :152-157; that
- * shape has no kernel here: PSS_E_ARG).  NFM accepts every factor >= 1. */
+ * Every factor >= 1 is served: NFM runs decimate(x, 1) at factor 1 (as the reference does); WFM at factor 1 skips the decimate() stage as
+ * the reference does (:152-155) and normalises the de-emphasised channels (n - 1 samples per channel; plain kernels). */
 int pss_set_target_rate(pss_ctx *ctx, double target_rate);
 int pss_demod_out_len_ctx(pss_ctx *ctx, int mode, int n, double fs);
 int pss_demod_out_len_rate(int mode, int n, double fs, double target_rate);

@@ -1586,6 +1586,34 @@ __global__ __launch_bounds__(TPB) void k_wfm_finalize(const double *__restrict__
     }
 }
 
+// demodulate_wfm with int(sample_rate / target_rate) == 1: the reference skips its decimate() stage (:152-155) and normalises the de-emphasised
+// channels themselves.  One wavefront per row g = 2f + channel of k_wfm_front's extended rows: A[g][k] = U[g][EDGE + k] (row-major: k_wfm_finalize's
+// planar 2), mxrow[g] = np.max(np.abs(row)) (a NaN propagates).
+__global__ __launch_bounds__(256) void k_wfm_rows_q1(const double *__restrict__ U, long Lp, int M, long n_rows, double *__restrict__ A,
+                                                     double *__restrict__ mxrow)
+{
+    const int lane = threadIdx.x & 63;
+    for (long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6); g < n_rows; g += (long)gridDim.x * 4) {
+        const double *u = U + (size_t)g * Lp + EDGE;
+        double mx = 0.0;
+        int has_nan = 0;
+        for (int k = lane; k < M; k += 64) {
+            const double v = u[k];
+            A[(size_t)g * M + k] = v;
+            const double av = fabs(v);
+            has_nan |= av != av;
+            mx = av > mx ? av : mx;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(mx, off);
+            mx = o > mx ? o : mx;
+            has_nan |= __shfl_xor(has_nan, off);
+        }
+        if (lane == 0) mxrow[g] = has_nan ? __builtin_nan("") : mx;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // WFM for SMALL batches (the interactive loop: one frame per call).  k_wfm_fwd steps ~200 float64 instructions per sample
 // on ONE lane per frame; here every filter section is its own lane (systolic array, one frame per 16-lane DPP row, four
@@ -3337,7 +3365,8 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
     }
     if (mode == PSS_MODE_WFM) {
         const int q = (int)(fs / ctx->target_rate);
-        if (q < 2) return pss_fail(ctx, PSS_E_ARG, "WFM: sample_rate < 2 * target_rate (decimation factor int(fs / target_rate) < 2: the reference then skips its decimate() stage) is not supported");
+        if (q < 1) return pss_fail(ctx, PSS_E_ARG, "WFM: sample rate below the target rate");
+        const bool q1 = q == 1;     // the reference skips its decimate() stage (:152-155): the plain kernels, normalisation of the de-emphasised rows
         if (n - 1 <= EDGE)
             return pss_fail(ctx, PSS_E_PADLEN, "The length of the input vector x must be greater than padlen, which is 27.");
         PssWfmFilt *wf;
@@ -3359,7 +3388,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         bool b121_dec = true;  // decimator sections 1..3 with numerator exactly [1, 2, 1]: the fused kernels' shape
         for (int s1 = 1; s1 < 4; s1++)
             b121_dec = b121_dec && flt->sos[6 * s1] == 1.0 && flt->sos[6 * s1 + 1] == 2.0 && flt->sos[6 * s1 + 2] == 1.0;
-        r = pss_ensure_scratch(ctx, ((ctx->no_wfm_fused || !b121_dec) ? szU : 0) + szY + szA + szM);
+        r = pss_ensure_scratch(ctx, ((ctx->no_wfm_fused || !b121_dec || q1) ? szU : 0) + szY + szA + szM);
         if (r) return r;
         char *base = reinterpret_cast<char *>(ctx->scratch);
         double *U = reinterpret_cast<double *>(base), *Y = reinterpret_cast<double *>(base + szU);
@@ -3392,7 +3421,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         ctx->wfm_correct = false;
         ctx->wfm_scal = nullptr;
         if (correct) {
-            const bool fused_path = !(!ctx->no_small_batch && n_frames <= ctx->wfm_small_batch_max) && !ctx->no_wfm_fused && b121 && !ctx->wfm_corr_copy;
+            const bool fused_path = !(!ctx->no_small_batch && n_frames <= ctx->wfm_small_batch_max) && !ctx->no_wfm_fused && b121 && !ctx->wfm_corr_copy && !q1;
             if (fused_path) {
                 r = pss_ensure_buffer(ctx, &ctx->scratch_iqc, &ctx->scratch_iqc_bytes, (size_t)n_frames * 8 * sizeof(float), "iq_correction scalars");
                 if (!r) r = iq_correction_launch(ctx, d_iq, n_frames, n, nullptr, nullptr, reinterpret_cast<float *>(ctx->scratch_iqc));
@@ -3404,7 +3433,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             }
             if (r) { pss_time_end(ctx); return r; }
         }
-        if (!ctx->no_small_batch && n_frames <= ctx->wfm_small_batch_max) {
+        if (!q1 && !ctx->no_small_batch && n_frames <= ctx->wfm_small_batch_max) {
             // a handful of frames: one lane per filter SECTION instead of one lane per frame (k_wfm_casc, k_iir4_sys)
             const int M = n - 1;
             const size_t szR = align256((size_t)n_frames * M * sizeof(double));
@@ -3517,7 +3546,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
             pss_time_end(ctx);
             return pss_hip_check(ctx, hipGetLastError(), "wfm small-batch launch");
         }
-        if (!ctx->no_wfm_fused && b121) {
+        if (!q1 && !ctx->no_wfm_fused && b121) {
             // fused path (decimator sections 1..3 with numerator [1, 2, 1]): forward decimator pass inside the front kernel, y_fwd planar-transposed, u[] never stored
             double *Yf = reinterpret_cast<double *>(base), *Af = reinterpret_cast<double *>(base + szY);
             double *MXf = reinterpret_cast<double *>(base + szY + szA);
@@ -3550,6 +3579,20 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         hipLaunchKernelGGL(spec ? k_wfm_front<true> : k_wfm_front<false>, dim3((unsigned)tiles), dim3(TILE), 0, PSS_STREAM(ctx),
                            reinterpret_cast<const float2 *>(d_iq), U, n, n_frames, Lp, swapped, wc);
         pss_kernel_end(ctx);
+        if (q1) {
+            // no decimate() stage: the de-emphasised channels are normalised as they are (n_out = n - 1 samples per channel)
+            pss_kernel_begin(ctx, "k_wfm_rows_q1");
+            hipLaunchKernelGGL(k_wfm_rows_q1, dim3((unsigned)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192)), dim3(256), 0, PSS_STREAM(ctx), U, Lp, n - 1, rows, A, MX);
+            pss_kernel_end(ctx);
+            size_t tot1 = (size_t)n_frames * n_out;
+            size_t g1 = (tot1 + TPB - 1) / TPB;
+            if (g1 > 16384) g1 = 16384;
+            pss_kernel_begin(ctx, "k_wfm_finalize");
+            hipLaunchKernelGGL(k_wfm_finalize, dim3((unsigned)g1), dim3(TPB), 0, PSS_STREAM(ctx), A, MX, n_out, n_frames, 2, d_pcm, d_audio);
+            pss_kernel_end(ctx);
+            pss_time_end(ctx);
+            return pss_hip_check(ctx, hipGetLastError(), "wfm (decimation factor 1) launch");
+        }
         pss_kernel_begin(ctx, "k_nfm_iir");
         if (b121)
             hipLaunchKernelGGL((k_nfm_iir<true, true>), dim3((unsigned)tiles2), dim3(TILE), 0, PSS_STREAM(ctx), U, Y, A, n, q,

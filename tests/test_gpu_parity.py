@@ -1738,6 +1738,27 @@ def test_round6_complex128_buffers_vs_reference_goldens(golden):
                     a = sp.demodulate_nfm(x, fs, tr)
                     assert a.shape == (len(x) - 1, 2) and np.array_equal(a[:, 0], g[f"n_audio_{t}"][k]), (t, k, scipy_tables)
                     assert np.array_equal(np.int16(a[:, 0] * 32767), g[f"n_pcm_{t}"][k]), (t, k)
+            # demodulate_wfm at factor one: the decimate() stage is skipped (:152-155), the de-emphasised channels normalised as they are;
+            # one buffer through the drop-in function, and a batch through the device entry point (the large-batch branch takes the plain kernels too)
+            for t in g["wq1_tags"]:
+                fs, tr = float(g[f"w_fs_{t}"]), int(g[f"w_tr_{t}"])
+                for k, x in enumerate(g[f"w_iq_{t}"]):
+                    a = sp.demodulate_wfm(x, fs, tr)
+                    assert a.shape == (len(x) - 1, 2) and np.array_equal(a, g[f"w_audio_{t}"][k]), (t, k, scipy_tables)
+                    assert np.array_equal(np.int16(a * 32767), g[f"w_pcm_{t}"][k]), (t, k)
+                iq = g[f"w_iq_{t}"]
+                big = np.tile(iq, (1500, 1))
+                n = iq.shape[1]
+                try:
+                    e.set_target_rate(float(tr))
+                    if scipy_tables:
+                        e.set_wfm_filters(fs, g[f"w_lp_{t}"], g[f"w_pil_{t}"], g[f"w_lmr_{t}"], float(g[f"w_alpha_{t}"]))
+                    d_pcm, d_au = G.empty((len(big), n - 1, 2), torch.int16), G.empty((len(big), n - 1, 2), torch.float64)
+                    e.demod(L.MODE_WFM, G.dev(big), len(big), n, fs, d_pcm, d_au)
+                    e.sync()
+                    assert np.array_equal(G.host(d_au)[-2:], g[f"w_audio_{t}"]) and np.array_equal(G.host(d_pcm)[:2], g[f"w_pcm_{t}"]), (t, scipy_tables)
+                finally:
+                    e.set_target_rate(22050)
     finally:
         sp.USE_SCIPY_DESIGNS = keep
         sp._designed.clear()

@@ -495,6 +495,15 @@ def test_round6_complex128_buffers_oracle_vs_reference(golden):
         for k, x in enumerate(g[f"n_iq_{t}"]):
             a = O.demod_nfm(x, fs, g[f"n_taps_{t}"], g[f"n_sos_{t}"], g[f"n_zi_{t}"], target_rate=tr)
             assert a.shape == (len(x) - 1,) and np.array_equal(a, g[f"n_audio_{t}"][k]), (t, k)
+    # demodulate_wfm at a decimation factor of one: no decimate() stage at all (:152-155)
+    import scipy.signal as ss
+    dec = ss.cheby1(8, 0.05, 0.8, output="sos")      # (unused at factor 1; the oracle's argument list wants a table)
+    for t in g["wq1_tags"]:
+        fs, tr = float(g[f"w_fs_{t}"]), float(g[f"w_tr_{t}"])
+        filt = dict(lp_sos=g[f"w_lp_{t}"], pilot_sos=g[f"w_pil_{t}"], lmr_sos=g[f"w_lmr_{t}"], alpha=float(g[f"w_alpha_{t}"]), dec_sos=dec, dec_zi=ss.sosfilt_zi(dec))
+        for k, x in enumerate(g[f"w_iq_{t}"]):
+            a = O.demod_wfm(x, fs, filt, target_rate=tr)
+            assert a.shape == (len(x) - 1, 2) and np.array_equal(a, g[f"w_audio_{t}"][k]), (t, k)
     with np.errstate(all="ignore"):
         z = g["iq_z"][0]
         assert np.array_equal(O.compute_fft_c128(z), g["db_z"][0])                 # every bin exactly -100 dB

@@ -63,6 +63,22 @@ def main():
         d[f"n_sos_{tag}"], d[f"n_zi_{tag}"] = sos, ss.sosfilt_zi(sos)
         qt.append(tag)
     d["q1_tags"] = np.array(qt)
+    # demodulate_wfm at a decimation factor of one: the reference SKIPS decimate() (`if decimation_factor > 1`, :152-155) and normalises the
+    # de-emphasised channels themselves
+    wt = []
+    for tag, n, fs, tr, seed in (("w1a", 4096, 240e3, 192000, 81), ("w1b", 3000, 250e3, 130000, 82)):
+        iq = mg.wfm_iq(2, n, fs, seed)
+        aud = np.stack([sp.demodulate_wfm(f, fs, tr) for f in iq])
+        assert int(fs / tr) == 1 and aud.shape == (2, n - 1, 2)
+        nyq = fs / 2
+        d[f"w_iq_{tag}"], d[f"w_fs_{tag}"], d[f"w_tr_{tag}"], d[f"w_audio_{tag}"] = iq, np.array(fs), np.array(tr), aud
+        d[f"w_pcm_{tag}"] = np.int16(aud * 32767)
+        d[f"w_lp_{tag}"] = ss.butter(5, 15000 / nyq, btype="low", output="sos")
+        d[f"w_pil_{tag}"] = ss.butter(5, [18800 / nyq, 19200 / nyq], btype="band", output="sos")
+        d[f"w_lmr_{tag}"] = ss.butter(5, [23000 / nyq, 53000 / nyq], btype="band", output="sos")
+        d[f"w_alpha_{tag}"] = np.array(np.exp(-1 / (75e-6 * fs)))
+        wt.append(tag)
+    d["wq1_tags"] = np.array(wt)
     d["tags"] = np.array(tags)
     d["am_sos"] = ss.butter(5, [300 / 11025, 3000 / 11025], btype="band", output="sos")   # demodulate_am's filter (:188-191, fs fixed at 22 050)
     mg.save("c128", **d)
