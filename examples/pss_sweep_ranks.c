@@ -3,7 +3,8 @@
  * only exchange step is pss_gather_packed to rank 0 (RCCL over xGMI, opened by libpss.so itself).  The halo step of the display
  * accumulators (pss_halo_from_left) is shown on the per-slice peaks.
  *   gcc -O2 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/pss_sweep_ranks.c -Lpyspecsdr_amd -lpss -L/opt/rocm/lib -lamdhip64 -lm -o /tmp/pss_sweep_ranks
- *   LD_LIBRARY_PATH=pyspecsdr_amd:/opt/rocm/lib /tmp/pss_sweep_ranks RANK N_RANKS ID_FILE [n_slices] [n]
+ *   LD_LIBRARY_PATH=pyspecsdr_amd:/opt/rocm/lib /tmp/pss_sweep_ranks RANK N_RANKS ID_FILE [n_slices] [n] [all]
+ * ("all": every rank additionally all-gathers the packed results — pss_gather_packed with dst = -1 — and prints the sum of all peaks)
  * Rendezvous: rank 0 writes the 128-byte id to ID_FILE (which must not exist beforehand), the others wait for the file.  ID_FILE "-" with N_RANKS 1: a lone rank, RCCL is
  * never opened.  Start one process per rank (any launcher: a shell loop, mpirun, srun); rank r takes device r mod pss_device_count().
  * Rank 0 prints one line per slice in sweep order: "slice k peak <dB> count <bins>"; every rank prints its halo. */
@@ -36,6 +37,7 @@ int main(int argc, char **argv)
     const char *id_file = argv[3];
     const long n_slices = argc > 4 ? atol(argv[4]) : 37;
     const int n = argc > 5 ? atoi(argv[5]) : 4096;
+    const int all_gather = argc > 6 && strcmp(argv[6], "all") == 0;
     const double fs = 2.4e6;
     const long halo = 3;
     pss_ctx *ctx = NULL;
@@ -106,6 +108,20 @@ int main(int argc, char **argv)
     printf("rank %d block %ld %ld halo", rank, start, count);
     for (long k = 0; k < n_halo; k++) printf(" %.6f", h_halo[k]);
     printf("\n");
+    if (all_gather) {       /* the all-gather form of the same collective: every rank ends up with every rank's packed results */
+        char *d_every = NULL;
+        HK(hipMalloc((void **)&d_every, bytes * n_ranks));
+        CK(pss_gather_packed(ctx, d_packed, bytes, d_every, -1));
+        CK(pss_sync(ctx));
+        char *every = (char *)malloc(bytes * n_ranks);
+        HK(hipMemcpy(every, d_every, bytes * n_ranks, hipMemcpyDeviceToHost));
+        double sum = 0.0;
+        for (int r = 0; r < n_ranks; r++)
+            for (long k = 0; k < counts[r]; k++) sum += ((const float *)(every + (size_t)r * bytes + o_peak))[k];
+        printf("rank %d allgather %.6f\n", rank, sum);
+        free(every);
+        hipFree(d_every);
+    }
     if (rank == 0) {
         char *all = (char *)malloc(bytes * n_ranks);
         HK(hipMemcpy(all, d_all, bytes * n_ranks, hipMemcpyDeviceToHost));

@@ -501,7 +501,7 @@ int pss_h_stream_display_nfm_f64(pss_ctx *ctx, const float *h_iq, long n_frames,
  * the data path.  What crosses ranks is the gather of a rank's results to one rank (or all), and — for the display accumulators — the row
  * extremes of the frames just before a rank's block.  A Python host does both over torch.distributed (pyspecsdr_amd/shard.py); these
  * entry points are the same two steps for a host without it, queued on the context's stream.  librccl.so.1 is opened at the first call
- * ($PSS_RCCL_LIB, the loader's path, /opt/rocm/lib; a copy the process already holds is shared) — the library does not link against it,
+ * ($PSS_RCCL_LIB if set — an explicit choice wins —, else a copy the process already holds, the loader's path, /opt/rocm/lib) — the library does not link against it,
  * and a lone rank (n_ranks = 1, id = NULL) never touches it.  Errors: PSS_E_COMM. */
 #define PSS_COMM_ID_BYTES 128
 /* contiguous blocks whose sizes differ by at most one: items [*start, *start + *count) belong to `rank` */

@@ -39,8 +39,9 @@ struct Rccl {
     std::string err;
 };
 
-// the process's RCCL: the copy already loaded (RTLD_NOLOAD matches torch's bundled librccl.so by its SONAME), else $PSS_RCCL_LIB, the
-// loader's search path, /opt/rocm/lib
+// the process's RCCL: $PSS_RCCL_LIB if the host names one (an explicit choice wins — also over a copy the process has loaded already: the tests
+// put a transport double there, tests/rccl_double/), else the copy already loaded (RTLD_NOLOAD matches torch's bundled librccl.so by its
+// SONAME), the loader's search path, /opt/rocm/lib
 Rccl *rccl()
 {
     static Rccl r;
@@ -48,8 +49,8 @@ Rccl *rccl()
     std::lock_guard<std::mutex> lock(mu);
     if (r.lib) return &r;
     const char *env = std::getenv("PSS_RCCL_LIB");
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-    if (!h && env && *env) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+    void *h = (env && *env) ? dlopen(env, RTLD_NOW | RTLD_LOCAL) : nullptr;
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) {

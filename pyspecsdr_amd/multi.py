@@ -25,6 +25,8 @@ from .shard import EngineGroup, ShardBuffer, gather_packed, halo_from_left, scan
 
 
 def _world_rank(group=None):
+    if isinstance(group, EngineGroup):       # exchange steps behind the C ABI: the communicator the Engine joined (no torch.distributed involved)
+        return group.world, group.rank
     if not dist.is_initialized():
         return 1, 0
     return dist.get_world_size(group), dist.get_rank(group)

@@ -2011,6 +2011,43 @@ def test_sharded_sweep_from_plain_c(tmp_path):
     assert np.allclose([float(v) for v in head1[6:]], pk[16:19], atol=1e-4)       # the three peaks before rank 1's block
 
 
+def test_exchange_steps_with_real_peers_over_a_transport_double(tmp_path):
+    """pss_gather_packed's grouped send / receive, its all-gather form, and pss_halo_from_left with one and with SEVERAL left neighbours, run by
+    two / three / four real processes of examples/pss_sweep_ranks.c (plain C, no torch) on this box's one GPU.  RCCL itself refuses two ranks
+    on one device, so the processes load tests/rccl_double/rccl_double.c in its place (PSS_RCCL_LIB; test infrastructure: RCCL's signatures and
+    group / ordering semantics, messages as files + hipMemcpy).  What this covers that one rank cannot: pss_comm.cpp's per-peer offsets, which
+    rows go to which neighbour, the order of posts inside a group.  What it does not: RCCL's own transport (xGMI) — no N > 1 timing."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe, env = _build_sweep_example(tmp_path)
+    dbl = str(tmp_path / "librccl_double.so")
+    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(root, "tests", "rccl_double", "rccl_double.c"),
+                    "-L/opt/rocm/lib", "-lamdhip64", "-o", dbl], check=True)
+    box = tmp_path / "mail"
+    box.mkdir()
+    env = dict(env, PSS_RCCL_LIB=dbl, PSS_RCCL_DOUBLE_DIR=str(box))
+    n = 4096
+    for world, n_slices in ((2, 37), (3, 37), (3, 5), (4, 6)):        # (3, 5): blocks 2 / 2 / 1, (4, 6): 2 / 2 / 1 / 1 — a halo of 3 spans two left neighbours
+        idf = str(tmp_path / f"id_{world}_{n_slices}")
+        procs = [subprocess.Popen([exe, str(r), str(world), idf, str(n_slices), str(n), "all"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+                 for r in range(world)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+        texts = [[ln for ln in o[0].split("\n") if ln.startswith(("rank ", "slice "))] for o in outs]
+        pk = _check_sweep_output(texts[0], n_slices, n)              # rank 0's gathered sweep == the single-GPU sweep, slice for slice
+        starts = [sum(((n_slices // world) + (1 if q < n_slices % world else 0)) for q in range(r)) for r in range(world + 1)]
+        sums = []
+        for r in range(world):
+            head = [ln for ln in texts[r] if ln.startswith(f"rank {r} block")][0].split()
+            assert head[:5] == ["rank", str(r), "block", str(starts[r]), str(starts[r + 1] - starts[r])], head
+            want = pk[max(0, starts[r] - 3):starts[r]]                # the (at most three) peaks before this rank's block, whoever held them
+            got = [float(v) for v in head[6:]]
+            assert len(got) == len(want) and np.allclose(got, want, atol=1e-4), (world, n_slices, r, got, want)
+            sums.append(float([ln for ln in texts[r] if "allgather" in ln][0].split()[3]))
+        assert np.allclose(sums, float(np.sum(pk.astype(np.float64))), rtol=0, atol=2e-3) and len(set(sums)) == 1, (world, n_slices, sums)
+
+
 def test_agc(golden):
     g = golden["caller"]
     e = G.engine()

@@ -163,6 +163,74 @@ def _stream_worker(rank, world, port, backend, n_frames, n, fs, mode, q, rows="f
         dist.destroy_process_group()
 
 
+def _stream_worker_engine_group(rank, world, idfile, dbl, box, n_frames, n, fs, mode, q, rows):
+    """The same capture sharded over `world` processes whose exchange steps run BEHIND THE C ABI (shard.EngineGroup: pss_gather_packed /
+    pss_halo_from_left) — no torch.distributed at all.  All ranks share this box's GPU, so libpss.so is pointed at the transport double."""
+    os.environ["PSS_RCCL_LIB"], os.environ["PSS_RCCL_DOUBLE_DIR"] = dbl, box
+    import time
+    from pyspecsdr_amd.engine import Engine
+    from pyspecsdr_amd.multi import sharded_stream_display
+    from pyspecsdr_amd.shard import EngineGroup, shard_range
+    e = Engine(0)
+    if rank == 0:
+        ident = e.comm_id()
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(bytes(ident))
+        os.replace(idfile + ".tmp", idfile)
+    else:
+        for _ in range(3000):
+            if os.path.exists(idfile):
+                break
+            time.sleep(0.02)
+        ident = open(idfile, "rb").read()
+    e.comm_init(ident, rank, world)
+    grp = EngineGroup(e)
+    assert (grp.rank, grp.world) == (rank, world)
+    start, count = shard_range(n_frames, rank, world)
+    h = e.pinned_empty((count, n), np.complex64)
+    h[:] = _stream_iq(n_frames, n)[start:start + count]
+    res = sharded_stream_display(e, h, fs, 64, mode=mode, gather_dst=0, rows=rows, group=grp)
+    if rank == 0:
+        q.put(res)
+    e.pinned_free(h)
+    e.comm_free()
+    e.close()
+
+
+@pytest.mark.parametrize("world,mode,rows", [(2, "waterfall", "f64"), (3, "persistence", "f32")])
+def test_sharded_stream_over_the_c_abi_exchange_with_real_peers(world, mode, rows, tmp_path):
+    """shard.EngineGroup's multi-rank branches (the exchange steps behind the C ABI instead of torch.distributed) with real peer processes:
+    sharded_stream_display on 2 / 3 ranks == one rank streaming the whole capture.  The ranks share this box's one GPU, which RCCL refuses, so
+    libpss.so loads tests/rccl_double/rccl_double.c in RCCL's place (PSS_RCCL_LIB: test infrastructure — RCCL's signatures and group semantics
+    over files + hipMemcpy).  Covers block counts by all-gather, the halo of row extremes from the left neighbour(s), the uneven packed gather."""
+    import subprocess
+    from pyspecsdr_amd.engine import Engine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dbl = str(tmp_path / "librccl_double.so")
+    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(root, "tests", "rccl_double", "rccl_double.c"),
+                    "-L/opt/rocm/lib", "-lamdhip64", "-o", dbl], check=True)
+    box = tmp_path / "mail"
+    box.mkdir()
+    n_frames, n, fs = 301, 2048, 10e6
+    e = Engine(0)
+    h = e.pinned_empty((n_frames, n), np.complex64)
+    h[:] = _stream_iq(n_frames, n)
+    want = (e.stream_display_nfm_f64 if rows == "f64" else e.stream_display_nfm)(h, fs, 64, mode=mode)
+    e.pinned_free(h)
+    e.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stream_worker_engine_group, args=(r, world, str(tmp_path / "id"), dbl, str(box), n_frames, n, fs, mode, q, rows)) for r in range(world)]
+    for p in procs:
+        p.start()
+    lines, pcm = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert len(lines) == len(want["lines"]) and all(np.array_equal(a, b) for a, b in zip(lines, want["lines"]))
+    assert np.array_equal(pcm, want["pcm"])
+
+
 @pytest.mark.parametrize("world,mode,rows", [(2, "waterfall", "f32"), (3, "persistence", "f32"), (2, "persistence", "f64"), (3, "waterfall", "f64")])
 def test_sharded_stream_equals_single_rank(world, mode, rows):
     """BASELINE configs[4] on N ranks: each rank streams its block of the capture from its own pinned memory; display
