@@ -387,7 +387,10 @@ def main():
 
     # N ranks for --gpus N: re-executes under torch.distributed.run when started bare; exits 2 on any mismatch (pyspecsdr_amd/launch.py)
     from pyspecsdr_amd.launch import ensure_ranks
-    world, rank, local_rank = ensure_ranks(args.gpus, __file__, sys.argv[1:], need_gpus=not args.dry_run)
+    # PSS_BENCH_BACKEND=gloo: a FUNCTIONAL test hook for the N-rank code path on a box with fewer GPUs than ranks (tests/test_multi_gpu.py: two
+    # ranks sharing one GPU; the collectives go through host memory).  Never a measurement: the line says "backend": "gloo".
+    test_backend = os.environ.get("PSS_BENCH_BACKEND", "nccl")
+    world, rank, local_rank = ensure_ranks(args.gpus, __file__, sys.argv[1:], need_gpus=not args.dry_run and test_backend != "gloo")
     if args.dry_run:
         return dry_run(args, world, rank)
     # stdout carries ONE line: the result.  Everything else this process or its libraries print there (RCCL's version banner is a
@@ -400,11 +403,46 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if test_backend == "gloo":
+            local_rank = local_rank % max(1, torch.cuda.device_count())      # ranks share the visible GPU(s)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    staged = dist is not None and test_backend == "gloo"     # collectives through host copies (gloo moves no device memory)
+
+    def c_gather(src, recv_rows, dst=0):
+        """dist.gather of a device byte buffer to rank dst (recv_rows: its [world, bytes] device tensor there, None elsewhere)."""
+        if not staged:
+            dist.gather(src, list(recv_rows.unbind(0)) if rank == dst else None, dst=dst)
+            return
+        h = src.cpu()
+        parts = [torch.empty_like(h) for _ in range(world)] if rank == dst else None
+        dist.gather(h, parts, dst=dst)
+        if rank == dst:
+            recv_rows.copy_(torch.stack(parts))
+
+    def c_all_reduce(t, op):
+        if not staged:
+            dist.all_reduce(t, op=op)
+            return
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+
+    def c_all_gather(mine):
+        if not staged:
+            allr = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            return allr
+        h = mine.cpu()
+        allr = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(allr, h)
+        return allr
 
     from pyspecsdr_amd.engine import Engine
     eng = Engine(local_rank, order="none")   # this script orders its streams by hand (fences, events)
@@ -453,7 +491,7 @@ def main():
         src = packed[b] if exch == "display" else d_db[b % len(d_db)].view(torch.uint8).view(-1)
         comm.wait_stream(comp)
         with torch.cuda.stream(comm):
-            dist.gather(src, list(recv.unbind(0)) if rank == 0 else None, dst=0)
+            c_gather(src, recv)
             sent[b] = comm.record_event()
 
     def step(k):
@@ -524,7 +562,7 @@ def main():
         verified = verify_step(eng, iq, FS, d_db[last % len(d_db)], d_lo, d_hi, packed[last], o_col, o_pcm, n_out, WF_WINDOW, exact)
         if dist is not None:      # every rank checks its own outputs; the line reports the conjunction
             okt = torch.tensor([1 if verified["ok"] else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            c_all_reduce(okt, dist.ReduceOp.MIN)
             verified["ok_all_ranks"] = bool(okt.item())
 
     def timed(fn, reps=5):
@@ -590,7 +628,7 @@ def main():
                 buf = torch.empty((world, per), dtype=torch.uint8, device=dev) if rank == 0 else None
                 def go():
                     with torch.cuda.stream(comm_db):
-                        dist.gather(src, list(buf.unbind(0)) if rank == 0 else None, dst=0)
+                        c_gather(src, buf)
                 return timed(go, 3)
             side["exchange_display_ms"] = xfer(packed[0], set_bytes)
             side["exchange_display_bytes_per_rank"] = set_bytes
@@ -621,15 +659,13 @@ def main():
                 compute(k & 1)
             mine[2] = mine[3] = float(shader_clock_mhz(dev.index or 0) or 0)
             eng.sync()
-        allr = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        cols = torch.stack(allr).cpu().tolist()
+        cols = torch.stack(c_all_gather(mine)).cpu().tolist()
         per_rank = {"ms_per_step": [round(c[0], 4) for c in cols], "compute_ms": [None if c[1] != c[1] else round(c[1], 4) for c in cols],
                     "shader_clock_mhz": [int(c[2]) or None for c in cols], "dominant_kernel": dom,
                     "dominant_kernel_ms": [None if c[4] != c[4] else round(c[4], 4) for c in cols]}
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c_all_reduce(t, dist.ReduceOp.MAX)
     elapsed = float(t.item())
     total_samples = float(world) * nf * n * args.steps
     value = total_samples / elapsed

@@ -332,6 +332,34 @@ def test_rccl_path_runs_with_one_rank(script, extra):
         assert list(line)[-1] == "summary" and line["summary"]["headline"]["rows"] == "cells" and line["summary"]["headline"]["cd"] == 0
 
 
+def test_bench_two_ranks_functional_on_one_gpu():
+    """bench.py --gpus 2 END TO END with two real ranks: the self-launch under torch.distributed.run, double-buffered output sets, the in-region
+    gather to rank 0 with its `sent` events, the barrier fences, max-over-ranks timing, the all-reduced verification flag, the per-rank
+    readings, rank 0's one line.  RCCL refuses two ranks on one GPU, so PSS_BENCH_BACKEND=gloo routes the collectives through host copies: a
+    functional test of the N-rank CODE (which no round has been able to run on N GPUs), never a measurement — the line says backend gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PSS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for exchange in ("display", "db"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--regions", "2", "--frames", "4096",
+                            "--exchange", exchange, "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        line = lines[0]
+        assert line["n_gpus"] == 2 and line["ranks"]["world"] == 2 and line["ranks"]["backend"] == "gloo" and line["scaling"] == "weak"
+        assert line["verified"]["ok"] and line["verified"]["ok_all_ranks"] and line["verified"]["cells_differing"] == 0
+        pr = line["per_rank"]
+        assert len(pr["ms_per_step"]) == 2 and all(v is not None and v > 0 for v in pr["ms_per_step"] + pr["compute_ms"] + pr["dominant_kernel_ms"])
+        assert abs(line["value"] * 1e6 - 2 * 4096 * 1024 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"] * 1e6      # whole-job samples / max-over-ranks time
+        assert line["ms_per_step"] >= max(pr["ms_per_step"]) - 1e-3      # (the per-rank values are rounded to 4 decimals)
+        assert line["exchange_display_ms"] is not None and line["exchange_db_ms"] is not None and "other_configs" not in line
+        assert list(line)[-1] == "summary" and line["predicted"]["scaling_vs_1gpu"][1] == 2.0
+
+
 @pytest.mark.parametrize("rows", ["f64", "f32"])
 def test_bench_other_row_types_still_run(rows):
     """bench.py --rows f64 / f32 (round 5's timed step and the float32-row step; the default since round 6 is --rows cells): a short run at a
