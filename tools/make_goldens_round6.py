@@ -7,6 +7,8 @@ from the first statement on:
     compute_fft    (signal_processing.py:243-264): `samples * window` is a float64 product of float64 samples
     demodulate_am  (:179-195): np.abs / np.mean / the subtraction in float64 (complex64 input: float32)
 Rounds 1-5 narrowed such input to complex64 with a warning; round 6 serves these two functions in float64.
+The same file carries round 6's other new vectors: demodulate_nfm and demodulate_wfm at a decimation factor int(sample_rate / target_rate) of ONE
+(keys n_* / w_*: NFM runs decimate(x, 1), WFM skips the stage, signal_processing.py:111-112 / :152-155).
 
     python tools/make_goldens_round6.py
 """
