@@ -1846,10 +1846,15 @@ int pss_spec_post_chain(pss_ctx *ctx, const float *d_iq, long n_frames, int n_ff
     if (r) return r;
     using C = pss_r16::Cfg<2>;
     auto kern = d_db32 ? (d_db64 ? pss_sp::k_spectrum_post<true, true> : pss_sp::k_spectrum_post<true, false>) : pss_sp::k_spectrum_post<false, true>;
+#ifdef PSS_EXP_FUSE_LDS      // timing experiment (with PSS_EXP_FUSE_NOFFT: the staged rows only)
+    const size_t lds = PSS_EXP_FUSE_LDS;
+    const long cap = 256L * PSS_EXP_FUSE_WAVES * 2;
+#else
     const size_t lds = (size_t)C::FPW * C::EX * sizeof(double2) + (size_t)C::TW2 * sizeof(double2);
+    const long cap = 256L * 2 * 2;       // two 256-thread workgroups per CU (LDS, registers), two rounds
+#endif
     if (lds > 64 * 1024) PSS_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long groups = (n_frames + C::FPW - 1) / C::FPW;
-    const long cap = 256L * 2 * 2;       // two 256-thread workgroups per CU (LDS, registers), two rounds
     pss_time_begin(ctx);
     pss_kernel_begin(ctx, "k_spectrum_post");
     hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(256), lds, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq), d_db32,

@@ -17,8 +17,11 @@ namespace pss_sp {
 
 using namespace pss_r16;
 
+#ifndef PSS_EXP_FUSE_WAVES
+#define PSS_EXP_FUSE_WAVES 1     // (experiments: minimum workgroups per CU the register allocation has to allow)
+#endif
 template <bool ROW32, bool ROW64>
-__global__ __launch_bounds__(256) void k_spectrum_post(const float2 *__restrict__ iq, float *__restrict__ db32, double *__restrict__ db64,
+__global__ __launch_bounds__(256, PSS_EXP_FUSE_WAVES) void k_spectrum_post(const float2 *__restrict__ iq, float *__restrict__ db32, double *__restrict__ db64,
                                                        const double2 *__restrict__ tw, const double *__restrict__ win, long n_frames,
                                                        double *__restrict__ row_lo, double *__restrict__ row_hi, double *__restrict__ vals,
                                                        int disp_w)
@@ -31,11 +34,17 @@ __global__ __launch_bounds__(256) void k_spectrum_post(const float2 *__restrict_
     static_assert((size_t)(T + 1) * PC::S * sizeof(double) <= (size_t)C::EX * sizeof(double2), "the staged row fits the frame's exchange buffer");
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *ex_all = reinterpret_cast<double2 *>(smem);
+#ifdef PSS_EXP_FUSE_LDS
+    constexpr size_t EXS = PSS_EXP_FUSE_LDS / FPW / sizeof(double2);
+    double2 *tw2 = ex_all;
+#else
+    constexpr size_t EXS = C::EX;
     double2 *tw2 = ex_all + (size_t)FPW * C::EX;
+#endif
     const int tid = threadIdx.x;
     const int fl = __builtin_amdgcn_readfirstlane(tid / T);   // frame slot = wavefront of the workgroup
     const int t = tid % T;
-    double2 *ex = ex_all + (size_t)fl * C::EX;
+    double2 *ex = ex_all + (size_t)fl * EXS;
     double *stage = reinterpret_cast<double *>(ex);
     double2 tw1[16];
     double w[16];
@@ -44,10 +53,12 @@ __global__ __launch_bounds__(256) void k_spectrum_post(const float2 *__restrict_
     for (int k2 = 1; k2 < 16; k2++) tw1[k2] = tw[(size_t)t * k2];
 #pragma unroll
     for (int n2 = 0; n2 < 16; n2++) w[n2] = win[t + T * n2];
+#ifndef PSS_EXP_FUSE_LDS
     if (tid < R3 * 16) {
         const int m1 = tid / 16, j2 = tid % 16;
         tw2[C::tw2_slot(tid)] = tw[(size_t)(m1 * j2) * 16];
     }
+#endif
     __syncthreads();
     const long groups = (n_frames + FPW - 1) / FPW;
     float2 nx[16];
@@ -64,7 +75,11 @@ __global__ __launch_bounds__(256) void k_spectrum_post(const float2 *__restrict_
         const bool valid = f < n_frames;                      // wave-uniform
         double2 v[16];
 #pragma unroll
+#ifdef PSS_EXP_FUSE_NOFFT
+        for (int n2 = 0; n2 < 16; n2++) v[n2] = make_double2((double)nx[n2].x, (double)nx[n2].y);
+#else
         for (int n2 = 0; n2 < 16; n2++) v[n2] = make_double2((double)nx[n2].x * w[n2], (double)nx[n2].y * w[n2]);
+#endif
         if (g + gridDim.x < groups) fetch(g + gridDim.x);
         // row stores through buffer resources over the workgroup's FPW rows (frames past the end fall outside and are dropped): unconditional
         // in the instruction stream, see k_spectrum_r16
