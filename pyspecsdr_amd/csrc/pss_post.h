@@ -381,8 +381,12 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
 #pragma unroll
         for (int r = 0; r < EPL; r++) {
             double acc = 0.0;
+#if defined(PSS_EXP_POST_KNOCK) && (PSS_EXP_POST_KNOCK & 4)
+            acc = xd[r];
+#else
 #pragma unroll
             for (int k = 0; k < 5; k++) acc += xd[r + k] * 0.2;
+#endif
             const TR sm = (TR)acc;
             // padding sorts above everything
             const bool pad = FULL ? (r >= PAD_FROM && t == T - 1) : r >= nv;
@@ -397,6 +401,14 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
     // np.median: the middle order statistic, or the mean of the two middle ones
     const unsigned k1 = (unsigned)((m - 1) >> 1);
     K mn, mx, v1, v2;
+    // PSS_EXP_POST_KNOCK: timing experiments (results wrong) — bit 0: no order statistics, bit 1: no resampled row, bit 2: no smoothing (R6-11)
+#if defined(PSS_EXP_POST_KNOCK) && (PSS_EXP_POST_KNOCK & 1)
+    if constexpr (F64) {
+        v1 = v2 = O::enc((TR)guess); mn = O::enc((TR)(guess - 20.0f)); mx = O::enc((TR)(guess + 20.0f));
+#pragma unroll
+        for (int r = 0; r < EPL; r++) key[r] = ((K)kh[r] << 32) | kl[r];
+    } else
+#endif
     if constexpr (F64) {
         select_kth64<EPL, W, PAD_FROM>(kh, kl, k1, (unsigned)m, v1, v2, mn, mx, red, wave, lane, phase, guess);
 #pragma unroll
@@ -439,7 +451,11 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
                 if (c < mq) out4[c] = *reinterpret_cast<const float4 *>(buf + slot[j]);
             }
         }
+#if defined(PSS_EXP_POST_KNOCK) && (PSS_EXP_POST_KNOCK & 2)
+        if (false) {
+#else
         if (vals) {
+#endif
             const StagedRow<EPL, TR> row{buf};
             for (int x = t; x < disp_w; x += T) vals[(size_t)f * disp_w + x] = interp_at(row, m, disp_w, x);
         }
