@@ -324,7 +324,9 @@ __device__ __forceinline__ double interp_at(const Row &row, int len, int W, int 
     }
     if (xp >= stop) return (double)row[len - 1];
     const int j = (int)xp;
-    const double slope = ((double)row[j + 1] - (double)row[j]) / ((double)(j + 1) - (double)j);
+    // np.interp divides the difference by xp[j + 1] - xp[j]: np.arange's step, exactly 1.0, and x / 1.0 is x for every x — no division here
+    // (35 float64-class instructions per value otherwise)
+    const double slope = (double)row[j + 1] - (double)row[j];
     return slope * (xp - (double)j) + (double)row[j];
 }
 
