@@ -83,8 +83,24 @@ __device__ __forceinline__ unsigned long long readlane_k(unsigned long long v, i
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
     return ((unsigned long long)hi << 32) | lo;
 }
+// v_min / v_max as they are: -0 < +0, a NaN operand loses (fminf / fmin cost a canonicalising v_max x, x per operand in front of each; the
+// callers' operands are results of float additions / conversions)
+__device__ __forceinline__ float vmin_f32(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax_f32(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 struct OpAdd { template <class K> static __device__ __forceinline__ K f(K a, K b) { return a + b; } };
 struct OpFAdd { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return __float_as_uint(__uint_as_float(a) + __uint_as_float(b)); } };
+struct OpFMin { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return __float_as_uint(vmin_f32(__uint_as_float(a), __uint_as_float(b))); } };
+struct OpFMax { static __device__ __forceinline__ unsigned f(unsigned a, unsigned b) { return __float_as_uint(vmax_f32(__uint_as_float(a), __uint_as_float(b))); } };
 struct OpMin { template <class K> static __device__ __forceinline__ K f(K a, K b) { return a < b ? a : b; } };
 struct OpMax { template <class K> static __device__ __forceinline__ K f(K a, K b) { return a > b ? a : b; } };
 
@@ -288,6 +304,277 @@ __device__ __forceinline__ void select_kth64(const unsigned (&kh)[EPL], const un
     mx = join(mxh, lo_max(mxh));
 }
 
+// ---- the same order statistics for a row owned by ONE wavefront, by COMPACTION (round 6) -----------------------------------------------
+// Every counting pass of select_kth sweeps all EPL register slots of every lane (v_cmp + v_addc per element, then a wave reduction) to
+// learn ONE bit of rank k's position, although after the two bracket counts only the keys inside the bracket [lo, hi] (a tenth of a dB row
+// for the +-0.5 dB bracket around its mean) can still be rank k.  Here the sweep over all elements stops as soon as at most 64 CPL keys are
+// left in the bracket; those are compacted through LDS (positions from v_mbcnt over the ballots of the slots: no scan, no atomics) into CPL
+// whole 64-bit keys per lane, and the search continues on them alone: one v_cmp per lane-slot and pass, counted with s_bcnt1 on the ballot —
+// no wave reduction — down to the key itself (low words included: no masked low-word sweeps afterwards); rank k + 1 is the smallest
+// candidate above it (or, when rank k is the bracket's last key, the smallest key above the bracket: one sweep over the high words).
+// The row's extreme keys come from v_min_f64 / v_max_f64 over the smoothed values (dmin / dmax: this lane's, padding excluded) — valid
+// because this path is only taken for rows without a NaN (the row's mean, `guess`, is a sum over every element).
+// Every result is decided by exact counts, as in select_kth; returns false — nothing touched — when the row does not fit the scheme (NaN
+// or infinite mean, rank k outside both brackets, more than 64 CPL keys sharing one high word): the caller then runs select_kth64.
+#ifndef PSS_POST_CPL
+#define PSS_POST_CPL 2
+#endif
+// the lanes of one wavefront execute their LDS instructions in order: a fence, no workgroup barrier
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// v_min_f64 / v_max_f64 as they are: -0 < +0, a NaN operand loses (__builtin_fmin costs a canonicalising v_max_f64 x, x per operand in
+// front of each of them; the callers' operands are results of float64 additions)
+__device__ __forceinline__ double vmin_f64(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax_f64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const unsigned lo = dpp_u32<CTRL>((unsigned)__double2loint(v)), hi = dpp_u32<CTRL>((unsigned)__double2hiint(v));
+    return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ double vmin_f64_s(double a, double b_uniform)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
+    return r;
+}
+__device__ __forceinline__ double vmax_f64_s(double a, double b_uniform)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
+    return r;
+}
+// minimum / maximum over the wavefront's lanes, as the ordered image, wave-uniform (scalar registers)
+template <bool MIN>
+__device__ __forceinline__ unsigned long long wave_extreme_key_f64(double v)
+{
+    auto op = [](double a, double b) { return MIN ? vmin_f64(a, b) : vmax_f64(a, b); };
+    auto ops = [](double a, double b) { return MIN ? vmin_f64_s(a, b) : vmax_f64_s(a, b); };
+    v = op(v, dpp_f64<0xB1>(v));
+    v = op(v, dpp_f64<0x4E>(v));
+    v = op(v, dpp_f64<0x141>(v));
+    v = op(v, dpp_f64<0x140>(v));
+    auto rl = [&](int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    };
+    const double r = ops(ops(ops(v, rl(16)), rl(32)), rl(48));    // (lane 0 holds row 0's result: every lane of row 0 ends with the wavefront's)
+    const unsigned long long kk = d2ord(r);
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kk >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kk);
+}
+
+template <int EPL, int CPL>
+__device__ __forceinline__ bool select_kth64_compact(const unsigned (&kh)[EPL], const unsigned (&kl)[EPL], unsigned k, unsigned long long &v1,
+                                                     unsigned long long &v2, unsigned long long *cand, int lane, float guess)
+{
+    using K = unsigned long long;
+    constexpr K PADK = ~(K)0;
+    constexpr unsigned CAP = 64u * CPL;
+    if (!(guess - guess == 0.0f)) return false;               // NaN or infinite mean
+    int phase = 0;
+    auto join = [](unsigned h, unsigned l) { return ((K)h << 32) | l; };
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const float d = attempt ? 2.0f : 0.5f;
+        // (finite values: high words below 0xfff00000, so hi + 1 cannot wrap and the padding keys — all ones — are never counted)
+        // wave-uniform by construction; said so (v_readfirstlane), the search's 64-bit bracket arithmetic below runs on the scalar unit instead of
+        // as a dependent chain of a dozen vector instructions per pass
+        unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(d2ord((double)(guess - d)) >> 32));
+        unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(d2ord((double)(guess + d)) >> 32));
+        unsigned n_lo = count_below<EPL, 1>(kh, lo, nullptr, 0, lane, phase);            // #keys below the bracket
+        // The compaction sweep is the bracket's second count as well: every key inside [lo, hi] goes to LDS (slot r's keys take the positions
+        // after those of the slots before it, in lane order; the staging buffer holds a whole row) and their number M tells whether rank k
+        // lies inside.  More than CAP of them (the wide bracket): sweeps over all elements halve the bracket first, then a second compaction.
+        unsigned M = 0;
+        bool inside = true;
+        wave_lds_sync();                                       // (cand is the row's staging buffer: every lane has read its window)
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+            const unsigned span = hi - lo;
+            unsigned base = 0;
+#pragma unroll
+            for (int r = 0; r < EPL; r++) {
+                const bool in = kh[r] - lo <= span;
+                const K mask = __builtin_amdgcn_ballot_w64(in);
+                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, base));
+                if (in) cand[pos] = join(kh[r], kl[r]);
+                base += (unsigned)__builtin_popcountll(mask);
+#ifndef PSS_POST_CBAR
+#define PSS_POST_CBAR 4
+#endif
+                if (r % PSS_POST_CBAR == PSS_POST_CBAR - 1) __builtin_amdgcn_sched_barrier(0);   // (sixteen positions and addresses in flight cost 48 registers)
+            }
+            M = base;
+            if (pass == 0 && !(n_lo <= k && k < n_lo + M)) { inside = false; break; }
+            if (M <= CAP) break;
+            if (pass == 1) return false;
+            unsigned n_hi = n_lo + M;
+#pragma unroll 1
+            while (n_hi - n_lo > CAP && lo < hi) {
+                const unsigned trial = lo + ((hi - lo + 1u) >> 1);
+                const unsigned c = count_below<EPL, 1>(kh, trial, nullptr, 0, lane, phase);
+                if (c <= k) { lo = trial; n_lo = c; } else { hi = trial - 1u; n_hi = c; }
+            }
+            if (n_hi - n_lo > CAP) return false;               // (more than CAP keys share one high word)
+            wave_lds_sync();
+        }
+        if (!inside) continue;
+        const unsigned j = k - n_lo;                           // rank among the candidates
+        wave_lds_sync();
+        K c[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; i++) c[i] = (unsigned)(lane + 64 * i) < M ? cand[lane + 64 * i] : PADK;
+        // the search continued on whole keys of the candidates: a = #candidates below lo64, b = #candidates up to hi64
+        K lo64 = join(lo, 0u), hi64 = join(hi, 0xffffffffu);
+        unsigned a = 0, b = M;
+#pragma unroll 1
+        while (b - a > 1u && lo64 != hi64) {          // (lo64 <= hi64 throughout; s_cmp_lg_u64 is a scalar instruction, an ordered 64-bit compare is not)
+            const K trial = lo64 + ((hi64 - lo64 + 1u) >> 1);
+            unsigned cnt = 0;
+#pragma unroll
+            for (int i = 0; i < CPL; i++) cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c[i] < trial));
+            if (cnt <= j) { lo64 = trial; a = cnt; } else { hi64 = trial - 1u; b = cnt; }
+        }
+        if (b - a == 1u) {
+            // one candidate in [lo64, hi64] (the padding lanes hold all ones, above every bracket): rank k
+            K got = 0;
+            const K w64 = hi64 - lo64;
+#pragma unroll
+            for (int i = 0; i < CPL; i++) {
+                const K mask = __builtin_amdgcn_ballot_w64(c[i] - lo64 <= w64);
+                if (mask) got = readlane_k(c[i], (int)__builtin_ctzll(mask));
+            }
+            v1 = got;
+        } else {
+            v1 = lo64;                                         // lo64 == hi64: the value holds the ranks a .. b - 1
+        }
+        if (j + 1u < b) {
+            v2 = v1;                                           // several candidates share the value and rank k + 1 is one of them
+        } else if (j + 1u < M) {
+            K nx = PADK;                                       // the smallest candidate above it
+#pragma unroll
+            for (int i = 0; i < CPL; i++) nx = (c[i] > v1 && c[i] < nx) ? c[i] : nx;
+            v2 = wave_reduce<OpMin>(nx);
+        } else {
+            // rank k is the bracket's last key: rank k + 1 is the smallest key above the bracket
+            unsigned nh = 0xffffffffu;
+#pragma unroll
+            for (int r = 0; r < EPL; r++) nh = (kh[r] > hi && kh[r] < nh) ? kh[r] : nh;
+            nh = wave_reduce<OpMin>(nh);
+            unsigned nl = 0xffffffffu;
+#pragma unroll
+            for (int r = 0; r < EPL; r++) nl = (kh[r] == nh && kl[r] < nl) ? kl[r] : nl;
+            v2 = join(nh, wave_reduce<OpMin>(nl));
+        }
+        return true;
+    }
+    return false;
+}
+
+// The same for float32 rows (32-bit keys; CPL candidates per lane).  mn / mx are not produced here: the caller takes them from v_min_f32 / v_max_f32.
+template <int EPL, int CPL>
+__device__ __forceinline__ bool select_kth32_compact(const unsigned (&key)[EPL], unsigned k, unsigned &v1, unsigned &v2, unsigned *cand, int lane, float guess)
+{
+    constexpr unsigned PADK = 0xffffffffu, CAP = 64u * CPL;
+    if (!(guess - guess == 0.0f)) return false;               // NaN or infinite mean
+    int phase = 0;
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const float d = attempt ? 2.0f : 0.5f;
+        // (finite values: keys below 0xff800000, so hi + 1 cannot wrap and the padding keys are never inside a bracket)
+        unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)f2ord(guess - d));
+        unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)f2ord(guess + d));
+        unsigned n_lo = count_below<EPL, 1>(key, lo, nullptr, 0, lane, phase);
+        unsigned M = 0;
+        bool inside = true;
+        wave_lds_sync();
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+            const unsigned span = hi - lo;
+            unsigned base = 0;
+#pragma unroll
+            for (int r = 0; r < EPL; r++) {
+                const bool in = key[r] - lo <= span;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+                const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, base));
+                if (in) cand[pos] = key[r];
+                base += (unsigned)__builtin_popcountll(mask);
+                if (r % PSS_POST_CBAR == PSS_POST_CBAR - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            M = base;
+            if (pass == 0 && !(n_lo <= k && k < n_lo + M)) { inside = false; break; }
+            if (M <= CAP) break;
+            if (pass == 1) return false;
+            unsigned n_hi = n_lo + M;
+#pragma unroll 1
+            while (n_hi - n_lo > CAP && lo < hi) {
+                const unsigned trial = lo + ((hi - lo + 1u) >> 1);
+                const unsigned c = count_below<EPL, 1>(key, trial, nullptr, 0, lane, phase);
+                if (c <= k) { lo = trial; n_lo = c; } else { hi = trial - 1u; n_hi = c; }
+            }
+            if (n_hi - n_lo > CAP) return false;               // (more than CAP equal keys)
+            wave_lds_sync();
+        }
+        if (!inside) continue;
+        const unsigned j = k - n_lo;
+        wave_lds_sync();
+        unsigned c[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; i++) c[i] = (unsigned)(lane + 64 * i) < M ? cand[lane + 64 * i] : PADK;
+        unsigned a = 0, b = M;
+#pragma unroll 1
+        while (b - a > 1u && lo != hi) {
+            const unsigned trial = lo + ((hi - lo + 1u) >> 1);
+            unsigned cnt = 0;
+#pragma unroll
+            for (int i = 0; i < CPL; i++) cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c[i] < trial));
+            if (cnt <= j) { lo = trial; a = cnt; } else { hi = trial - 1u; b = cnt; }
+        }
+        if (b - a == 1u) {
+            unsigned got = 0;
+            const unsigned w = hi - lo;
+#pragma unroll
+            for (int i = 0; i < CPL; i++) {
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(c[i] - lo <= w);
+                if (mask) got = readlane_k(c[i], (int)__builtin_ctzll(mask));
+            }
+            v1 = got;
+        } else {
+            v1 = lo;                                           // lo == hi: the value holds the ranks a .. b - 1
+        }
+        if (j + 1u < b) {
+            v2 = v1;
+        } else if (j + 1u < M) {
+            unsigned nx = PADK;
+#pragma unroll
+            for (int i = 0; i < CPL; i++) nx = (c[i] > v1 && c[i] < nx) ? c[i] : nx;
+            v2 = wave_reduce<OpMin>(nx);
+        } else {
+            // rank k is the bracket's last key: rank k + 1 is the smallest key above the ORIGINAL candidates' upper end — above v1 will do
+            unsigned nx = PADK;
+#pragma unroll
+            for (int r = 0; r < EPL; r++) nx = (key[r] > v1 && key[r] < nx) ? key[r] : nx;
+            v2 = wave_reduce<OpMin>(nx);
+        }
+        return true;
+    }
+    return false;
+}
+
 // LDS row stride (elements) of a thread's EPL consecutive elements: the stride in bytes is = 16 mod 32, so that the 16 lanes
 // a ds_read_b128 / ds_write_b128 services together start 16 bytes apart modulo the 64 banks (conflict-free).
 // float: EPL + 4 (or + 8); double: EPL + 2.
@@ -366,6 +653,8 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
     K key[EPL];                                  // (float64 rows: the two words of a key live in kh / kl below; `key` is then unused)
     unsigned kh[F64 ? EPL : 1], kl[F64 ? EPL : 1];
     float lsum = 0.0f;
+    double dmin = INFINITY, dmax = -INFINITY;    // (float64 rows of one wavefront: this lane's smoothed extremes, for select_kth64_compact)
+    float fmin32 = INFINITY, fmax32 = -INFINITY; // (float32 rows: the same)
     {
         double xd[EPL + 4];
 #pragma unroll
@@ -396,6 +685,14 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
             if constexpr (F64) { kh[r] = (unsigned)(kk0 >> 32); kl[r] = (unsigned)kk0; }
             else key[r] = kk0;
             lsum += pad ? 0.0f : (float)sm;
+            if constexpr (!F64 && W == 1) {
+                if (FULL && r < PAD_FROM) { fmin32 = vmin_f32(fmin32, (float)sm); fmax32 = vmax_f32(fmax32, (float)sm); }
+                else { fmin32 = vmin_f32(fmin32, pad ? INFINITY : (float)sm); fmax32 = vmax_f32(fmax32, pad ? -INFINITY : (float)sm); }
+            }
+            if constexpr (F64 && W == 1) {
+                if (FULL && r < PAD_FROM) { dmin = vmin_f64(dmin, (double)sm); dmax = vmax_f64(dmax, (double)sm); }
+                else { dmin = vmin_f64(dmin, pad ? (double)INFINITY : (double)sm); dmax = vmax_f64(dmax, pad ? -(double)INFINITY : (double)sm); }
+            }
         }
     }
     // the row's mean: where the median search starts looking (select_kth; a hint only, never part of a result)
@@ -412,13 +709,32 @@ __device__ __forceinline__ void post_row_staged(TR *buf, const int (&slot)[PostC
     } else
 #endif
     if constexpr (F64) {
-        select_kth64<EPL, W, PAD_FROM>(kh, kl, k1, (unsigned)m, v1, v2, mn, mx, red, wave, lane, phase, guess);
+        bool done = false;
+#ifndef PSS_POST_NO_COMPACT
+        if constexpr (W == 1) {
+            // (the row's extreme keys first: two wave-uniform results instead of two per-lane doubles kept across the search)
+            mn = wave_extreme_key_f64<true>(dmin);
+            mx = wave_extreme_key_f64<false>(dmax);
+            done = select_kth64_compact<EPL, PSS_POST_CPL>(kh, kl, k1, v1, v2, reinterpret_cast<K *>(buf), lane, guess);
+        }
+#endif
+        if (!done) select_kth64<EPL, W, PAD_FROM>(kh, kl, k1, (unsigned)m, v1, v2, mn, mx, red, wave, lane, phase, guess);
 #pragma unroll
         for (int r = 0; r < EPL; r++) key[r] = ((K)kh[r] << 32) | kl[r];     // (register pairs: no instruction)
     } else {
-        unsigned below, upto;
-        v1 = select_kth<EPL, W, PAD_FROM, K>(key, k1, (unsigned)m, v2, mn, mx, below, upto, red, wave, lane, phase, guess == guess,
-                                             [&](float d) { return f2ord(guess + d); });
+        bool done = false;
+#ifndef PSS_POST_NO_COMPACT
+        if constexpr (W == 1) {
+            mn = (K)__builtin_amdgcn_readfirstlane((int)f2ord(__uint_as_float(wave_reduce<OpFMin>(__float_as_uint(fmin32)))));
+            mx = (K)__builtin_amdgcn_readfirstlane((int)f2ord(__uint_as_float(wave_reduce<OpFMax>(__float_as_uint(fmax32)))));
+            done = select_kth32_compact<EPL, PSS_POST_CPL>(key, k1, v1, v2, reinterpret_cast<unsigned *>(buf), lane, guess);
+        }
+#endif
+        if (!done) {
+            unsigned below, upto;
+            v1 = select_kth<EPL, W, PAD_FROM, K>(key, k1, (unsigned)m, v2, mn, mx, below, upto, red, wave, lane, phase, guess == guess,
+                                                 [&](float d) { return f2ord(guess + d); });
+        }
     }
     const double med = (m & 1) ? (double)O::dec(v1) : 0.5 * ((double)O::dec(v1) + (double)O::dec(v2));
     // fd[fd < thr] = thr (:2282-2283).  float32(max(s, thr)) = max(float32(s), float32(thr)) (rounding is monotonic), and

@@ -18,7 +18,7 @@ namespace pss_sp {
 using namespace pss_r16;
 
 #ifndef PSS_EXP_FUSE_WAVES
-#define PSS_EXP_FUSE_WAVES 1     // (experiments: minimum workgroups per CU the register allocation has to allow)
+#define PSS_EXP_FUSE_WAVES 2     // minimum workgroups per CU the register allocation has to allow: two wavefronts per SIMD = at most 256 VGPRs
 #endif
 template <bool ROW32, bool ROW64>
 __global__ __launch_bounds__(256, PSS_EXP_FUSE_WAVES) void k_spectrum_post(const float2 *__restrict__ iq, float *__restrict__ db32, double *__restrict__ db64,

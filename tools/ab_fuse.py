@@ -62,6 +62,9 @@ def main():
         call(v)
     eng.sync()
     ref = {k: (x.cpu().numpy() if x is not None else None) for k, x in bufs[names[0]].items()}
+    import hashlib
+    print("sha256[:16] of", names[0], {k: hashlib.sha256(np.ascontiguousarray(x)).hexdigest()[:16] for k, x in ref.items() if x is not None and k != "pcm"},
+          "(compare across libraries: PSS_LIBRARY=...)", flush=True)
     for v in names[1:]:
         got = {k: (x.cpu().numpy() if x is not None else None) for k, x in bufs[v].items()}
         res = {}
