@@ -462,6 +462,118 @@ def test_float64_pipeline_register_kernels_equal_plain_kernels_and_numpy():
             assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), (nf, n, k, "float32 rows")
 
 
+def _select_branch_rows(n, rng):
+    """dB rows that drive the compaction select of one-wavefront rows (pss_post.h select_kth64_compact / select_kth32_compact) through each of
+    its branches; the second value classifies them with a host emulation of the bracket logic (counts on the keys' high words)."""
+    fam = [-50.0 + 0.25 * rng.standard_normal((6, n)),                      # everything inside the first bracket: more candidates than the cap
+           -50.0 - 3.0 * np.log(rng.random((6, n)))]                        # skewed: the median ~0.9 dB below the mean (second bracket)
+    for _ in range(3):                                                      # long runs on a 0.6 dB grid: ties among the candidates
+        rows = np.empty((16, n))
+        for k in range(16):
+            pos = 0
+            while pos < n:
+                ln = int(rng.integers(5, 40))
+                rows[k, pos:pos + ln] = -50.0 + 0.6 * rng.integers(-3, 4)
+                pos += ln
+        fam.append(rows)
+    rows = np.empty((6, n))                                                 # two far-apart modes in long runs: the median outside both brackets
+    for k in range(6):
+        pos = 0
+        while pos < n:
+            ln = min(int(rng.integers(20, 60)), n - pos)
+            rows[k, pos:pos + ln] = (-40.0 + rng.standard_normal(ln)) if rng.random() < 0.55 else (-75.0 + 0.1 * rng.standard_normal(ln))
+            pos += ln
+    fam.append(rows)
+    r = -45.0 + 5.6 * rng.standard_normal((6, n))                           # a third of the row inside one high word around the median
+    idx = rng.permutation(n)[: n // 3]
+    r[:, idx] = -45.0 + 1e-9 * rng.standard_normal((6, idx.size))
+    fam.append(r)
+    fam.append(-45.0 + 5.6 * rng.standard_normal((300, n)))                 # noise rows: rank k is the last key of its bracket in ~1 % of them
+    return np.concatenate(fam)
+
+
+def _select_branch_classes(rows, cap=128):
+    def d2ord(v):
+        u = np.asarray(v, dtype=np.float64).view(np.uint64)
+        return np.where((u >> np.uint64(63)).astype(bool), ~u, u | np.uint64(1 << 63))
+    out = []
+    for row in rows:
+        m = row.size - 4
+        sm = row[0:m] * 0.2
+        for j in range(1, 5):
+            sm = sm + row[j:j + m] * 0.2
+        g = np.float32(sm.astype(np.float32).sum(dtype=np.float32) / np.float32(m))
+        k = (m - 1) >> 1
+        kh = (d2ord(sm) >> np.uint64(32)).astype(np.int64)
+        srt = np.sort(sm)
+        cls = "general"
+        for d in (np.float32(0.5), np.float32(2.0)):
+            lo, hi = (int(d2ord(np.float64(np.float32(x))) >> np.uint64(32)) for x in (g - d, g + d))
+            nlo, M = int((kh < lo).sum()), int(((kh >= lo) & (kh <= hi)).sum())
+            if not (nlo <= k < nlo + M):
+                continue
+            cls, nhi = ("first" if d < 1 else "second"), nlo + M
+            if M > cap:
+                cls += ":narrowed"
+                while nhi - nlo > cap and lo < hi:
+                    t = lo + ((hi - lo + 1) >> 1)
+                    c = int((kh < t).sum())
+                    if c <= k:
+                        lo, nlo = t, c
+                    else:
+                        hi, nhi = t - 1, c
+                if nhi - nlo > cap:
+                    cls += ":fallback"
+                    break
+            cls += ":tie" if srt[k] == srt[k + 1] else ":last" if k + 1 == nhi else ""
+            break
+        out.append(cls)
+    return out
+
+
+def test_compaction_select_branches_equal_numpy():
+    """The order statistics of rows owned by one wavefront (round 6: candidates of the bracket compacted through LDS, the search continued on whole
+    keys with ballot counts): rows built to take every branch — more candidates than the cap (sweeps + second compaction), the second bracket,
+    neither bracket (the general search), ties among the candidates, rank k + 1 equal to rank k, rank k the LAST key of its bracket (rank k + 1
+    then comes from a sweep over all elements), too many keys sharing a high word (falls back) — against np.convolve / np.median / the clamp
+    bit for bit, float64 rows and float32 rows (the float32 rounding of the float64 sums), row extremes included."""
+    e = G.engine()
+    import collections
+    for n in (260, 516, 1024, 1028, 2048):
+        rng = np.random.default_rng(5 + n)
+        rows = _select_branch_rows(n, rng)
+        nf, m = rows.shape[0], n - 4
+        seen = collections.Counter(c2 for c in _select_branch_classes(rows) for c2 in c.split(":"))
+        for need in ("first", "general", "narrowed", "tie") + (("fallback", "last") if n >= 1024 else ()) + (("second",) if n <= 1028 else ()):
+            assert seen[need] > 0, (n, need, dict(seen))          # (the host classification of THESE seeded rows; no GPU involved)
+        sm = rows[:, 0:m] * 0.2
+        for j in range(1, 5):
+            sm = sm + rows[:, j:j + m] * 0.2
+        # float64 rows
+        d_p, d_lo, d_hi = G.empty((nf, m), torch.float64), G.empty((nf,), torch.float64), G.empty((nf,), torch.float64)
+        e.spectrum_post_f64(G.dev(rows), nf, n, d_p, d_lo, d_hi)
+        e.sync()
+        med = np.median(sm, axis=1)
+        want = np.maximum(sm, (med - 10)[:, None])
+        assert np.array_equal(G.host(d_p), want), n
+        assert np.array_equal(G.host(d_lo), want.min(axis=1)) and np.array_equal(G.host(d_hi), want.max(axis=1)), n
+        # float32 rows: the smoothed row is the float32 rounding of the float64 sums; the median of THOSE values; the threshold rounded to float32
+        rows32 = rows.astype(np.float32)
+        s32 = rows32[:, 0:m].astype(np.float64) * 0.2
+        for j in range(1, 5):
+            s32 = s32 + rows32[:, j:j + m].astype(np.float64) * 0.2
+        s32 = s32.astype(np.float32)
+        srt = np.sort(s32, axis=1)
+        k = (m - 1) >> 1
+        med32 = srt[:, k].astype(np.float64) if m & 1 else 0.5 * (srt[:, k].astype(np.float64) + srt[:, k + 1].astype(np.float64))
+        want32 = np.maximum(s32, (med32 - 10.0).astype(np.float32)[:, None])
+        d_p, d_lo, d_hi = G.empty((nf, m), torch.float32), G.empty((nf,), torch.float32), G.empty((nf,), torch.float32)
+        e.spectrum_post_extremes(G.dev(rows32), nf, n, d_p, d_lo, d_hi)
+        e.sync()
+        assert np.array_equal(G.host(d_p), want32), n
+        assert np.array_equal(G.host(d_lo), want32.min(axis=1)) and np.array_equal(G.host(d_hi), want32.max(axis=1)), n
+
+
 def test_full_size_float64_pipeline_cells_equal_the_oracle_from_iq():
     """BASELINE.json cfg 2 size (65 536 x 1024) through pss_frame_pipeline_nfm_f64 without materialised rows — the cell-exact step bench.py
     times: EVERY waterfall cell (glyph and colour, 2 x 7.3 million) and every int16 PCM sample against the oracle's own step from IQ in the
