@@ -1682,10 +1682,21 @@ int display_rows(pss_ctx *ctx, const T *d_post, long n_frames, int len, const T 
         (n_frames > 0 && ((!d_post && !d_vals) || !d_lo || !d_hi || !d_a || (MODE == 0 && !d_b))))
         return pss_fail(ctx, PSS_E_ARG, "bad display-rows arguments");
     if (n_frames == 0) return PSS_OK;
-    int r = pss_ensure_buffer(ctx, &ctx->scratch_win, &ctx->scratch_win_bytes, (size_t)n_frames * 2 * sizeof(double), "window extremes");
-    if (r) return r;
-    double *wlo = reinterpret_cast<double *>(ctx->scratch_win), *whi = wlo + n_frames;
     pss_time_begin(ctx);
+    if (d_vals) {
+        // the batched steps: window extremes and the lines from the resampled rows in ONE launch
+        constexpr int RPB = 32;
+        const long groups = (n_frames + RPB - 1) / RPB;
+        pss_kernel_begin(ctx, "k_disp_rows");
+        hipLaunchKernelGGL((pss_post::k_disp_vals_win<MODE, T, RPB>), dim3((unsigned)(groups < 8192 ? groups : 8192)), dim3(256), 0, PSS_STREAM(ctx),
+                           d_vals, d_lo, d_hi, n_frames, n_halo, window, disp_w, disp_h, d_a, d_b);
+        pss_kernel_end(ctx);
+        pss_time_end(ctx);
+        return pss_hip_check(ctx, hipGetLastError(), "k_disp_vals_win launch");
+    }
+    int r = pss_ensure_buffer(ctx, &ctx->scratch_win, &ctx->scratch_win_bytes, (size_t)n_frames * 2 * sizeof(double), "window extremes");
+    if (r) { pss_time_end(ctx); return r; }
+    double *wlo = reinterpret_cast<double *>(ctx->scratch_win), *whi = wlo + n_frames;
     pss_kernel_begin(ctx, "k_slide_extremes");
     hipLaunchKernelGGL(pss_post::k_slide_extremes<T>, dim3((unsigned)((n_frames + 255) / 256 < 4096 ? (n_frames + 255) / 256 : 4096)),
                        dim3(256), 0, PSS_STREAM(ctx), d_lo, d_hi, n_frames, n_halo, window, wlo, whi);

@@ -994,4 +994,44 @@ __global__ __launch_bounds__(256) void k_disp_vals(const double *__restrict__ va
     }
 }
 
+// k_slide_extremes and k_disp_vals in one launch (the batched steps: one kernel and one launch gap less at the end of the display chain): a
+// workgroup takes RPB consecutive frames, its first RPB threads form their frames' window extremes (the same loop as k_slide_extremes: <= window
+// (lo, hi) pairs each, L2-resident), then all threads quantise the RPB x disp_w cells; the window extremes never reach memory.
+template <int MODE, class T, int RPB>
+__global__ __launch_bounds__(256) void k_disp_vals_win(const double *__restrict__ vals, const T *__restrict__ row_lo, const T *__restrict__ row_hi,
+                                                       long n_frames, int n_halo, int window, int disp_w, int disp_h, int8_t *__restrict__ out_a,
+                                                       int8_t *__restrict__ out_b)
+{
+    __shared__ double s_lo[RPB], s_hi[RPB];
+    const long groups = (n_frames + RPB - 1) / RPB;
+    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+        const long f0 = g * RPB;
+        const int rows = (int)(n_frames - f0 < RPB ? n_frames - f0 : RPB);
+        if ((int)threadIdx.x < rows) {
+            const long i = f0 + threadIdx.x, p = i + n_halo;
+            long first = p - (window - 1);
+            if (first < 0) first = 0;
+            double lo = INFINITY, hi = -INFINITY;
+            for (long q = first; q <= p; q++) {
+                const double a = (double)row_lo[q], b = (double)row_hi[q];
+                lo = a < lo ? a : lo;
+                hi = b > hi ? b : hi;
+            }
+            s_lo[threadIdx.x] = lo;
+            s_hi[threadIdx.x] = hi;
+        }
+        __syncthreads();
+        const int cells = rows * disp_w;
+        const size_t c0 = (size_t)f0 * disp_w;
+        for (int c = threadIdx.x; c < cells; c += blockDim.x) {
+            const int fr = c / disp_w;
+            int8_t a, b = 0;
+            quantise_cell<MODE>(vals[c0 + c], s_lo[fr], s_hi[fr], disp_h, a, b);
+            out_a[c0 + c] = a;
+            if (MODE == 0) out_b[c0 + c] = b;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace pss_post
