@@ -489,6 +489,9 @@ __global__ __launch_bounds__(WFM ? 2 * TILE : TILE) void k_nfm_bwd(const double 
                                                   int n_out, long n_frames, NfmCoef c, int16_t *__restrict__ pcm,
                                                   double *__restrict__ audio)
 {
+#ifdef PSS_EXP_BWD_PRIO     // timing experiment: the backward pass's user priority while it runs beside the display chain (reset at the end)
+    __builtin_amdgcn_s_setprio(PSS_EXP_BWD_PRIO);
+#endif
     const int lane = threadIdx.x & (TILE - 1);
     const int chan = WFM ? (int)(threadIdx.x >> 6) : 0;
     const long tile = WFM ? 2 * (long)blockIdx.x + chan : (long)blockIdx.x;
@@ -497,7 +500,11 @@ __global__ __launch_bounds__(WFM ? 2 * TILE : TILE) void k_nfm_bwd(const double 
     const long L = (long)M + 2 * EDGE;
     const double *Yt = Y + (size_t)tile * L * TILE + lane;
     double *At = A + (size_t)tile * n_out * TILE + lane;
+#ifdef PSS_EXP_BWD_NOLOAD   // timing experiment only (results wrong): the backward pass without its y_fwd reads
+#define YAT(p) ((double)(p) * 1e-3 + (double)lane)
+#else
 #define YAT(p) Yt[(size_t)(p) * TILE]
+#endif
     const double ylast = YAT(L - 1);
     double z[8];
 #pragma unroll
@@ -547,6 +554,9 @@ __global__ __launch_bounds__(WFM ? 2 * TILE : TILE) void k_nfm_bwd(const double 
             }
         }
     }
+#ifdef PSS_EXP_BWD_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #undef YAT
 }
 

@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256, PSS_EXP_FUSE_WAVES) void k_spectrum_post(const
     constexpr size_t EXS = C::EX;
     double2 *tw2 = ex_all + (size_t)FPW * C::EX;
 #endif
+#ifdef PSS_EXP_POST_PRIO    // timing experiment: this kernel's user priority beside the backward pass (reset at the end)
+    __builtin_amdgcn_s_setprio(PSS_EXP_POST_PRIO);
+#endif
     const int tid = threadIdx.x;
     const int fl = __builtin_amdgcn_readfirstlane(tid / T);   // frame slot = wavefront of the workgroup
     const int t = tid % T;
@@ -121,6 +124,9 @@ __global__ __launch_bounds__(256, PSS_EXP_FUSE_WAVES) void k_spectrum_post(const
 #endif
         frame_sync<true>();                                    // the next frame's stage 1 overwrites the buffer
     }
+#ifdef PSS_EXP_POST_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 }  // namespace pss_sp
