@@ -141,7 +141,8 @@ def step_traffic(kernels, n_frames):
         if t.get("src_hash") != source_hash():
             return None, None
         ks = t["kernels"]
-        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel", "k_disp_rows": "k_disp_vals"}   # (k_spectrum_post: its own name)
+        # timer label -> kernel name in the digest (k_spectrum_post: its own name; the lines: one launch since round 6, k_disp_vals_win)
+        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel", "k_disp_rows": "k_disp_vals_win" if "k_disp_vals_win" in ks else "k_disp_vals"}
         tot = 0.0
         for k in kernels:
             d = ks.get(names.get(k, k))
@@ -162,7 +163,8 @@ def step_valu(kernels, n_frames, ms_per_step):
         if t.get("src_hash") != source_hash() or n_frames != t["n_frames"]:
             return None
         ks = t["kernels"]
-        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel", "k_disp_rows": "k_disp_vals"}
+        names = {"k_spectrum": "k_spectrum_r16", "k_post": "k_post_sel",
+                 "k_disp_rows": "k_disp_vals_win" if "k_disp_vals_win" in t["kernels"] else "k_disp_vals"}
         per = {}
         for k in kernels:
             d = ks.get(names.get(k, k))
