@@ -306,16 +306,19 @@ __device__ __forceinline__ void select_kth64(const unsigned (&kh)[EPL], const un
 
 // ---- the same order statistics for a row owned by ONE wavefront, by COMPACTION (round 6) -----------------------------------------------
 // Every counting pass of select_kth sweeps all EPL register slots of every lane (v_cmp + v_addc per element, then a wave reduction) to
-// learn ONE bit of rank k's position, although after the two bracket counts only the keys inside the bracket [lo, hi] (a tenth of a dB row
-// for the +-0.5 dB bracket around its mean) can still be rank k.  Here the sweep over all elements stops as soon as at most 64 CPL keys are
-// left in the bracket; those are compacted through LDS (positions from v_mbcnt over the ballots of the slots: no scan, no atomics) into CPL
-// whole 64-bit keys per lane, and the search continues on them alone: one v_cmp per lane-slot and pass, counted with s_bcnt1 on the ballot —
-// no wave reduction — down to the key itself (low words included: no masked low-word sweeps afterwards); rank k + 1 is the smallest
-// candidate above it (or, when rank k is the bracket's last key, the smallest key above the bracket: one sweep over the high words).
-// The row's extreme keys come from v_min_f64 / v_max_f64 over the smoothed values (dmin / dmax: this lane's, padding excluded) — valid
+// learn ONE bit of rank k's position, although only the keys inside the guess bracket [lo, hi] (a tenth of a dB row for the +-0.5 dB bracket
+// around its mean) can still be rank k.  Here: ONE counting sweep (keys below the bracket), then a COMPACTION sweep that is the bracket's second
+// count as well: every key inside goes to LDS (positions from v_mbcnt over the ballots of the slots + a running scalar base: no scan, no
+// atomics; the row's idle staging buffer holds a whole row).  More than 64 CPL of them: sweeps over all elements halve the bracket first, then a
+// second compaction.  CPL whole 64-bit keys per lane are read back and the search continues on them alone: one v_cmp per lane-slot and pass,
+// counted with s_bcnt1 on the ballot — no wave reduction, the bracket arithmetic on the scalar unit — down to the key itself (low words
+// included: no masked low-word sweeps afterwards); rank k + 1 is the smallest candidate above it (or, when rank k is the bracket's last key,
+// the smallest key above the bracket: one sweep over the high words, one over the low words).
+// The row's extreme keys come from v_min_f64 / v_max_f64 over the smoothed values (the caller reduces them before the search) — valid
 // because this path is only taken for rows without a NaN (the row's mean, `guess`, is a sum over every element).
-// Every result is decided by exact counts, as in select_kth; returns false — nothing touched — when the row does not fit the scheme (NaN
-// or infinite mean, rank k outside both brackets, more than 64 CPL keys sharing one high word): the caller then runs select_kth64.
+// Every result is decided by exact counts, as in select_kth; returns false — v1 / v2 untouched, only the idle staging buffer written — when the
+// row does not fit the scheme (NaN or infinite mean, rank k outside both brackets, more than 64 CPL keys sharing one high word): the caller then
+// runs select_kth64.
 #ifndef PSS_POST_CPL
 #define PSS_POST_CPL 2
 #endif
