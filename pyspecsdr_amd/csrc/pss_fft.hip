@@ -1704,9 +1704,7 @@ int display_rows(pss_ctx *ctx, const T *d_post, long n_frames, int len, const T 
     const long cells = n_frames * disp_w;
     pss_kernel_begin(ctx, "k_disp_rows");
     const dim3 dgrid((unsigned)((cells + 255) / 256 < 16384 ? (cells + 255) / 256 : 16384));
-    if (d_vals)
-        hipLaunchKernelGGL((pss_post::k_disp_vals<MODE>), dgrid, dim3(256), 0, PSS_STREAM(ctx), d_vals, wlo, whi, n_frames, disp_w, disp_h, d_a, d_b);
-    else if (d_thr)
+    if (d_thr)
         hipLaunchKernelGGL((pss_post::k_disp_rows<T, MODE, true>), dgrid, dim3(256), 0, PSS_STREAM(ctx), d_post, wlo, whi, n_frames, len,
                            disp_w, disp_h, d_a, d_b, d_thr);
     else

@@ -320,7 +320,10 @@ __device__ __forceinline__ void select_kth64(const unsigned (&kh)[EPL], const un
 // row does not fit the scheme (NaN or infinite mean, rank k outside both brackets, more than 64 CPL keys sharing one high word): the caller then
 // runs select_kth64.
 #ifndef PSS_POST_CPL
-#define PSS_POST_CPL 2
+#define PSS_POST_CPL 2       // candidates per lane after the compaction (3 / 4: measured no faster, NOTEBOOK R6-14)
+#endif
+#ifndef PSS_POST_CBAR
+#define PSS_POST_CBAR 4      // a scheduling barrier after every PSS_POST_CBAR-th slot of the compaction sweep
 #endif
 // the lanes of one wavefront execute their LDS instructions in order: a fence, no workgroup barrier
 __device__ __forceinline__ void wave_lds_sync()
@@ -416,9 +419,6 @@ __device__ __forceinline__ bool select_kth64_compact(const unsigned (&kh)[EPL], 
                 const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, base));
                 if (in) cand[pos] = join(kh[r], kl[r]);
                 base += (unsigned)__builtin_popcountll(mask);
-#ifndef PSS_POST_CBAR
-#define PSS_POST_CBAR 4
-#endif
                 if (r % PSS_POST_CBAR == PSS_POST_CBAR - 1) __builtin_amdgcn_sched_barrier(0);   // (sixteen positions and addresses in flight cost 48 registers)
             }
             M = base;
@@ -636,7 +636,7 @@ struct StagedRow {
 // threshold: k_disp_rows<..., FROM_DB>); row_thr (nullable) receives the row's clamp threshold (float32(median - 10); float64 rows: median - 10).
 // vals (nullable, with disp_w): the row resampled to the display width — np.interp(np.linspace(0, m - 1, disp_w), np.arange(m), row), float64,
 // what draw_waterfall / draw_persistence normalise and quantise (pyspecsdr.py:1379-1383, :1550-1554) — so that the display kernel of a batch
-// reads disp_w values per row instead of the row (k_disp_vals).
+// reads disp_w values per row instead of the row (k_disp_vals_win).
 // TR = float: the float32 rows of pss_spectrum_db (sums in float64, rounded once); TR = double: the reference's own row type throughout
 // (np.median of a row with a NaN is NaN and clamps nothing).
 template <int EPL, int W, bool FULL, class TR>
@@ -981,23 +981,8 @@ __global__ __launch_bounds__(256) void k_disp_rows(const T *__restrict__ post, c
     }
 }
 
-// The same line from the row already resampled to the display width (k_post_sel's `vals`): disp_w float64 values per frame instead of the row.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_disp_vals(const double *__restrict__ vals, const double *__restrict__ win_lo,
-                                                   const double *__restrict__ win_hi, long n_frames, int disp_w, int disp_h,
-                                                   int8_t *__restrict__ out_a, int8_t *__restrict__ out_b)
-{
-    const long total = n_frames * disp_w;
-    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long)gridDim.x * blockDim.x) {
-        const long f = c / disp_w;
-        int8_t a, b = 0;
-        quantise_cell<MODE>(vals[c], win_lo[f], win_hi[f], disp_h, a, b);
-        out_a[c] = a;
-        if (MODE == 0) out_b[c] = b;
-    }
-}
-
-// k_slide_extremes and k_disp_vals in one launch (the batched steps: one kernel and one launch gap less at the end of the display chain): a
+// The display lines of a batch from the rows already resampled to the display width (k_post_sel's `vals`: disp_w float64 values per frame instead
+// of the row) AND the sliding-window extremes they are normalised with, in one launch (one kernel and one launch gap less at the end of the chain): a
 // workgroup takes RPB consecutive frames, its first RPB threads form their frames' window extremes (the same loop as k_slide_extremes: <= window
 // (lo, hi) pairs each, L2-resident), then all threads quantise the RPB x disp_w cells; the window extremes never reach memory.
 template <int MODE, class T, int RPB>
