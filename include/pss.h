@@ -279,6 +279,12 @@ int pss_spectrum_db_c128(pss_ctx *ctx, const double *d_iq, long n_frames, int n_
 int pss_demod_am_c128(pss_ctx *ctx, const double *d_iq, long n_frames, int n, int16_t *d_pcm, double *d_audio);
 int pss_h_compute_fft_c128(pss_ctx *ctx, const double *h_iq, int n, double *h_db);
 int pss_h_demodulate_am_c128(pss_ctx *ctx, const double *h_iq, int n, double *h_audio_stereo, int16_t *h_pcm);
+/* measure_signal_power (signal_processing.py:325-328) of complex128 frames, the ARRAY part: d_power[f] = np.mean(np.abs(x) ** 2) in float64 (np.abs's
+ * scaled hypot, x * x, NumPy's pairwise sum, / n — tests/golden/c128.npz keys mp_*).  The scalar the reference finishes with,
+ * 10 * log10(power + 1e-10), is left to the caller: it is NumPy's float64 log10 of ONE number (the Python shim applies NumPy's own, which gives the
+ * reference's bits on the host it runs on: keys pw_*). */
+int pss_mean_power_c128(pss_ctx *ctx, const double *d_iq, long n_frames, int n, double *d_power);
+int pss_h_mean_power_c128(pss_ctx *ctx, const double *h_iq, int n, double *h_power);
 
 /* Waterfall / persistence quantisers over a ring of post-processed rows (pyspecsdr.py:1342-1406,
  * :1512-1564).  d_rows float32 [n_rows][len], oldest first (n_rows <= 30 / <= 10).

@@ -966,6 +966,14 @@ double pss_o_pairwise_sum_f64(const double *a, long n)
     for (long st = B; st < n; st += B) acc += pairwise_chunk_f64(a + st, (n - st) < B ? (n - st) : B);
     return acc;
 }
+/* measure_signal_power (signal_processing.py:325-328) of a complex128 buffer, the array part: np.mean(np.abs(samples) ** 2) in float64 — np.abs as
+ * above, x ** 2 = x * x, np.mean = the pairwise sum / n.  The caller finishes with the scalar 10 * log10(power + 1e-10) (NumPy's own float64 log10:
+ * tests/test_oracle_golden.py applies it with NumPy, as the drop-in shim does).  scratch: n doubles. */
+double pss_o_mean_power_c128(const double *iq, int n, double *scratch)
+{
+    for (int i = 0; i < n; i++) { const double a = pss_o_cabs(iq[2 * i], iq[2 * i + 1]); scratch[i] = a * a; }
+    return pss_o_pairwise_sum_f64(scratch, n) / (double)n;
+}
 void pss_o_demod_am_c128(const double *iq, int n, const double *sos, int nsec, double *audio)
 {
     for (int i = 0; i < n; i++) audio[i] = pss_o_cabs(iq[2 * i], iq[2 * i + 1]);   /* :182 */

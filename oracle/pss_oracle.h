@@ -55,6 +55,7 @@ int pss_o_demod_nfm(const float *iq, int n, double fs, int q, const double *taps
                     const double *zi, double *audio, float *disc_out, double *fir_out);
 /* demodulate_am — signal_processing.py:179-195 (+ bandpass_filter :34-42). sos[5][6]. audio[n]. */
 void pss_o_demod_am(const float *iq, int n, const double *sos, int nsec, double *audio);
+double pss_o_mean_power_c128(const double *iq, int n, double *scratch);   /* complex128 buffer: np.mean(np.abs(x) ** 2) in float64 (the array part of :325-328) */
 void pss_o_demod_am_c128(const double *iq, int n, const double *sos, int nsec, double *audio);   /* complex128 buffer: float64 abs / mean */
 double pss_o_cabs(double re, double im);
 double pss_o_pairwise_sum_f64(const double *a, long n);

@@ -368,6 +368,23 @@ extern "C" int pss_h_demodulate_am_c128(pss_ctx *ctx, const double *h_iq, int n,
     return PSS_OK;
 }
 
+extern "C" int pss_h_mean_power_c128(pss_ctx *ctx, const double *h_iq, int n, double *h_power)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (!h_iq || !h_power || n < 1) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
+    const size_t o_p = up256(sizeof(double) * 2 * n);
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_p + 256, "staging");
+    if (r) return r;
+    char *base = reinterpret_cast<char *>(ctx->stage);
+    PSS_HIP(ctx, hipMemcpyAsync(base, h_iq, sizeof(double) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
+    r = pss_mean_power_c128(ctx, reinterpret_cast<const double *>(base), 1, n, reinterpret_cast<double *>(base + o_p));
+    if (r) return r;
+    PSS_HIP(ctx, hipMemcpyAsync(h_power, base + o_p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSS_OK;
+}
+
 static int h_demod_impl(pss_ctx *ctx, int mode, const float *h_iq, int n, double fs, double *h_audio_stereo,
                         int16_t *h_pcm, bool dispatcher)
 {

@@ -3750,6 +3750,25 @@ __global__ __launch_bounds__(256) void k_am_env_c128(const double2 *__restrict__
         __syncthreads();
     }
 }
+// measure_signal_power's array part for complex128 frames (:327): P[f] = np.mean(np.abs(x) ** 2) in float64; E: n doubles of scratch per frame
+__global__ __launch_bounds__(256) void k_power_c128(const double2 *__restrict__ iq, int n, long n_frames, double *__restrict__ E, double *__restrict__ P)
+{
+    for (long f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const double2 *x = iq + (size_t)f * n;
+        double *e = E + (size_t)f * n;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const double a = cabs_np64(x[i].x, x[i].y);
+            e[i] = __dmul_rn(a, a);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double acc = pairwise_chunk_f64(e, n < 8192 ? n : 8192);
+            for (int st = 8192; st < n; st += 8192) acc = __dadd_rn(acc, pairwise_chunk_f64(e + st, (n - st) < 8192 ? (n - st) : 8192));
+            P[f] = __ddiv_rn(acc, (double)n);
+        }
+        __syncthreads();
+    }
+}
 // audio / np.max(np.abs(audio)) * 0.95 (:194; np.max propagates a NaN), mono float64 and / or int16 stereo
 __global__ __launch_bounds__(256) void k_norm_rows_f64(const double *__restrict__ Y, int n, long n_frames, int16_t *__restrict__ pcm, double *__restrict__ audio)
 {
@@ -3817,6 +3836,24 @@ extern "C" int pss_demod_am_c128(pss_ctx *ctx, const double *d_iq, long n_frames
     }
     pss_time_end(ctx);
     return r;
+}
+
+// measure_signal_power (signal_processing.py:325-328) of complex128 frames, the array part: d_power[f] = np.mean(np.abs(x) ** 2) in float64 as the
+// reference computes it for such a buffer.  The scalar that follows — 10 * log10(power + 1e-10), NumPy's float64 log10 — is the caller's (the Python
+// shim applies NumPy's own; tests/golden/c128.npz keys mp_* / pw_*).
+extern "C" int pss_mean_power_c128(pss_ctx *ctx, const double *d_iq, long n_frames, int n, double *d_power)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames < 0 || n < 1 || (n_frames > 0 && (!d_iq || !d_power))) return pss_fail(ctx, PSS_E_ARG, "pss_mean_power_c128: bad argument");
+    if (n_frames == 0) return PSS_OK;
+    int r = pss_ensure_scratch(ctx, align256((size_t)n_frames * n * sizeof(double)));
+    if (r) return r;
+    pss_kernel_begin(ctx, "k_power_c128");
+    hipLaunchKernelGGL(k_power_c128, dim3((unsigned)(n_frames < 4096 ? n_frames : 4096)), dim3(256), 0, PSS_STREAM(ctx), reinterpret_cast<const double2 *>(d_iq), n,
+                       n_frames, reinterpret_cast<double *>(ctx->scratch), d_power);
+    pss_kernel_end(ctx);
+    return pss_hip_check(ctx, hipGetLastError(), "k_power_c128 launch");
 }
 
 extern "C" int pss_afsk_n_bits(int n, double fs)

@@ -561,6 +561,16 @@ class Engine:
         self._ck(self.lib.pss_h_demodulate_am_c128(self.h, _ptr(iq), len(iq), _ptr(audio), _ptr(pcm)))
         return audio, pcm
 
+    def h_mean_power_c128(self, iq):
+        """np.mean(np.abs(iq) ** 2) of a complex128 buffer in float64 (the array part of measure_signal_power): np.float64."""
+        iq = np.ascontiguousarray(iq, np.complex128)
+        out = np.empty(1, np.float64)
+        self._ck(self.lib.pss_h_mean_power_c128(self.h, _ptr(iq), len(iq), _ptr(out)))
+        return out[0]
+
+    def mean_power_c128(self, d_iq, n_frames, n, d_power):
+        self._dev(self.lib.pss_mean_power_c128, _ptr(d_iq), n_frames, n, _ptr(d_power))
+
     def spectrum_db_c128(self, d_iq, n_frames, n_fft, d_db):
         self._dev(self.lib.pss_spectrum_db_c128, _ptr(d_iq), n_frames, n_fft, _ptr(d_db))
 

@@ -114,8 +114,8 @@ _warned_narrowing = False
 
 def _samples(samples):
     """The reference's read buffer is complex64 (pyspecsdr.py:1885-1891) and the kernels replay NumPy's complex64
-    arithmetic; wider input (complex128) makes the reference compute in float64.  compute_fft (power-of-two lengths) and
-    demodulate_am serve such buffers in float64 (pss_h_*_c128); everywhere else it is narrowed, with a one-time warning."""
+    arithmetic; wider input (complex128) makes the reference compute in float64.  compute_fft (power-of-two lengths),
+    demodulate_am and measure_signal_power serve such buffers in float64 (pss_h_*_c128); everywhere else it is narrowed, with a one-time warning."""
     global _warned_narrowing
     s = np.asarray(samples)
     if s.ndim != 1:
@@ -270,4 +270,8 @@ def demodulate_pcm(samples, sample_rate, mode='NFM'):
 
 
 def measure_signal_power(samples):
+    if _is_c128(samples) and len(samples) >= 1:
+        # float64 as the reference computes it for such a buffer: the mean power on the device, the scalar log10 with NumPy's own float64 log10
+        power = get_engine().h_mean_power_c128(samples)
+        return 10 * np.log10(power + 1e-10)
     return get_engine().h_measure_power(_samples(samples))

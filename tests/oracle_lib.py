@@ -137,6 +137,14 @@ def compute_fft_c128(iq):
     return out
 
 
+def mean_power_c128(iq):
+    """np.mean(np.abs(x) ** 2) of a complex128 buffer in float64 (the array part of measure_signal_power)."""
+    x = np.ascontiguousarray(iq, np.complex128)
+    f = lib().pss_o_mean_power_c128
+    f.argtypes, f.restype = [_f64p, C.c_int, _f64p], C.c_double
+    return np.float64(f(x.view(np.float64), len(x), np.empty(len(x), np.float64)))
+
+
 def demod_am_c128(iq, sos):
     """demodulate_am of a complex128 buffer (float64 np.abs / np.mean)."""
     x = np.ascontiguousarray(iq, np.complex128)

@@ -1812,6 +1812,10 @@ def test_round6_complex128_buffers_vs_reference_goldens(golden):
                 if n >= 16 and (n & (n - 1)) == 0:
                     db = sp.compute_fft(x)
                     assert db.dtype == np.float64 and np.allclose(db, g[f"db_{t}"][k], rtol=1e-9, atol=1e-9), (t, k)
+                # measure_signal_power: the mean power from the device in float64, the scalar log10 by NumPy on the host — the reference's bits
+                pw = sp.measure_signal_power(x)
+                assert isinstance(pw, np.float64) and pw == g[f"pw_{t}"][k], (t, k)
+                assert e.h_mean_power_c128(x) == g[f"mp_{t}"][k], (t, k)
         with np.errstate(all="ignore"):
             z = g["iq_z"][0]
             assert np.array_equal(sp.compute_fft(z), g["db_z"][0])
@@ -1829,6 +1833,10 @@ def test_round6_complex128_buffers_vs_reference_goldens(golden):
     assert np.allclose(G.host(d_db)[-nf:], g[f"db_{t}"], rtol=1e-9, atol=1e-9)
     assert np.array_equal(G.host(d_au)[:nf], g[f"audio_{t}"]) and np.array_equal(G.host(d_au)[-nf:], g[f"audio_{t}"])
     assert np.array_equal(G.host(d_pcm)[-nf:, :, 0], g[f"pcm_{t}"]) and np.array_equal(G.host(d_pcm)[..., 0], G.host(d_pcm)[..., 1])
+    d_pw = G.empty((len(big),), torch.float64)
+    e.mean_power_c128(d_iq, len(big), n, d_pw)
+    e.sync()
+    assert np.array_equal(G.host(d_pw)[:nf], g[f"mp_{t}"]) and np.array_equal(G.host(d_pw)[-nf:], g[f"mp_{t}"])
     # random buffers of awkward lengths against the oracle (the pairwise tree's uneven splits, chunks of 8192)
     rng = np.random.default_rng(66)
     sos = g["am_sos"]
@@ -1838,6 +1846,7 @@ def test_round6_complex128_buffers_vs_reference_goldens(golden):
             want = O.demod_am_c128(x, sos)
             got = sp.demodulate_am(x)[:, 0]
         assert np.array_equal(got, want, equal_nan=True), n
+        assert e.h_mean_power_c128(x) == O.mean_power_c128(x), n
     # demodulate_nfm at a decimation factor of ONE (target_rate above half the sample rate: nothing is dropped, n - 1 output samples)
     keep = sp.USE_SCIPY_DESIGNS
     try:

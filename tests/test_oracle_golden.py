@@ -489,6 +489,10 @@ def test_round6_complex128_buffers_oracle_vs_reference(golden):
             # narrowing to complex64 first (rounds 1-5) does NOT give these bits
             if len(x) >= 1000:
                 assert not np.array_equal(O.demod_am(x.astype(np.complex64), sos), g[f"audio_{t}"][k])
+            # measure_signal_power (:325-328): the array part np.mean(np.abs(x) ** 2) restated in float64, the scalar log10 with NumPy's own
+            p = O.mean_power_c128(x)
+            assert p == g[f"mp_{t}"][k], (t, k)
+            assert 10 * np.log10(p + 1e-10) == g[f"pw_{t}"][k], (t, k)
     # demodulate_nfm at a decimation factor of one (target_rate above half the sample rate)
     for t in g["q1_tags"]:
         fs, tr = float(g[f"n_fs_{t}"]), float(g[f"n_tr_{t}"])

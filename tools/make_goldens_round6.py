@@ -6,6 +6,7 @@ The reference's SDR read buffer is complex64 (pyspecsdr.py:1887), but its functi
 from the first statement on:
     compute_fft    (signal_processing.py:243-264): `samples * window` is a float64 product of float64 samples
     demodulate_am  (:179-195): np.abs / np.mean / the subtraction in float64 (complex64 input: float32)
+    measure_signal_power (:325-328): np.abs ** 2 / np.mean in float64, the scalar log10 in float64 (keys mp_* / pw_*)
 Rounds 1-5 narrowed such input to complex64 with a warning; round 6 serves these two functions in float64.
 The same file carries round 6's other new vectors: demodulate_nfm and demodulate_wfm at a decimation factor int(sample_rate / target_rate) of ONE
 (keys n_* / w_*: NFM runs decimate(x, 1), WFM skips the stage, signal_processing.py:111-112 / :152-155).
@@ -45,6 +46,10 @@ def main():
         d[f"pcm_{tag}"] = np.int16(aud[..., 0] * 32767)
         d[f"abs_{tag}"] = np.abs(iq[0])
         d[f"mean_{tag}"] = np.array(np.mean(np.abs(iq[0])))
+        # measure_signal_power (:325-328) of the same buffers: float64 np.abs ** 2 / np.mean, then the scalar 10 * np.log10(power + 1e-10);
+        # mp_*: the array part (the mean power), pw_*: what the function returns
+        d[f"mp_{tag}"] = np.array([np.mean(np.abs(x) ** 2) for x in iq])
+        d[f"pw_{tag}"] = np.array([sp.measure_signal_power(x) for x in iq])
         tags.append(tag)
     # a frame of zeros (np.abs = 0, silence -> NaN audio -> int16 0), one with an infinity
     z = np.zeros(512, np.complex128)
