@@ -279,6 +279,11 @@ int pss_spectrum_db_c128(pss_ctx *ctx, const double *d_iq, long n_frames, int n_
 int pss_demod_am_c128(pss_ctx *ctx, const double *d_iq, long n_frames, int n, int16_t *d_pcm, double *d_audio);
 int pss_h_compute_fft_c128(pss_ctx *ctx, const double *h_iq, int n, double *h_db);
 int pss_h_demodulate_am_c128(pss_ctx *ctx, const double *h_iq, int n, double *h_audio_stereo, int16_t *h_pcm);
+/* demodulate_ssb (signal_processing.py:198-217) of complex128 frames: lfilter's complex128 convolution on the samples as they are (a complex64 buffer is
+ * widened first by the reference: the same kernels behind a float64 loader), hilbert() round trip, normalisation, int16 (tests/golden/c128.npz keys
+ * ssb_*: int16 equal; float64 audio bit for bit with option "hilbert_exact" = 1 at power-of-two lengths, to ~1e-15 otherwise — as for complex64). */
+int pss_demod_ssb_c128(pss_ctx *ctx, int lower, const double *d_iq, long n_frames, int n, double fs, int16_t *d_pcm, double *d_audio);
+int pss_h_demodulate_ssb_c128(pss_ctx *ctx, int lower, const double *h_iq, int n, double fs, double *h_audio_stereo, int16_t *h_pcm);
 /* measure_signal_power (signal_processing.py:325-328) of complex128 frames, the ARRAY part: d_power[f] = np.mean(np.abs(x) ** 2) in float64 (np.abs's
  * scaled hypot, x * x, NumPy's pairwise sum, / n — tests/golden/c128.npz keys mp_*).  The scalar the reference finishes with,
  * 10 * log10(power + 1e-10), is left to the caller: it is NumPy's float64 log10 of ONE number (the Python shim applies NumPy's own, which gives the

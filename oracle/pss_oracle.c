@@ -1096,10 +1096,9 @@ int pss_o_demod_wfm(const float *iq, int n, int q, const double *lp_sos, const d
 void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio) { pss_o_demod_ssb_ex(iq, n, taps, audio, 1); }
 
 /* with_hilbert = 0: the chain without :205 / :210 (what the library's option "ssb_hilbert" = 0 computes) */
-void pss_o_demod_ssb_ex(const float *iq, int n, const double *taps, double *audio, int with_hilbert)
+/* the chain on the samples' real parts r[n] (float64): the complex FIR's real part only ever reads those (real taps) */
+static void demod_ssb_real(const double *r, int n, const double *taps, double *audio, int with_hilbert)
 {
-    double *r = (double *)malloc(sizeof(double) * n);
-    for (int i = 0; i < n; i++) r[i] = (double)iq[2 * i];
     double tr[65];
     for (int j = 0; j < 65; j++) tr[j] = taps[64 - j];
     for (int i = 0; i < n; i++) audio[i] = fir65z_at(taps, tr, r, i, n);                    /* :204/:209 real part */
@@ -1114,6 +1113,21 @@ void pss_o_demod_ssb_ex(const float *iq, int n, const double *taps, double *audi
     for (int i = 0; i < n; i++) { double a = fabs(audio[i]); if (a != a) has_nan = 1; if (a > mx) mx = a; }
     if (has_nan) mx = NAN;
     for (int i = 0; i < n; i++) audio[i] = (audio[i] / mx) * 0.95;                  /* :216 */
+}
+void pss_o_demod_ssb_ex(const float *iq, int n, const double *taps, double *audio, int with_hilbert)
+{
+    double *r = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) r[i] = (double)iq[2 * i];
+    demod_ssb_real(r, n, taps, audio, with_hilbert);
+    free(r);
+}
+/* a complex128 buffer: lfilter(taps, 1.0, samples) is the same complex128 convolution the reference runs for complex64 input (which it widens
+ * first), on samples that need no widening */
+void pss_o_demod_ssb_c128(const double *iq, int n, const double *taps, double *audio, int with_hilbert)
+{
+    double *r = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; i++) r[i] = iq[2 * i];
+    demod_ssb_real(r, n, taps, audio, with_hilbert);
     free(r);
 }
 

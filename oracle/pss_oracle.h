@@ -63,6 +63,7 @@ double pss_o_pairwise_sum_f64(const double *a, long n);
  * hilbert(real(z)).real is restated as real(z) (identity up to 1e-15 round-off). */
 void pss_o_demod_ssb(const float *iq, int n, const double *taps, double *audio);
 void pss_o_demod_ssb_ex(const float *iq, int n, const double *taps, double *audio, int with_hilbert);
+void pss_o_demod_ssb_c128(const double *iq, int n, const double *taps, double *audio, int with_hilbert);   /* complex128 buffer */
 /* pss_pocketfft.c: scipy.signal.hilbert of a real float64 row of n = 2^k samples, bit for bit (out: n complex128 values, interleaved);
  * the plan's twiddle table exp(2 pi i k / n); the forward / inverse halves alone (scipy.fft.fft of a real row, scipy.fft.ifft). */
 void pss_o_hilbert(const double *x, int n, double *out);

@@ -72,6 +72,8 @@ _SIGS = {
     "pss_demod_am_c128": (C.c_int, [_p, _p, C.c_long, C.c_int, _p, _p]),
     "pss_h_compute_fft_c128": (C.c_int, [_p, _p, C.c_int, _p]),
     "pss_h_demodulate_am_c128": (C.c_int, [_p, _p, C.c_int, _p, _p]),
+    "pss_demod_ssb_c128": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p]),
+    "pss_h_demodulate_ssb_c128": (C.c_int, [_p, C.c_int, _p, C.c_int, C.c_double, _p, _p]),
     "pss_mean_power_c128": (C.c_int, [_p, _p, C.c_long, C.c_int, _p]),
     "pss_h_mean_power_c128": (C.c_int, [_p, _p, C.c_int, _p]),
     "pss_frame_pipeline_cells": (C.c_int, [_p, C.c_int, _p, C.c_long, C.c_int, C.c_double, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),

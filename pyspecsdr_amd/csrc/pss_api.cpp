@@ -368,6 +368,27 @@ extern "C" int pss_h_demodulate_am_c128(pss_ctx *ctx, const double *h_iq, int n,
     return PSS_OK;
 }
 
+extern "C" int pss_h_demodulate_ssb_c128(pss_ctx *ctx, int lower, const double *h_iq, int n, double fs, double *h_audio_stereo, int16_t *h_pcm)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (!h_iq || n < 1 || (!h_audio_stereo && !h_pcm)) return pss_fail(ctx, PSS_E_ARG, "bad arguments");
+    const size_t o_pcm = up256(sizeof(double) * 2 * n), o_au = o_pcm + up256(sizeof(int16_t) * 2 * n);
+    int r = pss_ensure_buffer(ctx, &ctx->stage, &ctx->stage_bytes, o_au + up256(sizeof(double) * n), "staging");
+    if (r) return r;
+    char *base = reinterpret_cast<char *>(ctx->stage);
+    PSS_HIP(ctx, hipMemcpyAsync(base, h_iq, sizeof(double) * 2 * n, hipMemcpyHostToDevice, ctx->stream));
+    r = pss_demod_ssb_c128(ctx, lower, reinterpret_cast<const double *>(base), 1, n, fs, reinterpret_cast<int16_t *>(base + o_pcm), reinterpret_cast<double *>(base + o_au));
+    if (r) return r;
+    std::vector<double> au(n);
+    PSS_HIP(ctx, hipMemcpyAsync(au.data(), base + o_au, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_pcm) PSS_HIP(ctx, hipMemcpyAsync(h_pcm, base + o_pcm, sizeof(int16_t) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+    PSS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_audio_stereo)
+        for (int i = 0; i < n; i++) h_audio_stereo[2 * i] = h_audio_stereo[2 * i + 1] = au[i];   // mono_to_stereo (:83-88)
+    return PSS_OK;
+}
+
 extern "C" int pss_h_mean_power_c128(pss_ctx *ctx, const double *h_iq, int n, double *h_power)
 {
     if (!ctx) return PSS_E_ARG;

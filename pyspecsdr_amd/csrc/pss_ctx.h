@@ -39,6 +39,7 @@ struct pss_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;   // pss_order_after / pss_order_before (created on first use)
     int n_cus = 0;                                  // hipDeviceProp_t::multiProcessorCount
+    bool iq_c128 = false;           // set by pss_demod_ssb_c128 around pss_demod: d_iq points at complex128 frames (the SSB kernels' float64 loader)
     int fuse_post = 1;              // option "fuse_post" (float64-row pipelines, 1024-point frames): 1 = transform + post-process in ONE kernel (pss_spec_post.h), 0 = two kernels (A/B reference)
     double target_rate = 22050.0;   // demodulate_nfm / _wfm's target_rate (pss_set_target_rate): decimation factor int(fs / target_rate)
     bool wfm_correct = false;       // pss_demod(WFM) is handed the frames AS READ and applies iq_correction itself (consumed there; set by pss_demod_signal / pss_frame_pipeline)

@@ -642,7 +642,8 @@ __device__ __forceinline__ void ssb_track_max(unsigned long long m, unsigned lon
     __syncthreads();
 }
 
-__global__ __launch_bounds__(TPB) void k_ssb_fir(const float2 *__restrict__ iq, double *__restrict__ Yf,
+template <class IN>   // float2: the reference's complex64 read buffer (widened as lfilter widens it); double2: a complex128 buffer as it is
+__global__ __launch_bounds__(TPB) void k_ssb_fir(const IN *__restrict__ iq, double *__restrict__ Yf,
                                                  unsigned long long *__restrict__ mxbits, int n, long n_frames,
                                                  int chunks_per_frame, TapsArg taps)
 {
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(TPB) void k_ssb_fir(const float2 *__restrict__ iq, 
     for (long w = blockIdx.x; w < total; w += gridDim.x) {
         const long f = w / chunks_per_frame;
         const int i0 = (int)(w % chunks_per_frame) * SSB_CH;
-        const float2 *x = iq + (size_t)f * n;
+        const IN *x = iq + (size_t)f * n;
         for (int k = tid; k < SSB_CH + 64; k += TPB) {
             int i = i0 - 64 + k;
             xr[xpad4(k)] = (i >= 0 && i < n) ? (double)x[i].x : 0.0;
@@ -710,7 +711,8 @@ __global__ __launch_bounds__(TPB) void k_ssb_fir(const float2 *__restrict__ iq, 
 
 // Outputs whose window is shorter than 65 samples — i < 64, or every output of a frame of <= 65 samples (where
 // np.convolve keeps the taps as its first operand) — one output per lane with the predicated zdot tree.
-__global__ __launch_bounds__(128) void k_ssb_edge(const float2 *__restrict__ iq, double *__restrict__ Yf,
+template <class IN>
+__global__ __launch_bounds__(128) void k_ssb_edge(const IN *__restrict__ iq, double *__restrict__ Yf,
                                                   unsigned long long *__restrict__ mxbits, int n, long n_frames,
                                                   TapsArg taps)
 {
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(128) void k_ssb_edge(const float2 *__restrict__ iq,
     __shared__ unsigned long long wmax[2];
     const int tid = threadIdx.x;
     const long f = blockIdx.x;
-    const float2 *x = iq + (size_t)f * n;
+    const IN *x = iq + (size_t)f * n;
     if (tid < 65) ltaps[tid] = taps.fwd[tid];
     xr[tid] = tid < n ? (double)x[tid].x : 0.0;
     __syncthreads();
@@ -3317,7 +3319,7 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const TapsArg targ = make_taps(taps);
         pss_time_begin(ctx);
         PSS_HIP(ctx, hipMemsetAsync(mxb, 0, (size_t)n_frames * sizeof(double), PSS_STREAM(ctx)));
-        if (ctx->ssb_hilbert && pss_ssb_fused_supported(n) && !ctx->ssb_unfused && !ctx->hilbert_exact) {
+        if (ctx->ssb_hilbert && pss_ssb_fused_supported(n) && !ctx->ssb_unfused && !ctx->hilbert_exact && !ctx->iq_c128) {
             // frames of 8192 / 16 384 samples: FIR, hilbert() round trip, normalisation and PCM in ONE kernel (no float64 round trip of
             // the FIR output through HBM)
             r = pss_ssb_hilbert_fused(ctx, d_iq, n_frames, n, taps, d_audio, d_pcm);
@@ -3327,13 +3329,22 @@ extern "C" int pss_demod(pss_ctx *ctx, int mode, const float *d_iq, long n_frame
         const int cpf = (n + 1023) / 1024;
         long total = n_frames * cpf;
         long g = total < 16384 ? total : 16384;
+        // (iq_c128: d_iq points at complex128 frames — pss_demod_ssb_c128; the same kernels behind a float64 loader)
         pss_kernel_begin(ctx, "k_ssb_fir");
-        hipLaunchKernelGGL(k_ssb_fir, dim3((unsigned)g), dim3(TPB), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq),
-                           Yf, mxb, n, n_frames, cpf, targ);
+        if (ctx->iq_c128)
+            hipLaunchKernelGGL(k_ssb_fir<double2>, dim3((unsigned)g), dim3(TPB), 0, PSS_STREAM(ctx), reinterpret_cast<const double2 *>(d_iq),
+                               Yf, mxb, n, n_frames, cpf, targ);
+        else
+            hipLaunchKernelGGL(k_ssb_fir<float2>, dim3((unsigned)g), dim3(TPB), 0, PSS_STREAM(ctx), reinterpret_cast<const float2 *>(d_iq),
+                               Yf, mxb, n, n_frames, cpf, targ);
         pss_kernel_end(ctx);
         pss_kernel_begin(ctx, "k_ssb_edge");
-        hipLaunchKernelGGL(k_ssb_edge, dim3((unsigned)n_frames), dim3(128), 0, PSS_STREAM(ctx),
-                           reinterpret_cast<const float2 *>(d_iq), Yf, mxb, n, n_frames, targ);
+        if (ctx->iq_c128)
+            hipLaunchKernelGGL(k_ssb_edge<double2>, dim3((unsigned)n_frames), dim3(128), 0, PSS_STREAM(ctx),
+                               reinterpret_cast<const double2 *>(d_iq), Yf, mxb, n, n_frames, targ);
+        else
+            hipLaunchKernelGGL(k_ssb_edge<float2>, dim3((unsigned)n_frames), dim3(128), 0, PSS_STREAM(ctx),
+                               reinterpret_cast<const float2 *>(d_iq), Yf, mxb, n, n_frames, targ);
         pss_kernel_end(ctx);
         // hilbert(np.real(analytical)) and np.real of it again (signal_processing.py:205-213): the FFT round trip of the
         // reference, executed where a register transform exists for the frame length; numerically the identity on the
@@ -3836,6 +3847,18 @@ extern "C" int pss_demod_am_c128(pss_ctx *ctx, const double *d_iq, long n_frames
     }
     pss_time_end(ctx);
     return r;
+}
+
+// demodulate_ssb (signal_processing.py:198-217) of complex128 frames: lfilter's complex128 convolution on the samples as they are (for a complex64 buffer
+// the reference widens first — the same kernels behind a float64 loader), the hilbert() round trip, normalisation, int16.  d_iq: interleaved float64
+// (re, im) [n_frames][n]; d_pcm int16 [n_frames][n][2] and / or d_audio float64 [n_frames][n] (mono).  tests/golden/c128.npz keys ssb_*.
+extern "C" int pss_demod_ssb_c128(pss_ctx *ctx, int lower, const double *d_iq, long n_frames, int n, double fs, int16_t *d_pcm, double *d_audio)
+{
+    if (!ctx) return PSS_E_ARG;
+    PSS_GUARD(ctx);
+    if (n_frames < 0 || n < 1 || (n_frames > 0 && (!d_iq || (!d_pcm && !d_audio)))) return pss_fail(ctx, PSS_E_ARG, "pss_demod_ssb_c128: bad argument");
+    PssFlagScope wide(ctx->iq_c128, true);
+    return pss_demod(ctx, lower ? PSS_MODE_LSB : PSS_MODE_USB, reinterpret_cast<const float *>(d_iq), n_frames, n, fs, d_pcm, d_audio);
 }
 
 // measure_signal_power (signal_processing.py:325-328) of complex128 frames, the array part: d_power[f] = np.mean(np.abs(x) ** 2) in float64 as the

@@ -561,6 +561,17 @@ class Engine:
         self._ck(self.lib.pss_h_demodulate_am_c128(self.h, _ptr(iq), len(iq), _ptr(audio), _ptr(pcm)))
         return audio, pcm
 
+    def h_demodulate_ssb_c128(self, iq, fs, lower=True):
+        """demodulate_ssb of a complex128 buffer (the complex128 convolution on the samples as they are): (audio float64 (n, 2), pcm int16 (n, 2))."""
+        iq = np.ascontiguousarray(iq, np.complex128)
+        audio = np.empty((len(iq), 2), np.float64)
+        pcm = np.empty((len(iq), 2), np.int16)
+        self._ck(self.lib.pss_h_demodulate_ssb_c128(self.h, 1 if lower else 0, _ptr(iq), len(iq), float(fs), _ptr(audio), _ptr(pcm)))
+        return audio, pcm
+
+    def demod_ssb_c128(self, d_iq, n_frames, n, fs, d_pcm, d_audio, lower=True):
+        self._dev(self.lib.pss_demod_ssb_c128, 1 if lower else 0, _ptr(d_iq), n_frames, n, float(fs), _ptr(d_pcm), _ptr(d_audio))
+
     def h_mean_power_c128(self, iq):
         """np.mean(np.abs(iq) ** 2) of a complex128 buffer in float64 (the array part of measure_signal_power): np.float64."""
         iq = np.ascontiguousarray(iq, np.complex128)

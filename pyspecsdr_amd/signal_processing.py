@@ -115,7 +115,8 @@ _warned_narrowing = False
 def _samples(samples):
     """The reference's read buffer is complex64 (pyspecsdr.py:1885-1891) and the kernels replay NumPy's complex64
     arithmetic; wider input (complex128) makes the reference compute in float64.  compute_fft (power-of-two lengths),
-    demodulate_am and measure_signal_power serve such buffers in float64 (pss_h_*_c128); everywhere else it is narrowed, with a one-time warning."""
+    demodulate_am, demodulate_ssb and measure_signal_power serve such buffers in float64 (pss_h_*_c128); everywhere else it is narrowed, with a
+    one-time warning."""
     global _warned_narrowing
     s = np.asarray(samples)
     if s.ndim != 1:
@@ -236,6 +237,8 @@ def demodulate_am(samples):
 
 def demodulate_ssb(samples, sample_rate, lower=True):
     _inject_designs('ssb', sample_rate)
+    if _is_c128(samples) and len(samples) >= 1:        # lfilter's complex128 convolution on the samples as they are (no narrowing)
+        return get_engine().h_demodulate_ssb_c128(samples, sample_rate, lower)[0]
     audio, _ = get_engine().h_demodulate(L.MODE_LSB if lower else L.MODE_USB, _samples(samples), sample_rate)
     return audio
 

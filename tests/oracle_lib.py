@@ -327,6 +327,16 @@ def demod_ssb(iq, taps, hilbert=True):
     return out
 
 
+def demod_ssb_c128(iq, taps, hilbert=True):
+    """demodulate_ssb of a complex128 buffer."""
+    x = np.ascontiguousarray(iq, np.complex128)
+    out = np.empty(len(x), np.float64)
+    f = lib().pss_o_demod_ssb_c128
+    f.argtypes, f.restype = [_f64p, C.c_int, _f64p, _f64p, C.c_int], None
+    f(x.view(np.float64), len(x), np.ascontiguousarray(taps, np.float64), out, 1 if hilbert else 0)
+    return out
+
+
 def hilbert(x):
     """scipy.signal.hilbert of a real float64 row of 2^k samples (pss_pocketfft.c)."""
     x = np.ascontiguousarray(x, np.float64)

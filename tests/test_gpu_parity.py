@@ -1812,6 +1812,18 @@ def test_round6_complex128_buffers_vs_reference_goldens(golden):
                 if n >= 16 and (n & (n - 1)) == 0:
                     db = sp.compute_fft(x)
                     assert db.dtype == np.float64 and np.allclose(db, g[f"db_{t}"][k], rtol=1e-9, atol=1e-9), (t, k)
+                # demodulate_ssb: int16 equal, float64 audio to 2e-14 (the register transforms of the hilbert() round trip; option "hilbert_exact": bit for bit)
+                for lower in (True, False):
+                    a = sp.demodulate_ssb(x, 48000.0, lower=lower)
+                    assert a.shape == (n, 2) and a.dtype == np.float64 and np.array_equal(a[:, 0], a[:, 1])
+                    assert np.allclose(a[:, 0], g[f"ssb_{t}"][k], rtol=0, atol=2e-14), (t, k)
+                    assert np.array_equal(np.int16(a * 32767)[:, 0], g[f"ssbpcm_{t}"][k]), (t, k)
+                if (n & (n - 1)) == 0 and n >= 256:
+                    sp.get_engine().set_option("hilbert_exact", 1)        # (the drop-in module's own engine)
+                    try:
+                        assert np.array_equal(sp.demodulate_ssb(x, 48000.0)[:, 0], g[f"ssb_{t}"][k]), (t, k, "hilbert_exact")
+                    finally:
+                        sp.get_engine().set_option("hilbert_exact", 0)
                 # measure_signal_power: the mean power from the device in float64, the scalar log10 by NumPy on the host — the reference's bits
                 pw = sp.measure_signal_power(x)
                 assert isinstance(pw, np.float64) and pw == g[f"pw_{t}"][k], (t, k)
@@ -1835,7 +1847,12 @@ def test_round6_complex128_buffers_vs_reference_goldens(golden):
     assert np.array_equal(G.host(d_pcm)[-nf:, :, 0], g[f"pcm_{t}"]) and np.array_equal(G.host(d_pcm)[..., 0], G.host(d_pcm)[..., 1])
     d_pw = G.empty((len(big),), torch.float64)
     e.mean_power_c128(d_iq, len(big), n, d_pw)
+    d_sau, d_spcm = G.empty((len(big), n), torch.float64), G.empty((len(big), n, 2), torch.int16)
+    e.set_ssb_taps(48000.0, g["ssb_taps"])
+    e.demod_ssb_c128(d_iq, len(big), n, 48000.0, d_spcm, d_sau)
     e.sync()
+    assert np.allclose(G.host(d_sau)[-nf:], g[f"ssb_{t}"], rtol=0, atol=2e-14) and np.array_equal(G.host(d_spcm)[-nf:, :, 0], g[f"ssbpcm_{t}"])
+    assert np.array_equal(G.host(d_spcm)[:nf], G.host(d_spcm)[-nf:]) and np.array_equal(G.host(d_spcm)[..., 0], G.host(d_spcm)[..., 1])
     assert np.array_equal(G.host(d_pw)[:nf], g[f"mp_{t}"]) and np.array_equal(G.host(d_pw)[-nf:], g[f"mp_{t}"])
     # random buffers of awkward lengths against the oracle (the pairwise tree's uneven splits, chunks of 8192)
     rng = np.random.default_rng(66)
@@ -1847,6 +1864,10 @@ def test_round6_complex128_buffers_vs_reference_goldens(golden):
             got = sp.demodulate_am(x)[:, 0]
         assert np.array_equal(got, want, equal_nan=True), n
         assert e.h_mean_power_c128(x) == O.mean_power_c128(x), n
+        with np.errstate(all="ignore"):
+            got = sp.demodulate_ssb(x, 48000.0)[:, 0]
+            want = O.demod_ssb_c128(x, g["ssb_taps"])
+        assert np.allclose(got, want, rtol=0, atol=2e-14, equal_nan=True) and np.array_equal(np.int16(np.nan_to_num(got) * 32767), np.int16(np.nan_to_num(want) * 32767)), n
     # demodulate_nfm at a decimation factor of ONE (target_rate above half the sample rate: nothing is dropped, n - 1 output samples)
     keep = sp.USE_SCIPY_DESIGNS
     try:

@@ -489,6 +489,14 @@ def test_round6_complex128_buffers_oracle_vs_reference(golden):
             # narrowing to complex64 first (rounds 1-5) does NOT give these bits
             if len(x) >= 1000:
                 assert not np.array_equal(O.demod_am(x.astype(np.complex64), sos), g[f"audio_{t}"][k])
+            # demodulate_ssb (:198-217): the complex128 convolution on the samples as they are, hilbert() round trip (pocketfft restatement) at the
+            # power-of-two lengths: bit for bit there, int16 equal everywhere (the round trip is skipped at other lengths: ~1e-16)
+            a = O.demod_ssb_c128(x, g["ssb_taps"])
+            if (len(x) & (len(x) - 1)) == 0:
+                assert np.array_equal(a, g[f"ssb_{t}"][k]), (t, k)
+            assert np.allclose(a, g[f"ssb_{t}"][k], rtol=0, atol=2e-15) and np.array_equal(np.int16(a * 32767), g[f"ssbpcm_{t}"][k]), (t, k)
+            if len(x) >= 1000:
+                assert not np.array_equal(O.demod_ssb(x.astype(np.complex64), g["ssb_taps"]), g[f"ssb_{t}"][k])      # narrowing first changes the bits
             # measure_signal_power (:325-328): the array part np.mean(np.abs(x) ** 2) restated in float64, the scalar log10 with NumPy's own
             p = O.mean_power_c128(x)
             assert p == g[f"mp_{t}"][k], (t, k)

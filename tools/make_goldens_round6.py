@@ -7,6 +7,7 @@ from the first statement on:
     compute_fft    (signal_processing.py:243-264): `samples * window` is a float64 product of float64 samples
     demodulate_am  (:179-195): np.abs / np.mean / the subtraction in float64 (complex64 input: float32)
     measure_signal_power (:325-328): np.abs ** 2 / np.mean in float64, the scalar log10 in float64 (keys mp_* / pw_*)
+    demodulate_ssb (:198-217): the complex128 convolution on the samples as they are (keys ssb_* / ssbpcm_* / ssb_taps)
 Rounds 1-5 narrowed such input to complex64 with a warning; round 6 serves these two functions in float64.
 The same file carries round 6's other new vectors: demodulate_nfm and demodulate_wfm at a decimation factor int(sample_rate / target_rate) of ONE
 (keys n_* / w_*: NFM runs decimate(x, 1), WFM skips the stage, signal_processing.py:111-112 / :152-155).
@@ -48,6 +49,12 @@ def main():
         d[f"mean_{tag}"] = np.array(np.mean(np.abs(iq[0])))
         # measure_signal_power (:325-328) of the same buffers: float64 np.abs ** 2 / np.mean, then the scalar 10 * np.log10(power + 1e-10);
         # mp_*: the array part (the mean power), pw_*: what the function returns
+        # demodulate_ssb (:198-217; both branches are the same statements) at 48 kHz: the complex128 FIR the reference also runs for complex64 input
+        # (lfilter widens it), the hilbert() round trip, normalisation
+        ssb = np.stack([sp.demodulate_ssb(x, 48000.0, lower=bool(k & 1)) for k, x in enumerate(iq)])
+        assert np.array_equal(ssb[..., 0], ssb[..., 1])
+        d[f"ssb_{tag}"] = ssb[..., 0]
+        d[f"ssbpcm_{tag}"] = np.int16(ssb[..., 0] * 32767)
         d[f"mp_{tag}"] = np.array([np.mean(np.abs(x) ** 2) for x in iq])
         d[f"pw_{tag}"] = np.array([sp.measure_signal_power(x) for x in iq])
         tags.append(tag)
@@ -87,6 +94,7 @@ def main():
         wt.append(tag)
     d["wq1_tags"] = np.array(wt)
     d["tags"] = np.array(tags)
+    d["ssb_taps"] = ss.firwin(65, 3000 / 48000.0, window="hamming")                          # demodulate_ssb's taps at 48 kHz (:203 / :208)
     d["am_sos"] = ss.butter(5, [300 / 11025, 3000 / 11025], btype="band", output="sos")   # demodulate_am's filter (:188-191, fs fixed at 22 050)
     mg.save("c128", **d)
 
